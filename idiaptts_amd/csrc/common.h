@@ -1,0 +1,61 @@
+// Shared host/device helpers for the gfx950 kernels of libidiaptts_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/idiaptts_amd.h"
+
+namespace itts {
+
+void set_error(const std::string& msg);
+
+#define ITTS_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ::itts::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+      return ITTS_E_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define ITTS_REQUIRE(cond, msg)                                                           \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      ::itts::set_error(std::string(__func__) + ": " + (msg));                            \
+      return ITTS_E_INVALID;                                                              \
+    }                                                                                     \
+  } while (0)
+
+#define ITTS_LAUNCH_CHECK() ITTS_HIP_CHECK(hipGetLastError())
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x a multiple of 64 (<= 1024). `red` needs 16 doubles of LDS.
+// Result valid in every thread.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < nw; ++i) s += red[i];  // same order in every thread: deterministic
+  return s;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace itts

@@ -1,0 +1,262 @@
+// MLPG: maximum-likelihood parameter generation for the reference's three windows.
+// Replaces MLPG.generation (idiaptts/misc/mlpg.py:94-127), i.e. the 62 python-level bandmat
+// calls per utterance (build_poe :57-92, bla.solveh :125), by ONE launch over all
+// (utterance, dimension) pairs of a batch.
+//
+// Math (per dimension, T frames): P x = b with the symmetric pentadiagonal precision matrix
+//   P = diag(t0) + W1^T diag(t1) W1 + W2^T diag(t2) W2,   b = W0^T(m0 t0) + W1^T(m1 t1) + W2^T(m2 t2)
+// W1 = [-.5 0 .5], W2 = [1 -2 1] Toeplitz, t_w = 1/var_w with the delta variances of the first
+// and last frame forced to 1e11 (mlpg.py:114-117).  Solved by banded Cholesky (what
+// bandmat.linalg.solveh does): forward sweep stores (d, l1, l2, y) per frame, backward sweep
+// substitutes.  One lane owns one (utterance, dimension); a wave owns 64 neighbouring
+// dimensions so every row access is one coalesced 512-B segment.
+//
+// Roofline: HBM.  Algorithmic bytes per frame = 187*8 read + 63*8 written = 2000 B
+// (SURVEY.md section 8d); the factor scratch adds 3 f64 written + 4 read per (frame, dim).
+#include "common.h"
+
+namespace itts {
+
+constexpr double kBigVar = 100000000000.0;  // mlpg.py:114
+
+struct MlpgArgs {
+  const double* feat;
+  int64_t ld_feat;
+  int col0;
+  int dim;
+  const double* var;
+  const int64_t* offsets;  // device copy, [U+1]
+  double* out;
+  int64_t ld_out;
+  int ocol0;
+  double* scratch;  // 3 planes [Ttot, dim]: d, l1, l2
+  int64_t t_total;
+};
+
+__global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  const int u = blockIdx.y;
+  if (d >= a.dim) return;
+  const int64_t t0 = a.offsets[u];
+  const int64_t T = a.offsets[u + 1] - t0;
+  if (T <= 0) return;
+  const int D = a.dim;
+  const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
+  const double tau0 = 1.0 / v0;
+  const double tau1_in = 1.0 / v1, tau2_in = 1.0 / v2, tau_edge = 1.0 / kBigVar;
+
+  const double* f = a.feat + t0 * a.ld_feat + a.col0 + d;
+  double* o = a.out + t0 * a.ld_out + a.ocol0 + d;
+  const int64_t plane = a.t_total * (int64_t)D;
+  double* sd = a.scratch + t0 * D + d;
+  double* sl1 = sd + plane;
+  double* sl2 = sl1 + plane;
+
+  auto var1 = [&](int64_t t) { return (t == 0 || t == T - 1) ? kBigVar : v1; };
+  auto var2 = [&](int64_t t) { return (t == 0 || t == T - 1) ? kBigVar : v2; };
+  auto tau1 = [&](int64_t t) -> double {
+    if (t < 0 || t >= T) return 0.0;
+    return (t == 0 || t == T - 1) ? tau_edge : tau1_in;
+  };
+  auto tau2 = [&](int64_t t) -> double {
+    if (t < 0 || t >= T) return 0.0;
+    return (t == 0 || t == T - 1) ? tau_edge : tau2_in;
+  };
+
+  // b-frames (mean / var, mlpg.py:123) of rows j-1, j, j+1 for windows 1 and 2.
+  double p1 = 0.0, p2 = 0.0;  // row j-1
+  double c0, c1, c2;          // row j
+  c0 = f[0] / v0;
+  c1 = f[D] / var1(0);
+  c2 = f[2 * D] / var2(0);
+  // Cholesky state: row j entries L[j,j-1], L[j,j-2]; y[j-1], y[j-2]
+  double l1p = 0.0, l2p = 0.0, cprev = 0.0, y1 = 0.0, y2 = 0.0;
+
+  constexpr int PF = 4;  // rows prefetched ahead of the recurrence
+  double nb0[PF], nb1[PF], nb2[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t t = 1 + i;
+    if (t < T) {
+      const double* r = f + t * a.ld_feat;
+      nb0[i] = r[0];
+      nb1[i] = r[D];
+      nb2[i] = r[2 * D];
+    } else {
+      nb0[i] = nb1[i] = nb2[i] = 0.0;
+    }
+  }
+
+  for (int64_t jb = 0; jb < T; jb += PF) {
+    // issue loads for the block after this one before touching the recurrence
+    double fb0[PF], fb1[PF], fb2[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int64_t t = jb + PF + 1 + i;
+      if (t < T) {
+        const double* r = f + t * a.ld_feat;
+        fb0[i] = r[0];
+        fb1[i] = r[D];
+        fb2[i] = r[2 * D];
+      } else {
+        fb0[i] = fb1[i] = fb2[i] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int64_t j = jb + i;
+      if (j < T) {
+        // row j+1 b-frames
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+        if (j + 1 < T) {
+          n0 = nb0[i] / v0;
+          n1 = nb1[i] / var1(j + 1);
+          n2 = nb2[i] / var2(j + 1);
+        }
+        const double b = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
+        const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) +
+                           (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
+        const double pj1 = (j + 1 < T) ? -2.0 * (tau2(j) + tau2(j + 1)) : 0.0;
+        const double pj2 = (j + 2 < T) ? (tau2(j + 1) - 0.25 * tau1(j + 1)) : 0.0;
+        const double dd = sqrt(pjj - l1p * l1p - l2p * l2p);
+        const double l1 = (pj1 - cprev * l1p) / dd;  // L[j+1,j]
+        const double l2 = pj2 / dd;                  // L[j+2,j]
+        const double y = (b - l1p * y1 - l2p * y2) / dd;
+        sd[j * D] = dd;
+        sl1[j * D] = l1;
+        sl2[j * D] = l2;
+        o[j * a.ld_out] = y;
+        // advance to row j+1
+        l2p = cprev;  // L[j+1,j-1]
+        l1p = l1;
+        cprev = l2;
+        y2 = y1;
+        y1 = y;
+        p1 = c1;
+        p2 = c2;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      nb0[i] = fb0[i];
+      nb1[i] = fb1[i];
+      nb2[i] = fb2[i];
+    }
+  }
+
+  // backward substitution L^T x = y
+  double x1 = 0.0, x2 = 0.0;
+  for (int64_t jb = T - 1; jb >= 0; jb -= PF) {
+    double rd[PF], r1[PF], r2[PF], ry[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int64_t j = jb - i;
+      if (j >= 0) {
+        rd[i] = sd[j * D];
+        r1[i] = sl1[j * D];
+        r2[i] = sl2[j * D];
+        ry[i] = o[j * a.ld_out];
+      } else {
+        rd[i] = 1.0;
+        r1[i] = r2[i] = ry[i] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int64_t j = jb - i;
+      if (j >= 0) {
+        const double x = (ry[i] - r1[i] * x1 - r2[i] * x2) / rd[i];
+        o[j * a.ld_out] = x;
+        x2 = x1;
+        x1 = x;
+      }
+    }
+  }
+}
+
+// np.gradient(x, axis=0) in float32 (misc/utils.py:103-105): one-sided at the ends, central
+// inside; a single-frame utterance yields 0 (numpy raises there; the reference never hits it).
+__global__ void gradient_f32_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int dim,
+                                    const int64_t* offsets) {
+  const int u = blockIdx.y;
+  const int64_t t0 = offsets[u], T = offsets[u + 1] - t0;
+  const int64_t n = T * dim;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / dim;
+    const int d = (int)(i - t * dim);
+    const float* c = x + (t0 + t) * ldx + d;
+    float g;
+    if (T == 1) {
+      g = 0.f;
+    } else if (t == 0) {
+      g = c[ldx] - c[0];
+    } else if (t == T - 1) {
+      g = c[0] - c[-ldx];
+    } else {
+      g = (c[ldx] - c[-ldx]) / 2.0f;
+    }
+    out[(t0 + t) * ldo + d] = g;
+  }
+}
+
+}  // namespace itts
+
+using namespace itts;
+
+extern "C" int64_t itts_mlpg_scratch_bytes(int64_t t_total, int dim) {
+  if (t_total < 0 || dim <= 0) return 0;
+  // 3 factor planes + device copy of the offsets (<= t_total + 1 entries, padded)
+  return 3 * t_total * (int64_t)dim * 8 + (t_total + 2) * 8;
+}
+
+extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int dim,
+                                    const double* d_var, const int64_t* h_offsets, int n_utts,
+                                    double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
+                                    void* stream) {
+  ITTS_REQUIRE(d_feat && d_var && h_offsets && d_out && d_scratch, "null pointer");
+  ITTS_REQUIRE(dim > 0 && n_utts >= 0 && col0 >= 0 && ocol0 >= 0, "bad sizes");
+  ITTS_REQUIRE(ld_feat >= col0 + 3 * (int64_t)dim && ld_out >= ocol0 + (int64_t)dim,
+               "leading dimension too small");
+  if (n_utts == 0) return ITTS_OK;
+  const int64_t t_total = h_offsets[n_utts];
+  ITTS_REQUIRE(h_offsets[0] == 0 && t_total >= 0, "offsets must start at 0");
+  for (int u = 0; u < n_utts; ++u)
+    ITTS_REQUIRE(h_offsets[u + 1] >= h_offsets[u], "offsets must be non-decreasing");
+  ITTS_REQUIRE(n_utts <= t_total + 1, "more utterances than frames");
+  if (t_total == 0) return ITTS_OK;
+  hipStream_t s = as_stream(stream);
+  double* scratch = reinterpret_cast<double*>(d_scratch);
+  int64_t* d_off = reinterpret_cast<int64_t*>(scratch + 3 * t_total * (int64_t)dim);
+  ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, s));
+  MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total};
+  dim3 grid((dim + 63) / 64, n_utts);
+  hipLaunchKernelGGL(mlpg_kernel, grid, dim3(64), 0, s, a);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_out,
+                                 int dim, const int64_t* h_offsets, int n_utts, void* stream) {
+  ITTS_REQUIRE(d_x && d_out && h_offsets, "null pointer");
+  ITTS_REQUIRE(dim > 0 && ld_x >= dim && ld_out >= dim && n_utts >= 0, "bad sizes");
+  if (n_utts == 0 || h_offsets[n_utts] == 0) return ITTS_OK;
+  hipStream_t s = as_stream(stream);
+  int64_t* d_off = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_off, (n_utts + 1) * sizeof(int64_t), s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, s));
+  int64_t maxT = 0;
+  for (int u = 0; u < n_utts; ++u) maxT = std::max(maxT, h_offsets[u + 1] - h_offsets[u]);
+  int bx = (int)std::min<int64_t>((maxT * dim + 255) / 256, 64);
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(gradient_f32_kernel, dim3(bx, n_utts), dim3(256), 0, s, d_x, ld_x, d_out,
+                     ld_out, dim, d_off);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_off, s));
+  return ITTS_OK;
+}

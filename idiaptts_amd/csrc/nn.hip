@@ -1,0 +1,498 @@
+// Dense acoustic-model kernels for gfx950: fp32 MFMA GEMM with fused epilogues, masked MSE,
+// Adam.  Replaces the torch.nn.Linear / Tanh / MSELoss / torch.optim.Adam calls the reference
+// makes per mini-batch (rnn_dyn/FFWrapper.py:63-73, loss/NamedLoss.py:70-117,
+// ModularModelHandlerPyTorch.py:769-820).
+//
+// GEMM design (exact fp32: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak):
+//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
+//     2x2 MFMA tiles of 32x32 (64 accumulator VGPRs), K step 32, LDS double buffered
+//     (73.7 KB -> 2 workgroups per CU).
+//   * an operand is either "row form" [out][k] (k contiguous, e.g. x[M,K], w[N,K]) or "col
+//     form" [k][out] (e.g. dz[M,N] as the reduction-major operand of dW).  Row-form tiles are
+//     copied to LDS unchanged with a 4-float pad (144-B rows: conflict-free ds_read_b128);
+//     col-form tiles are [k][128+4] and read with ds_read_b32 (lanes = consecutive floats).
+//   * K permutation instead of an LDS transpose: the MFMA takes k = lane>>5 from each lane;
+//     lane half h feeds k = 8g + 4h + j on step j of k-group g, for A and B alike, so one
+//     ds_read_b128 per lane supplies four MFMAs.
+//   * roofline: MFMA fp32.  FLOPs per valid frame of the 425-512-512-187 model: fwd 1.15 M,
+//     fwd+bwd 3.45 M (first-layer input gradient skipped: 3.01 M) -- SURVEY.md section 8d.
+#include <algorithm>
+
+#include "common.h"
+
+namespace itts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_ROW = BK + 4;    // row-form tile [128][36]
+constexpr int LD_COL = BM + 4;    // col-form tile [32][132]
+constexpr int TILE_FLOATS = 128 * LD_ROW;  // 4608 >= 32*132 = 4224
+
+enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_DACT = 2 };
+
+struct GemmArgs {
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  float* C;
+  int64_t ldc;
+  int64_t M;  // output rows
+  int N;      // output cols
+  int64_t K;  // reduction length
+  const float* bias;
+  const float* aux;
+  int64_t ldaux;
+  int act;
+  int64_t kchunk;       // reduction elements per blockIdx.z (multiple of BK)
+  int64_t slab_stride;  // floats between split-K slabs of C
+  int vecA, vecB;       // 16-B vector loads allowed
+};
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ITTS_ACT_TANH) return tanhf(z);
+  if (act == ITTS_ACT_RELU) return z > 0.f ? z : 0.f;
+  return z;
+}
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  if (act == ITTS_ACT_TANH) return 1.f - y * y;
+  if (act == ITTS_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// Global -> registers for one 128(out) x 32(k) tile of an operand. 16 floats per thread.
+template <bool ROWFORM>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t out0,
+                                          int64_t out_dim, int64_t k0, int64_t k_end, int vec,
+                                          float4 (&r)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    int64_t o, k;
+    if (ROWFORM) {
+      o = out0 + (idx >> 3);
+      k = k0 + ((idx & 7) << 2);
+    } else {
+      k = k0 + (idx >> 5);
+      o = out0 + ((idx & 31) << 2);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ROWFORM) {
+      if (o < out_dim) {
+        const float* p = P + o * ld + k;
+        if (vec && k + 3 < k_end) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k < k_end) v.x = p[0];
+          if (k + 1 < k_end) v.y = p[1];
+          if (k + 2 < k_end) v.z = p[2];
+          if (k + 3 < k_end) v.w = p[3];
+        }
+      }
+    } else {
+      if (k < k_end) {
+        const float* p = P + k * ld + o;
+        if (vec && o + 3 < out_dim) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (o < out_dim) v.x = p[0];
+          if (o + 1 < out_dim) v.y = p[1];
+          if (o + 2 < out_dim) v.z = p[2];
+          if (o + 3 < out_dim) v.w = p[3];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+
+template <bool ROWFORM>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    int off;
+    if (ROWFORM)
+      off = (idx >> 3) * LD_ROW + ((idx & 7) << 2);
+    else
+      off = (idx >> 5) * LD_COL + ((idx & 31) << 2);
+    *reinterpret_cast<float4*>(S + off) = r[i];
+  }
+}
+
+// Fragment of k-group g for the 32 rows starting at `o` (tile-local): 4 k values per lane.
+template <bool ROWFORM>
+__device__ __forceinline__ float4 read_frag(const float* __restrict__ S, int o, int g, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  if (ROWFORM) {
+    return *reinterpret_cast<const float4*>(S + (o + r) * LD_ROW + g * 8 + 4 * h);
+  } else {
+    const float* p = S + (g * 8 + 4 * h) * LD_COL + o + r;
+    return make_float4(p[0], p[LD_COL], p[2 * LD_COL], p[3 * LD_COL]);
+  }
+}
+
+template <bool A_ROW, bool B_ROW, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
+  // buffer b: A tile at lds + 2b*TILE, B tile at lds + (2b+1)*TILE
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+  // XCD a contiguous run of tiles that share the same B panel (weights) where possible.
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int64_t tiles_m = (g.M + BM - 1) / BM;
+  const int64_t ntiles = tiles_m * tiles_n;
+  int64_t bid = blockIdx.x;
+  {
+    const int64_t q = ntiles / 8, r = ntiles % 8;
+    const int64_t xcd = bid % 8, pos = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int64_t tm = bid / tiles_n;
+  const int tn = (int)(bid % tiles_n);
+  const int64_t m0 = tm * BM;
+  const int n0 = tn * BN;
+
+  const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
+  const int64_t kend = std::min<int64_t>(g.K, kbeg + g.kchunk);
+  const int64_t nkt = (kend - kbeg + BK - 1) / BK;
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  if (nkt > 0) {
+    load_tile<A_ROW>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
+    load_tile<B_ROW>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    store_tile<A_ROW>(lds, ra);
+    store_tile<B_ROW>(lds + TILE_FLOATS, rb);
+  }
+  __syncthreads();
+
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int cur = (int)(kt & 1);
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      load_tile<A_ROW>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.vecA, ra);
+      load_tile<B_ROW>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.vecB, rb);
+    }
+    const float* cA = lds + (2 * cur) * TILE_FLOATS;
+    const float* cB = lds + (2 * cur + 1) * TILE_FLOATS;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_ROW>(cA, wm * 64 + i * 32, kg, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_ROW>(cB, wn * 64 + j * 32, kg, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) {
+      store_tile<A_ROW>(lds + (2 * (cur ^ 1)) * TILE_FLOATS, ra);
+      store_tile<B_ROW>(lds + (2 * (cur ^ 1) + 1) * TILE_FLOATS, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* C = g.C + (int64_t)blockIdx.z * g.slab_stride;
+  const int cl = lane & 31, rh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + cl;
+      if (col >= g.N) continue;
+      float bv = 0.f;
+      if (EPI == EPI_BIAS_ACT && g.bias) bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rh;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        if (EPI == EPI_BIAS_ACT) v = act_fwd(v + bv, g.act);
+        if (EPI == EPI_DACT) v *= act_grad_from_out(g.aux[row * g.ldaux + col], g.act);
+        C[row * g.ldc + col] = v;
+      }
+    }
+}
+
+template <bool A_ROW, bool B_ROW, int EPI>
+static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
+  const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (tiles <= 0) return ITTS_OK;
+  dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI>), grid, dim3(256), 0, s, g);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- split-K slab reduction (deterministic order) -------------------------------------------
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int64_t n,
+                                    float* __restrict__ out, int accumulate) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[(int64_t)z * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// column sums of dz[M,N] over a row slice -> partial[z][n]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz,
+                                                             int64_t ld, int64_t M, int N,
+                                                             int64_t rows_per_slice,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t r1 = std::min<int64_t>(M, r0 + rows_per_slice);
+  float s = 0.f;
+  if (col < N)
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += dz[r * ld + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N)
+    partial[(int64_t)blockIdx.y * N + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                               float* __restrict__ dz, int64_t n, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dz[i] = dy[i] * act_grad_from_out(y[i], act);
+}
+
+// ---- masked MSE -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_mse_kernel(
+    const float* __restrict__ pred, int64_t ldp, const float* __restrict__ target, int64_t ldt,
+    const uint8_t* __restrict__ valid, int64_t M, int D, float gscale, float* __restrict__ grad,
+    int64_t ldg, double* __restrict__ partial) {
+  __shared__ double red[16];
+  const int64_t n = M * D;
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D;
+    const int c = (int)(i - r * D);
+    float diff = 0.f;
+    if (valid[r]) diff = pred[r * ldp + c] - target[r * ldt + c];
+    s += (double)diff * (double)diff;
+    if (grad) grad[r * ldg + c] = gscale * diff;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void masked_mse_final_kernel(const double* __restrict__ partial, int nb, double scale,
+                                        float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += partial[i];
+    *loss = (float)(s * scale);
+  }
+}
+
+// ---- Adam ---------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
+                            float beta2, float eps, float wd, float step_size, float bc2_sqrt,
+                            float gscale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - beta1);         // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * beta2 + (1.f - beta2) * gi * gi;   // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+static int choose_splitk(int64_t M, int N, int K) {
+  const int64_t tiles = (int64_t)((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+  int64_t s = std::max<int64_t>(1, 512 / std::max<int64_t>(tiles, 1));
+  const int64_t max_by_rows = std::max<int64_t>(1, (M + 511) / 512);
+  s = std::min(s, max_by_rows);
+  return (int)std::min<int64_t>(s, 128);
+}
+
+}  // namespace itts
+
+using namespace itts;
+
+extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
+                               float* d_y, int64_t ldy, int64_t M, int N, int K, int act,
+                               void* stream) {
+  ITTS_REQUIRE(d_x && d_w && d_y, "null pointer");
+  ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, "bad sizes");
+  ITTS_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  if (M == 0) return ITTS_OK;
+  GemmArgs g{};
+  g.A = d_x; g.lda = ldx; g.B = d_w; g.ldb = K; g.C = d_y; g.ldc = ldy;
+  g.M = M; g.N = N; g.K = K; g.bias = d_b; g.act = act;
+  g.kchunk = ((K + BK - 1) / BK) * BK; g.slab_stride = 0;
+  g.vecA = (ldx % 4 == 0) && aligned16(d_x);
+  g.vecB = (K % 4 == 0) && aligned16(d_w);
+  return launch_gemm<true, true, EPI_BIAS_ACT>(g, 1, as_stream(stream));
+}
+
+extern "C" int itts_act_bwd(const float* d_dy, const float* d_y, float* d_dz, int64_t n_elem,
+                            int act, void* stream) {
+  ITTS_REQUIRE(d_dy && d_y && d_dz && n_elem >= 0, "bad arguments");
+  ITTS_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  if (n_elem == 0) return ITTS_OK;
+  const int blocks = (int)std::min<int64_t>((n_elem + 255) / 256, 4096);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_dy, d_y,
+                     d_dz, n_elem, act);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const float* d_w,
+                                     float* d_dx, int64_t lddx, const float* d_yprev,
+                                     int64_t ldyp, int act_prev, int64_t M, int N, int K,
+                                     void* stream) {
+  ITTS_REQUIRE(d_dz && d_w && d_dx, "null pointer");
+  ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && lddz >= N && lddx >= K, "bad sizes");
+  if (M == 0) return ITTS_OK;
+  // dx[M,K] = dz[M,N] (row form, reduction N) x w[N,K] (col form: [k=N][out=K])
+  GemmArgs g{};
+  g.A = d_dz; g.lda = lddz; g.B = d_w; g.ldb = K; g.C = d_dx; g.ldc = lddx;
+  g.M = M; g.N = K; g.K = N; g.aux = d_yprev; g.ldaux = ldyp; g.act = act_prev;
+  g.kchunk = ((N + BK - 1) / BK) * BK; g.slab_stride = 0;
+  g.vecA = (lddz % 4 == 0) && aligned16(d_dz);
+  g.vecB = (K % 4 == 0) && aligned16(d_w);
+  if (d_yprev) {
+    ITTS_REQUIRE(ldyp >= K, "ldyp too small");
+    return launch_gemm<true, false, EPI_DACT>(g, 1, as_stream(stream));
+  }
+  return launch_gemm<true, false, EPI_STORE>(g, 1, as_stream(stream));
+}
+
+extern "C" int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
+  if (M < 0 || N <= 0 || K <= 0) return 0;
+  const int s = choose_splitk(M, N, K);
+  return (int64_t)s * N * K * 4 + (int64_t)s * N * 4 + 256;
+}
+
+extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x,
+                                      int64_t ldx, float* d_dw, float* d_db, int64_t M, int N,
+                                      int K, void* d_workspace, int accumulate, void* stream) {
+  ITTS_REQUIRE(d_dz && d_x && d_dw && d_workspace, "null pointer");
+  ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && lddz >= N && ldx >= K, "bad sizes");
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    if (!accumulate) {
+      ITTS_HIP_CHECK(hipMemsetAsync(d_dw, 0, (size_t)N * K * 4, s));
+      if (d_db) ITTS_HIP_CHECK(hipMemsetAsync(d_db, 0, (size_t)N * 4, s));
+    }
+    return ITTS_OK;
+  }
+  const int S = choose_splitk(M, N, K);
+  int64_t kchunk = (M + S - 1) / S;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
+  const int S_eff = (int)((M + kchunk - 1) / kchunk);
+  float* slabs = reinterpret_cast<float*>(d_workspace);
+  float* bpart = slabs + (int64_t)S * N * K;
+  // dw[N,K] = dz^T x: A = dz as col form [k=M][out=N]; B = x as col form [k=M][out=K]
+  GemmArgs g{};
+  g.A = d_dz; g.lda = lddz; g.B = d_x; g.ldb = ldx; g.C = slabs; g.ldc = K;
+  g.M = N; g.N = K; g.K = M; g.kchunk = kchunk; g.slab_stride = (int64_t)N * K;
+  g.vecA = (lddz % 4 == 0) && aligned16(d_dz);
+  g.vecB = (ldx % 4 == 0) && aligned16(d_x);
+  int rc = launch_gemm<false, false, EPI_STORE>(g, S_eff, s);
+  if (rc) return rc;
+  const int64_t n = (int64_t)N * K;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)),
+                     dim3(256), 0, s, slabs, S_eff, n, d_dw, accumulate);
+  ITTS_LAUNCH_CHECK();
+  if (d_db) {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, S_eff), dim3(256), 0, s, d_dz,
+                       lddz, M, N, kchunk, bpart);
+    ITTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, s, bpart, S_eff,
+                       (int64_t)N, d_db, accumulate);
+    ITTS_LAUNCH_CHECK();
+  }
+  return ITTS_OK;
+}
+
+static int mse_blocks(int64_t M, int D) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>((M * D + 255) / 256, 2048));
+}
+
+extern "C" int64_t itts_masked_mse_workspace_bytes(int64_t M, int D) {
+  if (M < 0 || D <= 0) return 0;
+  return (int64_t)mse_blocks(M, D) * 8;
+}
+
+extern "C" int itts_masked_mse(const float* d_pred, int64_t ldp, const float* d_target,
+                               int64_t ldt, const uint8_t* d_row_valid, int64_t M, int D,
+                               double n_valid, float loss_weight, float* d_loss, float* d_grad,
+                               int64_t ldg, void* d_workspace, void* stream) {
+  ITTS_REQUIRE(d_pred && d_target && d_row_valid && d_loss && d_workspace, "null pointer");
+  ITTS_REQUIRE(M >= 0 && D > 0 && ldp >= D && ldt >= D && n_valid > 0, "bad sizes");
+  ITTS_REQUIRE(!d_grad || ldg >= D, "ldg too small");
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    ITTS_HIP_CHECK(hipMemsetAsync(d_loss, 0, 4, s));
+    return ITTS_OK;
+  }
+  const int nb = mse_blocks(M, D);
+  const double scale = (double)loss_weight / (n_valid * (double)D);
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(nb), dim3(256), 0, s, d_pred, ldp, d_target, ldt,
+                     d_row_valid, M, D, (float)(2.0 * scale), d_grad, ldg,
+                     reinterpret_cast<double*>(d_workspace));
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(64), 0, s,
+                     reinterpret_cast<const double*>(d_workspace), nb, scale, d_loss);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_avg,
+                              float* d_exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int64_t step, float grad_scale,
+                              void* stream) {
+  ITTS_REQUIRE(d_param && d_grad && d_exp_avg && d_exp_avg_sq, "null pointer");
+  ITTS_REQUIRE(n >= 0 && step >= 1, "bad sizes (step counts from 1)");
+  if (n == 0) return ITTS_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_param, d_grad,
+                     d_exp_avg, d_exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size,
+                     bc2_sqrt, grad_scale);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}

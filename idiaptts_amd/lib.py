@@ -1,0 +1,97 @@
+"""ctypes binding of libidiaptts_amd.so (the C ABI declared in include/idiaptts_amd.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails this module
+raises.  (cffi is not available in the target image, hence ctypes.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libidiaptts_amd.so")
+
+_lib = None
+
+
+class IttsError(RuntimeError):
+    pass
+
+
+_P = c_void_p  # device / host pointers travel as integers
+
+_SIGNATURES = {
+    "itts_abi_version": (c_int, []),
+    "itts_last_error": (c_char_p, []),
+    "itts_device_count": (c_int, []),
+    "itts_cheaptrick_fft_size": (c_int, [c_int, c_double]),
+    "itts_num_aperiodicities": (c_int, [c_int]),
+    "itts_mcep_alpha": (c_double, [c_int]),
+    "itts_world_num_frames": (c_int64, [c_int64, c_int, c_double]),
+    "itts_world_synth_length": (c_int64, [c_int64, c_int, c_double]),
+    "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
+    "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
+                                     c_int64, c_int, _P, _P]),
+    "itts_gradient_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, POINTER(c_int64), c_int, _P]),
+    "itts_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int,
+                                _P]),
+    "itts_act_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "itts_linear_bwd_input": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int64,
+                                      c_int, c_int, _P]),
+    "itts_linear_bwd_weight_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "itts_linear_bwd_weight": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, c_int,
+                                       _P, c_int, _P]),
+    "itts_masked_mse_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "itts_masked_mse": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_double, c_float,
+                                _P, _P, c_int64, _P, _P]),
+    "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
+                               c_float, c_int64, c_float, _P]),
+}
+
+
+def declared_symbols():
+    """Every symbol include/idiaptts_amd.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Loads the shared library (building is the job of __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IttsError(
+            "HIP library {} is missing. Build it with `python -m idiaptts_amd.build` "
+            "(there is no CPU fallback).".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().itts_last_error()
+        raise IttsError("{} failed with status {}: {}".format(
+            what or "libidiaptts_amd call", status, msg.decode() if msg else ""))
+
+
+def offsets_array(offsets):
+    arr = (c_int64 * len(offsets))(*[int(o) for o in offsets])
+    return arr
+
+
+def current_stream():
+    """Raw hipStream_t of torch's current stream (0 = default stream)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise IttsError("No HIP device visible: the idiaptts_amd hot path only runs on an "
+                        "MI355X-class GPU (there is no CPU fallback).")
+    load()

@@ -1,0 +1,126 @@
+"""MI355X-native training step of the feed-forward acoustic model (BASELINE configs 1/2).
+
+What the reference does per mini-batch in ModularModelHandlerPyTorch.process_dataloader
+(:745-820) for an `RNNDYN-2_TANH_512-1_FC_187` model -- FFWrapper forward (FFWrapper.py:63-73),
+NamedLoss masked MSE 'mean_per_frame' (NamedLoss.py:70-117), backward, Adam -- is done here on
+*packed valid frames* (FF layers are frame independent, so padding is never computed) with all
+parameters, gradients and Adam moments in ONE flat fp32 buffer each:
+
+  fwd   3 x fp32-MFMA GEMM with fused bias+tanh
+  loss  fused masked-MSE + dLoss/dPred
+  bwd   dX GEMMs with the previous layer's tanh' fused in the epilogue, dW GEMMs with
+        deterministic split-K slabs, bias column sums
+  DP    one all-reduce(sum) of the flat gradient buffer over RCCL (torch.distributed 'nccl');
+        local gradients are already divided by the GLOBAL valid-frame count, so the result equals
+        the single-GPU step on the concatenated batch
+  opt   one fused Adam launch over the flat buffers
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatFFModel:
+    """Dense stack dims[0] -> dims[1] -> ... with activations `acts` (one per layer)."""
+
+    def __init__(self, dims=(425, 512, 512, 187), acts=("tanh", "tanh", None), device="cuda",
+                 seed=0, state_dict=None):
+        assert len(acts) == len(dims) - 1
+        self.dims = tuple(int(d) for d in dims)
+        self.acts = [ops.ACT_BY_NAME[a] for a in acts]
+        self.device = torch.device(device)
+        self.layout = []  # (w_off, b_off, N, K)
+        off = 0
+        for K, N in zip(self.dims[:-1], self.dims[1:]):
+            w_off = off
+            off += _pad4(N * K)
+            b_off = off
+            off += _pad4(N)
+            self.layout.append((w_off, b_off, N, K))
+        self.numel = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.step_count = 0
+        if state_dict is None:
+            state_dict = self.reference_init(self.dims, seed)
+        self.load_layers(state_dict)
+
+    # torch.nn.Linear default init in the order the reference constructs the layers
+    @staticmethod
+    def reference_init(dims, seed):
+        g = torch.Generator().manual_seed(seed)
+        layers = []
+        for K, N in zip(dims[:-1], dims[1:]):
+            bound = 1.0 / math.sqrt(K)
+            w = (torch.rand(N, K, generator=g) * 2 - 1) * bound
+            b = (torch.rand(N, generator=g) * 2 - 1) * bound
+            layers.append((w, b))
+        return layers
+
+    def load_layers(self, layers):
+        for (w_off, b_off, N, K), (w, b) in zip(self.layout, layers):
+            self.params[w_off:w_off + N * K].copy_(w.reshape(-1).to(self.device))
+            self.params[b_off:b_off + N].copy_(b.to(self.device))
+
+    def weight(self, i, buf=None):
+        w_off, _, N, K = self.layout[i]
+        return (self.params if buf is None else buf)[w_off:w_off + N * K].view(N, K)
+
+    def bias(self, i, buf=None):
+        _, b_off, N, _ = self.layout[i]
+        return (self.params if buf is None else buf)[b_off:b_off + N]
+
+    def layers(self):
+        return [(self.weight(i).clone(), self.bias(i).clone()) for i in range(len(self.layout))]
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, x):
+        """x [M, dims[0]] fp32 packed frames -> list of layer outputs."""
+        acts = []
+        h = x
+        for i in range(len(self.layout)):
+            h = ops.linear_fwd(h, self.weight(i), self.bias(i), self.acts[i])
+            acts.append(h)
+        return acts
+
+    def loss_and_backward(self, x, target, row_valid, n_valid_global):
+        """Fills self.grads with d(loss)/d(params) of this rank's frames; returns loss tensor
+        (this rank's contribution, already divided by the global frame count)."""
+        hs = self.forward(x)
+        loss, dz = ops.masked_mse(hs[-1], target, row_valid, n_valid_global)
+        n = len(self.layout)
+        for i in range(n - 1, -1, -1):
+            inp = hs[i - 1] if i > 0 else x
+            ops.linear_bwd_weight(dz, inp, dw=self.weight(i, self.grads),
+                                  db=self.bias(i, self.grads))
+            if i > 0:
+                dz = ops.linear_bwd_input(dz, self.weight(i), yprev=hs[i - 1],
+                                          act_prev=self.acts[i - 1])
+        return loss
+
+    def train_step(self, x, target, row_valid, n_valid_global, lr=1e-3, betas=(0.9, 0.999),
+                   eps=1e-8, weight_decay=0.0, process_group=None, world_size=1):
+        loss = self.loss_and_backward(x, target, row_valid, n_valid_global)
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=process_group)
+        self.step_count += 1
+        ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count,
+                      lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        return loss
+
+
+def flops_per_frame(dims, skip_first_dgrad=True):
+    """fwd + bwd FLOPs per valid frame: 2*N*K fwd, 2*N*K dW, 2*N*K dX (not for layer 0)."""
+    f = 0
+    for i, (K, N) in enumerate(zip(dims[:-1], dims[1:])):
+        f += 2 * N * K * (2 if (i == 0 and skip_first_dgrad) else 3)
+    return f

@@ -1,0 +1,178 @@
+"""Thin tensor-level wrappers over the C ABI (torch is used for device memory and streams only).
+
+Every function takes CUDA(HIP) tensors, passes raw device pointers + the current HIP stream to
+libidiaptts_amd.so and raises on any failure.  Nothing here computes on the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+ACT_BY_NAME = {None: ACT_NONE, "none": ACT_NONE, "linear": ACT_NONE, "tanh": ACT_TANH,
+               "relu": ACT_RELU}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.IttsError("{} must live on the GPU (no CPU fallback)".format(name))
+    if t.dtype != dtype:
+        raise TypeError("{} must be {}, got {}".format(name, dtype, t.dtype))
+
+
+def _rows(t, name):
+    """2-D view contract: unit stride on the last dim, arbitrary row stride."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("{} must be 2-D with contiguous rows".format(name))
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ---------------------------------------------------------------------------------------- MLPG
+def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0):
+    """Batched MLPG (misc/mlpg.py:94-127). feat [Ttot, >=col0+3*dim] f64, variances [3*dim] f64,
+    offsets: python list of U+1 frame offsets. Returns out [Ttot, dim] f64 (or writes into out)."""
+    L = _lib.load()
+    _need(feat, torch.float64, "feat")
+    _need(variances, torch.float64, "variances")
+    ld = _rows(feat, "feat")
+    t_total = int(offsets[-1])
+    if feat.shape[0] != t_total:
+        raise ValueError("offsets[-1] != number of rows")
+    if out is None:
+        out = torch.empty((t_total, dim), dtype=torch.float64, device=feat.device)
+    _need(out, torch.float64, "out")
+    ldo = _rows(out, "out")
+    nbytes = L.itts_mlpg_scratch_bytes(t_total, dim)
+    scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=feat.device)
+    offs = _lib.offsets_array(offsets)
+    _lib.check(L.itts_mlpg_generation(_ptr(feat), ld, col0, dim, _ptr(variances.contiguous()),
+                                      offs, len(offsets) - 1, _ptr(out), ldo, ocol0,
+                                      _ptr(scratch), _stream()), "itts_mlpg_generation")
+    return out
+
+
+def gradient_f32(x, offsets, out=None):
+    """np.gradient(x, axis=0) per utterance in float32 (misc/utils.py:103-105)."""
+    L = _lib.load()
+    _need(x, torch.float32, "x")
+    ld = _rows(x, "x")
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(L.itts_gradient_f32(_ptr(x), ld, _ptr(out), _rows(out, "out"), x.shape[1],
+                                   _lib.offsets_array(offsets), len(offsets) - 1, _stream()),
+               "itts_gradient_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------ dense layers
+def linear_fwd(x, w, b, act=ACT_NONE, out=None):
+    L = _lib.load()
+    _need(x, torch.float32, "x")
+    _need(w, torch.float32, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise ValueError("w must be contiguous [N, K]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(L.itts_linear_fwd(_ptr(x), _rows(x, "x"), _ptr(w), _ptr(b), _ptr(out),
+                                 _rows(out, "out"), M, N, K, act, _stream()), "itts_linear_fwd")
+    return out
+
+
+def act_bwd(dy, y, act, out=None):
+    L = _lib.load()
+    dy = dy.contiguous()
+    y = y.contiguous()
+    if out is None:
+        out = torch.empty_like(dy)
+    _lib.check(L.itts_act_bwd(_ptr(dy), _ptr(y), _ptr(out), dy.numel(), act, _stream()),
+               "itts_act_bwd")
+    return out
+
+
+def linear_bwd_input(dz, w, yprev=None, act_prev=ACT_NONE, out=None):
+    L = _lib.load()
+    _need(dz, torch.float32, "dz")
+    M, N = dz.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
+    _lib.check(L.itts_linear_bwd_input(_ptr(dz), _rows(dz, "dz"), _ptr(w), _ptr(out),
+                                       _rows(out, "out"), _ptr(yprev),
+                                       _rows(yprev, "yprev") if yprev is not None else 0,
+                                       act_prev, M, N, K, _stream()), "itts_linear_bwd_input")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def linear_bwd_weight(dz, x, dw=None, db=None, accumulate=False, want_bias=True):
+    L = _lib.load()
+    _need(dz, torch.float32, "dz")
+    _need(x, torch.float32, "x")
+    M, N = dz.shape
+    K = x.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    if db is None and want_bias:
+        db = torch.empty((N,), dtype=torch.float32, device=dz.device)
+    ws = _workspace(L.itts_linear_bwd_weight_workspace_bytes(M, N, K), dz.device)
+    _lib.check(L.itts_linear_bwd_weight(_ptr(dz), _rows(dz, "dz"), _ptr(x), _rows(x, "x"),
+                                        _ptr(dw), _ptr(db), M, N, K, _ptr(ws),
+                                        1 if accumulate else 0, _stream()),
+               "itts_linear_bwd_weight")
+    return dw, db
+
+
+def masked_mse(pred, target, row_valid, n_valid, loss_weight=1.0, want_grad=True, grad=None):
+    """NamedLoss(MSELoss, 'mean_per_frame') (loss/NamedLoss.py:70-117) on [M, D] rows."""
+    L = _lib.load()
+    _need(pred, torch.float32, "pred")
+    _need(target, torch.float32, "target")
+    _need(row_valid, torch.uint8, "row_valid")
+    M, D = pred.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    if want_grad and grad is None:
+        grad = torch.empty((M, D), dtype=torch.float32, device=pred.device)
+    ws = torch.empty(max(L.itts_masked_mse_workspace_bytes(M, D), 8), dtype=torch.uint8,
+                     device=pred.device)
+    _lib.check(L.itts_masked_mse(_ptr(pred), _rows(pred, "pred"), _ptr(target),
+                                 _rows(target, "target"), _ptr(row_valid), M, D, float(n_valid),
+                                 float(loss_weight), _ptr(loss),
+                                 _ptr(grad) if want_grad else None,
+                                 _rows(grad, "grad") if want_grad else 0, _ptr(ws), _stream()),
+               "itts_masked_mse")
+    return loss, (grad if want_grad else None)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+              weight_decay=0.0, grad_scale=1.0):
+    L = _lib.load()
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"),
+                 (exp_avg_sq, "exp_avg_sq")):
+        _need(t, torch.float32, n)
+        if not t.is_contiguous():
+            raise ValueError(n + " must be contiguous")
+    _lib.check(L.itts_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                param.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                int(step), grad_scale, _stream()), "itts_adam_step")

@@ -1,0 +1,120 @@
+/*
+ * idiaptts_amd.h -- C ABI of the MI355X-native IdiapTTS hot path (libidiaptts_amd.so).
+ *
+ * The reference (idiap/IdiapTTS v0.2) has no FFI of its own: the boundary is the Python call
+ * surface that today delegates to pyworld / pysptk / bandmat / torch.  Every entry point below
+ * cites the reference call site it replaces (paths relative to /root/reference/idiaptts).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures.
+ *   - `d_*` parameters are DEVICE pointers (HBM), `h_*` are host pointers.  Buffers are
+ *     caller-owned and C-contiguous unless a leading dimension is passed; the library never
+ *     keeps a pointer after the call returns.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  GPU entry points are
+ *     asynchronous with respect to the host unless stated otherwise.
+ *   - return value: 0 = ok, negative = error (ITTS_E_*); itts_last_error() gives a message.
+ *   - no hidden global state besides read-only tables cached per device; HIP is not
+ *     initialised before the first GPU entry point is called (fork-safe for DataLoader workers,
+ *     src/neural_networks/pytorch/ModularModelHandlerPyTorch.py:528-548).
+ */
+#ifndef IDIAPTTS_AMD_H
+#define IDIAPTTS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITTS_OK 0
+#define ITTS_E_INVALID (-1)  /* bad argument (shape / size / null pointer)            */
+#define ITTS_E_HIP (-2)      /* HIP runtime error, see itts_last_error()               */
+#define ITTS_E_UNSUPPORTED (-3)
+
+/* ---- library ------------------------------------------------------------------------- */
+int itts_abi_version(void);
+const char* itts_last_error(void);
+/* number of visible HIP devices (initialises HIP). */
+int itts_device_count(void);
+
+/* ---- integer / scalar helpers (host, no GPU) ------------------------------------------- */
+/* pyworld.get_cheaptrick_fft_size(fs, f0_floor=71)  -- src/data_preparation/audio/AudioProcessing.py:60 */
+int itts_cheaptrick_fft_size(int fs, double f0_floor);
+/* pyworld.get_num_aperiodicities(fs)                -- AudioProcessing.py:71 */
+int itts_num_aperiodicities(int fs);
+/* pysptk.util.mcepalpha(fs)                         -- AudioProcessing.py:40 */
+double itts_mcep_alpha(int fs);
+/* number of analysis frames pyworld.wav2world yields: int(1000*n/fs/frame_period)+1 */
+int64_t itts_world_num_frames(int64_t n_samples, int fs, double frame_period_ms);
+/* samples pyworld.synthesize yields: int(T*frame_period*fs/1000) */
+int64_t itts_world_synth_length(int64_t n_frames, int fs, double frame_period_ms);
+
+/* ---- MLPG (misc/mlpg.py:94-127, bandmat solveh) ----------------------------------------- */
+/*
+ * Batched maximum-likelihood parameter generation with the reference's three windows
+ * ([1], [-.5,0,.5], [1,-2,1]) for U utterances stored back to back.
+ *   d_feat      [Ttot, ld_feat] f64; static/delta/delta-delta means of dimension d sit in
+ *               columns col0+d, col0+D+d, col0+2D+d          (mlpg.py:119-121)
+ *   d_var       [3*D] f64 diagonal of the 3D x 3D covariance (mlpg.py:111-113)
+ *   h_offsets   [U+1] frame offsets of the utterances (host), offsets[U] = Ttot
+ *   d_out       [Ttot, ld_out] f64; result for dimension d in column ocol0+d
+ *   d_scratch   >= itts_mlpg_scratch_bytes(Ttot, D) bytes
+ */
+int64_t itts_mlpg_scratch_bytes(int64_t t_total, int dim);
+int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int dim,
+                         const double* d_var, const int64_t* h_offsets, int n_utts,
+                         double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
+                         void* stream);
+
+/* ---- frame utilities (misc/utils.py:40-105) --------------------------------------------- */
+/* compute_deltas == np.gradient(x, axis=0) in float32, per utterance (utils.py:103-105). */
+int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_out, int dim,
+                      const int64_t* h_offsets, int n_utts, void* stream);
+
+/* ---- acoustic model: dense layers (rnn_dyn/FFWrapper.py:63-73 -> torch.nn.Linear + act) --- */
+#define ITTS_ACT_NONE 0
+#define ITTS_ACT_TANH 1
+#define ITTS_ACT_RELU 2
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + b[N]); fp32 MFMA. */
+int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
+                    float* d_y, int64_t ldy, int64_t M, int N, int K, int act, void* stream);
+/* dz = dy * act'(y)  (elementwise; act' expressed through the layer output y). */
+int itts_act_bwd(const float* d_dy, const float* d_y, float* d_dz, int64_t n_elem, int act,
+                 void* stream);
+/* dx[M,K] = dz[M,N] @ w[N,K]; if d_yprev != NULL the previous layer's act' (through its
+ * output yprev[M,K]) is fused into the epilogue: dx *= act'(yprev). */
+int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const float* d_w, float* d_dx,
+                          int64_t lddx, const float* d_yprev, int64_t ldyp, int act_prev,
+                          int64_t M, int N, int K, void* stream);
+/* dw[N,K] = dz[M,N]^T @ x[M,K], db[N] = colsum(dz).  Deterministic split-K through
+ * d_workspace (>= itts_linear_bwd_weight_workspace_bytes). If accumulate != 0, adds. */
+int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
+int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx,
+                           float* d_dw, float* d_db, int64_t M, int N, int K,
+                           void* d_workspace, int accumulate, void* stream);
+
+/* ---- masked MSE, reduction 'mean_per_frame' (loss/NamedLoss.py:70-117) -------------------- */
+/*
+ * loss = mean_d( sum_{valid frames} (pred-target)^2 / n_valid ), grad = dloss/dpred.
+ * d_row_valid [M] u8 (1 = frame inside the sequence, i.e. the seq mask), n_valid = number of
+ * valid frames of the GLOBAL batch (sum of lengths over all ranks when data parallel).
+ * d_loss: one f32 (sum over this rank's rows already divided by n_valid*D).
+ * d_grad may be NULL (evaluation).  d_workspace >= itts_masked_mse_workspace_bytes(M,D).
+ */
+int64_t itts_masked_mse_workspace_bytes(int64_t M, int D);
+int itts_masked_mse(const float* d_pred, int64_t ldp, const float* d_target, int64_t ldt,
+                    const uint8_t* d_row_valid, int64_t M, int D, double n_valid,
+                    float loss_weight, float* d_loss, float* d_grad, int64_t ldg,
+                    void* d_workspace, void* stream);
+
+/* ---- Adam on a flat fp32 parameter buffer (torch.optim.Adam semantics, ----------------------
+ *      ModularModelHandlerPyTorch.py:570-571); grad_scale multiplies the gradient first
+ *      (1/world_size after an all-reduce(sum)). */
+int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDIAPTTS_AMD_H */

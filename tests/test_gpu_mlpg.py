@@ -1,0 +1,70 @@
+"""GPU parity: HIP MLPG (through the C ABI) vs the C oracle (oracle/c/mlpg.c)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng, lengths, dim, extra_cols=0, col0=0):
+    T = int(sum(lengths))
+    feat = rng.normal(size=(T, col0 + 3 * dim + extra_cols))
+    var = rng.uniform(0.01, 1.0, size=3 * dim)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    return feat, var, offsets
+
+
+@pytest.mark.parametrize("lengths,dim,col0", [
+    ([1], 3, 0), ([2], 3, 0), ([3, 1, 2], 5, 0), ([4, 7, 300], 60, 0), ([1931], 20, 0),
+    ([50, 0, 75], 1, 2), ([640, 1300], 62, 1),
+])
+def test_mlpg_matches_oracle(gpu, lengths, dim, col0):
+    from idiaptts_amd import ops
+    from oracle import capi
+    rng = np.random.default_rng(7)
+    feat, var, offsets = _case(rng, lengths, dim, extra_cols=2, col0=col0)
+    out = ops.mlpg_generation(torch.from_numpy(feat).to(gpu), torch.from_numpy(var).to(gpu), dim,
+                              offsets.tolist(), col0=col0).cpu().numpy()
+    for u in range(len(lengths)):
+        a, b = offsets[u], offsets[u + 1]
+        if b == a:
+            continue
+        ref = capi.mlpg(feat[a:b], var, dim, col0=col0)
+        err = np.abs(out[a:b] - ref).max()
+        rmse = np.sqrt(np.mean((out[a:b] - ref) ** 2))
+        assert rmse <= 1e-10 and err <= 1e-9, (u, err, rmse)  # north-star bar: 1e-4 RMSE
+
+
+def test_mlpg_full_size_property(gpu):
+    """BASELINE config 4 shape (187-dim cmp, 256 utterances): P x = b must hold to fp64
+    round-off for the solution returned, checked through the normal equations on a sample."""
+    from idiaptts_amd import ops
+    rng = np.random.default_rng(11)
+    lengths = rng.integers(400, 2000, size=256)
+    dim = 60
+    feat, var, offsets = _case(rng, lengths, dim)
+    x = ops.mlpg_generation(torch.from_numpy(feat).to(gpu), torch.from_numpy(var).to(gpu), dim,
+                            offsets.tolist()).cpu().numpy()
+    assert np.isfinite(x).all()
+    for u in (0, 100, 255):
+        a, b = offsets[u], offsets[u + 1]
+        T = b - a
+        for d in (0, 31, 59):
+            tau = np.zeros((T, 3))
+            for w in range(3):
+                tau[:, w] = 1.0 / var[w * dim + d]
+            tau[0, 1:] = tau[-1, 1:] = 1e-11
+            m = feat[a:b, [d, dim + d, 2 * dim + d]]
+            xs = x[a:b, d]
+            # gradient of the quadratic form: sum_w W_w^T tau_w (W_w x - m_w) = 0
+            xp = np.concatenate([[0.0], xs, [0.0]])
+            w1x = 0.5 * (xp[2:] - xp[:-2])
+            w2x = xp[2:] - 2 * xp[1:-1] + xp[:-2]
+            r0 = tau[:, 0] * (xs - m[:, 0])
+            r1 = tau[:, 1] * (w1x - m[:, 1])
+            r2 = tau[:, 2] * (w2x - m[:, 2])
+            r1p = np.concatenate([[0.0], r1, [0.0]])
+            r2p = np.concatenate([[0.0], r2, [0.0]])
+            g = r0 + 0.5 * (r1p[:-2] - r1p[2:]) + (r2p[:-2] - 2 * r2p[1:-1] + r2p[2:])
+            scale = np.abs(tau[:, 0] * m[:, 0]).max() + 1.0
+            assert np.abs(g).max() / scale < 1e-9
