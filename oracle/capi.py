@@ -51,3 +51,134 @@ def mlpg(features, variances, dim, col0=0):
     if rc != 0:
         raise RuntimeError("orc_mlpg failed: {}".format(rc))
     return out
+
+
+# ---------------------------------------------------------------------------------- WORLD / SPTK
+def _fn(name, restype, argtypes):
+    f = getattr(lib(), name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+def num_frames(n, fs, frame_period=5.0):
+    return int(1000.0 * n / fs / frame_period) + 1
+
+
+def cheaptrick_fft_size(fs, f0_floor=71.0):
+    import math
+    return 2 ** (1 + int(math.log2(3.0 * fs / f0_floor + 1)))
+
+
+def dio(x, fs, frame_period=5.0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = num_frames(len(x), fs, frame_period)
+    f0 = np.zeros(T)
+    tp = np.zeros(T)
+    fn = _fn("orc_dio", c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double,
+                                c_double, c_void_p, c_void_p])
+    rc = fn(_p(x), len(x), fs, frame_period, 71.0, 800.0, 2.0, 0.1, _p(f0), _p(tp))
+    assert rc == 0
+    return f0, tp
+
+
+def stonemask(x, fs, tp, f0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(len(f0))
+    fn = _fn("orc_stonemask", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p])
+    assert fn(_p(x), len(x), fs, _p(np.ascontiguousarray(tp)), _p(np.ascontiguousarray(f0)),
+              len(f0), _p(out)) == 0
+    return out
+
+
+def cheaptrick(x, fs, tp, f0, fft_size=None, q1=-0.15):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    fft_size = fft_size or cheaptrick_fft_size(fs)
+    sp = np.zeros((len(f0), fft_size // 2 + 1))
+    fn = _fn("orc_cheaptrick", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_double, c_void_p])
+    assert fn(_p(x), len(x), fs, _p(np.ascontiguousarray(tp)), _p(np.ascontiguousarray(f0)),
+              len(f0), fft_size, q1, _p(sp)) == 0
+    return sp
+
+
+def d4c(x, fs, tp, f0, fft_size=None, threshold=0.85):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    fft_size = fft_size or cheaptrick_fft_size(fs)
+    ap = np.zeros((len(f0), fft_size // 2 + 1))
+    fn = _fn("orc_d4c", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                c_double, c_void_p])
+    assert fn(_p(x), len(x), fs, _p(np.ascontiguousarray(tp)), _p(np.ascontiguousarray(f0)),
+              len(f0), fft_size, threshold, _p(ap)) == 0
+    return ap
+
+
+def wav2world(x, fs, fft_size=None, frame_period=5.0):
+    """pyworld.wav2world -> (f0 [T], sp [T,K] power, ap [T,K])."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    fft_size = fft_size or cheaptrick_fft_size(fs)
+    T = num_frames(len(x), fs, frame_period)
+    K = fft_size // 2 + 1
+    f0 = np.zeros(T)
+    sp = np.zeros((T, K))
+    ap = np.zeros((T, K))
+    fn = _fn("orc_wav2world", c_int, [c_void_p, c_int, c_int, c_double, c_int, c_void_p,
+                                      c_void_p, c_void_p])
+    assert fn(_p(x), len(x), fs, frame_period, fft_size, _p(f0), _p(sp), _p(ap)) == 0
+    return f0, sp, ap
+
+
+def code_aperiodicity(ap, fs):
+    ap = np.ascontiguousarray(ap, dtype=np.float64)
+    T, K = ap.shape
+    nap = int(min(15000.0, fs / 2.0 - 3000.0) / 3000.0)
+    bap = np.zeros((T, nap))
+    fn = _fn("orc_code_aperiodicity", c_int, [c_void_p, c_int, c_int, c_int, c_void_p])
+    assert fn(_p(ap), T, (K - 1) * 2, fs, _p(bap)) == 0
+    return bap
+
+
+def decode_aperiodicity(bap, fs, fft_size):
+    bap = np.ascontiguousarray(bap, dtype=np.float64)
+    T = bap.shape[0]
+    ap = np.zeros((T, fft_size // 2 + 1))
+    fn = _fn("orc_decode_aperiodicity", c_int, [c_void_p, c_int, c_int, c_int, c_void_p])
+    assert fn(_p(bap), T, fs, fft_size, _p(ap)) == 0
+    return ap
+
+
+def mcep(amp_sp, order, alpha, eps=1e-8, miniter=2, maxiter=30, threshold=1e-3,
+         return_iters=False):
+    """pysptk.mcep(amp_sp, order, alpha, eps=eps, etype=1, itype=3) on [T, K] f64."""
+    a = np.ascontiguousarray(amp_sp, dtype=np.float64)
+    T, K = a.shape
+    out = np.zeros((T, order + 1))
+    iters = np.zeros(T, dtype=np.int32)
+    fn = _fn("orc_mcep", c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
+                                 c_double, c_void_p, c_void_p])
+    rc = fn(_p(a), T, K, order, alpha, eps, miniter, maxiter, threshold, _p(out), _p(iters))
+    assert rc == 0, rc
+    return (out, iters) if return_iters else out
+
+
+def mgc2sp_logamp(mc, alpha, fftlen):
+    """pysptk.mgc2sp(mc, alpha, 0.0, fftlen).real (log amplitude) [T, fftlen/2+1] f64."""
+    m = np.ascontiguousarray(mc, dtype=np.float64)
+    T, M1 = m.shape
+    out = np.zeros((T, fftlen // 2 + 1))
+    fn = _fn("orc_mgc2sp_logamp", c_int, [c_void_p, c_int, c_int, c_double, c_int, c_void_p])
+    assert fn(_p(m), T, M1 - 1, alpha, fftlen, _p(out)) == 0
+    return out
+
+
+def synthesize(f0, sp, ap, fs, frame_period=5.0):
+    f0 = np.ascontiguousarray(f0, dtype=np.float64)
+    sp = np.ascontiguousarray(sp, dtype=np.float64)
+    ap = np.ascontiguousarray(ap, dtype=np.float64)
+    T, K = sp.shape
+    yl = int(T * frame_period * fs / 1000)
+    y = np.zeros(yl)
+    fn = _fn("orc_synthesize", c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_double,
+                                       c_int, c_int, c_void_p])
+    assert fn(_p(f0), T, _p(sp), _p(ap), (K - 1) * 2, frame_period, fs, yl, _p(y)) == 0
+    return y
