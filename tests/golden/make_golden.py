@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/ (run in the BUILD container only;
+/root/reference does not exist on the GPU box and nothing here travels except the outputs).
+
+1. Copies DATA fixtures the reference's own tests hold (two short 16 kHz wavs and their golden
+   .cmp feature files, test/integration/fixtures/{database/wav,WORLD/cmp_mcep20}).
+2. Imports the reference's Python (stub harness of SURVEY.md Appendix A: MagicMock modules for
+   the absent third-party packages) and records input/output pairs of its own logic:
+   interpolate_lin, compute_deltas, convert_to_world_features, trim_to_shortest,
+   PyTorchDatareadersDataset._trim_datareader_output, sequence_mask, NamedLoss(mean_per_frame).
+3. Runs the reference's AcousticModelTrainer.benchmark known-answer test
+   (test/integration/model_trainers/test_AcousticModelTrainer.py:94-106) with the C oracle's MLPG
+   standing in for bandmat, asserts the pinned scores (8.616, 78.4, 0.609, 37.352) and stores
+   the MLPG inputs/outputs of that run.
+"""
+import base64
+import logging
+import os
+import pickle
+import shutil
+import sys
+import types
+import warnings
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+FIX = os.path.join(REF, "test", "integration", "fixtures")
+sys.path.insert(0, ROOT)
+
+
+def install_stub_harness():
+    warnings.simplefilter("ignore")
+    logging.raiseExceptions = False
+    os.environ["IDIAPTTS_ROOT"] = os.path.join(REF, "idiaptts")
+    sys.path.insert(0, REF)
+
+    class Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            m = MagicMock(name=self.__name__ + "." + k)
+            setattr(self, k, m)
+            return m
+
+    for n in ["git", "git.exc", "pyworld", "pyworld.pyworld", "pysptk", "pysptk.util", "bandmat",
+              "bandmat.linalg", "librosa", "librosa.display", "librosa.feature", "nnmnkwii",
+              "nnmnkwii.postfilters", "soundfile", "pydub", "pydub.utils", "wavenet_vocoder",
+              "wavenet_vocoder.util", "wavenet_vocoder.modules", "wavenet_vocoder.wavenet",
+              "wavenet_vocoder.mixture", "textgrid", "torchinfo", "tensorboard",
+              "numpy.lib.arraysetops"]:
+        m = Stub(n)
+        m.__path__ = []
+        sys.modules[n] = m
+
+    class _E(Exception):
+        pass
+    sys.modules["git.exc"].InvalidGitRepositoryError = _E
+    sys.modules["git"].exc = sys.modules["git.exc"]
+
+    def _repo(*a, **k):
+        raise _E()
+    sys.modules["git"].Repo = _repo
+    np.str = str
+    np.int = int
+    np.float = float
+    jp = types.ModuleType("jsonpickle")
+    jp.encode = lambda o, indent=None: base64.b64encode(pickle.dumps(o)).decode()
+    jp.decode = lambda s: pickle.loads(base64.b64decode(s))
+    sys.modules["jsonpickle"] = jp
+
+
+def copy_data_fixtures():
+    for name in ["LJ001-0002", "LJ001-0008"]:
+        shutil.copyfile(os.path.join(FIX, "database", "wav", name + ".wav"),
+                        os.path.join(HERE, name + ".wav"))
+        shutil.copyfile(os.path.join(FIX, "WORLD", "cmp_mcep20", name + ".cmp"),
+                        os.path.join(HERE, name + ".cmp"))
+        os.chmod(os.path.join(HERE, name + ".wav"), 0o644)
+        os.chmod(os.path.join(HERE, name + ".cmp"), 0o644)
+
+
+def capture_host_logic():
+    import torch
+    from idiaptts.misc.utils import compute_deltas, interpolate_lin
+    from idiaptts.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    from idiaptts.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+
+    rng = np.random.default_rng(2024)
+    out = {}
+    # interpolate_lin: Appendix-C cases + random float32 / float64 contours
+    cases = [[0, 0, 5, 5.2, 0, 0, 5.8, 0], [5, 0, 0, 0, 6, 0], [0, 0, 5, 0, 0, 6],
+             [0, 0, 5, 0, 0, 6, 6], [5, 0, 6], [0, 5], [0, 0, 0], [4.5]]
+    arrs = [np.array(c, dtype=np.float32) for c in cases]
+    for t in range(40):
+        n = int(rng.integers(1, 60))
+        x = (rng.uniform(3, 6, size=n) * (rng.uniform(size=n) < rng.uniform(0.1, 0.9)))
+        arrs.append(x.astype(np.float32 if t % 4 else np.float64))
+    for i, a in enumerate(arrs):
+        ip, vuv = interpolate_lin(a)
+        out["il_in_%d" % i] = a
+        out["il_ip_%d" % i] = ip
+        out["il_vuv_%d" % i] = vuv
+    out["il_count"] = np.array(len(arrs))
+    # compute_deltas
+    for i, shape in enumerate([(4, 2), (2, 3), (57, 5), (300, 1)]):
+        x = rng.normal(size=shape).astype(np.float32)
+        out["cd_in_%d" % i] = x
+        out["cd_out_%d" % i] = compute_deltas(x)
+    out["cd_count"] = np.array(4)
+    # convert_to_world_features with / without deltas (20 coded sps, 1 bap)
+    for i, (deltas, ncs, nb) in enumerate([(False, 20, 1), (True, 20, 1), (True, 60, 1),
+                                           (False, 60, 5)]):
+        width = (ncs + 1 + nb) * (3 if deltas else 1) + 1
+        s = rng.uniform(-1, 1.5, size=(13, width)).astype(np.float32)
+        c, l, v, b = WorldFeatLabelGen.convert_to_world_features(s, deltas, ncs, nb)
+        out["cw_in_%d" % i] = s
+        out["cw_meta_%d" % i] = np.array([int(deltas), ncs, nb])
+        out["cw_sp_%d" % i] = c
+        out["cw_lf0_%d" % i] = l
+        out["cw_vuv_%d" % i] = v
+        out["cw_bap_%d" % i] = b
+    out["cw_count"] = np.array(4)
+    # trim_to_shortest: symmetric trimming (front = diff//2)
+    feats = [np.arange(20, dtype=np.float32).reshape(10, 2), np.arange(7, dtype=np.float32)[:, None],
+             None, np.arange(8, dtype=np.float32)[:, None]]
+    trimmed = WorldFeatLabelGen.trim_to_shortest(list(feats))
+    out["tts_0"], out["tts_1"], out["tts_3"] = trimmed[0], trimmed[1], trimmed[3]
+    # sequence_mask both layouts
+    lens = torch.tensor([5, 2, 7, 1])
+    out["sm_len"] = lens.numpy()
+    out["sm_bf"] = Handler.sequence_mask(lens, 7, batch_first=True).numpy()
+    out["sm_tf"] = Handler.sequence_mask(lens, 7, batch_first=False).numpy()
+    # NamedLoss mean_per_frame (time-major, as the trainers feed it by default)
+    from idiaptts.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss
+    cfg = NamedLoss.Config(name="MSELoss_acoustic_features", type_="MSELoss",
+                           seq_mask="acoustic_features_mask",
+                           input_names=["acoustic_features", "pred_acoustic_features"],
+                           batch_first=False)
+    loss_mod = cfg.create_loss()
+    T, B, D = 9, 3, 6
+    lens = torch.tensor([9, 4, 6])
+    tgt = torch.from_numpy(rng.normal(size=(T, B, D)).astype(np.float32))
+    pred = torch.from_numpy(rng.normal(size=(T, B, D)).astype(np.float32)).requires_grad_(True)
+    mask = Handler.sequence_mask(lens, T, batch_first=False)
+    data = {"acoustic_features": tgt, "pred_acoustic_features": pred,
+            "acoustic_features_mask": mask}
+    ld = loss_mod(data, {"acoustic_features_mask": lens}, step=1)
+    val = list(ld.values())[0]
+    val.backward()
+    out["nl_target"], out["nl_pred"], out["nl_len"] = tgt.numpy(), pred.detach().numpy(), lens.numpy()
+    out["nl_loss"], out["nl_grad"] = val.detach().numpy(), pred.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "host_logic.npz"), **out)
+    print("host_logic.npz:", len(out), "arrays")
+
+
+def capture_benchmark_kat():
+    """Reference benchmark known answer with oracle MLPG as the bandmat stand-in."""
+    import idiaptts.misc.mlpg as ref_mlpg
+    import idiaptts.src.Metrics as ref_metrics
+    from idiaptts.src.model_trainers.AcousticModelTrainer import AcousticModelTrainer
+    from oracle import capi
+
+    calls = []
+
+    def generation(self, features, covariance, feature_dim):
+        var = np.ascontiguousarray(np.diag(covariance), dtype=np.float64)
+        res = capi.mlpg(np.asarray(features, dtype=np.float64), var, feature_dim)
+        calls.append((np.array(features), var, feature_dim, res))
+        return res
+    ref_mlpg.MLPG.generation = generation
+    ref_metrics.nnmnkwii_metrics.melcd = lambda X, Y, lengths=None: float(
+        10.0 / np.log(10) * np.sqrt(2.0) * np.sqrt(((X - Y) ** 2).sum(-1)).mean())
+
+    os.chdir(os.path.join(REF, "test"))
+    hp = AcousticModelTrainer.create_hparams()
+    hp.num_questions = 409
+    hp.voice = "full"
+    hp.data_dir = os.path.realpath(os.path.join("integration", "fixtures", "database"))
+    hp.out_dir = "/tmp/idiaptts_amd_golden_benchmark"
+    hp.frame_size_ms = 5
+    hp.num_coded_sps = 20
+    hp.seed = 1
+    hp.epochs = 3
+    hp.use_gpu = False
+    hp.model_type = "RNNDYN-1_RELU_32-1_FC_67"
+    hp.batch_size_train = 2
+    hp.batch_size_val = 50
+    hp.use_saved_learning_rate = True
+    hp.optimiser_args["lr"] = 0.001
+    hp.model_name = "test_model"
+    hp.epochs_per_checkpoint = 2
+    hp.world_dir = os.path.join("integration", "fixtures", "WORLD")
+    with open(os.path.join("integration", "fixtures", "database", "file_id_list.txt")) as f:
+        id_list = [s.strip() for s in f.readlines()]
+    trainer = AcousticModelTrainer(**AcousticModelTrainer.legacy_support_init(
+        hp.world_dir, os.path.join("integration", "fixtures", "questions"), id_list,
+        hp.num_questions, hp))
+    trainer.init(hp)
+    scores = trainer.benchmark(hp)["pred_acoustic_features"]
+    shutil.rmtree(hp.out_dir, ignore_errors=True)
+    print("benchmark scores", scores)
+    np.testing.assert_almost_equal((8.616, 78.4, 0.609, 37.352), scores, 3)
+    out = {"scores": np.array(scores, dtype=np.float64), "n_calls": np.array(len(calls))}
+    for i, (f, v, d, r) in enumerate(calls):
+        out["feat_%d" % i] = f.astype(np.float32) if f.dtype == np.float32 else f
+        out["var_%d" % i] = v
+        out["dim_%d" % i] = np.array(d)
+        out["out_%d" % i] = r
+    np.savez_compressed(os.path.join(HERE, "mlpg_benchmark_kat.npz"), **out)
+    print("mlpg_benchmark_kat.npz:", len(calls), "MLPG calls")
+
+
+if __name__ == "__main__":
+    copy_data_fixtures()
+    install_stub_harness()
+    capture_host_logic()
+    capture_benchmark_kat()

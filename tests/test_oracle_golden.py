@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (oracle/) against the reference's own golden vectors (CPU-only tests).
+
+* WORLD analysis + SPTK mcep vs test/integration/fixtures/WORLD/cmp_mcep20/*.cmp (copied under
+  tests/golden/): V/UV bit-exact, <= 1 float32 ulp on every other column, when run the way the
+  fixtures were made (pre-emphasis 0.97, alpha 0.58, order 19 -- SURVEY.md section 4).
+* MLPG vs the reference's benchmark known answer (test_AcousticModelTrainer.py:104), captured by
+  tests/golden/make_golden.py with the oracle standing in for bandmat.
+* the C oracle vs the numpy executable spec (oracle/world_spec.py) on a short clip.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from idiaptts_amd.misc.utils import compute_deltas, interpolate_lin
+from oracle import capi
+
+
+def _read(golden_dir, name):
+    fs, w = wavfile.read(os.path.join(golden_dir, name + ".wav"))
+    raw = w.astype(np.float64) / 32768.0          # soundfile.read scaling (AudioProcessing.py:113)
+    return np.append(raw[0], raw[1:] - 0.97 * raw[:-1]), fs   # get_raw pre-emphasis (:118)
+
+
+@pytest.mark.parametrize("name", ["LJ001-0002", "LJ001-0008"])
+def test_world_analysis_and_mcep_match_reference_cmp(golden_dir, name):
+    x, fs = _read(golden_dir, name)
+    cmp_ = np.fromfile(os.path.join(golden_dir, name + ".cmp"), dtype=np.float32).reshape(-1, 67)
+    f0, sp, ap = capi.wav2world(x, fs)
+    assert len(f0) == cmp_.shape[0] == capi.num_frames(len(x), fs)
+    # WorldFeatLabelGen.world_extract_features (:795-805)
+    lf0 = np.log(f0.clip(min=1e-10), dtype=np.float32)
+    lf0[lf0 <= math.log(30)] = 0
+    lf0, vuv = interpolate_lin(lf0)
+    bap = np.array(capi.code_aperiodicity(ap, fs), dtype=np.float32)
+    mc = capi.mcep(np.sqrt(sp), 19, 0.58).astype(np.float32)
+    ulp = 4.8e-7
+    assert np.array_equal(cmp_[:, 63], vuv[:, 0].astype(np.float32))          # V/UV bit-exact
+    assert np.abs(cmp_[:, 60] - lf0[:, 0].astype(np.float32)).max() <= ulp    # lf0
+    assert np.abs(cmp_[:, 64] - bap[:, 0]).max() <= ulp                       # bap
+    assert np.abs(cmp_[:, :20] - mc).max() <= ulp                             # mcep
+    assert np.sqrt(np.mean((cmp_[:, :20] - mc) ** 2)) < 1e-7
+    # deltas inside the cmp are np.gradient of the static columns
+    d = compute_deltas(cmp_[:, :20])
+    assert np.array_equal(d, cmp_[:, 20:40])
+    assert np.array_equal(compute_deltas(d), cmp_[:, 40:60])
+
+
+def test_mlpg_oracle_reproduces_reference_benchmark_run(golden_dir):
+    kat = np.load(os.path.join(golden_dir, "mlpg_benchmark_kat.npz"))
+    np.testing.assert_almost_equal((8.616, 78.4, 0.609, 37.352), kat["scores"], 3)
+    from scipy.linalg import solveh_banded
+    for i in range(int(kat["n_calls"])):
+        feat, var, dim = kat["feat_%d" % i], kat["var_%d" % i], int(kat["dim_%d" % i])
+        out = capi.mlpg(feat.astype(np.float64), var, dim)
+        assert np.array_equal(out, kat["out_%d" % i])
+        # independent check: LAPACK banded solve of the same normal equations, dimension 0
+        T = feat.shape[0]
+        tau = np.stack([np.full(T, 1.0 / var[w * dim]) for w in range(3)], 1)
+        tau[0, 1:] = tau[-1, 1:] = 1e-11
+        m = feat[:, [0, dim, 2 * dim]].astype(np.float64)
+        bf = m * tau
+        b = bf[:, 0].copy()
+        b[:-1] += -0.5 * bf[1:, 1]
+        b[1:] += 0.5 * bf[:-1, 1]
+        b += -2.0 * bf[:, 2]
+        b[:-1] += bf[1:, 2]
+        b[1:] += bf[:-1, 2]
+        ab = np.zeros((3, T))
+        ab[2] = tau[:, 0] + 4 * tau[:, 2]
+        ab[2, :-1] += 0.25 * tau[1:, 1] + tau[1:, 2]
+        ab[2, 1:] += 0.25 * tau[:-1, 1] + tau[:-1, 2]
+        ab[1, 1:] = -2 * (tau[:-1, 2] + tau[1:, 2])
+        ab[0, 2:] = tau[1:-1, 2] - 0.25 * tau[1:-1, 1]
+        ref = solveh_banded(ab, b)
+        assert np.abs(ref - out[:, 0]).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+def test_c_oracle_matches_numpy_spec_on_short_clip(golden_dir):
+    """The slow numpy spec and the C oracle are independent codings of
+    the same published algorithms; they must agree to fp64 round-off on 0.5 s of speech."""
+    from oracle import world_spec as ws
+    x, fs = _read(golden_dir, "LJ001-0008")
+    x = x[4000:12000]
+    f0_c, tp = capi.dio(x, fs)
+    f0_s, tp_s = ws.dio(x, fs)
+    assert np.array_equal(tp, tp_s) and np.abs(f0_c - f0_s).max() < 1e-8
+    f0r = capi.stonemask(x, fs, tp, f0_c)
+    f0r_s = np.array([ws.stonemask_frame(x, fs, tp[i], f0_c[i]) for i in range(len(tp))])
+    assert np.abs(f0r - f0r_s).max() < 1e-8
+    sp = capi.cheaptrick(x, fs, tp, f0r)
+    fft = 1024
+    floor = 3.0 * fs / (fft - 3.0)
+    for i in range(0, len(tp), 7):
+        s = ws.cheaptrick_frame(x, fs, f0r[i] if f0r[i] > floor else 500.0, tp[i], fft)
+        assert np.abs(s / sp[i] - 1).max() < 1e-9
+    ap = capi.d4c(x, fs, tp, f0r)
+    bap = capi.code_aperiodicity(ap, fs)
+    bap_s = ws.d4c_bap(x, fs, f0r, tp, fft)
+    assert np.abs(bap - bap_s).max() < 1e-7
+    mc = capi.mcep(np.sqrt(sp[::9]), 24, 0.41)
+    mc_s = np.array([ws.sptk_mcep(np.sqrt(s), 24, 0.41) for s in sp[::9]])
+    assert np.abs(mc - mc_s).max() < 1e-9
+    la = capi.mgc2sp_logamp(mc, 0.41, fft)
+    amp_s = np.array([ws.mcep_to_amp_sp(m, 0.41, fft) for m in mc])
+    assert np.abs(np.exp(la) / amp_s - 1).max() < 1e-10
+
+
+def test_synthesis_oracle_matches_numpy_spec_and_reference_bound(golden_dir):
+    """Synthesis has no golden in the reference (parity unpinned): check the two independent
+    restatements agree and that copy-synthesis passes the reference's own loose bound
+    (test_WorldFeatLabelGen.py:761-763: sum (orig - resynth)^2 < 10000)."""
+    from oracle import synth_spec as ss
+    fs, w = wavfile.read(os.path.join(golden_dir, "LJ001-0008.wav"))
+    raw = w.astype(np.float64) / 32768.0
+    f0, sp, ap = capi.wav2world(raw, fs)
+    y = capi.synthesize(f0, sp, ap, fs)
+    assert len(y) == int(len(f0) * 5.0 * fs / 1000)
+    n = min(len(y), len(raw))
+    assert ((raw[:n] - y[:n]) ** 2).sum() < 10000
+    # numpy spec on the first 0.6 s (it is slow); identical RNG stream => same samples
+    Tn = 120
+    y_c = capi.synthesize(f0[:Tn], sp[:Tn], ap[:Tn], fs)
+    y_s = ss.synthesize(f0[:Tn], sp[:Tn], ap[:Tn], fs)
+    assert np.abs(y_c - y_s).max() < 1e-9
+    bap = capi.code_aperiodicity(ap, fs)
+    ap_c = capi.decode_aperiodicity(bap, fs, 1024)
+    voiced = bap.mean(1) <= -0.5
+    ap_s = ss.decode_aperiodicity(bap[voiced], fs, 1024)
+    assert np.abs(ap_c[voiced] - ap_s).max() < 1e-12
+    assert np.all(ap_c[~voiced] == 1.0 - 1e-12)
