@@ -1,0 +1,230 @@
+// Workgroup-cooperative fp64 building blocks for the WORLD / SPTK frame kernels (gfx950).
+// One 256-thread workgroup (4 wavefronts) owns one analysis frame or one synthesis pulse; all
+// intermediates of the frame (windowed segment, spectra, cepstra, smoothing prefix sums) live
+// in LDS, so HBM only sees the waveform samples read and the feature row written.
+//
+//   fft_lds      in-place radix-2 DIT complex FFT on interleaved (re,im) doubles in LDS,
+//                twiddles from an LDS copy of the table (ds_read_b128 per operand)
+//   rfft/irfft   real transforms of length n through a complex FFT of length n/2
+//   block_scan   inclusive prefix sum (WORLD's cumulative spectra)
+//   dc_correction / linear_smoothing / interp1Q: WORLD common.cpp + matlabfunctions.cpp
+#pragma once
+#include "common.h"
+
+namespace itts {
+namespace wd {
+
+constexpr int NT = 256;       // threads per frame workgroup
+constexpr int TW_N = 16384;   // master twiddle table: tw[k] = exp(+2 pi i k / TW_N), k < TW_N/2
+constexpr double kEps = 1e-12;  // WORLD kMySafeGuardMinimum
+constexpr double kPi = 3.1415926535897932384626433832795;
+
+__device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
+__device__ __forceinline__ int ilog2(int n) { return 31 - __clz(n); }
+
+// Copies the twiddles of an n-point transform into LDS: tw[k] = exp(+2 pi i k / n), k < n/2.
+__device__ __forceinline__ void load_twiddles(double2* tw, const double2* __restrict__ g_tw, int n) {
+  const int stride = TW_N / n;
+  for (int k = threadIdx.x; k < n / 2; k += NT) tw[k] = g_tw[k * stride];
+}
+
+// In-place complex FFT of z[0..n) (n = 2^logn <= tw_n). tw holds exp(+2 pi i k / tw_n).
+// sign = -1: forward (e^{-i..}), +1: unnormalised inverse. Ends with a barrier.
+__device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, int tw_n, int sign) {
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const int j = (int)(__brev((unsigned)i) >> (32 - logn));
+    if (i < j) {
+      const double2 a = z[i], b = z[j];
+      z[i] = b;
+      z[j] = a;
+    }
+  }
+  __syncthreads();
+  const int tshift = ilog2(tw_n) - 1;  // twiddle index of w_{2h}^r in the tw_n table: r * tw_n/(2h)
+  for (int s = 1; s <= logn; ++s) {
+    const int h = 1 << (s - 1);
+    for (int t = threadIdx.x; t < n / 2; t += NT) {
+      const int r = t & (h - 1);
+      const int a = ((t >> (s - 1)) << s) + r;
+      const int b = a + h;
+      const double2 w = tw[r << (tshift - (s - 1))];
+      const double wi = sign < 0 ? -w.y : w.y;
+      const double2 zb = z[b], za = z[a];
+      const double xr = zb.x * w.x - zb.y * wi;
+      const double xi = zb.x * wi + zb.y * w.x;
+      z[b] = make_double2(za.x - xr, za.y - xi);
+      z[a] = make_double2(za.x + xr, za.y + xi);
+    }
+    __syncthreads();
+  }
+}
+
+// Real FFT: z viewed as n real samples (z[k] = (x[2k], x[2k+1])), needs n/2+1 complex slots.
+// On return z[k] = X[k], k = 0..n/2 (numpy.fft.rfft).
+__device__ inline void rfft_lds(double2* z, int n, int logn, const double2* tw, int tw_n) {
+  const int h = n / 2;
+  fft_lds(z, h, logn - 1, tw, tw_n, -1);
+  const int tstride = tw_n / n;
+  for (int k = threadIdx.x; k <= h / 2; k += NT) {
+    if (k == 0) {
+      const double2 z0 = z[0];
+      z[0] = make_double2(z0.x + z0.y, 0.0);
+      z[h] = make_double2(z0.x - z0.y, 0.0);
+    } else {
+      const int j = h - k;
+      const double2 zk = z[k], zj = z[j];
+      const double er = 0.5 * (zk.x + zj.x), ei = 0.5 * (zk.y - zj.y);
+      const double dr = 0.5 * (zk.x - zj.x), di = 0.5 * (zk.y + zj.y);
+      const double orr = di, oi = -dr;  // O = -i D
+      const double2 w = tw[k * tstride];
+      const double wr = w.x, wi = -w.y;  // w^k = e^{-2 pi i k / n}
+      const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
+      z[k] = make_double2(er + tr, ei + ti);
+      z[j] = make_double2(er - tr, -(ei - ti));
+    }
+  }
+  __syncthreads();
+}
+
+// Inverse real FFT: z[k] = X[k], k = 0..n/2 (imag of X[0], X[n/2] ignored) -> z viewed as n real
+// samples, normalised like numpy.fft.irfft.
+__device__ inline void irfft_lds(double2* z, int n, int logn, const double2* tw, int tw_n) {
+  const int h = n / 2;
+  const int tstride = tw_n / n;
+  for (int k = threadIdx.x; k <= h / 2; k += NT) {
+    const int j = h - k;
+    double2 xk = z[k], xj = z[j];
+    if (k == 0) {
+      xk.y = 0.0;
+      xj.y = 0.0;
+    }
+    const double er = 0.5 * (xk.x + xj.x), ei = 0.5 * (xk.y - xj.y);
+    const double dr = 0.5 * (xk.x - xj.x), di = 0.5 * (xk.y + xj.y);
+    const double2 w = tw[k * tstride];  // conj(w^k) = e^{+2 pi i k / n}
+    const double orr = dr * w.x - di * w.y, oi = dr * w.y + di * w.x;
+    const double2 zk = make_double2(er - oi, ei + orr);
+    const double2 zj = make_double2(er + oi, -ei + orr);
+    if (k == 0) {
+      z[0] = zk;
+    } else {
+      z[k] = zk;
+      if (j != k) z[j] = zj;
+    }
+  }
+  __syncthreads();
+  fft_lds(z, h, logn - 1, tw, tw_n, +1);
+  const double s = 1.0 / (double)h;
+  for (int k = threadIdx.x; k < h; k += NT) {
+    double2 v = z[k];
+    v.x *= s;
+    v.y *= s;
+    z[k] = v;
+  }
+  __syncthreads();
+}
+
+// Block-wide sum; result identical in every thread. red: >= 8 doubles of LDS.
+__device__ __forceinline__ double bsum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// In-place inclusive prefix sum of a[0..n) in LDS. red: >= NT+8 doubles. Ends with a barrier.
+__device__ inline void block_scan(double* a, int n, double* red) {
+  const int chunk = (n + NT - 1) / NT;
+  const int lo = threadIdx.x * chunk;
+  const int hi = min(n, lo + chunk);
+  double s = 0.0;
+  for (int i = lo; i < hi; ++i) {
+    s += a[i];
+    a[i] = s;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {  // one wave scans the 256 chunk totals (4 per lane)
+    double v0 = red[4 * threadIdx.x], v1 = red[4 * threadIdx.x + 1], v2 = red[4 * threadIdx.x + 2],
+           v3 = red[4 * threadIdx.x + 3];
+    v1 += v0;
+    v2 += v1;
+    v3 += v2;
+    double incl = v3;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(incl, off, 64);
+      if ((int)threadIdx.x >= off) incl += o;
+    }
+    const double excl = incl - v3;
+    red[4 * threadIdx.x] = excl;            // exclusive prefix of chunk totals
+    red[4 * threadIdx.x + 1] = excl + v0;
+    red[4 * threadIdx.x + 2] = excl + v1;
+    red[4 * threadIdx.x + 3] = excl + v2;
+  }
+  __syncthreads();
+  const double base = red[threadIdx.x];
+  for (int i = lo; i < hi; ++i) a[i] += base;
+  __syncthreads();
+}
+
+// WORLD interp1Q at one point: equally spaced abscissa x0 + i*shift, ordinate y[0..ylen)
+__device__ __forceinline__ double interp1q(double x0, double shift, const double* y, int ylen,
+                                           double xi) {
+  const double pos = (xi - x0) / shift;
+  const int base = (int)pos;
+  const double frac = pos - base;
+  const double dy = (base + 1 < ylen) ? y[base + 1] - y[base] : 0.0;
+  return y[base] + dy * frac;
+}
+
+// WORLD DCCorrection (common.cpp): P[0..upper-2] += mirrored replica around f0. P has >= upper+1
+// valid entries. Needs upper <= NT (f0 <= ~1 kHz at the FFT sizes in use). Ends with a barrier.
+__device__ inline void dc_correction(double* P, double f0, int fs, int fft) {
+  const int upper = 2 + (int)(f0 * fft / fs);
+  double rep = 0.0;
+  const int i = threadIdx.x;
+  for (int base = 0; base < upper - 1; base += NT) {
+    const int ii = base + i;
+    if (ii < upper - 1) {
+      const double lfa = (double)ii * fs / fft;
+      rep = interp1q(f0, -(double)fs / fft, P, upper + 1, lfa);
+    }
+    __syncthreads();
+    if (ii < upper - 1) P[ii] += rep;
+    __syncthreads();
+  }
+}
+
+// WORLD LinearSmoothing: out[k] = mean of P over [f_k - width/2, f_k + width/2], k = 0..fft/2.
+// mir: scratch of fft/2 + 2*boundary + 1 doubles; out may alias P. red: NT+8 doubles.
+__device__ inline void linear_smoothing(const double* P, double width, int fs, int fft, double* out,
+                                        double* mir, double* red) {
+  const int boundary = (int)(width * fft / fs) + 1;
+  const int h = fft / 2;
+  const int ml = h + boundary * 2 + 1;
+  for (int i = threadIdx.x; i < ml; i += NT) {
+    double v;
+    if (i < boundary)
+      v = P[boundary - i];
+    else if (i < h + boundary)
+      v = P[i - boundary];
+    else
+      v = P[h - (i - (h + boundary))];
+    mir[i] = v * fs / fft;
+  }
+  __syncthreads();
+  block_scan(mir, ml, red);
+  const double org = -((double)boundary - 0.5) * fs / fft;
+  const double dfi = (double)fs / fft;
+  for (int k = threadIdx.x; k <= h; k += NT) {
+    const double fa = (double)k / fft * fs - width / 2.0;
+    const double lo = interp1q(org, dfi, mir, ml, fa);
+    const double hi = interp1q(org, dfi, mir, ml, fa + width);
+    out[k] = (hi - lo) / width;
+  }
+  __syncthreads();
+}
+
+}  // namespace wd
+}  // namespace itts

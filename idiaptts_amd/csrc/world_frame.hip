@@ -1,0 +1,611 @@
+// Frame-parallel WORLD / SPTK kernels: CheapTrick spectral envelope, SPTK mel-cepstral analysis
+// (mcep), mel-cepstrum -> amplitude spectrum (mgc2sp), code / decode aperiodicity.
+//
+// Replaces (reference call sites, /root/reference/idiaptts):
+//   pyworld.cheaptrick inside pyworld.wav2world   src/data_preparation/world/WorldFeatLabelGen.py:792
+//   pysptk.mcep                                    src/data_preparation/audio/AudioProcessing.py:146-152
+//   pysptk.mgc2sp + exp(real)                      AudioProcessing.py:252-256
+//   pyworld.code_aperiodicity / decode_aperiodicity  WorldFeatLabelGen.py:805, :940-941
+//
+// One 256-thread workgroup per frame; everything between the waveform samples read and the
+// feature row written stays in LDS.  Roofline: HBM-bound by contract --
+// analysis reads 80 samples*8 B and writes K*8 B (+60*4 B mcep) per frame; in practice the
+// kernels are fp64-FFT/LDS bound, so achieved fp64 FLOP/s is reported beside GB/s.
+#include <algorithm>
+#include <cmath>
+
+#include "context.h"
+#include "world_dev.h"
+
+namespace itts {
+using namespace wd;
+
+// locate the utterance of global frame g: offsets[u] <= g < offsets[u+1]
+__device__ __forceinline__ int find_utt(const int64_t* __restrict__ off, int n_utts, int64_t g) {
+  int lo = 0, hi = n_utts;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CheapTrick for one frame. Result (power spectral envelope, fft/2+1 bins) is left in P.
+// LDS: z [fft/2+1] complex, P [fft/2+1], mir [fft/2 + 2*bmax + 1], red [NT+8], tw [fft/2] cplx
+struct CtLds {
+  double2* tw;
+  double2* z;
+  double* P;
+  double* mir;
+  double* red;
+};
+
+__device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl, int fs, double f0,
+                                        double pos, int fft, int logfft, double q1, const CtLds& L) {
+  const int h = fft / 2;
+  const int half = mround(1.5 * fs / f0);
+  const int n = 2 * half + 1;
+  const int64_t c = mround(pos * fs + 0.001);
+  double* zr = reinterpret_cast<double*>(L.z);  // real view, fft + 2 doubles
+  double* win = L.mir;                          // n <= fft-3 doubles of scratch
+  // window and its energy
+  double e = 0.0;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const int b = i - half;
+    const double w = 0.5 * cos(kPi * ((double)b / 1.5 / fs) * f0) + 0.5;
+    win[i] = w;
+    e += w * w;
+  }
+  e = sqrt(bsum(e, L.red));
+  double swf = 0.0, sw = 0.0;
+  for (int i = threadIdx.x; i < fft + 2; i += NT) {
+    double v = 0.0;
+    if (i < n) {
+      const double w = win[i] / e;
+      win[i] = w;
+      int64_t idx = c + i - half;
+      idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+      v = x[idx] * w;
+      swf += v;
+      sw += w;
+    }
+    zr[i] = v;
+  }
+  swf = bsum(swf, L.red);
+  sw = bsum(sw, L.red);
+  const double mean = swf / sw;
+  for (int i = threadIdx.x; i < n; i += NT) zr[i] -= win[i] * mean;
+  __syncthreads();
+  rfft_lds(L.z, fft, logfft, L.tw, fft);
+  for (int k = threadIdx.x; k <= h; k += NT) {
+    const double2 v = L.z[k];
+    L.P[k] = v.x * v.x + v.y * v.y;
+  }
+  __syncthreads();
+  dc_correction(L.P, f0, fs, fft);
+  linear_smoothing(L.P, f0 * 2.0 / 3.0, fs, fft, L.P, L.mir, L.red);
+  // smoothing with recovery (cepstral liftering)
+  for (int k = threadIdx.x; k <= h; k += NT) {
+    const double lp = log(L.P[k]);
+    zr[k] = lp;
+    if (k > 0 && k < h) zr[fft - k] = lp;
+  }
+  if (threadIdx.x == 0) {
+    zr[fft] = 0.0;
+    zr[fft + 1] = 0.0;
+  }
+  __syncthreads();
+  rfft_lds(L.z, fft, logfft, L.tw, fft);
+  for (int k = threadIdx.x; k <= h; k += NT) {
+    double sl = 1.0, cl = 1.0;
+    if (k > 0) {
+      const double q = (double)k / fs;
+      sl = sin(kPi * f0 * q) / (kPi * f0 * q);
+      cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * q * f0);
+    }
+    L.z[k] = make_double2(L.z[k].x * sl * cl, 0.0);
+  }
+  __syncthreads();
+  irfft_lds(L.z, fft, logfft, L.tw, fft);
+  for (int k = threadIdx.x; k <= h; k += NT) L.P[k] = exp(zr[k]);
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPTK mcep (itype 3: amplitude spectrum in, etype 1) for one frame.
+// in:  xp[0..f2] = amp^2 + eps (periodogram, half)      out: mc[0..m]
+// LDS: z [f2+1] cplx (flng real), mc[m+1], cr[2m+1], al unused, A [(m+1)*(m+2)], fcol[m+1], misc[8]
+struct McLds {
+  double2* tw;   // twiddles of an flng-point transform (flng/2 entries)
+  double2* z;
+  double* xp;
+  double* mc;
+  double* cr;
+  double* part;  // 4*(2m+1) partial sums
+  double* A;     // augmented system, row stride m+2
+  double* fcol;
+  double* misc;
+};
+
+__device__ inline int mcep_frame(const McLds& L, const FreqtTables& ft, int flng, int logflng, int m,
+                                 double alpha, int itr1, int itr2, double dd) {
+  const int f2 = flng / 2, m1 = m + 1, m2 = 2 * m, ld = m + 2;
+  double* zr = reinterpret_cast<double*>(L.z);
+  const int tid = threadIdx.x;
+  // c = irfft(log x): real even cepstrum
+  for (int k = tid; k <= f2; k += NT) L.z[k] = make_double2(log(L.xp[k]), 0.0);
+  __syncthreads();
+  irfft_lds(L.z, flng, logflng, L.tw, flng);
+  if (tid == 0) {
+    zr[0] /= 2;
+    zr[f2] /= 2;
+  }
+  __syncthreads();
+  // mc = freqt(c, f2 -> m, alpha): 4 input groups x (m+1) outputs
+  {
+    const int grp = tid >> 6, j = tid & 63;
+    const int per = (f2 + 1 + 3) / 4;
+    for (int jj = j; jj < m1; jj += 64) {
+      const int i0 = grp * per, i1 = min(f2 + 1, i0 + per);
+      double s = 0.0;
+      for (int i = i0; i < i1; ++i) s += ft.fwdT[(size_t)i * m1 + jj] * zr[i];
+      L.part[grp * m1 + jj] = s;
+    }
+    __syncthreads();
+    for (int jj = tid; jj < m1; jj += NT)
+      L.mc[jj] = (L.part[jj] + L.part[m1 + jj]) + (L.part[2 * m1 + jj] + L.part[3 * m1 + jj]);
+    if (tid == 0) L.misc[0] = zr[0];  // s = c[0]
+    __syncthreads();
+  }
+  int it;
+  for (it = 1; it <= itr2; ++it) {
+    // c' = freqt(mc, m -> f2, -alpha), zero padded to flng
+    for (int i = tid; i < flng + 2; i += NT) {
+      double s = 0.0;
+      if (i <= f2)
+        for (int j = 0; j < m1; ++j) s += ft.invT[(size_t)j * (f2 + 1) + i] * L.mc[j];
+      zr[i] = s;
+    }
+    __syncthreads();
+    rfft_lds(L.z, flng, logflng, L.tw, flng);
+    for (int k = tid; k <= f2; k += NT) L.z[k] = make_double2(L.xp[k] / exp(2.0 * L.z[k].x), 0.0);
+    __syncthreads();
+    irfft_lds(L.z, flng, logflng, L.tw, flng);
+    // cr = frqtr(r, f2 -> 2m, alpha): 2 input halves x (2m+1) outputs
+    {
+      const int grp = tid >> 7, j = tid & 127;
+      const int per = (f2 + 1 + 1) / 2;
+      for (int jj = j; jj <= m2; jj += 128) {
+        const int i0 = grp * per, i1 = min(f2 + 1, i0 + per);
+        double s = 0.0;
+        for (int i = i0; i < i1; ++i) s += ft.frqT[(size_t)i * (m2 + 1) + jj] * zr[i];
+        L.part[grp * (m2 + 1) + jj] = s;
+      }
+      __syncthreads();
+      for (int jj = tid; jj <= m2; jj += NT) L.cr[jj] = L.part[jj] + L.part[(m2 + 1) + jj];
+      __syncthreads();
+    }
+    const double t = L.cr[0];
+    if (it >= itr1) {
+      const double s = L.misc[0];
+      if (fabs((t - s) / t) < dd) break;  // uniform: every thread reads the same LDS values
+      __syncthreads();
+      if (tid == 0) L.misc[0] = t;
+    }
+    // Toeplitz + Hankel normal equations, augmented with b = cr[0..m] - (-alpha)^i
+    for (int idx = tid; idx < m1 * (m1 + 1); idx += NT) {
+      const int i = idx / (m1 + 1), k = idx - i * (m1 + 1);
+      double v;
+      if (k == m1) {
+        v = L.cr[i] - pow(-alpha, (double)i);
+      } else {
+        const int df = i > k ? i - k : k - i;
+        double tv = L.cr[df];
+        if (df == 0 || (df % 2 == 0)) tv += L.cr[0];   // t[0] = 2 cr[0]; even lags get + cr[0]
+        double hv = L.cr[i + k];
+        if (((i + k) & 1) == 0) hv -= L.cr[0];
+        v = tv + hv;
+      }
+      L.A[i * ld + k] = v;
+    }
+    __syncthreads();
+    // Gaussian elimination (system is symmetric positive definite: no pivoting)
+    for (int c = 0; c < m1; ++c) {
+      const double piv = L.A[c * ld + c];
+      for (int r = c + 1 + tid; r < m1; r += NT) L.fcol[r] = L.A[r * ld + c] / piv;
+      __syncthreads();
+      const int w = m1 - c;  // columns c+1 .. m1 (rhs)
+      for (int idx = tid; idx < (m1 - 1 - c) * w; idx += NT) {
+        const int r = c + 1 + idx / w, k = c + 1 + idx % w;
+        L.A[r * ld + k] -= L.fcol[r] * L.A[c * ld + k];
+      }
+      __syncthreads();
+    }
+    // back substitution by one wave (m1 <= 128): lane j owns x[j]
+    if (tid < 64) {
+      for (int r = m1 - 1; r >= 0; --r) {
+        double s = 0.0;
+        for (int k = r + 1 + tid; k < m1; k += 64) s += L.A[r * ld + k] * L.fcol[k];
+        s = wave_sum(s);
+        if (tid == 0) L.fcol[r] = (L.A[r * ld + m1] - s) / L.A[r * ld + r];
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < m1; j += NT) L.mc[j] += L.fcol[j];
+    __syncthreads();
+  }
+  return it > itr2 ? itr2 : it;
+}
+
+struct FrameArgs {
+  const double* x;          // concatenated waveforms
+  const int64_t* x_off;     // [U+1] sample offsets (device)
+  const double* f0;         // [Ttot]
+  const int64_t* f_off;     // [U+1] frame offsets (device)
+  int n_utts;
+  int fs;
+  double frame_period;      // ms
+  int fft, logfft;
+  double q1;
+  double* sp;               // [Ttot, K] power envelope or nullptr
+  // mcep (optional)
+  int do_mcep;
+  FreqtTables ft;
+  int m;
+  double alpha, eps;
+  int itr1, itr2;
+  double dd;
+  float* mc_f32;            // [Ttot, ld_mc] or nullptr
+  double* mc_f64;           // [Ttot, m+1] or nullptr
+  int64_t ld_mc;
+  int* iters;               // [Ttot] or nullptr
+  const double2* g_tw;
+  int bmax;                 // bound on the smoothing boundary (LDS carve)
+};
+
+__device__ inline void carve_ct(char*& p, int fft, int bmax, CtLds& L) {
+  L.tw = reinterpret_cast<double2*>(p); p += (size_t)(fft / 2) * sizeof(double2);
+  L.z = reinterpret_cast<double2*>(p); p += (size_t)(fft / 2 + 1) * sizeof(double2);
+  L.P = reinterpret_cast<double*>(p); p += (size_t)(fft / 2 + 2) * sizeof(double);
+  L.mir = reinterpret_cast<double*>(p); p += (size_t)(fft + 2 * bmax + 2) * sizeof(double);
+  L.red = reinterpret_cast<double*>(p); p += (size_t)(NT + 8) * sizeof(double);
+}
+static size_t ct_lds_bytes(int fft, int bmax) {
+  return (size_t)(fft / 2) * 16 + (size_t)(fft / 2 + 1) * 16 + (size_t)(fft / 2 + 2) * 8 +
+         (size_t)(fft + 2 * bmax + 2) * 8 + (size_t)(NT + 8) * 8;
+}
+__device__ inline void carve_mc(char*& p, int m, McLds& L) {
+  const int m1 = m + 1;
+  L.mc = reinterpret_cast<double*>(p); p += (size_t)(m1 + 1) * 8;
+  L.cr = reinterpret_cast<double*>(p); p += (size_t)(2 * m + 2) * 8;
+  L.part = reinterpret_cast<double*>(p); p += (size_t)(4 * (2 * m + 2)) * 8;
+  L.A = reinterpret_cast<double*>(p); p += (size_t)m1 * (m + 2) * 8;
+  L.fcol = reinterpret_cast<double*>(p); p += (size_t)(m1 + 1) * 8;
+  L.misc = reinterpret_cast<double*>(p); p += 8 * 8;
+}
+static size_t mc_lds_bytes(int m) {
+  const int m1 = m + 1;
+  return (size_t)(m1 + 1) * 8 + (size_t)(2 * m + 2) * 8 + (size_t)(4 * (2 * m + 2)) * 8 +
+         (size_t)m1 * (m + 2) * 8 + (size_t)(m1 + 1) * 8 + 64;
+}
+
+// CheapTrick (+ optional fused mcep) -- one workgroup per frame.
+__global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* p = smem;
+  CtLds L;
+  carve_ct(p, a.fft, a.bmax, L);
+  McLds M;
+  if (a.do_mcep) carve_mc(p, a.m, M);
+  const int64_t g = blockIdx.x;
+  const int u = find_utt(a.f_off, a.n_utts, g);
+  const int64_t t = g - a.f_off[u];
+  const double* x = a.x + a.x_off[u];
+  const int64_t xl = a.x_off[u + 1] - a.x_off[u];
+  load_twiddles(L.tw, a.g_tw, a.fft);
+  __syncthreads();
+  const double floor_f0 = 3.0 * a.fs / (a.fft - 3.0);
+  double f0 = a.f0[g];
+  if (!(f0 > floor_f0)) f0 = 500.0;  // WORLD kDefaultF0
+  const double pos = (double)t * a.frame_period / 1000.0;
+  cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L);
+  const int K = a.fft / 2 + 1;
+  if (a.sp)
+    for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
+  if (a.do_mcep) {
+    // amp = sqrt(pow) (WorldFeatLabelGen.py:795), periodogram = amp^2 + eps (SPTK mcep itype 3)
+    for (int k = threadIdx.x; k < K; k += NT) {
+      const double amp = sqrt(L.P[k]);
+      L.P[k] = amp * amp + a.eps;
+    }
+    __syncthreads();
+    M.tw = L.tw;
+    M.z = L.z;
+    M.xp = L.P;
+    const int it = mcep_frame(M, a.ft, a.fft, a.logfft, a.m, a.alpha, a.itr1, a.itr2, a.dd);
+    for (int j = threadIdx.x; j <= a.m; j += NT) {
+      if (a.mc_f32) a.mc_f32[g * a.ld_mc + j] = (float)M.mc[j];
+      if (a.mc_f64) a.mc_f64[g * (a.m + 1) + j] = M.mc[j];
+    }
+    if (a.iters && threadIdx.x == 0) a.iters[g] = it;
+  }
+}
+
+// mcep from a given amplitude spectrum [T, K] (AudioProcessing.extract_mcep)
+struct McepArgs {
+  const double* amp;
+  int64_t T;
+  int flng, logflng;
+  FreqtTables ft;
+  int m;
+  double alpha, eps;
+  int itr1, itr2;
+  double dd;
+  float* mc_f32;
+  double* mc_f64;
+  int64_t ld_mc;
+  int* iters;
+  const double2* g_tw;
+};
+
+__global__ __launch_bounds__(NT) void mcep_kernel(McepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* p = smem;
+  McLds M;
+  M.tw = reinterpret_cast<double2*>(p); p += (size_t)(a.flng / 2) * 16;
+  M.z = reinterpret_cast<double2*>(p); p += (size_t)(a.flng / 2 + 1) * 16;
+  M.xp = reinterpret_cast<double*>(p); p += (size_t)(a.flng / 2 + 2) * 8;
+  carve_mc(p, a.m, M);
+  const int64_t g = blockIdx.x;
+  const int K = a.flng / 2 + 1;
+  load_twiddles(M.tw, a.g_tw, a.flng);
+  for (int k = threadIdx.x; k < K; k += NT) {
+    const double v = a.amp[g * K + k];
+    M.xp[k] = v * v + a.eps;
+  }
+  __syncthreads();
+  const int it = mcep_frame(M, a.ft, a.flng, a.logflng, a.m, a.alpha, a.itr1, a.itr2, a.dd);
+  for (int j = threadIdx.x; j <= a.m; j += NT) {
+    if (a.mc_f32) a.mc_f32[g * a.ld_mc + j] = (float)M.mc[j];
+    if (a.mc_f64) a.mc_f64[g * (a.m + 1) + j] = M.mc[j];
+  }
+  if (a.iters && threadIdx.x == 0) a.iters[g] = it;
+}
+
+// mgc2sp(gamma = 0): c = freqt(mc, -alpha) to order fftlen/2, FFT, real part; optional exp.
+struct Mgc2spArgs {
+  const double* mc;   // [T, m+1]
+  int64_t T;
+  int m, fftlen, logfft;
+  const double* invT;
+  float* out_f32;     // exp(float(real))  (AudioProcessing.mcep_to_amp_sp :252-256)
+  double* out_f64;    // raw log amplitude
+  const double2* g_tw;
+};
+
+__global__ __launch_bounds__(NT) void mgc2sp_kernel(Mgc2spArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2* tw = reinterpret_cast<double2*>(smem);
+  double2* z = tw + a.fftlen / 2;
+  double* mc = reinterpret_cast<double*>(z + a.fftlen / 2 + 1);
+  double* zr = reinterpret_cast<double*>(z);
+  const int64_t g = blockIdx.x;
+  const int f2 = a.fftlen / 2, m1 = a.m + 1;
+  load_twiddles(tw, a.g_tw, a.fftlen);
+  for (int j = threadIdx.x; j < m1; j += NT) mc[j] = a.mc[g * m1 + j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.fftlen + 2; i += NT) {
+    double s = 0.0;
+    if (i <= f2)
+      for (int j = 0; j < m1; ++j) s += a.invT[(size_t)j * (f2 + 1) + i] * mc[j];
+    zr[i] = s;
+  }
+  __syncthreads();
+  rfft_lds(z, a.fftlen, a.logfft, tw, a.fftlen);
+  for (int k = threadIdx.x; k <= f2; k += NT) {
+    const double re = z[k].x;
+    if (a.out_f64) a.out_f64[g * (f2 + 1) + k] = re;
+    if (a.out_f32) a.out_f32[g * (f2 + 1) + k] = expf((float)re);
+  }
+}
+
+// ---- aperiodicity coding -----------------------------------------------------------------------
+// WORLD interp1 (with histc index semantics) on a short monotone knot vector, one query.
+__device__ __forceinline__ double interp1_small(const double* xk, const double* yk, int n, double xi) {
+  // histc: index k (1-based) with xk[k-1] <= xi < xk[k], clamped to [1, n-1]
+  int k = 1;
+  while (k < n - 1 && xi >= xk[k]) ++k;
+  const double h = xk[k] - xk[k - 1];
+  const double s = (xi - xk[k - 1]) / h;
+  return yk[k - 1] + s * (yk[k] - yk[k - 1]);
+}
+
+__global__ void code_aperiodicity_kernel(const double* __restrict__ ap, int64_t T, int fft_size, int fs,
+                                         int nap, double* __restrict__ bap_f64, float* __restrict__ bap_f32) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= T * nap) return;
+  const int64_t t = i / nap;
+  const int b = (int)(i - t * nap);
+  const int K = fft_size / 2 + 1;
+  const double cf = 3000.0 * (b + 1);
+  // frequency axis fa[k] = k*fs/fft_size; bracket cf (histc semantics, clamped)
+  int k = (int)(cf * fft_size / fs);
+  while (k + 1 < K && (double)(k + 1) * fs / fft_size <= cf) ++k;
+  while (k > 0 && (double)k * fs / fft_size > cf) --k;
+  if (k > K - 2) k = K - 2;
+  const double x0 = (double)k * fs / fft_size, x1 = (double)(k + 1) * fs / fft_size;
+  const double y0 = 20.0 * log10(ap[t * K + k]), y1 = 20.0 * log10(ap[t * K + k + 1]);
+  const double s = (cf - x0) / (x1 - x0);
+  const double v = y0 + s * (y1 - y0);
+  if (bap_f64) bap_f64[i] = v;
+  if (bap_f32) bap_f32[i] = (float)v;
+}
+
+__global__ void decode_aperiodicity_kernel(const double* __restrict__ bap, int64_t T, int fs, int fft_size,
+                                           int nap, double* __restrict__ ap) {
+  const int K = fft_size / 2 + 1;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= T * K) return;
+  const int64_t t = i / K;
+  const int k = (int)(i - t * K);
+  double cfa[8], cap[8];
+  double mean = 0.0;
+  for (int b = 0; b < nap; ++b) {
+    cfa[b] = b * 3000.0;
+    cap[b + 1] = bap[t * nap + b];
+    mean += cap[b + 1];
+  }
+  mean /= nap;
+  cfa[nap] = nap * 3000.0;
+  cfa[nap + 1] = fs / 2.0;
+  cap[0] = -60.0;
+  cap[nap + 1] = -kEps;
+  double v = 1.0 - kEps;
+  if (!(mean > -0.5)) {  // WORLD codec.cpp CheckVUV: mean band aperiodicity > -0.5 dB => unvoiced
+    const double f = (double)fs / fft_size * k;
+    v = pow(10.0, interp1_small(cfa, cap, nap + 2, f) / 20.0);
+  }
+  ap[i] = v;
+}
+
+static int smoothing_bmax(int fs, int fft, double max_width) { return (int)(max_width * fft / fs) + 2; }
+
+}  // namespace itts
+
+using namespace itts;
+
+static int ilog2_host(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, const double* d_f0,
+                                    const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
+                                    int fft_size, double q1, double* d_sp, int order, double alpha,
+                                    double eps, int miniter, int maxiter, double threshold,
+                                    float* d_mc_f32, int64_t ld_mc, double* d_mc_f64, int* d_iters,
+                                    void* stream) {
+  ITTS_REQUIRE(d_x && h_x_off && d_f0 && h_f_off, "null pointer");
+  ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
+  ITTS_REQUIRE(is_pow2(fft_size) && fft_size >= 512 && fft_size <= 8192, "fft_size must be 2^k in [512, 8192]");
+  const bool do_mcep = (d_mc_f32 != nullptr) || (d_mc_f64 != nullptr);
+  ITTS_REQUIRE(d_sp || do_mcep, "nothing to compute");
+  if (do_mcep) {
+    ITTS_REQUIRE(order >= 1 && order < fft_size / 2 && order <= 127, "bad mcep order");
+    ITTS_REQUIRE(!d_mc_f32 || ld_mc >= order + 1, "ld_mc too small");
+  }
+  if (n_utts == 0) return ITTS_OK;
+  const int64_t t_total = h_f_off[n_utts];
+  if (t_total == 0) return ITTS_OK;
+  for (int u = 0; u < n_utts; ++u) {
+    const int64_t n = h_x_off[u + 1] - h_x_off[u];
+    ITTS_REQUIRE(n > 0, "empty utterance");
+    ITTS_REQUIRE(h_f_off[u + 1] - h_f_off[u] == itts_world_num_frames(n, fs, frame_period_ms),
+                 "frame offsets do not match int(1000*n/fs/frame_period)+1");
+  }
+  hipStream_t s = as_stream(stream);
+  DeviceContext* ctx = get_context();
+  if (!ctx) return ITTS_E_HIP;
+  FrameArgs a{};
+  if (do_mcep) {
+    const FreqtTables* ft = get_freqt(ctx, order, fft_size / 2, alpha, true);
+    if (!ft) return ITTS_E_HIP;
+    a.ft = *ft;
+  }
+  int64_t *d_xo = nullptr, *d_fo = nullptr;
+  int rc = upload_i64(h_x_off, n_utts + 1, &d_xo, s);
+  if (rc) return rc;
+  rc = upload_i64(h_f_off, n_utts + 1, &d_fo, s);
+  if (rc) return rc;
+  a.x = d_x; a.x_off = d_xo; a.f0 = d_f0; a.f_off = d_fo; a.n_utts = n_utts; a.fs = fs;
+  a.frame_period = frame_period_ms; a.fft = fft_size; a.logfft = ilog2_host(fft_size); a.q1 = q1;
+  a.sp = d_sp; a.do_mcep = do_mcep ? 1 : 0; a.m = order; a.alpha = alpha; a.eps = eps;
+  a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64;
+  a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
+  a.bmax = smoothing_bmax(fs, fft_size, 1000.0);
+  size_t lds = ct_lds_bytes(fft_size, a.bmax) + (do_mcep ? mc_lds_bytes(order) : 0);
+  ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(cheaptrick_kernel, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  return ITTS_OK;
+}
+
+extern "C" int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, double alpha, double eps,
+                         int miniter, int maxiter, double threshold, float* d_mc_f32, int64_t ld_mc,
+                         double* d_mc_f64, int* d_iters, void* stream) {
+  ITTS_REQUIRE(d_amp_sp && (d_mc_f32 || d_mc_f64), "null pointer");
+  const int flng = (K - 1) * 2;
+  ITTS_REQUIRE(T >= 0 && is_pow2(flng) && flng >= 64 && flng <= 8192, "K must be 2^k/2+1");
+  ITTS_REQUIRE(order >= 1 && order < flng / 2 && order <= 127, "bad mcep order");
+  ITTS_REQUIRE(!d_mc_f32 || ld_mc >= order + 1, "ld_mc too small");
+  if (T == 0) return ITTS_OK;
+  DeviceContext* ctx = get_context();
+  if (!ctx) return ITTS_E_HIP;
+  const FreqtTables* ft = get_freqt(ctx, order, flng / 2, alpha, true);
+  if (!ft) return ITTS_E_HIP;
+  McepArgs a{};
+  a.amp = d_amp_sp; a.T = T; a.flng = flng; a.logflng = ilog2_host(flng); a.ft = *ft; a.m = order;
+  a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold;
+  a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64; a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
+  size_t lds = (size_t)(flng / 2) * 16 + (size_t)(flng / 2 + 1) * 16 + (size_t)(flng / 2 + 2) * 8 +
+               mc_lds_bytes(order);
+  ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcep_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mcep_kernel, dim3((unsigned)T), dim3(NT), lds, as_stream(stream), a);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alpha, int fftlen,
+                           float* d_amp_f32, double* d_logamp_f64, void* stream) {
+  ITTS_REQUIRE(d_mc && (d_amp_f32 || d_logamp_f64), "null pointer");
+  ITTS_REQUIRE(T >= 0 && is_pow2(fftlen) && fftlen >= 64 && fftlen <= 8192, "bad fftlen");
+  ITTS_REQUIRE(order >= 0 && order <= fftlen / 2 && order <= 1023, "bad order");
+  if (T == 0) return ITTS_OK;
+  DeviceContext* ctx = get_context();
+  if (!ctx) return ITTS_E_HIP;
+  const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
+  if (!ft) return ITTS_E_HIP;
+  Mgc2spArgs a{d_mc, T, order, fftlen, ilog2_host(fftlen), ft->invT, d_amp_f32, d_logamp_f64, ctx->twiddles};
+  size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16 + (size_t)(order + 2) * 8;
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mgc2sp_kernel, dim3((unsigned)T), dim3(NT), lds, as_stream(stream), a);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_code_aperiodicity(const double* d_ap, int64_t T, int fft_size, int fs,
+                                      double* d_bap_f64, float* d_bap_f32, void* stream) {
+  ITTS_REQUIRE(d_ap && (d_bap_f64 || d_bap_f32), "null pointer");
+  const int nap = itts_num_aperiodicities(fs);
+  ITTS_REQUIRE(T >= 0 && nap >= 1 && nap <= 5 && is_pow2(fft_size), "bad sizes");
+  if (T == 0) return ITTS_OK;
+  const int64_t n = T * nap;
+  hipLaunchKernelGGL(code_aperiodicity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), d_ap, T, fft_size, fs, nap, d_bap_f64, d_bap_f32);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_decode_aperiodicity(const double* d_bap, int64_t T, int fs, int fft_size,
+                                        double* d_ap, void* stream) {
+  ITTS_REQUIRE(d_bap && d_ap, "null pointer");
+  const int nap = itts_num_aperiodicities(fs);
+  ITTS_REQUIRE(T >= 0 && nap >= 1 && nap <= 5 && is_pow2(fft_size), "bad sizes");
+  if (T == 0) return ITTS_OK;
+  const int64_t n = T * (fft_size / 2 + 1);
+  hipLaunchKernelGGL(decode_aperiodicity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), d_bap, T, fs, fft_size, nap, d_ap);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}

@@ -43,6 +43,14 @@ _SIGNATURES = {
     "itts_masked_mse_workspace_bytes": (c_int64, [c_int64, c_int]),
     "itts_masked_mse": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_double, c_float,
                                 _P, _P, c_int64, _P, _P]),
+    "itts_cheaptrick_mcep": (c_int, [_P, POINTER(c_int64), _P, POINTER(c_int64), c_int, c_int,
+                                     c_double, c_int, c_double, _P, c_int, c_double, c_double,
+                                     c_int, c_int, c_double, _P, c_int64, _P, _P, _P]),
+    "itts_mcep": (c_int, [_P, c_int64, c_int, c_int, c_double, c_double, c_int, c_int, c_double,
+                          _P, c_int64, _P, _P, _P]),
+    "itts_mgc2sp": (c_int, [_P, c_int64, c_int, c_double, c_int, _P, _P, _P]),
+    "itts_code_aperiodicity": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P]),
+    "itts_decode_aperiodicity": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_float, _P]),
 }

@@ -176,3 +176,96 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
     _lib.check(L.itts_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                 param.numel(), lr, betas[0], betas[1], eps, weight_decay,
                                 int(step), grad_scale, _stream()), "itts_adam_step")
+
+
+# ------------------------------------------------------------------------- WORLD frame kernels
+def _c_int_ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def cheaptrick_mcep(x, x_off, f0, f_off, fs, frame_period=5.0, fft_size=None, q1=-0.15,
+                    want_sp=True, order=None, alpha=None, eps=1e-8, miniter=2, maxiter=30,
+                    threshold=1e-3, mc_dtype=torch.float32, want_iters=False):
+    """CheapTrick (+ fused SPTK mcep when `order` is given) for utterances stored back to back.
+    x f64 [Ntot], f0 f64 [Ttot]; x_off / f_off python lists (U+1). Returns (sp or None,
+    mcep or None, iters or None)."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    _need(f0, torch.float64, "f0")
+    fft_size = fft_size or L.itts_cheaptrick_fft_size(fs, 71.0)
+    T = int(f_off[-1])
+    K = fft_size // 2 + 1
+    sp = torch.empty((T, K), dtype=torch.float64, device=x.device) if want_sp else None
+    mc32 = mc64 = iters = None
+    if order is not None:
+        if mc_dtype == torch.float32:
+            mc32 = torch.empty((T, order + 1), dtype=torch.float32, device=x.device)
+        else:
+            mc64 = torch.empty((T, order + 1), dtype=torch.float64, device=x.device)
+        if want_iters:
+            iters = torch.empty((T,), dtype=torch.int32, device=x.device)
+    _lib.check(L.itts_cheaptrick_mcep(_ptr(x), _lib.offsets_array(x_off), _ptr(f0),
+                                      _lib.offsets_array(f_off), len(x_off) - 1, fs,
+                                      float(frame_period), fft_size, q1, _ptr(sp),
+                                      order if order is not None else 0,
+                                      float(alpha) if alpha is not None else 0.0, eps, miniter,
+                                      maxiter, threshold, _ptr(mc32), (order or 0) + 1, _ptr(mc64),
+                                      _ptr(iters), _stream()), "itts_cheaptrick_mcep")
+    return sp, (mc32 if mc32 is not None else mc64), iters
+
+
+def mcep(amp_sp, order, alpha, eps=1e-8, miniter=2, maxiter=30, threshold=1e-3,
+         dtype=torch.float32, want_iters=False):
+    """pysptk.mcep(amp_sp, order, alpha, eps, etype=1, itype=3) on [T, K] f64 (GPU)."""
+    L = _lib.load()
+    _need(amp_sp, torch.float64, "amp_sp")
+    amp_sp = amp_sp.contiguous()
+    T, K = amp_sp.shape
+    out = torch.empty((T, order + 1), dtype=dtype, device=amp_sp.device)
+    iters = torch.empty((T,), dtype=torch.int32, device=amp_sp.device) if want_iters else None
+    f32 = out if dtype == torch.float32 else None
+    f64 = out if dtype == torch.float64 else None
+    _lib.check(L.itts_mcep(_ptr(amp_sp), T, K, order, float(alpha), eps, miniter, maxiter,
+                           threshold, _ptr(f32), order + 1, _ptr(f64), _ptr(iters), _stream()),
+               "itts_mcep")
+    return (out, iters) if want_iters else out
+
+
+def mgc2sp(mc, alpha, fftlen, want_logamp=False):
+    """exp(float32(pysptk.mgc2sp(mc, alpha, 0, fftlen).real)) -> [T, fftlen/2+1] f32
+    (or the f64 log amplitude when want_logamp)."""
+    L = _lib.load()
+    _need(mc, torch.float64, "mc")
+    mc = mc.contiguous()
+    T, m1 = mc.shape
+    K = fftlen // 2 + 1
+    out32 = None if want_logamp else torch.empty((T, K), dtype=torch.float32, device=mc.device)
+    out64 = torch.empty((T, K), dtype=torch.float64, device=mc.device) if want_logamp else None
+    _lib.check(L.itts_mgc2sp(_ptr(mc), T, m1 - 1, float(alpha), fftlen, _ptr(out32), _ptr(out64),
+                             _stream()), "itts_mgc2sp")
+    return out64 if want_logamp else out32
+
+
+def code_aperiodicity(ap, fs, dtype=torch.float64):
+    L = _lib.load()
+    _need(ap, torch.float64, "ap")
+    ap = ap.contiguous()
+    T, K = ap.shape
+    nap = L.itts_num_aperiodicities(fs)
+    out = torch.empty((T, nap), dtype=dtype, device=ap.device)
+    _lib.check(L.itts_code_aperiodicity(_ptr(ap), T, (K - 1) * 2, fs,
+                                        _ptr(out) if dtype == torch.float64 else None,
+                                        _ptr(out) if dtype == torch.float32 else None, _stream()),
+               "itts_code_aperiodicity")
+    return out
+
+
+def decode_aperiodicity(bap, fs, fft_size):
+    L = _lib.load()
+    _need(bap, torch.float64, "bap")
+    bap = bap.contiguous()
+    T = bap.shape[0]
+    out = torch.empty((T, fft_size // 2 + 1), dtype=torch.float64, device=bap.device)
+    _lib.check(L.itts_decode_aperiodicity(_ptr(bap), T, fs, fft_size, _ptr(out), _stream()),
+               "itts_decode_aperiodicity")
+    return out

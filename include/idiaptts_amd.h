@@ -114,6 +114,41 @@ int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_avg, float*
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    int64_t step, float grad_scale, void* stream);
 
+/* ---- WORLD analysis, frame-parallel part --------------------------------------------------------
+ * Utterances are stored back to back: d_x holds the (pre-emphasised) f64 waveforms, h_x_off[U+1]
+ * their sample offsets, h_f_off[U+1] the frame offsets with
+ * frames(u) = int(1000*n_u/fs/frame_period)+1 and frame i at time i*frame_period/1000 s
+ * (pyworld.wav2world, src/data_preparation/world/WorldFeatLabelGen.py:792-793). */
+
+/* CheapTrick spectral envelope (WORLD cheaptrick.cpp; q1 = -0.15, f0 floor 71 Hz in wav2world)
+ * with SPTK mel-cepstral analysis optionally fused behind it, i.e.
+ *   sp   = pyworld.cheaptrick(x, f0, t, fs, fft_size=fft_size)            -> d_sp [Ttot, K] f64 power
+ *   mcep = pysptk.mcep(sqrt(sp), order, alpha, eps, min_det=0, etype=1, itype=3)
+ *          (AudioProcessing.extract_mcep, src/data_preparation/audio/AudioProcessing.py:142-153)
+ * d_sp may be NULL when only mcep is wanted (the envelope then never leaves the chip).
+ * d_mc_f32 [Ttot, ld_mc] and/or d_mc_f64 [Ttot, order+1]; d_iters [Ttot] Newton steps (optional). */
+int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, const double* d_f0,
+                         const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
+                         int fft_size, double q1, double* d_sp, int order, double alpha, double eps,
+                         int miniter, int maxiter, double threshold, float* d_mc_f32, int64_t ld_mc,
+                         double* d_mc_f64, int* d_iters, void* stream);
+
+/* pysptk.mcep on a given amplitude spectrum d_amp_sp [T, K] f64 (AudioProcessing.py:146-152). */
+int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, double alpha, double eps,
+              int miniter, int maxiter, double threshold, float* d_mc_f32, int64_t ld_mc,
+              double* d_mc_f64, int* d_iters, void* stream);
+
+/* pysptk.mgc2sp(mc, alpha, gamma=0, fftlen): d_logamp_f64 [T, fftlen/2+1] = real part (log
+ * amplitude); d_amp_f32 = exp(float32(real)) as AudioProcessing.mcep_to_amp_sp (:252-256). */
+int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alpha, int fftlen,
+                float* d_amp_f32, double* d_logamp_f64, void* stream);
+
+/* pyworld.code_aperiodicity (WorldFeatLabelGen.py:805) / pyworld.decode_aperiodicity (:940-941). */
+int itts_code_aperiodicity(const double* d_ap, int64_t T, int fft_size, int fs, double* d_bap_f64,
+                           float* d_bap_f32, void* stream);
+int itts_decode_aperiodicity(const double* d_bap, int64_t T, int fs, int fft_size, double* d_ap,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

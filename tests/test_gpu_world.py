@@ -1,0 +1,139 @@
+"""GPU parity of the WORLD / SPTK kernels (through the C ABI) against the C oracle, on the
+reference's fixture audio (tests/golden) and on synthetic audio. North-star bars: bit-exact
+V/UV and frame counts, <= 1e-4 RMSE on MGC / BAP / LF0 (we assert far tighter bounds)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(golden_dir, name, pre=0.97):
+    fs, w = wavfile.read(os.path.join(golden_dir, name + ".wav"))
+    raw = w.astype(np.float64) / 32768.0
+    return np.append(raw[0], raw[1:] - pre * raw[:-1]), fs
+
+
+def _synthetic(fs, seconds, seed):
+    """SURVEY.md section 8d style signal: harmonic source with F0 random walk, AR-shaped, + noise."""
+    rng = np.random.default_rng(1234 + seed)
+    n = int(fs * seconds)
+    f0 = np.clip(150 + np.cumsum(rng.normal(0, 0.02, n)) * 20, 90, 300)
+    voiced = (np.sin(2 * np.pi * np.arange(n) / fs * 1.3 + seed) > -0.3).astype(float)
+    phase = 2 * np.pi * np.cumsum(f0) / fs
+    src = sum(np.sin(k * phase) / k for k in range(1, 12)) * voiced
+    x = 0.3 * src / np.abs(src).max() + 10 ** (-40 / 20) * rng.normal(size=n)
+    return x
+
+
+@pytest.fixture(scope="module")
+def utts(golden_dir):
+    from oracle import capi
+    out = []
+    for name in ["LJ001-0008", "LJ001-0002"]:
+        x, fs = _read(golden_dir, name)
+        f0, tp = capi.dio(x, fs)
+        f0 = capi.stonemask(x, fs, tp, f0)
+        out.append((x, fs, f0, tp))
+    return out
+
+
+def _batch(utts, gpu):
+    xs = np.concatenate([u[0] for u in utts])
+    f0 = np.concatenate([u[2] for u in utts])
+    x_off = np.concatenate([[0], np.cumsum([len(u[0]) for u in utts])]).tolist()
+    f_off = np.concatenate([[0], np.cumsum([len(u[2]) for u in utts])]).tolist()
+    return torch.from_numpy(xs).to(gpu), torch.from_numpy(f0).to(gpu), x_off, f_off
+
+
+def test_cheaptrick_and_fused_mcep_match_oracle(gpu, utts, golden_dir):
+    from idiaptts_amd import ops
+    from oracle import capi
+    x, f0, x_off, f_off = _batch(utts, gpu)
+    fs = utts[0][1]
+    sp, mc, iters = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, order=19, alpha=0.58,
+                                        mc_dtype=torch.float64, want_iters=True)
+    sp = sp.cpu().numpy()
+    mc = mc.cpu().numpy()
+    iters = iters.cpu().numpy()
+    for u, (xu, _, f0u, tpu) in enumerate(utts):
+        a, b = f_off[u], f_off[u + 1]
+        sp_ref = capi.cheaptrick(xu, fs, tpu, f0u)
+        assert np.abs(sp[a:b] / sp_ref - 1).max() < 1e-8
+        mc_ref, it_ref = capi.mcep(np.sqrt(sp_ref), 19, 0.58, return_iters=True)
+        assert np.array_equal(iters[a:b], it_ref)            # same Newton trip counts
+        assert np.abs(mc[a:b] - mc_ref).max() < 1e-8
+    # and against the reference's golden cmp (float32 mcep columns): <= 1 ulp
+    cmp_ = np.fromfile(os.path.join(golden_dir, "LJ001-0008.cmp"), dtype=np.float32).reshape(-1, 67)
+    n0 = f_off[1]
+    assert np.abs(mc[:n0].astype(np.float32) - cmp_[:, :20]).max() <= 4.8e-7
+
+
+@pytest.mark.parametrize("order,alpha", [(59, 0.41), (24, 0.41), (79, 0.58)])
+def test_mcep_from_amp_and_mgc2sp_roundtrip(gpu, utts, order, alpha):
+    from idiaptts_amd import ops
+    from oracle import capi
+    xu, fs, f0u, tpu = utts[0]
+    sp_ref = capi.cheaptrick(xu, fs, tpu, f0u)
+    amp = np.sqrt(sp_ref)
+    mc, iters = ops.mcep(torch.from_numpy(amp).to(gpu), order, alpha, dtype=torch.float64,
+                         want_iters=True)
+    mc_ref, it_ref = capi.mcep(amp, order, alpha, return_iters=True)
+    assert np.array_equal(iters.cpu().numpy(), it_ref)
+    assert np.sqrt(np.mean((mc.cpu().numpy() - mc_ref) ** 2)) < 1e-8
+    mc32 = ops.mcep(torch.from_numpy(amp).to(gpu), order, alpha)
+    assert mc32.dtype == torch.float32
+    assert np.abs(mc32.cpu().numpy() - mc_ref.astype(np.float32)).max() <= 1e-6
+    # mgc2sp: log amplitude vs oracle and the reference's float32 exp form
+    la = ops.mgc2sp(mc, alpha, 1024, want_logamp=True).cpu().numpy()
+    la_ref = capi.mgc2sp_logamp(mc.cpu().numpy(), alpha, 1024)
+    assert np.abs(la - la_ref).max() < 1e-10
+    amp32 = ops.mgc2sp(mc, alpha, 1024).cpu().numpy()
+    ref32 = np.exp(la_ref.astype(np.float32))
+    assert np.abs(amp32 / ref32 - 1).max() < 1e-6
+    if order == 79:
+        # reference bound: sum (amp - reconstruction)^2 < 100 (test_WorldFeatLabelGen.py:816-824)
+        assert ((amp - amp32) ** 2).sum() < 100
+
+
+def test_code_decode_aperiodicity(gpu, utts):
+    from idiaptts_amd import ops
+    from oracle import capi
+    xu, fs, f0u, tpu = utts[0]
+    ap = capi.d4c(xu, fs, tpu, f0u)
+    bap_ref = capi.code_aperiodicity(ap, fs)
+    bap = ops.code_aperiodicity(torch.from_numpy(ap).to(gpu), fs).cpu().numpy()
+    assert np.abs(bap - bap_ref).max() < 1e-10
+    bap32 = ops.code_aperiodicity(torch.from_numpy(ap).to(gpu), fs, dtype=torch.float32)
+    assert np.array_equal(bap32.cpu().numpy(), bap_ref.astype(np.float32))
+    dec_ref = capi.decode_aperiodicity(bap_ref, fs, 1024)
+    dec = ops.decode_aperiodicity(torch.from_numpy(bap_ref).to(gpu), fs, 1024).cpu().numpy()
+    assert np.abs(dec - dec_ref).max() < 1e-12
+    # 48 kHz: 5 bands, fft 2048
+    rng = np.random.default_rng(0)
+    bap5 = -rng.uniform(0.0, 30.0, size=(50, 5))
+    bap5[::7] = -1e-12
+    d5 = ops.decode_aperiodicity(torch.from_numpy(bap5).to(gpu), 48000, 2048).cpu().numpy()
+    assert np.abs(d5 - capi.decode_aperiodicity(bap5, 48000, 2048)).max() < 1e-12
+    c5 = ops.code_aperiodicity(torch.from_numpy(d5).to(gpu), 48000).cpu().numpy()
+    assert np.abs(c5 - capi.code_aperiodicity(d5, 48000)).max() < 1e-9
+
+
+def test_cheaptrick_48k_synthetic(gpu):
+    from idiaptts_amd import ops
+    from oracle import capi
+    fs = 48000
+    x = _synthetic(fs, 0.8, 1)
+    f0, tp = capi.dio(x, fs)
+    f0 = capi.stonemask(x, fs, tp, f0)
+    sp, mc, _ = ops.cheaptrick_mcep(torch.from_numpy(x).to(gpu), [0, len(x)],
+                                    torch.from_numpy(f0).to(gpu), [0, len(f0)], fs, order=59,
+                                    alpha=0.554, mc_dtype=torch.float64)
+    sp_ref = capi.cheaptrick(x, fs, tp, f0)
+    assert sp.shape[1] == 1025
+    assert np.abs(sp.cpu().numpy() / sp_ref - 1).max() < 1e-8
+    mc_ref = capi.mcep(np.sqrt(sp_ref), 59, 0.554)
+    assert np.sqrt(np.mean((mc.cpu().numpy() - mc_ref) ** 2)) < 1e-7
