@@ -1,0 +1,552 @@
+// Frame-parallel WORLD kernels for F0 refinement and aperiodicity: StoneMask and D4C(+LoveTrain).
+//
+// Replaces the StoneMask and D4C stages of pyworld.wav2world
+// (src/data_preparation/world/WorldFeatLabelGen.py:792-793; also LF0LabelGen.py:263-264 for
+// stonemask) -- WORLD stonemask.cpp (two-stage refinement) and d4c.cpp (LoveTrain V/UV,
+// threshold 0.85).  One 256-thread workgroup per frame.
+//
+// StoneMask only needs the spectra of the two windowed segments at <= 2 + 6 harmonic bins, so
+// the FFTs are replaced by direct DFT sums at those bins (twiddles from the same master table)
+// -- no LDS FFT buffer, any f0-dependent FFT size.  D4C keeps every spectrum in LDS.
+#include <algorithm>
+#include <cmath>
+
+#include "context.h"
+#include "world_dev.h"
+
+namespace itts {
+using namespace wd;
+
+__device__ __forceinline__ int find_utt2(const int64_t* __restrict__ off, int n_utts, int64_t g) {
+  int lo = 0, hi = n_utts;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// exp(-2 pi i k / n) for 0 <= k < n from the master table exp(+2 pi i j / TW_N), j < TW_N/2.
+// For n > TW_N the angle is computed directly.
+__device__ __forceinline__ double2 twiddle_neg(const double2* __restrict__ g_tw, int k, int n) {
+  if (n <= TW_N) {
+    int j = k * (TW_N / n);
+    double sgn = 1.0;
+    if (j >= TW_N / 2) {
+      j -= TW_N / 2;
+      sgn = -1.0;
+    }
+    const double2 w = g_tw[j];
+    return make_double2(sgn * w.x, -sgn * w.y);
+  }
+  double s, c;
+  sincospi(2.0 * (double)k / (double)n, &s, &c);
+  return make_double2(c, -s);
+}
+
+struct SmArgs {
+  const double* x;
+  const int64_t* x_off;
+  const double* f0_in;
+  const int64_t* f_off;
+  int n_utts;
+  int fs;
+  double frame_period;
+  double* f0_out;
+  const double2* g_tw;
+  int nmax;  // LDS capacity (samples) per windowed segment
+};
+
+__global__ __launch_bounds__(NT) void stonemask_kernel(SmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sm = reinterpret_cast<double*>(smem);  // x * main window
+  double* sd = sm + a.nmax;                       // x * diff window
+  double* mw = sd + a.nmax;                       // main window
+  double* red = mw + a.nmax;                      // 4 * 32 doubles
+  const int64_t g = blockIdx.x;
+  const int u = find_utt2(a.f_off, a.n_utts, g);
+  const double* x = a.x + a.x_off[u];
+  const int64_t xl = a.x_off[u + 1] - a.x_off[u];
+  const int fs = a.fs;
+  const double f0 = a.f0_in[g];
+  const double pos = (double)(g - a.f_off[u]) * a.frame_period / 1000.0;
+  if (f0 <= 40.0 || f0 > fs / 12.0) {
+    if (threadIdx.x == 0) a.f0_out[g] = 0.0;
+    return;
+  }
+  const int half = (int)(1.5 * fs / f0 + 1.0);
+  const double wlt = (2.0 * half + 1.0) / fs;
+  const int n = 2 * half + 1;
+  const int fft = 1 << (2 + (int)(log(half * 2.0 + 1.0) / log(2.0)));
+  const int64_t i0 = mround((pos - (double)half / fs) * fs + 0.001);
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const double tmp = ((double)(i0 + i) - 1.0) / fs - pos;
+    mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * tmp / wlt) + 0.08 * cos(4.0 * kPi * tmp / wlt);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += NT) {
+    double dw;
+    if (i == 0) dw = -mw[1] / 2.0;
+    else if (i == n - 1) dw = mw[n - 2] / 2.0;
+    else dw = -(mw[i + 1] - mw[i - 1]) / 2.0;
+    int64_t idx = i0 + i - 1;
+    idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+    const double xv = x[idx];
+    sm[i] = xv * mw[i];
+    sd[i] = xv * dw;
+  }
+  __syncthreads();
+
+  // spectra (main M, diff D) at `nh` harmonic bins of `base`: direct DFT sums
+  auto refine = [&](double base, int nh) -> double {
+    int bins[6];
+    double acc[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int hq = 0; hq < 6; ++hq) bins[hq] = hq < nh ? mround(base * fft / fs * (hq + 1)) : 0;
+    for (int i = threadIdx.x; i < n; i += NT) {
+      const double vm = sm[i], vd = sd[i];
+#pragma unroll
+      for (int hq = 0; hq < 6; ++hq) {
+        if (hq < nh) {
+          const int k = (int)(((long long)bins[hq] * i) % fft);
+          const double2 w = twiddle_neg(a.g_tw, k, fft);
+          acc[4 * hq + 0] += vm * w.x;
+          acc[4 * hq + 1] += vm * w.y;
+          acc[4 * hq + 2] += vd * w.x;
+          acc[4 * hq + 3] += vd * w.y;
+        }
+      }
+    }
+    // block reduction of 4*nh values
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+      if (q < 4 * nh) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv * 32 + q] = v;
+      }
+    }
+    __syncthreads();
+    double num_sum = 0.0, den_sum = 0.0;
+    for (int hq = 0; hq < nh; ++hq) {
+      double v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        v[c] = (red[4 * hq + c] + red[32 + 4 * hq + c]) + (red[64 + 4 * hq + c] + red[96 + 4 * hq + c]);
+      const double Mr = v[0], Mi = v[1], Dr = v[2], Di = v[3];
+      const double numer = Mr * Di - Mi * Dr;
+      const double ps = Mr * Mr + Mi * Mi;
+      const int idx = bins[hq];
+      const double inst = ps == 0.0 ? 0.0 : (double)idx * fs / fft + numer / ps * fs / 2.0 / kPi;
+      const double amp = sqrt(ps);
+      num_sum += amp * inst;
+      den_sum += amp * (hq + 1);
+    }
+    return num_sum / (den_sum + kEps);
+  };
+
+  const double t = refine(f0, 2);
+  double mean = 0.0;
+  if (!(t <= 0.0 || t > f0 * 2)) {
+    int nh = (int)(fs / 2.0 / f0);
+    if (nh > 6) nh = 6;
+    mean = refine(t, nh);
+  }
+  if (threadIdx.x == 0) a.f0_out[g] = fabs(mean - f0) > f0 * 0.2 ? f0 : mean;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct D4cArgs {
+  const double* x;
+  const int64_t* x_off;
+  const double* f0;
+  const int64_t* f_off;
+  int n_utts;
+  int fs;
+  double frame_period;
+  int fft_size;   // output resolution (CheapTrick fft size)
+  int fftd, logfftd;
+  int fftl, logfftl;
+  double threshold;
+  int nap;
+  double* ap;       // [Ttot, K] or nullptr
+  double* bap_f64;  // [Ttot, nap] or nullptr
+  float* bap_f32;   // [Ttot, ld_bap] or nullptr
+  int64_t ld_bap;
+  const double2* g_tw;
+  int bmax;
+};
+
+struct D4cLds {
+  double2* tw;
+  double2* z;
+  double* A;   // [h+1]
+  double* B;
+  double* C;
+  double* D;
+  double* mir;
+  double* red;
+};
+
+// windowed segment written to zr[0..n) (zero padded to `pad`): x*win - win*mean. Returns n.
+// normalise: divide by sqrt(sum of squares) (D4C centroid). `ramp`: multiply sample i by (i+1).
+__device__ inline int windowed_to(const double* __restrict__ x, int64_t xl, int fs, double f0, double pos,
+                                  int blackman, double ratio, double* zr, int pad, bool normalise,
+                                  bool ramp, double* red) {
+  const int half = mround(ratio * fs / f0 / 2.0);
+  const int n = 2 * half + 1;
+  const int64_t c = mround(pos * fs + 0.001);
+  auto winv = [&](int i) {
+    const int b = i - half;
+    const double p = (2.0 * b / ratio) / fs;
+    return blackman ? 0.42 + 0.5 * cos(kPi * p * f0) + 0.08 * cos(kPi * p * f0 * 2)
+                    : 0.5 * cos(kPi * p * f0) + 0.5;
+  };
+  double swf = 0.0, sw = 0.0;
+  for (int i = threadIdx.x; i < pad; i += NT) {
+    double v = 0.0;
+    if (i < n) {
+      const double w = winv(i);
+      int64_t idx = c + i - half;
+      idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+      v = x[idx] * w;
+      swf += v;
+      sw += w;
+    }
+    zr[i] = v;
+  }
+  swf = bsum(swf, red);
+  sw = bsum(sw, red);
+  const double mean = swf / sw;
+  double pw = 0.0;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const double v = zr[i] - winv(i) * mean;
+    zr[i] = v;
+    pw += v * v;
+  }
+  if (normalise) {
+    pw = sqrt(bsum(pw, red));
+    for (int i = threadIdx.x; i < n; i += NT) {
+      double v = zr[i] / pw;
+      if (ramp) v *= (i + 1.0);
+      zr[i] = v;
+    }
+  }
+  __syncthreads();
+  return n;
+}
+
+__global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int fmax = max(a.fftd, a.fftl);
+  const int hmax = fmax / 2;
+  D4cLds L;
+  char* p = smem;
+  L.tw = reinterpret_cast<double2*>(p); p += (size_t)hmax * 16;
+  L.z = reinterpret_cast<double2*>(p); p += (size_t)(hmax + 1) * 16;
+  L.A = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  L.B = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  L.C = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  L.D = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  L.mir = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2 * a.bmax + 2) * 8;
+  L.red = reinterpret_cast<double*>(p);
+
+  const int64_t g = blockIdx.x;
+  const int u = find_utt2(a.f_off, a.n_utts, g);
+  const double* x = a.x + a.x_off[u];
+  const int64_t xl = a.x_off[u + 1] - a.x_off[u];
+  const int fs = a.fs;
+  const double f0raw = a.f0[g];
+  const double pos = (double)(g - a.f_off[u]) * a.frame_period / 1000.0;
+  const int K = a.fft_size / 2 + 1;
+  const int nap = a.nap;
+  double* zr = reinterpret_cast<double*>(L.z);
+
+  bool voiced = false;
+  double coarse[8];
+  if (f0raw != 0.0) {
+    // TW table of the largest transform; smaller ones stride through it
+    load_twiddles(L.tw, a.g_tw, fmax);
+    __syncthreads();
+    // ---- LoveTrain: energy ratio 100 Hz..4 kHz over 100 Hz..7.9 kHz
+    {
+      const int fft = a.fftl;
+      const int b0 = (int)ceil(100.0 * fft / fs), b1 = (int)ceil(4000.0 * fft / fs),
+                b2 = (int)ceil(7900.0 * fft / fs);
+      windowed_to(x, xl, fs, f0raw > 40.0 ? f0raw : 40.0, pos, 1, 3.0, zr,
+                  fft + 2, false, false, L.red);
+      rfft_lds(L.z, fft, a.logfftl, L.tw, fmax);
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = threadIdx.x; k <= b2; k += NT) {
+        if (k > b0) {
+          const double2 v = L.z[k];
+          const double ps = v.x * v.x + v.y * v.y;
+          s2 += ps;
+          if (k <= b1) s1 += ps;
+        }
+      }
+      s1 = bsum(s1, L.red);
+      s2 = bsum(s2, L.red);
+      voiced = (s1 / s2) > a.threshold;
+      __syncthreads();
+    }
+  }
+  if (voiced) {
+    const int fft = a.fftd, logfft = a.logfftd, h = fft / 2;
+    const double f0 = f0raw > 47.0 ? f0raw : 47.0;  // kFloorF0D4C
+    // twiddles in LDS are those of the largest transform (fmax); smaller ones stride through it
+    auto rfft = [&](void) { rfft_lds(L.z, fft, logfft, L.tw, fmax); };
+    // --- static centroid (two time-shifted analyses)
+    for (int side = 0; side < 2; ++side) {
+      const double cpos = side == 0 ? pos - 0.25 / f0 : pos + 0.25 / f0;
+      windowed_to(x, xl, fs, f0, cpos, 1, 4.0, zr, fft + 2, true, false, L.red);
+      rfft();
+      for (int k = threadIdx.x; k <= h; k += NT) {
+        L.B[k] = L.z[k].x;
+        L.C[k] = L.z[k].y;
+      }
+      __syncthreads();
+      windowed_to(x, xl, fs, f0, cpos, 1, 4.0, zr, fft + 2, true, true, L.red);
+      rfft();
+      for (int k = threadIdx.x; k <= h; k += NT) {
+        const double v = L.z[k].x * L.B[k] + L.C[k] * L.z[k].y;
+        L.A[k] = side == 0 ? v : L.A[k] + v;
+      }
+      __syncthreads();
+    }
+    dc_correction(L.A, f0, fs, fft);
+    // --- smoothed power spectrum
+    windowed_to(x, xl, fs, f0, pos, 0, 4.0, zr, fft + 2, false, false, L.red);
+    rfft();
+    for (int k = threadIdx.x; k <= h; k += NT) {
+      const double2 v = L.z[k];
+      L.B[k] = v.x * v.x + v.y * v.y;
+    }
+    __syncthreads();
+    dc_correction(L.B, f0, fs, fft);
+    linear_smoothing(L.B, f0, fs, fft, L.B, L.mir, L.red);
+    // --- static group delay
+    for (int k = threadIdx.x; k <= h; k += NT) L.C[k] = L.A[k] / L.B[k];
+    __syncthreads();
+    linear_smoothing(L.C, f0 / 2.0, fs, fft, L.C, L.mir, L.red);
+    linear_smoothing(L.C, f0, fs, fft, L.D, L.mir, L.red);
+    for (int k = threadIdx.x; k <= h; k += NT) L.C[k] -= L.D[k];
+    __syncthreads();
+    // --- coarse aperiodicity per 3 kHz band
+    const int wl = (int)(3000.0 * fft / fs) * 2 + 1;
+    const int boundary = mround(fft * 8.0 / wl);
+    const int halfw = wl / 2;
+    for (int b = 0; b < nap; ++b) {
+      const int center = (int)(3000.0 * (b + 1) * fft / fs);
+      for (int i = threadIdx.x; i < fft + 2; i += NT) {
+        double v = 0.0;
+        if (i <= halfw * 2) {
+          const double tt = (double)i / (wl - 1.0);
+          const double nw = 0.355768 - 0.487396 * cos(2.0 * kPi * tt) + 0.144232 * cos(4.0 * kPi * tt) -
+                            0.012604 * cos(6.0 * kPi * tt);
+          v = L.C[center - halfw + i] * nw;
+        }
+        zr[i] = v;
+      }
+      __syncthreads();
+      rfft();
+      // power spectrum: each thread keeps its (<= 9) bins; pop the boundary+1 largest of the block
+      constexpr int PER = 9;  // (4096/2+1)/256 rounded up
+      double mine[PER];
+      int cnt = 0;
+      for (int k = threadIdx.x; k <= h; k += NT) {
+        const double2 v = L.z[k];
+        mine[cnt++] = v.x * v.x + v.y * v.y;
+      }
+      // sort descending (tiny insertion sort in registers)
+#pragma unroll
+      for (int i = 1; i < PER; ++i) {
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+          if (j < cnt && mine[j] > mine[j - 1]) {
+            const double tswap = mine[j];
+            mine[j] = mine[j - 1];
+            mine[j - 1] = tswap;
+          }
+        }
+      }
+      double total = 0.0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (i < cnt) total += mine[i];
+      total = bsum(total, L.red);
+      int popped = 0;
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      double* cand = L.red;        // [4] wave maxima
+      int* candi = reinterpret_cast<int*>(L.red + 8);
+      for (int round = 0; round <= boundary; ++round) {
+        double v = -1.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+          if (i == popped && i < cnt) v = mine[i];
+        // wave arg-max
+        double best = v;
+        int who = threadIdx.x;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const double ov = __shfl_xor(best, off, 64);
+          const int ow = __shfl_xor(who, off, 64);
+          if (ov > best || (ov == best && ow < who)) {
+            best = ov;
+            who = ow;
+          }
+        }
+        __syncthreads();
+        if (lane == 0) {
+          cand[wv] = best;
+          candi[wv] = who;
+        }
+        __syncthreads();
+        double bb = cand[0];
+        int bw = candi[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (cand[q] > bb || (cand[q] == bb && candi[q] < bw)) {
+            bb = cand[q];
+            bw = candi[q];
+          }
+        if (bw == (int)threadIdx.x) ++popped;
+      }
+      __syncthreads();
+      double rest = 0.0;
+#pragma unroll
+      for (int i = PER - 1; i >= 0; --i)
+        if (i < cnt && i >= popped) rest += mine[i];
+      rest = bsum(rest, L.red);
+      const double ca = 10.0 * log10(rest / total);
+      const double cv = ca + (f0 - 100.0) / 50.0;
+      coarse[b] = cv < 0.0 ? cv : 0.0;
+      __syncthreads();
+    }
+  }
+  // ---- outputs: aperiodicity row and / or coded band aperiodicity
+  double cfa[8], cap[8];
+  for (int b = 0; b <= nap; ++b) cfa[b] = b * 3000.0;
+  cfa[nap + 1] = fs / 2.0;
+  cap[0] = -60.0;
+  for (int b = 0; b < nap; ++b) cap[b + 1] = voiced ? coarse[b] : 0.0;
+  cap[nap + 1] = -kEps;
+  auto ap_at = [&](int k) -> double {
+    if (!voiced) return 1.0 - kEps;
+    const double f = (double)k * fs / a.fft_size;
+    int kk = 1;
+    while (kk < nap + 1 && f >= cfa[kk]) ++kk;
+    const double s = (f - cfa[kk - 1]) / (cfa[kk] - cfa[kk - 1]);
+    return pow(10.0, (cap[kk - 1] + s * (cap[kk] - cap[kk - 1])) / 20.0);
+  };
+  if (a.ap)
+    for (int k = threadIdx.x; k < K; k += NT) a.ap[g * K + k] = ap_at(k);
+  if ((a.bap_f64 || a.bap_f32) && (int)threadIdx.x < nap) {
+    const int b = threadIdx.x;
+    const double cf = 3000.0 * (b + 1);
+    int k = (int)(cf * a.fft_size / fs);
+    while (k + 1 < K && (double)(k + 1) * fs / a.fft_size <= cf) ++k;
+    while (k > 0 && (double)k * fs / a.fft_size > cf) --k;
+    if (k > K - 2) k = K - 2;
+    const double x0 = (double)k * fs / a.fft_size, x1 = (double)(k + 1) * fs / a.fft_size;
+    const double y0 = 20.0 * log10(ap_at(k)), y1 = 20.0 * log10(ap_at(k + 1));
+    const double v = y0 + (cf - x0) / (x1 - x0) * (y1 - y0);
+    if (a.bap_f64) a.bap_f64[g * nap + b] = v;
+    if (a.bap_f32) a.bap_f32[g * a.ld_bap + b] = (float)v;
+  }
+}
+
+}  // namespace itts
+
+using namespace itts;
+
+static int ilog2h(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}
+
+static int check_offsets(const int64_t* h_x_off, const int64_t* h_f_off, int n_utts, int fs,
+                         double frame_period_ms) {
+  for (int u = 0; u < n_utts; ++u) {
+    const int64_t n = h_x_off[u + 1] - h_x_off[u];
+    ITTS_REQUIRE(n > 0, "empty utterance");
+    ITTS_REQUIRE(h_f_off[u + 1] - h_f_off[u] == itts_world_num_frames(n, fs, frame_period_ms),
+                 "frame offsets do not match int(1000*n/fs/frame_period)+1");
+  }
+  return ITTS_OK;
+}
+
+extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const double* d_f0_in,
+                              const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
+                              double* d_f0_out, void* stream) {
+  ITTS_REQUIRE(d_x && h_x_off && d_f0_in && h_f_off && d_f0_out, "null pointer");
+  ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
+  if (n_utts == 0 || h_f_off[n_utts] == 0) return ITTS_OK;
+  int rc = check_offsets(h_x_off, h_f_off, n_utts, fs, frame_period_ms);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  DeviceContext* ctx = get_context();
+  if (!ctx) return ITTS_E_HIP;
+  int64_t *d_xo = nullptr, *d_fo = nullptr;
+  if ((rc = upload_i64(h_x_off, n_utts + 1, &d_xo, s))) return rc;
+  if ((rc = upload_i64(h_f_off, n_utts + 1, &d_fo, s))) return rc;
+  SmArgs a{d_x, d_xo, d_f0_in, d_fo, n_utts, fs, frame_period_ms, d_f0_out, ctx->twiddles, 0};
+  a.nmax = 2 * (int)(1.5 * fs / 40.0 + 1.0) + 1 + 3;
+  const size_t lds = (size_t)a.nmax * 3 * 8 + 128 * 8;
+  ITTS_REQUIRE(lds <= 160 * 1024, "sampling rate too high for the StoneMask LDS budget");
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)h_f_off[n_utts]), dim3(NT), lds, s, a);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  return ITTS_OK;
+}
+
+extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double* d_f0,
+                        const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
+                        int fft_size, double threshold, double* d_ap, double* d_bap_f64,
+                        float* d_bap_f32, int64_t ld_bap, void* stream) {
+  ITTS_REQUIRE(d_x && h_x_off && d_f0 && h_f_off, "null pointer");
+  ITTS_REQUIRE(d_ap || d_bap_f64 || d_bap_f32, "nothing to compute");
+  ITTS_REQUIRE(n_utts >= 0 && fs >= 15800 && frame_period_ms > 0, "bad sizes (fs >= 15.8 kHz)");
+  ITTS_REQUIRE(fft_size > 0 && (fft_size & (fft_size - 1)) == 0, "fft_size must be a power of 2");
+  const int nap = itts_num_aperiodicities(fs);
+  ITTS_REQUIRE(nap >= 1 && nap <= 5, "unsupported number of aperiodicity bands");
+  ITTS_REQUIRE(!d_bap_f32 || ld_bap >= nap, "ld_bap too small");
+  if (n_utts == 0 || h_f_off[n_utts] == 0) return ITTS_OK;
+  int rc = check_offsets(h_x_off, h_f_off, n_utts, fs, frame_period_ms);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  DeviceContext* ctx = get_context();
+  if (!ctx) return ITTS_E_HIP;
+  D4cArgs a{};
+  a.fftd = 1 << (1 + (int)std::log2(4.0 * fs / 47.0 + 1));
+  a.fftl = 1 << (1 + (int)std::log2(3.0 * fs / 40.0 + 1));
+  ITTS_REQUIRE(std::max(a.fftd, a.fftl) <= 4096, "sampling rate too high for the D4C LDS budget");
+  a.logfftd = ilog2h(a.fftd);
+  a.logfftl = ilog2h(a.fftl);
+  int64_t *d_xo = nullptr, *d_fo = nullptr;
+  if ((rc = upload_i64(h_x_off, n_utts + 1, &d_xo, s))) return rc;
+  if ((rc = upload_i64(h_f_off, n_utts + 1, &d_fo, s))) return rc;
+  a.x = d_x; a.x_off = d_xo; a.f0 = d_f0; a.f_off = d_fo; a.n_utts = n_utts; a.fs = fs;
+  a.frame_period = frame_period_ms; a.fft_size = fft_size; a.threshold = threshold; a.nap = nap;
+  a.ap = d_ap; a.bap_f64 = d_bap_f64; a.bap_f32 = d_bap_f32; a.ld_bap = ld_bap;
+  a.g_tw = ctx->twiddles;
+  const int fmax = std::max(a.fftd, a.fftl), hmax = fmax / 2;
+  a.bmax = (int)(1200.0 * fmax / fs) + 2;
+  const size_t lds = (size_t)hmax * 16 + (size_t)(hmax + 1) * 16 + 4 * (size_t)(hmax + 2) * 8 +
+                     (size_t)(hmax + 2 * a.bmax + 2) * 8 + (size_t)(NT + 8) * 8;
+  ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)d4c_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(d4c_kernel, dim3((unsigned)h_f_off[n_utts]), dim3(NT), lds, s, a);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  return ITTS_OK;
+}

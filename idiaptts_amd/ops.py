@@ -269,3 +269,47 @@ def decode_aperiodicity(bap, fs, fft_size):
     _lib.check(L.itts_decode_aperiodicity(_ptr(bap), T, fs, fft_size, _ptr(out), _stream()),
                "itts_decode_aperiodicity")
     return out
+
+
+def dio(x, x_off, f_off, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
+        channels_in_octave=2.0, allowed_range=0.1):
+    """pyworld.dio for utterances stored back to back -> f0 [Ttot] f64."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    f0 = torch.empty((int(f_off[-1]),), dtype=torch.float64, device=x.device)
+    _lib.check(L.itts_dio(_ptr(x), _lib.offsets_array(x_off), _lib.offsets_array(f_off),
+                          len(x_off) - 1, fs, float(frame_period), f0_floor, f0_ceil,
+                          channels_in_octave, allowed_range, _ptr(f0), _stream()), "itts_dio")
+    return f0
+
+
+def stonemask(x, x_off, f0, f_off, fs, frame_period=5.0):
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    _need(f0, torch.float64, "f0")
+    out = torch.empty_like(f0)
+    _lib.check(L.itts_stonemask(_ptr(x), _lib.offsets_array(x_off), _ptr(f0),
+                                _lib.offsets_array(f_off), len(x_off) - 1, fs,
+                                float(frame_period), _ptr(out), _stream()), "itts_stonemask")
+    return out
+
+
+def d4c(x, x_off, f0, f_off, fs, frame_period=5.0, fft_size=None, threshold=0.85, want_ap=True,
+        want_bap=None):
+    """pyworld.d4c (+ optional fused code_aperiodicity). want_bap: None | torch.float64 | float32.
+    Returns (ap or None, bap or None)."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    _need(f0, torch.float64, "f0")
+    fft_size = fft_size or L.itts_cheaptrick_fft_size(fs, 71.0)
+    T = int(f_off[-1])
+    nap = L.itts_num_aperiodicities(fs)
+    ap = torch.empty((T, fft_size // 2 + 1), dtype=torch.float64, device=x.device) if want_ap \
+        else None
+    bap = torch.empty((T, nap), dtype=want_bap, device=x.device) if want_bap is not None else None
+    _lib.check(L.itts_d4c(_ptr(x), _lib.offsets_array(x_off), _ptr(f0), _lib.offsets_array(f_off),
+                          len(x_off) - 1, fs, float(frame_period), fft_size, threshold, _ptr(ap),
+                          _ptr(bap) if want_bap == torch.float64 else None,
+                          _ptr(bap) if want_bap == torch.float32 else None, nap, _stream()),
+               "itts_d4c")
+    return ap, bap

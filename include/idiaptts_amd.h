@@ -149,6 +149,26 @@ int itts_code_aperiodicity(const double* d_ap, int64_t T, int fft_size, int fs, 
 int itts_decode_aperiodicity(const double* d_bap, int64_t T, int fs, int fft_size, double* d_ap,
                              void* stream);
 
+/* StoneMask F0 refinement (pyworld.stonemask; second stage of wav2world; also
+ * src/data_preparation/world/LF0LabelGen.py:263-264). d_f0_in / d_f0_out [Ttot] f64. */
+int itts_stonemask(const double* d_x, const int64_t* h_x_off, const double* d_f0_in,
+                   const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
+                   double* d_f0_out, void* stream);
+
+/* D4C band aperiodicity with LoveTrain V/UV (pyworld.d4c, threshold 0.85 in wav2world).
+ * d_ap [Ttot, fft_size/2+1] f64 (may be NULL) and / or the coded band aperiodicity
+ * pyworld.code_aperiodicity(ap, fs) as f64 [Ttot, nap] / f32 [Ttot, ld_bap] (may be NULL). */
+int itts_d4c(const double* d_x, const int64_t* h_x_off, const double* d_f0, const int64_t* h_f_off,
+             int n_utts, int fs, double frame_period_ms, int fft_size, double threshold,
+             double* d_ap, double* d_bap_f64, float* d_bap_f32, int64_t ld_bap, void* stream);
+
+/* DIO F0 estimation (pyworld.dio defaults: f0_floor 71, f0_ceil 800, channels_in_octave 2,
+ * speed 1, allowed_range 0.1; first stage of wav2world, WorldFeatLabelGen.py:792-793).
+ * d_f0 [Ttot] f64. Scratch is taken from the stream-ordered allocator (hipMallocAsync). */
+int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, int n_utts, int fs,
+             double frame_period_ms, double f0_floor, double f0_ceil, double channels_in_octave,
+             double allowed_range, double* d_f0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,85 @@ def test_cheaptrick_48k_synthetic(gpu):
     assert np.abs(sp.cpu().numpy() / sp_ref - 1).max() < 1e-8
     mc_ref = capi.mcep(np.sqrt(sp_ref), 59, 0.554)
     assert np.sqrt(np.mean((mc.cpu().numpy() - mc_ref) ** 2)) < 1e-7
+
+
+def test_dio_stonemask_match_oracle(gpu, utts):
+    from idiaptts_amd import ops
+    from oracle import capi
+    x, _, x_off, f_off = _batch(utts, gpu)
+    fs = utts[0][1]
+    f0d = ops.dio(x, x_off, f_off, fs)
+    f0r = ops.stonemask(x, x_off, f0d, f_off, fs).cpu().numpy()
+    f0d = f0d.cpu().numpy()
+    for u, (xu, _, f0_ref, tpu) in enumerate(utts):
+        a, b = f_off[u], f_off[u + 1]
+        d_ref, _ = capi.dio(xu, fs)
+        assert np.array_equal(f0d[a:b] == 0, d_ref == 0)            # discrete decisions identical
+        assert np.abs(f0d[a:b] - d_ref).max() < 1e-7
+        assert np.array_equal(f0r[a:b] == 0, f0_ref == 0)
+        assert np.abs(f0r[a:b] - f0_ref).max() < 1e-7
+
+
+def test_d4c_matches_oracle(gpu, utts):
+    from idiaptts_amd import ops
+    from oracle import capi
+    x, f0, x_off, f_off = _batch(utts, gpu)
+    fs = utts[0][1]
+    ap, bap = ops.d4c(x, x_off, f0, f_off, fs, want_bap=torch.float64)
+    ap = ap.cpu().numpy()
+    bap = bap.cpu().numpy()
+    for u, (xu, _, f0u, tpu) in enumerate(utts):
+        a, b = f_off[u], f_off[u + 1]
+        ap_ref = capi.d4c(xu, fs, tpu, f0u)
+        unv_ref = ap_ref[:, 0] > 0.999
+        assert np.array_equal(ap[a:b, 0] > 0.999, unv_ref)           # LoveTrain V/UV identical
+        assert np.abs(20 * np.log10(ap[a:b] / ap_ref)).max() < 1e-6  # dB
+        bap_ref = capi.code_aperiodicity(ap_ref, fs)
+        assert np.abs(bap[a:b] - bap_ref).max() < 1e-6
+
+
+def test_full_analysis_chain_matches_reference_cmp(gpu, golden_dir):
+    """wav -> DIO -> StoneMask -> CheapTrick -> mcep / D4C -> bap on the GPU, then the reference's
+    host logic (lf0 threshold, interpolate_lin), against the golden .cmp of the reference."""
+    import math
+    from idiaptts_amd import ops
+    from idiaptts_amd.misc.utils import interpolate_lin
+    names = ["LJ001-0008", "LJ001-0002"]
+    xs = [_read(golden_dir, n)[0] for n in names]
+    fs = 16000
+    x_off = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).tolist()
+    T = [int(1000.0 * len(x) / fs / 5.0) + 1 for x in xs]
+    f_off = np.concatenate([[0], np.cumsum(T)]).tolist()
+    x = torch.from_numpy(np.concatenate(xs)).to(gpu)
+    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs), f_off, fs)
+    _, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, want_sp=False, order=19, alpha=0.58)
+    _, bap = ops.d4c(x, x_off, f0, f_off, fs, want_ap=False, want_bap=torch.float32)
+    f0 = f0.cpu().numpy()
+    for u, name in enumerate(names):
+        a, b = f_off[u], f_off[u + 1]
+        cmp_ = np.fromfile(os.path.join(golden_dir, name + ".cmp"), dtype=np.float32).reshape(-1, 67)
+        lf0 = np.log(f0[a:b].clip(min=1e-10), dtype=np.float32)
+        lf0[lf0 <= math.log(30)] = 0
+        lf0, vuv = interpolate_lin(lf0)
+        assert np.array_equal(vuv[:, 0].astype(np.float32), cmp_[:, 63])        # bit-exact V/UV
+        assert np.sqrt(np.mean((lf0[:, 0] - cmp_[:, 60]) ** 2)) < 1e-6          # bar 1e-4
+        assert np.sqrt(np.mean((bap[a:b, 0].cpu().numpy() - cmp_[:, 64]) ** 2)) < 1e-6
+        assert np.sqrt(np.mean((mc[a:b].cpu().numpy() - cmp_[:, :20]) ** 2)) < 1e-6
+        assert np.abs(mc[a:b].cpu().numpy() - cmp_[:, :20]).max() <= 1e-6
+
+
+def test_analysis_48k_synthetic_matches_oracle(gpu):
+    from idiaptts_amd import ops
+    from oracle import capi
+    fs = 48000
+    x = _synthetic(fs, 1.0, 2)
+    T = int(1000.0 * len(x) / fs / 5.0) + 1
+    xg = torch.from_numpy(x).to(gpu)
+    f0 = ops.stonemask(xg, [0, len(x)], ops.dio(xg, [0, len(x)], [0, T], fs), [0, T], fs)
+    f0_ref, sp_ref, ap_ref = capi.wav2world(x, fs)
+    assert np.array_equal(f0.cpu().numpy() == 0, f0_ref == 0)
+    assert np.abs(f0.cpu().numpy() - f0_ref).max() < 1e-6
+    _, bap = ops.d4c(xg, [0, len(x)], f0, [0, T], fs, want_ap=False, want_bap=torch.float64)
+    bap_ref = capi.code_aperiodicity(ap_ref, fs)
+    assert bap.shape[1] == 5
+    assert np.sqrt(np.mean((bap.cpu().numpy() - bap_ref) ** 2)) < 1e-5
