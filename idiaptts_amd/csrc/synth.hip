@@ -1,0 +1,626 @@
+// WORLD waveform synthesis (synthesis.cpp) for batches of utterances + de-pre-emphasis.
+// Replaces pyworld.synthesize and the lfilter de-pre-emphasis in
+// WorldFeatLabelGen.world_features_to_raw (src/data_preparation/world/WorldFeatLabelGen.py:943-945,
+// src/data_preparation/audio/AudioProcessing.py:329-331).
+//
+// WORLD walks glottal pulses sequentially and draws noise from ONE xorshift128 stream.  Here:
+//   1. per-sample F0 / VUV interpolation is parallel; the phase sum keeps WORLD's sequential
+//      rounding (see syn_phase_seq_kernel);
+//   2. pulse positions are compacted in order (ballot + block offsets);
+//   3. the random stream is generated out of order with GF(2) jump-ahead: pulse q consumes
+//      stream positions [idx_q - idx_0, idx_{q+1} - idx_0), so stream position == sample offset
+//      and every 64-sample chunk of normals is produced by one lane from a jumped state --
+//      bit-identical to the sequential generator;
+//   4. one 256-thread workgroup per pulse builds the periodic + aperiodic responses in LDS
+//      (4 real FFTs for the two minimum-phase spectra, 1 for the noise, 2 inverse) and
+//      overlap-adds them with f64 atomics.
+// PARITY: the reference has no golden waveform; checked against oracle/c/synth.c.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "context.h"
+#include "world_dev.h"
+
+namespace itts {
+using namespace wd;
+
+constexpr int CHUNK = 2048;       // samples per block in the scan kernels (8 per thread)
+constexpr double kDefaultF0 = 500.0;
+constexpr int RCHUNK = 64;        // normals per lane in the RNG kernel
+constexpr int NJUMP = 20;         // jump matrices B^(2^k), B = 12*RCHUNK steps
+
+struct SynUtt {
+  int64_t f_off;   // frames offset
+  int T;
+  int64_t y_off;   // output samples offset
+  int yl;
+  int64_t s_off;   // offset into per-sample scratch
+  int64_t b_off;   // offset into per-block scratch
+  int nblk;
+};
+
+struct SynParams {
+  int fs, fft, logfft;
+  double fp;        // frame period in seconds
+  double lowest_f0;
+  int n_utts;
+};
+
+// WORLD interp1 on the uniform knots cta[j] = j*fp, j = 0..T (T+1 knots), histc semantics.
+__device__ __forceinline__ double interp_coarse(const double* __restrict__ f0, int T, double fp, double t,
+                                                double lowest, bool want_vuv) {
+  int j = (int)(t / fp);
+  while ((double)(j + 1) * fp <= t) ++j;
+  while (j > 0 && (double)j * fp > t) --j;
+  int k = j + 1;  // count of knots <= t
+  if (k < 1) k = 1;
+  if (k > T) k = T;
+  auto knot = [&](int q) -> double {  // value at knot q (0..T)
+    auto base = [&](int r) -> double {
+      const double v = f0[r] < lowest ? 0.0 : f0[r];
+      return want_vuv ? (v == 0.0 ? 0.0 : 1.0) : v;
+    };
+    if (q < T) return base(q);
+    return base(T - 1) * 2 - base(T - 2);
+  };
+  const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
+  const double y0 = knot(k - 1), y1 = knot(k);
+  const double s = (t - x0) / (x1 - x0);
+  return y0 + s * (y1 - y0);
+}
+
+// K1: phase increments + V/UV per sample, block sums
+__global__ __launch_bounds__(NT) void syn_inc_kernel(const double* __restrict__ f0, const SynUtt* __restrict__ utts,
+                                                     SynParams p, double* __restrict__ inc,
+                                                     uint8_t* __restrict__ vuv, double* __restrict__ bsums) {
+  __shared__ double red[8];
+  const SynUtt u = utts[blockIdx.y];
+  if ((int)blockIdx.x >= u.nblk) return;
+  const double* f = f0 + u.f_off;
+  const int i0 = blockIdx.x * CHUNK + threadIdx.x * (CHUNK / NT);
+  double s = 0.0;
+  for (int r = 0; r < CHUNK / NT; ++r) {
+    const int i = i0 + r;
+    if (i < u.yl) {
+      const double t = i / (double)p.fs;
+      const double v = interp_coarse(f, u.T, p.fp, t, p.lowest_f0, true) > 0.5 ? 1.0 : 0.0;
+      double fi = interp_coarse(f, u.T, p.fp, t, p.lowest_f0, false);
+      if (v == 0.0) fi = kDefaultF0;
+      const double d = 2.0 * kPi * fi / p.fs;
+      inc[u.s_off + i] = d;
+      vuv[u.s_off + i] = (uint8_t)(v != 0.0);
+      s += d;
+    }
+  }
+  s = bsum(s, red);
+  if (threadIdx.x == 0) bsums[u.b_off + blockIdx.x] = s;
+}
+
+// exclusive scan of per-block values of each utterance (double or int payload in double)
+__global__ void syn_scan_blocks_kernel(const SynUtt* __restrict__ utts, double* __restrict__ vals,
+                                       double* __restrict__ totals) {
+  const SynUtt u = utts[blockIdx.x];
+  if (threadIdx.x != 0) return;
+  double run = 0.0;
+  for (int b = 0; b < u.nblk; ++b) {
+    const double v = vals[u.b_off + b];
+    vals[u.b_off + b] = run;
+    run += v;
+  }
+  if (totals) totals[blockIdx.x] = run;
+}
+
+// K3: total phase -> wrapped phase.  WORLD accumulates the phase sample by sample; in unvoiced
+// regions (default 500 Hz) at fs = 16 kHz the running sum lands on multiples of 2 pi up to
+// rounding, so the pulse positions depend on the exact sequential rounding.  The chain
+// total += inc[i] is therefore evaluated strictly in order by one lane per utterance (the loads
+// and the fmod are done by the whole wave); ~8 cycles per sample, utterances in parallel.
+constexpr int SEQ = 1024;
+__global__ __launch_bounds__(64) void syn_phase_seq_kernel(const SynUtt* __restrict__ utts,
+                                                           double* __restrict__ inc_wrap) {
+  __shared__ double buf[SEQ];
+  const SynUtt u = utts[blockIdx.x];
+  double* a = inc_wrap + u.s_off;
+  double total = 0.0;
+  for (int base = 0; base < u.yl; base += SEQ) {
+    const int n = min(SEQ, u.yl - base);
+    for (int i = threadIdx.x; i < n; i += 64) buf[i] = a[base + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll 8
+      for (int i = 0; i < n; ++i) {
+        total = __dadd_rn(total, buf[i]);
+        buf[i] = total;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) a[base + i] = fmod(buf[i], 2.0 * kPi);
+    __syncthreads();
+  }
+}
+
+// K4: pulses per block (pulse at sample i when |wrap[i+1]-wrap[i]| > pi, i <= yl-2)
+__global__ __launch_bounds__(NT) void syn_pulse_count_kernel(const SynUtt* __restrict__ utts,
+                                                             const double* __restrict__ wrap,
+                                                             double* __restrict__ pcnt) {
+  __shared__ double red[8];
+  const SynUtt u = utts[blockIdx.y];
+  if ((int)blockIdx.x >= u.nblk) return;
+  const double* w = wrap + u.s_off;
+  double c = 0.0;
+  for (int r = 0; r < CHUNK / NT; ++r) {
+    const int i = blockIdx.x * CHUNK + r * NT + threadIdx.x;
+    if (i < u.yl - 1 && fabs(w[i + 1] - w[i]) > kPi) c += 1.0;
+  }
+  c = bsum(c, red);
+  if (threadIdx.x == 0) pcnt[u.b_off + blockIdx.x] = c;
+}
+
+// K6: ordered compaction of pulse indices
+__global__ __launch_bounds__(NT) void syn_pulse_emit_kernel(const SynUtt* __restrict__ utts,
+                                                            const double* __restrict__ wrap,
+                                                            const double* __restrict__ poff,
+                                                            int* __restrict__ pidx, SynParams p) {
+  __shared__ int wcnt[4];
+  __shared__ int base_s;
+  const SynUtt u = utts[blockIdx.y];
+  if ((int)blockIdx.x >= u.nblk) return;
+  const double* w = wrap + u.s_off;
+  if (threadIdx.x == 0) base_s = (int)poff[u.b_off + blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = 0; r < CHUNK / NT; ++r) {
+    const int i = blockIdx.x * CHUNK + r * NT + threadIdx.x;
+    const bool pulse = (i < u.yl - 1) && fabs(w[i + 1] - w[i]) > kPi;
+    const unsigned long long bal = __ballot(pulse);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int q = 0; q < wv; ++q) off += wcnt[q];
+    if (pulse) pidx[u.s_off + off + before] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+}
+
+// flat pulse numbering over the batch: gpoff[u] = sum_{u'<u} P_u', gpoff[U] = total
+__global__ void syn_pulse_offsets_kernel(const double* __restrict__ ptot, int n_utts, int64_t* __restrict__ gpoff) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t run = 0;
+    for (int u = 0; u < n_utts; ++u) {
+      gpoff[u] = run;
+      run += (int64_t)ptot[u];
+    }
+    gpoff[n_utts] = run;
+  }
+}
+
+// ---- WORLD randn stream with jump-ahead ---------------------------------------------------------
+struct JumpTable {
+  uint32_t col[NJUMP][128][4];  // column j of B^(2^k): image of basis vector e_j
+};
+
+__device__ __forceinline__ void xs_step(uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& w) {
+  const uint32_t t = x ^ (x << 11);
+  x = y; y = z; z = w;
+  w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+}
+
+__global__ __launch_bounds__(NT) void syn_randn_kernel(const SynUtt* __restrict__ utts,
+                                                       const JumpTable* __restrict__ jt,
+                                                       double* __restrict__ R) {
+  const SynUtt u = utts[blockIdx.y];
+  const int chunk = blockIdx.x * NT + threadIdx.x;
+  const int n0 = chunk * RCHUNK;
+  if (n0 >= u.yl) return;
+  uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+  // state after 12*RCHUNK*chunk steps: apply B^(2^k) for every set bit k of `chunk`
+  for (int k = 0; k < NJUMP; ++k) {
+    if ((chunk >> k) & 1) {
+      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      for (int j = 0; j < 128; ++j) {
+        if ((s[j >> 5] >> (j & 31)) & 1u) {
+          r0 ^= jt->col[k][j][0];
+          r1 ^= jt->col[k][j][1];
+          r2 ^= jt->col[k][j][2];
+          r3 ^= jt->col[k][j][3];
+        }
+      }
+      s[0] = r0; s[1] = r1; s[2] = r2; s[3] = r3;
+    }
+  }
+  uint32_t x = s[0], y = s[1], z = s[2], w = s[3];
+  double* out = R + u.s_off + n0;
+  const int cnt = min(RCHUNK, u.yl - n0);
+  for (int i = 0; i < cnt; ++i) {
+    xs_step(x, y, z, w);
+    uint32_t tmp = w >> 4;
+    for (int q = 0; q < 11; ++q) {
+      xs_step(x, y, z, w);
+      tmp += w >> 4;
+    }
+    out[i] = tmp / 268435456.0 - 6.0;
+  }
+}
+
+// ---- one workgroup per pulse ------------------------------------------------------------------------
+struct PulseArgs {
+  const double* f0;
+  const double* sp;
+  const double* ap;
+  const SynUtt* utts;
+  const int64_t* gpoff;
+  const double* ptot;
+  const int* pidx;
+  const double* wrap;
+  const uint8_t* vuv;
+  const double* R;
+  double* y;
+  SynParams p;
+  const double2* g_tw;
+};
+
+// minimum phase spectrum of the log-amplitude lg[0..h] (in z.x of the first h+1 entries is NOT
+// assumed): input array `lg`, output mp[0..h] complex. Uses z as FFT scratch.
+__device__ inline void min_phase(const double* lg, int fft, int logfft, double2* z, const double2* tw,
+                                 double2* mp) {
+  const int h = fft / 2;
+  double* zr = reinterpret_cast<double*>(z);
+  for (int k = threadIdx.x; k <= h; k += NT) {
+    const double v = lg[k];
+    zr[k] = v;
+    if (k > 0 && k < h) zr[fft - k] = v;
+  }
+  __syncthreads();
+  rfft_lds(z, fft, logfft, tw, fft);  // real even input -> real spectrum = fft * cepstrum
+  // fold: c[0], 2 c[1..h-1], c[h], zeros; keep the (real) values, build the real sequence
+  double cv[ (4096 / 2 + 1 + NT - 1) / NT ];
+  int cnt = 0;
+  for (int k = threadIdx.x; k <= h; k += NT) cv[cnt++] = z[k].x * ((k == 0 || k == h) ? 1.0 : 2.0);
+  __syncthreads();
+  cnt = 0;
+  for (int k = threadIdx.x; k <= h; k += NT) zr[k] = cv[cnt++];
+  for (int k = h + 1 + threadIdx.x; k < fft + 2; k += NT) zr[k] = 0.0;
+  __syncthreads();
+  rfft_lds(z, fft, logfft, tw, fft);
+  for (int k = threadIdx.x; k <= h; k += NT) {
+    const double t = exp(z[k].x / fft);
+    double sn, cs;
+    sincos(z[k].y / fft, &sn, &cs);
+    mp[k] = make_double2(t * cs, t * sn);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int fft = a.p.fft, logfft = a.p.logfft, h = fft / 2, K = h + 1;
+  char* q = smem;
+  double2* tw = reinterpret_cast<double2*>(q); q += (size_t)h * 16;
+  double2* z = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
+  double2* mp = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
+  double2* nzs = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
+  double* se = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
+  double* ar = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
+  double* lg = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
+  double* per = reinterpret_cast<double*>(q); q += (size_t)fft * 8;
+  double* red = reinterpret_cast<double*>(q);
+  double* zr = reinterpret_cast<double*>(z);
+
+  load_twiddles(tw, a.g_tw, fft);
+  __syncthreads();
+  const int64_t total = a.gpoff[a.p.n_utts];
+  for (int64_t g = blockIdx.x; g < total; g += gridDim.x) {
+    // utterance of flat pulse g
+    int lo = 0, hi = a.p.n_utts;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.gpoff[mid] <= g) lo = mid; else hi = mid;
+    }
+    const SynUtt u = a.utts[lo];
+    const int P = (int)a.ptot[lo];
+    const int qi = (int)(g - a.gpoff[lo]);
+    const int* pidx = a.pidx + u.s_off;
+    const int idx = pidx[qi];
+    const int idx_next = pidx[min(P - 1, qi + 1)];
+    const int noise_size = idx_next - idx;
+    const double* wrap = a.wrap + u.s_off;
+    const double y1 = wrap[idx] - 2.0 * kPi, y2 = wrap[idx + 1];
+    const double tshift = (-y1 / (y2 - y1)) / a.p.fs;
+    const double t = idx / (double)a.p.fs;
+    const double vuv = a.vuv[u.s_off + idx] ? 1.0 : 0.0;
+    const int T = u.T;
+    int fl = (int)floor(t / a.p.fp), ce = (int)ceil(t / a.p.fp);
+    if (fl > T - 1) fl = T - 1;
+    if (ce > T - 1) ce = T - 1;
+    const double al = t / a.p.fp - fl;
+    const double* sp0 = a.sp + (u.f_off + fl) * K;
+    const double* sp1 = a.sp + (u.f_off + ce) * K;
+    const double* ap0 = a.ap + (u.f_off + fl) * K;
+    const double* ap1 = a.ap + (u.f_off + ce) * K;
+    for (int k = threadIdx.x; k < K; k += NT) {
+      const double s0 = fabs(sp0[k]);
+      double a0 = ap0[k];
+      a0 = a0 > 0.999999999999 ? 0.999999999999 : a0;
+      a0 = a0 < 0.001 ? 0.001 : a0;
+      if (fl == ce) {
+        se[k] = s0;
+        ar[k] = pow(a0, 2.0);
+      } else {
+        const double s1 = fabs(sp1[k]);
+        double a1 = ap1[k];
+        a1 = a1 > 0.999999999999 ? 0.999999999999 : a1;
+        a1 = a1 < 0.001 ? 0.001 : a1;
+        se[k] = (1.0 - al) * s0 + al * s1;
+        ar[k] = (1.0 - al) * pow(a0, 2.0) + al * pow(a1, 2.0);
+      }
+    }
+    __syncthreads();
+    // ---- periodic response
+    const bool has_per = !(vuv <= 0.5 || ar[0] > 0.999);
+    if (has_per) {
+      for (int k = threadIdx.x; k < K; k += NT) lg[k] = log(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
+      __syncthreads();
+      min_phase(lg, fft, logfft, z, tw, mp);
+      const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
+      for (int k = threadIdx.x; k < K; k += NT) {
+        const double re2 = cos(coef * k);
+        const double im2 = sqrt(1.0 - re2 * re2);
+        const double2 m = mp[k];
+        z[k] = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);
+      }
+      __syncthreads();
+      irfft_lds(z, fft, logfft, tw, fft);
+      // fftshift + DC removal
+      double dc = 0.0;
+      for (int i = threadIdx.x; i < h; i += NT) dc += zr[i];  // shifted index i+h <- zr[i]
+      dc = bsum(dc, red);
+      // dc_remover[i] = hann(i) / sum, symmetric
+      double dsum = 0.0;
+      for (int i = threadIdx.x; i < h; i += NT) dsum += (0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft))) * 2.0;
+      dsum = bsum(dsum, red);
+      for (int i = threadIdx.x; i < fft; i += NT) {
+        const int m = i < h ? i : fft - 1 - i;
+        const double dcr = (0.5 - 0.5 * cos(2.0 * kPi * (m + 1.0) / (1.0 + fft))) / dsum;
+        // shifted response: y[i] = x[i+h] (i<h), y[i] = x[i-h] (i>=h)
+        per[i] = (i < h) ? -dc * dcr : zr[i - h] - dc * dcr;
+      }
+      __syncthreads();
+    }
+    // ---- aperiodic response: noise spectrum
+    {
+      const double* R = a.R + u.s_off + (idx - pidx[0]);
+      double s = 0.0;
+      for (int i = threadIdx.x; i < fft + 2; i += NT) {
+        double v = 0.0;
+        if (i < noise_size && i < fft) {
+          v = R[i];
+          s += v;
+        }
+        zr[i] = v;
+      }
+      s = bsum(s, red);
+      if (noise_size > 0) {
+        const double avg = s / noise_size;
+        for (int i = threadIdx.x; i < noise_size && i < fft; i += NT) zr[i] -= avg;
+      }
+      __syncthreads();
+      rfft_lds(z, fft, logfft, tw, fft);
+      for (int k = threadIdx.x; k < K; k += NT) nzs[k] = z[k];
+      __syncthreads();
+    }
+    for (int k = threadIdx.x; k < K; k += NT)
+      lg[k] = (vuv != 0.0) ? log(se[k] * ar[k]) / 2.0 : log(se[k]) / 2.0;
+    __syncthreads();
+    min_phase(lg, fft, logfft, z, tw, mp);
+    for (int k = threadIdx.x; k < K; k += NT) {
+      const double2 m = mp[k], n = nzs[k];
+      z[k] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
+    }
+    __syncthreads();
+    irfft_lds(z, fft, logfft, tw, fft);
+    // ---- overlap-add
+    const double sq = sqrt((double)noise_size);
+    const int off = idx - h + 1;
+    double* y = a.y + u.y_off;
+    for (int j = threadIdx.x; j < fft; j += NT) {
+      const int tgt = j + off;
+      if (tgt >= 0 && tgt < u.yl) {
+        const double apv = (j < h) ? zr[j + h] : zr[j - h];  // fftshift
+        const double v = (has_per ? per[j] * sq : 0.0) + apv;
+        atomicAdd(&y[tgt], v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// y f64 -> out (f32 and/or f64) through float32 rounding and 1st-order de-pre-emphasis
+// lfilter([1], [1, -pre]) evaluated in f64 on the f32-rounded samples (as scipy does).
+__global__ void syn_finalize_kernel(const double* __restrict__ y, const SynUtt* __restrict__ utts, double pre,
+                                    float* __restrict__ out_f32, double* __restrict__ out_f64) {
+  const SynUtt u = utts[blockIdx.x];
+  if (pre == 0.0) {
+    for (int i = threadIdx.x; i < u.yl; i += blockDim.x) {
+      const float v = (float)y[u.y_off + i];
+      if (out_f32) out_f32[u.y_off + i] = v;
+      if (out_f64) out_f64[u.y_off + i] = (double)v;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    double prev = 0.0;
+    for (int i = 0; i < u.yl; ++i) {
+      const double v = (double)(float)y[u.y_off + i] + pre * prev;
+      prev = v;
+      if (out_f32) out_f32[u.y_off + i] = (float)v;
+      if (out_f64) out_f64[u.y_off + i] = v;
+    }
+  }
+}
+
+// ---- host: GF(2) jump matrices of the xorshift128 step ---------------------------------------------
+struct Mat128 {
+  uint32_t col[128][4];
+};
+static void mat_apply(const Mat128& m, const uint32_t* v, uint32_t* out) {
+  uint32_t r[4] = {0, 0, 0, 0};
+  for (int j = 0; j < 128; ++j)
+    if ((v[j >> 5] >> (j & 31)) & 1u)
+      for (int c = 0; c < 4; ++c) r[c] ^= m.col[j][c];
+  std::memcpy(out, r, sizeof(r));
+}
+static void mat_mul(const Mat128& a, const Mat128& b, Mat128* out) {  // out = a * b (apply b first)
+  Mat128 r;
+  for (int j = 0; j < 128; ++j) mat_apply(a, b.col[j], r.col[j]);
+  *out = r;
+}
+
+static JumpTable* g_jump_dev[64] = {nullptr};
+
+static const JumpTable* get_jump_table(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  if (g_jump_dev[device]) return g_jump_dev[device];
+  Mat128 step;
+  for (int j = 0; j < 128; ++j) {
+    uint32_t s[4] = {0, 0, 0, 0};
+    s[j >> 5] = 1u << (j & 31);
+    uint32_t x = s[0], y = s[1], z = s[2], w = s[3];
+    const uint32_t t = x ^ (x << 11);
+    x = y; y = z; z = w;
+    w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+    step.col[j][0] = x; step.col[j][1] = y; step.col[j][2] = z; step.col[j][3] = w;
+  }
+  // B = step^(12*RCHUNK) by square-and-multiply
+  Mat128 B, pw = step;
+  bool have = false;
+  for (int e = 12 * RCHUNK; e > 0; e >>= 1) {
+    if (e & 1) {
+      if (!have) { B = pw; have = true; } else mat_mul(pw, B, &B);
+    }
+    mat_mul(pw, pw, &pw);
+  }
+  std::vector<JumpTable> jt(1);
+  Mat128 cur = B;
+  for (int k = 0; k < NJUMP; ++k) {
+    std::memcpy(jt[0].col[k], cur.col, sizeof(cur.col));
+    mat_mul(cur, cur, &cur);
+  }
+  JumpTable* d = nullptr;
+  if (hipMalloc((void**)&d, sizeof(JumpTable)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, jt.data(), sizeof(JumpTable), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  g_jump_dev[device] = d;
+  return d;
+}
+
+}  // namespace itts
+
+using namespace itts;
+
+extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* d_ap,
+                                     const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
+                                     double frame_period_ms, int fft_size, double preemphasis,
+                                     float* d_y_f32, double* d_y_f64, void* stream) {
+  ITTS_REQUIRE(d_f0 && d_sp && d_ap && h_f_off && h_y_off && (d_y_f32 || d_y_f64), "null pointer");
+  ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
+  ITTS_REQUIRE(fft_size >= 256 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0,
+               "fft_size must be 2^k in [256, 4096]");
+  if (n_utts == 0) return ITTS_OK;
+  hipStream_t s = as_stream(stream);
+  DeviceContext* ctx = get_context();
+  if (!ctx) return ITTS_E_HIP;
+  const JumpTable* jt = get_jump_table(ctx->device);
+  if (!jt) {
+    set_error("could not create the RNG jump table");
+    return ITTS_E_HIP;
+  }
+  SynParams p{};
+  p.fs = fs; p.fft = fft_size; p.logfft = 0;
+  while ((1 << p.logfft) < fft_size) ++p.logfft;
+  p.fp = frame_period_ms / 1000.0;
+  p.lowest_f0 = (double)(fs / fft_size) + 1.0;  // integer division as in WORLD
+  p.n_utts = n_utts;
+  std::vector<SynUtt> utts(n_utts);
+  int64_t s_n = 0, b_n = 0;
+  int max_nblk = 0, max_yl = 0;
+  for (int u = 0; u < n_utts; ++u) {
+    const int64_t T = h_f_off[u + 1] - h_f_off[u];
+    const int64_t yl = itts_world_synth_length(T, fs, frame_period_ms);
+    ITTS_REQUIRE(T >= 2 && yl >= 2 && yl < ((int64_t)1 << 30), "each utterance needs >= 2 frames");
+    ITTS_REQUIRE(h_y_off[u + 1] - h_y_off[u] == yl, "output offsets do not match int(T*frame_period*fs/1000)");
+    ITTS_REQUIRE(yl < (int64_t)RCHUNK << NJUMP, "utterance too long for the RNG jump table");
+    SynUtt& d = utts[u];
+    d.f_off = h_f_off[u]; d.T = (int)T; d.y_off = h_y_off[u]; d.yl = (int)yl;
+    d.s_off = s_n; d.b_off = b_n; d.nblk = (int)((yl + CHUNK - 1) / CHUNK);
+    s_n += yl + 8; b_n += d.nblk;
+    max_nblk = std::max(max_nblk, d.nblk);
+    max_yl = std::max(max_yl, d.yl);
+  }
+  const int64_t y_total = h_y_off[n_utts];
+  SynUtt* d_utts = nullptr;
+  double *d_wrap = nullptr, *d_R = nullptr, *d_bs = nullptr, *d_pc = nullptr, *d_ptot = nullptr, *d_y = nullptr;
+  uint8_t* d_vuv = nullptr;
+  int* d_pidx = nullptr;
+  int64_t* d_gpoff = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_utts, n_utts * sizeof(SynUtt), s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_wrap, s_n * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_R, s_n * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_vuv, s_n, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_pidx, s_n * 4, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_bs, b_n * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_pc, b_n * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_ptot, n_utts * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_gpoff, (n_utts + 1) * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_y, y_total * 8, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), n_utts * sizeof(SynUtt), hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, y_total * 8, s));
+
+  const dim3 gblk(max_nblk, n_utts);
+  hipLaunchKernelGGL(syn_inc_kernel, gblk, dim3(NT), 0, s, d_f0, d_utts, p, d_wrap, d_vuv, d_bs);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(syn_phase_seq_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(syn_pulse_count_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(syn_scan_blocks_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_pc, d_ptot);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(syn_pulse_emit_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc, d_pidx, p);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(syn_pulse_offsets_kernel, dim3(1), dim3(64), 0, s, d_ptot, n_utts, d_gpoff);
+  ITTS_LAUNCH_CHECK();
+  {
+    const int nchunks = (max_yl + RCHUNK - 1) / RCHUNK;
+    hipLaunchKernelGGL(syn_randn_kernel, dim3((nchunks + NT - 1) / NT, n_utts), dim3(NT), 0, s, d_utts, jt, d_R);
+    ITTS_LAUNCH_CHECK();
+  }
+  {
+    PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p, ctx->twiddles};
+    const int h = fft_size / 2;
+    const size_t lds = (size_t)h * 16 + 3 * (size_t)(h + 1) * 16 + 3 * (size_t)(h + 2) * 8 +
+                       (size_t)fft_size * 8 + 16 * 8;
+    ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int blocks_per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
+    hipLaunchKernelGGL(syn_pulse_kernel, dim3(256 * blocks_per_cu), dim3(NT), lds, s, a);
+    ITTS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(syn_finalize_kernel, dim3(n_utts), dim3(NT), 0, s, d_y, d_utts, preemphasis, d_y_f32, d_y_f64);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_utts, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_wrap, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_R, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_vuv, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_pidx, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_bs, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_pc, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_ptot, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_gpoff, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_y, s));
+  return ITTS_OK;
+}

@@ -57,6 +57,8 @@ _SIGNATURES = {
                          c_double, _P, _P, _P, c_int64, _P]),
     "itts_dio": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), c_int, c_int, c_double, c_double,
                          c_double, c_double, c_double, _P, _P]),
+    "itts_world_synthesize": (c_int, [_P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int,
+                                      c_double, c_int, c_double, _P, _P, _P]),
     "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_float, _P]),
 }

@@ -313,3 +313,28 @@ def d4c(x, x_off, f0, f_off, fs, frame_period=5.0, fft_size=None, threshold=0.85
                           _ptr(bap) if want_bap == torch.float32 else None, nap, _stream()),
                "itts_d4c")
     return ap, bap
+
+
+def world_synthesize(f0, sp, ap, f_off, fs, frame_period=5.0, preemphasis=0.0,
+                     dtype=torch.float32):
+    """pyworld.synthesize + float32 cast + de-pre-emphasis for utterances stored back to back.
+    Returns (y [Ytot], y_off list)."""
+    L = _lib.load()
+    for t, n in ((f0, "f0"), (sp, "sp"), (ap, "ap")):
+        _need(t, torch.float64, n)
+    sp = sp.contiguous()
+    ap = ap.contiguous()
+    K = sp.shape[1]
+    fft_size = (K - 1) * 2
+    y_off = [0]
+    for u in range(len(f_off) - 1):
+        y_off.append(y_off[-1] + L.itts_world_synth_length(int(f_off[u + 1] - f_off[u]), fs,
+                                                           float(frame_period)))
+    y = torch.empty((y_off[-1],), dtype=dtype, device=f0.device)
+    _lib.check(L.itts_world_synthesize(_ptr(f0), _ptr(sp), _ptr(ap), _lib.offsets_array(f_off),
+                                       _lib.offsets_array(y_off), len(f_off) - 1, fs,
+                                       float(frame_period), fft_size, float(preemphasis),
+                                       _ptr(y) if dtype == torch.float32 else None,
+                                       _ptr(y) if dtype == torch.float64 else None, _stream()),
+               "itts_world_synthesize")
+    return y, y_off

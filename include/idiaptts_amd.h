@@ -169,6 +169,16 @@ int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, 
              double frame_period_ms, double f0_floor, double f0_ceil, double channels_in_octave,
              double allowed_range, double* d_f0, void* stream);
 
+/* WORLD synthesis (pyworld.synthesize(f0, sp, ap, fs, frame_period)) followed by the reference's
+ * float32 cast and de-pre-emphasis lfilter([1],[1,-preemphasis]) -- WorldFeatLabelGen.py:943-945.
+ * d_f0 [Ttot] f64, d_sp / d_ap [Ttot, fft_size/2+1] f64 (power spectrum / aperiodicity);
+ * h_y_off[U+1] sample offsets with y_len(u) = int(T_u*frame_period*fs/1000).
+ * d_y_f32 and / or d_y_f64 [Ytot] (f64 = what scipy.signal.lfilter returns). */
+int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* d_ap,
+                          const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
+                          double frame_period_ms, int fft_size, double preemphasis, float* d_y_f32,
+                          double* d_y_f64, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
