@@ -1,0 +1,93 @@
+"""Batched, GPU-resident WORLD feature path (the MI355X-native fast path behind the drop-in shims).
+
+analysis : wav(s) -> DIO -> StoneMask -> CheapTrick (+ fused SPTK mcep) / D4C (+ coded bap)
+synthesis: (f0, sp, ap) -> WORLD synthesis -> float32 (+ de-pre-emphasis)
+Utterances are concatenated and processed by single launches; only the small per-frame features
+(f0, mcep, bap) travel back to the host unless the spectral envelope is asked for.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import ops
+from .misc.utils import interpolate_lin
+
+
+def _device(device):
+    _lib.require_gpu()
+    return torch.device(device if device is not None else "cuda")
+
+
+def num_frames(n, fs, hop_ms=5.0):
+    return int(_lib.load().itts_world_num_frames(int(n), int(fs), float(hop_ms)))
+
+
+def offsets(lengths):
+    off = [0]
+    for n in lengths:
+        off.append(off[-1] + int(n))
+    return off
+
+
+def lf0_vuv_from_f0(f0, f0_silence_threshold=30, lf0_zero=0):
+    """WorldFeatLabelGen.world_extract_features :798-802 (host: float32 log, threshold,
+    interpolate_lin)."""
+    lf0 = np.log(f0.clip(min=1E-10), dtype=np.float32)
+    lf0[lf0 <= math.log(f0_silence_threshold)] = lf0_zero
+    lf0, vuv = interpolate_lin(lf0)
+    return lf0.astype(dtype=np.float32), vuv.astype(dtype=np.float32)
+
+
+def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
+                  mcep_order=None, mcep_alpha=None, want_bap=True, device=None):
+    """raws: list of float64 waveforms (already pre-emphasised). Returns a list of dicts with
+    f0 [T] f64, and optionally sp [T,K] f64 (power), ap [T,K] f64, mcep [T,order+1] f32,
+    bap [T,nap] f32."""
+    dev = _device(device)
+    L = _lib.load()
+    n_fft = n_fft or L.itts_cheaptrick_fft_size(int(fs), 71.0)
+    x_off = offsets([len(r) for r in raws])
+    f_off = offsets([num_frames(len(r), fs, hop_ms) for r in raws])
+    x = torch.from_numpy(np.ascontiguousarray(np.concatenate(raws), dtype=np.float64)).to(dev)
+    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
+    sp = mc = ap = bap = None
+    if want_sp or mcep_order is not None:
+        sp, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=want_sp,
+                                        order=mcep_order, alpha=mcep_alpha)
+    if want_ap or want_bap:
+        ap, bap = ops.d4c(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_ap=want_ap,
+                          want_bap=torch.float32 if want_bap else None)
+    f0 = f0.cpu().numpy()
+    sp = sp.cpu().numpy() if sp is not None else None
+    mc = mc.cpu().numpy() if mc is not None else None
+    ap = ap.cpu().numpy() if ap is not None else None
+    bap = bap.cpu().numpy() if bap is not None else None
+    out = []
+    for u in range(len(raws)):
+        a, b = f_off[u], f_off[u + 1]
+        out.append({"f0": f0[a:b],
+                    "sp": sp[a:b] if sp is not None else None,
+                    "ap": ap[a:b] if ap is not None else None,
+                    "mcep": mc[a:b] if mc is not None else None,
+                    "bap": bap[a:b] if bap is not None else None})
+    return out
+
+
+def synthesise_batch(f0s, sps, baps, fs, n_fft, hop_ms=5.0, preemphasis=0.0, device=None,
+                     out_dtype=np.float64):
+    """f0s: list of [T] f64; sps: list of [T,K] f64 POWER spectra; baps: list of [T,nap] f64 coded
+    aperiodicity. Returns list of waveforms (float32 samples; float64 container when
+    out_dtype is float64, like scipy.signal.lfilter gives the reference)."""
+    dev = _device(device)
+    f_off = offsets([len(f) for f in f0s])
+    f0 = torch.from_numpy(np.ascontiguousarray(np.concatenate(f0s), dtype=np.float64)).to(dev)
+    sp = torch.from_numpy(np.ascontiguousarray(np.concatenate(sps), dtype=np.float64)).to(dev)
+    bap = torch.from_numpy(np.ascontiguousarray(np.concatenate(baps), dtype=np.float64)).to(dev)
+    ap = ops.decode_aperiodicity(bap, fs, n_fft)
+    y, y_off = ops.world_synthesize(f0, sp, ap, f_off, fs, hop_ms, preemphasis,
+                                    dtype=torch.float64 if out_dtype == np.float64
+                                    else torch.float32)
+    y = y.cpu().numpy()
+    return [y[y_off[u]:y_off[u + 1]] for u in range(len(f0s))]

@@ -1,0 +1,91 @@
+"""Drop-in surface on the GPU: the reference's own integration checks for the WORLD path
+(test/integration/data_preparation/world/test_WorldFeatLabelGen.py) restated against our shims."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_world_extract_and_resynth_bounds(gpu, golden_dir):
+    """reference test_WorldFeatLabelGen.py:722-763: shapes/dtypes of world_extract_features and
+    sum (orig - WORLD resynth)^2 < 10000."""
+    from idiaptts_amd.src.data_preparation.audio.AudioProcessing import AudioProcessing
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    raw, fs = AudioProcessing.get_raw(os.path.join(golden_dir, "LJ001-0008.wav"), 0.0)
+    amp_sp, lf0, vuv, bap = WorldFeatLabelGen.world_extract_features(raw, fs, 5)
+    T = int(1000.0 * len(raw) / fs / 5) + 1
+    assert amp_sp.shape == (T, 513) and amp_sp.dtype == np.float64
+    assert lf0.shape == (T, 1) and lf0.dtype == np.float32
+    assert vuv.shape == (T, 1) and vuv.dtype == np.float32 and set(np.unique(vuv)) <= {0.0, 1.0}
+    assert bap.shape == (T, 1) and bap.dtype == np.float32
+    wav = WorldFeatLabelGen.world_features_to_raw(amp_sp, lf0, vuv, bap, fs=fs, n_fft=1024)
+    n = min(len(wav), len(raw))
+    assert ((raw[:n] - wav[:n]) ** 2).sum() < 10000
+    # mcep80 -> spectrum reconstruction bound (reference :816-824): sum err^2 < 100
+    mcep = AudioProcessing.extract_mcep(amp_sp, 80, 0.42)
+    assert mcep.dtype == np.float32 and mcep.shape == (T, 80)
+    rec = AudioProcessing.mcep_to_amp_sp(mcep, fs, 0.42)
+    assert rec.dtype == np.float32 and ((amp_sp - rec) ** 2).sum() < 100
+
+
+def test_gen_data_matches_reference_cmp_and_roundtrips(gpu, golden_dir, tmp_path):
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    ids = ["LJ001-0002", "LJ001-0008"]
+    gen = WorldFeatLabelGen(str(tmp_path), add_deltas=True, preemphasis=0.97, num_coded_sps=20,
+                            mgc_alpha=0.58)
+    label_dict, mean, cov = gen.gen_data(golden_dir, str(tmp_path), "ids.txt", id_list=ids,
+                                         return_dict=True)
+    for n in ids:
+        cmp_ = np.fromfile(os.path.join(golden_dir, n + ".cmp"), dtype=np.float32).reshape(-1, 67)
+        got = label_dict[n]
+        assert got.shape == cmp_.shape
+        assert np.array_equal(got[:, 63], cmp_[:, 63])                  # V/UV bit-exact
+        assert np.sqrt(np.mean((got - cmp_) ** 2)) < 1e-6               # bar: 1e-4 RMSE
+        assert np.array_equal(gen.load(n), got)                          # npz round trip
+    assert os.path.isfile(os.path.join(str(tmp_path), "mcep20", "ids-deltas-mean-covariance.npz"))
+    assert os.path.isfile(os.path.join(str(tmp_path), "lf0", "ids-deltas-stats.npz"))
+    assert len(mean) == 4 and cov[0].shape == (60, 60)
+    # legacy cmp fallback of load(): directory layout <dir>/cmp_mcep20/<id>.cmp
+    os.makedirs(os.path.join(str(tmp_path), "legacy", "cmp_mcep20"))
+    import shutil
+    shutil.copy(os.path.join(golden_dir, "LJ001-0008.cmp"),
+                os.path.join(str(tmp_path), "legacy", "cmp_mcep20", "LJ001-0008.cmp"))
+    leg = WorldFeatLabelGen(os.path.join(str(tmp_path), "legacy"), add_deltas=True,
+                            num_coded_sps=20)
+    cmp_ = np.fromfile(os.path.join(golden_dir, "LJ001-0008.cmp"), dtype=np.float32).reshape(-1, 67)
+    assert np.array_equal(leg.load("LJ001-0008"), cmp_)
+
+
+def test_postprocess_world_mlpg_and_run_world_synth(gpu, golden_dir, tmp_path):
+    from idiaptts_amd.src.Synthesiser import Synthesiser
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    from oracle import capi
+    cmp_ = np.fromfile(os.path.join(golden_dir, "LJ001-0008.cmp"), dtype=np.float32).reshape(-1, 67)
+    gen = WorldFeatLabelGen(None, add_deltas=True, num_coded_sps=20)
+    rng = np.random.default_rng(0)
+    gen.covs = [np.diag(rng.uniform(0.05, 1, 60)), np.diag(rng.uniform(0.05, 1, 3)), None,
+                np.diag(rng.uniform(0.05, 1, 3))]
+    sample = cmp_.astype(np.float64).copy()
+    out = gen._postprocess_world(sample)
+    assert out.shape == (cmp_.shape[0], 23)
+    ref_sp = capi.mlpg(cmp_[:, :60].astype(np.float64), np.diag(gen.covs[0]), 20)
+    ref_lf0 = capi.mlpg(cmp_[:, 60:63].astype(np.float64), np.diag(gen.covs[1]), 1)
+    ref_bap = capi.mlpg(cmp_[:, 64:67].astype(np.float64), np.diag(gen.covs[3]), 1)
+    assert np.abs(out[:, :20] - ref_sp).max() < 1e-9
+    assert np.abs(out[:, 20:21] - ref_lf0).max() < 1e-9
+    assert np.array_equal(out[:, 21], cmp_[:, 63])
+    assert np.abs(out[:, 22:23] - ref_bap).max() < 1e-9
+    # run_world_synth on static features: wav written with the reference's file name and length
+    hp = types.SimpleNamespace(synth_fs=16000, num_coded_sps=20, num_bap=1, sp_type="mcep",
+                               out_dir=str(tmp_path), model_name="m", synth_file_suffix="_x",
+                               synth_ext="wav", do_post_filtering=False)
+    wavs = Synthesiser.run_world_synth({"LJ001-0008": out.astype(np.float32)}, hp,
+                                       return_waveforms=True)
+    path = os.path.join(str(tmp_path), "m", "synth", "LJ001-0008_x_20mcep_WORLD.wav")
+    assert os.path.isfile(path)
+    # length check of the reference's synth test (test_AcousticModelTrainer.py:161-168)
+    assert len(wavs["LJ001-0008"]) == int(cmp_.shape[0] * 5 * 16000 / 1000)
+    assert Synthesiser.synth_world_features is not None
