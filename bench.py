@@ -41,15 +41,25 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
     batch exactly like process_dataloader; bounded sample."""
     from idiaptts_amd.bench_support import (TorchRefFF, make_ff_batch, pad_batch, torch_ref_step)
     from idiaptts_amd.native_ff import FlatFFModel
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     dims, acts = (425, 512, 512, 187), ("tanh", "tanh", None)
     ref = TorchRefFF(FlatFFModel.reference_init(dims, 0), acts)
     opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
     x, y, lengths = make_ff_batch(n_utts, seed=0)
     lt = torch.from_numpy(lengths)
     xp, yp = pad_batch(x, lt), pad_batch(y, lt)
-    torch_ref_step(ref, opt, xp, yp, lt)  # warm-up
+    # torch's intra-op pool over-subscribes badly with all hardware threads of a big host:
+    # take the best of a short sweep (one step each) as the baseline's thread count.
+    best, cores = None, ncpu
+    for nt in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32), min(ncpu, 16)}):
+        torch.set_num_threads(nt)
+        torch_ref_step(ref, opt, xp, yp, lt)  # warm-up for this pool size
+        t = time.perf_counter()
+        torch_ref_step(ref, opt, xp, yp, lt)
+        t = time.perf_counter() - t
+        if best is None or t < best:
+            best, cores = t, nt
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     steps = 0
     while True:
@@ -65,6 +75,99 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
                       "frames)".format(steps, n_utts, int(lengths.sum()))}
 
 
+def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
+    """WORLD feature path on `n_utts` synthetic utterances (inputs resident in HBM, GPU time by
+    events on the launch stream): analysis wav -> (f0, mcep60, bap), synthesis
+    (mcep60, bap, f0) -> wav, MLPG on the 187-dim cmp, and the C-oracle CPU baseline on a
+    bounded sample (one utterance at a time on one core, like WorldFeatLabelGen.py:996)."""
+    from idiaptts_amd import lib, ops, world
+    from idiaptts_amd.bench_support import make_audio_batch
+    L = lib.load()
+    raws = make_audio_batch(n_utts, fs, seed=0)
+    hop = 5.0
+    order, alpha = 59, L.itts_mcep_alpha(fs)
+    n_fft = L.itts_cheaptrick_fft_size(fs, 71.0)
+    x_off = world.offsets([len(r) for r in raws])
+    f_off = world.offsets([world.num_frames(len(r), fs, hop) for r in raws])
+    audio_s = x_off[-1] / fs
+    x = torch.from_numpy(np.concatenate(raws)).to(dev)
+    stream = torch.cuda.current_stream()
+    res = {}
+
+    def analysis():
+        f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop), f_off, fs, hop)
+        _, mc, it = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop, n_fft, want_sp=False,
+                                        order=order, alpha=alpha, want_iters=True)
+        _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop, n_fft, want_ap=False,
+                         want_bap=torch.float32)
+        return f0, mc, bap, it
+
+    f0, mc, bap, iters = analysis()
+    torch.cuda.synchronize()
+    ms_an = hip_event_time_ms(analysis, stream, 3)
+    mc64 = mc.double()
+    bap64 = bap.double()
+    f0s = f0.clone()
+
+    def synthesis():
+        pw = ops.mgc2sp(mc64, alpha, n_fft, want_pow=True)
+        apd = ops.decode_aperiodicity(bap64, fs, n_fft)
+        return ops.world_synthesize(f0s, pw, apd, f_off, fs, hop)
+
+    synthesis()
+    torch.cuda.synchronize()
+    ms_sy = hip_event_time_ms(synthesis, stream, 3)
+    frames = f_off[-1]
+    res["world"] = {
+        "fs": fs, "utterances": n_utts, "audio_seconds": audio_s, "frames": frames,
+        "analysis_ms": ms_an, "analysis_rtf": ms_an * 1e-3 / audio_s,
+        "analysis_frames_per_s": frames / (ms_an * 1e-3),
+        "synthesis_ms": ms_sy, "synthesis_rtf": ms_sy * 1e-3 / audio_s,
+        "mcep_newton_iters_mean": float(iters.float().mean().item()),
+        # algorithmic HBM bytes per frame (SURVEY.md section 8d): fused analysis->features 640 + 248;
+        # synthesis 8536
+        "analysis_algorithmic_GBps": frames * (80 * 8 + 62 * 4) / (ms_an * 1e-3) / 1e9,
+        "synthesis_algorithmic_GBps": frames * 8536 / (ms_sy * 1e-3) / 1e9,
+    }
+    # MLPG on [T, 187] (62 static dims in 3 streams): algorithmic 2000 B / frame
+    feat = torch.randn(frames, 186, dtype=torch.float64, device=dev)
+    var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
+    ops.mlpg_generation(feat, var, 62, f_off)
+    torch.cuda.synchronize()
+    ms_ml = hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, f_off), stream, 5)
+    res["mlpg"] = {"ms": ms_ml, "frames_per_s": frames / (ms_ml * 1e-3),
+                   "algorithmic_GBps": frames * 2000 / (ms_ml * 1e-3) / 1e9,
+                   "frac_of_hbm_peak": frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if with_cpu:
+        from oracle import capi
+        t0 = time.perf_counter()
+        done_s = 0.0
+        t_an = t_sy = 0.0
+        k = 0
+        while time.perf_counter() - t0 < cpu_seconds and k < len(raws):
+            r = raws[k]
+            a = time.perf_counter()
+            f0c, spc, apc = capi.wav2world(r, fs)
+            bapc = capi.code_aperiodicity(apc, fs)
+            mcc = capi.mcep(np.sqrt(spc), order, alpha)
+            b = time.perf_counter()
+            la = capi.mgc2sp_logamp(mcc, alpha, n_fft)
+            pw = np.exp(la.astype(np.float32)).astype(np.float64) ** 2
+            apd = capi.decode_aperiodicity(bapc, fs, n_fft)
+            capi.synthesize(f0c, pw, apd, fs)
+            c = time.perf_counter()
+            t_an += b - a
+            t_sy += c - b
+            done_s += len(r) / fs
+            k += 1
+        res["world"]["cpu_baseline"] = {
+            "kind": "port", "cores": 1,
+            "sample": "{} utterances ({:.1f} s of audio) through the C oracle, one at a time on "
+                      "one core".format(k, done_s),
+            "analysis_rtf": t_an / done_s, "synthesis_rtf": t_sy / done_s}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +175,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--utts-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--world-utts", type=int, default=48,
+                    help="utterances in the WORLD feature-path section (0 = skip)")
+    ap.add_argument("--world-fs", type=int, default=16000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +272,10 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline_ff(args.utts_per_gpu)
+        extra = {}
+        if world == 1 and args.world_utts > 0:
+            extra = world_section(dev, args.world_utts, args.world_fs,
+                                  with_cpu=not args.no_cpu_baseline)
         out = {
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,6 +288,7 @@ def main():
                        "utts_per_gpu": args.utts_per_gpu, "parallelism": "dp{}".format(world)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out.update(extra)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -382,6 +382,7 @@ struct Mgc2spArgs {
   const double* invT;
   float* out_f32;     // exp(float(real))  (AudioProcessing.mcep_to_amp_sp :252-256)
   double* out_f64;    // raw log amplitude
+  double* out_pow;    // double(exp(float(real)))^2: what world_features_to_raw feeds WORLD (:925)
   const double2* g_tw;
 };
 
@@ -407,7 +408,9 @@ __global__ __launch_bounds__(NT) void mgc2sp_kernel(Mgc2spArgs a) {
   for (int k = threadIdx.x; k <= f2; k += NT) {
     const double re = z[k].x;
     if (a.out_f64) a.out_f64[g * (f2 + 1) + k] = re;
-    if (a.out_f32) a.out_f32[g * (f2 + 1) + k] = expf((float)re);
+    const float amp = expf((float)re);
+    if (a.out_f32) a.out_f32[g * (f2 + 1) + k] = amp;
+    if (a.out_pow) a.out_pow[g * (f2 + 1) + k] = (double)amp * (double)amp;
   }
 }
 
@@ -566,8 +569,8 @@ extern "C" int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, do
 }
 
 extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alpha, int fftlen,
-                           float* d_amp_f32, double* d_logamp_f64, void* stream) {
-  ITTS_REQUIRE(d_mc && (d_amp_f32 || d_logamp_f64), "null pointer");
+                           float* d_amp_f32, double* d_logamp_f64, double* d_pow_f64, void* stream) {
+  ITTS_REQUIRE(d_mc && (d_amp_f32 || d_logamp_f64 || d_pow_f64), "null pointer");
   ITTS_REQUIRE(T >= 0 && is_pow2(fftlen) && fftlen >= 64 && fftlen <= 8192, "bad fftlen");
   ITTS_REQUIRE(order >= 0 && order <= fftlen / 2 && order <= 1023, "bad order");
   if (T == 0) return ITTS_OK;
@@ -575,7 +578,7 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   if (!ctx) return ITTS_E_HIP;
   const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
   if (!ft) return ITTS_E_HIP;
-  Mgc2spArgs a{d_mc, T, order, fftlen, ilog2_host(fftlen), ft->invT, d_amp_f32, d_logamp_f64, ctx->twiddles};
+  Mgc2spArgs a{d_mc, T, order, fftlen, ilog2_host(fftlen), ft->invT, d_amp_f32, d_logamp_f64, d_pow_f64, ctx->twiddles};
   size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16 + (size_t)(order + 2) * 8;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -110,8 +110,8 @@ class FlatFFModel:
                    eps=1e-8, weight_decay=0.0, process_group=None, world_size=1):
         loss = self.loss_and_backward(x, target, row_valid, n_valid_global)
         if world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=process_group)
+            from .parallel import allreduce_flat_
+            allreduce_flat_(self.grads, process_group)
         self.step_count += 1
         ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count,
                       lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)

@@ -231,19 +231,21 @@ def mcep(amp_sp, order, alpha, eps=1e-8, miniter=2, maxiter=30, threshold=1e-3,
     return (out, iters) if want_iters else out
 
 
-def mgc2sp(mc, alpha, fftlen, want_logamp=False):
+def mgc2sp(mc, alpha, fftlen, want_logamp=False, want_pow=False):
     """exp(float32(pysptk.mgc2sp(mc, alpha, 0, fftlen).real)) -> [T, fftlen/2+1] f32
-    (or the f64 log amplitude when want_logamp)."""
+    (or the f64 log amplitude when want_logamp, or the f64 power spectrum when want_pow)."""
     L = _lib.load()
     _need(mc, torch.float64, "mc")
     mc = mc.contiguous()
     T, m1 = mc.shape
     K = fftlen // 2 + 1
-    out32 = None if want_logamp else torch.empty((T, K), dtype=torch.float32, device=mc.device)
+    out32 = None if (want_logamp or want_pow) else torch.empty((T, K), dtype=torch.float32,
+                                                               device=mc.device)
     out64 = torch.empty((T, K), dtype=torch.float64, device=mc.device) if want_logamp else None
+    outpw = torch.empty((T, K), dtype=torch.float64, device=mc.device) if want_pow else None
     _lib.check(L.itts_mgc2sp(_ptr(mc), T, m1 - 1, float(alpha), fftlen, _ptr(out32), _ptr(out64),
-                             _stream()), "itts_mgc2sp")
-    return out64 if want_logamp else out32
+                             _ptr(outpw), _stream()), "itts_mgc2sp")
+    return out64 if want_logamp else (outpw if want_pow else out32)
 
 
 def code_aperiodicity(ap, fs, dtype=torch.float64):

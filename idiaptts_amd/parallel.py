@@ -1,0 +1,62 @@
+"""Data-parallel plumbing (one process per GPU, torch.distributed: 'nccl' = RCCL over xGMI on
+the GPU box, 'gloo' in CPU tests).  The reference's multi-GPU hook is torch.nn.DataParallel
+(ModularModelHandlerPyTorch.py:732-735), single process and non-functional;
+the semantics defined here: synchronous DP whose result equals the single-GPU step on the
+concatenated batch.
+
+* utterances are sharded, never split (feature extraction / MLPG / synthesis need no collective);
+* the loss is sum(masked sq. err) / (GLOBAL valid frames * D) (NamedLoss 'mean_per_frame',
+  loss/NamedLoss.py:113-117), so local gradients are scaled by the global frame count BEFORE a
+  sum all-reduce of the flat gradient buffer -- no second pass, no averaging;
+* normalisation statistics are additive (MeanStdDevExtractor.combine_stats :163-204): one
+  all-reduce(sum) of (count, sum x, sum x^2 | sum x x^T).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_by_length(lengths, world_size):
+    """Greedy length-balanced partition of utterance indices (longest first onto the lightest
+    rank). Deterministic; returns world_size lists of indices (each sorted ascending)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += int(lengths[i])
+    return [sorted(s) for s in shards]
+
+
+def global_sum(value, group=None, device=None):
+    """Sum of a python number over all ranks (e.g. the global valid-frame count of a step)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())
+
+
+def allreduce_flat_(buf, group=None):
+    """In-place sum all-reduce of a flat buffer (gradients or statistics)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def allreduce_stats_(extractor, group=None, device=None):
+    """Merges Mean{StdDev,Covariance}Extractor statistics across ranks in place."""
+    second = "sum_squared_frames" if hasattr(extractor, "sum_squared_frames") \
+        else "sum_product_frames"
+    a = np.atleast_1d(np.asarray(extractor.sum_frames, dtype=np.float64))
+    b = np.atleast_1d(np.asarray(getattr(extractor, second), dtype=np.float64))
+    flat = torch.from_numpy(np.concatenate([[float(extractor.sum_length)], a.ravel(), b.ravel()]))
+    if device is not None:
+        flat = flat.to(device)
+    allreduce_flat_(flat, group)
+    flat = flat.cpu().numpy()
+    extractor.sum_length = int(round(flat[0]))
+    extractor.sum_frames = flat[1:1 + a.size].reshape(a.shape)
+    setattr(extractor, second, flat[1 + a.size:].reshape(b.shape))
+    return extractor

@@ -139,9 +139,11 @@ int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, double alpha,
               double* d_mc_f64, int* d_iters, void* stream);
 
 /* pysptk.mgc2sp(mc, alpha, gamma=0, fftlen): d_logamp_f64 [T, fftlen/2+1] = real part (log
- * amplitude); d_amp_f32 = exp(float32(real)) as AudioProcessing.mcep_to_amp_sp (:252-256). */
+ * amplitude); d_amp_f32 = exp(float32(real)) as AudioProcessing.mcep_to_amp_sp (:252-256);
+ * d_pow_f64 = float64(d_amp_f32)^2, the power spectrum world_features_to_raw hands to WORLD
+ * (WorldFeatLabelGen.py:925). Any of the three outputs may be NULL. */
 int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alpha, int fftlen,
-                float* d_amp_f32, double* d_logamp_f64, void* stream);
+                float* d_amp_f32, double* d_logamp_f64, double* d_pow_f64, void* stream);
 
 /* pyworld.code_aperiodicity (WorldFeatLabelGen.py:805) / pyworld.decode_aperiodicity (:940-941). */
 int itts_code_aperiodicity(const double* d_ap, int64_t T, int fft_size, int fs, double* d_bap_f64,

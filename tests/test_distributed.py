@@ -1,0 +1,114 @@
+"""N > 1 path on CPU (gloo, world_size 2): sharding, global frame count, flat-gradient
+all-reduce and statistics merge reproduce the single-process result."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from idiaptts_amd import parallel
+from idiaptts_amd.bench_support import TorchRefFF, make_ff_batch
+from idiaptts_amd.misc.normalisation.MeanCovarianceExtractor import MeanCovarianceExtractor
+from idiaptts_amd.misc.normalisation.MeanStdDevExtractor import MeanStdDevExtractor
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _layers(dims, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [((torch.rand(n, k, generator=g) - 0.5) * 0.2, (torch.rand(n, generator=g) - 0.5) * 0.2)
+            for k, n in zip(dims[:-1], dims[1:])]
+
+
+def _flat_grad(model):
+    return torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+
+
+def _local_grad(x, y, lengths, idx, n_global, dims, acts):
+    """Gradient of this shard's frames with the loss normalised by the GLOBAL frame count."""
+    model = TorchRefFF(_layers(dims, 7), acts).double()
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    rows = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in idx]) if len(idx) else \
+        np.zeros(0, dtype=np.int64)
+    pred = model(x[rows].double())
+    loss = ((pred - y[rows].double()) ** 2).sum() / (n_global * dims[-1])
+    loss.backward()
+    return _flat_grad(model), float(loss.detach())
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dims, acts = (12, 16, 9), ("tanh", None)
+    x, y, lengths = make_ff_batch(5, seed=3, in_dim=12, out_dim=9)
+    lengths = (lengths // 40).astype(np.int64) + 1
+    n = int(lengths.sum())
+    x, y = x[:n], y[:n]
+    shards = parallel.shard_by_length(lengths, world)
+    n_local = int(sum(lengths[i] for i in shards[rank]))
+    n_global = parallel.global_sum(n_local)
+    grad, loss = _local_grad(x, y, lengths, shards[rank], n_global, dims, acts)
+    parallel.allreduce_flat_(grad)
+    loss_g = parallel.global_sum(loss)
+    # statistics merge
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    ms, mc = MeanStdDevExtractor(), MeanCovarianceExtractor()
+    for i in shards[rank]:
+        ms.add_sample(y[offs[i]:offs[i + 1]].double().numpy())
+        mc.add_sample(y[offs[i]:offs[i + 1]].double().numpy())
+    parallel.allreduce_stats_(ms)
+    parallel.allreduce_stats_(mc)
+    if rank == 0:
+        ret["n_global"] = n_global
+        ret["grad"] = grad.numpy()
+        ret["loss"] = loss_g
+        ret["mean"], ret["std"] = ms.get_params()
+        ret["cov"] = mc.get_params()[1]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_equals_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    dims, acts = (12, 16, 9), ("tanh", None)
+    x, y, lengths = make_ff_batch(5, seed=3, in_dim=12, out_dim=9)
+    lengths = (lengths // 40).astype(np.int64) + 1
+    n = int(lengths.sum())
+    x, y = x[:n], y[:n]
+    assert ret["n_global"] == n
+    grad, loss = _local_grad(x, y, lengths, list(range(len(lengths))), float(n), dims, acts)
+    assert abs(ret["loss"] - loss) < 1e-12
+    assert np.abs(ret["grad"] - grad.numpy()).max() < 1e-12
+    ms, mc = MeanStdDevExtractor(), MeanCovarianceExtractor()
+    ms.add_sample(y.double().numpy())
+    mc.add_sample(y.double().numpy())
+    assert np.allclose(ret["mean"], ms.get_params()[0], atol=1e-12)
+    assert np.allclose(ret["std"], ms.get_params()[1], atol=1e-9)
+    assert np.allclose(ret["cov"], mc.get_params()[1], atol=1e-9)
+
+
+def test_shard_by_length_is_balanced_and_complete():
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(400, 2000, size=64)
+    for world in (1, 2, 4, 8):
+        shards = parallel.shard_by_length(lengths, world)
+        assert sorted(i for s in shards for i in s) == list(range(64))
+        loads = [sum(int(lengths[i]) for i in s) for s in shards]
+        assert max(loads) - min(loads) <= int(lengths.max())
+    assert parallel.shard_by_length([5, 5], 4) == [[0], [1], [], []]
