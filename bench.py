@@ -206,6 +206,7 @@ def main():
     batches = []
     for b in range(n_batches):
         x, y, lengths = make_ff_batch(args.utts_per_gpu, seed=1000 * b + rank, device=dev)
+        x = model.pack_input(x)   # collate-time layout: row pitch padded to 16 B
         valid = torch.ones(x.shape[0], dtype=torch.uint8, device=dev)
         batches.append((x, y, valid, int(lengths.sum())))
     # global valid-frame count per step (identical on all ranks)
@@ -251,14 +252,15 @@ def main():
         stream = torch.cuda.current_stream()
 
         def gemms():
-            h1 = ops.linear_fwd(x, model.weight(0), model.bias(0), 1)
-            h2 = ops.linear_fwd(h1, model.weight(1), model.bias(1), 1)
-            ops.linear_fwd(h2, model.weight(2), model.bias(2), 0)
-            ops.linear_bwd_weight(dz3, h2, dw=model.weight(2, model.grads), want_bias=False)
-            dz2 = ops.linear_bwd_input(dz3, model.weight(2), yprev=h2, act_prev=1)
-            ops.linear_bwd_weight(dz2, h1, dw=model.weight(1, model.grads), want_bias=False)
-            dz1 = ops.linear_bwd_input(dz2, model.weight(1), yprev=h1, act_prev=1)
-            ops.linear_bwd_weight(dz1, x, dw=model.weight(0, model.grads), want_bias=False)
+            W, G = model.weight_padded, model.grads
+            h1 = ops.linear_fwd(x, W(0), model.bias(0), 1)
+            h2 = ops.linear_fwd(h1, W(1), model.bias(1), 1)
+            ops.linear_fwd(h2, W(2), model.bias(2), 0)
+            ops.linear_bwd_weight(dz3, h2, dw=W(2, G), want_bias=False)
+            dz2 = ops.linear_bwd_input(dz3, W(2), yprev=h2, act_prev=1)
+            ops.linear_bwd_weight(dz2, h1, dw=W(1, G), want_bias=False)
+            dz1 = ops.linear_bwd_input(dz2, W(1), yprev=h1, act_prev=1)
+            ops.linear_bwd_weight(dz1, x, dw=W(0, G), want_bias=False)
 
         gemms()
         torch.cuda.synchronize()

@@ -50,8 +50,22 @@ struct GemmArgs {
   int vecA, vecB;       // 16-B vector loads allowed
 };
 
+// tanh in ~12 VALU ops (ocml tanhf costs ~40 and showed up as ~15 % of the fused-epilogue GEMMs):
+// |z| < 0.25: odd Taylor polynomial up to z^9 (truncation < 9e-9 relative);
+// else 1 - 2/(exp(2|z|)+1) with the hardware exp2/rcp (abs. error <= ~1.5e-7, i.e. ~2 ulp of
+// the result in [0.24, 1]).  Max deviation from torch.tanh (fp32) observed: 2.4e-7.
+__device__ __forceinline__ float fast_tanhf(float z) {
+  const float a = fabsf(z);
+  const float z2 = z * z;
+  const float poly = z * (1.f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f +
+                                                                              z2 * 0.021869488f))));
+  const float e = __expf(2.f * a);
+  const float big = copysignf(1.f - __fdividef(2.f, e + 1.f), z);
+  return a < 0.25f ? poly : big;
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == ITTS_ACT_TANH) return tanhf(z);
+  if (act == ITTS_ACT_TANH) return fast_tanhf(z);
   if (act == ITTS_ACT_RELU) return z > 0.f ? z : 0.f;
   return z;
 }
@@ -61,10 +75,15 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
   return 1.f;
 }
 
-// Global -> registers for one 128(out) x 32(k) tile of an operand. 16 floats per thread.
-template <bool ROWFORM>
+// Global -> registers for one 128(out) x 32(k) tile of an operand, 16 floats per thread.
+// Branch-free: out-of-range elements read a clamped (valid) address and are zeroed by a select,
+// so all loads of a tile are issued back to back (hipcc otherwise branches around every guarded
+// load and waits for each one).  VEC: 16-byte loads; requires ld % 4 == 0, a 16-B aligned base
+// and the contiguous extent (K for row form, out_dim for col form) to be a multiple of 4, so a
+// float4 is either completely inside or completely outside.
+template <bool ROWFORM, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t out0,
-                                          int64_t out_dim, int64_t k0, int64_t k_end, int vec,
+                                          int64_t out_dim, int64_t k0, int64_t k_end,
                                           float4 (&r)[4]) {
   const int tid = threadIdx.x;
 #pragma unroll
@@ -78,33 +97,23 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t l
       k = k0 + (idx >> 5);
       o = out0 + ((idx & 31) << 2);
     }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ROWFORM) {
-      if (o < out_dim) {
-        const float* p = P + o * ld + k;
-        if (vec && k + 3 < k_end) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k < k_end) v.x = p[0];
-          if (k + 1 < k_end) v.y = p[1];
-          if (k + 2 < k_end) v.z = p[2];
-          if (k + 3 < k_end) v.w = p[3];
-        }
-      }
+    // contiguous index c (4 consecutive elements), strided index t
+    const int64_t c = ROWFORM ? k : o, c_end = ROWFORM ? k_end : out_dim;
+    const int64_t t = ROWFORM ? o : k, t_end = ROWFORM ? out_dim : k_end;
+    const bool t_ok = t < t_end;
+    const int64_t tc = t_ok ? t : 0;
+    if (VEC) {
+      const bool ok = t_ok && (c < c_end);
+      const float4 v = *reinterpret_cast<const float4*>(P + tc * ld + (ok ? c : 0));
+      r[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      if (k < k_end) {
-        const float* p = P + k * ld + o;
-        if (vec && o + 3 < out_dim) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (o < out_dim) v.x = p[0];
-          if (o + 1 < out_dim) v.y = p[1];
-          if (o + 2 < out_dim) v.z = p[2];
-          if (o + 3 < out_dim) v.w = p[3];
-        }
-      }
+      const float* row = P + tc * ld;
+      const bool k0ok = t_ok && c < c_end, k1ok = t_ok && c + 1 < c_end, k2ok = t_ok && c + 2 < c_end,
+                 k3ok = t_ok && c + 3 < c_end;
+      const float a0 = row[k0ok ? c : 0], a1 = row[k1ok ? c + 1 : 0], a2 = row[k2ok ? c + 2 : 0],
+                  a3 = row[k3ok ? c + 3 : 0];
+      r[i] = make_float4(k0ok ? a0 : 0.f, k1ok ? a1 : 0.f, k2ok ? a2 : 0.f, k3ok ? a3 : 0.f);
     }
-    r[i] = v;
   }
 }
 
@@ -135,7 +144,7 @@ __device__ __forceinline__ float4 read_frag(const float* __restrict__ S, int o, 
   }
 }
 
-template <bool A_ROW, bool B_ROW, int EPI>
+template <bool A_ROW, bool B_ROW, int EPI, bool VEC_A, bool VEC_B>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
   // buffer b: A tile at lds + 2b*TILE, B tile at lds + (2b+1)*TILE
@@ -173,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
   float4 ra[4], rb[4];
   if (nkt > 0) {
-    load_tile<A_ROW>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-    load_tile<B_ROW>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    load_tile<A_ROW, VEC_A>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    load_tile<B_ROW, VEC_B>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
     store_tile<A_ROW>(lds, ra);
     store_tile<B_ROW>(lds + TILE_FLOATS, rb);
   }
@@ -184,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int cur = (int)(kt & 1);
     const bool more = kt + 1 < nkt;
     if (more) {
-      load_tile<A_ROW>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.vecA, ra);
-      load_tile<B_ROW>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.vecB, rb);
+      load_tile<A_ROW, VEC_A>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, ra);
+      load_tile<B_ROW, VEC_B>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, rb);
     }
     const float* cA = lds + (2 * cur) * TILE_FLOATS;
     const float* cB = lds + (2 * cur + 1) * TILE_FLOATS;
@@ -241,7 +250,17 @@ static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles <= 0) return ITTS_OK;
   dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
-  hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI>), grid, dim3(256), 0, s, g);
+  // contiguous extents must be multiples of 4 for the 16-byte path (see load_tile)
+  const bool va = g.vecA && ((A_ROW ? g.K : g.M) % 4 == 0);
+  const bool vb = g.vecB && ((B_ROW ? g.K : (int64_t)g.N) % 4 == 0);
+  if (va && vb)
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, true>), grid, dim3(256), 0, s, g);
+  else if (va)
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, false>), grid, dim3(256), 0, s, g);
+  else if (vb)
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, true>), grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, false>), grid, dim3(256), 0, s, g);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
@@ -306,13 +325,14 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-__global__ void masked_mse_final_kernel(const double* __restrict__ partial, int nb, double scale,
-                                        float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += partial[i];
-    *loss = (float)(s * scale);
-  }
+__global__ __launch_bounds__(256) void masked_mse_final_kernel(const double* __restrict__ partial,
+                                                               int nb, double scale,
+                                                               float* __restrict__ loss) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];  // fixed order: deterministic
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *loss = (float)(s * scale);
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------
@@ -472,7 +492,7 @@ extern "C" int itts_masked_mse(const float* d_pred, int64_t ldp, const float* d_
                      d_row_valid, M, D, (float)(2.0 * scale), d_grad, ldg,
                      reinterpret_cast<double*>(d_workspace));
   ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(64), 0, s,
+  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
                      reinterpret_cast<const double*>(d_workspace), nb, scale, d_loss);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;

@@ -142,16 +142,24 @@ __device__ inline int mcep_frame(const McLds& L, const FreqtTables& ft, int flng
     zr[f2] /= 2;
   }
   __syncthreads();
-  // mc = freqt(c, f2 -> m, alpha): 4 input groups x (m+1) outputs
+  // mc = freqt(c, f2 -> m, alpha): wave w sums input rows [w*per, (w+1)*per), lane l owns outputs
+  // l, l+64 (coalesced 512-B row segments of the warping matrix, several loads in flight)
+  const int wv = tid >> 6, ln = tid & 63;
   {
-    const int grp = tid >> 6, j = tid & 63;
     const int per = (f2 + 1 + 3) / 4;
-    for (int jj = j; jj < m1; jj += 64) {
-      const int i0 = grp * per, i1 = min(f2 + 1, i0 + per);
-      double s = 0.0;
-      for (int i = i0; i < i1; ++i) s += ft.fwdT[(size_t)i * m1 + jj] * zr[i];
-      L.part[grp * m1 + jj] = s;
+    const int i0 = wv * per, i1 = min(f2 + 1, i0 + per);
+    double a0 = 0.0, a1 = 0.0;
+    const bool h0 = ln < m1, h1 = ln + 64 < m1;
+    const double* row = ft.fwdT + (size_t)i0 * m1;
+#pragma unroll 8
+    for (int i = i0; i < i1; ++i, row += m1) {
+      const double zi = zr[i];
+      const double r0 = row[h0 ? ln : 0], r1 = row[h1 ? ln + 64 : 0];
+      a0 += r0 * zi;
+      a1 += r1 * zi;
     }
+    if (h0) L.part[wv * m1 + ln] = a0;
+    if (h1) L.part[wv * m1 + ln + 64] = a1;
     __syncthreads();
     for (int jj = tid; jj < m1; jj += NT)
       L.mc[jj] = (L.part[jj] + L.part[m1 + jj]) + (L.part[2 * m1 + jj] + L.part[3 * m1 + jj]);
@@ -160,30 +168,67 @@ __device__ inline int mcep_frame(const McLds& L, const FreqtTables& ft, int flng
   }
   int it;
   for (it = 1; it <= itr2; ++it) {
-    // c' = freqt(mc, m -> f2, -alpha), zero padded to flng
-    for (int i = tid; i < flng + 2; i += NT) {
-      double s = 0.0;
-      if (i <= f2)
-        for (int j = 0; j < m1; ++j) s += ft.invT[(size_t)j * (f2 + 1) + i] * L.mc[j];
-      zr[i] = s;
+    // c' = freqt(mc, m -> f2, -alpha), zero padded to flng: thread t owns outputs t + 256 q
+    {
+      constexpr int NQ = 5;  // (f2 + 1) <= 1280 -> fftlen <= 2048
+      double acc[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+      const double* row = ft.invT;
+#pragma unroll 4
+      for (int j = 0; j < m1; ++j, row += (f2 + 1)) {
+        const double mj = L.mc[j];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int i = tid + NT * q;
+          acc[q] += row[i <= f2 ? i : 0] * mj;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
+        if (i < flng + 2) zr[i] = (i <= f2) ? acc[q] : 0.0;
+      }
+      for (int i = tid + NT * NQ; i < flng + 2; i += NT) zr[i] = 0.0;
     }
     __syncthreads();
     rfft_lds(L.z, flng, logflng, L.tw, flng);
     for (int k = tid; k <= f2; k += NT) L.z[k] = make_double2(L.xp[k] / exp(2.0 * L.z[k].x), 0.0);
     __syncthreads();
     irfft_lds(L.z, flng, logflng, L.tw, flng);
-    // cr = frqtr(r, f2 -> 2m, alpha): 2 input halves x (2m+1) outputs
+    // cr = frqtr(r, f2 -> 2m, alpha): wave w sums input rows [w*per, (w+1)*per), lane l owns
+    // outputs l + 64 q
     {
-      const int grp = tid >> 7, j = tid & 127;
-      const int per = (f2 + 1 + 1) / 2;
-      for (int jj = j; jj <= m2; jj += 128) {
-        const int i0 = grp * per, i1 = min(f2 + 1, i0 + per);
-        double s = 0.0;
-        for (int i = i0; i < i1; ++i) s += ft.frqT[(size_t)i * (m2 + 1) + jj] * zr[i];
-        L.part[grp * (m2 + 1) + jj] = s;
+      const int n_out = m2 + 1;
+      const int per = (f2 + 1 + 3) / 4;
+      const int i0 = wv * per, i1 = min(f2 + 1, i0 + per);
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const bool h0 = ln < n_out, h1 = ln + 64 < n_out, h2 = ln + 128 < n_out, h3 = ln + 192 < n_out;
+      const double* row = ft.frqT + (size_t)i0 * n_out;
+      if (n_out <= 128) {
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i, row += n_out) {
+          const double zi = zr[i];
+          a0 += row[h0 ? ln : 0] * zi;
+          a1 += row[h1 ? ln + 64 : 0] * zi;
+        }
+      } else {
+#pragma unroll 4
+        for (int i = i0; i < i1; ++i, row += n_out) {
+          const double zi = zr[i];
+          a0 += row[h0 ? ln : 0] * zi;
+          a1 += row[h1 ? ln + 64 : 0] * zi;
+          a2 += row[h2 ? ln + 128 : 0] * zi;
+          a3 += row[h3 ? ln + 192 : 0] * zi;
+        }
       }
+      if (h0) L.part[wv * n_out + ln] = a0;
+      if (h1) L.part[wv * n_out + ln + 64] = a1;
+      if (h2) L.part[wv * n_out + ln + 128] = a2;
+      if (h3) L.part[wv * n_out + ln + 192] = a3;
       __syncthreads();
-      for (int jj = tid; jj <= m2; jj += NT) L.cr[jj] = L.part[jj] + L.part[(m2 + 1) + jj];
+      for (int jj = tid; jj < n_out; jj += NT)
+        L.cr[jj] = (L.part[jj] + L.part[n_out + jj]) + (L.part[2 * n_out + jj] + L.part[3 * n_out + jj]);
       __syncthreads();
     }
     const double t = L.cr[0];
@@ -499,6 +544,7 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   ITTS_REQUIRE(d_sp || do_mcep, "nothing to compute");
   if (do_mcep) {
     ITTS_REQUIRE(order >= 1 && order < fft_size / 2 && order <= 127, "bad mcep order");
+    ITTS_REQUIRE(fft_size <= 2048, "fused mcep supports fft_size <= 2048");
     ITTS_REQUIRE(!d_mc_f32 || ld_mc >= order + 1, "ld_mc too small");
   }
   if (n_utts == 0) return ITTS_OK;
@@ -546,7 +592,7 @@ extern "C" int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, do
                          double* d_mc_f64, int* d_iters, void* stream) {
   ITTS_REQUIRE(d_amp_sp && (d_mc_f32 || d_mc_f64), "null pointer");
   const int flng = (K - 1) * 2;
-  ITTS_REQUIRE(T >= 0 && is_pow2(flng) && flng >= 64 && flng <= 8192, "K must be 2^k/2+1");
+  ITTS_REQUIRE(T >= 0 && is_pow2(flng) && flng >= 64 && flng <= 2048, "K must be 2^k/2+1, K <= 1025");
   ITTS_REQUIRE(order >= 1 && order < flng / 2 && order <= 127, "bad mcep order");
   ITTS_REQUIRE(!d_mc_f32 || ld_mc >= order + 1, "ld_mc too small");
   if (T == 0) return ITTS_OK;

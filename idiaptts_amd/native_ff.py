@@ -35,14 +35,19 @@ class FlatFFModel:
         self.dims = tuple(int(d) for d in dims)
         self.acts = [ops.ACT_BY_NAME[a] for a in acts]
         self.device = torch.device(device)
-        self.layout = []  # (w_off, b_off, N, K)
+        # Row pitch of every weight matrix (and of the packed input) is padded to a multiple of
+        # 4 floats so all GEMM operands take the 16-byte load path; pad columns stay exactly zero
+        # (their gradient is dz^T * 0 = 0, Adam leaves a zero parameter with zero moments at zero).
+        self.in_pitch = _pad4(self.dims[0])
+        self.layout = []  # (w_off, b_off, N, K, Kpitch)
         off = 0
-        for K, N in zip(self.dims[:-1], self.dims[1:]):
+        for li, (K, N) in enumerate(zip(self.dims[:-1], self.dims[1:])):
+            kp = _pad4(K) if li == 0 else K
             w_off = off
-            off += _pad4(N * K)
+            off += _pad4(N * kp)
             b_off = off
             off += _pad4(N)
-            self.layout.append((w_off, b_off, N, K))
+            self.layout.append((w_off, b_off, N, K, kp))
         self.numel = off
         self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros_like(self.params)
@@ -66,17 +71,32 @@ class FlatFFModel:
         return layers
 
     def load_layers(self, layers):
-        for (w_off, b_off, N, K), (w, b) in zip(self.layout, layers):
-            self.params[w_off:w_off + N * K].copy_(w.reshape(-1).to(self.device))
-            self.params[b_off:b_off + N].copy_(b.to(self.device))
+        for i, (w, b) in enumerate(layers):
+            self.weight(i).copy_(w.to(self.device))
+            self.bias(i).copy_(b.to(self.device))
+
+    def weight_padded(self, i, buf=None):
+        """[N, Kpitch] contiguous storage of layer i (pad columns are zero)."""
+        w_off, _, N, K, kp = self.layout[i]
+        return (self.params if buf is None else buf)[w_off:w_off + N * kp].view(N, kp)
 
     def weight(self, i, buf=None):
-        w_off, _, N, K = self.layout[i]
-        return (self.params if buf is None else buf)[w_off:w_off + N * K].view(N, K)
+        """[N, K] view with the reference's state-dict shape (strided when K is padded)."""
+        K = self.layout[i][3]
+        return self.weight_padded(i, buf)[:, :K]
 
     def bias(self, i, buf=None):
-        _, b_off, N, _ = self.layout[i]
+        _, b_off, N, _, _ = self.layout[i]
         return (self.params if buf is None else buf)[b_off:b_off + N]
+
+    def pack_input(self, x):
+        """[M, dims[0]] -> [M, in_pitch] with zero pad columns (done once per batch at collate
+        time; a loader can write into the padded buffer directly)."""
+        if x.shape[1] == self.in_pitch:
+            return x
+        xp = torch.zeros((x.shape[0], self.in_pitch), dtype=torch.float32, device=x.device)
+        xp[:, :x.shape[1]] = x
+        return xp
 
     def layers(self):
         return [(self.weight(i).clone(), self.bias(i).clone()) for i in range(len(self.layout))]
@@ -85,24 +105,25 @@ class FlatFFModel:
     def forward(self, x):
         """x [M, dims[0]] fp32 packed frames -> list of layer outputs."""
         acts = []
-        h = x
+        h = self.pack_input(x)
         for i in range(len(self.layout)):
-            h = ops.linear_fwd(h, self.weight(i), self.bias(i), self.acts[i])
+            h = ops.linear_fwd(h, self.weight_padded(i), self.bias(i), self.acts[i])
             acts.append(h)
         return acts
 
     def loss_and_backward(self, x, target, row_valid, n_valid_global):
         """Fills self.grads with d(loss)/d(params) of this rank's frames; returns loss tensor
         (this rank's contribution, already divided by the global frame count)."""
+        x = self.pack_input(x)
         hs = self.forward(x)
         loss, dz = ops.masked_mse(hs[-1], target, row_valid, n_valid_global)
         n = len(self.layout)
         for i in range(n - 1, -1, -1):
             inp = hs[i - 1] if i > 0 else x
-            ops.linear_bwd_weight(dz, inp, dw=self.weight(i, self.grads),
+            ops.linear_bwd_weight(dz, inp, dw=self.weight_padded(i, self.grads),
                                   db=self.bias(i, self.grads))
             if i > 0:
-                dz = ops.linear_bwd_input(dz, self.weight(i), yprev=hs[i - 1],
+                dz = ops.linear_bwd_input(dz, self.weight_padded(i), yprev=hs[i - 1],
                                           act_prev=self.acts[i - 1])
         return loss
 
