@@ -1,0 +1,317 @@
+// (Bi)LSTM recurrence for padded batches of frame sequences -- the recurrent half of the
+// acoustic model of BASELINE config 3 (3 x 512 BiLSTM).  Replaces what torch.nn.LSTM does between
+// pack_padded_sequence(enforce_sorted=False) and pad_packed_sequence in
+// rnn_dyn/RNNWrapper.py:45-107 (cuDNN / MIOpen RNN in the reference).
+//
+// Split of the work (per layer):
+//   * gin = X W_ih^T + (b_ih + b_hh) for ALL time steps and both directions is ONE fp32-MFMA GEMM
+//     (nn.hip), so are dX, dW_ih, dW_hh and the bias gradients in the backward pass;
+//   * only the true recurrence h_{t-1} W_hh^T runs per time step.  One launch per step, both
+//     directions in it: the kernel boundary is the grid-wide dependency (~1.5 us; an in-kernel
+//     grid barrier costs 4-7 us on this chip).  A workgroup owns a slice of hidden units, keeps
+//     its W_hh rows in LDS and streams h_{t-1} [B, H] from L2 through v_mfma_f32_16x16x4_f32
+//     (exact fp32, same K-permutation trick as the GEMM: one 16-byte load feeds 4 MFMAs).
+//   * packed-sequence semantics: row b is active for step s < len_b; the forward direction
+//     visits t = s, the reverse direction t = len_b - 1 - s (it starts at each sequence's own
+//     last frame); padded outputs are zero; the state of an inactive row is frozen.
+// Gate order i, f, g, o and the two bias vectors follow torch.nn.LSTM.
+#include <algorithm>
+
+#include "common.h"
+
+namespace itts {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FW_UNITS = 4;    // hidden units per workgroup in the forward step (16 gate rows)
+constexpr int BW_UNITS = 16;   // hidden units per workgroup in the backward step
+
+struct LstmArgs {
+  // geometry
+  int T, B, H, ndir;
+  const int* lengths;     // [B] device
+  // per-row layout of time-major tensors: row(t, b) = t * B + b
+  const float* gin;       // [T*B, ndir*4H] input projections incl. both biases
+  const float* whh;       // [ndir][4H][H]
+  const float* whh_t;     // [ndir][H][4H]   (backward)
+  const float* h0;        // [ndir][H] initial state (broadcast over the batch)
+  const float* c0;
+  float* hs;              // [2 parity][ndir][B][H] running hidden state
+  float* cs;              // [2 parity][ndir][B][H] running cell state / running dc (backward)
+  float* y;               // [T*B, ndir*H] layer output
+  float* gates;           // [T*B, ndir*4H] post-activation gates i,f,g,o (saved for backward)
+  float* csave;           // [T*B, ndir*H] c_t
+  float* hprev;           // [T*B, ndir*H] h_{t-1} that entered step t (for dW_hh)
+  // backward
+  const float* dy;        // [T*B, ndir*H]
+  float* dg;              // [T*B, ndir*4H] gradient wrt pre-activation gates
+  int step;
+};
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+// time index visited by row b at recurrence step s, or -1 when the row is inactive
+__device__ __forceinline__ int time_of(int dir, int s, int len) {
+  if (s >= len) return -1;
+  return dir == 0 ? s : len - 1 - s;
+}
+
+// ---- forward step -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, B = a.B, G4 = 4 * H;
+  const int ldw = H + 4;
+  float* Ws = smem;                 // [16][H+4]: row n = gate*4 + u  <->  W_hh[gate*H + j0 + u][:]
+  float* Gt = smem + 16 * ldw;      // [64][17] gate pre-activations of one batch tile
+  const int dir = blockIdx.y;
+  const int j0 = blockIdx.x * FW_UNITS;
+  const int par = a.step & 1;
+  const float* whh = a.whh + (size_t)dir * G4 * H;
+  for (int idx = threadIdx.x; idx < 16 * (H / 4); idx += 256) {
+    const int n = idx / (H / 4), q = idx - n * (H / 4);
+    const int grow = (n >> 2) * H + j0 + (n & 3);
+    *reinterpret_cast<float4*>(Ws + n * ldw + 4 * q) =
+        *reinterpret_cast<const float4*>(whh + (size_t)grow * H + 4 * q);
+  }
+  __syncthreads();
+  const float* hprev = a.hs + ((size_t)par * a.ndir + dir) * B * H;
+  const float* cprev = a.cs + ((size_t)par * a.ndir + dir) * B * H;
+  float* hnext = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
+  float* cnext = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    // gates[b, n] = sum_k h_prev[b, k] * Ws[n, k]   (16 batch rows per wave)
+    const int row = b0 + wv * 16 + lr;
+    const bool rok = row < B;
+    const float* hp = hprev + (size_t)(rok ? row : 0) * H + 4 * kg;
+    const float* wp = Ws + lr * ldw + 4 * kg;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < H / 16; ++s) {
+      float4 av = *reinterpret_cast<const float4*>(hp + 16 * s);
+      if (!rok) av = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv = *reinterpret_cast<const float4*>(wp + 16 * s);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    __syncthreads();  // previous tile's Gt readers are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gt[(wv * 16 + kg * 4 + r) * 17 + lr] = acc[r];
+    __syncthreads();
+    // cell update: thread -> (batch row, unit)
+    const int bl = threadIdx.x >> 2, u = threadIdx.x & 3;
+    const int b = b0 + bl;
+    if (b < B) {
+      const int j = j0 + u;
+      const int len = a.lengths[b];
+      const int t = time_of(dir, a.step, len);
+      const float hp_v = hprev[(size_t)b * H + j], cp_v = cprev[(size_t)b * H + j];
+      float hn = hp_v, cn = cp_v;
+      if (t >= 0) {
+        const size_t r = (size_t)t * B + b;
+        const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+        const float pi = Gt[bl * 17 + 0 + u] + gi[0];
+        const float pf = Gt[bl * 17 + 4 + u] + gi[H];
+        const float pg = Gt[bl * 17 + 8 + u] + gi[2 * H];
+        const float po = Gt[bl * 17 + 12 + u] + gi[3 * H];
+        const float ig = sigmoidf_acc(pi), fg = sigmoidf_acc(pf), gg = tanhf(pg), og = sigmoidf_acc(po);
+        cn = fg * cp_v + ig * gg;
+        hn = og * tanhf(cn);
+        a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
+        if (a.gates) {
+          float* gs = a.gates + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+          gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+          a.csave[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = cn;
+          a.hprev[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hp_v;
+        }
+      }
+      hnext[(size_t)b * H + j] = hn;
+      cnext[(size_t)b * H + j] = cn;
+    }
+  }
+}
+
+// state init: hs/cs[parity 0][dir][b][:] = h0/c0[dir][:]
+__global__ void lstm_init_state_kernel(const float* __restrict__ h0, const float* __restrict__ c0,
+                                       float* __restrict__ hs, float* __restrict__ cs, int ndir, int B, int H) {
+  const int64_t n = (int64_t)ndir * B * H;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H);
+    const int d = (int)(i / ((int64_t)B * H));
+    hs[i] = h0 ? h0[d * H + j] : 0.f;
+    cs[i] = c0 ? c0[d * H + j] : 0.f;
+  }
+}
+
+// ---- backward step ----------------------------------------------------------------------------------
+// Processes recurrence step s = a.step (called with s = T-1 ... 0). For row b active at s:
+//   dh = dy[t] + dG[t_{s+1}] W_hh   (second term only if the row is active at s+1)
+//   standard LSTM cell gradients -> dG[t], running dc (cs buffers, parity by step)
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, B = a.B, G4 = 4 * H;
+  const int ldw = G4 + 4;
+  float* Wt = smem;                  // [16][4H+4]: row n <-> W_hh^T[j0 + n][:]  (k = gate row)
+  float* Dt = smem + 16 * ldw;       // [64][17] dh_rec of one batch tile
+  const int dir = blockIdx.y;
+  const int j0 = blockIdx.x * BW_UNITS;
+  const int par = a.step & 1;
+  const float* wt = a.whh_t + (size_t)dir * H * G4;
+  for (int idx = threadIdx.x; idx < 16 * (G4 / 4); idx += 256) {
+    const int n = idx / (G4 / 4), q = idx - n * (G4 / 4);
+    *reinterpret_cast<float4*>(Wt + n * ldw + 4 * q) =
+        *reinterpret_cast<const float4*>(wt + (size_t)(j0 + n) * G4 + 4 * q);
+  }
+  __syncthreads();
+  // running dc: written for step s into parity (s&1), read from parity ((s+1)&1)
+  const float* dc_in = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
+  float* dc_out = a.cs + ((size_t)par * a.ndir + dir) * B * H;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int row = b0 + wv * 16 + lr;
+    bool has_next = false;
+    const float* dgp = a.dg;
+    if (row < B) {
+      const int len = a.lengths[row];
+      const int tn = time_of(dir, a.step + 1, len);
+      if (tn >= 0) {
+        has_next = true;
+        dgp = a.dg + ((size_t)tn * B + row) * ldg + (size_t)dir * G4 + 4 * kg;
+      }
+    }
+    const float* wp = Wt + lr * ldw + 4 * kg;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < G4 / 16; ++s) {
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_next) av = *reinterpret_cast<const float4*>(dgp + 16 * s);
+      const float4 bv = *reinterpret_cast<const float4*>(wp + 16 * s);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dt[(wv * 16 + kg * 4 + r) * 17 + lr] = acc[r];
+    __syncthreads();
+    // elementwise: thread -> batch row bl, 4 of the 16 units
+    const int bl = threadIdx.x >> 2, uq = threadIdx.x & 3;
+    const int b = b0 + bl;
+    if (b < B) {
+      const int len = a.lengths[b];
+      const int t = time_of(dir, a.step, len);
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        const int n = uq * 4 + uu;
+        const int j = j0 + n;
+        float dc_keep = 0.f;
+        if (t >= 0) {
+          const size_t r = (size_t)t * B + b;
+          const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
+          const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
+          const float ct = a.csave[r * ldh + (size_t)dir * H + j];
+          const int tp = time_of(dir, a.step - 1, len);  // previous recurrence step of this row
+          const float cp = (a.step > 0 && tp >= 0) ? a.csave[((size_t)tp * B + b) * ldh + (size_t)dir * H + j]
+                                                   : (a.c0 ? a.c0[dir * H + j] : 0.f);
+          const float tc = tanhf(ct);
+          const float dh = a.dy[r * ldh + (size_t)dir * H + j] + Dt[bl * 17 + n];
+          const float dcv = dh * og * (1.f - tc * tc) + dc_in[(size_t)b * H + j];
+          float* dgo = a.dg + r * ldg + (size_t)dir * G4 + j;
+          dgo[0] = dcv * gg * ig * (1.f - ig);
+          dgo[H] = dcv * cp * fg * (1.f - fg);
+          dgo[2 * H] = dcv * ig * (1.f - gg * gg);
+          dgo[3 * H] = dh * tc * og * (1.f - og);
+          dc_keep = dcv * fg;
+        }
+        dc_out[(size_t)b * H + j] = dc_keep;
+      }
+    }
+  }
+}
+
+}  // namespace itts
+
+using namespace itts;
+
+static int lstm_check(int T, int B, int H, int ndir) {
+  ITTS_REQUIRE(T >= 1 && B >= 1 && (ndir == 1 || ndir == 2), "bad sizes");
+  ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 2048, "hidden size must be a multiple of 16 (<= 2048)");
+  return ITTS_OK;
+}
+
+extern "C" int64_t itts_lstm_state_bytes(int B, int H, int ndir) {
+  if (B <= 0 || H <= 0 || ndir <= 0) return 0;
+  return (int64_t)2 * 2 * ndir * B * H * 4;  // hs + cs, two parities each
+}
+
+// Runs the recurrence of one (bi)directional LSTM layer over T steps.
+extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0,
+                                   const float* d_c0, const int* d_lengths, int T, int B, int H, int ndir,
+                                   float* d_y, float* d_gates, float* d_csave, float* d_hprev,
+                                   float* d_hn, float* d_cn, void* d_state, void* stream) {
+  ITTS_REQUIRE(d_gin && d_whh && d_lengths && d_y && d_state, "null pointer");
+  ITTS_REQUIRE((d_gates == nullptr) == (d_csave == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
+               "gates / csave / hprev must be given together (training) or all NULL (inference)");
+  int rc = lstm_check(T, B, H, ndir);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  LstmArgs a{};
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.gin = d_gin; a.whh = d_whh;
+  a.h0 = d_h0; a.c0 = d_c0; a.y = d_y; a.gates = d_gates; a.csave = d_csave; a.hprev = d_hprev;
+  const size_t st = (size_t)2 * ndir * B * H;
+  a.hs = reinterpret_cast<float*>(d_state);
+  a.cs = a.hs + st;
+  ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, (size_t)T * B * ndir * H * 4, s));  // padded frames are zero
+  const int64_t n = (int64_t)ndir * B * H;
+  hipLaunchKernelGGL(lstm_init_state_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256),
+                     0, s, d_h0, d_c0, a.hs, a.cs, ndir, B, H);
+  ITTS_LAUNCH_CHECK();
+  const size_t lds = (size_t)(16 * (H + 4) + 64 * 17) * 4;
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_step_fwd_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int step = 0; step < T; ++step) {
+    a.step = step;
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(H / FW_UNITS, ndir), dim3(256), lds, s, a);
+  }
+  ITTS_LAUNCH_CHECK();
+  // final states live in parity (T & 1)
+  const size_t off = (size_t)(T & 1) * ndir * B * H;
+  if (d_hn) ITTS_HIP_CHECK(hipMemcpyAsync(d_hn, a.hs + off, n * 4, hipMemcpyDeviceToDevice, s));
+  if (d_cn) ITTS_HIP_CHECK(hipMemcpyAsync(d_cn, a.cs + off, n * 4, hipMemcpyDeviceToDevice, s));
+  return ITTS_OK;
+}
+
+// Backward recurrence: fills d_dg [T*B, ndir*4H] (zero on padded rows) from d_dy and the saved
+// forward tensors. d_whh_t is W_hh transposed per direction ([ndir][H][4H]).
+extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_c0,
+                                   const float* d_gates, const float* d_csave, const int* d_lengths,
+                                   int T, int B, int H, int ndir, float* d_dg, void* d_state, void* stream) {
+  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_csave && d_lengths && d_dg && d_state, "null pointer");
+  int rc = lstm_check(T, B, H, ndir);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  LstmArgs a{};
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.whh_t = d_whh_t; a.c0 = d_c0;
+  a.gates = const_cast<float*>(d_gates); a.csave = const_cast<float*>(d_csave); a.dy = d_dy; a.dg = d_dg;
+  const size_t st = (size_t)2 * ndir * B * H;
+  a.hs = reinterpret_cast<float*>(d_state);
+  a.cs = a.hs + st;
+  ITTS_HIP_CHECK(hipMemsetAsync(d_dg, 0, (size_t)T * B * ndir * 4 * H * 4, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(a.cs, 0, st * 4, s));
+  const size_t lds = (size_t)(16 * (4 * H + 4) + 64 * 17) * 4;
+  ITTS_REQUIRE(lds <= 160 * 1024, "hidden size too large for the backward LDS tile");
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_step_bwd_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int step = T - 1; step >= 0; --step) {
+    a.step = step;
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(H / BW_UNITS, ndir), dim3(256), lds, s, a);
+  }
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}

@@ -181,6 +181,27 @@ int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* 
                           double frame_period_ms, int fft_size, double preemphasis, float* d_y_f32,
                           double* d_y_f64, void* stream);
 
+/* ---- acoustic model: (Bi)LSTM recurrence (torch.nn.LSTM inside rnn_dyn/RNNWrapper.py:45-107) ------
+ * Time-major rows: row(t, b) = t*B + b.  Direction d owns column block d of every tensor.
+ *   d_gin    [T*B, ndir*4H]  x W_ih^T + b_ih + b_hh for all steps (one itts_linear_fwd call)
+ *   d_whh    [ndir][4H][H]   gate order i, f, g, o
+ *   d_h0/c0  [ndir][H] or NULL (zeros); d_lengths [B] int32 (packed-sequence semantics,
+ *            enforce_sorted=False: the reverse direction starts at each row's own last frame)
+ *   d_y      [T*B, ndir*H]   zero on padded frames (pad_packed_sequence)
+ *   d_gates / d_csave / d_hprev: tensors saved for the backward pass (all NULL for inference)
+ *   d_hn/d_cn [ndir][B][H]   final states (may be NULL); d_state >= itts_lstm_state_bytes bytes */
+int64_t itts_lstm_state_bytes(int B, int H, int ndir);
+int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0, const float* d_c0,
+                        const int* d_lengths, int T, int B, int H, int ndir, float* d_y,
+                        float* d_gates, float* d_csave, float* d_hprev, float* d_hn, float* d_cn,
+                        void* d_state, void* stream);
+/* d_dg [T*B, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [T*B, ndir*H]; d_whh_t is W_hh
+ * transposed per direction ([ndir][H][4H]).  dW_ih, dW_hh, db and dX follow from d_dg with
+ * itts_linear_bwd_weight / itts_linear_bwd_input. */
+int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_c0,
+                        const float* d_gates, const float* d_csave, const int* d_lengths, int T, int B,
+                        int H, int ndir, float* d_dg, void* d_state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
