@@ -168,6 +168,50 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
     return res
 
 
+def bilstm_section(dev, n_utts=64, steps=3):
+    """BASELINE config 3: 425 -> 3 x 512 BiLSTM -> 187, batch 64 padded utterances, Adam, fp32,
+    through the drop-in module stack (RNNDyn + NamedLoss + fused HIP Adam)."""
+    import types
+    from idiaptts_amd.bench_support import make_ff_batch
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    from idiaptts_amd.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import \
+        NamedForwardWrapper
+    torch.manual_seed(0)
+    hp = types.SimpleNamespace(model_type="RNNDYN-3_BiLSTM_512-1_FC_187", batch_first=False,
+                               dropout=0.0)
+    h = Handler()
+    h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((425,), hp),
+                                              input_names=["questions"], batch_first=False,
+                                              name="AcousticModel",
+                                              output_names=["pred_acoustic_features"]))
+    h.set_optimiser("Adam", lr=1e-3)
+    h.set_losses([NamedLoss.Config(name="MSELoss_acoustic_features", type_="MSELoss",
+                                   seq_mask="acoustic_features_mask",
+                                   input_names=["acoustic_features", "pred_acoustic_features"],
+                                   batch_first=False)])
+    x, y, lengths = make_ff_batch(n_utts, seed=7)
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    batch = [{"questions": x[offs[i]:offs[i + 1]], "acoustic_features": y[offs[i]:offs[i + 1]]}
+             for i in range(n_utts)]
+    data, lens = Handler.prepare_batch(batch, batch_first=False, mask_keys=("acoustic_features",))
+    data = {k: v.to(dev) for k, v in data.items()}
+    h.process_batch(data, lens, 0, training=True)      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        ld, _ = h.process_batch(data, lens, s + 1, training=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    frames = int(lengths.sum())
+    return {"bilstm": {"model": "425 -> 3x512 BiLSTM -> 187", "utterances": n_utts,
+                       "valid_frames": frames, "max_frames": int(lengths.max()),
+                       "ms_per_step": dt * 1e3, "valid_frames_per_s": frames / dt,
+                       "loss": ld["MSELoss_acoustic_features"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +222,8 @@ def main():
     ap.add_argument("--world-utts", type=int, default=48,
                     help="utterances in the WORLD feature-path section (0 = skip)")
     ap.add_argument("--world-fs", type=int, default=16000)
+    ap.add_argument("--bilstm-utts", type=int, default=64,
+                    help="utterances of the BiLSTM (config 3) section (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -278,6 +324,8 @@ def main():
         if world == 1 and args.world_utts > 0:
             extra = world_section(dev, args.world_utts, args.world_fs,
                                   with_cpu=not args.no_cpu_baseline)
+        if world == 1 and args.bilstm_utts > 0:
+            extra.update(bilstm_section(dev, args.bilstm_utts))
         out = {
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

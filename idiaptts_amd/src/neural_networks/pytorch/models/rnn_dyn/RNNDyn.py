@@ -1,0 +1,134 @@
+"""RNNDyn and its layer-group wrappers on the HIP kernels
+(reference: rnn_dyn/RNNDyn.py:26-147, FFWrapper.py:37-88, RNNWrapper.py:45-107).
+
+state_dict() keys and shapes equal the reference's, so its checkpoints load unchanged:
+FF group `<i>.module.<k>.weight/bias` with k = index of the Linear inside the nn.Sequential
+(non-linearity / dropout modules keep their slots), RNN group `<i>.module.weight_ih_l0[_reverse]`,
+`<i>.h_0`, `<i>.c_0`; the group index starts at 1 because `emb_groups` takes slot 0 of the
+ModuleList.
+"""
+import copy
+
+import torch
+from torch import nn
+
+from idiaptts_amd.nn.modules import LSTM, LinearAct
+
+
+class FusedActivation(nn.Identity):
+    """Keeps the Tanh / ReLU slot of the reference's nn.Sequential; the activation itself is
+    applied in the epilogue of the preceding LinearAct GEMM."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def extra_repr(self):
+        return "{} (fused into the previous Linear)".format(self.name)
+
+
+class FFWrapper(nn.Module):
+    def __init__(self, in_dim, layer_config):
+        super().__init__()
+        if layer_config.type != "Linear" or layer_config.nonlin not in (None, "Tanh", "ReLU"):
+            raise NotImplementedError("Only Linear(+Tanh/ReLU) groups are accelerated, got {}."
+                                      .format(layer_config))
+        layers = []
+        for _ in range(layer_config.num_layers):
+            layers.append(LinearAct(in_dim, layer_config.out_dim, act=layer_config.nonlin,
+                                    **layer_config.kwargs))
+            in_dim = layer_config.out_dim
+            if layer_config.nonlin is not None:
+                layers.append(FusedActivation(layer_config.nonlin))
+            if layer_config.dropout > 0.0:
+                layers.append(nn.Dropout(layer_config.dropout))
+        self.module = nn.Sequential(*layers)
+        self.out_dim = in_dim
+
+    def init_hidden(self, batch_size=1):
+        pass
+
+    def forward(self, input_, **kwargs):
+        return self.module(input_), kwargs
+
+
+class RNNWrapper(nn.Module):
+    def __init__(self, in_dim, layer_config, batch_first=True, enforce_sorted=True):
+        super().__init__()
+        if layer_config.type != 'LSTM':
+            raise NotImplementedError("{} groups are scheduled for a later round; LSTM is "
+                                      "accelerated.".format(layer_config.type))
+        self.batch_first = batch_first
+        self.bidirectional = layer_config.kwargs.get("bidirectional", False)
+        self.hidden = None
+        self.pack = True
+        self.unpack = True
+        self.module = LSTM(input_size=in_dim, hidden_size=layer_config.out_dim,
+                           num_layers=layer_config.num_layers, dropout=layer_config.dropout,
+                           batch_first=batch_first, bidirectional=self.bidirectional)
+        ndir = 2 if self.bidirectional else 1
+        init = layer_config.kwargs.get('hidden_init_value', 0.0)
+        h0 = torch.full((layer_config.num_layers * ndir, 1, layer_config.out_dim), float(init))
+        c0 = h0.clone()
+        if layer_config.kwargs.get('train_hidden_init', False):
+            raise NotImplementedError("train_hidden_init is not supported yet")
+        self.register_buffer('h_0', h0)
+        self.register_buffer('c_0', c0)
+        self.out_dim = layer_config.out_dim * ndir
+
+    def init_hidden(self, batch_size=1):
+        size = list(self.h_0.size())
+        size[1] = batch_size
+        self.hidden = (self.h_0.expand(size).contiguous(), self.c_0.expand(size).contiguous())
+
+    def forward(self, input_, seq_lengths_input, max_length_inputs, hidden=None, **kwargs):
+        # the kernels take the padded tensor + lengths directly (no PackedSequence round trip)
+        output, self.hidden = self.module(input_, self.hidden if hidden is None else hidden,
+                                          seq_lengths_input)
+        time_dim = 1 if self.batch_first else 0
+        total = int(max_length_inputs)
+        if output.shape[time_dim] < total:      # pad_packed_sequence(total_length=...)
+            pad_shape = list(output.shape)
+            pad_shape[time_dim] = total - output.shape[time_dim]
+            output = torch.cat((output, output.new_zeros(pad_shape)), dim=time_dim)
+        kwargs["hidden"] = self.hidden
+        kwargs["seq_lengths_input"] = seq_lengths_input
+        kwargs["max_length_inputs"] = max_length_inputs
+        return output, kwargs
+
+
+class RNNDyn(nn.ModuleList):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = copy.deepcopy(config)
+        self.emb_groups = nn.ModuleDict()      # slot 0 of the ModuleList, like the reference
+        self.layer_groups = []
+        in_dim = config.in_dim
+        for layer_config in config.layer_configs:
+            if layer_config.needs_packing:
+                layer = RNNWrapper(in_dim, layer_config, config.batch_first, enforce_sorted=False)
+            elif layer_config.needs_transposing:
+                raise NotImplementedError("Conv / BatchNorm groups are outside the accelerated "
+                                          "path (SURVEY.md section 2).")
+            else:
+                layer = FFWrapper(in_dim, layer_config)
+            in_dim = layer.out_dim
+            self.append(layer)
+            self.layer_groups.append(layer)
+
+    def forward(self, input_, *emb_inputs, **kwargs):
+        last_hidden = None
+        for module in self.layer_groups:
+            input_, kwargs = module(input_, **kwargs)
+            # hidden states are not passed from one RNN group to the next (reference :118-121)
+            last_hidden = kwargs.pop("hidden", last_hidden)
+        kwargs["hidden"] = last_hidden
+        return input_, kwargs
+
+    def init_hidden(self, batch_size=1):
+        for module in self.layer_groups:
+            module.init_hidden(batch_size)
+
+    def set_gpu_flag(self, use_gpu):
+        self.use_gpu = use_gpu

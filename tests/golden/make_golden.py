@@ -215,8 +215,83 @@ def capture_benchmark_kat():
     print("mlpg_benchmark_kat.npz:", len(calls), "MLPG calls")
 
 
-if __name__ == "__main__":
+def _main():
     copy_data_fixtures()
     install_stub_harness()
+    if "--models" in sys.argv:
+        capture_reference_model_forward()
+        return
     capture_host_logic()
     capture_benchmark_kat()
+    capture_reference_model_forward()
+
+
+def capture_reference_model_forward():
+    """Forward / loss / gradients of the reference's own RNNDyn + NamedForwardWrapper + NamedLoss
+    (torch CPU) for (a) the fixture checkpoint test_model_in409_out67 on fixture questions and
+    (b) a small seeded BiLSTM model on a padded batch -- inputs, state dict and outputs stored."""
+    import torch
+    from idiaptts.src.neural_networks.pytorch.models import rnn_dyn
+    from idiaptts.src.neural_networks.pytorch.models.NamedForwardWrapper import NamedForwardWrapper
+    from idiaptts.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss
+    from idiaptts.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    out = {}
+    # (a) fixture checkpoint: RNNDYN-1_RELU_32-1_FC_67, 409 -> 67
+    hp = types.SimpleNamespace(model_type="RNNDYN-1_RELU_32-1_FC_67", batch_first=False,
+                               dropout=0.0)
+    cfg = NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((409,), hp),
+                                     input_names=["questions"], batch_first=False,
+                                     name="AcousticModel", output_names=["pred_acoustic_features"])
+    model = cfg.create_model()
+    ck = torch.load(os.path.join(FIX, "test_model_in409_out67", "nn", "params_best"),
+                    weights_only=False)
+    model.load_state_dict(ck["params"])
+    q = np.fromfile(os.path.join(FIX, "questions", "LJ001-0008.questions"),
+                    dtype=np.float32).reshape(-1, 409)[:120]
+    data = {"questions": torch.from_numpy(q[:, None, :].copy())}
+    lengths = {"questions": torch.tensor([120])}
+    model.init_hidden(1)
+    model(data, lengths, {"questions": 120})
+    out["a_questions"] = q
+    out["a_pred"] = data["pred_acoustic_features"].detach().numpy()
+    for k, v in ck["params"].items():
+        out["a_sd_" + k] = v.numpy()
+    # (b) seeded small BiLSTM: 2_TANH_24-2_BiLSTM_16-1_FC_7 on a ragged batch, time-major
+    torch.manual_seed(5)
+    hp = types.SimpleNamespace(model_type="RNNDYN-2_TANH_24-2_BiLSTM_16-1_FC_7", batch_first=False,
+                               dropout=0.0)
+    cfg = NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((11,), hp),
+                                     input_names=["questions"], batch_first=False, name="AM",
+                                     output_names=["pred_acoustic_features"])
+    model = cfg.create_model()
+    lens = torch.tensor([9, 4, 7])
+    x = torch.randn(9, 3, 11)
+    tgt = torch.randn(9, 3, 7)
+    for b, l in enumerate(lens):
+        x[l:, b] = 0
+        tgt[l:, b] = 0
+    mask = Handler.sequence_mask(lens, 9, batch_first=False)
+    data = {"questions": x, "acoustic_features": tgt, "acoustic_features_mask": mask}
+    lengths = {"questions": lens, "acoustic_features": lens, "acoustic_features_mask": lens}
+    model.init_hidden(3)
+    model(data, lengths, {"questions": 9})
+    loss_mod = NamedLoss.Config(name="MSELoss_acoustic_features", type_="MSELoss",
+                                seq_mask="acoustic_features_mask",
+                                input_names=["acoustic_features", "pred_acoustic_features"],
+                                batch_first=False).create_loss()
+    loss = list(loss_mod(data, lengths, step=1).values())[0]
+    loss.backward()
+    out["b_x"], out["b_tgt"], out["b_len"] = x.numpy(), tgt.numpy(), lens.numpy()
+    out["b_pred"] = data["pred_acoustic_features"].detach().numpy()
+    out["b_loss"] = loss.detach().numpy()
+    for k, v in model.state_dict().items():
+        out["b_sd_" + k] = v.numpy()
+    for k, p in model.named_parameters():
+        out["b_grad_" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "model_forward.npz"), **out)
+    print("model_forward.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    _main()
