@@ -1,0 +1,92 @@
+"""Reader-side helpers of the hot path: per-stream `.npz` / legacy raw-float32 loading with
+(de)normalisation (reference NpzDataReader.py:312-420, QuestionLabelGen reader) and the length
+matching of PyTorchDatareadersDataset (:99-197) -- symmetric trimming, bit-exact index math."""
+import os
+
+import numpy as np
+
+
+def trim_to_reference(value, ref_lengths):
+    """PyTorchDatareadersDataset._trim_datareader_output (:179-197): for every leading dim,
+    front = (-diff) // 2, end = -diff - front; raises ValueError when the reference is longer.
+    Returns (trimmed value, was_trimmed)."""
+    slices, do_trim = [], False
+    for dim, ref_length in enumerate(ref_lengths):
+        len_diff = ref_length - value.shape[dim]
+        if len_diff > 0:
+            raise ValueError()
+        front = (-len_diff) // 2
+        end = -len_diff - front
+        slices.append(slice(front, value.shape[dim] - end))
+        do_trim |= front != 0 or end != 0
+    return (value[tuple(slices)], True) if do_trim else (value, False)
+
+
+def match_lengths(outputs, match_length):
+    """outputs: {name: array}; match_length: {name: [reference names]} as in the reader configs.
+    Repeats trimming until stable (cyclic dependencies allowed), like _match_output_lengths
+    (:99-140): a stream is trimmed to its reference; if the reference is longer the pair is
+    skipped and the reference gets trimmed on its own turn."""
+    changed = True
+    while changed:
+        changed = False
+        for name, refs in match_length.items():
+            if not refs:
+                continue
+            ref_lengths = [outputs[r].shape[0] for r in refs]
+            try:
+                outputs[name], was = trim_to_reference(outputs[name], ref_lengths)
+            except ValueError:
+                was = False
+            if was:
+                changed = True
+                break
+    return outputs
+
+
+class NpzStreamReader(object):
+    """Loads `<dir>/<id>.npz[feature_names]` (concatenated on the feature axis) or a legacy raw
+    float32 file `<dir>/<id>.<ext>` with `legacy_dim` columns; optional mean/std or min/max
+    normalisation as in NpzDataReader.preprocess_sample / postprocess_sample (:347-420)."""
+
+    def __init__(self, directory, feature_names, legacy_ext=None, legacy_dim=None,
+                 norm_type=None, norm_params=None):
+        self.directory = directory
+        self.feature_names = [feature_names] if isinstance(feature_names, str) else feature_names
+        self.legacy_ext, self.legacy_dim = legacy_ext, legacy_dim
+        self.norm_type, self.norm_params = norm_type, norm_params
+
+    def load(self, id_name):
+        base = os.path.join(self.directory, os.path.basename(id_name))
+        if os.path.isfile(base + ".npz"):
+            arch = np.load(base + ".npz")
+            feats = [arch[n] for n in self.feature_names]
+            return feats[0] if len(feats) == 1 else np.concatenate(feats, axis=1)
+        if self.legacy_ext is None:
+            raise FileNotFoundError(base + ".npz")
+        return np.fromfile(base + "." + self.legacy_ext, dtype=np.float32) \
+            .reshape(-1, self.legacy_dim)
+
+    def normalise(self, sample):
+        if self.norm_type is None:
+            return sample
+        a, b = self.norm_params
+        if self.norm_type == "mean_variance":
+            return ((sample - a) / b).astype(np.float32)
+        if self.norm_type == "min_max":     # MinMaxExtractor._normalise (:35-38): (x-min)/range,
+            rng = np.array(b - a)           # zero ranges replaced by 1 (_fix_range_inplace)
+            rng[rng == 0.0] = 1.0
+            return ((sample - a) / rng).astype(np.float32)
+        raise NotImplementedError(self.norm_type)
+
+    def denormalise(self, sample):
+        if self.norm_type is None:
+            return sample
+        a, b = self.norm_params
+        if self.norm_type == "mean_variance":
+            return sample * b + a
+        if self.norm_type == "min_max":
+            rng = np.array(b - a)
+            rng[rng == 0.0] = 1.0
+            return sample * rng + a
+        raise NotImplementedError(self.norm_type)

@@ -29,3 +29,42 @@ def test_compute_deltas_bit_exact(host):
     x = np.array([[1, 2], [2, 5], [4, 4], [8, 0]], dtype=np.float32)
     assert np.array_equal(compute_deltas(x), np.array([[1, 3], [1.5, 1], [3, -2.5], [4, -4]],
                                                        dtype=np.float32))
+
+
+def test_state_align_durations_bit_exact(golden_dir):
+    """reference fixtures dur/*.dur == _get_full_state_align_dur(label_state_align/*.lab)
+    (float32 parse + float32 division, PhonemeDurationLabelGen.py:306-314)."""
+    from idiaptts_amd.src.data_preparation.phonemes.PhonemeDurationLabelGen import \
+        PhonemeDurationLabelGen as P
+    for name in ["LJ001-0002", "LJ001-0008"]:
+        dur = P._get_full_state_align_dur(os.path.join(golden_dir, name + ".lab"), 50000, 5)
+        ref = np.fromfile(os.path.join(golden_dir, name + ".dur"), dtype=np.float32).reshape(-1, 5)
+        assert dur.dtype == np.float32 and np.array_equal(dur, ref)
+        A = P.convert_to_matrix(dur)
+        assert A.shape == (int(ref.sum()), ref.shape[0]) and A.dtype == np.float32
+        assert np.array_equal(A.sum(0), ref.sum(1))
+    # docstring example of the reference (:181-189)
+    A = P.durations_to_hard_attention_matrix(np.array([3, 0, 1, 2]))
+    assert np.array_equal(A, np.array([[1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0],
+                                       [0, 0, 0, 1], [0, 0, 0, 1]], dtype=np.float32))
+    assert np.array_equal(P.load_sample("LJ001-0008", golden_dir),
+                          np.fromfile(os.path.join(golden_dir, "LJ001-0008.dur"),
+                                      dtype=np.float32).reshape(-1, 5))
+
+
+def test_length_matching_index_math():
+    """WORLD 1931 frames vs questions 1926 -> trim front 2, end 3 (SURVEY.md Appendix C;
+    PyTorchDatareadersDataset.py:179-197); the longer stream is the one trimmed."""
+    from idiaptts_amd.src.data_preparation.DataReaders import match_lengths, trim_to_reference
+    w = np.arange(1931 * 2).reshape(1931, 2)
+    q = np.arange(1926 * 3).reshape(1926, 3)
+    t, was = trim_to_reference(w, [1926])
+    assert was and t.shape[0] == 1926 and t[0, 0] == w[2, 0] and t[-1, 0] == w[-4, 0]
+    with pytest.raises(ValueError):
+        trim_to_reference(q, [1931])
+    out = match_lengths({"acoustic_features": w, "questions": q},
+                        {"acoustic_features": ["questions"], "questions": ["acoustic_features"]})
+    assert out["acoustic_features"].shape[0] == out["questions"].shape[0] == 1926
+    assert np.array_equal(out["questions"], q)
+    same, was = trim_to_reference(q, [1926])
+    assert not was and same is q
