@@ -24,7 +24,7 @@ namespace itts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128, BK = 32;  // BN: widest tile (TN = 2)
 constexpr int LD_ROW = BK + 4;    // row-form tile [128][36]
 constexpr int LD_COL = BM + 4;    // col-form tile [32][132]
 constexpr int TILE_FLOATS = 128 * LD_ROW;  // 4608 >= 32*132 = 4224
@@ -81,21 +81,21 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
 // load and waits for each one).  VEC: 16-byte loads; requires ld % 4 == 0, a 16-B aligned base
 // and the contiguous extent (K for row form, out_dim for col form) to be a multiple of 4, so a
 // float4 is either completely inside or completely outside.
-template <bool ROWFORM, bool VEC>
+template <bool ROWFORM, bool VEC, int NROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t out0,
                                           int64_t out_dim, int64_t k0, int64_t k_end,
-                                          float4 (&r)[4]) {
+                                          float4 (&r)[NROWS / 32]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NROWS / 32; ++i) {
     const int idx = tid + 256 * i;
     int64_t o, k;
     if (ROWFORM) {
       o = out0 + (idx >> 3);
       k = k0 + ((idx & 7) << 2);
     } else {
-      k = k0 + (idx >> 5);
-      o = out0 + ((idx & 31) << 2);
+      k = k0 + idx / (NROWS / 4);
+      o = out0 + ((idx % (NROWS / 4)) << 2);
     }
     // contiguous index c (4 consecutive elements), strided index t
     const int64_t c = ROWFORM ? k : o, c_end = ROWFORM ? k_end : out_dim;
@@ -117,41 +117,45 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t l
   }
 }
 
-template <bool ROWFORM>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[4]) {
+template <bool ROWFORM, int NROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[NROWS / 32]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NROWS / 32; ++i) {
     const int idx = tid + 256 * i;
     int off;
     if (ROWFORM)
       off = (idx >> 3) * LD_ROW + ((idx & 7) << 2);
     else
-      off = (idx >> 5) * LD_COL + ((idx & 31) << 2);
+      off = (idx / (NROWS / 4)) * (NROWS + 4) + ((idx % (NROWS / 4)) << 2);
     *reinterpret_cast<float4*>(S + off) = r[i];
   }
 }
 
 // Fragment of k-group g for the 32 rows starting at `o` (tile-local): 4 k values per lane.
-template <bool ROWFORM>
+template <bool ROWFORM, int NROWS>
 __device__ __forceinline__ float4 read_frag(const float* __restrict__ S, int o, int g, int lane) {
   const int r = lane & 31, h = lane >> 5;
   if (ROWFORM) {
     return *reinterpret_cast<const float4*>(S + (o + r) * LD_ROW + g * 8 + 4 * h);
   } else {
-    const float* p = S + (g * 8 + 4 * h) * LD_COL + o + r;
-    return make_float4(p[0], p[LD_COL], p[2 * LD_COL], p[3 * LD_COL]);
+    constexpr int LDC = NROWS + 4;
+    const float* p = S + (g * 8 + 4 * h) * LDC + o + r;
+    return make_float4(p[0], p[LDC], p[2 * LDC], p[3 * LDC]);
   }
 }
 
-template <bool A_ROW, bool B_ROW, int EPI, bool VEC_A, bool VEC_B>
+// TN = MFMA tiles per wave along N: output tile 128 x (64*TN). TN = 1 halves the tile so that
+// narrow outputs (N = 187) and awkward tile counts waste fewer workgroup slots.
+template <bool A_ROW, bool B_ROW, int EPI, bool VEC_A, bool VEC_B, int TN>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BNT = 64 * TN;
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
   // buffer b: A tile at lds + 2b*TILE, B tile at lds + (2b+1)*TILE
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
   // XCD a contiguous run of tiles that share the same B panel (weights) where possible.
-  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_n = (g.N + BNT - 1) / BNT;
   const int64_t tiles_m = (g.M + BM - 1) / BM;
   const int64_t ntiles = tiles_m * tiles_n;
   int64_t bid = blockIdx.x;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int64_t tm = bid / tiles_n;
   const int tn = (int)(bid % tiles_n);
   const int64_t m0 = tm * BM;
-  const int n0 = tn * BN;
+  const int n0 = tn * BNT;
 
   const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
   const int64_t kend = std::min<int64_t>(g.K, kbeg + g.kchunk);
@@ -172,20 +176,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
+  float4 ra[4], rb[BNT / 32];
   if (nkt > 0) {
-    load_tile<A_ROW, VEC_A>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
-    load_tile<B_ROW, VEC_B>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
-    store_tile<A_ROW>(lds, ra);
-    store_tile<B_ROW>(lds + TILE_FLOATS, rb);
+    load_tile<A_ROW, VEC_A, BM>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    load_tile<B_ROW, VEC_B, BNT>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+    store_tile<A_ROW, BM>(lds, ra);
+    store_tile<B_ROW, BNT>(lds + TILE_FLOATS, rb);
   }
   __syncthreads();
 
@@ -193,22 +197,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int cur = (int)(kt & 1);
     const bool more = kt + 1 < nkt;
     if (more) {
-      load_tile<A_ROW, VEC_A>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, ra);
-      load_tile<B_ROW, VEC_B>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, rb);
+      load_tile<A_ROW, VEC_A, BM>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, ra);
+      load_tile<B_ROW, VEC_B, BNT>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, rb);
     }
     const float* cA = lds + (2 * cur) * TILE_FLOATS;
     const float* cB = lds + (2 * cur + 1) * TILE_FLOATS;
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
-      float4 fa[2], fb[2];
+      float4 fa[2], fb[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_ROW>(cA, wm * 64 + i * 32, kg, lane);
+      for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_ROW, BM>(cA, wm * 64 + i * 32, kg, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_ROW>(cB, wn * 64 + j * 32, kg, lane);
+      for (int j = 0; j < TN; ++j) fb[j] = read_frag<B_ROW, BNT>(cB, wn * 32 * TN + j * 32, kg, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
@@ -216,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         }
     }
     if (more) {
-      store_tile<A_ROW>(lds + (2 * (cur ^ 1)) * TILE_FLOATS, ra);
-      store_tile<B_ROW>(lds + (2 * (cur ^ 1) + 1) * TILE_FLOATS, rb);
+      store_tile<A_ROW, BM>(lds + (2 * (cur ^ 1)) * TILE_FLOATS, ra);
+      store_tile<B_ROW, BNT>(lds + (2 * (cur ^ 1) + 1) * TILE_FLOATS, rb);
     }
     __syncthreads();
   }
@@ -228,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + cl;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + j * 32 + cl;
       if (col >= g.N) continue;
       float bv = 0.f;
       if (EPI == EPI_BIAS_ACT && g.bias) bv = g.bias[col];
@@ -245,24 +249,42 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <bool A_ROW, bool B_ROW, int EPI>
-static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
-  const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  if (tiles <= 0) return ITTS_OK;
+template <bool A_ROW, bool B_ROW, int EPI, int TN>
+static int launch_gemm_tn(const GemmArgs& g, int splitk, hipStream_t s) {
+  const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + 64 * TN - 1) / (64 * TN));
   dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
   // contiguous extents must be multiples of 4 for the 16-byte path (see load_tile)
   const bool va = g.vecA && ((A_ROW ? g.K : g.M) % 4 == 0);
   const bool vb = g.vecB && ((B_ROW ? g.K : (int64_t)g.N) % 4 == 0);
   if (va && vb)
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, true>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, true, TN>), grid, dim3(256), 0, s, g);
   else if (va)
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, false>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, false, TN>), grid, dim3(256), 0, s, g);
   else if (vb)
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, true>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, true, TN>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, false>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, false, TN>), grid, dim3(256), 0, s, g);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
+}
+
+// Tile width choice: 128x128 tiles reuse operands best, 128x64 tiles quantise better onto the
+// 512 resident workgroup slots (256 CUs x 2) and waste less on narrow outputs.
+static double tile_efficiency(int64_t M, int N, int splitk, int tn, double loop_eff) {
+  const int bn = 64 * tn;
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn) * splitk;
+  const int64_t rounds = (tiles + 511) / 512;
+  const double useful = (double)N / (double)(((N + bn - 1) / bn) * bn);
+  return loop_eff * useful * (double)tiles / (double)(rounds * 512);
+}
+
+template <bool A_ROW, bool B_ROW, int EPI>
+static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return ITTS_OK;
+  const double e2 = tile_efficiency(g.M, g.N, splitk, 2, 1.0);
+  const double e1 = tile_efficiency(g.M, g.N, splitk, 1, 0.90);
+  if (e1 > e2) return launch_gemm_tn<A_ROW, B_ROW, EPI, 1>(g, splitk, s);
+  return launch_gemm_tn<A_ROW, B_ROW, EPI, 2>(g, splitk, s);
 }
 
 static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
