@@ -46,6 +46,7 @@ struct LstmArgs {
   const float* dy;        // [T*B, ndir*H]
   float* dg;              // [T*B, ndir*4H] gradient wrt pre-activation gates
   int step;
+  int ksplit, kiter;  // forward: K = H split over `ksplit` waves, `kiter` steps of 16 each
 };
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
@@ -57,80 +58,94 @@ __device__ __forceinline__ int time_of(int dir, int s, int len) {
 }
 
 // ---- forward step -----------------------------------------------------------------------------------
+// Workgroup = (4 hidden units = 16 gate rows) x (16 batch rows); its 4 waves split K = H four
+// ways, every wave streams its A (h_{t-1}) and B (W_hh) fragments straight from L2 into registers
+// (all loads of the step in flight at once, no LDS staging: each element is used by exactly one
+// MFMA), the partial 16x16 tiles are reduced through LDS and 64 threads apply the cell update.
+// Grid: (H/4 * ceil(B/16), ndir) -> 1024 workgroups for H = 512, B = 64: the whole chip per step.
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float P[4][16][17];
   const int H = a.H, B = a.B, G4 = 4 * H;
-  const int ldw = H + 4;
-  float* Ws = smem;                 // [16][H+4]: row n = gate*4 + u  <->  W_hh[gate*H + j0 + u][:]
-  float* Gt = smem + 16 * ldw;      // [64][17] gate pre-activations of one batch tile
   const int dir = blockIdx.y;
-  const int j0 = blockIdx.x * FW_UNITS;
+  const int ngroups = H / FW_UNITS;
+  const int j0 = (blockIdx.x % ngroups) * FW_UNITS;
+  const int b0 = (blockIdx.x / ngroups) * 16;
   const int par = a.step & 1;
   const float* whh = a.whh + (size_t)dir * G4 * H;
-  for (int idx = threadIdx.x; idx < 16 * (H / 4); idx += 256) {
-    const int n = idx / (H / 4), q = idx - n * (H / 4);
-    const int grow = (n >> 2) * H + j0 + (n & 3);
-    *reinterpret_cast<float4*>(Ws + n * ldw + 4 * q) =
-        *reinterpret_cast<const float4*>(whh + (size_t)grow * H + 4 * q);
-  }
-  __syncthreads();
   const float* hprev = a.hs + ((size_t)par * a.ndir + dir) * B * H;
   const float* cprev = a.cs + ((size_t)par * a.ndir + dir) * B * H;
   float* hnext = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
   float* cnext = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    // gates[b, n] = sum_k h_prev[b, k] * Ws[n, k]   (16 batch rows per wave)
-    const int row = b0 + wv * 16 + lr;
-    const bool rok = row < B;
-    const float* hp = hprev + (size_t)(rok ? row : 0) * H + 4 * kg;
-    const float* wp = Ws + lr * ldw + 4 * kg;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s = 0; s < H / 16; ++s) {
-      float4 av = *reinterpret_cast<const float4*>(hp + 16 * s);
-      if (!rok) av = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 bv = *reinterpret_cast<const float4*>(wp + 16 * s);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+
+  // elementwise operands of this workgroup's 16 rows x 4 units: issue their loads first
+  const int bl = threadIdx.x >> 2, u = threadIdx.x & 3;
+  const int b = b0 + bl, j = j0 + u;
+  const bool ew = threadIdx.x < 64 && b < B;
+  int t = -1;
+  float hp_v = 0.f, cp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+  size_t r = 0;
+  if (ew) {
+    t = time_of(dir, a.step, a.lengths[b]);
+    hp_v = hprev[(size_t)b * H + j];
+    cp_v = cprev[(size_t)b * H + j];
+    if (t >= 0) {
+      r = (size_t)t * B + b;
+      const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+      g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
     }
-    __syncthreads();  // previous tile's Gt readers are done
+  }
+
+  const int row = b0 + lr;
+  const bool rok = row < B;
+  // K = H is split over the first a.ksplit waves, a.kiter steps of 16 k each
+  const int kiter = wv < a.ksplit ? a.kiter : 0;
+  const int kbase = wv * (16 * a.kiter) + 4 * kg;
+  const float* hp = hprev + (size_t)(rok ? row : 0) * H + (kiter ? kbase : 0);
+  const float* wp = whh + (size_t)((lr >> 2) * H + j0 + (lr & 3)) * H + (kiter ? kbase : 0);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int c = 0; c * 8 < kiter; ++c) {
+    float4 av[8], bv[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Gt[(wv * 16 + kg * 4 + r) * 17 + lr] = acc[r];
-    __syncthreads();
-    // cell update: thread -> (batch row, unit)
-    const int bl = threadIdx.x >> 2, u = threadIdx.x & 3;
-    const int b = b0 + bl;
-    if (b < B) {
-      const int j = j0 + u;
-      const int len = a.lengths[b];
-      const int t = time_of(dir, a.step, len);
-      const float hp_v = hprev[(size_t)b * H + j], cp_v = cprev[(size_t)b * H + j];
-      float hn = hp_v, cn = cp_v;
-      if (t >= 0) {
-        const size_t r = (size_t)t * B + b;
-        const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
-        const float pi = Gt[bl * 17 + 0 + u] + gi[0];
-        const float pf = Gt[bl * 17 + 4 + u] + gi[H];
-        const float pg = Gt[bl * 17 + 8 + u] + gi[2 * H];
-        const float po = Gt[bl * 17 + 12 + u] + gi[3 * H];
-        const float ig = sigmoidf_acc(pi), fg = sigmoidf_acc(pf), gg = tanhf(pg), og = sigmoidf_acc(po);
-        cn = fg * cp_v + ig * gg;
-        hn = og * tanhf(cn);
-        a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
-        if (a.gates) {
-          float* gs = a.gates + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
-          gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
-          a.csave[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = cn;
-          a.hprev[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hp_v;
-        }
-      }
-      hnext[(size_t)b * H + j] = hn;
-      cnext[(size_t)b * H + j] = cn;
+    for (int s = 0; s < 8; ++s) {
+      const int i = c * 8 + s;
+      const int o = i < kiter ? 16 * i : 0;
+      av[s] = *reinterpret_cast<const float4*>(hp + o);
+      bv[s] = *reinterpret_cast<const float4*>(wp + o);
     }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float4 x = av[s];
+      if (!rok || c * 8 + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
+  __syncthreads();
+  if (ew) {
+    float hn = hp_v, cn = cp_v;
+    if (t >= 0) {
+      auto gate = [&](int n) { return (P[0][bl][n] + P[1][bl][n]) + (P[2][bl][n] + P[3][bl][n]); };
+      const float ig = sigmoidf_acc(gate(u) + g0), fg = sigmoidf_acc(gate(4 + u) + g1),
+                  gg = tanhf(gate(8 + u) + g2), og = sigmoidf_acc(gate(12 + u) + g3);
+      cn = fg * cp_v + ig * gg;
+      hn = og * tanhf(cn);
+      a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
+      if (a.gates) {
+        float* gs = a.gates + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+        gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+        a.csave[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = cn;
+        a.hprev[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hp_v;
+      }
+    }
+    hnext[(size_t)b * H + j] = hn;
+    cnext[(size_t)b * H + j] = cn;
   }
 }
 
@@ -150,88 +165,99 @@ __global__ void lstm_init_state_kernel(const float* __restrict__ h0, const float
 // Processes recurrence step s = a.step (called with s = T-1 ... 0). For row b active at s:
 //   dh = dy[t] + dG[t_{s+1}] W_hh   (second term only if the row is active at s+1)
 //   standard LSTM cell gradients -> dG[t], running dc (cs buffers, parity by step)
+// Workgroup = 16 hidden units x 16 batch rows; the 4 waves split the K = 4H gate rows, operands
+// stream from L2 into registers in chunks of 8 k-steps.  Grid (H/16 * ceil(B/16), ndir).
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float P[4][16][17];
   const int H = a.H, B = a.B, G4 = 4 * H;
-  const int ldw = G4 + 4;
-  float* Wt = smem;                  // [16][4H+4]: row n <-> W_hh^T[j0 + n][:]  (k = gate row)
-  float* Dt = smem + 16 * ldw;       // [64][17] dh_rec of one batch tile
   const int dir = blockIdx.y;
-  const int j0 = blockIdx.x * BW_UNITS;
+  const int ngroups = H / BW_UNITS;
+  const int j0 = (blockIdx.x % ngroups) * BW_UNITS;
+  const int b0 = (blockIdx.x / ngroups) * 16;
   const int par = a.step & 1;
   const float* wt = a.whh_t + (size_t)dir * H * G4;
-  for (int idx = threadIdx.x; idx < 16 * (G4 / 4); idx += 256) {
-    const int n = idx / (G4 / 4), q = idx - n * (G4 / 4);
-    *reinterpret_cast<float4*>(Wt + n * ldw + 4 * q) =
-        *reinterpret_cast<const float4*>(wt + (size_t)(j0 + n) * G4 + 4 * q);
-  }
-  __syncthreads();
-  // running dc: written for step s into parity (s&1), read from parity ((s+1)&1)
   const float* dc_in = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
   float* dc_out = a.cs + ((size_t)par * a.ndir + dir) * B * H;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    const int row = b0 + wv * 16 + lr;
-    bool has_next = false;
-    const float* dgp = a.dg;
-    if (row < B) {
-      const int len = a.lengths[row];
-      const int tn = time_of(dir, a.step + 1, len);
-      if (tn >= 0) {
-        has_next = true;
-        dgp = a.dg + ((size_t)tn * B + row) * ldg + (size_t)dir * G4 + 4 * kg;
-      }
+
+  // elementwise operands (thread -> batch row bl, unit n): load early
+  const int bl = threadIdx.x >> 4, n = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + n;
+  int t = -1;
+  float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f, dyv = 0.f, dcin = 0.f;
+  size_t r = 0;
+  if (b < B) {
+    const int len = a.lengths[b];
+    t = time_of(dir, a.step, len);
+    if (t >= 0) {
+      r = (size_t)t * B + b;
+      const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
+      ig = gs[0]; fg = gs[H]; gg = gs[2 * H]; og = gs[3 * H];
+      ct = a.csave[r * ldh + (size_t)dir * H + j];
+      const int tp = time_of(dir, a.step - 1, len);
+      cp = (a.step > 0 && tp >= 0) ? a.csave[((size_t)tp * B + b) * ldh + (size_t)dir * H + j]
+                                   : (a.c0 ? a.c0[dir * H + j] : 0.f);
+      dyv = a.dy[r * ldh + (size_t)dir * H + j];
+      dcin = dc_in[(size_t)b * H + j];
     }
-    const float* wp = Wt + lr * ldw + 4 * kg;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s = 0; s < G4 / 16; ++s) {
-      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_next) av = *reinterpret_cast<const float4*>(dgp + 16 * s);
-      const float4 bv = *reinterpret_cast<const float4*>(wp + 16 * s);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+  }
+
+  // dh_rec tile: A = dG of the next recurrence step (rows), B = W_hh^T rows of our 16 units
+  const int row = b0 + lr;
+  bool has_next = false;
+  const float* dgp = a.dg;
+  if (row < B) {
+    const int tn = time_of(dir, a.step + 1, a.lengths[row]);
+    if (tn >= 0) {
+      has_next = true;
+      dgp = a.dg + ((size_t)tn * B + row) * ldg + (size_t)dir * G4;
     }
-    __syncthreads();
+  }
+  const int kiter = H / 16;            // 4H gate rows / 4 waves / 16 per step
+  const int kbase = wv * H + 4 * kg;  // this wave's quarter of the 4H gate rows
+  dgp += kbase;
+  const float* wp = wt + (size_t)(j0 + lr) * G4 + kbase;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int c = 0; c * 8 < kiter; ++c) {
+    float4 av[8], bv[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Dt[(wv * 16 + kg * 4 + r) * 17 + lr] = acc[r];
-    __syncthreads();
-    // elementwise: thread -> batch row bl, 4 of the 16 units
-    const int bl = threadIdx.x >> 2, uq = threadIdx.x & 3;
-    const int b = b0 + bl;
-    if (b < B) {
-      const int len = a.lengths[b];
-      const int t = time_of(dir, a.step, len);
-#pragma unroll
-      for (int uu = 0; uu < 4; ++uu) {
-        const int n = uq * 4 + uu;
-        const int j = j0 + n;
-        float dc_keep = 0.f;
-        if (t >= 0) {
-          const size_t r = (size_t)t * B + b;
-          const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
-          const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
-          const float ct = a.csave[r * ldh + (size_t)dir * H + j];
-          const int tp = time_of(dir, a.step - 1, len);  // previous recurrence step of this row
-          const float cp = (a.step > 0 && tp >= 0) ? a.csave[((size_t)tp * B + b) * ldh + (size_t)dir * H + j]
-                                                   : (a.c0 ? a.c0[dir * H + j] : 0.f);
-          const float tc = tanhf(ct);
-          const float dh = a.dy[r * ldh + (size_t)dir * H + j] + Dt[bl * 17 + n];
-          const float dcv = dh * og * (1.f - tc * tc) + dc_in[(size_t)b * H + j];
-          float* dgo = a.dg + r * ldg + (size_t)dir * G4 + j;
-          dgo[0] = dcv * gg * ig * (1.f - ig);
-          dgo[H] = dcv * cp * fg * (1.f - fg);
-          dgo[2 * H] = dcv * ig * (1.f - gg * gg);
-          dgo[3 * H] = dh * tc * og * (1.f - og);
-          dc_keep = dcv * fg;
-        }
-        dc_out[(size_t)b * H + j] = dc_keep;
-      }
+    for (int s = 0; s < 8; ++s) {
+      const int i = c * 8 + s;
+      const int o = i < kiter ? 16 * i : 0;
+      av[s] = *reinterpret_cast<const float4*>(dgp + o);
+      bv[s] = *reinterpret_cast<const float4*>(wp + o);
     }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float4 x = av[s];
+      if (!has_next || c * 8 + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
+  __syncthreads();
+  if (b < B) {
+    float dc_keep = 0.f;
+    if (t >= 0) {
+      const float dhr = (P[0][bl][n] + P[1][bl][n]) + (P[2][bl][n] + P[3][bl][n]);
+      const float tc = tanhf(ct);
+      const float dh = dyv + dhr;
+      const float dcv = dh * og * (1.f - tc * tc) + dcin;
+      float* dgo = a.dg + r * ldg + (size_t)dir * G4 + j;
+      dgo[0] = dcv * gg * ig * (1.f - ig);
+      dgo[H] = dcv * cp * fg * (1.f - fg);
+      dgo[2 * H] = dcv * ig * (1.f - gg * gg);
+      dgo[3 * H] = dh * tc * og * (1.f - og);
+      dc_keep = dcv * fg;
+    }
+    dc_out[(size_t)b * H + j] = dc_keep;
   }
 }
 
@@ -241,7 +267,7 @@ using namespace itts;
 
 static int lstm_check(int T, int B, int H, int ndir) {
   ITTS_REQUIRE(T >= 1 && B >= 1 && (ndir == 1 || ndir == 2), "bad sizes");
-  ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 2048, "hidden size must be a multiple of 16 (<= 2048)");
+  ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 4096, "hidden size must be a multiple of 16");
   return ITTS_OK;
 }
 
@@ -272,12 +298,12 @@ extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const
   hipLaunchKernelGGL(lstm_init_state_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256),
                      0, s, d_h0, d_c0, a.hs, a.cs, ndir, B, H);
   ITTS_LAUNCH_CHECK();
-  const size_t lds = (size_t)(16 * (H + 4) + 64 * 17) * 4;
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_step_fwd_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((H / FW_UNITS) * ((B + 15) / 16), ndir);
+  a.ksplit = (H % 64 == 0) ? 4 : ((H % 32 == 0) ? 2 : 1);
+  a.kiter = H / (16 * a.ksplit);
   for (int step = 0; step < T; ++step) {
     a.step = step;
-    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(H / FW_UNITS, ndir), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
   // final states live in parity (T & 1)
@@ -304,13 +330,10 @@ extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, cons
   a.cs = a.hs + st;
   ITTS_HIP_CHECK(hipMemsetAsync(d_dg, 0, (size_t)T * B * ndir * 4 * H * 4, s));
   ITTS_HIP_CHECK(hipMemsetAsync(a.cs, 0, st * 4, s));
-  const size_t lds = (size_t)(16 * (4 * H + 4) + 64 * 17) * 4;
-  ITTS_REQUIRE(lds <= 160 * 1024, "hidden size too large for the backward LDS tile");
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_step_bwd_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((H / BW_UNITS) * ((B + 15) / 16), ndir);
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
-    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(H / BW_UNITS, ndir), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
