@@ -313,10 +313,18 @@ def main():
         ms = hip_event_time_ms(gemms, stream, 10)
         flops = flops_per_frame(dims) * nloc
         achieved = flops / (ms * 1e-3) / 1e12
+        # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # see profiles/r1_gemm_traffic.json); not re-measured inside bench.py.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")
+        if os.path.isfile(tpath) and args.utts_per_gpu == 32:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (8 launches per step)",
                     "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": None,
-                    "gemm_ms_per_step": ms}
+                    "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
+                    "algorithmic_flops_per_launch": flops / 8.0,
+                    "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / 8.0}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline_ff(args.utts_per_gpu)

@@ -310,9 +310,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int col = blockIdx.x * 64 + tx;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
   const int64_t r1 = std::min<int64_t>(M, r0 + rows_per_slice);
-  float s = 0.f;
-  if (col < N)
-    for (int64_t r = r0 + ty; r < r1; r += 4) s += dz[r * ld + col];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < N) {
+    int64_t r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {  // 4 independent loads in flight per thread
+      s0 += dz[r * ld + col];
+      s1 += dz[(r + 4) * ld + col];
+      s2 += dz[(r + 8) * ld + col];
+      s3 += dz[(r + 12) * ld + col];
+    }
+    for (; r < r1; r += 4) s0 += dz[r * ld + col];
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && col < N)
@@ -378,6 +387,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+constexpr int kColsumSlices = 256;  // row slices of the bias-gradient column sums
+
 static int choose_splitk(int64_t M, int N, int K) {
   const int64_t tiles = (int64_t)((N + BM - 1) / BM) * ((K + BN - 1) / BN);
   int64_t s = std::max<int64_t>(1, 512 / std::max<int64_t>(tiles, 1));
@@ -442,7 +453,7 @@ extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const floa
 extern "C" int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
   const int s = choose_splitk(M, N, K);
-  return (int64_t)s * N * K * 4 + (int64_t)s * N * 4 + 256;
+  return (int64_t)s * N * K * 4 + (int64_t)kColsumSlices * N * 4 + 256;
 }
 
 extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x,
@@ -477,10 +488,13 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
                      dim3(256), 0, s, slabs, S_eff, n, d_dw, accumulate);
   ITTS_LAUNCH_CHECK();
   if (d_db) {
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, S_eff), dim3(256), 0, s, d_dz,
-                       lddz, M, N, kchunk, bpart);
+    int64_t rows = (M + kColsumSlices - 1) / kColsumSlices;
+    rows = std::max<int64_t>(rows, 16);
+    const int cs = (int)((M + rows - 1) / rows);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, cs), dim3(256), 0, s, d_dz,
+                       lddz, M, N, rows, bpart);
     ITTS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, s, bpart, S_eff,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, s, bpart, cs,
                        (int64_t)N, d_db, accumulate);
     ITTS_LAUNCH_CHECK();
   }
