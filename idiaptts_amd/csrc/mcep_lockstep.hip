@@ -1,0 +1,316 @@
+// SPTK mcep (pysptk.mcep, AudioProcessing.py:146-152) in LOCKSTEP over all frames of a batch.
+//
+// The per-frame kernel (world_frame.hip: mcep_frame) re-reads the three frequency-warping
+// matrices (735 KB at order 59) from L2 for every frame and Newton iteration and was bound by
+// exactly that traffic (4.3 TB/s aggregate, 118 us per iteration and workgroup).  The warping
+// steps are linear maps, so over a batch they are matrix products with T rows:
+//     mc   = C  [T x 513] . Fwd [513 x 60]          once
+//     c'   = MC [T x 60 ] . Inv [60 x 513]          per iteration
+//     cr   = R  [T x 513] . Frq [513 x 119]         per iteration
+// evaluated here with fp64 MFMA (v_mfma_f64_16x16x4_f64; GEMM-shaped fp64 work is what the
+// matrix core is for), while the per-frame pieces (2 real FFTs + exp, convergence test, the
+// 60x60 Toeplitz-plus-Hankel solve) stay one workgroup per frame.  All frames advance one Newton
+// step per round; converged frames are frozen by a flag and skipped by the per-frame kernels.
+// The arithmetic per frame is the same as in mcep_frame up to summation order (<= 1e-15 rel.).
+#include <algorithm>
+#include <vector>
+
+#include "context.h"
+#include "world_dev.h"
+
+namespace itts {
+using namespace wd;
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// C[T, N] = A[T, K] . B[K, N]; all row-major f64. Workgroup: 64 rows x 64 cols, wave: 16 x 64.
+__global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
+                                                       const double* __restrict__ Bm, int64_t ldb,
+                                                       double* __restrict__ C, int64_t ldc, int64_t T,
+                                                       int N, int K) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 64 + wv * 16;
+  const int c0 = blockIdx.y * 64;
+  const int64_t row = r0 + lr;
+  const bool rok = row < T;
+  const double* ap = A + (rok ? row : 0) * lda;
+  f64x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  bool cok[4];
+  int ccol[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ccol[q] = c0 + 16 * q + lr;
+    cok[q] = ccol[q] < N;
+    if (!cok[q]) ccol[q] = 0;
+  }
+  // K permutation: lane (lr, kg) supplies k = 16 s + 4 kg + j on MFMA j of chunk s
+  for (int s = 0; s < K; s += 16) {
+    double av[4];
+    double bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = s + 4 * kg + j;
+      const bool kok = k < K;
+      const int kc = kok ? k : 0;
+      const double a = ap[kc];
+      av[j] = (kok && rok) ? a : 0.0;
+      const double* brow = Bm + (int64_t)kc * ldb;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double b = brow[ccol[q]];
+        bv[j][q] = (kok && cok[q]) ? b : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j][q], acc[q], 0, 0, 0);
+  }
+  // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!cok[q]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = r0 + kg + 4 * r;
+      if (orow < T) C[orow * ldc + ccol[q]] = acc[q][r];
+    }
+  }
+}
+
+struct LsArgs {
+  const double* in;      // amplitude [T,K] (mode 0) or power envelope [T,K] (mode 1)
+  int in_is_power;
+  int64_t T;
+  int flng, logflng, m;
+  double alpha, eps;
+  int itr1, itr2;
+  double dd;
+  double* xp;            // [T, f2+1] periodogram
+  double* cbuf;          // [T, f2+1] cepstrum / c' / r (reused)
+  double* mc;            // [T, m+1]
+  double* cr;            // [T, 2m+1]
+  double* sprev;         // [T]
+  int* done;             // [T]
+  int* iters;            // [T]
+  int* n_active;         // [1]
+  int iter;              // current Newton iteration (1-based)
+  const double2* g_tw;
+};
+
+// x = amp^2 + eps; c = irfft(log x), c[0] /= 2, c[f2] /= 2
+__global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int f2 = a.flng / 2, K = f2 + 1;
+  double2* tw = reinterpret_cast<double2*>(smem);
+  double2* z = tw + f2;
+  double* zr = reinterpret_cast<double*>(z);
+  const int64_t g = blockIdx.x;
+  load_twiddles(tw, a.g_tw, a.flng);
+  for (int k = threadIdx.x; k < K; k += NT) {
+    double v = a.in[g * K + k];
+    if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
+    const double x = v * v + a.eps;
+    a.xp[g * K + k] = x;
+    z[k] = make_double2(log(x), 0.0);
+  }
+  __syncthreads();
+  irfft_lds(z, a.flng, a.logflng, tw, a.flng);
+  for (int k = threadIdx.x; k < K; k += NT) {
+    double v = zr[k];
+    if (k == 0 || k == f2) v /= 2;
+    a.cbuf[g * K + k] = v;
+  }
+  if (threadIdx.x == 0) {
+    a.sprev[g] = zr[0] / 2;
+    a.done[g] = 0;
+    a.iters[g] = 0;
+  }
+}
+
+// r = irfft( xp / exp(2 Re rfft(c')) ), in place on cbuf rows of active frames
+__global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t g = blockIdx.x;
+  if (a.done[g]) return;
+  const int f2 = a.flng / 2, K = f2 + 1;
+  double2* tw = reinterpret_cast<double2*>(smem);
+  double2* z = tw + f2;
+  double* zr = reinterpret_cast<double*>(z);
+  load_twiddles(tw, a.g_tw, a.flng);
+  double* row = a.cbuf + g * K;
+  for (int i = threadIdx.x; i < a.flng + 2; i += NT) zr[i] = (i <= f2) ? row[i] : 0.0;
+  __syncthreads();
+  rfft_lds(z, a.flng, a.logflng, tw, a.flng);
+  const double* xp = a.xp + g * K;
+  for (int k = threadIdx.x; k <= f2; k += NT) z[k] = make_double2(xp[k] / exp(2.0 * z[k].x), 0.0);
+  __syncthreads();
+  irfft_lds(z, a.flng, a.logflng, tw, a.flng);
+  for (int k = threadIdx.x; k <= f2; k += NT) row[k] = zr[k];
+}
+
+// convergence test + Newton update of one frame from cr
+__global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t g = blockIdx.x;
+  if (a.done[g]) return;
+  const int m = a.m, m1 = m + 1, m2 = 2 * m, ld = m + 2;
+  double* cr = reinterpret_cast<double*>(smem);   // [2m+1]
+  double* A = cr + (m2 + 2);                      // [m1][m+2]
+  double* fcol = A + (size_t)m1 * ld;             // [m1]
+  const int tid = threadIdx.x;
+  for (int j = tid; j <= m2; j += NT) cr[j] = a.cr[g * (m2 + 1) + j];
+  __syncthreads();
+  const double t = cr[0];
+  if (a.iter >= a.itr1) {
+    const double s = a.sprev[g];
+    if (fabs((t - s) / t) < a.dd) {  // uniform
+      if (tid == 0) {
+        a.done[g] = 1;
+        a.iters[g] = a.iter;
+        atomicSub(a.n_active, 1);
+      }
+      return;
+    }
+    if (tid == 0) a.sprev[g] = t;
+  }
+  for (int idx = tid; idx < m1 * (m1 + 1); idx += NT) {
+    const int i = idx / (m1 + 1), k = idx - i * (m1 + 1);
+    double v;
+    if (k == m1) {
+      v = cr[i] - pow(-a.alpha, (double)i);
+    } else {
+      const int df = i > k ? i - k : k - i;
+      double tv = cr[df];
+      if (df == 0 || (df % 2 == 0)) tv += cr[0];
+      double hv = cr[i + k];
+      if (((i + k) & 1) == 0) hv -= cr[0];
+      v = tv + hv;
+    }
+    A[i * ld + k] = v;
+  }
+  __syncthreads();
+  for (int c = 0; c < m1; ++c) {
+    const double piv = A[c * ld + c];
+    for (int r = c + 1 + tid; r < m1; r += NT) fcol[r] = A[r * ld + c] / piv;
+    __syncthreads();
+    const int w = m1 - c;
+    for (int idx = tid; idx < (m1 - 1 - c) * w; idx += NT) {
+      const int r = c + 1 + idx / w, k = c + 1 + idx % w;
+      A[r * ld + k] -= fcol[r] * A[c * ld + k];
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {
+    for (int r = m1 - 1; r >= 0; --r) {
+      double s = 0.0;
+      for (int k = r + 1 + tid; k < m1; k += 64) s += A[r * ld + k] * fcol[k];
+      s = wave_sum(s);
+      if (tid == 0) fcol[r] = (A[r * ld + m1] - s) / A[r * ld + r];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < m1; j += NT) a.mc[g * m1 + j] += fcol[j];
+  if (tid == 0 && a.iter == a.itr2) {
+    a.done[g] = 1;
+    a.iters[g] = a.itr2;
+    atomicSub(a.n_active, 1);
+  }
+}
+
+__global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, int m1,
+                                     float* __restrict__ o32, int64_t ld32, double* __restrict__ o64,
+                                     const int* __restrict__ iters_in, int* __restrict__ iters_out) {
+  const int64_t n = T * m1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / m1;
+    const int j = (int)(i - t * m1);
+    const double v = mc[i];
+    if (o32) o32[t * ld32 + j] = (float)v;
+    if (o64) o64[i] = v;
+    if (iters_out && j == 0) iters_out[t] = iters_in[t];
+  }
+}
+
+static int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                           int64_t ldc, int64_t T, int N, int K, hipStream_t s) {
+  dim3 grid((unsigned)((T + 63) / 64), (unsigned)((N + 63) / 64));
+  hipLaunchKernelGGL(gemm_f64_kernel, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+// d_in: amplitude or power spectra [T, K]; results as in itts_mcep.
+int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64_t T, int K, int order,
+                  double alpha, double eps, int miniter, int maxiter, double threshold, float* d_mc_f32,
+                  int64_t ld_mc, double* d_mc_f64, int* d_iters, hipStream_t s) {
+  const int flng = (K - 1) * 2, f2 = flng / 2, m1 = order + 1, m2 = 2 * order;
+  const FreqtTables* ft = get_freqt(ctx, order, f2, alpha, true);
+  if (!ft) return ITTS_E_HIP;
+  int logflng = 0;
+  while ((1 << logflng) < flng) ++logflng;
+  double *xp = nullptr, *cbuf = nullptr, *mc = nullptr, *cr = nullptr, *sprev = nullptr;
+  int *done = nullptr, *iters = nullptr, *n_active = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&xp, (size_t)T * K * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&cbuf, (size_t)T * K * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&mc, (size_t)T * m1 * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&cr, (size_t)T * (m2 + 1) * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&sprev, (size_t)T * 8, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&done, (size_t)T * 4, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&iters, (size_t)T * 4, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&n_active, 4, s));
+  const int tcount = (int)T;
+  ITTS_HIP_CHECK(hipMemcpyAsync(n_active, &tcount, 4, hipMemcpyHostToDevice, s));
+  LsArgs a{};
+  a.in = d_in; a.in_is_power = in_is_power; a.T = T; a.flng = flng; a.logflng = logflng; a.m = order;
+  a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.xp = xp;
+  a.cbuf = cbuf; a.mc = mc; a.cr = cr; a.sprev = sprev; a.done = done; a.iters = iters;
+  a.n_active = n_active; a.g_tw = ctx->twiddles;
+  const size_t lds_fft = (size_t)f2 * 16 + (size_t)(f2 + 1) * 16;
+  const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_spec_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+  hipLaunchKernelGGL(mcls_init_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
+  ITTS_LAUNCH_CHECK();
+  int rc = launch_gemm_f64(cbuf, K, ft->fwdT, m1, mc, m1, T, m1, K, s);
+  if (rc) return rc;
+  for (int it = 1; it <= maxiter; ++it) {
+    a.iter = it;
+    if ((rc = launch_gemm_f64(mc, m1, ft->invT, K, cbuf, K, T, K, m1, s))) return rc;
+    hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
+    ITTS_LAUNCH_CHECK();
+    if ((rc = launch_gemm_f64(cbuf, K, ft->frqT, m2 + 1, cr, m2 + 1, T, m2 + 1, K, s))) return rc;
+    hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)T), dim3(NT), lds_solve, s, a);
+    ITTS_LAUNCH_CHECK();
+    if (it >= miniter && it < maxiter) {
+      int remaining = 0;
+      ITTS_HIP_CHECK(hipMemcpyAsync(&remaining, n_active, 4, hipMemcpyDeviceToHost, s));
+      ITTS_HIP_CHECK(hipStreamSynchronize(s));
+      if (remaining <= 0) break;
+    }
+  }
+  const int64_t n = T * m1;
+  hipLaunchKernelGGL(mcls_finalize_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256),
+                     0, s, mc, T, m1, d_mc_f32, ld_mc, d_mc_f64, iters, d_iters);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(xp, s));
+  ITTS_HIP_CHECK(hipFreeAsync(cbuf, s));
+  ITTS_HIP_CHECK(hipFreeAsync(mc, s));
+  ITTS_HIP_CHECK(hipFreeAsync(cr, s));
+  ITTS_HIP_CHECK(hipFreeAsync(sprev, s));
+  ITTS_HIP_CHECK(hipFreeAsync(done, s));
+  ITTS_HIP_CHECK(hipFreeAsync(iters, s));
+  ITTS_HIP_CHECK(hipFreeAsync(n_active, s));
+  return ITTS_OK;
+}
+
+}  // namespace itts

@@ -518,6 +518,16 @@ __global__ void decode_aperiodicity_kernel(const double* __restrict__ bap, int64
   ap[i] = v;
 }
 
+// mcep_lockstep.hip
+int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64_t T, int K, int order,
+                  double alpha, double eps, int miniter, int maxiter, double threshold, float* d_mc_f32,
+                  int64_t ld_mc, double* d_mc_f64, int* d_iters, hipStream_t s);
+
+static bool use_fused_mcep() {
+  const char* e = getenv("ITTS_MCEP_FUSED");  // A/B switch: per-frame fused kernel instead of lockstep
+  return e && e[0] == '1';
+}
+
 static int smoothing_bmax(int fs, int fft, double max_width) { return (int)(max_width * fft / fs) + 2; }
 
 }  // namespace itts
@@ -560,11 +570,16 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
   FrameArgs a{};
-  if (do_mcep) {
+  const bool fused = do_mcep && use_fused_mcep();
+  if (fused) {
     const FreqtTables* ft = get_freqt(ctx, order, fft_size / 2, alpha, true);
     if (!ft) return ITTS_E_HIP;
     a.ft = *ft;
   }
+  // lockstep mcep needs the envelope in memory: use the caller's buffer or a temporary
+  double* sp_buf = d_sp;
+  if (do_mcep && !fused && !sp_buf)
+    ITTS_HIP_CHECK(hipMallocAsync((void**)&sp_buf, (size_t)t_total * (fft_size / 2 + 1) * 8, s));
   int64_t *d_xo = nullptr, *d_fo = nullptr;
   int rc = upload_i64(h_x_off, n_utts + 1, &d_xo, s);
   if (rc) return rc;
@@ -572,11 +587,11 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   if (rc) return rc;
   a.x = d_x; a.x_off = d_xo; a.f0 = d_f0; a.f_off = d_fo; a.n_utts = n_utts; a.fs = fs;
   a.frame_period = frame_period_ms; a.fft = fft_size; a.logfft = ilog2_host(fft_size); a.q1 = q1;
-  a.sp = d_sp; a.do_mcep = do_mcep ? 1 : 0; a.m = order; a.alpha = alpha; a.eps = eps;
+  a.sp = fused ? d_sp : sp_buf; a.do_mcep = fused ? 1 : 0; a.m = order; a.alpha = alpha; a.eps = eps;
   a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64;
   a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
   a.bmax = smoothing_bmax(fs, fft_size, 1000.0);
-  size_t lds = ct_lds_bytes(fft_size, a.bmax) + (do_mcep ? mc_lds_bytes(order) : 0);
+  size_t lds = ct_lds_bytes(fft_size, a.bmax) + (fused ? mc_lds_bytes(order) : 0);
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -584,6 +599,12 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  if (do_mcep && !fused) {
+    rc = mcep_lockstep(ctx, sp_buf, 1, t_total, fft_size / 2 + 1, order, alpha, eps, miniter, maxiter,
+                       threshold, d_mc_f32, ld_mc, d_mc_f64, d_iters, s);
+    if (sp_buf != d_sp) ITTS_HIP_CHECK(hipFreeAsync(sp_buf, s));
+    if (rc) return rc;
+  }
   return ITTS_OK;
 }
 
@@ -598,6 +619,9 @@ extern "C" int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, do
   if (T == 0) return ITTS_OK;
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
+  if (!use_fused_mcep())
+    return mcep_lockstep(ctx, d_amp_sp, 0, T, K, order, alpha, eps, miniter, maxiter, threshold,
+                         d_mc_f32, ld_mc, d_mc_f64, d_iters, as_stream(stream));
   const FreqtTables* ft = get_freqt(ctx, order, flng / 2, alpha, true);
   if (!ft) return ITTS_E_HIP;
   McepArgs a{};
