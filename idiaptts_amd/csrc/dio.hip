@@ -48,6 +48,7 @@ struct DioParams {
   int hal[MAXB];
   int lowcut_n;   // taps of the 50 Hz low-cut (odd)
   int pad;        // zeros kept on both sides of ylc
+  unsigned contour_lds;  // bytes of LDS the contour kernel may use for the candidates
 };
 
 // ---- per-utterance mean of y (x zero-extended by one sample) ---------------------------------
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(NT) void dio_candidates_kernel(const DioUtt* __rest
 }
 
 // ---- best band + FixF0Contour ------------------------------------------------------------------------
-__device__ inline double select_best(double cur, double past, const double* __restrict__ cands, int nb,
+__device__ inline double select_best(double cur, double past, const double* cands, int nb,
                                      int T, int ti, double ar) {
   const double ref = (cur * 3.0 - past) / 2.0;
   double me = fabs(ref - cands[ti]);
@@ -284,19 +285,30 @@ __global__ __launch_bounds__(NT) void dio_contour_kernel(const DioUtt* __restric
                                                          const double* __restrict__ scores_all,
                                                          double* __restrict__ tmp_all,
                                                          double* __restrict__ f0_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
   const DioUtt u = utts[blockIdx.x];
   const int T = u.T, nb = p.nb;
   const double* cands = cands_all + u.cand_off;
   const double* scores = scores_all + u.cand_off;
-  double* base = tmp_all + u.tmp_off;  // best, then step arrays
-  double* s1 = base + T;
-  double* s2 = s1 + T;
   double* out = f0_out + u.f_off;
   const double ar = p.allowed_range;
   const int vrm = (int)(0.5 + 1000.0 / p.frame_period / p.f0_floor) * 2 + 1;
   if (T <= vrm) {
     for (int i = threadIdx.x; i < T; i += NT) out[i] = 0.0;
     return;
+  }
+  // The sequential passes (steps 3 / 4) are chains of dependent reads: keep the candidates and
+  // the two working contours in LDS when they fit ((nb + 2) * T doubles), else in global scratch.
+  const bool in_lds = (size_t)(nb + 2) * T * 8 <= p.contour_lds;
+  double* lds = reinterpret_cast<double*>(smem_c);
+  double* base = tmp_all + u.tmp_off;                 // best candidate per frame
+  double* s1 = in_lds ? lds + (size_t)nb * T : base + T;          // step-2 contour (boundaries)
+  double* s3 = in_lds ? lds + (size_t)(nb + 1) * T : base + 2 * T;  // working contour
+  double* tmp = base + 3 * T;                         // step-1 contour
+  const double* scand = cands;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < nb * T; i += NT) lds[i] = cands[i];
+    scand = lds;
   }
   // best candidate per frame (first band wins ties), restricted to [vrm, T-vrm)
   for (int i = threadIdx.x; i < T; i += NT) {
@@ -315,51 +327,43 @@ __global__ __launch_bounds__(NT) void dio_contour_kernel(const DioUtt* __restric
   for (int i = threadIdx.x; i < T; i += NT) {
     double v = 0.0;
     if (i >= vrm) v = fabs((base[i] - base[i - 1]) / (kEps + base[i])) < ar ? base[i] : 0.0;
-    s1[i] = v;
+    tmp[i] = v;
   }
   __syncthreads();
   // step 2: drop frames whose +-c neighbourhood contains an unvoiced frame
   const int c = (vrm - 1) / 2;
   for (int i = threadIdx.x; i < T; i += NT) {
-    double v = s1[i];
+    double v = tmp[i];
     if (i >= c && i < T - c) {
       for (int j = -c; j <= c; ++j)
-        if (s1[i + j] == 0.0) {
+        if (tmp[i + j] == 0.0) {
           v = 0.0;
           break;
         }
     }
-    s2[i] = v;
+    s1[i] = v;
+    s3[i] = v;
   }
   __syncthreads();
   // steps 3 and 4 are sequential along time (each extension reads values the previous one wrote)
   if (threadIdx.x == 0) {
-    double* s3 = s2;  // extend in place: positive / negative boundaries are taken from s2 first
-    // boundaries (from the unmodified step-2 contour) are recomputed on the fly: keep a copy in s1
-    for (int i = 0; i < T; ++i) s1[i] = s2[i];
-    // step 3: forward extension from every voiced->unvoiced boundary
-    int next_neg = -1;
-    // find the list of negative boundaries lazily: neg = i-1 where s1[i]==0 && s1[i-1]!=0
+    // step 3: forward extension from every voiced->unvoiced boundary of the step-2 contour
     int i = 1;
     while (i < T) {
       while (i < T && !(s1[i] == 0.0 && s1[i - 1] != 0.0)) ++i;
       if (i >= T) break;
       const int neg = i - 1;
-      // next negative boundary
       int k = i + 1;
       while (k < T && !(s1[k] == 0.0 && s1[k - 1] != 0.0)) ++k;
       const int limit = (k >= T) ? T - 1 : k - 1;
       for (int j = neg; j < limit; ++j) {
-        s3[j + 1] = select_best(s3[j], s3[j - 1], cands, nb, T, j + 1, ar);
+        s3[j + 1] = select_best(s3[j], s3[j - 1], scand, nb, T, j + 1, ar);
         if (s3[j + 1] == 0.0) break;
       }
       i = k;
       if (k >= T) break;
-      (void)next_neg;
     }
-    // step 4: backward extension from every unvoiced->voiced boundary of the step-2 contour
-    for (int q = 0; q < T; ++q) out[q] = s3[q];
-    // positive boundaries in descending order: pos = i where s1[i-1]==0 && s1[i]!=0
+    // step 4: backward extension from every unvoiced->voiced boundary (in place on s3)
     int ii = T - 1;
     while (ii >= 1) {
       while (ii >= 1 && !(s1[ii - 1] == 0.0 && s1[ii] != 0.0)) --ii;
@@ -369,13 +373,15 @@ __global__ __launch_bounds__(NT) void dio_contour_kernel(const DioUtt* __restric
       while (k >= 1 && !(s1[k - 1] == 0.0 && s1[k] != 0.0)) --k;
       const int limit = (k < 1) ? 1 : k;
       for (int j = pos; j > limit; --j) {
-        out[j - 1] = select_best(out[j], out[j + 1], cands, nb, T, j - 1, ar);
-        if (out[j - 1] == 0.0) break;
+        s3[j - 1] = select_best(s3[j], s3[j + 1], scand, nb, T, j - 1, ar);
+        if (s3[j - 1] == 0.0) break;
       }
       ii = k;
       if (k < 1) break;
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T; i += NT) out[i] = s3[i];
 }
 
 }  // namespace itts
@@ -508,7 +514,14 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
     hipLaunchKernelGGL(dio_candidates_kernel, dim3((max_T + NT - 1) / NT, p.nb, U), dim3(NT), 0, s, d_utts,
                        p, d_fine, d_cnt, d_cand, d_score);
     ITTS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dio_contour_kernel, dim3(U), dim3(NT), 0, s, d_utts, p, d_cand, d_score, d_tmp, d_f0);
+    {
+      size_t lds = std::min<size_t>((size_t)(p.nb + 2) * max_T * 8, 150 * 1024);
+      p.contour_lds = (unsigned)lds;
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)dio_contour_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(dio_contour_kernel, dim3(U), dim3(NT), lds, s, d_utts, p, d_cand, d_score, d_tmp,
+                         d_f0);
+    }
     ITTS_LAUNCH_CHECK();
     ITTS_HIP_CHECK(hipFreeAsync(d_utts, s));
     ITTS_HIP_CHECK(hipFreeAsync(d_mean, s));

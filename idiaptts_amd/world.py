@@ -20,6 +20,16 @@ def _device(device):
     return torch.device(device if device is not None else "cuda")
 
 
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
 def num_frames(n, fs, hop_ms=5.0):
     return int(_lib.load().itts_world_num_frames(int(n), int(fs), float(hop_ms)))
 
@@ -53,12 +63,22 @@ def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
     x = torch.from_numpy(np.ascontiguousarray(np.concatenate(raws), dtype=np.float64)).to(dev)
     f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
     sp = mc = ap = bap = None
+    # CheapTrick/mcep and D4C only share their inputs: run D4C on a side stream so the two
+    # occupancy-bound kernels overlap
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    if want_ap or want_bap:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ap, bap = ops.d4c(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_ap=want_ap,
+                              want_bap=torch.float32 if want_bap else None)
     if want_sp or mcep_order is not None:
         sp, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=want_sp,
                                         order=mcep_order, alpha=mcep_alpha)
     if want_ap or want_bap:
-        ap, bap = ops.d4c(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_ap=want_ap,
-                          want_bap=torch.float32 if want_bap else None)
+        main.wait_stream(side)
+        for t in (x, f0):
+            t.record_stream(side)
     f0 = f0.cpu().numpy()
     sp = sp.cpu().numpy() if sp is not None else None
     mc = mc.cpu().numpy() if mc is not None else None
