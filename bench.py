@@ -129,15 +129,20 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
         "analysis_algorithmic_GBps": frames * (80 * 8 + 62 * 4) / (ms_an * 1e-3) / 1e9,
         "synthesis_algorithmic_GBps": frames * 8536 / (ms_sy * 1e-3) / 1e9,
     }
-    # MLPG on [T, 187] (62 static dims in 3 streams): algorithmic 2000 B / frame
-    feat = torch.randn(frames, 186, dtype=torch.float64, device=dev)
+    # MLPG on [T, 187] (62 static dims in 3 streams), 256 utterances of 2-10 s (SURVEY.md section 8d,
+    # config 4): algorithmic 2000 B / frame
+    from idiaptts_amd.bench_support import utterance_lengths
+    ml_off = world.offsets(utterance_lengths(256, seed=5).tolist())
+    ml_frames = ml_off[-1]
+    feat = torch.randn(ml_frames, 186, dtype=torch.float64, device=dev)
     var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
-    ops.mlpg_generation(feat, var, 62, f_off)
+    ops.mlpg_generation(feat, var, 62, ml_off)
     torch.cuda.synchronize()
-    ms_ml = hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, f_off), stream, 5)
-    res["mlpg"] = {"ms": ms_ml, "frames_per_s": frames / (ms_ml * 1e-3),
-                   "algorithmic_GBps": frames * 2000 / (ms_ml * 1e-3) / 1e9,
-                   "frac_of_hbm_peak": frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    ms_ml = hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off), stream, 5)
+    res["mlpg"] = {"utterances": 256, "frames": ml_frames, "ms": ms_ml,
+                   "frames_per_s": ml_frames / (ms_ml * 1e-3),
+                   "algorithmic_GBps": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9,
+                   "frac_of_hbm_peak": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS}
     if with_cpu:
         from oracle import capi
         t0 = time.perf_counter()

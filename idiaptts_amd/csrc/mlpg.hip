@@ -13,6 +13,8 @@
 //
 // Roofline: HBM.  Algorithmic bytes per frame = 187*8 read + 63*8 written = 2000 B
 // (SURVEY.md section 8d); the factor scratch adds 3 f64 written + 4 read per (frame, dim).
+#include <algorithm>
+
 #include "common.h"
 
 namespace itts {
@@ -29,12 +31,60 @@ struct MlpgArgs {
   double* out;
   int64_t ld_out;
   int ocol0;
-  double* scratch;  // 3 planes [Ttot, dim]: d, l1, l2
+  double* scratch;  // 3 planes [Ttot, dim]: 1/d, l1, l2 (shared factor) + nconv
   int64_t t_total;
+  int* nconv;       // [dim] frame index where the shared factor becomes stationary
 };
 
-__global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
+// The Cholesky factor of P depends on the variances and on the frame index only (not on the
+// data), and -- because the delta variances are constant except in the first and last frame --
+// it is the SAME for every utterance up to frame T-3.  mlpg_factor_kernel computes that shared
+// factor once per dimension for the longest utterance ("T = infinity": edge variance at frame 0
+// only); the per-utterance solve reads it and only re-derives the last two frames.  The solve is
+// then two first-order-dependent sweeps of ~3 FMAs per frame instead of a sqrt and three
+// divisions per frame in the dependency chain.
+__global__ __launch_bounds__(64) void mlpg_factor_kernel(MlpgArgs a, int t_max) {
   const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= a.dim) return;
+  const int D = a.dim;
+  const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
+  const double tau0 = 1.0 / v0, tau1_in = 1.0 / v1, tau2_in = 1.0 / v2, tau_edge = 1.0 / kBigVar;
+  auto tau1 = [&](int t) -> double { return t < 0 ? 0.0 : (t == 0 ? tau_edge : tau1_in); };
+  auto tau2 = [&](int t) -> double { return t < 0 ? 0.0 : (t == 0 ? tau_edge : tau2_in); };
+  const int64_t plane = (int64_t)t_max * D;
+  double* fd = a.scratch + d;
+  double* fl1 = fd + plane;
+  double* fl2 = fl1 + plane;
+  double l1p = 0.0, l2p = 0.0, cprev = 0.0;
+  int j = 0;
+  for (; j < t_max; ++j) {
+    const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) + (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
+    const double pj1 = -2.0 * (tau2(j) + tau2(j + 1));
+    const double pj2 = tau2(j + 1) - 0.25 * tau1(j + 1);
+    const double dd = sqrt(pjj - l1p * l1p - l2p * l2p);
+    const double l1 = (pj1 - cprev * l1p) / dd;
+    const double l2 = pj2 / dd;
+    fd[(int64_t)j * D] = 1.0 / dd;   // reciprocal: the solve multiplies instead of dividing
+    fl1[(int64_t)j * D] = l1;
+    fl2[(int64_t)j * D] = l2;
+    // P is constant for j >= 2, so the recurrence is a fixed map of (l1p, l2p, cprev): once the
+    // state repeats bit for bit every later frame has the same factor -> stop (the solve clamps
+    // its factor index to this frame)
+    const bool fixed = j >= 3 && l1 == l1p && l2 == cprev && cprev == l2p;
+    l2p = cprev;
+    l1p = l1;
+    cprev = l2;
+    if (fixed) break;
+  }
+  a.nconv[d] = j < t_max ? j : t_max - 1;
+}
+
+// Latency-bound sequential sweeps: what limits throughput is the number of independent chains in
+// flight, so a workgroup carries only LANES (16) dimensions -- a quarter-filled wave per
+// workgroup, 128-B row segments -- which quadruples the waves (and outstanding loads) per batch.
+constexpr int MLPG_LANES = 16;
+__global__ __launch_bounds__(MLPG_LANES) void mlpg_kernel(MlpgArgs a, int t_max) {
+  const int d = blockIdx.x * MLPG_LANES + threadIdx.x;
   const int u = blockIdx.y;
   if (d >= a.dim) return;
   const int64_t t0 = a.offsets[u];
@@ -47,13 +97,11 @@ __global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
 
   const double* f = a.feat + t0 * a.ld_feat + a.col0 + d;
   double* o = a.out + t0 * a.ld_out + a.ocol0 + d;
-  const int64_t plane = a.t_total * (int64_t)D;
-  double* sd = a.scratch + t0 * D + d;
-  double* sl1 = sd + plane;
-  double* sl2 = sl1 + plane;
+  const int64_t plane = (int64_t)t_max * D;
+  const double* fd = a.scratch + d;
+  const double* fl1 = fd + plane;
+  const double* fl2 = fl1 + plane;
 
-  auto var1 = [&](int64_t t) { return (t == 0 || t == T - 1) ? kBigVar : v1; };
-  auto var2 = [&](int64_t t) { return (t == 0 || t == T - 1) ? kBigVar : v2; };
   auto tau1 = [&](int64_t t) -> double {
     if (t < 0 || t >= T) return 0.0;
     return (t == 0 || t == T - 1) ? tau_edge : tau1_in;
@@ -63,68 +111,78 @@ __global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
     return (t == 0 || t == T - 1) ? tau_edge : tau2_in;
   };
 
+  const int64_t ncv = a.nconv[d];
+  const double rv0 = 1.0 / v0, rv1 = 1.0 / v1, rv2 = 1.0 / v2, rvb = 1.0 / kBigVar;
+  auto rvar1 = [&](int64_t t) { return (t == 0 || t == T - 1) ? rvb : rv1; };
+  auto rvar2 = [&](int64_t t) { return (t == 0 || t == T - 1) ? rvb : rv2; };
+  // factor of frame j: shared for j <= T-3, re-derived with the true edge variances for the last
+  // two frames (tail[0] = frame T-2, tail[1] = frame T-1; T < 3: everything re-derived)
+  double tl_d[2] = {1.0, 1.0}, tl_1[2] = {0.0, 0.0}, tl_2[2] = {0.0, 0.0};
+  const int64_t n_shared = T >= 3 ? T - 2 : 0;
+
   // b-frames (mean / var, mlpg.py:123) of rows j-1, j, j+1 for windows 1 and 2.
   double p1 = 0.0, p2 = 0.0;  // row j-1
   double c0, c1, c2;          // row j
-  c0 = f[0] / v0;
-  c1 = f[D] / var1(0);
-  c2 = f[2 * D] / var2(0);
+  c0 = f[0] * rv0;
+  c1 = f[D] * rvar1(0);
+  c2 = f[2 * D] * rvar2(0);
   // Cholesky state: row j entries L[j,j-1], L[j,j-2]; y[j-1], y[j-2]
   double l1p = 0.0, l2p = 0.0, cprev = 0.0, y1 = 0.0, y2 = 0.0;
 
-  constexpr int PF = 4;  // rows prefetched ahead of the recurrence
-  double nb0[PF], nb1[PF], nb2[PF];
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    const int64_t t = 1 + i;
-    if (t < T) {
-      const double* r = f + t * a.ld_feat;
-      nb0[i] = r[0];
-      nb1[i] = r[D];
-      nb2[i] = r[2 * D];
-    } else {
-      nb0[i] = nb1[i] = nb2[i] = 0.0;
-    }
-  }
-
-  for (int64_t jb = 0; jb < T; jb += PF) {
-    // issue loads for the block after this one before touching the recurrence
-    double fb0[PF], fb1[PF], fb2[PF];
+  constexpr int PF = 8;  // rows prefetched ahead of the recurrence
+  double nb0[PF], nb1[PF], nb2[PF], nd[PF], nl1[PF], nl2[PF];
+  auto load_block = [&](int64_t jb, double (&b0)[PF], double (&b1)[PF], double (&b2)[PF],
+                        double (&bd)[PF], double (&bl1)[PF], double (&bl2)[PF]) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      const int64_t t = jb + PF + 1 + i;
-      if (t < T) {
-        const double* r = f + t * a.ld_feat;
-        fb0[i] = r[0];
-        fb1[i] = r[D];
-        fb2[i] = r[2 * D];
-      } else {
-        fb0[i] = fb1[i] = fb2[i] = 0.0;
-      }
+      const int64_t t = jb + 1 + i;  // mean row j+1
+      const int64_t tc = t < T ? t : T - 1;
+      const double* r = f + tc * a.ld_feat;
+      b0[i] = r[0];
+      b1[i] = r[D];
+      b2[i] = r[2 * D];
+      const int64_t j = jb + i;      // factor of frame j
+      const int64_t jc = j < n_shared ? (j < ncv ? j : ncv) : 0;
+      bd[i] = fd[jc * D];
+      bl1[i] = fl1[jc * D];
+      bl2[i] = fl2[jc * D];
     }
+  };
+  load_block(0, nb0, nb1, nb2, nd, nl1, nl2);
+
+  for (int64_t jb = 0; jb < T; jb += PF) {
+    // issue the loads of the next block before touching the recurrence
+    double fb0[PF], fb1[PF], fb2[PF], fbd[PF], fbl1[PF], fbl2[PF];
+    load_block(jb + PF, fb0, fb1, fb2, fbd, fbl1, fbl2);
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int64_t j = jb + i;
       if (j < T) {
-        // row j+1 b-frames
         double n0 = 0.0, n1 = 0.0, n2 = 0.0;
         if (j + 1 < T) {
-          n0 = nb0[i] / v0;
-          n1 = nb1[i] / var1(j + 1);
-          n2 = nb2[i] / var2(j + 1);
+          n0 = nb0[i] * rv0;
+          n1 = nb1[i] * rvar1(j + 1);
+          n2 = nb2[i] * rvar2(j + 1);
         }
         const double b = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
-        const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) +
-                           (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
-        const double pj1 = (j + 1 < T) ? -2.0 * (tau2(j) + tau2(j + 1)) : 0.0;
-        const double pj2 = (j + 2 < T) ? (tau2(j + 1) - 0.25 * tau1(j + 1)) : 0.0;
-        const double dd = sqrt(pjj - l1p * l1p - l2p * l2p);
-        const double l1 = (pj1 - cprev * l1p) / dd;  // L[j+1,j]
-        const double l2 = pj2 / dd;                  // L[j+2,j]
-        const double y = (b - l1p * y1 - l2p * y2) / dd;
-        sd[j * D] = dd;
-        sl1[j * D] = l1;
-        sl2[j * D] = l2;
+        double dd, l1, l2;  // dd holds 1 / L[j,j]
+        if (j < n_shared) {
+          dd = nd[i];
+          l1 = nl1[i];
+          l2 = nl2[i];
+        } else {
+          const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) +
+                             (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
+          const double pj1 = (j + 1 < T) ? -2.0 * (tau2(j) + tau2(j + 1)) : 0.0;
+          const double pj2 = (j + 2 < T) ? (tau2(j + 1) - 0.25 * tau1(j + 1)) : 0.0;
+          dd = 1.0 / sqrt(pjj - l1p * l1p - l2p * l2p);
+          l1 = (pj1 - cprev * l1p) * dd;  // L[j+1,j]
+          l2 = pj2 * dd;                  // L[j+2,j]
+          const int q = (int)(j - (T - 2));  // 0 or 1 (or negative for T < 2: only frame T-1 => q = 1)
+          if (q == 0) { tl_d[0] = dd; tl_1[0] = l1; tl_2[0] = l2; }
+          else { tl_d[1] = dd; tl_1[1] = l1; tl_2[1] = l2; }
+        }
+        const double y = (b - l1p * y1 - l2p * y2) * dd;
         o[j * a.ld_out] = y;
         // advance to row j+1
         l2p = cprev;  // L[j+1,j-1]
@@ -141,9 +199,8 @@ __global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      nb0[i] = fb0[i];
-      nb1[i] = fb1[i];
-      nb2[i] = fb2[i];
+      nb0[i] = fb0[i]; nb1[i] = fb1[i]; nb2[i] = fb2[i];
+      nd[i] = fbd[i]; nl1[i] = fbl1[i]; nl2[i] = fbl2[i];
     }
   }
 
@@ -155,10 +212,17 @@ __global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
     for (int i = 0; i < PF; ++i) {
       const int64_t j = jb - i;
       if (j >= 0) {
-        rd[i] = sd[j * D];
-        r1[i] = sl1[j * D];
-        r2[i] = sl2[j * D];
+        const int64_t jc = j < n_shared ? (j < ncv ? j : ncv) : 0;
+        rd[i] = fd[jc * D];
+        r1[i] = fl1[jc * D];
+        r2[i] = fl2[jc * D];
         ry[i] = o[j * a.ld_out];
+        if (j >= n_shared) {
+          const int q = (j == T - 1) ? 1 : 0;
+          rd[i] = tl_d[q];
+          r1[i] = tl_1[q];
+          r2[i] = tl_2[q];
+        }
       } else {
         rd[i] = 1.0;
         r1[i] = r2[i] = ry[i] = 0.0;
@@ -168,7 +232,7 @@ __global__ __launch_bounds__(64) void mlpg_kernel(MlpgArgs a) {
     for (int i = 0; i < PF; ++i) {
       const int64_t j = jb - i;
       if (j >= 0) {
-        const double x = (ry[i] - r1[i] * x1 - r2[i] * x2) / rd[i];
+        const double x = (ry[i] - r1[i] * x1 - r2[i] * x2) * rd[i];
         o[j * a.ld_out] = x;
         x2 = x1;
         x1 = x;
@@ -210,7 +274,7 @@ using namespace itts;
 extern "C" int64_t itts_mlpg_scratch_bytes(int64_t t_total, int dim) {
   if (t_total < 0 || dim <= 0) return 0;
   // 3 factor planes + device copy of the offsets (<= t_total + 1 entries, padded)
-  return 3 * t_total * (int64_t)dim * 8 + (t_total + 2) * 8;
+  return 3 * t_total * (int64_t)dim * 8 + (t_total + 2) * 8 + (int64_t)dim * 4 + 16;
 }
 
 extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int dim,
@@ -233,9 +297,14 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   int64_t* d_off = reinterpret_cast<int64_t*>(scratch + 3 * t_total * (int64_t)dim);
   ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
                                 hipMemcpyHostToDevice, s));
-  MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total};
-  dim3 grid((dim + 63) / 64, n_utts);
-  hipLaunchKernelGGL(mlpg_kernel, grid, dim3(64), 0, s, a);
+  int* d_nconv = reinterpret_cast<int*>(d_off + (t_total + 2));
+  MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total, d_nconv};
+  int64_t t_max = 0;
+  for (int u = 0; u < n_utts; ++u) t_max = std::max(t_max, h_offsets[u + 1] - h_offsets[u]);
+  hipLaunchKernelGGL(mlpg_factor_kernel, dim3((dim + 63) / 64), dim3(64), 0, s, a, (int)t_max);
+  ITTS_LAUNCH_CHECK();
+  dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
+  hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
