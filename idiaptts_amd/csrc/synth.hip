@@ -129,10 +129,20 @@ __global__ __launch_bounds__(64) void syn_phase_seq_kernel(const SynUtt* __restr
     for (int i = threadIdx.x; i < n; i += 64) buf[i] = a[base + i];
     __syncthreads();
     if (threadIdx.x == 0) {
-#pragma unroll 8
-      for (int i = 0; i < n; ++i) {
-        total = __dadd_rn(total, buf[i]);
-        buf[i] = total;
+      // 8 samples per trip: loads first, then the strictly ordered additions, then the stores, so
+      // the LDS latency is paid once per 8 samples instead of once per sample
+      for (int i = 0; i < n; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = buf[i + q < SEQ ? i + q : SEQ - 1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (i + q < n) total = __dadd_rn(total, v[q]);
+          v[q] = total;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (i + q < n) buf[i + q] = v[q];
       }
     }
     __syncthreads();

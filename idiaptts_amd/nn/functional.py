@@ -60,7 +60,9 @@ class LSTMLayerFunction(torch.autograd.Function):
         keep = bool(training)
         gates = torch.empty((T * B, ndir * G4), dtype=torch.float32, device=dev) if keep else None
         csave = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
-        hprev = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        # zero-filled: padded rows enter the dW_hh GEMM multiplied by zero gate gradients, and
+        # 0 * (uninitialised NaN) would poison the sum
+        hprev = torch.zeros((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
         hn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         cn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_lstm_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
