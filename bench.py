@@ -75,7 +75,7 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
                       "frames)".format(steps, n_utts, int(lengths.sum()))}
 
 
-def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
+def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=True, key="world"):
     """WORLD feature path on `n_utts` synthetic utterances (inputs resident in HBM, GPU time by
     events on the launch stream): analysis wav -> (f0, mcep60, bap), synthesis
     (mcep60, bap, f0) -> wav, MLPG on the 187-dim cmp, and the C-oracle CPU baseline on a
@@ -118,7 +118,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
     torch.cuda.synchronize()
     ms_sy = hip_event_time_ms(synthesis, stream, 3)
     frames = f_off[-1]
-    res["world"] = {
+    res[key] = {
         "fs": fs, "utterances": n_utts, "audio_seconds": audio_s, "frames": frames,
         "analysis_ms": ms_an, "analysis_rtf": ms_an * 1e-3 / audio_s,
         "analysis_frames_per_s": frames / (ms_an * 1e-3),
@@ -126,23 +126,26 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
         "mcep_newton_iters_mean": float(iters.float().mean().item()),
         # algorithmic HBM bytes per frame: fused analysis->features 640 + 248;
         # synthesis 8536
-        "analysis_algorithmic_GBps": frames * (80 * 8 + 62 * 4) / (ms_an * 1e-3) / 1e9,
-        "synthesis_algorithmic_GBps": frames * 8536 / (ms_sy * 1e-3) / 1e9,
+        "analysis_algorithmic_GBps": frames * (fs // 200 * 8 + (61 + L.itts_num_aperiodicities(fs)) * 4)
+        / (ms_an * 1e-3) / 1e9,
+        "synthesis_algorithmic_GBps": frames * ((n_fft // 2 + 1) * 16 + 8 + fs // 200 * 4)
+        / (ms_sy * 1e-3) / 1e9,
     }
-    # MLPG on [T, 187] (62 static dims in 3 streams), 256 utterances of 2-10 s (SURVEY.md section 8d,
-    # config 4): algorithmic 2000 B / frame
-    from idiaptts_amd.bench_support import utterance_lengths
-    ml_off = world.offsets(utterance_lengths(256, seed=5).tolist())
-    ml_frames = ml_off[-1]
-    feat = torch.randn(ml_frames, 186, dtype=torch.float64, device=dev)
-    var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
-    ops.mlpg_generation(feat, var, 62, ml_off)
-    torch.cuda.synchronize()
-    ms_ml = hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off), stream, 5)
-    res["mlpg"] = {"utterances": 256, "frames": ml_frames, "ms": ms_ml,
-                   "frames_per_s": ml_frames / (ms_ml * 1e-3),
-                   "algorithmic_GBps": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9,
-                   "frac_of_hbm_peak": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if with_mlpg:
+        # MLPG on [T, 187] (62 static dims in 3 streams), 256 utterances of 2-10 s (SURVEY.md section 8d,
+        # config 4): algorithmic 2000 B / frame
+        from idiaptts_amd.bench_support import utterance_lengths
+        ml_off = world.offsets(utterance_lengths(256, seed=5).tolist())
+        ml_frames = ml_off[-1]
+        feat = torch.randn(ml_frames, 186, dtype=torch.float64, device=dev)
+        var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
+        ops.mlpg_generation(feat, var, 62, ml_off)
+        torch.cuda.synchronize()
+        ms_ml = hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off), stream, 5)
+        res["mlpg"] = {"utterances": 256, "frames": ml_frames, "ms": ms_ml,
+                       "frames_per_s": ml_frames / (ms_ml * 1e-3),
+                       "algorithmic_GBps": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9,
+                       "frac_of_hbm_peak": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS}
     if with_cpu:
         from oracle import capi
         t0 = time.perf_counter()
@@ -165,7 +168,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True):
             t_sy += c - b
             done_s += len(r) / fs
             k += 1
-        res["world"]["cpu_baseline"] = {
+        res[key]["cpu_baseline"] = {
             "kind": "port", "cores": 1,
             "sample": "{} utterances ({:.1f} s of audio) through the C oracle, one at a time on "
                       "one core".format(k, done_s),
@@ -331,12 +334,16 @@ def main():
                     "algorithmic_flops_per_launch": flops / 8.0,
                     "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / 8.0}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N = 1 only
             cpu = cpu_baseline_ff(args.utts_per_gpu)
         extra = {}
         if world == 1 and args.world_utts > 0:
             extra = world_section(dev, args.world_utts, args.world_fs,
                                   with_cpu=not args.no_cpu_baseline)
+            # config 5 also quotes 48 kHz (fft 2048, 5 aperiodicity bands): a smaller batch
+            extra.update(world_section(dev, max(4, args.world_utts // 4), 48000, cpu_seconds=12.0,
+                                       with_cpu=not args.no_cpu_baseline, with_mlpg=False,
+                                       key="world_48k"))
         if world == 1 and args.bilstm_utts > 0:
             extra.update(bilstm_section(dev, args.bilstm_utts))
         out = {
