@@ -201,7 +201,40 @@ def capture_benchmark_kat():
         hp.world_dir, os.path.join("integration", "fixtures", "questions"), id_list,
         hp.num_questions, hp))
     trainer.init(hp)
+    # end-to-end capture: what the test utterance looks like at every stage boundary
+    e2e = {}
+    wreader = trainer.datareaders["acoustic_features"]
+    qreader = trainer.datareaders["questions"]
+    from idiaptts.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen as RefW
+    orig_post = RefW._postprocess_world
+
+    def rec_post(self, sample, *a, **k):
+        e2e["denormalised"] = np.array(sample)
+        return orig_post(self, sample, *a, **k)
+    RefW._postprocess_world = rec_post
+    orig_inf = trainer.model_handler.inference
+
+    def rec_inf(data, *a, **k):
+        e2e["questions_norm"] = np.array(data["questions"].detach().cpu().numpy()
+                                         if hasattr(data["questions"], "detach")
+                                         else data["questions"])
+        out = orig_inf(data, *a, **k)
+        return out
+    trainer.model_handler.inference = rec_inf
     scores = trainer.benchmark(hp)["pred_acoustic_features"]
+    RefW._postprocess_world = orig_post
+    e2e["test_id"] = np.array(trainer.id_list_test[0])
+    e2e["out_mean"] = np.asarray(wreader.norm_params[0], dtype=np.float64)
+    e2e["out_std"] = np.asarray(wreader.norm_params[1], dtype=np.float64)
+    for i, c in enumerate(wreader.covs):
+        if c is not None:
+            e2e["cov_%d" % i] = np.asarray(c, dtype=np.float64)
+    for k, v in trainer.model_handler.model.state_dict().items():
+        e2e["sd_" + k] = v.cpu().numpy()
+    e2e["original"] = np.asarray(trainer.get_output_dict(trainer.id_list_test, hp)[trainer.id_list_test[0]])
+    e2e["scores"] = np.array(scores, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "benchmark_e2e.npz"), **e2e)
+    print("benchmark_e2e.npz:", {k: getattr(v, "shape", None) for k, v in e2e.items() if not k.startswith("sd_")})
     shutil.rmtree(hp.out_dir, ignore_errors=True)
     print("benchmark scores", scores)
     np.testing.assert_almost_equal((8.616, 78.4, 0.609, 37.352), scores, 3)
@@ -220,6 +253,9 @@ def _main():
     install_stub_harness()
     if "--models" in sys.argv:
         capture_reference_model_forward()
+        return
+    if "--kat" in sys.argv:
+        capture_benchmark_kat()
         return
     capture_host_logic()
     capture_benchmark_kat()

@@ -102,3 +102,35 @@ def test_handler_trains_and_checkpoints(gpu, tmp_path):
     assert (epoch, step) == (1, 12) and not missing and not unexpected
     for (k, a), (_, b) in zip(h.model.state_dict().items(), h2.model.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
+
+
+def test_benchmark_known_answer_end_to_end(gpu, golden_dir):
+    """The reference's pinned benchmark (test_AcousticModelTrainer.py:94-106: MCD 8.616, F0-RMSE
+    78.4, VDE 0.609, BAP 37.352 for an untrained seed-1 RNNDYN-1_RELU_32-1_FC_67) recomputed on
+    the GPU stack: HIP forward of the reference's weights on its normalised test-utterance input,
+    de-normalisation, HIP MLPG per stream (_postprocess_world), objective scores."""
+    from idiaptts_amd.src.Metrics import Metrics
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    g = np.load(os.path.join(golden_dir, "benchmark_e2e.npz"))
+    model = _wrapped("RNNDYN-1_RELU_32-1_FC_67", 409).create_model()
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")})
+    model = model.to(gpu)
+    q = torch.from_numpy(g["questions_norm"]).to(gpu)             # [T, 1, 409] time-major
+    T = q.shape[0]
+    data, lengths = {"questions": q}, {"questions": torch.tensor([T])}
+    model.init_hidden(1)
+    with torch.no_grad():
+        model(data, lengths, {"questions": T})
+    pred = data["pred_acoustic_features"][:, 0].cpu().numpy()
+    denorm = pred * g["out_std"] + g["out_mean"]                  # NpzDataReader.postprocess_sample
+    assert np.abs(denorm - g["denormalised"]).max() < 1e-4
+    gen = WorldFeatLabelGen(None, add_deltas=True, num_coded_sps=20, num_bap=1)
+    gen.covs = [g["cov_0"], g["cov_1"], None, g["cov_3"]]
+    post = gen._postprocess_world(np.array(denorm, dtype=np.float64))
+    out = WorldFeatLabelGen.convert_to_world_features(post, contains_deltas=False,
+                                                      num_coded_sps=20, num_bap=1)
+    org = WorldFeatLabelGen.convert_to_world_features(g["original"], contains_deltas=True,
+                                                      num_coded_sps=20, num_bap=1)
+    scores = Metrics.get_metrics(org, out)
+    np.testing.assert_almost_equal((8.616, 78.4, 0.609, 37.352), scores, 3)
+    assert np.allclose(scores, g["scores"], rtol=1e-5)
