@@ -387,6 +387,34 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---- SGD (torch.optim.SGD: weight decay, momentum, dampening, Nesterov) -------------------------
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                           float* __restrict__ buf, int64_t n, float lr, float momentum,
+                           float dampening, float wd, int nesterov, int first, float gscale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    if (momentum != 0.f) {
+      float bi = first ? gi : buf[i] * momentum + (1.f - dampening) * gi;
+      buf[i] = bi;
+      gi = nesterov ? gi + momentum * bi : bi;
+    }
+    p[i] = pi - lr * gi;
+  }
+}
+
+// ---- exponential moving average of the parameters: shadow -= (1-decay) * (shadow - x) ---------
+__global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__ x, int64_t n,
+                           float one_minus_decay) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float sh = shadow[i];
+    shadow[i] = sh - one_minus_decay * (sh - x[i]);
+  }
+}
+
 constexpr int kColsumSlices = 256;  // row slices of the bias-gradient column sums
 
 static int choose_splitk(int64_t M, int N, int K) {
@@ -549,6 +577,33 @@ extern "C" int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_param, d_grad,
                      d_exp_avg, d_exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size,
                      bc2_sqrt, grad_scale);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_sgd_step(float* d_param, const float* d_grad, float* d_momentum_buf, int64_t n,
+                             float lr, float momentum, float dampening, float weight_decay,
+                             int nesterov, int first_step, float grad_scale, void* stream) {
+  ITTS_REQUIRE(d_param && d_grad, "null pointer");
+  ITTS_REQUIRE(momentum == 0.f || d_momentum_buf, "momentum needs a buffer");
+  ITTS_REQUIRE(n >= 0, "bad size");
+  if (n == 0) return ITTS_OK;
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_param, d_grad,
+                     d_momentum_buf, n, lr, momentum, dampening, weight_decay, nesterov,
+                     first_step, grad_scale);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_ema_update(float* d_shadow, const float* d_param, int64_t n, float decay,
+                               void* stream) {
+  ITTS_REQUIRE(d_shadow && d_param, "null pointer");
+  ITTS_REQUIRE(n >= 0, "bad size");
+  if (n == 0) return ITTS_OK;
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(ema_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_shadow, d_param,
+                     n, 1.f - decay);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }

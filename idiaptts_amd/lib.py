@@ -66,6 +66,9 @@ _SIGNATURES = {
                                     _P]),
     "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_float, _P]),
+    "itts_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int,
+                              c_int, c_float, _P]),
+    "itts_ema_update": (c_int, [_P, _P, c_int64, c_float, _P]),
 }
 
 

@@ -178,6 +178,31 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
                                 int(step), grad_scale, _stream()), "itts_adam_step")
 
 
+def sgd_step(param, grad, momentum_buf=None, first_step=False, lr=1e-3, momentum=0.0,
+             dampening=0.0, weight_decay=0.0, nesterov=False, grad_scale=1.0):
+    L = _lib.load()
+    for t, n in ((param, "param"), (grad, "grad")) + \
+            (((momentum_buf, "momentum_buf"),) if momentum_buf is not None else ()):
+        _need(t, torch.float32, n)
+        if not t.is_contiguous():
+            raise ValueError(n + " must be contiguous")
+    _lib.check(L.itts_sgd_step(_ptr(param), _ptr(grad),
+                               _ptr(momentum_buf) if momentum_buf is not None else None,
+                               param.numel(), lr, momentum, dampening, weight_decay,
+                               int(bool(nesterov)), int(bool(first_step)), grad_scale,
+                               _stream()), "itts_sgd_step")
+
+
+def ema_update(shadow, param, decay):
+    L = _lib.load()
+    for t, n in ((shadow, "shadow"), (param, "param")):
+        _need(t, torch.float32, n)
+        if not t.is_contiguous():
+            raise ValueError(n + " must be contiguous")
+    _lib.check(L.itts_ema_update(_ptr(shadow), _ptr(param), shadow.numel(), float(decay),
+                                 _stream()), "itts_ema_update")
+
+
 # ------------------------------------------------------------------------- WORLD frame kernels
 def _c_int_ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None

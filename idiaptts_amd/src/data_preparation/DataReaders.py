@@ -90,3 +90,84 @@ class NpzStreamReader(object):
             rng[rng == 0.0] = 1.0
             return sample * rng + a
         raise NotImplementedError(self.norm_type)
+
+
+class ReaderBase(object):
+    """What every data reader exposes to the dataset and to prepare_batch (reference
+    data_preparation/DataReader.py:22-137 plus the attributes DataReaderConfig.create_reader
+    attaches, DataReaderConfig.py:120-143): `reader[id]` -> {output_name: preprocessed sample,
+    "_id_list": id}, `get_length`, `pad`, `trim`."""
+
+    name = None
+    output_names = None
+    match_length = None
+    min_frames = None
+    max_frames = None
+    pad_mode = 'constant'
+    other_pad_dims = None
+    random_select = False
+    chunk_size = 1
+    requires_seq_mask = False
+
+    def _configure(self, name, output_names=None, match_length=None, min_frames=None,
+                   max_frames=None, pad_mode='constant', other_pad_dims=None,
+                   random_select=False, chunk_size=1, requires_seq_mask=False):
+        self.name = name
+        self.output_names = list(output_names) if output_names is not None else [name]
+        if match_length is not None and not isinstance(match_length, (tuple, list)):
+            match_length = (match_length,)
+        self.match_length = match_length
+        self.min_frames, self.max_frames = min_frames, max_frames
+        self.pad_mode, self.other_pad_dims = pad_mode, other_pad_dims
+        self.random_select, self.chunk_size = random_select, chunk_size
+        self.requires_seq_mask = requires_seq_mask
+        self._length_cache = {}
+        return self
+
+    def __getitem__(self, id_name):
+        item = self.preprocess_sample(self.load(id_name))
+        items = item if isinstance(item, (tuple, list)) else (item,)
+        if len(items) != len(self.output_names):
+            raise RuntimeError("The data reader returns {} item(s) but {} output names were given."
+                               .format(len(items), len(self.output_names)))
+        if self.chunk_size > 1:
+            items = [self.pad(i, chunk_padding(i, self.chunk_size)) for i in items]
+        out = dict(zip(self.output_names, items))
+        out["_id_list"] = id_name
+        return out
+
+    def get_length(self, id_name):
+        if id_name not in self._length_cache:
+            out = self[id_name]
+            length = max(len(v) for k, v in out.items() if k != "_id_list")
+            c = self.chunk_size
+            self._length_cache[id_name] = ((length + c - 1) // c) * c
+        return self._length_cache[id_name]
+
+    def pad(self, sample, pad_width, pad_mode=None):
+        return np.pad(sample, pad_width, self.pad_mode if pad_mode is None else pad_mode)
+
+    @staticmethod
+    def trim(sample, trim_width):
+        """trim_width: per dim (front, end) tuples (DataReader.trim :131-137)."""
+        if (np.array(trim_width) == 0).all():
+            return sample
+        return sample[tuple(slice(v[0], sample.shape[d] - v[1]) if isinstance(v, tuple) else v
+                            for d, v in enumerate(trim_width))]
+
+    @staticmethod
+    def trim_end_sample(sample, length, reverse=False):
+        """Removes `length` frames from the end (reverse: from the front), as the reference's
+        docstring states (DataReader.py:118-129).  The reference's body hands plain ints to
+        `trim`, which then indexes a single element instead of slicing -- its only caller
+        (AcousticModelTrainer.synthesize :497-500, the synth_load_org_* path) cannot work as
+        written, so the documented behaviour is what is implemented here."""
+        if length == 0:
+            return sample
+        return sample[length:] if reverse else sample[:len(sample) - length]
+
+
+def chunk_padding(item, chunk_size):
+    length = len(item)
+    first = (0, ((length + chunk_size - 1) // chunk_size) * chunk_size - length)
+    return (first, *([(0, 0)] * (item.ndim - 1)))

@@ -25,6 +25,8 @@ from ....misc.normalisation.MeanCovarianceExtractor import MeanCovarianceExtract
 from ....misc.normalisation.MeanStdDevExtractor import MeanStdDevExtractor
 from ....misc.utils import compute_deltas, interpolate_lin  # noqa: F401  (re-exported)
 from ..audio.AudioProcessing import AudioProcessing
+from ..DataReaderConfig import DataReaderConfig
+from ..DataReaders import ReaderBase
 
 
 def _save_to_npz(file_path, features, feature_name):
@@ -39,8 +41,29 @@ def _save_to_npz(file_path, features, feature_name):
     os.replace(tmp, file_path)
 
 
-class WorldFeatLabelGen(object):
+class WorldFeatLabelGen(ReaderBase):
     """Create world feat labels for .wav files."""
+
+    class Config(DataReaderConfig):
+        """Reader config with the WORLD-specific arguments spelled out (reference :62-135);
+        the stream layout is fixed by (sp_type, num_coded_sps, num_bap, add_deltas)."""
+
+        def __init__(self, name, directory=None, features=None, output_names=None,
+                     add_deltas=False, preemphasis=0.0, n_fft=None, win_length_ms=None,
+                     num_coded_sps=60, num_bap=1, sp_type="mcep", load_sp=True, load_lf0=True,
+                     load_vuv=True, load_bap=True, apply_mlpg=True, **kwargs):
+            reader_args = {k: kwargs.pop(k) for k in list(kwargs)
+                           if k in ("hop_size_ms", "mgc_alpha", "batch_utts")}
+            super().__init__(name, WorldFeatLabelGen, directory=directory, features=features,
+                             output_names=output_names, **kwargs)
+            if type(directory) in (tuple, list):
+                directory = directory[0]
+            self.directory = directory
+            self.kwargs = dict(add_deltas=add_deltas, preemphasis=preemphasis, n_fft=n_fft,
+                               win_length_ms=win_length_ms, num_coded_sps=num_coded_sps,
+                               num_bap=num_bap, sp_type=sp_type, load_sp=load_sp,
+                               load_lf0=load_lf0, load_vuv=load_vuv, load_bap=load_bap,
+                               apply_mlpg=apply_mlpg, **reader_args)
 
     f0_silence_threshold = 30
     lf0_zero = 0
@@ -63,8 +86,12 @@ class WorldFeatLabelGen(object):
     def __init__(self, dir_labels=None, add_deltas=False, preemphasis=0.0, n_fft=None,
                  win_length_ms=None, num_coded_sps=60, num_bap=1, sp_type="mcep", hop_size_ms=5,
                  load_sp=True, load_lf0=True, load_vuv=True, load_bap=True, mgc_alpha=None,
-                 batch_utts=32):
+                 batch_utts=32, apply_mlpg=True):
+        if type(dir_labels) in (tuple, list):
+            dir_labels = dir_labels[0]
         self.dir_labels = dir_labels
+        self.apply_mlpg = apply_mlpg
+        self._configure("cmp_features", ["acoustic_features"])
         self.add_deltas = add_deltas
         self.preemphasis = preemphasis
         self.n_fft = n_fft
@@ -386,6 +413,98 @@ class WorldFeatLabelGen(object):
         if return_dict:
             return label_dict, output_means, output_std_dev
         return output_means, output_std_dev
+
+    # ----------------------------------------------------------------------------- reader surface
+    @property
+    def load_flags(self):
+        return (self.load_sp, self.load_lf0, self.load_vuv, self.load_bap)
+
+    def get_normalisation_params(self, dir_out=None, file_name=None):
+        """(mean, std_dev) over the loaded streams, V/UV as (0, 1); with deltas the per-stream
+        covariances land in self.covs for MLPG (reference :575-731).  Looks for the per-stream
+        `.npz` files gen_data writes (`<dir>/<stream>/[<name>-]deltas-mean-covariance.npz` or
+        `[<name>-]mean-std_dev.npz`), then for the legacy `<dir>/cmp_<sp><n>/[<name>-]<stream>-
+        mean-covariance.bin` and its older `mean-covariance_<stream>.bin` spelling."""
+        if dir_out is None:
+            dir_out = self.dir_labels
+        sub_dirs = (self.dir_coded_sps, self.dir_lf0, self.dir_vuv, self.dir_bap)
+        prefix = "" if file_name is None or os.path.basename(file_name) == "" \
+            else file_name + "-"
+        means, std_devs = [], []
+        try:
+            for idx, (load, sub) in enumerate(zip(self.load_flags, sub_dirs)):
+                if not load:
+                    continue
+                if sub == self.dir_vuv:
+                    means.append(np.atleast_2d(0.0))
+                    std_devs.append(np.atleast_2d(1.0))
+                    continue
+                base = os.path.join(dir_out, sub, prefix)
+                if self.add_deltas:
+                    mean, cov, std_dev = MeanCovarianceExtractor.load(
+                        base + "deltas-" + MeanCovarianceExtractor.file_name_appendix + ".npz")
+                    self.covs[idx] = cov
+                else:
+                    mean, std_dev = MeanStdDevExtractor.load(
+                        base + MeanStdDevExtractor.file_name_appendix + ".npz")
+                means.append(np.atleast_2d(mean))
+                std_devs.append(np.atleast_2d(std_dev))
+            self.norm_params = (np.concatenate(means, axis=1), np.concatenate(std_devs, axis=1))
+            return self.norm_params
+        except FileNotFoundError as e0:
+            means, std_devs = [], []
+            for idx, (load, sub) in enumerate(zip(self.load_flags, sub_dirs)):
+                if not load:
+                    continue
+                if sub == self.dir_vuv:
+                    means.append(np.atleast_2d(0.0))
+                    std_devs.append(np.atleast_2d(1.0))
+                    continue
+                appendix = MeanCovarianceExtractor.file_name_appendix
+                candidates = [os.path.join(dir_out, self.dir_deltas,
+                                           "{}{}-{}.bin".format(prefix, sub, appendix)),
+                              os.path.join(dir_out, self.dir_deltas,
+                                           "{}{}_{}.bin".format(prefix, appendix, sub))]
+                for path in candidates:
+                    if os.path.isfile(path):
+                        mean, cov, std_dev = MeanCovarianceExtractor.load(path)
+                        break
+                else:
+                    raise FileNotFoundError([e0] + candidates)
+                if not self.add_deltas:
+                    n = len(cov) // 3
+                    assert len(cov) == 3 * n, "Legacy statistics are expected to hold deltas."
+                    cov, mean, std_dev = cov[:n, :n], mean[:n], std_dev[:n]
+                self.covs[idx] = cov
+                means.append(np.atleast_2d(mean))
+                std_devs.append(np.atleast_2d(std_dev))
+            self.norm_params = (np.concatenate(means, axis=1), np.concatenate(std_devs, axis=1))
+            if self.add_deltas:
+                self.norm_params = (self.norm_params[0][0], self.norm_params[1][0])
+            return self.norm_params
+
+    def preprocess_sample(self, sample, norm_params=None):
+        """(x - mean) / std_dev, float32 (NpzDataReader.preprocess_sample :347-371)."""
+        mean, std_dev = self.norm_params if norm_params is None else norm_params
+        return ((sample - mean) / std_dev).astype(np.float32, copy=False)
+
+    def postprocess_sample(self, sample, norm_params=None, apply_mlpg=None):
+        """De-normalise, then MLPG per stream (reference :338-355 / NpzDataReader :399-420)."""
+        mean, std_dev = self.norm_params if norm_params is None else norm_params
+        sample = sample * std_dev + mean
+        return self._postprocess_world(
+            sample, apply_mlpg=self.apply_mlpg if apply_mlpg is None else apply_mlpg)
+
+    @staticmethod
+    def load_sample(id_name, dir_out, add_deltas=False, num_coded_sps=60, num_bap=1,
+                    sp_type="mcep", load_sp=True, load_lf0=True, load_vuv=True, load_bap=True):
+        """Un-normalised features of one id (reference :417-457)."""
+        assert dir_out is not None, "dir_out cannot be None"
+        id_name = os.path.splitext(os.path.basename(id_name))[0]
+        return WorldFeatLabelGen(dir_labels=dir_out, add_deltas=add_deltas,
+                                 num_coded_sps=num_coded_sps, num_bap=num_bap, sp_type=sp_type,
+                                 load_sp=load_sp, load_lf0=load_lf0, load_vuv=load_vuv,
+                                 load_bap=load_bap).load(id_name)
 
     # -------------------------------------------------------------------------------------- load
     def load(self, id_name: str):

@@ -1,19 +1,34 @@
-"""Model handler: batching, train / eval step, checkpoints -- the subset of the reference's
-ModularModelHandlerPyTorch (neural_networks/pytorch/ModularModelHandlerPyTorch.py) that the
-acoustic-model hot path exercises: prepare_batch / sequence_mask / unsorted_pad_sequence
-(:388-499), the body of process_dataloader for one mini-batch (:745-831), save_checkpoint /
-load_checkpoint with the reference's file layout (:71-262: `params_<suffix>`,
-`optimiser_<suffix>`, suffix in {e<N>, s<N>, best, last}; each `torch.save({'params':
-state_dict, 'epoch', 'step'})`).  The optimiser is a fused HIP Adam (one launch per tensor).
-"""
+"""Model handler: batching, the train / validation loop, inference, checkpoints -- the reference's
+ModularModelHandlerPyTorch (neural_networks/pytorch/ModularModelHandlerPyTorch.py) with the same
+method names and argument meaning:
+
+  prepare_batch / sequence_mask / unsorted_pad_sequence   (:388-499)
+  set_dataset / _get_dataloader                           (:500-548)
+  set_optimiser (Adam, SGD) / set_scheduler / run_scheduler  (:553-656, :941-962)
+  train / test / process_dataloader                       (:667-882)
+  inference                                               (:964-993)
+  save_checkpoint / load_checkpoint                       (:71-262; `params_<suffix>`,
+      `optimiser_<suffix>`, `scheduler_<suffix>`, `config.json`, suffix in {e<N>, s<N>, best,
+      last}; each file `torch.save({'params': state_dict, 'epoch', 'step'[, 'best_loss']})`)
+
+The optimisers are fused HIP kernels (one launch per tensor), EMA is a HIP kernel, and the
+models / losses the handler drives run the HIP forward / backward; `process_batch` is one
+iteration of process_dataloader for callers that bring their own batches."""
+import glob
+import logging
 import os
 import re
+from datetime import datetime
+from functools import partial
 
 import numpy as np
 import torch
 from torch.nn.utils.rnn import pad_sequence
+from torch.optim.lr_scheduler import ExponentialLR, LambdaLR, ReduceLROnPlateau
+from torch.utils.data import DataLoader
 
 from idiaptts_amd import ops
+from idiaptts_amd.src.neural_networks.pytorch import config_json
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -33,20 +48,91 @@ class HipAdam(torch.optim.Optimizer):
                     state['step'] = 0
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                state['step'] += 1
+                state['step'] = int(state['step']) + 1
                 ops.adam_step(p.data.view(-1), p.grad.contiguous().view(-1),
                               state['exp_avg'].view(-1), state['exp_avg_sq'].view(-1),
                               state['step'], lr=group['lr'], betas=group['betas'],
                               eps=group['eps'], weight_decay=group['weight_decay'])
 
 
+class HipSGD(torch.optim.Optimizer):
+    """torch.optim.SGD semantics through itts_sgd_step."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0,
+                 nesterov=False):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening,
+                                      weight_decay=weight_decay, nesterov=nesterov))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                buf, first = None, False
+                if group['momentum'] != 0:
+                    first = 'momentum_buffer' not in state
+                    if first:
+                        state['momentum_buffer'] = torch.empty_like(
+                            p, memory_format=torch.contiguous_format)
+                    buf = state['momentum_buffer'].view(-1)
+                ops.sgd_step(p.data.view(-1), p.grad.contiguous().view(-1), buf, first,
+                             lr=group['lr'], momentum=group['momentum'],
+                             dampening=group['dampening'], weight_decay=group['weight_decay'],
+                             nesterov=group['nesterov'])
+
+
+class ExponentialMovingAverage(object):
+    """Shadow copy of the trainable parameters, `shadow = decay * shadow + (1 - decay) * x` after
+    every optimiser step (reference ExponentialMovingAverage.py:13-45); validation and the saved
+    checkpoints use the averaged parameters."""
+
+    def __init__(self, model, decay):
+        import copy
+        self.model = copy.deepcopy(model)
+        self.decay = decay
+        self.shadow = {}
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                self.shadow[name] = param.data
+            param.detach_()
+
+    def update_params(self, other_model):
+        assert other_model is not self.model
+        for name, param in other_model.named_parameters():
+            if name in self.shadow:
+                ops.ema_update(self.shadow[name].view(-1), param.data.contiguous().view(-1),
+                               self.decay)
+
+
 class ModularModelHandlerPyTorch(object):
+    logger = logging.getLogger(__name__)
 
     def __init__(self):
         self.model = None
-        self.optimiser = None
-        self.losses = []
         self.model_config = None
+        self.optimiser = None
+        self.scheduler = None
+        self._scheduler_step_fn = None
+        self.ema = None
+        self.losses = []
+        self.dataloader_train = None
+        self.dataloader_val = None
+
+    @staticmethod
+    def cuda_is_available():
+        return torch.cuda.is_available()
+
+    @staticmethod
+    def device_count():
+        return torch.cuda.device_count()
+
+    @staticmethod
+    def seed(seed):
+        torch.manual_seed(seed)
 
     # ----------------------------------------------------------------------------- batching
     @staticmethod
@@ -68,57 +154,336 @@ class ModularModelHandlerPyTorch(object):
 
     @staticmethod
     def prepare_batch(batch, common_divisor=1, batch_first=False, mask_keys=()):
-        """List of {name: array [T_i, D]} dicts -> (data, temporal lengths). The remainder that
-        is not divisible by `common_divisor` (# GPUs) is dropped first (reference :392-395);
-        every key in `mask_keys` also gets `<key>_mask`."""
+        """Collate function (reference :388-465).  `batch` holds the dataset's
+        ({name: array [T_i, D]}, dataset) items (bare dicts are accepted too).  The remainder that
+        is not divisible by `common_divisor` (# GPUs) is dropped first (:392-395); every key whose
+        data reader sets `requires_seq_mask` (or that is listed in `mask_keys`) also gets
+        `<key>_mask`; keys without a reader or with ragged non-array content stay lists.
+        Returns (data, temporal lengths)."""
         assert len(batch) >= common_divisor
         remainder = len(batch) % common_divisor
         if remainder > 0:
             batch = batch[:-remainder]
+        dataset = None
+        if isinstance(batch[0], (tuple, list)):
+            dataset = batch[0][1]
+            batch = [b[0] for b in batch]
         data, lengths = dict(), dict()
         for key in batch[0].keys():
             values = [b[key] for b in batch if key in b]
             if key == "_id_list":
                 data[key] = list(values)
                 continue
-            lengths[key] = torch.tensor([x.shape[0] for x in values], dtype=torch.long)
-            if key in mask_keys:
+            reader = None
+            if dataset is not None:
+                try:
+                    reader = dataset.get_datareader_by_output_name(key)
+                except KeyError:
+                    data[key] = list(values)
+                    continue
+            shapes = torch.tensor([x.shape for x in values], dtype=torch.long)
+            lengths[key] = shapes[:, 0]
+            max_shape, max_idx = shapes.max(dim=0)
+            max_frames = int(max_shape[0])
+            if reader is not None and reader.min_frames is not None \
+                    and max_frames < reader.min_frames:
+                # Padding the longest sample brings the whole batch to min_frames.
+                i = int(max_idx[0])
+                padding = [(0, reader.min_frames - max_frames)] + \
+                    [(0, 0)] * (values[i].ndim - 1)
+                values[i] = reader.pad(values[i], padding)
+                max_frames = reader.min_frames
+            if reader is not None and reader.other_pad_dims is not None:
+                for idx, sample in enumerate(values):
+                    padding = [(0, 0)] * sample.ndim
+                    for dim in reader.other_pad_dims:
+                        if dim != 0:
+                            padding[dim] = (0, int(max_shape[dim]) - sample.shape[dim])
+                    values[idx] = reader.pad(sample, padding)
+            if key in mask_keys or (reader is not None and reader.requires_seq_mask):
+                assert reader is None or reader.other_pad_dims is None, \
+                    "Sequence mask for padding in multiple dimensions is not implemented."
                 data[key + "_mask"] = ModularModelHandlerPyTorch.sequence_mask(
-                    lengths[key], int(lengths[key].max()), batch_first=batch_first)
+                    lengths[key], max_frames, batch_first=batch_first)
                 lengths[key + "_mask"] = lengths[key]
             data[key] = ModularModelHandlerPyTorch.unsorted_pad_sequence(values, batch_first)
         return data, lengths
 
+    def set_dataset(self, hparams, dataset_train, dataset_val, collate_fn=None):
+        num_workers = hparams.dataset_num_workers_gpu if hparams.use_gpu \
+            else hparams.dataset_num_workers_cpu
+        common = dict(batch_first=hparams.batch_first, collate_fn=collate_fn,
+                      common_divisor=hparams.num_gpus, num_workers=num_workers,
+                      pin_memory=hparams.dataset_pin_memory)
+        self.dataloader_train = self._get_dataloader(
+            batch_size=hparams.batch_size_train, dataset=dataset_train,
+            shuffle=hparams.shuffle_train_set, **common)
+        self.dataloader_val = self._get_dataloader(
+            batch_size=hparams.batch_size_val, dataset=dataset_val,
+            shuffle=hparams.shuffle_val_set, **common)
+
+    def _get_dataloader(self, batch_size, dataset, batch_first=True, collate_fn=None,
+                        common_divisor=1, num_workers=1, pin_memory=True, shuffle=False):
+        collate_fn = self.prepare_batch if collate_fn is None else collate_fn
+        return DataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle,
+                          num_workers=num_workers,
+                          collate_fn=partial(collate_fn, common_divisor=common_divisor,
+                                             batch_first=batch_first),
+                          pin_memory=pin_memory and torch.cuda.is_available())
+
     # -------------------------------------------------------------------------------- model
-    def create_model(self, config, use_gpu=True):
-        self.model_config = config
-        self.model = config.create_model()
+    def create_model(self, model_config, use_gpu=True):
+        self.logger.info("Create network from config: {}".format(type(model_config)))
+        self.model_config = model_config
+        self.model = model_config.create_model()
         if use_gpu:
             self.model = self.model.cuda()
         return self.model
 
-    def set_optimiser(self, optimiser_type="Adam", **optimiser_args):
-        if optimiser_type != "Adam":
-            raise NotImplementedError("Only Adam has a fused HIP kernel so far.")
-        self.optimiser = HipAdam(self.model.parameters(), **optimiser_args)
+    def set_losses(self, losses):
+        """Loss modules (the reference's signature, :550-551); loss configs are instantiated."""
+        self.losses = [l.create_loss() if hasattr(l, "create_loss") else l for l in losses]
 
-    def set_losses(self, loss_configs):
-        self.losses = [c.create_loss() for c in loss_configs]
+    def set_optimiser(self, hparams="Adam", reset=False, **optimiser_args):
+        """reference :553-583.  Also accepts the optimiser type as a string with keyword
+        arguments (`set_optimiser("Adam", lr=1e-3)`)."""
+        if isinstance(hparams, str):
+            cls = {"Adam": HipAdam, "SGD": HipSGD}.get(hparams)
+            if cls is None:
+                raise NotImplementedError("Optimiser type {} is not implemented.".format(hparams))
+            self.optimiser = cls(self.model.parameters(), **optimiser_args)
+            return
+        if self.optimiser is None or reset:
+            if hparams.optimiser is None:
+                self.logger.info("Create {} optimiser.".format(hparams.optimiser_type))
+                if "params" in hparams.optimiser_args:
+                    args = dict(hparams.optimiser_args)
+                else:
+                    if "lr" not in hparams.optimiser_args:       # backwards compatible
+                        try:
+                            hparams.optimiser_args["lr"] = hparams.learning_rate
+                        except AttributeError:
+                            raise AttributeError("Learning rate not defined in "
+                                                 "hparams.optimiser_args[\"lr\"]")
+                    args = {"params": self.model.parameters()}
+                    args.update(hparams.optimiser_args)
+                if hparams.optimiser_type == "Adam":
+                    if args.pop("amsgrad", False):
+                        raise NotImplementedError("amsgrad has no fused kernel.")
+                    self.optimiser = HipAdam(**args)
+                elif hparams.optimiser_type == "SGD":
+                    self.optimiser = HipSGD(**args)
+                else:
+                    raise NotImplementedError("Optimiser type {} is not implemented."
+                                              .format(hparams.optimiser_type))
+            else:
+                self.optimiser = hparams.optimiser(self.model.parameters())
+        if not hparams.use_saved_learning_rate and "lr" in hparams.optimiser_args:
+            for g in self.optimiser.param_groups:
+                g['lr'] = hparams.optimiser_args["lr"]
 
-    def _to_device(self, data, device):
-        return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v)
+    def set_scheduler(self, hparams, current_epoch=None, current_step=None, reset=False):
+        """reference :585-656: Plateau (stepped with the validation loss), Exponential and Noam
+        (stepped per iteration unless epochs_per_scheduler_step is set)."""
+        if self.scheduler is not None and not reset:
+            return
+        if hparams.scheduler is not None:
+            self.scheduler = hparams.scheduler(self.optimiser)
+            self._scheduler_step_fn = self._scheduler_step
+            return
+        if hparams.scheduler_type.lower() == "none":
+            return
+        assert hparams.scheduler_type != "default", \
+            "Please define a default scheduler type in the trainer class."
+        self.logger.info("Create {} scheduler.".format(hparams.scheduler_type))
+        if current_epoch == 0:        # PyTorch schedulers count from -1 and step immediately.
+            current_epoch = -1
+        if current_step == 0:
+            current_step = -1
+        if hparams.scheduler_type == "Plateau":
+            args = dict(hparams.scheduler_args)
+            args.pop("verbose", None)
+            self.scheduler = ReduceLROnPlateau(self.optimiser, **args)
+            self._scheduler_step_fn = self._scheduler_step_with_loss
+            if hparams.epochs_per_scheduler_step is None \
+                    and hparams.iterations_per_scheduler_step is None:
+                hparams.epochs_per_scheduler_step = 1
+            return
+        if current_step is None and self.dataloader_train is not None:
+            current_step = max((current_epoch - 1) * len(self.dataloader_train), -1)
+        per_iteration = hparams.epochs_per_scheduler_step is None
+        if per_iteration and hparams.iterations_per_scheduler_step is None:
+            hparams.iterations_per_scheduler_step = 1
+        last = current_step if per_iteration else current_epoch - 1
+        if last is not None and last >= 0:
+            for group in self.optimiser.param_groups:
+                group.setdefault('initial_lr', group['lr'])
+        if hparams.scheduler_type == "Exponential":
+            self.scheduler = ExponentialLR(self.optimiser, last_epoch=last,
+                                           **hparams.scheduler_args)
+        elif hparams.scheduler_type == "Noam":
+            assert "wormup_steps" in hparams.scheduler_args, \
+                "Please define wormup_steps in hparams.scheduler_args."
+            warmup = float(hparams.scheduler_args['wormup_steps'])
+
+            def noam_decay(iteration):
+                return warmup ** 0.5 * np.minimum((iteration + 1) * warmup ** -1.5,
+                                                  (iteration + 1) ** -0.5)
+            self.scheduler = LambdaLR(self.optimiser, noam_decay, last_epoch=last)
+        else:
+            raise NotImplementedError("Scheduler type {} is not implemented."
+                                      .format(hparams.scheduler_type))
+        self._scheduler_step_fn = self._scheduler_step
+
+    def _scheduler_step_with_loss(self, loss):
+        self.scheduler.step(float(loss))
+
+    def _scheduler_step(self, loss):
+        self.scheduler.step()
+
+    def run_scheduler(self, hparams, loss, current_iter=None, current_epoch=None):
+        """reference :941-962"""
+        if self.scheduler is None:
+            return
+        if hparams.iterations_per_scheduler_step:
+            if current_iter is None or current_iter % hparams.iterations_per_scheduler_step != 0:
+                return
+        elif hparams.epochs_per_scheduler_step:
+            if current_epoch is None or current_epoch % hparams.epochs_per_scheduler_step != 0:
+                return
+        else:
+            raise ValueError("Scheduler {} is defined but neither hparams.iteration_per_scheduler"
+                             "_step nor hparams.epochs_per_scheduler_step is set."
+                             .format(hparams.scheduler_type))
+        self._scheduler_step_fn(loss)
+
+    @staticmethod
+    def _get_current_iteration(batch_index, current_epoch, dataloader_length, hparams,
+                               total_epoch):
+        epoch = total_epoch if hparams.use_saved_learning_rate else current_epoch
+        assert epoch is not None
+        return (epoch - 1) * dataloader_length + batch_index + 1
+
+    @staticmethod
+    def get_summed_losses_subset(loss_names, losses):
+        if loss_names is None:
+            return sum(losses.values())
+        return sum(losses[name] for name in loss_names)
+
+    # ------------------------------------------------------------------- train / validation
+    def _to_device(self, data, device, non_blocking=True):
+        return {k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v)
                 for k, v in data.items()}
 
+    def _device(self):
+        return next(self.model.parameters()).device
+
+    def test(self, hparams, total_epoch, total_steps, current_epoch):
+        return self.process_dataloader(self.dataloader_val, hparams, total_epoch, total_steps,
+                                       current_epoch, training=False)
+
+    def train(self, hparams, total_epoch, total_steps, current_epoch):
+        if hparams.ema_decay and not self.ema:
+            self.ema = ExponentialMovingAverage(self.model, hparams.ema_decay)
+        return self.process_dataloader(self.dataloader_train, hparams, total_epoch, total_steps,
+                                       current_epoch, training=True)
+
+    def process_dataloader(self, dataloader, hparams, total_epoch, total_steps,
+                           current_epoch=None, training=True):
+        """One pass over the loader (reference :683-882): per mini-batch forward, named losses,
+        NaN / Inf checks, and when training backward, optional clipping, optimiser, EMA and
+        scheduler; returns {loss name: mean over the mini-batches} as numpy scalars.
+        hparams.num_gpus > 1 is served by one process per GPU (idiaptts_amd.parallel), not by
+        replicating the module inside one process as the reference's DataParallel does."""
+        model = self.model
+        if training:
+            model.train()
+            self.logger.info("{}: Train with {} on {}.".format(
+                datetime.now().strftime("%Y-%m-%d %H:%M:%S"), type(self.optimiser).__name__,
+                self._device()))
+        else:
+            if self.ema is not None:
+                self.logger.info("Using averaged model for validation.")
+                model = self.ema.model
+            model.eval()
+        device = self._device()
+        logging_batch_index = (len(dataloader) // hparams.logging_batch_index_perc) + 1
+        total_losses = dict()
+        for batch_index, (data_dict, lengths) in enumerate(dataloader):
+            data_dict = self._to_device(data_dict, device, hparams.dataset_load_async)
+            batch_size = len(next(iter(lengths.values())))
+            model.init_hidden(batch_size)
+            max_lengths = {k: max(lengths[k]) for k in data_dict if k in lengths}
+            with torch.enable_grad() if training else torch.no_grad():
+                model(data_dict, lengths, max_lengths)
+                losses = {}
+                for loss_fn in self.losses:
+                    for loss_name, l in loss_fn(data_dict, lengths, total_steps).items():
+                        if torch.isnan(l):
+                            raise ValueError("Found NaN in {} loss.".format(loss_name))
+                        if not hparams.replace_inf_grads_by_zero and torch.isinf(l):
+                            raise ValueError("Found +/-Inf in {} loss.".format(loss_name))
+                        if loss_name in losses:
+                            raise KeyError("Loss with name {} defined twice.".format(loss_name))
+                        losses[loss_name] = l
+                backprop_loss = self.get_summed_losses_subset(hparams.backprop_loss_names, losses)
+            if hparams.backprop_loss_names is None and hparams.scheduler_loss_names is None:
+                scheduler_loss = backprop_loss.detach()
+            else:
+                scheduler_loss = self.get_summed_losses_subset(
+                    hparams.scheduler_loss_names, losses).detach()
+            if training:
+                self.optimiser.zero_grad()
+                backprop_loss.backward(retain_graph=hparams.backward_retain_graph)
+                total_steps += 1
+                if hparams.replace_inf_grads_by_zero:
+                    self._replace_inf_grads_by_zero()
+                if hparams.grad_clip_norm_type is not None:
+                    torch.nn.utils.clip_grad_norm_(self.model.parameters(),
+                                                   hparams.grad_clip_max_norm,
+                                                   hparams.grad_clip_norm_type)
+                if hparams.grad_clip_thresh is not None:
+                    torch.nn.utils.clip_grad_value_(self.model.parameters(),
+                                                    hparams.grad_clip_thresh)
+                self.optimiser.step()
+                if self.ema:
+                    self.ema.update_params(model)
+                current_iter = self._get_current_iteration(
+                    batch_index=batch_index, current_epoch=current_epoch,
+                    dataloader_length=len(dataloader), hparams=hparams, total_epoch=total_epoch)
+                self.run_scheduler(hparams=hparams, loss=scheduler_loss,
+                                   current_iter=current_iter)
+            if batch_index % logging_batch_index == 0:
+                self.logger.info("{} mini batch [{}/{}]\tLoss: {}".format(
+                    "Train" if training else "Test", batch_index + 1, len(dataloader),
+                    " ".join("{}: {:.3f}".format(k, float(l.detach())) for k, l in losses.items())))
+            for key, loss in losses.items():
+                loss = loss.detach()
+                total_losses[key] = loss if key not in total_losses else total_losses[key] + loss
+        total_losses = {k: v / len(dataloader) for k, v in total_losses.items()}
+        if not training:
+            self.logger.info('Validation set: Total loss: {}\nAverage loss:\n\t{}\n'.format(
+                float(sum(total_losses.values())),
+                "\n\t".join("{}: {:.3f}".format(k, float(l)) for k, l in total_losses.items())))
+            fn_log_per_test = getattr(self.model, "log_per_test", None)
+            if callable(fn_log_per_test):
+                fn_log_per_test()
+        return {k: l.cpu().numpy() for k, l in total_losses.items()}
+
+    def _replace_inf_grads_by_zero(self):
+        for p in self.model.parameters():
+            if p.grad is not None:
+                p.grad[torch.isinf(p.grad)] = 0.0
+
     def process_batch(self, data, lengths, step, training=True, grad_clip_norm=None):
-        """One iteration of process_dataloader (:745-831): forward, losses, backward, clip, step."""
-        device = next(self.model.parameters()).device
+        """One iteration of process_dataloader (:745-831) on a caller-supplied batch."""
+        device = self._device()
         data = self._to_device(data, device)
         max_lengths = {k: int(v.max()) for k, v in lengths.items()}
         batch_dim = 0 if self.model.batch_first else 1
         B = data[self.model.input_names[0]].shape[batch_dim]
         self.model.init_hidden(B)
-        ctx = torch.enable_grad() if training else torch.no_grad()
-        with ctx:
+        with torch.enable_grad() if training else torch.no_grad():
             self.model(data, lengths, max_lengths)
             loss_dict = {}
             for loss_fn in self.losses:
@@ -132,42 +497,188 @@ class ModularModelHandlerPyTorch(object):
                 if grad_clip_norm is not None:
                     torch.nn.utils.clip_grad_norm_(self.model.parameters(), grad_clip_norm)
                 self.optimiser.step()
+                if self.ema:
+                    self.ema.update_params(self.model)
         return {k: float(v.detach()) for k, v in loss_dict.items()}, data
 
-    # -------------------------------------------------------------------------- checkpoints
+    # ----------------------------------------------------------------------------- inference
+    def inference(self, data, hparams, seq_lengths):
+        """reference :964-993: eval mode, numpy / tensors in, numpy out (keys starting with '_'
+        are dropped)."""
+        self.model.eval()
+        to_torch = lambda v: torch.from_numpy(v) if isinstance(v, np.ndarray) else v  # noqa: E731
+        device = self._device()
+        data_torch = self._to_device({k: to_torch(v) for k, v in data.items()}, device)
+        lengths_torch = {k: to_torch(v) for k, v in seq_lengths.items()}
+        max_lengths = {k: max(v) for k, v in seq_lengths.items()}
+        self.model.init_hidden(len(next(iter(seq_lengths.values()))))
+        with torch.no_grad():
+            self.model.inference(data_torch, lengths_torch, max_lengths)
+        out = {k: self._return_values_to_numpy(v) for k, v in data_torch.items()
+               if not k.startswith('_')}
+        out_lengths = {k: self._return_values_to_numpy(v) for k, v in lengths_torch.items()
+                       if not k.startswith('_')}
+        return out, out_lengths
+
     @staticmethod
-    def _suffix(epoch=None, step=None, best=False, last=False):
-        if best:
-            return "best"
-        if last:
-            return "last"
-        return "e{}".format(epoch) if epoch is not None else "s{}".format(step)
+    def _return_values_to_numpy(value, from_gpu=None):
+        if value is None:
+            return None
+        if isinstance(value, (tuple, list)):
+            return tuple(ModularModelHandlerPyTorch._return_values_to_numpy(v) for v in value)
+        if torch.is_tensor(value):
+            return value.detach().cpu().numpy()
+        return value
 
-    def save_checkpoint(self, model_path, epoch=None, step=None, best=False, last=False,
-                        save_optimiser=True):
+    # -------------------------------------------------------------------------- checkpoints
+    def save_checkpoint(self, model_path, best_loss=np.inf, epoch=None, step=None,
+                        save_as_best_model=False, save_as_epoch=True, save_as_last_model=False,
+                        save_as_step=True):
+        """reference :71-123"""
+        assert save_as_best_model or save_as_last_model or step is not None \
+            or epoch is not None, "Epoch or step needs to be given."
+        assert model_path is not None, "Given model_path cannot be None."
+        if save_as_best_model:
+            suffix = "best"
+        elif save_as_last_model:
+            suffix = "last"
+        elif epoch is not None and save_as_epoch:
+            suffix = "e{}".format(epoch)
+        elif step is not None and save_as_step:
+            suffix = "s{}".format(step)
+        else:
+            raise NotImplementedError()
+        self.logger.info("Save {} checkpoint to {}.".format(suffix, model_path))
         os.makedirs(model_path, exist_ok=True)
-        sfx = self._suffix(epoch, step, best, last)
-        torch.save({"params": self.model.state_dict(), "epoch": epoch, "step": step},
-                   os.path.join(model_path, "params_" + sfx))
-        if save_optimiser and self.optimiser is not None:
-            torch.save({"params": self.optimiser.state_dict(), "epoch": epoch, "step": step},
-                       os.path.join(model_path, "optimiser_" + sfx))
+        config = self.model_config if self.model_config is not None \
+            else getattr(self.model, "config", None)
+        if config is not None:
+            with open(os.path.join(model_path, "config.json"), "w") as f:
+                f.write(config_json.encode(config))
+        params = self.model.state_dict()
+        if self.ema:
+            params.update(self.ema.shadow)      # only the shadowed (trainable) parameters
+        torch.save({"params": params, "epoch": epoch, "step": step},
+                   os.path.join(model_path, "params_" + suffix))
+        if self.optimiser is not None:
+            torch.save({"params": self.optimiser.state_dict(), "epoch": epoch, "step": step,
+                        "best_loss": best_loss}, os.path.join(model_path, "optimiser_" + suffix))
+        if self.scheduler is not None:
+            torch.save({"params": self.scheduler.state_dict(), "epoch": epoch, "step": step},
+                       os.path.join(model_path, "scheduler_" + suffix))
 
-    def load_checkpoint(self, model_path, epoch=None, step=None, best=False, last=False,
-                        ignore_layers=None, load_optimiser=False):
-        sfx = self._suffix(epoch, step, best, last)
-        ckpt = torch.load(os.path.join(model_path, "params_" + sfx), map_location="cpu",
-                          weights_only=False)
-        params = ckpt["params"]
-        if ignore_layers:  # regex list (reference :285-309)
-            pats = [re.compile(p) for p in ignore_layers]
-            own = self.model.state_dict()
-            params = {k: (own[k] if any(p.fullmatch(k) or p.match(k) for p in pats) else v)
-                      for k, v in params.items()}
-        missing, unexpected = self.model.load_state_dict(params, strict=False)
-        if load_optimiser and self.optimiser is not None:
-            path = os.path.join(model_path, "optimiser_" + sfx)
-            if os.path.isfile(path):
-                self.optimiser.load_state_dict(torch.load(path, map_location="cpu",
-                                                          weights_only=False)["params"])
-        return ckpt.get("epoch"), ckpt.get("step"), missing, unexpected
+    def load_checkpoint(self, hparams, model_path, epoch=None, ignore_layers=True,
+                        load_optimiser=True, load_scheduler=True, step=None, verbose=True,
+                        load_best_model=False):
+        """reference :125-262.  Returns (best_loss, epoch, step)."""
+        assert load_best_model or step is None or epoch is None, \
+            "Only epoch ({}) OR step ({}) can be not None".format(epoch, step)
+        if load_best_model or epoch == -1 or step == -1:
+            suffix = "_best"
+        elif hparams.load_newest_checkpoint:
+            assert step is None and epoch is None
+            file_list = glob.glob(os.path.join(model_path, "params_*"))
+            if len(file_list) == 0:
+                raise FileNotFoundError("No newest checkpoint found in {}.".format(model_path))
+            if len(file_list) > 1:
+                file_list = [f for f in file_list
+                             if os.path.basename(f) not in ["params_e0", "params_s0"]]
+            suffix = "_" + os.path.basename(max(file_list, key=os.path.getctime)).split('_')[1]
+        else:
+            assert step is not None or epoch is not None, \
+                "Either step or epoch is required. Use -1 in one of them to load the best model."
+            suffix = "_s{}".format(step) if step is not None else "_e{}".format(epoch)
+        params_path = os.path.join(model_path, "params" + suffix)
+        if verbose:
+            self.logger.info("Load model state dict from {}".format(params_path))
+        checkpoint = torch.load(params_path, map_location="cpu", weights_only=False)
+        params = checkpoint["params"] if "params" in checkpoint \
+            else checkpoint["model_state_dict"]
+        best_loss = np.inf
+        epoch = checkpoint["epoch"]
+        step = checkpoint.get("step")
+        if self.model is None:
+            with open(os.path.join(model_path, "config.json"), "r") as f:
+                self.model_config = config_json.decode(f.read())
+            self.model = self.model_config.create_model()
+        if hparams.has_value("layer_map") and len(hparams.layer_map) > 0:
+            params = self._map_layer_names(params, hparams.layer_map, verbose)
+        if ignore_layers:
+            params = self._remove_ignored_layers(params, self.model, hparams)
+        missing_keys, unexpected_keys = self.model.load_state_dict(
+            params, strict=not hparams.allow_missing_layers)
+        if verbose and len(missing_keys) > 0:
+            self.logger.warning("Did not load: {}".format(", ".join(missing_keys)))
+        if verbose and len(unexpected_keys) > 0:
+            self.logger.warning("Found unexpected keys: {}".format(", ".join(unexpected_keys)))
+        if hparams.use_gpu:
+            self.model = self.model.cuda()
+        if load_optimiser:
+            checkpoint = torch.load(os.path.join(model_path, "optimiser" + suffix),
+                                    map_location="cpu", weights_only=False)
+            if "best_loss" in checkpoint and (not ignore_layers or not hparams.ignore_layers):
+                best_loss = checkpoint["best_loss"]
+            self._load_optimiser(checkpoint["params"], hparams)
+            scheduler_path = os.path.join(model_path, "scheduler" + suffix)
+            if load_scheduler and os.path.isfile(scheduler_path):
+                sched = torch.load(scheduler_path, map_location="cpu", weights_only=False)
+                self._load_scheduler(sched["params"],
+                                     epoch if epoch is not None else sched['epoch'],
+                                     step if step is not None else sched['step'], hparams)
+        return best_loss, epoch, step
+
+    @staticmethod
+    def _map_layer_names(params, layer_map, verbose=True):
+        new_params = {}
+        for name, param in params.items():
+            for pattern, replacement in layer_map:
+                if re.search(pattern, name) is not None:
+                    name = re.sub(pattern, replacement, name)
+                    break
+            new_params[name] = param
+        return new_params
+
+    @staticmethod
+    def _remove_ignored_layers(model_dict, model, hparams):
+        """Layers matching hparams.ignore_layers keep the model's current values (:285-309)."""
+        ignore = getattr(hparams, "ignore_layers", None) or []
+        keys_to_pop = []
+        for ignored_layer in ignore:
+            found = [k for k in model_dict if re.match(ignored_layer, k)]
+            if not found:
+                raise KeyError("Cannot find layer {} in saved model dict: {}".format(
+                    ignored_layer, ", ".join(model_dict.keys())))
+            keys_to_pop += found
+        if keys_to_pop:
+            org = model.state_dict()
+            model_dict = {k: v for k, v in model_dict.items() if k not in keys_to_pop}
+            model_dict.update({k: org[k] for k in keys_to_pop if k in org})
+        return model_dict
+
+    def _load_optimiser(self, opt_params, hparams):
+        self.set_optimiser(hparams, reset=True)
+        try:
+            self.optimiser.load_state_dict(opt_params)
+        except ValueError as e:
+            self.logger.warning("Optimiser state of the checkpoint does not match {}: {}\n"
+                                "Continuing without loading it.".format(
+                                    hparams.optimiser_type, e))
+        # torch's load_state_dict casts state tensors to the parameter's device already.
+        if "lr" in hparams.optimiser_args:
+            for group in self.optimiser.param_groups:
+                group.setdefault('initial_lr', hparams.optimiser_args["lr"])
+
+    def _load_scheduler(self, scheduler_params, current_epoch, current_step, hparams):
+        if hparams.epochs_per_scheduler_step is not None:
+            self.set_scheduler(hparams, current_epoch=current_epoch, reset=True)
+        elif hparams.iterations_per_scheduler_step is not None:
+            self.set_scheduler(hparams, current_step=current_step, reset=True)
+        else:
+            self.set_scheduler(hparams, current_epoch=current_epoch, current_step=current_step,
+                               reset=True)
+        if self.scheduler is not None:
+            try:
+                self.scheduler.load_state_dict(scheduler_params)
+            except (ValueError, KeyError) as e:
+                self.logger.warning("Scheduler state of the checkpoint does not match {}: {}"
+                                    .format(hparams.scheduler_type, e))

@@ -30,16 +30,19 @@ class FusedActivation(nn.Identity):
 class FFWrapper(nn.Module):
     def __init__(self, in_dim, layer_config):
         super().__init__()
-        if layer_config.type != "Linear" or layer_config.nonlin not in (None, "Tanh", "ReLU"):
+        nonlin = layer_config.nonlin      # "ReLU" / "Tanh"; older config.json files hold "relu"
+        if nonlin is not None:
+            nonlin = {"relu": "ReLU", "tanh": "Tanh"}.get(nonlin.lower(), nonlin)
+        if layer_config.type != "Linear" or nonlin not in (None, "Tanh", "ReLU"):
             raise NotImplementedError("Only Linear(+Tanh/ReLU) groups are accelerated, got {}."
                                       .format(layer_config))
         layers = []
         for _ in range(layer_config.num_layers):
-            layers.append(LinearAct(in_dim, layer_config.out_dim, act=layer_config.nonlin,
+            layers.append(LinearAct(in_dim, layer_config.out_dim, act=nonlin,
                                     **layer_config.kwargs))
             in_dim = layer_config.out_dim
-            if layer_config.nonlin is not None:
-                layers.append(FusedActivation(layer_config.nonlin))
+            if nonlin is not None:
+                layers.append(FusedActivation(nonlin))
             if layer_config.dropout > 0.0:
                 layers.append(nn.Dropout(layer_config.dropout))
         self.module = nn.Sequential(*layers)

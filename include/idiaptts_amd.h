@@ -114,6 +114,18 @@ int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_avg, float*
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    int64_t step, float grad_scale, void* stream);
 
+/* SGD on a flat fp32 buffer (torch.optim.SGD semantics, ModularModelHandlerPyTorch.py:572-573):
+ * g += weight_decay*p; with momentum: buf = g on the first step, else momentum*buf +
+ * (1-dampening)*g; g = nesterov ? g + momentum*buf : buf; p -= lr*g.  d_momentum_buf may be NULL
+ * when momentum == 0. */
+int itts_sgd_step(float* d_param, const float* d_grad, float* d_momentum_buf, int64_t n, float lr,
+                  float momentum, float dampening, float weight_decay, int nesterov,
+                  int first_step, float grad_scale, void* stream);
+
+/* Exponential moving average of the parameters, shadow -= (1-decay)*(shadow - param)
+ * (neural_networks/pytorch/ExponentialMovingAverage.py:32-45). */
+int itts_ema_update(float* d_shadow, const float* d_param, int64_t n, float decay, void* stream);
+
 /* ---- WORLD analysis, frame-parallel part --------------------------------------------------------
  * Utterances are stored back to back: d_x holds the (pre-emphasised) f64 waveforms, h_x_off[U+1]
  * their sample offsets, h_f_off[U+1] the frame offsets with

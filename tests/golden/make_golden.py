@@ -248,6 +248,79 @@ def capture_benchmark_kat():
     print("mlpg_benchmark_kat.npz:", len(calls), "MLPG calls")
 
 
+def _ref_hparams(AcousticModelTrainer, out_dir):
+    hp = AcousticModelTrainer.create_hparams()
+    hp.num_questions = 409
+    hp.voice = "full"
+    hp.data_dir = os.path.realpath(os.path.join("integration", "fixtures", "database"))
+    hp.out_dir = out_dir
+    hp.frame_size_ms = 5
+    hp.num_coded_sps = 20
+    hp.seed = 1
+    hp.epochs = 3
+    hp.use_gpu = False
+    hp.model_type = "RNNDYN-1_RELU_32-1_FC_67"
+    hp.batch_size_train = 2
+    hp.batch_size_val = 50
+    hp.use_saved_learning_rate = True
+    hp.optimiser_args["lr"] = 0.001
+    hp.model_name = "test_model"
+    hp.epochs_per_checkpoint = 2
+    hp.world_dir = os.path.join("integration", "fixtures", "WORLD")
+    return hp
+
+
+def capture_trainer_fixture():
+    """Data the reference's trainer tests read (test/integration/fixtures/{questions,WORLD/
+    cmp_mcep20,database/file_id_list.txt}: 9 utterances of raw-f32 `.questions` / `.cmp` plus the
+    legacy `.bin` normalisation files) packed into one compressed archive, and the losses of the
+    reference's own test_train run (test_AcousticModelTrainer.py:75-92: seed 1234, 3 epochs,
+    CPU) for the trainer parity test."""
+    from idiaptts.src.model_trainers.AcousticModelTrainer import AcousticModelTrainer
+    os.chdir(os.path.join(REF, "test"))
+    with open(os.path.join("integration", "fixtures", "database", "file_id_list.txt")) as f:
+        id_list = [s.strip() for s in f.readlines()]
+    out = {"id_list": np.array(id_list)}
+    for i in id_list:
+        q = np.fromfile(os.path.join(FIX, "questions", i + ".questions"), dtype=np.float32)
+        out["questions/" + i] = q.reshape(-1, 409)
+        out["cmp/" + i] = np.fromfile(os.path.join(FIX, "WORLD", "cmp_mcep20", i + ".cmp"),
+                                      dtype=np.float32).reshape(-1, 67)
+    out["bin/questions/min-max.bin"] = np.fromfile(os.path.join(FIX, "questions", "min-max.bin"),
+                                                   dtype=np.uint8)
+    for n in ["mcep20", "lf0", "bap"]:
+        name = n + "-mean-covariance.bin"
+        out["bin/WORLD/cmp_mcep20/" + name] = np.fromfile(
+            os.path.join(FIX, "WORLD", "cmp_mcep20", name), dtype=np.uint8)
+
+    out_dir = "/tmp/idiaptts_amd_golden_train"
+    for seed, tag in [(1234, "train"), (1, "seed1")]:
+        hp = _ref_hparams(AcousticModelTrainer, out_dir)
+        hp.seed = seed
+        hp.use_best_as_final_model = False
+        trainer = AcousticModelTrainer(**AcousticModelTrainer.legacy_support_init(
+            hp.world_dir, os.path.join("integration", "fixtures", "questions"), id_list,
+            hp.num_questions, hp))
+        trainer.init(hp)
+        out[tag + "_ids_train"] = np.array(trainer.id_list_train)
+        out[tag + "_ids_val"] = np.array(trainer.id_list_val)
+        out[tag + "_ids_test"] = np.array(trainer.id_list_test)
+        for k, v in trainer.model_handler.model.state_dict().items():
+            out[tag + "_init/" + k] = np.array(v.cpu().numpy(), copy=True)
+        if tag == "train":
+            all_loss, all_loss_train, _ = trainer.train(hp)
+            key = "MSELoss_acoustic_features"
+            out["train_val_losses"] = np.asarray(all_loss[key], dtype=np.float64)
+            out["train_train_losses"] = np.asarray(all_loss_train[key], dtype=np.float64)
+            for k, v in trainer.model_handler.model.state_dict().items():
+                out["train_final/" + k] = v.cpu().numpy()
+            print("reference losses: val", out["train_val_losses"], "train",
+                  out["train_train_losses"])
+        shutil.rmtree(out_dir, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, "trainer_fixture.npz"), **out)
+    print("trainer_fixture.npz:", os.path.getsize(os.path.join(HERE, "trainer_fixture.npz")), "bytes")
+
+
 def _main():
     copy_data_fixtures()
     install_stub_harness()
@@ -256,6 +329,9 @@ def _main():
         return
     if "--kat" in sys.argv:
         capture_benchmark_kat()
+        return
+    if "--trainer" in sys.argv:
+        capture_trainer_fixture()
         return
     capture_host_logic()
     capture_benchmark_kat()

@@ -96,10 +96,17 @@ def test_handler_trains_and_checkpoints(gpu, tmp_path):
     h.save_checkpoint(str(tmp_path), epoch=1, step=12)
     assert os.path.isfile(os.path.join(str(tmp_path), "params_e1"))
     assert os.path.isfile(os.path.join(str(tmp_path), "optimiser_e1"))
-    h2 = Handler()
-    h2.create_model(_wrapped("RNNDYN-1_TANH_32-1_BiLSTM_16-1_FC_5", 12))
-    epoch, step, missing, unexpected = h2.load_checkpoint(str(tmp_path), epoch=1)
-    assert (epoch, step) == (1, 12) and not missing and not unexpected
+    assert os.path.isfile(os.path.join(str(tmp_path), "config.json"))
+    from idiaptts_amd.src.ExtendedHParams import ExtendedHParams
+    hp = ExtendedHParams.create_hparams()
+    hp.use_gpu = True
+    hp.optimiser_args["lr"] = 1e-2
+    h2 = Handler()                       # the model is rebuilt from config.json
+    best_loss, epoch, step = h2.load_checkpoint(hp, str(tmp_path), epoch=1)
+    assert (epoch, step) == (1, 12) and np.isinf(best_loss)
+    st1, st2 = h.optimiser.state_dict()["state"], h2.optimiser.state_dict()["state"]
+    assert st1.keys() == st2.keys() and all(
+        torch.equal(st1[k]["exp_avg"].cpu(), st2[k]["exp_avg"].cpu()) for k in st1)
     for (k, a), (_, b) in zip(h.model.state_dict().items(), h2.model.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
 

@@ -1,0 +1,133 @@
+"""The reference's trainer tests (test/integration/model_trainers/test_AcousticModelTrainer.py)
+re-run against the drop-in AcousticModelTrainer on the GPU stack: same fixture data (packed in
+tests/golden/trainer_fixture.npz), same hparams, same assertions -- plus parity of the whole
+training trajectory with the losses the reference's CPU run produced."""
+import os
+
+import numpy as np
+import pytest
+import scipy.io.wavfile
+import torch
+
+from fixture_dirs import materialise
+from idiaptts_amd.src.model_trainers.AcousticModelTrainer import AcousticModelTrainer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fixture(golden_dir, tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("trainer_fixture"))
+    ids, wdir, qdir, g = materialise(golden_dir, root)
+    return root, ids, wdir, qdir, g
+
+
+def _hparams(root, wdir, name):
+    """test_AcousticModelTrainer.py:33-58, on the GPU"""
+    hp = AcousticModelTrainer.create_hparams()
+    hp.num_questions = 409
+    hp.voice = "full"
+    hp.out_dir = os.path.join(root, name)
+    hp.frame_size_ms = 5
+    hp.num_coded_sps = 20
+    hp.seed = 1
+    hp.epochs = 3
+    hp.use_gpu = True
+    hp.dataset_num_workers_gpu = 0
+    hp.model_type = "RNNDYN-1_RELU_32-1_FC_67"
+    hp.batch_size_train = 2
+    hp.batch_size_val = 50
+    hp.use_saved_learning_rate = True
+    hp.optimiser_args["lr"] = 0.001
+    hp.model_name = "test_model"
+    hp.epochs_per_checkpoint = 2
+    hp.world_dir = wdir
+    return hp
+
+
+def _trainer(fixture, hp):
+    root, ids, wdir, qdir, g = fixture
+    return AcousticModelTrainer(**AcousticModelTrainer.legacy_support_init(
+        wdir, qdir, ids, hp.num_questions, hp))
+
+
+def test_init(gpu, fixture):
+    hp = _hparams(fixture[0], fixture[2], "test_init")
+    trainer = _trainer(fixture, hp)
+    trainer.init(hp)
+    nn_dir = os.path.join(hp.out_dir, hp.model_name, hp.networks_dir)
+    assert sorted(os.listdir(nn_dir)) == ["config.json", "params_e0"]   # initial checkpoint
+    assert next(trainer.model_handler.model.parameters()).is_cuda
+
+
+def test_train_reproduces_reference_losses(gpu, fixture):
+    """test_train (:75-92): seed 1234, 3 epochs, batch size 2, Adam 1e-3, Plateau scheduler.
+    The reference asserts that the training loss decreases; with identical initial weights,
+    shuffling (same torch RNG stream) and arithmetic the per-epoch losses of the reference's CPU
+    run are reproduced by the HIP forward / backward / Adam to float32 accuracy."""
+    g = fixture[4]
+    hp = _hparams(fixture[0], fixture[2], "test_train")
+    hp.seed = 1234
+    hp.use_best_as_final_model = False
+    trainer = _trainer(fixture, hp)
+    trainer.init(hp)
+    all_loss, all_loss_train, handler = trainer.train(hp)
+    val = all_loss["MSELoss_acoustic_features"]
+    train = all_loss_train["MSELoss_acoustic_features"]
+    assert train[-1] < train[1 if hp.start_with_test else 0]
+    np.testing.assert_allclose(val, g["train_val_losses"], rtol=2e-5)
+    np.testing.assert_allclose(train, g["train_train_losses"], rtol=2e-5)
+    sd = handler.model.state_dict()
+    for k in sd:
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g["train_final/" + k], rtol=0, atol=2e-5)
+    nn_dir = os.path.join(hp.out_dir, hp.model_name, hp.networks_dir)
+    files = set(os.listdir(nn_dir))
+    assert {"config.json", "params_e0", "params_e2", "params_e3", "params_best", "optimiser_e3",
+            "optimiser_best", "scheduler_e3", "scheduler_best"} <= files
+    # resume: the newest checkpoint continues with the saved optimiser / epoch counters
+    hp2 = _hparams(fixture[0], fixture[2], "test_train")
+    hp2.seed = 1234
+    hp2.load_checkpoint_epoch = 3
+    hp2.epochs = 1
+    trainer2 = _trainer(fixture, hp2)
+    trainer2.init(hp2)
+    assert (trainer2.total_epoch, trainer2.total_steps) == (3, trainer.total_steps)
+    _, train2, _ = trainer2.train(hp2)
+    assert trainer2.total_epoch == 4
+    assert train2["MSELoss_acoustic_features"][-1] < train[-1]
+
+
+def test_benchmark(gpu, fixture):
+    """test_benchmark (:94-106): the untrained seed-1 model scores (8.616, 78.4, 0.609, 37.352)."""
+    hp = _hparams(fixture[0], fixture[2], "test_benchmark")
+    trainer = _trainer(fixture, hp)
+    trainer.init(hp)
+    scores = trainer.benchmark(hp)
+    np.testing.assert_almost_equal((8.616, 78.4, 0.609, 37.352),
+                                   scores["pred_acoustic_features"], 3)
+
+
+def test_synth_wav_and_copy_synth(gpu, fixture):
+    """test_synth_wav / test_copy_synth (:131-178): one wav per id in
+    <out_dir>/<model>/synth/e<epoch>, named <id>_<n><sp_type>_WORLD.wav (copy synthesis:
+    <id>_ref_... in hparams.synth_dir)."""
+    root, ids = fixture[0], fixture[1]
+    hp = _hparams(root, fixture[2], "test_synth")
+    hp.synth_fs = 16000
+    trainer = _trainer(fixture, hp)
+    trainer.init(hp)
+    outputs, outputs_post = trainer.synth(hp, ids[:2])
+    assert set(outputs) == set(ids[:2])
+    synth_dir = os.path.join(hp.out_dir, hp.model_name, "synth", "e0")
+    for i in ids[:2]:
+        assert outputs[i]["pred_acoustic_features"].shape[1] == 67
+        post = outputs_post[i]["pred_acoustic_features"]
+        assert post.shape == (len(outputs[i]["pred_acoustic_features"]), 23)   # static after MLPG
+        fs, wav = scipy.io.wavfile.read(os.path.join(synth_dir, i + "_20mcep_WORLD.wav"))
+        assert fs == 16000 and len(wav) == len(post) * 80      # pyworld.synthesize length
+    hp.synth_dir = os.path.join(hp.out_dir, "copy")
+    os.makedirs(hp.synth_dir, exist_ok=True)
+    trainer.copy_synth(hp, ids[:2])
+    for i in ids[:2]:
+        fs, wav = scipy.io.wavfile.read(os.path.join(hp.synth_dir, i + "_ref_20mcep_WORLD.wav"))
+        assert fs == 16000 and np.abs(wav).max() > 1000          # real speech comes back
