@@ -1,1 +1,1 @@
-from .modules import LSTM, LinearAct  # noqa: F401
+from .modules import GRU, LSTM, LinearAct  # noqa: F401

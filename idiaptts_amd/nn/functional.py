@@ -104,3 +104,65 @@ class LSTMLayerFunction(torch.autograd.Function):
             dx = ops.linear_bwd_input(dg, w_ih_cat).reshape(T, B, F)
         db = db.reshape(ndir, G4)
         return dx, None, dw_ih.reshape(ndir, G4, F), dw_hh, db, db.clone(), None, None, None
+
+
+class GRULayerFunction(torch.autograd.Function):
+    """One (bi)directional GRU layer on a time-major padded batch x [T, B, F] with per-row
+    lengths (torch.nn.GRU on packed sequences, rnn_dyn/RNNWrapper.py:45-107)."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, h0, training):
+        L = _lib.load()
+        T, B, F = x.shape
+        ndir, G3, H = w_hh.shape
+        x2 = x.contiguous().reshape(T * B, F)
+        w_ih_cat = w_ih.reshape(ndir * G3, F)
+        gin = ops.linear_fwd(x2, w_ih_cat, b_ih.reshape(-1), ops.ACT_NONE)
+        dev = x.device
+        y = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev)
+        keep = bool(training)
+        gates = torch.empty((T * B, ndir * G3), dtype=torch.float32, device=dev) if keep else None
+        hnpre = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        # zero-filled: padded rows meet zero gate gradients in the dW_hh GEMM (0 * NaN guard)
+        hprev = torch.zeros((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        hn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
+        state = torch.empty(L.itts_gru_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
+        w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
+        h0c = h0.contiguous() if h0 is not None else None
+        _lib.check(L.itts_gru_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(b_hh_c), _iptr(h0c),
+                                        _iptr(lengths), T, B, H, ndir, _iptr(y), _iptr(gates),
+                                        _iptr(hnpre), _iptr(hprev), _iptr(hn), _iptr(state),
+                                        ops._stream()), "itts_gru_layer_fwd")
+        if keep:
+            ctx.save_for_backward(x2, lengths, w_ih_cat, w_hh_c, gates, hnpre, hprev)
+            ctx.dims = (T, B, F, H, ndir)
+        return y.reshape(T, B, ndir * H), hn
+
+    @staticmethod
+    def backward(ctx, dy, dhn):
+        L = _lib.load()
+        x2, lengths, w_ih_cat, w_hh, gates, hnpre, hprev = ctx.saved_tensors
+        T, B, F, H, ndir = ctx.dims
+        G3 = 3 * H
+        dev = dy.device
+        dy2 = dy.contiguous().reshape(T * B, ndir * H)
+        dgi = torch.empty((T * B, ndir * G3), dtype=torch.float32, device=dev)
+        dgh = torch.empty((T * B, ndir * G3), dtype=torch.float32, device=dev)
+        state = torch.empty(L.itts_gru_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
+        w_hh_t = w_hh.transpose(1, 2).contiguous()          # [ndir, H, 3H]
+        _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh_t), _iptr(gates), _iptr(hnpre),
+                                        _iptr(hprev), _iptr(lengths), T, B, H, ndir, _iptr(dgi),
+                                        _iptr(dgh), _iptr(state), ops._stream()),
+                   "itts_gru_layer_bwd")
+        dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]
+        dw_hh = torch.empty((ndir, G3, H), dtype=torch.float32, device=dev)
+        db_hh = torch.empty((ndir, G3), dtype=torch.float32, device=dev)
+        for d in range(ndir):
+            _, db = ops.linear_bwd_weight(dgh[:, d * G3:(d + 1) * G3], hprev[:, d * H:(d + 1) * H],
+                                          dw=dw_hh[d])
+            db_hh[d] = db
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_bwd_input(dgi, w_ih_cat).reshape(T, B, F)
+        return dx, None, dw_ih.reshape(ndir, G3, F), dw_hh, db_ih.reshape(ndir, G3), db_hh, \
+            None, None

@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .functional import LinearActFunction, LSTMLayerFunction
+from .functional import GRULayerFunction, LinearActFunction, LSTMLayerFunction
 
 
 class LinearAct(nn.Linear):
@@ -83,3 +83,57 @@ class LSTM(nn.Module):
             cn_all.append(cn)
         out = x.transpose(0, 1) if self.batch_first else x
         return out, (torch.cat(hn_all, 0), torch.cat(cn_all, 0))
+
+
+class GRU(nn.Module):
+    """Drop-in for torch.nn.GRU(input_size, hidden_size, num_layers, bidirectional, batch_first)
+    as RNNWrapper uses it; same parameter names (weight_ih_l0[_reverse], ...), gate order r, z, n.
+        output, h_n = gru(padded, h_0, lengths)"""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bias=True, batch_first=False,
+                 dropout=0.0, bidirectional=False):
+        super().__init__()
+        assert bias, "bias=False is not supported"
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.batch_first, self.dropout, self.bidirectional = batch_first, dropout, bidirectional
+        ndir = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            in_size = input_size if layer == 0 else hidden_size * ndir
+            for d in range(ndir):
+                sfx = "_l{}{}".format(layer, "_reverse" if d == 1 else "")
+                self.register_parameter("weight_ih" + sfx, nn.Parameter(torch.empty(3 * hidden_size, in_size)))
+                self.register_parameter("weight_hh" + sfx, nn.Parameter(torch.empty(3 * hidden_size, hidden_size)))
+                self.register_parameter("bias_ih" + sfx, nn.Parameter(torch.empty(3 * hidden_size)))
+                self.register_parameter("bias_hh" + sfx, nn.Parameter(torch.empty(3 * hidden_size)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.hidden_size)
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+    def _stack(self, name, layer):
+        ndir = 2 if self.bidirectional else 1
+        return torch.stack([getattr(self, "{}_l{}{}".format(name, layer, "_reverse" if d else ""))
+                            for d in range(ndir)], dim=0)
+
+    def forward(self, input_, hx=None, lengths=None):
+        ndir = 2 if self.bidirectional else 1
+        x = input_.transpose(0, 1) if self.batch_first else input_
+        T, B = x.shape[0], x.shape[1]
+        if lengths is None:
+            lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
+        lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32)
+        hn_all = []
+        for layer in range(self.num_layers):
+            # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0
+            hl = hx[layer * ndir:(layer + 1) * ndir, 0, :] if hx is not None else None
+            x, hn = GRULayerFunction.apply(
+                x, lengths, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
+                self._stack("bias_ih", layer), self._stack("bias_hh", layer), hl,
+                torch.is_grad_enabled())
+            if self.dropout > 0 and self.training and layer < self.num_layers - 1:
+                x = torch.nn.functional.dropout(x, self.dropout, True)
+            hn_all.append(hn)
+        out = x.transpose(0, 1) if self.batch_first else x
+        return out, torch.cat(hn_all, 0)

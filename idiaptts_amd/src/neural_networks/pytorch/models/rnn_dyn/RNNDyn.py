@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-from idiaptts_amd.nn.modules import LSTM, LinearAct
+from idiaptts_amd.nn.modules import GRU, LSTM, LinearAct
 
 
 class FusedActivation(nn.Identity):
@@ -58,15 +58,16 @@ class FFWrapper(nn.Module):
 class RNNWrapper(nn.Module):
     def __init__(self, in_dim, layer_config, batch_first=True, enforce_sorted=True):
         super().__init__()
-        if layer_config.type != 'LSTM':
-            raise NotImplementedError("{} groups are scheduled for a later round; LSTM is "
+        if layer_config.type not in ('LSTM', 'GRU'):
+            raise NotImplementedError("{} groups have no HIP recurrence; LSTM and GRU are "
                                       "accelerated.".format(layer_config.type))
         self.batch_first = batch_first
         self.bidirectional = layer_config.kwargs.get("bidirectional", False)
         self.hidden = None
         self.pack = True
         self.unpack = True
-        self.module = LSTM(input_size=in_dim, hidden_size=layer_config.out_dim,
+        cell = LSTM if layer_config.type == 'LSTM' else GRU
+        self.module = cell(input_size=in_dim, hidden_size=layer_config.out_dim,
                            num_layers=layer_config.num_layers, dropout=layer_config.dropout,
                            batch_first=batch_first, bidirectional=self.bidirectional)
         ndir = 2 if self.bidirectional else 1
@@ -82,7 +83,9 @@ class RNNWrapper(nn.Module):
     def init_hidden(self, batch_size=1):
         size = list(self.h_0.size())
         size[1] = batch_size
-        self.hidden = (self.h_0.expand(size).contiguous(), self.c_0.expand(size).contiguous())
+        h_0 = self.h_0.expand(size).contiguous()
+        self.hidden = (h_0, self.c_0.expand(size).contiguous()) if isinstance(self.module, LSTM) \
+            else h_0
 
     def forward(self, input_, seq_lengths_input, max_length_inputs, hidden=None, **kwargs):
         # the kernels take the padded tensor + lengths directly (no PackedSequence round trip)

@@ -214,6 +214,26 @@ int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_
                         const float* d_gates, const float* d_csave, const int* d_lengths, int T, int B,
                         int H, int ndir, float* d_dg, void* d_state, void* stream);
 
+/* ---- (Bi)GRU recurrence (torch.nn.GRU behind rnn_dyn/RNNWrapper.py:45-107 for `..GRU..` groups;
+ *      gate order r, z, n; packed-sequence semantics as for the LSTM entry points above).
+ * d_gin  [T*B, ndir*3H] = X W_ih^T + b_ih for all steps (one itts_linear_fwd call),
+ * d_whh  [ndir][3H][H], d_bhh [ndir][3H] (b_hn sits inside r * (W_hn h + b_hn)), d_h0 [ndir][H] or
+ * NULL.  Training saves d_gates [T*B, ndir*3H] (r, z, n after activation), d_hnpre and d_hprev
+ * [T*B, ndir*H]; pass all three NULL for inference.  d_hn [ndir][B][H] may be NULL.
+ * d_state >= itts_gru_state_bytes(B, H, ndir).
+ * Backward fills d_dgi (gradient wrt d_gin: feeds dX, dW_ih, db_ih) and d_dgh (gradient wrt the
+ * hidden projections: feeds dW_hh with d_hprev, db_hh), both [T*B, ndir*3H], zero on padded rows.
+ * d_whh_t is W_hh transposed per direction ([ndir][H][3H]). */
+int64_t itts_gru_state_bytes(int B, int H, int ndir);
+int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
+                       const float* d_h0, const int* d_lengths, int T, int B, int H, int ndir,
+                       float* d_y, float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn,
+                       void* d_state, void* stream);
+int itts_gru_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_gates,
+                       const float* d_hnpre, const float* d_hprev, const int* d_lengths, int T,
+                       int B, int H, int ndir, float* d_dgi, float* d_dgh, void* d_state,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
