@@ -176,7 +176,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     return res
 
 
-def bilstm_section(dev, n_utts=64, steps=3):
+def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM"):
     """BASELINE config 3: 425 -> 3 x 512 BiLSTM -> 187, batch 64 padded utterances, Adam, fp32,
     through the drop-in module stack (RNNDyn + NamedLoss + fused HIP Adam)."""
     import types
@@ -188,7 +188,7 @@ def bilstm_section(dev, n_utts=64, steps=3):
     from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import \
         NamedForwardWrapper
     torch.manual_seed(0)
-    hp = types.SimpleNamespace(model_type="RNNDYN-3_BiLSTM_512-1_FC_187", batch_first=False,
+    hp = types.SimpleNamespace(model_type="RNNDYN-3_Bi{}_512-1_FC_187".format(cell), batch_first=False,
                                dropout=0.0)
     h = Handler()
     h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((425,), hp),
@@ -214,7 +214,7 @@ def bilstm_section(dev, n_utts=64, steps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     frames = int(lengths.sum())
-    return {"bilstm": {"model": "425 -> 3x512 BiLSTM -> 187", "utterances": n_utts,
+    return {"bi" + cell.lower(): {"model": "425 -> 3x512 Bi{} -> 187".format(cell), "utterances": n_utts,
                        "valid_frames": frames, "max_frames": int(lengths.max()),
                        "ms_per_step": dt * 1e3, "valid_frames_per_s": frames / dt,
                        "loss": ld["MSELoss_acoustic_features"]}}

@@ -6,8 +6,9 @@
 //   * the recurrence h_{t-1} W_hh^T runs one launch per step (the kernel boundary is the grid-wide
 //     dependency), both directions in it, operands streamed from L2 into
 //     v_mfma_f32_16x16x4_f32 with the K-permutation trick (one 16-byte load feeds 4 MFMAs);
-//   * packed-sequence semantics as in lstm.hip (row b active for step s < len_b, the reverse
-//     direction starts at each row's own last frame, padded outputs zero, inactive state frozen).
+//   * packed-sequence semantics and the packed row layout of lstm.hip (rows sorted by decreasing
+//     length, frame t of row b at packed row row_off[t] + b, step s launches only the batch tiles
+//     that still hold active rows, the reverse direction starts at each row's own last frame).
 // torch.nn.GRU cell, gate order r, z, n:
 //   r = sigmoid(gin_r + W_hr h + b_hr)      z = sigmoid(gin_z + W_hz h + b_hz)
 //   n = tanh(gin_n + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
@@ -24,20 +25,21 @@ constexpr int GRU_BW_UNITS = 16;   // hidden units per workgroup, backward
 
 struct GruArgs {
   int T, B, H, ndir;
-  const int* lengths;     // [B]
-  const float* gin;       // [T*B, ndir*3H] input projections incl. b_ih
+  const int* lengths;     // [B] sorted by decreasing length
+  const int* row_off;     // [T] packed row of (t, b) = row_off[t] + b
+  const float* gin;       // [N, ndir*3H] input projections incl. b_ih (N = sum of lengths)
   const float* whh;       // [ndir][3H][H]
   const float* whh_t;     // [ndir][H][3H]   (backward)
   const float* bhh;       // [ndir][3H]
   const float* h0;        // [ndir][H] or NULL
   float* hs;              // [2 parity][ndir][B][H] running hidden state (fwd) / carried dh*z (bwd)
-  float* y;               // [T*B, ndir*H]
-  float* gates;           // [T*B, ndir*3H] r, z, n after activation (saved for backward)
-  float* hnpre;           // [T*B, ndir*H]  W_hn h + b_hn
-  float* hprev;           // [T*B, ndir*H]  h_{t-1} that entered step t
-  const float* dy;        // [T*B, ndir*H]
-  float* dgi;             // [T*B, ndir*3H] gradient wrt gin  (da_r, da_z, da_n)
-  float* dgh;             // [T*B, ndir*3H] gradient wrt the hidden projections (da_r, da_z, da_n*r)
+  float* y;               // [N, ndir*H]
+  float* gates;           // [N, ndir*3H] r, z, n after activation (saved for backward)
+  float* hnpre;           // [N, ndir*H]  W_hn h + b_hn
+  float* hprev;           // [N, ndir*H]  h_{t-1} that entered step t
+  const float* dy;        // [N, ndir*H]
+  float* dgi;             // [N, ndir*3H] gradient wrt gin  (da_r, da_z, da_n)
+  float* dgh;             // [N, ndir*3H] gradient wrt the hidden projections (da_r, da_z, da_n*r)
   int step;
   int ksplit, kiter;
 };
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruArgs a) {
     t = gru_time_of(dir, a.step, a.lengths[b]);
     hp_v = hprev[(size_t)b * H + j];
     if (t >= 0) {
-      r = (size_t)t * B + b;
+      r = (size_t)a.row_off[t] + b;
       const float* gi = a.gin + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
       g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H];
       const float* bh = a.bhh + (size_t)dir * G3 + j;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
   if (b < B) {
     t = gru_time_of(dir, a.step, a.lengths[b]);
     if (t >= 0) {
-      r = (size_t)t * B + b;
+      r = (size_t)a.row_off[t] + b;
       const float* gs = a.gates + r * ldg + (size_t)dir * G3 + j;
       rg = gs[0]; zg = gs[H]; ng = gs[2 * H];
       const size_t oh = r * ldh + (size_t)dir * H + j;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
     const int tn = gru_time_of(dir, a.step + 1, a.lengths[row]);
     if (tn >= 0) {
       has_next = true;
-      dgp = a.dgh + ((size_t)tn * B + row) * ldg + (size_t)dir * G3;
+      dgp = a.dgh + ((size_t)a.row_off[tn] + row) * ldg + (size_t)dir * G3;
     }
   }
   const int kiter = wv < 3 ? H / 16 : 0;
@@ -249,14 +251,33 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
   }
 }
 
+__global__ void gru_final_state_kernel(const float* __restrict__ st, const int* __restrict__ lengths,
+                                       float* __restrict__ out, int ndir, int B, int H) {
+  const int64_t n = (int64_t)ndir * B * H;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)((i / H) % B);
+    out[i] = st[(int64_t)(lengths[b] & 1) * n + i];   // parity written by the row's last active step
+  }
+}
+
 }  // namespace itts
 
 using namespace itts;
 
-static int gru_check(int T, int B, int H, int ndir) {
+static int gru_check(const int* h_lengths, int T, int B, int H, int ndir) {
   ITTS_REQUIRE(T >= 1 && B >= 1 && (ndir == 1 || ndir == 2), "bad sizes");
   ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 4096, "hidden size must be a multiple of 16");
+  ITTS_REQUIRE(h_lengths != nullptr, "host copy of the lengths is required");
+  ITTS_REQUIRE(h_lengths[0] == T && h_lengths[B - 1] >= 1, "T must be the longest length, all lengths >= 1");
+  for (int b = 1; b < B; ++b) ITTS_REQUIRE(h_lengths[b] <= h_lengths[b - 1], "rows must be sorted by decreasing length");
   return ITTS_OK;
+}
+
+static inline int gru_active_rows(const int* h_lengths, int B, int s, int* p) {
+  while (*p > 0 && h_lengths[*p - 1] <= s) --*p;
+  while (*p < B && h_lengths[*p] > s) ++*p;
+  return *p;
 }
 
 extern "C" int64_t itts_gru_state_bytes(int B, int H, int ndir) {
@@ -265,59 +286,63 @@ extern "C" int64_t itts_gru_state_bytes(int B, int H, int ndir) {
 }
 
 extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
-                                  const float* d_h0, const int* d_lengths, int T, int B, int H,
-                                  int ndir, float* d_y, float* d_gates, float* d_hnpre,
-                                  float* d_hprev, float* d_hn, void* d_state, void* stream) {
-  ITTS_REQUIRE(d_gin && d_whh && d_bhh && d_lengths && d_y && d_state, "null pointer");
+                                  const float* d_h0, const int* d_lengths, const int* h_lengths,
+                                  const int* d_row_off, int T, int B, int H, int ndir, float* d_y,
+                                  float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn,
+                                  void* d_state, void* stream) {
+  ITTS_REQUIRE(d_gin && d_whh && d_bhh && d_lengths && d_row_off && d_y && d_state, "null pointer");
   ITTS_REQUIRE((d_gates == nullptr) == (d_hnpre == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
                "gates / hnpre / hprev must be given together (training) or all NULL (inference)");
-  int rc = gru_check(T, B, H, ndir);
+  int rc = gru_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   GruArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.gin = d_gin; a.whh = d_whh;
-  a.bhh = d_bhh; a.h0 = d_h0; a.y = d_y; a.gates = d_gates; a.hnpre = d_hnpre; a.hprev = d_hprev;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.gin = d_gin;
+  a.whh = d_whh; a.bhh = d_bhh; a.h0 = d_h0; a.y = d_y; a.gates = d_gates; a.hnpre = d_hnpre;
+  a.hprev = d_hprev;
   a.hs = reinterpret_cast<float*>(d_state);
-  ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, (size_t)T * B * ndir * H * 4, s));  // padded frames are zero
   const int64_t n = (int64_t)ndir * B * H;
-  hipLaunchKernelGGL(gru_init_state_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)),
-                     dim3(256), 0, s, d_h0, a.hs, ndir, B, H);
+  const dim3 eg((unsigned)std::min<int64_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(gru_init_state_kernel, eg, dim3(256), 0, s, d_h0, a.hs, ndir, B, H);
   ITTS_LAUNCH_CHECK();
-  const dim3 grid((H / GRU_FW_UNITS) * ((B + 15) / 16), ndir);
   a.ksplit = (H % 64 == 0) ? 4 : ((H % 32 == 0) ? 2 : 1);
   a.kiter = H / (16 * a.ksplit);
+  int p = B;
   for (int step = 0; step < T; ++step) {
     a.step = step;
-    hipLaunchKernelGGL(gru_step_fwd_kernel, grid, dim3(256), 0, s, a);
+    const int nact = gru_active_rows(h_lengths, B, step, &p);
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((H / GRU_FW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0,
+                       s, a);
   }
   ITTS_LAUNCH_CHECK();
-  if (d_hn)
-    ITTS_HIP_CHECK(hipMemcpyAsync(d_hn, a.hs + (size_t)(T & 1) * n, n * 4, hipMemcpyDeviceToDevice, s));
+  if (d_hn) {
+    hipLaunchKernelGGL(gru_final_state_kernel, eg, dim3(256), 0, s, a.hs, d_lengths, d_hn, ndir, B, H);
+    ITTS_LAUNCH_CHECK();
+  }
   return ITTS_OK;
 }
 
 extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_gates,
                                   const float* d_hnpre, const float* d_hprev, const int* d_lengths,
-                                  int T, int B, int H, int ndir, float* d_dgi, float* d_dgh,
-                                  void* d_state, void* stream) {
-  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_hnpre && d_hprev && d_lengths && d_dgi && d_dgh && d_state,
-               "null pointer");
-  int rc = gru_check(T, B, H, ndir);
+                                  const int* h_lengths, const int* d_row_off, int T, int B, int H,
+                                  int ndir, float* d_dgi, float* d_dgh, void* d_state, void* stream) {
+  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_hnpre && d_hprev && d_lengths && d_row_off && d_dgi && d_dgh &&
+                   d_state, "null pointer");
+  int rc = gru_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   GruArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.whh_t = d_whh_t;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.whh_t = d_whh_t;
   a.gates = const_cast<float*>(d_gates); a.hnpre = const_cast<float*>(d_hnpre);
   a.hprev = const_cast<float*>(d_hprev); a.dy = d_dy; a.dgi = d_dgi; a.dgh = d_dgh;
   a.hs = reinterpret_cast<float*>(d_state);
-  const size_t gbytes = (size_t)T * B * ndir * 3 * H * 4;
-  ITTS_HIP_CHECK(hipMemsetAsync(d_dgi, 0, gbytes, s));
-  ITTS_HIP_CHECK(hipMemsetAsync(d_dgh, 0, gbytes, s));
-  ITTS_HIP_CHECK(hipMemsetAsync(a.hs, 0, (size_t)2 * ndir * B * H * 4, s));
-  const dim3 grid((H / GRU_BW_UNITS) * ((B + 15) / 16), ndir);
+  ITTS_HIP_CHECK(hipMemsetAsync(a.hs, 0, (size_t)2 * ndir * B * H * 4, s));   // carry of not-yet-active rows
+  int p = 0;
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
-    hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, s, a);
+    const int nact = gru_active_rows(h_lengths, B, step, &p);
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((H / GRU_BW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0,
+                       s, a);
   }
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;

@@ -13,7 +13,12 @@
 //     (exact fp32, same K-permutation trick as the GEMM: one 16-byte load feeds 4 MFMAs).
 //   * packed-sequence semantics: row b is active for step s < len_b; the forward direction
 //     visits t = s, the reverse direction t = len_b - 1 - s (it starts at each sequence's own
-//     last frame); padded outputs are zero; the state of an inactive row is frozen.
+//     last frame); the state of an inactive row is frozen.
+//   * packed row layout (what pack_padded_sequence produces): the batch rows are sorted by
+//     decreasing length, frame t of row b lives at packed row row_off[t] + b, where
+//     row_off[t] = sum_{t' < t} nact(t') and nact(t) = #{b : len_b > t}.  Only valid frames exist,
+//     so the GEMMs around the recurrence touch N = sum(len) rows instead of T*B, and step s
+//     launches workgroups for the ceil(nact(s) / 16) batch tiles that still have active rows.
 // Gate order i, f, g, o and the two bias vectors follow torch.nn.LSTM.
 #include <algorithm>
 
@@ -29,22 +34,22 @@ constexpr int BW_UNITS = 16;   // hidden units per workgroup in the backward ste
 struct LstmArgs {
   // geometry
   int T, B, H, ndir;
-  const int* lengths;     // [B] device
-  // per-row layout of time-major tensors: row(t, b) = t * B + b
-  const float* gin;       // [T*B, ndir*4H] input projections incl. both biases
+  const int* lengths;     // [B] device, sorted by decreasing length
+  const int* row_off;     // [T] device: packed row of (t, b) = row_off[t] + b
+  const float* gin;       // [N, ndir*4H] input projections incl. both biases (N = sum of lengths)
   const float* whh;       // [ndir][4H][H]
   const float* whh_t;     // [ndir][H][4H]   (backward)
   const float* h0;        // [ndir][H] initial state (broadcast over the batch)
   const float* c0;
   float* hs;              // [2 parity][ndir][B][H] running hidden state
   float* cs;              // [2 parity][ndir][B][H] running cell state / running dc (backward)
-  float* y;               // [T*B, ndir*H] layer output
-  float* gates;           // [T*B, ndir*4H] post-activation gates i,f,g,o (saved for backward)
-  float* csave;           // [T*B, ndir*H] c_t
-  float* hprev;           // [T*B, ndir*H] h_{t-1} that entered step t (for dW_hh)
+  float* y;               // [N, ndir*H] layer output
+  float* gates;           // [N, ndir*4H] post-activation gates i,f,g,o (saved for backward)
+  float* csave;           // [N, ndir*H] c_t
+  float* hprev;           // [N, ndir*H] h_{t-1} that entered step t (for dW_hh)
   // backward
-  const float* dy;        // [T*B, ndir*H]
-  float* dg;              // [T*B, ndir*4H] gradient wrt pre-activation gates
+  const float* dy;        // [N, ndir*H]
+  float* dg;              // [N, ndir*4H] gradient wrt pre-activation gates
   int step;
   int ksplit, kiter;  // forward: K = H split over `ksplit` waves, `kiter` steps of 16 each
 };
@@ -62,7 +67,7 @@ __device__ __forceinline__ int time_of(int dir, int s, int len) {
 // ways, every wave streams its A (h_{t-1}) and B (W_hh) fragments straight from L2 into registers
 // (all loads of the step in flight at once, no LDS staging: each element is used by exactly one
 // MFMA), the partial 16x16 tiles are reduced through LDS and 64 threads apply the cell update.
-// Grid: (H/4 * ceil(B/16), ndir) -> 1024 workgroups for H = 512, B = 64: the whole chip per step.
+// Grid: (H/4 * ceil(nact/16), ndir) -> 1024 workgroups for H = 512 while all 64 rows are active.
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
   __shared__ float P[4][16][17];
   const int H = a.H, B = a.B, G4 = 4 * H;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
     hp_v = hprev[(size_t)b * H + j];
     cp_v = cprev[(size_t)b * H + j];
     if (t >= 0) {
-      r = (size_t)t * B + b;
+      r = (size_t)a.row_off[t] + b;
       const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
       g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
     }
@@ -166,7 +171,7 @@ __global__ void lstm_init_state_kernel(const float* __restrict__ h0, const float
 //   dh = dy[t] + dG[t_{s+1}] W_hh   (second term only if the row is active at s+1)
 //   standard LSTM cell gradients -> dG[t], running dc (cs buffers, parity by step)
 // Workgroup = 16 hidden units x 16 batch rows; the 4 waves split the K = 4H gate rows, operands
-// stream from L2 into registers in chunks of 8 k-steps.  Grid (H/16 * ceil(B/16), ndir).
+// stream from L2 into registers in chunks of 8 k-steps.  Grid (H/16 * ceil(nact/16), ndir).
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
   __shared__ float P[4][16][17];
   const int H = a.H, B = a.B, G4 = 4 * H;
@@ -192,12 +197,12 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
     const int len = a.lengths[b];
     t = time_of(dir, a.step, len);
     if (t >= 0) {
-      r = (size_t)t * B + b;
+      r = (size_t)a.row_off[t] + b;
       const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
       ig = gs[0]; fg = gs[H]; gg = gs[2 * H]; og = gs[3 * H];
       ct = a.csave[r * ldh + (size_t)dir * H + j];
       const int tp = time_of(dir, a.step - 1, len);
-      cp = (a.step > 0 && tp >= 0) ? a.csave[((size_t)tp * B + b) * ldh + (size_t)dir * H + j]
+      cp = (a.step > 0 && tp >= 0) ? a.csave[((size_t)a.row_off[tp] + b) * ldh + (size_t)dir * H + j]
                                    : (a.c0 ? a.c0[dir * H + j] : 0.f);
       dyv = a.dy[r * ldh + (size_t)dir * H + j];
       dcin = dc_in[(size_t)b * H + j];
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
     const int tn = time_of(dir, a.step + 1, a.lengths[row]);
     if (tn >= 0) {
       has_next = true;
-      dgp = a.dg + ((size_t)tn * B + row) * ldg + (size_t)dir * G4;
+      dgp = a.dg + ((size_t)a.row_off[tn] + row) * ldg + (size_t)dir * G4;
     }
   }
   const int kiter = H / 16;            // 4H gate rows / 4 waves / 16 per step
@@ -261,14 +266,35 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
   }
 }
 
+// hn / cn of row b sit in the parity written by its last active step: (len_b & 1)
+__global__ void rnn_final_state_kernel(const float* __restrict__ st, const int* __restrict__ lengths,
+                                       float* __restrict__ out, int ndir, int B, int H) {
+  const int64_t n = (int64_t)ndir * B * H;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)((i / H) % B);
+    out[i] = st[(int64_t)(lengths[b] & 1) * n + i];
+  }
+}
+
 }  // namespace itts
 
 using namespace itts;
 
-static int lstm_check(int T, int B, int H, int ndir) {
+static int lstm_check(const int* h_lengths, int T, int B, int H, int ndir) {
   ITTS_REQUIRE(T >= 1 && B >= 1 && (ndir == 1 || ndir == 2), "bad sizes");
   ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 4096, "hidden size must be a multiple of 16");
+  ITTS_REQUIRE(h_lengths != nullptr, "host copy of the lengths is required");
+  ITTS_REQUIRE(h_lengths[0] == T && h_lengths[B - 1] >= 1, "T must be the longest length, all lengths >= 1");
+  for (int b = 1; b < B; ++b) ITTS_REQUIRE(h_lengths[b] <= h_lengths[b - 1], "rows must be sorted by decreasing length");
   return ITTS_OK;
+}
+
+// number of rows still active at recurrence step s (lengths sorted decreasingly); `p` carries the
+// previous answer so that a whole sweep costs O(B + T)
+static inline int active_rows(const int* h_lengths, int B, int s, int* p) {
+  while (*p > 0 && h_lengths[*p - 1] <= s) --*p;
+  while (*p < B && h_lengths[*p] > s) ++*p;
+  return *p;
 }
 
 extern "C" int64_t itts_lstm_state_bytes(int B, int H, int ndir) {
@@ -276,64 +302,66 @@ extern "C" int64_t itts_lstm_state_bytes(int B, int H, int ndir) {
   return (int64_t)2 * 2 * ndir * B * H * 4;  // hs + cs, two parities each
 }
 
-// Runs the recurrence of one (bi)directional LSTM layer over T steps.
+// Runs the recurrence of one (bi)directional LSTM layer over T steps (packed rows, see the top).
 extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0,
-                                   const float* d_c0, const int* d_lengths, int T, int B, int H, int ndir,
-                                   float* d_y, float* d_gates, float* d_csave, float* d_hprev,
-                                   float* d_hn, float* d_cn, void* d_state, void* stream) {
-  ITTS_REQUIRE(d_gin && d_whh && d_lengths && d_y && d_state, "null pointer");
+                                   const float* d_c0, const int* d_lengths, const int* h_lengths,
+                                   const int* d_row_off, int T, int B, int H, int ndir, float* d_y,
+                                   float* d_gates, float* d_csave, float* d_hprev, float* d_hn,
+                                   float* d_cn, void* d_state, void* stream) {
+  ITTS_REQUIRE(d_gin && d_whh && d_lengths && d_row_off && d_y && d_state, "null pointer");
   ITTS_REQUIRE((d_gates == nullptr) == (d_csave == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
                "gates / csave / hprev must be given together (training) or all NULL (inference)");
-  int rc = lstm_check(T, B, H, ndir);
+  int rc = lstm_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   LstmArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.gin = d_gin; a.whh = d_whh;
-  a.h0 = d_h0; a.c0 = d_c0; a.y = d_y; a.gates = d_gates; a.csave = d_csave; a.hprev = d_hprev;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.gin = d_gin;
+  a.whh = d_whh; a.h0 = d_h0; a.c0 = d_c0; a.y = d_y; a.gates = d_gates; a.csave = d_csave; a.hprev = d_hprev;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   a.cs = a.hs + st;
-  ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, (size_t)T * B * ndir * H * 4, s));  // padded frames are zero
   const int64_t n = (int64_t)ndir * B * H;
-  hipLaunchKernelGGL(lstm_init_state_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256),
-                     0, s, d_h0, d_c0, a.hs, a.cs, ndir, B, H);
+  const dim3 eg((unsigned)std::min<int64_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(lstm_init_state_kernel, eg, dim3(256), 0, s, d_h0, d_c0, a.hs, a.cs, ndir, B, H);
   ITTS_LAUNCH_CHECK();
-  const dim3 grid((H / FW_UNITS) * ((B + 15) / 16), ndir);
   a.ksplit = (H % 64 == 0) ? 4 : ((H % 32 == 0) ? 2 : 1);
   a.kiter = H / (16 * a.ksplit);
+  int p = B;
   for (int step = 0; step < T; ++step) {
     a.step = step;
-    hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), 0, s, a);
+    const int nact = active_rows(h_lengths, B, step, &p);
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((H / FW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
-  // final states live in parity (T & 1)
-  const size_t off = (size_t)(T & 1) * ndir * B * H;
-  if (d_hn) ITTS_HIP_CHECK(hipMemcpyAsync(d_hn, a.hs + off, n * 4, hipMemcpyDeviceToDevice, s));
-  if (d_cn) ITTS_HIP_CHECK(hipMemcpyAsync(d_cn, a.cs + off, n * 4, hipMemcpyDeviceToDevice, s));
+  if (d_hn) hipLaunchKernelGGL(rnn_final_state_kernel, eg, dim3(256), 0, s, a.hs, d_lengths, d_hn, ndir, B, H);
+  if (d_cn) hipLaunchKernelGGL(rnn_final_state_kernel, eg, dim3(256), 0, s, a.cs, d_lengths, d_cn, ndir, B, H);
+  ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
 
-// Backward recurrence: fills d_dg [T*B, ndir*4H] (zero on padded rows) from d_dy and the saved
-// forward tensors. d_whh_t is W_hh transposed per direction ([ndir][H][4H]).
+// Backward recurrence: fills d_dg [N, ndir*4H] from d_dy and the saved forward tensors.
+// d_whh_t is W_hh transposed per direction ([ndir][H][4H]).
 extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_c0,
                                    const float* d_gates, const float* d_csave, const int* d_lengths,
-                                   int T, int B, int H, int ndir, float* d_dg, void* d_state, void* stream) {
-  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_csave && d_lengths && d_dg && d_state, "null pointer");
-  int rc = lstm_check(T, B, H, ndir);
+                                   const int* h_lengths, const int* d_row_off, int T, int B, int H,
+                                   int ndir, float* d_dg, void* d_state, void* stream) {
+  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_csave && d_lengths && d_row_off && d_dg && d_state, "null pointer");
+  int rc = lstm_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   LstmArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.whh_t = d_whh_t; a.c0 = d_c0;
-  a.gates = const_cast<float*>(d_gates); a.csave = const_cast<float*>(d_csave); a.dy = d_dy; a.dg = d_dg;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.whh_t = d_whh_t;
+  a.c0 = d_c0; a.gates = const_cast<float*>(d_gates); a.csave = const_cast<float*>(d_csave); a.dy = d_dy;
+  a.dg = d_dg;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   a.cs = a.hs + st;
-  ITTS_HIP_CHECK(hipMemsetAsync(d_dg, 0, (size_t)T * B * ndir * 4 * H * 4, s));
-  ITTS_HIP_CHECK(hipMemsetAsync(a.cs, 0, st * 4, s));
-  const dim3 grid((H / BW_UNITS) * ((B + 15) / 16), ndir);
+  ITTS_HIP_CHECK(hipMemsetAsync(a.cs, 0, st * 4, s));   // running dc of rows that are not active yet
+  int p = 0;
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
-    hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, s, a);
+    const int nact = active_rows(h_lengths, B, step, &p);
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((H / BW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;

@@ -43,26 +43,68 @@ def _iptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class PackedBatch(object):
+    """Index bookkeeping of pack_padded_sequence(enforce_sorted=False) (rnn_dyn/RNNWrapper.py:89-92)
+    for a padded batch: rows sorted by decreasing length (stable), packed row of frame t of sorted
+    row b = row_off[t] + b.  `flat_index` maps every packed row to its row in the padded tensor
+    flattened over (time, batch) -- or (batch, time) when batch_first -- so packing is one
+    index_select and unpacking one index_copy."""
+
+    def __init__(self, lengths, padded_time, batch_first, device):
+        import numpy as np
+        lengths = np.asarray(torch.as_tensor(lengths).cpu(), dtype=np.int64)
+        if lengths.ndim != 1 or len(lengths) == 0 or lengths.min() < 1:
+            raise ValueError("lengths must be a non-empty vector of positive values")
+        if lengths.max() > padded_time:
+            raise ValueError("a length exceeds the padded time extent")
+        self.B, self.T = len(lengths), int(lengths.max())
+        perm = np.argsort(-lengths, kind="stable")
+        sorted_len = lengths[perm]
+        nact = (sorted_len[None, :] > np.arange(self.T)[:, None]).sum(axis=1)      # [T]
+        row_off = np.concatenate([[0], np.cumsum(nact)[:-1]])
+        self.N = int(nact.sum())
+        t_of = np.repeat(np.arange(self.T), nact)
+        b_of = np.arange(self.N) - row_off[t_of]
+        flat = perm[b_of] * padded_time + t_of if batch_first else t_of * self.B + perm[b_of]
+        self.h_lengths = torch.from_numpy(sorted_len.astype(np.int32))            # host, sorted
+        self.d_lengths = self.h_lengths.to(device)
+        self.d_row_off = torch.from_numpy(row_off.astype(np.int32)).to(device)
+        self.flat_index = torch.from_numpy(flat.astype(np.int64)).to(device)
+        self.perm = torch.from_numpy(perm.astype(np.int64)).to(device)
+        self.inv_perm = torch.from_numpy(np.argsort(perm).astype(np.int64)).to(device)
+
+    def pack(self, padded):
+        """[T, B, F] (or [B, T, F]) -> [N, F]"""
+        return padded.reshape(-1, padded.shape[-1]).index_select(0, self.flat_index)
+
+    def unpack(self, packed, padded_shape):
+        """[N, D] -> zero-padded [T, B, D] / [B, T, D] (pad_packed_sequence)"""
+        out = packed.new_zeros((padded_shape[0] * padded_shape[1], packed.shape[-1]))
+        return out.index_copy(0, self.flat_index, packed).reshape(
+            padded_shape[0], padded_shape[1], packed.shape[-1])
+
+    def _hptr(self):
+        return ctypes.c_void_p(self.h_lengths.data_ptr())
+
+
 class LSTMLayerFunction(torch.autograd.Function):
-    """One (bi)directional LSTM layer on a time-major padded batch x [T, B, F] with per-row
-    lengths (packed-sequence semantics of rnn_dyn/RNNWrapper.py:89-102)."""
+    """One (bi)directional LSTM layer on packed rows x [N, F] (see PackedBatch)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, h0, c0, training):
+    def forward(ctx, x2, pb, w_ih, w_hh, b_ih, b_hh, h0, c0, training):
         L = _lib.load()
-        T, B, F = x.shape
+        N, F = x2.shape
         ndir, G4, H = w_hh.shape
-        x2 = x.contiguous().reshape(T * B, F)
+        T, B = pb.T, pb.B
+        x2 = x2.contiguous()
         w_ih_cat = w_ih.reshape(ndir * G4, F)
         gin = ops.linear_fwd(x2, w_ih_cat, (b_ih + b_hh).reshape(-1), ops.ACT_NONE)
-        dev = x.device
-        y = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev)
+        dev = x2.device
+        y = torch.empty((N, ndir * H), dtype=torch.float32, device=dev)
         keep = bool(training)
-        gates = torch.empty((T * B, ndir * G4), dtype=torch.float32, device=dev) if keep else None
-        csave = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
-        # zero-filled: padded rows enter the dW_hh GEMM multiplied by zero gate gradients, and
-        # 0 * (uninitialised NaN) would poison the sum
-        hprev = torch.zeros((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        gates = torch.empty((N, ndir * G4), dtype=torch.float32, device=dev) if keep else None
+        csave = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        hprev = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
         hn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         cn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_lstm_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
@@ -70,28 +112,32 @@ class LSTMLayerFunction(torch.autograd.Function):
         h0c = h0.contiguous() if h0 is not None else None
         c0c = c0.contiguous() if c0 is not None else None
         _lib.check(L.itts_lstm_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(h0c), _iptr(c0c),
-                                         _iptr(lengths), T, B, H, ndir, _iptr(y), _iptr(gates),
-                                         _iptr(csave), _iptr(hprev), _iptr(hn), _iptr(cn),
-                                         _iptr(state), ops._stream()), "itts_lstm_layer_fwd")
+                                         _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
+                                         T, B, H, ndir, _iptr(y), _iptr(gates), _iptr(csave),
+                                         _iptr(hprev), _iptr(hn), _iptr(cn), _iptr(state),
+                                         ops._stream()), "itts_lstm_layer_fwd")
         if keep:
-            ctx.save_for_backward(x2, lengths, w_ih_cat, w_hh_c, gates, csave, hprev,
+            ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, csave, hprev,
                                   c0c if c0c is not None else torch.empty(0, device=dev))
-            ctx.dims = (T, B, F, H, ndir, c0c is not None)
-        return y.reshape(T, B, ndir * H), hn, cn
+            ctx.pb = pb
+            ctx.dims = (F, H, ndir, c0c is not None)
+        return y, hn, cn
 
     @staticmethod
     def backward(ctx, dy, dhn, dcn):
         L = _lib.load()
-        x2, lengths, w_ih_cat, w_hh, gates, csave, hprev, c0 = ctx.saved_tensors
-        T, B, F, H, ndir, has_c0 = ctx.dims
+        x2, w_ih_cat, w_hh, gates, csave, hprev, c0 = ctx.saved_tensors
+        pb = ctx.pb
+        F, H, ndir, has_c0 = ctx.dims
         G4 = 4 * H
         dev = dy.device
-        dy2 = dy.contiguous().reshape(T * B, ndir * H)
-        dg = torch.empty((T * B, ndir * G4), dtype=torch.float32, device=dev)
-        state = torch.empty(L.itts_lstm_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
+        dy2 = dy.contiguous()
+        dg = torch.empty((pb.N, ndir * G4), dtype=torch.float32, device=dev)
+        state = torch.empty(L.itts_lstm_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
         w_hh_t = w_hh.transpose(1, 2).contiguous()          # [ndir, H, 4H]
         _lib.check(L.itts_lstm_layer_bwd(_iptr(dy2), _iptr(w_hh_t), _iptr(c0 if has_c0 else None),
-                                         _iptr(gates), _iptr(csave), _iptr(lengths), T, B, H, ndir,
+                                         _iptr(gates), _iptr(csave), _iptr(pb.d_lengths),
+                                         pb._hptr(), _iptr(pb.d_row_off), pb.T, pb.B, H, ndir,
                                          _iptr(dg), _iptr(state), ops._stream()),
                    "itts_lstm_layer_bwd")
         dw_ih, db = ops.linear_bwd_weight(dg, x2)                      # [ndir*4H, F], [ndir*4H]
@@ -101,57 +147,61 @@ class LSTMLayerFunction(torch.autograd.Function):
                                   dw=dw_hh[d], want_bias=False)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bwd_input(dg, w_ih_cat).reshape(T, B, F)
+            dx = ops.linear_bwd_input(dg, w_ih_cat)
         db = db.reshape(ndir, G4)
         return dx, None, dw_ih.reshape(ndir, G4, F), dw_hh, db, db.clone(), None, None, None
 
 
 class GRULayerFunction(torch.autograd.Function):
-    """One (bi)directional GRU layer on a time-major padded batch x [T, B, F] with per-row
-    lengths (torch.nn.GRU on packed sequences, rnn_dyn/RNNWrapper.py:45-107)."""
+    """One (bi)directional GRU layer on packed rows x [N, F] (torch.nn.GRU on a PackedSequence,
+    rnn_dyn/RNNWrapper.py:45-107)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, h0, training):
+    def forward(ctx, x2, pb, w_ih, w_hh, b_ih, b_hh, h0, training):
         L = _lib.load()
-        T, B, F = x.shape
+        N, F = x2.shape
         ndir, G3, H = w_hh.shape
-        x2 = x.contiguous().reshape(T * B, F)
+        T, B = pb.T, pb.B
+        x2 = x2.contiguous()
         w_ih_cat = w_ih.reshape(ndir * G3, F)
         gin = ops.linear_fwd(x2, w_ih_cat, b_ih.reshape(-1), ops.ACT_NONE)
-        dev = x.device
-        y = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev)
+        dev = x2.device
+        y = torch.empty((N, ndir * H), dtype=torch.float32, device=dev)
         keep = bool(training)
-        gates = torch.empty((T * B, ndir * G3), dtype=torch.float32, device=dev) if keep else None
-        hnpre = torch.empty((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
-        # zero-filled: padded rows meet zero gate gradients in the dW_hh GEMM (0 * NaN guard)
-        hprev = torch.zeros((T * B, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        gates = torch.empty((N, ndir * G3), dtype=torch.float32, device=dev) if keep else None
+        hnpre = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        hprev = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
         hn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_gru_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
         w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
         h0c = h0.contiguous() if h0 is not None else None
         _lib.check(L.itts_gru_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(b_hh_c), _iptr(h0c),
-                                        _iptr(lengths), T, B, H, ndir, _iptr(y), _iptr(gates),
-                                        _iptr(hnpre), _iptr(hprev), _iptr(hn), _iptr(state),
-                                        ops._stream()), "itts_gru_layer_fwd")
+                                        _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
+                                        T, B, H, ndir, _iptr(y), _iptr(gates), _iptr(hnpre),
+                                        _iptr(hprev), _iptr(hn), _iptr(state), ops._stream()),
+                   "itts_gru_layer_fwd")
         if keep:
-            ctx.save_for_backward(x2, lengths, w_ih_cat, w_hh_c, gates, hnpre, hprev)
-            ctx.dims = (T, B, F, H, ndir)
-        return y.reshape(T, B, ndir * H), hn
+            ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, hnpre, hprev)
+            ctx.pb = pb
+            ctx.dims = (F, H, ndir)
+        return y, hn
 
     @staticmethod
     def backward(ctx, dy, dhn):
         L = _lib.load()
-        x2, lengths, w_ih_cat, w_hh, gates, hnpre, hprev = ctx.saved_tensors
-        T, B, F, H, ndir = ctx.dims
+        x2, w_ih_cat, w_hh, gates, hnpre, hprev = ctx.saved_tensors
+        pb = ctx.pb
+        F, H, ndir = ctx.dims
         G3 = 3 * H
         dev = dy.device
-        dy2 = dy.contiguous().reshape(T * B, ndir * H)
-        dgi = torch.empty((T * B, ndir * G3), dtype=torch.float32, device=dev)
-        dgh = torch.empty((T * B, ndir * G3), dtype=torch.float32, device=dev)
-        state = torch.empty(L.itts_gru_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
+        dy2 = dy.contiguous()
+        dgi = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
+        dgh = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
+        state = torch.empty(L.itts_gru_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
         w_hh_t = w_hh.transpose(1, 2).contiguous()          # [ndir, H, 3H]
         _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh_t), _iptr(gates), _iptr(hnpre),
-                                        _iptr(hprev), _iptr(lengths), T, B, H, ndir, _iptr(dgi),
+                                        _iptr(hprev), _iptr(pb.d_lengths), pb._hptr(),
+                                        _iptr(pb.d_row_off), pb.T, pb.B, H, ndir, _iptr(dgi),
                                         _iptr(dgh), _iptr(state), ops._stream()),
                    "itts_gru_layer_bwd")
         dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]
@@ -163,6 +213,6 @@ class GRULayerFunction(torch.autograd.Function):
             db_hh[d] = db
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bwd_input(dgi, w_ih_cat).reshape(T, B, F)
+            dx = ops.linear_bwd_input(dgi, w_ih_cat)
         return dx, None, dw_ih.reshape(ndir, G3, F), dw_hh, db_ih.reshape(ndir, G3), db_hh, \
             None, None

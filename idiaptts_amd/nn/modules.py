@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .functional import GRULayerFunction, LinearActFunction, LSTMLayerFunction
+from .functional import GRULayerFunction, LinearActFunction, LSTMLayerFunction, PackedBatch
 
 
 class LinearAct(nn.Linear):
@@ -58,11 +58,12 @@ class LSTM(nn.Module):
 
     def forward(self, input_, hx=None, lengths=None):
         ndir = 2 if self.bidirectional else 1
-        x = input_.transpose(0, 1) if self.batch_first else input_
-        T, B = x.shape[0], x.shape[1]
+        time_dim, batch_dim = (1, 0) if self.batch_first else (0, 1)
         if lengths is None:
-            lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
-        lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32)
+            lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
+        # pack once (valid frames only, rows sorted by length), run all layers on packed rows
+        pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
+        x = pb.pack(input_)
         h0 = c0 = None
         if hx is not None:
             h0, c0 = hx      # [num_layers*ndir, B, H]; RNNWrapper expands one vector per row
@@ -74,14 +75,14 @@ class LSTM(nn.Module):
                 hl = h0[layer * ndir:(layer + 1) * ndir, 0, :]
                 cl = c0[layer * ndir:(layer + 1) * ndir, 0, :]
             x, hn, cn = LSTMLayerFunction.apply(
-                x, lengths, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
+                x, pb, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
                 self._stack("bias_ih", layer), self._stack("bias_hh", layer), hl, cl,
                 torch.is_grad_enabled())
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = torch.nn.functional.dropout(x, self.dropout, True)
-            hn_all.append(hn)
-            cn_all.append(cn)
-        out = x.transpose(0, 1) if self.batch_first else x
+            hn_all.append(hn.index_select(1, pb.inv_perm))      # back to the caller's row order
+            cn_all.append(cn.index_select(1, pb.inv_perm))
+        out = pb.unpack(x, input_.shape)
         return out, (torch.cat(hn_all, 0), torch.cat(cn_all, 0))
 
 
@@ -119,21 +120,21 @@ class GRU(nn.Module):
 
     def forward(self, input_, hx=None, lengths=None):
         ndir = 2 if self.bidirectional else 1
-        x = input_.transpose(0, 1) if self.batch_first else input_
-        T, B = x.shape[0], x.shape[1]
+        time_dim, batch_dim = (1, 0) if self.batch_first else (0, 1)
         if lengths is None:
-            lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
-        lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32)
+            lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
+        pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
+        x = pb.pack(input_)
         hn_all = []
         for layer in range(self.num_layers):
             # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0
             hl = hx[layer * ndir:(layer + 1) * ndir, 0, :] if hx is not None else None
             x, hn = GRULayerFunction.apply(
-                x, lengths, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
+                x, pb, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
                 self._stack("bias_ih", layer), self._stack("bias_hh", layer), hl,
                 torch.is_grad_enabled())
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = torch.nn.functional.dropout(x, self.dropout, True)
-            hn_all.append(hn)
-        out = x.transpose(0, 1) if self.batch_first else x
+            hn_all.append(hn.index_select(1, pb.inv_perm))
+        out = pb.unpack(x, input_.shape)
         return out, torch.cat(hn_all, 0)

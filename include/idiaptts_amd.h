@@ -194,45 +194,53 @@ int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* 
                           double* d_y_f64, void* stream);
 
 /* ---- acoustic model: (Bi)LSTM recurrence (torch.nn.LSTM inside rnn_dyn/RNNWrapper.py:45-107) ------
- * Time-major rows: row(t, b) = t*B + b.  Direction d owns column block d of every tensor.
- *   d_gin    [T*B, ndir*4H]  x W_ih^T + b_ih + b_hh for all steps (one itts_linear_fwd call)
+ * Packed rows, the layout pack_padded_sequence produces (RNNWrapper.py:89-92): the B sequences are
+ * sorted by decreasing length, frame t of sequence b is packed row d_row_off[t] + b with
+ * d_row_off[t] = sum_{t' < t} #{b : len_b > t'}; N = sum of the lengths rows in total, T = the
+ * longest length.  Direction d owns column block d of every tensor.
+ *   d_gin    [N, ndir*4H]    x W_ih^T + b_ih + b_hh for all frames (one itts_linear_fwd call)
  *   d_whh    [ndir][4H][H]   gate order i, f, g, o
- *   d_h0/c0  [ndir][H] or NULL (zeros); d_lengths [B] int32 (packed-sequence semantics,
- *            enforce_sorted=False: the reverse direction starts at each row's own last frame)
- *   d_y      [T*B, ndir*H]   zero on padded frames (pad_packed_sequence)
+ *   d_h0/c0  [ndir][H] or NULL (zeros)
+ *   d_lengths [B] int32 on the device, h_lengths the same values on the host (sorted decreasingly;
+ *            the host copy sizes the per-step launches), d_row_off [T] int32 on the device;
+ *            the reverse direction starts at each sequence's own last frame
+ *   d_y      [N, ndir*H]
  *   d_gates / d_csave / d_hprev: tensors saved for the backward pass (all NULL for inference)
- *   d_hn/d_cn [ndir][B][H]   final states (may be NULL); d_state >= itts_lstm_state_bytes bytes */
+ *   d_hn/d_cn [ndir][B][H]   final states in sorted row order (may be NULL);
+ *   d_state >= itts_lstm_state_bytes bytes */
 int64_t itts_lstm_state_bytes(int B, int H, int ndir);
 int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0, const float* d_c0,
-                        const int* d_lengths, int T, int B, int H, int ndir, float* d_y,
-                        float* d_gates, float* d_csave, float* d_hprev, float* d_hn, float* d_cn,
-                        void* d_state, void* stream);
-/* d_dg [T*B, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [T*B, ndir*H]; d_whh_t is W_hh
+                        const int* d_lengths, const int* h_lengths, const int* d_row_off, int T,
+                        int B, int H, int ndir, float* d_y, float* d_gates, float* d_csave,
+                        float* d_hprev, float* d_hn, float* d_cn, void* d_state, void* stream);
+/* d_dg [N, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [N, ndir*H]; d_whh_t is W_hh
  * transposed per direction ([ndir][H][4H]).  dW_ih, dW_hh, db and dX follow from d_dg with
  * itts_linear_bwd_weight / itts_linear_bwd_input. */
 int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_c0,
-                        const float* d_gates, const float* d_csave, const int* d_lengths, int T, int B,
-                        int H, int ndir, float* d_dg, void* d_state, void* stream);
+                        const float* d_gates, const float* d_csave, const int* d_lengths,
+                        const int* h_lengths, const int* d_row_off, int T, int B, int H, int ndir,
+                        float* d_dg, void* d_state, void* stream);
 
 /* ---- (Bi)GRU recurrence (torch.nn.GRU behind rnn_dyn/RNNWrapper.py:45-107 for `..GRU..` groups;
- *      gate order r, z, n; packed-sequence semantics as for the LSTM entry points above).
- * d_gin  [T*B, ndir*3H] = X W_ih^T + b_ih for all steps (one itts_linear_fwd call),
+ *      gate order r, z, n; packed rows, lengths and row offsets as for the LSTM entry points).
+ * d_gin  [N, ndir*3H] = X W_ih^T + b_ih for all frames (one itts_linear_fwd call),
  * d_whh  [ndir][3H][H], d_bhh [ndir][3H] (b_hn sits inside r * (W_hn h + b_hn)), d_h0 [ndir][H] or
- * NULL.  Training saves d_gates [T*B, ndir*3H] (r, z, n after activation), d_hnpre and d_hprev
- * [T*B, ndir*H]; pass all three NULL for inference.  d_hn [ndir][B][H] may be NULL.
+ * NULL.  Training saves d_gates [N, ndir*3H] (r, z, n after activation), d_hnpre and d_hprev
+ * [N, ndir*H]; pass all three NULL for inference.  d_hn [ndir][B][H] may be NULL.
  * d_state >= itts_gru_state_bytes(B, H, ndir).
  * Backward fills d_dgi (gradient wrt d_gin: feeds dX, dW_ih, db_ih) and d_dgh (gradient wrt the
- * hidden projections: feeds dW_hh with d_hprev, db_hh), both [T*B, ndir*3H], zero on padded rows.
+ * hidden projections: feeds dW_hh with d_hprev, db_hh), both [N, ndir*3H].
  * d_whh_t is W_hh transposed per direction ([ndir][H][3H]). */
 int64_t itts_gru_state_bytes(int B, int H, int ndir);
 int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
-                       const float* d_h0, const int* d_lengths, int T, int B, int H, int ndir,
-                       float* d_y, float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn,
-                       void* d_state, void* stream);
-int itts_gru_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_gates,
-                       const float* d_hnpre, const float* d_hprev, const int* d_lengths, int T,
-                       int B, int H, int ndir, float* d_dgi, float* d_dgh, void* d_state,
+                       const float* d_h0, const int* d_lengths, const int* h_lengths,
+                       const int* d_row_off, int T, int B, int H, int ndir, float* d_y,
+                       float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn, void* d_state,
                        void* stream);
+int itts_gru_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_gates,
+                       const float* d_hnpre, const float* d_hprev, const int* d_lengths,
+                       const int* h_lengths, const int* d_row_off, int T, int B, int H, int ndir,
+                       float* d_dgi, float* d_dgh, void* d_state, void* stream);
 
 #ifdef __cplusplus
 }
