@@ -12,27 +12,22 @@
 // torch.nn.GRU cell, gate order r, z, n:
 //   r = sigmoid(gin_r + W_hr h + b_hr)      z = sigmoid(gin_z + W_hz h + b_hz)
 //   n = tanh(gin_n + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
-#include <algorithm>
-
-#include "common.h"
+#include "rnn_common.h"
 
 namespace itts {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GRU_FW_UNITS = 4;    // hidden units per workgroup, forward (12 of 16 tile rows used)
 constexpr int GRU_BW_UNITS = 16;   // hidden units per workgroup, backward
 
 struct GruArgs {
   int T, B, H, ndir;
-  const int* lengths;     // [B] sorted by decreasing length
   const int* row_off;     // [T] packed row of (t, b) = row_off[t] + b
+  const int* rev_row;     // [T*B] packed row of the reverse direction at step s, row b
   const float* gin;       // [N, ndir*3H] input projections incl. b_ih (N = sum of lengths)
-  const float* whh;       // [ndir][3H][H]
-  const float* whh_t;     // [ndir][H][3H]   (backward)
+  const float* wp;        // re-tiled W_hh (rnn_common.h)
   const float* bhh;       // [ndir][3H]
-  const float* h0;        // [ndir][H] or NULL
-  float* hs;              // [2 parity][ndir][B][H] running hidden state (fwd) / carried dh*z (bwd)
+  float* hs;              // [2 parity][ndir] K-blocked running hidden state (fwd) / dh*z carry (bwd)
+  float* dgb;             // [2 parity][ndir] K-blocked dGh of the step just processed (backward)
   float* y;               // [N, ndir*H]
   float* gates;           // [N, ndir*3H] r, z, n after activation (saved for backward)
   float* hnpre;           // [N, ndir*H]  W_hn h + b_hn
@@ -42,112 +37,117 @@ struct GruArgs {
   float* dgh;             // [N, ndir*3H] gradient wrt the hidden projections (da_r, da_z, da_n*r)
   int step;
   int ksplit, kiter;
+  int nact, nact_next;    // rows active at this step / at step + 1 (a prefix: rows are sorted)
 };
 
-__device__ __forceinline__ float gru_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-
-__device__ __forceinline__ int gru_time_of(int dir, int s, int len) {
-  if (s >= len) return -1;
-  return dir == 0 ? s : len - 1 - s;
+__device__ __forceinline__ size_t gru_row_at(const GruArgs& a, int dir, int s, int b) {
+  return dir == 0 ? (size_t)(a.row_off[s] + b) : (size_t)a.rev_row[(size_t)s * a.B + b];
 }
 
 // ---- forward step ---------------------------------------------------------------------------------
-// Workgroup = 4 hidden units x 3 gates (tile rows 0..11, row = gate*4 + unit) x 16 batch rows; the
-// waves split K = H, partial tiles meet in LDS, 64 threads apply the cell update.
+// Workgroup = 4 hidden units x 3 gates (tile rows 0..11, row = gate*4 + unit; rows 12..15 of the
+// re-tiled W_hh are zero) x every active batch tile (NT tiles of 16 rows per pass); the waves
+// split K = H, a wave's W_hh fragments are loaded once and all operand loads are in flight before
+// the first MFMA; partial tiles meet in LDS and thread (tile, row, unit) applies the cell update.
+// Grid (H/4, ndir).
+template <int NT>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruArgs a) {
-  __shared__ float P[4][16][17];
+  __shared__ float P[NT][4][16][17];
   const int H = a.H, B = a.B, G3 = 3 * H;
   const int dir = blockIdx.y;
-  const int ngroups = H / GRU_FW_UNITS;
-  const int j0 = (blockIdx.x % ngroups) * GRU_FW_UNITS;
-  const int b0 = (blockIdx.x / ngroups) * 16;
+  const int j0 = blockIdx.x * GRU_FW_UNITS;
   const int par = a.step & 1;
-  const float* whh = a.whh + (size_t)dir * G3 * H;
-  const float* hprev = a.hs + ((size_t)par * a.ndir + dir) * B * H;
-  float* hnext = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
+  const size_t dsz = (size_t)B * H;
+  const float* hprev = a.hs + ((size_t)par * a.ndir + dir) * dsz;
+  float* hnext = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * dsz;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
+  const int ntiles = (a.nact + 15) >> 4;
 
-  const int bl = threadIdx.x >> 2, u = threadIdx.x & 3;
-  const int b = b0 + bl, j = j0 + u;
-  const bool ew = threadIdx.x < 64 && b < B;
-  int t = -1;
-  float hp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f;
-  size_t r = 0;
-  if (ew) {
-    t = gru_time_of(dir, a.step, a.lengths[b]);
-    hp_v = hprev[(size_t)b * H + j];
-    if (t >= 0) {
-      r = (size_t)a.row_off[t] + b;
-      const float* gi = a.gin + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
-      g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H];
-      const float* bh = a.bhh + (size_t)dir * G3 + j;
-      bh0 = bh[0]; bh1 = bh[H]; bh2 = bh[2 * H];
-    }
-  }
-
-  const int row = b0 + lr;
-  const bool rok = row < B;
   const int kiter = wv < a.ksplit ? a.kiter : 0;
-  const int kbase = wv * (16 * a.kiter) + 4 * kg;
-  const int gate = lr >> 2;                    // tile row -> gate; rows 12..15 are padding
-  const bool gok = gate < 3;
-  const float* hp = hprev + (size_t)(rok ? row : 0) * H + (kiter ? kbase : 0);
-  const float* wp = whh + (size_t)((gok ? gate : 0) * H + j0 + (lr & 3)) * H + (kiter ? kbase : 0);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int kb0 = wv * 4 * a.kiter + kg;
+  const float4* wp = reinterpret_cast<const float4*>(a.wp) +
+                     (((size_t)dir * (H / 4) + blockIdx.x) * (H / 4) + (kiter ? kb0 : 0)) * 16 + lr;
+  const float4* hp4 = reinterpret_cast<const float4*>(hprev);
+
+  for (int tb = 0; tb < ntiles; tb += NT) {
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt][0] = acc[tt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q = threadIdx.x >> 6, bl = (threadIdx.x >> 2) & 15, u = threadIdx.x & 3;
+    const int b = (tb + q) * 16 + bl, j = j0 + u;
+    const bool ew = q < NT && b < B && tb + q < ntiles;
+    const bool act = ew && b < a.nact;
+    const size_t sidx = ((size_t)blockIdx.x * B + (ew ? b : 0)) * 4 + u;   // blocked(b, j)
+    float hp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f;
+    size_t r = 0;
 #pragma unroll 1
-  for (int c = 0; c * 8 < kiter; ++c) {
-    float4 av[8], bv[8];
+    for (int c = 0; c < kiter || c == 0; c += 8) {
+      float4 bv[8], av[NT][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int i = c * 8 + s;
-      const int o = i < kiter ? 16 * i : 0;
-      av[s] = *reinterpret_cast<const float4*>(hp + o);
-      bv[s] = *reinterpret_cast<const float4*>(wp + o);
-    }
+      for (int s = 0; s < 8; ++s) bv[s] = wp[(size_t)(c + s < kiter ? 4 * (c + s) : 0) * 16];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      float4 x = av[s];
-      if (!rok || c * 8 + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc1, 0, 0, 0);
-    }
-  }
+      for (int tt = 0; tt < NT; ++tt) {
+        const int row = (tb + tt) * 16 + lr;
+        const float4* hp = hp4 + (size_t)(kiter ? kb0 : 0) * B + (row < B ? row : 0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
-  __syncthreads();
-  if (ew) {
-    float hn = hp_v;
-    if (t >= 0) {
-      auto proj = [&](int n) { return (P[0][bl][n] + P[1][bl][n]) + (P[2][bl][n] + P[3][bl][n]); };
-      const float rg = gru_sigmoid(g0 + proj(u) + bh0);
-      const float zg = gru_sigmoid(g1 + proj(4 + u) + bh1);
-      const float hnp = proj(8 + u) + bh2;
-      const float ng = tanhf(g2 + rg * hnp);
-      hn = (1.f - zg) * ng + zg * hp_v;
-      const size_t oh = r * (size_t)(a.ndir * H) + (size_t)dir * H + j;
-      a.y[oh] = hn;
-      if (a.gates) {
-        float* gs = a.gates + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
-        gs[0] = rg; gs[H] = zg; gs[2 * H] = ng;
-        a.hnpre[oh] = hnp;
-        a.hprev[oh] = hp_v;
+        for (int s = 0; s < 8; ++s) av[tt][s] = hp[(size_t)(c + s < kiter ? 4 * (c + s) : 0) * B];
+      }
+      if (c == 0 && ew) {
+        hp_v = hprev[sidx];
+        if (act) {
+          r = gru_row_at(a, dir, a.step, b);
+          const float* gi = a.gin + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
+          g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H];
+          const float* bh = a.bhh + (size_t)dir * G3 + j;
+          bh0 = bh[0]; bh1 = bh[H]; bh2 = bh[2 * H];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // all loads above are in flight before the first MFMA
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const bool rok = (tb + tt) * 16 + lr < B;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float4 x = av[tt][s];
+          if (!rok || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc[tt][0], 0, 0, 0);
+          acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc[tt][1], 0, 0, 0);
+          acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc[tt][0], 0, 0, 0);
+          acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc[tt][1], 0, 0, 0);
+        }
       }
     }
-    hnext[(size_t)b * H + j] = hn;
-  }
-}
-
-__global__ void gru_init_state_kernel(const float* __restrict__ h0, float* __restrict__ hs, int ndir,
-                                      int B, int H) {
-  const int64_t n = (int64_t)ndir * B * H;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int j = (int)(i % H);
-    const int d = (int)(i / ((int64_t)B * H));
-    hs[i] = h0 ? h0[d * H + j] : 0.f;
+    if (tb > 0) __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[tt][wv][kg * 4 + e][lr] = acc[tt][0][e] + acc[tt][1][e];
+    }
+    __syncthreads();
+    if (ew) {
+      float hn = hp_v;
+      if (act) {
+        const int qq = q < NT ? q : 0;
+        auto proj = [&](int n) {
+          return (P[qq][0][bl][n] + P[qq][1][bl][n]) + (P[qq][2][bl][n] + P[qq][3][bl][n]);
+        };
+        const float rg = sigmoid_acc(g0 + proj(u) + bh0);
+        const float zg = sigmoid_acc(g1 + proj(4 + u) + bh1);
+        const float hnp = proj(8 + u) + bh2;
+        const float ng = tanhf(g2 + rg * hnp);
+        hn = (1.f - zg) * ng + zg * hp_v;
+        const size_t oh = r * (size_t)(a.ndir * H) + (size_t)dir * H + j;
+        a.y[oh] = hn;
+        if (a.gates) {
+          float* gs = a.gates + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
+          gs[0] = rg; gs[H] = zg; gs[2 * H] = ng;
+          a.hnpre[oh] = hnp;
+          a.hprev[oh] = hp_v;
+        }
+      }
+      hnext[sidx] = hn;
+    }
   }
 }
 
@@ -157,32 +157,55 @@ __global__ void gru_init_state_kernel(const float* __restrict__ h0, float* __res
 //   dn   = dh (1 - z)      dz = dh (h_prev - n)         new carry = dh * z
 //   da_n = dn (1 - n^2)    da_r = da_n * hn_pre * r (1 - r)      da_z = dz * z (1 - z)
 //   dGi[t] = (da_r, da_z, da_n)      dGh[t] = (da_r, da_z, da_n * r)
-// Workgroup = 16 hidden units x 16 batch rows; three waves take one gate block (K = H) each of the
-// 3H rows of W_hh^T, the fourth idles.
-__global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
-  __shared__ float P[4][16][17];
+// dGh is also written K-blocked into dgb, the MFMA operand of the next launch.
+// Workgroup = 16 hidden units x 16 batch rows; up to 12 waves split the K = 3H rows of W_hh^T so
+// that a wave has at most 8 k-steps (16 operand loads) per chunk, all in flight at once.
+__global__ __launch_bounds__(768) void gru_step_bwd_kernel(GruArgs a) {
+  __shared__ float P[12][16][17];
   const int H = a.H, B = a.B, G3 = 3 * H;
   const int dir = blockIdx.y;
   const int ngroups = H / GRU_BW_UNITS;
-  const int j0 = (blockIdx.x % ngroups) * GRU_BW_UNITS;
+  const int jg = blockIdx.x % ngroups;
+  const int j0 = jg * GRU_BW_UNITS;
   const int b0 = (blockIdx.x / ngroups) * 16;
   const int par = a.step & 1;
-  const float* wt = a.whh_t + (size_t)dir * H * G3;
-  const float* carry_in = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
-  float* carry_out = a.hs + ((size_t)par * a.ndir + dir) * B * H;
+  const size_t dsz = (size_t)B * H;
+  const float* carry_in = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * dsz;
+  float* carry_out = a.hs + ((size_t)par * a.ndir + dir) * dsz;
+  const float* dgb_in = a.dgb + ((size_t)(par ^ 1) * a.ndir + dir) * 3 * dsz;
+  float* dgb_out = a.dgb + ((size_t)par * a.ndir + dir) * 3 * dsz;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const size_t ldg = (size_t)a.ndir * G3, ldh = (size_t)a.ndir * H;
 
-  const int bl = threadIdx.x >> 4, n = threadIdx.x & 15;
+  const int row = b0 + lr;
+  const bool has_next = row < a.nact_next;
+  const int kiter = a.kiter;                     // 3H rows / waves / 16 per step
+  const int kb0 = wv * 4 * kiter + kg;
+  const int KB = 3 * H / 4;
+  const float4* ap = reinterpret_cast<const float4*>(dgb_in) + (size_t)kb0 * B + (row < B ? row : 0);
+  const float4* wp = reinterpret_cast<const float4*>(a.wp) +
+                     (((size_t)dir * ngroups + jg) * (size_t)KB + kb0) * 16 + lr;
+
+  const int bl = (threadIdx.x >> 4) & 15, n = threadIdx.x & 15;
   const int b = b0 + bl, j = j0 + n;
-  int t = -1;
+  const bool ew = threadIdx.x < 256 && b < B;
+  const bool act = ew && b < a.nact;
   float rg = 0.f, zg = 0.f, ng = 0.f, hnp = 0.f, hpv = 0.f, dyv = 0.f, cin = 0.f;
   size_t r = 0;
-  if (b < B) {
-    t = gru_time_of(dir, a.step, a.lengths[b]);
-    if (t >= 0) {
-      r = (size_t)a.row_off[t] + b;
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int c = 0; c < kiter; c += 8) {
+    float4 av[8], bv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const size_t o = c + s < kiter ? 4 * (c + s) : 0;
+      av[s] = ap[o * B];
+      bv[s] = wp[o * 16];
+    }
+    if (c == 0 && act) {
+      r = gru_row_at(a, dir, a.step, b);
       const float* gs = a.gates + r * ldg + (size_t)dir * G3 + j;
       rg = gs[0]; zg = gs[H]; ng = gs[2 * H];
       const size_t oh = r * ldh + (size_t)dir * H + j;
@@ -191,37 +214,11 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
       dyv = a.dy[oh];
       cin = carry_in[(size_t)b * H + j];
     }
-  }
-
-  const int row = b0 + lr;
-  bool has_next = false;
-  const float* dgp = a.dgh;
-  if (row < B) {
-    const int tn = gru_time_of(dir, a.step + 1, a.lengths[row]);
-    if (tn >= 0) {
-      has_next = true;
-      dgp = a.dgh + ((size_t)a.row_off[tn] + row) * ldg + (size_t)dir * G3;
-    }
-  }
-  const int kiter = wv < 3 ? H / 16 : 0;
-  const int kbase = (wv < 3 ? wv * H : 0) + 4 * kg;
-  dgp += kbase;
-  const float* wp = wt + (size_t)(j0 + lr) * G3 + kbase;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int c = 0; c * 8 < kiter; ++c) {
-    float4 av[8], bv[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int i = c * 8 + s;
-      const int o = i < kiter ? 16 * i : 0;
-      av[s] = *reinterpret_cast<const float4*>(dgp + o);
-      bv[s] = *reinterpret_cast<const float4*>(wp + o);
-    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       float4 x = av[s];
-      if (!has_next || c * 8 + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!has_next || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
@@ -231,10 +228,11 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
   __syncthreads();
-  if (b < B) {
+  if (ew) {
     float carry = 0.f;
-    if (t >= 0) {
-      const float dhr = (P[0][bl][n] + P[1][bl][n]) + (P[2][bl][n] + P[3][bl][n]);
+    if (act) {
+      float dhr = 0.f;
+      for (int w = 0; w < a.ksplit; ++w) dhr += P[w][bl][n];
       const float dh = dyv + dhr + cin;
       const float dn = dh * (1.f - zg);
       const float dz = dh * (hpv - ng);
@@ -245,19 +243,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruArgs a) {
       float* gh = a.dgh + r * ldg + (size_t)dir * G3 + j;
       gi[0] = dar; gi[H] = daz; gi[2 * H] = dan;
       gh[0] = dar; gh[H] = daz; gh[2 * H] = dan * rg;
+      dgb_out[blocked(b, j, B)] = dar;
+      dgb_out[blocked(b, H + j, B)] = daz;
+      dgb_out[blocked(b, 2 * H + j, B)] = dan * rg;
       carry = dh * zg;
     }
     carry_out[(size_t)b * H + j] = carry;
-  }
-}
-
-__global__ void gru_final_state_kernel(const float* __restrict__ st, const int* __restrict__ lengths,
-                                       float* __restrict__ out, int ndir, int B, int H) {
-  const int64_t n = (int64_t)ndir * B * H;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)((i / H) % B);
-    out[i] = st[(int64_t)(lengths[b] & 1) * n + i];   // parity written by the row's last active step
   }
 }
 
@@ -265,84 +256,89 @@ __global__ void gru_final_state_kernel(const float* __restrict__ st, const int* 
 
 using namespace itts;
 
-static int gru_check(const int* h_lengths, int T, int B, int H, int ndir) {
-  ITTS_REQUIRE(T >= 1 && B >= 1 && (ndir == 1 || ndir == 2), "bad sizes");
-  ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 4096, "hidden size must be a multiple of 16");
-  ITTS_REQUIRE(h_lengths != nullptr, "host copy of the lengths is required");
-  ITTS_REQUIRE(h_lengths[0] == T && h_lengths[B - 1] >= 1, "T must be the longest length, all lengths >= 1");
-  for (int b = 1; b < B; ++b) ITTS_REQUIRE(h_lengths[b] <= h_lengths[b - 1], "rows must be sorted by decreasing length");
-  return ITTS_OK;
-}
-
-static inline int gru_active_rows(const int* h_lengths, int B, int s, int* p) {
-  while (*p > 0 && h_lengths[*p - 1] <= s) --*p;
-  while (*p < B && h_lengths[*p] > s) ++*p;
-  return *p;
-}
-
+// d_state: [hs / carry 2*ndir*B*H | dgb 2*ndir*B*3H | re-tiled W_hh ndir*4H*H (fwd pads the 4th gate)]
 extern "C" int64_t itts_gru_state_bytes(int B, int H, int ndir) {
   if (B <= 0 || H <= 0 || ndir <= 0) return 0;
-  return (int64_t)2 * ndir * B * H * 4;  // two parities of the running state
+  return ((int64_t)8 * ndir * B * H + (int64_t)ndir * 4 * H * H) * 4;
 }
 
 extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
                                   const float* d_h0, const int* d_lengths, const int* h_lengths,
-                                  const int* d_row_off, int T, int B, int H, int ndir, float* d_y,
-                                  float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn,
-                                  void* d_state, void* stream) {
+                                  const int* d_row_off, const int* d_rev_row, int T, int B, int H,
+                                  int ndir, float* d_y, float* d_gates, float* d_hnpre,
+                                  float* d_hprev, float* d_hn, void* d_state, void* stream) {
   ITTS_REQUIRE(d_gin && d_whh && d_bhh && d_lengths && d_row_off && d_y && d_state, "null pointer");
+  ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
   ITTS_REQUIRE((d_gates == nullptr) == (d_hnpre == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
                "gates / hnpre / hprev must be given together (training) or all NULL (inference)");
-  int rc = gru_check(h_lengths, T, B, H, ndir);
+  int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   GruArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.gin = d_gin;
-  a.whh = d_whh; a.bhh = d_bhh; a.h0 = d_h0; a.y = d_y; a.gates = d_gates; a.hnpre = d_hnpre;
-  a.hprev = d_hprev;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row; a.gin = d_gin;
+  a.bhh = d_bhh; a.y = d_y; a.gates = d_gates; a.hnpre = d_hnpre; a.hprev = d_hprev;
+  const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
+  float* wp = a.hs + 4 * st;
+  a.wp = wp;
   const int64_t n = (int64_t)ndir * B * H;
-  const dim3 eg((unsigned)std::min<int64_t>((n + 255) / 256, 1024));
-  hipLaunchKernelGGL(gru_init_state_kernel, eg, dim3(256), 0, s, d_h0, a.hs, ndir, B, H);
+  hipLaunchKernelGGL(rnn_pack_w_fwd_kernel, rnn_ew_grid((int64_t)ndir * H * H), dim3(256), 0, s, d_whh, wp, ndir, 3, H);
+  hipLaunchKernelGGL(rnn_init_state_kernel, rnn_ew_grid(n), dim3(256), 0, s, d_h0, a.hs, ndir, B, H);
   ITTS_LAUNCH_CHECK();
   a.ksplit = (H % 64 == 0) ? 4 : ((H % 32 == 0) ? 2 : 1);
   a.kiter = H / (16 * a.ksplit);
+  const dim3 grid(H / GRU_FW_UNITS, ndir);
   int p = B;
   for (int step = 0; step < T; ++step) {
     a.step = step;
-    const int nact = gru_active_rows(h_lengths, B, step, &p);
-    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((H / GRU_FW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0,
-                       s, a);
+    a.nact = rnn_active_rows(h_lengths, B, step, &p);
+    switch (std::min((a.nact + 15) / 16, 4)) {
+      case 1: hipLaunchKernelGGL(gru_step_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(gru_step_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(gru_step_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(gru_step_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
   }
   ITTS_LAUNCH_CHECK();
   if (d_hn) {
-    hipLaunchKernelGGL(gru_final_state_kernel, eg, dim3(256), 0, s, a.hs, d_lengths, d_hn, ndir, B, H);
+    hipLaunchKernelGGL(rnn_final_state_kernel, rnn_ew_grid(n), dim3(256), 0, s, a.hs, d_lengths, d_hn, ndir, B, H);
     ITTS_LAUNCH_CHECK();
   }
   return ITTS_OK;
 }
 
-extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_gates,
-                                  const float* d_hnpre, const float* d_hprev, const int* d_lengths,
-                                  const int* h_lengths, const int* d_row_off, int T, int B, int H,
+extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const float* d_gates,
+                                  const float* d_hnpre, const float* d_hprev, const int* h_lengths,
+                                  const int* d_row_off, const int* d_rev_row, int T, int B, int H,
                                   int ndir, float* d_dgi, float* d_dgh, void* d_state, void* stream) {
-  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_hnpre && d_hprev && d_lengths && d_row_off && d_dgi && d_dgh &&
-                   d_state, "null pointer");
-  int rc = gru_check(h_lengths, T, B, H, ndir);
+  ITTS_REQUIRE(d_dy && d_whh && d_gates && d_hnpre && d_hprev && d_row_off && d_dgi && d_dgh && d_state,
+               "null pointer");
+  ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
+  int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   GruArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.whh_t = d_whh_t;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row;
   a.gates = const_cast<float*>(d_gates); a.hnpre = const_cast<float*>(d_hnpre);
   a.hprev = const_cast<float*>(d_hprev); a.dy = d_dy; a.dgi = d_dgi; a.dgh = d_dgh;
+  const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
-  ITTS_HIP_CHECK(hipMemsetAsync(a.hs, 0, (size_t)2 * ndir * B * H * 4, s));   // carry of not-yet-active rows
-  int p = 0;
+  a.dgb = a.hs + st;
+  float* wp = a.hs + 4 * st;
+  a.wp = wp;
+  hipLaunchKernelGGL(rnn_pack_w_bwd_kernel, rnn_ew_grid((int64_t)ndir * H * H), dim3(256), 0, s, d_whh, wp, ndir, 3, H);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipMemsetAsync(a.hs, 0, st * 4, s));   // carry of not-yet-active rows
+  a.ksplit = (H % 64 == 0) ? 12 : ((H % 32 == 0) ? 6 : 3);   // waves per workgroup; 3H/16 k-steps in all
+  a.kiter = (3 * H / 16) / a.ksplit;
+  int p = 0, nact_next = 0;
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
-    const int nact = gru_active_rows(h_lengths, B, step, &p);
-    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((H / GRU_BW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0,
-                       s, a);
+    a.nact = rnn_active_rows(h_lengths, B, step, &p);
+    a.nact_next = nact_next;
+    nact_next = a.nact;
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((H / GRU_BW_UNITS) * ((a.nact + 15) / 16), ndir),
+                       dim3(64 * a.ksplit), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;

@@ -8,8 +8,8 @@
 //     (nn.hip), so are dX, dW_ih, dW_hh and the bias gradients in the backward pass;
 //   * only the true recurrence h_{t-1} W_hh^T runs per time step.  One launch per step, both
 //     directions in it: the kernel boundary is the grid-wide dependency (~1.5 us; an in-kernel
-//     grid barrier costs 4-7 us on this chip).  A workgroup owns a slice of hidden units, keeps
-//     its W_hh rows in LDS and streams h_{t-1} [B, H] from L2 through v_mfma_f32_16x16x4_f32
+//     grid barrier costs 4-7 us on this chip).  A workgroup owns a slice of hidden units and
+//     streams its W_hh rows and h_{t-1} [B, H] from L2 through v_mfma_f32_16x16x4_f32
 //     (exact fp32, same K-permutation trick as the GEMM: one 16-byte load feeds 4 MFMAs).
 //   * packed-sequence semantics: row b is active for step s < len_b; the forward direction
 //     visits t = s, the reverse direction t = len_b - 1 - s (it starts at each sequence's own
@@ -18,15 +18,18 @@
 //     decreasing length, frame t of row b lives at packed row row_off[t] + b, where
 //     row_off[t] = sum_{t' < t} nact(t') and nact(t) = #{b : len_b > t}.  Only valid frames exist,
 //     so the GEMMs around the recurrence touch N = sum(len) rows instead of T*B, and step s
-//     launches workgroups for the ceil(nact(s) / 16) batch tiles that still have active rows.
+//     works on the ceil(nact(s) / 16) batch tiles that still have active rows.  The reverse
+//     direction's row at step s, row_off[len_b - 1 - s] + b, comes from a table built once per
+//     batch (rev_row[s][b]) so that no step chases lengths -> offsets -> data through memory.
+//   * a step is latency bound (one dependent pass over ~10 MB that the previous launch left cold
+//     in L2): every operand load of a wave is issued before the first MFMA
+//     (__builtin_amdgcn_sched_barrier keeps the scheduler from pairing loads with their MFMAs,
+//     which costs ~0.2 us per load when it happens), and every operand load is a contiguous 1 KB
+//     wave access thanks to the K-blocked state / re-tiled W_hh layouts of rnn_common.h.
 // Gate order i, f, g, o and the two bias vectors follow torch.nn.LSTM.
-#include <algorithm>
-
-#include "common.h"
+#include "rnn_common.h"
 
 namespace itts {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FW_UNITS = 4;    // hidden units per workgroup in the forward step (16 gate rows)
 constexpr int BW_UNITS = 16;   // hidden units per workgroup in the backward step
@@ -34,15 +37,15 @@ constexpr int BW_UNITS = 16;   // hidden units per workgroup in the backward ste
 struct LstmArgs {
   // geometry
   int T, B, H, ndir;
-  const int* lengths;     // [B] device, sorted by decreasing length
   const int* row_off;     // [T] device: packed row of (t, b) = row_off[t] + b
+  const int* rev_row;     // [T*B] device: packed row the reverse direction visits at step s for
+                          //       row b, row_off[len_b - 1 - s] + b (unused where s >= len_b)
   const float* gin;       // [N, ndir*4H] input projections incl. both biases (N = sum of lengths)
-  const float* whh;       // [ndir][4H][H]
-  const float* whh_t;     // [ndir][H][4H]   (backward)
-  const float* h0;        // [ndir][H] initial state (broadcast over the batch)
-  const float* c0;
-  float* hs;              // [2 parity][ndir][B][H] running hidden state
-  float* cs;              // [2 parity][ndir][B][H] running cell state / running dc (backward)
+  const float* wp;        // re-tiled W_hh (rnn_pack_w_fwd_kernel / rnn_pack_w_bwd_kernel)
+  const float* c0;        // [ndir][H] or NULL
+  float* hs;              // [2 parity][ndir] K-blocked running hidden state
+  float* cs;              // [2 parity][ndir] K-blocked running cell state / running dc (backward)
+  float* dgb;             // [2 parity][ndir] K-blocked dG of the step just processed (backward)
   float* y;               // [N, ndir*H] layer output
   float* gates;           // [N, ndir*4H] post-activation gates i,f,g,o (saved for backward)
   float* csave;           // [N, ndir*H] c_t
@@ -51,118 +54,123 @@ struct LstmArgs {
   const float* dy;        // [N, ndir*H]
   float* dg;              // [N, ndir*4H] gradient wrt pre-activation gates
   int step;
-  int ksplit, kiter;  // forward: K = H split over `ksplit` waves, `kiter` steps of 16 each
+  int ksplit, kiter;      // K is split over `ksplit` waves, `kiter` steps of 16 k each
+  int nact, nact_next;    // rows active at this step / at step + 1 (a prefix: rows are sorted)
 };
 
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
-
-// time index visited by row b at recurrence step s, or -1 when the row is inactive
-__device__ __forceinline__ int time_of(int dir, int s, int len) {
-  if (s >= len) return -1;
-  return dir == 0 ? s : len - 1 - s;
+// packed row that row b visits at recurrence step s (the caller knows that it is active)
+__device__ __forceinline__ size_t row_at(const LstmArgs& a, int dir, int s, int b) {
+  return dir == 0 ? (size_t)(a.row_off[s] + b) : (size_t)a.rev_row[(size_t)s * a.B + b];
 }
 
 // ---- forward step -----------------------------------------------------------------------------------
-// Workgroup = (4 hidden units = 16 gate rows) x (16 batch rows); its 4 waves split K = H four
-// ways, every wave streams its A (h_{t-1}) and B (W_hh) fragments straight from L2 into registers
-// (all loads of the step in flight at once, no LDS staging: each element is used by exactly one
-// MFMA), the partial 16x16 tiles are reduced through LDS and 64 threads apply the cell update.
-// Grid: (H/4 * ceil(nact/16), ndir) -> 1024 workgroups for H = 512 while all 64 rows are active.
+// Workgroup = 4 hidden units (16 gate rows of W_hh) x every active batch tile.  Its 4 waves split
+// K = H four ways; a wave loads its W_hh fragments once, then the h_{t-1} fragments of NT batch
+// tiles of 16 rows, straight from L2 into registers (every element feeds exactly one MFMA, so
+// there is no LDS staging).  The partial 16x16 tiles are reduced through LDS and thread
+// (tile, row, unit) applies the cell update.
+// Grid: (H/4, ndir) -> 256 workgroups for H = 512; W_hh traffic does not grow with the batch.
+template <int NT>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
-  __shared__ float P[4][16][17];
+  __shared__ float P[NT][4][16][17];
   const int H = a.H, B = a.B, G4 = 4 * H;
   const int dir = blockIdx.y;
-  const int ngroups = H / FW_UNITS;
-  const int j0 = (blockIdx.x % ngroups) * FW_UNITS;
-  const int b0 = (blockIdx.x / ngroups) * 16;
+  const int j0 = blockIdx.x * FW_UNITS;
   const int par = a.step & 1;
-  const float* whh = a.whh + (size_t)dir * G4 * H;
-  const float* hprev = a.hs + ((size_t)par * a.ndir + dir) * B * H;
-  const float* cprev = a.cs + ((size_t)par * a.ndir + dir) * B * H;
-  float* hnext = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
-  float* cnext = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
+  const size_t dsz = (size_t)B * H;
+  const float* hprev = a.hs + ((size_t)par * a.ndir + dir) * dsz;
+  const float* cprev = a.cs + ((size_t)par * a.ndir + dir) * dsz;
+  float* hnext = a.hs + ((size_t)(par ^ 1) * a.ndir + dir) * dsz;
+  float* cnext = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * dsz;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
+  const int ntiles = (a.nact + 15) >> 4;
 
-  // elementwise operands of this workgroup's 16 rows x 4 units: issue their loads first
-  const int bl = threadIdx.x >> 2, u = threadIdx.x & 3;
-  const int b = b0 + bl, j = j0 + u;
-  const bool ew = threadIdx.x < 64 && b < B;
-  int t = -1;
-  float hp_v = 0.f, cp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-  size_t r = 0;
-  if (ew) {
-    t = time_of(dir, a.step, a.lengths[b]);
-    hp_v = hprev[(size_t)b * H + j];
-    cp_v = cprev[(size_t)b * H + j];
-    if (t >= 0) {
-      r = (size_t)a.row_off[t] + b;
-      const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
-      g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
-    }
-  }
-
-  const int row = b0 + lr;
-  const bool rok = row < B;
-  // K = H is split over the first a.ksplit waves, a.kiter steps of 16 k each
+  // K split over a.ksplit waves, a.kiter steps of 16 k (4 k-blocks) each, in chunks of 8 steps
   const int kiter = wv < a.ksplit ? a.kiter : 0;
-  const int kbase = wv * (16 * a.kiter) + 4 * kg;
-  const float* hp = hprev + (size_t)(rok ? row : 0) * H + (kiter ? kbase : 0);
-  const float* wp = whh + (size_t)((lr >> 2) * H + j0 + (lr & 3)) * H + (kiter ? kbase : 0);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int kb0 = wv * 4 * a.kiter + kg;                       // this lane's first k-block
+  const float4* wp = reinterpret_cast<const float4*>(a.wp) +
+                     (((size_t)dir * (H / 4) + blockIdx.x) * (H / 4) + (kiter ? kb0 : 0)) * 16 + lr;
+  const float4* hp4 = reinterpret_cast<const float4*>(hprev);
+
+  for (int tb = 0; tb < ntiles; tb += NT) {
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt][0] = acc[tt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // elementwise operands of thread (tile q, batch row bl, unit u); their loads are issued behind
+    // the first chunk's operand loads (loads return in order)
+    const int q = threadIdx.x >> 6, bl = (threadIdx.x >> 2) & 15, u = threadIdx.x & 3;
+    const int b = (tb + q) * 16 + bl, j = j0 + u;
+    const bool ew = q < NT && b < B && tb + q < ntiles;   // rows of a launched tile
+    const bool act = ew && b < a.nact;
+    const size_t sidx = ((size_t)blockIdx.x * B + (ew ? b : 0)) * 4 + u;   // blocked(b, j)
+    float hp_v = 0.f, cp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    size_t r = 0;
 #pragma unroll 1
-  for (int c = 0; c * 8 < kiter; ++c) {
-    float4 av[8], bv[8];
+    for (int c = 0; c < kiter || c == 0; c += 8) {
+      float4 bv[8], av[NT][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int i = c * 8 + s;
-      const int o = i < kiter ? 16 * i : 0;
-      av[s] = *reinterpret_cast<const float4*>(hp + o);
-      bv[s] = *reinterpret_cast<const float4*>(wp + o);
-    }
+      for (int s = 0; s < 8; ++s) bv[s] = wp[(size_t)(c + s < kiter ? 4 * (c + s) : 0) * 16];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      float4 x = av[s];
-      if (!rok || c * 8 + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc1, 0, 0, 0);
-    }
-  }
+      for (int tt = 0; tt < NT; ++tt) {
+        const int row = (tb + tt) * 16 + lr;
+        const float4* hp = hp4 + (size_t)(kiter ? kb0 : 0) * B + (row < B ? row : 0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
-  __syncthreads();
-  if (ew) {
-    float hn = hp_v, cn = cp_v;
-    if (t >= 0) {
-      auto gate = [&](int n) { return (P[0][bl][n] + P[1][bl][n]) + (P[2][bl][n] + P[3][bl][n]); };
-      const float ig = sigmoidf_acc(gate(u) + g0), fg = sigmoidf_acc(gate(4 + u) + g1),
-                  gg = tanhf(gate(8 + u) + g2), og = sigmoidf_acc(gate(12 + u) + g3);
-      cn = fg * cp_v + ig * gg;
-      hn = og * tanhf(cn);
-      a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
-      if (a.gates) {
-        float* gs = a.gates + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
-        gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
-        a.csave[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = cn;
-        a.hprev[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hp_v;
+        for (int s = 0; s < 8; ++s) av[tt][s] = hp[(size_t)(c + s < kiter ? 4 * (c + s) : 0) * B];
+      }
+      if (c == 0 && ew) {
+        hp_v = hprev[sidx];
+        cp_v = cprev[sidx];
+        if (act) {
+          r = row_at(a, dir, a.step, b);
+          const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+          g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // all loads above are in flight before the first MFMA
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const bool rok = (tb + tt) * 16 + lr < B;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float4 x = av[tt][s];
+          if (!rok || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc[tt][0], 0, 0, 0);
+          acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc[tt][1], 0, 0, 0);
+          acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc[tt][0], 0, 0, 0);
+          acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc[tt][1], 0, 0, 0);
+        }
       }
     }
-    hnext[(size_t)b * H + j] = hn;
-    cnext[(size_t)b * H + j] = cn;
-  }
-}
-
-// state init: hs/cs[parity 0][dir][b][:] = h0/c0[dir][:]
-__global__ void lstm_init_state_kernel(const float* __restrict__ h0, const float* __restrict__ c0,
-                                       float* __restrict__ hs, float* __restrict__ cs, int ndir, int B, int H) {
-  const int64_t n = (int64_t)ndir * B * H;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int j = (int)(i % H);
-    const int d = (int)(i / ((int64_t)B * H));
-    hs[i] = h0 ? h0[d * H + j] : 0.f;
-    cs[i] = c0 ? c0[d * H + j] : 0.f;
+    if (tb > 0) __syncthreads();   // P of the previous group has been consumed
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[tt][wv][kg * 4 + e][lr] = acc[tt][0][e] + acc[tt][1][e];
+    }
+    __syncthreads();
+    if (ew) {
+      float hn = hp_v, cn = cp_v;
+      if (act) {
+        const int qq = q < NT ? q : 0;
+        auto gate = [&](int n) {
+          return (P[qq][0][bl][n] + P[qq][1][bl][n]) + (P[qq][2][bl][n] + P[qq][3][bl][n]);
+        };
+        const float ig = sigmoid_acc(gate(u) + g0), fg = sigmoid_acc(gate(4 + u) + g1),
+                    gg = tanhf(gate(8 + u) + g2), og = sigmoid_acc(gate(12 + u) + g3);
+        cn = fg * cp_v + ig * gg;
+        hn = og * tanhf(cn);
+        a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
+        if (a.gates) {
+          float* gs = a.gates + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+          gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+          a.csave[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = cn;
+          a.hprev[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hp_v;
+        }
+      }
+      hnext[sidx] = hn;
+      cnext[sidx] = cn;
+    }
   }
 }
 
@@ -170,75 +178,72 @@ __global__ void lstm_init_state_kernel(const float* __restrict__ h0, const float
 // Processes recurrence step s = a.step (called with s = T-1 ... 0). For row b active at s:
 //   dh = dy[t] + dG[t_{s+1}] W_hh   (second term only if the row is active at s+1)
 //   standard LSTM cell gradients -> dG[t], running dc (cs buffers, parity by step)
-// Workgroup = 16 hidden units x 16 batch rows; the 4 waves split the K = 4H gate rows, operands
-// stream from L2 into registers in chunks of 8 k-steps.  Grid (H/16 * ceil(nact/16), ndir).
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
-  __shared__ float P[4][16][17];
+// dG of a step is written twice: row-major into dg (for the dW / dX GEMMs) and K-blocked into dgb,
+// which is what the next launch reads as its MFMA operand.
+// Workgroup = 16 hidden units x 16 batch rows; up to 16 waves split the K = 4H gate rows so that
+// a wave has at most 8 k-steps (16 operand loads) per chunk, all in flight at once.
+// Grid (H/16 * ceil(nact/16), ndir).
+__global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
+  __shared__ float P[16][16][17];
   const int H = a.H, B = a.B, G4 = 4 * H;
   const int dir = blockIdx.y;
   const int ngroups = H / BW_UNITS;
-  const int j0 = (blockIdx.x % ngroups) * BW_UNITS;
+  const int jg = blockIdx.x % ngroups;
+  const int j0 = jg * BW_UNITS;
   const int b0 = (blockIdx.x / ngroups) * 16;
   const int par = a.step & 1;
-  const float* wt = a.whh_t + (size_t)dir * H * G4;
-  const float* dc_in = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * B * H;
-  float* dc_out = a.cs + ((size_t)par * a.ndir + dir) * B * H;
+  const size_t dsz = (size_t)B * H;
+  const float* dc_in = a.cs + ((size_t)(par ^ 1) * a.ndir + dir) * dsz;
+  float* dc_out = a.cs + ((size_t)par * a.ndir + dir) * dsz;
+  const float* dgb_in = a.dgb + ((size_t)(par ^ 1) * a.ndir + dir) * 4 * dsz;
+  float* dgb_out = a.dgb + ((size_t)par * a.ndir + dir) * 4 * dsz;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
 
-  // elementwise operands (thread -> batch row bl, unit n): load early
-  const int bl = threadIdx.x >> 4, n = threadIdx.x & 15;
+  // dh_rec tile: A = dG of the next recurrence step (rows b0..b0+15, K-blocked), B = W_hh^T rows
+  // of our 16 units (re-tiled)
+  const int row = b0 + lr;
+  const bool has_next = row < a.nact_next;
+  const int kiter = a.kiter;                     // 4H gate rows / waves / 16 per step
+  const int kb0 = wv * 4 * kiter + kg;
+  const float4* ap = reinterpret_cast<const float4*>(dgb_in) + (size_t)kb0 * B + (row < B ? row : 0);
+  const float4* wp = reinterpret_cast<const float4*>(a.wp) +
+                     (((size_t)dir * ngroups + jg) * (size_t)H + kb0) * 16 + lr;   // K/4 = H blocks
+
+  // elementwise operands (thread -> batch row bl, unit n)
+  const int bl = (threadIdx.x >> 4) & 15, n = threadIdx.x & 15;
   const int b = b0 + bl, j = j0 + n;
-  int t = -1;
+  const bool ew = threadIdx.x < 256 && b < B;
+  const bool act = ew && b < a.nact;
   float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f, dyv = 0.f, dcin = 0.f;
   size_t r = 0;
-  if (b < B) {
-    const int len = a.lengths[b];
-    t = time_of(dir, a.step, len);
-    if (t >= 0) {
-      r = (size_t)a.row_off[t] + b;
-      const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
-      ig = gs[0]; fg = gs[H]; gg = gs[2 * H]; og = gs[3 * H];
-      ct = a.csave[r * ldh + (size_t)dir * H + j];
-      const int tp = time_of(dir, a.step - 1, len);
-      cp = (a.step > 0 && tp >= 0) ? a.csave[((size_t)a.row_off[tp] + b) * ldh + (size_t)dir * H + j]
-                                   : (a.c0 ? a.c0[dir * H + j] : 0.f);
-      dyv = a.dy[r * ldh + (size_t)dir * H + j];
-      dcin = dc_in[(size_t)b * H + j];
-    }
-  }
 
-  // dh_rec tile: A = dG of the next recurrence step (rows), B = W_hh^T rows of our 16 units
-  const int row = b0 + lr;
-  bool has_next = false;
-  const float* dgp = a.dg;
-  if (row < B) {
-    const int tn = time_of(dir, a.step + 1, a.lengths[row]);
-    if (tn >= 0) {
-      has_next = true;
-      dgp = a.dg + ((size_t)a.row_off[tn] + row) * ldg + (size_t)dir * G4;
-    }
-  }
-  const int kiter = H / 16;            // 4H gate rows / 4 waves / 16 per step
-  const int kbase = wv * H + 4 * kg;  // this wave's quarter of the 4H gate rows
-  dgp += kbase;
-  const float* wp = wt + (size_t)(j0 + lr) * G4 + kbase;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int c = 0; c * 8 < kiter; ++c) {
+  for (int c = 0; c < kiter; c += 8) {
     float4 av[8], bv[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const int i = c * 8 + s;
-      const int o = i < kiter ? 16 * i : 0;
-      av[s] = *reinterpret_cast<const float4*>(dgp + o);
-      bv[s] = *reinterpret_cast<const float4*>(wp + o);
+      const size_t o = c + s < kiter ? 4 * (c + s) : 0;
+      av[s] = ap[o * B];
+      bv[s] = wp[o * 16];
     }
+    if (c == 0 && act) {
+      r = row_at(a, dir, a.step, b);
+      const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
+      ig = gs[0]; fg = gs[H]; gg = gs[2 * H]; og = gs[3 * H];
+      ct = a.csave[r * ldh + (size_t)dir * H + j];
+      cp = a.step > 0 ? a.csave[row_at(a, dir, a.step - 1, b) * ldh + (size_t)dir * H + j]
+                      : (a.c0 ? a.c0[dir * H + j] : 0.f);
+      dyv = a.dy[r * ldh + (size_t)dir * H + j];
+      dcin = dc_in[(size_t)b * H + j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       float4 x = av[s];
-      if (!has_next || c * 8 + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!has_next || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
@@ -248,31 +253,25 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
   __syncthreads();
-  if (b < B) {
+  if (ew) {
     float dc_keep = 0.f;
-    if (t >= 0) {
-      const float dhr = (P[0][bl][n] + P[1][bl][n]) + (P[2][bl][n] + P[3][bl][n]);
+    if (act) {
+      float dhr = 0.f;
+      for (int w = 0; w < a.ksplit; ++w) dhr += P[w][bl][n];
       const float tc = tanhf(ct);
       const float dh = dyv + dhr;
       const float dcv = dh * og * (1.f - tc * tc) + dcin;
+      const float d0 = dcv * gg * ig * (1.f - ig), d1 = dcv * cp * fg * (1.f - fg),
+                  d2 = dcv * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
       float* dgo = a.dg + r * ldg + (size_t)dir * G4 + j;
-      dgo[0] = dcv * gg * ig * (1.f - ig);
-      dgo[H] = dcv * cp * fg * (1.f - fg);
-      dgo[2 * H] = dcv * ig * (1.f - gg * gg);
-      dgo[3 * H] = dh * tc * og * (1.f - og);
+      dgo[0] = d0; dgo[H] = d1; dgo[2 * H] = d2; dgo[3 * H] = d3;
+      dgb_out[blocked(b, j, B)] = d0;
+      dgb_out[blocked(b, H + j, B)] = d1;
+      dgb_out[blocked(b, 2 * H + j, B)] = d2;
+      dgb_out[blocked(b, 3 * H + j, B)] = d3;
       dc_keep = dcv * fg;
     }
     dc_out[(size_t)b * H + j] = dc_keep;
-  }
-}
-
-// hn / cn of row b sit in the parity written by its last active step: (len_b & 1)
-__global__ void rnn_final_state_kernel(const float* __restrict__ st, const int* __restrict__ lengths,
-                                       float* __restrict__ out, int ndir, int B, int H) {
-  const int64_t n = (int64_t)ndir * B * H;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)((i / H) % B);
-    out[i] = st[(int64_t)(lengths[b] & 1) * n + i];
   }
 }
 
@@ -280,88 +279,93 @@ __global__ void rnn_final_state_kernel(const float* __restrict__ st, const int* 
 
 using namespace itts;
 
-static int lstm_check(const int* h_lengths, int T, int B, int H, int ndir) {
-  ITTS_REQUIRE(T >= 1 && B >= 1 && (ndir == 1 || ndir == 2), "bad sizes");
-  ITTS_REQUIRE(H >= 16 && H % 16 == 0 && H <= 4096, "hidden size must be a multiple of 16");
-  ITTS_REQUIRE(h_lengths != nullptr, "host copy of the lengths is required");
-  ITTS_REQUIRE(h_lengths[0] == T && h_lengths[B - 1] >= 1, "T must be the longest length, all lengths >= 1");
-  for (int b = 1; b < B; ++b) ITTS_REQUIRE(h_lengths[b] <= h_lengths[b - 1], "rows must be sorted by decreasing length");
-  return ITTS_OK;
-}
-
-// number of rows still active at recurrence step s (lengths sorted decreasingly); `p` carries the
-// previous answer so that a whole sweep costs O(B + T)
-static inline int active_rows(const int* h_lengths, int B, int s, int* p) {
-  while (*p > 0 && h_lengths[*p - 1] <= s) --*p;
-  while (*p < B && h_lengths[*p] > s) ++*p;
-  return *p;
-}
-
+// d_state: [hs 2*ndir*B*H | cs 2*ndir*B*H | dgb 2*ndir*B*4H | re-tiled W_hh ndir*4H*H] floats
 extern "C" int64_t itts_lstm_state_bytes(int B, int H, int ndir) {
   if (B <= 0 || H <= 0 || ndir <= 0) return 0;
-  return (int64_t)2 * 2 * ndir * B * H * 4;  // hs + cs, two parities each
+  return ((int64_t)12 * ndir * B * H + (int64_t)ndir * 4 * H * H) * 4;
 }
 
 // Runs the recurrence of one (bi)directional LSTM layer over T steps (packed rows, see the top).
 extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0,
                                    const float* d_c0, const int* d_lengths, const int* h_lengths,
-                                   const int* d_row_off, int T, int B, int H, int ndir, float* d_y,
-                                   float* d_gates, float* d_csave, float* d_hprev, float* d_hn,
-                                   float* d_cn, void* d_state, void* stream) {
+                                   const int* d_row_off, const int* d_rev_row, int T, int B, int H,
+                                   int ndir, float* d_y, float* d_gates, float* d_csave,
+                                   float* d_hprev, float* d_hn, float* d_cn, void* d_state,
+                                   void* stream) {
   ITTS_REQUIRE(d_gin && d_whh && d_lengths && d_row_off && d_y && d_state, "null pointer");
+  ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
   ITTS_REQUIRE((d_gates == nullptr) == (d_csave == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
                "gates / csave / hprev must be given together (training) or all NULL (inference)");
-  int rc = lstm_check(h_lengths, T, B, H, ndir);
+  int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   LstmArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.gin = d_gin;
-  a.whh = d_whh; a.h0 = d_h0; a.c0 = d_c0; a.y = d_y; a.gates = d_gates; a.csave = d_csave; a.hprev = d_hprev;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row; a.gin = d_gin;
+  a.y = d_y; a.gates = d_gates; a.csave = d_csave; a.hprev = d_hprev;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   a.cs = a.hs + st;
+  float* wp = a.hs + 6 * st;
+  a.wp = wp;
   const int64_t n = (int64_t)ndir * B * H;
-  const dim3 eg((unsigned)std::min<int64_t>((n + 255) / 256, 1024));
-  hipLaunchKernelGGL(lstm_init_state_kernel, eg, dim3(256), 0, s, d_h0, d_c0, a.hs, a.cs, ndir, B, H);
+  hipLaunchKernelGGL(rnn_pack_w_fwd_kernel, rnn_ew_grid((int64_t)ndir * H * H), dim3(256), 0, s, d_whh, wp, ndir, 4, H);
+  hipLaunchKernelGGL(rnn_init_state_kernel, rnn_ew_grid(n), dim3(256), 0, s, d_h0, a.hs, ndir, B, H);
+  hipLaunchKernelGGL(rnn_init_state_kernel, rnn_ew_grid(n), dim3(256), 0, s, d_c0, a.cs, ndir, B, H);
   ITTS_LAUNCH_CHECK();
   a.ksplit = (H % 64 == 0) ? 4 : ((H % 32 == 0) ? 2 : 1);
   a.kiter = H / (16 * a.ksplit);
+  const dim3 grid(H / FW_UNITS, ndir);
   int p = B;
   for (int step = 0; step < T; ++step) {
     a.step = step;
-    const int nact = active_rows(h_lengths, B, step, &p);
-    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((H / FW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0, s, a);
+    a.nact = rnn_active_rows(h_lengths, B, step, &p);
+    switch (std::min((a.nact + 15) / 16, 4)) {
+      case 1: hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(lstm_step_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(lstm_step_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
   }
   ITTS_LAUNCH_CHECK();
-  if (d_hn) hipLaunchKernelGGL(rnn_final_state_kernel, eg, dim3(256), 0, s, a.hs, d_lengths, d_hn, ndir, B, H);
-  if (d_cn) hipLaunchKernelGGL(rnn_final_state_kernel, eg, dim3(256), 0, s, a.cs, d_lengths, d_cn, ndir, B, H);
+  if (d_hn) hipLaunchKernelGGL(rnn_final_state_kernel, rnn_ew_grid(n), dim3(256), 0, s, a.hs, d_lengths, d_hn, ndir, B, H);
+  if (d_cn) hipLaunchKernelGGL(rnn_final_state_kernel, rnn_ew_grid(n), dim3(256), 0, s, a.cs, d_lengths, d_cn, ndir, B, H);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
 
 // Backward recurrence: fills d_dg [N, ndir*4H] from d_dy and the saved forward tensors.
-// d_whh_t is W_hh transposed per direction ([ndir][H][4H]).
-extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_c0,
-                                   const float* d_gates, const float* d_csave, const int* d_lengths,
-                                   const int* h_lengths, const int* d_row_off, int T, int B, int H,
+extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const float* d_c0,
+                                   const float* d_gates, const float* d_csave, const int* h_lengths,
+                                   const int* d_row_off, const int* d_rev_row, int T, int B, int H,
                                    int ndir, float* d_dg, void* d_state, void* stream) {
-  ITTS_REQUIRE(d_dy && d_whh_t && d_gates && d_csave && d_lengths && d_row_off && d_dg && d_state, "null pointer");
-  int rc = lstm_check(h_lengths, T, B, H, ndir);
+  ITTS_REQUIRE(d_dy && d_whh && d_gates && d_csave && d_row_off && d_dg && d_state, "null pointer");
+  ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
+  int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   LstmArgs a{};
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.lengths = d_lengths; a.row_off = d_row_off; a.whh_t = d_whh_t;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row;
   a.c0 = d_c0; a.gates = const_cast<float*>(d_gates); a.csave = const_cast<float*>(d_csave); a.dy = d_dy;
   a.dg = d_dg;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   a.cs = a.hs + st;
+  a.dgb = a.hs + 2 * st;
+  float* wp = a.hs + 6 * st;
+  a.wp = wp;
+  hipLaunchKernelGGL(rnn_pack_w_bwd_kernel, rnn_ew_grid((int64_t)ndir * H * H), dim3(256), 0, s, d_whh, wp, ndir, 4, H);
+  ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(hipMemsetAsync(a.cs, 0, st * 4, s));   // running dc of rows that are not active yet
-  int p = 0;
+  a.ksplit = (H % 64 == 0) ? 16 : ((H % 32 == 0) ? 8 : 4);   // waves per workgroup
+  a.kiter = H / (4 * a.ksplit);
+  int p = 0, nact_next = 0;
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
-    const int nact = active_rows(h_lengths, B, step, &p);
-    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((H / BW_UNITS) * ((nact + 15) / 16), ndir), dim3(256), 0, s, a);
+    a.nact = rnn_active_rows(h_lengths, B, step, &p);
+    a.nact_next = nact_next;
+    nact_next = a.nact;
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((H / BW_UNITS) * ((a.nact + 15) / 16), ndir),
+                       dim3(64 * a.ksplit), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;

@@ -69,6 +69,10 @@ class PackedBatch(object):
         self.h_lengths = torch.from_numpy(sorted_len.astype(np.int32))            # host, sorted
         self.d_lengths = self.h_lengths.to(device)
         self.d_row_off = torch.from_numpy(row_off.astype(np.int32)).to(device)
+        # packed row the reverse direction visits at step s for sorted row b (0 where inactive)
+        t_rev = np.maximum(sorted_len[None, :] - 1 - np.arange(self.T)[:, None], 0)  # [T, B]
+        rev = row_off[t_rev] + np.arange(self.B)[None, :]
+        self.d_rev_row = torch.from_numpy(np.ascontiguousarray(rev, dtype=np.int32)).to(device)
         self.flat_index = torch.from_numpy(flat.astype(np.int64)).to(device)
         self.perm = torch.from_numpy(perm.astype(np.int64)).to(device)
         self.inv_perm = torch.from_numpy(np.argsort(perm).astype(np.int64)).to(device)
@@ -113,7 +117,8 @@ class LSTMLayerFunction(torch.autograd.Function):
         c0c = c0.contiguous() if c0 is not None else None
         _lib.check(L.itts_lstm_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(h0c), _iptr(c0c),
                                          _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
-                                         T, B, H, ndir, _iptr(y), _iptr(gates), _iptr(csave),
+                                         _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y),
+                                         _iptr(gates), _iptr(csave),
                                          _iptr(hprev), _iptr(hn), _iptr(cn), _iptr(state),
                                          ops._stream()), "itts_lstm_layer_fwd")
         if keep:
@@ -134,10 +139,9 @@ class LSTMLayerFunction(torch.autograd.Function):
         dy2 = dy.contiguous()
         dg = torch.empty((pb.N, ndir * G4), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_lstm_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
-        w_hh_t = w_hh.transpose(1, 2).contiguous()          # [ndir, H, 4H]
-        _lib.check(L.itts_lstm_layer_bwd(_iptr(dy2), _iptr(w_hh_t), _iptr(c0 if has_c0 else None),
-                                         _iptr(gates), _iptr(csave), _iptr(pb.d_lengths),
-                                         pb._hptr(), _iptr(pb.d_row_off), pb.T, pb.B, H, ndir,
+        _lib.check(L.itts_lstm_layer_bwd(_iptr(dy2), _iptr(w_hh), _iptr(c0 if has_c0 else None),
+                                         _iptr(gates), _iptr(csave), pb._hptr(),
+                                         _iptr(pb.d_row_off), _iptr(pb.d_rev_row), pb.T, pb.B, H, ndir,
                                          _iptr(dg), _iptr(state), ops._stream()),
                    "itts_lstm_layer_bwd")
         dw_ih, db = ops.linear_bwd_weight(dg, x2)                      # [ndir*4H, F], [ndir*4H]
@@ -177,7 +181,8 @@ class GRULayerFunction(torch.autograd.Function):
         h0c = h0.contiguous() if h0 is not None else None
         _lib.check(L.itts_gru_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(b_hh_c), _iptr(h0c),
                                         _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
-                                        T, B, H, ndir, _iptr(y), _iptr(gates), _iptr(hnpre),
+                                        _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y), _iptr(gates),
+                                        _iptr(hnpre),
                                         _iptr(hprev), _iptr(hn), _iptr(state), ops._stream()),
                    "itts_gru_layer_fwd")
         if keep:
@@ -198,10 +203,9 @@ class GRULayerFunction(torch.autograd.Function):
         dgi = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
         dgh = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_gru_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
-        w_hh_t = w_hh.transpose(1, 2).contiguous()          # [ndir, H, 3H]
-        _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh_t), _iptr(gates), _iptr(hnpre),
-                                        _iptr(hprev), _iptr(pb.d_lengths), pb._hptr(),
-                                        _iptr(pb.d_row_off), pb.T, pb.B, H, ndir, _iptr(dgi),
+        _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh), _iptr(gates), _iptr(hnpre),
+                                        _iptr(hprev), pb._hptr(), _iptr(pb.d_row_off),
+                                        _iptr(pb.d_rev_row), pb.T, pb.B, H, ndir, _iptr(dgi),
                                         _iptr(dgh), _iptr(state), ops._stream()),
                    "itts_gru_layer_bwd")
         dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]

@@ -203,22 +203,25 @@ int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* 
  *   d_h0/c0  [ndir][H] or NULL (zeros)
  *   d_lengths [B] int32 on the device, h_lengths the same values on the host (sorted decreasingly;
  *            the host copy sizes the per-step launches), d_row_off [T] int32 on the device;
- *            the reverse direction starts at each sequence's own last frame
+ *   d_rev_row [T*B] int32 on the device (needed when ndir == 2): the reverse direction starts at
+ *            each sequence's own last frame, at step s it visits packed row
+ *            d_rev_row[s*B + b] = d_row_off[len_b - 1 - s] + b (entries with s >= len_b unused)
  *   d_y      [N, ndir*H]
  *   d_gates / d_csave / d_hprev: tensors saved for the backward pass (all NULL for inference)
  *   d_hn/d_cn [ndir][B][H]   final states in sorted row order (may be NULL);
  *   d_state >= itts_lstm_state_bytes bytes */
 int64_t itts_lstm_state_bytes(int B, int H, int ndir);
 int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0, const float* d_c0,
-                        const int* d_lengths, const int* h_lengths, const int* d_row_off, int T,
-                        int B, int H, int ndir, float* d_y, float* d_gates, float* d_csave,
-                        float* d_hprev, float* d_hn, float* d_cn, void* d_state, void* stream);
-/* d_dg [N, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [N, ndir*H]; d_whh_t is W_hh
- * transposed per direction ([ndir][H][4H]).  dW_ih, dW_hh, db and dX follow from d_dg with
- * itts_linear_bwd_weight / itts_linear_bwd_input. */
-int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_c0,
-                        const float* d_gates, const float* d_csave, const int* d_lengths,
-                        const int* h_lengths, const int* d_row_off, int T, int B, int H, int ndir,
+                        const int* d_lengths, const int* h_lengths, const int* d_row_off,
+                        const int* d_rev_row, int T, int B, int H, int ndir, float* d_y,
+                        float* d_gates, float* d_csave, float* d_hprev, float* d_hn, float* d_cn,
+                        void* d_state, void* stream);
+/* d_dg [N, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [N, ndir*H]; d_whh as in the
+ * forward call.  dW_ih, dW_hh, db and dX follow from d_dg with itts_linear_bwd_weight /
+ * itts_linear_bwd_input. */
+int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const float* d_c0,
+                        const float* d_gates, const float* d_csave, const int* h_lengths,
+                        const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
                         float* d_dg, void* d_state, void* stream);
 
 /* ---- (Bi)GRU recurrence (torch.nn.GRU behind rnn_dyn/RNNWrapper.py:45-107 for `..GRU..` groups;
@@ -229,17 +232,16 @@ int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_
  * [N, ndir*H]; pass all three NULL for inference.  d_hn [ndir][B][H] may be NULL.
  * d_state >= itts_gru_state_bytes(B, H, ndir).
  * Backward fills d_dgi (gradient wrt d_gin: feeds dX, dW_ih, db_ih) and d_dgh (gradient wrt the
- * hidden projections: feeds dW_hh with d_hprev, db_hh), both [N, ndir*3H].
- * d_whh_t is W_hh transposed per direction ([ndir][H][3H]). */
+ * hidden projections: feeds dW_hh with d_hprev, db_hh), both [N, ndir*3H]. */
 int64_t itts_gru_state_bytes(int B, int H, int ndir);
 int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
                        const float* d_h0, const int* d_lengths, const int* h_lengths,
-                       const int* d_row_off, int T, int B, int H, int ndir, float* d_y,
-                       float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn, void* d_state,
-                       void* stream);
-int itts_gru_layer_bwd(const float* d_dy, const float* d_whh_t, const float* d_gates,
-                       const float* d_hnpre, const float* d_hprev, const int* d_lengths,
-                       const int* h_lengths, const int* d_row_off, int T, int B, int H, int ndir,
+                       const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
+                       float* d_y, float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn,
+                       void* d_state, void* stream);
+int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const float* d_gates,
+                       const float* d_hnpre, const float* d_hprev, const int* h_lengths,
+                       const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
                        float* d_dgi, float* d_dgh, void* d_state, void* stream);
 
 #ifdef __cplusplus
