@@ -29,9 +29,9 @@ struct GruArgs {
   float* hs;              // [2 parity][ndir] K-blocked running hidden state (fwd) / dh*z carry (bwd)
   float* dgb;             // [2 parity][ndir] K-blocked dGh of the step just processed (backward)
   float* y;               // [N, ndir*H]
-  float* gates;           // [N, ndir*3H] r, z, n after activation (saved for backward)
-  float* hnpre;           // [N, ndir*H]  W_hn h + b_hn
-  float* hprev;           // [N, ndir*H]  h_{t-1} that entered step t
+  float* gates;           // [N, ndir, H, 4] (r, z, n, W_hn h + b_hn) of every unit, saved for backward:
+                          //       one 16-byte store / load per (frame, unit)
+  const float* hprev;     // [N, ndir*H]  h_{t-1} that entered step t (backward input)
   const float* dy;        // [N, ndir*H]
   float* dgi;             // [N, ndir*3H] gradient wrt gin  (da_r, da_z, da_n)
   float* dgh;             // [N, ndir*3H] gradient wrt the hidden projections (da_r, da_z, da_n*r)
@@ -139,12 +139,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruArgs a) {
         hn = (1.f - zg) * ng + zg * hp_v;
         const size_t oh = r * (size_t)(a.ndir * H) + (size_t)dir * H + j;
         a.y[oh] = hn;
-        if (a.gates) {
-          float* gs = a.gates + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
-          gs[0] = rg; gs[H] = zg; gs[2 * H] = ng;
-          a.hnpre[oh] = hnp;
-          a.hprev[oh] = hp_v;
-        }
+        if (a.gates) reinterpret_cast<float4*>(a.gates)[(r * a.ndir + dir) * H + j] = make_float4(rg, zg, ng, hnp);
       }
       hnext[sidx] = hn;
     }
@@ -206,10 +201,9 @@ __global__ __launch_bounds__(768) void gru_step_bwd_kernel(GruArgs a) {
     }
     if (c == 0 && act) {
       r = gru_row_at(a, dir, a.step, b);
-      const float* gs = a.gates + r * ldg + (size_t)dir * G3 + j;
-      rg = gs[0]; zg = gs[H]; ng = gs[2 * H];
+      const float4 gs = reinterpret_cast<const float4*>(a.gates)[(r * a.ndir + dir) * H + j];
+      rg = gs.x; zg = gs.y; ng = gs.z; hnp = gs.w;
       const size_t oh = r * ldh + (size_t)dir * H + j;
-      hnp = a.hnpre[oh];
       hpv = a.hprev[oh];
       dyv = a.dy[oh];
       cin = carry_in[(size_t)b * H + j];
@@ -265,18 +259,16 @@ extern "C" int64_t itts_gru_state_bytes(int B, int H, int ndir) {
 extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
                                   const float* d_h0, const int* d_lengths, const int* h_lengths,
                                   const int* d_row_off, const int* d_rev_row, int T, int B, int H,
-                                  int ndir, float* d_y, float* d_gates, float* d_hnpre,
-                                  float* d_hprev, float* d_hn, void* d_state, void* stream) {
+                                  int ndir, float* d_y, float* d_gates, float* d_hn, void* d_state,
+                                  void* stream) {
   ITTS_REQUIRE(d_gin && d_whh && d_bhh && d_lengths && d_row_off && d_y && d_state, "null pointer");
   ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
-  ITTS_REQUIRE((d_gates == nullptr) == (d_hnpre == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
-               "gates / hnpre / hprev must be given together (training) or all NULL (inference)");
   int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   GruArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row; a.gin = d_gin;
-  a.bhh = d_bhh; a.y = d_y; a.gates = d_gates; a.hnpre = d_hnpre; a.hprev = d_hprev;
+  a.bhh = d_bhh; a.y = d_y; a.gates = d_gates;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   float* wp = a.hs + 4 * st;
@@ -308,19 +300,17 @@ extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const 
 }
 
 extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const float* d_gates,
-                                  const float* d_hnpre, const float* d_hprev, const int* h_lengths,
+                                  const float* d_hprev, const int* h_lengths,
                                   const int* d_row_off, const int* d_rev_row, int T, int B, int H,
                                   int ndir, float* d_dgi, float* d_dgh, void* d_state, void* stream) {
-  ITTS_REQUIRE(d_dy && d_whh && d_gates && d_hnpre && d_hprev && d_row_off && d_dgi && d_dgh && d_state,
-               "null pointer");
+  ITTS_REQUIRE(d_dy && d_whh && d_gates && d_hprev && d_row_off && d_dgi && d_dgh && d_state, "null pointer");
   ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
   int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   GruArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row;
-  a.gates = const_cast<float*>(d_gates); a.hnpre = const_cast<float*>(d_hnpre);
-  a.hprev = const_cast<float*>(d_hprev); a.dy = d_dy; a.dgi = d_dgi; a.dgh = d_dgh;
+  a.gates = const_cast<float*>(d_gates); a.hprev = d_hprev; a.dy = d_dy; a.dgi = d_dgi; a.dgh = d_dgh;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   a.dgb = a.hs + st;

@@ -47,9 +47,9 @@ struct LstmArgs {
   float* cs;              // [2 parity][ndir] K-blocked running cell state / running dc (backward)
   float* dgb;             // [2 parity][ndir] K-blocked dG of the step just processed (backward)
   float* y;               // [N, ndir*H] layer output
-  float* gates;           // [N, ndir*4H] post-activation gates i,f,g,o (saved for backward)
+  float* gates;           // [N, ndir, H, 4] post-activation gates (i, f, g, o) of every unit, saved
+                          //       for backward: one 16-byte store / load per (frame, unit)
   float* csave;           // [N, ndir*H] c_t
-  float* hprev;           // [N, ndir*H] h_{t-1} that entered step t (for dW_hh)
   // backward
   const float* dy;        // [N, ndir*H]
   float* dg;              // [N, ndir*4H] gradient wrt pre-activation gates
@@ -162,10 +162,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
         hn = og * tanhf(cn);
         a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
         if (a.gates) {
-          float* gs = a.gates + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
-          gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+          reinterpret_cast<float4*>(a.gates)[(r * a.ndir + dir) * H + j] = make_float4(ig, fg, gg, og);
           a.csave[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = cn;
-          a.hprev[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hp_v;
         }
       }
       hnext[sidx] = hn;
@@ -231,8 +229,8 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
     }
     if (c == 0 && act) {
       r = row_at(a, dir, a.step, b);
-      const float* gs = a.gates + r * ldg + (size_t)dir * G4 + j;
-      ig = gs[0]; fg = gs[H]; gg = gs[2 * H]; og = gs[3 * H];
+      const float4 gs = reinterpret_cast<const float4*>(a.gates)[(r * a.ndir + dir) * H + j];
+      ig = gs.x; fg = gs.y; gg = gs.z; og = gs.w;
       ct = a.csave[r * ldh + (size_t)dir * H + j];
       cp = a.step > 0 ? a.csave[row_at(a, dir, a.step - 1, b) * ldh + (size_t)dir * H + j]
                       : (a.c0 ? a.c0[dir * H + j] : 0.f);
@@ -290,18 +288,17 @@ extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const
                                    const float* d_c0, const int* d_lengths, const int* h_lengths,
                                    const int* d_row_off, const int* d_rev_row, int T, int B, int H,
                                    int ndir, float* d_y, float* d_gates, float* d_csave,
-                                   float* d_hprev, float* d_hn, float* d_cn, void* d_state,
-                                   void* stream) {
+                                   float* d_hn, float* d_cn, void* d_state, void* stream) {
   ITTS_REQUIRE(d_gin && d_whh && d_lengths && d_row_off && d_y && d_state, "null pointer");
   ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
-  ITTS_REQUIRE((d_gates == nullptr) == (d_csave == nullptr) && (d_gates == nullptr) == (d_hprev == nullptr),
-               "gates / csave / hprev must be given together (training) or all NULL (inference)");
+  ITTS_REQUIRE((d_gates == nullptr) == (d_csave == nullptr),
+               "gates / csave must be given together (training) or both NULL (inference)");
   int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   LstmArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row; a.gin = d_gin;
-  a.y = d_y; a.gates = d_gates; a.csave = d_csave; a.hprev = d_hprev;
+  a.y = d_y; a.gates = d_gates; a.csave = d_csave;
   const size_t st = (size_t)2 * ndir * B * H;
   a.hs = reinterpret_cast<float*>(d_state);
   a.cs = a.hs + st;

@@ -61,13 +61,13 @@ _SIGNATURES = {
                                       c_double, c_int, c_double, _P, _P, _P]),
     "itts_lstm_state_bytes": (c_int64, [c_int, c_int, c_int]),
     "itts_lstm_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
-                                    _P, _P, _P, _P, _P, _P, _P]),
+                                    _P, _P, _P, _P, _P, _P]),
     "itts_lstm_layer_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
                                     _P, _P]),
     "itts_gru_state_bytes": (c_int64, [c_int, c_int, c_int]),
     "itts_gru_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
-                                   _P, _P, _P, _P, _P, _P]),
-    "itts_gru_layer_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
+                                   _P, _P, _P, _P]),
+    "itts_gru_layer_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
                                    _P, _P, _P]),
     "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_float, _P]),

@@ -74,6 +74,12 @@ class PackedBatch(object):
         rev = row_off[t_rev] + np.arange(self.B)[None, :]
         self.d_rev_row = torch.from_numpy(np.ascontiguousarray(rev, dtype=np.int32)).to(device)
         self.flat_index = torch.from_numpy(flat.astype(np.int64)).to(device)
+        # packed row of the previous frame of the same sequence in each direction's visiting order
+        # (forward: t - 1, reverse: t + 1); first frames point at row N, where shift() puts h0
+        prev_f = np.where(t_of > 0, row_off[np.maximum(t_of - 1, 0)] + b_of, self.N)
+        nxt = np.minimum(t_of + 1, self.T - 1)
+        prev_r = np.where(t_of + 1 < sorted_len[b_of], row_off[nxt] + b_of, self.N)
+        self.prev_row = [torch.from_numpy(p_.astype(np.int64)).to(device) for p_ in (prev_f, prev_r)]
         self.perm = torch.from_numpy(perm.astype(np.int64)).to(device)
         self.inv_perm = torch.from_numpy(np.argsort(perm).astype(np.int64)).to(device)
 
@@ -86,6 +92,16 @@ class PackedBatch(object):
         out = packed.new_zeros((padded_shape[0] * padded_shape[1], packed.shape[-1]))
         return out.index_copy(0, self.flat_index, packed).reshape(
             padded_shape[0], padded_shape[1], packed.shape[-1])
+
+    def shift(self, y, h0, ndir, H):
+        """h_{t-1} of every packed frame: the layer output [N, ndir*H] moved by one frame along each
+        sequence (per direction), the initial state h0 [ndir, H] (or zeros) at the first frame."""
+        out = torch.empty_like(y)
+        for d in range(ndir):
+            first = h0[d:d + 1] if h0 is not None else y.new_zeros((1, H))
+            src = torch.cat((y[:, d * H:(d + 1) * H], first), dim=0)
+            out[:, d * H:(d + 1) * H] = src.index_select(0, self.prev_row[d])
+        return out
 
     def _hptr(self):
         return ctypes.c_void_p(self.h_lengths.data_ptr())
@@ -108,7 +124,6 @@ class LSTMLayerFunction(torch.autograd.Function):
         keep = bool(training)
         gates = torch.empty((N, ndir * G4), dtype=torch.float32, device=dev) if keep else None
         csave = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
-        hprev = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
         hn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         cn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_lstm_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
@@ -118,22 +133,24 @@ class LSTMLayerFunction(torch.autograd.Function):
         _lib.check(L.itts_lstm_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(h0c), _iptr(c0c),
                                          _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
                                          _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y),
-                                         _iptr(gates), _iptr(csave),
-                                         _iptr(hprev), _iptr(hn), _iptr(cn), _iptr(state),
-                                         ops._stream()), "itts_lstm_layer_fwd")
+                                         _iptr(gates), _iptr(csave), _iptr(hn), _iptr(cn),
+                                         _iptr(state), ops._stream()), "itts_lstm_layer_fwd")
         if keep:
-            ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, csave, hprev,
-                                  c0c if c0c is not None else torch.empty(0, device=dev))
+            empty = torch.empty(0, device=dev)
+            ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, csave, y,
+                                  h0c if h0c is not None else empty,
+                                  c0c if c0c is not None else empty)
             ctx.pb = pb
-            ctx.dims = (F, H, ndir, c0c is not None)
+            ctx.dims = (F, H, ndir, h0c is not None, c0c is not None)
         return y, hn, cn
 
     @staticmethod
     def backward(ctx, dy, dhn, dcn):
         L = _lib.load()
-        x2, w_ih_cat, w_hh, gates, csave, hprev, c0 = ctx.saved_tensors
+        x2, w_ih_cat, w_hh, gates, csave, y, h0, c0 = ctx.saved_tensors
         pb = ctx.pb
-        F, H, ndir, has_c0 = ctx.dims
+        F, H, ndir, has_h0, has_c0 = ctx.dims
+        hprev = pb.shift(y, h0 if has_h0 else None, ndir, H)
         G4 = 4 * H
         dev = dy.device
         dy2 = dy.contiguous()
@@ -172,9 +189,7 @@ class GRULayerFunction(torch.autograd.Function):
         dev = x2.device
         y = torch.empty((N, ndir * H), dtype=torch.float32, device=dev)
         keep = bool(training)
-        gates = torch.empty((N, ndir * G3), dtype=torch.float32, device=dev) if keep else None
-        hnpre = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
-        hprev = torch.empty((N, ndir * H), dtype=torch.float32, device=dev) if keep else None
+        gates = torch.empty((N, ndir * H * 4), dtype=torch.float32, device=dev) if keep else None
         hn = torch.empty((ndir, B, H), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_gru_state_bytes(B, H, ndir), dtype=torch.uint8, device=dev)
         w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
@@ -182,28 +197,29 @@ class GRULayerFunction(torch.autograd.Function):
         _lib.check(L.itts_gru_layer_fwd(_iptr(gin), _iptr(w_hh_c), _iptr(b_hh_c), _iptr(h0c),
                                         _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
                                         _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y), _iptr(gates),
-                                        _iptr(hnpre),
-                                        _iptr(hprev), _iptr(hn), _iptr(state), ops._stream()),
+                                        _iptr(hn), _iptr(state), ops._stream()),
                    "itts_gru_layer_fwd")
         if keep:
-            ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, hnpre, hprev)
+            ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, y,
+                                  h0c if h0c is not None else torch.empty(0, device=dev))
             ctx.pb = pb
-            ctx.dims = (F, H, ndir)
+            ctx.dims = (F, H, ndir, h0c is not None)
         return y, hn
 
     @staticmethod
     def backward(ctx, dy, dhn):
         L = _lib.load()
-        x2, w_ih_cat, w_hh, gates, hnpre, hprev = ctx.saved_tensors
+        x2, w_ih_cat, w_hh, gates, y, h0 = ctx.saved_tensors
         pb = ctx.pb
-        F, H, ndir = ctx.dims
+        F, H, ndir, has_h0 = ctx.dims
+        hprev = pb.shift(y, h0 if has_h0 else None, ndir, H)
         G3 = 3 * H
         dev = dy.device
         dy2 = dy.contiguous()
         dgi = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
         dgh = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_gru_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
-        _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh), _iptr(gates), _iptr(hnpre),
+        _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh), _iptr(gates),
                                         _iptr(hprev), pb._hptr(), _iptr(pb.d_row_off),
                                         _iptr(pb.d_rev_row), pb.T, pb.B, H, ndir, _iptr(dgi),
                                         _iptr(dgh), _iptr(state), ops._stream()),

@@ -207,15 +207,17 @@ int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* 
  *            each sequence's own last frame, at step s it visits packed row
  *            d_rev_row[s*B + b] = d_row_off[len_b - 1 - s] + b (entries with s >= len_b unused)
  *   d_y      [N, ndir*H]
- *   d_gates / d_csave / d_hprev: tensors saved for the backward pass (all NULL for inference)
+ *   d_gates [N, ndir, H, 4] (i, f, g, o after activation, gate-minor) and d_csave [N, ndir*H] (c_t):
+ *            saved for the backward pass, both NULL for inference.  h_{t-1}, which dW_hh needs next
+ *            to d_dg, is d_y shifted by one frame along each sequence (h0 at the first frame).
  *   d_hn/d_cn [ndir][B][H]   final states in sorted row order (may be NULL);
  *   d_state >= itts_lstm_state_bytes bytes */
 int64_t itts_lstm_state_bytes(int B, int H, int ndir);
 int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h0, const float* d_c0,
                         const int* d_lengths, const int* h_lengths, const int* d_row_off,
                         const int* d_rev_row, int T, int B, int H, int ndir, float* d_y,
-                        float* d_gates, float* d_csave, float* d_hprev, float* d_hn, float* d_cn,
-                        void* d_state, void* stream);
+                        float* d_gates, float* d_csave, float* d_hn, float* d_cn, void* d_state,
+                        void* stream);
 /* d_dg [N, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [N, ndir*H]; d_whh as in the
  * forward call.  dW_ih, dW_hh, db and dX follow from d_dg with itts_linear_bwd_weight /
  * itts_linear_bwd_input. */
@@ -228,19 +230,19 @@ int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const float* d_c0
  *      gate order r, z, n; packed rows, lengths and row offsets as for the LSTM entry points).
  * d_gin  [N, ndir*3H] = X W_ih^T + b_ih for all frames (one itts_linear_fwd call),
  * d_whh  [ndir][3H][H], d_bhh [ndir][3H] (b_hn sits inside r * (W_hn h + b_hn)), d_h0 [ndir][H] or
- * NULL.  Training saves d_gates [N, ndir*3H] (r, z, n after activation), d_hnpre and d_hprev
- * [N, ndir*H]; pass all three NULL for inference.  d_hn [ndir][B][H] may be NULL.
+ * NULL.  Training saves d_gates [N, ndir, H, 4] = (r, z, n after activation, W_hn h + b_hn) per
+ * unit; NULL for inference.  d_hn [ndir][B][H] may be NULL.
  * d_state >= itts_gru_state_bytes(B, H, ndir).
- * Backward fills d_dgi (gradient wrt d_gin: feeds dX, dW_ih, db_ih) and d_dgh (gradient wrt the
+ * Backward takes d_hprev [N, ndir*H] (h_{t-1} of every frame: d_y shifted by one frame along each
+ * sequence, h0 at the first frame) and fills d_dgi (gradient wrt d_gin: feeds dX, dW_ih, db_ih) and d_dgh (gradient wrt the
  * hidden projections: feeds dW_hh with d_hprev, db_hh), both [N, ndir*3H]. */
 int64_t itts_gru_state_bytes(int B, int H, int ndir);
 int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
                        const float* d_h0, const int* d_lengths, const int* h_lengths,
                        const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
-                       float* d_y, float* d_gates, float* d_hnpre, float* d_hprev, float* d_hn,
-                       void* d_state, void* stream);
+                       float* d_y, float* d_gates, float* d_hn, void* d_state, void* stream);
 int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const float* d_gates,
-                       const float* d_hnpre, const float* d_hprev, const int* h_lengths,
+                       const float* d_hprev, const int* h_lengths,
                        const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
                        float* d_dgi, float* d_dgh, void* d_state, void* stream);
 

@@ -26,7 +26,7 @@ def main():
         whh = torch.randn(ndir, G * H, H, device=dev) * 0.05
         bhh = torch.zeros(ndir, G * H, device=dev)
         y = torch.empty(N, ndir * H, device=dev)
-        gates = torch.empty(N, ndir * G * H, device=dev)
+        gates = torch.empty(N, ndir * 4 * H, device=dev)
         aux1 = torch.empty(N, ndir * H, device=dev)
         aux2 = torch.empty(N, ndir * H, device=dev)
         dy = torch.randn(N, ndir * H, device=dev)
@@ -36,19 +36,18 @@ def main():
         state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
         def fwd(train):
-            g, a1, a2 = (gates, aux1, aux2) if train else (None, None, None)
+            g, a1 = (gates, aux1) if train else (None, None)
             if cell == "lstm":
                 _lib.check(L.itts_lstm_layer_fwd(_iptr(gin), _iptr(whh), None, None,
                                                  _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
                                                  _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y), _iptr(g),
-                                                 _iptr(a1), _iptr(a2), None, None, _iptr(state),
+                                                 _iptr(a1), None, None, _iptr(state),
                                                  ops._stream()), "f")
             else:
                 _lib.check(L.itts_gru_layer_fwd(_iptr(gin), _iptr(whh), _iptr(bhh), None,
                                                 _iptr(pb.d_lengths), pb._hptr(), _iptr(pb.d_row_off),
                                                 _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y), _iptr(g),
-                                                _iptr(a1), _iptr(a2), None, _iptr(state),
-                                                ops._stream()), "f")
+                                                None, _iptr(state), ops._stream()), "f")
 
         def bwd():
             if cell == "lstm":
@@ -57,7 +56,7 @@ def main():
                                                  _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(dg),
                                                  _iptr(state), ops._stream()), "b")
             else:
-                _lib.check(L.itts_gru_layer_bwd(_iptr(dy), _iptr(whh), _iptr(gates), _iptr(aux1),
+                _lib.check(L.itts_gru_layer_bwd(_iptr(dy), _iptr(whh), _iptr(gates),
                                                 _iptr(aux2), pb._hptr(), _iptr(pb.d_row_off),
                                                 _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(dg),
                                                 _iptr(dg2), _iptr(state), ops._stream()), "b")
