@@ -176,10 +176,13 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     return res
 
 
-def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM"):
-    """BASELINE config 3: 425 -> 3 x 512 BiLSTM -> 187, batch 64 padded utterances, Adam, fp32,
-    through the drop-in module stack (RNNDyn + NamedLoss + fused HIP Adam)."""
+def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM", rank=0, world=1):
+    """BASELINE config 3: 425 -> 3 x 512 BiLSTM -> 187, batch 64 padded utterances per GPU, Adam,
+    fp32, through the drop-in module stack (RNNDyn + NamedLoss + fused HIP Adam).  With world > 1
+    every rank trains on its own 64 utterances and the handler sums the frame-weighted gradients
+    over RCCL (weak scaling); the reported rate is the whole job's."""
     import types
+    from idiaptts_amd import parallel
     from idiaptts_amd.bench_support import make_ff_batch
     from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
         ModularModelHandlerPyTorch as Handler
@@ -188,8 +191,8 @@ def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM"):
     from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import \
         NamedForwardWrapper
     torch.manual_seed(0)
-    hp = types.SimpleNamespace(model_type="RNNDYN-3_Bi{}_512-1_FC_187".format(cell), batch_first=False,
-                               dropout=0.0)
+    hp = types.SimpleNamespace(model_type="RNNDYN-3_Bi{}_512-1_FC_187".format(cell),
+                               batch_first=False, dropout=0.0)
     h = Handler()
     h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((425,), hp),
                                               input_names=["questions"], batch_first=False,
@@ -200,24 +203,35 @@ def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM"):
                                    seq_mask="acoustic_features_mask",
                                    input_names=["acoustic_features", "pred_acoustic_features"],
                                    batch_first=False)])
-    x, y, lengths = make_ff_batch(n_utts, seed=7)
+    x, y, lengths = make_ff_batch(n_utts, seed=7 + 100 * rank)
     offs = np.concatenate([[0], np.cumsum(lengths)])
     batch = [{"questions": x[offs[i]:offs[i + 1]], "acoustic_features": y[offs[i]:offs[i + 1]]}
              for i in range(n_utts)]
     data, lens = Handler.prepare_batch(batch, batch_first=False, mask_keys=("acoustic_features",))
     data = {k: v.to(dev) for k, v in data.items()}
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     h.process_batch(data, lens, 0, training=True)      # warm-up
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for s in range(steps):
         ld, _ = h.process_batch(data, lens, s + 1, training=True)
-    torch.cuda.synchronize()
+    barrier()
     dt = (time.perf_counter() - t0) / steps
-    frames = int(lengths.sum())
-    return {"bi" + cell.lower(): {"model": "425 -> 3x512 Bi{} -> 187".format(cell), "utterances": n_utts,
-                       "valid_frames": frames, "max_frames": int(lengths.max()),
-                       "ms_per_step": dt * 1e3, "valid_frames_per_s": frames / dt,
-                       "loss": ld["MSELoss_acoustic_features"]}}
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    frames = int(parallel.global_sum(int(lengths.sum()), device=dev))
+    return {"bi" + cell.lower(): {
+        "model": "425 -> 3x512 Bi{} -> 187".format(cell), "utterances_per_gpu": n_utts,
+        "n_gpus": world, "valid_frames": frames, "max_frames": int(lengths.max()),
+        "ms_per_step": dt * 1e3, "valid_frames_per_s": frames / dt,
+        "loss": ld["MSELoss_acoustic_features"]}}
 
 
 def main():
@@ -231,7 +245,7 @@ def main():
                     help="utterances in the WORLD feature-path section (0 = skip)")
     ap.add_argument("--world-fs", type=int, default=16000)
     ap.add_argument("--bilstm-utts", type=int, default=64,
-                    help="utterances of the BiLSTM (config 3) section (0 = skip)")
+                    help="utterances per GPU of the BiLSTM / BiGRU (config 3) section (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -295,6 +309,13 @@ def main():
     frames = sum(global_counts[i % n_batches] for i in range(args.steps))
     value = frames / dt
 
+    # config 3 (and its GRU variant): every rank takes part, rank 0 reports
+    rnn_extra = {}
+    if args.bilstm_utts > 0:
+        for cell in ("LSTM", "GRU"):
+            rnn_extra.update(bilstm_section(dev, args.bilstm_utts, cell=cell, rank=rank,
+                                            world=world))
+
     out = None
     if rank == 0:
         # dominant kernel roofline: the fp32-MFMA GEMM launches of one step, timed live with
@@ -344,8 +365,7 @@ def main():
             extra.update(world_section(dev, max(4, args.world_utts // 4), 48000, cpu_seconds=12.0,
                                        with_cpu=not args.no_cpu_baseline, with_mlpg=False,
                                        key="world_48k"))
-        if world == 1 and args.bilstm_utts > 0:
-            extra.update(bilstm_section(dev, args.bilstm_utts))
+        extra.update(rnn_extra)
         out = {
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

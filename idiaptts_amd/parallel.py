@@ -60,3 +60,29 @@ def allreduce_stats_(extractor, group=None, device=None):
     extractor.sum_frames = flat[1:1 + a.size].reshape(a.shape)
     setattr(extractor, second, flat[1 + a.size:].reshape(b.shape))
     return extractor
+
+
+def dp_rank_world(group=None):
+    """(rank, world size) of the data-parallel group, (0, 1) without torch.distributed."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def allreduce_module_grads_(params, local_weight, group=None):
+    """Gradient step of synchronous data parallelism for an autograd module whose loss is a mean
+    over the LOCAL valid frames: every rank scales its gradients by local_weight = n_local /
+    n_global, then one sum all-reduce of the flattened gradients (a single bucket: the acoustic
+    models here hold a few million parameters).  The result equals the gradient of the
+    single-process step on the concatenated batch."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    _, world = dp_rank_world(group)
+    if world == 1:
+        return
+    flat = torch._utils._flatten_dense_tensors(grads)
+    flat.mul_(float(local_weight))
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    for g, synced in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+        g.copy_(synced)

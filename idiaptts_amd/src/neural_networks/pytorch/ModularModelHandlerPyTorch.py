@@ -27,7 +27,7 @@ from torch.nn.utils.rnn import pad_sequence
 from torch.optim.lr_scheduler import ExponentialLR, LambdaLR, ReduceLROnPlateau
 from torch.utils.data import DataLoader
 
-from idiaptts_amd import ops
+from idiaptts_amd import ops, parallel
 from idiaptts_amd.src.neural_networks.pytorch import config_json
 
 
@@ -153,17 +153,20 @@ class ModularModelHandlerPyTorch(object):
         return pad_sequence(sequence, batch_first)
 
     @staticmethod
-    def prepare_batch(batch, common_divisor=1, batch_first=False, mask_keys=()):
+    def prepare_batch(batch, common_divisor=1, batch_first=False, mask_keys=(), shard=None):
         """Collate function (reference :388-465).  `batch` holds the dataset's
         ({name: array [T_i, D]}, dataset) items (bare dicts are accepted too).  The remainder that
         is not divisible by `common_divisor` (# GPUs) is dropped first (:392-395); every key whose
         data reader sets `requires_seq_mask` (or that is listed in `mask_keys`) also gets
         `<key>_mask`; keys without a reader or with ragged non-array content stay lists.
+        `shard=(rank, world)` keeps this rank's samples of the (identically drawn) global batch.
         Returns (data, temporal lengths)."""
         assert len(batch) >= common_divisor
         remainder = len(batch) % common_divisor
         if remainder > 0:
             batch = batch[:-remainder]
+        if shard is not None:            # data parallel: rank r of w keeps samples r, r + w, ...
+            batch = batch[shard[0]::shard[1]]
         dataset = None
         if isinstance(batch[0], (tuple, list)):
             dataset = batch[0][1]
@@ -225,10 +228,17 @@ class ModularModelHandlerPyTorch(object):
     def _get_dataloader(self, batch_size, dataset, batch_first=True, collate_fn=None,
                         common_divisor=1, num_workers=1, pin_memory=True, shuffle=False):
         collate_fn = self.prepare_batch if collate_fn is None else collate_fn
+        rank, world = parallel.dp_rank_world()
+        extra = {}
+        if world > 1:
+            # One process per GPU: every rank draws the same global batches (same seed, same
+            # sampler) and keeps its own samples; common_divisor makes the split even.
+            common_divisor = max(common_divisor, world)
+            extra["shard"] = (rank, world)
         return DataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle,
                           num_workers=num_workers,
                           collate_fn=partial(collate_fn, common_divisor=common_divisor,
-                                             batch_first=batch_first),
+                                             batch_first=batch_first, **extra),
                           pin_memory=pin_memory and torch.cuda.is_available())
 
     # -------------------------------------------------------------------------------- model
@@ -393,8 +403,10 @@ class ModularModelHandlerPyTorch(object):
         """One pass over the loader (reference :683-882): per mini-batch forward, named losses,
         NaN / Inf checks, and when training backward, optional clipping, optimiser, EMA and
         scheduler; returns {loss name: mean over the mini-batches} as numpy scalars.
-        hparams.num_gpus > 1 is served by one process per GPU (idiaptts_amd.parallel), not by
-        replicating the module inside one process as the reference's DataParallel does."""
+        Multi-GPU: one process per GPU under torch.distributed (idiaptts_amd.parallel) instead of
+        the reference's in-process DataParallel -- every rank draws the same global batch, keeps
+        its own samples, and the frame-count-weighted gradients are summed over RCCL, which
+        reproduces the single-GPU step on the whole batch."""
         model = self.model
         if training:
             model.train()
@@ -432,10 +444,13 @@ class ModularModelHandlerPyTorch(object):
             else:
                 scheduler_loss = self.get_summed_losses_subset(
                     hparams.scheduler_loss_names, losses).detach()
+            dp_weight = self._dp_weight(lengths, device)
             if training:
                 self.optimiser.zero_grad()
                 backprop_loss.backward(retain_graph=hparams.backward_retain_graph)
                 total_steps += 1
+                if dp_weight is not None:
+                    parallel.allreduce_module_grads_(list(self.model.parameters()), dp_weight)
                 if hparams.replace_inf_grads_by_zero:
                     self._replace_inf_grads_by_zero()
                 if hparams.grad_clip_norm_type is not None:
@@ -459,6 +474,8 @@ class ModularModelHandlerPyTorch(object):
                     " ".join("{}: {:.3f}".format(k, float(l.detach())) for k, l in losses.items())))
             for key, loss in losses.items():
                 loss = loss.detach()
+                if dp_weight is not None:        # loss of the global batch
+                    loss = parallel.allreduce_flat_(loss * dp_weight)
                 total_losses[key] = loss if key not in total_losses else total_losses[key] + loss
         total_losses = {k: v / len(dataloader) for k, v in total_losses.items()}
         if not training:
@@ -469,6 +486,17 @@ class ModularModelHandlerPyTorch(object):
             if callable(fn_log_per_test):
                 fn_log_per_test()
         return {k: l.cpu().numpy() for k, l in total_losses.items()}
+
+    def _dp_weight(self, lengths, device):
+        """n_local / n_global valid frames of this step under data parallelism (None on a single
+        process): the losses are means over the local frames (NamedLoss 'mean_per_frame'), so this
+        weight turns the local loss and gradients into this rank's share of the global mean."""
+        if parallel.dp_rank_world()[1] == 1:
+            return None
+        key = next((l.seq_mask for l in self.losses if getattr(l, "seq_mask", None) in lengths),
+                   next(iter(lengths)))
+        n_local = float(sum(lengths[key]))
+        return n_local / parallel.global_sum(n_local, device=device)
 
     def _replace_inf_grads_by_zero(self):
         for p in self.model.parameters():
@@ -491,14 +519,20 @@ class ModularModelHandlerPyTorch(object):
             total = sum(loss_dict.values())
             if torch.isnan(total):
                 raise ValueError("Found NaN in loss.")       # reference :778-781
+            dp_weight = self._dp_weight(lengths, device)
             if training:
                 self.optimiser.zero_grad()
                 total.backward()
+                if dp_weight is not None:
+                    parallel.allreduce_module_grads_(list(self.model.parameters()), dp_weight)
                 if grad_clip_norm is not None:
                     torch.nn.utils.clip_grad_norm_(self.model.parameters(), grad_clip_norm)
                 self.optimiser.step()
                 if self.ema:
                     self.ema.update_params(self.model)
+        if dp_weight is not None:
+            loss_dict = {k: parallel.allreduce_flat_(v.detach() * dp_weight)
+                         for k, v in loss_dict.items()}
         return {k: float(v.detach()) for k, v in loss_dict.items()}, data
 
     # ----------------------------------------------------------------------------- inference

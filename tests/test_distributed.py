@@ -112,3 +112,75 @@ def test_shard_by_length_is_balanced_and_complete():
         loads = [sum(int(lengths[i]) for i in s) for s in shards]
         assert max(loads) - min(loads) <= int(lengths.max())
     assert parallel.shard_by_length([5, 5], 4) == [[0], [1], [], []]
+
+
+def _handler_dp_worker(rank, world, port, ret):
+    """The module-stack handler's DP step on CPU stand-ins: prepare_batch(shard=...) picks this
+    rank's samples of the global batch, the loss is a mean over the LOCAL frames, _dp_weight and
+    allreduce_module_grads_ turn local gradients into the global-batch gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    batch, model = _dp_case()
+    data, lengths = Handler.prepare_batch(batch, common_divisor=world, batch_first=False,
+                                          mask_keys=("y",), shard=(rank, world))
+    h = Handler()
+    h.model = model
+    h.losses = [type("L", (), {"seq_mask": "y_mask"})()]
+    w = h._dp_weight(lengths, torch.device("cpu"))
+    loss = _masked_mean_loss(model, data, lengths)
+    loss.backward()
+    parallel.allreduce_module_grads_(list(model.parameters()), w)
+    loss_g = parallel.allreduce_flat_(loss.detach() * w)
+    if rank == 0:
+        ret["ids"] = list(data["_id_list"])
+        ret["grad"] = _flat_grad(model).numpy()
+        ret["loss"] = float(loss_g)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_case():
+    g = torch.Generator().manual_seed(11)
+    lens = [7, 3, 5, 9, 2]          # 5 samples: the remainder sample is dropped for world 2
+    batch = [{"x": torch.randn(t, 6, generator=g, dtype=torch.float64).numpy(),
+              "y": torch.randn(t, 4, generator=g, dtype=torch.float64).numpy(),
+              "_id_list": "utt%d" % i} for i, t in enumerate(lens)]
+    model = torch.nn.Linear(6, 4).double()
+    with torch.no_grad():
+        model.weight.copy_(torch.randn(4, 6, generator=g, dtype=torch.float64) * 0.3)
+        model.bias.copy_(torch.randn(4, generator=g, dtype=torch.float64) * 0.1)
+    return batch, model
+
+
+def _masked_mean_loss(model, data, lengths):
+    pred = model(data["x"])
+    se = ((pred - data["y"]) ** 2) * data["y_mask"]
+    return se.sum() / (float(sum(lengths["y_mask"])) * pred.shape[-1])
+
+
+def test_handler_data_parallel_step_equals_single_process():
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_handler_dp_worker, args=(r, world, port, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    batch, model = _dp_case()
+    data, lengths = Handler.prepare_batch(batch, common_divisor=world, batch_first=False,
+                                          mask_keys=("y",))
+    assert data["_id_list"] == ["utt0", "utt1", "utt2", "utt3"]      # remainder dropped
+    assert ret["ids"] == ["utt0", "utt2"]                            # rank 0 of 2
+    loss = _masked_mean_loss(model, data, lengths)
+    loss.backward()
+    assert abs(ret["loss"] - float(loss)) < 1e-12
+    assert np.abs(ret["grad"] - _flat_grad(model).numpy()).max() < 1e-12

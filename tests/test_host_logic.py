@@ -68,3 +68,44 @@ def test_length_matching_index_math():
     assert np.array_equal(out["questions"], q)
     same, was = trim_to_reference(q, [1926])
     assert not was and same is q
+
+
+def test_packed_batch_matches_torch_packed_sequence():
+    """PackedBatch (the index bookkeeping in front of the recurrent kernels) reproduces
+    pack_padded_sequence(enforce_sorted=False) / pad_packed_sequence, the calls of
+    rnn_dyn/RNNWrapper.py:89-102: same row order, same per-step batch sizes, same padding; and its
+    shifted-frame index gives h_{t-1} of every packed frame."""
+    import torch
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from idiaptts_amd.nn.functional import PackedBatch
+    g = torch.Generator().manual_seed(5)
+    for batch_first in (False, True):
+        for lens in ([5, 9, 1, 9, 3], [4], [2, 2, 2], list(range(1, 18))):
+            B, T = len(lens), max(lens) + 2                   # padded beyond the longest row
+            x = torch.randn((B, T, 3) if batch_first else (T, B, 3), generator=g)
+            pb = PackedBatch(lens, T, batch_first, "cpu")
+            ref = pack_padded_sequence(x, torch.tensor(lens), batch_first=batch_first,
+                                       enforce_sorted=False)
+            assert torch.equal(pb.pack(x), ref.data)
+            sizes = np.diff(np.concatenate([pb.d_row_off.numpy(), [pb.N]]))
+            assert list(sizes) == list(ref.batch_sizes.numpy())
+            assert torch.equal(pb.perm, ref.sorted_indices) and pb.T == max(lens)
+            back, _ = pad_packed_sequence(ref, batch_first=batch_first, total_length=T)
+            assert torch.equal(pb.unpack(pb.pack(x), x.shape), back)
+            # reverse-direction row table and the h_{t-1} shift, against explicit loops
+            sl = pb.h_lengths.numpy()
+            off = pb.d_row_off.numpy()
+            rev = pb.d_rev_row.numpy()
+            y = torch.arange(pb.N * 2, dtype=torch.float32).reshape(pb.N, 2) + 1.0
+            h0 = torch.tensor([[-1.0], [-2.0]])
+            hp = pb.shift(y, h0, 2, 1)
+            for b in range(B):
+                for t in range(sl[b]):
+                    s = sl[b] - 1 - t
+                    assert rev[s, b] == off[t] + b
+                    r = off[t] + b
+                    want_f = y[off[t - 1] + b, 0] if t > 0 else h0[0, 0]
+                    want_r = y[off[t + 1] + b, 1] if t + 1 < sl[b] else h0[1, 0]
+                    assert hp[r, 0] == want_f and hp[r, 1] == want_r
+    with pytest.raises(ValueError):
+        PackedBatch([3, 0], 3, False, "cpu")
