@@ -323,18 +323,20 @@ def main():
         from idiaptts_amd import ops
         x, y, valid, nloc = batches[0]
         hs = model.forward(x)
-        _, dz3 = ops.masked_mse(hs[-1], y, valid, float(nloc))
+        M = x.shape[0]
+        buf = model._rows_buffer       # the step's own padded-pitch activation buffers
+        _, dz3 = ops.masked_mse(hs[-1], y, valid, float(nloc), grad=buf("dz_out", M, dims[3]))
         stream = torch.cuda.current_stream()
 
         def gemms():
             W, G = model.weight_padded, model.grads
-            h1 = ops.linear_fwd(x, W(0), model.bias(0), 1)
-            h2 = ops.linear_fwd(h1, W(1), model.bias(1), 1)
-            ops.linear_fwd(h2, W(2), model.bias(2), 0)
+            h1 = ops.linear_fwd(x, W(0), model.bias(0), 1, out=buf("h0", M, dims[1]))
+            h2 = ops.linear_fwd(h1, W(1), model.bias(1), 1, out=buf("h1", M, dims[2]))
+            ops.linear_fwd(h2, W(2), model.bias(2), 0, out=buf("h2", M, dims[3]))
             ops.linear_bwd_weight(dz3, h2, dw=W(2, G), want_bias=False)
-            dz2 = ops.linear_bwd_input(dz3, W(2), yprev=h2, act_prev=1)
+            dz2 = ops.linear_bwd_input(dz3, W(2), yprev=h2, act_prev=1, out=buf("dz0", M, dims[2]))
             ops.linear_bwd_weight(dz2, h1, dw=W(1, G), want_bias=False)
-            dz1 = ops.linear_bwd_input(dz2, W(1), yprev=h1, act_prev=1)
+            dz1 = ops.linear_bwd_input(dz2, W(1), yprev=h1, act_prev=1, out=buf("dz1", M, dims[1]))
             ops.linear_bwd_weight(dz1, x, dw=W(0, G), want_bias=False)
 
         gemms()

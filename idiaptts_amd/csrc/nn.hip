@@ -78,9 +78,11 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
 // Global -> registers for one 128(out) x 32(k) tile of an operand, 16 floats per thread.
 // Branch-free: out-of-range elements read a clamped (valid) address and are zeroed by a select,
 // so all loads of a tile are issued back to back (hipcc otherwise branches around every guarded
-// load and waits for each one).  VEC: 16-byte loads; requires ld % 4 == 0, a 16-B aligned base
-// and the contiguous extent (K for row form, out_dim for col form) to be a multiple of 4, so a
-// float4 is either completely inside or completely outside.
+// load and waits for each one).  VEC: 16-byte loads; requires ld % 4 == 0 and a 16-B aligned base.
+// When the contiguous extent (K for row form, out_dim for col form) is not a multiple of 4 the
+// last float4 of a row also reads the 1-3 pad elements between the extent and the pitch: pad
+// output columns are never stored, pad K elements meet a zero of the other operand -- so the pad
+// only has to be finite (callers keep it zero; see the pitch rule in include/idiaptts_amd.h).
 template <bool ROWFORM, bool VEC, int NROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t out0,
                                           int64_t out_dim, int64_t k0, int64_t k_end,
@@ -253,9 +255,7 @@ template <bool A_ROW, bool B_ROW, int EPI, int TN>
 static int launch_gemm_tn(const GemmArgs& g, int splitk, hipStream_t s) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + 64 * TN - 1) / (64 * TN));
   dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
-  // contiguous extents must be multiples of 4 for the 16-byte path (see load_tile)
-  const bool va = g.vecA && ((A_ROW ? g.K : g.M) % 4 == 0);
-  const bool vb = g.vecB && ((B_ROW ? g.K : (int64_t)g.N) % 4 == 0);
+  const bool va = g.vecA, vb = g.vecB;   // pitch and alignment allow 16-byte loads (see load_tile)
   if (va && vb)
     hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, true, TN>), grid, dim3(256), 0, s, g);
   else if (va)

@@ -54,6 +54,7 @@ class FlatFFModel:
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.step_count = 0
+        self._buffers = {}
         if state_dict is None:
             state_dict = self.reference_init(self.dims, seed)
         self.load_layers(state_dict)
@@ -102,12 +103,25 @@ class FlatFFModel:
         return [(self.weight(i).clone(), self.bias(i).clone()) for i in range(len(self.layout))]
 
     # ------------------------------------------------------------------------------------
+    def _rows_buffer(self, name, M, width):
+        """[M, width] view of a persistent zero-initialised buffer whose row pitch is padded to a
+        multiple of 4 floats (16-byte GEMM loads); the pad columns are never written, so they
+        stay zero.  One buffer per name, grown to the largest M seen."""
+        pitch = _pad4(width)
+        buf = self._buffers.get(name)
+        if buf is None or buf.shape[0] < M:
+            buf = torch.zeros((M, pitch), dtype=torch.float32, device=self.device)
+            self._buffers[name] = buf
+        return buf[:M, :width]
+
     def forward(self, x):
         """x [M, dims[0]] fp32 packed frames -> list of layer outputs."""
         acts = []
         h = self.pack_input(x)
+        M = h.shape[0]
         for i in range(len(self.layout)):
-            h = ops.linear_fwd(h, self.weight_padded(i), self.bias(i), self.acts[i])
+            h = ops.linear_fwd(h, self.weight_padded(i), self.bias(i), self.acts[i],
+                               out=self._rows_buffer("h%d" % i, M, self.layout[i][2]))
             acts.append(h)
         return acts
 
@@ -116,7 +130,9 @@ class FlatFFModel:
         (this rank's contribution, already divided by the global frame count)."""
         x = self.pack_input(x)
         hs = self.forward(x)
-        loss, dz = ops.masked_mse(hs[-1], target, row_valid, n_valid_global)
+        M = x.shape[0]
+        loss, dz = ops.masked_mse(hs[-1], target, row_valid, n_valid_global,
+                                  grad=self._rows_buffer("dz_out", M, self.dims[-1]))
         n = len(self.layout)
         for i in range(n - 1, -1, -1):
             inp = hs[i - 1] if i > 0 else x
@@ -124,7 +140,9 @@ class FlatFFModel:
                                   db=self.bias(i, self.grads))
             if i > 0:
                 dz = ops.linear_bwd_input(dz, self.weight_padded(i), yprev=hs[i - 1],
-                                          act_prev=self.acts[i - 1])
+                                          act_prev=self.acts[i - 1],
+                                          out=self._rows_buffer("dz%d" % (i & 1), M,
+                                                                self.layout[i][3]))
         return loss
 
     def train_step(self, x, target, row_valid, n_valid_global, lr=1e-3, betas=(0.9, 0.999),

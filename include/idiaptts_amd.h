@@ -75,7 +75,12 @@ int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_o
 #define ITTS_ACT_NONE 0
 #define ITTS_ACT_TANH 1
 #define ITTS_ACT_RELU 2
-/* y[M,N] = act(x[M,K] @ w[N,K]^T + b[N]); fp32 MFMA. */
+/* Pitch rule for the row-major activations of the four entry points below (x, y, dz, dx, yprev):
+ * a row pitch (ld*) that is a multiple of 4 floats on a 16-byte aligned base selects 16-byte loads.
+ * If the logical width is not a multiple of 4, the 1-3 floats between the width and the next
+ * multiple of 4 are then read as well and must be finite (keep them zero): a padded reduction
+ * element meets a zero of the other operand, a padded output column is never stored.
+ * y[M,N] = act(x[M,K] @ w[N,K]^T + b[N]); fp32 MFMA. */
 int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
                     float* d_y, int64_t ldy, int64_t M, int N, int K, int act, void* stream);
 /* dz = dy * act'(y)  (elementwise; act' expressed through the layer output y). */
