@@ -6,7 +6,8 @@
 // GEMM design (exact fp32: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak):
 //   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
 //     2x2 MFMA tiles of 32x32 (64 accumulator VGPRs), K step 32, LDS double buffered
-//     (73.7 KB -> 2 workgroups per CU).
+//     (73.7 KB -> 2 workgroups per CU); or a 128x64 tile with a single LDS stage (36.9 KB,
+//     106 VGPRs -> 4 workgroups per CU) -- see launch_gemm for which shape runs when.
 //   * an operand is either "row form" [out][k] (k contiguous, e.g. x[M,K], w[N,K]) or "col
 //     form" [k][out] (e.g. dz[M,N] as the reduction-major operand of dW).  Row-form tiles are
 //     copied to LDS unchanged with a 4-float pad (144-B rows: conflict-free ds_read_b128);
@@ -149,11 +150,14 @@ __device__ __forceinline__ float4 read_frag(const float* __restrict__ S, int o, 
 
 // TN = MFMA tiles per wave along N: output tile 128 x (64*TN). TN = 1 halves the tile so that
 // narrow outputs (N = 187) and awkward tile counts waste fewer workgroup slots.
-template <bool A_ROW, bool B_ROW, int EPI, bool VEC_A, bool VEC_B, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+template <bool A_ROW, bool B_ROW, int EPI, bool VEC_A, bool VEC_B, int TN, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BNT = 64 * TN;
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
-  // buffer b: A tile at lds + 2b*TILE, B tile at lds + (2b+1)*TILE
+  constexpr int B_FLOATS = STAGES == 1 ? (B_ROW ? BNT * LD_ROW : BK * (BNT + 4)) : TILE_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * 2 * TILE_FLOATS - (STAGES == 1 ? TILE_FLOATS - B_FLOATS : 0)];
+  // buffer b: A tile at lds + 2b*TILE, B tile at lds + (2b+1)*TILE.  STAGES == 1: one LDS buffer
+  // (36.9 KB -> 4 workgroups per CU), the next tile waits in registers and two barriers per K
+  // tile separate its store from the reads of the current one.
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
   // XCD a contiguous run of tiles that share the same B panel (weights) where possible.
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   __syncthreads();
 
   for (int64_t kt = 0; kt < nkt; ++kt) {
-    const int cur = (int)(kt & 1);
+    const int cur = STAGES == 1 ? 0 : (int)(kt & 1);
     const bool more = kt + 1 < nkt;
     if (more) {
       load_tile<A_ROW, VEC_A, BM>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, ra);
@@ -221,9 +225,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (STAGES == 1) __syncthreads();   // everyone has read the current tile
     if (more) {
-      store_tile<A_ROW, BM>(lds + (2 * (cur ^ 1)) * TILE_FLOATS, ra);
-      store_tile<B_ROW, BNT>(lds + (2 * (cur ^ 1) + 1) * TILE_FLOATS, rb);
+      constexpr int nb = STAGES == 1 ? 0 : 1;
+      store_tile<A_ROW, BM>(lds + (2 * (cur ^ nb)) * TILE_FLOATS, ra);
+      store_tile<B_ROW, BNT>(lds + (2 * (cur ^ nb) + 1) * TILE_FLOATS, rb);
     }
     __syncthreads();
   }
@@ -251,25 +257,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <bool A_ROW, bool B_ROW, int EPI, int TN>
+template <bool A_ROW, bool B_ROW, int EPI, int TN, int STAGES>
 static int launch_gemm_tn(const GemmArgs& g, int splitk, hipStream_t s) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + 64 * TN - 1) / (64 * TN));
   dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
   const bool va = g.vecA, vb = g.vecB;   // pitch and alignment allow 16-byte loads (see load_tile)
   if (va && vb)
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, true, TN>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, true, TN, STAGES>), grid, dim3(256), 0, s, g);
   else if (va)
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, false, TN>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, true, false, TN, STAGES>), grid, dim3(256), 0, s, g);
   else if (vb)
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, true, TN>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, true, TN, STAGES>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, false, TN>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_ROW, B_ROW, EPI, false, false, TN, STAGES>), grid, dim3(256), 0, s, g);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
 
-// Tile width choice: 128x128 tiles reuse operands best, 128x64 tiles quantise better onto the
-// 512 resident workgroup slots (256 CUs x 2) and waste less on narrow outputs.
+// Kernel shape choice.  Measured on the acoustic-model GEMMs (MI355X, MfmaUtil from rocprofv3):
+//   * row-form A (forward and input-gradient GEMMs: M = frames, short K): 128x64 tiles with ONE LDS
+//     stage -- 37 KB and 106 VGPRs, so 4 workgroups per CU instead of 2.  Twice the waves per SIMD
+//     cover the barrier / LDS-refill gaps of a K tile: +21 % per-tile rate over the double-buffered
+//     128x128 kernel although it needs two barriers per K tile.
+//   * col-form A (weight-gradient GEMMs, split-K, long K loops): double-buffered tiles; 128x128
+//     reuses operands best, 128x64 quantises better onto the 512 resident slots (256 CUs x 2) and
+//     wastes less on narrow outputs -- pick by the slot-quantisation estimate below.  (The
+//     single-stage variant spills in col form and is slower.)
 static double tile_efficiency(int64_t M, int N, int splitk, int tn, double loop_eff) {
   const int bn = 64 * tn;
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn) * splitk;
@@ -281,10 +294,11 @@ static double tile_efficiency(int64_t M, int N, int splitk, int tn, double loop_
 template <bool A_ROW, bool B_ROW, int EPI>
 static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return ITTS_OK;
+  if (A_ROW) return launch_gemm_tn<A_ROW, B_ROW, EPI, 1, 1>(g, splitk, s);
   const double e2 = tile_efficiency(g.M, g.N, splitk, 2, 1.0);
   const double e1 = tile_efficiency(g.M, g.N, splitk, 1, 0.90);
-  if (e1 > e2) return launch_gemm_tn<A_ROW, B_ROW, EPI, 1>(g, splitk, s);
-  return launch_gemm_tn<A_ROW, B_ROW, EPI, 2>(g, splitk, s);
+  if (e1 > e2) return launch_gemm_tn<A_ROW, B_ROW, EPI, 1, 2>(g, splitk, s);
+  return launch_gemm_tn<A_ROW, B_ROW, EPI, 2, 2>(g, splitk, s);
 }
 
 static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
