@@ -304,14 +304,75 @@ static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
 static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- split-K slab reduction (deterministic order) -------------------------------------------
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int64_t n,
-                                    float* __restrict__ out, int accumulate) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[(int64_t)z * n + i];
-    out[i] = accumulate ? out[i] + s : s;
+// out[i] = sum_z slabs[z][i].  Memory bound (S x n floats in, n out); a workgroup owns 64 float4
+// columns, its 4 waves take every 4th slab each (all loads of a thread independent -> in flight
+// together) and the four partial sums meet in LDS in a fixed order.  n % 4 == 0 and 16-byte
+// aligned buffers take this path, anything else the scalar tail kernel.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int S,
+                                                           int64_t n, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ float4 part[3][64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t n4 = n >> 2;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < n4) {
+    const float4* p = reinterpret_cast<const float4*>(slabs) + c;
+#pragma unroll 8
+    for (int z = grp; z < S; z += 4) {
+      const float4 v = p[(int64_t)z * n4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
+  if (grp > 0) part[grp - 1][tx] = s;
+  __syncthreads();
+  if (grp == 0 && c < n4) {
+#pragma unroll
+    for (int g2 = 0; g2 < 3; ++g2) {
+      const float4 v = part[g2][tx];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out) + c;
+    if (accumulate) {
+      const float4 v = *o;
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *o = s;
+  }
+}
+
+// same split of the work for buffers that cannot be read as float4 (n % 4 != 0, e.g. 187 biases)
+__global__ __launch_bounds__(256) void reduce_slabs_scalar_kernel(const float* __restrict__ slabs, int S,
+                                                                  int64_t n, float* __restrict__ out,
+                                                                  int accumulate) {
+  __shared__ float part[3][64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < n) {
+#pragma unroll 8
+    for (int z = grp; z < S; z += 4) s += slabs[(int64_t)z * n + c];
+  }
+  if (grp > 0) part[grp - 1][tx] = s;
+  __syncthreads();
+  if (grp == 0 && c < n) {
+    s += part[0][tx];
+    s += part[1][tx];
+    s += part[2][tx];
+    out[c] = accumulate ? out[c] + s : s;
+  }
+}
+
+static int launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, int accumulate,
+                               hipStream_t s) {
+  if (n % 4 == 0 && aligned16(slabs) && aligned16(out))
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, S,
+                       n, out, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs,
+                       S, n, out, accumulate);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
 }
 
 // column sums of dz[M,N] over a row slice -> partial[z][n]
@@ -526,9 +587,8 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
   int rc = launch_gemm<false, false, EPI_STORE>(g, S_eff, s);
   if (rc) return rc;
   const int64_t n = (int64_t)N * K;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)),
-                     dim3(256), 0, s, slabs, S_eff, n, d_dw, accumulate);
-  ITTS_LAUNCH_CHECK();
+  rc = launch_reduce_slabs(slabs, S_eff, n, d_dw, accumulate, s);
+  if (rc) return rc;
   if (d_db) {
     int64_t rows = (M + kColsumSlices - 1) / kColsumSlices;
     rows = std::max<int64_t>(rows, 16);
@@ -536,9 +596,8 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, cs), dim3(256), 0, s, d_dz,
                        lddz, M, N, rows, bpart);
     ITTS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, s, bpart, cs,
-                       (int64_t)N, d_db, accumulate);
-    ITTS_LAUNCH_CHECK();
+    rc = launch_reduce_slabs(bpart, cs, (int64_t)N, d_db, accumulate, s);
+    if (rc) return rc;
   }
   return ITTS_OK;
 }
