@@ -223,6 +223,88 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
   }
 }
 
+// ---- the same Newton update, one WAVE per frame (orders up to 63) -------------------------------
+// The system matrix (Toeplitz + Hankel of cr) is symmetric positive definite and small; the
+// workgroup-per-frame elimination above spends its time in 2 x 60 block barriers and index
+// arithmetic (77 us per solve).  Here lane r owns row r in REGISTERS and the wave runs a
+// Gauss-Jordan elimination without a single barrier:
+//   * at pivot step c every lane drops its leading element: the row is kept SHIFTED so that
+//     a[j] always means column c + j, and the update a[j-1] = a[j] - f * p[j] doubles as the shift
+//     (all register indices are compile-time constants, the step loop is a real loop);
+//   * the pivot row is never broadcast lane by lane: the trailing block is symmetric, so
+//     p[j] = A[c][c+j] = A[c+j][c] is the leading element of lane c+j -- one ds_write_b64 of a[0]
+//     by the whole wave publishes the pivot row, uniform-address LDS reads return it;
+//   * rows above the pivot are eliminated too (Gauss-Jordan), so no U factor is stored and no
+//     back substitution runs: lane r keeps its pivot d_r and ends with x_r = b_r / d_r.
+// 61 FMAs per step and lane, 60 steps: ~18 k VALU cycles per solve instead of ~185 k.
+template <int W>   // W >= m + 1: register row length (24, 32, 48 or 64)
+__global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
+  __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
+  __shared__ double piv[4][64 + W];   // leading elements of all rows (the pivot row), zero padded
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t g = (int64_t)blockIdx.x * 4 + wv;
+  if (g >= a.T || a.done[g]) return;                 // wave-uniform
+  const int m = a.m, m1 = m + 1, m2 = 2 * m;
+  double* cr = crs[wv];
+  double* P = piv[wv];
+  for (int j = lane; j <= m2; j += 64) cr[j] = a.cr[g * (m2 + 1) + j];
+  for (int j = lane; j < W; j += 64) P[64 + j] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  const double t = cr[0];
+  if (a.iter >= a.itr1) {
+    const double sp = a.sprev[g];
+    if (fabs((t - sp) / t) < a.dd) {                 // uniform
+      if (lane == 0) {
+        a.done[g] = 1;
+        a.iters[g] = a.iter;
+        atomicSub(a.n_active, 1);
+      }
+      return;
+    }
+    if (lane == 0) a.sprev[g] = t;
+  }
+  const int r = lane;
+  const bool rowok = r < m1;
+  double row[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    double v = 0.0;
+    if (rowok && k < m1) {
+      const int df = r > k ? r - k : k - r;
+      double tv = cr[df];
+      if ((df & 1) == 0) tv += t;
+      double hv = cr[r + k];
+      if (((r + k) & 1) == 0) hv -= t;
+      v = tv + hv;
+    }
+    row[k] = v;
+  }
+  double b = rowok ? cr[r] - pow(-a.alpha, (double)r) : 0.0;
+  double d = 1.0;
+#pragma unroll 1
+  for (int c = 0; c < m1; ++c) {
+    P[lane] = row[0];
+    __builtin_amdgcn_wave_barrier();
+    const double pc = P[c];                                            // pivot A[c][c]
+    const double bc = __shfl(b, c);
+    const bool is_piv = lane == c;
+    if (is_piv) d = pc;
+    const double f = is_piv ? 0.0 : row[0] / pc;
+    const double* p = P + c;
+#pragma unroll
+    for (int j = 1; j < W; ++j) row[j - 1] = row[j] - f * p[j];
+    row[W - 1] = 0.0;
+    b -= f * bc;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (rowok) a.mc[g * m1 + r] += b / d;
+  if (lane == 0 && a.iter == a.itr2) {
+    a.done[g] = 1;
+    a.iters[g] = a.itr2;
+    atomicSub(a.n_active, 1);
+  }
+}
+
 __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, int m1,
                                      float* __restrict__ o32, int64_t ld32, double* __restrict__ o64,
                                      const int* __restrict__ iters_in, int* __restrict__ iters_out) {
@@ -289,7 +371,12 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
     ITTS_LAUNCH_CHECK();
     if ((rc = launch_gemm_f64(cbuf, K, ft->frqT, m2 + 1, cr, m2 + 1, T, m2 + 1, K, s))) return rc;
-    hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)T), dim3(NT), lds_solve, s, a);
+    const dim3 wgrid((unsigned)((T + 3) / 4));
+    if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_wave_kernel<24>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 32) hipLaunchKernelGGL(mcls_solve_wave_kernel<32>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 48) hipLaunchKernelGGL(mcls_solve_wave_kernel<48>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 64) hipLaunchKernelGGL(mcls_solve_wave_kernel<64>, wgrid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)T), dim3(NT), lds_solve, s, a);
     ITTS_LAUNCH_CHECK();
     if (it >= miniter && it < maxiter) {
       int remaining = 0;
