@@ -23,18 +23,24 @@ using namespace wd;
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// C[T, N] = A[T, K] . B[K, N]; all row-major f64. Workgroup: 64 rows x 64 cols, wave: 16 x 64.
+// C[rows, N] = A[rows, K] . B[K, N]; all row-major f64. Workgroup: 64 rows x 64 cols, wave: 16 x 64.
+// `rows` (optional) lists the physical row of every logical row: the Newton rounds only touch the
+// frames that have not converged yet.  VEC_A: a lane's four consecutive k of a chunk come as two
+// 16-byte loads (needs an even lda and a 16-byte aligned base; rows may be read up to 3 doubles
+// past K, the callers' buffers have that slack).
+template <bool VEC_A>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
                                                        const double* __restrict__ Bm, int64_t ldb,
                                                        double* __restrict__ C, int64_t ldc, int64_t T,
-                                                       int N, int K) {
+                                                       int N, int K, const int* __restrict__ rows) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * 64 + wv * 16;
   const int c0 = blockIdx.y * 64;
   const int64_t row = r0 + lr;
   const bool rok = row < T;
-  const double* ap = A + (rok ? row : 0) * lda;
+  const int64_t prow = rok ? (rows ? rows[row] : row) : 0;
+  const double* ap = A + prow * lda;
   f64x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
@@ -50,13 +56,24 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
   for (int s = 0; s < K; s += 16) {
     double av[4];
     double bv[4][4];
+    if (VEC_A) {
+      const int k0 = s + 4 * kg;
+      const double2* p2 = reinterpret_cast<const double2*>(ap + (k0 < K ? k0 : 0));
+      const double2 v0 = p2[0], v1 = p2[1];
+      av[0] = (rok && k0 < K) ? v0.x : 0.0;
+      av[1] = (rok && k0 + 1 < K) ? v0.y : 0.0;
+      av[2] = (rok && k0 + 2 < K) ? v1.x : 0.0;
+      av[3] = (rok && k0 + 3 < K) ? v1.y : 0.0;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = s + 4 * kg + j;
       const bool kok = k < K;
       const int kc = kok ? k : 0;
-      const double a = ap[kc];
-      av[j] = (kok && rok) ? a : 0.0;
+      if (!VEC_A) {
+        const double a = ap[kc];
+        av[j] = (kok && rok) ? a : 0.0;
+      }
       const double* brow = Bm + (int64_t)kc * ldb;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -72,14 +89,21 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
   }
   // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (!cok[q]) continue;
+  for (int r = 0; r < 4; ++r) {
+    const int64_t orow = r0 + kg + 4 * r;
+    if (orow >= T) continue;
+    const int64_t prow_o = rows ? rows[orow] : orow;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t orow = r0 + kg + 4 * r;
-      if (orow < T) C[orow * ldc + ccol[q]] = acc[q][r];
-    }
+    for (int q = 0; q < 4; ++q)
+      if (cok[q]) C[prow_o * ldc + ccol[q]] = acc[q][r];
   }
+}
+
+// list of the frames that are still iterating (order irrelevant: frames are independent)
+__global__ void mcls_compact_kernel(const int* __restrict__ done, int64_t T, int* __restrict__ rows,
+                                    int* __restrict__ count) {
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < T; g += (int64_t)gridDim.x * blockDim.x)
+    if (!done[g]) rows[atomicAdd(count, 1)] = (int)g;
 }
 
 struct LsArgs {
@@ -99,6 +123,9 @@ struct LsArgs {
   int* iters;            // [T]
   int* n_active;         // [1]
   int iter;              // current Newton iteration (1-based)
+  int64_t ldk;           // row pitch of xp / cbuf (K rounded up to even: 16-byte aligned rows)
+  const int* rows;       // frames still iterating (NULL: all T)
+  int64_t n_rows;
   const double2* g_tw;
 };
 
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
     double v = a.in[g * K + k];
     if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
     const double x = v * v + a.eps;
-    a.xp[g * K + k] = x;
+    a.xp[g * a.ldk + k] = x;
     z[k] = make_double2(log(x), 0.0);
   }
   __syncthreads();
@@ -123,7 +150,7 @@ __global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
   for (int k = threadIdx.x; k < K; k += NT) {
     double v = zr[k];
     if (k == 0 || k == f2) v /= 2;
-    a.cbuf[g * K + k] = v;
+    a.cbuf[g * a.ldk + k] = v;
   }
   if (threadIdx.x == 0) {
     a.sprev[g] = zr[0] / 2;
@@ -135,18 +162,18 @@ __global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
 // r = irfft( xp / exp(2 Re rfft(c')) ), in place on cbuf rows of active frames
 __global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t g = blockIdx.x;
+  const int64_t g = a.rows ? a.rows[blockIdx.x] : blockIdx.x;
   if (a.done[g]) return;
-  const int f2 = a.flng / 2, K = f2 + 1;
+  const int f2 = a.flng / 2;
   double2* tw = reinterpret_cast<double2*>(smem);
   double2* z = tw + f2;
   double* zr = reinterpret_cast<double*>(z);
   load_twiddles(tw, a.g_tw, a.flng);
-  double* row = a.cbuf + g * K;
+  double* row = a.cbuf + g * a.ldk;
   for (int i = threadIdx.x; i < a.flng + 2; i += NT) zr[i] = (i <= f2) ? row[i] : 0.0;
   __syncthreads();
   rfft_lds(z, a.flng, a.logflng, tw, a.flng);
-  const double* xp = a.xp + g * K;
+  const double* xp = a.xp + g * a.ldk;
   for (int k = threadIdx.x; k <= f2; k += NT) z[k] = make_double2(xp[k] / exp(2.0 * z[k].x), 0.0);
   __syncthreads();
   irfft_lds(z, a.flng, a.logflng, tw, a.flng);
@@ -156,7 +183,7 @@ __global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
 // convergence test + Newton update of one frame from cr
 __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t g = blockIdx.x;
+  const int64_t g = a.rows ? a.rows[blockIdx.x] : blockIdx.x;
   if (a.done[g]) return;
   const int m = a.m, m1 = m + 1, m2 = 2 * m, ld = m + 2;
   double* cr = reinterpret_cast<double*>(smem);   // [2m+1]
@@ -242,8 +269,10 @@ __global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
   __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
   __shared__ double piv[4][64 + W];   // leading elements of all rows (the pivot row), zero padded
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t g = (int64_t)blockIdx.x * 4 + wv;
-  if (g >= a.T || a.done[g]) return;                 // wave-uniform
+  const int64_t slot = (int64_t)blockIdx.x * 4 + wv;
+  if (slot >= a.n_rows) return;                      // wave-uniform
+  const int64_t g = a.rows ? a.rows[slot] : slot;
+  if (a.done[g]) return;
   const int m = a.m, m1 = m + 1, m2 = 2 * m;
   double* cr = crs[wv];
   double* P = piv[wv];
@@ -320,9 +349,13 @@ __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, i
 }
 
 static int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
-                           int64_t ldc, int64_t T, int N, int K, hipStream_t s) {
+                           int64_t ldc, int64_t T, int N, int K, const int* rows, hipStream_t s) {
+  if (T <= 0) return ITTS_OK;
   dim3 grid((unsigned)((T + 63) / 64), (unsigned)((N + 63) / 64));
-  hipLaunchKernelGGL(gemm_f64_kernel, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K);
+  if (lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0)
+    hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
+  else
+    hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
@@ -337,22 +370,25 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   int logflng = 0;
   while ((1 << logflng) < flng) ++logflng;
   double *xp = nullptr, *cbuf = nullptr, *mc = nullptr, *cr = nullptr, *sprev = nullptr;
-  int *done = nullptr, *iters = nullptr, *n_active = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&xp, (size_t)T * K * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&cbuf, (size_t)T * K * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&mc, (size_t)T * m1 * 8, s));
+  int *done = nullptr, *iters = nullptr, *n_active = nullptr, *rows = nullptr;
+  const int64_t Kp = K + (K & 1);   // even pitch: 16-byte aligned rows for the vector loads
+  const size_t slack = 64;          // the vector loads may run up to 3 doubles past a row's end
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&xp, (size_t)T * Kp * 8 + slack, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&cbuf, (size_t)T * Kp * 8 + slack, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&mc, (size_t)T * m1 * 8 + slack, s));
   ITTS_HIP_CHECK(hipMallocAsync((void**)&cr, (size_t)T * (m2 + 1) * 8, s));
   ITTS_HIP_CHECK(hipMallocAsync((void**)&sprev, (size_t)T * 8, s));
   ITTS_HIP_CHECK(hipMallocAsync((void**)&done, (size_t)T * 4, s));
   ITTS_HIP_CHECK(hipMallocAsync((void**)&iters, (size_t)T * 4, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&n_active, 4, s));
-  const int tcount = (int)T;
-  ITTS_HIP_CHECK(hipMemcpyAsync(n_active, &tcount, 4, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&rows, (size_t)T * 4, s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&n_active, 8, s));   // [0] active frames, [1] list cursor
+  const int tcount[2] = {(int)T, 0};
+  ITTS_HIP_CHECK(hipMemcpyAsync(n_active, tcount, 8, hipMemcpyHostToDevice, s));
   LsArgs a{};
   a.in = d_in; a.in_is_power = in_is_power; a.T = T; a.flng = flng; a.logflng = logflng; a.m = order;
   a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.xp = xp;
   a.cbuf = cbuf; a.mc = mc; a.cr = cr; a.sprev = sprev; a.done = done; a.iters = iters;
-  a.n_active = n_active; a.g_tw = ctx->twiddles;
+  a.n_active = n_active; a.g_tw = ctx->twiddles; a.ldk = Kp; a.rows = nullptr; a.n_rows = T;
   const size_t lds_fft = (size_t)f2 * 16 + (size_t)(f2 + 1) * 16;
   const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_kernel,
@@ -363,26 +399,35 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
   hipLaunchKernelGGL(mcls_init_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
   ITTS_LAUNCH_CHECK();
-  int rc = launch_gemm_f64(cbuf, K, ft->fwdT, m1, mc, m1, T, m1, K, s);
+  int rc = launch_gemm_f64(cbuf, Kp, ft->fwdT, m1, mc, m1, T, m1, K, nullptr, s);
   if (rc) return rc;
   for (int it = 1; it <= maxiter; ++it) {
     a.iter = it;
-    if ((rc = launch_gemm_f64(mc, m1, ft->invT, K, cbuf, K, T, K, m1, s))) return rc;
-    hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
+    const int64_t nr = a.n_rows;      // frames still iterating (their list is a.rows)
+    if ((rc = launch_gemm_f64(mc, m1, ft->invT, K, cbuf, Kp, nr, K, m1, a.rows, s))) return rc;
+    hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)nr), dim3(NT), lds_fft, s, a);
     ITTS_LAUNCH_CHECK();
-    if ((rc = launch_gemm_f64(cbuf, K, ft->frqT, m2 + 1, cr, m2 + 1, T, m2 + 1, K, s))) return rc;
-    const dim3 wgrid((unsigned)((T + 3) / 4));
+    if ((rc = launch_gemm_f64(cbuf, Kp, ft->frqT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
+    const dim3 wgrid((unsigned)((nr + 3) / 4));
     if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_wave_kernel<24>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 32) hipLaunchKernelGGL(mcls_solve_wave_kernel<32>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 48) hipLaunchKernelGGL(mcls_solve_wave_kernel<48>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 64) hipLaunchKernelGGL(mcls_solve_wave_kernel<64>, wgrid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)T), dim3(NT), lds_solve, s, a);
+    else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)nr), dim3(NT), lds_solve, s, a);
     ITTS_LAUNCH_CHECK();
     if (it >= miniter && it < maxiter) {
       int remaining = 0;
       ITTS_HIP_CHECK(hipMemcpyAsync(&remaining, n_active, 4, hipMemcpyDeviceToHost, s));
       ITTS_HIP_CHECK(hipStreamSynchronize(s));
       if (remaining <= 0) break;
+      if (remaining < nr) {          // shrink the work list to the frames that still iterate
+        ITTS_HIP_CHECK(hipMemsetAsync(n_active + 1, 0, 4, s));
+        hipLaunchKernelGGL(mcls_compact_kernel, dim3((unsigned)std::min<int64_t>((T + 255) / 256, 1024)),
+                           dim3(256), 0, s, done, T, rows, n_active + 1);
+        ITTS_LAUNCH_CHECK();
+        a.rows = rows;
+        a.n_rows = remaining;
+      }
     }
   }
   const int64_t n = T * m1;
@@ -397,6 +442,7 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   ITTS_HIP_CHECK(hipFreeAsync(done, s));
   ITTS_HIP_CHECK(hipFreeAsync(iters, s));
   ITTS_HIP_CHECK(hipFreeAsync(n_active, s));
+  ITTS_HIP_CHECK(hipFreeAsync(rows, s));
   return ITTS_OK;
 }
 
