@@ -3,7 +3,7 @@
 // intermediates of the frame (windowed segment, spectra, cepstra, smoothing prefix sums) live
 // in LDS, so HBM only sees the waveform samples read and the feature row written.
 //
-//   fft_lds      in-place radix-2 DIT complex FFT on interleaved (re,im) doubles in LDS,
+//   fft_lds      in-place DIT complex FFT (two radix-2 stages per pass) on interleaved (re,im) doubles in LDS,
 //                twiddles from an LDS copy of the table (ds_read_b128 per operand)
 //   rfft/irfft   real transforms of length n through a complex FFT of length n/2
 //   block_scan   inclusive prefix sum (WORLD's cumulative spectra)
@@ -41,19 +41,48 @@ __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, i
   }
   __syncthreads();
   const int tshift = ilog2(tw_n) - 1;  // twiddle index of w_{2h}^r in the tw_n table: r * tw_n/(2h)
-  for (int s = 1; s <= logn; ++s) {
+  // complex product with the (possibly conjugated) twiddle, the one expression every stage uses
+  auto twmul = [&](const double2 v, const double2 w) {
+    const double wi = sign < 0 ? -w.y : w.y;
+    return make_double2(v.x * w.x - v.y * wi, v.x * wi + v.y * w.x);
+  };
+  int s = 1;
+  // Two radix-2 stages per pass: a thread takes the four elements a0 + {0, h, 2h, 3h} through
+  // stage s (pairs at distance h) and stage s+1 (pairs at distance 2h) in registers.  Same
+  // butterflies, same twiddle-table entries, same operation order as two separate radix-2
+  // passes -- the results are bit-identical -- with 11 instead of 20 LDS accesses per four
+  // elements and half the barriers (these kernels are bound by LDS traffic).
+  for (; s + 1 <= logn; s += 2) {
+    const int h = 1 << (s - 1);
+    for (int t = threadIdx.x; t < n / 4; t += NT) {
+      const int r = t & (h - 1);
+      const int a0 = ((t >> (s - 1)) << (s + 1)) + r;
+      const int a1 = a0 + h, a2 = a0 + 2 * h, a3 = a0 + 3 * h;
+      const double2 w1 = tw[r << (tshift - (s - 1))];
+      const double2 w2 = tw[r << (tshift - s)];
+      const double2 w3 = tw[(r + h) << (tshift - s)];
+      const double2 z0 = z[a0], z1 = z[a1], z2 = z[a2], z3 = z[a3];
+      const double2 x1 = twmul(z1, w1), x3 = twmul(z3, w1);
+      const double2 y0 = make_double2(z0.x + x1.x, z0.y + x1.y), y1 = make_double2(z0.x - x1.x, z0.y - x1.y);
+      const double2 y2 = make_double2(z2.x + x3.x, z2.y + x3.y), y3 = make_double2(z2.x - x3.x, z2.y - x3.y);
+      const double2 u2 = twmul(y2, w2), u3 = twmul(y3, w3);
+      z[a0] = make_double2(y0.x + u2.x, y0.y + u2.y);
+      z[a2] = make_double2(y0.x - u2.x, y0.y - u2.y);
+      z[a1] = make_double2(y1.x + u3.x, y1.y + u3.y);
+      z[a3] = make_double2(y1.x - u3.x, y1.y - u3.y);
+    }
+    __syncthreads();
+  }
+  for (; s <= logn; ++s) {   // odd log2(n): one plain radix-2 stage is left
     const int h = 1 << (s - 1);
     for (int t = threadIdx.x; t < n / 2; t += NT) {
       const int r = t & (h - 1);
       const int a = ((t >> (s - 1)) << s) + r;
       const int b = a + h;
-      const double2 w = tw[r << (tshift - (s - 1))];
-      const double wi = sign < 0 ? -w.y : w.y;
-      const double2 zb = z[b], za = z[a];
-      const double xr = zb.x * w.x - zb.y * wi;
-      const double xi = zb.x * wi + zb.y * w.x;
-      z[b] = make_double2(za.x - xr, za.y - xi);
-      z[a] = make_double2(za.x + xr, za.y + xi);
+      const double2 x = twmul(z[b], tw[r << (tshift - (s - 1))]);
+      const double2 za = z[a];
+      z[b] = make_double2(za.x - x.x, za.y - x.y);
+      z[a] = make_double2(za.x + x.x, za.y + x.y);
     }
     __syncthreads();
   }
