@@ -71,6 +71,43 @@ class FlatFFModel:
             layers.append((w, b))
         return layers
 
+    @staticmethod
+    def from_module(model, device=None):
+        """Mirror of a drop-in module stack (NamedForwardWrapper / RNNDyn) that consists of Linear
+        groups only: same weights, flat buffers.  Returns None when the model has anything else
+        (recurrent groups, dropout) -- those train through the module path."""
+        from .nn.modules import LinearAct
+        inner = getattr(model, "model", model)
+        layers, acts = [], []
+        for group in getattr(inner, "layer_groups", []):
+            seq = getattr(group, "module", None)
+            if not isinstance(seq, torch.nn.Sequential):
+                return None
+            for m in seq:
+                if isinstance(m, LinearAct):
+                    layers.append((m.weight.detach(), m.bias.detach()))
+                    acts.append({ops.ACT_NONE: None, ops.ACT_TANH: "tanh", ops.ACT_RELU: "relu"}[m.act])
+                elif isinstance(m, torch.nn.Dropout):
+                    return None
+                elif type(m).__name__ != "FusedActivation":
+                    return None
+        if not layers:
+            return None
+        dims = [layers[0][0].shape[1]] + [w.shape[0] for w, _ in layers]
+        device = device if device is not None else layers[0][0].device
+        return FlatFFModel(dims, acts, device=device, state_dict=layers)
+
+    def store_to_module(self, model):
+        """Writes the flat parameters back into the module stack (checkpoints, inference)."""
+        from .nn.modules import LinearAct
+        inner = getattr(model, "model", model)
+        mods = [m for g in inner.layer_groups for m in g.module if isinstance(m, LinearAct)]
+        with torch.no_grad():
+            for i, m in enumerate(mods):
+                m.weight.copy_(self.weight(i))
+                m.bias.copy_(self.bias(i))
+        return mods
+
     def load_layers(self, layers):
         for i, (w, b) in enumerate(layers):
             self.weight(i).copy_(w.to(self.device))

@@ -97,6 +97,9 @@ class ExtendedHParams(object):
             dataset_type="PyTorchDatareadersDataset", dataset_num_workers_gpu=4,
             dataset_num_workers_cpu=0, dataset_pin_memory=True, dataset_load_async=True,
             teacher_forcing_in_test=False, preload_next_batch_to_gpu=False,
+            # not in the reference: keep the (normalised, length matched) training data resident in
+            # HBM as packed frame shards instead of loading one file per item and step
+            resident_dataset=False,
             # data
             input_norm_params_file_prefix=None, output_norm_params_file_prefix=None,
             len_in_out_multiplier=1, out_dir=None, world_dir=None,

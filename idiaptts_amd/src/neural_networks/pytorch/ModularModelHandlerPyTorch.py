@@ -121,6 +121,7 @@ class ModularModelHandlerPyTorch(object):
         self.losses = []
         self.dataloader_train = None
         self.dataloader_val = None
+        self._resident = None          # HBM-resident training state (set_dataset, resident_dataset)
 
     @staticmethod
     def cuda_is_available():
@@ -213,6 +214,9 @@ class ModularModelHandlerPyTorch(object):
         return data, lengths
 
     def set_dataset(self, hparams, dataset_train, dataset_val, collate_fn=None):
+        if hparams.get_value("resident_dataset", False):
+            return self._set_resident_dataset(hparams, dataset_train, dataset_val)
+        self._resident = None
         num_workers = hparams.dataset_num_workers_gpu if hparams.use_gpu \
             else hparams.dataset_num_workers_cpu
         common = dict(batch_first=hparams.batch_first, collate_fn=collate_fn,
@@ -240,6 +244,140 @@ class ModularModelHandlerPyTorch(object):
                           collate_fn=partial(collate_fn, common_divisor=common_divisor,
                                              batch_first=batch_first, **extra),
                           pin_memory=pin_memory and torch.cuda.is_available())
+
+    # ------------------------------------------------------------------- HBM-resident data
+    class _IndexDataset(torch.utils.data.Dataset):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return i
+
+    def _set_resident_dataset(self, hparams, dataset_train, dataset_val):
+        """hparams.resident_dataset: the data readers run ONCE per id, their normalised, length
+        matched outputs are packed into FrameShards and uploaded; the
+        loaders then only draw utterance indices -- same batch sizes, same shuffling and the same
+        RNG consumption as the per-item loaders -- and every mini-batch is gathered on the device
+        as packed valid frames.  Feed-forward models only (frame-independent layers)."""
+        from idiaptts_amd.native_ff import FlatFFModel
+        from idiaptts_amd.src.data_preparation.FrameShard import FrameShard
+        flat = FlatFFModel.from_module(self.model, self._device())
+        if flat is None:
+            raise NotImplementedError("hparams.resident_dataset needs a feed-forward model "
+                                      "(Linear groups without dropout).")
+        if not hparams.use_gpu:
+            raise RuntimeError("hparams.resident_dataset needs hparams.use_gpu.")
+        device = self._device()
+        in_name = self.model.input_names[0]
+        shards = {}
+        for key, ds in (("train", dataset_train), ("val", dataset_val)):
+            if ds is None:
+                continue
+            target = self._resident_target_name(ds, in_name)
+            shards[key] = FrameShard.from_dataset(ds, in_name, target).to(device)
+        common = dict(num_workers=0, collate_fn=list, pin_memory=False)
+        self.dataloader_train = DataLoader(self._IndexDataset(len(shards["train"])),
+                                           batch_size=hparams.batch_size_train,
+                                           shuffle=hparams.shuffle_train_set, **common)
+        self.dataloader_val = DataLoader(self._IndexDataset(len(shards["val"])),
+                                         batch_size=hparams.batch_size_val,
+                                         shuffle=hparams.shuffle_val_set, **common) \
+            if "val" in shards else None
+        self._resident = {"flat": flat, "shards": shards, "synced": False}
+
+    @staticmethod
+    def _resident_target_name(dataset, input_name):
+        names = [n for r in dataset.datareaders for n in r.output_names if n != input_name]
+        if len(names) != 1:
+            raise NotImplementedError("resident_dataset expects one input and one target stream, "
+                                      "found targets {}.".format(names))
+        return names[0]
+
+    def _resident_sync_from_module(self):
+        """Flat buffers <- module parameters and optimiser state (fresh model or loaded
+        checkpoint); done once before the first resident step."""
+        res = self._resident
+        flat = res["flat"]
+        from idiaptts_amd.native_ff import FlatFFModel
+        fresh = FlatFFModel.from_module(self.model, self._device())
+        flat.params.copy_(fresh.params)
+        flat.step_count = 0
+        if self.optimiser is not None:
+            from idiaptts_amd.nn.modules import LinearAct
+            inner = getattr(self.model, "model", self.model)
+            lin = [m for g in inner.layer_groups for m in g.module if isinstance(m, LinearAct)]
+            for i, m in enumerate(lin):
+                for p, view in ((m.weight, flat.weight), (m.bias, flat.bias)):
+                    st = self.optimiser.state.get(p, {})
+                    if "exp_avg" in st:
+                        view(i, flat.exp_avg).copy_(st["exp_avg"])
+                        view(i, flat.exp_avg_sq).copy_(st["exp_avg_sq"])
+                        flat.step_count = int(st["step"])
+        res["synced"] = True
+
+    def _resident_sync_to_module(self):
+        """Module parameters and optimiser state <- flat buffers (validation through the module
+        stack, checkpoints, inference)."""
+        res = self._resident
+        if res is None or not res["synced"]:
+            return
+        flat = res["flat"]
+        lin = flat.store_to_module(self.model)
+        if self.optimiser is not None and isinstance(self.optimiser, HipAdam) and flat.step_count > 0:
+            for i, m in enumerate(lin):
+                for p, view in ((m.weight, flat.weight), (m.bias, flat.bias)):
+                    self.optimiser.state[p] = {
+                        "step": flat.step_count,
+                        "exp_avg": view(i, flat.exp_avg).clone().contiguous(),
+                        "exp_avg_sq": view(i, flat.exp_avg_sq).clone().contiguous()}
+
+    def _process_resident(self, dataloader, shard, hparams, total_epoch, total_steps,
+                          current_epoch, training):
+        """process_dataloader on HBM-resident shards with the flat feed-forward step
+        (idiaptts_amd.native_ff): same losses, same Adam, same scheduler calls."""
+        res = self._resident
+        flat = res["flat"]
+        if not isinstance(self.optimiser, HipAdam) and training:
+            raise NotImplementedError("resident_dataset trains with Adam.")
+        if hparams.ema_decay or hparams.grad_clip_norm_type is not None \
+                or hparams.grad_clip_thresh is not None:
+            raise NotImplementedError("EMA / gradient clipping are not available with "
+                                      "resident_dataset.")
+        if not res["synced"]:
+            self._resident_sync_from_module()
+        if len(self.losses) != 1 or getattr(self.losses[0], "loss_weight", 1.0) != 1.0:
+            raise NotImplementedError("resident_dataset trains one unweighted masked-MSE loss.")
+        loss_name = self.losses[0].name
+        rank, world = parallel.dp_rank_world()
+        total = None
+        for batch_index, indices in enumerate(dataloader):
+            if world > 1:                      # this rank's utterances of the global batch
+                indices = indices[:len(indices) - len(indices) % world][rank::world]
+            x, y, lens = shard.gather(indices)
+            n_local = float(lens.sum())
+            n_global = parallel.global_sum(n_local, device=x.device)
+            valid = torch.ones(x.shape[0], dtype=torch.uint8, device=x.device)
+            if training:
+                group = self.optimiser.param_groups[0]
+                loss = flat.train_step(x, y, valid, n_global, lr=group["lr"], betas=group["betas"],
+                                       eps=group["eps"], weight_decay=group["weight_decay"],
+                                       world_size=world)
+                total_steps += 1
+            else:
+                loss, _ = ops.masked_mse(flat.forward(x)[-1], y, valid, n_global, want_grad=False)
+            loss = parallel.allreduce_flat_(loss.clone())[0]
+            if torch.isnan(loss):
+                raise ValueError("Found NaN in {} loss.".format(loss_name))
+            if training:
+                current_iter = self._get_current_iteration(
+                    batch_index=batch_index, current_epoch=current_epoch,
+                    dataloader_length=len(dataloader), hparams=hparams, total_epoch=total_epoch)
+                self.run_scheduler(hparams=hparams, loss=loss, current_iter=current_iter)
+            total = loss if total is None else total + loss
+        return {loss_name: (total / len(dataloader)).cpu().numpy()}
 
     # -------------------------------------------------------------------------------- model
     def create_model(self, model_config, use_gpu=True):
@@ -407,6 +545,11 @@ class ModularModelHandlerPyTorch(object):
         the reference's in-process DataParallel -- every rank draws the same global batch, keeps
         its own samples, and the frame-count-weighted gradients are summed over RCCL, which
         reproduces the single-GPU step on the whole batch."""
+        if self._resident is not None and dataloader in (self.dataloader_train,
+                                                            self.dataloader_val):
+            key = "train" if dataloader is self.dataloader_train else "val"
+            return self._process_resident(dataloader, self._resident["shards"][key], hparams,
+                                          total_epoch, total_steps, current_epoch, training)
         model = self.model
         if training:
             model.train()
@@ -539,6 +682,7 @@ class ModularModelHandlerPyTorch(object):
     def inference(self, data, hparams, seq_lengths):
         """reference :964-993: eval mode, numpy / tensors in, numpy out (keys starting with '_'
         are dropped)."""
+        self._resident_sync_to_module()
         self.model.eval()
         to_torch = lambda v: torch.from_numpy(v) if isinstance(v, np.ndarray) else v  # noqa: E731
         device = self._device()
@@ -584,6 +728,7 @@ class ModularModelHandlerPyTorch(object):
             raise NotImplementedError()
         self.logger.info("Save {} checkpoint to {}.".format(suffix, model_path))
         os.makedirs(model_path, exist_ok=True)
+        self._resident_sync_to_module()
         config = self.model_config if self.model_config is not None \
             else getattr(self.model, "config", None)
         if config is not None:
@@ -659,6 +804,8 @@ class ModularModelHandlerPyTorch(object):
                 self._load_scheduler(sched["params"],
                                      epoch if epoch is not None else sched['epoch'],
                                      step if step is not None else sched['step'], hparams)
+        if self._resident is not None:
+            self._resident["synced"] = False      # flat buffers follow the loaded state
         return best_loss, epoch, step
 
     @staticmethod

@@ -131,3 +131,36 @@ def test_synth_wav_and_copy_synth(gpu, fixture):
     for i in ids[:2]:
         fs, wav = scipy.io.wavfile.read(os.path.join(hp.synth_dir, i + "_ref_20mcep_WORLD.wav"))
         assert fs == 16000 and np.abs(wav).max() > 1000          # real speech comes back
+
+
+def test_train_with_hbm_resident_shards_reproduces_reference_losses(gpu, fixture):
+    """hparams.resident_dataset: readers run once, the normalised frames live
+    in HBM as packed shards, the epochs run the flat feed-forward step on gathered mini-batches.
+    Same shuffling (same RNG stream), same arithmetic: the reference's per-epoch losses again."""
+    g = fixture[4]
+    hp = _hparams(fixture[0], fixture[2], "test_train_resident")
+    hp.seed = 1234
+    hp.use_best_as_final_model = False
+    hp.resident_dataset = True
+    trainer = _trainer(fixture, hp)
+    trainer.init(hp)
+    all_loss, all_loss_train, handler = trainer.train(hp)
+    np.testing.assert_allclose(all_loss["MSELoss_acoustic_features"], g["train_val_losses"],
+                               rtol=2e-5)
+    np.testing.assert_allclose(all_loss_train["MSELoss_acoustic_features"],
+                               g["train_train_losses"], rtol=2e-5)
+    sd = handler.model.state_dict()          # flat parameters were written back to the modules
+    for k in sd:
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g["train_final/" + k], rtol=0, atol=2e-5)
+    shard = handler._resident["shards"]["train"]
+    assert shard.x.is_cuda and shard.x.shape[1] == 412 and len(shard) == 7
+    # the saved checkpoint holds the trained weights and an optimiser state a module-path run can
+    # continue from
+    nn_dir = os.path.join(hp.out_dir, hp.model_name, hp.networks_dir)
+    ck = torch.load(os.path.join(nn_dir, "params_e3"), map_location="cpu", weights_only=False)
+    for k in sd:
+        assert torch.equal(ck["params"][k], sd[k].cpu())
+    opt = torch.load(os.path.join(nn_dir, "optimiser_e3"), map_location="cpu", weights_only=False)
+    assert len(opt["params"]["state"]) == 4 and opt["params"]["state"][0]["step"] == 12   # 4 batches x 3 epochs
+    scores = trainer.benchmark(hp)["pred_acoustic_features"]
+    assert np.isfinite(scores).all()

@@ -109,3 +109,30 @@ def test_packed_batch_matches_torch_packed_sequence():
                     assert hp[r, 0] == want_f and hp[r, 1] == want_r
     with pytest.raises(ValueError):
         PackedBatch([3, 0], 3, False, "cpu")
+
+
+def test_frame_shard_round_trip_and_gather(tmp_path):
+    from idiaptts_amd.src.data_preparation.FrameShard import FrameShard
+    rng = np.random.default_rng(0)
+    lens = (3, 7, 2, 5)
+    xs = [rng.normal(size=(t, 5)).astype(np.float32) for t in lens]
+    ys = [rng.normal(size=(t, 3)).astype(np.float32) for t in lens]
+    shard = FrameShard.from_arrays(xs, ys, ["a", "b", "c", "d"], {"norm": "min_max"})
+    assert shard.x.shape == (17, 8) and shard.y.shape == (17, 4)       # pitches padded to 4 floats
+    assert np.all(shard.x[:, 5:] == 0) and np.all(shard.y[:, 3:] == 0)
+    path = shard.save(str(tmp_path / "train.ittshard"))
+    for mmap in (True, False):
+        back = FrameShard.load(path, mmap=mmap)
+        assert back.ids == ["a", "b", "c", "d"] and back.meta == {"norm": "min_max"}
+        assert list(back.offsets) == [0, 3, 10, 12, 17] and list(back.lengths) == list(lens)
+        x, y, l = back.gather([3, 0, 1])
+        assert list(l) == [5, 3, 7]
+        assert np.array_equal(x[:, :5], np.concatenate([xs[3], xs[0], xs[1]]))
+        assert np.array_equal(y, np.concatenate([ys[3], ys[0], ys[1]]))
+    dev = shard.to("cpu")                      # torch-resident variant (the device path)
+    x, y, _ = dev.gather([2])
+    assert np.array_equal(x[:, :5].numpy(), xs[2]) and y.shape == (2, 3) and y.stride(0) == 4
+    with open(path, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        FrameShard.load(path)
