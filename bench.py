@@ -234,6 +234,43 @@ def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM", rank=0, world=1):
         "loss": ld["MSELoss_acoustic_features"]}}
 
 
+def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
+    """one epoch of the FF model over an HBM-resident FrameShard (synthetic,
+    LJSpeech-shaped utterances), mini-batches of `batch_utts` shuffled utterances gathered on the
+    device as packed valid frames, flat train step.  The rate includes the index upload and the
+    row gathers, i.e. everything the reference does per step between disk and optimiser."""
+    from idiaptts_amd.bench_support import utterance_lengths
+    from idiaptts_amd.native_ff import FlatFFModel
+    from idiaptts_amd.src.data_preparation.FrameShard import FrameShard
+    lengths = utterance_lengths(n_utts, seed=11)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    n = int(offsets[-1])
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.zeros((n, 428), dtype=torch.float32, device=dev)
+    x[:, :425] = torch.rand((n, 425), generator=g, device=dev)
+    y = torch.zeros((n, 188), dtype=torch.float32, device=dev)
+    y[:, :187] = torch.randn((n, 187), generator=g, device=dev)
+    shard = FrameShard(x, y, offsets, ["utt%05d" % i for i in range(n_utts)], 425, 187)
+    model = FlatFFModel((425, 512, 512, 187), ("tanh", "tanh", None), device=dev, seed=0)
+    order = torch.randperm(n_utts, generator=torch.Generator().manual_seed(5)).numpy()
+
+    def epoch():
+        for b in range(0, n_utts, batch_utts):
+            xb, yb, lens = shard.gather(order[b:b + batch_utts])
+            valid = torch.ones(xb.shape[0], dtype=torch.uint8, device=dev)
+            model.train_step(xb, yb, valid, float(lens.sum()), lr=1e-3)
+
+    epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"resident_epoch": {"utterances": n_utts, "frames": n, "batch_utts": batch_utts,
+                               "shard_GB": (x.numel() + y.numel()) * 4 / 1e9,
+                               "epoch_ms": dt * 1e3, "valid_frames_per_s": n / dt}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,6 +405,8 @@ def main():
                                        with_cpu=not args.no_cpu_baseline, with_mlpg=False,
                                        key="world_48k"))
         extra.update(rnn_extra)
+        if world == 1 and args.world_utts > 0:
+            extra.update(resident_epoch_section(dev))
         out = {
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
