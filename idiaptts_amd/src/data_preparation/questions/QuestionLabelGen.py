@@ -1,7 +1,9 @@
 """Reader side of the question labels (reference data_preparation/questions/QuestionLabelGen.py:
 load with the legacy raw-float32 fallback :119-131, min-max normalisation parameters with the
-legacy `.bin` fallback :133-149).  Generating question labels from HTK label files
-(label_normalisation.py) is SURVEY.md §8(f) row 2 and is not part of this class yet."""
+legacy `.bin` fallback :133-149) and their generation from HTK label files (gen_data :150-203,
+on top of questions/label_normalisation.py)."""
+import glob
+import logging
 import os
 
 import numpy as np
@@ -66,3 +68,65 @@ class QuestionLabelGen(ReaderBase):
     def postprocess_sample(self, sample, norm_params=None):
         min_, max_ = self.norm_params if norm_params is None else norm_params
         return sample * self._range(min_, max_) + min_
+
+    # ------------------------------------------------------------------------------ generation
+    @staticmethod
+    def gen_data(dir_in, file_questions, dir_out=None, file_id_list="", id_list=None,
+                 return_dict=False):
+        """Question labels from HTK full-context labels with state alignment (`<dir_in>/<id>.lab`):
+        one `<dir_out>/<id>.npz` {"questions": float32 [frames, n_questions + 9]} per id and the
+        min / max over all of them in `<dir_out>/<id list name>-min-max.npz`.  Returns
+        (min, max), preceded by an OrderedDict id -> labels when return_dict."""
+        from idiaptts_amd.src.data_preparation.questions.label_normalisation import \
+            HTSLabelNormalisation
+        if id_list is None:
+            id_list = [os.path.splitext(os.path.basename(f))[0]
+                       for f in glob.glob(os.path.join(dir_in, "*.lab"))]
+            file_id_list_name = "all"
+        else:
+            file_id_list_name = os.path.splitext(os.path.basename(file_id_list))[0]
+            id_list = ['{}'.format(os.path.basename(e)) for e in id_list]
+        if dir_out is not None:
+            os.makedirs(dir_out, exist_ok=True)
+        operator = HTSLabelNormalisation(file_questions)
+        out = operator.perform_normalisation(file_id_list_name, id_list, dir_in, dir_out,
+                                             return_dict=return_dict)
+        if return_dict:
+            return out[0], out[1][0], out[1][1]
+        return out[0], out[1]
+
+    @staticmethod
+    def questions_to_phoneme_indices(questions, np_phoneme_indices_in_question, default_index=-1):
+        """Index (within the given phoneme questions) of the phoneme of every frame; frames without
+        any phoneme get `default_index` (reference :216-241)."""
+        sub = questions[:, np_phoneme_indices_in_question]
+        indices = sub.argmax(axis=1)
+        no_phoneme = sub.max(axis=1) == 0
+        if no_phoneme.any():
+            logging.warning("Using default phoneme index {} for frames without phoneme "
+                            "information which are {}".format(default_index,
+                                                              np.flatnonzero(no_phoneme)))
+        indices[no_phoneme] = default_index
+        return indices
+
+    @staticmethod
+    def questions_to_phoneme_per_frame(questions, np_phoneme_indices_in_question_file,
+                                       question_file):
+        """Phoneme name of every frame, '?' where none is set (reference :243-278)."""
+        with open(question_file) as f:
+            lines = np.array(f.readlines())[np_phoneme_indices_in_question_file]
+        names = [l.split()[1].replace('C_', '').replace('C-', '').replace('\"', '') for l in lines]
+        idx = QuestionLabelGen.questions_to_phoneme_indices(
+            questions, np_phoneme_indices_in_question_file) + 1
+        return np.insert(np.array(names), 0, '?', axis=0)[idx]
+
+    @staticmethod
+    def questions_to_phonemes(questions, np_phoneme_indices_in_question_file, question_file):
+        """(first frame, phoneme) for every run of equal phonemes (reference :280-309)."""
+        per_frame = QuestionLabelGen.questions_to_phoneme_per_frame(
+            questions, np_phoneme_indices_in_question_file, question_file)
+        phonemes = [(0, per_frame[0])]
+        for index, phoneme in enumerate(per_frame):
+            if phonemes[-1][1] != phoneme:
+                phonemes.append((index, phoneme))
+        return np.array(phonemes)

@@ -136,3 +136,43 @@ def test_frame_shard_round_trip_and_gather(tmp_path):
         f.write(b"XXXX")
     with pytest.raises(ValueError):
         FrameShard.load(path)
+
+
+def test_question_labels_from_hts_labels_are_bit_exact(golden_dir, tmp_path):
+    """HTS full-context labels + question file -> the frame-level question labels
+    the reference's fixtures hold (test/integration/fixtures/questions/*.questions, generated by
+    its label_normalisation.py), bit for bit, and the min / max over them."""
+    import zipfile
+    from idiaptts_amd.src.data_preparation.questions.QuestionLabelGen import QuestionLabelGen
+    from idiaptts_amd.src.data_preparation.questions.label_normalisation import \
+        HTSLabelNormalisation, wildcards_to_regex
+    lab_dir = str(tmp_path / "lab")
+    zipfile.ZipFile(os.path.join(golden_dir, "labels_state_align.zip")).extractall(lab_dir)
+    qfile = os.path.join(golden_dir, "questions-en-radio_dnn_400.hed")
+    g = np.load(os.path.join(golden_dir, "trainer_fixture.npz"))
+    ids = [str(i) for i in g["id_list"]]
+    out_dir = str(tmp_path / "questions")
+    labels, qmin, qmax = QuestionLabelGen.gen_data(lab_dir, qfile, out_dir, "file_id_list.txt",
+                                                   ids, return_dict=True)
+    assert list(labels) == ids
+    for i in ids:
+        saved = np.load(os.path.join(out_dir, i + ".npz"))["questions"]
+        assert saved.dtype == np.float32 and np.array_equal(saved, g["questions/" + i]), i
+        assert np.array_equal(labels[i].astype(np.float32), saved)
+    mm = np.load(os.path.join(out_dir, "file_id_list-min-max.npz"))
+    ref = np.frombuffer(g["bin/questions/min-max.bin"].tobytes(), dtype=np.float64).reshape(2, -1)
+    assert np.array_equal(mm["min"], qmin) and np.array_equal(mm["max"], qmax)
+    assert np.array_equal(qmin, ref[0]) and np.array_equal(qmax, ref[1])
+    # the reader side reads what gen_data wrote
+    reader = QuestionLabelGen(out_dir, 409)
+    reader.get_normalisation_params(out_dir, "file_id_list")
+    x = reader[ids[1]]["questions"]
+    assert x.dtype == np.float32 and x.min() >= 0.0 and x.max() <= 1.0
+    # pattern translation: anchoring and the numeric capture group
+    assert wildcards_to_regex("*-aa+*") == r"\-aa\+"
+    assert wildcards_to_regex("aa~*") == r"\Aaa\~" and wildcards_to_regex("*|1") == r"\|1\Z"
+    assert wildcards_to_regex(r"@(\d+)_", True) == r"@(\d+)_"
+    h = HTSLabelNormalisation(qfile)
+    assert (h.dict_size, h.dimension) == (400, 409)
+    with pytest.raises(NotImplementedError):
+        HTSLabelNormalisation(qfile, subphone_feats="none")
