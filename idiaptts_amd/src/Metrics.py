@@ -12,6 +12,22 @@ class Metrics(object):
     F0_RMSE = "F0 RMSE"
     VDE = "VDE"
     BAP_distortion = "BAP distortion"
+    Dur_RMSE = "Dur RMSE"
+    Dur_pearson = "Dur pearson"
+
+    @staticmethod
+    def rmse(org, output, axis=None):
+        """sqrt(sum of squared errors / number of ROWS) (reference :165-171: with axis=None the sum
+        runs over all elements but the divisor stays the row count)."""
+        mse = (org - output) ** 2
+        return np.sqrt(mse.sum(axis=axis) / len(mse))
+
+    @staticmethod
+    def pearson(org, output):
+        """Pearson correlation per column (reference :173-175, scipy.stats.pearsonr)."""
+        o = org - org.mean(axis=0)
+        p = output - output.mean(axis=0)
+        return (o * p).sum(axis=0) / np.sqrt((o * o).sum(axis=0) * (p * p).sum(axis=0))
 
     @staticmethod
     def melcd(x, y):

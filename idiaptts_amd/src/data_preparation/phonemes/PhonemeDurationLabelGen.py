@@ -5,12 +5,52 @@ import os
 
 import numpy as np
 
+from idiaptts_amd.misc.normalisation.MeanStdDevExtractor import MeanStdDevExtractor
+from idiaptts_amd.src.data_preparation.DataReaders import ReaderBase
 
-class PhonemeDurationLabelGen(object):
+
+class PhonemeDurationLabelGen(ReaderBase):
     dir_labels = "dur"
     ext_durations = ".dur"
     num_states = 5
     min_length = 50000  # one 5 ms frame in HTK 100 ns units
+
+    def __init__(self, dir_labels=None, norm_type="mean_stddev", load_as_matrix=False, **kwargs):
+        """Reader over `<dir_labels>/<id>.npz` ('dur') or legacy raw-float32 `.dur` files with
+        mean / std-dev normalisation (reference :40-125); `load_as_matrix` returns the hard
+        attention matrix of the summed state durations instead (never normalised)."""
+        self.directory = dir_labels
+        self.load_as_matrix = load_as_matrix
+        self.norm_type = None if load_as_matrix else norm_type
+        self.norm_params = None
+        self._configure("durations")
+
+    def load(self, id_name):
+        sample = self.load_sample(id_name, self.directory)
+        return self.convert_to_matrix(sample) if self.load_as_matrix else sample
+
+    def get_normalisation_params(self, dir_out=None, file_name=None):
+        """(mean, std_dev): `<dir>/[<name>-]mean-std_dev.npz` or the legacy `.bin`."""
+        if self.norm_type is None:
+            return None
+        directory = self.directory if dir_out is None else dir_out
+        prefix = "" if file_name is None or os.path.basename(file_name) == "" else file_name + "-"
+        base = os.path.join(directory, prefix + MeanStdDevExtractor.file_name_appendix)
+        self.norm_params = MeanStdDevExtractor.load(base + (".npz" if os.path.isfile(base + ".npz")
+                                                            else ".bin"))
+        return self.norm_params
+
+    def preprocess_sample(self, sample):
+        if self.norm_type is None:
+            return sample
+        mean, std_dev = self.norm_params
+        return ((sample - mean) / std_dev).astype(np.float32, copy=False)
+
+    def postprocess_sample(self, sample):
+        if self.norm_type is None:
+            return sample
+        mean, std_dev = self.norm_params
+        return sample * std_dev + mean
 
     @staticmethod
     def _get_full_state_align_dur(file_path, min_length: int = 50000, num_states: int = 5):
@@ -52,7 +92,6 @@ class PhonemeDurationLabelGen(object):
 
     @staticmethod
     def gen_data(dir_in, dir_out, id_list, label_ext=".lab", return_dict=False):
-        from ....misc.normalisation.MeanStdDevExtractor import MeanStdDevExtractor
         norm = MeanStdDevExtractor()
         out = {}
         for name in id_list:

@@ -321,6 +321,40 @@ def capture_trainer_fixture():
     print("trainer_fixture.npz:", os.path.getsize(os.path.join(HERE, "trainer_fixture.npz")), "bytes")
 
 
+def capture_duration_fixture():
+    """Data the reference's (commented-out) duration-trainer tests read -- fixtures/dur/*.dur with
+    mean-std_dev.bin, labels/mono_no_align/*.lab, labels/mono_phone.list -- and what the
+    reference's PhonemeLabelGen returns for both label layouts."""
+    from idiaptts.src.data_preparation.phonemes.PhonemeLabelGen import PhonemeLabelGen
+    import idiaptts.src.Metrics as ref_metrics
+    import scipy.stats
+    with open(os.path.join(FIX, "database", "file_id_list.txt")) as f:
+        id_list = [s.strip() for s in f.readlines()]
+    out = {"id_list": np.array(id_list)}
+    with open(os.path.join(FIX, "labels", "mono_phone.list")) as f:
+        out["mono_phone_list"] = np.array(f.read())
+    out["bin/dur/mean-std_dev.bin"] = np.fromfile(os.path.join(FIX, "dur", "mean-std_dev.bin"), dtype=np.uint8)
+    symbol_dict = PhonemeLabelGen.get_symbol_dict(os.path.join(FIX, "labels", "mono_phone.list"))
+    out["symbols"] = np.array(list(symbol_dict.keys()))
+    out["symbol_ids"] = np.array(list(symbol_dict.values()))
+    for i in id_list:
+        out["dur/" + i] = np.fromfile(os.path.join(FIX, "dur", i + ".dur"), dtype=np.float32).reshape(-1, 5)
+        with open(os.path.join(FIX, "labels", "mono_no_align", i + ".lab")) as f:
+            out["mono_no_align/" + i] = np.array(f.read())
+        for ltype, sub in (("full_state_align", "label_state_align"), ("mono_no_align", "mono_no_align")):
+            ids = PhonemeLabelGen.load_sample(i, os.path.join(FIX, "labels", sub), symbol_dict, ltype)
+            out["ids_%s/%s" % (ltype, i)] = np.asarray(ids)
+    rng = np.random.default_rng(3)
+    a, b = rng.normal(size=(40, 5)), rng.normal(size=(40, 5))
+    ref_metrics.scipy = sys.modules.get("scipy", __import__("scipy"))
+    out["metric_a"], out["metric_b"] = a, b
+    out["metric_rmse"] = ref_metrics.Metrics.rmse(a, b)
+    out["metric_pearson"] = np.array([scipy.stats.pearsonr(a[:, k], b[:, k])[0] for k in range(5)])
+    np.savez_compressed(os.path.join(HERE, "duration_fixture.npz"), **out)
+    print("duration_fixture.npz:", os.path.getsize(os.path.join(HERE, "duration_fixture.npz")), "bytes;",
+          len(symbol_dict), "symbols")
+
+
 def _main():
     copy_data_fixtures()
     install_stub_harness()
@@ -332,6 +366,9 @@ def _main():
         return
     if "--trainer" in sys.argv:
         capture_trainer_fixture()
+        return
+    if "--duration" in sys.argv:
+        capture_duration_fixture()
         return
     capture_host_logic()
     capture_benchmark_kat()

@@ -176,3 +176,49 @@ def test_question_labels_from_hts_labels_are_bit_exact(golden_dir, tmp_path):
     assert (h.dict_size, h.dimension) == (400, 409)
     with pytest.raises(NotImplementedError):
         HTSLabelNormalisation(qfile, subphone_feats="none")
+
+
+def test_phoneme_and_duration_readers_match_reference(golden_dir, tmp_path):
+    """Config 4 inputs: PhonemeLabelGen ids for both label layouts equal what the reference's
+    reader returned (tests/golden/make_golden.py --duration); the duration reader reads the
+    legacy fixtures, normalises with the legacy mean-std_dev.bin and regenerates the same
+    durations from the state-aligned labels."""
+    from fixture_dirs import materialise_duration
+    from idiaptts_amd.src.Metrics import Metrics
+    from idiaptts_amd.src.data_preparation.phonemes.PhonemeDurationLabelGen import \
+        PhonemeDurationLabelGen
+    from idiaptts_amd.src.data_preparation.phonemes.PhonemeLabelGen import PhonemeLabelGen
+    root = str(tmp_path)
+    ids, g = materialise_duration(golden_dir, root)
+    plist = os.path.join(root, "labels", "mono_phone.list")
+    sd = PhonemeLabelGen.get_symbol_dict(plist)
+    assert list(sd.keys()) == [str(s) for s in g["symbols"]] and sd["EOF"] == len(sd) - 1
+    for ltype, sub in (("full_state_align", "label_state_align"), ("mono_no_align", "mono_no_align")):
+        reader = PhonemeLabelGen(os.path.join(root, "labels", sub), plist, label_type=ltype,
+                                 one_hot=True)
+        for i in ids:
+            raw = reader.load(i)
+            assert raw.dtype == np.int64 and np.array_equal(raw, g["ids_%s/%s" % (ltype, i)])
+            oh = reader[i]["phonemes"]
+            assert oh.shape == (len(raw), len(sd)) and np.array_equal(oh.argmax(1), raw[:, 0])
+    with pytest.raises(AssertionError):
+        PhonemeLabelGen(os.path.join(root, "labels", "label_state_align"), plist,
+                        label_type="HTK full").load(ids[0])
+    eof = PhonemeLabelGen(os.path.join(root, "labels", "mono_no_align"), plist,
+                          label_type="mono_no_align", add_EOF=True)
+    x = eof[ids[0]]["phonemes"]
+    assert x[-1, 0] == sd["EOF"] and np.array_equal(eof.postprocess_sample(x), x[:-1])
+    # durations: legacy files, legacy normalisation parameters, regeneration from labels
+    dreader = PhonemeDurationLabelGen(os.path.join(root, "dur"))
+    mean, std = dreader.get_normalisation_params()
+    assert mean.shape[-1] == 5 and std.shape[-1] == 5
+    for i in ids:
+        d = dreader.load(i)
+        assert np.array_equal(d, g["dur/" + i])
+        gen = PhonemeDurationLabelGen._get_full_state_align_dur(
+            os.path.join(root, "labels", "label_state_align", i + ".lab"))
+        assert np.array_equal(gen, d)
+        n = dreader[i]["durations"]
+        assert n.dtype == np.float32 and np.allclose(dreader.postprocess_sample(n), d, atol=1e-5)
+    assert np.array_equal(Metrics.rmse(g["metric_a"], g["metric_b"]), g["metric_rmse"])
+    assert np.abs(Metrics.pearson(g["metric_a"], g["metric_b"]) - g["metric_pearson"]).max() < 1e-12
