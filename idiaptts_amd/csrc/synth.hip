@@ -17,6 +17,7 @@
 // PARITY: the reference has no golden waveform; checked against oracle/c/synth.c.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -140,6 +141,122 @@ __global__ __launch_bounds__(64) void syn_phase_seq_kernel(const SynUtt* __restr
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 64) a[base + i] = fmod(buf[i], 2.0 * kPi);
     __syncthreads();
+  }
+}
+
+// K3': the same running sum, bit for bit, as a parallel scan.
+// While the total stays inside one binade [2^e, 2^(e+1)) it is a multiple of u = 2^(e-52) and
+// fl(total + d) is again a multiple of u: total + u * R, where R is d / u rounded to an integer --
+// ties going to whichever neighbour makes the SUM even.  In units of u the chain is therefore
+// exact integer arithmetic:  S -> S + I + [f > 1/2]            (d / u = I + f, no tie)
+//                            S -> S + I + ((S + I) mod 2)      (f = 1/2: round half to even)
+// Both are maps of the form S -> S + a[S mod 2]; such pairs (a[0], a[1]) compose associatively,
+// (a o b)[p] = a[p] + b[(p + a[p]) mod 2], so a wave scans 1024 samples at once.  The scan stops at
+// the first sample whose sum leaves the binade (S >= 2^53); that one addition is done in floating
+// point (its rounding grid is the next binade's), then the scan resumes there.  A 10 s utterance
+// crosses ~20 binades.  Verified bit-identical to syn_phase_seq_kernel (tests/test_gpu_world.py).
+struct PhaseMap {
+  unsigned long long a0, a1;   // addend for even / odd S (unsigned: sums past the cut may wrap)
+};
+__device__ __forceinline__ PhaseMap phase_compose(const PhaseMap f, const PhaseMap g) {   // g after f
+  PhaseMap r;
+  r.a0 = f.a0 + ((f.a0 & 1) ? g.a1 : g.a0);
+  r.a1 = f.a1 + (((1 + f.a1) & 1) ? g.a1 : g.a0);
+  return r;
+}
+constexpr unsigned long long kBinadeTop = 1ull << 53;
+
+__global__ __launch_bounds__(64) void syn_phase_scan_kernel(const SynUtt* __restrict__ utts,
+                                                            double* __restrict__ inc_wrap) {
+  constexpr int PER = 16, BLK = 64 * PER;
+  const SynUtt u = utts[blockIdx.x];
+  double* a = inc_wrap + u.s_off;
+  const int lane = threadIdx.x;
+  double total = 0.0;      // wave-uniform running sum (value after sample `pos - 1`)
+  int pos = 0;
+  while (pos < u.yl) {
+    // a total of zero or a sample that does not fit the integer picture: plain addition
+    int ex;
+    frexp(total, &ex);                       // total = m * 2^ex, m in [0.5, 1)
+    const int e = ex - 1;
+    const double first = a[pos];
+    if (!(total > 0.0) || !(first < ldexp(1.0, e + 2)) || !(first >= 0.0) || e < -900) {
+      total = __dadd_rn(total, first);
+      if (lane == 0) a[pos] = fmod(total, 2.0 * kPi);
+      ++pos;
+      continue;
+    }
+    const unsigned long long S0 = (unsigned long long)ldexp(total, 52 - e);   // in [2^52, 2^53)
+    // per-lane maps of PER consecutive samples
+    double d[PER];
+    PhaseMap m[PER];
+    PhaseMap agg = {0, 0};
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = pos + lane * PER + r;
+      d[r] = i < u.yl ? a[i] : 0.0;
+      const double x = ldexp(d[r], 52 - e);                         // exact: d / u
+      const bool fits = d[r] >= 0.0 && d[r] < ldexp(1.0, e + 2);    // else: forces the crossing path
+      const double fl = floor(x);
+      const double f = x - fl;                                      // exact
+      const unsigned long long I = fits ? (unsigned long long)fl : kBinadeTop;
+      if (f == 0.5 && fits) {
+        m[r].a0 = I + (I & 1);
+        m[r].a1 = I + ((I + 1) & 1);
+      } else {
+        m[r].a0 = m[r].a1 = I + (f > 0.5 ? 1 : 0);
+      }
+      agg = r == 0 ? m[0] : phase_compose(agg, m[r]);
+    }
+    // exclusive scan of the lane aggregates over the wave
+    PhaseMap inc = agg;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      PhaseMap o;
+      o.a0 = (unsigned long long)__shfl_up((long long)inc.a0, off);
+      o.a1 = (unsigned long long)__shfl_up((long long)inc.a1, off);
+      if (lane >= off) inc = phase_compose(o, inc);
+    }
+    PhaseMap ex_map;
+    ex_map.a0 = (unsigned long long)__shfl_up((long long)inc.a0, 1);
+    ex_map.a1 = (unsigned long long)__shfl_up((long long)inc.a1, 1);
+    if (lane == 0) ex_map.a0 = ex_map.a1 = 0;
+    // walk the lane's samples from its entry value; find the first that leaves the binade
+    unsigned long long S = S0 + ((S0 & 1) ? ex_map.a1 : ex_map.a0);
+    unsigned long long vals[PER];
+    int first_out = PER;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      S += (S & 1) ? m[r].a1 : m[r].a0;
+      vals[r] = S;
+      if (first_out == PER && (S >= kBinadeTop || pos + lane * PER + r >= u.yl)) first_out = r;
+    }
+    // (an overflowed lane poisons the lanes behind it, which is fine: they are past the cut)
+    const int my_cut = first_out < PER ? lane * PER + first_out : BLK;   // block-local index, BLK = none
+    int cut = my_cut;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cut = min(cut, __shfl_xor(cut, off));
+    const int n_ok = min(cut, min(BLK, u.yl - pos));               // samples pos .. pos+n_ok-1 are final
+    double last_total = total;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int li = lane * PER + r;
+      if (li < n_ok) {
+        const double t = ldexp((double)vals[r], e - 52);           // exact
+        a[pos + li] = fmod(t, 2.0 * kPi);
+        if (li == n_ok - 1) last_total = t;
+      }
+    }
+    if (n_ok > 0) {
+      const int owner = (n_ok - 1) / PER;
+      total = __shfl(last_total, owner);
+    }
+    pos += n_ok;
+    if (pos < u.yl && n_ok < BLK) {      // the sample that crosses the binade: one real addition
+      total = __dadd_rn(total, a[pos]);
+      if (lane == 0) a[pos] = fmod(total, 2.0 * kPi);
+      ++pos;
+    }
   }
 }
 
@@ -585,7 +702,11 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   const dim3 gblk(max_nblk, n_utts);
   hipLaunchKernelGGL(syn_inc_kernel, gblk, dim3(NT), 0, s, d_f0, d_utts, p, d_wrap, d_vuv, d_bs);
   ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syn_phase_seq_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
+  const bool seq_phase = getenv("ITTS_SYNTH_SEQ_PHASE") != nullptr;   // A/B switch for the tests
+  if (seq_phase)
+    hipLaunchKernelGGL(syn_phase_seq_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
+  else
+    hipLaunchKernelGGL(syn_phase_scan_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
   ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(syn_pulse_count_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc);
   ITTS_LAUNCH_CHECK();

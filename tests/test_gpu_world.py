@@ -268,3 +268,43 @@ def test_synthesis_48k(gpu):
                                     dtype=torch.float64)
     assert y_off[-1] == len(ref)
     assert np.sqrt(np.mean((y.cpu().numpy() - ref.astype(np.float32)) ** 2)) < 1e-7
+
+
+def test_parallel_phase_scan_is_bit_identical_to_the_sequential_chain(gpu):
+    """WORLD's pulse positions hang on the sequential rounding of the running phase sum
+    (synthesis.cpp GetTemporalParametersForTimeBase); the scan kernel reproduces that chain exactly
+    in integer units of the current ulp (ties, binade crossings).  Whole waveforms from the scan
+    and from the strictly sequential kernel (ITTS_SYNTH_SEQ_PHASE) must be the same bits, on
+    contours that exercise long unvoiced runs (constant 500 Hz: the sum hits multiples of 2 pi),
+    random voiced contours and very short utterances."""
+    from idiaptts_amd import ops
+    rng = np.random.default_rng(11)
+    fs, K = 16000, 513
+    f0s = []
+    for T in (2, 3, 7, 400, 1500, 2000):
+        f0 = np.clip(150 + np.cumsum(rng.normal(0, 3, T)), 60, 400)
+        unv = np.zeros(T, dtype=bool)
+        p = 0
+        while p < T:
+            seg = int(rng.integers(5, 120))
+            if rng.uniform() < 0.45:
+                unv[p:p + seg] = True
+            p += seg
+        f0[unv] = 0.0
+        f0s.append(f0)
+    f0s.append(np.zeros(900))                       # all unvoiced
+    f0s.append(np.full(900, 71.0))                  # lowest F0, all voiced
+    f_off = np.concatenate([[0], np.cumsum([len(f) for f in f0s])]).tolist()
+    n = f_off[-1]
+    sp = torch.from_numpy(np.abs(rng.normal(1e-3, 2e-4, size=(n, K))) + 1e-5).to(gpu)
+    ap = torch.from_numpy(rng.uniform(0.01, 0.95, size=(n, K))).to(gpu)
+    f0 = torch.from_numpy(np.concatenate(f0s)).to(gpu)
+    os.environ.pop("ITTS_SYNTH_SEQ_PHASE", None)
+    y_scan, y_off = ops.world_synthesize(f0, sp, ap, f_off, fs, dtype=torch.float64)
+    os.environ["ITTS_SYNTH_SEQ_PHASE"] = "1"
+    try:
+        y_seq, _ = ops.world_synthesize(f0, sp, ap, f_off, fs, dtype=torch.float64)
+    finally:
+        os.environ.pop("ITTS_SYNTH_SEQ_PHASE", None)
+    assert torch.isfinite(y_scan).all() and y_scan.abs().max() > 0
+    assert torch.equal(y_scan, y_seq)
