@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void syn_phase_seq_kernel(const SynUtt* __restr
 // exact integer arithmetic:  S -> S + I + [f > 1/2]            (d / u = I + f, no tie)
 //                            S -> S + I + ((S + I) mod 2)      (f = 1/2: round half to even)
 // Both are maps of the form S -> S + a[S mod 2]; such pairs (a[0], a[1]) compose associatively,
-// (a o b)[p] = a[p] + b[(p + a[p]) mod 2], so a wave scans 1024 samples at once.  The scan stops at
+// (a o b)[p] = a[p] + b[(p + a[p]) mod 2], so a workgroup scans 4096 samples at once.  The scan stops at
 // the first sample whose sum leaves the binade (S >= 2^53); that one addition is done in floating
 // point (its rounding grid is the next binade's), then the scan resumes there.  A 10 s utterance
 // crosses ~20 binades.  Verified bit-identical to syn_phase_seq_kernel (tests/test_gpu_world.py).
@@ -166,37 +166,79 @@ __device__ __forceinline__ PhaseMap phase_compose(const PhaseMap f, const PhaseM
 }
 constexpr unsigned long long kBinadeTop = 1ull << 53;
 
-__global__ __launch_bounds__(64) void syn_phase_scan_kernel(const SynUtt* __restrict__ utts,
+// fmod(t, y) for 0 <= t < 2^20, y = double(2 pi): the quotient estimate is off by at most one and
+// every candidate remainder t - q y is a multiple of ulp(y) below 8, hence exactly representable:
+// the fma and the one-step correction are exact, the result is the exact remainder like fmod's.
+__device__ __forceinline__ double fmod_2pi(double t) {
+  constexpr double y = 2.0 * kPi;
+  const double q = floor(t * (1.0 / y));
+  double r = fma(-q, y, t);
+  if (r < 0.0) r += y;
+  else if (r >= y) r -= y;
+  return r;
+}
+
+// One 256-thread workgroup per utterance, 4096 samples per round: the round's increments are
+// staged in LDS by coalesced loads (the next round's are already in flight), thread t owns the 16
+// consecutive samples 16 t .. 16 t + 15.
+__global__ __launch_bounds__(NT) void syn_phase_scan_kernel(const SynUtt* __restrict__ utts,
                                                             double* __restrict__ inc_wrap) {
-  constexpr int PER = 16, BLK = 64 * PER;
+  constexpr int PER = 16, BLK = NT * PER;
+  __shared__ double buf[BLK + 1];
+  __shared__ PhaseMap wagg[4];
+  __shared__ int wcut[4];
+  __shared__ double s_total;
   const SynUtt u = utts[blockIdx.x];
   double* a = inc_wrap + u.s_off;
-  const int lane = threadIdx.x;
-  double total = 0.0;      // wave-uniform running sum (value after sample `pos - 1`)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double total = 0.0;      // uniform running sum (value after sample `pos - 1`)
   int pos = 0;
+  int have = -1;           // first sample of the increments held in `pre` (prefetched), or -1
+  double pre[PER];
   while (pos < u.yl) {
-    // a total of zero or a sample that does not fit the integer picture: plain addition
+    // stage samples pos .. pos + BLK (one extra: the sample a binade crossing would need)
+    if (have == pos) {
+#pragma unroll
+      for (int r = 0; r < PER; ++r) buf[r * NT + tid] = pre[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < PER; ++r) {
+        const int i = pos + r * NT + tid;
+        buf[r * NT + tid] = i < u.yl ? a[i] : 0.0;
+      }
+    }
+    // next round's increments (used if this round ends without a crossing)
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = pos + BLK + r * NT + tid;
+      pre[r] = i < u.yl ? a[i] : 0.0;
+    }
+    have = pos + BLK;
+    __syncthreads();
+
     int ex;
     frexp(total, &ex);                       // total = m * 2^ex, m in [0.5, 1)
     const int e = ex - 1;
-    const double first = a[pos];
+    const double first = buf[0];
     if (!(total > 0.0) || !(first < ldexp(1.0, e + 2)) || !(first >= 0.0) || e < -900) {
+      // a total of zero or a sample that does not fit the integer picture: plain addition
       total = __dadd_rn(total, first);
-      if (lane == 0) a[pos] = fmod(total, 2.0 * kPi);
+      if (tid == 0) a[pos] = fmod(total, 2.0 * kPi);
       ++pos;
+      have = -1;
+      __syncthreads();
       continue;
     }
-    const unsigned long long S0 = (unsigned long long)ldexp(total, 52 - e);   // in [2^52, 2^53)
-    // per-lane maps of PER consecutive samples
-    double d[PER];
+    const double up = ldexp(1.0, 52 - e), down = ldexp(1.0, e - 52);           // exact scalings by u
+    const double dmax = ldexp(1.0, e + 2);
+    const unsigned long long S0 = (unsigned long long)(total * up);            // in [2^52, 2^53)
     PhaseMap m[PER];
     PhaseMap agg = {0, 0};
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
-      const int i = pos + lane * PER + r;
-      d[r] = i < u.yl ? a[i] : 0.0;
-      const double x = ldexp(d[r], 52 - e);                         // exact: d / u
-      const bool fits = d[r] >= 0.0 && d[r] < ldexp(1.0, e + 2);    // else: forces the crossing path
+      const double d = buf[tid * PER + r];
+      const double x = d * up;                                      // exact: d / u
+      const bool fits = d >= 0.0 && d < dmax;                       // else: forces the crossing path
       const double fl = floor(x);
       const double f = x - fl;                                      // exact
       const unsigned long long I = fits ? (unsigned long long)fl : kBinadeTop;
@@ -208,7 +250,7 @@ __global__ __launch_bounds__(64) void syn_phase_scan_kernel(const SynUtt* __rest
       }
       agg = r == 0 ? m[0] : phase_compose(agg, m[r]);
     }
-    // exclusive scan of the lane aggregates over the wave
+    // inclusive scan of the thread aggregates inside the wave, then across the four waves
     PhaseMap inc = agg;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -217,11 +259,16 @@ __global__ __launch_bounds__(64) void syn_phase_scan_kernel(const SynUtt* __rest
       o.a1 = (unsigned long long)__shfl_up((long long)inc.a1, off);
       if (lane >= off) inc = phase_compose(o, inc);
     }
+    if (lane == 63) wagg[wv] = inc;
     PhaseMap ex_map;
     ex_map.a0 = (unsigned long long)__shfl_up((long long)inc.a0, 1);
     ex_map.a1 = (unsigned long long)__shfl_up((long long)inc.a1, 1);
     if (lane == 0) ex_map.a0 = ex_map.a1 = 0;
-    // walk the lane's samples from its entry value; find the first that leaves the binade
+    __syncthreads();
+    PhaseMap wpre = {0, 0};
+    for (int w = 0; w < wv; ++w) wpre = phase_compose(wpre, wagg[w]);
+    ex_map = phase_compose(wpre, ex_map);
+    // walk the thread's samples from its entry value; find the first that leaves the binade
     unsigned long long S = S0 + ((S0 & 1) ? ex_map.a1 : ex_map.a0);
     unsigned long long vals[PER];
     int first_out = PER;
@@ -229,34 +276,44 @@ __global__ __launch_bounds__(64) void syn_phase_scan_kernel(const SynUtt* __rest
     for (int r = 0; r < PER; ++r) {
       S += (S & 1) ? m[r].a1 : m[r].a0;
       vals[r] = S;
-      if (first_out == PER && (S >= kBinadeTop || pos + lane * PER + r >= u.yl)) first_out = r;
+      if (first_out == PER && (S >= kBinadeTop || pos + tid * PER + r >= u.yl)) first_out = r;
     }
-    // (an overflowed lane poisons the lanes behind it, which is fine: they are past the cut)
-    const int my_cut = first_out < PER ? lane * PER + first_out : BLK;   // block-local index, BLK = none
-    int cut = my_cut;
+    // (a thread past the cut may hold wrapped garbage, which is fine: it is past the cut)
+    int cut = first_out < PER ? tid * PER + first_out : BLK;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cut = min(cut, __shfl_xor(cut, off));
+    if (lane == 0) wcut[wv] = cut;
+    __syncthreads();
+    cut = min(min(wcut[0], wcut[1]), min(wcut[2], wcut[3]));
     const int n_ok = min(cut, min(BLK, u.yl - pos));               // samples pos .. pos+n_ok-1 are final
-    double last_total = total;
+    const double crossing_inc = buf[n_ok < BLK ? n_ok : 0];        // read before buf is overwritten
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
-      const int li = lane * PER + r;
+      const int li = tid * PER + r;
       if (li < n_ok) {
-        const double t = ldexp((double)vals[r], e - 52);           // exact
-        a[pos + li] = fmod(t, 2.0 * kPi);
-        if (li == n_ok - 1) last_total = t;
+        const double t = (double)vals[r] * down;                   // exact
+        buf[li] = t < 1048576.0 ? fmod_2pi(t) : fmod(t, 2.0 * kPi);
+        if (li == n_ok - 1) s_total = t;
       }
     }
-    if (n_ok > 0) {
-      const int owner = (n_ok - 1) / PER;
-      total = __shfl(last_total, owner);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int li = r * NT + tid;
+      if (li < n_ok) a[pos + li] = buf[li];
     }
+    if (n_ok > 0) total = s_total;
     pos += n_ok;
-    if (pos < u.yl && n_ok < BLK) {      // the sample that crosses the binade: one real addition
-      total = __dadd_rn(total, a[pos]);
-      if (lane == 0) a[pos] = fmod(total, 2.0 * kPi);
-      ++pos;
+    if (n_ok < BLK) {
+      have = -1;                         // the prefetched round no longer lines up
+      if (pos < u.yl) {                  // the sample that crosses the binade: one real addition
+        total = __dadd_rn(total, crossing_inc);
+        if (tid == 0) a[pos] = fmod(total, 2.0 * kPi);
+        ++pos;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -706,7 +763,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   if (seq_phase)
     hipLaunchKernelGGL(syn_phase_seq_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
   else
-    hipLaunchKernelGGL(syn_phase_scan_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
+    hipLaunchKernelGGL(syn_phase_scan_kernel, dim3(n_utts), dim3(NT), 0, s, d_utts, d_wrap);
   ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(syn_pulse_count_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc);
   ITTS_LAUNCH_CHECK();
