@@ -507,7 +507,7 @@ using namespace itts;
 extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
                                float* d_y, int64_t ldy, int64_t M, int N, int K, int act,
                                void* stream) {
-  ITTS_REQUIRE(d_x && d_w && d_y, "null pointer");
+  ITTS_REQUIRE(d_w && (M == 0 || (d_x && d_y)), "null pointer");
   ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, "bad sizes");
   ITTS_REQUIRE(act >= 0 && act <= 2, "unknown activation");
   if (M == 0) return ITTS_OK;
@@ -536,7 +536,7 @@ extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const floa
                                      float* d_dx, int64_t lddx, const float* d_yprev,
                                      int64_t ldyp, int act_prev, int64_t M, int N, int K,
                                      void* stream) {
-  ITTS_REQUIRE(d_dz && d_w && d_dx, "null pointer");
+  ITTS_REQUIRE(d_w && (M == 0 || (d_dz && d_dx)), "null pointer");
   ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && lddz >= N && lddx >= K, "bad sizes");
   if (M == 0) return ITTS_OK;
   // dx[M,K] = dz[M,N] (row form, reduction N) x w[N,K] (col form: [k=N][out=K])
@@ -562,7 +562,7 @@ extern "C" int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
 extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x,
                                       int64_t ldx, float* d_dw, float* d_db, int64_t M, int N,
                                       int K, void* d_workspace, int accumulate, void* stream) {
-  ITTS_REQUIRE(d_dz && d_x && d_dw && d_workspace, "null pointer");
+  ITTS_REQUIRE(d_dw && d_workspace && (M == 0 || (d_dz && d_x)), "null pointer");
   ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && lddz >= N && ldx >= K, "bad sizes");
   hipStream_t s = as_stream(stream);
   if (M == 0) {

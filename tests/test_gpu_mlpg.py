@@ -17,6 +17,8 @@ def _case(rng, lengths, dim, extra_cols=0, col0=0):
 @pytest.mark.parametrize("lengths,dim,col0", [
     ([1], 3, 0), ([2], 3, 0), ([3, 1, 2], 5, 0), ([4, 7, 300], 60, 0), ([1931], 20, 0),
     ([50, 0, 75], 1, 2), ([640, 1300], 62, 1),
+    # time-parallel path: utterance lengths around the 64-frame chunk boundaries, mixed with short ones
+    ([194, 195, 257, 258, 259, 130, 66, 3, 1, 322], 4, 0), ([193, 2], 2, 0), ([4098], 1, 0),
 ])
 def test_mlpg_matches_oracle(gpu, lengths, dim, col0):
     from idiaptts_amd import ops

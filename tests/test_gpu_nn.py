@@ -143,3 +143,41 @@ def test_ff_train_steps_match_reference_stack(gpu):
     for i, lin in enumerate(lins):
         assert (model.weight(i).cpu() - lin.weight.detach()).abs().max().item() < 2e-6
         assert (model.bias(i).cpu() - lin.bias.detach()).abs().max().item() < 2e-6
+
+
+def test_degenerate_sizes_and_error_reporting(gpu):
+    """Edge cases through the C ABI: empty batches are no-ops (or zero the gradients), bad
+    arguments come back as IttsError with the library's message (no crash, no silent fallback)."""
+    from idiaptts_amd import lib, ops
+    w = torch.randn(5, 8, device=gpu)
+    b = torch.randn(5, device=gpu)
+    empty = torch.empty((0, 8), device=gpu)
+    assert ops.linear_fwd(empty, w, b, 1).shape == (0, 5)
+    dz = torch.empty((0, 5), device=gpu)
+    assert ops.linear_bwd_input(dz, w).shape == (0, 8)
+    dw, db = ops.linear_bwd_weight(dz, empty)
+    assert float(dw.abs().sum()) == 0.0 and float(db.abs().sum()) == 0.0
+    # one frame, one column
+    y = ops.linear_fwd(torch.ones((1, 1), device=gpu), torch.full((1, 1), 2.0, device=gpu),
+                       torch.full((1,), 0.5, device=gpu), 0)
+    assert float(y) == 2.5
+    with pytest.raises(ValueError):
+        ops.linear_fwd(torch.randn(3, 7, device=gpu), w, b)             # K mismatch
+    with pytest.raises(lib.IttsError) as e:
+        ops.mlpg_generation(torch.zeros((4, 2), dtype=torch.float64, device=gpu),
+                            torch.ones(3, dtype=torch.float64, device=gpu), 1, [0, 4])
+    assert "leading dimension" in str(e.value)
+    from idiaptts_amd.nn.functional import PackedBatch
+    with pytest.raises(ValueError):
+        PackedBatch([3, 5], 4, False, gpu)                                # length beyond the padding
+    # recurrent entry points refuse unsorted lengths instead of computing garbage
+    L = lib.load()
+    import ctypes
+    hl = (ctypes.c_int * 2)(2, 3)
+    dummy = torch.zeros(64, device=gpu)
+    rc = L.itts_lstm_layer_fwd(ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(dummy.data_ptr()),
+                               None, None, ctypes.c_void_p(dummy.data_ptr()), hl,
+                               ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(dummy.data_ptr()),
+                               3, 2, 16, 1, ctypes.c_void_p(dummy.data_ptr()), None, None, None, None,
+                               ctypes.c_void_p(dummy.data_ptr()), None)
+    assert rc != 0 and b"longest" in L.itts_last_error()
