@@ -2,6 +2,7 @@
 // matrices).  Created lazily on the first GPU call of a device; never touched before that, so
 // forked DataLoader workers do not inherit an initialised HIP runtime.
 #pragma once
+#include <cstdint>
 #include <map>
 #include <tuple>
 
@@ -19,9 +20,43 @@ struct FreqtTables {
   double alpha = 0;
 };
 
+// WORLD's randn() is a xorshift128 stream (fixed seed per CheapTrick / Synthesis call) consumed in
+// order; the kernels generate it out of order: one lane produces RNG_CHUNK consecutive normals
+// from a state jumped ahead with GF(2) matrices B^(2^k), B = 12 * RNG_CHUNK generator steps.
+constexpr int RNG_CHUNK = 64;
+constexpr int RNG_NJUMP = 26;    // streams of up to RNG_CHUNK << RNG_NJUMP = 2^32 normals
+constexpr int RNG_TABLE_LOG2 = 20;  // generator states of the first 2^20 chunks are tabulated (16 MB)
+struct JumpTable {
+  uint32_t col[RNG_NJUMP][128][4];  // column j of B^(2^k): image of basis vector e_j
+  uint4* states;                    // [1 << RNG_TABLE_LOG2] state at the start of chunk c (seed fixed)
+};
+
+// generator state at the start of chunk `chunk` of a stream: table look-up for the low bits, GF(2)
+// matrix-vector products for the (rarely set) high bits -- powers of B commute
+__device__ __forceinline__ uint4 rng_chunk_state(const JumpTable* __restrict__ jt, int64_t chunk) {
+  uint4 st = jt->states[chunk & ((1 << RNG_TABLE_LOG2) - 1)];
+  for (int k = RNG_TABLE_LOG2; k < RNG_NJUMP; ++k) {
+    if ((chunk >> k) & 1) {
+      const uint32_t s[4] = {st.x, st.y, st.z, st.w};
+      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      for (int j = 0; j < 128; ++j) {
+        if ((s[j >> 5] >> (j & 31)) & 1u) {
+          r0 ^= jt->col[k][j][0];
+          r1 ^= jt->col[k][j][1];
+          r2 ^= jt->col[k][j][2];
+          r3 ^= jt->col[k][j][3];
+        }
+      }
+      st = make_uint4(r0, r1, r2, r3);
+    }
+  }
+  return st;
+}
+
 struct DeviceContext {
   int device = -1;
   double2* twiddles = nullptr;  // [TW_N/2] exp(+2 pi i k / TW_N)
+  JumpTable* jump = nullptr;    // created by get_jump_table
   std::map<std::tuple<int, int, long long>, FreqtTables> freqt;
 };
 
@@ -31,6 +66,13 @@ DeviceContext* get_context();
 // Returns warping tables for (order m, f2 = fftlen/2, alpha); nullptr + error on failure.
 // need_fwd_frq = false builds only invT (enough for mgc2sp).
 const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq);
+
+// Jump matrices of the randn() generator on the context's device; nullptr + error on failure.
+const JumpTable* get_jump_table(DeviceContext* ctx);
+// R[off[u] + i] = the integer behind normal i of utterance u's stream (i < len[u]; off / len are
+// device arrays): randn() = R / 2^28 - 6.  max_len bounds len[u] (sizes the grid).
+int launch_randn_u32(DeviceContext* ctx, const int64_t* d_off, const int64_t* d_len, int n_utts,
+                     int64_t max_len, uint32_t* d_R, hipStream_t s);
 
 // Small stream-ordered device copy of a host int64 array (offsets). Caller frees with
 // hipFreeAsync on the same stream.

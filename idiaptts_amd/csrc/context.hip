@@ -22,6 +22,14 @@ static int create_context(DeviceContext* ctx) {
   }
   ITTS_HIP_CHECK(hipMalloc((void**)&ctx->twiddles, n * sizeof(double2)));
   ITTS_HIP_CHECK(hipMemcpy(ctx->twiddles, tw.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+  // The entry points take their scratch from the device's stream-ordered pool.  By default the
+  // pool hands everything back to the driver at the next synchronisation, which turns every call
+  // into fresh multi-hundred-MB allocations; let it keep up to 16 GB (of 288) between calls.
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {
+    uint64_t keep = 16ull << 30;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
   return ITTS_OK;
 }
 
@@ -42,6 +50,132 @@ DeviceContext* get_context() {
   }
   g_contexts[dev] = ctx;
   return ctx;
+}
+
+// ---- WORLD randn(): GF(2) jump matrices of the xorshift128 step + the out-of-order generator ------
+struct Mat128 {
+  uint32_t col[128][4];
+};
+static void mat_apply(const Mat128& m, const uint32_t* v, uint32_t* out) {
+  uint32_t r[4] = {0, 0, 0, 0};
+  for (int j = 0; j < 128; ++j)
+    if ((v[j >> 5] >> (j & 31)) & 1u)
+      for (int c = 0; c < 4; ++c) r[c] ^= m.col[j][c];
+  std::memcpy(out, r, sizeof(r));
+}
+static void mat_mul(const Mat128& a, const Mat128& b, Mat128* out) {  // out = a * b (apply b first)
+  Mat128 r;
+  for (int j = 0; j < 128; ++j) mat_apply(a, b.col[j], r.col[j]);
+  *out = r;
+}
+
+// states[c] = B^c * seed for c < 2^RNG_TABLE_LOG2 (once per device)
+__global__ __launch_bounds__(256) void rng_states_kernel(const JumpTable* __restrict__ jt) {
+  const int chunk = blockIdx.x * 256 + threadIdx.x;
+  uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+  for (int k = 0; k < RNG_TABLE_LOG2; ++k) {
+    if ((chunk >> k) & 1) {
+      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      for (int j = 0; j < 128; ++j) {
+        if ((s[j >> 5] >> (j & 31)) & 1u) {
+          r0 ^= jt->col[k][j][0];
+          r1 ^= jt->col[k][j][1];
+          r2 ^= jt->col[k][j][2];
+          r3 ^= jt->col[k][j][3];
+        }
+      }
+      s[0] = r0; s[1] = r1; s[2] = r2; s[3] = r3;
+    }
+  }
+  jt->states[chunk] = make_uint4(s[0], s[1], s[2], s[3]);
+}
+
+const JumpTable* get_jump_table(DeviceContext* ctx) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  if (ctx->jump) return ctx->jump;
+  Mat128 step;
+  for (int j = 0; j < 128; ++j) {
+    uint32_t s[4] = {0, 0, 0, 0};
+    s[j >> 5] = 1u << (j & 31);
+    uint32_t x = s[0], y = s[1], z = s[2], w = s[3];
+    const uint32_t t = x ^ (x << 11);
+    x = y; y = z; z = w;
+    w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+    step.col[j][0] = x; step.col[j][1] = y; step.col[j][2] = z; step.col[j][3] = w;
+  }
+  // B = step^(12*RNG_CHUNK) by square-and-multiply
+  Mat128 B, pw = step;
+  bool have = false;
+  for (int e = 12 * RNG_CHUNK; e > 0; e >>= 1) {
+    if (e & 1) {
+      if (!have) { B = pw; have = true; } else mat_mul(pw, B, &B);
+    }
+    mat_mul(pw, pw, &pw);
+  }
+  std::vector<JumpTable> jt(1);
+  Mat128 cur = B;
+  for (int k = 0; k < RNG_NJUMP; ++k) {
+    std::memcpy(jt[0].col[k], cur.col, sizeof(cur.col));
+    mat_mul(cur, cur, &cur);
+  }
+  JumpTable* d = nullptr;
+  uint4* states = nullptr;
+  const int n_states = 1 << RNG_TABLE_LOG2;
+  if (hipMalloc((void**)&states, sizeof(uint4) * n_states) != hipSuccess ||
+      hipMalloc((void**)&d, sizeof(JumpTable)) != hipSuccess) {
+    set_error("could not create the RNG jump table");
+    return nullptr;
+  }
+  jt[0].states = states;
+  if (hipMemcpy(d, jt.data(), sizeof(JumpTable), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("could not create the RNG jump table");
+    return nullptr;
+  }
+  hipLaunchKernelGGL(rng_states_kernel, dim3(n_states / 256), dim3(256), 0, 0, d);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) {
+    set_error("could not tabulate the RNG states");
+    return nullptr;
+  }
+  ctx->jump = d;
+  return d;
+}
+
+__global__ __launch_bounds__(256) void randn_u32_kernel(const int64_t* __restrict__ off,
+                                                        const int64_t* __restrict__ len,
+                                                        const JumpTable* __restrict__ jt,
+                                                        uint32_t* __restrict__ R) {
+  const int u = blockIdx.y;
+  const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n0 = chunk * RNG_CHUNK;
+  const int64_t n = len[u];
+  if (n0 >= n) return;
+  const uint4 st = rng_chunk_state(jt, chunk);
+  uint32_t x = st.x, y = st.y, z = st.z, w = st.w;
+  uint32_t* out = R + off[u] + n0;
+  const int cnt = (int)(n - n0 < RNG_CHUNK ? n - n0 : RNG_CHUNK);
+  for (int i = 0; i < cnt; ++i) {
+    uint32_t tmp = 0;
+    for (int q = 0; q < 12; ++q) {
+      const uint32_t t = x ^ (x << 11);
+      x = y; y = z; z = w;
+      w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+      tmp += w >> 4;
+    }
+    out[i] = tmp;
+  }
+}
+
+int launch_randn_u32(DeviceContext* ctx, const int64_t* d_off, const int64_t* d_len, int n_utts,
+                     int64_t max_len, uint32_t* d_R, hipStream_t s) {
+  const JumpTable* jt = get_jump_table(ctx);
+  if (!jt) return ITTS_E_HIP;
+  ITTS_REQUIRE(max_len < ((int64_t)RNG_CHUNK << RNG_NJUMP), "utterance too long for the RNG jump table");
+  if (n_utts == 0 || max_len <= 0) return ITTS_OK;
+  const int64_t chunks = (max_len + RNG_CHUNK - 1) / RNG_CHUNK;
+  hipLaunchKernelGGL(randn_u32_kernel, dim3((unsigned)((chunks + 255) / 256), n_utts), dim3(256), 0, s,
+                     d_off, d_len, jt, d_R);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
 }
 
 // SPTK freqt applied to the unit vector e_idx of an (m1+1)-vector -> g[0..m2]

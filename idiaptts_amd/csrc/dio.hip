@@ -393,7 +393,7 @@ static int mround_h(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); 
 extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, int n_utts,
                         int fs, double frame_period_ms, double f0_floor, double f0_ceil,
                         double channels_in_octave, double allowed_range, double* d_f0, void* stream) {
-  ITTS_REQUIRE(d_x && h_x_off && h_f_off && d_f0, "null pointer");
+  ITTS_REQUIRE(h_x_off && h_f_off && (n_utts == 0 || (d_x && d_f0)), "null pointer");
   ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
   ITTS_REQUIRE(f0_floor > 0 && f0_ceil > f0_floor && channels_in_octave > 0, "bad f0 range");
   if (n_utts == 0) return ITTS_OK;

@@ -564,7 +564,7 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
                                     const double* d_var, const int64_t* h_offsets, int n_utts,
                                     double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
                                     void* stream) {
-  ITTS_REQUIRE(d_feat && d_var && h_offsets && d_out && d_scratch, "null pointer");
+  ITTS_REQUIRE(d_var && h_offsets && (n_utts == 0 || (d_feat && d_out && d_scratch)), "null pointer");
   ITTS_REQUIRE(dim > 0 && n_utts >= 0 && col0 >= 0 && ocol0 >= 0, "bad sizes");
   ITTS_REQUIRE(ld_feat >= col0 + 3 * (int64_t)dim && ld_out >= ocol0 + (int64_t)dim,
                "leading dimension too small");
@@ -611,7 +611,7 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
 
 extern "C" int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_out,
                                  int dim, const int64_t* h_offsets, int n_utts, void* stream) {
-  ITTS_REQUIRE(d_x && d_out && h_offsets, "null pointer");
+  ITTS_REQUIRE(h_offsets && (n_utts == 0 || (d_x && d_out)), "null pointer");
   ITTS_REQUIRE(dim > 0 && ld_x >= dim && ld_out >= dim && n_utts >= 0, "bad sizes");
   if (n_utts == 0 || h_offsets[n_utts] == 0) return ITTS_OK;
   hipStream_t s = as_stream(stream);

@@ -29,8 +29,8 @@ using namespace wd;
 
 constexpr int CHUNK = 2048;       // samples per block in the scan kernels (8 per thread)
 constexpr double kDefaultF0 = 500.0;
-constexpr int RCHUNK = 64;        // normals per lane in the RNG kernel
-constexpr int NJUMP = 20;         // jump matrices B^(2^k), B = 12*RCHUNK steps
+constexpr int RCHUNK = RNG_CHUNK;  // normals per lane in the RNG kernel (context.h)
+constexpr int NJUMP = RNG_NJUMP;
 
 struct SynUtt {
   int64_t f_off;   // frames offset
@@ -376,10 +376,6 @@ __global__ void syn_pulse_offsets_kernel(const double* __restrict__ ptot, int n_
 }
 
 // ---- WORLD randn stream with jump-ahead ---------------------------------------------------------
-struct JumpTable {
-  uint32_t col[NJUMP][128][4];  // column j of B^(2^k): image of basis vector e_j
-};
-
 __device__ __forceinline__ void xs_step(uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& w) {
   const uint32_t t = x ^ (x << 11);
   x = y; y = z; z = w;
@@ -393,23 +389,8 @@ __global__ __launch_bounds__(NT) void syn_randn_kernel(const SynUtt* __restrict_
   const int chunk = blockIdx.x * NT + threadIdx.x;
   const int n0 = chunk * RCHUNK;
   if (n0 >= u.yl) return;
-  uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
-  // state after 12*RCHUNK*chunk steps: apply B^(2^k) for every set bit k of `chunk`
-  for (int k = 0; k < NJUMP; ++k) {
-    if ((chunk >> k) & 1) {
-      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-      for (int j = 0; j < 128; ++j) {
-        if ((s[j >> 5] >> (j & 31)) & 1u) {
-          r0 ^= jt->col[k][j][0];
-          r1 ^= jt->col[k][j][1];
-          r2 ^= jt->col[k][j][2];
-          r3 ^= jt->col[k][j][3];
-        }
-      }
-      s[0] = r0; s[1] = r1; s[2] = r2; s[3] = r3;
-    }
-  }
-  uint32_t x = s[0], y = s[1], z = s[2], w = s[3];
+  const uint4 st = rng_chunk_state(jt, chunk);
+  uint32_t x = st.x, y = st.y, z = st.z, w = st.w;
   double* out = R + u.s_off + n0;
   const int cnt = min(RCHUNK, u.yl - n0);
   for (int i = 0; i < cnt; ++i) {
@@ -639,60 +620,6 @@ __global__ void syn_finalize_kernel(const double* __restrict__ y, const SynUtt* 
   }
 }
 
-// ---- host: GF(2) jump matrices of the xorshift128 step ---------------------------------------------
-struct Mat128 {
-  uint32_t col[128][4];
-};
-static void mat_apply(const Mat128& m, const uint32_t* v, uint32_t* out) {
-  uint32_t r[4] = {0, 0, 0, 0};
-  for (int j = 0; j < 128; ++j)
-    if ((v[j >> 5] >> (j & 31)) & 1u)
-      for (int c = 0; c < 4; ++c) r[c] ^= m.col[j][c];
-  std::memcpy(out, r, sizeof(r));
-}
-static void mat_mul(const Mat128& a, const Mat128& b, Mat128* out) {  // out = a * b (apply b first)
-  Mat128 r;
-  for (int j = 0; j < 128; ++j) mat_apply(a, b.col[j], r.col[j]);
-  *out = r;
-}
-
-static JumpTable* g_jump_dev[64] = {nullptr};
-
-static const JumpTable* get_jump_table(int device) {
-  if (device < 0 || device >= 64) return nullptr;
-  if (g_jump_dev[device]) return g_jump_dev[device];
-  Mat128 step;
-  for (int j = 0; j < 128; ++j) {
-    uint32_t s[4] = {0, 0, 0, 0};
-    s[j >> 5] = 1u << (j & 31);
-    uint32_t x = s[0], y = s[1], z = s[2], w = s[3];
-    const uint32_t t = x ^ (x << 11);
-    x = y; y = z; z = w;
-    w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
-    step.col[j][0] = x; step.col[j][1] = y; step.col[j][2] = z; step.col[j][3] = w;
-  }
-  // B = step^(12*RCHUNK) by square-and-multiply
-  Mat128 B, pw = step;
-  bool have = false;
-  for (int e = 12 * RCHUNK; e > 0; e >>= 1) {
-    if (e & 1) {
-      if (!have) { B = pw; have = true; } else mat_mul(pw, B, &B);
-    }
-    mat_mul(pw, pw, &pw);
-  }
-  std::vector<JumpTable> jt(1);
-  Mat128 cur = B;
-  for (int k = 0; k < NJUMP; ++k) {
-    std::memcpy(jt[0].col[k], cur.col, sizeof(cur.col));
-    mat_mul(cur, cur, &cur);
-  }
-  JumpTable* d = nullptr;
-  if (hipMalloc((void**)&d, sizeof(JumpTable)) != hipSuccess) return nullptr;
-  if (hipMemcpy(d, jt.data(), sizeof(JumpTable), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-  g_jump_dev[device] = d;
-  return d;
-}
-
 }  // namespace itts
 
 using namespace itts;
@@ -701,7 +628,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
                                      const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
                                      double frame_period_ms, int fft_size, double preemphasis,
                                      float* d_y_f32, double* d_y_f64, void* stream) {
-  ITTS_REQUIRE(d_f0 && d_sp && d_ap && h_f_off && h_y_off && (d_y_f32 || d_y_f64), "null pointer");
+  ITTS_REQUIRE(h_f_off && h_y_off && (n_utts == 0 || (d_f0 && d_sp && d_ap && (d_y_f32 || d_y_f64))), "null pointer");
   ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
   ITTS_REQUIRE(fft_size >= 256 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0,
                "fft_size must be 2^k in [256, 4096]");
@@ -709,7 +636,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   hipStream_t s = as_stream(stream);
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
-  const JumpTable* jt = get_jump_table(ctx->device);
+  const JumpTable* jt = get_jump_table(ctx);
   if (!jt) {
     set_error("could not create the RNG jump table");
     return ITTS_E_HIP;

@@ -483,7 +483,7 @@ static int check_offsets(const int64_t* h_x_off, const int64_t* h_f_off, int n_u
 extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const double* d_f0_in,
                               const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
                               double* d_f0_out, void* stream) {
-  ITTS_REQUIRE(d_x && h_x_off && d_f0_in && h_f_off && d_f0_out, "null pointer");
+  ITTS_REQUIRE(h_x_off && h_f_off && (n_utts == 0 || (d_x && d_f0_in && d_f0_out)), "null pointer");
   ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
   if (n_utts == 0 || h_f_off[n_utts] == 0) return ITTS_OK;
   int rc = check_offsets(h_x_off, h_f_off, n_utts, fs, frame_period_ms);
@@ -511,8 +511,8 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
                         const int64_t* h_f_off, int n_utts, int fs, double frame_period_ms,
                         int fft_size, double threshold, double* d_ap, double* d_bap_f64,
                         float* d_bap_f32, int64_t ld_bap, void* stream) {
-  ITTS_REQUIRE(d_x && h_x_off && d_f0 && h_f_off, "null pointer");
-  ITTS_REQUIRE(d_ap || d_bap_f64 || d_bap_f32, "nothing to compute");
+  ITTS_REQUIRE(h_x_off && h_f_off && (n_utts == 0 || (d_x && d_f0)), "null pointer");
+  ITTS_REQUIRE(n_utts == 0 || d_ap || d_bap_f64 || d_bap_f32, "nothing to compute");
   ITTS_REQUIRE(n_utts >= 0 && fs >= 15800 && frame_period_ms > 0, "bad sizes (fs >= 15.8 kHz)");
   ITTS_REQUIRE(fft_size > 0 && (fft_size & (fft_size - 1)) == 0, "fft_size must be a power of 2");
   const int nap = itts_num_aperiodicities(fs);

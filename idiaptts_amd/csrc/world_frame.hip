@@ -41,8 +41,17 @@ struct CtLds {
   double* red;
 };
 
+//
+// rn = this frame's slice of the call's randn() stream (as the integers behind the normals, see
+// context.h): WORLD adds 1e-12 * randn to every windowed sample and eps * |randn| to every bin of
+// the smoothed spectrum, consuming one stream per CheapTrick() call frame after frame
+// (cheaptrick.cpp GetWindowedWaveform / AddInfinitesimalNoise).  Irrelevant next to speech, but
+// it is what keeps the envelope of digitally silent frames finite, so it is reproduced exactly.
+__device__ __forceinline__ double randn_of(uint32_t r) { return r / 268435456.0 - 6.0; }
+
 __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl, int fs, double f0,
-                                        double pos, int fft, int logfft, double q1, const CtLds& L) {
+                                        double pos, int fft, int logfft, double q1, const CtLds& L,
+                                        const uint32_t* __restrict__ rn) {
   const int h = fft / 2;
   const int half = mround(1.5 * fs / f0);
   const int n = 2 * half + 1;
@@ -67,6 +76,8 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
       int64_t idx = c + i - half;
       idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
       v = x[idx] * w;
+      const double nz = randn_of(rn[i]) * 1e-12;
+      v = v + nz;
       swf += v;
       sw += w;
     }
@@ -87,7 +98,8 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
   linear_smoothing(L.P, f0 * 2.0 / 3.0, fs, fft, L.P, L.mir, L.red);
   // smoothing with recovery (cepstral liftering)
   for (int k = threadIdx.x; k <= h; k += NT) {
-    const double lp = log(L.P[k]);
+    const double nz = fabs(randn_of(rn[n + k])) * 2.2204460492503131e-16;
+    const double lp = log(L.P[k] + nz);
     zr[k] = lp;
     if (k > 0 && k < h) zr[fft - k] = lp;
   }
@@ -308,7 +320,57 @@ struct FrameArgs {
   int* iters;               // [Ttot] or nullptr
   const double2* g_tw;
   int bmax;                 // bound on the smoothing boundary (LDS carve)
+  const uint32_t* rn;       // safeguard-noise streams, utterance u at rn + f_off[u] * rn_pitch
+  const int64_t* rn_pos;    // [Ttot] position of each frame inside its utterance's stream
+  int64_t rn_pitch;         // bound on the normals one frame consumes
 };
+
+__device__ __forceinline__ double ct_frame_f0(double f0, int fs, int fft) {
+  const double floor_f0 = 3.0 * fs / (fft - 3.0);
+  return f0 > floor_f0 ? f0 : 500.0;  // WORLD kDefaultF0
+}
+
+// Stream positions: frame t of an utterance starts where frames 0..t-1 stopped; each consumes its
+// window length (2 * round(1.5 fs / f0) + 1) plus fft/2+1 normals.  One workgroup per utterance,
+// blocked exclusive scan with a running carry.  Also writes the stream's offset and length.
+__global__ __launch_bounds__(256) void ct_noise_pos_kernel(const double* __restrict__ f0,
+                                                           const int64_t* __restrict__ f_off, int fs,
+                                                           int fft, int64_t pitch,
+                                                           int64_t* __restrict__ pos,
+                                                           int64_t* __restrict__ r_off,
+                                                           int64_t* __restrict__ r_len) {
+  __shared__ int64_t wsum[4];
+  __shared__ int64_t carry_s;
+  const int u = blockIdx.x;
+  const int64_t g0 = f_off[u];
+  const int64_t T = f_off[u + 1] - g0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < T; base += 256) {
+    const int64_t t = base + threadIdx.x;
+    int64_t cnt = 0;
+    if (t < T) cnt = 2 * (int64_t)mround(1.5 * fs / ct_frame_f0(f0[g0 + t], fs, fft)) + 1 + fft / 2 + 1;
+    int64_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int64_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int64_t before = carry_s;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    if (t < T) pos[g0 + t] = before + inc - cnt;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = before + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    r_off[u] = g0 * pitch;
+    r_len[u] = carry_s;
+  }
+}
 
 __device__ inline void carve_ct(char*& p, int fft, int bmax, CtLds& L) {
   L.tw = reinterpret_cast<double2*>(p); p += (size_t)(fft / 2) * sizeof(double2);
@@ -351,11 +413,10 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
   load_twiddles(L.tw, a.g_tw, a.fft);
   __syncthreads();
-  const double floor_f0 = 3.0 * a.fs / (a.fft - 3.0);
-  double f0 = a.f0[g];
-  if (!(f0 > floor_f0)) f0 = 500.0;  // WORLD kDefaultF0
+  const double f0 = ct_frame_f0(a.f0[g], a.fs, a.fft);
   const double pos = (double)t * a.frame_period / 1000.0;
-  cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L);
+  cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L,
+                   a.rn + a.f_off[u] * a.rn_pitch + a.rn_pos[g]);
   const int K = a.fft / 2 + 1;
   if (a.sp)
     for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
@@ -547,11 +608,11 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
                                     double eps, int miniter, int maxiter, double threshold,
                                     float* d_mc_f32, int64_t ld_mc, double* d_mc_f64, int* d_iters,
                                     void* stream) {
-  ITTS_REQUIRE(d_x && h_x_off && d_f0 && h_f_off, "null pointer");
+  ITTS_REQUIRE(h_x_off && h_f_off && (n_utts == 0 || (d_x && d_f0)), "null pointer");
   ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
   ITTS_REQUIRE(is_pow2(fft_size) && fft_size >= 512 && fft_size <= 8192, "fft_size must be 2^k in [512, 8192]");
   const bool do_mcep = (d_mc_f32 != nullptr) || (d_mc_f64 != nullptr);
-  ITTS_REQUIRE(d_sp || do_mcep, "nothing to compute");
+  ITTS_REQUIRE(n_utts == 0 || d_sp || do_mcep, "nothing to compute");
   if (do_mcep) {
     ITTS_REQUIRE(order >= 1 && order < fft_size / 2 && order <= 127, "bad mcep order");
     ITTS_REQUIRE(fft_size <= 2048, "fused mcep supports fft_size <= 2048");
@@ -591,6 +652,23 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64;
   a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
   a.bmax = smoothing_bmax(fs, fft_size, 1000.0);
+  // safeguard-noise streams: positions (scan over the frames' window lengths), then the normals
+  const int K = fft_size / 2 + 1;
+  const int64_t rn_pitch = 2 * (int64_t)std::lround((fft_size - 3.0) / 2.0) + 1 + K;
+  int64_t t_max = 0;
+  for (int u = 0; u < n_utts; ++u) t_max = std::max<int64_t>(t_max, h_f_off[u + 1] - h_f_off[u]);
+  int64_t* d_rpos = nullptr;   // [t_total] + r_off [U] + r_len [U]
+  uint32_t* d_rn = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_rpos, (size_t)(t_total + 2 * n_utts) * sizeof(int64_t), s));
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_rn, (size_t)t_total * rn_pitch * sizeof(uint32_t), s));
+  int64_t* d_roff = d_rpos + t_total;
+  int64_t* d_rlen = d_roff + n_utts;
+  hipLaunchKernelGGL(ct_noise_pos_kernel, dim3(n_utts), dim3(256), 0, s, d_f0, d_fo, fs, fft_size,
+                     rn_pitch, d_rpos, d_roff, d_rlen);
+  ITTS_LAUNCH_CHECK();
+  rc = launch_randn_u32(ctx, d_roff, d_rlen, n_utts, t_max * rn_pitch, d_rn, s);
+  if (rc) return rc;
+  a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch;
   size_t lds = ct_lds_bytes(fft_size, a.bmax) + (fused ? mc_lds_bytes(order) : 0);
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
@@ -599,6 +677,8 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_rpos, s));
+  ITTS_HIP_CHECK(hipFreeAsync(d_rn, s));
   if (do_mcep && !fused) {
     rc = mcep_lockstep(ctx, sp_buf, 1, t_total, fft_size / 2 + 1, order, alpha, eps, miniter, maxiter,
                        threshold, d_mc_f32, ld_mc, d_mc_f64, d_iters, s);

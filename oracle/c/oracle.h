@@ -15,4 +15,24 @@ int orc_mround(double x);
 void orc_interp1(const double* x, const double* y, int n, const double* xi, int m, double* yi);
 void orc_nuttall(int n, double* w);
 
+/* WORLD's randn() (common.cpp / matlabfunctions.cpp): xorshift128 with the fixed seed that
+ * randn_reseed() restores at the start of CheapTrick / D4C / Synthesis; one normal deviate is
+ * the sum of 12 draws of 28 bits. */
+#include <stdint.h>
+typedef struct { uint32_t x, y, z, w; } rng_t;
+static inline void rng_seed(rng_t* s) { s->x = 123456789u; s->y = 362436069u; s->z = 521288629u; s->w = 88675123u; }
+static inline double rng_randn(rng_t* s) {
+  uint32_t t = s->x ^ (s->x << 11);
+  s->x = s->y; s->y = s->z; s->z = s->w;
+  s->w = (s->w ^ (s->w >> 19)) ^ (t ^ (t >> 8));
+  uint32_t tmp = s->w >> 4;
+  for (int i = 0; i < 11; ++i) {
+    t = s->x ^ (s->x << 11);
+    s->x = s->y; s->y = s->z; s->z = s->w;
+    s->w = (s->w ^ (s->w >> 19)) ^ (t ^ (t >> 8));
+    tmp += s->w >> 4;
+  }
+  return tmp / 268435456.0 - 6.0;
+}
+
 #endif

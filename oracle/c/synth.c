@@ -26,22 +26,6 @@ static double dmin(double a, double b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
 static int imin(int a, int b) { return a < b ? a : b; }
 
-typedef struct { uint32_t x, y, z, w; } rng_t;
-static void rng_seed(rng_t* s) { s->x = 123456789u; s->y = 362436069u; s->z = 521288629u; s->w = 88675123u; }
-static double rng_randn(rng_t* s) {
-  uint32_t t = s->x ^ (s->x << 11);
-  s->x = s->y; s->y = s->z; s->z = s->w;
-  s->w = (s->w ^ (s->w >> 19)) ^ (t ^ (t >> 8));
-  uint32_t tmp = s->w >> 4;
-  for (int i = 0; i < 11; ++i) {
-    t = s->x ^ (s->x << 11);
-    s->x = s->y; s->y = s->z; s->z = s->w;
-    s->w = (s->w ^ (s->w >> 19)) ^ (t ^ (t >> 8));
-    tmp += s->w >> 4;
-  }
-  return tmp / 268435456.0 - 6.0;
-}
-
 int orc_decode_aperiodicity(const double* bap, int T, int fs, int fft_size, double* ap) {
   const int K = fft_size / 2 + 1;
   const int nap = (int)(dmin(15000.0, fs / 2.0 - 3000.0) / 3000.0);

@@ -7,8 +7,10 @@
  * /root/reference and cannot be installed, so this restates the published algorithms:
  *   Dio (dio.cpp), StoneMask (stonemask.cpp, two-stage variant), CheapTrick (cheaptrick.cpp),
  *   D4C + LoveTrain (d4c.cpp), CodeAperiodicity (codec.cpp), common helpers (common.cpp,
- *   matlabfunctions.cpp).  WORLD's 1e-12 "safeguard" randn() terms are omitted (below f32
- *   resolution of every output).
+ *   matlabfunctions.cpp).  CheapTrick carries WORLD's two safeguard noise terms (1e-12 * randn on
+ *   the windowed waveform, eps * |randn| on the smoothed spectrum, one stream per call) -- they
+ *   decide the envelope of digitally silent frames; D4C's 1e-12 window noise is omitted (it only
+ *   acts on voiced frames, where it is below f32 resolution of every output).
  * Pinned against the reference's golden fixtures test/integration/fixtures/WORLD/cmp_mcep20/
  * (tests/test_oracle_golden.py; settings: pre-emphasis 0.97, frame period 5 ms).
  */
@@ -404,7 +406,7 @@ int orc_stonemask(const double* x, int xl, int fs, const double* tp, const doubl
 
 /* ---- CheapTrick -------------------------------------------------------------------------------- */
 static void cheaptrick_frame(const double* x, int xl, int fs, double f0, double pos, int fft,
-                             double q1, double* out, double* buf) {
+                             double q1, double* out, double* buf, rng_t* rng) {
   const int half = orc_mround(1.5 * fs / f0);
   const int n = 2 * half + 1;
   const int h = fft / 2;
@@ -429,7 +431,7 @@ static void cheaptrick_frame(const double* x, int xl, int fs, double f0, double 
   double swf = 0.0, sw = 0.0;
   for (int i = 0; i < n; ++i) {
     const int idx = imin(xl - 1, imax(0, c + i - half));
-    wf[i] = x[idx] * win[i];
+    wf[i] = x[idx] * win[i] + rng_randn(rng) * 1e-12;   /* cheaptrick.cpp GetWindowedWaveform */
     swf += wf[i];
     sw += win[i];
   }
@@ -439,6 +441,8 @@ static void cheaptrick_frame(const double* x, int xl, int fs, double f0, double 
   for (int k = 0; k <= h; ++k) P[k] = Sr[k] * Sr[k] + Si[k] * Si[k];
   dc_correction(P, f0, fs, fft);
   linear_smoothing(P, f0 * 2.0 / 3.0, fs, fft, P);
+  /* cheaptrick.cpp AddInfinitesimalNoise (kEps = 2^-52) */
+  for (int k = 0; k <= h; ++k) P[k] = P[k] + fabs(rng_randn(rng)) * 2.2204460492503131e-16;
   /* smoothing with recovery: cepstral liftering */
   for (int k = 0; k <= h; ++k) lp[k] = log(P[k]);
   for (int k = 1; k < h; ++k) lp[fft - k] = lp[k];
@@ -463,9 +467,11 @@ int orc_cheaptrick(const double* x, int xl, int fs, const double* tp, const doub
   const int maxhalf = orc_mround(1.5 * fs / floor_f0) + 2;
   double* buf = (double*)malloc(sizeof(double) * ((2 * maxhalf + 1) + 4 * fft + 3 * (fft / 2 + 1)));
   if (!buf) return -1;
+  rng_t rng;
+  rng_seed(&rng);                                       /* randn_reseed() at the top of CheapTrick() */
   for (int i = 0; i < T; ++i) {
     const double cf0 = f0[i] > floor_f0 ? f0[i] : 500.0;
-    cheaptrick_frame(x, xl, fs, cf0, tp[i], fft, q1, sp + (size_t)i * (fft / 2 + 1), buf);
+    cheaptrick_frame(x, xl, fs, cf0, tp[i], fft, q1, sp + (size_t)i * (fft / 2 + 1), buf, &rng);
   }
   free(buf);
   return 0;

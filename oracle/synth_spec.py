@@ -8,16 +8,7 @@ WORLD algorithm (mmorise/World synthesis.cpp) and is sanity-checked by re-analys
 # Recollection of WORLD Synthesis / DecodeAperiodicity (numpy, float64). NOT pinned by any reference golden;
 # sanity-checked only by re-analysis.
 import numpy as np, math
-from .world_spec import interp1, EPS
-class XorShift:
-    def __init__(s): s.x,s.y,s.z,s.w=123456789,362436069,521288629,88675123
-    def _step(s):
-        t=(s.x^((s.x<<11)&0xFFFFFFFF))&0xFFFFFFFF; s.x,s.y,s.z=s.y,s.z,s.w
-        s.w=((s.w^(s.w>>19))^(t^(t>>8)))&0xFFFFFFFF; return s.w
-    def randn(s):
-        tmp=s._step()>>4
-        for _ in range(11): tmp+=s._step()>>4
-        return tmp/268435456.0-6.0
+from .world_spec import interp1, EPS, XorShift
 def decode_aperiodicity(bap, fs, fft_size):
     T,n=bap.shape; fa=np.arange(fft_size//2+1)*fs/fft_size
     cfa=np.concatenate([np.arange(n+1)*3000.0,[fs/2.0]]); out=np.empty((T,fft_size//2+1))

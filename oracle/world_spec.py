@@ -165,16 +165,30 @@ def stonemask_frame(x, fs, pos, f0):
     mean = 0.0 if (t <= 0.0 or t > f0 * 2) else _fixf0(ps, num, fft, fs, t, min(int(fs / 2.0 / f0), 6))
     return f0 if abs(mean - f0) > f0 * 0.2 else mean
 
+# ---------- WORLD randn(): xorshift128, fixed seed restored by randn_reseed() ----------
+class XorShift:
+    def __init__(s): s.x,s.y,s.z,s.w=123456789,362436069,521288629,88675123
+    def _step(s):
+        t=(s.x^((s.x<<11)&0xFFFFFFFF))&0xFFFFFFFF; s.x,s.y,s.z=s.y,s.z,s.w
+        s.w=((s.w^(s.w>>19))^(t^(t>>8)))&0xFFFFFFFF; return s.w
+    def randn(s):
+        tmp=s._step()>>4
+        for _ in range(11): tmp+=s._step()>>4
+        return tmp/268435456.0-6.0
+
 # ---------- CheapTrick (one frame) ----------
-def cheaptrick_frame(x, fs, f0, pos, fft_size, q1=-0.15):
-    # caller passes f0 = 500.0 when f0 <= 3*fs/(fft_size-3)
+def cheaptrick_frame(x, fs, f0, pos, fft_size, q1=-0.15, rng=None):
+    # caller passes f0 = 500.0 when f0 <= 3*fs/(fft_size-3); rng = the XorShift stream of this
+    # CheapTrick() call (frames consume it in order); None drops WORLD's two safeguard noise terms
     half = mround(1.5 * fs / f0); base = np.arange(-half, half + 1)
     safe = np.minimum(len(x) - 1, np.maximum(0, mround(pos * fs + 0.001) + base))
     win = 0.5 * np.cos(np.pi * (base / 1.5 / fs) * f0) + 0.5; win /= np.sqrt(np.sum(win * win))
-    wf = x[safe] * win                       # (+ randn()*1e-12 in WORLD; irrelevant at 1e-7)
+    wf = x[safe] * win
+    if rng is not None: wf = wf + np.array([rng.randn() for _ in range(len(base))]) * 1e-12
     wf = wf - win * (wf.sum() / win.sum())
     S = np.fft.rfft(wf, fft_size); P = dc_correction(S.real ** 2 + S.imag ** 2, f0, fs, fft_size)
-    P = linear_smoothing(P, f0 * 2.0 / 3.0, fs, fft_size)          # (+ |randn()|*2.2e-16 in WORLD)
+    P = linear_smoothing(P, f0 * 2.0 / 3.0, fs, fft_size)
+    if rng is not None: P = P + np.abs(np.array([rng.randn() for _ in range(fft_size // 2 + 1)])) * 2.2204460492503131e-16
     h = fft_size // 2; q = np.arange(1, h + 1) / fs
     sl = np.ones(h + 1); cl = np.ones(h + 1)
     sl[1:] = np.sin(np.pi * f0 * q) / (np.pi * f0 * q); cl[1:] = (1 - 2 * q1) + 2 * q1 * np.cos(2 * np.pi * q * f0)
@@ -269,7 +283,8 @@ def analyse(x_raw, fs, preemphasis, order, alpha, frame_period=5.0):
     f0d, tp = dio(x, fs, frame_period)
     f0 = np.array([stonemask_frame(x, fs, tp[i], f0d[i]) for i in range(len(tp))])
     fft = 2 ** (1 + int(math.log2(3.0 * fs / 71.0 + 1))); floor = 3.0 * fs / (fft - 3.0)
-    sp = np.array([cheaptrick_frame(x, fs, (f0[i] if f0[i] > floor else 500.0), tp[i], fft) for i in range(len(tp))])
+    rng = XorShift()
+    sp = np.array([cheaptrick_frame(x, fs, (f0[i] if f0[i] > floor else 500.0), tp[i], fft, rng=rng) for i in range(len(tp))])
     bap = d4c_bap(x, fs, f0, tp, fft)
     mc = np.array([sptk_mcep(np.sqrt(s), order, alpha) for s in sp])
     return f0, sp, bap, mc

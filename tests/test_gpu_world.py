@@ -308,3 +308,50 @@ def test_parallel_phase_scan_is_bit_identical_to_the_sequential_chain(gpu):
         os.environ.pop("ITTS_SYNTH_SEQ_PHASE", None)
     assert torch.isfinite(y_scan).all() and y_scan.abs().max() > 0
     assert torch.equal(y_scan, y_seq)
+
+
+def test_ragged_batch_with_silence_and_very_short_utterances(gpu):
+    """Edge cases of the batched entry points: a digitally silent utterance (all frames unvoiced,
+    CheapTrick on its default F0, D4C's LoveTrain rejects every frame), utterances of a handful of
+    frames (DIO's decimated signal shorter than its filters), next to a normal one.  Every
+    utterance must equal the oracle run on it alone (no leakage across the batch), and an empty
+    batch is a no-op."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    fs = 16000
+    xs = [_synthetic(fs, 0.5, 5), np.zeros(4000), _synthetic(fs, 0.05, 6), _synthetic(fs, 0.011, 7),
+          1e-3 * np.random.default_rng(3).normal(size=2400)]
+    T = [int(1000.0 * len(x) / fs / 5.0) + 1 for x in xs]
+    x_off = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).tolist()
+    f_off = np.concatenate([[0], np.cumsum(T)]).tolist()
+    x = torch.from_numpy(np.concatenate(xs)).to(gpu)
+    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs), f_off, fs)
+    sp, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, order=19, alpha=0.58,
+                                    mc_dtype=torch.float64)
+    ap, bap = ops.d4c(x, x_off, f0, f_off, fs, want_bap=torch.float64)
+    y, y_off = ops.world_synthesize(f0, sp, ap, f_off, fs, dtype=torch.float64)
+    f0, sp, mc, ap, bap, y = (t.cpu().numpy() for t in (f0, sp, mc, ap, bap, y))
+    for u, xu in enumerate(xs):
+        a, b = f_off[u], f_off[u + 1]
+        f0_ref, sp_ref, ap_ref = capi.wav2world(xu, fs)
+        assert len(f0_ref) == b - a
+        assert np.array_equal(f0[a:b] == 0, f0_ref == 0), u
+        assert np.abs(f0[a:b] - f0_ref).max() < 1e-7, u
+        assert np.abs(np.log(sp[a:b] / sp_ref)).max() < 1e-8, u
+        assert np.abs(20 * np.log10(ap[a:b] / ap_ref)).max() < 1e-6, u
+        assert np.abs(bap[a:b] - capi.code_aperiodicity(ap_ref, fs)).max() < 1e-6, u
+        assert np.abs(mc[a:b] - capi.mcep(np.sqrt(sp_ref), 19, 0.58)).max() < 1e-6, u
+        y_ref = capi.synthesize(f0_ref, sp_ref, ap_ref, fs).astype(np.float32)
+        assert y_off[u + 1] - y_off[u] == len(y_ref)
+        assert np.abs(y[y_off[u]:y_off[u + 1]] - y_ref).max() < 1e-6, u
+    assert (f0[f_off[1]:f_off[2]] == 0).all()                      # silence: nothing voiced
+    # empty batch
+    e = torch.empty((0,), dtype=torch.float64, device=gpu)
+    assert ops.dio(e, [0], [0], fs).numel() == 0
+    assert ops.stonemask(e, [0], e, [0], fs).numel() == 0
+    sp0, mc0, _ = ops.cheaptrick_mcep(e, [0], e, [0], fs, order=19, alpha=0.58)
+    assert sp0.shape == (0, 513) and mc0.shape == (0, 20)
+    ap0, _ = ops.d4c(e, [0], e, [0], fs)
+    assert ap0.shape == (0, 513)
+    y0, y0_off = ops.world_synthesize(e, sp0, ap0, [0], fs)
+    assert y0.numel() == 0 and y0_off == [0]
