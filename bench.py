@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
@@ -75,15 +76,19 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
                       "frames)".format(steps, n_utts, int(lengths.sum()))}
 
 
-def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=True, key="world"):
+def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=True, key="world",
+                  rank=0, n_ranks=1):
     """WORLD feature path on `n_utts` synthetic utterances (inputs resident in HBM, GPU time by
     events on the launch stream): analysis wav -> (f0, mcep60, bap), synthesis
     (mcep60, bap, f0) -> wav, MLPG on the 187-dim cmp, and the C-oracle CPU baseline on a
-    bounded sample (one utterance at a time on one core, like WorldFeatLabelGen.py:996)."""
+    bounded sample (one utterance at a time on one core, like WorldFeatLabelGen.py:996).
+    With n_ranks > 1 every rank owns its own `n_utts` utterances (utterances are independent: no
+    data-path collective); times are the max over ranks after a barrier, audio and frames the
+    sum, so the real-time factors are whole-job figures."""
     from idiaptts_amd import lib, ops, world
     from idiaptts_amd.bench_support import make_audio_batch
     L = lib.load()
-    raws = make_audio_batch(n_utts, fs, seed=0)
+    raws = make_audio_batch(n_utts, fs, seed=rank)
     hop = 5.0
     order, alpha = 59, L.itts_mcep_alpha(fs)
     n_fft = L.itts_cheaptrick_fft_size(fs, 71.0)
@@ -102,9 +107,21 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                          want_bap=torch.float32)
         return f0, mc, bap, it
 
+    def over_ranks(value, op):
+        if n_ranks == 1:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=op)
+        return t.item()
+
+    def sync():
+        torch.cuda.synchronize()
+        if n_ranks > 1:
+            dist.barrier()
+
     f0, mc, bap, iters = analysis()
-    torch.cuda.synchronize()
-    ms_an = hip_event_time_ms(analysis, stream, 3)
+    sync()
+    ms_an = over_ranks(hip_event_time_ms(analysis, stream, 3), dist.ReduceOp.MAX)
     mc64 = mc.double()
     bap64 = bap.double()
     f0s = f0.clone()
@@ -115,11 +132,13 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         return ops.world_synthesize(f0s, pw, apd, f_off, fs, hop)
 
     synthesis()
-    torch.cuda.synchronize()
-    ms_sy = hip_event_time_ms(synthesis, stream, 3)
-    frames = f_off[-1]
+    sync()
+    ms_sy = over_ranks(hip_event_time_ms(synthesis, stream, 3), dist.ReduceOp.MAX)
+    frames = int(over_ranks(f_off[-1], dist.ReduceOp.SUM))
+    audio_s = over_ranks(audio_s, dist.ReduceOp.SUM)
     res[key] = {
-        "fs": fs, "utterances": n_utts, "audio_seconds": audio_s, "frames": frames,
+        "fs": fs, "utterances": n_utts * n_ranks, "n_gpus": n_ranks, "audio_seconds": audio_s,
+        "frames": frames,
         "analysis_ms": ms_an, "analysis_rtf": ms_an * 1e-3 / audio_s,
         "analysis_frames_per_s": frames / (ms_an * 1e-3),
         "synthesis_ms": ms_sy, "synthesis_rtf": ms_sy * 1e-3 / audio_s,
@@ -140,12 +159,15 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         feat = torch.randn(ml_frames, 186, dtype=torch.float64, device=dev)
         var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
         ops.mlpg_generation(feat, var, 62, ml_off)
-        torch.cuda.synchronize()
-        ms_ml = hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off), stream, 5)
-        res["mlpg"] = {"utterances": 256, "frames": ml_frames, "ms": ms_ml,
+        sync()
+        ms_ml = over_ranks(hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off),
+                                             stream, 5), dist.ReduceOp.MAX)
+        ml_frames *= n_ranks                      # same lengths on every rank
+        res["mlpg"] = {"utterances": 256 * n_ranks, "frames": ml_frames, "ms": ms_ml,
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
                        "algorithmic_GBps": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9,
-                       "frac_of_hbm_peak": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                       "frac_of_hbm_peak": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS
+                       / n_ranks}
     if with_cpu:
         from oracle import capi
         t0 = time.perf_counter()
@@ -296,7 +318,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=dev)
@@ -353,6 +374,17 @@ def main():
             rnn_extra.update(bilstm_section(dev, args.bilstm_utts, cell=cell, rank=rank,
                                             world=world))
 
+    # config 5 (WORLD analysis / synthesis real-time factors, MLPG): every rank takes part
+    world_extra = {}
+    if args.world_utts > 0:
+        with_cpu = not args.no_cpu_baseline and world == 1    # CPU baseline: rank 0 at N = 1 only
+        world_extra = world_section(dev, args.world_utts, args.world_fs, with_cpu=with_cpu,
+                                    rank=rank, n_ranks=world)
+        # config 5 also quotes 48 kHz (fft 2048, 5 aperiodicity bands): a smaller batch
+        world_extra.update(world_section(dev, max(4, args.world_utts // 4), 48000, cpu_seconds=12.0,
+                                         with_cpu=with_cpu, with_mlpg=False, key="world_48k",
+                                         rank=rank, n_ranks=world))
+
     out = None
     if rank == 0:
         # dominant kernel roofline: the fp32-MFMA GEMM launches of one step, timed live with
@@ -397,14 +429,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N = 1 only
             cpu = cpu_baseline_ff(args.utts_per_gpu)
-        extra = {}
-        if world == 1 and args.world_utts > 0:
-            extra = world_section(dev, args.world_utts, args.world_fs,
-                                  with_cpu=not args.no_cpu_baseline)
-            # config 5 also quotes 48 kHz (fft 2048, 5 aperiodicity bands): a smaller batch
-            extra.update(world_section(dev, max(4, args.world_utts // 4), 48000, cpu_seconds=12.0,
-                                       with_cpu=not args.no_cpu_baseline, with_mlpg=False,
-                                       key="world_48k"))
+        extra = dict(world_extra)
         extra.update(rnn_extra)
         if world == 1 and args.world_utts > 0:
             extra.update(resident_epoch_section(dev))

@@ -46,11 +46,21 @@ def allreduce_flat_(buf, group=None):
 
 
 def allreduce_stats_(extractor, group=None, device=None):
-    """Merges Mean{StdDev,Covariance}Extractor statistics across ranks in place."""
+    """Merges Mean{StdDev,Covariance}Extractor statistics across ranks in place.  A rank whose
+    shard was empty (no add_sample yet: scalar zeros) takes the shapes of the others."""
     second = "sum_squared_frames" if hasattr(extractor, "sum_squared_frames") \
         else "sum_product_frames"
     a = np.atleast_1d(np.asarray(extractor.sum_frames, dtype=np.float64))
     b = np.atleast_1d(np.asarray(getattr(extractor, second), dtype=np.float64))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dims = torch.tensor([a.shape[-1], b.ndim], dtype=torch.int64)
+        if device is not None:
+            dims = dims.to(device)
+        dist.all_reduce(dims, op=dist.ReduceOp.MAX, group=group)
+        d, nd = (int(v) for v in dims.cpu())
+        if extractor.sum_length == 0 and a.shape[-1] != d:
+            a = np.zeros((1, d) if nd == 2 else (d,))     # the covariance extractor keeps [1, D] sums
+            b = np.zeros((d, d) if nd == 2 else (d,))
     flat = torch.from_numpy(np.concatenate([[float(extractor.sum_length)], a.ravel(), b.ravel()]))
     if device is not None:
         flat = flat.to(device)

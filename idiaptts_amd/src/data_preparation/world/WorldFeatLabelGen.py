@@ -19,6 +19,7 @@ from typing import List, Union
 
 import numpy as np
 
+from .... import parallel as _parallel
 from .... import world as _world
 from ....misc.mlpg import MLPG
 from ....misc.normalisation.MeanCovarianceExtractor import MeanCovarianceExtractor
@@ -27,6 +28,15 @@ from ....misc.utils import compute_deltas, interpolate_lin  # noqa: F401  (re-ex
 from ..audio.AudioProcessing import AudioProcessing
 from ..DataReaderConfig import DataReaderConfig
 from ..DataReaders import ReaderBase
+
+
+def _dist_device():
+    """Device the statistics all-reduce runs on: the current GPU under RCCL ('nccl'), host
+    memory under gloo."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) \
+        if dist.get_backend() == "nccl" else None
 
 
 def _save_to_npz(file_path, features, feature_name):
@@ -356,7 +366,12 @@ class WorldFeatLabelGen(ReaderBase):
     def gen_data(self, dir_in, dir_out=None, file_id_list="", file_ext="wav", id_list=None,
                  return_dict=False):
         """Prepare acoustic features from audio files (reference :947-1071); utterances are
-        analysed `batch_utts` at a time on the GPU."""
+        analysed `batch_utts` at a time on the GPU.
+
+        Under torch.distributed (one process per GPU) the utterance list is partitioned over the
+        ranks, length balanced by file size, every rank writes the features of its own utterances
+        and the additive normalisation statistics are merged with one sum all-reduce per stream
+        (SURVEY.md section 8e); all ranks return the same parameters, rank 0 writes them."""
         if id_list is None:
             id_list = [os.path.splitext(os.path.basename(f))[0]
                        for f in glob.glob(os.path.join(dir_in, "*" + file_ext))]
@@ -372,6 +387,11 @@ class WorldFeatLabelGen(ReaderBase):
                     os.makedirs(os.path.join(dir_out, d), exist_ok=True)
         label_dict = OrderedDict()
         self._create_norm_params_extractors()
+        rank, world = _parallel.dp_rank_world()
+        all_ids = list(id_list)
+        if world > 1:
+            sizes = [os.path.getsize(os.path.join(dir_in, n + "." + file_ext)) for n in all_ids]
+            id_list = [all_ids[i] for i in _parallel.shard_by_length(sizes, world)[rank]]
         for b0 in range(0, len(id_list), self.batch_utts):
             names = id_list[b0:b0 + self.batch_utts]
             raws, fss = [], []
@@ -390,6 +410,19 @@ class WorldFeatLabelGen(ReaderBase):
                 output = self.save_output(f, dir_out, n)
                 if return_dict:
                     label_dict[n] = np.concatenate(output, axis=1) if len(output) > 0 else None
+        if world > 1:
+            import torch.distributed as dist
+            dev = _dist_device()
+            for load, _, ext, normaliser in self._streams():
+                if load and ext != self.ext_vuv:
+                    _parallel.allreduce_stats_(normaliser, device=dev)
+            if return_dict:
+                gathered = [None] * world
+                dist.all_gather_object(gathered, label_dict)
+                merged = {}
+                for d in gathered:
+                    merged.update(d)
+                label_dict = OrderedDict((n, merged[n]) for n in all_ids)
         output_means, output_std_dev = list(), list()
         for load, feature_dir, ext, normaliser in self._streams():
             if not load:
@@ -397,7 +430,7 @@ class WorldFeatLabelGen(ReaderBase):
             norm = normaliser.get_params()
             output_means.append(norm[0])
             output_std_dev.append(norm[1])
-            if dir_out:
+            if dir_out and rank == 0:
                 norm_file_path = os.path.join(dir_out, feature_dir, file_id_list_name)
                 if self.add_deltas and ext != self.ext_vuv:
                     if file_id_list_name is not None and os.path.basename(file_id_list_name) != "":
@@ -410,6 +443,8 @@ class WorldFeatLabelGen(ReaderBase):
                 output_std_dev = np.concatenate(output_std_dev, axis=0)
             else:
                 output_means = output_std_dev = None
+        if world > 1:
+            dist.barrier()          # the parameter files exist when any rank returns
         if return_dict:
             return label_dict, output_means, output_std_dev
         return output_means, output_std_dev

@@ -65,6 +65,13 @@ def _worker(rank, world, port, ret):
         mc.add_sample(y[offs[i]:offs[i + 1]].double().numpy())
     parallel.allreduce_stats_(ms)
     parallel.allreduce_stats_(mc)
+    # a rank whose shard is empty (fewer utterances than ranks) still takes part in the merge
+    for lone in (MeanStdDevExtractor(), MeanCovarianceExtractor()):
+        if rank == 0:
+            lone.add_sample(y[:7].double().numpy())
+        parallel.allreduce_stats_(lone)
+        if rank == 1:
+            ret["lone_" + type(lone).__name__] = lone.get_params()
     if rank == 0:
         ret["n_global"] = n_global
         ret["grad"] = grad.numpy()
@@ -101,6 +108,10 @@ def test_world_size_2_equals_single_process():
     assert np.allclose(ret["mean"], ms.get_params()[0], atol=1e-12)
     assert np.allclose(ret["std"], ms.get_params()[1], atol=1e-9)
     assert np.allclose(ret["cov"], mc.get_params()[1], atol=1e-9)
+    for lone in (MeanStdDevExtractor(), MeanCovarianceExtractor()):
+        lone.add_sample(y[:7].double().numpy())
+        for got, want in zip(ret["lone_" + type(lone).__name__], lone.get_params()):
+            assert np.allclose(got, want, atol=1e-12)
 
 
 def test_shard_by_length_is_balanced_and_complete():

@@ -128,3 +128,60 @@ def test_lf0_label_gen_matches_oracle_dio_stonemask(gpu, golden_dir, tmp_path):
                                                                add_deltas=True, return_dict=True)
     assert d[ids[1]].shape[1] == 4 and dm[-1] == 0.0 and abs(ds[-1] - 1.0) < 1e-12
     assert np.array_equal(LF0LabelGen.load_sample(ids[1], out_dir, add_deltas=True), d[ids[1]])
+
+
+def _gen_data_worker(rank, world, port, wav_dir, out_dir, ids, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    gen = WorldFeatLabelGen(out_dir, add_deltas=True, num_coded_sps=20)
+    label_dict, mean, cov = gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids, return_dict=True)
+    ret[rank] = (list(label_dict.keys()), [np.asarray(m) for m in mean], [np.asarray(c) for c in cov])
+    dist.destroy_process_group()
+
+
+def test_gen_data_sharded_over_two_ranks_equals_single_process(gpu, golden_dir, tmp_path):
+    """utterances are partitioned over the ranks (one process per GPU; here
+    two processes share the one GPU of the test box and talk over gloo), each analyses and writes
+    its own, the normalisation statistics are merged by a sum all-reduce.  Files and parameters
+    must equal the single-process run."""
+    import shutil
+    import socket
+    import torch.multiprocessing as mp
+    from scipy.io import wavfile
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    ids = ["LJ001-0002", "LJ001-0008"]
+    for n in ids:
+        shutil.copy(os.path.join(golden_dir, n + ".wav"), str(wav_dir / (n + ".wav")))
+    fs, w = wavfile.read(os.path.join(golden_dir, "LJ001-0008.wav"))
+    for k, (a, b) in enumerate([(0, 30000), (9000, 21000), (15000, 60000)]):   # ragged extra clips
+        wavfile.write(str(wav_dir / "clip{}.wav".format(k)), fs, w[a:b])
+        ids.append("clip{}".format(k))
+    single = tmp_path / "single"
+    gen = WorldFeatLabelGen(str(single), add_deltas=True, num_coded_sps=20)
+    ref_dict, ref_mean, ref_cov = gen.gen_data(str(wav_dir), str(single), "ids.txt", id_list=ids,
+                                               return_dict=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    sharded = tmp_path / "sharded"
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_gen_data_worker, args=(2, port, str(wav_dir), str(sharded), ids, ret), nprocs=2,
+             join=True)
+    for rank in (0, 1):
+        keys, mean, cov = ret[rank]
+        assert keys == ids                                               # same order on every rank
+        # (like the reference, the extractors sum float32 features per utterance: the grouping of
+        # the partial sums shows at float32 resolution)
+        for m, r in zip(mean, ref_mean):
+            assert np.allclose(m, r, rtol=1e-5, atol=1e-6)
+        for c, r in zip(cov, ref_cov):
+            assert np.allclose(c, r, rtol=1e-4, atol=1e-5)
+    reader = WorldFeatLabelGen(str(sharded), add_deltas=True, num_coded_sps=20)
+    for n in ids:
+        assert np.array_equal(reader.load(n), ref_dict[n])               # feature files identical
+    assert os.path.isfile(str(sharded / "mcep20" / "ids-deltas-mean-covariance.npz"))
