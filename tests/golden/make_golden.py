@@ -355,6 +355,75 @@ def capture_duration_fixture():
           len(symbol_dict), "symbols")
 
 
+def npz_reader_cases(tmp):
+    """Writes the seeded archives + parameter files of the NpzDataReader cases below `tmp` and
+    returns {case: Config kwargs}; shared by the capture (reference reader) and the test (ours)."""
+    rng = np.random.default_rng(42)
+    d1, d2 = os.path.join(tmp, "a"), os.path.join(tmp, "b")
+    os.makedirs(d1, exist_ok=True)
+    os.makedirs(d2, exist_ok=True)
+    for k, n in enumerate(["utt1", "utt2"]):
+        T = 17 + 6 * k
+        np.savez(os.path.join(d1, n), cmp=rng.normal(size=(T, 7)), dur=rng.integers(1, 9, (T, 2)))
+        np.savez(os.path.join(d2, n), lf0=rng.normal(size=(T, 2)).astype(np.float32))
+    mean, std = rng.normal(size=7), rng.uniform(0.5, 2.0, size=7)
+    np.savez(os.path.join(d1, "set-mean-std_dev"), mean=mean, std_dev=std, sum_length=np.array(40))
+    mn, mx = -rng.uniform(1, 2, size=2), rng.uniform(1, 2, size=2)
+    np.savez(os.path.join(d2, "min-max"), min=mn, max=mx)
+    return {
+        "plain": dict(name="cmp", directory=d1),
+        "stddev_file": dict(name="cmp", directory=d1, norm_type="MEAN_STDDEV",
+                            norm_file=(d1, "set")),
+        "indices": dict(name="cmp", directory=d1, indices=np.array([5, 0, 3]),
+                        norm_type="MEAN_STDDEV",
+                        norm_params=(mean[[5, 0, 3]], std[[5, 0, 3]])),
+        "two_dirs": dict(name="both", directory=[d1, d2], features=["lf0", "dur"],
+                         output_names=["f", "d"]),
+        "fn_before": dict(name="cmp", directory=d1, norm_type="MEAN_STDDEV",
+                          norm_params=(mean, std), preprocessing_fn="square",
+                          preprocess_before_norm=True, postprocessing_fn="square",
+                          postprocess_before_norm=False),
+        "minmax_chunk": dict(name="lf0", directory=d2, norm_type="MIN_MAX", norm_file=(None, None),
+                             chunk_size=4, pad_mode="edge"),
+    }
+
+
+def run_npz_reader_cases(NpzDataReader, tmp):
+    """{case/id/output: array} for both ids through reader[id] and postprocess_sample."""
+    out = {}
+    for case, kw in npz_reader_cases(tmp).items():
+        kw = dict(kw)
+        norm_file = kw.pop("norm_file", None)
+        kw["norm_type"] = getattr(NpzDataReader.Config.NormType, kw.pop("norm_type", "NONE"))
+        for fn in ("preprocessing_fn", "postprocessing_fn"):
+            if kw.get(fn) == "square":
+                kw[fn] = np.square
+        reader = NpzDataReader.Config(**kw).create_reader()
+        if norm_file is not None:
+            reader.get_normalisation_params(*norm_file)
+        for n in ["utt1", "utt2"]:
+            item = reader[n]
+            for name in reader.output_names:
+                out["{}/{}/{}".format(case, n, name)] = item[name]
+            out["{}/{}/len".format(case, n)] = np.array(reader.get_length(n))
+            if len(reader.output_names) == 1:
+                out["{}/{}/post".format(case, n)] = np.asarray(
+                    reader.postprocess_sample(item[reader.output_names[0]]))
+    return out
+
+
+def capture_npz_reader():
+    """reference NpzDataReader (data_preparation/NpzDataReader.py) on seeded archives ->
+    npz_reader_fixture.npz"""
+    import tempfile
+    np.long = np.int64        # removed from numpy; the reference's Config casts indices with it
+    from idiaptts.src.data_preparation.NpzDataReader import NpzDataReader
+    with tempfile.TemporaryDirectory() as tmp:
+        out = run_npz_reader_cases(NpzDataReader, tmp)
+    np.savez_compressed(os.path.join(HERE, "npz_reader_fixture.npz"), **out)
+    print("wrote npz_reader_fixture.npz:", len(out), "arrays")
+
+
 def _main():
     copy_data_fixtures()
     install_stub_harness()
@@ -369,6 +438,9 @@ def _main():
         return
     if "--duration" in sys.argv:
         capture_duration_fixture()
+        return
+    if "--npz-reader" in sys.argv:
+        capture_npz_reader()
         return
     capture_host_logic()
     capture_benchmark_kat()
