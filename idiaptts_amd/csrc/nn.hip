@@ -462,6 +462,83 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// Adam with the gradient clipping in front and the parameter EMA behind it, one pass.
+__global__ void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                  float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                  float beta1, float beta2, float eps, float wd, float step_size,
+                                  float bc2_sqrt, float gscale, const float* __restrict__ norm_accum,
+                                  int norm_kind, float max_norm, float clip_value,
+                                  float* __restrict__ shadow, float one_minus_decay) {
+  float coef = gscale;
+  if (norm_accum) {
+    const float a = norm_accum[0];
+    const float total = (norm_kind == 2 ? sqrtf(a) : a) * fabsf(gscale);
+    coef *= fminf(1.f, max_norm / (total + 1e-6f));
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * coef;
+    if (clip_value > 0.f) gi = fminf(fmaxf(gi, -clip_value), clip_value);
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    vi = vi * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (shadow) {
+      const float si = shadow[i];
+      shadow[i] = si - one_minus_decay * (si - pi);
+    }
+  }
+}
+
+// sum x^2 / max |x| of a flat buffer: fixed grid of partials, then one block (deterministic)
+constexpr int kNormBlocks = 1024;
+__global__ __launch_bounds__(256) void grad_norm_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                               int kind, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float xi = x[i];
+    acc = kind == 2 ? acc + xi * xi : fmaxf(acc, fabsf(xi));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(acc, off, 64);
+    acc = kind == 2 ? acc + o : fmaxf(acc, o);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[blockIdx.x] = kind == 2 ? (red[0] + red[1]) + (red[2] + red[3])
+                                 : fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void grad_norm_final_kernel(const float* __restrict__ part, int nb,
+                                                             int kind, float* __restrict__ out,
+                                                             int accumulate) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc = kind == 2 ? acc + part[i] : fmaxf(acc, part[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(acc, off, 64);
+    acc = kind == 2 ? acc + o : fmaxf(acc, o);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = kind == 2 ? (red[0] + red[1]) + (red[2] + red[3])
+                        : fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (accumulate) r = kind == 2 ? out[0] + r : fmaxf(out[0], r);
+    out[0] = r;
+  }
+}
+
 // ---- SGD (torch.optim.SGD: weight decay, momentum, dampening, Nesterov) -------------------------
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                            float* __restrict__ buf, int64_t n, float lr, float momentum,
@@ -650,6 +727,45 @@ extern "C" int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_param, d_grad,
                      d_exp_avg, d_exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size,
                      bc2_sqrt, grad_scale);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_grad_norm_accum(const float* d_x, int64_t n, int norm_kind, float* d_accum,
+                                    int accumulate, void* d_workspace, void* stream) {
+  ITTS_REQUIRE(d_accum && d_workspace && (n == 0 || d_x), "null pointer");
+  ITTS_REQUIRE(n >= 0 && (norm_kind == 2 || norm_kind == 0), "norm_kind must be 2 or 0 (infinity)");
+  const int nb = (int)std::min<int64_t>((n + 255) / 256, kNormBlocks);
+  hipStream_t s = as_stream(stream);
+  float* part = static_cast<float*>(d_workspace);
+  if (nb > 0) {
+    hipLaunchKernelGGL(grad_norm_partial_kernel, dim3(nb), dim3(256), 0, s, d_x, n, norm_kind, part);
+    ITTS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, s, part, nb, norm_kind, d_accum,
+                     accumulate);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_adam_step_fused(float* d_param, const float* d_grad, float* d_exp_avg,
+                                    float* d_exp_avg_sq, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int64_t step,
+                                    float grad_scale, const float* d_norm_accum, int norm_kind,
+                                    float clip_max_norm, float clip_value, float* d_ema_shadow,
+                                    float ema_decay, void* stream) {
+  ITTS_REQUIRE(d_param && d_grad && d_exp_avg && d_exp_avg_sq, "null pointer");
+  ITTS_REQUIRE(n >= 0 && step >= 1, "bad sizes (step counts from 1)");
+  ITTS_REQUIRE(!d_norm_accum || ((norm_kind == 2 || norm_kind == 0) && clip_max_norm > 0.f),
+               "norm clipping needs norm_kind 2 or 0 and a positive max norm");
+  if (n == 0) return ITTS_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_param,
+                     d_grad, d_exp_avg, d_exp_avg_sq, n, beta1, beta2, eps, weight_decay,
+                     (float)(lr / bc1), (float)sqrt(bc2), grad_scale, d_norm_accum, norm_kind,
+                     clip_max_norm, clip_value, d_ema_shadow, 1.f - ema_decay);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }

@@ -71,6 +71,10 @@ _SIGNATURES = {
                                    _P, _P, _P]),
     "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_float, _P]),
+    "itts_grad_norm_accum": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P]),
+    "itts_adam_step_fused": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
+                                     c_float, c_int64, c_float, _P, c_int, c_float, c_float, _P,
+                                     c_float, _P]),
     "itts_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int,
                               c_int, c_float, _P]),
     "itts_ema_update": (c_int, [_P, _P, c_int64, c_float, _P]),

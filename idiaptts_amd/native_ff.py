@@ -97,15 +97,16 @@ class FlatFFModel:
         device = device if device is not None else layers[0][0].device
         return FlatFFModel(dims, acts, device=device, state_dict=layers)
 
-    def store_to_module(self, model):
-        """Writes the flat parameters back into the module stack (checkpoints, inference)."""
+    def store_to_module(self, model, buf=None):
+        """Writes the flat parameters (or another buffer of the same layout, e.g. the EMA shadow)
+        back into the module stack (checkpoints, inference)."""
         from .nn.modules import LinearAct
         inner = getattr(model, "model", model)
         mods = [m for g in inner.layer_groups for m in g.module if isinstance(m, LinearAct)]
         with torch.no_grad():
             for i, m in enumerate(mods):
-                m.weight.copy_(self.weight(i))
-                m.bias.copy_(self.bias(i))
+                m.weight.copy_(self.weight(i, buf))
+                m.bias.copy_(self.bias(i, buf))
         return mods
 
     def load_layers(self, layers):
@@ -183,14 +184,33 @@ class FlatFFModel:
         return loss
 
     def train_step(self, x, target, row_valid, n_valid_global, lr=1e-3, betas=(0.9, 0.999),
-                   eps=1e-8, weight_decay=0.0, process_group=None, world_size=1):
+                   eps=1e-8, weight_decay=0.0, process_group=None, world_size=1,
+                   clip_norm_kind=None, clip_max_norm=0.0, clip_value=None, ema_shadow=None,
+                   ema_decay=0.0):
+        """forward + masked MSE + backward + [all-reduce] + optimiser tail.  clip_norm_kind 2 / 0
+        (infinity) clips the gradient norm to clip_max_norm, clip_value clamps the elements,
+        ema_shadow (flat, this model's layout) is updated with ema_decay -- all inside the one
+        Adam pass (itts_adam_step_fused)."""
         loss = self.loss_and_backward(x, target, row_valid, n_valid_global)
         if world_size > 1:
             from .parallel import allreduce_flat_
             allreduce_flat_(self.grads, process_group)
         self.step_count += 1
-        ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count,
-                      lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        if clip_norm_kind is None and not clip_value and ema_shadow is None:
+            ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count,
+                          lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+            return loss
+        accum = None
+        if clip_norm_kind is not None:
+            if getattr(self, "_norm_accum", None) is None:
+                self._norm_accum = torch.zeros(1, dtype=torch.float32, device=self.device)
+            accum = ops.grad_norm_accum(self.grads, self._norm_accum, clip_norm_kind)
+        ops.adam_step_fused(self.params, self.grads, self.exp_avg, self.exp_avg_sq,
+                            self.step_count, lr=lr, betas=betas, eps=eps,
+                            weight_decay=weight_decay, norm_accum=accum,
+                            norm_kind=clip_norm_kind if clip_norm_kind is not None else 2,
+                            clip_max_norm=clip_max_norm, clip_value=clip_value or 0.0,
+                            ema_shadow=ema_shadow, ema_decay=ema_decay)
         return loss
 
 

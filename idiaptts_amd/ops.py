@@ -178,6 +178,41 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
                                 int(step), grad_scale, _stream()), "itts_adam_step")
 
 
+def grad_norm_accum(x, accum, norm_kind=2, accumulate=False):
+    """accum[0] (+)= sum x^2 (norm_kind 2) or max(accum[0], max |x|) (norm_kind 0 = infinity norm)
+    of a flat f32 buffer; the input of the clipping inside adam_step_fused."""
+    L = _lib.load()
+    _need(x, torch.float32, "x")
+    _need(accum, torch.float32, "accum")
+    if not x.is_contiguous():
+        raise ValueError("x must be contiguous")
+    _lib.check(L.itts_grad_norm_accum(_ptr(x), x.numel(), int(norm_kind), _ptr(accum),
+                                      int(bool(accumulate)), _ptr(_workspace(4096, x.device)),
+                                      _stream()), "itts_grad_norm_accum")
+    return accum
+
+
+def adam_step_fused(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                    weight_decay=0.0, grad_scale=1.0, norm_accum=None, norm_kind=2,
+                    clip_max_norm=0.0, clip_value=0.0, ema_shadow=None, ema_decay=0.0):
+    """Gradient clipping (by norm from `norm_accum`, by value), Adam and the parameter EMA in one
+    pass over flat f32 buffers."""
+    L = _lib.load()
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"),
+                 (exp_avg_sq, "exp_avg_sq")) + \
+            (((ema_shadow, "ema_shadow"),) if ema_shadow is not None else ()):
+        _need(t, torch.float32, n)
+        if not t.is_contiguous() or t.numel() != param.numel():
+            raise ValueError(n + " must be contiguous and as long as param")
+    _lib.check(L.itts_adam_step_fused(
+        _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, betas[0],
+        betas[1], eps, weight_decay, int(step), grad_scale,
+        _ptr(norm_accum) if norm_accum is not None else None, int(norm_kind),
+        float(clip_max_norm), float(clip_value or 0.0),
+        _ptr(ema_shadow) if ema_shadow is not None else None, float(ema_decay), _stream()),
+        "itts_adam_step_fused")
+
+
 def sgd_step(param, grad, momentum_buf=None, first_step=False, lr=1e-3, momentum=0.0,
              dampening=0.0, weight_decay=0.0, nesterov=False, grad_scale=1.0):
     L = _lib.load()

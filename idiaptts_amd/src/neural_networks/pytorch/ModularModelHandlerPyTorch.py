@@ -32,13 +32,177 @@ from idiaptts_amd.src.neural_networks.pytorch import config_json
 
 
 class HipAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (no amsgrad) through itts_adam_step."""
+    """torch.optim.Adam semantics (no amsgrad) on the HIP kernels.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    Flat arena (default on the GPU): the parameters of a group, their gradients and both moment
+    buffers live in four flat fp32 buffers; `p.data`, `p.grad` and the per-parameter state tensors
+    are views into them (the state_dict stays torch.optim.Adam's).  One step is then ONE launch
+    per group that also does what the reference's handler does around the optimiser
+    (ModularModelHandlerPyTorch.py:810-831): gradient clipping by norm (norm types 2 and inf) and
+    by value in front, the parameter EMA (ExponentialMovingAverage.py:32-45) behind -- see
+    `configure_clipping` / `attach_ema`; the data-parallel all-reduce runs on the flat gradient
+    without a flatten / unflatten copy (`allreduce_grads_`).  Autograd accumulates into the
+    gradient views in place, so `zero_grad` zeroes the flat buffer instead of dropping `.grad`.
+    Differences to torch: a parameter that never receives a gradient is stepped with g = 0
+    (torch skips it)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 flat=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._arenas = None
+        self._clip = None            # (norm_kind | None, max_norm, clip_value | None)
+        self._ema = None
+        self._norm_accum = None
+        self._flat = flat
+        self._build_arenas()
+
+    # ------------------------------------------------------------------------------ flat arena
+    def _build_arenas(self):
+        """(Re)creates the flat buffers; a no-op while the parameters are not (yet) fp32 on a GPU
+        -- tried again at the next zero_grad / step, e.g. after `model.cuda()`."""
+        if not self._flat:
+            return
+        groups = [[p for p in g['params'] if p.requires_grad] for g in self.param_groups]
+        ok = all(p.is_cuda and p.dtype == torch.float32 and not p.is_sparse
+                 for ps in groups for p in ps) and any(len(ps) for ps in groups)
+        if not ok:
+            return
+        self._arenas = []
+        for ps in groups:
+            if not ps:
+                self._arenas.append(None)
+                continue
+            n = sum(p.numel() for p in ps)
+            dev = ps[0].device
+            a = dict(params=ps, n=n, step=0,
+                     p=torch.empty(n, dtype=torch.float32, device=dev),
+                     g=torch.zeros(n, dtype=torch.float32, device=dev),
+                     m=torch.zeros(n, dtype=torch.float32, device=dev),
+                     v=torch.zeros(n, dtype=torch.float32, device=dev), shadow=None)
+            off = 0
+            with torch.no_grad():
+                for p in ps:
+                    k = p.numel()
+                    a['p'][off:off + k].copy_(p.data.reshape(-1))
+                    p.data = a['p'][off:off + k].view(p.shape)
+                    if p.grad is not None:
+                        a['g'][off:off + k].copy_(p.grad.reshape(-1))
+                    p.grad = a['g'][off:off + k].view(p.shape)
+                    st = self.state[p]
+                    if 'exp_avg' in st:      # re-pack (load_state_dict)
+                        a['m'][off:off + k].copy_(st['exp_avg'].reshape(-1))
+                        a['v'][off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+                        a['step'] = max(a['step'], int(st.get('step', 0)))
+                    st['step'] = a['step']
+                    st['exp_avg'] = a['m'][off:off + k].view(p.shape)
+                    st['exp_avg_sq'] = a['v'][off:off + k].view(p.shape)
+                    off += k
+            self._arenas.append(a)
+        if self._ema is not None:
+            self.attach_ema(self._ema)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)       # replaces the state tensors by copies
+        if self._arenas is not None:
+            self._build_arenas()
+
+    def zero_grad(self, set_to_none=True):
+        if self._arenas is None:
+            self._build_arenas()
+        if self._arenas is None:
+            return super().zero_grad(set_to_none)
+        for a in self._arenas:
+            if a is not None:
+                a['g'].zero_()
+
+    def configure_clipping(self, norm_type=None, max_norm=None, clip_value=None):
+        """Gradient clipping inside the step (torch.nn.utils.clip_grad_norm_ then
+        clip_grad_value_).  Returns False when this optimiser cannot do it (no arena, or a norm
+        type other than 2 / inf): the caller then clips with the torch utilities before step()."""
+        self._clip = None
+        if norm_type is None and clip_value is None:
+            return True
+        kind = None
+        if norm_type is not None:
+            if float(norm_type) == 2.0:
+                kind = 2
+            elif float(norm_type) == float("inf"):
+                kind = 0
+            else:
+                return False
+        if self._arenas is None:
+            return False
+        self._clip = (kind, float(max_norm) if kind is not None else 0.0, clip_value)
+        return True
+
+    def attach_ema(self, ema):
+        """Fuses the update of an ExponentialMovingAverage into the step: its shadow parameters
+        are re-pointed into a flat buffer in this optimiser's parameter order.  False without an
+        arena or when the two models do not line up."""
+        if ema is None:
+            return False
+        self._ema = ema                 # remembered: attached when the arena comes into being
+        if self._arenas is None:
+            self._build_arenas()
+            return self._arenas is not None and ema.fused
+        by_param = {id(p): n for n, p in ema.source_named_parameters()}
+        for a in self._arenas:
+            if a is None:
+                continue
+            names = [by_param.get(id(p)) for p in a['params']]
+            if any(n is None or n not in ema.shadow for n in names):
+                return False
+            a['shadow'] = torch.empty_like(a['p'])
+            off = 0
+            for n, p in zip(names, a['params']):
+                k = p.numel()
+                a['shadow'][off:off + k].copy_(ema.shadow[n].reshape(-1))
+                ema.repoint(n, a['shadow'][off:off + k].view(p.shape))
+                off += k
+        ema.fused = True
+        return True
+
+    def allreduce_grads_(self, local_weight, group=None):
+        """Data-parallel gradient step on the flat buffers (see parallel.allreduce_module_grads_);
+        False without an arena."""
+        if self._arenas is None:
+            return False
+        import torch.distributed as dist
+        for a in self._arenas:
+            if a is not None:
+                a['g'].mul_(float(local_weight))
+                dist.all_reduce(a['g'], op=dist.ReduceOp.SUM, group=group)
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self._arenas is None:
+            return self._step_per_tensor()
+        accum, kind, max_norm, clip_value = None, 2, 0.0, 0.0
+        if self._clip is not None:
+            kind, max_norm, clip_value = self._clip
+            if kind is not None:
+                live = [a for a in self._arenas if a is not None]
+                if self._norm_accum is None:
+                    self._norm_accum = torch.zeros(1, dtype=torch.float32, device=live[0]['p'].device)
+                accum = self._norm_accum
+                for i, a in enumerate(live):
+                    ops.grad_norm_accum(a['g'], accum, kind, accumulate=i > 0)
+        for group, a in zip(self.param_groups, self._arenas):
+            if a is None:
+                continue
+            a['step'] += 1
+            ops.adam_step_fused(a['p'], a['g'], a['m'], a['v'], a['step'], lr=group['lr'],
+                                betas=group['betas'], eps=group['eps'],
+                                weight_decay=group['weight_decay'], norm_accum=accum,
+                                norm_kind=kind if kind is not None else 2,
+                                clip_max_norm=max_norm, clip_value=clip_value or 0.0,
+                                ema_shadow=a['shadow'],
+                                ema_decay=self._ema.decay if a['shadow'] is not None else 0.0)
+            for p in a['params']:
+                self.state[p]['step'] = a['step']
+
+    def _step_per_tensor(self):
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is None:
@@ -88,20 +252,34 @@ class HipSGD(torch.optim.Optimizer):
 class ExponentialMovingAverage(object):
     """Shadow copy of the trainable parameters, `shadow = decay * shadow + (1 - decay) * x` after
     every optimiser step (reference ExponentialMovingAverage.py:13-45); validation and the saved
-    checkpoints use the averaged parameters."""
+    checkpoints use the averaged parameters.  HipAdam.attach_ema moves the shadow parameters into
+    a flat buffer and updates them inside its fused step (`fused` is then True and
+    update_params a no-op)."""
 
     def __init__(self, model, decay):
         import copy
         self.model = copy.deepcopy(model)
         self.decay = decay
         self.shadow = {}
+        self.fused = False
+        self._source = model
         for name, param in self.model.named_parameters():
             if param.requires_grad:
                 self.shadow[name] = param.data
             param.detach_()
 
+    def source_named_parameters(self):
+        return self._source.named_parameters()
+
+    def repoint(self, name, tensor):
+        """Makes `tensor` (same shape, already holding the values) the storage of shadow `name`."""
+        dict(self.model.named_parameters())[name].data = tensor
+        self.shadow[name] = tensor
+
     def update_params(self, other_model):
         assert other_model is not self.model
+        if self.fused:
+            return
         for name, param in other_model.named_parameters():
             if name in self.shadow:
                 ops.ema_update(self.shadow[name].view(-1), param.data.contiguous().view(-1),
@@ -326,6 +504,8 @@ class ModularModelHandlerPyTorch(object):
             return
         flat = res["flat"]
         lin = flat.store_to_module(self.model)
+        if res.get("ema_shadow") is not None and self.ema is not None:
+            flat.store_to_module(self.ema.model, res["ema_shadow"])
         if self.optimiser is not None and isinstance(self.optimiser, HipAdam) and flat.step_count > 0:
             for i, m in enumerate(lin):
                 for p, view in ((m.weight, flat.weight), (m.bias, flat.bias)):
@@ -333,6 +513,8 @@ class ModularModelHandlerPyTorch(object):
                         "step": flat.step_count,
                         "exp_avg": view(i, flat.exp_avg).clone().contiguous(),
                         "exp_avg_sq": view(i, flat.exp_avg_sq).clone().contiguous()}
+            if self.optimiser._arenas is not None:
+                self.optimiser._build_arenas()        # re-pack the arena from the new state
 
     def _process_resident(self, dataloader, shard, hparams, total_epoch, total_steps,
                           current_epoch, training):
@@ -342,12 +524,22 @@ class ModularModelHandlerPyTorch(object):
         flat = res["flat"]
         if not isinstance(self.optimiser, HipAdam) and training:
             raise NotImplementedError("resident_dataset trains with Adam.")
-        if hparams.ema_decay or hparams.grad_clip_norm_type is not None \
-                or hparams.grad_clip_thresh is not None:
-            raise NotImplementedError("EMA / gradient clipping are not available with "
+        clip_kind = None
+        if hparams.grad_clip_norm_type is not None:
+            clip_kind = {2.0: 2, float("inf"): 0}.get(float(hparams.grad_clip_norm_type))
+            if clip_kind is None:
+                raise NotImplementedError("resident_dataset clips with norm type 2 or inf.")
+        if hparams.replace_inf_grads_by_zero:
+            raise NotImplementedError("replace_inf_grads_by_zero is not available with "
                                       "resident_dataset.")
         if not res["synced"]:
             self._resident_sync_from_module()
+        if training and self.ema is not None and res.get("ema_shadow") is None:
+            # flat shadow in the step's layout, seeded from the averaged model
+            res["ema_shadow"] = torch.zeros_like(flat.params)
+            from idiaptts_amd.native_ff import FlatFFModel
+            res["ema_shadow"].copy_(FlatFFModel.from_module(self.ema.model, self._device()).params)
+            self.ema.fused = True
         if len(self.losses) != 1 or getattr(self.losses[0], "loss_weight", 1.0) != 1.0:
             raise NotImplementedError("resident_dataset trains one unweighted masked-MSE loss.")
         loss_name = self.losses[0].name
@@ -364,10 +556,21 @@ class ModularModelHandlerPyTorch(object):
                 group = self.optimiser.param_groups[0]
                 loss = flat.train_step(x, y, valid, n_global, lr=group["lr"], betas=group["betas"],
                                        eps=group["eps"], weight_decay=group["weight_decay"],
-                                       world_size=world)
+                                       world_size=world, clip_norm_kind=clip_kind,
+                                       clip_max_norm=hparams.grad_clip_max_norm or 0.0,
+                                       clip_value=hparams.grad_clip_thresh,
+                                       ema_shadow=res.get("ema_shadow"),
+                                       ema_decay=self.ema.decay if self.ema is not None else 0.0)
                 total_steps += 1
             else:
-                loss, _ = ops.masked_mse(flat.forward(x)[-1], y, valid, n_global, want_grad=False)
+                live = flat.params       # validation uses the averaged parameters (reference :704-707)
+                if res.get("ema_shadow") is not None:
+                    flat.params = res["ema_shadow"]
+                try:
+                    loss, _ = ops.masked_mse(flat.forward(x)[-1], y, valid, n_global,
+                                             want_grad=False)
+                finally:
+                    flat.params = live
             loss = parallel.allreduce_flat_(loss.clone())[0]
             if torch.isnan(loss):
                 raise ValueError("Found NaN in {} loss.".format(loss_name))
@@ -533,6 +736,8 @@ class ModularModelHandlerPyTorch(object):
     def train(self, hparams, total_epoch, total_steps, current_epoch):
         if hparams.ema_decay and not self.ema:
             self.ema = ExponentialMovingAverage(self.model, hparams.ema_decay)
+            if isinstance(self.optimiser, HipAdam):
+                self.optimiser.attach_ema(self.ema)       # updated inside the fused step
         return self.process_dataloader(self.dataloader_train, hparams, total_epoch, total_steps,
                                        current_epoch, training=True)
 
@@ -564,6 +769,11 @@ class ModularModelHandlerPyTorch(object):
         device = self._device()
         logging_batch_index = (len(dataloader) // hparams.logging_batch_index_perc) + 1
         total_losses = dict()
+        # clipping inside the optimiser's fused step when it can (HipAdam, norm types 2 / inf)
+        fused_clip = False
+        if training and hasattr(self.optimiser, "configure_clipping"):
+            fused_clip = self.optimiser.configure_clipping(
+                hparams.grad_clip_norm_type, hparams.grad_clip_max_norm, hparams.grad_clip_thresh)
         for batch_index, (data_dict, lengths) in enumerate(dataloader):
             data_dict = self._to_device(data_dict, device, hparams.dataset_load_async)
             batch_size = len(next(iter(lengths.values())))
@@ -593,14 +803,16 @@ class ModularModelHandlerPyTorch(object):
                 backprop_loss.backward(retain_graph=hparams.backward_retain_graph)
                 total_steps += 1
                 if dp_weight is not None:
-                    parallel.allreduce_module_grads_(list(self.model.parameters()), dp_weight)
+                    flat_sync = getattr(self.optimiser, "allreduce_grads_", None)
+                    if flat_sync is None or not flat_sync(dp_weight):
+                        parallel.allreduce_module_grads_(list(self.model.parameters()), dp_weight)
                 if hparams.replace_inf_grads_by_zero:
                     self._replace_inf_grads_by_zero()
-                if hparams.grad_clip_norm_type is not None:
+                if hparams.grad_clip_norm_type is not None and not fused_clip:
                     torch.nn.utils.clip_grad_norm_(self.model.parameters(),
                                                    hparams.grad_clip_max_norm,
                                                    hparams.grad_clip_norm_type)
-                if hparams.grad_clip_thresh is not None:
+                if hparams.grad_clip_thresh is not None and not fused_clip:
                     torch.nn.utils.clip_grad_value_(self.model.parameters(),
                                                     hparams.grad_clip_thresh)
                 self.optimiser.step()

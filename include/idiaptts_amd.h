@@ -119,6 +119,27 @@ int itts_adam_step(float* d_param, const float* d_grad, float* d_exp_avg, float*
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    int64_t step, float grad_scale, void* stream);
 
+/* Gradient norm of a flat fp32 buffer for clipping (torch.nn.utils.clip_grad_norm_,
+ * ModularModelHandlerPyTorch.py:810-814): norm_kind 2 -> d_accum[0] (+)= sum x^2, norm_kind 0 ->
+ * d_accum[0] = max(d_accum[0], max |x|) (infinity norm).  accumulate = 0 overwrites d_accum.
+ * Deterministic two-stage reduction; d_workspace >= 4096 bytes. */
+int itts_grad_norm_accum(const float* d_x, int64_t n, int norm_kind, float* d_accum,
+                         int accumulate, void* d_workspace, void* stream);
+
+/* The whole optimiser tail of one training step in one pass over a flat parameter buffer
+ * (ModularModelHandlerPyTorch.py:810-831 + ExponentialMovingAverage.py:32-45):
+ *   g = grad * grad_scale
+ *   d_norm_accum != NULL: g *= min(1, clip_max_norm / (norm + 1e-6)), norm = sqrt(accum) (kind 2)
+ *                         or accum (kind 0) of the scaled gradient    [clip_grad_norm_]
+ *   clip_value > 0:       g = clamp(g, -clip_value, clip_value)        [clip_grad_value_]
+ *   Adam update as itts_adam_step
+ *   d_ema_shadow != NULL: shadow -= (1 - ema_decay) * (shadow - param_new) */
+int itts_adam_step_fused(float* d_param, const float* d_grad, float* d_exp_avg,
+                         float* d_exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int64_t step, float grad_scale,
+                         const float* d_norm_accum, int norm_kind, float clip_max_norm,
+                         float clip_value, float* d_ema_shadow, float ema_decay, void* stream);
+
 /* SGD on a flat fp32 buffer (torch.optim.SGD semantics, ModularModelHandlerPyTorch.py:572-573):
  * g += weight_decay*p; with momentum: buf = g on the first step, else momentum*buf +
  * (1-dampening)*g; g = nesterov ? g + momentum*buf : buf; p -= lr*g.  d_momentum_buf may be NULL

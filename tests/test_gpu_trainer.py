@@ -203,3 +203,37 @@ def test_duration_model_trainer(gpu, golden_dir, tmp_path):
             assert post[i].shape == g["dur/" + i].shape and post[i].dtype == np.int64
             assert (post[i] % hp.min_phoneme_length == 0).all() and (post[i] >= 0).all()
             assert out[i]["pred_durations"].shape == g["dur/" + i].shape
+
+
+def test_ema_and_gradient_clipping_module_path_equals_resident_path(gpu, fixture):
+    """hparams.ema_decay / grad_clip_* (reference handler :810-831): the module path (HipAdam's
+    fused step on its flat arena) and the resident path (FlatFFModel's fused step) are separate
+    plumbing over the same kernels (pinned against torch in tests/test_gpu_optim.py) -- they must
+    produce the same losses; validation runs on the averaged parameters in both."""
+    runs = []
+    for resident in (False, True):
+        hp = _hparams(fixture[0], fixture[2], "test_ema_clip_{}".format(int(resident)))
+        hp.seed = 1234
+        hp.use_best_as_final_model = False
+        hp.resident_dataset = resident
+        hp.ema_decay = 0.8
+        hp.grad_clip_norm_type = 2
+        hp.grad_clip_max_norm = 0.05
+        hp.grad_clip_thresh = 0.01
+        trainer = _trainer(fixture, hp)
+        trainer.init(hp)
+        val, train, handler = trainer.train(hp)
+        assert handler.ema is not None and handler.ema.fused
+        ema_sd = {k: v.detach().cpu().numpy().copy() for k, v in handler.ema.model.state_dict().items()}
+        live_sd = {k: v.detach().cpu().numpy().copy() for k, v in handler.model.state_dict().items()}
+        runs.append((val["MSELoss_acoustic_features"], train["MSELoss_acoustic_features"],
+                     ema_sd, live_sd))
+    (v0, t0, e0, l0), (v1, t1, e1, l1) = runs
+    np.testing.assert_allclose(v0, v1, rtol=2e-5)
+    np.testing.assert_allclose(t0, t1, rtol=2e-5)
+    for k in e0:
+        np.testing.assert_allclose(e0[k], e1[k], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(l0[k], l1[k], rtol=0, atol=2e-6)
+        assert np.abs(e0[k] - l0[k]).max() > 0          # the averaged model lags the live one
+    g = fixture[4]
+    assert np.abs(np.asarray(t0[1:]) - np.asarray(g["train_train_losses"][1:])).max() > 1e-6   # clipping acted
