@@ -18,6 +18,47 @@ def _dev():
     return torch.device("cuda")
 
 
+def merlin_post_filter(mgc, alpha, minimum_phase_order=511, fftlen=1024, coef=1.4, weight=None):
+    """Merlin's formant-enhancing post filter on mel-cepstra [T, D] (nnmnkwii.postfilters.
+    merlin_post_filter, called by the reference's decode_sp, AudioProcessing.py:308-314; nnmnkwii is
+    not vendored: parity unpinned, the algorithm is restated from its published form):
+    coefficients >= 2 are scaled by `coef`, then the 0th MLSA coefficient is corrected so that the
+    frame keeps its energy r0 = c2acr(freqt(mc, -alpha))[0].
+
+    The two energies come from the mgc2sp kernel (power spectrum of the de-warped cepstrum; its
+    mean over the fftlen bins is the 0th autocorrelation); mc2b / b2mc are O(D) recursions over
+    the coefficient index, vectorised over the frames on the host.  The de-warped cepstrum is
+    truncated at fftlen/2 instead of minimum_phase_order: the omitted coefficient is ~ alpha^450."""
+    mgc = np.ascontiguousarray(mgc, dtype=np.float64)
+    T, D = mgc.shape
+    if weight is None:
+        weight = np.ones(D) * coef
+        weight[:2] = 1
+    assert len(weight) == D
+    dev = _dev()
+
+    def r0(mc):
+        p = torch.exp(2.0 * ops.mgc2sp(torch.from_numpy(np.ascontiguousarray(mc)).to(dev), alpha,
+                                       fftlen, want_logamp=True))
+        return ((p[:, 0] + p[:, -1] + 2.0 * p[:, 1:-1].sum(dim=1)) / fftlen).cpu().numpy()
+
+    def mc2b(mc):
+        b = mc.copy()
+        for m in range(D - 2, -1, -1):
+            b[:, m] = mc[:, m] - alpha * b[:, m + 1]
+        return b
+
+    def b2mc(b):
+        mc = b.copy()
+        mc[:, :-1] = b[:, :-1] + alpha * b[:, 1:]
+        return mc
+
+    weighted = mgc * weight
+    b = mc2b(weighted)
+    b[:, 0] = np.log(r0(mgc) / r0(weighted)) / 2 + b[:, 0]
+    return b2mc(b)
+
+
 class AudioProcessing:
     mgc_gamma = -1. / 3.
 
@@ -82,7 +123,10 @@ class AudioProcessing:
                   mgc_gamma: float = None, n_fft: int = None, post_filtering: bool = False):
         """reference :303-327"""
         if post_filtering:
-            logging.warning("merlin_post_filter is not part of the hot path; ignoring.")
+            if sp_type in ("mcep", "mgc"):
+                coded_sp = merlin_post_filter(coded_sp, AudioProcessing.fs_to_mgc_alpha(fs))
+            else:
+                logging.warning("Post-filtering only implemented for cepstrum features.")
         if sp_type == "mcep":
             return AudioProcessing.mcep_to_amp_sp(coded_sp, fs, alpha)
         elif sp_type == "amp_sp":

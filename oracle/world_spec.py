@@ -255,6 +255,23 @@ def frqtr(c1, m1, m2, a):
         d[0] = g[0]; g[0] = c1[-i]
         for j in range(1, m2 + 1): d[j] = g[j]; g[j] = d[j - 1] + a * (d[j] - g[j - 1])
     return g
+def merlin_post_filter(mgc, alpha, minimum_phase_order=511, fftlen=1024, coef=1.4):
+    # nnmnkwii.postfilters.merlin_post_filter restated with SPTK's freqt / c2acr / mc2b / b2mc
+    T, D = mgc.shape; w = np.ones(D) * coef; w[:2] = 1
+    def c2acr0(c):                                   # 0th autocorrelation of the minimum-phase spectrum
+        cc = np.zeros(fftlen); cc[:len(c)] = c
+        return np.mean(np.exp(2 * np.fft.fft(cc).real))
+    def mc2b(mc):
+        b = mc.copy()
+        for m in range(D - 2, -1, -1): b[m] = mc[m] - alpha * b[m + 1]
+        return b
+    out = np.zeros_like(mgc)
+    for t in range(T):
+        r0 = c2acr0(freqt(mgc[t], D - 1, minimum_phase_order, -alpha))
+        r0p = c2acr0(freqt(mgc[t] * w, D - 1, minimum_phase_order, -alpha))
+        b = mc2b(mgc[t] * w); b[0] = np.log(r0 / r0p) / 2 + b[0]
+        out[t] = b; out[t, :-1] = b[:-1] + alpha * b[1:]
+    return out
 def sptk_mcep(amp, m, a, eps=1e-8, itr1=2, itr2=30, dd=1e-3):
     flng = (len(amp) - 1) * 2; f2 = flng // 2; m2 = 2 * m
     x = amp * amp + eps; x = np.concatenate([x, x[f2 - 1:0:-1]])

@@ -185,3 +185,29 @@ def test_gen_data_sharded_over_two_ranks_equals_single_process(gpu, golden_dir, 
     for n in ids:
         assert np.array_equal(reader.load(n), ref_dict[n])               # feature files identical
     assert os.path.isfile(str(sharded / "mcep20" / "ids-deltas-mean-covariance.npz"))
+
+
+def test_merlin_post_filter_and_decode_sp(gpu, golden_dir):
+    """decode_sp(post_filtering=True) (AudioProcessing.py:303-314): the post filter against the
+    numpy restatement (nnmnkwii is not vendored: parity unpinned), energy preserved, formants
+    sharpened; then the decoded spectrum."""
+    from idiaptts_amd.src.data_preparation.audio.AudioProcessing import (AudioProcessing,
+                                                                         merlin_post_filter)
+    from oracle import world_spec as ws
+    cmp_ = np.fromfile(os.path.join(golden_dir, "LJ001-0008.cmp"), dtype=np.float32).reshape(-1, 67)
+    mc = cmp_[100:140, :20].astype(np.float64)
+    alpha = 0.41
+    got = merlin_post_filter(mc, alpha)
+    want = ws.merlin_post_filter(mc, alpha)
+    assert np.abs(got - want).max() < 1e-10
+    sp0 = AudioProcessing.decode_sp(mc, "mcep", 16000, alpha)
+    sp1 = AudioProcessing.decode_sp(mc, "mcep", 16000, post_filtering=True)
+    assert sp1.dtype == np.float32 and sp1.shape == sp0.shape == (40, 513)
+    def energy(sp):                     # mean power over the full circle from the half spectrum
+        p = sp.astype(np.float64) ** 2
+        return (p[:, 0] + p[:, -1] + 2 * p[:, 1:-1].sum(axis=1)) / 1024
+    e0, e1 = energy(sp0), energy(sp1)
+    assert np.abs(e1 / e0 - 1).max() < 1e-4                     # frame energy kept
+    d0 = np.log(sp0).max(axis=1) - np.log(sp0).min(axis=1)
+    d1 = np.log(sp1).max(axis=1) - np.log(sp1).min(axis=1)
+    assert (d1 > d0).mean() > 0.9                               # peaks-to-valleys enhanced
