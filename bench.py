@@ -101,10 +101,12 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
 
     def analysis():
         f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop), f_off, fs, hop)
-        _, mc, it = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop, n_fft, want_sp=False,
-                                        order=order, alpha=alpha, want_iters=True)
+        # D4C first, like world.analyse_batch: the mcep Newton loop reads trip counts back from
+        # the device, so whatever is queued behind it starts late
         _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop, n_fft, want_ap=False,
                          want_bap=torch.float32)
+        _, mc, it = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop, n_fft, want_sp=False,
+                                        order=order, alpha=alpha, want_iters=True)
         return f0, mc, bap, it
 
     def over_ranks(value, op):

@@ -30,6 +30,22 @@ void set_error(const std::string& msg);
 
 #define ITTS_LAUNCH_CHECK() ITTS_HIP_CHECK(hipGetLastError())
 
+// Host wait for everything queued on `s`, by polling: hipStreamSynchronize puts the thread to
+// sleep when the wait gets long (a millisecond-scale kernel in front) and the wake-up then costs
+// up to a millisecond of idle GPU; data-dependent loops that need a count back from the device
+// between launches (mcep trip counts) poll an event instead.
+static inline hipError_t itts_spin_sync(hipStream_t s) {
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(ev, s);
+  if (e == hipSuccess)
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
+    }
+  (void)hipEventDestroy(ev);
+  return e;
+}
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -440,7 +440,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
   ITTS_HIP_CHECK(hipMemcpyAsync(d_taps, taps.data(), taps.size() * 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf, lpf.data(), lpf.size() * 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf_off, lpf_off.data(), lpf_off.size() * 4, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors die with this frame
+  ITTS_HIP_CHECK(itts_spin_sync(s));  // host staging vectors die with this frame
 
   const int64_t budget = (int64_t)3 << 30;  // scratch bytes per sub-batch
   int u0 = 0;
@@ -485,7 +485,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
     ITTS_HIP_CHECK(hipMallocAsync((void**)&d_tmp, tmp_n * 8, s));
     ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cnt, cnt_n * 4, s));
     ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), U * sizeof(DioUtt), hipMemcpyHostToDevice, s));
-    ITTS_HIP_CHECK(hipStreamSynchronize(s));
+    ITTS_HIP_CHECK(itts_spin_sync(s));
 
     hipLaunchKernelGGL(dio_mean_kernel, dim3(U), dim3(NT), 0, s, d_x, d_utts, d_mean);
     ITTS_LAUNCH_CHECK();

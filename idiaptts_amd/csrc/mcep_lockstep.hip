@@ -422,7 +422,7 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     if (it >= miniter && it < maxiter) {
       int remaining = 0;
       ITTS_HIP_CHECK(hipMemcpyAsync(&remaining, n_active, 4, hipMemcpyDeviceToHost, s));
-      ITTS_HIP_CHECK(hipStreamSynchronize(s));
+      ITTS_HIP_CHECK(itts_spin_sync(s));
       if (remaining <= 0) break;
       if (remaining < nr) {          // shrink the work list to the frames that still iterate
         ITTS_HIP_CHECK(hipMemsetAsync(n_active + 1, 0, 4, s));

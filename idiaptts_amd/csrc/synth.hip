@@ -680,7 +680,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   ITTS_HIP_CHECK(hipMallocAsync((void**)&d_gpoff, (n_utts + 1) * 8, s));
   ITTS_HIP_CHECK(hipMallocAsync((void**)&d_y, y_total * 8, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), n_utts * sizeof(SynUtt), hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  ITTS_HIP_CHECK(itts_spin_sync(s));
   ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, y_total * 8, s));
 
   const dim3 gblk(max_nblk, n_utts);

@@ -398,14 +398,16 @@ static size_t mc_lds_bytes(int m) {
          (size_t)m1 * (m + 2) * 8 + (size_t)(m1 + 1) * 8 + 64;
 }
 
-// CheapTrick (+ optional fused mcep) -- one workgroup per frame.
+// CheapTrick (+ optional fused mcep) -- one workgroup per frame.  Two instantiations: the fused
+// Newton loop needs ~240 VGPRs, plain CheapTrick far fewer (twice the workgroups per CU).
+template <bool DO_MCEP>
 __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* p = smem;
   CtLds L;
   carve_ct(p, a.fft, a.bmax, L);
   McLds M;
-  if (a.do_mcep) carve_mc(p, a.m, M);
+  if (DO_MCEP) carve_mc(p, a.m, M);
   const int64_t g = blockIdx.x;
   const int u = find_utt(a.f_off, a.n_utts, g);
   const int64_t t = g - a.f_off[u];
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   const int K = a.fft / 2 + 1;
   if (a.sp)
     for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
-  if (a.do_mcep) {
+  if (DO_MCEP) {
     // amp = sqrt(pow) (WorldFeatLabelGen.py:795), periodogram = amp^2 + eps (SPTK mcep itype 3)
     for (int k = threadIdx.x; k < K; k += NT) {
       const double amp = sqrt(L.P[k]);
@@ -671,9 +673,15 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch;
   size_t lds = ct_lds_bytes(fft_size, a.bmax) + (fused ? mc_lds_bytes(order) : 0);
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(cheaptrick_kernel, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  if (fused) {
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(cheaptrick_kernel<true>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  } else {
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(cheaptrick_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  }
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
