@@ -302,7 +302,8 @@ extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const 
 extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const float* d_gates,
                                   const float* d_hprev, const int* h_lengths,
                                   const int* d_row_off, const int* d_rev_row, int T, int B, int H,
-                                  int ndir, float* d_dgi, float* d_dgh, void* d_state, void* stream) {
+                                  int ndir, float* d_dgi, float* d_dgh, float* d_dh0, void* d_state,
+                                  void* stream) {
   ITTS_REQUIRE(d_dy && d_whh && d_gates && d_hprev && d_row_off && d_dgi && d_dgh && d_state, "null pointer");
   ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
   int rc = rnn_check(h_lengths, T, B, H, ndir);
@@ -331,5 +332,8 @@ extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const f
                        dim3(64 * a.ksplit), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
+  // step 0 (all rows active) leaves dh * z in the parity-0 carry buffer [ndir][B][H]
+  if (d_dh0)
+    ITTS_HIP_CHECK(hipMemcpyAsync(d_dh0, a.hs, (size_t)ndir * B * H * 4, hipMemcpyDeviceToDevice, s));
   return ITTS_OK;
 }

@@ -334,7 +334,8 @@ extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const
 extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const float* d_c0,
                                    const float* d_gates, const float* d_csave, const int* h_lengths,
                                    const int* d_row_off, const int* d_rev_row, int T, int B, int H,
-                                   int ndir, float* d_dg, void* d_state, void* stream) {
+                                   int ndir, float* d_dg, float* d_dc0, void* d_state,
+                                   void* stream) {
   ITTS_REQUIRE(d_dy && d_whh && d_gates && d_csave && d_row_off && d_dg && d_state, "null pointer");
   ITTS_REQUIRE(ndir == 1 || d_rev_row, "the reverse direction needs its row table");
   int rc = rnn_check(h_lengths, T, B, H, ndir);
@@ -365,5 +366,9 @@ extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const 
                        dim3(64 * a.ksplit), 0, s, a);
   }
   ITTS_LAUNCH_CHECK();
+  // step 0 has every row active and leaves dc * f, the gradient of the initial cell state, in the
+  // parity-0 carry buffer [ndir][B][H]
+  if (d_dc0)
+    ITTS_HIP_CHECK(hipMemcpyAsync(d_dc0, a.cs, (size_t)ndir * B * H * 4, hipMemcpyDeviceToDevice, s));
   return ITTS_OK;
 }

@@ -63,12 +63,12 @@ _SIGNATURES = {
     "itts_lstm_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
                                     _P, _P, _P, _P, _P, _P]),
     "itts_lstm_layer_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
-                                    _P, _P]),
+                                    _P, _P, _P]),
     "itts_gru_state_bytes": (c_int64, [c_int, c_int, c_int]),
     "itts_gru_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
                                    _P, _P, _P, _P]),
     "itts_gru_layer_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
-                                   _P, _P, _P]),
+                                   _P, _P, _P, _P]),
     "itts_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_float, _P]),
     "itts_grad_norm_accum": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P]),

@@ -103,6 +103,14 @@ class PackedBatch(object):
             out[:, d * H:(d + 1) * H] = src.index_select(0, self.prev_row[d])
         return out
 
+    def first_rows(self, d):
+        """Packed rows of the first frame direction d processes in every sequence ([B] indices):
+        where the recurrence starts from the initial state."""
+        cache = self.__dict__.setdefault("_first_rows", {})
+        if d not in cache:
+            cache[d] = (self.prev_row[d] == self.N).nonzero().reshape(-1)
+        return cache[d]
+
     def _hptr(self):
         return ctypes.c_void_p(self.h_lengths.data_ptr())
 
@@ -156,11 +164,21 @@ class LSTMLayerFunction(torch.autograd.Function):
         dy2 = dy.contiguous()
         dg = torch.empty((pb.N, ndir * G4), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_lstm_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
+        want_h0, want_c0 = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
+        dc0_rows = torch.empty((ndir, pb.B, H), dtype=torch.float32, device=dev) if want_c0 else None
         _lib.check(L.itts_lstm_layer_bwd(_iptr(dy2), _iptr(w_hh), _iptr(c0 if has_c0 else None),
                                          _iptr(gates), _iptr(csave), pb._hptr(),
                                          _iptr(pb.d_row_off), _iptr(pb.d_rev_row), pb.T, pb.B, H, ndir,
-                                         _iptr(dg), _iptr(state), ops._stream()),
+                                         _iptr(dg), _iptr(dc0_rows), _iptr(state), ops._stream()),
                    "itts_lstm_layer_bwd")
+        # trainable initial states (RNNWrapper train_hidden_init): one vector per direction shared
+        # by all rows -> sum over the rows; dh0 = W_hh^T dG at the first processed frame
+        dh0 = dc0 = None
+        if want_h0:
+            dh0 = torch.stack([dg[:, d * G4:(d + 1) * G4].index_select(0, pb.first_rows(d)).sum(0)
+                               @ w_hh[d] for d in range(ndir)], dim=0)
+        if want_c0:
+            dc0 = dc0_rows.sum(dim=1)
         dw_ih, db = ops.linear_bwd_weight(dg, x2)                      # [ndir*4H, F], [ndir*4H]
         dw_hh = torch.empty((ndir, G4, H), dtype=torch.float32, device=dev)
         for d in range(ndir):
@@ -170,7 +188,7 @@ class LSTMLayerFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dg, w_ih_cat)
         db = db.reshape(ndir, G4)
-        return dx, None, dw_ih.reshape(ndir, G4, F), dw_hh, db, db.clone(), None, None, None
+        return dx, None, dw_ih.reshape(ndir, G4, F), dw_hh, db, db.clone(), dh0, dc0, None
 
 
 class GRULayerFunction(torch.autograd.Function):
@@ -219,11 +237,18 @@ class GRULayerFunction(torch.autograd.Function):
         dgi = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
         dgh = torch.empty((pb.N, ndir * G3), dtype=torch.float32, device=dev)
         state = torch.empty(L.itts_gru_state_bytes(pb.B, H, ndir), dtype=torch.uint8, device=dev)
+        want_h0 = ctx.needs_input_grad[6]
+        dh0_rows = torch.empty((ndir, pb.B, H), dtype=torch.float32, device=dev) if want_h0 else None
         _lib.check(L.itts_gru_layer_bwd(_iptr(dy2), _iptr(w_hh), _iptr(gates),
                                         _iptr(hprev), pb._hptr(), _iptr(pb.d_row_off),
                                         _iptr(pb.d_rev_row), pb.T, pb.B, H, ndir, _iptr(dgi),
-                                        _iptr(dgh), _iptr(state), ops._stream()),
+                                        _iptr(dgh), _iptr(dh0_rows), _iptr(state), ops._stream()),
                    "itts_gru_layer_bwd")
+        dh0 = None
+        if want_h0:      # direct part dh * z from the kernel + recurrent part W_hh^T dGh, summed over rows
+            dh0 = dh0_rows.sum(dim=1) + torch.stack(
+                [dgh[:, d * G3:(d + 1) * G3].index_select(0, pb.first_rows(d)).sum(0) @ w_hh[d]
+                 for d in range(ndir)], dim=0)
         dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]
         dw_hh = torch.empty((ndir, G3, H), dtype=torch.float32, device=dev)
         db_hh = torch.empty((ndir, G3), dtype=torch.float32, device=dev)
@@ -235,4 +260,4 @@ class GRULayerFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dgi, w_ih_cat)
         return dx, None, dw_ih.reshape(ndir, G3, F), dw_hh, db_ih.reshape(ndir, G3), db_hh, \
-            None, None
+            dh0, None

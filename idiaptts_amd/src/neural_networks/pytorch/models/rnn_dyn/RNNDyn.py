@@ -74,10 +74,12 @@ class RNNWrapper(nn.Module):
         init = layer_config.kwargs.get('hidden_init_value', 0.0)
         h0 = torch.full((layer_config.num_layers * ndir, 1, layer_config.out_dim), float(init))
         c0 = h0.clone()
-        if layer_config.kwargs.get('train_hidden_init', False):
-            raise NotImplementedError("train_hidden_init is not supported yet")
-        self.register_buffer('h_0', h0)
-        self.register_buffer('c_0', c0)
+        if layer_config.kwargs.get('train_hidden_init', False):     # reference RNNWrapper.py:66-71
+            self.register_parameter('h_0', nn.Parameter(h0))
+            self.register_parameter('c_0', nn.Parameter(c0))
+        else:
+            self.register_buffer('h_0', h0)
+            self.register_buffer('c_0', c0)
         self.out_dim = layer_config.out_dim * ndir
 
     def init_hidden(self, batch_size=1):

@@ -246,11 +246,13 @@ int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const float* d_h
                         void* stream);
 /* d_dg [N, ndir*4H] = dLoss/d(pre-activation gates) from d_dy [N, ndir*H]; d_whh as in the
  * forward call.  dW_ih, dW_hh, db and dX follow from d_dg with itts_linear_bwd_weight /
- * itts_linear_bwd_input. */
+ * itts_linear_bwd_input.  d_dc0 [ndir][B][H] (may be NULL) receives dLoss/d(initial cell state) per
+ * packed row (RNNWrapper's train_hidden_init, rnn_dyn/RNNWrapper.py:66-71: sum over the rows);
+ * dLoss/d(initial hidden state) of row b is W_hh^T d_dg[first processed frame of b]. */
 int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const float* d_c0,
                         const float* d_gates, const float* d_csave, const int* h_lengths,
                         const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
-                        float* d_dg, void* d_state, void* stream);
+                        float* d_dg, float* d_dc0, void* d_state, void* stream);
 
 /* ---- (Bi)GRU recurrence (torch.nn.GRU behind rnn_dyn/RNNWrapper.py:45-107 for `..GRU..` groups;
  *      gate order r, z, n; packed rows, lengths and row offsets as for the LSTM entry points).
@@ -261,7 +263,9 @@ int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const float* d_c0
  * d_state >= itts_gru_state_bytes(B, H, ndir).
  * Backward takes d_hprev [N, ndir*H] (h_{t-1} of every frame: d_y shifted by one frame along each
  * sequence, h0 at the first frame) and fills d_dgi (gradient wrt d_gin: feeds dX, dW_ih, db_ih) and d_dgh (gradient wrt the
- * hidden projections: feeds dW_hh with d_hprev, db_hh), both [N, ndir*3H]. */
+ * hidden projections: feeds dW_hh with d_hprev, db_hh), both [N, ndir*3H].  d_dh0 [ndir][B][H] (may
+ * be NULL) receives the direct part dh * z of dLoss/d(initial hidden state) per packed row; the
+ * recurrent part of row b is W_hh^T d_dgh[first processed frame of b] (train_hidden_init). */
 int64_t itts_gru_state_bytes(int B, int H, int ndir);
 int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bhh,
                        const float* d_h0, const int* d_lengths, const int* h_lengths,
@@ -270,7 +274,7 @@ int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const float* d_bh
 int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const float* d_gates,
                        const float* d_hprev, const int* h_lengths,
                        const int* d_row_off, const int* d_rev_row, int T, int B, int H, int ndir,
-                       float* d_dgi, float* d_dgh, void* d_state, void* stream);
+                       float* d_dgi, float* d_dgh, float* d_dh0, void* d_state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,12 +54,12 @@ def main():
                 _lib.check(L.itts_lstm_layer_bwd(_iptr(dy), _iptr(whh), None, _iptr(gates),
                                                  _iptr(aux1), pb._hptr(), _iptr(pb.d_row_off),
                                                  _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(dg),
-                                                 _iptr(state), ops._stream()), "b")
+                                                 None, _iptr(state), ops._stream()), "b")
             else:
                 _lib.check(L.itts_gru_layer_bwd(_iptr(dy), _iptr(whh), _iptr(gates),
                                                 _iptr(aux2), pb._hptr(), _iptr(pb.d_row_off),
                                                 _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(dg),
-                                                _iptr(dg2), _iptr(state), ops._stream()), "b")
+                                                _iptr(dg2), None, _iptr(state), ops._stream()), "b")
 
         for name, fn in (("fwd(train)", lambda: fwd(True)), ("fwd(infer)", lambda: fwd(False)),
                          ("bwd", bwd)):
