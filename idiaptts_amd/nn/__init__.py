@@ -1,1 +1,1 @@
-from .modules import GRU, LSTM, LinearAct  # noqa: F401
+from .modules import GRU, LSTM, RNN, LinearAct  # noqa: F401

@@ -138,3 +138,94 @@ class GRU(nn.Module):
             hn_all.append(hn.index_select(1, pb.inv_perm))
         out = pb.unpack(x, input_.shape)
         return out, torch.cat(hn_all, 0)
+
+
+class RNN(nn.Module):
+    """Drop-in for torch.nn.RNN(input_size, hidden_size, num_layers, nonlinearity, bidirectional,
+    batch_first) as RNNWrapper builds it for 'RNNTANH' / 'RNNRELU' groups (rnn_dyn/RNNWrapper.py:
+    45-54, RNNDyn.py:268-272); same parameter names.
+        output, h_n = rnn(padded, h_0, lengths)
+    The cell is one fused linear layer per step, h_t = act([h_{t-1} | W_ih x_t + b] [W_hh | I]^T):
+    the input projection of all frames is one GEMM on packed rows, every step one launch of the
+    same fp32-MFMA kernel on the rows still active (the identity block adds the projection), and
+    autograd chains the steps.  Unlike LSTM / GRU there is no dedicated recurrence kernel -- this
+    cell type is kept for completeness, not speed."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, nonlinearity='tanh', bias=True,
+                 batch_first=False, dropout=0.0, bidirectional=False):
+        super().__init__()
+        assert bias, "bias=False is not supported"
+        if nonlinearity.lower() not in ("tanh", "relu"):
+            raise ValueError("Unknown nonlinearity '{}'".format(nonlinearity))
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.nonlinearity = nonlinearity.lower()
+        self.batch_first, self.dropout, self.bidirectional = batch_first, dropout, bidirectional
+        ndir = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            in_size = input_size if layer == 0 else hidden_size * ndir
+            for d in range(ndir):
+                sfx = "_l{}{}".format(layer, "_reverse" if d == 1 else "")
+                self.register_parameter("weight_ih" + sfx, nn.Parameter(torch.empty(hidden_size, in_size)))
+                self.register_parameter("weight_hh" + sfx, nn.Parameter(torch.empty(hidden_size, hidden_size)))
+                self.register_parameter("bias_ih" + sfx, nn.Parameter(torch.empty(hidden_size)))
+                self.register_parameter("bias_hh" + sfx, nn.Parameter(torch.empty(hidden_size)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.hidden_size)
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+    def _direction(self, x, pb, layer, d, h0):
+        """x [N, F] packed rows -> (y [N, H] packed, h_n [B, H] in sorted row order)"""
+        H = self.hidden_size
+        sfx = "_l{}{}".format(layer, "_reverse" if d == 1 else "")
+        w_ih, w_hh = getattr(self, "weight_ih" + sfx), getattr(self, "weight_hh" + sfx)
+        bias = getattr(self, "bias_ih" + sfx) + getattr(self, "bias_hh" + sfx)
+        act = ops.ACT_TANH if self.nonlinearity == "tanh" else ops.ACT_RELU
+        gin = LinearActFunction.apply(x, w_ih, bias, ops.ACT_NONE)                    # [N, H]
+        w_step = torch.cat((w_hh, torch.eye(H, dtype=w_hh.dtype, device=w_hh.device)), dim=1)
+        lengths = pb.h_lengths.tolist()
+        row_off = pb.d_row_off.tolist()
+        h = h0.unsqueeze(0).expand(pb.B, H) if h0 is not None else x.new_zeros((pb.B, H))
+        steps, finished = [], []
+        nact_prev = pb.B
+        for s in range(pb.T):
+            nact = sum(1 for n in lengths if n > s)             # sorted: the first nact rows
+            if d == 0:
+                g = gin[row_off[s]:row_off[s] + nact]
+            else:
+                g = gin.index_select(0, pb.d_rev_row[s, :nact].long())
+            if nact < nact_prev:
+                finished.append(h[nact:nact_prev])               # their last state is final
+            h = LinearActFunction.apply(torch.cat((h[:nact], g), dim=1), w_step, None, act)
+            steps.append(h)
+            nact_prev = nact
+        finished.append(h)
+        h_n = torch.cat(finished[::-1], dim=0)                   # rows 0 .. B-1 (sorted order)
+        if d == 0:
+            y = torch.cat(steps, dim=0)                          # packed order is step order
+        else:
+            idx = torch.cat([pb.d_rev_row[s, :steps[s].shape[0]].long() for s in range(pb.T)])
+            y = torch.empty_like(gin).index_copy(0, idx, torch.cat(steps, dim=0))
+        return y, h_n
+
+    def forward(self, input_, hx=None, lengths=None):
+        ndir = 2 if self.bidirectional else 1
+        time_dim, batch_dim = (1, 0) if self.batch_first else (0, 1)
+        if lengths is None:
+            lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
+        pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
+        x = pb.pack(input_)
+        hn_all = []
+        for layer in range(self.num_layers):
+            outs = []
+            for d in range(ndir):
+                h0 = hx[layer * ndir + d, 0, :] if hx is not None else None   # shared by all rows
+                y, h_n = self._direction(x, pb, layer, d, h0)
+                outs.append(y)
+                hn_all.append(h_n.index_select(0, pb.inv_perm))
+            x = outs[0] if ndir == 1 else torch.cat(outs, dim=1)
+            if self.dropout > 0 and self.training and layer < self.num_layers - 1:
+                x = torch.nn.functional.dropout(x, self.dropout, True)
+        return pb.unpack(x, input_.shape), torch.stack(hn_all, 0)

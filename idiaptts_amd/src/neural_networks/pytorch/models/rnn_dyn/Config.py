@@ -78,11 +78,14 @@ def config_from_legacy_string(in_dim, name, batch_first=False, dropout=0.0):
         bidirectional = layer_type[:2] == 'Bi'
         if bidirectional:
             layer_type = layer_type[2:]
-        if layer_type in ('LSTM', 'GRU'):
-            layer_configs.append(Config.LayerConfig(layer_type=layer_type, out_dim=out_dim,
-                                                    num_layers=n_layers, nonlin=None,
-                                                    dropout=dropout if n_layers > 1 else 0.0,
-                                                    bidirectional=bidirectional))
+        if layer_type in ('LSTM', 'GRU', 'RNNTANH', 'RNNRELU'):
+            rnn_nonlin = {'RNNTANH': 'tanh', 'RNNRELU': 'relu'}.get(layer_type)
+            lc = Config.LayerConfig(layer_type='RNN' if rnn_nonlin else layer_type,
+                                    out_dim=out_dim, num_layers=n_layers, nonlin=None,
+                                    dropout=dropout if n_layers > 1 else 0.0,
+                                    bidirectional=bidirectional)
+            lc.nonlin = rnn_nonlin                  # reference RNNDyn.py:268-279
+            layer_configs.append(lc)
         elif layer_type.upper() in nonlins or layer_type in ('FC', 'LIN', 'linear'):
             layer_configs.append(Config.LayerConfig(layer_type='Linear', out_dim=out_dim,
                                                     num_layers=n_layers,

@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-from idiaptts_amd.nn.modules import GRU, LSTM, LinearAct
+from idiaptts_amd.nn.modules import GRU, LSTM, RNN, LinearAct
 
 
 class FusedActivation(nn.Identity):
@@ -58,18 +58,22 @@ class FFWrapper(nn.Module):
 class RNNWrapper(nn.Module):
     def __init__(self, in_dim, layer_config, batch_first=True, enforce_sorted=True):
         super().__init__()
-        if layer_config.type not in ('LSTM', 'GRU'):
-            raise NotImplementedError("{} groups have no HIP recurrence; LSTM and GRU are "
-                                      "accelerated.".format(layer_config.type))
+        if layer_config.nonlin is not None and layer_config.type != 'RNN':
+            raise NotImplementedError("Non-linearity is not supported for {}."
+                                      .format(layer_config.type))
+        if layer_config.type not in ('LSTM', 'GRU', 'RNN'):
+            raise NotImplementedError("Unknown recurrent layer type {}.".format(layer_config.type))
         self.batch_first = batch_first
         self.bidirectional = layer_config.kwargs.get("bidirectional", False)
         self.hidden = None
         self.pack = True
         self.unpack = True
-        cell = LSTM if layer_config.type == 'LSTM' else GRU
+        cell = {'LSTM': LSTM, 'GRU': GRU, 'RNN': RNN}[layer_config.type]
+        extra = {'nonlinearity': (layer_config.nonlin or 'tanh').lower()} \
+            if layer_config.type == 'RNN' else {}
         self.module = cell(input_size=in_dim, hidden_size=layer_config.out_dim,
                            num_layers=layer_config.num_layers, dropout=layer_config.dropout,
-                           batch_first=batch_first, bidirectional=self.bidirectional)
+                           batch_first=batch_first, bidirectional=self.bidirectional, **extra)
         ndir = 2 if self.bidirectional else 1
         init = layer_config.kwargs.get('hidden_init_value', 0.0)
         h0 = torch.full((layer_config.num_layers * ndir, 1, layer_config.out_dim), float(init))

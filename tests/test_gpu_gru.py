@@ -111,3 +111,52 @@ def test_ema_kernel_matches_reference_formula(gpu):
     for n in shadow:
         assert (ema.shadow[n].cpu().double() - shadow[n]).abs().max().item() < 1e-6
     assert all(not p.requires_grad for p in ema.model.parameters())
+
+
+@pytest.mark.parametrize("nonlin,bidir,layers,batch_first", [
+    ("tanh", True, 2, False), ("relu", False, 1, True), ("tanh", False, 1, False)])
+def test_vanilla_rnn_matches_torch(gpu, nonlin, bidir, layers, batch_first):
+    """torch.nn.RNN on a PackedSequence (RNNWrapper 'RNN' groups, legacy 'RNNTANH' / 'RNNRELU'):
+    output, final states and all gradients against torch CPU float64."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from idiaptts_amd.nn import RNN
+    torch.manual_seed(5)
+    in_dim, H, B, T = 6, 16, 4, 11
+    lengths = torch.tensor([7, 11, 1, 7])
+    mine = RNN(in_dim, H, layers, nonlinearity=nonlin, bidirectional=bidir,
+               batch_first=batch_first).to(gpu)
+    ref = torch.nn.RNN(in_dim, H, layers, nonlinearity=nonlin, bidirectional=bidir,
+                       batch_first=batch_first).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in mine.state_dict().items()})
+    shape = (B, T, in_dim) if batch_first else (T, B, in_dim)
+    x = torch.randn(shape)
+    ndir = 2 if bidir else 1
+    w = torch.randn(shape[0], shape[1], ndir * H)
+    h0 = torch.randn(layers * ndir, 1, H) * 0.3
+    out_ref, hn_ref = ref(pack_padded_sequence(x.double(), lengths, batch_first=batch_first,
+                                               enforce_sorted=False),
+                          h0.double().expand(-1, B, -1).contiguous())
+    out_ref, _ = pad_packed_sequence(out_ref, batch_first=batch_first, total_length=T)
+    (out_ref * w.double()).sum().backward()
+    out, hn = mine(x.to(gpu), h0.to(gpu).expand(-1, B, -1).contiguous(), lengths)
+    (out * w.to(gpu)).sum().backward()
+    assert (out.detach().cpu().double() - out_ref.detach()).abs().max() < 2e-5
+    assert (hn.detach().cpu().double() - hn_ref.detach()).abs().max() < 2e-5
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        err = (pm.grad.cpu().double() - pr.grad).abs().max().item()
+        assert err < 1e-4 * max(1.0, pr.grad.abs().max().item()), (n, err)
+
+
+def test_rnntanh_group_in_rnndyn(gpu):
+    import types
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    hp = types.SimpleNamespace(model_type="RNNDYN-1_RELU_16-1_BiRNNTANH_8-1_FC_3", batch_first=True,
+                               dropout=0.0)
+    model = rnn_dyn.convert_legacy_to_config((5,), hp).create_model().to(gpu)
+    assert "2.module.weight_hh_l0_reverse" in model.state_dict()
+    model.init_hidden(2)
+    out, kw = model(torch.randn(2, 6, 5, device=gpu), seq_lengths_input=torch.tensor([6, 2]),
+                    max_length_inputs=6)
+    assert out.shape == (2, 6, 3) and torch.isfinite(out).all() and kw["hidden"].shape == (2, 2, 8)
+    out.sum().backward()
+    assert all(p.grad is not None for p in model.parameters())
