@@ -31,6 +31,7 @@ def match_lengths(outputs, match_length):
     while changed:
         changed = False
         for name, refs in match_length.items():
+            refs = [r for r in refs if r in outputs] if refs else refs   # streams not loaded now
             if not refs:
                 continue
             ref_lengths = [outputs[r].shape[0] for r in refs]

@@ -53,6 +53,8 @@ class PyTorchDatareadersDataset(Dataset):
 
     def _trim_datareader(self, reader, output_dict, id_name, known_length):
         ref_lengths = self._get_ref_lengths(reader.match_length, id_name, known_length)
+        if not ref_lengths:
+            return False
         for key in reader.output_names:
             if key == "_id_list":
                 continue
@@ -67,7 +69,10 @@ class PyTorchDatareadersDataset(Dataset):
 
     def _get_ref_lengths(self, match_length, id_name, known_length):
         ref_lengths = []
+        present = {r.name for r in self.datareaders}
         for name in match_length:
+            if name not in present:      # stream not loaded (inference without stored targets)
+                continue
             reader = self.get_datareader_by_name(name)
             if reader.name not in known_length:
                 known_length[reader.name] = [reader.get_length(id_name)]
@@ -95,7 +100,10 @@ class PyTorchDatareadersDataset(Dataset):
         processed.add(reader)
         for name in reader.output_names:
             output_dict[name] = output_dict[name][start:end]
+        present = {r.name for r in self.datareaders}
         for ref_name in reader.match_length or ():
+            if ref_name not in present:
+                continue
             ref = self.get_datareader_by_name(ref_name)
             if ref.max_frames is not None and ref not in processed:
                 self._select_max_frames(processed, output_dict, ref, start, end)

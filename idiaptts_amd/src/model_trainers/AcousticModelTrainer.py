@@ -89,7 +89,8 @@ class AcousticModelTrainer(ModularTrainer):
                                  post_processing_mapping=post_processing_mapping,
                                  ids_input=ids_input)
 
-    def synth(self, hparams, ids_input, post_processing_mapping=None, plotter_configs=None):
+    def synth(self, hparams, ids_input, post_processing_mapping=None, plotter_configs=None,
+              load_target=True):
         if post_processing_mapping is None:
             post_processing_mapping = {"pred_acoustic_features": "cmp_features",
                                        "acoustic_features": "cmp_features"}
@@ -98,7 +99,7 @@ class AcousticModelTrainer(ModularTrainer):
             hparams.add_hparams(synth_feature_names=["pred_acoustic_features"])
         return super().synth(hparams=hparams, ids_input=ids_input,
                              post_processing_mapping=post_processing_mapping,
-                             plotter_configs=plotter_configs)
+                             plotter_configs=plotter_configs, load_target=load_target)
 
     def compute_score(self, data, output, hparams):
         """{label name: (MCD, F0 RMSE, VDE, BAP distortion) averaged over the ids}; `data` holds

@@ -73,13 +73,15 @@ class DurationModelTrainer(ModularTrainer):
         super().init(hparams=hparams, data_reader_configs=data_reader_configs,
                      model_config=model_config, loss_configs=loss_configs)
 
-    def forward(self, hparams, id_list, only_positive=True, post_processing_mapping=None):
+    def forward(self, hparams, id_list, only_positive=True, post_processing_mapping=None,
+                load_target=True):
         """(network outputs, durations in HTK time units per id): de-normalised predictions rounded
         to whole frames times hparams.min_phoneme_length, negative values set to 0 when
         `only_positive`."""
         if post_processing_mapping is None:
             post_processing_mapping = {"pred_durations": "durations"}
-        output_dict, output_dict_post = super().forward(hparams, id_list, post_processing_mapping)
+        output_dict, output_dict_post = super().forward(hparams, id_list, post_processing_mapping,
+                                                        load_target=load_target)
         post = {}
         for id_name, feats in output_dict_post.items():
             dur = np.around(feats["pred_durations"]).astype(np.int64) * hparams.min_phoneme_length

@@ -404,20 +404,25 @@ class ModularTrainer(object):
                                        current_epoch=self.total_epoch)
 
     # ----------------------------------------------------------- forward / synth / benchmark
-    def forward(self, hparams, ids_input, post_processing_mapping=None):
+    def forward(self, hparams, ids_input, post_processing_mapping=None, load_target=True):
+        """`load_target=False` reads only the streams the model consumes -- for ids that have no
+        stored targets yet (text-to-speech: TTSModel.run_DM_AM)."""
         id_list = self._input_to_str_list(ids_input)
         return self._forward_batched(batch_size=hparams.batch_size_val, hparams=hparams,
                                      id_list=id_list,
-                                     post_processing_mapping=post_processing_mapping)
+                                     post_processing_mapping=post_processing_mapping,
+                                     load_target=load_target)
 
-    def synth(self, hparams, ids_input, post_processing_mapping=None, plotter_configs=None):
+    def synth(self, hparams, ids_input, post_processing_mapping=None, plotter_configs=None,
+              load_target=True):
         id_list = self._input_to_str_list(ids_input)
         self.logger.info("Start synthesising [{0}]".format(", ".join(str(i) for i in id_list)))
         t_start = timer()
         out = self._forward_batched(batch_size=hparams.batch_size_synth, hparams=hparams,
                                     id_list=id_list,
                                     post_processing_mapping=post_processing_mapping,
-                                    gen_figure=hparams.synth_gen_figure, synth=True)
+                                    gen_figure=hparams.synth_gen_figure, synth=True,
+                                    load_target=load_target)
         self.logger.info('Synthesis time for {} sample(s): {}'.format(
             len(id_list), timedelta(seconds=timer() - t_start)))
         return out
@@ -472,8 +477,12 @@ class ModularTrainer(object):
         assert len(id_list) > 0, "Received empty id_list."
         if gen_figure:
             raise NotImplementedError("Figure generation is outside the accelerated path.")
-        dataset = self.get_dataset(id_list=id_list, datareaders=self._unique_readers(),
-                                   hparams=hparams)
+        readers = self._unique_readers()
+        if not load_target:
+            wanted = set(self._model_input_names())
+            readers = [r for r in readers if wanted & set(r.output_names)]
+            assert readers, "No data reader provides the model inputs {}.".format(sorted(wanted))
+        dataset = self.get_dataset(id_list=id_list, datareaders=readers, hparams=hparams)
         dataloader = self.model_handler._get_dataloader(
             batch_size=batch_size, dataset=dataset, batch_first=hparams.batch_first,
             common_divisor=1, collate_fn=self.batch_collate_fn, num_workers=0,
@@ -493,7 +502,7 @@ class ModularTrainer(object):
                             and feature_name in post_processing_mapping:
                         reader_name = post_processing_mapping[feature_name]
                         if reader_name is not None:
-                            features = dataset.get_datareader_by_name(reader_name) \
+                            features = self._reader_by_name(reader_name) \
                                 .postprocess_sample(features)
                         output_post[feature_name] = features
                 dict_outputs_post[id_name] = output_post
@@ -503,6 +512,21 @@ class ModularTrainer(object):
         if synth:
             self.gen_waveform(data=dict_outputs_post, hparams=hparams, id_list=id_list)
         return dict_outputs, dict_outputs_post
+
+    def _reader_by_name(self, name):
+        for reader in self._unique_readers():
+            if reader.name == name:
+                return reader
+        raise KeyError("Unknown data reader {}.".format(name))
+
+    def _model_input_names(self):
+        """Names of the streams the (wrapped) model reads, from its config."""
+        config = self.model_handler.model_config
+        if config is None:
+            config = getattr(self.model_handler.model, "config", None)
+        names = getattr(config, "input_names", None)
+        assert names, "The model config does not name its inputs."
+        return list(names)
 
     # ------------------------------------------------------------------------------ waveforms
     def gen_waveform(self, id_list, data, hparams, use_model_name=True, has_deltas=False):
