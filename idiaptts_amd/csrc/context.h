@@ -57,6 +57,7 @@ struct DeviceContext {
   int device = -1;
   double2* twiddles = nullptr;  // [TW_N/2] exp(+2 pi i k / TW_N)
   JumpTable* jump = nullptr;    // created by get_jump_table
+  int64_t* pinned = nullptr;    // [64] page-locked host slots for small device -> host read-backs
   std::map<std::tuple<int, int, long long>, FreqtTables> freqt;
 };
 
@@ -73,6 +74,9 @@ const JumpTable* get_jump_table(DeviceContext* ctx);
 // device arrays): randn() = R / 2^28 - 6.  max_len bounds len[u] (sizes the grid).
 int launch_randn_u32(DeviceContext* ctx, const int64_t* d_off, const int64_t* d_len, int n_utts,
                      int64_t max_len, uint32_t* d_R, hipStream_t s);
+
+// One of the context's page-locked host slots (round robin) for a read-back of a few bytes.
+int64_t* pinned_slot(DeviceContext* ctx);
 
 // Small stream-ordered device copy of a host int64 array (offsets). Caller frees with
 // hipFreeAsync on the same stream.

@@ -1,6 +1,7 @@
 // Device context: twiddle table and SPTK frequency-warping matrices (see context.h).
 #include "context.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -25,12 +26,18 @@ static int create_context(DeviceContext* ctx) {
   // The entry points take their scratch from the device's stream-ordered pool.  By default the
   // pool hands everything back to the driver at the next synchronisation, which turns every call
   // into fresh multi-hundred-MB allocations; let it keep up to 16 GB (of 288) between calls.
+  ITTS_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, 64 * sizeof(int64_t), hipHostMallocDefault));
   hipMemPool_t pool;
   if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {
     uint64_t keep = 16ull << 30;
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
   }
   return ITTS_OK;
+}
+
+int64_t* pinned_slot(DeviceContext* ctx) {
+  static std::atomic<unsigned> next{0};
+  return ctx->pinned + (next.fetch_add(1) & 63u);
 }
 
 DeviceContext* get_context() {

@@ -427,7 +427,7 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
                                  double2* mp) {
   const int h = fft / 2;
   double* zr = reinterpret_cast<double*>(z);
-  for (int k = threadIdx.x; k <= h; k += NT) {
+  for (int k = tid(); k <= h; k += NT) {
     const double v = lg[k];
     zr[k] = v;
     if (k > 0 && k < h) zr[fft - k] = v;
@@ -437,14 +437,14 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
   // fold: c[0], 2 c[1..h-1], c[h], zeros; keep the (real) values, build the real sequence
   double cv[ (4096 / 2 + 1 + NT - 1) / NT ];
   int cnt = 0;
-  for (int k = threadIdx.x; k <= h; k += NT) cv[cnt++] = z[k].x * ((k == 0 || k == h) ? 1.0 : 2.0);
+  for (int k = tid(); k <= h; k += NT) cv[cnt++] = z[k].x * ((k == 0 || k == h) ? 1.0 : 2.0);
   __syncthreads();
   cnt = 0;
-  for (int k = threadIdx.x; k <= h; k += NT) zr[k] = cv[cnt++];
-  for (int k = h + 1 + threadIdx.x; k < fft + 2; k += NT) zr[k] = 0.0;
+  for (int k = tid(); k <= h; k += NT) zr[k] = cv[cnt++];
+  for (int k = h + 1 + tid(); k < fft + 2; k += NT) zr[k] = 0.0;
   __syncthreads();
   rfft_lds(z, fft, logfft, tw, fft);
-  for (int k = threadIdx.x; k <= h; k += NT) {
+  for (int k = tid(); k <= h; k += NT) {
     const double t = exp(z[k].x / fft);
     double sn, cs;
     sincos(z[k].y / fft, &sn, &cs);
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
   load_twiddles(tw, a.g_tw, fft);
   __syncthreads();
   const int64_t total = a.gpoff[a.p.n_utts];
-  for (int64_t g = blockIdx.x; g < total; g += gridDim.x) {
+  const int64_t g = blockIdx.x;           // one pulse per workgroup (the host reads the pulse count)
+  if (g < total) {
     // utterance of flat pulse g
     int lo = 0, hi = a.p.n_utts;
     while (hi - lo > 1) {
@@ -499,32 +500,32 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
     const double* sp1 = a.sp + (u.f_off + ce) * K;
     const double* ap0 = a.ap + (u.f_off + fl) * K;
     const double* ap1 = a.ap + (u.f_off + ce) * K;
-    for (int k = threadIdx.x; k < K; k += NT) {
+    for (int k = tid(); k < K; k += NT) {
       const double s0 = fabs(sp0[k]);
       double a0 = ap0[k];
       a0 = a0 > 0.999999999999 ? 0.999999999999 : a0;
       a0 = a0 < 0.001 ? 0.001 : a0;
       if (fl == ce) {
         se[k] = s0;
-        ar[k] = pow(a0, 2.0);
+        ar[k] = a0 * a0;                    // pow(x, 2.0): compilers fold it to x * x
       } else {
         const double s1 = fabs(sp1[k]);
         double a1 = ap1[k];
         a1 = a1 > 0.999999999999 ? 0.999999999999 : a1;
         a1 = a1 < 0.001 ? 0.001 : a1;
         se[k] = (1.0 - al) * s0 + al * s1;
-        ar[k] = (1.0 - al) * pow(a0, 2.0) + al * pow(a1, 2.0);
+        ar[k] = (1.0 - al) * (a0 * a0) + al * (a1 * a1);
       }
     }
     __syncthreads();
     // ---- periodic response
     const bool has_per = !(vuv <= 0.5 || ar[0] > 0.999);
     if (has_per) {
-      for (int k = threadIdx.x; k < K; k += NT) lg[k] = log(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
+      for (int k = tid(); k < K; k += NT) lg[k] = log(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
       __syncthreads();
       min_phase(lg, fft, logfft, z, tw, mp);
       const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
-      for (int k = threadIdx.x; k < K; k += NT) {
+      for (int k = tid(); k < K; k += NT) {
         const double re2 = cos(coef * k);
         const double im2 = sqrt(1.0 - re2 * re2);
         const double2 m = mp[k];
@@ -534,13 +535,13 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
       irfft_lds(z, fft, logfft, tw, fft);
       // fftshift + DC removal
       double dc = 0.0;
-      for (int i = threadIdx.x; i < h; i += NT) dc += zr[i];  // shifted index i+h <- zr[i]
+      for (int i = tid(); i < h; i += NT) dc += zr[i];  // shifted index i+h <- zr[i]
       dc = bsum(dc, red);
       // dc_remover[i] = hann(i) / sum, symmetric
       double dsum = 0.0;
-      for (int i = threadIdx.x; i < h; i += NT) dsum += (0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft))) * 2.0;
+      for (int i = tid(); i < h; i += NT) dsum += (0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft))) * 2.0;
       dsum = bsum(dsum, red);
-      for (int i = threadIdx.x; i < fft; i += NT) {
+      for (int i = tid(); i < fft; i += NT) {
         const int m = i < h ? i : fft - 1 - i;
         const double dcr = (0.5 - 0.5 * cos(2.0 * kPi * (m + 1.0) / (1.0 + fft))) / dsum;
         // shifted response: y[i] = x[i+h] (i<h), y[i] = x[i-h] (i>=h)
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
     {
       const double* R = a.R + u.s_off + (idx - pidx[0]);
       double s = 0.0;
-      for (int i = threadIdx.x; i < fft + 2; i += NT) {
+      for (int i = tid(); i < fft + 2; i += NT) {
         double v = 0.0;
         if (i < noise_size && i < fft) {
           v = R[i];
@@ -563,18 +564,18 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
       s = bsum(s, red);
       if (noise_size > 0) {
         const double avg = s / noise_size;
-        for (int i = threadIdx.x; i < noise_size && i < fft; i += NT) zr[i] -= avg;
+        for (int i = tid(); i < noise_size && i < fft; i += NT) zr[i] -= avg;
       }
       __syncthreads();
       rfft_lds(z, fft, logfft, tw, fft);
-      for (int k = threadIdx.x; k < K; k += NT) nzs[k] = z[k];
+      for (int k = tid(); k < K; k += NT) nzs[k] = z[k];
       __syncthreads();
     }
-    for (int k = threadIdx.x; k < K; k += NT)
+    for (int k = tid(); k < K; k += NT)
       lg[k] = (vuv != 0.0) ? log(se[k] * ar[k]) / 2.0 : log(se[k]) / 2.0;
     __syncthreads();
     min_phase(lg, fft, logfft, z, tw, mp);
-    for (int k = threadIdx.x; k < K; k += NT) {
+    for (int k = tid(); k < K; k += NT) {
       const double2 m = mp[k], n = nzs[k];
       z[k] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
     }
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
     const double sq = sqrt((double)noise_size);
     const int off = idx - h + 1;
     double* y = a.y + u.y_off;
-    for (int j = threadIdx.x; j < fft; j += NT) {
+    for (int j = tid(); j < fft; j += NT) {
       const int tgt = j + off;
       if (tgt >= 0 && tgt < u.yl) {
         const double apv = (j < h) ? zr[j + h] : zr[j - h];  // fftshift
@@ -700,12 +701,31 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(syn_pulse_offsets_kernel, dim3(1), dim3(64), 0, s, d_ptot, n_utts, d_gpoff);
   ITTS_LAUNCH_CHECK();
+  // The pulse kernel runs one workgroup per pulse, so the host needs the pulse count: it is copied
+  // to a page-locked slot right here and awaited (polling) only after the noise generator has
+  // been queued, which keeps the GPU busy meanwhile.  (A persistent-workgroup loop over the pulses
+  // avoided the read-back but made every loop-invariant address and fp64 constant of the seven
+  // FFTs live across the whole kernel: 239 VGPRs instead of 94.)
+  int64_t* h_total = pinned_slot(ctx);
+  hipEvent_t ev_total;
+  ITTS_HIP_CHECK(hipEventCreateWithFlags(&ev_total, hipEventDisableTiming));
+  ITTS_HIP_CHECK(hipMemcpyAsync(h_total, d_gpoff + n_utts, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipEventRecord(ev_total, s));
   {
     const int nchunks = (max_yl + RCHUNK - 1) / RCHUNK;
     hipLaunchKernelGGL(syn_randn_kernel, dim3((nchunks + NT - 1) / NT, n_utts), dim3(NT), 0, s, d_utts, jt, d_R);
     ITTS_LAUNCH_CHECK();
   }
   {
+    hipError_t e;
+    while ((e = hipEventQuery(ev_total)) == hipErrorNotReady) {
+    }
+    (void)hipEventDestroy(ev_total);
+    ITTS_HIP_CHECK(e);
+  }
+  const int64_t n_pulses = *h_total;
+  ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
+  if (n_pulses > 0) {
     PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p, ctx->twiddles};
     const int h = fft_size / 2;
     const size_t lds = (size_t)h * 16 + 3 * (size_t)(h + 1) * 16 + 3 * (size_t)(h + 2) * 8 +
@@ -713,8 +733,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
     ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int blocks_per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
-    hipLaunchKernelGGL(syn_pulse_kernel, dim3(256 * blocks_per_cu), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL(syn_pulse_kernel, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(syn_finalize_kernel, dim3(n_utts), dim3(NT), 0, s, d_y, d_utts, preemphasis, d_y_f32, d_y_f64);

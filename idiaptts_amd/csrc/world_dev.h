@@ -19,19 +19,30 @@ constexpr int TW_N = 16384;   // master twiddle table: tw[k] = exp(+2 pi i k / T
 constexpr double kEps = 1e-12;  // WORLD kMySafeGuardMinimum
 constexpr double kPi = 3.1415926535897932384626433832795;
 
+// Thread index as an opaque value.  The frame kernels are long sequences of short
+// `for (i = thread; i < n; i += NT)` loops over LDS arrays; with the plain built-in the compiler
+// computes every thread-dependent address once, up front, and keeps it alive through the whole
+// kernel (and hoists it out of a persistent workgroup loop): 80+ VGPRs of loop-invariant integers
+// that halve the occupancy.  Recomputing a few integer operations per loop is far cheaper.
+__device__ __forceinline__ int tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 __device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
 __device__ __forceinline__ int ilog2(int n) { return 31 - __clz(n); }
 
 // Copies the twiddles of an n-point transform into LDS: tw[k] = exp(+2 pi i k / n), k < n/2.
 __device__ __forceinline__ void load_twiddles(double2* tw, const double2* __restrict__ g_tw, int n) {
   const int stride = TW_N / n;
-  for (int k = threadIdx.x; k < n / 2; k += NT) tw[k] = g_tw[k * stride];
+  for (int k = tid(); k < n / 2; k += NT) tw[k] = g_tw[k * stride];
 }
 
 // In-place complex FFT of z[0..n) (n = 2^logn <= tw_n). tw holds exp(+2 pi i k / tw_n).
 // sign = -1: forward (e^{-i..}), +1: unnormalised inverse. Ends with a barrier.
 __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, int tw_n, int sign) {
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = tid(); i < n; i += NT) {
     const int j = (int)(__brev((unsigned)i) >> (32 - logn));
     if (i < j) {
       const double2 a = z[i], b = z[j];
@@ -54,7 +65,7 @@ __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, i
   // elements and half the barriers (these kernels are bound by LDS traffic).
   for (; s + 1 <= logn; s += 2) {
     const int h = 1 << (s - 1);
-    for (int t = threadIdx.x; t < n / 4; t += NT) {
+    for (int t = tid(); t < n / 4; t += NT) {
       const int r = t & (h - 1);
       const int a0 = ((t >> (s - 1)) << (s + 1)) + r;
       const int a1 = a0 + h, a2 = a0 + 2 * h, a3 = a0 + 3 * h;
@@ -75,7 +86,7 @@ __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, i
   }
   for (; s <= logn; ++s) {   // odd log2(n): one plain radix-2 stage is left
     const int h = 1 << (s - 1);
-    for (int t = threadIdx.x; t < n / 2; t += NT) {
+    for (int t = tid(); t < n / 2; t += NT) {
       const int r = t & (h - 1);
       const int a = ((t >> (s - 1)) << s) + r;
       const int b = a + h;
@@ -94,7 +105,7 @@ __device__ inline void rfft_lds(double2* z, int n, int logn, const double2* tw, 
   const int h = n / 2;
   fft_lds(z, h, logn - 1, tw, tw_n, -1);
   const int tstride = tw_n / n;
-  for (int k = threadIdx.x; k <= h / 2; k += NT) {
+  for (int k = tid(); k <= h / 2; k += NT) {
     if (k == 0) {
       const double2 z0 = z[0];
       z[0] = make_double2(z0.x + z0.y, 0.0);
@@ -120,7 +131,7 @@ __device__ inline void rfft_lds(double2* z, int n, int logn, const double2* tw, 
 __device__ inline void irfft_lds(double2* z, int n, int logn, const double2* tw, int tw_n) {
   const int h = n / 2;
   const int tstride = tw_n / n;
-  for (int k = threadIdx.x; k <= h / 2; k += NT) {
+  for (int k = tid(); k <= h / 2; k += NT) {
     const int j = h - k;
     double2 xk = z[k], xj = z[j];
     if (k == 0) {
@@ -143,7 +154,7 @@ __device__ inline void irfft_lds(double2* z, int n, int logn, const double2* tw,
   __syncthreads();
   fft_lds(z, h, logn - 1, tw, tw_n, +1);
   const double s = 1.0 / (double)h;
-  for (int k = threadIdx.x; k < h; k += NT) {
+  for (int k = tid(); k < h; k += NT) {
     double2 v = z[k];
     v.x *= s;
     v.y *= s;
@@ -156,7 +167,7 @@ __device__ inline void irfft_lds(double2* z, int n, int logn, const double2* tw,
 __device__ __forceinline__ double bsum(double v, double* red) {
   v = wave_sum(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((tid() & 63) == 0) red[tid() >> 6] = v;
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
@@ -164,18 +175,18 @@ __device__ __forceinline__ double bsum(double v, double* red) {
 // In-place inclusive prefix sum of a[0..n) in LDS. red: >= NT+8 doubles. Ends with a barrier.
 __device__ inline void block_scan(double* a, int n, double* red) {
   const int chunk = (n + NT - 1) / NT;
-  const int lo = threadIdx.x * chunk;
+  const int lo = tid() * chunk;
   const int hi = min(n, lo + chunk);
   double s = 0.0;
   for (int i = lo; i < hi; ++i) {
     s += a[i];
     a[i] = s;
   }
-  red[threadIdx.x] = s;
+  red[tid()] = s;
   __syncthreads();
-  if (threadIdx.x < 64) {  // one wave scans the 256 chunk totals (4 per lane)
-    double v0 = red[4 * threadIdx.x], v1 = red[4 * threadIdx.x + 1], v2 = red[4 * threadIdx.x + 2],
-           v3 = red[4 * threadIdx.x + 3];
+  if (tid() < 64) {  // one wave scans the 256 chunk totals (4 per lane)
+    double v0 = red[4 * tid()], v1 = red[4 * tid() + 1], v2 = red[4 * tid() + 2],
+           v3 = red[4 * tid() + 3];
     v1 += v0;
     v2 += v1;
     v3 += v2;
@@ -183,16 +194,16 @@ __device__ inline void block_scan(double* a, int n, double* red) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const double o = __shfl_up(incl, off, 64);
-      if ((int)threadIdx.x >= off) incl += o;
+      if ((int)tid() >= off) incl += o;
     }
     const double excl = incl - v3;
-    red[4 * threadIdx.x] = excl;            // exclusive prefix of chunk totals
-    red[4 * threadIdx.x + 1] = excl + v0;
-    red[4 * threadIdx.x + 2] = excl + v1;
-    red[4 * threadIdx.x + 3] = excl + v2;
+    red[4 * tid()] = excl;            // exclusive prefix of chunk totals
+    red[4 * tid() + 1] = excl + v0;
+    red[4 * tid() + 2] = excl + v1;
+    red[4 * tid() + 3] = excl + v2;
   }
   __syncthreads();
-  const double base = red[threadIdx.x];
+  const double base = red[tid()];
   for (int i = lo; i < hi; ++i) a[i] += base;
   __syncthreads();
 }
@@ -212,7 +223,7 @@ __device__ __forceinline__ double interp1q(double x0, double shift, const double
 __device__ inline void dc_correction(double* P, double f0, int fs, int fft) {
   const int upper = 2 + (int)(f0 * fft / fs);
   double rep = 0.0;
-  const int i = threadIdx.x;
+  const int i = tid();
   for (int base = 0; base < upper - 1; base += NT) {
     const int ii = base + i;
     if (ii < upper - 1) {
@@ -232,7 +243,7 @@ __device__ inline void linear_smoothing(const double* P, double width, int fs, i
   const int boundary = (int)(width * fft / fs) + 1;
   const int h = fft / 2;
   const int ml = h + boundary * 2 + 1;
-  for (int i = threadIdx.x; i < ml; i += NT) {
+  for (int i = tid(); i < ml; i += NT) {
     double v;
     if (i < boundary)
       v = P[boundary - i];
@@ -246,7 +257,7 @@ __device__ inline void linear_smoothing(const double* P, double width, int fs, i
   block_scan(mir, ml, red);
   const double org = -((double)boundary - 0.5) * fs / fft;
   const double dfi = (double)fs / fft;
-  for (int k = threadIdx.x; k <= h; k += NT) {
+  for (int k = tid(); k <= h; k += NT) {
     const double fa = (double)k / fft * fs - width / 2.0;
     const double lo = interp1q(org, dfi, mir, ml, fa);
     const double hi = interp1q(org, dfi, mir, ml, fa + width);
