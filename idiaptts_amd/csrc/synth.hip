@@ -422,7 +422,8 @@ struct PulseArgs {
 };
 
 // minimum phase spectrum of the log-amplitude lg[0..h] (in z.x of the first h+1 entries is NOT
-// assumed): input array `lg`, output mp[0..h] complex. Uses z as FFT scratch.
+// assumed): input array `lg`, output mp[0..h] complex. Uses z as FFT scratch.  lg is consumed by
+// the first loop, so it may live inside mp's storage.
 __device__ inline void min_phase(const double* lg, int fft, int logfft, double2* z, const double2* tw,
                                  double2* mp) {
   const int h = fft / 2;
@@ -435,12 +436,9 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
   __syncthreads();
   rfft_lds(z, fft, logfft, tw, fft);  // real even input -> real spectrum = fft * cepstrum
   // fold: c[0], 2 c[1..h-1], c[h], zeros; keep the (real) values, build the real sequence
-  double cv[ (4096 / 2 + 1 + NT - 1) / NT ];
-  int cnt = 0;
-  for (int k = tid(); k <= h; k += NT) cv[cnt++] = z[k].x * ((k == 0 || k == h) ? 1.0 : 2.0);
+  for (int k = tid(); k <= h; k += NT) mp[k].x = z[k].x * ((k == 0 || k == h) ? 1.0 : 2.0);
   __syncthreads();
-  cnt = 0;
-  for (int k = tid(); k <= h; k += NT) zr[k] = cv[cnt++];
+  for (int k = tid(); k <= h; k += NT) zr[k] = mp[k].x;
   for (int k = h + 1 + tid(); k < fft + 2; k += NT) zr[k] = 0.0;
   __syncthreads();
   rfft_lds(z, fft, logfft, tw, fft);
@@ -460,11 +458,10 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
   double2* tw = reinterpret_cast<double2*>(q); q += (size_t)h * 16;
   double2* z = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
   double2* mp = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
-  double2* nzs = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
+  double* lg = reinterpret_cast<double*>(mp);      // input of min_phase, dead before mp is written
   double* se = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
   double* ar = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
-  double* lg = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
-  double* per = reinterpret_cast<double*>(q); q += (size_t)fft * 8;
+  double* per = reinterpret_cast<double*>(q); q += (size_t)h * 8;
   double* red = reinterpret_cast<double*>(q);
   double* zr = reinterpret_cast<double*>(z);
 
@@ -520,6 +517,7 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
     __syncthreads();
     // ---- periodic response
     const bool has_per = !(vuv <= 0.5 || ar[0] > 0.999);
+    double per_dc = 0.0, per_dsum = 1.0;
     if (has_per) {
       for (int k = tid(); k < K; k += NT) lg[k] = log(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
       __syncthreads();
@@ -541,15 +539,23 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
       double dsum = 0.0;
       for (int i = tid(); i < h; i += NT) dsum += (0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft))) * 2.0;
       dsum = bsum(dsum, red);
-      for (int i = tid(); i < fft; i += NT) {
-        const int m = i < h ? i : fft - 1 - i;
+      // shifted response minus its DC share: y[i] = x[i+h] - dc * dcr (i < h; x is zero there, so
+      // that half is recomputed at the overlap-add), y[i] = x[i-h] - dc * dcr (i >= h; kept)
+      for (int i = tid(); i < h; i += NT) {
+        const int m = h - 1 - i;                  // = fft - 1 - (i + h)
         const double dcr = (0.5 - 0.5 * cos(2.0 * kPi * (m + 1.0) / (1.0 + fft))) / dsum;
-        // shifted response: y[i] = x[i+h] (i<h), y[i] = x[i-h] (i>=h)
-        per[i] = (i < h) ? -dc * dcr : zr[i - h] - dc * dcr;
+        per[i] = zr[i] - dc * dcr;
       }
+      per_dc = dc;
+      per_dsum = dsum;
       __syncthreads();
     }
-    // ---- aperiodic response: noise spectrum
+    // ---- aperiodic response: minimum-phase spectrum first (into mp), then the noise spectrum in z,
+    // multiplied in place
+    for (int k = tid(); k < K; k += NT)
+      lg[k] = (vuv != 0.0) ? log(se[k] * ar[k]) / 2.0 : log(se[k]) / 2.0;
+    __syncthreads();
+    min_phase(lg, fft, logfft, z, tw, mp);
     {
       const double* R = a.R + u.s_off + (idx - pidx[0]);
       double s = 0.0;
@@ -568,15 +574,9 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
       }
       __syncthreads();
       rfft_lds(z, fft, logfft, tw, fft);
-      for (int k = tid(); k < K; k += NT) nzs[k] = z[k];
-      __syncthreads();
     }
-    for (int k = tid(); k < K; k += NT)
-      lg[k] = (vuv != 0.0) ? log(se[k] * ar[k]) / 2.0 : log(se[k]) / 2.0;
-    __syncthreads();
-    min_phase(lg, fft, logfft, z, tw, mp);
     for (int k = tid(); k < K; k += NT) {
-      const double2 m = mp[k], n = nzs[k];
+      const double2 m = mp[k], n = z[k];
       z[k] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
     }
     __syncthreads();
@@ -589,7 +589,16 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
       const int tgt = j + off;
       if (tgt >= 0 && tgt < u.yl) {
         const double apv = (j < h) ? zr[j + h] : zr[j - h];  // fftshift
-        const double v = (has_per ? per[j] * sq : 0.0) + apv;
+        double pv = 0.0;
+        if (has_per) {
+          if (j < h) {
+            const double dcr = (0.5 - 0.5 * cos(2.0 * kPi * (j + 1.0) / (1.0 + fft))) / per_dsum;
+            pv = -per_dc * dcr;
+          } else {
+            pv = per[j - h];
+          }
+        }
+        const double v = (has_per ? pv * sq : 0.0) + apv;
         atomicAdd(&y[tgt], v);
       }
     }
@@ -728,8 +737,8 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   if (n_pulses > 0) {
     PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p, ctx->twiddles};
     const int h = fft_size / 2;
-    const size_t lds = (size_t)h * 16 + 3 * (size_t)(h + 1) * 16 + 3 * (size_t)(h + 2) * 8 +
-                       (size_t)fft_size * 8 + 16 * 8;
+    const size_t lds = (size_t)h * 16 + 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
+                       (size_t)h * 8 + 16 * 8;            // 36.2 KB at fft 1024: 4 workgroups per CU
     ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
