@@ -26,6 +26,13 @@ static int create_context(DeviceContext* ctx) {
   // The entry points take their scratch from the device's stream-ordered pool.  By default the
   // pool hands everything back to the driver at the next synchronisation, which turns every call
   // into fresh multi-hundred-MB allocations; let it keep up to 16 GB (of 288) between calls.
+  for (int L = 9; (1 << L) <= wd::TW_N; ++L) {
+    const int m = (1 << L) / 2, stride = wd::TW_N / (1 << L);
+    std::vector<double2> c(m);
+    for (int k = 0; k < m; ++k) c[k] = tw[(size_t)k * stride];
+    ITTS_HIP_CHECK(hipMalloc((void**)&ctx->tw_compact[L], m * sizeof(double2)));
+    ITTS_HIP_CHECK(hipMemcpy(ctx->tw_compact[L], c.data(), m * sizeof(double2), hipMemcpyHostToDevice));
+  }
   ITTS_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, 64 * sizeof(int64_t), hipHostMallocDefault));
   hipMemPool_t pool;
   if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {

@@ -176,12 +176,12 @@ struct D4cArgs {
   double* bap_f64;  // [Ttot, nap] or nullptr
   float* bap_f32;   // [Ttot, ld_bap] or nullptr
   int64_t ld_bap;
-  const double2* g_tw;
+  const double2* g_tw;    // compact table of the largest transform (DeviceContext::tw_compact)
   int bmax;
 };
 
 struct D4cLds {
-  double2* tw;
+  const double2* tw;
   double2* z;
   double* A;   // [h+1]
   double* B;
@@ -245,12 +245,15 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
   const int hmax = fmax / 2;
   D4cLds L;
   char* p = smem;
-  L.tw = reinterpret_cast<double2*>(p); p += (size_t)hmax * 16;
+  // Twiddles are read through the cache from a compact global table (16 KB for the 2048-point
+  // transforms, shared by all workgroups of a CU) and D lives in A's storage (A is dead when D is
+  // written): 53 KB of LDS instead of 77 KB, three workgroups per CU instead of two.
+  L.tw = a.g_tw;
   L.z = reinterpret_cast<double2*>(p); p += (size_t)(hmax + 1) * 16;
   L.A = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
   L.B = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
   L.C = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
-  L.D = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  L.D = L.A;
   L.mir = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2 * a.bmax + 2) * 8;
   L.red = reinterpret_cast<double*>(p);
 
@@ -268,9 +271,6 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
   bool voiced = false;
   double coarse[8];
   if (f0raw != 0.0) {
-    // TW table of the largest transform; smaller ones stride through it
-    load_twiddles(L.tw, a.g_tw, fmax);
-    __syncthreads();
     // ---- LoveTrain: energy ratio 100 Hz..4 kHz over 100 Hz..7.9 kHz
     {
       const int fft = a.fftl;
@@ -536,10 +536,10 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   a.x = d_x; a.x_off = d_xo; a.f0 = d_f0; a.f_off = d_fo; a.n_utts = n_utts; a.fs = fs;
   a.frame_period = frame_period_ms; a.fft_size = fft_size; a.threshold = threshold; a.nap = nap;
   a.ap = d_ap; a.bap_f64 = d_bap_f64; a.bap_f32 = d_bap_f32; a.ld_bap = ld_bap;
-  a.g_tw = ctx->twiddles;
   const int fmax = std::max(a.fftd, a.fftl), hmax = fmax / 2;
+  a.g_tw = ctx->tw_compact[ilog2h(fmax)];
   a.bmax = (int)(1200.0 * fmax / fs) + 2;
-  const size_t lds = (size_t)hmax * 16 + (size_t)(hmax + 1) * 16 + 4 * (size_t)(hmax + 2) * 8 +
+  const size_t lds = (size_t)(hmax + 1) * 16 + 3 * (size_t)(hmax + 2) * 8 +
                      (size_t)(hmax + 2 * a.bmax + 2) * 8 + (size_t)(NT + 8) * 8;
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)d4c_kernel,
