@@ -606,27 +606,44 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
   }
 }
 
-// y f64 -> out (f32 and/or f64) through float32 rounding and 1st-order de-pre-emphasis
-// lfilter([1], [1, -pre]) evaluated in f64 on the f32-rounded samples (as scipy does).
-__global__ void syn_finalize_kernel(const double* __restrict__ y, const SynUtt* __restrict__ utts, double pre,
-                                    float* __restrict__ out_f32, double* __restrict__ out_f64) {
-  const SynUtt u = utts[blockIdx.x];
-  if (pre == 0.0) {
-    for (int i = threadIdx.x; i < u.yl; i += blockDim.x) {
-      const float v = (float)y[u.y_off + i];
-      if (out_f32) out_f32[u.y_off + i] = v;
-      if (out_f64) out_f64[u.y_off + i] = (double)v;
-    }
-    return;
+// y f64 -> out (f32 and/or f64) through float32 rounding (utterances are stored back to back: one
+// flat pass)
+__global__ void syn_cast_kernel(const double* __restrict__ y, int64_t n, float* __restrict__ out_f32,
+                                double* __restrict__ out_f64) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = (float)y[i];
+    if (out_f32) out_f32[i] = v;
+    if (out_f64) out_f64[i] = (double)v;
   }
-  if (threadIdx.x == 0) {
-    double prev = 0.0;
-    for (int i = 0; i < u.yl; ++i) {
-      const double v = (double)(float)y[u.y_off + i] + pre * prev;
-      prev = v;
-      if (out_f32) out_f32[u.y_off + i] = (float)v;
-      if (out_f64) out_f64[u.y_off + i] = v;
-    }
+}
+
+// ... and 1st-order de-pre-emphasis lfilter([1], [1, -pre]) evaluated in f64 on the f32-rounded
+// samples (as scipy does): v[i] = x[i] + pre * v[i-1].  The recurrence forgets: a sample `warm`
+// steps back contributes pre^warm <= 2^-64 of its value, below the rounding of the running sum, so
+// every thread owns `seg` consecutive samples and starts `warm` samples earlier from a zero state
+// (from the true start of the utterance when that is closer).  grid (ceil(max_yl/seg/64), U).
+__global__ __launch_bounds__(64) void syn_deemph_kernel(const double* __restrict__ y,
+                                                        const SynUtt* __restrict__ utts, double pre,
+                                                        int seg, int warm, float* __restrict__ out_f32,
+                                                        double* __restrict__ out_f64) {
+  const SynUtt u = utts[blockIdx.y];
+  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t lo = c * seg;
+  if (lo >= u.yl) return;
+  const int64_t hi = min((int64_t)u.yl, lo + seg);
+  const double* x = y + u.y_off;
+  double prev = 0.0;
+  // (product and sum in separate statements: lfilter rounds twice, an fma would round once)
+  for (int64_t i = max((int64_t)0, lo - warm); i < lo; ++i) {
+    const double fb = pre * prev;
+    prev = (double)(float)x[i] + fb;
+  }
+  for (int64_t i = lo; i < hi; ++i) {
+    const double fb = pre * prev;
+    const double v = (double)(float)x[i] + fb;
+    prev = v;
+    if (out_f32) out_f32[u.y_off + i] = (float)v;
+    if (out_f64) out_f64[u.y_off + i] = v;
   }
 }
 
@@ -745,7 +762,20 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
     hipLaunchKernelGGL(syn_pulse_kernel, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(syn_finalize_kernel, dim3(n_utts), dim3(NT), 0, s, d_y, d_utts, preemphasis, d_y_f32, d_y_f64);
+  if (preemphasis == 0.0) {
+    hipLaunchKernelGGL(syn_cast_kernel, dim3((unsigned)std::min<int64_t>((y_total + 255) / 256, 8192)), dim3(256),
+                       0, s, d_y, y_total, d_y_f32, d_y_f64);
+  } else {
+    // pre^warm <= 2^-64; |pre| >= 1 (not a de-emphasis filter) or a very slow decay: one thread per
+    // utterance from its first sample
+    const double ap = std::fabs(preemphasis);
+    int64_t warm = ap < 1.0 ? (int64_t)std::ceil(-64.0 * std::log(2.0) / std::log(ap)) : max_yl;
+    int64_t seg = std::max<int64_t>(2048, warm);
+    if (warm >= max_yl) { warm = max_yl; seg = max_yl; }
+    const int64_t nseg = (max_yl + seg - 1) / seg;
+    hipLaunchKernelGGL(syn_deemph_kernel, dim3((unsigned)((nseg + 63) / 64), n_utts), dim3(64), 0, s, d_y,
+                       d_utts, preemphasis, (int)seg, (int)warm, d_y_f32, d_y_f64);
+  }
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(hipFreeAsync(d_utts, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_wrap, s));

@@ -254,6 +254,23 @@ def test_synthesis_matches_oracle(gpu, golden_dir):
                                  preemphasis=0.97, dtype=torch.float64)
     ref2 = scipy.signal.lfilter([1], [1, -0.97], ys[0].astype(np.float32))
     assert np.abs(y2.cpu().numpy() - ref2).max() < 1e-5
+    # the filter runs segment-parallel with a warm-up (0.97^warm <= 2^-64): against the strictly
+    # sequential recurrence on the kernel's own f32-rounded samples the result is exact
+    y0, _ = ops.world_synthesize(torch.from_numpy(f0s[0]).to(gpu), torch.from_numpy(sps[0]).to(gpu),
+                                 torch.from_numpy(aps[0]).to(gpu), [0, len(f0s[0])], 16000,
+                                 dtype=torch.float64)
+    seq = np.empty(len(y0))
+    prev = 0.0
+    for i, v in enumerate(y0.cpu().numpy()):
+        prev = v + 0.97 * prev
+        seq[i] = prev
+    assert np.array_equal(y2.cpu().numpy(), seq)
+    for pre in (0.5, 0.999, -0.9, 1.0):      # short / very long memory (single segment), odd cases
+        yp, _ = ops.world_synthesize(torch.from_numpy(f0s[0]).to(gpu), torch.from_numpy(sps[0]).to(gpu),
+                                     torch.from_numpy(aps[0]).to(gpu), [0, len(f0s[0])], 16000,
+                                     preemphasis=pre, dtype=torch.float64)
+        refp = scipy.signal.lfilter([1], [1, -pre], y0.cpu().numpy())
+        assert np.abs(yp.cpu().numpy() - refp).max() < 1e-9 * max(1.0, np.abs(refp).max())
 
 
 def test_synthesis_48k(gpu):
