@@ -79,6 +79,11 @@ const JumpTable* get_jump_table(DeviceContext* ctx);
 int launch_randn_u32(DeviceContext* ctx, const int64_t* d_off, const int64_t* d_len, int n_utts,
                      int64_t max_len, uint32_t* d_R, hipStream_t s);
 
+// C [T, N] = A [T, K] x B [K, N] in fp64 on the matrix cores (mcep_lockstep.hip); `rows` (or
+// NULL) lists the rows of A / C to work on; a_has_slack: A may be read up to 3 doubles past a row.
+int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                    int64_t T, int N, int K, const int* rows, hipStream_t s, bool a_has_slack = true);
+
 // One of the context's page-locked host slots (round robin) for a read-back of a few bytes.
 int64_t* pinned_slot(DeviceContext* ctx);
 

@@ -350,11 +350,14 @@ __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, i
   }
 }
 
-static int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
-                           int64_t ldc, int64_t T, int N, int K, const int* rows, hipStream_t s) {
+int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                    int64_t ldc, int64_t T, int N, int K, const int* rows, hipStream_t s,
+                    bool a_has_slack) {
   if (T <= 0) return ITTS_OK;
   dim3 grid((unsigned)((T + 63) / 64), (unsigned)((N + 63) / 64));
-  if (lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0)
+  // the 16-byte loads of A cover k .. k+3: past the end of a row (and of the last row's buffer)
+  // unless K is a multiple of 4 or the caller's buffer has that slack
+  if (lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (a_has_slack || K % 4 == 0))
     hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
   else
     hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);

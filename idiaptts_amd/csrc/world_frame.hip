@@ -484,10 +484,10 @@ __global__ __launch_bounds__(NT) void mcep_kernel(McepArgs a) {
 
 // mgc2sp(gamma = 0): c = freqt(mc, -alpha) to order fftlen/2, FFT, real part; optional exp.
 struct Mgc2spArgs {
-  const double* mc;   // [T, m+1]
+  const double* cep;  // [T, ld_cep] de-warped cepstra, f2 + 1 per frame
+  int64_t ld_cep;
   int64_t T;
   int m, fftlen, logfft;
-  const double* invT;
   float* out_f32;     // exp(float(real))  (AudioProcessing.mcep_to_amp_sp :252-256)
   double* out_f64;    // raw log amplitude
   double* out_pow;    // double(exp(float(real)))^2: what world_features_to_raw feeds WORLD (:925)
@@ -498,22 +498,18 @@ __global__ __launch_bounds__(NT) void mgc2sp_kernel(Mgc2spArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* tw = reinterpret_cast<double2*>(smem);
   double2* z = tw + a.fftlen / 2;
-  double* mc = reinterpret_cast<double*>(z + a.fftlen / 2 + 1);
   double* zr = reinterpret_cast<double*>(z);
   const int64_t g = blockIdx.x;
-  const int f2 = a.fftlen / 2, m1 = a.m + 1;
+  const int f2 = a.fftlen / 2;
   load_twiddles(tw, a.g_tw, a.fftlen);
-  for (int j = threadIdx.x; j < m1; j += NT) mc[j] = a.mc[g * m1 + j];
-  __syncthreads();
-  for (int i = threadIdx.x; i < a.fftlen + 2; i += NT) {
-    double s = 0.0;
-    if (i <= f2)
-      for (int j = 0; j < m1; ++j) s += a.invT[(size_t)j * (f2 + 1) + i] * mc[j];
-    zr[i] = s;
-  }
+  // the de-warped cepstrum c = freqt(mc, m -> f2, -alpha) of all frames comes from one fp64-MFMA
+  // GEMM (per-frame matrix-vector products streamed the 250 KB warping matrix through every
+  // workgroup: L2-bandwidth bound)
+  const double* c = a.cep + g * a.ld_cep;
+  for (int i = tid(); i < a.fftlen + 2; i += NT) zr[i] = i <= f2 ? c[i] : 0.0;
   __syncthreads();
   rfft_lds(z, a.fftlen, a.logfft, tw, a.fftlen);
-  for (int k = threadIdx.x; k <= f2; k += NT) {
+  for (int k = tid(); k <= f2; k += NT) {
     const double re = z[k].x;
     if (a.out_f64) a.out_f64[g * (f2 + 1) + k] = re;
     const float amp = expf((float)re);
@@ -736,12 +732,22 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   if (!ctx) return ITTS_E_HIP;
   const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
   if (!ft) return ITTS_E_HIP;
-  Mgc2spArgs a{d_mc, T, order, fftlen, ilog2_host(fftlen), ft->invT, d_amp_f32, d_logamp_f64, d_pow_f64, ctx->twiddles};
-  size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16 + (size_t)(order + 2) * 8;
+  hipStream_t s = as_stream(stream);
+  const int K = fftlen / 2 + 1;
+  const int64_t ld_cep = (K + 1) & ~1;
+  double* d_cep = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cep, (size_t)T * ld_cep * 8, s));
+  int rc = launch_gemm_f64(d_mc, order + 1, ft->invT, K, d_cep, ld_cep, T, K, order + 1, nullptr, s,
+                           /*a_has_slack=*/false);
+  if (rc) return rc;
+  Mgc2spArgs a{d_cep, ld_cep, T, order, fftlen, ilog2_host(fftlen), d_amp_f32, d_logamp_f64, d_pow_f64,
+               ctx->twiddles};
+  size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mgc2sp_kernel, dim3((unsigned)T), dim3(NT), lds, as_stream(stream), a);
+  hipLaunchKernelGGL(mgc2sp_kernel, dim3((unsigned)T), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_cep, s));
   return ITTS_OK;
 }
 
