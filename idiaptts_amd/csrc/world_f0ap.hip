@@ -178,7 +178,22 @@ struct D4cArgs {
   int64_t ld_bap;
   const double2* g_tw;    // compact table of the largest transform (DeviceContext::tw_compact)
   int bmax;
+  const int* order;       // workgroup -> frame: voiced frames first (they do all the work)
 };
+
+// Voiced frames to the front of the launch order, unvoiced ones (which only write constants) to the
+// back: interleaved as they come, the instantly finishing unvoiced workgroups leave the CUs
+// half empty between dispatches.  cnt[0] / cnt[1] count from both ends; the order inside each
+// part does not matter (frames are independent).
+__global__ void d4c_order_kernel(const double* __restrict__ f0, int64_t T, int* __restrict__ order,
+                                 int* __restrict__ cnt) {
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < T; g += (int64_t)gridDim.x * blockDim.x) {
+    if (f0[g] != 0.0)
+      order[atomicAdd(&cnt[0], 1)] = (int)g;
+    else
+      order[T - 1 - atomicAdd(&cnt[1], 1)] = (int)g;
+  }
+}
 
 struct D4cLds {
   const double2* tw;
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
   L.mir = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2 * a.bmax + 2) * 8;
   L.red = reinterpret_cast<double*>(p);
 
-  const int64_t g = blockIdx.x;
+  const int64_t g = a.order[blockIdx.x];
   const int u = find_utt2(a.f_off, a.n_utts, g);
   const double* x = a.x + a.x_off[u];
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
@@ -544,8 +559,18 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)d4c_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(d4c_kernel, dim3((unsigned)h_f_off[n_utts]), dim3(NT), lds, s, a);
+  const int64_t t_total = h_f_off[n_utts];
+  ITTS_REQUIRE(t_total < ((int64_t)1 << 31), "too many frames in one call");
+  int* d_order = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_order, (size_t)(t_total + 2) * sizeof(int), s));
+  ITTS_HIP_CHECK(hipMemsetAsync(d_order + t_total, 0, 2 * sizeof(int), s));
+  hipLaunchKernelGGL(d4c_order_kernel, dim3((unsigned)std::min<int64_t>((t_total + 255) / 256, 1024)), dim3(256),
+                     0, s, d_f0, t_total, d_order, d_order + t_total);
   ITTS_LAUNCH_CHECK();
+  a.order = d_order;
+  hipLaunchKernelGGL(d4c_kernel, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(hipFreeAsync(d_order, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
   return ITTS_OK;
