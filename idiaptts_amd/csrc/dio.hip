@@ -345,39 +345,63 @@ __global__ __launch_bounds__(NT) void dio_contour_kernel(const DioUtt* __restric
     s3[i] = v;
   }
   __syncthreads();
+  // Voiced->unvoiced ("negative") and unvoiced->voiced ("positive") boundaries of the step-2
+  // contour as bit masks, built by all threads: the sequential lane below then walks set bits
+  // instead of scanning the contour with dependent loads.  The step-1 buffer is dead by now and
+  // holds the masks ([nw] negative, [nw] positive) when they do not fit the static LDS copy.
+  const int nw = (T + 63) / 64;
+  __shared__ unsigned long long mask_lds[2][128];
+  unsigned long long* negm = nw <= 128 ? mask_lds[0] : reinterpret_cast<unsigned long long*>(tmp);
+  unsigned long long* posm = nw <= 128 ? mask_lds[1] : negm + nw;
+  __syncthreads();                                   // everyone is done reading tmp (step 2)
+  for (int base_i = 0; base_i < nw * 64; base_i += NT) {
+    const int i = base_i + threadIdx.x;
+    const bool in = i >= 1 && i < T;
+    const double a0 = in ? s1[i - 1] : 0.0, a1 = in ? s1[i] : 0.0;
+    const unsigned long long nm = __ballot(in && a1 == 0.0 && a0 != 0.0);
+    const unsigned long long pm = __ballot(in && a0 == 0.0 && a1 != 0.0);
+    if ((threadIdx.x & 63) == 0 && i / 64 < nw) {
+      negm[i / 64] = nm;
+      posm[i / 64] = pm;
+    }
+  }
+  __syncthreads();
   // steps 3 and 4 are sequential along time (each extension reads values the previous one wrote)
   if (threadIdx.x == 0) {
-    // step 3: forward extension from every voiced->unvoiced boundary of the step-2 contour
-    int i = 1;
-    while (i < T) {
-      while (i < T && !(s1[i] == 0.0 && s1[i - 1] != 0.0)) ++i;
-      if (i >= T) break;
-      const int neg = i - 1;
-      int k = i + 1;
-      while (k < T && !(s1[k] == 0.0 && s1[k - 1] != 0.0)) ++k;
-      const int limit = (k >= T) ? T - 1 : k - 1;
-      for (int j = neg; j < limit; ++j) {
-        s3[j + 1] = select_best(s3[j], s3[j - 1], scand, nb, T, j + 1, ar);
-        if (s3[j + 1] == 0.0) break;
+    // step 3: forward extension from every negative boundary up to the frame before the next one
+    int prev = -1;
+    for (int w = 0; w <= nw; ++w) {
+      unsigned long long m = w < nw ? negm[w] : 1ull;          // sentinel: flush the last boundary
+      while (m) {
+        const int bnd = w < nw ? w * 64 + __ffsll((long long)m) - 1 : T;
+        m &= m - 1;
+        if (prev >= 0) {
+          const int limit = bnd >= T ? T - 1 : bnd - 1;
+          for (int j = prev - 1; j < limit; ++j) {
+            s3[j + 1] = select_best(s3[j], s3[j - 1], scand, nb, T, j + 1, ar);
+            if (s3[j + 1] == 0.0) break;
+          }
+        }
+        prev = bnd;
       }
-      i = k;
-      if (k >= T) break;
     }
-    // step 4: backward extension from every unvoiced->voiced boundary (in place on s3)
-    int ii = T - 1;
-    while (ii >= 1) {
-      while (ii >= 1 && !(s1[ii - 1] == 0.0 && s1[ii] != 0.0)) --ii;
-      if (ii < 1) break;
-      const int pos = ii;
-      int k = ii - 1;
-      while (k >= 1 && !(s1[k - 1] == 0.0 && s1[k] != 0.0)) --k;
-      const int limit = (k < 1) ? 1 : k;
-      for (int j = pos; j > limit; --j) {
-        s3[j - 1] = select_best(s3[j], s3[j + 1], scand, nb, T, j - 1, ar);
-        if (s3[j - 1] == 0.0) break;
+    // step 4: backward extension from every positive boundary down to the previous one (in place)
+    prev = -1;
+    for (int w = nw - 1; w >= -1; --w) {
+      unsigned long long m = w >= 0 ? posm[w] : 1ull;
+      while (m) {
+        const int hb = 63 - __clzll((long long)m);
+        const int bnd = w >= 0 ? w * 64 + hb : 0;
+        m &= ~(1ull << hb);
+        if (prev >= 0) {
+          const int limit = bnd < 1 ? 1 : bnd;
+          for (int j = prev; j > limit; --j) {
+            s3[j - 1] = select_best(s3[j], s3[j + 1], scand, nb, T, j - 1, ar);
+            if (s3[j - 1] == 0.0) break;
+          }
+        }
+        prev = bnd;
       }
-      ii = k;
-      if (k < 1) break;
     }
   }
   __syncthreads();
