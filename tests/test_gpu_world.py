@@ -372,3 +372,33 @@ def test_ragged_batch_with_silence_and_very_short_utterances(gpu):
     assert ap0.shape == (0, 513)
     y0, y0_off = ops.world_synthesize(e, sp0, ap0, [0], fs)
     assert y0.numel() == 0 and y0_off == [0]
+
+
+def test_long_utterances_exercise_the_large_size_paths(gpu):
+    """Sizes past the small-case shortcuts: (1) a 9.5-minute digitally silent utterance -- its
+    CheapTrick envelope is nothing but WORLD's safeguard noise, 68 M normals into the stream, i.e.
+    past the tabulated generator states (2^20 chunks), so the GF(2) jump matrices decide the last
+    frames; (2) a 50 s utterance (10 k frames) through DIO, whose contour kernel then keeps its
+    candidates and boundary masks in global scratch instead of LDS."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    fs = 16000
+    n = int(fs * 570)
+    T = int(1000.0 * n / fs / 5.0) + 1
+    x = torch.zeros(n, dtype=torch.float64, device=gpu)
+    f0 = torch.zeros(T, dtype=torch.float64, device=gpu)
+    sp, _, _ = ops.cheaptrick_mcep(x, [0, n], f0, [0, T], fs)
+    assert T * (97 + 513) > 64 * 2 ** 20                       # beyond the state table
+    tp = np.arange(T) * 0.005
+    sp_ref = capi.cheaptrick(np.zeros(n), fs, tp, np.zeros(T))
+    got = sp.cpu().numpy()
+    for sl in (slice(0, 50), slice(T // 2, T // 2 + 50), slice(T - 50, T)):
+        assert np.abs(np.log(got[sl] / sp_ref[sl])).max() < 1e-9
+    del sp, got, sp_ref
+    xl = _synthetic(fs, 50.0, 9)
+    Tl = int(1000.0 * len(xl) / fs / 5.0) + 1
+    assert Tl > 8192
+    xg = torch.from_numpy(xl).to(gpu)
+    f0d = ops.dio(xg, [0, len(xl)], [0, Tl], fs).cpu().numpy()
+    d_ref, _ = capi.dio(xl, fs)
+    assert np.array_equal(f0d == 0, d_ref == 0) and np.abs(f0d - d_ref).max() < 1e-7
