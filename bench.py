@@ -317,12 +317,20 @@ def main():
 
     from idiaptts_amd import lib
     lib.require_gpu()
+    # Functional check of the N > 1 control flow on a one-GPU box: ITTS_BENCH_SHARE_GPU=1 puts all
+    # ranks on device 0 and runs the collectives over gloo (RCCL refuses two ranks on one device).
+    # Never set for measurements.
+    share_gpu = os.environ.get("ITTS_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from idiaptts_amd.bench_support import make_ff_batch
     from idiaptts_amd.native_ff import FlatFFModel, flops_per_frame
