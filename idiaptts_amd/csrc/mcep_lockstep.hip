@@ -44,14 +44,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
   f64x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  bool cok[4];
-  int ccol[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    ccol[q] = c0 + 16 * q + lr;
-    cok[q] = ccol[q] < N;
-    if (!cok[q]) ccol[q] = 0;
-  }
+  // MFMA q of a lane group covers the columns c0 + 4 lr + q: a lane's four B values of one k are
+  // four consecutive columns (one 32-byte load instead of four 8-byte ones) and its four results
+  // of one output row likewise (one 32-byte store).
+  const int cb = c0 + 4 * lr;
+  const bool cfull = cb + 3 < N;               // all four columns inside the matrix
   // K permutation: lane (lr, kg) supplies k = 16 s + 4 kg + j on MFMA j of chunk s
   for (int s = 0; s < K; s += 16) {
     double av[4];
@@ -75,10 +72,16 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
         av[j] = (kok && rok) ? a : 0.0;
       }
       const double* brow = Bm + (int64_t)kc * ldb;
+      if (cfull) {
+        const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb);   // global: dword alignment suffices
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double b = brow[ccol[q]];
-        bv[j][q] = (kok && cok[q]) ? b : 0.0;
+        for (int q = 0; q < 4; ++q) bv[j][q] = kok ? b4[q] : 0.0;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double b = brow[cb + q < N ? cb + q : 0];
+          bv[j][q] = (kok && cb + q < N) ? b : 0.0;
+        }
       }
     }
 #pragma unroll
@@ -93,9 +96,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
     const int64_t orow = r0 + kg + 4 * r;
     if (orow >= T) continue;
     const int64_t prow_o = rows ? rows[orow] : orow;
+    double* crow = C + prow_o * ldc + cb;
+    if (cfull) {
+      *reinterpret_cast<f64x4*>(crow) = (f64x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (cok[q]) C[prow_o * ldc + ccol[q]] = acc[q][r];
+      for (int q = 0; q < 4; ++q)
+        if (cb + q < N) crow[q] = acc[q][r];
+    }
   }
 }
 
