@@ -100,6 +100,8 @@ class ExtendedHParams(object):
             # not in the reference: keep the (normalised, length matched) training data resident in
             # HBM as packed frame shards instead of loading one file per item and step
             resident_dataset=False,
+            # not in the reference: checkpoints are serialised by a background thread
+            async_checkpoint=False,
             # data
             input_norm_params_file_prefix=None, output_norm_params_file_prefix=None,
             len_in_out_multiplier=1, out_dir=None, world_dir=None,

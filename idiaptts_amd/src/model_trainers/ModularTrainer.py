@@ -276,6 +276,7 @@ class ModularTrainer(object):
         self.logger.info("Training set size: {}".format(len(self.id_list_train)))
 
         handler = self.model_handler
+        handler.async_checkpoint = bool(hparams.get_value("async_checkpoint", False))
         handler.set_dataset(hparams, self.dataset_train, self.dataset_val, self.batch_collate_fn)
         handler.set_optimiser(hparams)
         handler.set_scheduler(hparams,
@@ -343,6 +344,7 @@ class ModularTrainer(object):
                 self.load_best_model(hparams)
             if hparams.save_final_model:
                 self.save_checkpoint(hparams)
+        self.model_handler.wait_for_checkpoints()     # everything on disk when train() returns
         return (*self.get_losses(), self.model_handler)
 
     def sanity_check_train(self, hparams):

@@ -286,8 +286,65 @@ class ExponentialMovingAverage(object):
                                self.decay)
 
 
+def _host_copy(obj):
+    """Detached, compact CPU copies of all tensors in a (nested) state dict."""
+    if torch.is_tensor(obj):
+        return obj.detach().to("cpu", copy=True).contiguous().clone()
+    if isinstance(obj, dict):
+        return type(obj)((k, _host_copy(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_host_copy(v) for v in obj)
+    return obj
+
+
+class _CheckpointWriter(object):
+    """One background thread that serialises checkpoints (hparams.async_checkpoint): the training
+    loop only pays for the device -> host copy of the state, `torch.save` and the file system run
+    behind the next steps (SURVEY.md section 8(f) row 3).  Files appear in submission order;
+    `wait()` (also called before any checkpoint is read and at interpreter exit) blocks until
+    everything is on disk and re-raises a writer error."""
+
+    def __init__(self):
+        import atexit
+        import queue
+        import threading
+        self._queue = queue.Queue()
+        self._error = None
+        self._thread = threading.Thread(target=self._run, name="itts-checkpoint-writer",
+                                        daemon=True)
+        self._thread.start()
+        atexit.register(self.wait)
+
+    def _run(self):
+        while True:
+            obj, path = self._queue.get()
+            try:
+                torch.save(obj, path + ".tmp")
+                os.replace(path + ".tmp", path)
+            except Exception as e:       # surfaced by wait()
+                self._error = e
+            finally:
+                self._queue.task_done()
+
+    def submit(self, obj, path):
+        self._queue.put((_host_copy(obj), path))
+
+    def wait(self):
+        self._queue.join()
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
+
+
 class ModularModelHandlerPyTorch(object):
     logger = logging.getLogger(__name__)
+    _checkpoint_writer = None          # shared _CheckpointWriter, created on first use
+
+    @classmethod
+    def wait_for_checkpoints(cls):
+        """Blocks until all asynchronously written checkpoints are on disk."""
+        if cls._checkpoint_writer is not None:
+            cls._checkpoint_writer.wait()
 
     def __init__(self):
         self.model = None
@@ -949,19 +1006,27 @@ class ModularModelHandlerPyTorch(object):
         params = self.model.state_dict()
         if self.ema:
             params.update(self.ema.shadow)      # only the shadowed (trainable) parameters
-        torch.save({"params": params, "epoch": epoch, "step": step},
-                   os.path.join(model_path, "params_" + suffix))
+        if getattr(self, "async_checkpoint", False):
+            cls = type(self)
+            if cls._checkpoint_writer is None:
+                cls._checkpoint_writer = _CheckpointWriter()
+            save = cls._checkpoint_writer.submit
+        else:
+            save = torch.save
+        save({"params": params, "epoch": epoch, "step": step},
+             os.path.join(model_path, "params_" + suffix))
         if self.optimiser is not None:
-            torch.save({"params": self.optimiser.state_dict(), "epoch": epoch, "step": step,
-                        "best_loss": best_loss}, os.path.join(model_path, "optimiser_" + suffix))
+            save({"params": self.optimiser.state_dict(), "epoch": epoch, "step": step,
+                  "best_loss": best_loss}, os.path.join(model_path, "optimiser_" + suffix))
         if self.scheduler is not None:
-            torch.save({"params": self.scheduler.state_dict(), "epoch": epoch, "step": step},
-                       os.path.join(model_path, "scheduler_" + suffix))
+            save({"params": self.scheduler.state_dict(), "epoch": epoch, "step": step},
+                 os.path.join(model_path, "scheduler_" + suffix))
 
     def load_checkpoint(self, hparams, model_path, epoch=None, ignore_layers=True,
                         load_optimiser=True, load_scheduler=True, step=None, verbose=True,
                         load_best_model=False):
         """reference :125-262.  Returns (best_loss, epoch, step)."""
+        self.wait_for_checkpoints()
         assert load_best_model or step is None or epoch is None, \
             "Only epoch ({}) OR step ({}) can be not None".format(epoch, step)
         if load_best_model or epoch == -1 or step == -1:

@@ -307,3 +307,35 @@ def test_tts_chain_labels_to_waveform(gpu, fixture, golden_dir, tmp_path):
         from scipy.io import wavfile
         fs, w = wavfile.read(os.path.join(hpt.synth_dir, wavs[0]))
         assert fs == 16000 and len(w) == n_frames * 80 and np.abs(w).max() > 0
+
+
+def test_async_checkpoints_equal_synchronous_ones(gpu, fixture):
+    """hparams.async_checkpoint: the background writer produces the same files with the same
+    contents as the synchronous torch.save calls, and resuming from them works."""
+    outs = {}
+    for mode in (False, True):
+        hp = _hparams(fixture[0], fixture[2], "test_async_{}".format(int(mode)))
+        hp.seed = 1234
+        hp.use_best_as_final_model = True          # exercises a checkpoint read inside train()
+        hp.async_checkpoint = mode
+        trainer = _trainer(fixture, hp)
+        trainer.init(hp)
+        val, train, handler = trainer.train(hp)
+        nn_dir = os.path.join(hp.out_dir, hp.model_name, hp.networks_dir)
+        outs[mode] = (nn_dir, val["MSELoss_acoustic_features"])
+    (d0, v0), (d1, v1) = outs[False], outs[True]
+    np.testing.assert_allclose(v0, v1, rtol=0, atol=0)
+    assert sorted(os.listdir(d0)) == sorted(os.listdir(d1))
+    for f in os.listdir(d0):
+        if f == "config.json" or f.startswith("scheduler"):
+            continue
+        a = torch.load(os.path.join(d0, f), map_location="cpu", weights_only=False)
+        b = torch.load(os.path.join(d1, f), map_location="cpu", weights_only=False)
+        assert a["epoch"] == b["epoch"]
+        pa, pb = a["params"], b["params"]
+        if "state" in pa:                          # optimiser file
+            for k in pa["state"]:
+                assert torch.equal(pa["state"][k]["exp_avg"], pb["state"][k]["exp_avg"])
+        else:
+            for k in pa:
+                assert torch.equal(pa[k], pb[k])
