@@ -62,10 +62,15 @@ def merlin_post_filter(mgc, alpha, minimum_phase_order=511, fftlen=1024, coef=1.
 class AudioProcessing:
     mgc_gamma = -1. / 3.
 
+    _alpha_cache = {}
+
     @staticmethod
     def fs_to_mgc_alpha(fs):
-        """pysptk.util.mcepalpha(fs) (reference :32-40)."""
-        return _lib.load().itts_mcep_alpha(int(fs))
+        """pysptk.util.mcepalpha(fs) (reference :32-40); a 23 ms search, cached per rate."""
+        fs = int(fs)
+        if fs not in AudioProcessing._alpha_cache:
+            AudioProcessing._alpha_cache[fs] = _lib.load().itts_mcep_alpha(fs)
+        return AudioProcessing._alpha_cache[fs]
 
     @staticmethod
     def fs_to_frame_length(fs):

@@ -40,12 +40,19 @@ def _dist_device():
 
 
 def _save_to_npz(file_path, features, feature_name):
-    """LabelGen._save_to_npz (reference LabelGen.py:63-101): merge into an existing archive."""
+    """LabelGen._save_to_npz (reference LabelGen.py:63-101): merge into an existing archive.
+    `features` / `feature_name` may be lists: all of them go into the archive in one
+    read-modify-write (the reference rewrites the archive once per feature)."""
     os.makedirs(os.path.dirname(file_path), exist_ok=True)
     if not file_path.endswith(".npz"):
         file_path += ".npz"
-    saved = dict(np.load(file_path)) if os.path.isfile(file_path) else {}
-    saved[feature_name] = features
+    if not isinstance(feature_name, (list, tuple)):
+        features, feature_name = [features], [feature_name]
+    saved = {}
+    if os.path.isfile(file_path):
+        with np.load(file_path) as archive:
+            saved = {k: archive[k] for k in archive.files if k not in feature_name}
+    saved.update(zip(feature_name, features))
     tmp = file_path + "_tmp.npz"
     np.savez(tmp, **saved)
     os.replace(tmp, file_path)
@@ -351,10 +358,12 @@ class WorldFeatLabelGen(ReaderBase):
                     double_deltas = compute_deltas(deltas)
                 if dir_out is not None:
                     file_path = os.path.join(dir_out, feature_dir, file_name)
-                    _save_to_npz(file_path, feature, feature_ext)
                     if feature_dir != self.dir_vuv:
-                        _save_to_npz(file_path, deltas, feature_ext + "_deltas")
-                        _save_to_npz(file_path, double_deltas, feature_ext + "_double_deltas")
+                        _save_to_npz(file_path, [feature, deltas, double_deltas],
+                                     [feature_ext, feature_ext + "_deltas",
+                                      feature_ext + "_double_deltas"])
+                    else:
+                        _save_to_npz(file_path, feature, feature_ext)
                 if feature_dir != self.dir_vuv:
                     feature = np.concatenate((feature, deltas, double_deltas), axis=1)
             elif dir_out is not None:
