@@ -132,10 +132,15 @@ class WorldFeatLabelGen(ReaderBase):
     def _postprocess_world(self, sample, norm_params=None, apply_mlpg=True):
         """Turns a de-normalised network output with deltas back into static WORLD features
         (reference :357-415): every continuous stream (coded sp, lf0, bap) goes through MLPG with
-        that stream's covariance (all three solves share one GPU round trip here), V/UV is
-        binarised with `<= 0.5 -> 0` (note: convert_to_world_features uses `< 0.5`)."""
+        that stream's covariance, V/UV is binarised with `<= 0.5 -> 0` (note:
+        convert_to_world_features uses `< 0.5`)."""
+        return self._postprocess_world_batch([sample], apply_mlpg=apply_mlpg)[0]
+
+    def _postprocess_world_batch(self, samples, apply_mlpg=True):
+        """_postprocess_world for several utterances: one MLPG launch (one host <-> device round
+        trip) per stream for all of them instead of one per stream and utterance."""
         if not self.add_deltas:
-            return sample
+            return list(samples)
         widths = []  # (stream index into self.covs, static width, is_vuv)
         if self.load_sp:
             widths.append((0, self.num_coded_sps, False))
@@ -145,27 +150,31 @@ class WorldFeatLabelGen(ReaderBase):
             widths.append((2, 1, True))
         if self.load_bap:
             widths.append((3, self.num_bap, False))
-        pieces, col = [], 0
+        pieces = [[] for _ in samples]
+        col = 0
         mlpg = MLPG()
         for cov_idx, width, is_vuv in widths:
             if is_vuv:
-                vuv = sample[:, col]          # view: the caller's array is binarised in place,
-                vuv[vuv <= 0.5] = 0.0         # exactly like the reference (:396-399)
-                vuv[vuv > 0.5] = 1.0
-                pieces.append(vuv[:, None])
+                for u, sample in enumerate(samples):
+                    vuv = sample[:, col]      # view: the caller's array is binarised in place,
+                    vuv[vuv <= 0.5] = 0.0     # exactly like the reference (:396-399)
+                    vuv[vuv > 0.5] = 1.0
+                    pieces[u].append(vuv[:, None])
                 col += 1
                 continue
             if cov_idx == 3:                  # reference slices bap from the END of the row
-                block = sample[:, -width * 3:]
+                blocks = [sample[:, -width * 3:] for sample in samples]
             else:
-                block = sample[:, col:col + 3 * width]
+                blocks = [sample[:, col:col + 3 * width] for sample in samples]
             col += 3 * width
             if apply_mlpg:
                 cov = self.covs[cov_idx]
-                pieces.append(mlpg.generation(block, cov, cov.shape[0] // 3))
+                for u, traj in enumerate(mlpg.generation_batch(blocks, cov, cov.shape[0] // 3)):
+                    pieces[u].append(traj)
             else:
-                pieces.append(block[:, :width])
-        return np.concatenate(pieces, axis=1)
+                for u, block in enumerate(blocks):
+                    pieces[u].append(block[:, :width])
+        return [np.concatenate(p_, axis=1) for p_ in pieces]
 
     # ------------------------------------------------------------------------------ conversions
     @staticmethod
@@ -538,6 +547,14 @@ class WorldFeatLabelGen(ReaderBase):
         sample = sample * std_dev + mean
         return self._postprocess_world(
             sample, apply_mlpg=self.apply_mlpg if apply_mlpg is None else apply_mlpg)
+
+    def postprocess_sample_batch(self, samples, norm_params=None, apply_mlpg=None):
+        """[postprocess_sample(s) for s in samples] with the MLPG solves of all utterances batched
+        per stream (what the trainers' forward / synth use for a mini-batch of outputs)."""
+        mean, std_dev = self.norm_params if norm_params is None else norm_params
+        return self._postprocess_world_batch(
+            [sample * std_dev + mean for sample in samples],
+            apply_mlpg=self.apply_mlpg if apply_mlpg is None else apply_mlpg)
 
     @staticmethod
     def load_sample(id_name, dir_out, add_deltas=False, num_coded_sps=60, num_bap=1,

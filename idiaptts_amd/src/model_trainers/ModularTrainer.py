@@ -495,19 +495,25 @@ class ModularTrainer(object):
             data, seq_lengths = self.model_handler.inference(data=data, hparams=hparams,
                                                              seq_lengths=seq_lengths)
             outputs = self.batch_decollate_fn(data, seq_lengths, batch_first=hparams.batch_first)
+            # post-processing per output stream; readers that can handle the whole mini-batch at
+            # once (WorldFeatLabelGen: one MLPG launch per stream) get it in one call
+            post = {}
+            for feature_name, per_id in outputs.items():
+                if post_processing_mapping is None or feature_name not in post_processing_mapping:
+                    continue
+                reader_name = post_processing_mapping[feature_name]
+                if reader_name is None:
+                    post[feature_name] = list(per_id)
+                    continue
+                reader = self._reader_by_name(reader_name)
+                batch_fn = getattr(reader, "postprocess_sample_batch", None)
+                if batch_fn is not None:
+                    post[feature_name] = batch_fn(list(per_id))
+                else:
+                    post[feature_name] = [reader.postprocess_sample(f) for f in per_id]
             for idx, id_name in enumerate(id_sub_list):
-                output = {k: v[idx] for k, v in outputs.items()}
-                dict_outputs[id_name] = output
-                output_post = {}
-                for feature_name, features in output.items():
-                    if post_processing_mapping is not None \
-                            and feature_name in post_processing_mapping:
-                        reader_name = post_processing_mapping[feature_name]
-                        if reader_name is not None:
-                            features = self._reader_by_name(reader_name) \
-                                .postprocess_sample(features)
-                        output_post[feature_name] = features
-                dict_outputs_post[id_name] = output_post
+                dict_outputs[id_name] = {k: v[idx] for k, v in outputs.items()}
+                dict_outputs_post[id_name] = {k: v[idx] for k, v in post.items()}
         if benchmark:
             return self.compute_score(data=dict_outputs_post, output=dict_outputs,
                                       hparams=hparams)
