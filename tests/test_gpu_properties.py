@@ -1,0 +1,108 @@
+"""Size-independent properties at the sizes of the bench / BASELINE configs (where the CPU oracle
+would take minutes): batch independence, determinism, linearity, round trips."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_world_batch_of_48_utterances_equals_utterance_by_utterance(gpu):
+    """Config 5 batch (48 utterances, ~290 s, 58 k frames): every kernel of the analysis /
+    synthesis chain treats utterances independently, so the rows of an utterance inside the batch
+    are bit-identical to the result of analysing it alone."""
+    from idiaptts_amd import ops, world
+    from idiaptts_amd.bench_support import make_audio_batch
+    fs = 16000
+    raws = make_audio_batch(48, fs, seed=0)
+    x_off = world.offsets([len(r) for r in raws])
+    f_off = world.offsets([world.num_frames(len(r), fs, 5.0) for r in raws])
+    x = torch.from_numpy(np.concatenate(raws)).to(gpu)
+
+    def chain(x, x_off, f_off):
+        f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs), f_off, fs)
+        sp, mc, it = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, order=59, alpha=0.41,
+                                         mc_dtype=torch.float64, want_iters=True)
+        ap, bap = ops.d4c(x, x_off, f0, f_off, fs, want_bap=torch.float64)
+        y, y_off = ops.world_synthesize(f0, sp, ap, f_off, fs, dtype=torch.float64)
+        return f0, sp, mc, it, ap, bap, y, y_off
+
+    f0, sp, mc, it, ap, bap, y, y_off = chain(x, x_off, f_off)
+    assert f_off[-1] > 55000 and torch.isfinite(mc).all() and torch.isfinite(y).all()
+    for u in (0, 17, 47):
+        xu = torch.from_numpy(raws[u]).to(gpu)
+        T = f_off[u + 1] - f_off[u]
+        f0u, spu, mcu, itu, apu, bapu, yu, _ = chain(xu, [0, len(raws[u])], [0, T])
+        a, b = f_off[u], f_off[u + 1]
+        for whole, alone in ((f0, f0u), (sp, spu), (mc, mcu), (it, itu), (ap, apu), (bap, bapu)):
+            assert torch.equal(whole[a:b], alone)
+        assert torch.equal(y[y_off[u]:y_off[u + 1]], yu)
+    # re-analysis of the synthesised batch finds (nearly) the same voicing and pitch
+    f_off2 = world.offsets([world.num_frames(y_off[u + 1] - y_off[u], fs, 5.0) for u in range(48)])
+    f0r_all = ops.stonemask(y, y_off, ops.dio(y, y_off, f_off2, fs), f_off2, fs)
+    # the synthesised signal is T * 80 samples long: it has the same number of frames or one more
+    f0r = torch.cat([f0r_all[f_off2[u]:f_off2[u] + (f_off[u + 1] - f_off[u])] for u in range(48)])
+    v0, v1 = f0 > 0, f0r > 0
+    assert float((v0 == v1).double().mean()) > 0.9          # boundary frames flip, nothing else
+    both = v0 & v1
+    cents = 1200 * torch.log2(f0r[both] / f0[both])
+    assert float(cents.abs().median()) < 5.0
+
+
+def test_mlpg_is_linear_in_the_means_at_config_4_size(gpu):
+    """256 utterances, 310 k frames x 62 dims: P x = b with b linear in the means, so
+    mlpg(a f + c g) = a mlpg(f) + c mlpg(g) for fixed variances (to fp64 round-off), and a
+    constant static trajectory with zero deltas is reproduced."""
+    from idiaptts_amd import ops, world
+    from idiaptts_amd.bench_support import utterance_lengths
+    off = world.offsets(utterance_lengths(256, seed=5).tolist())
+    n = off[-1]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    f = torch.randn(n, 186, dtype=torch.float64, generator=g).to(gpu)
+    h = torch.randn(n, 186, dtype=torch.float64, generator=g).to(gpu)
+    var = (torch.rand(186, dtype=torch.float64, generator=g) * 0.99 + 0.01).to(gpu)
+    mf, mh = ops.mlpg_generation(f, var, 62, off), ops.mlpg_generation(h, var, 62, off)
+    mix = ops.mlpg_generation(0.3 * f - 1.7 * h, var, 62, off)
+    assert (mix - (0.3 * mf - 1.7 * mh)).abs().max() < 1e-10 * max(1.0, float(mf.abs().max()))
+    const = torch.zeros(n, 186, dtype=torch.float64, device=gpu)
+    const[:, :62] = torch.linspace(-2, 2, 62, dtype=torch.float64, device=gpu)
+    out = ops.mlpg_generation(const, var, 62, off)
+    assert (out - const[:, :62]).abs().max() < 1e-9
+
+
+def test_ff_train_step_is_deterministic_at_bench_size(gpu):
+    """Config 2 step (32 utterances, 39 k frames): split-K slabs are reduced in a fixed order, so
+    two runs from the same state give the same bits in the loss and in every parameter."""
+    from idiaptts_amd.bench_support import make_ff_batch
+    from idiaptts_amd.native_ff import FlatFFModel
+    x, y, lengths = make_ff_batch(32, seed=0, device=gpu)
+    valid = torch.ones(x.shape[0], dtype=torch.uint8, device=gpu)
+    runs = []
+    for _ in range(2):
+        model = FlatFFModel((425, 512, 512, 187), ("tanh", "tanh", None), device=gpu, seed=0)
+        losses = [float(model.train_step(x, y, valid, float(lengths.sum()))) for _ in range(5)]
+        runs.append((losses, model.params.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][-1] < runs[0][0][0]
+
+
+def test_bilstm_output_does_not_depend_on_the_order_of_the_batch(gpu):
+    """Config 3 shape (64 utterances, 3 x 512 BiLSTM): rows are sorted by length internally;
+    permuting the utterances permutes the outputs and nothing else (bit for bit), padding stays
+    zero."""
+    from idiaptts_amd.nn import LSTM
+    torch.manual_seed(0)
+    B, H = 64, 512
+    lengths = torch.randint(40, 200, (B,))
+    T = int(lengths.max())
+    x = torch.randn(T, B, 425, device=gpu)
+    for b in range(B):
+        x[lengths[b]:, b] = 0
+    net = LSTM(425, H, 3, bidirectional=True).to(gpu)
+    with torch.no_grad():
+        out, _ = net(x, None, lengths)
+        perm = torch.randperm(B)
+        out_p, _ = net(x[:, perm], None, lengths[perm])
+    assert torch.equal(out[:, perm], out_p)
+    for b in (0, 31, 63):
+        assert float(out[lengths[b]:, b].abs().max()) == 0.0 if lengths[b] < T else True
