@@ -36,7 +36,9 @@ def test_world_batch_of_48_utterances_equals_utterance_by_utterance(gpu):
         a, b = f_off[u], f_off[u + 1]
         for whole, alone in ((f0, f0u), (sp, spu), (mc, mcu), (it, itu), (ap, apu), (bap, bapu)):
             assert torch.equal(whole[a:b], alone)
-        assert torch.equal(y[y_off[u]:y_off[u + 1]], yu)
+        # (overlap-add uses f64 atomics: the order of the ~10 pulses meeting in a sample is not
+        # fixed by the programming model, so the waveform is compared to round-off, not to the bit)
+        assert (y[y_off[u]:y_off[u + 1]] - yu).abs().max() < 1e-13
     # re-analysis of the synthesised batch finds (nearly) the same voicing and pitch
     f_off2 = world.offsets([world.num_frames(y_off[u + 1] - y_off[u], fs, 5.0) for u in range(48)])
     f0r_all = ops.stonemask(y, y_off, ops.dio(y, y_off, f_off2, fs), f_off2, fs)

@@ -324,7 +324,9 @@ def test_parallel_phase_scan_is_bit_identical_to_the_sequential_chain(gpu):
     finally:
         os.environ.pop("ITTS_SYNTH_SEQ_PHASE", None)
     assert torch.isfinite(y_scan).all() and y_scan.abs().max() > 0
-    assert torch.equal(y_scan, y_seq)
+    # identical pulse positions and phases -> identical waveforms up to the order in which the f64
+    # atomics of overlapping pulses land (a pulse moved by one sample would show as ~1e-3)
+    assert (y_scan - y_seq).abs().max() < 1e-13
 
 
 def test_ragged_batch_with_silence_and_very_short_utterances(gpu):
