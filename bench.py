@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--utts-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--world-utts", type=int, default=48,
+    ap.add_argument("--world-utts", type=int, default=256,
                     help="utterances in the WORLD feature-path section (0 = skip)")
     ap.add_argument("--world-fs", type=int, default=16000)
     ap.add_argument("--bilstm-utts", type=int, default=64,
