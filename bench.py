@@ -37,6 +37,23 @@ def hip_event_time_ms(fn, stream, iters):
     return start.elapsed_time(end) / iters
 
 
+def hip_event_median_ms(fn, stream, iters):
+    """Median duration of fn() over `iters` passes, each bracketed by its own event pair on
+    `stream` (the secondary sections: one slow pass -- a pool growing, a clock ramp -- must not
+    decide the figure)."""
+    times = []
+    with torch.cuda.stream(stream):
+        for _ in range(iters):
+            start = torch.cuda.Event(enable_timing=True)
+            end = torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+            fn()
+            end.record(stream)
+            end.synchronize()
+            times.append(start.elapsed_time(end))
+    return float(np.median(times))
+
+
 def cpu_baseline_ff(n_utts, max_seconds=20.0):
     """Reference stack (torch.nn.Linear/Tanh + MSELoss*mask + Adam) on the host cores, padded
     batch exactly like process_dataloader; bounded sample."""
@@ -123,7 +140,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
 
     f0, mc, bap, iters = analysis()
     sync()
-    ms_an = over_ranks(hip_event_time_ms(analysis, stream, 3), dist.ReduceOp.MAX)
+    ms_an = over_ranks(hip_event_median_ms(analysis, stream, 5), dist.ReduceOp.MAX)
     mc64 = mc.double()
     bap64 = bap.double()
     f0s = f0.clone()
@@ -135,12 +152,12 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
 
     synthesis()
     sync()
-    ms_sy = over_ranks(hip_event_time_ms(synthesis, stream, 3), dist.ReduceOp.MAX)
+    ms_sy = over_ranks(hip_event_median_ms(synthesis, stream, 5), dist.ReduceOp.MAX)
     frames = int(over_ranks(f_off[-1], dist.ReduceOp.SUM))
     audio_s = over_ranks(audio_s, dist.ReduceOp.SUM)
     res[key] = {
         "fs": fs, "utterances": n_utts * n_ranks, "n_gpus": n_ranks, "audio_seconds": audio_s,
-        "frames": frames,
+        "frames": frames, "timing": "median of 5 passes, HIP events on the launch stream",
         "analysis_ms": ms_an, "analysis_rtf": ms_an * 1e-3 / audio_s,
         "analysis_frames_per_s": frames / (ms_an * 1e-3),
         "synthesis_ms": ms_sy, "synthesis_rtf": ms_sy * 1e-3 / audio_s,
@@ -162,8 +179,8 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
         ops.mlpg_generation(feat, var, 62, ml_off)
         sync()
-        ms_ml = over_ranks(hip_event_time_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off),
-                                             stream, 5), dist.ReduceOp.MAX)
+        ms_ml = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off),
+                                               stream, 7), dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
         res["mlpg"] = {"utterances": 256 * n_ranks, "frames": ml_frames, "ms": ms_ml,
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
