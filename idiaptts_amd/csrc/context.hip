@@ -25,7 +25,7 @@ static int create_context(DeviceContext* ctx) {
   ITTS_HIP_CHECK(hipMemcpy(ctx->twiddles, tw.data(), n * sizeof(double2), hipMemcpyHostToDevice));
   // The entry points take their scratch from the device's stream-ordered pool.  By default the
   // pool hands everything back to the driver at the next synchronisation, which turns every call
-  // into fresh multi-hundred-MB allocations; let it keep up to 16 GB (of 288) between calls.
+  // into fresh multi-hundred-MB allocations; let it keep up to 64 GB (of 288) between calls.
   for (int L = 9; (1 << L) <= wd::TW_N; ++L) {
     const int m = (1 << L) / 2, stride = wd::TW_N / (1 << L);
     std::vector<double2> c(m);
@@ -36,7 +36,7 @@ static int create_context(DeviceContext* ctx) {
   ITTS_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, 64 * sizeof(int64_t), hipHostMallocDefault));
   hipMemPool_t pool;
   if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {
-    uint64_t keep = 16ull << 30;
+    uint64_t keep = 64ull << 30;
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
   }
   return ITTS_OK;
