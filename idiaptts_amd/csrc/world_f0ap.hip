@@ -342,12 +342,12 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
     }
     __syncthreads();
     dc_correction(L.B, f0, fs, fft);
-    linear_smoothing(L.B, f0, fs, fft, L.B, L.mir, L.red);
+    linear_smoothing(L.B, f0, fs, fft, L.B, L.mir, zr);     // z is idle here: scan scratch
     // --- static group delay
     for (int k = threadIdx.x; k <= h; k += NT) L.C[k] = L.A[k] / L.B[k];
     __syncthreads();
-    linear_smoothing(L.C, f0 / 2.0, fs, fft, L.C, L.mir, L.red);
-    linear_smoothing(L.C, f0, fs, fft, L.D, L.mir, L.red);
+    linear_smoothing(L.C, f0 / 2.0, fs, fft, L.C, L.mir, zr);
+    linear_smoothing(L.C, f0, fs, fft, L.D, L.mir, zr);
     for (int k = threadIdx.x; k <= h; k += NT) L.C[k] -= L.D[k];
     __syncthreads();
     // --- coarse aperiodicity per 3 kHz band
@@ -554,8 +554,10 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   const int fmax = std::max(a.fftd, a.fftl), hmax = fmax / 2;
   a.g_tw = ctx->tw_compact[ilog2h(fmax)];
   a.bmax = (int)(1200.0 * fmax / fs) + 2;
+  // 51.8 KB for the 2048-point transforms: three workgroups per CU also if LDS is handed out in
+  // 4 KB blocks (the block-scan scratch of the smoothing passes lives in the idle FFT buffer)
   const size_t lds = (size_t)(hmax + 1) * 16 + 3 * (size_t)(hmax + 2) * 8 +
-                     (size_t)(hmax + 2 * a.bmax + 2) * 8 + (size_t)(NT + 8) * 8;
+                     (size_t)(hmax + 2 * a.bmax + 2) * 8 + 32 * 8;
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)d4c_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
