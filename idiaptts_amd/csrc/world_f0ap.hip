@@ -254,22 +254,33 @@ __device__ inline int windowed_to(const double* __restrict__ x, int64_t xl, int 
   return n;
 }
 
+// AREG: the centroid accumulates in registers and only two bin arrays live in LDS (needed to get
+// two workgroups per CU with the 4096-point transforms of 48 kHz; costs ~60 VGPRs, so the
+// 2048-point case keeps three arrays and stays at three workgroups per CU).
+template <bool AREG>
 __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int fmax = max(a.fftd, a.fftl);
   const int hmax = fmax / 2;
   D4cLds L;
   char* p = smem;
-  // Twiddles are read through the cache from a compact global table (16 KB for the 2048-point
-  // transforms, shared by all workgroups of a CU) and D lives in A's storage (A is dead when D is
-  // written): 53 KB of LDS instead of 77 KB, three workgroups per CU instead of two.
+  // LDS is handed out in coarse blocks, so the footprint decides the workgroups per CU in steps:
+  // twiddles are read through the cache from a compact global table, D lives in A's storage (A is
+  // dead by then), with AREG also C in B's, and the smoothing passes use the idle FFT buffer z for
+  // their mirrored copy and scan scratch.  41 KB for the 2048-point transforms (16 kHz: three
+  // workgroups per CU), 66 KB for 4096 with AREG (48 kHz: two instead of one).
   L.tw = a.g_tw;
-  L.z = reinterpret_cast<double2*>(p); p += (size_t)(hmax + 1) * 16;
+  L.z = reinterpret_cast<double2*>(p);
+  p += max((size_t)(hmax + 1) * 16, (size_t)(hmax + 2 * a.bmax + 2) * 8 + (size_t)(NT + 8) * 8);
   L.A = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
   L.B = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
-  L.C = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  if (AREG) {
+    L.C = L.B;
+  } else {
+    L.C = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2) * 8;
+  }
   L.D = L.A;
-  L.mir = reinterpret_cast<double*>(p); p += (size_t)(hmax + 2 * a.bmax + 2) * 8;
+  L.mir = reinterpret_cast<double*>(L.z);
   L.red = reinterpret_cast<double*>(p);
 
   const int64_t g = a.order[blockIdx.x];
@@ -314,21 +325,45 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
     const double f0 = f0raw > 47.0 ? f0raw : 47.0;  // kFloorF0D4C
     // twiddles in LDS are those of the largest transform (fmax); smaller ones stride through it
     auto rfft = [&](void) { rfft_lds(L.z, fft, logfft, L.tw, fmax); };
-    // --- static centroid (two time-shifted analyses)
+    // --- static centroid (two time-shifted analyses): the first spectrum of a side waits in
+    // B (re) and C (im) -- with AREG in B and A, the centroid then accumulates in registers (a thread
+    // always owns the bins tid + 256 i) and moves to A when both sides are done
+    constexpr int APER = 9;                     // (4096 / 2 + 1) / 256 rounded up
+    double acc_a[AREG ? APER : 1];
+    double* im1 = AREG ? L.A : L.C;
     for (int side = 0; side < 2; ++side) {
       const double cpos = side == 0 ? pos - 0.25 / f0 : pos + 0.25 / f0;
       windowed_to(x, xl, fs, f0, cpos, 1, 4.0, zr, fft + 2, true, false, L.red);
       rfft();
       for (int k = threadIdx.x; k <= h; k += NT) {
         L.B[k] = L.z[k].x;
-        L.C[k] = L.z[k].y;
+        im1[k] = L.z[k].y;
       }
       __syncthreads();
       windowed_to(x, xl, fs, f0, cpos, 1, 4.0, zr, fft + 2, true, true, L.red);
       rfft();
-      for (int k = threadIdx.x; k <= h; k += NT) {
-        const double v = L.z[k].x * L.B[k] + L.C[k] * L.z[k].y;
-        L.A[k] = side == 0 ? v : L.A[k] + v;
+      if (AREG) {
+#pragma unroll
+        for (int i = 0; i < APER; ++i) {
+          const int k = threadIdx.x + i * NT;
+          if (k <= h) {
+            const double v = L.z[k].x * L.B[k] + im1[k] * L.z[k].y;
+            acc_a[i] = side == 0 ? v : acc_a[i] + v;
+          }
+        }
+      } else {
+        for (int k = threadIdx.x; k <= h; k += NT) {
+          const double v = L.z[k].x * L.B[k] + im1[k] * L.z[k].y;
+          L.A[k] = side == 0 ? v : L.A[k] + v;
+        }
+      }
+      __syncthreads();
+    }
+    if (AREG) {
+#pragma unroll
+      for (int i = 0; i < APER; ++i) {
+        const int k = threadIdx.x + i * NT;
+        if (k <= h) L.A[k] = acc_a[i];
       }
       __syncthreads();
     }
@@ -342,12 +377,13 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
     }
     __syncthreads();
     dc_correction(L.B, f0, fs, fft);
-    linear_smoothing(L.B, f0, fs, fft, L.B, L.mir, zr);     // z is idle here: scan scratch
+    double* scan = L.mir + (hmax + 2 * a.bmax + 2);     // behind the mirrored copy, inside z
+    linear_smoothing(L.B, f0, fs, fft, L.B, L.mir, scan);
     // --- static group delay
     for (int k = threadIdx.x; k <= h; k += NT) L.C[k] = L.A[k] / L.B[k];
     __syncthreads();
-    linear_smoothing(L.C, f0 / 2.0, fs, fft, L.C, L.mir, zr);
-    linear_smoothing(L.C, f0, fs, fft, L.D, L.mir, zr);
+    linear_smoothing(L.C, f0 / 2.0, fs, fft, L.C, L.mir, scan);
+    linear_smoothing(L.C, f0, fs, fft, L.D, L.mir, scan);
     for (int k = threadIdx.x; k <= h; k += NT) L.C[k] -= L.D[k];
     __syncthreads();
     // --- coarse aperiodicity per 3 kHz band
@@ -554,12 +590,13 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   const int fmax = std::max(a.fftd, a.fftl), hmax = fmax / 2;
   a.g_tw = ctx->tw_compact[ilog2h(fmax)];
   a.bmax = (int)(1200.0 * fmax / fs) + 2;
-  // 51.8 KB for the 2048-point transforms: three workgroups per CU also if LDS is handed out in
-  // 4 KB blocks (the block-scan scratch of the smoothing passes lives in the idle FFT buffer)
-  const size_t lds = (size_t)(hmax + 1) * 16 + 3 * (size_t)(hmax + 2) * 8 +
-                     (size_t)(hmax + 2 * a.bmax + 2) * 8 + 32 * 8;
+  // z doubles as the smoothing passes' mirrored copy + scan scratch: it has to hold them
+  const size_t z_bytes = std::max((size_t)(hmax + 1) * 16,
+                                  (size_t)(hmax + 2 * a.bmax + 2) * 8 + (size_t)(NT + 8) * 8);
+  const bool areg = hmax > 1024;            // 4096-point transforms: two bin arrays, see the kernel
+  const size_t lds = z_bytes + (areg ? 2 : 3) * (size_t)(hmax + 2) * 8 + 32 * 8;
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)d4c_kernel,
+  ITTS_HIP_CHECK(hipFuncSetAttribute(areg ? (const void*)d4c_kernel<true> : (const void*)d4c_kernel<false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t t_total = h_f_off[n_utts];
   ITTS_REQUIRE(t_total < ((int64_t)1 << 31), "too many frames in one call");
@@ -570,7 +607,10 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
                      0, s, d_f0, t_total, d_order, d_order + t_total);
   ITTS_LAUNCH_CHECK();
   a.order = d_order;
-  hipLaunchKernelGGL(d4c_kernel, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  if (areg)
+    hipLaunchKernelGGL(d4c_kernel<true>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  else
+    hipLaunchKernelGGL(d4c_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(hipFreeAsync(d_order, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
