@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int fft = a.p.fft, logfft = a.p.logfft, h = fft / 2, K = h + 1;
   char* q = smem;
-  double2* tw = reinterpret_cast<double2*>(q); q += (size_t)h * 16;
+  const double2* tw = a.g_tw;          // compact table read through the cache: 8 KB of LDS less
   double2* z = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
   double2* mp = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
   double* lg = reinterpret_cast<double*>(mp);      // input of min_phase, dead before mp is written
@@ -465,8 +465,6 @@ __global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
   double* red = reinterpret_cast<double*>(q);
   double* zr = reinterpret_cast<double*>(z);
 
-  load_twiddles(tw, a.g_tw, fft);
-  __syncthreads();
   const int64_t total = a.gpoff[a.p.n_utts];
   const int64_t g = blockIdx.x;           // one pulse per workgroup (the host reads the pulse count)
   if (g < total) {
@@ -752,10 +750,11 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   const int64_t n_pulses = *h_total;
   ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
   if (n_pulses > 0) {
-    PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p, ctx->twiddles};
+    PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
+                ctx->tw_compact[p.logfft]};
     const int h = fft_size / 2;
-    const size_t lds = (size_t)h * 16 + 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
-                       (size_t)h * 8 + 16 * 8;            // 36.2 KB at fft 1024: 4 workgroups per CU
+    const size_t lds = 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
+                       (size_t)h * 8 + 16 * 8;            // 28.2 KB at fft 1024: 5 workgroups per CU
     ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
