@@ -34,7 +34,7 @@ __device__ __forceinline__ int find_utt(const int64_t* __restrict__ off, int n_u
 // CheapTrick for one frame. Result (power spectral envelope, fft/2+1 bins) is left in P.
 // LDS: z [fft/2+1] complex, P [fft/2+1], mir [fft/2 + 2*bmax + 1], red [NT+8], tw [fft/2] cplx
 struct CtLds {
-  double2* tw;
+  const double2* tw;
   double2* z;
   double* P;
   double* mir;
@@ -129,7 +129,7 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
 // in:  xp[0..f2] = amp^2 + eps (periodogram, half)      out: mc[0..m]
 // LDS: z [f2+1] cplx (flng real), mc[m+1], cr[2m+1], al unused, A [(m+1)*(m+2)], fcol[m+1], misc[8]
 struct McLds {
-  double2* tw;   // twiddles of an flng-point transform (flng/2 entries)
+  const double2* tw;   // twiddles of an flng-point transform (flng/2 entries)
   double2* z;
   double* xp;
   double* mc;
@@ -319,6 +319,7 @@ struct FrameArgs {
   int64_t ld_mc;
   int* iters;               // [Ttot] or nullptr
   const double2* g_tw;
+  const double2* g_tw_compact;   // DeviceContext::tw_compact of this fft size
   int bmax;                 // bound on the smoothing boundary (LDS carve)
   const uint32_t* rn;       // safeguard-noise streams, utterance u at rn + f_off[u] * rn_pitch
   const int64_t* rn_pos;    // [Ttot] position of each frame inside its utterance's stream
@@ -372,15 +373,16 @@ __global__ __launch_bounds__(256) void ct_noise_pos_kernel(const double* __restr
   }
 }
 
-__device__ inline void carve_ct(char*& p, int fft, int bmax, CtLds& L) {
-  L.tw = reinterpret_cast<double2*>(p); p += (size_t)(fft / 2) * sizeof(double2);
+__device__ inline void carve_ct(char*& p, int fft, int bmax, CtLds& L, bool tw_in_lds) {
+  L.tw = reinterpret_cast<double2*>(p);
+  if (tw_in_lds) p += (size_t)(fft / 2) * sizeof(double2);
   L.z = reinterpret_cast<double2*>(p); p += (size_t)(fft / 2 + 1) * sizeof(double2);
   L.P = reinterpret_cast<double*>(p); p += (size_t)(fft / 2 + 2) * sizeof(double);
   L.mir = reinterpret_cast<double*>(p); p += (size_t)(fft + 2 * bmax + 2) * sizeof(double);
   L.red = reinterpret_cast<double*>(p); p += (size_t)(NT + 8) * sizeof(double);
 }
-static size_t ct_lds_bytes(int fft, int bmax) {
-  return (size_t)(fft / 2) * 16 + (size_t)(fft / 2 + 1) * 16 + (size_t)(fft / 2 + 2) * 8 +
+static size_t ct_lds_bytes(int fft, int bmax, bool tw_in_lds) {
+  return (tw_in_lds ? (size_t)(fft / 2) * 16 : 0) + (size_t)(fft / 2 + 1) * 16 + (size_t)(fft / 2 + 2) * 8 +
          (size_t)(fft + 2 * bmax + 2) * 8 + (size_t)(NT + 8) * 8;
 }
 __device__ inline void carve_mc(char*& p, int m, McLds& L) {
@@ -405,7 +407,9 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* p = smem;
   CtLds L;
-  carve_ct(p, a.fft, a.bmax, L);
+  // plain CheapTrick reads its twiddles through the cache from the compact table (8 KB of LDS less:
+  // six workgroups per CU instead of five); the fused variant keeps them in LDS for the Newton loop
+  carve_ct(p, a.fft, a.bmax, L, DO_MCEP);
   McLds M;
   if (DO_MCEP) carve_mc(p, a.m, M);
   const int64_t g = blockIdx.x;
@@ -413,8 +417,12 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   const int64_t t = g - a.f_off[u];
   const double* x = a.x + a.x_off[u];
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
-  load_twiddles(L.tw, a.g_tw, a.fft);
-  __syncthreads();
+  if (DO_MCEP) {
+    load_twiddles(const_cast<double2*>(L.tw), a.g_tw, a.fft);
+    __syncthreads();
+  } else {
+    L.tw = a.g_tw_compact;
+  }
   const double f0 = ct_frame_f0(a.f0[g], a.fs, a.fft);
   const double pos = (double)t * a.frame_period / 1000.0;
   cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L,
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(NT) void mcep_kernel(McepArgs a) {
   carve_mc(p, a.m, M);
   const int64_t g = blockIdx.x;
   const int K = a.flng / 2 + 1;
-  load_twiddles(M.tw, a.g_tw, a.flng);
+  load_twiddles(const_cast<double2*>(M.tw), a.g_tw, a.flng);
   for (int k = threadIdx.x; k < K; k += NT) {
     const double v = a.amp[g * K + k];
     M.xp[k] = v * v + a.eps;
@@ -649,6 +657,7 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   a.sp = fused ? d_sp : sp_buf; a.do_mcep = fused ? 1 : 0; a.m = order; a.alpha = alpha; a.eps = eps;
   a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64;
   a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
+  a.g_tw_compact = ctx->tw_compact[a.logfft];
   a.bmax = smoothing_bmax(fs, fft_size, 1000.0);
   // safeguard-noise streams: positions (scan over the frames' window lengths), then the normals
   const int K = fft_size / 2 + 1;
@@ -667,7 +676,7 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   rc = launch_randn_u32(ctx, d_roff, d_rlen, n_utts, t_max * rn_pitch, d_rn, s);
   if (rc) return rc;
   a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch;
-  size_t lds = ct_lds_bytes(fft_size, a.bmax) + (fused ? mc_lds_bytes(order) : 0);
+  size_t lds = ct_lds_bytes(fft_size, a.bmax, fused) + (fused ? mc_lds_bytes(order) : 0);
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
   if (fused) {
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel<true>,
