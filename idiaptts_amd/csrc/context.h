@@ -56,7 +56,7 @@ __device__ __forceinline__ uint4 rng_chunk_state(const JumpTable* __restrict__ j
 struct DeviceContext {
   int device = -1;
   double2* twiddles = nullptr;  // [TW_N/2] exp(+2 pi i k / TW_N)
-  // the same values re-packed per transform size n = 2^L (L = 9 .. 14): tw_compact[L][k] =
+  // the same values re-packed per transform size n = 2^L (L = 5 .. 14): tw_compact[L][k] =
   // twiddles[k * TW_N / n], k < n/2 -- contiguous, for kernels that read twiddles through the
   // cache instead of keeping a copy in LDS
   double2* tw_compact[16] = {nullptr};

@@ -26,7 +26,7 @@ static int create_context(DeviceContext* ctx) {
   // The entry points take their scratch from the device's stream-ordered pool.  By default the
   // pool hands everything back to the driver at the next synchronisation, which turns every call
   // into fresh multi-hundred-MB allocations; let it keep up to 64 GB (of 288) between calls.
-  for (int L = 9; (1 << L) <= wd::TW_N; ++L) {
+  for (int L = 5; (1 << L) <= wd::TW_N; ++L) {
     const int m = (1 << L) / 2, stride = wd::TW_N / (1 << L);
     std::vector<double2> c(m);
     for (int k = 0; k < m; ++k) c[k] = tw[(size_t)k * stride];

@@ -135,6 +135,7 @@ struct LsArgs {
   const int* rows;       // frames still iterating (NULL: all T)
   int64_t n_rows;
   const double2* g_tw;
+  const double2* g_tw_compact;   // DeviceContext::tw_compact of the transform size
 };
 
 // x = amp^2 + eps; c = irfft(log x), c[0] /= 2, c[f2] /= 2
@@ -173,10 +174,9 @@ __global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
   const int64_t g = a.rows ? a.rows[blockIdx.x] : blockIdx.x;
   if (a.done[g]) return;
   const int f2 = a.flng / 2;
-  double2* tw = reinterpret_cast<double2*>(smem);
-  double2* z = tw + f2;
+  const double2* tw = a.g_tw_compact;        // read through the cache: the LDS pipe only carries data
+  double2* z = reinterpret_cast<double2*>(smem);
   double* zr = reinterpret_cast<double*>(z);
-  load_twiddles(tw, a.g_tw, a.flng);
   double* row = a.cbuf + g * a.ldk;
   for (int i = threadIdx.x; i < a.flng + 2; i += NT) zr[i] = (i <= f2) ? row[i] : 0.0;
   __syncthreads();
@@ -401,7 +401,7 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   a.in = d_in; a.in_is_power = in_is_power; a.T = T; a.flng = flng; a.logflng = logflng; a.m = order;
   a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.xp = xp;
   a.cbuf = cbuf; a.mc = mc; a.cr = cr; a.sprev = sprev; a.done = done; a.iters = iters;
-  a.n_active = n_active; a.g_tw = ctx->twiddles; a.ldk = Kp; a.rows = nullptr; a.n_rows = T;
+  a.n_active = n_active; a.g_tw = ctx->twiddles; a.g_tw_compact = ctx->tw_compact[logflng]; a.ldk = Kp; a.rows = nullptr; a.n_rows = T;
   const size_t lds_fft = (size_t)f2 * 16 + (size_t)(f2 + 1) * 16;
   const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_kernel,
