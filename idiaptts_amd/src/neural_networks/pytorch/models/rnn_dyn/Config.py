@@ -36,6 +36,26 @@ class Config:
                 rep += ", " + ", ".join("{}: {}".format(k, v) for k, v in self.kwargs.items())
             return rep
 
+    class EmbeddingConfig:
+        """An nn.Embedding whose vectors are concatenated to the input of the layer groups named in
+        `affected_layer_group_indices` (-1: all groups); the index arrives as a separate input or
+        as the last input column (reference Config.py:81-111)."""
+
+        def __init__(self, embedding_dim, name, num_embedding, affected_layer_group_indices=-1):
+            self.embedding_dim = embedding_dim
+            self.name = name
+            self.num_embedding = num_embedding
+            if affected_layer_group_indices is None \
+                    or isinstance(affected_layer_group_indices, (tuple, list, set)):
+                self.affected_layer_group_indices = affected_layer_group_indices
+            else:
+                self.affected_layer_group_indices = (affected_layer_group_indices,)
+
+        def __repr__(self):
+            return "{}: {} inputs, {} embedding dim, affected groups: ({})".format(
+                self.name, self.num_embedding, self.embedding_dim,
+                ", ".join(str(i) for i in self.affected_layer_group_indices))
+
     def __init__(self, config_str: str = None, in_dim: int = 0, hparams=None,
                  batch_first: bool = True, layer_configs: List["Config.LayerConfig"] = None,
                  emb_configs=None):
@@ -49,8 +69,6 @@ class Config:
         self.batch_first = batch_first
         self.layer_configs = layer_configs
         self.emb_configs = emb_configs
-        if emb_configs:
-            raise NotImplementedError("Embedding groups are outside the accelerated path.")
 
     def create_model(self):
         from .RNNDyn import RNNDyn

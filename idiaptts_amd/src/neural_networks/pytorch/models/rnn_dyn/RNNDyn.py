@@ -115,9 +115,15 @@ class RNNDyn(nn.ModuleList):
         super().__init__()
         self.config = copy.deepcopy(config)
         self.emb_groups = nn.ModuleDict()      # slot 0 of the ModuleList, like the reference
+        for emb_config in config.emb_configs or ():
+            emb = nn.Embedding(emb_config.num_embedding, emb_config.embedding_dim)
+            emb.affected_layer_group_indices = emb_config.affected_layer_group_indices
+            emb.name = emb_config.name
+            self.emb_groups[emb_config.name] = emb
         self.layer_groups = []
         in_dim = config.in_dim
-        for layer_config in config.layer_configs:
+        for group_idx, layer_config in enumerate(config.layer_configs):
+            in_dim += self._get_embeddings_dim(group_idx)
             if layer_config.needs_packing:
                 layer = RNNWrapper(in_dim, layer_config, config.batch_first, enforce_sorted=False)
             elif layer_config.needs_transposing:
@@ -130,13 +136,51 @@ class RNNDyn(nn.ModuleList):
             self.layer_groups.append(layer)
 
     def forward(self, input_, *emb_inputs, **kwargs):
+        """reference :88-121.  Embedding indices come as extra arguments (one [T, B, 1] tensor
+        per embedding group) or -- deprecated in the reference, but what its wrappers do -- as the
+        last columns of the input."""
+        embeddings = {}
+        if len(self.emb_groups) > 0:
+            n = len(self.emb_groups)
+            if len(emb_inputs) > 0:
+                if len(emb_inputs) != n:
+                    raise ValueError("Given number of embedding inputs ({}) does not match number "
+                                     "of embedding groups ({}) in model.".format(len(emb_inputs), n))
+            else:
+                emb_inputs = [input_[:, :, input_.shape[2] - n + i:input_.shape[2] - n + i + 1]
+                              for i in range(n)]
+                input_ = input_[:, :, :-n]
+            for idx, emb in enumerate(self.emb_groups.values()):
+                embeddings[emb.name] = emb(emb_inputs[idx][:, :, 0].long())
         last_hidden = None
-        for module in self.layer_groups:
+        for group_idx, module in enumerate(self.layer_groups):
+            for emb in self.emb_groups.values():
+                if self._affects(emb, group_idx):
+                    input_ = torch.cat((input_, embeddings[emb.name]), dim=2)
             input_, kwargs = module(input_, **kwargs)
             # hidden states are not passed from one RNN group to the next (reference :118-121)
             last_hidden = kwargs.pop("hidden", last_hidden)
         kwargs["hidden"] = last_hidden
         return input_, kwargs
+
+    @staticmethod
+    def _affects(emb, group_idx):
+        idx = emb.affected_layer_group_indices
+        return idx is not None and (-1 in idx or group_idx in idx)
+
+    def _get_embeddings_dim(self, group_idx):
+        return sum(emb.embedding_dim for emb in self.emb_groups.values()
+                   if self._affects(emb, group_idx))
+
+    def __getitem__(self, item):
+        """Zero-based indexing of the layer groups (reference :364-366)."""
+        return self.layer_groups[item]
+
+    def get_embeddings(self):
+        return self.emb_groups
+
+    def get_group_out_dim(self, group_idx):
+        return self.layer_groups[group_idx].out_dim
 
     def init_hidden(self, batch_size=1):
         for module in self.layer_groups:

@@ -355,6 +355,38 @@ def capture_duration_fixture():
           len(symbol_dict), "symbols")
 
 
+def capture_embedding_model():
+    """reference RNNDyn with an embedding group (rnn_dyn/RNNDyn.py:39-49, 88-134): index in the
+    last input column, embedding concatenated in front of groups 0 and 2 -> model_embedding.npz"""
+    import torch
+    from idiaptts.src.neural_networks.pytorch.models.rnn_dyn.Config import Config
+    torch.manual_seed(9)
+    cfg = Config(in_dim=6, batch_first=False, layer_configs=[
+        Config.LayerConfig(layer_type="Linear", out_dim=8, num_layers=1, nonlin="tanh"),
+        Config.LayerConfig(layer_type="GRU", out_dim=16, num_layers=1, bidirectional=True),
+        Config.LayerConfig(layer_type="Linear", out_dim=4, num_layers=1)],
+        emb_configs=[Config.EmbeddingConfig(embedding_dim=3, name="emb_speaker", num_embedding=4,
+                                            affected_layer_group_indices=(0, 2))])
+    model = cfg.create_model()
+    lens = torch.tensor([7, 3, 5])
+    x = torch.randn(7, 3, 6)
+    idx = torch.tensor([2.0, 0.0, 3.0]).view(1, 3, 1).expand(7, 3, 1)
+    w = torch.randn(7, 3, 4)
+    for b, l in enumerate(lens):
+        w[l:, b] = 0
+    model.init_hidden(3)
+    out, _ = model(torch.cat((x, idx), dim=2), seq_lengths_input=lens, max_length_inputs=7)
+    (out * w).sum().backward()
+    res = {"x": x.numpy(), "idx": idx.contiguous().numpy(), "w": w.numpy(), "len": lens.numpy(),
+           "out": out.detach().numpy()}
+    for k, v in model.state_dict().items():
+        res["sd_" + k] = v.numpy()
+    for k, p_ in model.named_parameters():
+        res["grad_" + k] = p_.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "model_embedding.npz"), **res)
+    print("model_embedding.npz:", sorted(res))
+
+
 def npz_reader_cases(tmp):
     """Writes the seeded archives + parameter files of the NpzDataReader cases below `tmp` and
     returns {case: Config kwargs}; shared by the capture (reference reader) and the test (ours)."""
@@ -441,6 +473,9 @@ def _main():
         return
     if "--npz-reader" in sys.argv:
         capture_npz_reader()
+        return
+    if "--embedding" in sys.argv:
+        capture_embedding_model()
         return
     capture_host_logic()
     capture_benchmark_kat()

@@ -141,3 +141,38 @@ def test_benchmark_known_answer_end_to_end(gpu, golden_dir):
     scores = Metrics.get_metrics(org, out)
     np.testing.assert_almost_equal((8.616, 78.4, 0.609, 37.352), scores, 3)
     assert np.allclose(scores, g["scores"], rtol=1e-5)
+
+
+def test_embedding_group_matches_reference(gpu, golden_dir):
+    """RNNDyn with an embedding group (rnn_dyn/RNNDyn.py:39-49, 88-134): the index rides in the
+    last input column, its vector is concatenated in front of groups 0 and 2.  Output and all
+    gradients against the reference's own module (tests/golden/make_golden.py --embedding)."""
+    from idiaptts_amd.src.neural_networks.pytorch.models.rnn_dyn.Config import Config
+    g = np.load(os.path.join(golden_dir, "model_embedding.npz"))
+    cfg = Config(in_dim=6, batch_first=False, layer_configs=[
+        Config.LayerConfig(layer_type="Linear", out_dim=8, num_layers=1, nonlin="tanh"),
+        Config.LayerConfig(layer_type="GRU", out_dim=16, num_layers=1, bidirectional=True),
+        Config.LayerConfig(layer_type="Linear", out_dim=4, num_layers=1)],
+        emb_configs=[Config.EmbeddingConfig(embedding_dim=3, name="emb_speaker", num_embedding=4,
+                                            affected_layer_group_indices=(0, 2))])
+    model = cfg.create_model()
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    assert set(sd) == set(model.state_dict())
+    model.load_state_dict(sd)
+    model.to(gpu)
+    assert model.get_group_out_dim(1) == 32 and model[0].out_dim == 8
+    x = torch.from_numpy(np.concatenate([g["x"], g["idx"]], axis=2)).to(gpu)
+    lens = torch.from_numpy(g["len"])
+    model.init_hidden(3)
+    out, _ = model(x, seq_lengths_input=lens, max_length_inputs=7)
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 2e-6
+    (out * torch.from_numpy(g["w"]).to(gpu)).sum().backward()
+    for name, p in model.named_parameters():
+        ref = g["grad_" + name]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), name
+    # the same through explicit embedding inputs
+    model.zero_grad()
+    model.init_hidden(3)
+    out2, _ = model(torch.from_numpy(g["x"]).to(gpu), torch.from_numpy(g["idx"]).to(gpu),
+                    seq_lengths_input=lens, max_length_inputs=7)
+    assert torch.equal(out2, out)
