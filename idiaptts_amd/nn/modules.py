@@ -22,6 +22,31 @@ class LinearAct(nn.Linear):
         return LinearActFunction.apply(input_, self.weight, self.bias, self.act)
 
 
+def _pad_hidden(w_ih, w_hh, biases, h0s, G, H):
+    """The recurrence kernels tile the hidden units in groups of 16.  Any other hidden size runs
+    zero-padded to the next multiple: a padded unit has zero weights and biases, so its gates sit
+    at sigma(0) / tanh(0), its state stays exactly 0 and -- its W_hh columns being zero -- it never
+    reaches a real unit.  Differentiable torch ops: autograd slices the gradients back.
+    w_ih [ndir, G*H, F], w_hh [ndir, G*H, H], biases [ndir, G*H] each, h0s [ndir, H] or None."""
+    Hp = (H + 15) // 16 * 16
+    if Hp == H:
+        return w_ih, w_hh, biases, h0s, H
+    ndir, _, F = w_ih.shape
+    pad = torch.nn.functional.pad
+    w_ih = pad(w_ih.reshape(ndir, G, H, F), (0, 0, 0, Hp - H)).reshape(ndir, G * Hp, F)
+    w_hh = pad(w_hh.reshape(ndir, G, H, H), (0, Hp - H, 0, Hp - H)).reshape(ndir, G * Hp, Hp)
+    biases = [pad(b.reshape(ndir, G, H), (0, Hp - H)).reshape(ndir, G * Hp) for b in biases]
+    h0s = [pad(h, (0, Hp - H)) if h is not None else None for h in h0s]
+    return w_ih, w_hh, biases, h0s, Hp
+
+
+def _unpad_rows(x, ndir, H, Hp):
+    """[N, ndir*Hp] -> [N, ndir*H]"""
+    if Hp == H:
+        return x
+    return x.reshape(x.shape[0], ndir, Hp)[:, :, :H].reshape(x.shape[0], ndir * H)
+
+
 class LSTM(nn.Module):
     """Drop-in for torch.nn.LSTM(input_size, hidden_size, num_layers, bidirectional, batch_first)
     as RNNWrapper uses it (rnn_dyn/RNNWrapper.py:45-54).  forward takes the padded tensor and
@@ -74,10 +99,13 @@ class LSTM(nn.Module):
                 # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0
                 hl = h0[layer * ndir:(layer + 1) * ndir, 0, :]
                 cl = c0[layer * ndir:(layer + 1) * ndir, 0, :]
-            x, hn, cn = LSTMLayerFunction.apply(
-                x, pb, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
-                self._stack("bias_ih", layer), self._stack("bias_hh", layer), hl, cl,
-                torch.is_grad_enabled())
+            H = self.hidden_size
+            w_ih, w_hh, (b_ih, b_hh), (hl, cl), Hp = _pad_hidden(
+                self._stack("weight_ih", layer), self._stack("weight_hh", layer),
+                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl, cl], 4, H)
+            x, hn, cn = LSTMLayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl, cl,
+                                                torch.is_grad_enabled())
+            x, hn, cn = _unpad_rows(x, ndir, H, Hp), hn[:, :, :H], cn[:, :, :H]
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = torch.nn.functional.dropout(x, self.dropout, True)
             hn_all.append(hn.index_select(1, pb.inv_perm))      # back to the caller's row order
@@ -129,10 +157,13 @@ class GRU(nn.Module):
         for layer in range(self.num_layers):
             # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0
             hl = hx[layer * ndir:(layer + 1) * ndir, 0, :] if hx is not None else None
-            x, hn = GRULayerFunction.apply(
-                x, pb, self._stack("weight_ih", layer), self._stack("weight_hh", layer),
-                self._stack("bias_ih", layer), self._stack("bias_hh", layer), hl,
-                torch.is_grad_enabled())
+            H = self.hidden_size
+            w_ih, w_hh, (b_ih, b_hh), (hl,), Hp = _pad_hidden(
+                self._stack("weight_ih", layer), self._stack("weight_hh", layer),
+                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl], 3, H)
+            x, hn = GRULayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl,
+                                           torch.is_grad_enabled())
+            x, hn = _unpad_rows(x, ndir, H, Hp), hn[:, :, :H]
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = torch.nn.functional.dropout(x, self.dropout, True)
             hn_all.append(hn.index_select(1, pb.inv_perm))

@@ -119,3 +119,33 @@ def test_trainable_initial_states_match_torch(gpu, cell):
     for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.module.named_parameters()):
         err = (pm.grad.cpu().double() - pr.grad).abs().max().item()
         assert err < 1e-4 * max(1.0, pr.grad.abs().max().item()), (n, err)
+
+
+@pytest.mark.parametrize("cell,H", [("LSTM", 5), ("GRU", 20), ("LSTM", 100)])
+def test_hidden_sizes_that_are_not_multiples_of_16(gpu, cell, H):
+    """Any hidden size works (the kernels tile 16 units; other sizes run zero-padded, which is
+    exact): output, final states and gradients against torch CPU float64."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from idiaptts_amd import nn as inn
+    torch.manual_seed(2)
+    in_dim, B, T = 9, 4, 10
+    lengths = torch.tensor([10, 3, 7, 10])
+    mine = getattr(inn, cell)(in_dim, H, 2, bidirectional=True).to(gpu)
+    ref = getattr(torch.nn, cell)(in_dim, H, 2, bidirectional=True).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in mine.state_dict().items()})
+    x = torch.randn(T, B, in_dim)
+    w = torch.randn(T, B, 2 * H)
+    out_ref, hn_ref = ref(pack_padded_sequence(x.double(), lengths, enforce_sorted=False))
+    out_ref, _ = pad_packed_sequence(out_ref, total_length=T)
+    (out_ref * w.double()).sum().backward()
+    out, hn = mine(x.to(gpu), None, lengths)
+    (out * w.to(gpu)).sum().backward()
+    assert out.shape == (T, B, 2 * H)
+    assert (out.detach().cpu().double() - out_ref.detach()).abs().max() < 2e-5
+    h_mine = hn[0] if cell == "LSTM" else hn
+    h_ref = hn_ref[0] if cell == "LSTM" else hn_ref
+    assert (h_mine.detach().cpu().double() - h_ref.detach()).abs().max() < 2e-5
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert pm.grad.shape == pr.grad.shape
+        err = (pm.grad.cpu().double() - pr.grad).abs().max().item()
+        assert err < 1e-4 * max(1.0, pr.grad.abs().max().item()), (n, err)
