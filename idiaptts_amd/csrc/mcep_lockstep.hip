@@ -272,6 +272,39 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
 //   * rows above the pivot are eliminated too (Gauss-Jordan), so no U factor is stored and no
 //     back substitution runs: lane r keeps its pivot d_r and ends with x_r = b_r / d_r.
 // 61 FMAs per step and lane, 60 steps; measured 29 ns per solve chip-wide (was 200 ns).
+// Pivot steps 8 S .. 8 S + 7 of the barrier-free Gauss-Jordan elimination below.  The rows are kept
+// shifted (row[0] is always the current column), so after c steps only their first W - c entries
+// can be non-zero -- zeros are shifted in from the right, and the pivot row is zero beyond the
+// matrix.  A segment therefore updates W - 8 S entries (compile-time width: static register
+// indices), about half of the full-width work over the whole elimination; the dropped operations
+// are 0 - f * 0.  The segments follow each other as straight-line code (template recursion).
+template <int W, int S>
+__device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double& d, double* P,
+                                            int lane, int m1) {
+  if constexpr (8 * S < W) {
+    constexpr int WW = W - 8 * S;
+#pragma unroll 1
+    for (int c = 8 * S; c < 8 * S + 8 && c < m1; ++c) {
+      P[lane] = row[0];
+      __builtin_amdgcn_wave_barrier();
+      const double pc = P[c];                                            // pivot A[c][c]
+      const double bc = __shfl(b, c);
+      const bool is_piv = lane == c;
+      if (is_piv) d = pc;
+      const double f = is_piv ? 0.0 : row[0] * (1.0 / pc);   // 1/pc is wave-uniform: one division per step
+      // uniform-address LDS reads: this is what bounds the kernel (a broadcast read still delivers
+      // 16 bytes to each of the 64 lanes)
+      const double* p = P + c;
+#pragma unroll
+      for (int j = 1; j < WW; ++j) row[j - 1] = row[j] - f * p[j];
+      row[WW - 1] = 0.0;
+      b -= f * bc;
+      __builtin_amdgcn_wave_barrier();
+    }
+    ls_segments<W, S + 1>(row, b, d, P, lane, m1);
+  }
+}
+
 template <int W>   // W >= m + 1: register row length (20, 24, 32, 48, 60 or 64)
 __global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
   __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
@@ -318,24 +351,7 @@ __global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
   }
   double b = rowok ? cr[r] - pow(-a.alpha, (double)r) : 0.0;
   double d = 1.0;
-#pragma unroll 1
-  for (int c = 0; c < m1; ++c) {
-    P[lane] = row[0];
-    __builtin_amdgcn_wave_barrier();
-    const double pc = P[c];                                            // pivot A[c][c]
-    const double bc = __shfl(b, c);
-    const bool is_piv = lane == c;
-    if (is_piv) d = pc;
-    const double f = is_piv ? 0.0 : row[0] * (1.0 / pc);   // 1/pc is wave-uniform: one division per step
-    // 61 uniform-address LDS reads per step and lane: this is what bounds the kernel (a broadcast
-    // read still delivers 16 bytes to each of the 64 lanes: ~30 KB of LDS traffic per step and wave)
-    const double* p = P + c;
-#pragma unroll
-    for (int j = 1; j < W; ++j) row[j - 1] = row[j] - f * p[j];
-    row[W - 1] = 0.0;
-    b -= f * bc;
-    __builtin_amdgcn_wave_barrier();
-  }
+  ls_segments<W, 0>(row, b, d, P, lane, m1);
   if (rowok) a.mc[g * m1 + r] += b / d;
   if (lane == 0 && a.iter == a.itr2) {
     a.done[g] = 1;
