@@ -30,7 +30,7 @@ o = ["# Round 1 ({}): {}\n".format(tag, title),
      "| FF 425-512-512-187 train step, 32 utterances / step | %.3f ms -> %.1f M valid frames/s |" % (d["ms_per_step"], d["value"] / 1e6),
      "| fp32-MFMA GEMMs of one step (8 launches, events on the launch stream, live in bench.py) | %.3f ms, avg %.1f us per launch, %.1f TFLOP/s = %.1f %% of 157.3 |" % (rf["gemm_ms_per_step"], rf["avg_launch_us"], rf["achieved"], 100 * rf["frac"]),
      "| the same launches in `rocprofv3 --kernel-trace --stats` (`%s_ff_kernel_stats.csv`: `python3 bench.py --world-utts 0 --bilstm-utts 0 --no-cpu-baseline`) | %d GEMM launches, avg %.1f us (kernel time only; the live figure includes the gaps between the launches) |" % (tag, gc, gt / gc / 1e3),
-     "| HBM bytes per GEMM launch (PMC, `r1g_gemm_traffic.json`, `r1g_pmc_*.csv`) | %.0f MB |" % (rf["traffic"] / 1e6),
+     "| HBM bytes per GEMM launch (PMC, `r1h_gemm_traffic.json`, `r1h_pmc_*.csv`) | %.0f MB |" % (rf["traffic"] / 1e6),
      "| CPU baseline (torch reference stack, %d threads) | %.0f valid frames/s |" % (d["cpu_baseline"]["cores"], d["cpu_baseline"]["value"]),
      "| WORLD analysis, %d utterances = %.0f s of 16 kHz audio | %.2f ms, RTF %.2e (C oracle, 1 core: %.3f) |" % (w["utterances"], w["audio_seconds"], w["analysis_ms"], w["analysis_rtf"], w["cpu_baseline"]["analysis_rtf"]),
      "| WORLD synthesis, same batch | %.2f ms, RTF %.2e (C oracle: %.3f) |" % (w["synthesis_ms"], w["synthesis_rtf"], w["cpu_baseline"]["synthesis_rtf"]),
