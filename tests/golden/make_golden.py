@@ -477,6 +477,9 @@ def _main():
     if "--embedding" in sys.argv:
         capture_embedding_model()
         return
+    if "--config3" in sys.argv:
+        capture_config3_step()
+        return
     capture_host_logic()
     capture_benchmark_kat()
     capture_reference_model_forward()
@@ -547,6 +550,60 @@ def capture_reference_model_forward():
         out["b_grad_" + k] = p.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "model_forward.npz"), **out)
     print("model_forward.npz:", len(out), "arrays")
+
+
+def capture_config3_step():
+    """One training step of the reference's own module stack at the BASELINE config-3 size
+    (RNNDYN-3_BiLSTM_512-1_FC_187, 425 -> 187, B = 33 ragged rows, torch CPU fp32): forward,
+    NamedLoss(MSELoss x mask, mean per frame), backward, torch.optim.Adam(lr 1e-3) step -- the
+    calls of ModularModelHandlerPyTorch.py:745-831.  Weights / batch are regenerated from seeds
+    (tests/config3_data.py); stored: prediction of two rows, loss, per-parameter gradient norm,
+    sum and sampled entries, sampled parameters after the step."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import config3_data as c3
+    from idiaptts.src.neural_networks.pytorch.models import rnn_dyn
+    from idiaptts.src.neural_networks.pytorch.models.NamedForwardWrapper import NamedForwardWrapper
+    from idiaptts.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss
+    from idiaptts.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    torch.set_num_threads(8)
+    hp = types.SimpleNamespace(model_type=c3.MODEL_TYPE, batch_first=False, dropout=0.0)
+    cfg = NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((c3.IN_DIM,), hp),
+                                     input_names=["questions"], batch_first=False, name="AM",
+                                     output_names=["pred_acoustic_features"])
+    model = cfg.create_model()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in c3.state(shapes).items()})
+    x, y, lens = c3.batch()
+    lens_t = torch.from_numpy(lens)
+    T, B = x.shape[:2]
+    data = {"questions": torch.from_numpy(x), "acoustic_features": torch.from_numpy(y),
+            "acoustic_features_mask": Handler.sequence_mask(lens_t, T, batch_first=False)}
+    lengths = {"questions": lens_t, "acoustic_features": lens_t, "acoustic_features_mask": lens_t}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model.init_hidden(B)
+    model(data, lengths, {"questions": T})
+    loss_mod = NamedLoss.Config(name="MSELoss_acoustic_features", type_="MSELoss",
+                                seq_mask="acoustic_features_mask",
+                                input_names=["acoustic_features", "pred_acoustic_features"],
+                                batch_first=False).create_loss()
+    loss = list(loss_mod(data, lengths, step=1).values())[0]
+    loss.backward()
+    out = {"loss": loss.detach().numpy(), "lens": lens,
+           "pred_rows": data["pred_acoustic_features"].detach().numpy()[:, [0, B - 1]],
+           "keys": np.array(sorted(shapes))}
+    for k, p in model.named_parameters():
+        g = p.grad.numpy().reshape(-1)
+        idx = c3.sample_index(k, g.size)
+        out["gnorm_" + k] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["gsum_" + k] = np.array(g.astype(np.float64).sum())
+        out["gsamp_" + k] = g[idx]
+    opt.step()
+    for k, p in model.named_parameters():
+        out["psamp_" + k] = p.detach().numpy().reshape(-1)[c3.sample_index(k, p.numel())]
+    np.savez_compressed(os.path.join(HERE, "config3_step.npz"), **out)
+    print("config3_step.npz: loss", float(loss), "params", sum(int(np.prod(s)) for s in shapes.values()))
 
 
 if __name__ == "__main__":
