@@ -312,6 +312,28 @@ def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
                                "epoch_ms": dt * 1e3, "valid_frames_per_s": n / dt}}
 
 
+def spawn_ranks(args):
+    """Launches `torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child
+    process and returns its exit code (rank 0 of the child job prints the JSON line).  Nothing
+    here initialises HIP: torch.cuda.device_count() only counts devices on this image."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if n_dev < args.gpus and not (args.share_gpu or env.get("ITTS_BENCH_SHARE_GPU") == "1"):
+        print("bench.py: --gpus {} but only {} device(s) visible (use --share-gpu for a functional "
+              "check of the N > 1 path on one device)".format(args.gpus, n_dev), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,15 +344,24 @@ def main():
     ap.add_argument("--world-utts", type=int, default=256,
                     help="utterances in the WORLD feature-path section (0 = skip)")
     ap.add_argument("--world-fs", type=int, default=16000)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional check only: all ranks on device 0, collectives over gloo "
+                         "(never a measurement; the JSON line says so)")
     ap.add_argument("--bilstm-utts", type=int, default=64,
                     help="utterances per GPU of the BiLSTM / BiGRU (config 3) section (0 = skip)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, before this process
+        # makes any HIP call (a process that touched the GPU must never be replaced or forked)
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node {}".format(args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    if args.share_gpu:
+        os.environ["ITTS_BENCH_SHARE_GPU"] = "1"
 
     from idiaptts_amd import lib
     lib.require_gpu()
@@ -472,6 +503,9 @@ def main():
                        "utts_per_gpu": args.utts_per_gpu, "parallelism": "dp{}".format(world)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if share_gpu:
+            out["shared_gpu"] = ("functional check only: {} ranks on ONE device, collectives over "
+                                 "gloo -- not a measurement".format(world))
         out.update(extra)
         print(json.dumps(out))
     if world > 1:

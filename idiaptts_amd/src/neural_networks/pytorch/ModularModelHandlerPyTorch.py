@@ -936,7 +936,9 @@ class ModularModelHandlerPyTorch(object):
                 self.optimiser.zero_grad()
                 total.backward()
                 if dp_weight is not None:
-                    parallel.allreduce_module_grads_(list(self.model.parameters()), dp_weight)
+                    flat_sync = getattr(self.optimiser, "allreduce_grads_", None)
+                    if flat_sync is None or not flat_sync(dp_weight):
+                        parallel.allreduce_module_grads_(list(self.model.parameters()), dp_weight)
                 if grad_clip_norm is not None:
                     torch.nn.utils.clip_grad_norm_(self.model.parameters(), grad_clip_norm)
                 self.optimiser.step()
