@@ -32,6 +32,13 @@ _SIGNATURES = {
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),
     "itts_gradient_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, POINTER(c_int64), c_int, _P]),
+    "itts_lf0_vuv": (c_int, [_P, POINTER(c_int64), c_int, c_double, c_float, _P, _P, _P]),
+    "itts_interpolate_lin_f32": (c_int, [_P, POINTER(c_int64), c_int, _P, _P, _P]),
+    "itts_assemble_cmp_f32": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int64, c_int,
+                                      POINTER(c_int64), c_int, c_int, _P, c_int64, _P]),
+    "itts_feature_stats_workspace_bytes": (c_int64, [c_int, c_int]),
+    "itts_feature_stats": (c_int, [_P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P,
+                                   _P]),
     "itts_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int,
                                 _P]),
     "itts_act_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

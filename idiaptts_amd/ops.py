@@ -73,6 +73,69 @@ def gradient_f32(x, offsets, out=None):
     return out
 
 
+def lf0_vuv(f0, offsets, f0_silence_threshold=30.0, lf0_zero=0.0):
+    """f0 [Ttot] f64 -> (lf0 [Ttot] f32 interpolated, vuv [Ttot] f32): WorldFeatLabelGen.py:798-802
+    (float32 log, threshold, interpolate_lin) per utterance."""
+    L = _lib.load()
+    _need(f0, torch.float64, "f0")
+    f0 = f0.contiguous()
+    lf0 = torch.empty(f0.shape[0], dtype=torch.float32, device=f0.device)
+    vuv = torch.empty_like(lf0)
+    _lib.check(L.itts_lf0_vuv(_ptr(f0), _lib.offsets_array(offsets), len(offsets) - 1,
+                              float(f0_silence_threshold), float(lf0_zero), _ptr(lf0), _ptr(vuv),
+                              _stream()), "itts_lf0_vuv")
+    return lf0, vuv
+
+
+def interpolate_lin_f32(x, offsets):
+    """interpolate_lin (misc/utils.py:40-86) on float32 contours stored back to back:
+    (interpolated [Ttot], vuv [Ttot])."""
+    L = _lib.load()
+    _need(x, torch.float32, "x")
+    x = x.contiguous()
+    ip = torch.empty_like(x)
+    vuv = torch.empty_like(x)
+    _lib.check(L.itts_interpolate_lin_f32(_ptr(x), _lib.offsets_array(offsets), len(offsets) - 1,
+                                          _ptr(ip), _ptr(vuv), _stream()),
+               "itts_interpolate_lin_f32")
+    return ip, vuv
+
+
+def assemble_cmp(sp, lf0, vuv, bap, offsets, add_deltas=True, out=None):
+    """[sp, d, dd | lf0, d, dd | vuv | bap, d, dd] (or the static layout) per frame, float32
+    (save_output WorldFeatLabelGen.py:1121-1172 + compute_deltas misc/utils.py:103-105)."""
+    L = _lib.load()
+    for t, n in ((sp, "sp"), (lf0, "lf0"), (vuv, "vuv"), (bap, "bap")):
+        _need(t, torch.float32, n)
+    n_sp, n_bap = sp.shape[1], bap.shape[1]
+    width = (3 if add_deltas else 1) * (n_sp + 1 + n_bap) + 1
+    if out is None:
+        out = torch.empty((sp.shape[0], width), dtype=torch.float32, device=sp.device)
+    _lib.check(L.itts_assemble_cmp_f32(_ptr(sp), _rows(sp, "sp"), n_sp, _ptr(lf0.contiguous()),
+                                       _ptr(vuv.contiguous()), _ptr(bap), _rows(bap, "bap"), n_bap,
+                                       _lib.offsets_array(offsets), len(offsets) - 1,
+                                       1 if add_deltas else 0, _ptr(out), _rows(out, "out"),
+                                       _stream()), "itts_assemble_cmp_f32")
+    return out
+
+
+def feature_stats(x, col0, width, want_cov, sums=None, second=None):
+    """sum x [width] and sum x x^T [width, width] (want_cov) or sum x^2 [width] over the rows of
+    x[:, col0:col0+width] in fp64; adds to `sums` / `second` when given."""
+    L = _lib.load()
+    _need(x, torch.float32, "x")
+    accumulate = sums is not None
+    if sums is None:
+        sums = torch.empty(width, dtype=torch.float64, device=x.device)
+        second = torch.empty((width, width) if want_cov else (width,), dtype=torch.float64,
+                             device=x.device)
+    ws = _workspace(L.itts_feature_stats_workspace_bytes(width, 1 if want_cov else 0), x.device)
+    _lib.check(L.itts_feature_stats(_ptr(x), _rows(x, "x"), x.shape[0], col0, width,
+                                    1 if want_cov else 0, 1 if accumulate else 0, _ptr(sums),
+                                    _ptr(second), _ptr(ws), _stream()), "itts_feature_stats")
+    return sums, second
+
+
 # ------------------------------------------------------------------------------ dense layers
 def linear_fwd(x, w, b, act=ACT_NONE, out=None):
     L = _lib.load()
@@ -118,7 +181,9 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch of the current (device, stream): two streams never share a workspace."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

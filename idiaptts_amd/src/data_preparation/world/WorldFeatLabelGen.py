@@ -237,14 +237,17 @@ class WorldFeatLabelGen(ReaderBase):
             lf0_zero = WorldFeatLabelGen.lf0_zero
         if mgc_alpha is None:
             mgc_alpha = AudioProcessing.fs_to_mgc_alpha(fs)
-        res = _world.analyse_batch(raws, fs, hop_size_ms, n_fft, want_sp=False,
-                                   mcep_order=num_coded_sps - 1, mcep_alpha=mgc_alpha,
-                                   want_bap=True)
+        cmp_dev, f_off = _world.extract_cmp_batch(raws, fs, hop_size_ms, n_fft, num_coded_sps - 1,
+                                                  mgc_alpha, f0_silence_threshold, lf0_zero,
+                                                  add_deltas=False)
+        cmp_host = cmp_dev.cpu().numpy()
         out = []
-        for r in res:
-            lf0, vuv = _world.lf0_vuv_from_f0(r["f0"], f0_silence_threshold, lf0_zero)
-            assert len(r["mcep"]) == len(lf0), "Requires testing. Possibly trimming is a solution."
-            out.append(tuple(WorldFeatLabelGen.trim_to_shortest([r["mcep"], lf0, vuv, r["bap"]])))
+        for u in range(len(raws)):
+            c = cmp_host[f_off[u]:f_off[u + 1]]
+            out.append((np.ascontiguousarray(c[:, :num_coded_sps]),
+                        np.ascontiguousarray(c[:, num_coded_sps:num_coded_sps + 1]),
+                        np.ascontiguousarray(c[:, num_coded_sps + 1:num_coded_sps + 2]),
+                        np.ascontiguousarray(c[:, num_coded_sps + 2:])))
         return out
 
     @staticmethod
@@ -381,6 +384,89 @@ class WorldFeatLabelGen(ReaderBase):
             output.append(feature)
         return output
 
+    # stream layout of the feature matrix the device assembles (itts_assemble_cmp_f32)
+    def _cmp_columns(self, num_bap=None):
+        f = 3 if self.add_deltas else 1
+        ncs, nb = self.num_coded_sps, self.num_bap if num_bap is None else num_bap
+        return {"sp": (0, f * ncs), "lf0": (f * ncs, f), "vuv": (f * (ncs + 1), 1),
+                "bap": (f * (ncs + 1) + 1, f * nb)}
+
+    def _write_utterance(self, dir_out, name, cmp_u, cols):
+        """The files save_output writes for one utterance (:1121-1172), from its feature matrix."""
+        for (load, feature_dir, ext, _), key in zip(self._streams(), ("sp", "lf0", "vuv", "bap")):
+            if not load:
+                continue
+            c0, w = cols[key]
+            path = os.path.join(dir_out, feature_dir, name)
+            if self.add_deltas and key != "vuv":
+                k = w // 3
+                _save_to_npz(path, [np.ascontiguousarray(cmp_u[:, c0 + i * k:c0 + (i + 1) * k])
+                                    for i in range(3)],
+                             [ext, ext + "_deltas", ext + "_double_deltas"])
+            else:
+                _save_to_npz(path, np.ascontiguousarray(cmp_u[:, c0:c0 + w]), ext)
+
+    def _gen_data_pipeline(self, dir_in, dir_out, file_ext, id_list, label_dict):
+        """The hot loop of gen_data (reference :996-1013, one utterance at a time on one core):
+        reader threads decode and pre-emphasise the next batches, the device turns a batch of
+        waveforms into the finished feature matrix (analysis, lf0 interpolation, deltas, stream
+        layout) and adds it to the normalisation sums, ONE device -> host copy per batch, writer
+        threads store the per-utterance archives while the next batch is analysed."""
+        import concurrent.futures as cf
+        import torch
+        loaded = [k for k, load in zip(("sp", "lf0", "vuv", "bap"), self.load_flags) if load]
+        cols = stats = None
+        batches = [id_list[b0:b0 + self.batch_utts] for b0 in range(0, len(id_list), self.batch_utts)]
+
+        def read(names):
+            raws, fss = [], []
+            for n in names:
+                raw, fs = AudioProcessing.get_raw(os.path.join(dir_in, n + "." + file_ext),
+                                                  self.preemphasis)
+                raws.append(raw)
+                fss.append(fs)
+            return raws, fss
+
+        n_io = max(2, min(8, (os.cpu_count() or 2) // 2))
+        with cf.ThreadPoolExecutor(n_io) as readers, cf.ThreadPoolExecutor(n_io) as writers:
+            pending_reads = [readers.submit(read, names) for names in batches[:2]]
+            writes = []
+            for bi, names in enumerate(batches):
+                raws, fss = pending_reads[bi].result()
+                if bi + 2 < len(batches):
+                    pending_reads.append(readers.submit(read, batches[bi + 2]))
+                assert len(set(fss)) == 1, "All files of a batch need the same sampling rate."
+                fs = fss[0]
+                if cols is None:      # WORLD fixes the number of bap bands by the sampling rate
+                    cols = self._cmp_columns(AudioProcessing.fs_to_num_bap(fs))
+                    stats = _world.StreamStats({k: cols[k] for k in loaded if k != "vuv"},
+                                               self.add_deltas)
+                alpha = self.mgc_alpha if self.mgc_alpha is not None \
+                    else AudioProcessing.fs_to_mgc_alpha(fs)
+                cmp_dev, f_off = _world.extract_cmp_batch(
+                    raws, fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1, alpha,
+                    WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
+                    self.add_deltas)
+                stats.add(cmp_dev)
+                host = torch.empty(cmp_dev.shape, dtype=torch.float32, pin_memory=True)
+                host.copy_(cmp_dev, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                cmp_host = host.numpy()
+                for u, n in enumerate(names):
+                    cmp_u = cmp_host[f_off[u]:f_off[u + 1]]
+                    if dir_out is not None:
+                        writes.append(writers.submit(self._write_utterance, dir_out,
+                                                     os.path.basename(n), cmp_u, cols))
+                    if label_dict is not None:
+                        label_dict[n] = np.concatenate(
+                            [cmp_u[:, cols[k][0]:cols[k][0] + cols[k][1]] for k in loaded], axis=1) \
+                            if loaded else None
+            for w in writes:
+                w.result()          # re-raises a writer's exception
+        for (load, _, _, normaliser), key in zip(self._streams(), ("sp", "lf0", "vuv", "bap")):
+            if load and key != "vuv" and stats is not None:
+                stats.store(key, normaliser)
+
     def gen_data(self, dir_in, dir_out=None, file_id_list="", file_ext="wav", id_list=None,
                  return_dict=False):
         """Prepare acoustic features from audio files (reference :947-1071); utterances are
@@ -410,24 +496,10 @@ class WorldFeatLabelGen(ReaderBase):
         if world > 1:
             sizes = [os.path.getsize(os.path.join(dir_in, n + "." + file_ext)) for n in all_ids]
             id_list = [all_ids[i] for i in _parallel.shard_by_length(sizes, world)[rank]]
-        for b0 in range(0, len(id_list), self.batch_utts):
-            names = id_list[b0:b0 + self.batch_utts]
-            raws, fss = [], []
-            for n in names:
-                raw, fs = AudioProcessing.get_raw(os.path.join(dir_in, n + "." + file_ext),
-                                                  self.preemphasis)
-                raws.append(raw)
-                fss.append(fs)
-            assert len(set(fss)) == 1, "All files of a batch need the same sampling rate."
-            feats = WorldFeatLabelGen.extract_features_batch(
-                raws, fss[0], n_fft=self.n_fft, hop_size_ms=self.hop_size_ms, sp_type=self.sp_type,
-                num_coded_sps=self.num_coded_sps, mgc_alpha=self.mgc_alpha,
-                f0_silence_threshold=WorldFeatLabelGen.f0_silence_threshold,
-                lf0_zero=WorldFeatLabelGen.lf0_zero)
-            for n, f in zip(names, feats):
-                output = self.save_output(f, dir_out, n)
-                if return_dict:
-                    label_dict[n] = np.concatenate(output, axis=1) if len(output) > 0 else None
+        if self.sp_type != "mcep":
+            raise NotImplementedError("Only sp_type='mcep' is on the accelerated path.")
+        self._gen_data_pipeline(dir_in, dir_out, file_ext, id_list, label_dict if return_dict
+                                else None)
         if world > 1:
             import torch.distributed as dist
             dev = _dist_device()

@@ -5,14 +5,11 @@ synthesis: (f0, sp, ap) -> WORLD synthesis -> float32 (+ de-pre-emphasis)
 Utterances are concatenated and processed by single launches; only the small per-frame features
 (f0, mcep, bap) travel back to the host unless the spectral envelope is asked for.
 """
-import math
-
 import numpy as np
 import torch
 
 from . import lib as _lib
 from . import ops
-from .misc.utils import interpolate_lin
 
 
 def _device(device):
@@ -41,13 +38,14 @@ def offsets(lengths):
     return off
 
 
-def lf0_vuv_from_f0(f0, f0_silence_threshold=30, lf0_zero=0):
-    """WorldFeatLabelGen.world_extract_features :798-802 (host: float32 log, threshold,
-    interpolate_lin)."""
-    lf0 = np.log(f0.clip(min=1E-10), dtype=np.float32)
-    lf0[lf0 <= math.log(f0_silence_threshold)] = lf0_zero
-    lf0, vuv = interpolate_lin(lf0)
-    return lf0.astype(dtype=np.float32), vuv.astype(dtype=np.float32)
+def lf0_vuv_from_f0(f0, f0_silence_threshold=30, lf0_zero=0, device=None):
+    """WorldFeatLabelGen.world_extract_features :798-802 (float32 log, threshold,
+    interpolate_lin) for one contour: (lf0 [T, 1] f32, vuv [T, 1] f32)."""
+    dev = _device(device)
+    f0 = np.ascontiguousarray(f0, dtype=np.float64).reshape(-1)
+    lf0, vuv = ops.lf0_vuv(torch.from_numpy(f0).to(dev), [0, len(f0)], f0_silence_threshold,
+                           lf0_zero)
+    return lf0.cpu().numpy()[:, None], vuv.cpu().numpy()[:, None]
 
 
 def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
@@ -93,6 +91,72 @@ def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
                     "mcep": mc[a:b] if mc is not None else None,
                     "bap": bap[a:b] if bap is not None else None})
     return out
+
+
+class StreamStats(object):
+    """Normalisation sums of the continuous streams (coded sp, lf0, bap) of a feature matrix,
+    accumulated on the device over the batches of a gen_data run (fp64, fixed summation order):
+    what MeanCovarianceExtractor / MeanStdDevExtractor.add_sample gather utterance by utterance
+    (misc/normalisation/*.py).  `columns`: {stream name: (first column, width)}."""
+
+    def __init__(self, columns, want_cov):
+        self.columns = dict(columns)
+        self.want_cov = bool(want_cov)
+        self.count = 0
+        self.sums = {}
+
+    def add(self, cmp_dev):
+        for name, (c0, w) in self.columns.items():
+            if w == 0:
+                continue
+            acc = self.sums.get(name)
+            if acc is None:
+                self.sums[name] = ops.feature_stats(cmp_dev, c0, w, self.want_cov)
+            else:
+                ops.feature_stats(cmp_dev, c0, w, self.want_cov, sums=acc[0], second=acc[1])
+        self.count += int(cmp_dev.shape[0])
+
+    def store(self, name, extractor):
+        """Hands the sums of one stream to an extractor (adds to what it already holds)."""
+        if name not in self.sums:
+            return
+        first, second = (t.cpu().numpy() for t in self.sums[name])
+        extractor.sum_length += self.count
+        if self.want_cov:
+            extractor.sum_frames = extractor.sum_frames + first[None, :]
+            extractor.sum_product_frames = extractor.sum_product_frames + second
+        else:
+            extractor.sum_frames = extractor.sum_frames + first
+            extractor.sum_squared_frames = extractor.sum_squared_frames + second
+
+
+def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alpha=None,
+                      f0_silence_threshold=30, lf0_zero=0, add_deltas=True, device=None):
+    """wav(s) -> the `[T, 3*(ncs+1+nb)+1]` feature matrix of the reference's gen_data in one go,
+    everything on the device: DIO + StoneMask, D4C -> coded bap, CheapTrick -> mcep, lf0 / V-UV
+    with interpolate_lin, deltas and the stream layout (WorldFeatLabelGen.py:778-807, 809-889,
+    1121-1172).  Returns (cmp [Ttot, W] f32 on the device, frame offsets [U+1])."""
+    dev = _device(device)
+    L = _lib.load()
+    n_fft = n_fft or L.itts_cheaptrick_fft_size(int(fs), 71.0)
+    x_off = offsets([len(r) for r in raws])
+    f_off = offsets([num_frames(len(r), fs, hop_ms) for r in raws])
+    x = torch.from_numpy(np.ascontiguousarray(np.concatenate(raws), dtype=np.float64)).to(dev)
+    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_ap=False,
+                         want_bap=torch.float32)
+        lf0, vuv = ops.lf0_vuv(f0, f_off, f0_silence_threshold, lf0_zero)
+    _, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=False,
+                                   order=mcep_order, alpha=mcep_alpha)
+    main.wait_stream(side)
+    for t in (x, f0, bap, lf0, vuv):
+        t.record_stream(side)
+        t.record_stream(main)
+    return ops.assemble_cmp(mc, lf0, vuv, bap, f_off, add_deltas=add_deltas), f_off
 
 
 def synthesise_batch(f0s, sps, baps, fs, n_fft, hop_ms=5.0, preemphasis=0.0, device=None,

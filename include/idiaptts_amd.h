@@ -71,6 +71,41 @@ int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int di
 int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_out, int dim,
                       const int64_t* h_offsets, int n_utts, void* stream);
 
+/* lf0 / V-UV of WorldFeatLabelGen.world_extract_features (world/WorldFeatLabelGen.py:798-802):
+ *   lf0 = float32 log(clip(f0, 1e-10)); lf0[lf0 <= log(f0_silence_threshold)] = lf0_zero;
+ *   lf0, vuv = interpolate_lin(lf0)
+ * for U utterances stored back to back (h_f_off [U+1] frame offsets, each utterance < 2^24
+ * frames).  d_f0 [Ttot] f64 -> d_lf0 [Ttot] f32 (interpolated, continuous), d_vuv [Ttot] f32. */
+int itts_lf0_vuv(const double* d_f0, const int64_t* h_f_off, int n_utts,
+                 double f0_silence_threshold, float lf0_zero, float* d_lf0, float* d_vuv,
+                 void* stream);
+/* interpolate_lin (misc/utils.py:40-86) on float32 contours stored back to back: frames <= 0 are
+ * gaps; bit-exact including the reference's quirks (target reached one frame early; a gap whose
+ * next voiced frame is the last frame is filled, with that frame, by the last voiced value).
+ * d_ip [Ttot] f32 interpolated contour, d_vuv [Ttot] f32 (1 where d_in > 0).  In place
+ * (d_ip == d_in) is allowed. */
+int itts_interpolate_lin_f32(const float* d_in, const int64_t* h_off, int n_utts, float* d_ip,
+                             float* d_vuv, void* stream);
+/* Feature matrix of save_output / load (WorldFeatLabelGen.py:1121-1172, :459-573) for U utterances:
+ * add_deltas != 0: [sp, d sp, dd sp | lf0, d, dd | vuv | bap, d bap, dd bap], width
+ * 3*(n_sp+1+n_bap)+1 (the `.cmp` layout), d = compute_deltas = np.gradient in float32 per
+ * utterance (misc/utils.py:103-105), dd = compute_deltas(d); else [sp | lf0 | vuv | bap].
+ * d_sp [Ttot, ld_sp] f32, d_lf0 / d_vuv [Ttot] f32, d_bap [Ttot, ld_bap] f32 -> d_out [Ttot, ld_out]. */
+int itts_assemble_cmp_f32(const float* d_sp, int64_t ld_sp, int n_sp, const float* d_lf0,
+                          const float* d_vuv, const float* d_bap, int64_t ld_bap, int n_bap,
+                          const int64_t* h_f_off, int n_utts, int add_deltas, float* d_out,
+                          int64_t ld_out, void* stream);
+/* Normalisation sums of MeanCovarianceExtractor / MeanStdDevExtractor.add_sample
+ * (misc/normalisation/MeanCovarianceExtractor.py:27-31, MeanStdDevExtractor.py) over columns
+ * [col0, col0+width) of d_x [n_rows, ld_x] f32, accumulated in fp64 with a fixed summation order:
+ * d_sum [width] = sum x; d_second = sum x x^T [width, width] (want_cov != 0; fp64 matrix cores)
+ * or sum x^2 [width].  accumulate != 0 adds to the outputs.
+ * d_workspace >= itts_feature_stats_workspace_bytes(width, want_cov). */
+int64_t itts_feature_stats_workspace_bytes(int width, int want_cov);
+int itts_feature_stats(const float* d_x, int64_t ld_x, int64_t n_rows, int col0, int width,
+                       int want_cov, int accumulate, double* d_sum, double* d_second,
+                       void* d_workspace, void* stream);
+
 /* ---- acoustic model: dense layers (rnn_dyn/FFWrapper.py:63-73 -> torch.nn.Linear + act) --- */
 #define ITTS_ACT_NONE 0
 #define ITTS_ACT_TANH 1

@@ -1,6 +1,8 @@
-"""Wall-clock split of WorldFeatLabelGen.gen_data (host work vs GPU calls) on synthetic wavs.
-usage: python3 scripts/prof_gen_data.py [n_utts]"""
+"""End-to-end wall clock of WorldFeatLabelGen.gen_data (wav files -> per-stream .npz with deltas +
+normalisation statistics) on synthetic wavs, file I/O included.
+usage: python3 scripts/prof_gen_data.py [n_utts] [batch_utts] [--profile]"""
 import cProfile
+import json
 import os
 import pstats
 import sys
@@ -14,7 +16,9 @@ from scipy.io import wavfile
 from idiaptts_amd.bench_support import make_audio_batch
 from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if len(args) > 0 else 256
+batch = int(args[1]) if len(args) > 1 else 64
 with tempfile.TemporaryDirectory() as tmp:
     wav_dir, out_dir = os.path.join(tmp, "wav"), os.path.join(tmp, "out")
     os.makedirs(wav_dir)
@@ -22,14 +26,22 @@ with tempfile.TemporaryDirectory() as tmp:
     for i, x in enumerate(make_audio_batch(n, 16000, seed=0)):
         wavfile.write(os.path.join(wav_dir, "u%03d.wav" % i), 16000, (x * 32767).astype(np.int16))
         ids.append("u%03d" % i)
-    gen = WorldFeatLabelGen(out_dir, add_deltas=True, num_coded_sps=60)
-    gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids[:4])          # warm-up (library, tables)
-    t0 = time.perf_counter()
-    pr = cProfile.Profile()
-    pr.enable()
-    gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids)
-    pr.disable()
-    dt = time.perf_counter() - t0
+    gen = WorldFeatLabelGen(out_dir, add_deltas=True, num_coded_sps=60, batch_utts=batch)
+    gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids[:batch])      # warm-up (library, tables)
+    pr = cProfile.Profile() if "--profile" in sys.argv else None
+    times = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        if pr is not None and rep == 2:
+            pr.enable()
+        gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids)
+        if pr is not None and rep == 2:
+            pr.disable()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     audio = sum(os.path.getsize(os.path.join(wav_dir, i + ".wav")) for i in ids) / 2 / 16000
-    print("gen_data: %d utterances, %.1f s of audio in %.3f s -> RTF %.2e" % (n, audio, dt, dt / audio))
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    print(json.dumps({"gen_data": {"utterances": n, "batch_utts": batch, "audio_seconds": audio,
+                                   "seconds": dt, "all_passes": times, "rtf": dt / audio,
+                                   "host_cpus": os.cpu_count()}}))
+    if pr is not None:
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
