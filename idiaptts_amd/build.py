@@ -18,6 +18,10 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall",
             "-Wno-unused-function", "-ffp-contract=on", "-munsafe-fp-atomics"]
 
 
+# host-only translation units (file I/O): no device code, no contraction of a*b+c
+HOST_CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off", "-pthread"]
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -26,7 +30,8 @@ def _hipcc():
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                  if f.endswith(".hip") or f.endswith(".cpp"))
 
 
 def _deps():
@@ -43,7 +48,8 @@ def _stale(target, deps):
 
 
 def _compile(src, obj):
-    cmd = [_hipcc()] + CXXFLAGS + ["-c", src, "-o", obj]
+    flags = HOST_CXXFLAGS if src.endswith(".cpp") else CXXFLAGS
+    cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for {}:\n{}".format(src, res.stdout))
@@ -54,7 +60,7 @@ def build_library(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = sources()
     hdrs = _deps()
-    objs = [os.path.join(LIB_DIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    objs = [os.path.join(LIB_DIR, os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
     todo = [(s, o) for s, o in zip(srcs, objs) if force or _stale(o, [s] + hdrs)]
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(todo))) as ex:
@@ -62,7 +68,7 @@ def build_library(force=False, verbose=False):
                 if verbose and out.strip():
                     print(out)
     if todo or _stale(LIB_PATH, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", "-pthread", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n" + res.stdout)

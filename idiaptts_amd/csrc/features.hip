@@ -240,7 +240,7 @@ __global__ void reduce_parts_kernel(const double* __restrict__ part, int n_parts
 
 // sum x x^T on the fp64 matrix cores: one wave per (16x16 output tile, row chunk).
 // v_mfma_f64_16x16x4_f64: A [16 x 4] lane l holds A[l % 16][l / 16]; B [4 x 16] lane l holds
-// B[l / 16][l % 16]; D lane l holds D[4 * (l / 16) + i][l % 16], i = 0..3.
+// B[l / 16][l % 16]; D lane l holds D[(l / 16) + 4 * i][l % 16], i = 0..3.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int XTX_CHUNKS = 64;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void xtx_partial_kernel(const float* __restrict
   double* p = part + (int64_t)chunk * width * width;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = ti * 16 + 4 * (lane >> 4) + i;
+    const int row = ti * 16 + (lane >> 4) + 4 * i;
     if (row < width && okj) p[(int64_t)row * width + cj] = acc[i];
   }
 }

@@ -28,6 +28,13 @@ _SIGNATURES = {
     "itts_mcep_alpha": (c_double, [c_int]),
     "itts_world_num_frames": (c_int64, [c_int64, c_int, c_double]),
     "itts_world_synth_length": (c_int64, [c_int64, c_int, c_double]),
+    "itts_wav_info": (c_int, [c_char_p, POINTER(c_int), POINTER(c_int64)]),
+    "itts_wav_read_batch": (c_int, [POINTER(c_char_p), c_int, POINTER(c_int64), c_double, _P,
+                                    c_int]),
+    "itts_write_feature_archives": (c_int, [_P, c_int64, POINTER(c_int64), c_int,
+                                            POINTER(c_char_p), c_int, POINTER(c_int),
+                                            POINTER(c_int), POINTER(c_int), POINTER(c_char_p),
+                                            c_int]),
     "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),

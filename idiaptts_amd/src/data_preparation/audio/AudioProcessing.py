@@ -3,6 +3,7 @@
 by the HIP kernels behind libidiaptts_amd.so. librosa-based helpers (mel filter banks,
 Griffin-Lim) are out of scope."""
 import logging
+import os
 
 import numpy as np
 import scipy.io.wavfile
@@ -102,6 +103,52 @@ class AudioProcessing:
         raw, fs = AudioProcessing.read_wav(audio_name)
         raw = np.append(raw[0], raw[1:] - preemphasis * raw[:-1])
         return raw, fs
+
+    @staticmethod
+    def get_raw_batch(audio_names, preemphasis: float = 0.0, n_threads: int = 8):
+        """get_raw for a list of files in one native call (csrc/hostio.cpp, a pool of plain
+        threads): returns (samples of all files back to back as one float64 array, sample offsets
+        [n+1], sampling rates).  Files the native reader does not take (multi-channel, exotic
+        encodings) are read by get_raw."""
+        import ctypes
+        L = _lib.load()
+        n = len(audio_names)
+        fs = ctypes.c_int()
+        ns = ctypes.c_int64()
+        lengths, rates = [], []
+        fallback = {}
+        for i, name in enumerate(audio_names):
+            rc = L.itts_wav_info(os.fsencode(name), ctypes.byref(fs), ctypes.byref(ns))
+            if rc == 0:
+                lengths.append(ns.value)
+                rates.append(fs.value)
+            elif rc == -3:                      # ITTS_E_UNSUPPORTED
+                raw, rate = AudioProcessing.get_raw(name, preemphasis)
+                fallback[i] = raw
+                lengths.append(len(raw))
+                rates.append(rate)
+            else:
+                _lib.check(rc, "itts_wav_info")
+        offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        out = np.empty(int(offsets[-1]), dtype=np.float64)
+        for i, raw in fallback.items():
+            out[offsets[i]:offsets[i + 1]] = raw
+        # the native call fills consecutive files: one call per run of natively readable files
+        run_start = None
+        for i in list(range(n)) + [n]:
+            is_native = i < n and i not in fallback
+            if is_native and run_start is None:
+                run_start = i
+            elif not is_native and run_start is not None:
+                a, b = run_start, i
+                sub = (ctypes.c_char_p * (b - a))(*[os.fsencode(audio_names[k])
+                                                    for k in range(a, b)])
+                offs = (ctypes.c_int64 * (b - a + 1))(*[int(o) for o in offsets[a:b + 1]])
+                _lib.check(L.itts_wav_read_batch(sub, b - a, offs, float(preemphasis),
+                                                 out.ctypes.data, int(n_threads)),
+                           "itts_wav_read_batch")
+                run_start = None
+        return out, offsets, rates
 
     @staticmethod
     def extract_mcep(amp_sp: np.array, num_coded_sps: int, mgc_alpha: float) -> np.array:

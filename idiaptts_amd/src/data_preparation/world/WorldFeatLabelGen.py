@@ -58,6 +58,40 @@ def _save_to_npz(file_path, features, feature_name):
     os.replace(tmp, file_path)
 
 
+def _write_archives_native(cmp_host, f_off, utts, names, dir_out, streams, add_deltas, n_threads):
+    """One itts_write_feature_archives call for the utterances `utts` of a batch (csrc/hostio.cpp:
+    the archives np.savez would write, by a pool of plain threads).  streams: (directory, key,
+    (first column, width incl. deltas))."""
+    import ctypes
+    from .... import lib as _lib
+    L = _lib.load()
+    n_streams = len(streams)
+    paths = (ctypes.c_char_p * (len(utts) * n_streams))(*[
+        os.fsencode(os.path.join(dir_out, d, os.path.basename(names[u]) + ".npz"))
+        for u in utts for d, _, _ in streams])
+    parts = [3 if (add_deltas and w > 1 and key != WorldFeatLabelGen.ext_vuv) else 1
+             for _, key, (_, w) in streams]
+    col0 = (ctypes.c_int * n_streams)(*[c0 for _, _, (c0, _) in streams])
+    width = (ctypes.c_int * n_streams)(*[w // p_ for (_, _, (_, w)), p_ in zip(streams, parts)])
+    parts_c = (ctypes.c_int * n_streams)(*parts)
+    keys = (ctypes.c_char_p * n_streams)(*[key.encode() for _, key, _ in streams])
+    # the utterances of `utts` are addressed through their own offset pairs
+    contiguous = all(b == a + 1 for a, b in zip(utts[:-1], utts[1:]))
+    if contiguous:
+        offs = (ctypes.c_int64 * (len(utts) + 1))(*[int(f_off[u]) for u in utts] +
+                                                   [int(f_off[utts[-1] + 1])])
+        _lib.check(L.itts_write_feature_archives(
+            cmp_host.ctypes.data, cmp_host.strides[0] // 4, offs, len(utts), paths, n_streams,
+            col0, width, parts_c, keys, int(n_threads)), "itts_write_feature_archives")
+        return
+    for i, u in enumerate(utts):
+        offs = (ctypes.c_int64 * 2)(int(f_off[u]), int(f_off[u + 1]))
+        sub = (ctypes.c_char_p * n_streams)(*paths[i * n_streams:(i + 1) * n_streams])
+        _lib.check(L.itts_write_feature_archives(
+            cmp_host.ctypes.data, cmp_host.strides[0] // 4, offs, 1, sub, n_streams, col0, width,
+            parts_c, keys, 1), "itts_write_feature_archives")
+
+
 class WorldFeatLabelGen(ReaderBase):
     """Create world feat labels for .wav files."""
 
@@ -418,21 +452,35 @@ class WorldFeatLabelGen(ReaderBase):
         cols = stats = None
         batches = [id_list[b0:b0 + self.batch_utts] for b0 in range(0, len(id_list), self.batch_utts)]
 
-        def read(names):
-            raws, fss = [], []
-            for n in names:
-                raw, fs = AudioProcessing.get_raw(os.path.join(dir_in, n + "." + file_ext),
-                                                  self.preemphasis)
-                raws.append(raw)
-                fss.append(fs)
-            return raws, fss
+        n_io = max(2, min(16, (os.cpu_count() or 2) // 2))
 
-        n_io = max(2, min(8, (os.cpu_count() or 2) // 2))
-        with cf.ThreadPoolExecutor(n_io) as readers, cf.ThreadPoolExecutor(n_io) as writers:
+        def read(names):
+            return AudioProcessing.get_raw_batch(
+                [os.path.join(dir_in, n + "." + file_ext) for n in names], self.preemphasis, n_io)
+
+        def write(names, cmp_host, f_off, cols):
+            todo = [u for u, n in enumerate(names)]
+            streams = [(d, ext, cols[k]) for (load, d, ext, _), k
+                       in zip(self._streams(), ("sp", "lf0", "vuv", "bap")) if load]
+            # archives that already exist are merged into by the Python path (_save_to_npz keeps
+            # their other keys); fresh ones are written by the native batch writer
+            fresh = [u for u in todo if not any(
+                os.path.isfile(os.path.join(dir_out, d, os.path.basename(names[u]) + ".npz"))
+                for d, _, _ in streams)]
+            for u in todo:
+                if u not in set(fresh):
+                    self._write_utterance(dir_out, os.path.basename(names[u]),
+                                          cmp_host[f_off[u]:f_off[u + 1]], cols)
+            if fresh:
+                _write_archives_native(cmp_host, f_off, fresh, names, dir_out, streams,
+                                       self.add_deltas, n_io)
+
+        with cf.ThreadPoolExecutor(2) as readers, cf.ThreadPoolExecutor(2) as writers:
             pending_reads = [readers.submit(read, names) for names in batches[:2]]
             writes = []
             for bi, names in enumerate(batches):
-                raws, fss = pending_reads[bi].result()
+                samples, x_off, fss = pending_reads[bi].result()
+                pending_reads[bi] = None
                 if bi + 2 < len(batches):
                     pending_reads.append(readers.submit(read, batches[bi + 2]))
                 assert len(set(fss)) == 1, "All files of a batch need the same sampling rate."
@@ -444,20 +492,19 @@ class WorldFeatLabelGen(ReaderBase):
                 alpha = self.mgc_alpha if self.mgc_alpha is not None \
                     else AudioProcessing.fs_to_mgc_alpha(fs)
                 cmp_dev, f_off = _world.extract_cmp_batch(
-                    raws, fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1, alpha,
-                    WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
+                    (samples, x_off), fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1,
+                    alpha, WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
                     self.add_deltas)
                 stats.add(cmp_dev)
                 host = torch.empty(cmp_dev.shape, dtype=torch.float32, pin_memory=True)
                 host.copy_(cmp_dev, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 cmp_host = host.numpy()
-                for u, n in enumerate(names):
-                    cmp_u = cmp_host[f_off[u]:f_off[u + 1]]
-                    if dir_out is not None:
-                        writes.append(writers.submit(self._write_utterance, dir_out,
-                                                     os.path.basename(n), cmp_u, cols))
-                    if label_dict is not None:
+                if dir_out is not None:
+                    writes.append(writers.submit(write, names, cmp_host, f_off, cols))
+                if label_dict is not None:
+                    for u, n in enumerate(names):
+                        cmp_u = cmp_host[f_off[u]:f_off[u + 1]]
                         label_dict[n] = np.concatenate(
                             [cmp_u[:, cols[k][0]:cols[k][0] + cols[k][1]] for k in loaded], axis=1) \
                             if loaded else None

@@ -139,9 +139,14 @@ def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alph
     dev = _device(device)
     L = _lib.load()
     n_fft = n_fft or L.itts_cheaptrick_fft_size(int(fs), 71.0)
-    x_off = offsets([len(r) for r in raws])
-    f_off = offsets([num_frames(len(r), fs, hop_ms) for r in raws])
-    x = torch.from_numpy(np.ascontiguousarray(np.concatenate(raws), dtype=np.float64)).to(dev)
+    if isinstance(raws, tuple):       # (samples of all utterances back to back, sample offsets)
+        samples, x_off = raws
+        x_off = [int(o) for o in x_off]
+    else:
+        x_off = offsets([len(r) for r in raws])
+        samples = np.concatenate(raws) if len(raws) else np.empty(0)
+    f_off = offsets([num_frames(b - a, fs, hop_ms) for a, b in zip(x_off[:-1], x_off[1:])])
+    x = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float64)).to(dev)
     f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)

@@ -49,6 +49,28 @@ int64_t itts_world_num_frames(int64_t n_samples, int fs, double frame_period_ms)
 /* samples pyworld.synthesize yields: int(T*frame_period*fs/1000) */
 int64_t itts_world_synth_length(int64_t n_frames, int fs, double frame_period_ms);
 
+/* ---- host file I/O of the feature-extraction loop (no GPU; csrc/hostio.cpp) --------------------
+ * AudioProcessing.get_raw (src/data_preparation/audio/AudioProcessing.py:107-120) for a batch:
+ * mono PCM 8 / 16 / 32-bit or IEEE-float wav files -> float64 samples in [-1, 1] with
+ * pre-emphasis raw[i] - p * raw[i-1], files read by n_threads threads.  Two passes: itts_wav_info
+ * gives rate and length (ITTS_E_UNSUPPORTED for other layouts: read those another way), the caller
+ * sizes one buffer, itts_wav_read_batch fills h_out[h_offsets[i] .. h_offsets[i+1]) with file i. */
+int itts_wav_info(const char* h_path, int* fs, int64_t* n_samples);
+int itts_wav_read_batch(const char* const* h_paths, int n_files, const int64_t* h_offsets,
+                        double preemphasis, double* h_out, int n_threads);
+/* The `.npz` archives save_output writes (world/WorldFeatLabelGen.py:1121-1172 through
+ * LabelGen._save_to_npz, data_preparation/LabelGen.py:63-101) for a batch of utterances whose
+ * features sit in one host matrix h_feat [Ttot, ld] f32 (utterance u = rows h_f_off[u] ..
+ * h_f_off[u+1]): archive h_paths[u * n_streams + s] gets stream s = columns h_col0[s] ..., stored
+ * as `<key>.npy` (h_parts[s] == 1, width h_width[s]) or as `<key>.npy`, `<key>_deltas.npy`,
+ * `<key>_double_deltas.npy` (h_parts[s] == 3, three blocks of h_width[s] columns).  Archives are
+ * written to `<path>_tmp` and renamed; an existing archive is REPLACED (callers that must merge
+ * into existing archives keep using the Python path).  n_threads writer threads. */
+int itts_write_feature_archives(const float* h_feat, int64_t ld, const int64_t* h_f_off, int n_utts,
+                                const char* const* h_paths, int n_streams, const int* h_col0,
+                                const int* h_width, const int* h_parts, const char* const* h_keys,
+                                int n_threads);
+
 /* ---- MLPG (misc/mlpg.py:94-127, bandmat solveh) ----------------------------------------- */
 /*
  * Batched maximum-likelihood parameter generation with the reference's three windows

@@ -17,9 +17,10 @@ from idiaptts_amd.bench_support import make_audio_batch
 from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
+base = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--dir=")), None)
 n = int(args[0]) if len(args) > 0 else 256
 batch = int(args[1]) if len(args) > 1 else 64
-with tempfile.TemporaryDirectory() as tmp:
+with tempfile.TemporaryDirectory(dir=base) as tmp:
     wav_dir, out_dir = os.path.join(tmp, "wav"), os.path.join(tmp, "out")
     os.makedirs(wav_dir)
     ids = []
@@ -42,6 +43,6 @@ with tempfile.TemporaryDirectory() as tmp:
     audio = sum(os.path.getsize(os.path.join(wav_dir, i + ".wav")) for i in ids) / 2 / 16000
     print(json.dumps({"gen_data": {"utterances": n, "batch_utts": batch, "audio_seconds": audio,
                                    "seconds": dt, "all_passes": times, "rtf": dt / audio,
-                                   "host_cpus": os.cpu_count()}}))
+                                   "host_cpus": os.cpu_count(), "dir": base or tempfile.gettempdir()}}))
     if pr is not None:
         pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
