@@ -221,6 +221,32 @@ void append_member(std::vector<unsigned char>& z, std::vector<Member>& dir, cons
   dir.push_back(m);
 }
 
+// Member names of an existing archive (central directory of a ZIP file without comment); false
+// when the file is not there or not such an archive.
+bool archive_members(const char* path, std::vector<std::string>* names) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  bool ok = false;
+  unsigned char e[22];
+  if (fseek(f, -22, SEEK_END) == 0 && fread(e, 1, 22, f) == 22 && rd32(e) == 0x06054b50u) {
+    const uint32_t n = rd16(e + 10), cd_size = rd32(e + 12), cd_off = rd32(e + 16);
+    std::vector<unsigned char> cd(cd_size);
+    if (fseek(f, (long)cd_off, SEEK_SET) == 0 && fread(cd.data(), 1, cd_size, f) == cd_size) {
+      size_t p = 0;
+      ok = true;
+      for (uint32_t i = 0; i < n && ok; ++i) {
+        if (p + 46 > cd.size() || rd32(cd.data() + p) != 0x02014b50u) { ok = false; break; }
+        const size_t nl = rd16(cd.data() + p + 28), xl = rd16(cd.data() + p + 30), cl = rd16(cd.data() + p + 32);
+        if (p + 46 + nl > cd.size()) { ok = false; break; }
+        names->emplace_back(reinterpret_cast<const char*>(cd.data() + p + 46), nl);
+        p += 46 + nl + xl + cl;
+      }
+    }
+  }
+  fclose(f);
+  return ok;
+}
+
 bool finish_archive(std::vector<unsigned char>& z, const std::vector<Member>& dir, const char* path,
                     std::string* err) {
   const uint32_t cd_off = (uint32_t)z.size();
@@ -283,7 +309,8 @@ extern "C" int itts_wav_read_batch(const char* const* h_paths, int n_files, cons
 extern "C" int itts_write_feature_archives(const float* h_feat, int64_t ld, const int64_t* h_f_off,
                                            int n_utts, const char* const* h_paths, int n_streams,
                                            const int* h_col0, const int* h_width, const int* h_parts,
-                                           const char* const* h_keys, int n_threads) {
+                                           const char* const* h_keys, int n_threads,
+                                           unsigned char* h_needs_merge) {
   if (n_utts < 0 || n_streams < 0 ||
       (n_utts * n_streams > 0 && (!h_feat || !h_f_off || !h_paths || !h_col0 || !h_width || !h_parts || !h_keys))) {
     itts::set_error("itts_write_feature_archives: null pointer");
@@ -305,6 +332,25 @@ extern "C" int itts_write_feature_archives(const float* h_feat, int64_t ld, cons
   std::string err;
   const bool ok = run_parallel(n_utts * n_streams, n_threads, [&](int job, std::string* e) {
     const int u = job / n_streams, s = job % n_streams;
+    const char* path = h_paths[(int64_t)u * n_streams + s];
+    if (h_needs_merge) {
+      // an existing archive that holds members this call does not write keeps them: left to the
+      // caller's merging path (LabelGen._save_to_npz semantics)
+      h_needs_merge[job] = 0;
+      std::vector<std::string> have;
+      FILE* probe = fopen(path, "rb");
+      if (probe) {
+        fclose(probe);
+        bool subset = archive_members(path, &have);
+        for (size_t i = 0; subset && i < have.size(); ++i) {
+          bool found = false;
+          for (int p = 0; p < h_parts[s]; ++p)
+            found = found || have[i] == std::string(h_keys[s]) + suffix[p] + ".npy";
+          subset = found;
+        }
+        if (!subset) { h_needs_merge[job] = 1; return true; }
+      }
+    }
     const int64_t rows = h_f_off[u + 1] - h_f_off[u];
     const float* base = h_feat + h_f_off[u] * ld + h_col0[s];
     std::vector<unsigned char> z;
@@ -313,7 +359,7 @@ extern "C" int itts_write_feature_archives(const float* h_feat, int64_t ld, cons
     for (int p = 0; p < h_parts[s]; ++p)
       append_member(z, dir, std::string(h_keys[s]) + suffix[p], base + (int64_t)p * h_width[s], ld, rows,
                     h_width[s]);
-    return finish_archive(z, dir, h_paths[(int64_t)u * n_streams + s], e);
+    return finish_archive(z, dir, path, e);
   }, &err);
   if (!ok) { itts::set_error("itts_write_feature_archives: " + err); return ITTS_E_INVALID; }
   return ITTS_OK;

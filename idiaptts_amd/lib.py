@@ -34,7 +34,7 @@ _SIGNATURES = {
     "itts_write_feature_archives": (c_int, [_P, c_int64, POINTER(c_int64), c_int,
                                             POINTER(c_char_p), c_int, POINTER(c_int),
                                             POINTER(c_int), POINTER(c_int), POINTER(c_char_p),
-                                            c_int]),
+                                            c_int, _P]),
     "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),

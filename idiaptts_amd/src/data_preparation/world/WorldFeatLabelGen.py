@@ -58,38 +58,30 @@ def _save_to_npz(file_path, features, feature_name):
     os.replace(tmp, file_path)
 
 
-def _write_archives_native(cmp_host, f_off, utts, names, dir_out, streams, add_deltas, n_threads):
-    """One itts_write_feature_archives call for the utterances `utts` of a batch (csrc/hostio.cpp:
-    the archives np.savez would write, by a pool of plain threads).  streams: (directory, key,
-    (first column, width incl. deltas))."""
+def _write_archives_native(cmp_host, f_off, names, dir_out, streams, add_deltas, n_threads):
+    """One itts_write_feature_archives call for the utterances of a batch (csrc/hostio.cpp: the
+    archives np.savez would write, by a pool of plain threads).  streams: (directory, key,
+    (first column, width incl. deltas)).  Returns the (utterance index, stream index) pairs whose
+    archive exists with other keys in it: those are merged by the caller (_save_to_npz)."""
     import ctypes
     from .... import lib as _lib
     L = _lib.load()
-    n_streams = len(streams)
-    paths = (ctypes.c_char_p * (len(utts) * n_streams))(*[
-        os.fsencode(os.path.join(dir_out, d, os.path.basename(names[u]) + ".npz"))
-        for u in utts for d, _, _ in streams])
-    parts = [3 if (add_deltas and w > 1 and key != WorldFeatLabelGen.ext_vuv) else 1
-             for _, key, (_, w) in streams]
+    n_utts, n_streams = len(names), len(streams)
+    paths = (ctypes.c_char_p * (n_utts * n_streams))(*[
+        os.fsencode(os.path.join(dir_out, d, os.path.basename(n) + ".npz"))
+        for n in names for d, _, _ in streams])
+    parts = [3 if (add_deltas and key != WorldFeatLabelGen.ext_vuv) else 1 for _, key, _ in streams]
     col0 = (ctypes.c_int * n_streams)(*[c0 for _, _, (c0, _) in streams])
     width = (ctypes.c_int * n_streams)(*[w // p_ for (_, _, (_, w)), p_ in zip(streams, parts)])
     parts_c = (ctypes.c_int * n_streams)(*parts)
     keys = (ctypes.c_char_p * n_streams)(*[key.encode() for _, key, _ in streams])
-    # the utterances of `utts` are addressed through their own offset pairs
-    contiguous = all(b == a + 1 for a, b in zip(utts[:-1], utts[1:]))
-    if contiguous:
-        offs = (ctypes.c_int64 * (len(utts) + 1))(*[int(f_off[u]) for u in utts] +
-                                                   [int(f_off[utts[-1] + 1])])
-        _lib.check(L.itts_write_feature_archives(
-            cmp_host.ctypes.data, cmp_host.strides[0] // 4, offs, len(utts), paths, n_streams,
-            col0, width, parts_c, keys, int(n_threads)), "itts_write_feature_archives")
-        return
-    for i, u in enumerate(utts):
-        offs = (ctypes.c_int64 * 2)(int(f_off[u]), int(f_off[u + 1]))
-        sub = (ctypes.c_char_p * n_streams)(*paths[i * n_streams:(i + 1) * n_streams])
-        _lib.check(L.itts_write_feature_archives(
-            cmp_host.ctypes.data, cmp_host.strides[0] // 4, offs, 1, sub, n_streams, col0, width,
-            parts_c, keys, 1), "itts_write_feature_archives")
+    offs = (ctypes.c_int64 * (n_utts + 1))(*[int(o) for o in f_off[:n_utts + 1]])
+    flags = (ctypes.c_ubyte * (n_utts * n_streams))()
+    _lib.check(L.itts_write_feature_archives(
+        cmp_host.ctypes.data, cmp_host.strides[0] // 4, offs, n_utts, paths, n_streams, col0,
+        width, parts_c, keys, int(n_threads), ctypes.addressof(flags)),
+        "itts_write_feature_archives")
+    return [(j // n_streams, j % n_streams) for j, f in enumerate(flags) if f]
 
 
 class WorldFeatLabelGen(ReaderBase):
@@ -459,27 +451,31 @@ class WorldFeatLabelGen(ReaderBase):
                 [os.path.join(dir_in, n + "." + file_ext) for n in names], self.preemphasis, n_io)
 
         def write(names, cmp_host, f_off, cols):
-            todo = [u for u, n in enumerate(names)]
             streams = [(d, ext, cols[k]) for (load, d, ext, _), k
                        in zip(self._streams(), ("sp", "lf0", "vuv", "bap")) if load]
-            # archives that already exist are merged into by the Python path (_save_to_npz keeps
-            # their other keys); fresh ones are written by the native batch writer
-            fresh = [u for u in todo if not any(
-                os.path.isfile(os.path.join(dir_out, d, os.path.basename(names[u]) + ".npz"))
-                for d, _, _ in streams)]
-            for u in todo:
-                if u not in set(fresh):
-                    self._write_utterance(dir_out, os.path.basename(names[u]),
-                                          cmp_host[f_off[u]:f_off[u + 1]], cols)
-            if fresh:
-                _write_archives_native(cmp_host, f_off, fresh, names, dir_out, streams,
-                                       self.add_deltas, n_io)
+            merge = _write_archives_native(cmp_host, f_off, names, dir_out, streams,
+                                           self.add_deltas, n_io)
+            for u, si in merge:      # archive with foreign keys: _save_to_npz keeps them
+                d, ext, (c0, w) = streams[si]
+                cmp_u = cmp_host[f_off[u]:f_off[u + 1]]
+                path = os.path.join(dir_out, d, os.path.basename(names[u]))
+                if self.add_deltas and ext != self.ext_vuv:
+                    k = w // 3
+                    _save_to_npz(path, [np.ascontiguousarray(cmp_u[:, c0 + i * k:c0 + (i + 1) * k])
+                                        for i in range(3)],
+                                 [ext, ext + "_deltas", ext + "_double_deltas"])
+                else:
+                    _save_to_npz(path, np.ascontiguousarray(cmp_u[:, c0:c0 + w]), ext)
 
         with cf.ThreadPoolExecutor(2) as readers, cf.ThreadPoolExecutor(2) as writers:
             pending_reads = [readers.submit(read, names) for names in batches[:2]]
             writes = []
+            trace = os.environ.get("ITTS_GEN_DATA_TRACE") == "1"
+            import time as _time
             for bi, names in enumerate(batches):
+                t_a = _time.perf_counter()
                 samples, x_off, fss = pending_reads[bi].result()
+                t_b = _time.perf_counter()
                 pending_reads[bi] = None
                 if bi + 2 < len(batches):
                     pending_reads.append(readers.submit(read, batches[bi + 2]))
@@ -500,6 +496,9 @@ class WorldFeatLabelGen(ReaderBase):
                 host.copy_(cmp_dev, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 cmp_host = host.numpy()
+                if trace:
+                    print("gen_data batch {}: waited {:.1f} ms for the reader, device {:.1f} ms"
+                          .format(bi, (t_b - t_a) * 1e3, (_time.perf_counter() - t_b) * 1e3))
                 if dir_out is not None:
                     writes.append(writers.submit(write, names, cmp_host, f_off, cols))
                 if label_dict is not None:
@@ -508,8 +507,12 @@ class WorldFeatLabelGen(ReaderBase):
                         label_dict[n] = np.concatenate(
                             [cmp_u[:, cols[k][0]:cols[k][0] + cols[k][1]] for k in loaded], axis=1) \
                             if loaded else None
+            t_a = _time.perf_counter()
             for w in writes:
                 w.result()          # re-raises a writer's exception
+            if trace:
+                print("gen_data: waited {:.1f} ms for the writers".format(
+                    (_time.perf_counter() - t_a) * 1e3))
         for (load, _, _, normaliser), key in zip(self._streams(), ("sp", "lf0", "vuv", "bap")):
             if load and key != "vuv" and stats is not None:
                 stats.store(key, normaliser)

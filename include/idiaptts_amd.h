@@ -64,12 +64,14 @@ int itts_wav_read_batch(const char* const* h_paths, int n_files, const int64_t* 
  * h_f_off[u+1]): archive h_paths[u * n_streams + s] gets stream s = columns h_col0[s] ..., stored
  * as `<key>.npy` (h_parts[s] == 1, width h_width[s]) or as `<key>.npy`, `<key>_deltas.npy`,
  * `<key>_double_deltas.npy` (h_parts[s] == 3, three blocks of h_width[s] columns).  Archives are
- * written to `<path>_tmp` and renamed; an existing archive is REPLACED (callers that must merge
- * into existing archives keep using the Python path).  n_threads writer threads. */
+ * written to `<path>_tmp` and renamed.  _save_to_npz keeps the other keys of an archive that already
+ * exists: with h_needs_merge != NULL ([n_utts * n_streams] bytes) an existing archive holding
+ * members this call would not write is left untouched and flagged 1 there (the caller merges it);
+ * with NULL existing archives are replaced.  n_threads writer threads. */
 int itts_write_feature_archives(const float* h_feat, int64_t ld, const int64_t* h_f_off, int n_utts,
                                 const char* const* h_paths, int n_streams, const int* h_col0,
                                 const int* h_width, const int* h_parts, const char* const* h_keys,
-                                int n_threads);
+                                int n_threads, unsigned char* h_needs_merge);
 
 /* ---- MLPG (misc/mlpg.py:94-127, bandmat solveh) ----------------------------------------- */
 /*

@@ -57,8 +57,19 @@ def test_native_archives_read_back_like_np_savez(tmp_path):
                    in zip(gen._streams(), ("sp", "lf0", "vuv", "bap"))]
         for d, _, _ in streams:
             os.makedirs(os.path.join(out_dir, d), exist_ok=True)
-        _write_archives_native(cmp_host, f_off, [0, 1, 2, 3], names, out_dir, streams, add_deltas, 3)
-        _write_archives_native(cmp_host, f_off, [1, 3], names, out_dir, streams, add_deltas, 2)
+        assert _write_archives_native(cmp_host, f_off, names, out_dir, streams, add_deltas, 3) == []
+        # again: the archives exist with exactly these keys -> replaced, nothing to merge
+        assert _write_archives_native(cmp_host, f_off, names, out_dir, streams, add_deltas, 2) == []
+        # an archive with a foreign key is left alone and reported
+        from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import _save_to_npz
+        foreign = os.path.join(out_dir, streams[1][0], "a")
+        _save_to_npz(foreign, np.arange(3.0), "something_else")
+        before = open(foreign + ".npz", "rb").read()
+        assert _write_archives_native(cmp_host, f_off, names, out_dir, streams, add_deltas, 2) \
+            == [(0, 1)]
+        assert open(foreign + ".npz", "rb").read() == before
+        os.remove(foreign + ".npz")
+        assert _write_archives_native(cmp_host, f_off, names, out_dir, streams, add_deltas, 2) == []
         ref_dir = out_dir + "_ref"
         ref = WorldFeatLabelGen(ref_dir, add_deltas=add_deltas, num_coded_sps=20, num_bap=n_bap)
         ref._create_norm_params_extractors()
