@@ -14,6 +14,9 @@
 // Roofline: HBM.  Algorithmic bytes per frame = 187*8 read + 63*8 written = 2000 B
 // (SURVEY.md section 8d); the factor scratch adds 3 f64 written + 4 read per (frame, dim).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -519,6 +522,448 @@ __global__ __launch_bounds__(64) void mlpg_chunk_kernel(MlpgArgs a, int t_max) {
   }
 }
 
+// ---- fused single-pass solve ----------------------------------------------------------------------
+// The four chunk passes above read the input twice and send the forward-sweep result through HBM
+// (2.3x the algorithmic bytes).  Here a wave keeps its FU_FL frames x 64 dimensions in registers
+// from the first load to the last store, so the input is read ONCE and the output written ONCE:
+//   1  b_j from the three input columns; forward sweep from a zero state together with the two
+//      unit responses -> this chunk's (M, e)                                   [registers]
+//   2  (M, e) of the workgroup's FW chunks meet in LDS; every wave folds the ones before it; the
+//      workgroup's aggregate is published; aggregates of the EARLIER super-chunks of the utterance
+//      (other workgroups) are folded in -> true entry state; forward sweep again, y replaces b
+//   3  the same backwards over y: (M, e) -> LDS -> aggregate published -> aggregates of the LATER
+//      super-chunks folded in -> true entry state
+//   4  backward sweep from the true state, x written out
+// Cross-workgroup exchange: a workgroup takes its super-chunk from a ticket counter (so every
+// super-chunk with a lower ticket is held by a RUNNING workgroup), publishes aggregates without
+// waiting for anybody, and waits only for aggregates -- forward ones of lower tickets, backward
+// ones of the same utterance, whose owners need nothing but forward aggregates: no cycle, at most
+// (super-chunks per utterance - 1) workgroups can be parked on a ticket that is not handed out yet.
+// Values travel without fences (an agent-scope release writes the L2 back on this chip): every
+// double is stored as the pair (bits, ~bits) with relaxed agent-scope atomics into zeroed memory
+// and read until the two words are complements -- a torn or missing pair never validates.
+constexpr int FU_MAX_SC = 64;      // super-chunks per utterance the fused path accepts
+
+struct FusedArgs {
+  MlpgArgs a;
+  int t_max;
+  const int* sc_utt;     // [n_sc] utterance of the super-chunk
+  const int* sc_k0;      // [n_sc] its first chunk (index inside the utterance)
+  const int* utt_sc0;    // [U+1] first super-chunk of every utterance
+  int n_sc, nblk;
+  unsigned* ticket;
+  unsigned long long* agg;   // [n_sc][12][2][nblk * 64]
+  int stagger_n, stagger_steps;
+  int* err;                  // set when a wait ran out of its polling budget
+  unsigned long long* trace; // optional [tickets][FW][8] wall-clock stamps (ITTS_MLPG_TRACE)
+};
+
+template <int FU_FL>
+__device__ __forceinline__ int fu_num_chunks(int64_t T) { return (int)((T + FU_FL - 1) / FU_FL); }
+// the last chunk always holds both re-derived tail frames: a one-frame remainder takes a frame
+// from the chunk before it
+template <int FU_FL>
+__device__ __forceinline__ int64_t fu_chunk_start(int k, int K, int64_t T) {
+  int64_t s = (int64_t)k * FU_FL;
+  if (k == K - 1 && K > 1 && T - s == 1) s -= 1;
+  return k >= K ? T : s;
+}
+
+__device__ __forceinline__ void fu_publish(unsigned long long* p, int64_t pair_stride, double v) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + pair_stride, ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fu_consume(const unsigned long long* p, int64_t pair_stride) {
+  unsigned long long x, y;
+  for (;;) {
+    x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    y = __hip_atomic_load(p + pair_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (x == ~y) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return __longlong_as_double((long long)x);
+}
+
+// The six doubles of one aggregate (M00, M01, M10, M11, e0, e1) at p[2 * i * stride] for this
+// lane.  Waiting is done by ONE lane on ONE pair (`flag`: the last pair the owner's lane 0 writes)
+// with a sleep between polls -- thousands of waves polling every word flood the memory system and
+// starve the producers -- then all twelve words of every lane are requested together and checked,
+// which is retried in the rare case that some pair has not landed yet.  `budget` bounds the total
+// number of polls of this wave: when it runs out the wave stops waiting (the result is then wrong
+// and *err is set) instead of hanging the device.
+__device__ __forceinline__ void fu_consume6(const unsigned long long* p, int64_t stride,
+                                            const unsigned long long* flag, double (&v)[6],
+                                            int& budget, int* err) {
+  if ((threadIdx.x & 63) == 0) {
+    for (;;) {
+      const unsigned long long x = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long y = __hip_atomic_load(flag + stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (x == ~y || --budget <= 0) break;
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  budget = __shfl(budget, 0, 64);
+  for (;;) {
+    unsigned long long x[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      x[i] = __hip_atomic_load(p + (int64_t)(2 * i) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      y[i] = __hip_atomic_load(p + (int64_t)(2 * i + 1) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ok = ok && (x[i] == ~y[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = __longlong_as_double((long long)x[i]);
+    if (__all(ok)) return;
+    if (--budget <= 0) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 1);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
+struct FuFac {
+  const double* fd;
+  const double* fl1;
+  const double* fl2;
+  int64_t ncv, n_shared, T;
+  int D;
+  double tau0, tau1_in, tau2_in;
+  __device__ __forceinline__ double F(const double* pl, int64_t j) const {
+    return j < 0 ? 0.0 : pl[(j < ncv ? j : ncv) * D];
+  }
+  __device__ __forceinline__ double tau1(int64_t t) const {
+    if (t < 0 || t >= T) return 0.0;
+    return (t == 0 || t == T - 1) ? 1.0 / kBigVar : tau1_in;
+  }
+  __device__ __forceinline__ double tau2(int64_t t) const {
+    if (t < 0 || t >= T) return 0.0;
+    return (t == 0 || t == T - 1) ? 1.0 / kBigVar : tau2_in;
+  }
+  // factor of a tail frame (j >= n_shared) from the Cholesky state that reaches it
+  __device__ __forceinline__ void derive(int64_t j, double l1p, double l2p, double cprev, double& dd,
+                                         double& l1, double& l2) const {
+    const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) + (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
+    const double pj1 = (j + 1 < T) ? -2.0 * (tau2(j) + tau2(j + 1)) : 0.0;
+    const double pj2 = (j + 2 < T) ? (tau2(j + 1) - 0.25 * tau1(j + 1)) : 0.0;
+    dd = 1.0 / sqrt(pjj - l1p * l1p - l2p * l2p);
+    l1 = (pj1 - cprev * l1p) * dd;
+    l2 = pj2 * dd;
+  }
+};
+
+// Forward sweep over the chunk [j0, j0 + n).  PASS_A: zero-state response e and the two unit
+// responses M, b untouched; else: from (s1, s2), y replaces b.  tl: factors of frames T-2, T-1.
+template <int FU_FL, bool CONST, bool PASS_A>
+__device__ __forceinline__ void fu_fwd(const FuFac& c, double (&b)[FU_FL], int64_t j0, int n, double s1,
+                                       double s2, double (&M)[4], double (&e)[2], double (&tl)[6]) {
+  double kd = 0.0, k1 = 0.0, k2 = 0.0;
+  double l1p, l2p, cprev;
+  if (CONST) {
+    kd = c.fd[c.ncv * c.D];
+    k1 = c.fl1[c.ncv * c.D];
+    k2 = c.fl2[c.ncv * c.D];
+    l1p = k1; l2p = k2; cprev = k2;
+  } else {
+    l1p = c.F(c.fl1, j0 - 1); l2p = c.F(c.fl2, j0 - 2); cprev = c.F(c.fl2, j0 - 1);
+    if (c.n_shared == 0) l1p = l2p = cprev = 0.0;
+  }
+  double y1 = s1, y2 = s2, u1 = 1.0, u2 = 0.0, v1 = 0.0, v2 = 1.0;
+#pragma unroll
+  for (int i = 0; i < FU_FL; ++i) {
+    if (CONST || i < n) {
+      const int64_t j = j0 + i;
+      double dd, l1, l2;
+      if (CONST) {
+        dd = kd; l1 = k1; l2 = k2;
+      } else if (j < c.n_shared) {
+        const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;
+        dd = c.fd[jc]; l1 = c.fl1[jc]; l2 = c.fl2[jc];
+      } else {
+        c.derive(j, l1p, l2p, cprev, dd, l1, l2);
+        if (j == c.T - 1) { tl[3] = dd; tl[4] = l1; tl[5] = l2; }
+        else { tl[0] = dd; tl[1] = l1; tl[2] = l2; }
+      }
+      const double y = (b[i] - l1p * y1 - l2p * y2) * dd;
+      if (PASS_A) {
+        const double u = (-l1p * u1 - l2p * u2) * dd;
+        const double v = (-l1p * v1 - l2p * v2) * dd;
+        u2 = u1; u1 = u; v2 = v1; v1 = v;
+      } else {
+        b[i] = y;
+      }
+      y2 = y1; y1 = y;
+      l2p = cprev; l1p = l1; cprev = l2;
+    }
+  }
+  if (PASS_A) {
+    M[0] = u1; M[1] = v1; M[2] = u2; M[3] = v2;
+    e[0] = y1; e[1] = y2;
+  }
+}
+
+// Backward sweep over y (in b).  PASS_A: (M, e) of the chunk; else: x from (s1, s2) = (x_{j1},
+// x_{j1+1}) written to `o` (row pitch ldo), when `store`.
+template <int FU_FL, bool CONST, bool PASS_A>
+__device__ __forceinline__ void fu_bwd(const FuFac& c, double (&b)[FU_FL], int64_t j0, int n, double s1,
+                                       double s2, double (&M)[4], double (&e)[2], const double (&tl)[6],
+                                       double* o, int64_t ldo, bool store) {
+  double kd = 0.0, k1 = 0.0, k2 = 0.0;
+  if (CONST) {
+    kd = c.fd[c.ncv * c.D];
+    k1 = c.fl1[c.ncv * c.D];
+    k2 = c.fl2[c.ncv * c.D];
+  }
+  double x1 = s1, x2 = s2, u1 = 1.0, u2 = 0.0, v1 = 0.0, v2 = 1.0;
+#pragma unroll
+  for (int i = FU_FL - 1; i >= 0; --i) {
+    if (CONST || i < n) {
+      const int64_t j = j0 + i;
+      double dd, l1, l2;
+      if (CONST) {
+        dd = kd; l1 = k1; l2 = k2;
+      } else if (j < c.n_shared) {
+        const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;
+        dd = c.fd[jc]; l1 = c.fl1[jc]; l2 = c.fl2[jc];
+      } else {
+        const bool last = j == c.T - 1;
+        dd = last ? tl[3] : tl[0]; l1 = last ? tl[4] : tl[1]; l2 = last ? tl[5] : tl[2];
+      }
+      const double x = (b[i] - l1 * x1 - l2 * x2) * dd;
+      if (PASS_A) {
+        const double u = (-l1 * u1 - l2 * u2) * dd;
+        const double v = (-l1 * v1 - l2 * v2) * dd;
+        u2 = u1; u1 = u; v2 = v1; v1 = v;
+      } else if (store) {
+        o[j * ldo] = x;
+      }
+      x2 = x1; x1 = x;
+    }
+  }
+  if (PASS_A) {
+    M[0] = u1; M[1] = v1; M[2] = u2; M[3] = v2;
+    e[0] = x1; e[1] = x2;
+  }
+}
+
+template <int FU_FL, int FW, int WPE>
+__global__ __launch_bounds__(FW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void mlpg_fused_kernel(FusedArgs g) {
+  __shared__ double lds_f[FW][6][64];
+  __shared__ double lds_b[FW][6][64];
+  __shared__ unsigned s_ticket;
+  const MlpgArgs& a = g.a;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(g.ticket, 1u);
+  __syncthreads();
+  const int sc = (int)(s_ticket / (unsigned)g.nblk), db = (int)(s_ticket % (unsigned)g.nblk);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int D = a.dim;
+  const bool dok = db * 64 + lane < D;
+  const int d = dok ? db * 64 + lane : D - 1;
+  const int u = g.sc_utt[sc];
+  const int64_t t0 = a.offsets[u];
+  const int64_t T = a.offsets[u + 1] - t0;
+  const int K = fu_num_chunks<FU_FL>(T);
+  const int k = g.sc_k0[sc] + w;
+  const bool wact = k < K;
+  const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
+  const int n = wact ? (int)(j1 - j0) : 0;
+  const int64_t Dp = (int64_t)g.nblk * 64;
+  const int64_t dcol = (int64_t)db * 64 + lane;
+  unsigned long long* tr = g.trace ? g.trace + ((int64_t)s_ticket * FW + w) * 8 : nullptr;
+#define FU_STAMP(i) do { if (tr && lane == 0) tr[i] = wall_clock64(); } while (0)
+  FU_STAMP(0);
+  if (g.stagger_n > 0 && (int)s_ticket < g.stagger_n) {
+    // first round only: spread the start of the resident workgroups (they would otherwise all
+    // load, all compute and all wait at the same time, round after round)
+    const int steps = (int)((int64_t)s_ticket * g.stagger_steps / g.stagger_n);
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
+  const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
+  FuFac c;
+  const int64_t plane = (int64_t)g.t_max * D;
+  c.fd = a.scratch + d; c.fl1 = c.fd + plane; c.fl2 = c.fl1 + plane;
+  c.ncv = a.nconv[d]; c.n_shared = T >= 3 ? T - 2 : 0; c.T = T; c.D = D;
+  c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
+
+  double b[FU_FL];
+  double M[4] = {1.0, 0.0, 0.0, 1.0}, e[2] = {0.0, 0.0}, tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+  // a chunk whose frames (and the two before it) all lie in the stationary part of the shared
+  // factor runs with the factor in three registers
+  const bool cst_lane = wact && (j0 - 2 >= c.ncv) && (j1 <= c.n_shared) && n == FU_FL;
+  const bool cst = __all(cst_lane || !wact) && wact;
+
+  if (wact) {
+    const double rv0 = 1.0 / v0, rv1 = 1.0 / v1, rv2 = 1.0 / v2, rvb = 1.0 / kBigVar;
+    const double* f = a.feat + t0 * a.ld_feat + a.col0 + d;
+    if (cst) {
+      // interior chunk: rows j0-1 .. j0+FU_FL all exist and none is an edge frame
+      const double* r0 = f + j0 * a.ld_feat;
+#pragma unroll
+      for (int i = 0; i < FU_FL; ++i) b[i] = r0[(int64_t)i * a.ld_feat] * rv0;
+      {
+        double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int i = -1; i <= FU_FL; ++i) {
+          const double v = r0[(int64_t)i * a.ld_feat + D] * rv1;
+          if (i >= 1) b[i - 1] += 0.5 * (m2 - v);
+          m2 = m1; m1 = v;
+        }
+      }
+      {
+        double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int i = -1; i <= FU_FL; ++i) {
+          const double v = r0[(int64_t)i * a.ld_feat + 2 * D] * rv2;
+          if (i >= 1) b[i - 1] += (m2 - 2.0 * m1 + v);
+          m2 = m1; m1 = v;
+        }
+      }
+    } else {
+      auto rowp = [&](int64_t r) { return f + (r < 0 ? 0 : (r >= T ? T - 1 : r)) * a.ld_feat; };
+#pragma unroll
+      for (int i = 0; i < FU_FL; ++i) b[i] = i < n ? rowp(j0 + i)[0] * rv0 : 0.0;
+      {
+        double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int i = -1; i <= FU_FL; ++i) {
+          const int64_t r = j0 + i;
+          double v = 0.0;
+          if (i <= n && r >= 0 && r < T) v = rowp(r)[D] * ((r == 0 || r == T - 1) ? rvb : rv1);
+          if (i >= 1 && i - 1 < n) b[i - 1] += 0.5 * (m2 - v);
+          m2 = m1; m1 = v;
+        }
+      }
+      {
+        double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int i = -1; i <= FU_FL; ++i) {
+          const int64_t r = j0 + i;
+          double v = 0.0;
+          if (i <= n && r >= 0 && r < T) v = rowp(r)[2 * D] * ((r == 0 || r == T - 1) ? rvb : rv2);
+          if (i >= 1 && i - 1 < n) b[i - 1] += (m2 - 2.0 * m1 + v);
+          m2 = m1; m1 = v;
+        }
+      }
+    }
+    FU_STAMP(1);
+    if (cst) fu_fwd<FU_FL, true, true>(c, b, j0, n, 0.0, 0.0, M, e, tl);
+    else fu_fwd<FU_FL, false, true>(c, b, j0, n, 0.0, 0.0, M, e, tl);
+  }
+  FU_STAMP(2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lds_f[w][i][lane] = M[i];
+  lds_f[w][4][lane] = e[0];
+  lds_f[w][5][lane] = e[1];
+  __syncthreads();
+  // state = P s_in + q after the chunks in front of this wave; the whole workgroup for wave 0
+  double P[4] = {1.0, 0.0, 0.0, 1.0}, q[2] = {0.0, 0.0};
+  double Pw[4] = {1.0, 0.0, 0.0, 1.0}, qw[2] = {0.0, 0.0};
+  for (int cidx = 0; cidx < FW; ++cidx) {
+    if (cidx == w) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Pw[i] = P[i];
+      qw[0] = q[0]; qw[1] = q[1];
+      if (w != 0) break;
+    }
+    const double m00 = lds_f[cidx][0][lane], m01 = lds_f[cidx][1][lane], m10 = lds_f[cidx][2][lane],
+                 m11 = lds_f[cidx][3][lane], e0 = lds_f[cidx][4][lane], e1 = lds_f[cidx][5][lane];
+    const double p0 = m00 * P[0] + m01 * P[2], p1 = m00 * P[1] + m01 * P[3];
+    const double p2 = m10 * P[0] + m11 * P[2], p3 = m10 * P[1] + m11 * P[3];
+    const double q0 = m00 * q[0] + m01 * q[1] + e0, q1 = m10 * q[0] + m11 * q[1] + e1;
+    P[0] = p0; P[1] = p1; P[2] = p2; P[3] = p3; q[0] = q0; q[1] = q1;
+  }
+  unsigned long long* my_agg = g.agg + (int64_t)sc * 24 * Dp + dcol;
+  if (w == 0 && dok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fu_publish(my_agg + (int64_t)(2 * i) * Dp, Dp, P[i]);
+    fu_publish(my_agg + (int64_t)8 * Dp, Dp, q[0]);
+    fu_publish(my_agg + (int64_t)10 * Dp, Dp, q[1]);
+  }
+  FU_STAMP(3);
+  double s1 = 0.0, s2 = 0.0;
+  int budget = 1 << 21;          // ~2 s of polling at most
+  const int64_t ccol = (int64_t)db * 64 + (dok ? lane : 0);     // idle lanes re-read column 0
+  if (wact) {
+    for (int p = g.utt_sc0[u]; p < sc; ++p) {
+      const unsigned long long* pa = g.agg + (int64_t)p * 24 * Dp + ccol;
+      double av[6];
+      fu_consume6(pa, Dp, g.agg + (int64_t)p * 24 * Dp + 10 * Dp + (int64_t)db * 64, av, budget, g.err);
+      const double n1 = av[0] * s1 + av[1] * s2 + av[4], n2 = av[2] * s1 + av[3] * s2 + av[5];
+      s1 = n1; s2 = n2;
+    }
+  }
+  {
+    const double n1 = Pw[0] * s1 + Pw[1] * s2 + qw[0], n2 = Pw[2] * s1 + Pw[3] * s2 + qw[1];
+    s1 = n1; s2 = n2;
+  }
+  M[0] = 1.0; M[1] = 0.0; M[2] = 0.0; M[3] = 1.0; e[0] = e[1] = 0.0;
+  FU_STAMP(4);
+  if (wact) {
+    if (cst) fu_fwd<FU_FL, true, false>(c, b, j0, n, s1, s2, M, e, tl);
+    else fu_fwd<FU_FL, false, false>(c, b, j0, n, s1, s2, M, e, tl);
+    // backwards: the chunk's (M, e); the stationary test now needs frames j0 .. j1-1 only, which
+    // the forward test already covers
+    if (cst) fu_bwd<FU_FL, true, true>(c, b, j0, n, 0.0, 0.0, M, e, tl, nullptr, 0, false);
+    else fu_bwd<FU_FL, false, true>(c, b, j0, n, 0.0, 0.0, M, e, tl, nullptr, 0, false);
+  }
+  FU_STAMP(5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lds_b[w][i][lane] = M[i];
+  lds_b[w][4][lane] = e[0];
+  lds_b[w][5][lane] = e[1];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { P[i] = (i == 0 || i == 3) ? 1.0 : 0.0; Pw[i] = P[i]; }
+  q[0] = q[1] = qw[0] = qw[1] = 0.0;
+  for (int cidx = FW - 1; cidx >= 0; --cidx) {
+    if (cidx == w) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Pw[i] = P[i];
+      qw[0] = q[0]; qw[1] = q[1];
+      if (w != 0) break;
+    }
+    const double m00 = lds_b[cidx][0][lane], m01 = lds_b[cidx][1][lane], m10 = lds_b[cidx][2][lane],
+                 m11 = lds_b[cidx][3][lane], e0 = lds_b[cidx][4][lane], e1 = lds_b[cidx][5][lane];
+    const double p0 = m00 * P[0] + m01 * P[2], p1 = m00 * P[1] + m01 * P[3];
+    const double p2 = m10 * P[0] + m11 * P[2], p3 = m10 * P[1] + m11 * P[3];
+    const double q0 = m00 * q[0] + m01 * q[1] + e0, q1 = m10 * q[0] + m11 * q[1] + e1;
+    P[0] = p0; P[1] = p1; P[2] = p2; P[3] = p3; q[0] = q0; q[1] = q1;
+  }
+  if (w == 0 && dok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fu_publish(my_agg + (int64_t)(12 + 2 * i) * Dp, Dp, P[i]);
+    fu_publish(my_agg + (int64_t)20 * Dp, Dp, q[0]);
+    fu_publish(my_agg + (int64_t)22 * Dp, Dp, q[1]);
+  }
+  FU_STAMP(6);
+  s1 = s2 = 0.0;
+  if (wact) {
+    for (int p = g.utt_sc0[u + 1] - 1; p > sc; --p) {
+      const unsigned long long* pa = g.agg + (int64_t)p * 24 * Dp + 12 * Dp + ccol;
+      double av[6];
+      fu_consume6(pa, Dp, g.agg + (int64_t)p * 24 * Dp + 22 * Dp + (int64_t)db * 64, av, budget, g.err);
+      const double n1 = av[0] * s1 + av[1] * s2 + av[4], n2 = av[2] * s1 + av[3] * s2 + av[5];
+      s1 = n1; s2 = n2;
+    }
+  }
+  {
+    const double n1 = Pw[0] * s1 + Pw[1] * s2 + qw[0], n2 = Pw[2] * s1 + Pw[3] * s2 + qw[1];
+    s1 = n1; s2 = n2;
+  }
+  if (wact) {
+    double* o = a.out + t0 * a.ld_out + a.ocol0 + d;
+    if (cst) fu_bwd<FU_FL, true, false>(c, b, j0, n, s1, s2, M, e, tl, o, a.ld_out, dok);
+    else fu_bwd<FU_FL, false, false>(c, b, j0, n, s1, s2, M, e, tl, o, a.ld_out, dok);
+  }
+  FU_STAMP(7);
+#undef FU_STAMP
+}
+
 // np.gradient(x, axis=0) in float32 (misc/utils.py:103-105): one-sided at the ends, central
 // inside; a single-frame utterance yields 0 (numpy raises there; the reference never hits it).
 __global__ void gradient_f32_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int dim,
@@ -591,6 +1036,96 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
     dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
     hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
     ITTS_LAUNCH_CHECK();
+    return ITTS_OK;
+  }
+  // fused single-pass solve (one read of the input, one write of the output) unless an utterance
+  // is so long that its super-chunks could exhaust the resident workgroups (see the kernel)
+  // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW> picks one of the
+  // compiled variants; experiments)
+  int FL = 16, FW = 16;
+  if (const char* geom = getenv("ITTS_MLPG_GEOM")) sscanf(geom, "%dx%d", &FL, &FW);
+  const int64_t sc_frames = (int64_t)FL * FW;
+  const char* force = getenv("ITTS_MLPG_MULTIPASS");
+  if (t_max <= sc_frames * FU_MAX_SC && !(force && force[0] == '1')) {
+    std::vector<int> tab;
+    std::vector<int> sc_utt, sc_k0, utt_sc0(n_utts + 1, 0);
+    for (int u = 0; u < n_utts; ++u) {
+      const int64_t T = h_offsets[u + 1] - h_offsets[u];
+      utt_sc0[u] = (int)sc_utt.size();
+      const int K = T > 0 ? (int)((T + FL - 1) / FL) : 0;
+      for (int k0 = 0; k0 < K; k0 += FW) {
+        sc_utt.push_back(u);
+        sc_k0.push_back(k0);
+      }
+    }
+    utt_sc0[n_utts] = (int)sc_utt.size();
+    const int n_sc = (int)sc_utt.size();
+    const int nblk = (dim + 63) / 64;
+    tab.insert(tab.end(), sc_utt.begin(), sc_utt.end());
+    tab.insert(tab.end(), sc_k0.begin(), sc_k0.end());
+    tab.insert(tab.end(), utt_sc0.begin(), utt_sc0.end());
+    tab.push_back(0);                                           // ticket counter
+    tab.push_back(0);                                           // error flag
+    const size_t tab_bytes = (tab.size() * sizeof(int) + 15) / 16 * 16;
+    const size_t agg_bytes = (size_t)n_sc * 24 * nblk * 64 * sizeof(unsigned long long);
+    char* blk = nullptr;
+    ITTS_HIP_CHECK(hipMallocAsync((void**)&blk, tab_bytes + agg_bytes, s));
+    ITTS_HIP_CHECK(hipMemcpyAsync(blk, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    ITTS_HIP_CHECK(hipMemsetAsync(blk + tab_bytes, 0, agg_bytes, s));
+    FusedArgs g;
+    g.a = a;
+    g.t_max = (int)t_max;
+    g.sc_utt = reinterpret_cast<const int*>(blk);
+    g.sc_k0 = g.sc_utt + n_sc;
+    g.utt_sc0 = g.sc_k0 + n_sc;
+    g.ticket = reinterpret_cast<unsigned*>(const_cast<int*>(g.utt_sc0 + n_utts + 1));
+    g.err = reinterpret_cast<int*>(g.ticket + 1);
+    g.n_sc = n_sc;
+    g.nblk = nblk;
+    g.agg = reinterpret_cast<unsigned long long*>(blk + tab_bytes);
+    g.stagger_n = g.stagger_steps = 0;
+    if (const char* st = getenv("ITTS_MLPG_STAGGER")) sscanf(st, "%d,%d", &g.stagger_n, &g.stagger_steps);
+    g.trace = nullptr;
+    const char* trace_path = getenv("ITTS_MLPG_TRACE");
+    const size_t trace_words = (size_t)n_sc * nblk * FW * 8;
+    if (trace_path && trace_path[0]) {
+      ITTS_HIP_CHECK(hipMalloc((void**)&g.trace, trace_words * 8));
+      ITTS_HIP_CHECK(hipMemset(g.trace, 0, trace_words * 8));
+    }
+    const dim3 grid(n_sc * nblk);
+#define FU_LAUNCH(fl, fw, wpe)                                                                  \
+  if (FL == fl && FW == fw) {                                                                    \
+    hipLaunchKernelGGL((mlpg_fused_kernel<fl, fw, wpe>), grid, dim3(fw * 64), 0, s, g);          \
+    launched = true;                                                                             \
+  }
+    bool launched = false;
+    FU_LAUNCH(16, 16, 4)
+    FU_LAUNCH(32, 16, 4)
+    FU_LAUNCH(16, 8, 4)
+#undef FU_LAUNCH
+    ITTS_REQUIRE(launched, "unknown ITTS_MLPG_GEOM");
+    ITTS_LAUNCH_CHECK();
+    if (getenv("ITTS_MLPG_CHECK")) {      // debugging aid: did a wait give up?
+      int herr = 0;
+      ITTS_HIP_CHECK(hipStreamSynchronize(s));
+      ITTS_HIP_CHECK(hipMemcpy(&herr, g.err, sizeof(int), hipMemcpyDeviceToHost));
+      ITTS_REQUIRE(herr == 0, "fused solve: a workgroup ran out of its polling budget");
+    }
+    if (g.trace) {          // debugging aid: per-wave phase stamps (100 MHz wall clock) as text
+      std::vector<unsigned long long> h(trace_words);
+      ITTS_HIP_CHECK(hipStreamSynchronize(s));
+      ITTS_HIP_CHECK(hipMemcpy(h.data(), g.trace, trace_words * 8, hipMemcpyDeviceToHost));
+      ITTS_HIP_CHECK(hipFree(g.trace));
+      if (FILE* tf = fopen(trace_path, "w")) {
+        for (size_t r = 0; r < trace_words / 8; ++r) {
+          fprintf(tf, "%zu %zu", r / FW, r % FW);
+          for (int i = 0; i < 8; ++i) fprintf(tf, " %llu", h[r * 8 + i]);
+          fprintf(tf, "\n");
+        }
+        fclose(tf);
+      }
+    }
+    ITTS_HIP_CHECK(hipFreeAsync(blk, s));
     return ITTS_OK;
   }
   double* extra = reinterpret_cast<double*>(reinterpret_cast<char*>(d_nconv) + ((int64_t)dim * 4 + 16) / 8 * 8 + 8);
