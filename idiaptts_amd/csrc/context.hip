@@ -1,4 +1,6 @@
 // Device context: twiddle table and SPTK frequency-warping matrices (see context.h).
+#include <cstdlib>
+
 #include "context.h"
 
 #include <atomic>
@@ -36,7 +38,11 @@ static int create_context(DeviceContext* ctx) {
   ITTS_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, 64 * sizeof(int64_t), hipHostMallocDefault));
   hipMemPool_t pool;
   if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {
-    uint64_t keep = 64ull << 30;
+    // scratch the stream-ordered pool keeps between calls (invisible to PyTorch's allocator):
+    // ITTS_POOL_KEEP_GB, default 8 GB -- enough for a 256-utterance analysis batch
+    uint64_t keep_gb = 8;
+    if (const char* e = getenv("ITTS_POOL_KEEP_GB")) keep_gb = strtoull(e, nullptr, 10);
+    uint64_t keep = keep_gb << 30;
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
   }
   return ITTS_OK;

@@ -143,6 +143,9 @@ class LSTMLayerFunction(torch.autograd.Function):
                                          _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y),
                                          _iptr(gates), _iptr(csave), _iptr(hn), _iptr(cn),
                                          _iptr(state), ops._stream()), "itts_lstm_layer_fwd")
+        ctx.set_materialize_grads(False)      # unused h_n / c_n arrive as None in backward
+        if not keep:
+            ctx.mark_non_differentiable(y, hn, cn)
         if keep:
             empty = torch.empty(0, device=dev)
             ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, csave, y,
@@ -154,8 +157,13 @@ class LSTMLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dhn, dcn):
+        if dhn is not None or dcn is not None:
+            raise NotImplementedError("Gradients through the final states h_n / c_n are not "
+                                      "implemented (the acoustic models only use the output).")
         L = _lib.load()
         x2, w_ih_cat, w_hh, gates, csave, y, h0, c0 = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(y)
         pb = ctx.pb
         F, H, ndir, has_h0, has_c0 = ctx.dims
         hprev = pb.shift(y, h0 if has_h0 else None, ndir, H)
@@ -217,6 +225,9 @@ class GRULayerFunction(torch.autograd.Function):
                                         _iptr(pb.d_rev_row), T, B, H, ndir, _iptr(y), _iptr(gates),
                                         _iptr(hn), _iptr(state), ops._stream()),
                    "itts_gru_layer_fwd")
+        ctx.set_materialize_grads(False)
+        if not keep:
+            ctx.mark_non_differentiable(y, hn)
         if keep:
             ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, y,
                                   h0c if h0c is not None else torch.empty(0, device=dev))
@@ -226,8 +237,13 @@ class GRULayerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dhn):
+        if dhn is not None:
+            raise NotImplementedError("Gradients through the final state h_n are not implemented "
+                                      "(the acoustic models only use the output).")
         L = _lib.load()
         x2, w_ih_cat, w_hh, gates, y, h0 = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(y)
         pb = ctx.pb
         F, H, ndir, has_h0 = ctx.dims
         hprev = pb.shift(y, h0 if has_h0 else None, ndir, H)

@@ -47,6 +47,17 @@ def _unpad_rows(x, ndir, H, Hp):
     return x.reshape(x.shape[0], ndir, Hp)[:, :, :H].reshape(x.shape[0], ndir * H)
 
 
+def _shared_initial_state(h):
+    """The recurrence kernels take ONE initial state per layer and direction, shared by all rows
+    (what RNNWrapper.init_hidden passes: a [.., 1, H] vector expanded over the batch).  Anything
+    else would silently be replaced by row 0's state, so it is refused."""
+    if h is None or h.shape[1] == 1 or h.stride(1) == 0:
+        return
+    if not bool((h == h[:, :1]).all()):
+        raise NotImplementedError("Per-sequence initial states are not implemented: all rows of "
+                                  "hx must be equal (expand one [layers*dirs, 1, H] state).")
+
+
 class LSTM(nn.Module):
     """Drop-in for torch.nn.LSTM(input_size, hidden_size, num_layers, bidirectional, batch_first)
     as RNNWrapper uses it (rnn_dyn/RNNWrapper.py:45-54).  forward takes the padded tensor and
@@ -92,6 +103,8 @@ class LSTM(nn.Module):
         h0 = c0 = None
         if hx is not None:
             h0, c0 = hx      # [num_layers*ndir, B, H]; RNNWrapper expands one vector per row
+            _shared_initial_state(h0)
+            _shared_initial_state(c0)
         hn_all, cn_all = [], []
         for layer in range(self.num_layers):
             hl = cl = None
@@ -153,6 +166,7 @@ class GRU(nn.Module):
             lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
         pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
         x = pb.pack(input_)
+        _shared_initial_state(hx)
         hn_all = []
         for layer in range(self.num_layers):
             # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0

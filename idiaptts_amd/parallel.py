@@ -96,3 +96,33 @@ def allreduce_module_grads_(params, local_weight, group=None):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     for g, synced in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
         g.copy_(synced)
+
+
+def broadcast_int(value, src=0, group=None, device=None):
+    """The integer `value` of rank `src` on every rank (e.g. the seed of the epoch's shuffling)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def broadcast_tensors_(tensors, src=0, group=None):
+    """In-place broadcast of a list of tensors from rank `src` (model parameters, buffers,
+    optimiser state after create / load): one flat message per dtype and device."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    buckets = {}
+    for t in tensors:
+        if torch.is_tensor(t) and t.numel() > 0:
+            buckets.setdefault((t.dtype, t.device), []).append(t)
+    for ts in buckets.values():
+        flat = torch._utils._flatten_dense_tensors([t.detach() for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        for t, synced in zip(ts, torch._utils._unflatten_dense_tensors(flat, ts)):
+            t.detach().copy_(synced)
+
+
+def barrier(group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)

@@ -469,13 +469,19 @@ class ModularModelHandlerPyTorch(object):
         collate_fn = self.prepare_batch if collate_fn is None else collate_fn
         rank, world = parallel.dp_rank_world()
         extra = {}
+        generator = None
         if world > 1:
-            # One process per GPU: every rank draws the same global batches (same seed, same
-            # sampler) and keeps its own samples; common_divisor makes the split even.
+            # One process per GPU: every rank draws the same global batches and keeps its own
+            # samples; common_divisor makes the split even.  "The same batches" must not depend on
+            # the user seeding every rank alike: the sampler's generator is seeded with a value
+            # rank 0 draws and broadcasts.
             common_divisor = max(common_divisor, world)
             extra["shard"] = (rank, world)
+            seed = parallel.broadcast_int(int(torch.empty((), dtype=torch.int64).random_().item()),
+                                          device=self._dist_device())
+            generator = torch.Generator().manual_seed(seed)
         return DataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle,
-                          num_workers=num_workers,
+                          num_workers=num_workers, generator=generator,
                           collate_fn=partial(collate_fn, common_divisor=common_divisor,
                                              batch_first=batch_first, **extra),
                           pin_memory=pin_memory and torch.cuda.is_available())
@@ -646,7 +652,37 @@ class ModularModelHandlerPyTorch(object):
         self.model = model_config.create_model()
         if use_gpu:
             self.model = self.model.cuda()
+        self.sync_from_rank0()
         return self.model
+
+    @staticmethod
+    def _dist_device():
+        """Device collectives of small host values run on: the current GPU under RCCL ('nccl'),
+        host memory under gloo (None)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return None
+
+    def sync_from_rank0(self, optimiser=True):
+        """Data parallelism (one process per GPU) needs identical replicas: after a model has been
+        created or loaded every rank takes rank 0's parameters, buffers and optimiser state, so
+        nothing depends on the ranks having been seeded alike.  No-op on a single process."""
+        if parallel.dp_rank_world()[1] == 1 or self.model is None:
+            return
+        tensors = [p.data for p in self.model.parameters()] + [b for b in self.model.buffers()]
+        if optimiser and self.optimiser is not None:
+            for st in self.optimiser.state.values():
+                tensors += [v for v in st.values() if torch.is_tensor(v)]
+        if self._dist_device() is None:       # gloo moves host memory
+            host = [t.detach().cpu() for t in tensors]
+            parallel.broadcast_tensors_(host)
+            for t, h in zip(tensors, host):
+                t.detach().copy_(h)
+        else:
+            parallel.broadcast_tensors_(tensors)
+        if self._resident is not None:
+            self._resident["synced"] = False
 
     def set_losses(self, losses):
         """Loss modules (the reference's signature, :550-551); loss configs are instantiated."""
@@ -660,6 +696,7 @@ class ModularModelHandlerPyTorch(object):
             if cls is None:
                 raise NotImplementedError("Optimiser type {} is not implemented.".format(hparams))
             self.optimiser = cls(self.model.parameters(), **optimiser_args)
+            self._reattach_ema()
             return
         if self.optimiser is None or reset:
             if hparams.optimiser is None:
@@ -686,9 +723,30 @@ class ModularModelHandlerPyTorch(object):
                                               .format(hparams.optimiser_type))
             else:
                 self.optimiser = hparams.optimiser(self.model.parameters())
+            self._reattach_ema()
         if not hparams.use_saved_learning_rate and "lr" in hparams.optimiser_args:
             for g in self.optimiser.param_groups:
                 g['lr'] = hparams.optimiser_args["lr"]
+
+    def _reattach_ema(self):
+        """A new optimiser means new flat buffers: an existing EMA either moves its shadow into
+        them (fused update inside the step) or goes back to the separate update kernel -- it must
+        never be left pointing at a discarded optimiser (its update would silently stop)."""
+        if self.ema is None:
+            return
+        attach = getattr(self.optimiser, "attach_ema", None)
+        if attach is None or not attach(self.ema):
+            self.ema.fused = False
+
+    def _reseed_ema(self):
+        """After parameters were loaded the shadow restarts from them (reference: the EMA is
+        created from the model it averages, ExponentialMovingAverage.py:13-30)."""
+        if self.ema is None:
+            return
+        with torch.no_grad():
+            for name, p in self.model.named_parameters():
+                if name in self.ema.shadow:
+                    self.ema.shadow[name].copy_(p.data)
 
     def set_scheduler(self, hparams, current_epoch=None, current_step=None, reset=False):
         """reference :585-656: Plateau (stepped with the validation loss), Exponential and Noam
@@ -997,9 +1055,14 @@ class ModularModelHandlerPyTorch(object):
             suffix = "s{}".format(step)
         else:
             raise NotImplementedError()
+        self._resident_sync_to_module()
+        if parallel.dp_rank_world()[0] != 0:
+            # data parallel: the replicas are identical, rank 0 writes; nobody runs ahead of the
+            # files (a load may follow)
+            parallel.barrier()
+            return
         self.logger.info("Save {} checkpoint to {}.".format(suffix, model_path))
         os.makedirs(model_path, exist_ok=True)
-        self._resident_sync_to_module()
         config = self.model_config if self.model_config is not None \
             else getattr(self.model, "config", None)
         if config is not None:
@@ -1023,12 +1086,16 @@ class ModularModelHandlerPyTorch(object):
         if self.scheduler is not None:
             save({"params": self.scheduler.state_dict(), "epoch": epoch, "step": step},
                  os.path.join(model_path, "scheduler_" + suffix))
+        if parallel.dp_rank_world()[1] > 1:
+            self.wait_for_checkpoints()
+            parallel.barrier()
 
     def load_checkpoint(self, hparams, model_path, epoch=None, ignore_layers=True,
                         load_optimiser=True, load_scheduler=True, step=None, verbose=True,
                         load_best_model=False):
         """reference :125-262.  Returns (best_loss, epoch, step)."""
         self.wait_for_checkpoints()
+        parallel.barrier()
         assert load_best_model or step is None or epoch is None, \
             "Only epoch ({}) OR step ({}) can be not None".format(epoch, step)
         if load_best_model or epoch == -1 or step == -1:
@@ -1085,6 +1152,8 @@ class ModularModelHandlerPyTorch(object):
                                      step if step is not None else sched['step'], hparams)
         if self._resident is not None:
             self._resident["synced"] = False      # flat buffers follow the loaded state
+        self._reseed_ema()
+        self.sync_from_rank0()
         return best_loss, epoch, step
 
     @staticmethod

@@ -195,3 +195,72 @@ def test_handler_data_parallel_step_equals_single_process():
     loss.backward()
     assert abs(ret["loss"] - float(loss)) < 1e-12
     assert np.abs(ret["grad"] - _flat_grad(model).numpy()).max() < 1e-12
+
+
+class _IdDataset(torch.utils.data.Dataset):
+    def __len__(self):
+        return 24
+
+    def __getitem__(self, i):
+        return {"x": np.full((3 + i % 4, 2), float(i), dtype=np.float32), "_id_list": "utt%02d" % i}
+
+
+def _replica_worker(rank, world, port, tmp, ret):
+    """Unseeded ranks (different RNG states on purpose): create_model must leave identical
+    replicas, the train loader identical shuffling, checkpoints are written once and load alike."""
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + 17 * rank)
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import \
+        NamedForwardWrapper
+    hp = types.SimpleNamespace(model_type="RNNDYN-1_TANH_8-1_FC_3", batch_first=False, dropout=0.0)
+    h = Handler()
+    h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((5,), hp),
+                                              input_names=["x"], batch_first=False, name="AM",
+                                              output_names=["pred"]), use_gpu=False)
+    flat = torch.cat([p.detach().reshape(-1) for p in h.model.parameters()]).numpy().copy()
+    loader = h._get_dataloader(batch_size=6, dataset=_IdDataset(), shuffle=True, num_workers=0,
+                               batch_first=False, pin_memory=False)
+    batches = [list(data["_id_list"]) for data, _ in loader]
+    # checkpoint: rank 0 writes, both load the same thing
+    with torch.no_grad():
+        for p in h.model.parameters():
+            p.add_(float(rank))                  # make the replicas differ before saving
+    h.save_checkpoint(tmp, epoch=1, step=3)
+    from idiaptts_amd.src.ExtendedHParams import ExtendedHParams
+    hparams = ExtendedHParams.create_hparams()
+    hparams.use_gpu = False
+    best, epoch, step = h.load_checkpoint(hparams, tmp, epoch=1, load_optimiser=False)
+    loaded = torch.cat([p.detach().reshape(-1) for p in h.model.parameters()]).numpy().copy()
+    ret[rank] = (flat, batches, loaded, sorted(os.listdir(tmp)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_loaders_and_checkpoints_do_not_depend_on_per_rank_seeds(tmp_path):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, str(tmp_path), ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    (flat0, b0, loaded0, files0), (flat1, b1, loaded1, files1) = ret[0], ret[1]
+    assert np.array_equal(flat0, flat1)                       # rank 0's initialisation everywhere
+    assert len(b0) == len(b1) == 4
+    seen = []
+    for x0, x1 in zip(b0, b1):                                # halves of the same global batch
+        assert len(x0) == len(x1) == 3 and not set(x0) & set(x1)
+        seen += x0 + x1
+    assert sorted(seen) == ["utt%02d" % i for i in range(24)]  # one shared permutation
+    assert np.array_equal(loaded0, loaded1)                   # both loaded rank 0's file
+    assert np.array_equal(loaded0, flat0)                     # ... which held rank 0's (+0) weights
+    assert "params_e1" in files0 and not any(f.endswith(".tmp") for f in files0)

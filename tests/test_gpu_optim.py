@@ -123,3 +123,65 @@ def test_grad_norm_accum_large_buffers(gpu):
     assert float(acc) == float(torch.maximum(x.abs().max(), y.abs().max()))
     ops.grad_norm_accum(x[:0], acc, 2, accumulate=False)          # empty buffer -> 0
     assert float(acc) == 0.0
+
+
+def test_ema_keeps_averaging_after_the_optimiser_is_replaced(gpu, tmp_path):
+    """Loading a checkpoint (or resetting the optimiser) builds a new HipAdam with new flat
+    buffers.  An existing EMA must follow: re-attached to the new optimiser (fused update) and its
+    shadow restarted from the loaded parameters -- it must never keep pointing at the discarded
+    optimiser, where its update would silently stop."""
+    import types
+    from idiaptts_amd.src.ExtendedHParams import ExtendedHParams
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import (
+        ExponentialMovingAverage, ModularModelHandlerPyTorch as Handler)
+    from idiaptts_amd.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import \
+        NamedForwardWrapper
+    torch.manual_seed(3)
+    hp = types.SimpleNamespace(model_type="RNNDYN-1_TANH_16-1_FC_4", batch_first=False, dropout=0.0)
+    h = Handler()
+    h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((6,), hp),
+                                              input_names=["questions"], batch_first=False,
+                                              name="AM", output_names=["pred"]))
+    hparams = ExtendedHParams.create_hparams()
+    hparams.use_gpu = True
+    hparams.optimiser_args["lr"] = 1e-2
+    h.set_optimiser(hparams)
+    h.set_losses([NamedLoss.Config(name="MSELoss_y", type_="MSELoss", seq_mask="y_mask",
+                                   input_names=["y", "pred"], batch_first=False)])
+    h.ema = ExponentialMovingAverage(h.model, 0.5)
+    assert h.optimiser.attach_ema(h.ema) and h.ema.fused
+    rng = np.random.default_rng(0)
+    batch = [{"questions": rng.normal(size=(t, 6)).astype(np.float32),
+              "y": rng.normal(size=(t, 4)).astype(np.float32)} for t in (9, 5)]
+    data, lengths = Handler.prepare_batch(batch, batch_first=False, mask_keys=("y",))
+
+    def shadow():
+        return torch.cat([s.reshape(-1) for s in h.ema.shadow.values()]).clone()
+
+    def params():
+        return torch.cat([p.detach().reshape(-1) for p in h.model.parameters()]).clone()
+
+    h.process_batch(data, lengths, 0, training=True)
+    h.save_checkpoint(str(tmp_path), epoch=1, step=1)
+    h.process_batch(data, lengths, 1, training=True)
+    old_opt = h.optimiser
+    h.load_checkpoint(hparams, str(tmp_path), epoch=1)
+    assert h.optimiser is not old_opt
+    # the checkpoint holds the averaged parameters; the shadow restarts from what was loaded
+    assert torch.equal(shadow(), params())
+    s0 = shadow()
+    for step in range(3):
+        h.process_batch(data, lengths, step + 2, training=True)
+        s1 = shadow()
+        assert not torch.equal(s0, s1), "the EMA stopped following the parameters"
+        # shadow = 0.5 * shadow + 0.5 * param after every step
+        s0 = s1
+    p = params()
+    assert float((s1 - p).abs().max()) > 0 and float((s1 - p).abs().max()) < 0.1
+    # same with an optimiser that cannot fuse the update: falls back to the separate kernel
+    h.set_optimiser("SGD", lr=1e-2)
+    assert not h.ema.fused
+    h.process_batch(data, lengths, 9, training=True)
+    assert not torch.equal(shadow(), s1)
