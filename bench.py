@@ -20,7 +20,102 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F64_TFLOPS = 78.6         # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
 PEAK_HBM_GBS = 8000.0
+
+
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count()}
+
+
+def _oracle_utterance(args):
+    """Pool worker: one synthetic utterance through the C oracle (analysis, then synthesis)."""
+    fs, seed, seconds = args
+    from idiaptts_amd.bench_support import make_audio
+    from oracle import capi
+    from idiaptts_amd import lib
+    L = lib.load()
+    order, alpha = 59, L.itts_mcep_alpha(fs)
+    n_fft = L.itts_cheaptrick_fft_size(fs, 71.0)
+    r = make_audio(fs, seconds, seed)
+    a = time.perf_counter()
+    f0c, spc, apc = capi.wav2world(r, fs)
+    bapc = capi.code_aperiodicity(apc, fs)
+    mcc = capi.mcep(np.sqrt(spc), order, alpha)
+    b = time.perf_counter()
+    la = capi.mgc2sp_logamp(mcc, alpha, n_fft)
+    pw = np.exp(la.astype(np.float32)).astype(np.float64) ** 2
+    apd = capi.decode_aperiodicity(bapc, fs, n_fft)
+    capi.synthesize(f0c, pw, apd, fs)
+    c = time.perf_counter()
+    return len(r) / fs, b - a, c - b
+
+
+def cpu_baseline_world_pool(fs=16000, seconds=4.0):
+    """the reference's feature extraction is an embarrassingly parallel loop
+    over files (WorldFeatLabelGen.py:996); its best case on this host is one process per core.
+    Forked BEFORE anything touches HIP: every core analyses and re-synthesises one utterance
+    through the C oracle; the figure is whole-pool wall time over the pool's audio."""
+    import multiprocessing as mp
+    n = os.cpu_count() or 1
+    rng = np.random.default_rng(5)
+    jobs = [(fs, 7000 + i, float(seconds * rng.uniform(0.8, 1.2))) for i in range(n)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(n) as pool:
+        res = pool.map(_oracle_utterance, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    audio = sum(r[0] for r in res)
+    return {"kind": "port", "cores": n, "processes": n,
+            "sample": "{} utterances ({:.0f} s of audio), one per process, C oracle analysis + "
+                      "synthesis, wall time incl. process start".format(n, audio),
+            "analysis_plus_synthesis_rtf": wall / audio,
+            "per_core_analysis_rtf": float(np.mean([r[1] / r[0] for r in res])),
+            "per_core_synthesis_rtf": float(np.mean([r[2] / r[0] for r in res]))}
+
+
+def cpu_baseline_bilstm(n_utts=4, max_seconds=20.0):
+    """The reference's config-3 stack on the host: torch.nn.LSTM(425, 512, 3, bidirectional) on a
+    PackedSequence (rnn_dyn/RNNWrapper.py:45-107) + Linear(1024, 187), masked MSE mean_per_frame,
+    Adam; a bounded sample (a few steps on a small padded batch)."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from idiaptts_amd.bench_support import make_ff_batch, pad_batch
+    torch.manual_seed(0)
+    lstm = torch.nn.LSTM(425, 512, 3, bidirectional=True)
+    fc = torch.nn.Linear(1024, 187)
+    opt = torch.optim.Adam(list(lstm.parameters()) + list(fc.parameters()), lr=1e-3)
+    x, y, lengths = make_ff_batch(n_utts, seed=7)
+    lt = torch.from_numpy(lengths)
+    xp, yp = pad_batch(x, lt).transpose(0, 1).contiguous(), pad_batch(y, lt).transpose(0, 1).contiguous()
+    T = xp.shape[0]
+    mask = (torch.arange(T)[:, None] < lt[None, :]).unsqueeze(-1).float()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def step():
+        out, _ = lstm(pack_padded_sequence(xp, lt, enforce_sorted=False))
+        out, _ = pad_packed_sequence(out, total_length=T)
+        pred = fc(out)
+        loss = ((pred - yp) ** 2 * mask).sum() / (float(lt.sum()) * 187)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 3 and time.perf_counter() - t0 < max_seconds:
+        step()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"kind": "port", "cores": torch.get_num_threads(), "value": float(lengths.sum()) * steps / dt,
+            "unit": "valid frames/s",
+            "sample": "{} training steps of torch.nn.LSTM(425,512,3,bidirectional)+Linear on {} "
+                      "padded utterances ({} valid frames)".format(steps, n_utts, int(lengths.sum()))}
 
 
 def hip_event_time_ms(fn, stream, iters):
@@ -169,6 +264,34 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         "synthesis_algorithmic_GBps": frames * ((n_fft // 2 + 1) * 16 + 8 + fs // 200 * 4)
         / (ms_sy * 1e-3) / 1e9,
     }
+    # rooflines (the WORLD kernels are HBM-bound by contract; in fact they are
+    # fp64 FFT / LDS work, so the fp64 rate is stated beside the algorithmic bandwidth).  FLOPs per
+    # frame: analysis ~ DIO 3.5 kFLOP/sample + CheapTrick / D4C FFTs + mcep Newton (measured
+    # iterations x (2 FFT + 3 warping products + 60^3/3 solve)); synthesis 7 FFT-n_fft per pulse.
+    w = res[key]
+    it = w["mcep_newton_iters_mean"]
+    lg = np.log2(n_fft)
+    fft = 2.5 * n_fft * lg                     # real FFT of n_fft points
+    K = n_fft // 2 + 1
+    an_flops = (fs // 200) * 3500 + 3 * fft + 8 * 2.5 * 2 * n_fft * (lg + 1) + \
+        2 * K * 60 + it * (2 * fft + 2 * K * (60 + 60 + 119) + 60 ** 3 / 3)
+    sy_flops = 7 * fft * 1.3 + 2 * 60 * K
+    nap = L.itts_num_aperiodicities(fs) if n_ranks >= 1 else 1
+    w["analysis_roofline"] = {
+        "bound": "hbm", "kernel": "mcls_solve_wave_kernel + d4c_kernel + gemm_f64_kernel (see profiles/)",
+        "achieved": w["analysis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": w["analysis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS, "traffic": None,
+        "algorithmic_bytes_per_frame": fs // 200 * 8 + (61 + nap) * 4,
+        "fp64_tflops": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks,
+        "fp64_frac_of_peak": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS,
+        "fp64_flops_per_frame_estimate": an_flops}
+    w["synthesis_roofline"] = {
+        "bound": "hbm", "kernel": "syn_pulse_kernel",
+        "achieved": w["synthesis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": w["synthesis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS, "traffic": None,
+        "algorithmic_bytes_per_frame": (n_fft // 2 + 1) * 16 + 8 + fs // 200 * 4,
+        "fp64_tflops": frames * sy_flops / (ms_sy * 1e-3) / 1e12 / n_ranks,
+        "fp64_frac_of_peak": frames * sy_flops / (ms_sy * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS}
     if with_mlpg:
         # MLPG on [T, 187] (62 static dims in 3 streams), 256 utterances of 2-10 s (SURVEY.md section 8d,
         # config 4): algorithmic 2000 B / frame
@@ -182,11 +305,15 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         ms_ml = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off),
                                                stream, 7), dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
+        gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
         res["mlpg"] = {"utterances": 256 * n_ranks, "frames": ml_frames, "ms": ms_ml,
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
-                       "algorithmic_GBps": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9,
-                       "frac_of_hbm_peak": ml_frames * 2000 / (ms_ml * 1e-3) / 1e9 / PEAK_HBM_GBS
-                       / n_ranks}
+                       "algorithmic_GBps": gbs,
+                       "frac_of_hbm_peak": gbs / PEAK_HBM_GBS / n_ranks,
+                       "roofline": {"bound": "hbm", "kernel": "mlpg_fused_kernel",
+                                    "achieved": gbs / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": gbs / PEAK_HBM_GBS / n_ranks, "traffic": None,
+                                    "algorithmic_bytes_per_frame": 2000}}
     if with_cpu:
         from oracle import capi
         t0 = time.perf_counter()
@@ -217,11 +344,27 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     return res
 
 
-def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM", rank=0, world=1):
-    """BASELINE config 3: 425 -> 3 x 512 BiLSTM -> 187, batch 64 padded utterances per GPU, Adam,
+def rnn_flops_per_frame(in_dim=425, H=512, layers=3, out_dim=187, gates=4):
+    """fwd + bwd GEMM FLOPs per valid frame of the (bi)recurrent stack: input projections, the
+    recurrent products (h W_hh^T forward, dG W_hh and dW_hh backward), dX of every layer but the
+    first, and the output layer."""
+    f = 0
+    for layer in range(layers):
+        k = in_dim if layer == 0 else 2 * H
+        per_dir = 2 * (k + H) * gates * H                    # forward
+        per_dir += 2 * k * gates * H + 2 * 2 * H * gates * H    # dW_ih, dG W_hh, dW_hh
+        if layer > 0:
+            per_dir += 2 * k * gates * H                     # dX
+        f += 2 * per_dir
+    return f + 3 * 2 * 2 * H * out_dim
+
+
+def bilstm_section(dev, n_utts=64, steps=6, cell="LSTM", rank=0, world=1, key=None):
+    """BASELINE config 3: 425 -> 3 x 512 BiLSTM -> 187, `n_utts` padded utterances per GPU, Adam,
     fp32, through the drop-in module stack (RNNDyn + NamedLoss + fused HIP Adam).  With world > 1
-    every rank trains on its own 64 utterances and the handler sums the frame-weighted gradients
-    over RCCL (weak scaling); the reported rate is the whole job's."""
+    every rank trains on its own utterances and the handler sums the frame-weighted gradients over
+    RCCL; the reported rate is the whole job's.  Timed with events on the launch stream over
+    `steps` steps after two warm-up steps."""
     import types
     from idiaptts_amd import parallel
     from idiaptts_amd.bench_support import make_ff_batch
@@ -256,23 +399,103 @@ def bilstm_section(dev, n_utts=64, steps=3, cell="LSTM", rank=0, world=1):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    h.process_batch(data, lens, 0, training=True)      # warm-up
+    for s in range(2):
+        ld, _ = h.process_batch(data, lens, s, training=True)      # warm-up
     barrier()
-    t0 = time.perf_counter()
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
     for s in range(steps):
-        ld, _ = h.process_batch(data, lens, s + 1, training=True)
+        ld, _ = h.process_batch(data, lens, s + 2, training=True)
+    e1.record(stream)
+    e1.synchronize()
+    dt = e0.elapsed_time(e1) * 1e-3 / steps
     barrier()
-    dt = (time.perf_counter() - t0) / steps
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
     frames = int(parallel.global_sum(int(lengths.sum()), device=dev))
-    return {"bi" + cell.lower(): {
+    gates = 4 if cell == "LSTM" else 3
+    tflops = rnn_flops_per_frame(gates=gates) * frames / dt / 1e12
+    return {key or ("bi" + cell.lower()): {
         "model": "425 -> 3x512 Bi{} -> 187".format(cell), "utterances_per_gpu": n_utts,
-        "n_gpus": world, "valid_frames": frames, "max_frames": int(lengths.max()),
+        "utterances_global": n_utts * world, "n_gpus": world, "valid_frames": frames,
+        "max_frames": int(lengths.max()), "steps_timed": steps,
+        "timing": "HIP events on the launch stream, 2 warm-up steps",
         "ms_per_step": dt * 1e3, "valid_frames_per_s": frames / dt,
-        "loss": ld["MSELoss_acoustic_features"]}}
+        "loss": ld["MSELoss_acoustic_features"],
+        "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel + {}_step_fwd/bwd_kernel".format(
+                         cell.lower()),
+                     "achieved": tflops / world, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / world / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                     "algorithmic_flops_per_frame": rnn_flops_per_frame(gates=gates)}}}
+
+
+def duration_mlpg_section(dev, n_utts=256):
+    """BASELINE config 4: duration model (per-phone question vector 416 -> 2 x 512 tanh -> 5 state
+    durations) + MLPG of the 187-dim acoustic trajectory, inference only: utterances per second
+    through [duration forward, duration post-processing, MLPG] with inputs resident."""
+    from idiaptts_amd import ops, world
+    from idiaptts_amd.bench_support import utterance_lengths
+    from idiaptts_amd.native_ff import FlatFFModel
+    lengths = utterance_lengths(n_utts, seed=5)
+    phones = np.maximum(lengths // 18, 1)                 # ~90 ms per phone at 5 ms frames
+    P = int(phones.sum())
+    model = FlatFFModel((416, 512, 512, 5), ("tanh", "tanh", None), device=dev, seed=2)
+    g = torch.Generator(device=dev).manual_seed(9)
+    q = (torch.rand((P, 416), generator=g, device=dev) < 0.05).float()
+    ml_off = world.offsets(lengths.tolist())
+    feat = torch.randn(ml_off[-1], 186, dtype=torch.float64, device=dev)
+    var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
+    stream = torch.cuda.current_stream()
+
+    def run():
+        dur = model.forward(q)[-1]
+        frames = torch.clamp(torch.round(dur), min=0).to(torch.int64)     # DurationModelTrainer.forward
+        out = ops.mlpg_generation(feat, var, 62, ml_off)
+        return frames, out
+
+    run()
+    torch.cuda.synchronize()
+    ms = hip_event_median_ms(run, stream, 7)
+    ms_dur = hip_event_median_ms(lambda: model.forward(q), stream, 7)
+    return {"duration_mlpg": {
+        "utterances": n_utts, "phones": P, "frames": int(ml_off[-1]), "ms": ms,
+        "duration_model_ms": ms_dur, "utterances_per_s": n_utts / (ms * 1e-3),
+        "phones_per_s": P / (ms_dur * 1e-3), "frames_per_s": ml_off[-1] / (ms * 1e-3),
+        "timing": "median of 7 passes, HIP events on the launch stream"}}
+
+
+def gen_data_section(n_utts=128, batch_utts=64):
+    """The drop-in WorldFeatLabelGen.gen_data end to end: wav files on
+    disk -> per-stream .npz archives with deltas + normalisation statistics, file I/O, host <->
+    device copies and all host work included (median of 3 passes over the same files)."""
+    import tempfile
+    from scipy.io import wavfile
+    from idiaptts_amd.bench_support import make_audio_batch
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    with tempfile.TemporaryDirectory() as tmp:
+        wav_dir, out_dir = os.path.join(tmp, "wav"), os.path.join(tmp, "out")
+        os.makedirs(wav_dir)
+        ids = []
+        audio = 0.0
+        for i, xw in enumerate(make_audio_batch(n_utts, 16000, seed=0)):
+            wavfile.write(os.path.join(wav_dir, "u%03d.wav" % i), 16000, (xw * 32767).astype(np.int16))
+            ids.append("u%03d" % i)
+            audio += len(xw) / 16000.0
+        gen = WorldFeatLabelGen(out_dir, add_deltas=True, num_coded_sps=60, batch_utts=batch_utts)
+        gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids[:batch_utts])
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids)
+            times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    return {"gen_data": {"utterances": n_utts, "batch_utts": batch_utts, "audio_seconds": audio,
+                         "seconds": dt, "rtf": dt / audio,
+                         "what": "wav files -> mcep60 / lf0 / vuv / bap .npz with deltas + "
+                                 "mean-covariance files, file I/O included"}}
 
 
 def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
@@ -363,6 +586,13 @@ def main():
     if args.share_gpu:
         os.environ["ITTS_BENCH_SHARE_GPU"] = "1"
 
+    # CPU baselines (rank 0 at N = 1 only) run first: the process pool is forked before anything
+    # touches HIP
+    cpu_extra = {}
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu and args.world_utts > 0:
+        cpu_extra["world_pool"] = cpu_baseline_world_pool(args.world_fs)
+
     from idiaptts_amd import lib
     lib.require_gpu()
     # Functional check of the N > 1 control flow on a one-GPU box: ITTS_BENCH_SHARE_GPU=1 puts all
@@ -431,6 +661,13 @@ def main():
         for cell in ("LSTM", "GRU"):
             rnn_extra.update(bilstm_section(dev, args.bilstm_utts, cell=cell, rank=rank,
                                             world=world))
+        if world > 1 and args.bilstm_utts >= world:
+            # SURVEY.md section 8(d) defines config 3 as 64 utterances GLOBAL (strong scaling: 64 / N
+            # per GPU); "bilstm" above is 64 per GPU (weak scaling).  Both are reported.
+            rnn_extra.update(bilstm_section(dev, args.bilstm_utts // world, cell="LSTM", rank=rank,
+                                            world=world, key="bilstm_global_batch"))
+            rnn_extra["bilstm_global_batch"]["scaling"] = "strong"
+        rnn_extra["bilstm"]["scaling"] = "weak"
 
     # config 5 (WORLD analysis / synthesis real-time factors, MLPG): every rank takes part
     world_extra = {}
@@ -485,12 +722,20 @@ def main():
                     "algorithmic_flops_per_launch": flops / 8.0,
                     "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / 8.0}
         cpu = None
-        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N = 1 only
+        if want_cpu:   # CPU baseline: rank 0 at N = 1 only
             cpu = cpu_baseline_ff(args.utts_per_gpu)
+            cpu.update(host_info())
+            if args.bilstm_utts > 0:
+                rnn_extra["bilstm"]["cpu_baseline"] = cpu_baseline_bilstm()
         extra = dict(world_extra)
         extra.update(rnn_extra)
+        if "world_pool" in cpu_extra and "world" in extra:
+            extra["world"]["cpu_baseline_pool"] = cpu_extra["world_pool"]
         if world == 1 and args.world_utts > 0:
             extra.update(resident_epoch_section(dev))
+            extra.update(duration_mlpg_section(dev))
+            extra.update(gen_data_section(min(128, max(8, args.world_utts // 2)),
+                                          min(64, max(4, args.world_utts // 4))))
         out = {
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
