@@ -36,6 +36,10 @@ int itts_abi_version(void);
 const char* itts_last_error(void);
 /* number of visible HIP devices (initialises HIP). */
 int itts_device_count(void);
+/* The GPU entry points take their scratch from the current device's stream-ordered pool, which keeps
+ * up to ITTS_POOL_KEEP_GB (environment, default 64) between calls.  This synchronises the device
+ * and hands all of it back, e.g. between a feature-extraction job and training in one process. */
+int itts_release_scratch(void);
 
 /* ---- integer / scalar helpers (host, no GPU) ------------------------------------------- */
 /* pyworld.get_cheaptrick_fft_size(fs, f0_floor=71)  -- src/data_preparation/audio/AudioProcessing.py:60 */

@@ -131,6 +131,7 @@ def test_ema_keeps_averaging_after_the_optimiser_is_replaced(gpu, tmp_path):
     shadow restarted from the loaded parameters -- it must never keep pointing at the discarded
     optimiser, where its update would silently stop."""
     import types
+    import numpy as np
     from idiaptts_amd.src.ExtendedHParams import ExtendedHParams
     from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import (
         ExponentialMovingAverage, ModularModelHandlerPyTorch as Handler)
