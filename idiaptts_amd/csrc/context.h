@@ -16,6 +16,9 @@ struct FreqtTables {
   double* fwdT = nullptr;  // [f2+1][m+1]   mc[j]  = sum_i fwdT[i][j] * c[i]      freqt(c, f2 -> m, +a)
   double* invT = nullptr;  // [m+1][f2+1]   c'[i]  = sum_j invT[j][i] * mc[j]    freqt(mc, m -> f2, -a)
   double* frqT = nullptr;  // [f2+1][2m+1]  cr[j]  = sum_i frqT[i][j] * r[i]     frqtr(r, f2 -> 2m, +a)
+  // SPTK mgcep's own transform b2c (freqt without the `+ a d[0]` in the zeroth term):
+  double* b1T = nullptr;   // [m+1][f2+1]   c[i]   = sum_j b1T[j][i] * b[j]      b2c(b, m -> f2, -a)
+  double* p2T = nullptr;   // [f2+1][2m+1]  p~[j]  = sum_i p2T[i][j] * p[i]      b2c(p, f2 -> 2m, +a)
   int m = 0, f2 = 0;
   double alpha = 0;
 };
@@ -70,7 +73,8 @@ struct DeviceContext {
 DeviceContext* get_context();
 // Returns warping tables for (order m, f2 = fftlen/2, alpha); nullptr + error on failure.
 // need_fwd_frq = false builds only invT (enough for mgc2sp).
-const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq);
+const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq,
+                             bool need_mgc = false);
 
 // Jump matrices of the randn() generator on the context's device; nullptr + error on failure.
 const JumpTable* get_jump_table(DeviceContext* ctx);

@@ -249,13 +249,34 @@ static void frqtr_unit(int idx, int m2, double a, double* g, double* d) {
   }
 }
 
+// SPTK mgcep.c's b2c applied to the unit vector e_idx -> g[0..m2]
+static void b2c_unit(int idx, int m2, double a, double* g, double* d) {
+  const double k = 1.0 - a * a;
+  std::memset(g, 0, sizeof(double) * (m2 + 1));
+  std::memset(d, 0, sizeof(double) * (m2 + 1));
+  for (int i = -idx; i <= 0; ++i) {
+    const double cin = (i == -idx) ? 1.0 : 0.0;
+    d[0] = g[0];
+    g[0] = cin;
+    if (m2 >= 1) {
+      d[1] = g[1];
+      g[1] = k * d[0] + a * d[1];
+    }
+    for (int j = 2; j <= m2; ++j) {
+      d[j] = g[j];
+      g[j] = d[j - 1] + a * (d[j] - g[j - 1]);
+    }
+  }
+}
+
 static int upload(const std::vector<double>& h, double** d) {
   ITTS_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(double)));
   ITTS_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
   return ITTS_OK;
 }
 
-const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq) {
+const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq,
+                             bool need_mgc) {
   long long abits;
   std::memcpy(&abits, &alpha, sizeof(abits));
   const auto key = std::make_tuple(m, f2, abits);
@@ -284,6 +305,19 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
     }
     if (upload(fwd, &t.fwdT) != ITTS_OK) return nullptr;
     if (upload(frq, &t.frqT) != ITTS_OK) return nullptr;
+  }
+  if (need_mgc && !t.b1T) {
+    std::vector<double> b1((size_t)(m + 1) * (f2 + 1)), p2((size_t)(f2 + 1) * (m2 + 1));
+    for (int j = 0; j <= m; ++j) {
+      b2c_unit(j, f2, -alpha, g.data(), d.data());
+      for (int i = 0; i <= f2; ++i) b1[(size_t)j * (f2 + 1) + i] = g[i];
+    }
+    for (int i = 0; i <= f2; ++i) {
+      b2c_unit(i, m2, alpha, g.data(), d.data());
+      for (int j = 0; j <= m2; ++j) p2[(size_t)i * (m2 + 1) + j] = g[j];
+    }
+    if (upload(b1, &t.b1T) != ITTS_OK) return nullptr;
+    if (upload(p2, &t.p2T) != ITTS_OK) return nullptr;
   }
   return &t;
 }

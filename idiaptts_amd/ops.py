@@ -373,6 +373,42 @@ def mgc2sp(mc, alpha, fftlen, want_logamp=False, want_pow=False):
     return out64 if want_logamp else (outpw if want_pow else out32)
 
 
+def mgcep(sp, order, alpha, gamma, eps=1e-8, miniter=2, maxiter=30, threshold=1e-3,
+          dtype=torch.float32, want_iters=False, input_is_power=False):
+    """pysptk.mgcep(amp_sp, order, alpha, gamma, eps, min_det=0, etype=1, itype=3) on [T, K] f64
+    amplitude spectra (or power spectra with input_is_power)."""
+    L = _lib.load()
+    _need(sp, torch.float64, "sp")
+    sp = sp.contiguous()
+    T, K = sp.shape
+    out = torch.empty((T, order + 1), dtype=dtype, device=sp.device)
+    iters = torch.empty((T,), dtype=torch.int32, device=sp.device) if want_iters else None
+    f32 = out if dtype == torch.float32 else None
+    f64 = out if dtype == torch.float64 else None
+    _lib.check(L.itts_mgcep(_ptr(sp), 1 if input_is_power else 0, T, K, order, float(alpha),
+                            float(gamma), eps, miniter, maxiter, threshold, _ptr(f32), order + 1,
+                            _ptr(f64), _ptr(iters), _stream()), "itts_mgcep")
+    return (out, iters) if want_iters else out
+
+
+def mgc2sp_gamma(mgc, alpha, gamma, fftlen, want_logamp=False, want_pow=False):
+    """exp(float32(pysptk.mgc2sp(mgc, alpha, gamma, fftlen).real)) -> [T, fftlen/2+1] f32 (or the f64
+    log amplitude / f64 power spectrum)."""
+    L = _lib.load()
+    _need(mgc, torch.float64, "mgc")
+    mgc = mgc.contiguous()
+    T, m1 = mgc.shape
+    K = fftlen // 2 + 1
+    out32 = None if (want_logamp or want_pow) else torch.empty((T, K), dtype=torch.float32,
+                                                               device=mgc.device)
+    out64 = torch.empty((T, K), dtype=torch.float64, device=mgc.device) if want_logamp else None
+    outpw = torch.empty((T, K), dtype=torch.float64, device=mgc.device) if want_pow else None
+    _lib.check(L.itts_mgc2sp_gamma(_ptr(mgc), T, m1 - 1, float(alpha), float(gamma), fftlen,
+                                   _ptr(out32), _ptr(out64), _ptr(outpw), _stream()),
+               "itts_mgc2sp_gamma")
+    return out64 if want_logamp else (outpw if want_pow else out32)
+
+
 def code_aperiodicity(ap, fs, dtype=torch.float64):
     L = _lib.load()
     _need(ap, torch.float64, "ap")

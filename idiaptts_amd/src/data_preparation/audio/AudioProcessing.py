@@ -158,9 +158,29 @@ class AudioProcessing:
         return ops.mcep(a, num_coded_sps - 1, mgc_alpha, eps=1.0e-8).cpu().numpy()
 
     @staticmethod
-    def extract_mgc(amp_sp, fs=None, num_coded_sps=60, mgc_alpha=None):
-        raise NotImplementedError("mgcep (gamma=-1/3) is a 'next' row (SURVEY.md section 8f); "
-                                  "use sp_type='mcep'.")
+    def extract_mgc(amp_sp: np.array, fs: int = None, num_coded_sps: int = 60,
+                    mgc_alpha: float = None) -> np.array:
+        """pysptk.mgcep(amp_sp, order, alpha, gamma=-1/3, eps=1e-8, min_det=0, etype=1, itype=3)
+        as float32 (reference :123-140)."""
+        if mgc_alpha is None:
+            assert fs is not None, "Either sampling rate or mgc alpha has to be given."
+            mgc_alpha = AudioProcessing.fs_to_mgc_alpha(fs)
+        a = torch.from_numpy(np.ascontiguousarray(amp_sp, dtype=np.float64)).to(_dev())
+        return ops.mgcep(a, num_coded_sps - 1, mgc_alpha, AudioProcessing.mgc_gamma,
+                         eps=1.0e-8).cpu().numpy()
+
+    @staticmethod
+    def mgc_to_amp_sp(mgc: np.array, fs: int, alpha: float = None, gamma: float = None,
+                      n_fft: int = None):
+        """exp(float32(pysptk.mgc2sp(mgc, alpha, gamma, fftlen).real)) (reference :259-275)."""
+        if alpha is None:
+            alpha = AudioProcessing.fs_to_mgc_alpha(fs)
+        if gamma is None:
+            gamma = AudioProcessing.mgc_gamma
+        if n_fft is None:
+            n_fft = AudioProcessing.fs_to_frame_length(fs)
+        m = torch.from_numpy(np.ascontiguousarray(mgc, dtype=np.float64)).to(_dev())
+        return ops.mgc2sp_gamma(m, alpha, gamma, n_fft).cpu().numpy()
 
     @staticmethod
     def mcep_to_amp_sp(mcep: np.array, fs: int, alpha: float = None):
@@ -181,9 +201,11 @@ class AudioProcessing:
                 logging.warning("Post-filtering only implemented for cepstrum features.")
         if sp_type == "mcep":
             return AudioProcessing.mcep_to_amp_sp(coded_sp, fs, alpha)
+        elif sp_type == "mgc":
+            return AudioProcessing.mgc_to_amp_sp(coded_sp, fs, alpha, mgc_gamma, n_fft)
         elif sp_type == "amp_sp":
             return coded_sp
-        elif sp_type in ("mgc", "mfbanks"):
+        elif sp_type == "mfbanks":
             raise NotImplementedError("sp_type {} is outside the accelerated path.".format(sp_type))
         else:
             raise NotImplementedError("Unknown feature type {}. No decoding method available."

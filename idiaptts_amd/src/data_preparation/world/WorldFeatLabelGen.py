@@ -255,17 +255,18 @@ class WorldFeatLabelGen(ReaderBase):
                                f0_silence_threshold=None, lf0_zero=None):
         """MI355X-native batched form of extract_features: the spectral envelope never leaves
         the GPU (CheapTrick -> mcep fused). Returns a list of (coded_sp, lf0, vuv, bap)."""
-        if sp_type != "mcep":
-            raise NotImplementedError("Only sp_type='mcep' is on the accelerated path.")
+        if sp_type not in ("mcep", "mgc"):
+            raise NotImplementedError("Only sp_type 'mcep' and 'mgc' are on the accelerated path.")
         if f0_silence_threshold is None:
             f0_silence_threshold = WorldFeatLabelGen.f0_silence_threshold
         if lf0_zero is None:
             lf0_zero = WorldFeatLabelGen.lf0_zero
         if mgc_alpha is None:
             mgc_alpha = AudioProcessing.fs_to_mgc_alpha(fs)
-        cmp_dev, f_off = _world.extract_cmp_batch(raws, fs, hop_size_ms, n_fft, num_coded_sps - 1,
-                                                  mgc_alpha, f0_silence_threshold, lf0_zero,
-                                                  add_deltas=False)
+        cmp_dev, f_off = _world.extract_cmp_batch(
+            raws, fs, hop_size_ms, n_fft, num_coded_sps - 1, mgc_alpha, f0_silence_threshold,
+            lf0_zero, add_deltas=False,
+            mgc_gamma=AudioProcessing.mgc_gamma if sp_type == "mgc" else None)
         cmp_host = cmp_dev.cpu().numpy()
         out = []
         for u in range(len(raws)):
@@ -490,7 +491,8 @@ class WorldFeatLabelGen(ReaderBase):
                 cmp_dev, f_off = _world.extract_cmp_batch(
                     (samples, x_off), fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1,
                     alpha, WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
-                    self.add_deltas)
+                    self.add_deltas,
+                    mgc_gamma=AudioProcessing.mgc_gamma if self.sp_type == "mgc" else None)
                 stats.add(cmp_dev)
                 host = torch.empty(cmp_dev.shape, dtype=torch.float32, pin_memory=True)
                 host.copy_(cmp_dev, non_blocking=True)
@@ -546,8 +548,8 @@ class WorldFeatLabelGen(ReaderBase):
         if world > 1:
             sizes = [os.path.getsize(os.path.join(dir_in, n + "." + file_ext)) for n in all_ids]
             id_list = [all_ids[i] for i in _parallel.shard_by_length(sizes, world)[rank]]
-        if self.sp_type != "mcep":
-            raise NotImplementedError("Only sp_type='mcep' is on the accelerated path.")
+        if self.sp_type not in ("mcep", "mgc"):
+            raise NotImplementedError("Only sp_type 'mcep' and 'mgc' are on the accelerated path.")
         self._gen_data_pipeline(dir_in, dir_out, file_ext, id_list, label_dict if return_dict
                                 else None)
         if world > 1:

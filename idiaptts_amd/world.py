@@ -131,7 +131,8 @@ class StreamStats(object):
 
 
 def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alpha=None,
-                      f0_silence_threshold=30, lf0_zero=0, add_deltas=True, device=None):
+                      f0_silence_threshold=30, lf0_zero=0, add_deltas=True, device=None,
+                      mgc_gamma=None):
     """wav(s) -> the `[T, 3*(ncs+1+nb)+1]` feature matrix of the reference's gen_data in one go,
     everything on the device: DIO + StoneMask, D4C -> coded bap, CheapTrick -> mcep, lf0 / V-UV
     with interpolate_lin, deltas and the stream layout (WorldFeatLabelGen.py:778-807, 809-889,
@@ -155,8 +156,12 @@ def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alph
         _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_ap=False,
                          want_bap=torch.float32)
         lf0, vuv = ops.lf0_vuv(f0, f_off, f0_silence_threshold, lf0_zero)
-    _, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=False,
-                                   order=mcep_order, alpha=mcep_alpha)
+    if mgc_gamma is None or mgc_gamma == 0.0:
+        _, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=False,
+                                       order=mcep_order, alpha=mcep_alpha)
+    else:       # sp_type "mgc": mel-generalized cepstrum of the CheapTrick envelope
+        sp, _, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=True)
+        mc = ops.mgcep(sp, mcep_order, mcep_alpha, mgc_gamma, input_is_power=True)
     main.wait_stream(side)
     for t in (x, f0, bap, lf0, vuv):
         t.record_stream(side)

@@ -246,6 +246,21 @@ int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, double alpha,
 int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alpha, int fftlen,
                 float* d_amp_f32, double* d_logamp_f64, double* d_pow_f64, void* stream);
 
+/* pysptk.mgcep(amp_sp, order, alpha, gamma, eps, min_det=0, etype=1, itype=3) with pysptk's defaults
+ * num_recursions = K - 1, otype = 0 (AudioProcessing.extract_mgc, AudioProcessing.py:123-140; the
+ * reference uses gamma = -1/3): d_amp_sp [T, K] f64 amplitude spectra (input_is_power != 0: power
+ * spectra, e.g. CheapTrick's output) -> mel-generalized cepstra d_mgc_f32 [T, ld_mgc] and / or
+ * d_mgc_f64 [T, order+1]; d_iters [T] Newton steps after the initial gamma = -1 step (optional).
+ * -1 <= gamma <= 0, order <= 63. */
+int itts_mgcep(const double* d_amp_sp, int input_is_power, int64_t T, int K, int order, double alpha,
+               double gamma, double eps, int miniter, int maxiter, double threshold,
+               float* d_mgc_f32, int64_t ld_mgc, double* d_mgc_f64, int* d_iters, void* stream);
+/* pysptk.mgc2sp(mgc, alpha, gamma, fftlen) (AudioProcessing.mgc_to_amp_sp, AudioProcessing.py:259-275):
+ * outputs as itts_mgc2sp; gamma = 0 is itts_mgc2sp. */
+int itts_mgc2sp_gamma(const double* d_mgc, int64_t T, int order, double alpha, double gamma,
+                      int fftlen, float* d_amp_f32, double* d_logamp_f64, double* d_pow_f64,
+                      void* stream);
+
 /* pyworld.code_aperiodicity (WorldFeatLabelGen.py:805) / pyworld.decode_aperiodicity (:940-941). */
 int itts_code_aperiodicity(const double* d_ap, int64_t T, int fft_size, int fs, double* d_bap_f64,
                            float* d_bap_f32, void* stream);

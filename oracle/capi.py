@@ -171,6 +171,31 @@ def mgc2sp_logamp(mc, alpha, fftlen):
     return out
 
 
+def mgcep(amp_sp, order, alpha, gamma, eps=1e-8, miniter=2, maxiter=30, threshold=1e-3,
+          return_iters=False):
+    """pysptk.mgcep(amp_sp, order, alpha, gamma, eps=eps, min_det=0, etype=1, itype=3) on [T, K]."""
+    a = np.ascontiguousarray(amp_sp, dtype=np.float64)
+    T, K = a.shape
+    out = np.zeros((T, order + 1))
+    iters = np.zeros(T, dtype=np.int32)
+    fn = _fn("orc_mgcep", c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_double,
+                                  c_int, c_int, c_double, c_void_p, c_void_p])
+    rc = fn(_p(a), T, K, order, alpha, gamma, eps, miniter, maxiter, threshold, _p(out), _p(iters))
+    assert rc == 0, rc
+    return (out, iters) if return_iters else out
+
+
+def mgc2sp_gamma_logamp(mgc, alpha, gamma, fftlen):
+    """pysptk.mgc2sp(mgc, alpha, gamma, fftlen).real (log amplitude) [T, fftlen/2+1] f64."""
+    m = np.ascontiguousarray(mgc, dtype=np.float64)
+    T, M1 = m.shape
+    out = np.zeros((T, fftlen // 2 + 1))
+    fn = _fn("orc_mgc2sp_gamma", c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int,
+                                         c_void_p])
+    assert fn(_p(m), T, M1 - 1, alpha, gamma, fftlen, _p(out)) == 0
+    return out
+
+
 def synthesize(f0, sp, ap, fs, frame_period=5.0):
     f0 = np.ascontiguousarray(f0, dtype=np.float64)
     sp = np.ascontiguousarray(sp, dtype=np.float64)

@@ -132,3 +132,53 @@ def test_synthesis_oracle_matches_numpy_spec_and_reference_bound(golden_dir):
     ap_s = ss.decode_aperiodicity(bap[voiced], fs, 1024)
     assert np.abs(ap_c[voiced] - ap_s).max() < 1e-12
     assert np.all(ap_c[~voiced] == 1.0 - 1e-12)
+
+
+def test_oracle_mgcep_is_the_minimiser_of_the_mgc_criterion(golden_dir):
+    """pysptk.mgcep (AudioProcessing.extract_mgc, gamma = -1/3) has no golden vector in the
+    reference and pysptk cannot be installed: PARITY UNPINNED.  What can be checked: (1) with
+    gamma = 0 the analysis agrees with the pinned mcep restatement to the stopping tolerance of
+    the two iterations; (2) for gamma < 0 its output is a stationary point of the criterion both
+    methods minimise, E = sum_w exp(R) - R - 1 with R = log periodogram - log model spectrum,
+    where the model spectrum is evaluated by the independent decoding path (mgc2sp: freqt,
+    gnorm, gc2gc, FFT) -- no perturbation of any coefficient lowers E; (3) the reconstruction
+    bound the reference's own test applies (test_WorldFeatLabelGen.py:827-836, sum of squared
+    amplitude errors < 1500 per utterance) holds on the fixture's CheapTrick envelope."""
+    from oracle import capi
+    cmp_ = np.fromfile(os.path.join(golden_dir, "LJ001-0008.cmp"), dtype=np.float32).reshape(-1, 67)
+    mc = cmp_[100:112, :20].astype(np.float64)
+    amp = np.exp(capi.mgc2sp_logamp(mc, 0.58, 1024))
+    x = amp ** 2 + 1e-8
+    m0 = capi.mgcep(amp, 19, 0.58, 0.0)
+    assert np.abs(m0 - capi.mcep(amp, 19, 0.58)).max() < 5e-3
+    assert np.abs(capi.mgc2sp_gamma_logamp(mc, 0.58, 0.0, 1024)
+                  - capi.mgc2sp_logamp(mc, 0.58, 1024)).max() < 1e-12
+
+    def criterion(mgc, g):
+        la = capi.mgc2sp_gamma_logamp(mgc, 0.58, g, 1024)
+        r = np.log(x) - 2 * la
+        w = np.ones(513)
+        w[0] = w[-1] = 0.5
+        return ((np.exp(r) - r - 1) * w).sum(axis=1)
+
+    for g in (-1.0 / 3.0, -0.5):
+        mgc, iters = capi.mgcep(amp, 19, 0.58, g, threshold=1e-10, maxiter=60, return_iters=True)
+        assert iters.max() < 60
+        e0 = criterion(mgc, g)
+        for k in range(20):
+            for sgn in (1.0, -1.0):
+                mp = mgc.copy()
+                mp[:, k] += sgn * 1e-4
+                assert (criterion(mp, g) - e0).min() > -1e-9, (g, k)
+        # the default stopping rule (1e-3 on log eps) lands within its tolerance of that optimum
+        assert np.abs(capi.mgcep(amp, 19, 0.58, g) - mgc).max() < 2e-2
+    # reference-style bound on a real envelope (CheapTrick of the fixture wav, order 59)
+    from scipy.io import wavfile
+    fs, w = wavfile.read(os.path.join(golden_dir, "LJ001-0008.wav"))
+    raw = w[:16000].astype(np.float64) / 32768.0
+    f0, sp, ap = capi.wav2world(raw, fs)
+    amp_sp = np.sqrt(sp)
+    alpha = 0.58
+    mgc = capi.mgcep(amp_sp, 59, alpha, -1.0 / 3.0)
+    rec = np.exp(capi.mgc2sp_gamma_logamp(mgc, alpha, -1.0 / 3.0, 1024).astype(np.float32))
+    assert ((amp_sp - rec) ** 2).sum() < 1500 * len(amp_sp) / 600.0
