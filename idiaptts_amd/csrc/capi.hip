@@ -81,3 +81,29 @@ extern "C" int64_t itts_world_synth_length(int64_t n_frames, int fs, double fram
   if (n_frames < 0 || fs <= 0 || frame_period_ms <= 0) return ITTS_E_INVALID;
   return (int64_t)(n_frames * frame_period_ms * fs / 1000.0);
 }
+
+// pyworld.wav2world(x, fs, fft_size, frame_period) (WorldFeatLabelGen.py:792-793) in one call:
+// DIO -> StoneMask -> CheapTrick -> D4C on utterances stored back to back.
+extern "C" int itts_wav2world(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off,
+                              int n_utts, int fs, double frame_period_ms, int fft_size, double* d_f0,
+                              double* d_sp, double* d_ap, void* stream) {
+  ITTS_REQUIRE(h_x_off && h_f_off && n_utts >= 0, "null offsets");
+  if (n_utts == 0 || h_f_off[n_utts] == 0) return ITTS_OK;
+  ITTS_REQUIRE(d_x && d_f0 && (d_sp || d_ap), "null pointer");
+  if (fft_size <= 0) fft_size = itts_cheaptrick_fft_size(fs, 71.0);
+  hipStream_t s = itts::as_stream(stream);
+  double* d_f0_raw = nullptr;
+  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_f0_raw, (size_t)h_f_off[n_utts] * sizeof(double), s));
+  int rc = itts_dio(d_x, h_x_off, h_f_off, n_utts, fs, frame_period_ms, 71.0, 800.0, 2.0, 0.1, d_f0_raw,
+                    stream);
+  if (rc == ITTS_OK)
+    rc = itts_stonemask(d_x, h_x_off, d_f0_raw, h_f_off, n_utts, fs, frame_period_ms, d_f0, stream);
+  if (rc == ITTS_OK && d_sp)
+    rc = itts_cheaptrick_mcep(d_x, h_x_off, d_f0, h_f_off, n_utts, fs, frame_period_ms, fft_size, -0.15,
+                              d_sp, 0, 0.0, 0.0, 0, 0, 0.0, nullptr, 0, nullptr, nullptr, stream);
+  if (rc == ITTS_OK && d_ap)
+    rc = itts_d4c(d_x, h_x_off, d_f0, h_f_off, n_utts, fs, frame_period_ms, fft_size, 0.85, d_ap, nullptr,
+                  nullptr, 0, stream);
+  ITTS_HIP_CHECK(hipFreeAsync(d_f0_raw, s));
+  return rc;
+}

@@ -446,6 +446,22 @@ def dio(x, x_off, f_off, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
     return f0
 
 
+def wav2world(x, x_off, f_off, fs, frame_period=5.0, fft_size=None, want_sp=True, want_ap=True):
+    """pyworld.wav2world for utterances stored back to back: (f0 [Ttot], sp [Ttot, K] or None,
+    ap [Ttot, K] or None), all f64 (WorldFeatLabelGen.py:792-793)."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    fft_size = fft_size or L.itts_cheaptrick_fft_size(fs, 71.0)
+    T, K = int(f_off[-1]), fft_size // 2 + 1
+    f0 = torch.empty((T,), dtype=torch.float64, device=x.device)
+    sp = torch.empty((T, K), dtype=torch.float64, device=x.device) if want_sp else None
+    ap = torch.empty((T, K), dtype=torch.float64, device=x.device) if want_ap else None
+    _lib.check(L.itts_wav2world(_ptr(x), _lib.offsets_array(x_off), _lib.offsets_array(f_off),
+                                len(x_off) - 1, fs, float(frame_period), fft_size, _ptr(f0),
+                                _ptr(sp), _ptr(ap), _stream()), "itts_wav2world")
+    return f0, sp, ap
+
+
 def stonemask(x, x_off, f0, f_off, fs, frame_period=5.0):
     L = _lib.load()
     _need(x, torch.float64, "x")

@@ -287,6 +287,14 @@ int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, 
              double frame_period_ms, double f0_floor, double f0_ceil, double channels_in_octave,
              double allowed_range, double* d_f0, void* stream);
 
+/* pyworld.wav2world(x, fs, fft_size=..., frame_period=...) in one call (WorldFeatLabelGen.py:792-793):
+ * DIO -> StoneMask -> CheapTrick -> D4C with wav2world's defaults (f0 floor 71 Hz, q1 -0.15, D4C
+ * threshold 0.85).  d_f0 [Ttot] f64, d_sp / d_ap [Ttot, fft_size/2+1] f64 (either may be NULL);
+ * fft_size <= 0: pyworld.get_cheaptrick_fft_size(fs). */
+int itts_wav2world(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, int n_utts,
+                   int fs, double frame_period_ms, int fft_size, double* d_f0, double* d_sp,
+                   double* d_ap, void* stream);
+
 /* WORLD synthesis (pyworld.synthesize(f0, sp, ap, fs, frame_period)) followed by the reference's
  * float32 cast and de-pre-emphasis lfilter([1],[1,-preemphasis]) -- WorldFeatLabelGen.py:943-945.
  * d_f0 [Ttot] f64, d_sp / d_ap [Ttot, fft_size/2+1] f64 (power spectrum / aperiodicity);

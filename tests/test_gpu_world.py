@@ -431,3 +431,30 @@ def test_other_sampling_rates_match_oracle(gpu, fs, nap):
                                 torch.from_numpy(ap_ref).to(gpu), [0, T], fs, dtype=torch.float64)
     y_ref = capi.synthesize(f0_ref, sp_ref, ap_ref, fs).astype(np.float32)
     assert np.abs(y.cpu().numpy() - y_ref).max() < 1e-6
+
+
+def test_wav2world_composite_equals_the_separate_calls_and_the_oracle(gpu, golden_dir):
+    """itts_wav2world (pyworld.wav2world, WorldFeatLabelGen.py:792-793) is DIO -> StoneMask ->
+    CheapTrick -> D4C in one call: identical to the separate entry points, and equal to the C
+    oracle's wav2world on a fixture clip."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    xs = [_read(golden_dir, "LJ001-0008")[0][:24000], _read(golden_dir, "LJ001-0002")[0][8000:20000]]
+    fs = 16000
+    x_off = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).tolist()
+    f_off = np.concatenate([[0], np.cumsum([int(1000.0 * len(x) / fs / 5.0) + 1 for x in xs])]).tolist()
+    x = torch.from_numpy(np.concatenate(xs)).to(gpu)
+    f0, sp, ap = ops.wav2world(x, x_off, f_off, fs)
+    f0_s = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs), f_off, fs)
+    sp_s, _, _ = ops.cheaptrick_mcep(x, x_off, f0_s, f_off, fs, want_sp=True)
+    ap_s, _ = ops.d4c(x, x_off, f0_s, f_off, fs, want_ap=True)
+    assert torch.equal(f0, f0_s) and torch.equal(sp, sp_s) and torch.equal(ap, ap_s)
+    f0_only, none_sp, ap_only = ops.wav2world(x, x_off, f_off, fs, want_sp=False)
+    assert none_sp is None and torch.equal(f0_only, f0) and torch.equal(ap_only, ap)
+    for u, xu in enumerate(xs):
+        a, b = f_off[u], f_off[u + 1]
+        f0_o, sp_o, ap_o = capi.wav2world(xu, fs)
+        assert np.array_equal(f0[a:b].cpu().numpy() > 0, f0_o > 0)
+        assert np.abs(f0[a:b].cpu().numpy() - f0_o).max() < 1e-6
+        assert np.abs(sp[a:b].cpu().numpy() / sp_o - 1).max() < 1e-6
+        assert np.abs(ap[a:b].cpu().numpy() - ap_o).max() < 1e-6
