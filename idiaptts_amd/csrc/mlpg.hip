@@ -1101,7 +1101,9 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
     bool launched = false;
     FU_LAUNCH(16, 16, 4)
     FU_LAUNCH(32, 16, 4)
-    FU_LAUNCH(16, 8, 4)
+    FU_LAUNCH(16, 8, 2)
+    FU_LAUNCH(24, 8, 2)
+    FU_LAUNCH(16, 4, 2)
 #undef FU_LAUNCH
     ITTS_REQUIRE(launched, "unknown ITTS_MLPG_GEOM");
     ITTS_LAUNCH_CHECK();
