@@ -12,6 +12,8 @@
 // torch.nn.GRU cell, gate order r, z, n:
 //   r = sigmoid(gin_r + W_hr h + b_hr)      z = sigmoid(gin_z + W_hz h + b_hz)
 //   n = tanh(gin_n + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
+#include <vector>
+
 #include "rnn_common.h"
 
 namespace itts {
@@ -38,10 +40,15 @@ struct GruArgs {
   int step;
   int ksplit, kiter;
   int nact, nact_next;    // rows active at this step / at step + 1 (a prefix: rows are sorted)
+  int row_base;           // row_off[step] from the host's copy of the lengths (no table read)
 };
 
 __device__ __forceinline__ size_t gru_row_at(const GruArgs& a, int dir, int s, int b) {
   return dir == 0 ? (size_t)(a.row_off[s] + b) : (size_t)a.rev_row[(size_t)s * a.B + b];
+}
+// packed row of the step being processed: only the reverse direction reads its table (see lstm.hip)
+__device__ __forceinline__ int gru_row_now(const GruArgs& a, int dir, int b) {
+  return dir == 0 ? a.row_base + b : a.rev_row[(size_t)a.step * a.B + b];
 }
 
 // ---- forward step ---------------------------------------------------------------------------------
@@ -80,6 +87,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruArgs a) {
     const bool act = ew && b < a.nact;
     const size_t sidx = ((size_t)blockIdx.x * B + (ew ? b : 0)) * 4 + u;   // blocked(b, j)
     float hp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f;
+    // index first: it heads the only dependent load chain of the step (see lstm.hip)
+    const int ridx = act ? gru_row_now(a, dir, b) : 0;
+    __builtin_amdgcn_sched_barrier(0);
     size_t r = 0;
 #pragma unroll 1
     for (int c = 0; c < kiter || c == 0; c += 8) {
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruArgs a) {
       if (c == 0 && ew) {
         hp_v = hprev[sidx];
         if (act) {
-          r = gru_row_at(a, dir, a.step, b);
+          r = (size_t)ridx;
           const float* gi = a.gin + r * (size_t)(a.ndir * G3) + (size_t)dir * G3 + j;
           g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H];
           const float* bh = a.bhh + (size_t)dir * G3 + j;
@@ -187,9 +197,12 @@ __global__ __launch_bounds__(768) void gru_step_bwd_kernel(GruArgs a) {
   const bool ew = threadIdx.x < 256 && b < B;
   const bool act = ew && b < a.nact;
   float rg = 0.f, zg = 0.f, ng = 0.f, hnp = 0.f, hpv = 0.f, dyv = 0.f, cin = 0.f;
+  const int ridx = act ? gru_row_now(a, dir, b) : 0;     // index first (see lstm.hip)
+  __builtin_amdgcn_sched_barrier(0);
   size_t r = 0;
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};   // four independent chains
 #pragma unroll 1
   for (int c = 0; c < kiter; c += 8) {
     float4 av[8], bv[8];
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(768) void gru_step_bwd_kernel(GruArgs a) {
       bv[s] = wp[o * 16];
     }
     if (c == 0 && act) {
-      r = gru_row_at(a, dir, a.step, b);
+      r = (size_t)ridx;
       const float4 gs = reinterpret_cast<const float4*>(a.gates)[(r * a.ndir + dir) * H + j];
       rg = gs.x; zg = gs.y; ng = gs.z; hnp = gs.w;
       const size_t oh = r * ldh + (size_t)dir * H + j;
@@ -215,12 +228,12 @@ __global__ __launch_bounds__(768) void gru_step_bwd_kernel(GruArgs a) {
       if (!has_next || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc3, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
+  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = (acc0[q] + acc1[q]) + (acc2[q] + acc3[q]);
   __syncthreads();
   if (ew) {
     float carry = 0.f;
@@ -281,9 +294,12 @@ extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const 
   a.kiter = H / (16 * a.ksplit);
   const dim3 grid(H / GRU_FW_UNITS, ndir);
   int p = B;
+  int row_base = 0;
   for (int step = 0; step < T; ++step) {
     a.step = step;
     a.nact = rnn_active_rows(h_lengths, B, step, &p);
+    a.row_base = row_base;          // row_off[step] = rows active in all earlier steps
+    row_base += a.nact;
     switch (std::min((a.nact + 15) / 16, 4)) {
       case 1: hipLaunchKernelGGL(gru_step_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(gru_step_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
@@ -323,11 +339,17 @@ extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const f
   a.ksplit = (H % 64 == 0) ? 12 : ((H % 32 == 0) ? 6 : 3);   // waves per workgroup; 3H/16 k-steps in all
   a.kiter = (3 * H / 16) / a.ksplit;
   int p = 0, nact_next = 0;
+  std::vector<int> row_off(T + 1, 0);      // host copy of the packed-row offsets
+  {
+    int q = B;
+    for (int t = 0; t < T; ++t) row_off[t + 1] = row_off[t] + rnn_active_rows(h_lengths, B, t, &q);
+  }
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
     a.nact = rnn_active_rows(h_lengths, B, step, &p);
     a.nact_next = nact_next;
     nact_next = a.nact;
+    a.row_base = row_off[step];
     hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((H / GRU_BW_UNITS) * ((a.nact + 15) / 16), ndir),
                        dim3(64 * a.ksplit), 0, s, a);
   }

@@ -27,6 +27,8 @@
 //     which costs ~0.2 us per load when it happens), and every operand load is a contiguous 1 KB
 //     wave access thanks to the K-blocked state / re-tiled W_hh layouts of rnn_common.h.
 // Gate order i, f, g, o and the two bias vectors follow torch.nn.LSTM.
+#include <vector>
+
 #include "rnn_common.h"
 
 namespace itts {
@@ -56,11 +58,21 @@ struct LstmArgs {
   int step;
   int ksplit, kiter;      // K is split over `ksplit` waves, `kiter` steps of 16 k each
   int nact, nact_next;    // rows active at this step / at step + 1 (a prefix: rows are sorted)
+  int row_base;           // row_off[step], from the host's copy of the lengths (no table read)
+  int row_base_prev;      // row_off[step - 1] (backward: c_{t-1} of the forward direction)
 };
 
 // packed row that row b visits at recurrence step s (the caller knows that it is active)
 __device__ __forceinline__ size_t row_at(const LstmArgs& a, int dir, int s, int b) {
   return dir == 0 ? (size_t)(a.row_off[s] + b) : (size_t)a.rev_row[(size_t)s * a.B + b];
+}
+// the same for the step being processed / the one before it: the forward direction's rows follow
+// from the host-side offsets, only the reverse direction reads its table
+__device__ __forceinline__ int row_now(const LstmArgs& a, int dir, int b) {
+  return dir == 0 ? a.row_base + b : a.rev_row[(size_t)a.step * a.B + b];
+}
+__device__ __forceinline__ int row_before(const LstmArgs& a, int dir, int b) {
+  return dir == 0 ? a.row_base_prev + b : a.rev_row[(size_t)(a.step - 1) * a.B + b];
 }
 
 // ---- forward step -----------------------------------------------------------------------------------
@@ -105,6 +117,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
     const bool act = ew && b < a.nact;
     const size_t sidx = ((size_t)blockIdx.x * B + (ew ? b : 0)) * 4 + u;   // blocked(b, j)
     float hp_v = 0.f, cp_v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    // The packed-row index heads the only dependent load chain of a step (index -> gin row): it
+    // is requested before the 40 operand loads, which then cover its latency, and the gin loads
+    // that need it are covered by the MFMAs (measured before: the first MFMA waited ~7 000 clocks
+    // for index + gin issued behind each other in front of it).
+    const int ridx = act ? row_now(a, dir, b) : 0;
+    __builtin_amdgcn_sched_barrier(0);
     size_t r = 0;
 #pragma unroll 1
     for (int c = 0; c < kiter || c == 0; c += 8) {
@@ -122,12 +140,15 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
         hp_v = hprev[sidx];
         cp_v = cprev[sidx];
         if (act) {
-          r = row_at(a, dir, a.step, b);
+          r = (size_t)ridx;
           const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
           g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // all loads above are in flight before the first MFMA
+      // tile-outermost order: the MFMAs of tile 0 start as soon as ITS operands are there, while
+      // the loads of the later tiles are still in flight (k-step-outermost, with 2 * NT independent
+      // accumulator chains, measured 9 % slower)
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         const bool rok = (tb + tt) * 16 + lr < B;
@@ -215,9 +236,15 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
   const bool ew = threadIdx.x < 256 && b < B;
   const bool act = ew && b < a.nact;
   float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f, dyv = 0.f, dcin = 0.f;
+  // packed-row indices first (see the forward kernel): the saved tensors they address are then
+  // requested behind the operand loads, under the MFMAs
+  const int ridx = act ? row_now(a, dir, b) : 0;
+  const int rpidx = (act && a.step > 0) ? row_before(a, dir, b) : 0;
+  __builtin_amdgcn_sched_barrier(0);
   size_t r = 0;
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};   // four independent chains
 #pragma unroll 1
   for (int c = 0; c < kiter; c += 8) {
     float4 av[8], bv[8];
@@ -228,11 +255,11 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
       bv[s] = wp[o * 16];
     }
     if (c == 0 && act) {
-      r = row_at(a, dir, a.step, b);
+      r = (size_t)ridx;
       const float4 gs = reinterpret_cast<const float4*>(a.gates)[(r * a.ndir + dir) * H + j];
       ig = gs.x; fg = gs.y; gg = gs.z; og = gs.w;
       ct = a.csave[r * ldh + (size_t)dir * H + j];
-      cp = a.step > 0 ? a.csave[row_at(a, dir, a.step - 1, b) * ldh + (size_t)dir * H + j]
+      cp = a.step > 0 ? a.csave[(size_t)rpidx * ldh + (size_t)dir * H + j]
                       : (a.c0 ? a.c0[dir * H + j] : 0.f);
       dyv = a.dy[r * ldh + (size_t)dir * H + j];
       dcin = dc_in[(size_t)b * H + j];
@@ -244,12 +271,12 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
       if (!has_next || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc3, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = acc0[q] + acc1[q];
+  for (int q = 0; q < 4; ++q) P[wv][kg * 4 + q][lr] = (acc0[q] + acc1[q]) + (acc2[q] + acc3[q]);
   __syncthreads();
   if (ew) {
     float dc_keep = 0.f;
@@ -313,9 +340,12 @@ extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const
   a.kiter = H / (16 * a.ksplit);
   const dim3 grid(H / FW_UNITS, ndir);
   int p = B;
+  int row_base = 0;
   for (int step = 0; step < T; ++step) {
     a.step = step;
     a.nact = rnn_active_rows(h_lengths, B, step, &p);
+    a.row_base = row_base;          // row_off[step] = rows active in all earlier steps
+    row_base += a.nact;
     switch (std::min((a.nact + 15) / 16, 4)) {
       case 1: hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
@@ -357,11 +387,18 @@ extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const 
   a.ksplit = (H % 64 == 0) ? 16 : ((H % 32 == 0) ? 8 : 4);   // waves per workgroup
   a.kiter = H / (4 * a.ksplit);
   int p = 0, nact_next = 0;
+  std::vector<int> row_off(T + 1, 0);      // host copy of the packed-row offsets
+  {
+    int q = B;
+    for (int t = 0; t < T; ++t) row_off[t + 1] = row_off[t] + rnn_active_rows(h_lengths, B, t, &q);
+  }
   for (int step = T - 1; step >= 0; --step) {
     a.step = step;
     a.nact = rnn_active_rows(h_lengths, B, step, &p);
     a.nact_next = nact_next;
     nact_next = a.nact;
+    a.row_base = row_off[step];
+    a.row_base_prev = step > 0 ? row_off[step - 1] : 0;
     hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((H / BW_UNITS) * ((a.nact + 15) / 16), ndir),
                        dim3(64 * a.ksplit), 0, s, a);
   }
