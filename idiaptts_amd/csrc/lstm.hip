@@ -106,9 +106,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
   const float4* hp4 = reinterpret_cast<const float4*>(hprev);
 
   for (int tb = 0; tb < ntiles; tb += NT) {
-    f32x4 acc[NT][2];
+    f32x4 acc[NT][4];      // four accumulator chains per tile: an MFMA never waits for its predecessor
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc[tt][0] = acc[tt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < NT; ++tt)
+      acc[tt][0] = acc[tt][1] = acc[tt][2] = acc[tt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
     // elementwise operands of thread (tile q, batch row bl, unit u); their loads are issued behind
     // the first chunk's operand loads (loads return in order)
     const int q = threadIdx.x >> 6, bl = (threadIdx.x >> 2) & 15, u = threadIdx.x & 3;
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
     // that need it are covered by the MFMAs (measured before: the first MFMA waited ~7 000 clocks
     // for index + gin issued behind each other in front of it).
     const int ridx = act ? row_now(a, dir, b) : 0;
+    // ... and the table row of the NEXT step is pulled into this XCD's L2 now (256 B that every
+    // workgroup of the reverse direction needs: whichever XCD it lands on next time finds it there;
+    // cold, that one load was ~6 000 clocks at the head of every step)
+    int pf = 0;
+    if (tb == 0 && dir == 1 && a.step + 1 < a.T && (int)threadIdx.x < B)
+      pf = a.rev_row[(size_t)(a.step + 1) * B + threadIdx.x];
     __builtin_amdgcn_sched_barrier(0);
     size_t r = 0;
 #pragma unroll 1
@@ -139,11 +146,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
       if (c == 0 && ew) {
         hp_v = hprev[sidx];
         cp_v = cprev[sidx];
-        if (act) {
-          r = (size_t)ridx;
-          const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
-          g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
-        }
       }
       __builtin_amdgcn_sched_barrier(0);   // all loads above are in flight before the first MFMA
       // tile-outermost order: the MFMAs of tile 0 start as soon as ITS operands are there, while
@@ -158,8 +160,20 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
           if (!rok || c + s >= kiter) x = make_float4(0.f, 0.f, 0.f, 0.f);
           acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bv[s].x, acc[tt][0], 0, 0, 0);
           acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bv[s].y, acc[tt][1], 0, 0, 0);
-          acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc[tt][0], 0, 0, 0);
-          acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc[tt][1], 0, 0, 0);
+          acc[tt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bv[s].z, acc[tt][2], 0, 0, 0);
+          acc[tt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bv[s].w, acc[tt][3], 0, 0, 0);
+        }
+        if (tt == 0 && c == 0) {
+          // the input projections of this element are requested here: the index (the oldest
+          // outstanding load) is back once tile 0's operands are, and the remaining tiles' MFMAs
+          // cover the latency of these loads
+          __builtin_amdgcn_sched_barrier(0);
+          if (act) {
+            r = (size_t)ridx;
+            const float* gi = a.gin + r * (size_t)(a.ndir * G4) + (size_t)dir * G4 + j;
+            g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H]; g3 = gi[3 * H];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -167,7 +181,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) P[tt][wv][kg * 4 + e][lr] = acc[tt][0][e] + acc[tt][1][e];
+      for (int e = 0; e < 4; ++e)
+        P[tt][wv][kg * 4 + e][lr] = (acc[tt][0][e] + acc[tt][1][e]) + (acc[tt][2][e] + acc[tt][3][e]);
     }
     __syncthreads();
     if (ew) {
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
       hnext[sidx] = hn;
       cnext[sidx] = cn;
     }
+    if (pf == 0x7fffffff) hnext[0] = 0.f;    // never true: keeps the prefetch load alive
   }
 }
 
