@@ -441,6 +441,36 @@ __global__ __launch_bounds__(256) void masked_mse_final_kernel(const double* __r
   if (threadIdx.x == 0) *loss = (float)(s * scale);
 }
 
+// ---- row-weighted elementwise losses (the other NamedLoss types / reductions) ------------------
+// loss = sum_r w[r] sum_c e(pred - target), e = squared (kind 0, MSELoss) or absolute (kind 1,
+// L1Loss) error; grad = w[r] e'(.) ; elem (optional) = w[r] e(.) per element (reduction 'none').
+// The sequence mask and every reduction of NamedLoss._reduce (loss/NamedLoss.py:113-131) are a
+// per-row weight: mean_per_frame mask / (frames D), mean_per_sample mask / (len_b B D),
+// mean mask / (T B D), sum / none mask.
+__global__ __launch_bounds__(256) void weighted_loss_kernel(
+    const float* __restrict__ pred, int64_t ldp, const float* __restrict__ target, int64_t ldt,
+    const float* __restrict__ w, int64_t M, int D, int kind, float* __restrict__ grad, int64_t ldg,
+    float* __restrict__ elem, int64_t lde, double* __restrict__ partial) {
+  __shared__ double red[16];
+  const int64_t n = M * D;
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D;
+    const int c = (int)(i - r * D);
+    const float wr = w[r];
+    const float diff = pred[r * ldp + c] - target[r * ldt + c];
+    const float e = kind == 0 ? diff * diff : fabsf(diff);
+    const float g = kind == 0 ? 2.f * diff : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+    const float v = wr == 0.f ? 0.f : wr * e;          // padding may hold anything (also NaN)
+    s += (double)v;
+    if (grad) grad[r * ldg + c] = wr == 0.f ? 0.f : wr * g;
+    if (elem) elem[r * lde + c] = v;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
 // ---- Adam ---------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
@@ -708,6 +738,29 @@ extern "C" int itts_masked_mse(const float* d_pred, int64_t ldp, const float* d_
   ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
                      reinterpret_cast<const double*>(d_workspace), nb, scale, d_loss);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_weighted_loss(const float* d_pred, int64_t ldp, const float* d_target, int64_t ldt,
+                                  const float* d_row_weight, int64_t M, int D, int kind,
+                                  float* d_loss, float* d_grad, int64_t ldg, float* d_elem,
+                                  int64_t lde, void* d_workspace, void* stream) {
+  ITTS_REQUIRE(d_pred && d_target && d_row_weight && d_loss && d_workspace, "null pointer");
+  ITTS_REQUIRE(M >= 0 && D > 0 && ldp >= D && ldt >= D && (kind == 0 || kind == 1), "bad sizes");
+  ITTS_REQUIRE((!d_grad || ldg >= D) && (!d_elem || lde >= D), "leading dimension too small");
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    ITTS_HIP_CHECK(hipMemsetAsync(d_loss, 0, 4, s));
+    return ITTS_OK;
+  }
+  const int nb = mse_blocks(M, D);
+  hipLaunchKernelGGL(weighted_loss_kernel, dim3(nb), dim3(256), 0, s, d_pred, ldp, d_target, ldt,
+                     d_row_weight, M, D, kind, d_grad, ldg, d_elem, lde,
+                     reinterpret_cast<double*>(d_workspace));
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
+                     reinterpret_cast<const double*>(d_workspace), nb, 1.0, d_loss);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }

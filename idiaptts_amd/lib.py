@@ -58,6 +58,8 @@ _SIGNATURES = {
     "itts_masked_mse_workspace_bytes": (c_int64, [c_int64, c_int]),
     "itts_masked_mse": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_double, c_float,
                                 _P, _P, c_int64, _P, _P]),
+    "itts_weighted_loss": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P, _P,
+                                   c_int64, _P, c_int64, _P, _P]),
     "itts_cheaptrick_mcep": (c_int, [_P, POINTER(c_int64), _P, POINTER(c_int64), c_int, c_int,
                                      c_double, c_int, c_double, _P, c_int, c_double, c_double,
                                      c_int, c_int, c_double, _P, c_int64, _P, _P, _P]),

@@ -230,6 +230,27 @@ def masked_mse(pred, target, row_valid, n_valid, loss_weight=1.0, want_grad=True
     return loss, (grad if want_grad else None)
 
 
+def weighted_loss(pred, target, row_weight, kind, want_grad=True, want_elem=False):
+    """sum_r w[r] sum_c e(pred - target) on [M, D] rows, e squared (kind 0) / absolute (kind 1)
+    error: (loss [1], grad or None, elementwise values or None)."""
+    L = _lib.load()
+    _need(pred, torch.float32, "pred")
+    _need(target, torch.float32, "target")
+    _need(row_weight, torch.float32, "row_weight")
+    M, D = pred.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    grad = torch.empty((M, D), dtype=torch.float32, device=pred.device) if want_grad else None
+    elem = torch.empty((M, D), dtype=torch.float32, device=pred.device) if want_elem else None
+    ws = torch.empty(max(L.itts_masked_mse_workspace_bytes(M, D), 8), dtype=torch.uint8,
+                     device=pred.device)
+    _lib.check(L.itts_weighted_loss(_ptr(pred), _rows(pred, "pred"), _ptr(target),
+                                    _rows(target, "target"), _ptr(row_weight.contiguous()), M, D,
+                                    int(kind), _ptr(loss), _ptr(grad), D if want_grad else 0,
+                                    _ptr(elem), D if want_elem else 0, _ptr(ws), _stream()),
+               "itts_weighted_loss")
+    return loss, grad, elem
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
               weight_decay=0.0, grad_scale=1.0):
     L = _lib.load()

@@ -1,6 +1,9 @@
-"""NamedLoss with the reference's interface (loss/NamedLoss.py:16-131) for the loss on the hot
-path: MSELoss(reduction='none') * seq_mask, reduced 'mean_per_frame' (sum over batch and time /
-total frames, mean over features) -- one fused HIP kernel producing the loss and its gradient."""
+"""NamedLoss with the reference's interface (loss/NamedLoss.py:16-131).  The loss on the hot path --
+MSELoss(reduction='none') * seq_mask, reduced 'mean_per_frame' (sum over batch and time / total
+frames, mean over features) -- is one fused HIP kernel producing the loss and its gradient.  The
+other element-wise types (MSELoss, L1Loss) and reductions ('mean_per_sample', 'mean', 'sum',
+'none', with or without a sequence mask; reference :113-131) run a second kernel in which the mask
+and the reduction are folded into one weight per frame."""
 import torch
 from torch import nn
 
@@ -28,6 +31,34 @@ class MaskedMSEFunction(torch.autograd.Function):
         return (grad * dloss).reshape(ctx.shape), None, None, None
 
 
+class WeightedLossFunction(torch.autograd.Function):
+    """sum_r w[r] sum_c e(pred - target) (e: squared / absolute error) or, with `elementwise`, the
+    weighted element-wise values themselves (reduction 'none')."""
+
+    @staticmethod
+    def forward(ctx, pred, target, row_weight, kind, elementwise):
+        D = pred.shape[-1]
+        p2 = pred.reshape(-1, D)
+        t2 = target.reshape(-1, D)
+        if p2.stride(-1) != 1:
+            p2 = p2.contiguous()
+        if t2.stride(-1) != 1:
+            t2 = t2.contiguous()
+        loss, grad, elem = ops.weighted_loss(p2, t2, row_weight, kind, want_grad=True,
+                                             want_elem=elementwise)
+        ctx.save_for_backward(grad)
+        ctx.shape = pred.shape
+        ctx.elementwise = elementwise
+        return elem.reshape(pred.shape) if elementwise else loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        if ctx.elementwise:
+            return grad.reshape(ctx.shape) * dloss, None, None, None, None
+        return (grad * dloss).reshape(ctx.shape), None, None, None, None
+
+
 class NamedLoss(nn.Module):
 
     class Config:
@@ -46,12 +77,21 @@ class NamedLoss(nn.Module):
         def create_loss(self):
             return NamedLoss(self)
 
+    KINDS = {"MSELoss": 0, "L1Loss": 1}
+    REDUCTIONS = ("mean_per_frame", "mean_per_sample", "mean", "sum", "none")
+
     def __init__(self, config):
         super().__init__()
-        if config.type != "MSELoss" or config.reduction != 'mean_per_frame' \
-                or config.seq_mask is None:
-            raise NotImplementedError("Accelerated: MSELoss with seq_mask and 'mean_per_frame' "
-                                      "(AcousticModelTrainer.py:179-185).")
+        if config.type not in self.KINDS:
+            raise NotImplementedError("Loss type {} has no kernel here (element-wise MSELoss and "
+                                      "L1Loss do).".format(config.type))
+        if config.reduction not in self.REDUCTIONS:
+            raise NotImplementedError("Unknown reduction type {}.".format(config.reduction))
+        if config.seq_mask is None and config.reduction in ("mean_per_frame", "mean_per_sample"):
+            raise ValueError("Reduction '{}' divides by the sequence lengths: it needs a seq_mask "
+                             "(reference NamedLoss.py:114-121).".format(config.reduction))
+        self.kind = self.KINDS[config.type]
+        self.reduction = config.reduction
         self.name = config.name
         self.input_names = config.input_names
         self.seq_mask = config.seq_mask
@@ -59,17 +99,51 @@ class NamedLoss(nn.Module):
         self.loss_weight = config.loss_weight
         self.start_step = config.start_step
 
+    def _row_weight(self, a, mask, length_dict):
+        """One weight per (time, batch) position: sequence mask x what the reduction divides by."""
+        D = a.shape[-1]
+        lead = tuple(a.shape[:-1])                            # [T, B] or [B, T]
+        n_rows = 1
+        for n in lead:
+            n_rows *= int(n)
+        if mask is not None:
+            w = data_mask = mask.reshape(lead).to(torch.float32)
+        else:
+            w = data_mask = torch.ones(lead, dtype=torch.float32, device=a.device)
+        if self.reduction == "mean_per_frame":
+            w = data_mask / (float(sum(length_dict[self.seq_mask])) * D)
+        elif self.reduction == "mean_per_sample":
+            lens = torch.as_tensor(length_dict[self.seq_mask], dtype=torch.float32, device=a.device)
+            batch_dim = 0 if self.batch_first else 1
+            shape = [1] * len(lead)
+            shape[batch_dim] = lens.numel()
+            w = data_mask / (lens.reshape(shape) * (lens.numel() * D))
+        elif self.reduction == "mean":
+            w = data_mask / float(n_rows * D)
+        return w.reshape(-1).contiguous()
+
     def forward(self, data, length_dict, step):
         a, b = (data[n] for n in self.input_names)       # (target, prediction)
-        mask = data[self.seq_mask]                       # [.., .., 1] float, 1 inside the sequence
-        row_valid = (mask.reshape(-1) > 0).to(torch.uint8)
-        total_num_frames = float(sum(length_dict[self.seq_mask]))
-        # MSE is symmetric: differentiate through whichever input needs it
-        if b.requires_grad or not a.requires_grad:
-            loss = MaskedMSEFunction.apply(b, a.detach(), row_valid, total_num_frames)
-        else:
-            loss = MaskedMSEFunction.apply(a, b.detach(), row_valid, total_num_frames)
         weight = 0. if step < self.start_step else self.loss_weight
+        if self.kind == 0 and self.reduction == "mean_per_frame":
+            mask = data[self.seq_mask]                   # [.., .., 1] float, 1 inside the sequence
+            row_valid = (mask.reshape(-1) > 0).to(torch.uint8)
+            total_num_frames = float(sum(length_dict[self.seq_mask]))
+            # MSE is symmetric: differentiate through whichever input needs it
+            if b.requires_grad or not a.requires_grad:
+                loss = MaskedMSEFunction.apply(b, a.detach(), row_valid, total_num_frames)
+            else:
+                loss = MaskedMSEFunction.apply(a, b.detach(), row_valid, total_num_frames)
+        else:
+            w = self._row_weight(a, data[self.seq_mask] if self.seq_mask is not None else None,
+                                 length_dict)
+            # both element-wise losses are symmetric in their arguments
+            if b.requires_grad or not a.requires_grad:
+                loss = WeightedLossFunction.apply(b, a.detach(), w, self.kind,
+                                                  self.reduction == "none")
+            else:
+                loss = WeightedLossFunction.apply(a, b.detach(), w, self.kind,
+                                                  self.reduction == "none")
         out = {self.name: loss * weight}
         data.update(out)
         return out

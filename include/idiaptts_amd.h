@@ -175,6 +175,18 @@ int itts_masked_mse(const float* d_pred, int64_t ldp, const float* d_target, int
                     float loss_weight, float* d_loss, float* d_grad, int64_t ldg,
                     void* d_workspace, void* stream);
 
+/* The other NamedLoss types and reductions (loss/NamedLoss.py:113-131): row-weighted elementwise loss
+ *   loss = sum_r w[r] sum_c e(pred[r,c] - target[r,c]),  e = squared (kind 0: MSELoss) or absolute
+ *   (kind 1: L1Loss) error;  d_grad = dloss/dpred;  d_elem (optional) = w[r] e per element.
+ * The sequence mask and the reduction are folded into d_row_weight [M] f32 by the caller:
+ * 'mean_per_frame' mask / (frames * D), 'mean_per_sample' mask / (len_b * B * D), 'mean' mask /
+ * (rows * D), 'sum' and 'none' mask.  Rows of weight 0 may hold anything.
+ * d_workspace >= itts_masked_mse_workspace_bytes(M, D). */
+int itts_weighted_loss(const float* d_pred, int64_t ldp, const float* d_target, int64_t ldt,
+                       const float* d_row_weight, int64_t M, int D, int kind, float* d_loss,
+                       float* d_grad, int64_t ldg, float* d_elem, int64_t lde, void* d_workspace,
+                       void* stream);
+
 /* ---- Adam on a flat fp32 parameter buffer (torch.optim.Adam semantics, ----------------------
  *      ModularModelHandlerPyTorch.py:570-571); grad_scale multiplies the gradient first
  *      (1/world_size after an all-reduce(sum)). */

@@ -181,3 +181,53 @@ def test_degenerate_sizes_and_error_reporting(gpu):
                                3, 2, 16, 1, ctypes.c_void_p(dummy.data_ptr()), None, None, None, None,
                                ctypes.c_void_p(dummy.data_ptr()), None)
     assert rc != 0 and b"longest" in L.itts_last_error()
+
+
+@pytest.mark.parametrize("type_,reduction,masked,batch_first", [
+    ("MSELoss", "mean_per_sample", True, False), ("MSELoss", "mean", True, False),
+    ("MSELoss", "sum", True, True), ("MSELoss", "none", True, False),
+    ("MSELoss", "mean", False, False), ("MSELoss", "sum", False, True),
+    ("L1Loss", "mean_per_frame", True, False), ("L1Loss", "mean_per_sample", True, True),
+    ("L1Loss", "mean", False, False), ("L1Loss", "none", True, False)])
+def test_named_loss_other_types_and_reductions(gpu, type_, reduction, masked, batch_first):
+    """NamedLoss.forward / _reduce (reference loss/NamedLoss.py:70-131) for the combinations the
+    hot path does not use: loss_fn(reduction='none') * seq_mask, then the reduction -- value and
+    gradient against the same formulas in torch on the CPU (float64)."""
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    from idiaptts_amd.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss
+    torch.manual_seed(3)
+    lens = torch.tensor([7, 3, 5])
+    T, B, D = 7, 3, 4
+    shape = (B, T, D) if batch_first else (T, B, D)
+    pred = torch.randn(shape)
+    target = torch.randn(shape)
+    mask = Handler.sequence_mask(lens, T, batch_first=batch_first)
+    loss_mod = NamedLoss.Config(name="l", type_=type_, seq_mask="m" if masked else None,
+                                input_names=["y", "p"], batch_first=batch_first,
+                                reduction=reduction, loss_weight=0.7).create_loss()
+    pg = pred.to(gpu).requires_grad_(True)
+    data = {"y": target.to(gpu), "p": pg, "m": mask.to(gpu)}
+    out = loss_mod(data, {"m": lens, "y": lens, "p": lens}, step=1)["l"]
+    w_out = torch.randn(out.shape).to(gpu) if reduction == "none" else None
+    (out * w_out).sum().backward() if reduction == "none" else out.backward()
+    # reference formulas
+    pr = pred.double().requires_grad_(True)
+    v = getattr(torch.nn, type_)(reduction="none")(target.double(), pr)
+    if masked:
+        v = mask.double() * v
+    if reduction == "mean_per_frame":
+        ref = (v.sum(dim=(0, 1)) / lens.sum().double()).mean()
+    elif reduction == "mean_per_sample":
+        ref = (v.sum(dim=1 if batch_first else 0) / lens.unsqueeze(-1).double()).mean()
+    elif reduction == "mean":
+        ref = v.mean()
+    elif reduction == "sum":
+        ref = v.sum()
+    else:
+        ref = v
+    ref = ref * 0.7
+    (ref * w_out.cpu().double()).sum().backward() if reduction == "none" else ref.backward()
+    assert out.shape == ref.shape
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert (pg.grad.cpu().double() - pr.grad).abs().max() < 1e-5 * max(1.0, float(pr.grad.abs().max()))
