@@ -36,6 +36,12 @@ _SIGNATURES = {
                                             POINTER(c_char_p), c_int, POINTER(c_int),
                                             POINTER(c_int), POINTER(c_int), POINTER(c_char_p),
                                             c_int, _P]),
+    "itts_questions_load": (c_int, [c_char_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]),
+    "itts_questions_free": (None, [c_void_p]),
+    "itts_questions_vector": (c_int, [c_void_p, c_char_p, _P]),
+    "itts_labels_count_frames": (c_int, [POINTER(c_char_p), c_int, POINTER(c_int64), c_int]),
+    "itts_labels_generate": (c_int, [c_void_p, POINTER(c_char_p), c_int, POINTER(c_int64), _P,
+                                     c_int64, c_int]),
     "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),

@@ -15,7 +15,14 @@ perform_normalisation :38-76), rebuilt around whole-utterance numpy arrays:
     backwards, phone length, state share of the phone, fraction through the phone backwards /
     forwards).  The question vector is matched once per distinct context string (cached across
     utterances), the nine features are computed for all frames of the utterance at once.
-Results are bit-identical to the reference's (same IEEE divisions, float64 then float32)."""
+Results are bit-identical to the reference's (same IEEE divisions, float64 then float32).
+
+The production path is native: `csrc/labels.cpp` behind the C ABI (itts_questions_load,
+itts_labels_count_frames, itts_labels_generate -- patterns compiled once per question, files spread
+over plain threads).  The numpy formulation below is kept as its
+checker (`HTSLabelNormalisation(..., native=False)`; tests/test_host_logic.py pins both to the
+reference's `questions/*.questions` fixtures)."""
+import ctypes
 import logging
 import os
 import re
@@ -93,7 +100,7 @@ class HTSLabelNormalisation(object):
     state_number = 5
 
     def __init__(self, file_questions=None, add_frame_features=True, subphone_feats='full',
-                 continuous_flag=True):
+                 continuous_flag=True, native=True, n_threads=None):
         if not add_frame_features or subphone_feats != 'full':
             raise NotImplementedError("Only frame-level labels with the nine 'full' sub-phone "
                                       "features are generated here (what the trainers use).")
@@ -102,6 +109,40 @@ class HTSLabelNormalisation(object):
         self.dict_size = len(self.questions)
         self.frame_feature_size = 9
         self.dimension = self.dict_size + self.frame_feature_size if self.dict_size else 0
+        self.n_threads = n_threads or max(1, min(16, (os.cpu_count() or 2) // 2))
+        self._handle = None
+        if native:
+            from idiaptts_amd import lib as _lib
+            self._lib = _lib
+            L = _lib.load()
+            handle, nb, nc = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+            _lib.check(L.itts_questions_load(os.fsencode(file_questions), ctypes.byref(handle),
+                                             ctypes.byref(nb), ctypes.byref(nc)),
+                       "itts_questions_load")
+            assert nb.value + nc.value == self.dict_size
+            self._handle = handle
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            self._lib.load().itts_questions_free(self._handle)
+            self._handle = None
+
+    def generate_batch(self, file_names):
+        """Labels of several `.lab` files in one native call: ([sum frames, dimension] float64,
+        frame offsets [n + 1])."""
+        L = self._lib.load()
+        n = len(file_names)
+        paths = (ctypes.c_char_p * n)(*[os.fsencode(f) for f in file_names])
+        frames = (ctypes.c_int64 * n)()
+        self._lib.check(L.itts_labels_count_frames(paths, n, frames, self.n_threads),
+                        "itts_labels_count_frames")
+        off = np.concatenate([[0], np.cumsum(np.frombuffer(frames, dtype=np.int64))]).astype(np.int64)
+        out = np.empty((int(off[-1]), self.dimension), dtype=np.float64)
+        offs = (ctypes.c_int64 * (n + 1))(*[int(o) for o in off])
+        self._lib.check(L.itts_labels_generate(self._handle, paths, n, offs, out.ctypes.data,
+                                               self.dimension, self.n_threads),
+                        "itts_labels_generate")
+        return out, off
 
     # reference method names for the two halves of a question vector
     def pattern_matching_binary(self, label):
@@ -130,6 +171,8 @@ class HTSLabelNormalisation(object):
 
     def load_labels_with_state_alignment(self, file_name):
         """[frames, dict_size + 9] float64 (reference :521-666)."""
+        if self._handle is not None:
+            return self.generate_batch([file_name])[0]
         n, state, labels = self.parse_state_alignment(file_name)
         S = self.state_number
         if len(n) % S != 0 or not np.array_equal(state, np.tile(np.arange(1, S + 1), len(n) // S)):
@@ -176,6 +219,31 @@ class HTSLabelNormalisation(object):
         their min / max (`<dir_out>/<id list name>-min-max.npz`); reference :38-76."""
         extractor = MinMaxExtractor()
         dict_labels = OrderedDict()
+        if self._handle is not None and len(id_list) > 0:
+            # native batch: all label files in one call, all archives in one call
+            files = [os.path.join(dir_labels, i + self.htk_label_extension) for i in id_list]
+            block, off = self.generate_batch(files)
+            if dir_out is not None:
+                block = block.astype(np.float32)          # what extract_linguistic_features saves
+                os.makedirs(dir_out, exist_ok=True)
+                L = self._lib.load()
+                n = len(id_list)
+                paths = (ctypes.c_char_p * n)(*[os.fsencode(os.path.join(dir_out, i + ".npz"))
+                                                for i in id_list])
+                for i in id_list:
+                    os.makedirs(os.path.dirname(os.path.join(dir_out, i)) or ".", exist_ok=True)
+                offs = (ctypes.c_int64 * (n + 1))(*[int(o) for o in off])
+                self._lib.check(L.itts_write_feature_archives(
+                    block.ctypes.data, self.dimension, offs, n, paths, 1, (ctypes.c_int * 1)(0),
+                    (ctypes.c_int * 1)(self.dimension), (ctypes.c_int * 1)(1),
+                    (ctypes.c_char_p * 1)(b"questions"), self.n_threads, None),
+                    "itts_write_feature_archives")
+            for k, file_id in enumerate(id_list):
+                labels = block[off[k]:off[k + 1]]
+                extractor.add_sample(labels)
+                if return_dict:
+                    dict_labels[file_id] = labels
+            id_list = []
         for file_id in id_list:
             out = os.path.join(dir_out, file_id + self.questions_label_extension) \
                 if dir_out is not None else None

@@ -77,6 +77,25 @@ int itts_write_feature_archives(const float* h_feat, int64_t ld, const int64_t* 
                                 const int* h_width, const int* h_parts, const char* const* h_keys,
                                 int n_threads, unsigned char* h_needs_merge);
 
+/* ---- question labels (host, no GPU; csrc/labels.cpp) ------------------------------------------------
+ * HTSLabelNormalisation (src/data_preparation/questions/label_normalisation.py): question-set
+ * loading :817-897 (patterns compiled once per question), pattern matching :753-791,
+ * load_labels_with_state_alignment :521-666.  Bit-identical to the reference.
+ *   itts_questions_load      compiles a `.hed` question file (QS / CQS lines); *handle is freed with
+ *                            itts_questions_free; label width = n_binary + n_continuous + 9
+ *   itts_questions_vector    question answers of one context string -> h_out [n_binary + n_continuous]
+ *   itts_labels_count_frames frames of every state-aligned `.lab` file (int((end - start) / 50000)
+ *                            per state line; five state lines [2]..[6] per phone)
+ *   itts_labels_generate     frame-level labels of all files into h_out [sum frames, ld_out] f64, file i at
+ *                            rows h_frame_off[i] .. h_frame_off[i+1]: question vector of the phone +
+ *                            the nine sub-phone features ('full'); files are spread over n_threads */
+int itts_questions_load(const char* h_path, void** handle, int* n_binary, int* n_continuous);
+void itts_questions_free(void* handle);
+int itts_questions_vector(void* handle, const char* h_label, double* h_out);
+int itts_labels_count_frames(const char* const* h_paths, int n_files, int64_t* h_frames, int n_threads);
+int itts_labels_generate(void* handle, const char* const* h_paths, int n_files,
+                         const int64_t* h_frame_off, double* h_out, int64_t ld_out, int n_threads);
+
 /* ---- MLPG (misc/mlpg.py:94-127, bandmat solveh) ----------------------------------------- */
 /*
  * Batched maximum-likelihood parameter generation with the reference's three windows

@@ -254,3 +254,65 @@ def test_npz_data_reader_matches_reference_fixture(golden_dir, tmp_path):
         normed["utt1"]                                  # parameters not loaded yet
     with pytest.raises(NotImplementedError):
         DataReader(DataReader.Config("base")).load("utt1")
+
+
+def test_native_question_labels_equal_the_regex_formulation(golden_dir, tmp_path):
+    """csrc/labels.cpp (token lists + backtracking matcher, the production path) against the
+    numpy / `re` formulation it replaces: identical label matrices on the fixture `.lab` files, and
+    identical answers on adversarial context strings / patterns (anchors, inner wildcards, the two
+    CQS capture groups, backtracking into the digit group, 'LL-' questions)."""
+    import ctypes
+    import zipfile
+    from idiaptts_amd import lib as _lib
+    from idiaptts_amd.src.data_preparation.questions.label_normalisation import \
+        HTSLabelNormalisation, QuestionSet
+    lab_dir = str(tmp_path / "lab")
+    zipfile.ZipFile(os.path.join(golden_dir, "labels_state_align.zip")).extractall(lab_dir)
+    qfile = os.path.join(golden_dir, "questions-en-radio_dnn_400.hed")
+    g = np.load(os.path.join(golden_dir, "trainer_fixture.npz"))
+    ids = [str(i) for i in g["id_list"]]
+    nat = HTSLabelNormalisation(qfile, n_threads=3)
+    ref = HTSLabelNormalisation(qfile, native=False)
+    assert nat._handle is not None and ref._handle is None
+    files = [os.path.join(lab_dir, i + ".lab") for i in ids]
+    block, off = nat.generate_batch(files)
+    for k, f in enumerate(files):
+        want = ref.load_labels_with_state_alignment(f)
+        assert np.array_equal(block[off[k]:off[k + 1]], want), f
+        assert np.array_equal(nat.load_labels_with_state_alignment(f), want)
+    # adversarial question file
+    qs = tmp_path / "q.hed"
+    qs.write_text("\n".join([
+        'QS "C-a" {*-a+*,*-aa+*}', 'QS "LL-x" {x^*,yy^*}', 'QS "exact" {abc}', 'QS "pre" {ab*}',
+        'QS "suf" {*yz}', 'QS "mid" {a*c*e}', 'QS "all" {*}', 'QS "dots" {*a.b*}',
+        'QS "paren" {*(x)*}', 'QS "two" {p*q,*r|s*}', 'QS "LL-lit" {lit}',
+        'CQS "num" {@(\\d+)_}', 'CQS "numdot" {*:([\\d\\.]+)+*}', 'CQS "back" {#(\\d+)5}',
+        'CQS "anch" {(\\d+)=*}', 'CQS "end" {*/E:(\\d+)}', '']))
+    L = _lib.load()
+    handle, nb, nc = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(L.itts_questions_load(os.fsencode(str(qs)), ctypes.byref(handle), ctypes.byref(nb),
+                                     ctypes.byref(nc)), "load")
+    py = QuestionSet(str(qs))
+    assert (nb.value, nc.value) == (len(py.binary), len(py.continuous)) == (11, 5)
+    rng = np.random.default_rng(0)
+    alphabet = list("abcxyz^-+|@_:#=/E.()0123456789prqslit")
+    labels = ["abc", "ab", "xabcx", "x^a-aa+b", "yy^", "ayy^", "aXcXe", "ace", "a.b", "aXb",
+              "(x)", "p..q", "r|s", "lit", "alit", "@12_", "@_", "x@007_y", ":1.5+", ":..+",
+              "#1255", "#55", "#5", "12=rest", "a12=", "/E:3", "/E:3x", "", "a-a+"]
+    labels += ["".join(rng.choice(alphabet, size=int(rng.integers(0, 14)))) for _ in range(3000)]
+    out = np.empty(16)
+    for lab in labels:
+        try:
+            want = py.vector(lab)
+        except ValueError:          # float('1..2'): the reference raises there as well
+            continue
+        _lib.check(L.itts_questions_vector(handle, lab.encode(), out.ctypes.data), "vector")
+        assert np.array_equal(out, want), (lab, out, want)
+    L.itts_questions_free(handle)
+    # malformed inputs come back as errors with a message
+    bad = tmp_path / "bad.lab"
+    bad.write_text("0 50000 a-b+c[2]\n50000 100000 a-b+c[3]\n")
+    with pytest.raises(_lib.IttsError):
+        nat.generate_batch([str(bad)])
+    with pytest.raises(_lib.IttsError):
+        nat.generate_batch([str(tmp_path / "missing.lab")])
