@@ -73,6 +73,15 @@ bool match_here(const Pattern& p, size_t ti, const std::string& s, size_t pos, i
 
 bool search(const Pattern& p, const std::string& s, int* cb, int* ce) {
   *cb = *ce = -1;
+  if (p.toks.size() == 1 && p.toks[0].kind == LIT) {
+    // the common case (`*-a+*`, `aa~*`, `*|1`, `abc`): one literal, anchored or not
+    const std::string& lit = p.toks[0].lit;
+    if (lit.size() > s.size()) return false;
+    if (p.anchor_start && p.anchor_end) return s == lit;
+    if (p.anchor_start) return s.compare(0, lit.size(), lit) == 0;
+    if (p.anchor_end) return s.compare(s.size() - lit.size(), lit.size(), lit) == 0;
+    return s.find(lit) != std::string::npos;
+  }
   if (p.anchor_start) return match_here(p, 0, s, 0, cb, ce);
   for (size_t st = 0; st <= s.size(); ++st)
     if (match_here(p, 0, s, st, cb, ce)) return true;
