@@ -83,6 +83,9 @@ _SIGNATURES = {
                          c_double, _P, _P, _P, c_int64, _P]),
     "itts_dio": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), c_int, c_int, c_double, c_double,
                          c_double, c_double, c_double, _P, _P]),
+    "itts_harvest_num_frames": (c_int64, [c_int64, c_int, c_double]),
+    "itts_harvest": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), c_int, c_int, c_double, c_double,
+                             c_double, _P, _P, _P, _P, _P, _P]),
     "itts_wav2world": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), c_int, c_int, c_double, c_int,
                                _P, _P, _P, _P]),
     "itts_world_synthesize": (c_int, [_P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int,

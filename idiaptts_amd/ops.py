@@ -467,6 +467,37 @@ def dio(x, x_off, f_off, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
     return f0
 
 
+def harvest_num_frames(n_samples, fs, frame_period=5.0):
+    return int(_lib.load().itts_harvest_num_frames(int(n_samples), int(fs), float(frame_period)))
+
+
+def harvest(x, x_off, f_off, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0, stages=False):
+    """pyworld.harvest for utterances stored back to back: f0 [Ttot] f64 (frame counts from
+    harvest_num_frames).  stages=True (one utterance): also a dict with the raw band candidates,
+    the refined candidates / scores and the 1 ms contour before smoothing."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    f0 = torch.empty((int(f_off[-1]),), dtype=torch.float64, device=x.device)
+    dbg = {}
+    ptrs = [None, None, None, None]
+    if stages:
+        import math
+        assert len(x_off) == 2, "stages are returned for a single utterance"
+        nch = 1 + int(math.log(f0_ceil * 1.1 / (f0_floor * 0.9)) / math.log(2.0) * 40.0)
+        maxc = int(nch / 10.0 + 0.5) * 7
+        T1 = harvest_num_frames(int(x_off[1]) - int(x_off[0]), fs, 1.0)
+        dbg = dict(raw=torch.zeros((nch, T1), dtype=torch.float64, device=x.device),
+                   cand=torch.zeros((T1, maxc), dtype=torch.float64, device=x.device),
+                   score=torch.zeros((T1, maxc), dtype=torch.float64, device=x.device),
+                   best=torch.zeros((T1,), dtype=torch.float64, device=x.device))
+        ptrs = [_ptr(dbg[k]) for k in ("raw", "cand", "score", "best")]
+    _lib.check(L.itts_harvest(_ptr(x), _lib.offsets_array(x_off), _lib.offsets_array(f_off),
+                              len(x_off) - 1, fs, float(frame_period), float(f0_floor),
+                              float(f0_ceil), _ptr(f0), ptrs[0], ptrs[1], ptrs[2], ptrs[3],
+                              _stream()), "itts_harvest")
+    return (f0, dbg) if stages else f0
+
+
 def wav2world(x, x_off, f_off, fs, frame_period=5.0, fft_size=None, want_sp=True, want_ap=True):
     """pyworld.wav2world for utterances stored back to back: (f0 [Ttot], sp [Ttot, K] or None,
     ap [Ttot, K] or None), all f64 (WorldFeatLabelGen.py:792-793)."""

@@ -318,6 +318,20 @@ int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, 
              double frame_period_ms, double f0_floor, double f0_ceil, double channels_in_octave,
              double allowed_range, double* d_f0, void* stream);
 
+/* Harvest F0 estimation (pyworld.harvest(x, fs, f0_floor=71, f0_ceil=800, frame_period=5): the
+ * estimator BASELINE.json's north_star names beside DIO; the reference's own extractor is
+ * dio + stonemask, WorldFeatLabelGen.py:792-793).  Frame count per utterance:
+ * itts_harvest_num_frames (WORLD GetSamplesForHarvest).  d_f0 [Ttot] f64.  The d_dbg_* pointers
+ * (NULL, or device buffers when n_utts == 1) receive intermediate stages on the 1 ms grid
+ * T1 = itts_harvest_num_frames(n, fs, 1.0): raw band candidates [channels, T1]; refined candidates
+ * and scores after RemoveUnreliableCandidates [T1, max_candidates]; the contour before smoothing
+ * [T1].  Synchronises the stream once at the end (event-list overflow check). */
+int64_t itts_harvest_num_frames(int64_t n_samples, int fs, double frame_period_ms);
+int itts_harvest(const double* d_x, const int64_t* h_x_off, const int64_t* h_f_off, int n_utts,
+                 int fs, double frame_period_ms, double f0_floor, double f0_ceil, double* d_f0,
+                 double* d_dbg_raw, double* d_dbg_cand, double* d_dbg_score, double* d_dbg_best,
+                 void* stream);
+
 /* pyworld.wav2world(x, fs, fft_size=..., frame_period=...) in one call (WorldFeatLabelGen.py:792-793):
  * DIO -> StoneMask -> CheapTrick -> D4C with wav2world's defaults (f0 floor 71 Hz, q1 -0.15, D4C
  * threshold 0.85).  d_f0 [Ttot] f64, d_sp / d_ap [Ttot, fft_size/2+1] f64 (either may be NULL);

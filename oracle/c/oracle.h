@@ -15,6 +15,17 @@ int orc_mround(double x);
 void orc_interp1(const double* x, const double* y, int n, const double* xi, int m, double* yi);
 void orc_nuttall(int n, double* w);
 
+/* Harvest (harvest.c) */
+void orc_harvest_set_mirror_write(int on);
+int orc_harvest_num_frames(int xl, int fs, double frame_period);
+void orc_decimate_coefficients(int r, double* a3, double* b2);
+int orc_harvest_waveform(const double* x, int xl, int fs, double* y);
+int orc_harvest(const double* x, int xl, int fs, double frame_period, double f0_floor,
+                double f0_ceil, double* f0_out, double* tp_out);
+int orc_harvest_debug(const double* x, int xl, int fs, double frame_period, double f0_floor,
+                      double f0_ceil, double* f0_out, double* tp_out, double* raw_out,
+                      double* cand_out, double* score_out, double* best_out, int* dims);
+
 /* WORLD's randn() (common.cpp / matlabfunctions.cpp): xorshift128 with the fixed seed that
  * randn_reseed() restores at the start of CheapTrick / D4C / Synthesis; one normal deviate is
  * the sum of 12 draws of 28 bits. */

@@ -82,6 +82,50 @@ def dio(x, fs, frame_period=5.0):
     return f0, tp
 
 
+def harvest_num_frames(n, fs, frame_period=5.0):
+    return int(1000.0 * n / fs / frame_period) + 1
+
+
+def harvest(x, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0, debug=False, mirror_write=True):
+    """pyworld.harvest(x, fs, f0_floor, f0_ceil, frame_period) -> (f0, t); with `debug` also the
+    per-stage arrays (1 ms grid).  mirror_write=False drops the spectrum bins that
+    GetFilteredSignal overwrites while it multiplies (test decomposition only)."""
+    _fn("orc_harvest_set_mirror_write", None, [c_int])(1 if mirror_write else 0)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = harvest_num_frames(len(x), fs, frame_period)
+    f0 = np.zeros(T)
+    tp = np.zeros(T)
+    fn = _fn("orc_harvest_debug", c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p])
+    if not debug:
+        assert fn(_p(x), len(x), fs, frame_period, f0_floor, f0_ceil, _p(f0), _p(tp), None, None,
+                  None, None, None) == 0
+        return f0, tp
+    import math
+    nch = 1 + int(math.log(f0_ceil * 1.1 / (f0_floor * 0.9)) / math.log(2.0) * 40.0)
+    T1 = harvest_num_frames(len(x), fs, 1.0)
+    maxc = int(nch / 10.0 + 0.5) * 7
+    raw = np.zeros((nch, T1))
+    cand = np.zeros((T1, maxc))
+    score = np.zeros((T1, maxc))
+    best = np.zeros(T1)
+    dims = np.zeros(8, dtype=np.int32)
+    assert fn(_p(x), len(x), fs, frame_period, f0_floor, f0_ceil, _p(f0), _p(tp), _p(raw),
+              _p(cand), _p(score), _p(best), _p(dims)) == 0
+    assert dims[0] == nch and dims[1] == T1 and dims[2] == maxc
+    return f0, tp, dict(raw=raw, cand=cand, score=score, best=best, n_cand=int(dims[4]),
+                        y_length=int(dims[3]))
+
+
+def harvest_waveform(x, fs):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(len(x) + 8)
+    fn = _fn("orc_harvest_waveform", c_int, [c_void_p, c_int, c_int, c_void_p])
+    n = fn(_p(x), len(x), fs, _p(y))
+    return y[:n].copy()
+
+
 def stonemask(x, fs, tp, f0):
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.zeros(len(f0))
