@@ -60,6 +60,7 @@ struct HvParams {
 struct HvUtt {
   int64_t x_off, f_off;
   int xl, yl, T1, T;
+  int nfft;  // WORLD's FFT length for this utterance (enters through the mirrored spectrum write)
   int64_t y_off, dec_off, sig_off, ev_off, cnt_off, raw_off, base_off, cand_off, ctr_off, mc_off,
       sm_off;
 };
@@ -145,6 +146,62 @@ __global__ __launch_bounds__(NT) void hv_decimate_kernel(const double* __restric
   for (int i = threadIdx.x; i < u.yl; i += NT) y[i] -= mean;
 }
 
+// ---- the mirrored spectrum write of GetFilteredSignal ------------------------------------------------
+// WORLD multiplies the spectra in place and copies every product P[i] to bin N - i - 1 while the
+// loop is still running: P[N/2 - 1] lands in bin N/2 before that bin is multiplied, so the inverse
+// transform sees P'[N/2] = Y[N/2] * P[N/2 - 1] and P'[N/2 - 1] = P'[N/2].  In the time domain that
+// adds (-1)^m / N * (dN + 2 Re(d1 exp(-2 pi i m / N))) to every filtered sample, with
+// dN = Re P'[N/2] - Y[N/2] F[N/2] and d1 = P'[N/2] - P[N/2 - 1]: about 1e-5 of the in-band level for
+// the shortest filters.  This kernel evaluates the two bins of Y and F directly and stores, per
+// (utterance, channel), G and H such that sample n (m = n + half + 1) receives
+// (-1)^n (G + Hr cos(2 pi n / N) + Hi sin(2 pi n / N)).  grid (utterances).
+__global__ __launch_bounds__(NT) void hv_mirror_kernel(const HvUtt* __restrict__ utts, HvParams p,
+                                                       const HvTables* __restrict__ tab,
+                                                       const double* __restrict__ wt,
+                                                       const double* __restrict__ ypad,
+                                                       double* __restrict__ coef) {
+  __shared__ double red[8];
+  const HvUtt u = utts[blockIdx.x];
+  const double* y = ypad + u.y_off + p.pad;
+  const double invn = 1.0 / (double)u.nfft;
+  double a = 0.0, br = 0.0, bi = 0.0;  // Y[N/2], Y[N/2 - 1] = sum y[n] (-1)^n exp(+2 pi i n / N)
+  for (int n = threadIdx.x; n < u.yl; n += NT) {
+    double sn, cs;
+    sincospi(2.0 * n * invn, &sn, &cs);
+    const double v = (n & 1) ? -y[n] : y[n];
+    a += v;
+    br += v * cs;
+    bi += v * sn;
+  }
+  a = bsum(a, red);
+  br = bsum(br, red);
+  bi = bsum(bi, red);
+  double* out = coef + (int64_t)blockIdx.x * p.nch * 3;
+  for (int c = threadIdx.x; c < p.nch; c += NT) {
+    const int t = c >> 4, cc = c & 15, hmax = tab->hmax[t], h = tab->half[c];
+    const double* W = wt + tab->woff[t];
+    double fn = 0.0, fr = 0.0, fi = 0.0;  // F[N/2], F[N/2 - 1] over taps f[j], j = d + h
+    for (int d = -h; d <= h; ++d) {
+      const int j = d + h;
+      double sn, cs;
+      sincospi(2.0 * j * invn, &sn, &cs);
+      const double v = (j & 1) ? -W[(d + hmax) * 16 + cc] : W[(d + hmax) * 16 + cc];
+      fn += v;
+      fr += v * cs;
+      fi += v * sn;
+    }
+    const double p1r = br * fr - bi * fi, p1i = br * fi + bi * fr;  // P[N/2 - 1]
+    const double dN = a * p1r - a * fn;
+    const double d1r = (a - 1.0) * p1r, d1i = (a - 1.0) * p1i;
+    double sn, cs;  // exp(-2 pi i (h + 1) / N)
+    sincospi(2.0 * (h + 1) * invn, &sn, &cs);
+    const double sg = ((h + 1) & 1) ? -invn : invn;
+    out[c * 3 + 0] = sg * dN;
+    out[c * 3 + 1] = 2.0 * sg * (d1r * cs + d1i * sn);
+    out[c * 3 + 2] = 2.0 * sg * (d1i * cs - d1r * sn);
+  }
+}
+
 // ---- band-pass filters on the fp64 matrix cores ---------------------------------------------------
 // sig_c[n] = sum_{d=-half_c}^{half_c} g_c(d) y[n + 1 + d]   (the +1 is WORLD's delay compensation
 // of half + 1 for a filter centred at half).  v_mfma_f64_16x16x4_f64: A lane l = A[l % 16][l / 16],
@@ -155,6 +212,7 @@ __global__ __launch_bounds__(NT) void hv_bandpass_kernel(const HvUtt* __restrict
                                                          const HvTables* __restrict__ tab,
                                                          const double* __restrict__ wt,
                                                          const double* __restrict__ ypad,
+                                                         const double* __restrict__ coef,
                                                          double* __restrict__ sig) {
   extern __shared__ __attribute__((aligned(16))) char smem_bp[];
   double* sy = reinterpret_cast<double*>(smem_bp);
@@ -189,13 +247,28 @@ __global__ __launch_bounds__(NT) void hv_bandpass_kernel(const HvUtt* __restrict
     a = a_next;
   }
   double* out = sig + u.sig_off;
+  // the mirrored-write term (hv_mirror_kernel)
+  const double* cf = coef + (int64_t)blockIdx.z * p.nch * 3;
+  double G[4], Hr[4], Hi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = min(16 * t + l4 + 4 * i, p.nch - 1);
+    G[i] = cf[c * 3];
+    Hr[i] = cf[c * 3 + 1];
+    Hi[i] = cf[c * 3 + 2];
+  }
+  const double invn = 1.0 / (double)u.nfft;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int n = n0 + 64 * wv + 16 * m + l15;
+    double sn, cs;
+    sincospi(2.0 * n * invn, &sn, &cs);
+    const double sg = (n & 1) ? -1.0 : 1.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = 16 * t + l4 + 4 * i;
-      if (c < p.nch && n < u.yl) out[(int64_t)c * u.yl + n] = acc[m][i];
+      if (c < p.nch && n < u.yl)
+        out[(int64_t)c * u.yl + n] = acc[m][i] + sg * (G[i] + Hr[i] * cs + Hi[i] * sn);
     }
   }
 }
@@ -1047,6 +1120,10 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
       d.yl = (xl + p.r - 1) / p.r;
       d.T1 = (int)itts_harvest_num_frames(xl, fs, 1.0);
       d.T = (int)itts_harvest_num_frames(xl, fs, frame_period_ms);
+      {
+        const int sample = d.yl + 5 + 2 * (int)(2.0 * p.afs / tab.bnd[0]);
+        d.nfft = (int)std::pow(2.0, (int)(std::log((double)sample) / std::log(2.0)) + 1.0);
+      }
       ITTS_REQUIRE(h_f_off[u1 + 1] - h_f_off[u1] == d.T, "frame offsets do not match the frame count");
       ITTS_REQUIRE(d.yl >= 4, "utterance too short");
       d.y_off = y_n; d.dec_off = dec_n; d.sig_off = sig_n; d.ev_off = ev_n; d.cnt_off = cnt_n;
@@ -1074,6 +1151,8 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
     double *d_y = nullptr, *d_dec = nullptr, *d_sig = nullptr, *d_ev = nullptr, *d_raw = nullptr,
            *d_base = nullptr, *d_cand = nullptr, *d_ctr = nullptr, *d_mc = nullptr, *d_sm = nullptr;
     int *d_cnt = nullptr, *d_nc = nullptr;
+    double* d_coef = nullptr;
+    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_coef, (size_t)U * p.nch * 3 * 8, s));
     ITTS_HIP_CHECK(hipMallocAsync((void**)&d_utts, U * sizeof(HvUtt), s));
     ITTS_HIP_CHECK(hipMallocAsync((void**)&d_y, y_n * 8, s));
     ITTS_HIP_CHECK(hipMallocAsync((void**)&d_dec, std::max<int64_t>(dec_n, 1) * 8, s));
@@ -1098,10 +1177,12 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
 
     hipLaunchKernelGGL(hv_decimate_kernel, dim3(U), dim3(NT), 0, s, d_x, d_utts, p, d_dec, d_y);
     ITTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hv_mirror_kernel, dim3(U), dim3(NT), 0, s, d_utts, p, d_tab, d_wt, d_y, d_coef);
+    ITTS_LAUNCH_CHECK();
     {
       const size_t lds = (size_t)(NT + tab.kt[0] + 4) * 8;
       hipLaunchKernelGGL(hv_bandpass_kernel, dim3((max_yl + NT - 1) / NT, p.ntiles, U), dim3(NT), lds, s,
-                         d_utts, p, d_tab, d_wt, d_y, d_sig);
+                         d_utts, p, d_tab, d_wt, d_y, d_coef, d_sig);
       ITTS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(hv_events_kernel, dim3(p.nch, U), dim3(NT), 0, s, d_utts, p, d_tab, d_sig, d_ev,
@@ -1163,6 +1244,7 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
     ITTS_HIP_CHECK(hipFreeAsync(d_sm, s));
     ITTS_HIP_CHECK(hipFreeAsync(d_cnt, s));
     ITTS_HIP_CHECK(hipFreeAsync(d_nc, s));
+    ITTS_HIP_CHECK(hipFreeAsync(d_coef, s));
     u0 = u1;
   }
   int64_t* slot = pinned_slot(ctx);

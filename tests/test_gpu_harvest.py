@@ -4,7 +4,9 @@ harvest.cpp in oracle/c/harvest.c, stage by stage and end to end.
 The oracle convolves the 152 band-pass filters through 2^16-point FFTs and refines every candidate
 with two FFTs; the kernels evaluate the same sums directly (matrix-core FIR, six spectral bins per
 candidate), so values agree to rounding (~1e-10 relative) rather than bit for bit; the voicing
-decisions built on them must agree exactly."""
+decisions built on them must agree exactly.  The spectrum bins WORLD overwrites while it multiplies
+(GetFilteredSignal's mirrored write, ~1e-5 of the band level in the short filters) are part of the
+oracle and of the kernels."""
 import os
 
 import numpy as np
@@ -53,7 +55,7 @@ def _close(a, b, rtol):
 def test_every_stage_matches_the_oracle_on_the_fixture_audio(gpu, golden_dir, name):
     from oracle import capi
     x, fs = _read(golden_dir, name)
-    f0_ref, tp, ref = capi.harvest(x, fs, debug=True, mirror_write=False)
+    f0_ref, tp, ref = capi.harvest(x, fs, debug=True)
     (f0, dbg), _ = _run(gpu, [x], fs, stages=True)
     nc = ref["n_cand"]
     raw = dbg["raw"].cpu().numpy()
@@ -78,7 +80,7 @@ def test_ragged_batch_other_rates_and_frame_periods(gpu, golden_dir):
         f0, f_off = _run(gpu, xs, fs, fp, **kw)
         f0 = f0.cpu().numpy()
         for u, x in enumerate(xs):
-            ref, _ = capi.harvest(x, fs, fp, mirror_write=False, **kw)
+            ref, _ = capi.harvest(x, fs, fp, **kw)
             _close(f0[f_off[u]:f_off[u + 1]], ref, 1e-7)
 
 
@@ -90,7 +92,7 @@ def test_silence_and_noise_are_unvoiced_like_the_oracle(gpu):
     f0, f_off = _run(gpu, xs, fs)
     f0 = f0.cpu().numpy()
     for u, x in enumerate(xs):
-        ref, _ = capi.harvest(x, fs, mirror_write=False)
+        ref, _ = capi.harvest(x, fs)
         _close(f0[f_off[u]:f_off[u + 1]], ref, 1e-7)
     assert (f0[:f_off[1]] == 0).all()
 
