@@ -66,28 +66,70 @@ struct HvUtt {
 };
 
 // ---- decimation --------------------------------------------------------------------------------
-// y = b(z)/a(z) x with the state recurrence of WORLD's FilterForDecimate; the output is written
-// reversed so that the second call runs the time-reversed pass.  One lane walks the recurrence,
-// the workgroup moves the data.
+// y = b(z)/a(z) x with the state recurrence of WORLD's FilterForDecimate (state s = (w0, w1, w2),
+// s' = C s + x e0); the output is written reversed so that the second call runs the time-reversed
+// pass.  The recurrence is linear, so the workgroup splits the signal into one chunk per thread:
+// every thread runs its chunk from a zero state, one lane chains the chunk states through C^L,
+// and every thread runs its chunk again from the true state (same values as the sequential loop up
+// to rounding).
 __device__ inline void hv_iir3_reversed(const double* in, double* out, int m, const HvParams& p,
-                                        double* buf) {
-  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-  for (int c0 = 0; c0 < m; c0 += NT) {
-    const int n = min(NT, m - c0);
-    __syncthreads();
-    if ((int)threadIdx.x < n) buf[threadIdx.x] = in[c0 + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < n; ++i) {
-        const double wt = buf[i] + p.da[0] * w0 + p.da[1] * w1 + p.da[2] * w2;
-        buf[i] = p.db[0] * wt + p.db[1] * w0 + p.db[1] * w1 + p.db[0] * w2;
-        w2 = w1;
-        w1 = w0;
-        w0 = wt;
-      }
+                                        double* sh /* 9 + 3 * NT doubles */) {
+  const double a0 = p.da[0], a1 = p.da[1], a2 = p.da[2], b0 = p.db[0], b1 = p.db[1];
+  const int L = (m + NT - 1) / NT;
+  const int lo = min(m, (int)threadIdx.x * L), hi = min(m, lo + L);
+  double* M = sh;        // C^L, column-major: M[3 * q + r] = (C^L)[r][q]
+  double* init = sh + 9; // [NT][3]
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double w0 = threadIdx.x == 0, w1 = threadIdx.x == 1, w2 = threadIdx.x == 2;
+    for (int i = 0; i < L; ++i) {
+      const double wt = a0 * w0 + a1 * w1 + a2 * w2;
+      w2 = w1;
+      w1 = w0;
+      w0 = wt;
     }
-    __syncthreads();
-    if ((int)threadIdx.x < n) out[m - 1 - (c0 + threadIdx.x)] = buf[threadIdx.x];
+    M[3 * threadIdx.x] = w0;
+    M[3 * threadIdx.x + 1] = w1;
+    M[3 * threadIdx.x + 2] = w2;
+  }
+  {
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+    for (int i = lo; i < hi; ++i) {
+      const double wt = in[i] + a0 * w0 + a1 * w1 + a2 * w2;
+      w2 = w1;
+      w1 = w0;
+      w0 = wt;
+    }
+    init[3 * threadIdx.x] = w0;
+    init[3 * threadIdx.x + 1] = w1;
+    init[3 * threadIdx.x + 2] = w2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < NT; ++t) {
+      const double l0 = init[3 * t], l1 = init[3 * t + 1], l2 = init[3 * t + 2];
+      init[3 * t] = s0;
+      init[3 * t + 1] = s1;
+      init[3 * t + 2] = s2;
+      const double n0 = M[0] * s0 + M[3] * s1 + M[6] * s2 + l0;
+      const double n1 = M[1] * s0 + M[4] * s1 + M[7] * s2 + l1;
+      const double n2 = M[2] * s0 + M[5] * s1 + M[8] * s2 + l2;
+      s0 = n0;
+      s1 = n1;
+      s2 = n2;
+    }
+  }
+  __syncthreads();
+  {
+    double w0 = init[3 * threadIdx.x], w1 = init[3 * threadIdx.x + 1], w2 = init[3 * threadIdx.x + 2];
+    for (int i = lo; i < hi; ++i) {
+      const double wt = in[i] + a0 * w0 + a1 * w1 + a2 * w2;
+      out[m - 1 - i] = b0 * wt + b1 * w0 + b1 * w1 + b0 * w2;
+      w2 = w1;
+      w1 = w0;
+      w0 = wt;
+    }
   }
   __syncthreads();
 }
@@ -96,7 +138,7 @@ __global__ __launch_bounds__(NT) void hv_decimate_kernel(const double* __restric
                                                          const HvUtt* __restrict__ utts, HvParams p,
                                                          double* __restrict__ dec,
                                                          double* __restrict__ ypad) {
-  __shared__ double buf[NT];
+  __shared__ double buf[9 + 3 * NT];
   __shared__ double red[8];
   const HvUtt u = utts[blockIdx.x];
   const double* xs = x + u.x_off;
@@ -413,7 +455,12 @@ __global__ __launch_bounds__(NT) void hv_detect_kernel(const HvUtt* __restrict__
 
 // ---- GetRefinedF0 for every (frame, candidate slot) --------------------------------------------------------
 // Slot j of frame i: column j % nc0 of frame i + shift(j / nc0), shift = 0,-1,-2,-3,+1,+2,+3
-// (OverlapF0Candidates).  One wave per frame walks the slots.
+// (OverlapF0Candidates).  One wave per frame walks the slots.  Per slot: (1) the Blackman-type
+// window on the wave's lanes (one sincos per lane, then rotations), (2) windowed / derivative-
+// windowed samples to LDS, (3) lanes regroup as 8 harmonics x 8 sample phases and accumulate the
+// harmonic bins of both spectra, (4) two short butterfly reductions.
+__device__ __forceinline__ double hv_xor_sum(double v, int mask) { return v + __shfl_xor(v, mask, 64); }
+
 __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__ utts, HvParams p,
                                                        const double2* __restrict__ g_tw,
                                                        const double* __restrict__ ypad,
@@ -423,7 +470,7 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
                                                        double* __restrict__ score) {
   extern __shared__ __attribute__((aligned(16))) char smem_rf[];
   double2* tw = reinterpret_cast<double2*>(smem_rf);                   // [fft_max / 2]
-  double* mws_all = reinterpret_cast<double*>(tw + p.fft_max / 2);      // [4][bl_max + 2]
+  double* ws_all = reinterpret_cast<double*>(tw + p.fft_max / 2);       // [4][3][bl_max + 2]
   const HvUtt u = utts[blockIdx.y];
   const int f0i = blockIdx.x * HV_REFINE_FRAMES;
   if (f0i >= u.T1) return;
@@ -432,7 +479,10 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = f0i + wv;
   if (i >= u.T1) return;
-  double* mws = mws_all + (size_t)wv * (p.bl_max + 2);
+  const int wstride = p.bl_max + 2;
+  double* mws = ws_all + (size_t)wv * 3 * wstride;
+  double* ams = mws + wstride;
+  double* ads = ams + wstride;
   const int nc0 = ncand[blockIdx.y];
   const int nc = nc0 * 7;
   const double* y = ypad + u.y_off + p.pad;
@@ -441,82 +491,103 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
   double* srow = score + u.cand_off + (int64_t)i * p.maxc;
   const double fs = p.afs;
   const double pos = (double)i * 1.0 / 1000.0;
-  for (int j = 0; j < nc; ++j) {
-    const int q = j / nc0, col = j - q * nc0;
-    const int src = q == 0 ? i : (q <= 3 ? i - q : i + (q - 3));
-    double f0 = 0.0;
-    if (src >= 0 && src < u.T1) f0 = bs[(int64_t)src * p.nbase + col];
-    if (f0 <= 0.0) {
-      if (lane == 0) {
+  const int hh = lane >> 3, g = lane & 7;
+  // 64 slots at a time: every lane fetches one slot's source candidate, the wave then walks the
+  // non-empty ones
+  for (int j0 = 0; j0 < nc; j0 += 64) {
+  double fl = 0.0;
+  {
+    const int j = j0 + lane;
+    if (j < nc) {
+      const int q = j / nc0, col = j - q * nc0;
+      const int src = q == 0 ? i : (q <= 3 ? i - q : i + (q - 3));
+      if (src >= 0 && src < u.T1) fl = bs[(int64_t)src * p.nbase + col];
+      if (fl <= 0.0) {
         crow[j] = 0.0;
         srow[j] = 0.0;
       }
-      continue;
     }
+  }
+  for (unsigned long long todo = __ballot(fl > 0.0); todo; todo &= todo - 1) {
+    const int jl = __builtin_ctzll(todo);
+    const int j = j0 + jl;
+    const double f0 = __shfl(fl, jl, 64);
     const int hw = (int)(1.5 * fs / f0 + 1.0);
     const int bl = hw * 2 + 1;
     const double wlt = (2.0 * hw + 1.0) / fs;
-    const int lg = 2 + (int)(log(hw * 2.0 + 1.0) / log(2.0));
+    const int lg = 2 + ilog2(bl);  // bl is odd: floor(log2) is exact
     const int fft = 1 << lg;
     const int tstride = p.fft_max >> lg;
     const double bt0 = (double)(-hw) / fs;
     const int basic = mround((pos + bt0) * fs + 0.001);
-    for (int k = lane; k < bl; k += 64) {
-      const double t = ((basic + k) - 1.0) / fs - pos;
-      mws[k] = 0.42 + 0.5 * cos(2.0 * kPi * t / wlt) + 0.08 * cos(4.0 * kPi * t / wlt);
+    {  // window: theta_k = 2 pi t_k / wlt, t_k = (basic + k - 1) / fs - pos
+      const double t = ((basic + lane) - 1.0) / fs - pos;
+      double sn, cs, rs, rc;
+      sincospi(2.0 * t / wlt, &sn, &cs);
+      sincospi(2.0 * 64.0 / (fs * wlt), &rs, &rc);
+      for (int k = lane; k < bl; k += 64) {
+        mws[k] = 0.42 + 0.5 * cs + 0.08 * (2.0 * cs * cs - 1.0);
+        const double c2 = cs * rc - sn * rs;
+        sn = sn * rc + cs * rs;
+        cs = c2;
+      }
     }
-    const int nh = min((int)(fs / 2.0 / f0), 6);
-    int idx[6];
-#pragma unroll
-    for (int h = 0; h < 6; ++h) idx[h] = min(mround(f0 * fft / fs * (h + 1)), fft / 2);
-    double Mr[6], Mi[6], Dr[6], Di[6];
-#pragma unroll
-    for (int h = 0; h < 6; ++h) Mr[h] = Mi[h] = Dr[h] = Di[h] = 0.0;
-    __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < bl; k += 64) {
       int si = basic + k - 1;
       si = si < 0 ? 0 : (si > u.yl - 1 ? u.yl - 1 : si);
       const double xv = y[si];
-      const double mw = mws[k];
       double dw;
       if (k == 0) dw = -mws[1] / 2.0;
       else if (k == bl - 1) dw = mws[bl - 2] / 2.0;
       else dw = -(mws[k + 1] - mws[k - 1]) / 2.0;
-      const double am = xv * mw, ad = xv * dw;
-#pragma unroll
-      for (int h = 0; h < 6; ++h) {
-        if (h < nh) {
-          const int m = (idx[h] * k) & (fft - 1);
-          double2 w;  // exp(-2 pi i m / fft)
-          if (m < fft / 2) {
-            w = tw[m * tstride];
-            w.y = -w.y;
-          } else {
-            w = tw[(m - fft / 2) * tstride];
-            w.x = -w.x;
-          }
-          Mr[h] += am * w.x;
-          Mi[h] += am * w.y;
-          Dr[h] += ad * w.x;
-          Di[h] += ad * w.y;
+      ams[k] = xv * mws[k];
+      ads[k] = xv * dw;
+    }
+    const int nh = min((int)(fs / 2.0 / f0), 6);
+    const int idx = min(mround(f0 * fft / fs * (hh + 1)), fft / 2);
+    double mr = 0.0, mi = 0.0, dr = 0.0, di = 0.0;
+    if (hh < nh) {
+      const int step = (idx * 8) & (fft - 1);
+      int m = (idx * g) & (fft - 1);
+      for (int k = g; k < bl; k += 8) {
+        double2 w;  // exp(-2 pi i m / fft)
+        if (m < fft / 2) {
+          w = tw[m * tstride];
+          w.y = -w.y;
+        } else {
+          w = tw[(m - fft / 2) * tstride];
+          w.x = -w.x;
         }
+        const double am = ams[k], ad = ads[k];
+        mr += am * w.x;
+        mi += am * w.y;
+        dr += ad * w.x;
+        di += ad * w.y;
+        m = (m + step) & (fft - 1);
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    double num = 0.0, den = 0.0, sc = 0.0;
 #pragma unroll
-    for (int h = 0; h < 6; ++h) {
-      if (h < nh) {
-        const double mr = wave_sum(Mr[h]), mi = wave_sum(Mi[h]);
-        const double dr = wave_sum(Dr[h]), di = wave_sum(Di[h]);
-        const double ps = mr * mr + mi * mi;
-        const double ni = mr * di - mi * dr;
-        const double inst = ps == 0.0 ? 0.0 : (double)idx[h] * fs / fft + ni / ps * fs / 2.0 / kPi;
-        const double amp = sqrt(ps);
-        num += amp * inst;
-        den += amp * (h + 1.0);
-        sc += fabs((inst / (h + 1.0) - f0) / f0);
-      }
+    for (int mask = 1; mask < 8; mask <<= 1) {
+      mr = hv_xor_sum(mr, mask);
+      mi = hv_xor_sum(mi, mask);
+      dr = hv_xor_sum(dr, mask);
+      di = hv_xor_sum(di, mask);
+    }
+    double num = 0.0, den = 0.0, sc = 0.0;
+    if (hh < nh) {
+      const double ps = mr * mr + mi * mi;
+      const double ni = mr * di - mi * dr;
+      const double inst = ps == 0.0 ? 0.0 : (double)idx * fs / fft + ni / ps * fs / 2.0 / kPi;
+      const double amp = sqrt(ps);
+      num = amp * inst;
+      den = amp * (hh + 1.0);
+      sc = fabs((inst / (hh + 1.0) - f0) / f0);
+    }
+#pragma unroll
+    for (int mask = 8; mask < 64; mask <<= 1) {
+      num = hv_xor_sum(num, mask);
+      den = hv_xor_sum(den, mask);
+      sc = hv_xor_sum(sc, mask);
     }
     double rf = num / (den + kEps);
     double rs = 1.0 / (sc / nh + kEps);
@@ -528,6 +599,7 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
       crow[j] = rf;
       srow[j] = rs;
     }
+  }
   }
 }
 
@@ -1195,7 +1267,7 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
                        d_base, d_nc);
     ITTS_LAUNCH_CHECK();
     {
-      const size_t lds = (size_t)(p.fft_max / 2) * 16 + (size_t)HV_REFINE_FRAMES * (p.bl_max + 2) * 8;
+      const size_t lds = (size_t)(p.fft_max / 2) * 16 + (size_t)HV_REFINE_FRAMES * 3 * (p.bl_max + 2) * 8;
       ITTS_REQUIRE(lds <= 160 * 1024, "refinement window does not fit the LDS");
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)hv_refine_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
