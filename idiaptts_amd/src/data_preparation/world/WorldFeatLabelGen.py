@@ -112,6 +112,9 @@ class WorldFeatLabelGen(ReaderBase):
     lf0_zero = 0
     preemphasis = 0.0
     n_fft = None
+    # F0 stage of the extractor: "dio" (DIO + StoneMask = pyworld.wav2world, what the reference
+    # runs, :792-793) or "harvest" (pyworld.harvest); an extension, the reference has no switch
+    f0_estimator = "dio"
     win_length_ms = None
 
     dir_lf0 = "lf0"
@@ -244,7 +247,8 @@ class WorldFeatLabelGen(ReaderBase):
         if lf0_zero is None:
             lf0_zero = WorldFeatLabelGen.lf0_zero
         res = _world.analyse_batch([np.asarray(raw, dtype=np.float64)], fs, hop_size_ms, n_fft,
-                                   want_sp=True, want_bap=True)[0]
+                                   want_sp=True, want_bap=True,
+                                   f0_method=WorldFeatLabelGen.f0_estimator)[0]
         amp_sp = np.sqrt(res["sp"])
         lf0, vuv = _world.lf0_vuv_from_f0(res["f0"], f0_silence_threshold, lf0_zero)
         return amp_sp, lf0, vuv, res["bap"]
@@ -266,7 +270,8 @@ class WorldFeatLabelGen(ReaderBase):
         cmp_dev, f_off = _world.extract_cmp_batch(
             raws, fs, hop_size_ms, n_fft, num_coded_sps - 1, mgc_alpha, f0_silence_threshold,
             lf0_zero, add_deltas=False,
-            mgc_gamma=AudioProcessing.mgc_gamma if sp_type == "mgc" else None)
+            mgc_gamma=AudioProcessing.mgc_gamma if sp_type == "mgc" else None,
+            f0_method=WorldFeatLabelGen.f0_estimator)
         cmp_host = cmp_dev.cpu().numpy()
         out = []
         for u in range(len(raws)):
@@ -492,7 +497,8 @@ class WorldFeatLabelGen(ReaderBase):
                     (samples, x_off), fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1,
                     alpha, WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
                     self.add_deltas,
-                    mgc_gamma=AudioProcessing.mgc_gamma if self.sp_type == "mgc" else None)
+                    mgc_gamma=AudioProcessing.mgc_gamma if self.sp_type == "mgc" else None,
+                    f0_method=self.f0_estimator)
                 stats.add(cmp_dev)
                 host = torch.empty(cmp_dev.shape, dtype=torch.float32, pin_memory=True)
                 host.copy_(cmp_dev, non_blocking=True)

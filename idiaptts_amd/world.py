@@ -48,8 +48,19 @@ def lf0_vuv_from_f0(f0, f0_silence_threshold=30, lf0_zero=0, device=None):
     return lf0.cpu().numpy()[:, None], vuv.cpu().numpy()[:, None]
 
 
+def estimate_f0(x, x_off, f_off, fs, hop_ms=5.0, f0_method="dio"):
+    """The F0 stage: "dio" = pyworld.wav2world's DIO + StoneMask (what the reference extracts with,
+    WorldFeatLabelGen.py:792-793); "harvest" = pyworld.harvest (no StoneMask pass: Harvest refines
+    its own candidates).  Both share the frame grid int(1000 n / fs / hop) + 1."""
+    if f0_method == "dio":
+        return ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
+    if f0_method == "harvest":
+        return ops.harvest(x, x_off, f_off, fs, hop_ms)
+    raise NotImplementedError("Unknown F0 estimator {} (dio, harvest).".format(f0_method))
+
+
 def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
-                  mcep_order=None, mcep_alpha=None, want_bap=True, device=None):
+                  mcep_order=None, mcep_alpha=None, want_bap=True, device=None, f0_method="dio"):
     """raws: list of float64 waveforms (already pre-emphasised). Returns a list of dicts with
     f0 [T] f64, and optionally sp [T,K] f64 (power), ap [T,K] f64, mcep [T,order+1] f32,
     bap [T,nap] f32."""
@@ -59,7 +70,7 @@ def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
     x_off = offsets([len(r) for r in raws])
     f_off = offsets([num_frames(len(r), fs, hop_ms) for r in raws])
     x = torch.from_numpy(np.ascontiguousarray(np.concatenate(raws), dtype=np.float64)).to(dev)
-    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
+    f0 = estimate_f0(x, x_off, f_off, fs, hop_ms, f0_method)
     sp = mc = ap = bap = None
     # CheapTrick/mcep and D4C only share their inputs: run D4C on a side stream so the two
     # occupancy-bound kernels overlap
@@ -132,7 +143,7 @@ class StreamStats(object):
 
 def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alpha=None,
                       f0_silence_threshold=30, lf0_zero=0, add_deltas=True, device=None,
-                      mgc_gamma=None):
+                      mgc_gamma=None, f0_method="dio"):
     """wav(s) -> the `[T, 3*(ncs+1+nb)+1]` feature matrix of the reference's gen_data in one go,
     everything on the device: DIO + StoneMask, D4C -> coded bap, CheapTrick -> mcep, lf0 / V-UV
     with interpolate_lin, deltas and the stream layout (WorldFeatLabelGen.py:778-807, 809-889,
@@ -148,7 +159,7 @@ def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alph
         samples = np.concatenate(raws) if len(raws) else np.empty(0)
     f_off = offsets([num_frames(b - a, fs, hop_ms) for a, b in zip(x_off[:-1], x_off[1:])])
     x = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float64)).to(dev)
-    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop_ms), f_off, fs, hop_ms)
+    f0 = estimate_f0(x, x_off, f_off, fs, hop_ms, f0_method)
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)

@@ -103,3 +103,26 @@ def test_batched_call_equals_one_call_per_utterance(gpu, golden_dir):
     for u, x in enumerate(xs):
         single, _ = _run(gpu, [x], 16000)
         assert torch.equal(single, f0[f_off[u]:f_off[u + 1]])
+
+
+def test_the_extractor_switch_routes_f0_through_harvest(gpu, golden_dir):
+    """WorldFeatLabelGen.f0_estimator = "harvest": lf0 / vuv come from Harvest, and the envelope
+    and aperiodicity are analysed at Harvest's F0 (pyworld.cheaptrick / d4c after pyworld.harvest)."""
+    from idiaptts_amd import world
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    from oracle import capi
+    x, fs = _read(golden_dir, "LJ001-0008")
+    before = WorldFeatLabelGen.f0_estimator
+    try:
+        WorldFeatLabelGen.f0_estimator = "harvest"
+        amp_sp, lf0, vuv, bap = WorldFeatLabelGen.world_extract_features(x, fs, 5)
+    finally:
+        WorldFeatLabelGen.f0_estimator = before
+    ref, tp = capi.harvest(x, fs)
+    lf0_ref, vuv_ref = world.lf0_vuv_from_f0(ref)
+    assert np.array_equal(vuv, vuv_ref)
+    assert np.abs(lf0 - lf0_ref).max() < 1e-5
+    sp_ref = capi.cheaptrick(x, fs, tp, ref)
+    assert np.abs(amp_sp ** 2 / sp_ref - 1).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        world.analyse_batch([x], fs, f0_method="swipe")

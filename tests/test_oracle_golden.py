@@ -182,3 +182,47 @@ def test_oracle_mgcep_is_the_minimiser_of_the_mgc_criterion(golden_dir):
     mgc = capi.mgcep(amp_sp, 59, alpha, -1.0 / 3.0)
     rec = np.exp(capi.mgc2sp_gamma_logamp(mgc, alpha, -1.0 / 3.0, 1024).astype(np.float32))
     assert ((amp_sp - rec) ** 2).sum() < 1500 * len(amp_sp) / 600.0
+
+
+def test_harvest_oracle_is_consistent_with_what_can_be_checked_here(golden_dir):
+    """No reference-held vector exists for Harvest (the reference extracts with dio + stonemask and
+    pyworld is not vendored): the restatement is checked against a tone of known pitch, against the
+    pinned DIO + StoneMask oracle on the reference's fixture audio, and its decimation filter
+    against scipy's Chebyshev design.  Parity with pyworld.harvest stays unpinned."""
+    import scipy.signal
+    import ctypes
+    fs = 16000
+    n = int(1.2 * fs)
+    t = np.arange(n) / fs
+    f_true = 180.0 + 40.0 * t                                  # slow glide
+    phase = 2 * np.pi * np.cumsum(f_true) / fs
+    x = 0.25 * sum(np.sin(k * phase) / k for k in range(1, 8))
+    f0, tp = capi.harvest(x, fs)
+    assert len(f0) == capi.harvest_num_frames(n, fs) == int(1000.0 * n / fs / 5.0) + 1
+    mid = slice(10, len(f0) - 10)
+    assert (f0[mid] > 0).all()
+    truth = np.interp(tp[mid], t, f_true)
+    assert np.abs(f0[mid] / truth - 1).max() < 5e-3
+    # silence stays unvoiced
+    assert (capi.harvest(np.zeros(4000), fs)[0] == 0).all()
+    # fixture audio: where both estimators call a frame voiced they agree closely
+    fs_w, w = wavfile.read(os.path.join(golden_dir, "LJ001-0008.wav"))
+    xw = w.astype(np.float64) / 32768.0
+    h, tph = capi.harvest(xw, fs_w)
+    d, tpd = capi.dio(xw, fs_w)
+    s = capi.stonemask(xw, fs_w, tpd, d)
+    assert len(h) == len(s) and np.array_equal(tph, tpd)
+    both = (h > 0) & (s > 0)
+    assert both.sum() > 150
+    assert np.median(np.abs(h[both] / s[both] - 1)) < 0.01
+    # a 1 ms frame period is the estimator's own grid; 5 ms picks every fifth value of it
+    h1, _ = capi.harvest(xw, fs_w, frame_period=1.0)
+    assert np.array_equal(h, h1[np.minimum(len(h1) - 1, np.arange(len(h)) * 5)])
+    # decimate's IIR: cheby1(3, 0.05 dB, 0.8 / r)
+    fn = capi._fn("orc_decimate_coefficients", None, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p])
+    for r in range(2, 13):
+        a3, b2 = np.zeros(3), np.zeros(2)
+        fn(r, capi._p(a3), capi._p(b2))
+        b, a = scipy.signal.cheby1(3, 0.05, 0.8 / r)
+        assert np.allclose(a3, -a[1:], rtol=1e-12, atol=0)
+        assert np.allclose(b2, b[:2], rtol=1e-12, atol=0)
