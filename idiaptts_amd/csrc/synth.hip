@@ -451,7 +451,8 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
   __syncthreads();
 }
 
-__global__ __launch_bounds__(NT) void syn_pulse_kernel(PulseArgs a) {
+// 28 KB of LDS at fft 1024: five workgroups fit a CU when a wave needs <= 102 VGPRs
+__global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int fft = a.p.fft, logfft = a.p.logfft, h = fft / 2, K = h + 1;
   char* q = smem;
