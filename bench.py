@@ -258,6 +258,18 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     synthesis()
     sync()
     ms_sy = over_ranks(hip_event_median_ms(synthesis, stream, 5), dist.ReduceOp.MAX)
+    harvest = None
+    if key == "world" and n_ranks == 1:
+        # the alternative F0 estimator (pyworld.harvest): its own 1 ms grid, so it is timed on a
+        # quarter of the utterances
+        nh = max(1, n_utts // 4)
+        xh, xoh, foh = x[:x_off[nh]], x_off[:nh + 1], f_off[:nh + 1]
+        ops.harvest(xh, xoh, foh, fs, hop)
+        sync()
+        ms_h = hip_event_median_ms(lambda: ops.harvest(xh, xoh, foh, fs, hop), stream, 3)
+        harvest = {"utterances": nh, "audio_seconds": xoh[-1] / fs, "ms": ms_h,
+                   "rtf": ms_h * 1e-3 / (xoh[-1] / fs),
+                   "note": "pyworld.harvest instead of dio + stonemask; HIP events, median of 3"}
     frames = int(over_ranks(f_off[-1], dist.ReduceOp.SUM))
     audio_s = over_ranks(audio_s, dist.ReduceOp.SUM)
     res[key] = {
@@ -267,6 +279,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         "analysis_frames_per_s": frames / (ms_an * 1e-3),
         "synthesis_ms": ms_sy, "synthesis_rtf": ms_sy * 1e-3 / audio_s,
         "mcep_newton_iters_mean": float(iters.float().mean().item()),
+        "harvest_f0": harvest,
         # algorithmic HBM bytes per frame: fused analysis->features 640 + 248;
         # synthesis 8536
         "analysis_algorithmic_GBps": frames * (fs // 200 * 8 + (61 + L.itts_num_aperiodicities(fs)) * 4)

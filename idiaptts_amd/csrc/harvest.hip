@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
                                                        double* __restrict__ score) {
   extern __shared__ __attribute__((aligned(16))) char smem_rf[];
   double2* tw = reinterpret_cast<double2*>(smem_rf);                   // [fft_max / 2]
-  double* ws_all = reinterpret_cast<double*>(tw + p.fft_max / 2);       // [4][3][bl_max + 2]
+  double* ws_all = reinterpret_cast<double*>(tw + p.fft_max / 2);       // [4][2][bl_max + 2]
   const HvUtt u = utts[blockIdx.y];
   const int f0i = blockIdx.x * HV_REFINE_FRAMES;
   if (f0i >= u.T1) return;
@@ -480,8 +480,7 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
   const int i = f0i + wv;
   if (i >= u.T1) return;
   const int wstride = p.bl_max + 2;
-  double* mws = ws_all + (size_t)wv * 3 * wstride;
-  double* ams = mws + wstride;
+  double* ams = ws_all + (size_t)wv * 2 * wstride;
   double* ads = ams + wstride;
   const int nc0 = ncand[blockIdx.y];
   const int nc = nc0 * 7;
@@ -520,28 +519,30 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
     const int tstride = p.fft_max >> lg;
     const double bt0 = (double)(-hw) / fs;
     const int basic = mround((pos + bt0) * fs + 0.001);
-    {  // window: theta_k = 2 pi t_k / wlt, t_k = (basic + k - 1) / fs - pos
+    {  // window theta_k = 2 pi t_k / wlt, t_k = (basic + k - 1) / fs - pos: one sincos per lane, then
+       // rotations by 64 samples; the neighbours the derivative window needs are rotations by one
       const double t = ((basic + lane) - 1.0) / fs - pos;
-      double sn, cs, rs, rc;
+      double sn, cs, rs, rc, ds1, dc1;
       sincospi(2.0 * t / wlt, &sn, &cs);
       sincospi(2.0 * 64.0 / (fs * wlt), &rs, &rc);
+      sincospi(2.0 / (fs * wlt), &ds1, &dc1);
+      auto win = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
       for (int k = lane; k < bl; k += 64) {
-        mws[k] = 0.42 + 0.5 * cs + 0.08 * (2.0 * cs * cs - 1.0);
+        int si = basic + k - 1;
+        si = si < 0 ? 0 : (si > u.yl - 1 ? u.yl - 1 : si);
+        const double xv = y[si];
+        const double mw = win(cs);
+        const double up = win(cs * dc1 - sn * ds1), dn = win(cs * dc1 + sn * ds1);  // mw[k + 1], mw[k - 1]
+        double dw;
+        if (k == 0) dw = -up / 2.0;
+        else if (k == bl - 1) dw = dn / 2.0;
+        else dw = -(up - dn) / 2.0;
+        ams[k] = xv * mw;
+        ads[k] = xv * dw;
         const double c2 = cs * rc - sn * rs;
         sn = sn * rc + cs * rs;
         cs = c2;
       }
-    }
-    for (int k = lane; k < bl; k += 64) {
-      int si = basic + k - 1;
-      si = si < 0 ? 0 : (si > u.yl - 1 ? u.yl - 1 : si);
-      const double xv = y[si];
-      double dw;
-      if (k == 0) dw = -mws[1] / 2.0;
-      else if (k == bl - 1) dw = mws[bl - 2] / 2.0;
-      else dw = -(mws[k + 1] - mws[k - 1]) / 2.0;
-      ams[k] = xv * mws[k];
-      ads[k] = xv * dw;
     }
     const int nh = min((int)(fs / 2.0 / f0), 6);
     const int idx = min(mround(f0 * fft / fs * (hh + 1)), fft / 2);
@@ -980,8 +981,12 @@ __global__ __launch_bounds__(NT) void hv_contour2_kernel(const HvUtt* __restrict
 }
 
 // SmoothF0Contour: each voiced section, held constant beyond its ends, through the 2nd-order
-// low-pass forwards and backwards over the whole padded length.  One lane per section; forward
-// outputs are parked position-major ([position][lane]) so the backward pass reads coalesced.
+// low-pass forwards and backwards.  WORLD runs both passes over the whole padded contour from a
+// zero state; the filter's poles have radius 0.875, so HV_LAG = 300 samples of the constant
+// extension bring the state to its fixed point to 4e-18 relative -- the passes here start HV_LAG
+// positions before / after the section (always inside the padded contour) and the values inside
+// the section are the same to the last bit or two.  One lane per section; forward outputs are
+// parked position-major ([offset][lane]) so the backward pass reads coalesced.
 __global__ __launch_bounds__(64) void hv_smooth_kernel(const HvUtt* __restrict__ utts, HvParams p,
                                                        double* __restrict__ ctr,
                                                        double* __restrict__ park) {
@@ -989,41 +994,60 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(const HvUtt* __restrict__
   const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
   const HvUtt u = utts[blockIdx.x];
   const HvCtr c = hv_ctr(ctr, u);
-  const int T = u.T1, n = T + 2 * HV_LAG, ns = c.meta[1];
+  const int ns = c.meta[1];
   double* pk = park + u.sm_off;
   const int lane = threadIdx.x;
   for (int g = 0; g < ns; g += 64) {
     const int s = g + lane;
     const bool on = s < ns;
-    const int st = on ? c.sb[2 * s] : 0, ed = on ? c.sb[2 * s + 1] : 0;
+    const int st = on ? c.sb[2 * s] : 0, ed = on ? c.sb[2 * s + 1] : -1;
+    const int len = ed - st + 1;                      // positions st .. ed; 0 for idle lanes
     const double cst = on ? c.B[st - HV_LAG] : 0.0, ced = on ? c.B[ed - HV_LAG] : 0.0;
-    double w0 = 0.0, w1 = 0.0;
-    for (int i = 0; i < n; ++i) {
-      double xv = cst;
-      if (i > ed) xv = ced;
-      else if (i > st) xv = c.B[i - HV_LAG];
-      const double wt = xv + a0 * w0 + a1 * w1;
-      const double o = b0 * wt + b1 * w0 + b0 * w1;
-      w1 = w0;
-      w0 = wt;
-      if (on && i >= st) pk[(int64_t)i * 64 + lane] = o;
-    }
-    w0 = w1 = 0.0;
-    for (int i0 = n - 1; i0 >= 0; i0 -= 8) {
-      double v[8];
+    int maxlen = len;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = i0 - k;
-        v[k] = (on && i >= st) ? pk[(int64_t)i * 64 + lane] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    // forward: offsets -HV_LAG .. len - 1 + HV_LAG relative to st; outputs kept from offset 0
+    constexpr int NB = 32;   // values requested together: the loads do not depend on the recurrence,
+                             // and one memory round trip per 32 steps is what keeps a lane moving
+    double w0 = 0.0, w1 = 0.0;
+    for (int k0 = -HV_LAG; k0 < maxlen + HV_LAG; k0 += NB) {
+      double xv[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int k = k0 + q;
+        xv[q] = cst;
+        if (k >= len) xv[q] = ced;
+        else if (k > 0) xv[q] = c.B[st + k - HV_LAG];
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = i0 - k;
-        const double wt = v[k] + a0 * w0 + a1 * w1;
+      for (int q = 0; q < NB; ++q) {
+        const int k = k0 + q;
+        const double wt = xv[q] + a0 * w0 + a1 * w1;
         const double o = b0 * wt + b1 * w0 + b0 * w1;
         w1 = w0;
         w0 = wt;
-        if (on && i >= st && i <= ed) c.C[i - HV_LAG] = o;
+        if (on && k >= 0 && k < len + HV_LAG) pk[(int64_t)k * 64 + lane] = o;
+      }
+    }
+    // backward from offset len - 1 + HV_LAG down to 0
+    w0 = w1 = 0.0;
+    for (int k0 = maxlen + HV_LAG - 1; k0 >= 0; k0 -= NB) {
+      double v[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int k = k0 - q;
+        v[q] = (on && k >= 0 && k < len + HV_LAG) ? pk[(int64_t)k * 64 + lane] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int k = k0 - q;
+        if (k < len + HV_LAG) {   // lanes with shorter sections start later, from a zero state
+          const double wt = v[q] + a0 * w0 + a1 * w1;
+          const double o = b0 * wt + b1 * w0 + b0 * w1;
+          w1 = w0;
+          w0 = wt;
+          if (on && k >= 0 && k < len) c.C[st + k - HV_LAG] = o;
+        }
       }
     }
   }
@@ -1267,7 +1291,7 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
                        d_base, d_nc);
     ITTS_LAUNCH_CHECK();
     {
-      const size_t lds = (size_t)(p.fft_max / 2) * 16 + (size_t)HV_REFINE_FRAMES * 3 * (p.bl_max + 2) * 8;
+      const size_t lds = (size_t)(p.fft_max / 2) * 16 + (size_t)HV_REFINE_FRAMES * 2 * (p.bl_max + 2) * 8;
       ITTS_REQUIRE(lds <= 160 * 1024, "refinement window does not fit the LDS");
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)hv_refine_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
