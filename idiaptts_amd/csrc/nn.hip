@@ -18,6 +18,7 @@
 //   * roofline: MFMA fp32.  FLOPs per valid frame of the 425-512-512-187 model: fwd 1.15 M,
 //     fwd+bwd 3.45 M (first-layer input gradient skipped: 3.01 M) -- SURVEY.md section 8d.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -49,6 +50,7 @@ struct GemmArgs {
   int64_t kchunk;       // reduction elements per blockIdx.z (multiple of BK)
   int64_t slab_stride;  // floats between split-K slabs of C
   int vecA, vecB;       // 16-B vector loads allowed
+  int wide_out;         // C (and bias, aux) allow 16-B accesses: float4 epilogue of the row-form kernel
 };
 
 // tanh in ~12 VALU ops (ocml tanhf costs ~40 and showed up as ~15 % of the fused-epilogue GEMMs):
@@ -237,6 +239,53 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (int64_t)blockIdx.z * g.slab_stride;
   const int cl = lane & 31, rh = lane >> 5;
+  if (STAGES == 1 && TN == 1 && g.wide_out) {
+    // Wide stores: a wave passes each of its 32 x 32 result blocks through its own 4.6 KB of the
+    // (now idle) LDS tile and writes rows back as float4 -- 8 store instructions of whole 128-byte
+    // row segments per thread instead of 32 dword stores; bias / activation / derivative are applied
+    // four columns at a time on the way out.  (The loop's last barrier has retired all tile reads;
+    // the staging area is private to the wave, LDS operations of a wave execute in order.)
+    float* stage = lds + wid * (32 * 36);
+    const int c4 = (lane & 7) << 2, rq = lane >> 3;
+    const int colb = n0 + wn * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * rh) * 36 + cl] = acc[i][0][r];
+      const int col = colb + c4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool full = col + 3 < g.N;
+      if (EPI == EPI_BIAS_ACT && g.bias && full) bv = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = rq + 8 * q;
+        const int64_t row = m0 + wm * 64 + i * 32 + rl;
+        float4 v = *reinterpret_cast<const float4*>(stage + rl * 36 + c4);
+        if (row >= g.M || col >= g.N) continue;
+        if (full) {
+          if (EPI == EPI_BIAS_ACT) {
+            v.x = act_fwd(v.x + bv.x, g.act); v.y = act_fwd(v.y + bv.y, g.act);
+            v.z = act_fwd(v.z + bv.z, g.act); v.w = act_fwd(v.w + bv.w, g.act);
+          }
+          if (EPI == EPI_DACT) {
+            const float4 a = *reinterpret_cast<const float4*>(g.aux + row * g.ldaux + col);
+            v.x *= act_grad_from_out(a.x, g.act); v.y *= act_grad_from_out(a.y, g.act);
+            v.z *= act_grad_from_out(a.z, g.act); v.w *= act_grad_from_out(a.w, g.act);
+          }
+          *reinterpret_cast<float4*>(C + row * g.ldc + col) = v;
+        } else {   // the float4 that straddles N: column by column
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && col + e < g.N; ++e) {
+            float o = vv[e];
+            if (EPI == EPI_BIAS_ACT) o = act_fwd(o + (g.bias ? g.bias[col + e] : 0.f), g.act);
+            if (EPI == EPI_DACT) o *= act_grad_from_out(g.aux[row * g.ldaux + col + e], g.act);
+            C[row * g.ldc + col + e] = o;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -624,6 +673,10 @@ extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, 
   g.kchunk = ((K + BK - 1) / BK) * BK; g.slab_stride = 0;
   g.vecA = (ldx % 4 == 0) && aligned16(d_x);
   g.vecB = (K % 4 == 0) && aligned16(d_w);
+  {
+    static const int wide = [] { const char* e = getenv("ITTS_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+    g.wide_out = wide && (ldy % 4 == 0) && aligned16(d_y) && (!d_b || aligned16(d_b));
+  }
   return launch_gemm<true, true, EPI_BIAS_ACT>(g, 1, as_stream(stream));
 }
 
@@ -653,6 +706,11 @@ extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const floa
   g.kchunk = ((N + BK - 1) / BK) * BK; g.slab_stride = 0;
   g.vecA = (lddz % 4 == 0) && aligned16(d_dz);
   g.vecB = (K % 4 == 0) && aligned16(d_w);
+  {
+    static const int wide = [] { const char* e = getenv("ITTS_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+    g.wide_out = wide && (lddx % 4 == 0) && aligned16(d_dx) &&
+                 (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
+  }
   if (d_yprev) {
     ITTS_REQUIRE(ldyp >= K, "ldyp too small");
     return launch_gemm<true, false, EPI_DACT>(g, 1, as_stream(stream));
