@@ -126,3 +126,31 @@ def test_the_extractor_switch_routes_f0_through_harvest(gpu, golden_dir):
     assert np.abs(amp_sp ** 2 / sp_ref - 1).max() < 1e-6
     with pytest.raises(NotImplementedError):
         world.analyse_batch([x], fs, f0_method="swipe")
+
+
+def test_tiny_and_long_utterances(gpu):
+    """utterances of a few frames, and one long enough that its event lists and section store are
+    sized by the general formulas rather than by the fixtures"""
+    from oracle import capi
+    fs = 16000
+    rng = np.random.default_rng(11)
+    xs = [1e-2 * rng.normal(size=n) for n in (64, 161, 800)] + [_synthetic(fs, 21.0, 3)]
+    f0, f_off = _run(gpu, xs, fs)
+    f0 = f0.cpu().numpy()
+    for u, x in enumerate(xs):
+        ref, _ = capi.harvest(x, fs)
+        _close(f0[f_off[u]:f_off[u + 1]], ref, 1e-7)
+
+
+def test_a_batch_larger_than_the_scratch_budget_is_processed_in_chunks(gpu):
+    """~130 MB of scratch per 6 s utterance against a 12 GB budget: 112 utterances need two
+    sub-batches; every utterance must come out as if it had been analysed alone"""
+    from oracle import capi
+    fs = 16000
+    xs = [_synthetic(fs, 5.5 + 0.01 * k, k % 7) for k in range(112)]
+    f0, f_off = _run(gpu, xs, fs)
+    for u in (0, 57, 111):
+        single, _ = _run(gpu, [xs[u]], fs)
+        assert torch.equal(single, f0[f_off[u]:f_off[u + 1]])
+    ref, _ = capi.harvest(xs[111], fs)
+    _close(f0[f_off[111]:f_off[112]].cpu().numpy(), ref, 1e-7)
