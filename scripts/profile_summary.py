@@ -34,6 +34,7 @@ o = ["# Profile set {}: {}\n".format(tag, title),
      "| CPU baseline (torch reference stack, %d threads) | %.0f valid frames/s |" % (d["cpu_baseline"]["cores"], d["cpu_baseline"]["value"]),
      "| WORLD analysis, %d utterances = %.0f s of 16 kHz audio | %.2f ms, RTF %.2e (C oracle, 1 core: %.3f) |" % (w["utterances"], w["audio_seconds"], w["analysis_ms"], w["analysis_rtf"], w["cpu_baseline"]["analysis_rtf"]),
      "| WORLD synthesis, same batch | %.2f ms, RTF %.2e (C oracle: %.3f) |" % (w["synthesis_ms"], w["synthesis_rtf"], w["cpu_baseline"]["synthesis_rtf"]),
+     "| Harvest F0 (pyworld.harvest) on %d of those utterances = %.0f s | %.1f ms, RTF %.2e |" % ((w.get("harvest_f0") or {}).get("utterances", 0), (w.get("harvest_f0") or {}).get("audio_seconds", 0.0), (w.get("harvest_f0") or {}).get("ms", float("nan")), (w.get("harvest_f0") or {}).get("rtf", float("nan"))),
      "| 48 kHz: analysis / synthesis of %.0f s | %.2f / %.2f ms, RTF %.2e / %.2e |" % (w48["audio_seconds"], w48["analysis_ms"], w48["synthesis_ms"], w48["analysis_rtf"], w48["synthesis_rtf"]),
      "| MLPG, %d utterances, %d frames x 62 dims | %.2f ms, %.0f GB/s algorithmic (%.1f %% of HBM peak) |" % (ml["utterances"], ml["frames"], ml["ms"], ml["algorithmic_GBps"], 100 * ml["frac_of_hbm_peak"]),
      "| %s train step, %d utterances (%d valid frames) | %.1f ms -> %.0f k valid frames/s |" % (bl["model"], bl["utterances_per_gpu"], bl["valid_frames"], bl["ms_per_step"], bl["valid_frames_per_s"] / 1e3),
