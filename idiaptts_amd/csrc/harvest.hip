@@ -404,11 +404,37 @@ __global__ __launch_bounds__(NT) void hv_raw_kernel(const HvUtt* __restrict__ ut
     for (int k = 0; k < 4; ++k) {
       const double* fe = lists + (int64_t)k * cap;
       const int n = cnt[k] - 1;  // intervals: loc[j] = (fe[j]+fe[j+1])/2/fs, f0[j] = fs/(fe[j+1]-fe[j])
-      int lo = 0, hi = n;        // histc: number of loc[j] <= t, clamped to [1, n-1]
+      // histc: number of loc[j] <= t, clamped to [1, n-1].  The events of a band are close to
+      // evenly spaced, so the search starts from the proportional guess and gallops outwards
+      // (same result as a bisection of [0, n), a third of the dependent loads)
+      auto loc_le = [&](int j) { return (fe[j] + fe[j + 1]) / 2.0 / fs <= t; };
+      int lo, hi;
+      {
+        int g = (int)((double)i / (double)u.T1 * n);
+        g = g < 0 ? 0 : (g > n - 1 ? n - 1 : g);
+        if (loc_le(g)) {
+          lo = g + 1;
+          int pb = g + 1, step = 1;
+          while (pb < n && loc_le(pb)) {
+            lo = pb + 1;
+            pb += step;
+            step <<= 1;
+          }
+          hi = pb < n ? pb : n;
+        } else {
+          hi = g;
+          int pb = g - 1, step = 1;
+          while (pb >= 0 && !loc_le(pb)) {
+            hi = pb;
+            pb -= step;
+            step <<= 1;
+          }
+          lo = pb < 0 ? 0 : pb + 1;
+        }
+      }
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const double loc = (fe[mid] + fe[mid + 1]) / 2.0 / fs;
-        if (loc <= t) lo = mid + 1; else hi = mid;
+        if (loc_le(mid)) lo = mid + 1; else hi = mid;
       }
       int kk = lo;
       if (kk < 1) kk = 1;
@@ -983,73 +1009,90 @@ __global__ __launch_bounds__(NT) void hv_contour2_kernel(const HvUtt* __restrict
 // SmoothF0Contour: each voiced section, held constant beyond its ends, through the 2nd-order
 // low-pass forwards and backwards.  WORLD runs both passes over the whole padded contour from a
 // zero state; the filter's poles have radius 0.875, so HV_LAG = 300 samples of the constant
-// extension bring the state to its fixed point to 4e-18 relative -- the passes here start HV_LAG
-// positions before / after the section (always inside the padded contour) and the values inside
-// the section are the same to the last bit or two.  One lane per section; forward outputs are
-// parked position-major ([offset][lane]) so the backward pass reads coalesced.
+// extension bring the state to its fixed point to 4e-18 relative -- the passes here cover the
+// section plus HV_LAG positions either side (always inside the padded contour).  Sections are few
+// and long (hundreds to thousands of frames), so one wave takes a section at a time and splits
+// each pass into 64 chunks: every lane runs its chunk from a zero state, the chunk states are
+// chained through C^L (the recurrence is linear, as in hv_iir3_reversed), and every lane runs its
+// chunk again from its true state.
+struct HvSt2 { double w0, w1; };
+
+template <typename In, typename Out>
+__device__ inline void hv_iir2_wave(In in, Out out, int n, int lane) {
+  const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
+  const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
+  const int L = (n + 63) / 64;
+  const int lo = min(n, lane * L), hi = min(n, lo + L);
+  // C^L by running the homogeneous recurrence from the two unit states (every lane the same)
+  double m00 = 1.0, m10 = 0.0, m01 = 0.0, m11 = 1.0;   // columns: images of (1,0) and (0,1)
+  for (int i = 0; i < L; ++i) {
+    const double t0 = a0 * m00 + a1 * m10, t1 = a0 * m01 + a1 * m11;
+    m10 = m00;
+    m11 = m01;
+    m00 = t0;
+    m01 = t1;
+  }
+  double w0 = 0.0, w1 = 0.0;
+  for (int i = lo; i < hi; ++i) {
+    const double wt = in(i) + a0 * w0 + a1 * w1;
+    w1 = w0;
+    w0 = wt;
+  }
+  // chain: state entering chunk k = C^L (state entering k-1) + local(k-1); lanes whose chunk is
+  // short or empty only exist at the end, where nothing reads their successor
+  double s0 = 0.0, s1 = 0.0, i0 = 0.0, i1 = 0.0;
+  for (int k = 0; k < 64; ++k) {
+    if (lane == k) {
+      i0 = s0;
+      i1 = s1;
+    }
+    const double l0 = __shfl(w0, k, 64), l1 = __shfl(w1, k, 64);
+    const double n0 = m00 * s0 + m01 * s1 + l0, n1 = m10 * s0 + m11 * s1 + l1;
+    s0 = n0;
+    s1 = n1;
+  }
+  w0 = i0;
+  w1 = i1;
+  for (int i = lo; i < hi; ++i) {
+    const double wt = in(i) + a0 * w0 + a1 * w1;
+    out(i, b0 * wt + b1 * w0 + b0 * w1);
+    w1 = w0;
+    w0 = wt;
+  }
+}
+
 __global__ __launch_bounds__(64) void hv_smooth_kernel(const HvUtt* __restrict__ utts, HvParams p,
                                                        double* __restrict__ ctr,
                                                        double* __restrict__ park) {
-  const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
-  const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
   const HvUtt u = utts[blockIdx.x];
   const HvCtr c = hv_ctr(ctr, u);
   const int ns = c.meta[1];
   double* pk = park + u.sm_off;
   const int lane = threadIdx.x;
-  for (int g = 0; g < ns; g += 64) {
-    const int s = g + lane;
-    const bool on = s < ns;
-    const int st = on ? c.sb[2 * s] : 0, ed = on ? c.sb[2 * s + 1] : -1;
-    const int len = ed - st + 1;                      // positions st .. ed; 0 for idle lanes
-    const double cst = on ? c.B[st - HV_LAG] : 0.0, ced = on ? c.B[ed - HV_LAG] : 0.0;
-    int maxlen = len;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-    // forward: offsets -HV_LAG .. len - 1 + HV_LAG relative to st; outputs kept from offset 0
-    constexpr int NB = 32;   // values requested together: the loads do not depend on the recurrence,
-                             // and one memory round trip per 32 steps is what keeps a lane moving
-    double w0 = 0.0, w1 = 0.0;
-    for (int k0 = -HV_LAG; k0 < maxlen + HV_LAG; k0 += NB) {
-      double xv[NB];
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int k = k0 + q;
-        xv[q] = cst;
-        if (k >= len) xv[q] = ced;
-        else if (k > 0) xv[q] = c.B[st + k - HV_LAG];
-      }
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int k = k0 + q;
-        const double wt = xv[q] + a0 * w0 + a1 * w1;
-        const double o = b0 * wt + b1 * w0 + b0 * w1;
-        w1 = w0;
-        w0 = wt;
-        if (on && k >= 0 && k < len + HV_LAG) pk[(int64_t)k * 64 + lane] = o;
-      }
-    }
-    // backward from offset len - 1 + HV_LAG down to 0
-    w0 = w1 = 0.0;
-    for (int k0 = maxlen + HV_LAG - 1; k0 >= 0; k0 -= NB) {
-      double v[NB];
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int k = k0 - q;
-        v[q] = (on && k >= 0 && k < len + HV_LAG) ? pk[(int64_t)k * 64 + lane] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int k = k0 - q;
-        if (k < len + HV_LAG) {   // lanes with shorter sections start later, from a zero state
-          const double wt = v[q] + a0 * w0 + a1 * w1;
-          const double o = b0 * wt + b1 * w0 + b0 * w1;
-          w1 = w0;
-          w0 = wt;
-          if (on && k >= 0 && k < len) c.C[st + k - HV_LAG] = o;
-        }
-      }
-    }
+  for (int s = 0; s < ns; ++s) {
+    const int st = c.sb[2 * s], ed = c.sb[2 * s + 1];
+    const int len = ed - st + 1, n = len + 2 * HV_LAG;
+    const double cst = c.B[st - HV_LAG], ced = c.B[ed - HV_LAG];
+    // forward over offsets k - HV_LAG relative to st; everything is parked (k = 0 .. n - 1)
+    hv_iir2_wave(
+        [&](int k) {
+          const int o = k - HV_LAG;
+          return o <= 0 ? cst : (o >= len ? ced : c.B[st + o - HV_LAG]);
+        },
+        [&](int k, double v) { pk[k] = v; }, n - HV_LAG + HV_LAG, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // backward: index k counts down from the last parked value
+    hv_iir2_wave([&](int k) { return pk[n - 1 - k]; },
+                 [&](int k, double v) {
+                   const int o = n - 1 - k - HV_LAG;
+                   if (o >= 0 && o < len) c.C[st + o - HV_LAG] = v;
+                 },
+                 n, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 }
 
