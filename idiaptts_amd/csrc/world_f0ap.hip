@@ -9,6 +9,7 @@
 // the FFTs are replaced by direct DFT sums at those bins (twiddles from the same master table)
 // -- no LDS FFT buffer, any f0-dependent FFT size.  D4C keeps every spectrum in LDS.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 
 #include "context.h"
@@ -156,6 +157,112 @@ __global__ __launch_bounds__(NT) void stonemask_kernel(SmArgs a) {
     mean = refine(t, nh);
   }
   if (threadIdx.x == 0) a.f0_out[g] = fabs(mean - f0) > f0 * 0.2 ? f0 : mean;
+}
+
+// One WAVE per frame (SM_WAVES frames per workgroup, no workgroup barriers): the windowed and
+// derivative-windowed samples go to the wave's LDS block once (window by one sincos per lane and
+// rotations), then both refinement passes regroup the lanes as harmonics x sample phases
+// (2 x 32 for the first pass, 8 x 8 for the second) so that the spectra at the harmonic bins need
+// one short butterfly reduction instead of a workgroup-wide one.  Same sums as stonemask_kernel in
+// a different order.
+__device__ __forceinline__ double sm_xor_sum(double v, int mask) { return v + __shfl_xor(v, mask, 64); }
+
+__global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wv >= waves) return;
+  const int64_t g = (int64_t)blockIdx.x * waves + wv;
+  if (g >= a.f_off[a.n_utts]) return;
+  double* sm = reinterpret_cast<double*>(smem) + (size_t)wv * 2 * a.nmax;  // x * main window
+  double* sd = sm + a.nmax;                                                  // x * diff window
+  const int u = find_utt2(a.f_off, a.n_utts, g);
+  const double* x = a.x + a.x_off[u];
+  const int64_t xl = a.x_off[u + 1] - a.x_off[u];
+  const int fs = a.fs;
+  const double f0 = a.f0_in[g];
+  const double pos = (double)(g - a.f_off[u]) * a.frame_period / 1000.0;
+  if (f0 <= 40.0 || f0 > fs / 12.0) {
+    if (lane == 0) a.f0_out[g] = 0.0;
+    return;
+  }
+  const int half = (int)(1.5 * fs / f0 + 1.0);
+  const double wlt = (2.0 * half + 1.0) / fs;
+  const int n = 2 * half + 1;
+  const int fft = 1 << (2 + ilog2(n));   // n is odd: floor(log2) is exact
+  const int64_t i0 = mround((pos - (double)half / fs) * fs + 0.001);
+  {
+    const double tmp = ((double)(i0 + lane) - 1.0) / fs - pos;
+    double sn, cs, rs, rc, ds1, dc1;
+    sincospi(2.0 * tmp / wlt, &sn, &cs);
+    sincospi(2.0 * 64.0 / (fs * wlt), &rs, &rc);
+    sincospi(2.0 / (fs * wlt), &ds1, &dc1);
+    auto win = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
+    for (int i = lane; i < n; i += 64) {
+      int64_t idx = i0 + i - 1;
+      idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+      const double xv = x[idx];
+      const double mw = win(cs);
+      const double up = win(cs * dc1 - sn * ds1), dn = win(cs * dc1 + sn * ds1);
+      double dw;
+      if (i == 0) dw = -up / 2.0;
+      else if (i == n - 1) dw = dn / 2.0;
+      else dw = -(up - dn) / 2.0;
+      sm[i] = xv * mw;
+      sd[i] = xv * dw;
+      const double c2 = cs * rc - sn * rs;
+      sn = sn * rc + cs * rs;
+      cs = c2;
+    }
+  }
+  // spectra (main M, diff D) at `nh` harmonic bins of `base`; lanes = 2^hb harmonics x 2^(6-hb) phases
+  auto refine = [&](double base, int nh, int hb) -> double {
+    const int pbits = 6 - hb, phases = 1 << pbits;
+    const int hq = lane >> pbits, ph = lane & (phases - 1);
+    const int bin = hq < nh ? mround(base * fft / fs * (hq + 1)) : 0;
+    double mr = 0.0, mi = 0.0, dr = 0.0, di = 0.0;
+    if (hq < nh) {
+      const int step = (int)(((long long)bin * phases) % fft);
+      int k = (int)(((long long)bin * ph) % fft);
+      for (int i = ph; i < n; i += phases) {
+        const double2 w = twiddle_neg(a.g_tw, k, fft);
+        const double vm = sm[i], vd = sd[i];
+        mr += vm * w.x;
+        mi += vm * w.y;
+        dr += vd * w.x;
+        di += vd * w.y;
+        k += step;
+        if (k >= fft) k -= fft;
+      }
+    }
+    for (int mask = 1; mask < phases; mask <<= 1) {
+      mr = sm_xor_sum(mr, mask);
+      mi = sm_xor_sum(mi, mask);
+      dr = sm_xor_sum(dr, mask);
+      di = sm_xor_sum(di, mask);
+    }
+    double num = 0.0, den = 0.0;
+    if (hq < nh) {
+      const double numer = mr * di - mi * dr;
+      const double ps = mr * mr + mi * mi;
+      const double inst = ps == 0.0 ? 0.0 : (double)bin * fs / fft + numer / ps * fs / 2.0 / kPi;
+      const double amp = sqrt(ps);
+      num = amp * inst;
+      den = amp * (hq + 1);
+    }
+    for (int mask = phases; mask < 64; mask <<= 1) {
+      num = sm_xor_sum(num, mask);
+      den = sm_xor_sum(den, mask);
+    }
+    return num / (den + kEps);
+  };
+  const double t = refine(f0, 2, 1);
+  double mean = 0.0;
+  if (!(t <= 0.0 || t > f0 * 2)) {
+    int nh = (int)(fs / 2.0 / f0);
+    if (nh > 6) nh = 6;
+    mean = refine(t, nh, 3);
+  }
+  if (lane == 0) a.f0_out[g] = fabs(mean - f0) > f0 * 0.2 ? f0 : mean;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,12 +654,26 @@ extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const d
   if ((rc = upload_i64(h_f_off, n_utts + 1, &d_fo, s))) return rc;
   SmArgs a{d_x, d_xo, d_f0_in, d_fo, n_utts, fs, frame_period_ms, d_f0_out, ctx->twiddles, 0};
   a.nmax = 2 * (int)(1.5 * fs / 40.0 + 1.0) + 1 + 3;
-  const size_t lds = (size_t)a.nmax * 3 * 8 + 128 * 8;
-  ITTS_REQUIRE(lds <= 160 * 1024, "sampling rate too high for the StoneMask LDS budget");
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)h_f_off[n_utts]), dim3(NT), lds, s, a);
-  ITTS_LAUNCH_CHECK();
+  static const int block_form = [] { const char* e = getenv("ITTS_STONEMASK_BLOCK"); return e ? atoi(e) : 0; }();
+  const size_t per_wave = (size_t)a.nmax * 2 * 8;
+  if (!block_form && per_wave <= 80 * 1024) {
+    // as many frames per workgroup as keep two workgroups on a CU (one wave each at 48 kHz)
+    const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (80 * 1024) / per_wave));
+    const size_t lds = per_wave * waves;
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_wave_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t T = h_f_off[n_utts];
+    hipLaunchKernelGGL(stonemask_wave_kernel, dim3((unsigned)((T + waves - 1) / waves)), dim3(NT), lds, s, a,
+                       waves);
+    ITTS_LAUNCH_CHECK();
+  } else {
+    const size_t lds = (size_t)a.nmax * 3 * 8 + 128 * 8;
+    ITTS_REQUIRE(lds <= 160 * 1024, "sampling rate too high for the StoneMask LDS budget");
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)h_f_off[n_utts]), dim3(NT), lds, s, a);
+    ITTS_LAUNCH_CHECK();
+  }
   ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
   ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
   return ITTS_OK;
