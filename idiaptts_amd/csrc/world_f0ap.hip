@@ -663,8 +663,8 @@ extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const d
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_wave_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t T = h_f_off[n_utts];
-    hipLaunchKernelGGL(stonemask_wave_kernel, dim3((unsigned)((T + waves - 1) / waves)), dim3(NT), lds, s, a,
-                       waves);
+    hipLaunchKernelGGL(stonemask_wave_kernel, dim3((unsigned)((T + waves - 1) / waves)), dim3(64 * waves), lds,
+                       s, a, waves);
     ITTS_LAUNCH_CHECK();
   } else {
     const size_t lds = (size_t)a.nmax * 3 * 8 + 128 * 8;
