@@ -142,6 +142,17 @@ def hip_event_time_ms(fn, stream, iters):
     return start.elapsed_time(end) / iters
 
 
+def scratch_pool_stats(L):
+    """reserved / used bytes and release threshold of the stream-ordered scratch pool: a section
+    that ran with a pool below its working set shows up here (and 5x slower)"""
+    import ctypes
+    r, u, k = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    if L.itts_scratch_pool_stats(ctypes.byref(r), ctypes.byref(u), ctypes.byref(k)) != 0:
+        return None
+    return {"reserved_GB": r.value / 2 ** 30, "used_GB": u.value / 2 ** 30,
+            "keep_threshold_GB": k.value / 2 ** 30}
+
+
 def hip_event_median_ms(fn, stream, iters):
     """Median duration of fn() over `iters` passes, each bracketed by its own event pair on
     `stream` (the secondary sections: one slow pass -- a pool growing, a clock ramp -- must not
@@ -156,6 +167,7 @@ def hip_event_median_ms(fn, stream, iters):
             end.record(stream)
             end.synchronize()
             times.append(start.elapsed_time(end))
+    hip_event_median_ms.last = [float(t) for t in times]   # all passes, for the sections that report them
     return float(np.median(times))
 
 
@@ -246,6 +258,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     f0, mc, bap, iters = analysis()
     sync()
     ms_an = over_ranks(hip_event_median_ms(analysis, stream, 5), dist.ReduceOp.MAX)
+    an_passes = list(hip_event_median_ms.last)
     mc64 = mc.double()
     bap64 = bap.double()
     f0s = f0.clone()
@@ -275,11 +288,12 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     res[key] = {
         "fs": fs, "utterances": n_utts * n_ranks, "n_gpus": n_ranks, "audio_seconds": audio_s,
         "frames": frames, "timing": "median of 5 passes, HIP events on the launch stream",
-        "analysis_ms": ms_an, "analysis_rtf": ms_an * 1e-3 / audio_s,
+        "analysis_ms": ms_an, "analysis_ms_passes": an_passes, "analysis_rtf": ms_an * 1e-3 / audio_s,
         "analysis_frames_per_s": frames / (ms_an * 1e-3),
         "synthesis_ms": ms_sy, "synthesis_rtf": ms_sy * 1e-3 / audio_s,
         "mcep_newton_iters_mean": float(iters.float().mean().item()),
         "harvest_f0": harvest,
+        "scratch_pool": scratch_pool_stats(L),
         # algorithmic HBM bytes per frame: fused analysis->features 640 + 248;
         # synthesis 8536
         "analysis_algorithmic_GBps": frames * (fs // 200 * 8 + (61 + L.itts_num_aperiodicities(fs)) * 4)
