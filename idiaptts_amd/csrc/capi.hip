@@ -93,7 +93,7 @@ extern "C" int itts_wav2world(const double* d_x, const int64_t* h_x_off, const i
   if (fft_size <= 0) fft_size = itts_cheaptrick_fft_size(fs, 71.0);
   hipStream_t s = itts::as_stream(stream);
   double* d_f0_raw = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_f0_raw, (size_t)h_f_off[n_utts] * sizeof(double), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_f0_raw, (size_t)h_f_off[n_utts] * sizeof(double), s));
   int rc = itts_dio(d_x, h_x_off, h_f_off, n_utts, fs, frame_period_ms, 71.0, 800.0, 2.0, 0.1, d_f0_raw,
                     stream);
   if (rc == ITTS_OK)
@@ -104,6 +104,6 @@ extern "C" int itts_wav2world(const double* d_x, const int64_t* h_x_off, const i
   if (rc == ITTS_OK && d_ap)
     rc = itts_d4c(d_x, h_x_off, d_f0, h_f_off, n_utts, fs, frame_period_ms, fft_size, 0.85, d_ap, nullptr,
                   nullptr, 0, stream);
-  ITTS_HIP_CHECK(hipFreeAsync(d_f0_raw, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_f0_raw, s));
   return rc;
 }

@@ -72,6 +72,19 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
+// Scratch memory of the entry points.  hipMallocAsync's pool hands its blocks back to the driver
+// whenever a request does not fit what it has cached (one Harvest call empties it), and a fresh
+// device allocation occasionally takes hundreds of milliseconds to seconds on this platform
+// (measured: an analysis pass of 65 ms took 2.3 s right after the pool had been emptied; a whole
+// bench process ran its analysis section at 330 ms per pass).  So the library keeps its own
+// blocks: scratch_malloc returns a cached block of the request's size class (plain hipMalloc the
+// first time), scratch_free marks it free behind an event on the caller's stream; a block that
+// moves to another stream waits for that event first (stream-ordered like hipMallocAsync /
+// hipFreeAsync).  At most ITTS_POOL_KEEP_GB (default 64) stay cached; itts_release_scratch() frees
+// everything that is not in use.
+hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t s);
+hipError_t scratch_free(void* p, hipStream_t s);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace itts

@@ -63,18 +63,132 @@ void keep_scratch_pool(int device) {
 
 }  // namespace itts
 
+
+// ---- scratch blocks ---------------------------------------------------------------------------------
+namespace itts {
+
+struct ScratchBlock {
+  void* p;
+  size_t bytes;
+  hipEvent_t ev;       // recorded on `last` when the block was handed back
+  hipStream_t last;
+  bool busy;
+};
+struct ScratchCache {
+  std::vector<ScratchBlock> blocks;
+  size_t total = 0;
+};
+static std::mutex g_scratch_mutex;
+static std::map<int, ScratchCache> g_scratch;
+
+static size_t scratch_class(size_t n) {
+  if (n <= ((size_t)1 << 20)) {          // powers of two from 256 B: exact-class reuse
+    size_t c = 256;
+    while (c < n) c <<= 1;
+    return c;
+  }
+  const size_t g = (size_t)2 << 20;      // multiples of 2 MB above
+  return (n + g - 1) / g * g;
+}
+
+static size_t scratch_keep_bytes() {
+  static const size_t keep = [] {
+    size_t gb = 64;
+    if (const char* e = getenv("ITTS_POOL_KEEP_GB")) gb = strtoull(e, nullptr, 10);
+    return gb << 30;
+  }();
+  return keep;
+}
+
+// frees idle blocks (largest first) until at most `limit` bytes are held; the caller holds the mutex
+static void scratch_evict(ScratchCache& c, size_t limit) {
+  while (c.total > limit) {
+    int pick = -1;
+    for (int i = 0; i < (int)c.blocks.size(); ++i)
+      if (!c.blocks[i].busy && (pick < 0 || c.blocks[i].bytes > c.blocks[pick].bytes)) pick = i;
+    if (pick < 0) return;
+    ScratchBlock b = c.blocks[pick];
+    (void)hipEventSynchronize(b.ev);
+    (void)hipFree(b.p);
+    (void)hipEventDestroy(b.ev);
+    c.total -= b.bytes;
+    c.blocks.erase(c.blocks.begin() + pick);
+  }
+}
+
+hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t s) {
+  *out = nullptr;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const size_t want = scratch_class(bytes);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  ScratchCache& c = g_scratch[dev];
+  int best = -1;
+  for (int i = 0; i < (int)c.blocks.size(); ++i) {
+    const ScratchBlock& b = c.blocks[i];
+    if (b.busy || b.bytes < want) continue;
+    if (want <= ((size_t)1 << 20) ? b.bytes != want : b.bytes > want + want / 4 + ((size_t)4 << 20)) continue;
+    if (best < 0 || b.bytes < c.blocks[best].bytes) best = i;
+  }
+  if (best >= 0) {
+    ScratchBlock& b = c.blocks[best];
+    if (b.last != s && (e = hipStreamWaitEvent(s, b.ev, 0)) != hipSuccess) return e;
+    b.busy = true;
+    *out = b.p;
+    return hipSuccess;
+  }
+  void* p = nullptr;
+  e = hipMalloc(&p, want);
+  if (e != hipSuccess) {               // out of memory: give back what is idle and try once more
+    (void)hipGetLastError();
+    scratch_evict(c, 0);
+    if ((e = hipMalloc(&p, want)) != hipSuccess) return e;
+  }
+  hipEvent_t ev;
+  if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+    (void)hipFree(p);
+    return e;
+  }
+  c.blocks.push_back(ScratchBlock{p, want, ev, s, true});
+  c.total += want;
+  if (c.total > scratch_keep_bytes()) scratch_evict(c, scratch_keep_bytes());
+  *out = p;
+  return hipSuccess;
+}
+
+hipError_t scratch_free(void* p, hipStream_t s) {
+  if (!p) return hipSuccess;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  for (auto& kv : g_scratch)
+    for (ScratchBlock& b : kv.second.blocks)
+      if (b.p == p) {
+        const hipError_t e = hipEventRecord(b.ev, s);
+        b.last = s;
+        b.busy = false;
+        return e;
+      }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace itts
+
 extern "C" int itts_scratch_pool_stats(int64_t* reserved, int64_t* used, int64_t* keep_threshold) {
   int dev = -1;
   ITTS_HIP_CHECK(hipGetDevice(&dev));
-  hipMemPool_t pool;
-  ITTS_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
-  uint64_t r = 0, u = 0, k = 0;
-  ITTS_HIP_CHECK(hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &r));
-  ITTS_HIP_CHECK(hipMemPoolGetAttribute(pool, hipMemPoolAttrUsedMemCurrent, &u));
-  ITTS_HIP_CHECK(hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &k));
+  size_t r = 0, u = 0;
+  {
+    std::lock_guard<std::mutex> lock(itts::g_scratch_mutex);
+    auto it = itts::g_scratch.find(dev);
+    if (it != itts::g_scratch.end())
+      for (const itts::ScratchBlock& b : it->second.blocks) {
+        r += b.bytes;
+        if (b.busy) u += b.bytes;
+      }
+  }
   if (reserved) *reserved = (int64_t)r;
   if (used) *used = (int64_t)u;
-  if (keep_threshold) *keep_threshold = (int64_t)k;
+  if (keep_threshold) *keep_threshold = (int64_t)itts::scratch_keep_bytes();
   return ITTS_OK;
 }
 
@@ -84,6 +198,11 @@ extern "C" int itts_release_scratch(void) {
   hipMemPool_t pool;
   ITTS_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
   ITTS_HIP_CHECK(hipDeviceSynchronize());
+  {
+    std::lock_guard<std::mutex> lock(itts::g_scratch_mutex);
+    auto it = itts::g_scratch.find(dev);
+    if (it != itts::g_scratch.end()) itts::scratch_evict(it->second, 0);
+  }
   ITTS_HIP_CHECK(hipMemPoolTrimTo(pool, 0));
   return ITTS_OK;
 }
@@ -352,7 +471,7 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
 }
 
 int upload_i64(const int64_t* h, int n, int64_t** d_out, hipStream_t s) {
-  ITTS_HIP_CHECK(hipMallocAsync((void**)d_out, (size_t)n * sizeof(int64_t), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)d_out, (size_t)n * sizeof(int64_t), s));
   ITTS_HIP_CHECK(hipMemcpyAsync(*d_out, h, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, s));
   return ITTS_OK;
 }

@@ -458,9 +458,9 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
   }
   double *d_taps = nullptr, *d_lpf = nullptr;
   int* d_lpf_off = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_taps, taps.size() * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_lpf, lpf.size() * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_lpf_off, lpf_off.size() * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_taps, taps.size() * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_lpf, lpf.size() * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_lpf_off, lpf_off.size() * 4, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_taps, taps.data(), taps.size() * 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf, lpf.data(), lpf.size() * 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf_off, lpf_off.data(), lpf_off.size() * 4, hipMemcpyHostToDevice, s));
@@ -499,15 +499,15 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
     double *d_mean = nullptr, *d_ylc = nullptr, *d_sig = nullptr, *d_fine = nullptr, *d_cand = nullptr,
            *d_score = nullptr, *d_tmp = nullptr;
     int* d_cnt = nullptr;
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_utts, U * sizeof(DioUtt), s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_mean, U * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_ylc, ylc_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_sig, sig_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_fine, fine_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cand, cand_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_score, cand_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_tmp, tmp_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cnt, cnt_n * 4, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_utts, U * sizeof(DioUtt), s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_mean, U * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_ylc, ylc_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_sig, sig_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_fine, fine_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cand, cand_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_score, cand_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_tmp, tmp_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cnt, cnt_n * 4, s));
     ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), U * sizeof(DioUtt), hipMemcpyHostToDevice, s));
     ITTS_HIP_CHECK(itts_spin_sync(s));
 
@@ -547,19 +547,19 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
                          d_f0);
     }
     ITTS_LAUNCH_CHECK();
-    ITTS_HIP_CHECK(hipFreeAsync(d_utts, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_mean, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_ylc, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_sig, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_fine, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_cand, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_score, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_tmp, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_cnt, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_utts, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_mean, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_ylc, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_sig, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_fine, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_cand, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_score, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_tmp, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_cnt, s));
     u0 = u1;
   }
-  ITTS_HIP_CHECK(hipFreeAsync(d_taps, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_lpf, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_lpf_off, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_taps, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_lpf, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_lpf_off, s));
   return ITTS_OK;
 }

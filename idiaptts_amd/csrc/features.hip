@@ -301,7 +301,7 @@ static int interpolate_launch(const double* d_f0, const float* d_in, const int64
   int rc = upload_i64(h_off, n_utts + 1, &d_off, s);
   if (rc != ITTS_OK) return rc;
   int* d_prev = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_prev, total * sizeof(int), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_prev, total * sizeof(int), s));
   if (d_f0)
     hipLaunchKernelGGL(interpolate_lin_kernel<true>, dim3(n_utts), dim3(IL_THREADS), 0, s, d_f0,
                        nullptr, d_off, (float)std::log(thr), lf0_zero, d_ip, d_vuv, d_prev);
@@ -309,8 +309,8 @@ static int interpolate_launch(const double* d_f0, const float* d_in, const int64
     hipLaunchKernelGGL(interpolate_lin_kernel<false>, dim3(n_utts), dim3(IL_THREADS), 0, s, nullptr,
                        d_in, d_off, 0.f, 0.f, d_ip, d_vuv, d_prev);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_prev, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_off, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_prev, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_off, s));
   return ITTS_OK;
 }
 
@@ -361,7 +361,7 @@ extern "C" int itts_assemble_cmp_f32(const float* d_sp, int64_t ld_sp, int n_sp,
   else
     hipLaunchKernelGGL(assemble_cmp_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_off, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_off, s));
   return ITTS_OK;
 }
 

@@ -1234,9 +1234,9 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
   HvTables* d_tab = nullptr;
   double* d_wt = nullptr;
   int* d_err = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_tab, sizeof(HvTables), s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_wt, wts.size() * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_err, 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_tab, sizeof(HvTables), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_wt, wts.size() * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_err, 4, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_tab, &tab, sizeof(HvTables), hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_wt, wts.data(), wts.size() * 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemsetAsync(d_err, 0, 4, s));
@@ -1291,20 +1291,20 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
            *d_base = nullptr, *d_cand = nullptr, *d_ctr = nullptr, *d_mc = nullptr, *d_sm = nullptr;
     int *d_cnt = nullptr, *d_nc = nullptr;
     double* d_coef = nullptr;
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_coef, (size_t)U * p.nch * 3 * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_utts, U * sizeof(HvUtt), s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_y, y_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_dec, std::max<int64_t>(dec_n, 1) * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_sig, sig_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_ev, ev_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_raw, raw_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_base, base_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cand, 4 * cand_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_ctr, ctr_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_mc, mc_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_sm, sm_n * 8, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cnt, cnt_n * 4, s));
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&d_nc, U * 4, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_coef, (size_t)U * p.nch * 3 * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_utts, U * sizeof(HvUtt), s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_y, y_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_dec, std::max<int64_t>(dec_n, 1) * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_sig, sig_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_ev, ev_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_raw, raw_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_base, base_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cand, 4 * cand_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_ctr, ctr_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_mc, mc_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_sm, sm_n * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cnt, cnt_n * 4, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_nc, U * 4, s));
     ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), U * sizeof(HvUtt), hipMemcpyHostToDevice, s));
     ITTS_HIP_CHECK(hipMemsetAsync(d_nc, 0, U * 4, s));
     ITTS_HIP_CHECK(hipMemsetAsync(d_mc, 0, mc_n * 8, s));
@@ -1370,20 +1370,20 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
       ITTS_HIP_CHECK(hipMemcpyAsync(d_dbg_cand, d_cand2, cand_n * 8, hipMemcpyDeviceToDevice, s));
     if (d_dbg_score)
       ITTS_HIP_CHECK(hipMemcpyAsync(d_dbg_score, d_score2, cand_n * 8, hipMemcpyDeviceToDevice, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_utts, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_y, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_dec, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_sig, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_ev, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_raw, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_base, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_cand, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_ctr, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_mc, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_sm, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_cnt, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_nc, s));
-    ITTS_HIP_CHECK(hipFreeAsync(d_coef, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_utts, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_y, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_dec, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_sig, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_ev, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_raw, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_base, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_cand, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_ctr, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_mc, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_sm, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_cnt, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_nc, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_coef, s));
     u0 = u1;
   }
   int64_t* slot = pinned_slot(ctx);
@@ -1391,9 +1391,9 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
   ITTS_HIP_CHECK(hipMemcpyAsync(slot, d_err, 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(itts_spin_sync(s));
   const bool overflow = *reinterpret_cast<int*>(slot) != 0;
-  ITTS_HIP_CHECK(hipFreeAsync(d_tab, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_wt, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_err, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_tab, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_wt, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_err, s));
   if (overflow) {
     set_error("itts_harvest: a band produced more zero crossings than its event list holds");
     return ITTS_E_INVALID;

@@ -402,15 +402,15 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   int *done = nullptr, *iters = nullptr, *n_active = nullptr, *rows = nullptr;
   const int64_t Kp = K + (K & 1);   // even pitch: 16-byte aligned rows for the vector loads
   const size_t slack = 64;          // the vector loads may run up to 3 doubles past a row's end
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&xp, (size_t)T * Kp * 8 + slack, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&cbuf, (size_t)T * Kp * 8 + slack, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&mc, (size_t)T * m1 * 8 + slack, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&cr, (size_t)T * (m2 + 1) * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&sprev, (size_t)T * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&done, (size_t)T * 4, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&iters, (size_t)T * 4, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&rows, (size_t)T * 4, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&n_active, 8, s));   // [0] active frames, [1] list cursor
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&xp, (size_t)T * Kp * 8 + slack, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&cbuf, (size_t)T * Kp * 8 + slack, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&mc, (size_t)T * m1 * 8 + slack, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&cr, (size_t)T * (m2 + 1) * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&sprev, (size_t)T * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&done, (size_t)T * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&iters, (size_t)T * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&rows, (size_t)T * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&n_active, 8, s));   // [0] active frames, [1] list cursor
   const int tcount[2] = {(int)T, 0};
   ITTS_HIP_CHECK(hipMemcpyAsync(n_active, tcount, 8, hipMemcpyHostToDevice, s));
   LsArgs a{};
@@ -465,15 +465,15 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   hipLaunchKernelGGL(mcls_finalize_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256),
                      0, s, mc, T, m1, d_mc_f32, ld_mc, d_mc_f64, iters, d_iters);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(xp, s));
-  ITTS_HIP_CHECK(hipFreeAsync(cbuf, s));
-  ITTS_HIP_CHECK(hipFreeAsync(mc, s));
-  ITTS_HIP_CHECK(hipFreeAsync(cr, s));
-  ITTS_HIP_CHECK(hipFreeAsync(sprev, s));
-  ITTS_HIP_CHECK(hipFreeAsync(done, s));
-  ITTS_HIP_CHECK(hipFreeAsync(iters, s));
-  ITTS_HIP_CHECK(hipFreeAsync(n_active, s));
-  ITTS_HIP_CHECK(hipFreeAsync(rows, s));
+  ITTS_HIP_CHECK(itts::scratch_free(xp, s));
+  ITTS_HIP_CHECK(itts::scratch_free(cbuf, s));
+  ITTS_HIP_CHECK(itts::scratch_free(mc, s));
+  ITTS_HIP_CHECK(itts::scratch_free(cr, s));
+  ITTS_HIP_CHECK(itts::scratch_free(sprev, s));
+  ITTS_HIP_CHECK(itts::scratch_free(done, s));
+  ITTS_HIP_CHECK(itts::scratch_free(iters, s));
+  ITTS_HIP_CHECK(itts::scratch_free(n_active, s));
+  ITTS_HIP_CHECK(itts::scratch_free(rows, s));
   return ITTS_OK;
 }
 

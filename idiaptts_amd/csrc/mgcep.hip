@@ -450,7 +450,7 @@ extern "C" int itts_mgc2sp_gamma(const double* d_mgc, int64_t T, int order, doub
   const int K = fftlen / 2 + 1;
   const int64_t ld_cep = (K + 1) & ~1;
   double* d_cep = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cep, (size_t)T * ld_cep * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cep, (size_t)T * ld_cep * 8, s));
   // freqt(mgc, m -> f2, -alpha) of all frames: one fp64-MFMA GEMM against the cached warping matrix
   int rc = launch_gemm_f64(d_mgc, order + 1, ft->invT, K, d_cep, ld_cep, T, K, order + 1, nullptr, s,
                            /*a_has_slack=*/false);
@@ -466,6 +466,6 @@ extern "C" int itts_mgc2sp_gamma(const double* d_mgc, int64_t T, int order, doub
   const size_t lds2 = (size_t)(fftlen / 2 + 1) * 16;
   hipLaunchKernelGGL(mg_c2sp_kernel, dim3((unsigned)T), dim3(NT), lds2, s, a);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_cep, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_cep, s));
   return ITTS_OK;
 }

@@ -1069,7 +1069,7 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
     const size_t tab_bytes = (tab.size() * sizeof(int) + 15) / 16 * 16;
     const size_t agg_bytes = (size_t)n_sc * 24 * nblk * 64 * sizeof(unsigned long long);
     char* blk = nullptr;
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&blk, tab_bytes + agg_bytes, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, tab_bytes + agg_bytes, s));
     ITTS_HIP_CHECK(hipMemcpyAsync(blk, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, s));
     ITTS_HIP_CHECK(hipMemsetAsync(blk + tab_bytes, 0, agg_bytes, s));
     FusedArgs g;
@@ -1127,7 +1127,7 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
         fclose(tf);
       }
     }
-    ITTS_HIP_CHECK(hipFreeAsync(blk, s));
+    ITTS_HIP_CHECK(itts::scratch_free(blk, s));
     return ITTS_OK;
   }
   double* extra = reinterpret_cast<double*>(reinterpret_cast<char*>(d_nconv) + ((int64_t)dim * 4 + 16) / 8 * 8 + 8);
@@ -1153,7 +1153,7 @@ extern "C" int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, i
   if (n_utts == 0 || h_offsets[n_utts] == 0) return ITTS_OK;
   hipStream_t s = as_stream(stream);
   int64_t* d_off = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_off, (n_utts + 1) * sizeof(int64_t), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_off, (n_utts + 1) * sizeof(int64_t), s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
                                 hipMemcpyHostToDevice, s));
   int64_t maxT = 0;
@@ -1163,6 +1163,6 @@ extern "C" int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, i
   hipLaunchKernelGGL(gradient_f32_kernel, dim3(bx, n_utts), dim3(256), 0, s, d_x, ld_x, d_out,
                      ld_out, dim, d_off);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_off, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_off, s));
   return ITTS_OK;
 }

@@ -695,16 +695,16 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   uint8_t* d_vuv = nullptr;
   int* d_pidx = nullptr;
   int64_t* d_gpoff = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_utts, n_utts * sizeof(SynUtt), s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_wrap, s_n * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_R, s_n * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_vuv, s_n, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_pidx, s_n * 4, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_bs, b_n * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_pc, b_n * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_ptot, n_utts * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_gpoff, (n_utts + 1) * 8, s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_y, y_total * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_utts, n_utts * sizeof(SynUtt), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_wrap, s_n * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_R, s_n * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_vuv, s_n, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_pidx, s_n * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_bs, b_n * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_pc, b_n * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_ptot, n_utts * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_gpoff, (n_utts + 1) * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_y, y_total * 8, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), n_utts * sizeof(SynUtt), hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(itts_spin_sync(s));
   ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, y_total * 8, s));
@@ -777,15 +777,15 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
                        d_utts, preemphasis, (int)seg, (int)warm, d_y_f32, d_y_f64);
   }
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_utts, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_wrap, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_R, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_vuv, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_pidx, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_bs, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_pc, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_ptot, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_gpoff, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_y, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_utts, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_wrap, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_R, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_vuv, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_pidx, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_bs, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_pc, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_ptot, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_gpoff, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_y, s));
   return ITTS_OK;
 }

@@ -674,8 +674,8 @@ extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const d
     hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)h_f_off[n_utts]), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
   }
-  ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_fo, s));
   return ITTS_OK;
 }
 
@@ -722,7 +722,7 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   const int64_t t_total = h_f_off[n_utts];
   ITTS_REQUIRE(t_total < ((int64_t)1 << 31), "too many frames in one call");
   int* d_order = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_order, (size_t)(t_total + 2) * sizeof(int), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_order, (size_t)(t_total + 2) * sizeof(int), s));
   ITTS_HIP_CHECK(hipMemsetAsync(d_order + t_total, 0, 2 * sizeof(int), s));
   hipLaunchKernelGGL(d4c_order_kernel, dim3((unsigned)std::min<int64_t>((t_total + 255) / 256, 1024)), dim3(256),
                      0, s, d_f0, t_total, d_order, d_order + t_total);
@@ -733,8 +733,8 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   else
     hipLaunchKernelGGL(d4c_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_order, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_order, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_fo, s));
   return ITTS_OK;
 }

@@ -646,7 +646,7 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   // lockstep mcep needs the envelope in memory: use the caller's buffer or a temporary
   double* sp_buf = d_sp;
   if (do_mcep && !fused && !sp_buf)
-    ITTS_HIP_CHECK(hipMallocAsync((void**)&sp_buf, (size_t)t_total * (fft_size / 2 + 1) * 8, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&sp_buf, (size_t)t_total * (fft_size / 2 + 1) * 8, s));
   int64_t *d_xo = nullptr, *d_fo = nullptr;
   int rc = upload_i64(h_x_off, n_utts + 1, &d_xo, s);
   if (rc) return rc;
@@ -666,8 +666,8 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   for (int u = 0; u < n_utts; ++u) t_max = std::max<int64_t>(t_max, h_f_off[u + 1] - h_f_off[u]);
   int64_t* d_rpos = nullptr;   // [t_total] + r_off [U] + r_len [U]
   uint32_t* d_rn = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_rpos, (size_t)(t_total + 2 * n_utts) * sizeof(int64_t), s));
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_rn, (size_t)t_total * rn_pitch * sizeof(uint32_t), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_rpos, (size_t)(t_total + 2 * n_utts) * sizeof(int64_t), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_rn, (size_t)t_total * rn_pitch * sizeof(uint32_t), s));
   int64_t* d_roff = d_rpos + t_total;
   int64_t* d_rlen = d_roff + n_utts;
   hipLaunchKernelGGL(ct_noise_pos_kernel, dim3(n_utts), dim3(256), 0, s, d_f0, d_fo, fs, fft_size,
@@ -688,14 +688,14 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
     hipLaunchKernelGGL(cheaptrick_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   }
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_xo, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_fo, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_rpos, s));
-  ITTS_HIP_CHECK(hipFreeAsync(d_rn, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_fo, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_rpos, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_rn, s));
   if (do_mcep && !fused) {
     rc = mcep_lockstep(ctx, sp_buf, 1, t_total, fft_size / 2 + 1, order, alpha, eps, miniter, maxiter,
                        threshold, d_mc_f32, ld_mc, d_mc_f64, d_iters, s);
-    if (sp_buf != d_sp) ITTS_HIP_CHECK(hipFreeAsync(sp_buf, s));
+    if (sp_buf != d_sp) ITTS_HIP_CHECK(itts::scratch_free(sp_buf, s));
     if (rc) return rc;
   }
   return ITTS_OK;
@@ -745,7 +745,7 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   const int K = fftlen / 2 + 1;
   const int64_t ld_cep = (K + 1) & ~1;
   double* d_cep = nullptr;
-  ITTS_HIP_CHECK(hipMallocAsync((void**)&d_cep, (size_t)T * ld_cep * 8, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cep, (size_t)T * ld_cep * 8, s));
   int rc = launch_gemm_f64(d_mc, order + 1, ft->invT, K, d_cep, ld_cep, T, K, order + 1, nullptr, s,
                            /*a_has_slack=*/false);
   if (rc) return rc;
@@ -756,7 +756,7 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(mgc2sp_kernel, dim3((unsigned)T), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(hipFreeAsync(d_cep, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_cep, s));
   return ITTS_OK;
 }
 

@@ -36,13 +36,14 @@ int itts_abi_version(void);
 const char* itts_last_error(void);
 /* number of visible HIP devices (initialises HIP). */
 int itts_device_count(void);
-/* Bytes the device's stream-ordered scratch pool holds (reserved), has handed out (used), and the
- * release threshold it keeps across synchronisations (ITTS_POOL_KEEP_GB); any pointer may be NULL. */
+/* Bytes of scratch the library holds on the current device (reserved), of which handed out (used),
+ * and the amount it may keep between calls (ITTS_POOL_KEEP_GB); any pointer may be NULL. */
 int itts_scratch_pool_stats(int64_t* reserved, int64_t* used, int64_t* keep_threshold);
 
-/* The GPU entry points take their scratch from the current device's stream-ordered pool, which keeps
- * up to ITTS_POOL_KEEP_GB (environment, default 64) between calls.  This synchronises the device
- * and hands all of it back, e.g. between a feature-extraction job and training in one process. */
+/* The GPU entry points take their scratch from blocks the library keeps per device (stream-ordered:
+ * a block handed back on one stream is reused on another only behind an event), up to
+ * ITTS_POOL_KEEP_GB (environment, default 64) between calls.  This synchronises the device and hands
+ * every idle block back, e.g. between a feature-extraction job and training in one process. */
 int itts_release_scratch(void);
 
 /* ---- integer / scalar helpers (host, no GPU) ------------------------------------------- */

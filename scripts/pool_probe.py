@@ -23,3 +23,23 @@ for i in range(6):
     before = stats()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("pass %d: %.1f ms | before sync: %s | after sync: %s | free %.1f GB" % (i, dt * 1e3, before, stats(), torch.cuda.mem_get_info()[0] / 2**30))
+
+if len(sys.argv) > 2:
+    # mixed sequence: analysis / harvest on a subset / analysis ... (does a large foreign request
+    # make the pool drop its cached blocks?)
+    nh = 64
+    xh, xoh, foh = x[:x_off[nh]], x_off[:nh + 1], [ops.harvest_num_frames(b - a, fs, 5.0) for a, b in zip(x_off[:nh], x_off[1:nh + 1])]
+    foh = world.offsets(foh)
+    def analysis():
+        f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs), f_off, fs)
+        ops.d4c(x, x_off, f0, f_off, fs, 5.0, 1024, want_ap=False, want_bap=torch.float32)
+        ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, 5.0, 1024, want_sp=False, order=59, alpha=0.41)
+    for i in range(12):
+        which = "harvest" if i % 3 == 2 else "analysis"
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if which == "harvest":
+            ops.harvest(xh, xoh, foh, fs, 5.0)
+        else:
+            analysis()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("%-8s %.1f ms | %s" % (which, dt * 1e3, stats()))
