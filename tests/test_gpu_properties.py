@@ -188,3 +188,25 @@ def test_copy_synthesis_bound_of_the_reference_on_every_fixture_wav(gpu, golden_
     wav = WorldFeatLabelGen.world_features_to_raw(amp_sp, lf0, vuv, bap, fs=fs, n_fft=1024)
     n = min(len(wav), len(raw))
     assert ((raw[:n] - wav[:n]) ** 2).sum() < 10000
+
+
+def test_harvest_is_invariant_to_the_signal_level_at_bench_size(gpu):
+    """Every stage of Harvest is homogeneous in the signal (decimation, DC removal, band-pass
+    filters, zero-crossing positions, instantaneous frequencies are ratios): scaling the audio by a
+    power of two scales every intermediate exactly, so the contour may only move through the two
+    1e-12 safeguards of the refinement.  64 utterances of 2-10 s (bench.py's Harvest workload)."""
+    from idiaptts_amd import ops
+    from idiaptts_amd.bench_support import make_audio_batch
+    fs = 16000
+    raws = make_audio_batch(64, fs, seed=2)
+    x_off = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).tolist()
+    f_off = np.concatenate([[0], np.cumsum([ops.harvest_num_frames(len(r), fs, 5.0) for r in raws])]).tolist()
+    x = torch.from_numpy(np.concatenate(raws)).to(gpu)
+    a = ops.harvest(x, x_off, f_off, fs)
+    b = ops.harvest(x * 0.25, x_off, f_off, fs)
+    va, vb = a > 0, b > 0
+    assert torch.equal(va, vb)
+    assert float(((a[va] - b[va]).abs() / a[va]).max()) < 1e-8
+    # in range, or unvoiced
+    assert bool(((a[va] >= 71.0) & (a[va] <= 800.0)).all())
+    assert 0.2 < float(va.double().mean()) < 0.8
