@@ -31,7 +31,7 @@ constexpr int LD_ROW = BK + 4;    // row-form tile [128][36]
 constexpr int LD_COL = BM + 4;    // col-form tile [32][132]
 constexpr int TILE_FLOATS = 128 * LD_ROW;  // 4608 >= 32*132 = 4224
 
-enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_DACT = 2 };
+enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_DACT = 2, EPI_MSE = 3 };
 
 struct GemmArgs {
   const float* A;
@@ -51,6 +51,10 @@ struct GemmArgs {
   int64_t slab_stride;  // floats between split-K slabs of C
   int vecA, vecB;       // 16-B vector loads allowed
   int wide_out;         // C (and bias, aux) allow 16-B accesses: float4 epilogue of the row-form kernel
+  // EPI_MSE (last layer of a training step): C receives d loss / d output instead of the output
+  const uint8_t* row_valid;   // [M]
+  float gscale;               // 2 * loss_weight / (n_valid * D)
+  double* loss_partial;       // [grid] sums of squared masked differences, one per workgroup
 };
 
 // tanh in ~12 VALU ops (ocml tanhf costs ~40 and showed up as ~15 % of the fused-epilogue GEMMs):
@@ -239,6 +243,48 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (int64_t)blockIdx.z * g.slab_stride;
   const int cl = lane & 31, rh = lane >> 5;
+  if (EPI == EPI_MSE) {
+    // Last layer of a training step: y = acc + bias never goes to memory; the masked difference to
+    // the target (aux) is squared into the workgroup's partial sum and scaled into C as
+    // d loss / d y (masked_mse_kernel's arithmetic: double accumulation of float differences).
+    float* stage = lds + wid * (32 * 36);
+    const int c4 = (lane & 7) << 2, rq = lane >> 3;
+    const int colb = n0 + wn * 32;
+    double lsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * rh) * 36 + cl] = acc[i][0][r];
+      const int col = colb + c4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = rq + 8 * q;
+        const int64_t row = m0 + wm * 64 + i * 32 + rl;
+        const float4 v = *reinterpret_cast<const float4*>(stage + rl * 36 + c4);
+        if (row >= g.M || col >= g.N) continue;
+        const bool ok = g.row_valid[row] != 0;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float dz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float diff = 0.f;
+          if (col + e < g.N && ok)
+            diff = (vv[e] + (g.bias ? g.bias[col + e] : 0.f)) - g.aux[row * g.ldaux + col + e];
+          lsum += (double)diff * (double)diff;
+          dz[e] = g.gscale * diff;
+        }
+        if (col + 3 < g.N) {
+          *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        } else {
+          for (int e = 0; e < 4 && col + e < g.N; ++e) C[row * g.ldc + col + e] = dz[e];
+        }
+      }
+    }
+    __shared__ double mse_red[16];
+    lsum = block_sum(lsum, mse_red);
+    if (threadIdx.x == 0) g.loss_partial[blockIdx.x] = lsum;
+    return;
+  }
   if (STAGES == 1 && TN == 1 && g.wide_out) {
     // Wide stores: a wave passes each of its 32 x 32 result blocks through its own 4.6 KB of the
     // (now idle) LDS tile and writes rows back as float4 -- 8 store instructions of whole 128-byte
@@ -678,6 +724,50 @@ extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, 
     g.wide_out = wide && (ldy % 4 == 0) && aligned16(d_y) && (!d_b || aligned16(d_b));
   }
   return launch_gemm<true, true, EPI_BIAS_ACT>(g, 1, as_stream(stream));
+}
+
+extern "C" int64_t itts_linear_fwd_mse_workspace_bytes(int64_t M, int N) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
+  return std::max<int64_t>(tiles, 1) * 8;
+}
+
+// Forward of the output layer fused with NamedLoss(MSELoss, 'mean_per_frame'): d_loss [1] and
+// d_dz [M, N] = d loss / d y; y itself is not stored (FFWrapper.py:63-73 followed by
+// NamedLoss.py:70-117 in a training step).  Falls back to nothing: the buffers must allow 16-byte
+// rows for x, w and dz (the trainer's buffers do); other callers use itts_linear_fwd +
+// itts_masked_mse.
+extern "C" int itts_linear_fwd_mse(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
+                                   const float* d_target, int64_t ldt, const uint8_t* d_row_valid,
+                                   double n_valid, float loss_weight, int64_t M, int N, int K,
+                                   float* d_loss, float* d_dz, int64_t lddz, void* d_workspace,
+                                   void* stream) {
+  ITTS_REQUIRE(d_w && d_loss && d_workspace && (M == 0 || (d_x && d_target && d_row_valid && d_dz)),
+               "null pointer");
+  ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldt >= N && lddz >= N && n_valid > 0, "bad sizes");
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    ITTS_HIP_CHECK(hipMemsetAsync(d_loss, 0, 4, s));
+    return ITTS_OK;
+  }
+  ITTS_REQUIRE((ldx % 4 == 0) && aligned16(d_x) && (K % 4 == 0) && aligned16(d_w) && (lddz % 4 == 0) &&
+                   aligned16(d_dz),
+               "x, w and dz need 16-byte aligned rows (use itts_linear_fwd + itts_masked_mse otherwise)");
+  GemmArgs g{};
+  g.A = d_x; g.lda = ldx; g.B = d_w; g.ldb = K; g.C = d_dz; g.ldc = lddz;
+  g.M = M; g.N = N; g.K = K; g.bias = d_b; g.act = 0;
+  g.kchunk = ((K + BK - 1) / BK) * BK; g.slab_stride = 0;
+  g.vecA = 1; g.vecB = 1; g.wide_out = 1;
+  g.aux = d_target; g.ldaux = ldt; g.row_valid = d_row_valid;
+  const double scale = (double)loss_weight / (n_valid * (double)N);
+  g.gscale = (float)(2.0 * scale);
+  g.loss_partial = reinterpret_cast<double*>(d_workspace);
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
+  int rc = launch_gemm_tn<true, true, EPI_MSE, 1, 1>(g, 1, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
+                     reinterpret_cast<const double*>(d_workspace), (int)tiles, scale, d_loss);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
 }
 
 extern "C" int itts_act_bwd(const float* d_dy, const float* d_y, float* d_dz, int64_t n_elem,

@@ -56,6 +56,9 @@ _SIGNATURES = {
                                    _P]),
     "itts_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int,
                                 _P]),
+    "itts_linear_fwd_mse_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "itts_linear_fwd_mse": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_double, c_float, c_int64,
+                                    c_int, c_int, _P, _P, c_int64, _P, _P]),
     "itts_act_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "itts_linear_bwd_input": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int64,
                                       c_int, c_int, _P]),

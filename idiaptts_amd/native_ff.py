@@ -16,6 +16,7 @@ parameters, gradients and Adam moments in ONE flat fp32 buffer each:
   opt   one fused Adam launch over the flat buffers
 """
 import math
+import os
 
 import torch
 
@@ -55,6 +56,7 @@ class FlatFFModel:
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.step_count = 0
         self._buffers = {}
+        self.fuse_output_loss = os.environ.get("ITTS_FF_FUSE_LOSS", "1") != "0"
         if state_dict is None:
             state_dict = self.reference_init(self.dims, seed)
         self.load_layers(state_dict)
@@ -152,12 +154,12 @@ class FlatFFModel:
             self._buffers[name] = buf
         return buf[:M, :width]
 
-    def forward(self, x):
-        """x [M, dims[0]] fp32 packed frames -> list of layer outputs."""
+    def forward(self, x, n_layers=None):
+        """x [M, dims[0]] fp32 packed frames -> list of layer outputs (of the first n_layers)."""
         acts = []
         h = self.pack_input(x)
         M = h.shape[0]
-        for i in range(len(self.layout)):
+        for i in range(len(self.layout) if n_layers is None else n_layers):
             h = ops.linear_fwd(h, self.weight_padded(i), self.bias(i), self.acts[i],
                                out=self._rows_buffer("h%d" % i, M, self.layout[i][2]))
             acts.append(h)
@@ -167,11 +169,20 @@ class FlatFFModel:
         """Fills self.grads with d(loss)/d(params) of this rank's frames; returns loss tensor
         (this rank's contribution, already divided by the global frame count)."""
         x = self.pack_input(x)
-        hs = self.forward(x)
         M = x.shape[0]
-        loss, dz = ops.masked_mse(hs[-1], target, row_valid, n_valid_global,
-                                  grad=self._rows_buffer("dz_out", M, self.dims[-1]))
         n = len(self.layout)
+        if self.acts[-1] in (None, ops.ACT_NONE) and n > 1 and self.fuse_output_loss:
+            # the output layer never materialises: its GEMM epilogue forms the masked difference
+            # to the target, the loss partial sums and d loss / d output
+            hs = self.forward(x, n_layers=n - 1)
+            loss, dz = ops.linear_fwd_mse(hs[-1], self.weight_padded(n - 1), self.bias(n - 1), target,
+                                          row_valid, n_valid_global,
+                                          grad=self._rows_buffer("dz_out", M, self.dims[-1]))
+            hs.append(None)
+        else:
+            hs = self.forward(x)
+            loss, dz = ops.masked_mse(hs[-1], target, row_valid, n_valid_global,
+                                      grad=self._rows_buffer("dz_out", M, self.dims[-1]))
         for i in range(n - 1, -1, -1):
             inp = hs[i - 1] if i > 0 else x
             ops.linear_bwd_weight(dz, inp, dw=self.weight_padded(i, self.grads),

@@ -152,6 +152,31 @@ def linear_fwd(x, w, b, act=ACT_NONE, out=None):
     return out
 
 
+def linear_fwd_mse(x, w, b, target, row_valid, n_valid, loss_weight=1.0, grad=None):
+    """Output layer + masked MSE ('mean_per_frame') of a training step in one launch:
+    (loss [1], d loss / d output [M, N]); the layer's output itself is not materialised."""
+    L = _lib.load()
+    _need(x, torch.float32, "x")
+    _need(w, torch.float32, "w")
+    _need(target, torch.float32, "target")
+    _need(row_valid, torch.uint8, "row_valid")
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise ValueError("w must be contiguous [N, K]")
+    loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+    if grad is None:
+        grad = torch.zeros((M, (N + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :N]
+    ws = torch.empty(max(L.itts_linear_fwd_mse_workspace_bytes(M, N), 8), dtype=torch.uint8,
+                     device=x.device)
+    _lib.check(L.itts_linear_fwd_mse(_ptr(x), _rows(x, "x"), _ptr(w), _ptr(b), _ptr(target),
+                                     _rows(target, "target"), _ptr(row_valid), float(n_valid),
+                                     float(loss_weight), M, N, K, _ptr(loss), _ptr(grad),
+                                     _rows(grad, "grad"), _ptr(ws), _stream()),
+               "itts_linear_fwd_mse")
+    return loss, grad
+
+
 def act_bwd(dy, y, act, out=None):
     L = _lib.load()
     dy = dy.contiguous()

@@ -170,6 +170,17 @@ int itts_feature_stats(const float* d_x, int64_t ld_x, int64_t n_rows, int col0,
  * y[M,N] = act(x[M,K] @ w[N,K]^T + b[N]); fp32 MFMA. */
 int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
                     float* d_y, int64_t ldy, int64_t M, int N, int K, int act, void* stream);
+/* Output layer of a training step fused with NamedLoss(MSELoss, reduction 'mean_per_frame')
+ * (FFWrapper.py:63-73 + loss/NamedLoss.py:70-117): y = x w^T + b is never stored; d_loss [1] receives
+ * loss_weight * sum_valid (y - target)^2 / (n_valid * N) and d_dz [M, N] its gradient w.r.t. y.
+ * x, w and dz need 16-byte aligned rows (ldx, K, lddz multiples of 4); d_workspace:
+ * itts_linear_fwd_mse_workspace_bytes(M, N) bytes. */
+int64_t itts_linear_fwd_mse_workspace_bytes(int64_t M, int N);
+int itts_linear_fwd_mse(const float* d_x, int64_t ldx, const float* d_w, const float* d_b,
+                        const float* d_target, int64_t ldt, const uint8_t* d_row_valid, double n_valid,
+                        float loss_weight, int64_t M, int N, int K, float* d_loss, float* d_dz,
+                        int64_t lddz, void* d_workspace, void* stream);
+
 /* dz = dy * act'(y)  (elementwise; act' expressed through the layer output y). */
 int itts_act_bwd(const float* d_dy, const float* d_y, float* d_dz, int64_t n_elem, int act,
                  void* stream);

@@ -231,3 +231,29 @@ def test_named_loss_other_types_and_reductions(gpu, type_, reduction, masked, ba
     assert out.shape == ref.shape
     assert (out.detach().cpu().double() - ref.detach()).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
     assert (pg.grad.cpu().double() - pr.grad).abs().max() < 1e-5 * max(1.0, float(pr.grad.abs().max()))
+
+
+def test_output_layer_fused_with_the_masked_mse_equals_the_two_kernels(gpu):
+    """itts_linear_fwd_mse (the output layer's GEMM epilogue forms the loss and its gradient; the
+    layer's output is never stored) against itts_linear_fwd + itts_masked_mse, on ragged sizes incl.
+    an output width that is no multiple of 4 and masked rows."""
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for M, K, N in [(1000, 512, 187), (129, 64, 4), (4097, 128, 62), (77, 32, 187)]:
+        x = torch.randn(M, K, generator=g).to(gpu)
+        w = (torch.randn(N, K, generator=g) * 0.1).to(gpu)
+        b = torch.randn(N, generator=g).to(gpu)
+        pitch = (N + 3) // 4 * 4
+        target = torch.randn(M, N, generator=g).to(gpu)
+        valid = (torch.rand(M, generator=g) > 0.2).to(torch.uint8).to(gpu)
+        n_valid = float(valid.sum().item())
+        y = ops.linear_fwd(x, w, b, ops.ACT_NONE)
+        loss_ref, dz_ref = ops.masked_mse(y, target, valid, n_valid)
+        dz = torch.zeros(M, pitch, device=gpu)[:, :N]
+        loss, dz = ops.linear_fwd_mse(x, w, b, target, valid, n_valid, grad=dz)
+        assert abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+        assert torch.equal(dz, dz_ref)          # same float arithmetic per element
+        # and against torch in fp64
+        yd = x.double().cpu() @ w.double().cpu().T + b.double().cpu()
+        d = (yd - target.double().cpu()) * valid.cpu().double()[:, None]
+        assert abs(float(loss) - float((d ** 2).sum() / (n_valid * N))) < 1e-5 * float(loss_ref)
