@@ -55,6 +55,10 @@ struct GemmArgs {
   const uint8_t* row_valid;   // [M]
   float gscale;               // 2 * loss_weight / (n_valid * D)
   double* loss_partial;       // [grid] sums of squared masked differences, one per workgroup
+  // col-form A (weight gradients): column sums of A over this launch's K chunk, i.e. the bias
+  // gradient, as a by-product of the workgroups of the first column tile
+  float* bias_part;           // [slab][M] or NULL
+  int64_t bias_part_stride;
 };
 
 // tanh in ~12 VALU ops (ocml tanhf costs ~40 and showed up as ~15 % of the fused-epilogue GEMMs):
@@ -196,6 +200,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool do_bias = !A_ROW && g.bias_part != nullptr && tn == 0;
+  float bsum = 0.f;
   float4 ra[4], rb[BNT / 32];
   if (nkt > 0) {
     load_tile<A_ROW, VEC_A, BM>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
@@ -231,6 +237,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (!A_ROW && do_bias) {   // column sums of the A tile ([k][out], pitch BM + 4) while it is resident
+      const int o = threadIdx.x & 127, kh = threadIdx.x >> 7;
+      const float* ct = cA + (kh * (BK / 2)) * (BM + 4) + o;
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) bsum += ct[kk * (BM + 4)];
+    }
     if (STAGES == 1) __syncthreads();   // everyone has read the current tile
     if (more) {
       constexpr int nb = STAGES == 1 ? 0 : 1;
@@ -240,6 +252,13 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
     __syncthreads();
   }
 
+  if (!A_ROW && do_bias) {   // the two k halves meet in LDS (all tile reads are behind the loop's last barrier)
+    const int o = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    if (kh == 1) lds[o] = bsum;
+    __syncthreads();
+    if (kh == 0 && m0 + o < g.M)
+      g.bias_part[(int64_t)blockIdx.z * g.bias_part_stride + m0 + o] = bsum + lds[o];
+  }
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (int64_t)blockIdx.z * g.slab_stride;
   const int cl = lane & 31, rh = lane >> 5;
@@ -811,7 +830,7 @@ extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const floa
 extern "C" int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
   const int s = choose_splitk(M, N, K);
-  return (int64_t)s * N * K * 4 + (int64_t)kColsumSlices * N * 4 + 256;
+  return (int64_t)s * N * K * 4 + (int64_t)kColsumSlices * N * 4 + 8192;
 }
 
 extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x,
@@ -839,9 +858,26 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
   g.M = N; g.N = K; g.K = M; g.kchunk = kchunk; g.slab_stride = (int64_t)N * K;
   g.vecA = (lddz % 4 == 0) && aligned16(d_dz);
   g.vecB = (ldx % 4 == 0) && aligned16(d_x);
+  static const int fuse_db = [] { const char* e = getenv("ITTS_GEMM_FUSE_DB"); return e ? atoi(e) : 1; }();
+  const int64_t n = (int64_t)N * K;
+  if (d_db && fuse_db) {
+    // The bias gradient (column sums of dz) comes out of the same launch: the workgroups of the
+    // first column tile add up their resident dz tiles.  When db follows dw in memory (the flat
+    // gradient arenas) and both lengths are multiples of 4, one reduction serves both.
+    const bool merged = d_db == d_dw + n && N % 4 == 0 && n % 4 == 0;
+    const int64_t stride = merged ? n + N : n;
+    g.slab_stride = stride;
+    g.bias_part = merged ? slabs + n : slabs + (int64_t)S_eff * n;
+    g.bias_part_stride = merged ? stride : N;
+    int rc = launch_gemm<false, false, EPI_STORE>(g, S_eff, s);
+    if (rc) return rc;
+    if (merged) return launch_reduce_slabs(slabs, S_eff, n + N, d_dw, accumulate, s);
+    rc = launch_reduce_slabs(slabs, S_eff, n, d_dw, accumulate, s);
+    if (rc) return rc;
+    return launch_reduce_slabs(g.bias_part, S_eff, (int64_t)N, d_db, accumulate, s);
+  }
   int rc = launch_gemm<false, false, EPI_STORE>(g, S_eff, s);
   if (rc) return rc;
-  const int64_t n = (int64_t)N * K;
   rc = launch_reduce_slabs(slabs, S_eff, n, d_dw, accumulate, s);
   if (rc) return rc;
   if (d_db) {
