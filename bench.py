@@ -233,14 +233,26 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     stream = torch.cuda.current_stream()
     res = {}
 
+    overlap = os.environ.get("ITTS_BENCH_D4C_SIDE", "1") != "0"
+    side = world._side_stream(dev)
+
     def analysis():
         f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop), f_off, fs, hop)
-        # D4C first, like world.analyse_batch: the mcep Newton loop reads trip counts back from
-        # the device, so whatever is queued behind it starts late
-        _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop, n_fft, want_ap=False,
-                         want_bap=torch.float32)
+        # as world.analyse_batch / extract_cmp_batch do it (the path gen_data takes): D4C on the
+        # side stream beside CheapTrick + mcep -- they only share their inputs, and the mcep Newton
+        # loop reads trip counts back from the device between launches
+        if overlap:
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop, n_fft, want_ap=False,
+                                 want_bap=torch.float32)
+        else:
+            _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop, n_fft, want_ap=False,
+                             want_bap=torch.float32)
         _, mc, it = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop, n_fft, want_sp=False,
                                         order=order, alpha=alpha, want_iters=True)
+        if overlap:
+            stream.wait_stream(side)
         return f0, mc, bap, it
 
     def over_ranks(value, op):
