@@ -257,3 +257,26 @@ def test_output_layer_fused_with_the_masked_mse_equals_the_two_kernels(gpu):
         yd = x.double().cpu() @ w.double().cpu().T + b.double().cpu()
         d = (yd - target.double().cpu()) * valid.cpu().double()[:, None]
         assert abs(float(loss) - float((d ** 2).sum() / (n_valid * N))) < 1e-5 * float(loss_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 512, 428), (700, 64, 96), (300, 188, 64)])
+def test_weight_and_bias_gradients_in_one_flat_arena(gpu, M, N, K):
+    """db right behind dw in one buffer (the layout of the flat gradient arenas): the bias sums come
+    out of the weight-gradient GEMM and one slab reduction writes both; also on top of what the
+    arena already holds (accumulate)."""
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    dz = torch.randn(M, N, generator=g)
+    x = torch.rand(M, K, generator=g)
+    rw = dz.double().t() @ x.double()
+    rb = dz.double().sum(0)
+    flat = torch.zeros(N * K + N, device=gpu)
+    dw, db = flat[:N * K].view(N, K), flat[N * K:]
+    ops.linear_bwd_weight(dz.to(gpu), x.to(gpu), dw=dw, db=db)
+    assert _rel(dw.cpu().double(), rw) < 3e-6 and _rel(db.cpu().double(), rb) < 3e-6
+    first = flat.clone()
+    ops.linear_bwd_weight(dz.to(gpu), x.to(gpu), dw=dw, db=db, accumulate=True)
+    assert _rel(dw.cpu().double(), 2 * rw) < 3e-6 and _rel(db.cpu().double(), 2 * rb) < 3e-6
+    # the separate-buffer form gives the same bits
+    dw2, db2 = ops.linear_bwd_weight(dz.to(gpu), x.to(gpu))
+    assert torch.equal(dw2.reshape(-1), first[:N * K]) and torch.equal(db2, first[N * K:])
