@@ -92,7 +92,7 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
 int64_t* pinned_slot(DeviceContext* ctx);
 
 // Small stream-ordered device copy of a host int64 array (offsets). Caller frees with
-// hipFreeAsync on the same stream.
+// scratch_free on the same stream.
 int upload_i64(const int64_t* h, int n, int64_t** d_out, hipStream_t s);
 
 }  // namespace itts

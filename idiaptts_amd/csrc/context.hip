@@ -12,7 +12,6 @@
 #include "world_dev.h"
 
 namespace itts {
-void keep_scratch_pool(int device);
 
 static std::mutex g_ctx_mutex;
 static std::map<int, DeviceContext*> g_contexts;
@@ -37,29 +36,9 @@ static int create_context(DeviceContext* ctx) {
     ITTS_HIP_CHECK(hipMemcpy(ctx->tw_compact[L], c.data(), m * sizeof(double2), hipMemcpyHostToDevice));
   }
   ITTS_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, 64 * sizeof(int64_t), hipHostMallocDefault));
-  keep_scratch_pool(ctx->device);
   return ITTS_OK;
 }
 
-// Scratch the stream-ordered pool keeps between calls (invisible to PyTorch's allocator):
-// ITTS_POOL_KEEP_GB, default 64 of the 288 GB -- a 256-utterance analysis batch takes ~20 GB of
-// scratch, and a pool that hands it back at every synchronisation makes each call 5x slower
-// (measured: 332 ms instead of 69 ms with 8 GB).  itts_release_scratch() returns it on demand.
-// Asserted again at every get_context(): the threshold is a property of the device's default pool,
-// which other libraries in the process may touch, and one bench run (of many) showed exactly the
-// 5x signature on the two sections with the largest scratch.
-void keep_scratch_pool(int device) {
-  static const uint64_t keep = [] {
-    uint64_t keep_gb = 64;
-    if (const char* e = getenv("ITTS_POOL_KEEP_GB")) keep_gb = strtoull(e, nullptr, 10);
-    return keep_gb << 30;
-  }();
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-    uint64_t v = keep;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v);
-  }
-}
 
 }  // namespace itts
 
@@ -195,15 +174,12 @@ extern "C" int itts_scratch_pool_stats(int64_t* reserved, int64_t* used, int64_t
 extern "C" int itts_release_scratch(void) {
   int dev = -1;
   ITTS_HIP_CHECK(hipGetDevice(&dev));
-  hipMemPool_t pool;
-  ITTS_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
   ITTS_HIP_CHECK(hipDeviceSynchronize());
   {
     std::lock_guard<std::mutex> lock(itts::g_scratch_mutex);
     auto it = itts::g_scratch.find(dev);
     if (it != itts::g_scratch.end()) itts::scratch_evict(it->second, 0);
   }
-  ITTS_HIP_CHECK(hipMemPoolTrimTo(pool, 0));
   return ITTS_OK;
 }
 
@@ -222,10 +198,7 @@ DeviceContext* get_context() {
   }
   std::lock_guard<std::mutex> lock(g_ctx_mutex);
   auto it = g_contexts.find(dev);
-  if (it != g_contexts.end()) {
-    keep_scratch_pool(dev);
-    return it->second;
-  }
+  if (it != g_contexts.end()) return it->second;
   DeviceContext* ctx = new DeviceContext();
   ctx->device = dev;
   if (create_context(ctx) != ITTS_OK) {
