@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_ring.h"
 
 namespace itts {
 
@@ -28,7 +29,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;  // BN: widest tile (TN = 2)
 constexpr int LD_ROW = BK + 4;    // row-form tile [128][36]
-constexpr int LD_COL = BM + 4;    // col-form tile [32][132]
 constexpr int TILE_FLOATS = 128 * LD_ROW;  // 4608 >= 32*132 = 4224
 
 enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_DACT = 2, EPI_MSE = 3 };
@@ -405,9 +405,70 @@ static double tile_efficiency(int64_t M, int N, int splitk, int tn, double loop_
   return loop_eff * useful * (double)tiles / (double)(rounds * 512);
 }
 
+static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- the LDS-DMA ring kernel (gemm_ring.h) -----------------------------------------------------
+// Takes every call whose operands allow 16-byte row accesses (the trainer's buffers all do); the
+// register-staged kernel above stays the general path (odd pitches, unaligned bases) and the A/B
+// checker (ITTS_GEMM_RING=0).
+static int ring_enabled() {
+  static const int on = [] { const char* e = getenv("ITTS_GEMM_RING"); return e ? atoi(e) : 1; }();
+  return on;
+}
+constexpr int kRingGrid = 512;   // persistent workgroups: 2 per CU
+
+template <bool A_ROW, bool B_ROW>
+static bool ring_ok(const GemmArgs& g, int splitk, int epi) {
+  if (!ring_enabled() || !g.vecA || !g.vecB) return false;
+  if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || g.slab_stride % 4 || !aligned16(g.C)) return false;
+  if ((epi == EPI_DACT || epi == EPI_MSE) && (g.ldaux % 4 || !aligned16(g.aux))) return false;
+  const int64_t lim = (int64_t)1 << 30;   // 32-bit byte offsets inside the buffer descriptors
+  if (g.M >= lim || g.K >= lim || g.lda >= lim / 256 || g.ldb >= lim / 256 || g.ldc >= lim / 256 ||
+      g.ldaux >= lim / 256)
+    return false;
+  if (!A_ROW && (g.kchunk + 32) * g.lda >= lim) return false;
+  if (!B_ROW && (g.kchunk + 32) * g.ldb >= lim) return false;
+  if (splitk > 1 && g.kchunk % 32) return false;
+  return true;
+}
+
+template <bool A_ROW, bool B_ROW, int EPI, int WM>
+static int launch_ring_wm(const GemmArgs& g, int splitk, hipStream_t s) {
+  constexpr int BMT = 64 * WM, BNT = 32 * (4 / WM);
+  ring::Args r{};
+  r.A = g.A; r.B = g.B; r.C = g.C; r.bias = g.bias; r.aux = g.aux;
+  r.row_valid = g.row_valid; r.loss_partial = g.loss_partial; r.bias_part = g.bias_part;
+  r.slab_stride = g.slab_stride; r.bias_part_stride = g.bias_part_stride;
+  r.lda = (int)g.lda; r.ldb = (int)g.ldb; r.ldc = (int)g.ldc; r.ldaux = (int)g.ldaux;
+  r.M = (int)g.M; r.N = g.N; r.K = (int)g.K; r.kchunk = (int)g.kchunk; r.splitk = splitk;
+  r.tiles_m = (int)((g.M + BMT - 1) / BMT);
+  r.tiles_n = (g.N + BNT - 1) / BNT;
+  r.act = g.act; r.gscale = g.gscale;
+  const int64_t ntiles = (int64_t)r.tiles_m * r.tiles_n * splitk;
+  ITTS_REQUIRE(ntiles < ((int64_t)1 << 31), "too many tiles");
+  const int grid = (int)std::min<int64_t>(kRingGrid, (ntiles + 7) / 8 * 8);
+  hipLaunchKernelGGL((ring::gemm_ring_kernel<A_ROW, B_ROW, EPI, WM>), dim3(grid), dim3(ring::THREADS), 0, s, r);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+// tile shape of the ring kernel for an [M x N] output: 128 x 64 or 64 x 128, whichever wastes less
+static int ring_wm(int64_t M, int N) {
+  const double w2 = (double)(((M + 127) / 128) * 128) * (double)(((N + 63) / 64) * 64);
+  const double w1 = (double)(((M + 63) / 64) * 64) * (double)(((N + 127) / 128) * 128);
+  return w1 < w2 ? 1 : 2;
+}
+
+template <bool A_ROW, bool B_ROW, int EPI>
+static int launch_ring(const GemmArgs& g, int splitk, hipStream_t s) {
+  if (ring_wm(g.M, g.N) == 1) return launch_ring_wm<A_ROW, B_ROW, EPI, 1>(g, splitk, s);
+  return launch_ring_wm<A_ROW, B_ROW, EPI, 2>(g, splitk, s);
+}
+
 template <bool A_ROW, bool B_ROW, int EPI>
 static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return ITTS_OK;
+  if (ring_ok<A_ROW, B_ROW>(g, splitk, EPI)) return launch_ring<A_ROW, B_ROW, EPI>(g, splitk, s);
   if (A_ROW) return launch_gemm_tn<A_ROW, B_ROW, EPI, 1, 1>(g, splitk, s);
   const double e2 = tile_efficiency(g.M, g.N, splitk, 2, 1.0);
   const double e1 = tile_efficiency(g.M, g.N, splitk, 1, 0.90);
@@ -415,7 +476,6 @@ static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
   return launch_gemm_tn<A_ROW, B_ROW, EPI, 2, 2>(g, splitk, s);
 }
 
-static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- split-K slab reduction (deterministic order) -------------------------------------------
 // out[i] = sum_z slabs[z][i].  Memory bound (S x n floats in, n out); a workgroup owns 64 float4
@@ -713,6 +773,17 @@ __global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__
 
 constexpr int kColsumSlices = 256;  // row slices of the bias-gradient column sums
 
+// split-K of a weight-gradient GEMM on the ring kernel: as many slabs as keep the 512 persistent
+// workgroups busy, chunks of whole K-steps
+static int choose_splitk_ring(int64_t M, int N, int K) {
+  const int wm = ring_wm(N, K);
+  const int bmt = 64 * wm, bnt = 32 * (4 / wm);
+  const int64_t tiles = (int64_t)((N + bmt - 1) / bmt) * ((K + bnt - 1) / bnt);
+  int64_t s = std::max<int64_t>(1, kRingGrid / std::max<int64_t>(tiles, 1));
+  s = std::min<int64_t>(s, std::max<int64_t>(1, (M + 255) / 256));
+  return (int)std::min<int64_t>(s, 128);
+}
+
 static int choose_splitk(int64_t M, int N, int K) {
   const int64_t tiles = (int64_t)((N + BM - 1) / BM) * ((K + BN - 1) / BN);
   int64_t s = std::max<int64_t>(1, 512 / std::max<int64_t>(tiles, 1));
@@ -747,7 +818,7 @@ extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, 
 
 extern "C" int64_t itts_linear_fwd_mse_workspace_bytes(int64_t M, int N) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
-  return std::max<int64_t>(tiles, 1) * 8;
+  return std::max<int64_t>(tiles, kRingGrid) * 8;   // one partial sum per tile, or per persistent workgroup
 }
 
 // Forward of the output layer fused with NamedLoss(MSELoss, 'mean_per_frame'): d_loss [1] and
@@ -780,8 +851,14 @@ extern "C" int itts_linear_fwd_mse(const float* d_x, int64_t ldx, const float* d
   const double scale = (double)loss_weight / (n_valid * (double)N);
   g.gscale = (float)(2.0 * scale);
   g.loss_partial = reinterpret_cast<double*>(d_workspace);
-  const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
-  int rc = launch_gemm_tn<true, true, EPI_MSE, 1, 1>(g, 1, s);
+  int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
+  int rc;
+  if (ring_ok<true, true>(g, 1, EPI_MSE) && (ldt % 4 == 0) && aligned16(d_target)) {
+    tiles = std::min<int64_t>(kRingGrid, (tiles + 7) / 8 * 8);   // partial sums per persistent workgroup
+    rc = launch_ring_wm<true, true, EPI_MSE, 2>(g, 1, s);
+  } else {
+    rc = launch_gemm_tn<true, true, EPI_MSE, 1, 1>(g, 1, s);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
                      reinterpret_cast<const double*>(d_workspace), (int)tiles, scale, d_loss);
@@ -829,8 +906,8 @@ extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const floa
 
 extern "C" int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
-  const int s = choose_splitk(M, N, K);
-  return (int64_t)s * N * K * 4 + (int64_t)kColsumSlices * N * 4 + 8192;
+  const int s = std::max(choose_splitk(M, N, K), choose_splitk_ring(M, N, K));
+  return (int64_t)s * ((int64_t)N * K + N) * 4 + (int64_t)kColsumSlices * N * 4 + 8192;
 }
 
 extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x,
@@ -846,12 +923,13 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
     }
     return ITTS_OK;
   }
-  const int S = choose_splitk(M, N, K);
+  const bool vec_ok = (lddz % 4 == 0) && aligned16(d_dz) && (ldx % 4 == 0) && aligned16(d_x) && (K % 4 == 0);
+  const int S = (ring_enabled() && vec_ok) ? choose_splitk_ring(M, N, K) : choose_splitk(M, N, K);
   int64_t kchunk = (M + S - 1) / S;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   const int S_eff = (int)((M + kchunk - 1) / kchunk);
   float* slabs = reinterpret_cast<float*>(d_workspace);
-  float* bpart = slabs + (int64_t)S * N * K;
+  float* bpart = slabs + (int64_t)S * ((int64_t)N * K + N);
   // dw[N,K] = dz^T x: A = dz as col form [k=M][out=N]; B = x as col form [k=M][out=K]
   GemmArgs g{};
   g.A = d_dz; g.lda = lddz; g.B = d_x; g.ldb = ldx; g.C = slabs; g.ldc = K;
