@@ -46,7 +46,10 @@ typedef __attribute__((address_space(3))) char* lds_char_p;
 
 constexpr int RBK = 32;                       // reduction elements per K-step
 constexpr int SLOT_BYTES = 192 * 128;         // A tile + B tile of one K-step: (128 + 64) x 128 B
-constexpr int NSLOT = 3;
+#ifndef RING_NSLOT
+#define RING_NSLOT 3
+#endif
+constexpr int NSLOT = RING_NSLOT;
 #ifndef RING_PRIO
 #define RING_PRIO 0
 #endif
@@ -96,7 +99,7 @@ __device__ __forceinline__ float fast_tanhf(float z) {
   const float poly = z * (1.f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f +
                                                                               z2 * 0.021869488f))));
   const float e = __expf(2.f * a);
-  const float big = copysignf(1.f - __fdividef(2.f, e + 1.f), z);
+  const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), z);
   return a < 0.25f ? poly : big;
 }
 
@@ -308,9 +311,7 @@ __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t l
   int ahead = 0;
   if (pvalid) {
     open();
-    produce();
-    ++ahead;
-    if (pvalid) { produce(); ++ahead; }
+    for (int i = 0; i < NSLOT - 1 && pvalid; ++i) { produce(); ++ahead; }
   }
   int ct = w.first, kt = 0, cslot = 0;
   bool have = ct < w.end;
@@ -318,7 +319,10 @@ __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t l
   if (have) c = decode_tile(g, ct, BMT, BNT);
   while (have) {
     // the pieces of this step have landed (those of the next one stay in flight)
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    if (ahead >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PIECES) : "memory");
+    else if (ahead == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES) : "memory");
+    else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     step_barrier();
     --ahead;
@@ -371,9 +375,24 @@ __device__ __forceinline__ float4 quad_transpose(float a0, float a1, float a2, f
 
 // Epilogue of one finished tile: a wave's two 32 x 32 accumulator blocks leave as float4 row
 // segments (8 store instructions of whole 128-byte lines).
+// bias of the four columns a lane stores (columns >= N: 0)
+template <int EPI>
+__device__ __forceinline__ float4 load_bias(const Args& g, int n0, int wn, int lane) {
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((EPI == EPI_BIAS_ACT || EPI == EPI_MSE) && g.bias) {
+    const int col = n0 + wn * 32 + 4 * ((lane & 31) >> 2);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.bias, (uint32_t)(g.N * 4));
+    bv.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4, 0, 0));
+    bv.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4 + 4, 0, 0));
+    bv.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4 + 8, 0, 0));
+    bv.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4 + 12, 0, 0));
+  }
+  return bv;
+}
+
 template <int EPI, int ACT>
 __device__ __forceinline__ void epilogue(const Args& g, const Tile& pc, const f32x16& acc0, const f32x16& acc1,
-                                         int wm, int wn, int lane, double& lsum) {
+                                         int wm, int wn, int lane, const float4& bv, double& lsum) {
   const int quad = (lane & 31) >> 2, j = lane & 3, h = lane >> 5;
   const int col = pc.n0 + wn * 32 + 4 * quad;
   const int rloc = wm * 64 + 4 * h + j;          // + 32 i + 8 rg
@@ -389,14 +408,6 @@ __device__ __forceinline__ void epilogue(const Args& g, const Tile& pc, const f3
   if (EPI == EPI_DACT || EPI == EPI_MSE) {
     rx = make_rsrc(g.aux + (int64_t)pc.m0 * g.ldaux, (uint32_t)((int64_t)rows_valid * g.ldaux * 4));
     xofs = col < g.ldaux ? (uint32_t)((rloc * g.ldaux + col) * 4) : 0xfffffff0u;
-  }
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((EPI == EPI_BIAS_ACT || EPI == EPI_MSE) && g.bias) {
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.bias, (uint32_t)(g.N * 4));   // col >= N -> 0
-    bv.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4, 0, 0));
-    bv.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4 + 4, 0, 0));
-    bv.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4 + 8, 0, 0));
-    bv.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, col * 4 + 12, 0, 0));
   }
   const bool k0 = col < g.N, k1 = col + 1 < g.N, k2 = col + 2 < g.N, k3 = col + 3 < g.N;
 #pragma unroll
@@ -473,7 +484,15 @@ __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid,
     // previous one
     step_barrier();
 #if RING_PRIO
-    if (kt == 0) __builtin_amdgcn_s_setprio((((int)blockIdx.x >> 3) >= ((int)gridDim.x >> 4)) ^ (ct & 1) ? 1 : 0);
+    if (kt == 0) {
+#if RING_PRIO == 1
+      const bool up = (((int)blockIdx.x >> 3) >= ((int)gridDim.x >> 4)) ^ ((ct / w.stride) & 1);
+#else
+      const bool up = ((int)blockIdx.x >> 3) >= ((int)gridDim.x >> 4);
+#endif
+      if (up) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
 #endif
     if (pending) {
       if (DO_BIAS && g.bias_part != nullptr && pc.tn == 0) {
@@ -490,9 +509,12 @@ __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid,
         float t = 0.f;
         for (int r = 0; r < 16; ++r) t += acc0[r] + acc1[r];
         if (t == 1.2345f) g.C[0] = t;
-      } else if (EPI == EPI_STORE || g.act == ACT_NONE) epilogue<EPI, ACT_NONE>(g, pc, acc0, acc1, wm, wn, lane, lsum);
-      else if (g.act == ACT_TANH) epilogue<EPI, ACT_TANH>(g, pc, acc0, acc1, wm, wn, lane, lsum);
-      else epilogue<EPI, ACT_RELU>(g, pc, acc0, acc1, wm, wn, lane, lsum);
+      } else {
+        const float4 bv = load_bias<EPI>(g, pc.n0, wn, lane);
+        if (EPI == EPI_STORE || g.act == ACT_NONE) epilogue<EPI, ACT_NONE>(g, pc, acc0, acc1, wm, wn, lane, bv, lsum);
+        else if (g.act == ACT_TANH) epilogue<EPI, ACT_TANH>(g, pc, acc0, acc1, wm, wn, lane, bv, lsum);
+        else epilogue<EPI, ACT_RELU>(g, pc, acc0, acc1, wm, wn, lane, bv, lsum);
+      }
       pending = false;
     }
     if (!have) break;   // only the last epilogue was left
@@ -591,6 +613,304 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_
     g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
     g.stamps[4 * blockIdx.x + 2] = t0r;
     g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)) ;   // HW_ID
+  }
+}
+
+// ================================================================================================
+// 128 x 128 tiles, one workgroup per CU: eight compute waves (2 x 4 blocks of 64 x 32, two waves
+// per SIMD) and four loader waves share a ring of four 32-KB slots.  A third less L2 -> LDS
+// traffic per FLOP than the 128 x 64 kernel, every wave of a CU ends with the last tile (no phase
+// in which half of the waves have run out of tiles), and the loaders run far enough ahead that
+// the slot of step s + 1 is complete at the barrier of step s: a compute wave fetches the first
+// fragments of the next step before that step's barrier and goes on issuing MFMAs right behind it.
+// For outputs whose width fills 128-column tiles (the 512-wide layers); the 128 x 64 / 64 x 128
+// kernel takes the rest.
+// ================================================================================================
+constexpr int T_SLOT_BYTES = 256 * 128;       // A tile + B tile of one K-step
+constexpr int T_NSLOT = 4;
+constexpr int T_RED_BYTES = 2 * 512 * 4;
+constexpr int T_LDS_BYTES = T_NSLOT * T_SLOT_BYTES + T_RED_BYTES;
+constexpr int T_PIECES = 8;                   // per loader wave and K-step
+constexpr int T_THREADS = 768;                // 8 compute waves + 4 loader waves
+
+template <bool A_ROW, bool B_ROW>
+__device__ __forceinline__ void loader_wave128(const Args& g, char* lds, uint32_t lds0, int lane, bool mse, int part) {
+  constexpr int BT = 128;
+  constexpr int A_BYTES = BT * 128;
+  const Walk w = my_tiles(g);
+  uint32_t va0, va1, vb0, vb1;
+  lane_offsets<A_ROW, BT>(g.lda, lane, va0, va1);
+  lane_offsets<B_ROW, BT>(g.ldb, lane, vb0, vb1);
+  Stream<A_ROW, BT> sa;
+  Stream<B_ROW, BT> sb;
+
+  int pt = w.first, pk = 0, pnk = 0;
+  uint32_t pdst = lds0;
+  bool pvalid = pt < w.end;
+  auto open = [&]() {
+    const Tile c = decode_tile(g, pt, BT, BT);
+    sa.open(g.A, g.lda, c.m0, g.M, c);
+    sb.open(g.B, g.ldb, c.n0, g.N, c);
+    pnk = c.nk;
+    pk = 0;
+  };
+  auto produce = [&]() {
+    if (!(RING_DBG & 1)) {
+      sa.issue(va0, va1, g.lda, pdst, part);
+      sb.issue(vb0, vb1, g.ldb, pdst + A_BYTES, part);
+    }
+    pdst = pdst == lds0 + (T_NSLOT - 1) * T_SLOT_BYTES ? lds0 : pdst + T_SLOT_BYTES;
+    sa.soff += sa.step;
+    sb.soff += sb.step;
+    if (++pk == pnk) {
+      pt += w.stride;
+      pvalid = pt < w.end;
+      if (pvalid) open();
+    }
+  };
+  int ahead = 0;
+  if (pvalid) {
+    open();
+    for (int i = 0; i < T_NSLOT - 1 && pvalid; ++i) { produce(); ++ahead; }
+  }
+  // consumer cursor; `zt/zk/zslot` run one step ahead of it: the step whose tail (if any) has to be
+  // zeroed before the coming barrier
+  int ct = w.first, kt = 0;
+  bool have = ct < w.end;
+  Tile c{};
+  if (have) c = decode_tile(g, ct, BT, BT);
+  int zt = ct, zk = 0, zslot = 0;
+  bool zhave = have;
+  Tile zc = c;
+  auto zero_next = [&]() {   // zero the tail of step (zt, zk) if it is a partial last step, then advance
+    if (!zhave) return;
+    if ((A_ROW || B_ROW) && zk == zc.nk - 1 && (zc.klen & (RBK - 1)) != 0) {
+      // each loader wave clears the rows it brought in itself (its own vmcnt wait covers them)
+      char* slot = lds + zslot * T_SLOT_BYTES;
+      const int krem = zc.klen & (RBK - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        const int row = 32 * part + (idx >> 3), ch = idx & 7;
+        const int lim = krem - 4 * ch;   // components j < lim stay
+        if (lim < 4) {
+          const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+          if (A_ROW) {
+            float4* q = reinterpret_cast<float4*>(slot + off);
+            float4 v = *q;
+            v.x = lim > 0 ? v.x : 0.f; v.y = lim > 1 ? v.y : 0.f; v.z = lim > 2 ? v.z : 0.f; v.w = 0.f;
+            *q = v;
+          }
+          if (B_ROW) {
+            float4* q = reinterpret_cast<float4*>(slot + A_BYTES + off);
+            float4 v = *q;
+            v.x = lim > 0 ? v.x : 0.f; v.y = lim > 1 ? v.y : 0.f; v.z = lim > 2 ? v.z : 0.f; v.w = 0.f;
+            *q = v;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    zslot = zslot == T_NSLOT - 1 ? 0 : zslot + 1;
+    if (++zk == zc.nk) {
+      zk = 0;
+      zt += w.stride;
+      zhave = zt < w.end;
+      if (zhave) zc = decode_tile(g, zt, BT, BT);
+    }
+  };
+  bool first = true;
+  uint64_t wait_dma = 0, wait_bar = 0;
+  while (have) {
+    // steps s and s + 1 have landed (the third one in flight stays in flight)
+    uint64_t ta = 0;
+    if (g.stamps) ta = __builtin_amdgcn_s_memtime();
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (first) { zero_next(); first = false; }   // step 0
+    zero_next();                                 // step s + 1
+    uint64_t tb = 0;
+    if (g.stamps) { tb = __builtin_amdgcn_s_memtime(); wait_dma += tb - ta; }
+    step_barrier();
+    if (g.stamps) wait_bar += __builtin_amdgcn_s_memtime() - tb;
+    --ahead;
+    if (pvalid) { produce(); ++ahead; }
+    if (++kt == c.nk) {
+      kt = 0;
+      ct += w.stride;
+      have = ct < w.end;
+      if (have) c = decode_tile(g, ct, BT, BT);
+    }
+  }
+  // barriers beyond the K-steps: the entry of the last epilogue, EPI_MSE's reduction
+  if (w.first < w.end) step_barrier();
+  if (mse) step_barrier();
+  if (g.stamps && part == 0 && lane == 0) {
+    g.stamps[4 * (1024 + blockIdx.x)] = wait_dma;
+    g.stamps[4 * (1024 + blockIdx.x) + 1] = wait_bar;
+  }
+}
+
+template <bool A_ROW, bool B_ROW, int EPI>
+__device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int wid, int lane) {
+  constexpr int BT = 128;
+  constexpr int A_BYTES = BT * 128;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tid = wid * 64 + lane;   // 0 .. 511
+  const Walk w = my_tiles(g);
+  const uint32_t fa0 = frag_base<A_ROW, BT>(wm * 64, lane);
+  const uint32_t fa1 = frag_base<A_ROW, BT>(wm * 64 + 32, lane);
+  const uint32_t fb0 = frag_base<B_ROW, BT>(wn * 32, lane);
+  float* red = reinterpret_cast<float*>(lds + T_NSLOT * T_SLOT_BYTES);
+  constexpr bool DO_BIAS = !A_ROW && EPI == EPI_STORE;
+
+  double lsum = 0.0;
+  int cslot = 0, redbuf = 0;
+  bool pending = false;
+  Tile pc{};
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  float bsum = 0.f;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), pbv = bv;
+  uint64_t cwait = 0;
+
+  int ct = w.first;
+  bool have = ct < w.end;
+  Tile c{};
+  int kt = 0;
+  // F0: the fragments of k-group 0 of the coming step; fetched one step early (the loaders see to it
+  // that the slot of step s + 1 is complete at the barrier of step s)
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0;
+  auto finish_tile = [&]() {   // epilogue of tile pc (behind a barrier: `red` is complete)
+    if (DO_BIAS && g.bias_part != nullptr && pc.tn == 0) {
+      const float* rb = red + (redbuf ^ 1) * 512;
+      if (tid < BT && pc.m0 + tid < g.M)
+        g.bias_part[(int64_t)pc.z * g.bias_part_stride + pc.m0 + tid] = (rb[tid] + rb[tid + 128]) + (rb[tid + 256] + rb[tid + 384]);
+    }
+    if (RING_DBG & 8) {
+      float t = 0.f;
+      for (int r = 0; r < 16; ++r) t += acc0[r] + acc1[r];
+      if (t == 1.2345f) g.C[0] = t;
+    } else if (EPI == EPI_STORE || g.act == ACT_NONE) epilogue<EPI, ACT_NONE>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
+    else if (g.act == ACT_TANH) epilogue<EPI, ACT_TANH>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
+    else epilogue<EPI, ACT_RELU>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
+    pending = false;
+  };
+  if (have) {
+    c = decode_tile(g, ct, BT, BT);
+    bv = load_bias<EPI>(g, c.n0, wn, lane);
+    step_barrier();   // steps 0 and 1 are complete
+    if (!(RING_DBG & 16)) {
+      a0 = read_frag<A_ROW, BT>(lds, fa0, 0);
+      a1 = read_frag<A_ROW, BT>(lds, fa1, 0);
+      b0 = read_frag<B_ROW, BT>(lds + A_BYTES, fb0, 0);
+    }
+  }
+  while (have) {
+    if (pending) finish_tile();
+    const char* tA = lds + cslot * T_SLOT_BYTES;
+    const char* tB = tA + A_BYTES;
+    const int nslot = cslot == T_NSLOT - 1 ? 0 : cslot + 1;
+    const char* nA = lds + nslot * T_SLOT_BYTES;
+    const char* nB = nA + A_BYTES;
+    if (DO_BIAS && g.bias_part != nullptr && c.tn == 0) {
+      const float* ctile = reinterpret_cast<const float*>(tA) + (tid >> 7) * 8 * BT + (tid & 127);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) bsum += ctile[kk * BT];
+    }
+    float4 p0, p1, q0;   // the k-group in flight
+    // k-group 0 (fragments in a0 / a1 / b0, fetched during the previous step)
+    if (kt == 0) {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, zero, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, zero, 0, 0, 0);
+    } else {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc1, 0, 0, 0);
+    }
+    // fetch k-group 1 behind the first MFMAs (a wait in front of them would wait for these reads too)
+    if (!(RING_DBG & 16)) { p0 = read_frag<A_ROW, BT>(tA, fa0, 1); p1 = read_frag<A_ROW, BT>(tA, fa1, 1); q0 = read_frag<B_ROW, BT>(tB, fb0, 1); }
+    else { p0 = a0; p1 = a1; q0 = b0; asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(q0.x)); }
+#define ITTS_MFMA6(A0, A1, B0)                                                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.y, B0.y, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.y, B0.y, acc1, 0, 0, 0);      \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.z, B0.z, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.z, B0.z, acc1, 0, 0, 0);      \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.w, B0.w, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.w, B0.w, acc1, 0, 0, 0);
+#define ITTS_MFMA8(A0, A1, B0)                                                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B0.x, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B0.x, acc1, 0, 0, 0);      \
+    ITTS_MFMA6(A0, A1, B0)
+    ITTS_MFMA6(a0, a1, b0)
+    // k-group 1, fetch k-group 2
+    if (!(RING_DBG & 16)) { a0 = read_frag<A_ROW, BT>(tA, fa0, 2); a1 = read_frag<A_ROW, BT>(tA, fa1, 2); b0 = read_frag<B_ROW, BT>(tB, fb0, 2); }
+    ITTS_MFMA8(p0, p1, q0)
+    // k-group 2, fetch k-group 3
+    if (!(RING_DBG & 16)) { p0 = read_frag<A_ROW, BT>(tA, fa0, 3); p1 = read_frag<A_ROW, BT>(tA, fa1, 3); q0 = read_frag<B_ROW, BT>(tB, fb0, 3); }
+    ITTS_MFMA8(a0, a1, b0)
+    // k-group 3, fetch k-group 0 of the next step (behind the last step: an unused read of a valid address)
+    if (!(RING_DBG & 16)) { a0 = read_frag<A_ROW, BT>(nA, fa0, 0); a1 = read_frag<A_ROW, BT>(nA, fa1, 0); b0 = read_frag<B_ROW, BT>(nB, fb0, 0); }
+    ITTS_MFMA8(p0, p1, q0)
+#undef ITTS_MFMA8
+#undef ITTS_MFMA6
+    cslot = nslot;
+    if (++kt == c.nk) {
+      if (DO_BIAS && g.bias_part != nullptr && c.tn == 0) {
+        red[redbuf * 512 + tid] = bsum;   // read behind the next barrier
+        bsum = 0.f;
+        redbuf ^= 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      pending = true;
+      pc = c;
+      pbv = bv;
+      kt = 0;
+      ct += w.stride;
+      have = ct < w.end;
+      if (have) {
+        c = decode_tile(g, ct, BT, BT);
+        bv = load_bias<EPI>(g, c.n0, wn, lane);
+      }
+    }
+    // entry of the next step (or of the last epilogue): its slot and the one behind it are complete,
+    // everybody has left this step
+    uint64_t tb = 0;
+    if (g.stamps) tb = __builtin_amdgcn_s_memtime();
+    step_barrier();
+    if (g.stamps) cwait += __builtin_amdgcn_s_memtime() - tb;
+  }
+  if (pending) finish_tile();
+  if (g.stamps && lane == 0 && (wid == 0 || wid == 4)) g.stamps[4 * (1024 + blockIdx.x) + 2 + (wid >> 2)] = cwait;
+  if (EPI == EPI_MSE) {
+    double* redd = reinterpret_cast<double*>(red);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+    if (lane == 0) redd[wid] = lsum;
+    lds_barrier();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int i = 0; i < 8; ++i) t += redd[i];
+      g.loss_partial[blockIdx.x] = t;
+    }
+  }
+}
+
+template <bool A_ROW, bool B_ROW, int EPI>
+__global__ __launch_bounds__(T_THREADS, 3) void gemm_ring128_kernel(Args g) {
+  __shared__ __attribute__((aligned(1024))) char lds[T_LDS_BYTES];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_p)lds;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint64_t t0c = 0, t0r = 0;
+  if (g.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+  if (wid >= 8) loader_wave128<A_ROW, B_ROW>(g, lds, lds0, lane, EPI == EPI_MSE, wid - 8);
+  else compute_waves128<A_ROW, B_ROW, EPI>(g, lds, wid, lane);
+  if (g.stamps && threadIdx.x == 0) {
+    g.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+    g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    g.stamps[4 * blockIdx.x + 2] = t0r;
   }
 }
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ float fast_tanhf(float z) {
   const float poly = z * (1.f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f +
                                                                               z2 * 0.021869488f))));
   const float e = __expf(2.f * a);
-  const float big = copysignf(1.f - __fdividef(2.f, e + 1.f), z);
+  const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), z);
   return a < 0.25f ? poly : big;
 }
 
