@@ -445,8 +445,12 @@ __device__ __forceinline__ void epilogue(const Args& g, const Tile& pc, const f3
       o[1] = k1 ? v.y : 0.f;
       o[2] = k2 ? v.z : 0.f;
       o[3] = k3 ? v.w : 0.f;
+      // the whole offset in the VGPR: a 16-byte store with an SGPR offset may fetch its data registers
+      // after a following VALU write to them (seen as lost elements when the CU's memory queue was
+      // busy with the loaders' DMA)
+      const uint32_t vo = col < g.ldc ? cofs + (uint32_t)(rl * g.ldc * 4) : 0xfffffff0u;
       if (RING_DBG & 64) asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
-      else __builtin_amdgcn_raw_buffer_store_b128(o, rc, cofs, rl * g.ldc * 4, RING_STORE_AUX);
+      else __builtin_amdgcn_raw_buffer_store_b128(o, rc, vo, 0, RING_STORE_AUX);
     }
   }
 }
@@ -619,31 +623,53 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_
 // ================================================================================================
 // 128 x 128 tiles, one workgroup per CU: eight compute waves (2 x 4 blocks of 64 x 32, two waves
 // per SIMD) and four loader waves share a ring of four 32-KB slots.  A third less L2 -> LDS
-// traffic per FLOP than the 128 x 64 kernel, every wave of a CU ends with the last tile (no phase
-// in which half of the waves have run out of tiles), and the loaders run far enough ahead that
-// the slot of step s + 1 is complete at the barrier of step s: a compute wave fetches the first
-// fragments of the next step before that step's barrier and goes on issuing MFMAs right behind it.
+// traffic per FLOP than the 128 x 64 kernel, and every wave of a CU ends with the last tile (no
+// phase in which half of the waves have run out of tiles).
+//
+// No workgroup barrier inside the K loop.  Measured with barriers: two compute waves share a SIMD,
+// the older one is served first, so per step one of them sat ~800 cycles at the barrier while the
+// matrix pipe idled ~600 of every 4 700 cycles.  Instead the waves exchange progress counters in
+// LDS: loader l publishes "my pieces of steps < n have landed" (behind its counted vmcnt wait),
+// compute wave w publishes "I have read all of steps < n"; a loader refills a slot when all eight
+// compute waves have left it, a compute wave starts step s when all four loaders have published
+// step s + 1 (it fetches the first fragments of step s + 1 while it still multiplies step s).
+// Waves drift apart by up to the ring depth, which is what lets the two waves of a SIMD cover each
+// other's LDS latencies.  Spins are bounded: a protocol failure raises `abort`, everybody leaves,
+// the output is garbage but the launch ends.
 // For outputs whose width fills 128-column tiles (the 512-wide layers); the 128 x 64 / 64 x 128
 // kernel takes the rest.
 // ================================================================================================
 constexpr int T_SLOT_BYTES = 256 * 128;       // A tile + B tile of one K-step
 constexpr int T_NSLOT = 4;
-constexpr int T_RED_BYTES = 2 * 512 * 4;
-constexpr int T_LDS_BYTES = T_NSLOT * T_SLOT_BYTES + T_RED_BYTES;
+constexpr int T_CTRL_BYTES = 256;             // lprog[4] @0, cprog[8] @64, abort @128, loss partials @192
+constexpr int T_LDS_BYTES = T_NSLOT * T_SLOT_BYTES + T_CTRL_BYTES;
 constexpr int T_PIECES = 8;                   // per loader wave and K-step
 constexpr int T_THREADS = 768;                // 8 compute waves + 4 loader waves
+constexpr int T_SPIN_LIMIT = 1 << 22;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int lds_min4(const int* p) {
+  const i32x4 v = *reinterpret_cast<const volatile i32x4*>(p);   // re-read on every call
+  const int m = min(min(v[0], v[1]), min(v[2], v[3]));
+  return __builtin_amdgcn_readfirstlane(m);
+}
 
 template <bool A_ROW, bool B_ROW>
-__device__ __forceinline__ void loader_wave128(const Args& g, char* lds, uint32_t lds0, int lane, bool mse, int part) {
+__device__ __forceinline__ void loader_wave128(const Args& g, char* lds, uint32_t lds0, int lane, int part) {
   constexpr int BT = 128;
   constexpr int A_BYTES = BT * 128;
   const Walk w = my_tiles(g);
+  int* ctrl = reinterpret_cast<int*>(lds + T_NSLOT * T_SLOT_BYTES);
+  volatile int* lprog = ctrl;
+  const int* cprog = ctrl + 16;
+  volatile int* abortp = ctrl + 32;
   uint32_t va0, va1, vb0, vb1;
   lane_offsets<A_ROW, BT>(g.lda, lane, va0, va1);
   lane_offsets<B_ROW, BT>(g.ldb, lane, vb0, vb1);
   Stream<A_ROW, BT> sa;
   Stream<B_ROW, BT> sb;
 
+  // producer cursor
   int pt = w.first, pk = 0, pnk = 0;
   uint32_t pdst = lds0;
   bool pvalid = pt < w.end;
@@ -668,26 +694,52 @@ __device__ __forceinline__ void loader_wave128(const Args& g, char* lds, uint32_
       if (pvalid) open();
     }
   };
-  int ahead = 0;
-  if (pvalid) {
-    open();
-    for (int i = 0; i < T_NSLOT - 1 && pvalid; ++i) { produce(); ++ahead; }
-  }
-  // consumer cursor; `zt/zk/zslot` run one step ahead of it: the step whose tail (if any) has to be
-  // zeroed before the coming barrier
-  int ct = w.first, kt = 0;
-  bool have = ct < w.end;
-  Tile c{};
-  if (have) c = decode_tile(g, ct, BT, BT);
-  int zt = ct, zk = 0, zslot = 0;
-  bool zhave = have;
-  Tile zc = c;
-  auto zero_next = [&]() {   // zero the tail of step (zt, zk) if it is a partial last step, then advance
-    if (!zhave) return;
-    if ((A_ROW || B_ROW) && zk == zc.nk - 1 && (zc.klen & (RBK - 1)) != 0) {
-      // each loader wave clears the rows it brought in itself (its own vmcnt wait covers them)
-      char* slot = lds + zslot * T_SLOT_BYTES;
-      const int krem = zc.klen & (RBK - 1);
+  if (pvalid) open();
+  // publishing cursor: the oldest step in flight
+  int qt = w.first, qk = 0, qslot = 0;
+  bool qhave = qt < w.end;
+  Tile qc{};
+  if (qhave) qc = decode_tile(g, qt, BT, BT);
+
+  int issued = 0, landed = 0;   // step counts
+  int freed = 0;                // compute waves have left every step < freed
+  int spins = 0;
+  uint64_t w_slot = 0, w_dma = 0, tmark = 0, lat = 0, tq0 = 0, tq1 = 0, tq2 = 0, w_issue = 0;
+  while (qhave) {
+    if (g.stamps) tmark = __builtin_amdgcn_s_memtime();
+    // issue while a slot is free: step `issued` goes where step issued - 4 was
+    while (pvalid && issued - landed < 3) {
+      if (issued - freed >= T_NSLOT) {
+        freed = min(lds_min4(cprog), lds_min4(cprog + 4));
+        if (issued - freed >= T_NSLOT) break;
+      }
+      uint64_t tp = 0;
+      if (g.stamps) tp = __builtin_amdgcn_s_memtime();
+      produce();
+      if (g.stamps) { tq0 = tq1; tq1 = tq2; tq2 = __builtin_amdgcn_s_memtime(); w_issue += tq2 - tp; }
+      ++issued;
+    }
+    if (issued == landed) {   // every slot is still being read
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > T_SPIN_LIMIT || *abortp) { *abortp = 1; return; }
+      if (g.stamps) w_slot += __builtin_amdgcn_s_memtime() - tmark;
+      continue;
+    }
+    if (g.stamps) tmark = __builtin_amdgcn_s_memtime();
+    // the oldest step in flight has landed
+    const int behind = issued - landed - 1;
+    if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T_PIECES) : "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g.stamps) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      w_dma += now - tmark;
+      lat += now - (behind >= 2 ? tq0 : behind == 1 ? tq1 : tq2);   // issue -> seen landed, of the oldest step
+    }
+    if ((A_ROW || B_ROW) && qk == qc.nk - 1 && (qc.klen & (RBK - 1)) != 0) {
+      // partial last K-step of a row-form tile: clear the columns k >= K of the rows this wave brought in
+      char* slot = lds + qslot * T_SLOT_BYTES;
+      const int krem = qc.klen & (RBK - 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int idx = lane + 64 * i;
@@ -711,82 +763,79 @@ __device__ __forceinline__ void loader_wave128(const Args& g, char* lds, uint32_
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    zslot = zslot == T_NSLOT - 1 ? 0 : zslot + 1;
-    if (++zk == zc.nk) {
-      zk = 0;
-      zt += w.stride;
-      zhave = zt < w.end;
-      if (zhave) zc = decode_tile(g, zt, BT, BT);
-    }
-  };
-  bool first = true;
-  uint64_t wait_dma = 0, wait_bar = 0;
-  while (have) {
-    // steps s and s + 1 have landed (the third one in flight stays in flight)
-    uint64_t ta = 0;
-    if (g.stamps) ta = __builtin_amdgcn_s_memtime();
-    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (first) { zero_next(); first = false; }   // step 0
-    zero_next();                                 // step s + 1
-    uint64_t tb = 0;
-    if (g.stamps) { tb = __builtin_amdgcn_s_memtime(); wait_dma += tb - ta; }
-    step_barrier();
-    if (g.stamps) wait_bar += __builtin_amdgcn_s_memtime() - tb;
-    --ahead;
-    if (pvalid) { produce(); ++ahead; }
-    if (++kt == c.nk) {
-      kt = 0;
-      ct += w.stride;
-      have = ct < w.end;
-      if (have) c = decode_tile(g, ct, BT, BT);
+    ++landed;
+    if (lane == 0) lprog[part] = landed;
+    qslot = qslot == T_NSLOT - 1 ? 0 : qslot + 1;
+    if (++qk == qc.nk) {
+      qk = 0;
+      qt += w.stride;
+      qhave = qt < w.end;
+      if (qhave) qc = decode_tile(g, qt, BT, BT);
     }
   }
-  // barriers beyond the K-steps: the entry of the last epilogue, EPI_MSE's reduction
-  if (w.first < w.end) step_barrier();
-  if (mse) step_barrier();
   if (g.stamps && part == 0 && lane == 0) {
-    g.stamps[4 * (1024 + blockIdx.x)] = wait_dma;
-    g.stamps[4 * (1024 + blockIdx.x) + 1] = wait_bar;
+    g.stamps[4 * (1024 + blockIdx.x)] = w_dma;
+    g.stamps[4 * (1024 + blockIdx.x) + 1] = w_slot;
+    g.stamps[4 * (1536 + blockIdx.x)] = lat / (landed > 0 ? landed : 1);
+    g.stamps[4 * (1536 + blockIdx.x) + 1] = w_issue / (landed > 0 ? landed : 1);
   }
 }
 
 template <bool A_ROW, bool B_ROW, int EPI>
-__device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int wid, int lane) {
+__device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int wid, int lane, double& lsum) {
   constexpr int BT = 128;
   constexpr int A_BYTES = BT * 128;
   const int wm = wid >> 2, wn = wid & 3;
-  const int tid = wid * 64 + lane;   // 0 .. 511
   const Walk w = my_tiles(g);
+  int* ctrl = reinterpret_cast<int*>(lds + T_NSLOT * T_SLOT_BYTES);
+  const int* lprog = ctrl;
+  volatile int* cprog = ctrl + 16;
+  volatile int* abortp = ctrl + 32;
   const uint32_t fa0 = frag_base<A_ROW, BT>(wm * 64, lane);
   const uint32_t fa1 = frag_base<A_ROW, BT>(wm * 64 + 32, lane);
   const uint32_t fb0 = frag_base<B_ROW, BT>(wn * 32, lane);
-  float* red = reinterpret_cast<float*>(lds + T_NSLOT * T_SLOT_BYTES);
   constexpr bool DO_BIAS = !A_ROW && EPI == EPI_STORE;
 
-  double lsum = 0.0;
-  int cslot = 0, redbuf = 0;
+  int cslot = 0;
   bool pending = false;
   Tile pc{};
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  float bsum = 0.f;
+  float bsum = 0.f, pbsum = 0.f;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), pbv = bv;
-  uint64_t cwait = 0;
 
   int ct = w.first;
   bool have = ct < w.end;
-  Tile c{};
-  int kt = 0;
-  // F0: the fragments of k-group 0 of the coming step; fetched one step early (the loaders see to it
-  // that the slot of step s + 1 is complete at the barrier of step s)
-  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0;
-  auto finish_tile = [&]() {   // epilogue of tile pc (behind a barrier: `red` is complete)
+  if (!have) return;
+  Tile c = decode_tile(g, ct, BT, BT);
+  bv = load_bias<EPI>(g, c.n0, wn, lane);
+  // total number of K-steps of this workgroup
+  int total = 0;
+  for (int t = w.first; t < w.end; t += w.stride) total += decode_tile(g, t, BT, BT).nk;
+  int kt = 0, step = 0, avail = 0;
+  uint64_t w_data = 0;
+  auto wait_landed = [&](int need) -> bool {   // all four loaders have published `need` steps
+    int spins = 0;
+    uint64_t tm = 0;
+    if (g.stamps && avail < need) tm = __builtin_amdgcn_s_memtime();
+    while (avail < need) {
+      avail = lds_min4(lprog);
+      if (avail >= need) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > T_SPIN_LIMIT || *abortp) { *abortp = 1; return false; }
+    }
+    if (g.stamps && tm) w_data += __builtin_amdgcn_s_memtime() - tm;
+    return true;
+  };
+  auto finish_tile = [&]() {   // epilogue of tile pc
     if (DO_BIAS && g.bias_part != nullptr && pc.tn == 0) {
-      const float* rb = red + (redbuf ^ 1) * 512;
-      if (tid < BT && pc.m0 + tid < g.M)
-        g.bias_part[(int64_t)pc.z * g.bias_part_stride + pc.m0 + tid] = (rb[tid] + rb[tid + 128]) + (rb[tid + 256] + rb[tid + 384]);
+      // column sums of A: this wave's 16 outs, the four k ranges sit in the lane groups of 16
+      float sres = pbsum;
+      sres += __shfl_xor(sres, 16, 64);
+      sres += __shfl_xor(sres, 32, 64);
+      const int o = pc.m0 + 16 * wid + lane;
+      if (lane < 16 && o < g.M) g.bias_part[(int64_t)pc.z * g.bias_part_stride + o] = sres;
     }
     if (RING_DBG & 8) {
       float t = 0.f;
@@ -797,25 +846,25 @@ __device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int w
     else epilogue<EPI, ACT_RELU>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
     pending = false;
   };
-  if (have) {
-    c = decode_tile(g, ct, BT, BT);
-    bv = load_bias<EPI>(g, c.n0, wn, lane);
-    step_barrier();   // steps 0 and 1 are complete
-    if (!(RING_DBG & 16)) {
-      a0 = read_frag<A_ROW, BT>(lds, fa0, 0);
-      a1 = read_frag<A_ROW, BT>(lds, fa1, 0);
-      b0 = read_frag<B_ROW, BT>(lds + A_BYTES, fb0, 0);
-    }
+  // F0: the fragments of k-group 0 of the coming step, fetched one step early
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0;
+  if (!wait_landed(total < 2 ? total : 2)) return;
+  if (!(RING_DBG & 16)) {
+    a0 = read_frag<A_ROW, BT>(lds, fa0, 0);
+    a1 = read_frag<A_ROW, BT>(lds, fa1, 0);
+    b0 = read_frag<B_ROW, BT>(lds + A_BYTES, fb0, 0);
   }
   while (have) {
     if (pending) finish_tile();
+    // this step reads slot `cslot` and, for the fragments of the next step, the slot behind it
+    if (!wait_landed(step + 2 < total ? step + 2 : total)) return;
     const char* tA = lds + cslot * T_SLOT_BYTES;
     const char* tB = tA + A_BYTES;
     const int nslot = cslot == T_NSLOT - 1 ? 0 : cslot + 1;
     const char* nA = lds + nslot * T_SLOT_BYTES;
     const char* nB = nA + A_BYTES;
     if (DO_BIAS && g.bias_part != nullptr && c.tn == 0) {
-      const float* ctile = reinterpret_cast<const float*>(tA) + (tid >> 7) * 8 * BT + (tid & 127);
+      const float* ctile = reinterpret_cast<const float*>(tA) + (lane >> 4) * 8 * BT + 16 * wid + (lane & 15);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) bsum += ctile[kk * BT];
     }
@@ -855,17 +904,16 @@ __device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int w
     ITTS_MFMA8(p0, p1, q0)
 #undef ITTS_MFMA8
 #undef ITTS_MFMA6
+    // every read of this step's slot has returned (its last fragments are in the MFMAs above)
+    ++step;
+    if (lane == 0) cprog[wid] = step;
     cslot = nslot;
     if (++kt == c.nk) {
-      if (DO_BIAS && g.bias_part != nullptr && c.tn == 0) {
-        red[redbuf * 512 + tid] = bsum;   // read behind the next barrier
-        bsum = 0.f;
-        redbuf ^= 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
       pending = true;
       pc = c;
       pbv = bv;
+      pbsum = bsum;
+      bsum = 0.f;
       kt = 0;
       ct += w.stride;
       have = ct < w.end;
@@ -874,27 +922,9 @@ __device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int w
         bv = load_bias<EPI>(g, c.n0, wn, lane);
       }
     }
-    // entry of the next step (or of the last epilogue): its slot and the one behind it are complete,
-    // everybody has left this step
-    uint64_t tb = 0;
-    if (g.stamps) tb = __builtin_amdgcn_s_memtime();
-    step_barrier();
-    if (g.stamps) cwait += __builtin_amdgcn_s_memtime() - tb;
   }
   if (pending) finish_tile();
-  if (g.stamps && lane == 0 && (wid == 0 || wid == 4)) g.stamps[4 * (1024 + blockIdx.x) + 2 + (wid >> 2)] = cwait;
-  if (EPI == EPI_MSE) {
-    double* redd = reinterpret_cast<double*>(red);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
-    if (lane == 0) redd[wid] = lsum;
-    lds_barrier();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int i = 0; i < 8; ++i) t += redd[i];
-      g.loss_partial[blockIdx.x] = t;
-    }
-  }
+  if (g.stamps && lane == 0 && (wid == 0 || wid == 4)) g.stamps[4 * (1024 + blockIdx.x) + 2 + (wid >> 2)] = w_data;
 }
 
 template <bool A_ROW, bool B_ROW, int EPI>
@@ -905,8 +935,25 @@ __global__ __launch_bounds__(T_THREADS, 3) void gemm_ring128_kernel(Args g) {
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint64_t t0c = 0, t0r = 0;
   if (g.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
-  if (wid >= 8) loader_wave128<A_ROW, B_ROW>(g, lds, lds0, lane, EPI == EPI_MSE, wid - 8);
-  else compute_waves128<A_ROW, B_ROW, EPI>(g, lds, wid, lane);
+  int* ctrl = reinterpret_cast<int*>(lds + T_NSLOT * T_SLOT_BYTES);
+  if (threadIdx.x < T_CTRL_BYTES / 4) ctrl[threadIdx.x] = 0;
+  lds_barrier();
+  double lsum = 0.0;
+  if (wid >= 8) loader_wave128<A_ROW, B_ROW>(g, lds, lds0, lane, wid - 8);
+  else compute_waves128<A_ROW, B_ROW, EPI>(g, lds, wid, lane, lsum);
+  if (EPI == EPI_MSE) {
+    // one double per compute wave through LDS, fixed order
+    double* redd = reinterpret_cast<double*>(ctrl + 48);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+    if (wid < 8 && lane == 0) redd[wid] = lsum;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int i = 0; i < 8; ++i) t += redd[i];
+      g.loss_partial[blockIdx.x] = t;
+    }
+  }
   if (g.stamps && threadIdx.x == 0) {
     g.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
     g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;

@@ -167,8 +167,8 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 
   uint64_t* stamps;
-  CK(hipMalloc(&stamps, 2048 * 32));
-  CK(hipMemset(stamps, 0, 2048 * 32));
+  CK(hipMalloc(&stamps, 4096 * 32));
+  CK(hipMemset(stamps, 0, 4096 * 32));
   auto clock_report = [&](const char* name, int G) {
     std::vector<uint64_t> h(4 * G);
     CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
@@ -196,10 +196,19 @@ int main(int argc, char** argv) {
       std::vector<uint64_t> hw(4 * 256);
       CK(hipMemcpy(hw.data(), stamps + 4 * 1024, hw.size() * 8, hipMemcpyDeviceToHost));
       std::vector<double> v[4];
-      for (int i = 0; i < 256; ++i) for (int k = 0; k < 4; ++k) if (hw[4 * i + 2]) v[k].push_back((double)hw[4 * i + k]);
+      for (int i = 0; i < 256; ++i) for (int k = 0; k < 4; ++k) if (hw[4 * i + 0]) v[k].push_back((double)hw[4 * i + k]);
       if (!v[0].empty()) {
+        std::vector<uint64_t> hl(4 * 256);
+        CK(hipMemcpy(hl.data(), stamps + 4 * 1536, hl.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> vl;
+        for (int i = 0; i < 256; ++i) if (hl[4 * i]) vl.push_back((double)hl[4 * i]);
+        std::sort(vl.begin(), vl.end());
+        std::vector<double> vi;
+        for (int i = 0; i < 256; ++i) if (hl[4 * i]) vi.push_back((double)hl[4 * i + 1]);
+        std::sort(vi.begin(), vi.end());
+        if (!vl.empty()) printf("   DMA issue -> seen landed, mean per step: median over workgroups %.0f cycles (max %.0f); cycles inside the 8 issue statements %.0f\n", vl[vl.size() / 2], vl.back(), vi[vi.size() / 2]);
         for (int k = 0; k < 4; ++k) std::sort(v[k].begin(), v[k].end());
-        printf("   waits (cycles, median over workgroups): loader dma %.0f, loader barrier %.0f, compute wave 0 barrier %.0f, wave 4 barrier %.0f\n",
+        printf("   waits (cycles, median over workgroups): loader dma %.0f, loader slot %.0f, compute wave 0 data %.0f, wave 4 data %.0f\n",
                v[0][v[0].size() / 2], v[1][v[1].size() / 2], v[2][v[2].size() / 2], v[3][v[3].size() / 2]);
       }
     }
@@ -262,6 +271,26 @@ int main(int argc, char** argv) {
     }
     g.stamps = nullptr;
     const double bd = max_abs_diff(o_old, o_new, M * ldc);
+    if (bd > 1e-3) {
+      std::vector<float> a((size_t)(M * ldc)), b((size_t)(M * ldc));
+      CK(hipMemcpy(a.data(), o_old, a.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(b.data(), o_new, b.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<int> hr(128, 0), hc(128, 0);
+      std::vector<int64_t> tl;
+      int64_t bad = 0; int shown = 0;
+      for (int64_t m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+        if (std::fabs(a[m * ldc + n] - b[m * ldc + n]) > 1e-3) {
+          ++bad; hr[m % 128]++; hc[n % 128]++; tl.push_back((m / 128) * 4 + n / 128);
+          if (shown++ < 4) printf("     bad (%lld,%d): old %g new %g\n", (long long)m, n, a[m * ldc + n], b[m * ldc + n]);
+        }
+      }
+      std::sort(tl.begin(), tl.end()); tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+      printf("     %lld bad in %zu tiles (first:", (long long)bad, tl.size());
+      for (size_t i = 0; i < tl.size() && i < 12; ++i) printf(" %lld", (long long)tl[i]);
+      printf(")\n     rows:"); for (int i = 0; i < 128; ++i) if (hr[i]) printf(" %d:%d", i, hr[i]);
+      printf("\n     cols:"); for (int i = 0; i < 128; ++i) if (hc[i]) printf(" %d:%d", i, hc[i]);
+      printf("\n");
+    }
     rows.push_back({name, t_old, t_new, 2.0 * M * N * (double)K, 0.0, bd});
   };
 
