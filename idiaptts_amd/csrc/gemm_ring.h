@@ -1,31 +1,40 @@
-// fp32-MFMA GEMM fed by an LDS-DMA loader wave: the kernel behind the dense layers of the acoustic
+// fp32-MFMA GEMM fed by LDS-DMA loader waves: the kernel behind the dense layers of the acoustic
 // model (rnn_dyn/FFWrapper.py:63-73 forward, autograd's dX / dW products behind it).
 //
 // Structure (gfx950, written for it):
-//   * persistent workgroups (2 per CU) of FIVE waves walk a static list of output tiles of 128 x 64
-//     (or 64 x 128): waves 0-3 compute (64 x 32 each = two v_mfma_f32_32x32x2_f32 accumulators),
-//     wave 4 only moves data;
-//   * the loader wave brings the operand tiles of 32 reduction elements global -> LDS with
-//     `buffer_load_dwordx4 ... lds` (1 KB per instruction, no VGPRs, no ds_write) into a ring of
-//     three 24-KB slots, two K-steps ahead of the compute waves and straight across tile
+//   * persistent workgroups of EIGHT waves, two per CU, walk a static list of output tiles of
+//     128 x 64 (or 64 x 128): waves 0-3 compute (64 x 32 each = two v_mfma_f32_32x32x2_f32
+//     accumulators), waves 4-7 only move data.  (Workgroups of five or six waves are never placed
+//     two to a CU on this chip, whatever the occupancy query says; 256- and 512-thread ones are.)
+//   * each loader wave brings a quarter of the operand tiles of 32 reduction elements global -> LDS
+//     with `buffer_load_dwordx4 ... lds` (1 KB per instruction, no VGPRs, no ds_write) into a ring
+//     of three 24-KB slots, two K-steps ahead of the compute waves and straight across tile
 //     boundaries, so neither the first loads of a tile nor its epilogue expose memory latency; its
-//     `s_waitcnt vmcnt(24)` is the only wait on that traffic.  (The DMA is inline asm: hipcc would
-//     otherwise drain it with vmcnt(0) in front of every ds_read of the ring.)  The compute waves
-//     issue no memory instruction inside the K loop except ds_read, and their epilogue stores are
-//     never waited for;
-//   * one workgroup barrier per K-step (everybody has left step s-1, whose slot the loader refills
-//     next; the loader has seen step s land);
+//     counted `s_waitcnt vmcnt(6)` is the only wait on that traffic.  (The DMA is inline asm: hipcc
+//     would otherwise drain it with vmcnt(0) in front of every ds_read of the ring.)  The compute
+//     waves issue no memory instruction inside the K loop except ds_read, and their epilogue
+//     stores are never waited for;
+//   * one workgroup barrier per K-step (everybody has left step s-1, whose slot the loaders refill
+//     next; the loaders have seen step s land);
 //   * row-form tiles [out][32 k] are stored unpadded (the DMA writes lane-linear) with the 16-byte
 //     chunk index XORed with (row >> 1) & 7 -- applied to the SOURCE address of the DMA and to the
 //     ds_read_b128 address -- which makes the fragment reads bank-conflict free; col-form tiles
 //     [32 k][out] are linear and read with ds_read_b32;
 //   * edges without branches in the loop: buffer descriptors end at the last valid row, so
 //     out-of-range rows of an operand arrive as zeros; the columns k >= K of a partial last K-step
-//     of a row-form tile are zeroed in LDS by the loader before it joins the barrier; stores go
-//     through a descriptor as well (rows beyond M are dropped);
+//     of a row-form tile are zeroed in LDS behind the step's barrier (one more barrier on that step
+//     only); stores go through a descriptor as well (rows beyond M are dropped);
 //   * epilogue without LDS: 4 x 4 transposes inside lane quads (DPP) turn the accumulator layout
 //     (lane = column) into float4 row segments; bias + activation / activation derivative / masked
 //     MSE are fused as in the register-staged kernel this one replaces.
+//
+// Two hardware traps found on the way, both only with two workgroups per CU (memory queue busy):
+//   * a 16-byte buffer store with an SGPR offset may fetch its data registers AFTER a following
+//     VALU write to them (lost elements at lanes 12 / 28 / 44 / 60): the stores carry their whole
+//     offset in the VGPR, and the accumulators are never cleared by VALU writes -- a new tile
+//     starts from a zero C operand instead;
+//   * the clock follows the previous kernel for milliseconds: time a kernel after it has run for a
+//     few hundred launches, never right behind another one.
 //
 // K order inside the MFMA chain equals the register-staged kernel's (nn.hip), so results are
 // bit-identical to it for the same split-K chunking.
@@ -50,22 +59,10 @@ constexpr int SLOT_BYTES = 192 * 128;         // A tile + B tile of one K-step: 
 #define RING_NSLOT 3
 #endif
 constexpr int NSLOT = RING_NSLOT;
-#ifndef RING_PRIO
-#define RING_PRIO 0
-#endif
-#ifndef RING_STORE_AUX
-#define RING_STORE_AUX 0   // cache-policy bits of the epilogue stores
-#endif
-#ifndef RING_RED_BYTES
-#define RING_RED_BYTES (2 * 256 * 4)
-#endif
-constexpr int RED_BYTES = RING_RED_BYTES;        // bias-gradient partial sums, double buffered
+constexpr int RED_BYTES = 2 * 256 * 4;        // bias-gradient partial sums, double buffered
 constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + RED_BYTES;
 constexpr int PIECES = 6;                     // 1-KB DMA instructions per loader wave and K-step
-#ifndef RING_THREADS
-#define RING_THREADS 512
-#endif
-constexpr int THREADS = RING_THREADS;         // 4 compute waves + 4 loader waves (workgroups of 5 or 6 waves do not share a CU)
+constexpr int THREADS = 512;         // 4 compute waves + 4 loader waves (workgroups of 5 or 6 waves do not share a CU)
 
 enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_DACT = 2, EPI_MSE = 3 };
 enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
@@ -274,7 +271,6 @@ __device__ __forceinline__ void zero_tail(char* tile, int krem, int tid) {
 
 template <bool A_ROW, bool B_ROW, int BMT, int BNT>
 __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t lds0, int lane, bool mse, int part) {
-  const bool idle = part >= 4;
   constexpr int A_BYTES = BMT * 128;
   const Walk w = my_tiles(g);
   uint32_t va0, va1, vb0, vb1;
@@ -295,7 +291,7 @@ __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t l
     pk = 0;
   };
   auto produce = [&]() {
-    if (!(RING_DBG & 1) && !idle) {
+    if (!(RING_DBG & 1)) {
       sa.issue(va0, va1, g.lda, pdst, part);
       sb.issue(vb0, vb1, g.ldb, pdst + A_BYTES, part);
     }
@@ -450,7 +446,7 @@ __device__ __forceinline__ void epilogue(const Args& g, const Tile& pc, const f3
       // busy with the loaders' DMA)
       const uint32_t vo = col < g.ldc ? cofs + (uint32_t)(rl * g.ldc * 4) : 0xfffffff0u;
       if (RING_DBG & 64) asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
-      else __builtin_amdgcn_raw_buffer_store_b128(o, rc, vo, 0, RING_STORE_AUX);
+      else __builtin_amdgcn_raw_buffer_store_b128(o, rc, vo, 0, 0);
     }
   }
 }
@@ -487,17 +483,6 @@ __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid,
     // step entry: behind the barrier the slot of this step is complete and everybody has left the
     // previous one
     step_barrier();
-#if RING_PRIO
-    if (kt == 0) {
-#if RING_PRIO == 1
-      const bool up = (((int)blockIdx.x >> 3) >= ((int)gridDim.x >> 4)) ^ ((ct / w.stride) & 1);
-#else
-      const bool up = ((int)blockIdx.x >> 3) >= ((int)gridDim.x >> 4);
-#endif
-      if (up) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-    }
-#endif
     if (pending) {
       if (DO_BIAS && g.bias_part != nullptr && pc.tn == 0) {
         // the k ranges' column sums of A met in LDS before the barrier
@@ -611,348 +596,6 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_
     loader_wave<A_ROW, B_ROW, BMT, BNT>(g, lds, lds0, lane, EPI == EPI_MSE, wid - 4);
   } else {
     compute_waves<A_ROW, B_ROW, EPI, BMT, BNT>(g, lds, wid, lane);
-  }
-  if (g.stamps && threadIdx.x == 0) {
-    g.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-    g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
-    g.stamps[4 * blockIdx.x + 2] = t0r;
-    g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)) ;   // HW_ID
-  }
-}
-
-// ================================================================================================
-// 128 x 128 tiles, one workgroup per CU: eight compute waves (2 x 4 blocks of 64 x 32, two waves
-// per SIMD) and four loader waves share a ring of four 32-KB slots.  A third less L2 -> LDS
-// traffic per FLOP than the 128 x 64 kernel, and every wave of a CU ends with the last tile (no
-// phase in which half of the waves have run out of tiles).
-//
-// No workgroup barrier inside the K loop.  Measured with barriers: two compute waves share a SIMD,
-// the older one is served first, so per step one of them sat ~800 cycles at the barrier while the
-// matrix pipe idled ~600 of every 4 700 cycles.  Instead the waves exchange progress counters in
-// LDS: loader l publishes "my pieces of steps < n have landed" (behind its counted vmcnt wait),
-// compute wave w publishes "I have read all of steps < n"; a loader refills a slot when all eight
-// compute waves have left it, a compute wave starts step s when all four loaders have published
-// step s + 1 (it fetches the first fragments of step s + 1 while it still multiplies step s).
-// Waves drift apart by up to the ring depth, which is what lets the two waves of a SIMD cover each
-// other's LDS latencies.  Spins are bounded: a protocol failure raises `abort`, everybody leaves,
-// the output is garbage but the launch ends.
-// For outputs whose width fills 128-column tiles (the 512-wide layers); the 128 x 64 / 64 x 128
-// kernel takes the rest.
-// ================================================================================================
-constexpr int T_SLOT_BYTES = 256 * 128;       // A tile + B tile of one K-step
-constexpr int T_NSLOT = 4;
-constexpr int T_CTRL_BYTES = 256;             // lprog[4] @0, cprog[8] @64, abort @128, loss partials @192
-constexpr int T_LDS_BYTES = T_NSLOT * T_SLOT_BYTES + T_CTRL_BYTES;
-constexpr int T_PIECES = 8;                   // per loader wave and K-step
-constexpr int T_THREADS = 768;                // 8 compute waves + 4 loader waves
-constexpr int T_SPIN_LIMIT = 1 << 22;
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int lds_min4(const int* p) {
-  const i32x4 v = *reinterpret_cast<const volatile i32x4*>(p);   // re-read on every call
-  const int m = min(min(v[0], v[1]), min(v[2], v[3]));
-  return __builtin_amdgcn_readfirstlane(m);
-}
-
-template <bool A_ROW, bool B_ROW>
-__device__ __forceinline__ void loader_wave128(const Args& g, char* lds, uint32_t lds0, int lane, int part) {
-  constexpr int BT = 128;
-  constexpr int A_BYTES = BT * 128;
-  const Walk w = my_tiles(g);
-  int* ctrl = reinterpret_cast<int*>(lds + T_NSLOT * T_SLOT_BYTES);
-  volatile int* lprog = ctrl;
-  const int* cprog = ctrl + 16;
-  volatile int* abortp = ctrl + 32;
-  uint32_t va0, va1, vb0, vb1;
-  lane_offsets<A_ROW, BT>(g.lda, lane, va0, va1);
-  lane_offsets<B_ROW, BT>(g.ldb, lane, vb0, vb1);
-  Stream<A_ROW, BT> sa;
-  Stream<B_ROW, BT> sb;
-
-  // producer cursor
-  int pt = w.first, pk = 0, pnk = 0;
-  uint32_t pdst = lds0;
-  bool pvalid = pt < w.end;
-  auto open = [&]() {
-    const Tile c = decode_tile(g, pt, BT, BT);
-    sa.open(g.A, g.lda, c.m0, g.M, c);
-    sb.open(g.B, g.ldb, c.n0, g.N, c);
-    pnk = c.nk;
-    pk = 0;
-  };
-  auto produce = [&]() {
-    if (!(RING_DBG & 1)) {
-      sa.issue(va0, va1, g.lda, pdst, part);
-      sb.issue(vb0, vb1, g.ldb, pdst + A_BYTES, part);
-    }
-    pdst = pdst == lds0 + (T_NSLOT - 1) * T_SLOT_BYTES ? lds0 : pdst + T_SLOT_BYTES;
-    sa.soff += sa.step;
-    sb.soff += sb.step;
-    if (++pk == pnk) {
-      pt += w.stride;
-      pvalid = pt < w.end;
-      if (pvalid) open();
-    }
-  };
-  if (pvalid) open();
-  // publishing cursor: the oldest step in flight
-  int qt = w.first, qk = 0, qslot = 0;
-  bool qhave = qt < w.end;
-  Tile qc{};
-  if (qhave) qc = decode_tile(g, qt, BT, BT);
-
-  int issued = 0, landed = 0;   // step counts
-  int freed = 0;                // compute waves have left every step < freed
-  int spins = 0;
-  uint64_t w_slot = 0, w_dma = 0, tmark = 0, lat = 0, tq0 = 0, tq1 = 0, tq2 = 0, w_issue = 0;
-  while (qhave) {
-    if (g.stamps) tmark = __builtin_amdgcn_s_memtime();
-    // issue while a slot is free: step `issued` goes where step issued - 4 was
-    while (pvalid && issued - landed < 3) {
-      if (issued - freed >= T_NSLOT) {
-        freed = min(lds_min4(cprog), lds_min4(cprog + 4));
-        if (issued - freed >= T_NSLOT) break;
-      }
-      uint64_t tp = 0;
-      if (g.stamps) tp = __builtin_amdgcn_s_memtime();
-      produce();
-      if (g.stamps) { tq0 = tq1; tq1 = tq2; tq2 = __builtin_amdgcn_s_memtime(); w_issue += tq2 - tp; }
-      ++issued;
-    }
-    if (issued == landed) {   // every slot is still being read
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > T_SPIN_LIMIT || *abortp) { *abortp = 1; return; }
-      if (g.stamps) w_slot += __builtin_amdgcn_s_memtime() - tmark;
-      continue;
-    }
-    if (g.stamps) tmark = __builtin_amdgcn_s_memtime();
-    // the oldest step in flight has landed
-    const int behind = issued - landed - 1;
-    if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T_PIECES) : "memory");
-    else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (g.stamps) {
-      const uint64_t now = __builtin_amdgcn_s_memtime();
-      w_dma += now - tmark;
-      lat += now - (behind >= 2 ? tq0 : behind == 1 ? tq1 : tq2);   // issue -> seen landed, of the oldest step
-    }
-    if ((A_ROW || B_ROW) && qk == qc.nk - 1 && (qc.klen & (RBK - 1)) != 0) {
-      // partial last K-step of a row-form tile: clear the columns k >= K of the rows this wave brought in
-      char* slot = lds + qslot * T_SLOT_BYTES;
-      const int krem = qc.klen & (RBK - 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = lane + 64 * i;
-        const int row = 32 * part + (idx >> 3), ch = idx & 7;
-        const int lim = krem - 4 * ch;   // components j < lim stay
-        if (lim < 4) {
-          const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
-          if (A_ROW) {
-            float4* q = reinterpret_cast<float4*>(slot + off);
-            float4 v = *q;
-            v.x = lim > 0 ? v.x : 0.f; v.y = lim > 1 ? v.y : 0.f; v.z = lim > 2 ? v.z : 0.f; v.w = 0.f;
-            *q = v;
-          }
-          if (B_ROW) {
-            float4* q = reinterpret_cast<float4*>(slot + A_BYTES + off);
-            float4 v = *q;
-            v.x = lim > 0 ? v.x : 0.f; v.y = lim > 1 ? v.y : 0.f; v.z = lim > 2 ? v.z : 0.f; v.w = 0.f;
-            *q = v;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    ++landed;
-    if (lane == 0) lprog[part] = landed;
-    qslot = qslot == T_NSLOT - 1 ? 0 : qslot + 1;
-    if (++qk == qc.nk) {
-      qk = 0;
-      qt += w.stride;
-      qhave = qt < w.end;
-      if (qhave) qc = decode_tile(g, qt, BT, BT);
-    }
-  }
-  if (g.stamps && part == 0 && lane == 0) {
-    g.stamps[4 * (1024 + blockIdx.x)] = w_dma;
-    g.stamps[4 * (1024 + blockIdx.x) + 1] = w_slot;
-    g.stamps[4 * (1536 + blockIdx.x)] = lat / (landed > 0 ? landed : 1);
-    g.stamps[4 * (1536 + blockIdx.x) + 1] = w_issue / (landed > 0 ? landed : 1);
-  }
-}
-
-template <bool A_ROW, bool B_ROW, int EPI>
-__device__ __forceinline__ void compute_waves128(const Args& g, char* lds, int wid, int lane, double& lsum) {
-  constexpr int BT = 128;
-  constexpr int A_BYTES = BT * 128;
-  const int wm = wid >> 2, wn = wid & 3;
-  const Walk w = my_tiles(g);
-  int* ctrl = reinterpret_cast<int*>(lds + T_NSLOT * T_SLOT_BYTES);
-  const int* lprog = ctrl;
-  volatile int* cprog = ctrl + 16;
-  volatile int* abortp = ctrl + 32;
-  const uint32_t fa0 = frag_base<A_ROW, BT>(wm * 64, lane);
-  const uint32_t fa1 = frag_base<A_ROW, BT>(wm * 64 + 32, lane);
-  const uint32_t fb0 = frag_base<B_ROW, BT>(wn * 32, lane);
-  constexpr bool DO_BIAS = !A_ROW && EPI == EPI_STORE;
-
-  int cslot = 0;
-  bool pending = false;
-  Tile pc{};
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  float bsum = 0.f, pbsum = 0.f;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), pbv = bv;
-
-  int ct = w.first;
-  bool have = ct < w.end;
-  if (!have) return;
-  Tile c = decode_tile(g, ct, BT, BT);
-  bv = load_bias<EPI>(g, c.n0, wn, lane);
-  // total number of K-steps of this workgroup
-  int total = 0;
-  for (int t = w.first; t < w.end; t += w.stride) total += decode_tile(g, t, BT, BT).nk;
-  int kt = 0, step = 0, avail = 0;
-  uint64_t w_data = 0;
-  auto wait_landed = [&](int need) -> bool {   // all four loaders have published `need` steps
-    int spins = 0;
-    uint64_t tm = 0;
-    if (g.stamps && avail < need) tm = __builtin_amdgcn_s_memtime();
-    while (avail < need) {
-      avail = lds_min4(lprog);
-      if (avail >= need) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > T_SPIN_LIMIT || *abortp) { *abortp = 1; return false; }
-    }
-    if (g.stamps && tm) w_data += __builtin_amdgcn_s_memtime() - tm;
-    return true;
-  };
-  auto finish_tile = [&]() {   // epilogue of tile pc
-    if (DO_BIAS && g.bias_part != nullptr && pc.tn == 0) {
-      // column sums of A: this wave's 16 outs, the four k ranges sit in the lane groups of 16
-      float sres = pbsum;
-      sres += __shfl_xor(sres, 16, 64);
-      sres += __shfl_xor(sres, 32, 64);
-      const int o = pc.m0 + 16 * wid + lane;
-      if (lane < 16 && o < g.M) g.bias_part[(int64_t)pc.z * g.bias_part_stride + o] = sres;
-    }
-    if (RING_DBG & 8) {
-      float t = 0.f;
-      for (int r = 0; r < 16; ++r) t += acc0[r] + acc1[r];
-      if (t == 1.2345f) g.C[0] = t;
-    } else if (EPI == EPI_STORE || g.act == ACT_NONE) epilogue<EPI, ACT_NONE>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
-    else if (g.act == ACT_TANH) epilogue<EPI, ACT_TANH>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
-    else epilogue<EPI, ACT_RELU>(g, pc, acc0, acc1, wm, wn, lane, pbv, lsum);
-    pending = false;
-  };
-  // F0: the fragments of k-group 0 of the coming step, fetched one step early
-  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0;
-  if (!wait_landed(total < 2 ? total : 2)) return;
-  if (!(RING_DBG & 16)) {
-    a0 = read_frag<A_ROW, BT>(lds, fa0, 0);
-    a1 = read_frag<A_ROW, BT>(lds, fa1, 0);
-    b0 = read_frag<B_ROW, BT>(lds + A_BYTES, fb0, 0);
-  }
-  while (have) {
-    if (pending) finish_tile();
-    // this step reads slot `cslot` and, for the fragments of the next step, the slot behind it
-    if (!wait_landed(step + 2 < total ? step + 2 : total)) return;
-    const char* tA = lds + cslot * T_SLOT_BYTES;
-    const char* tB = tA + A_BYTES;
-    const int nslot = cslot == T_NSLOT - 1 ? 0 : cslot + 1;
-    const char* nA = lds + nslot * T_SLOT_BYTES;
-    const char* nB = nA + A_BYTES;
-    if (DO_BIAS && g.bias_part != nullptr && c.tn == 0) {
-      const float* ctile = reinterpret_cast<const float*>(tA) + (lane >> 4) * 8 * BT + 16 * wid + (lane & 15);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) bsum += ctile[kk * BT];
-    }
-    float4 p0, p1, q0;   // the k-group in flight
-    // k-group 0 (fragments in a0 / a1 / b0, fetched during the previous step)
-    if (kt == 0) {
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, zero, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, zero, 0, 0, 0);
-    } else {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc1, 0, 0, 0);
-    }
-    // fetch k-group 1 behind the first MFMAs (a wait in front of them would wait for these reads too)
-    if (!(RING_DBG & 16)) { p0 = read_frag<A_ROW, BT>(tA, fa0, 1); p1 = read_frag<A_ROW, BT>(tA, fa1, 1); q0 = read_frag<B_ROW, BT>(tB, fb0, 1); }
-    else { p0 = a0; p1 = a1; q0 = b0; asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(q0.x)); }
-#define ITTS_MFMA6(A0, A1, B0)                                                   \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.y, B0.y, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.y, B0.y, acc1, 0, 0, 0);      \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.z, B0.z, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.z, B0.z, acc1, 0, 0, 0);      \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.w, B0.w, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.w, B0.w, acc1, 0, 0, 0);
-#define ITTS_MFMA8(A0, A1, B0)                                                   \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B0.x, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B0.x, acc1, 0, 0, 0);      \
-    ITTS_MFMA6(A0, A1, B0)
-    ITTS_MFMA6(a0, a1, b0)
-    // k-group 1, fetch k-group 2
-    if (!(RING_DBG & 16)) { a0 = read_frag<A_ROW, BT>(tA, fa0, 2); a1 = read_frag<A_ROW, BT>(tA, fa1, 2); b0 = read_frag<B_ROW, BT>(tB, fb0, 2); }
-    ITTS_MFMA8(p0, p1, q0)
-    // k-group 2, fetch k-group 3
-    if (!(RING_DBG & 16)) { p0 = read_frag<A_ROW, BT>(tA, fa0, 3); p1 = read_frag<A_ROW, BT>(tA, fa1, 3); q0 = read_frag<B_ROW, BT>(tB, fb0, 3); }
-    ITTS_MFMA8(a0, a1, b0)
-    // k-group 3, fetch k-group 0 of the next step (behind the last step: an unused read of a valid address)
-    if (!(RING_DBG & 16)) { a0 = read_frag<A_ROW, BT>(nA, fa0, 0); a1 = read_frag<A_ROW, BT>(nA, fa1, 0); b0 = read_frag<B_ROW, BT>(nB, fb0, 0); }
-    ITTS_MFMA8(p0, p1, q0)
-#undef ITTS_MFMA8
-#undef ITTS_MFMA6
-    // every read of this step's slot has returned (its last fragments are in the MFMAs above)
-    ++step;
-    if (lane == 0) cprog[wid] = step;
-    cslot = nslot;
-    if (++kt == c.nk) {
-      pending = true;
-      pc = c;
-      pbv = bv;
-      pbsum = bsum;
-      bsum = 0.f;
-      kt = 0;
-      ct += w.stride;
-      have = ct < w.end;
-      if (have) {
-        c = decode_tile(g, ct, BT, BT);
-        bv = load_bias<EPI>(g, c.n0, wn, lane);
-      }
-    }
-  }
-  if (pending) finish_tile();
-  if (g.stamps && lane == 0 && (wid == 0 || wid == 4)) g.stamps[4 * (1024 + blockIdx.x) + 2 + (wid >> 2)] = w_data;
-}
-
-template <bool A_ROW, bool B_ROW, int EPI>
-__global__ __launch_bounds__(T_THREADS, 3) void gemm_ring128_kernel(Args g) {
-  __shared__ __attribute__((aligned(1024))) char lds[T_LDS_BYTES];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_p)lds;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint64_t t0c = 0, t0r = 0;
-  if (g.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
-  int* ctrl = reinterpret_cast<int*>(lds + T_NSLOT * T_SLOT_BYTES);
-  if (threadIdx.x < T_CTRL_BYTES / 4) ctrl[threadIdx.x] = 0;
-  lds_barrier();
-  double lsum = 0.0;
-  if (wid >= 8) loader_wave128<A_ROW, B_ROW>(g, lds, lds0, lane, wid - 8);
-  else compute_waves128<A_ROW, B_ROW, EPI>(g, lds, wid, lane, lsum);
-  if (EPI == EPI_MSE) {
-    // one double per compute wave through LDS, fixed order
-    double* redd = reinterpret_cast<double*>(ctrl + 48);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
-    if (wid < 8 && lane == 0) redd[wid] = lsum;
-    lds_barrier();
-    if (threadIdx.x == 0) {
-      double t = 0.0;
-      for (int i = 0; i < 8; ++i) t += redd[i];
-      g.loss_partial[blockIdx.x] = t;
-    }
   }
   if (g.stamps && threadIdx.x == 0) {
     g.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;

@@ -85,15 +85,6 @@ static void launch_ring(Args g, hipStream_t s, int maxwg = 512) {
   hipLaunchKernelGGL((gemm_ring_kernel<A_ROW, B_ROW, EPI, WM>), dim3(G), dim3(THREADS), 0, s, g);
 }
 
-template <bool A_ROW, bool B_ROW, int EPI>
-static void launch_ring128(Args g, hipStream_t s, int maxwg = 256) {
-  g.tiles_m = (g.M + 127) / 128;
-  g.tiles_n = (g.N + 127) / 128;
-  const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n * g.splitk;
-  const int G = (int)std::min<int64_t>(std::min(maxwg, 256), (ntiles + 7) / 8 * 8);
-  hipLaunchKernelGGL((gemm_ring128_kernel<A_ROW, B_ROW, EPI>), dim3(G), dim3(T_THREADS), 0, s, g);
-}
-
 struct Timer {
   hipEvent_t a, b;
   Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -141,7 +132,6 @@ int main(int argc, char** argv) {
   const int64_t M = argc > 2 ? atoll(argv[2]) : 39129;
   const int maxwg = argc > 3 ? atoi(argv[3]) : 512;
   const char* only = argc > 4 ? argv[4] : "";
-  const bool t128 = argc > 5 && atoi(argv[5]) == 128;
   Timer T;
   float* x = dalloc(M, 428, 425, 1);
   float* h1 = dalloc(M, 512, 512, 2, 1.8f);
@@ -192,26 +182,6 @@ int main(int argc, char** argv) {
       printf("   ranks %s: start min %.1f med %.1f max %.1f us; end min %.1f med %.1f max %.1f us\n", b ? "upper" : "lower",
              st[b].front(), st[b][st[b].size() / 2], st[b].back(), en[b].front(), en[b][en[b].size() / 2], en[b].back());
     }
-    {   // 128-tile kernel: waits, in shader cycles, medians over workgroups
-      std::vector<uint64_t> hw(4 * 256);
-      CK(hipMemcpy(hw.data(), stamps + 4 * 1024, hw.size() * 8, hipMemcpyDeviceToHost));
-      std::vector<double> v[4];
-      for (int i = 0; i < 256; ++i) for (int k = 0; k < 4; ++k) if (hw[4 * i + 0]) v[k].push_back((double)hw[4 * i + k]);
-      if (!v[0].empty()) {
-        std::vector<uint64_t> hl(4 * 256);
-        CK(hipMemcpy(hl.data(), stamps + 4 * 1536, hl.size() * 8, hipMemcpyDeviceToHost));
-        std::vector<double> vl;
-        for (int i = 0; i < 256; ++i) if (hl[4 * i]) vl.push_back((double)hl[4 * i]);
-        std::sort(vl.begin(), vl.end());
-        std::vector<double> vi;
-        for (int i = 0; i < 256; ++i) if (hl[4 * i]) vi.push_back((double)hl[4 * i + 1]);
-        std::sort(vi.begin(), vi.end());
-        if (!vl.empty()) printf("   DMA issue -> seen landed, mean per step: median over workgroups %.0f cycles (max %.0f); cycles inside the 8 issue statements %.0f\n", vl[vl.size() / 2], vl.back(), vi[vi.size() / 2]);
-        for (int k = 0; k < 4; ++k) std::sort(v[k].begin(), v[k].end());
-        printf("   waits (cycles, median over workgroups): loader dma %.0f, loader slot %.0f, compute wave 0 data %.0f, wave 4 data %.0f\n",
-               v[0][v[0].size() / 2], v[1][v[1].size() / 2], v[2][v[2].size() / 2], v[3][v[3].size() / 2]);
-      }
-    }
     // which CU: HW_ID bits: cu_id [11:8], sh_id [12], se_id [15:13] (gfx9 layout), xcc via blockIdx
     std::sort(ghz.begin(), ghz.end());
     std::sort(us.begin(), us.end());
@@ -230,12 +200,8 @@ int main(int argc, char** argv) {
     g.A = A; g.lda = (int)lda; g.B = B; g.ldb = (int)ldb; g.C = o_new; g.ldc = (int)ldc; g.M = (int)M; g.N = N; g.K = (int)K;
     g.bias = bias; g.aux = aux; g.ldaux = (int)ldaux; g.act = act;
     g.kchunk = (int)((K + 31) / 32 * 32); g.splitk = 1; g.slab_stride = 0;
-    const bool big = t128 && N >= 256;
     auto new_fn = [&]() {
-      if (big) {
-        if (brow) launch_ring128<true, true, EPI_BIAS_ACT>(g, 0, maxwg);
-        else launch_ring128<true, false, EPI_DACT>(g, 0, maxwg);
-      } else if (brow) launch_ring<true, true, EPI_BIAS_ACT, 2>(g, 0, maxwg);
+      if (brow) launch_ring<true, true, EPI_BIAS_ACT, 2>(g, 0, maxwg);
       else launch_ring<true, false, EPI_DACT, 2>(g, 0, maxwg);
     };
     CK(hipMemset(o_old, 0, (size_t)M * 512 * 4));
@@ -243,8 +209,7 @@ int main(int argc, char** argv) {
     const double t_old = T.us(old_fn, reps);
     const double t_new = T.us(new_fn, reps);
     { Args gc = g; step_old.push_back(old_fn);
-      step_new.push_back([=]() { if (big) { if (brow) launch_ring128<true, true, EPI_BIAS_ACT>(gc, 0, maxwg); else launch_ring128<true, false, EPI_DACT>(gc, 0, maxwg); }
-        else if (brow) launch_ring<true, true, EPI_BIAS_ACT, 2>(gc, 0, maxwg); else launch_ring<true, false, EPI_DACT, 2>(gc, 0, maxwg); }); }
+      step_new.push_back([=]() { if (brow) launch_ring<true, true, EPI_BIAS_ACT, 2>(gc, 0, maxwg); else launch_ring<true, false, EPI_DACT, 2>(gc, 0, maxwg); }); }
     g.stamps = stamps;
     CK(hipGetLastError());
     clock_report("(timed loop)", 512);
@@ -311,16 +276,14 @@ int main(int argc, char** argv) {
     if (*only && !strstr(name, only)) return;
     Args g{};
     g.A = dz; g.lda = (int)lddz; g.B = xin; g.ldb = (int)ldx; g.C = slabs; g.ldc = Kc; g.M = N; g.N = Kc; g.K = (int)M;
-    const bool big = t128 && wm == 2 && N >= 256;
-    const int bmt = big ? 128 : 64 * wm, bnt = big ? 128 : 32 * (4 / wm);
+    const int bmt = 64 * wm, bnt = 32 * (4 / wm);
     const int tiles = ((N + bmt - 1) / bmt) * ((Kc + bnt - 1) / bnt);
-    int S = std::max(1, (big ? 256 : maxwg) / tiles);
+    int S = std::max(1, maxwg / tiles);
     int64_t kchunk = ((M + S - 1) / S + 31) / 32 * 32;
     S = (int)((M + kchunk - 1) / kchunk);
     g.kchunk = (int)kchunk; g.splitk = S; g.slab_stride = (int64_t)N * Kc;
     auto new_fn = [&]() {
-      if (big) launch_ring128<false, false, EPI_STORE>(g, 0, maxwg);
-      else if (wm == 2) launch_ring<false, false, EPI_STORE, 2>(g, 0, maxwg);
+      if (wm == 2) launch_ring<false, false, EPI_STORE, 2>(g, 0, maxwg);
       else launch_ring<false, false, EPI_STORE, 1>(g, 0, maxwg);
       hipLaunchKernelGGL(reduce_slabs_ref, dim3((unsigned)(((int64_t)N * Kc + 255) / 256)), dim3(256), 0, 0, slabs,
                          S, (int64_t)N * Kc, dw_new);
@@ -329,7 +292,7 @@ int main(int argc, char** argv) {
     const double t_old = T.us(old_fn, reps);
     const double t_new = T.us(new_fn, reps);
     if (!strstr(name, "wm1")) { step_old.push_back(old_fn); Args gc = g; int Sc = S;
-      step_new.push_back([=]() { if (big) launch_ring128<false, false, EPI_STORE>(gc, 0, maxwg); else if (wm == 2) launch_ring<false, false, EPI_STORE, 2>(gc, 0, maxwg); else launch_ring<false, false, EPI_STORE, 1>(gc, 0, maxwg);
+      step_new.push_back([=]() { if (wm == 2) launch_ring<false, false, EPI_STORE, 2>(gc, 0, maxwg); else launch_ring<false, false, EPI_STORE, 1>(gc, 0, maxwg);
         hipLaunchKernelGGL(reduce_slabs_ref, dim3((unsigned)(((int64_t)N * Kc + 255) / 256)), dim3(256), 0, 0, slabs, Sc, (int64_t)N * Kc, dw_new); }); }
     CK(hipGetLastError());
     hipLaunchKernelGGL(ref_gemm, dim3((unsigned)(((int64_t)N * Kc + 255) / 256)), dim3(256), 0, 0, dz, lddz, 0, xin,
@@ -350,8 +313,7 @@ int main(int argc, char** argv) {
     g.A = x; g.lda = 428; g.B = w1; g.ldb = 428; g.C = o_new; g.ldc = 512; g.M = (int)M; g.N = 512; g.K = Kt;
     g.kchunk = (Kt + 31) / 32 * 32; g.splitk = 1;
     CK(hipMemset(o_new, 0, (size_t)M * 512 * 4));
-    if (t128) launch_ring128<true, true, EPI_STORE>(g, 0, maxwg);
-    else launch_ring<true, true, EPI_STORE, 2>(g, 0, maxwg);
+    launch_ring<true, true, EPI_STORE, 2>(g, 0, maxwg);
     hipLaunchKernelGGL(ref_gemm, dim3((unsigned)((M * 512 + 255) / 256)), dim3(256), 0, 0, x, (int64_t)428, 1, w1,
                        (int64_t)428, 1, ref, M, 512, (int64_t)Kt);
     CK(hipDeviceSynchronize());
