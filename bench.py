@@ -41,26 +41,55 @@ def _oracle_utterance(args):
     return len(r) / fs, b - a, c - b
 
 
-def cpu_baseline_world_pool(fs=16000, seconds=4.0):
+def _pool_warm(_):
+    from oracle import capi   # load the oracle library in the worker before the clock starts
+    capi.num_frames(16000, 16000)
+    return os.getpid()
+
+
+def cpu_baseline_world_pool(fs=16000, seconds=4.0, budget_s=40.0):
     """the reference's feature extraction is an embarrassingly parallel loop
-    over files (WorldFeatLabelGen.py:996); its best case on this host is one process per core.
-    Forked BEFORE anything touches HIP: every core analyses and re-synthesises one utterance
-    through the C oracle; the figure is whole-pool wall time over the pool's audio."""
+    over files (WorldFeatLabelGen.py:996); its best case on this host is a pool of single-threaded
+    worker processes.  The figure reported is the best of a sweep over the pool size (all logical
+    CPUs, half, a quarter, ...): workers are started and warmed first, then every worker gets four
+    utterances (C oracle: analysis + synthesis) and the pool's wall time over the pool's audio is
+    taken.  Runs in an interpreter that never loads torch or touches HIP; bounded by budget_s."""
     import multiprocessing as mp
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ[var] = "1"
     n = os.cpu_count() or 1
+    sizes = sorted({n, max(1, n // 2), max(1, n // 4), max(1, min(n, 32))}, reverse=True)
     rng = np.random.default_rng(5)
-    jobs = [(fs, 7000 + i, float(seconds * rng.uniform(0.8, 1.2))) for i in range(n)]
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(n) as pool:
-        res = pool.map(_oracle_utterance, jobs, chunksize=1)
-    wall = time.perf_counter() - t0
-    audio = sum(r[0] for r in res)
-    return {"kind": "port", "cores": n, "processes": n,
-            "sample": "{} utterances ({:.0f} s of audio), one per process, C oracle analysis + "
-                      "synthesis, wall time incl. process start".format(n, audio),
-            "analysis_plus_synthesis_rtf": wall / audio,
-            "per_core_analysis_rtf": float(np.mean([r[1] / r[0] for r in res])),
-            "per_core_synthesis_rtf": float(np.mean([r[2] / r[0] for r in res]))}
+    sweep, best = [], None
+    t_start = time.perf_counter()
+    for p in sizes:
+        if sweep and time.perf_counter() - t_start > budget_s:
+            break
+        jobs = [(fs, 7000 + i, float(seconds * rng.uniform(0.8, 1.2))) for i in range(4 * p)]
+        with mp.get_context("fork").Pool(p) as pool:
+            pool.map(_pool_warm, range(p), chunksize=1)
+            t0 = time.perf_counter()
+            res = pool.map(_oracle_utterance, jobs, chunksize=1)
+            wall = time.perf_counter() - t0
+        audio = sum(r[0] for r in res)
+        row = {"processes": p, "utterances": len(jobs), "audio_s": audio, "wall_s": wall,
+               "analysis_plus_synthesis_rtf": wall / audio,
+               "per_core_analysis_rtf": float(np.mean([r[1] / r[0] for r in res])),
+               "per_core_synthesis_rtf": float(np.mean([r[2] / r[0] for r in res]))}
+        sweep.append(row)
+        if best is None or row["analysis_plus_synthesis_rtf"] < best["analysis_plus_synthesis_rtf"]:
+            best = row
+    out = {"kind": "port", "cores": best["processes"], "processes": best["processes"],
+           "logical_cpus": n,
+           "sample": "best of a sweep over the pool size: {} single-threaded worker processes, {} "
+                     "utterances ({:.0f} s of audio, four per worker), C oracle analysis + synthesis, "
+                     "workers started and warmed before the clock".format(
+                         best["processes"], best["utterances"], best["audio_s"]),
+           "analysis_plus_synthesis_rtf": best["analysis_plus_synthesis_rtf"],
+           "per_core_analysis_rtf": best["per_core_analysis_rtf"],
+           "per_core_synthesis_rtf": best["per_core_synthesis_rtf"],
+           "sweep": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in sweep]}
+    return out
 
 
 
@@ -68,7 +97,8 @@ if __name__ == "__main__" and "--cpu-pool-worker" in sys.argv:
     # child of the bench: the one-process-per-core C-oracle baseline, in an interpreter that never
     # loads torch or touches HIP (forking 256 workers out of the benchmark process itself, before
     # its GPU sections, slowed the launch-bound BiGRU section by 10 %)
-    print(json.dumps(cpu_baseline_world_pool(int(sys.argv[sys.argv.index("--cpu-pool-worker") + 1]))))
+    _a = sys.argv[sys.argv.index("--cpu-pool-worker") + 1:]
+    print(json.dumps(cpu_baseline_world_pool(int(_a[0]), budget_s=float(_a[1]) if len(_a) > 1 else 40.0)))
     sys.exit(0)
 
 import torch  # noqa: E402
@@ -597,13 +627,36 @@ def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
                                "epoch_ms": dt * 1e3, "valid_frames_per_s": n / dt}}
 
 
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT touching HIP: the compute nodes of the KFD
+    topology (sysfs) that have SIMDs, cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when one of them is set."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([t for t in v.split(",") if t.strip() != ""])
+            n = min(n, listed) if n else listed
+    return n
+
+
 def spawn_ranks(args):
     """Launches `torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child
     process and returns its exit code (rank 0 of the child job prints the JSON line).  Nothing
-    here initialises HIP: torch.cuda.device_count() only counts devices on this image."""
+    here initialises HIP (the devices are counted in sysfs), and the ranks are fresh interpreters
+    started with subprocess, never forks of a process that has touched the GPU."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_gpus()
     env = dict(os.environ)
     if n_dev < args.gpus and not (args.share_gpu or env.get("ITTS_BENCH_SHARE_GPU") == "1"):
         print("bench.py: --gpus {} but only {} device(s) visible (use --share-gpu for a functional "
@@ -626,12 +679,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--utts-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=100.0,
+                    help="wall-time budget of ALL host baselines together (FF stack, BiLSTM stack, "
+                         "C oracle on one core, C oracle process pool): each gets a quarter")
     ap.add_argument("--world-utts", type=int, default=256,
                     help="utterances in the WORLD feature-path section (0 = skip)")
     ap.add_argument("--world-fs", type=int, default=16000)
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check only: all ranks on device 0, collectives over gloo "
                          "(never a measurement; the JSON line says so)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: initialise RCCL with one rank and issue every collective of "
+                         "the N > 1 path anyway (a one-rank sum is the identity)")
     ap.add_argument("--bilstm-utts", type=int, default=64,
                     help="utterances per GPU of the BiLSTM / BiGRU (config 3) section (0 = skip)")
     args = ap.parse_args()
@@ -661,12 +720,20 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.force_dist:
+            from idiaptts_amd import parallel
+            parallel.force_collectives(True)
 
     from idiaptts_amd.bench_support import make_ff_batch
     from idiaptts_amd.native_ff import FlatFFModel, flops_per_frame
@@ -683,7 +750,8 @@ def main():
         batches.append((x, y, valid, int(lengths.sum())))
     # global valid-frame count per step (identical on all ranks)
     counts = torch.tensor([b[3] for b in batches], dtype=torch.float64, device=dev)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         dist.all_reduce(counts)
     global_counts = counts.cpu().tolist()
 
@@ -696,7 +764,7 @@ def main():
         step(i)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -706,7 +774,7 @@ def main():
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -732,9 +800,10 @@ def main():
     if args.world_utts > 0:
         with_cpu = not args.no_cpu_baseline and world == 1    # CPU baseline: rank 0 at N = 1 only
         world_extra = world_section(dev, args.world_utts, args.world_fs, with_cpu=with_cpu,
+                                    cpu_seconds=min(25.0, args.cpu_budget_s / 6),
                                     rank=rank, n_ranks=world)
         # config 5 also quotes 48 kHz (fft 2048, 5 aperiodicity bands): a smaller batch
-        world_extra.update(world_section(dev, max(4, args.world_utts // 4), 48000, cpu_seconds=12.0,
+        world_extra.update(world_section(dev, max(4, args.world_utts // 4), 48000, cpu_seconds=min(12.0, args.cpu_budget_s / 12),
                                          with_cpu=with_cpu, with_mlpg=False, key="world_48k",
                                          rank=rank, n_ranks=world))
 
@@ -781,10 +850,11 @@ def main():
                     "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / 8.0}
         cpu = None
         if want_cpu:   # CPU baseline: rank 0 at N = 1 only
-            cpu = cpu_baseline_ff(args.utts_per_gpu)
+            cpu = cpu_baseline_ff(args.utts_per_gpu, max_seconds=min(20.0, args.cpu_budget_s / 4))
             cpu.update(host_info())
             if args.bilstm_utts > 0:
-                rnn_extra["bilstm"]["cpu_baseline"] = cpu_baseline_bilstm()
+                rnn_extra["bilstm"]["cpu_baseline"] = cpu_baseline_bilstm(
+                    max_seconds=min(20.0, args.cpu_budget_s / 4))
         extra = dict(world_extra)
         extra.update(rnn_extra)
         if want_cpu and "world" in extra:
@@ -792,7 +862,8 @@ def main():
             # interpreter of its own
             import subprocess
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-pool-worker",
-                                  str(args.world_fs)], stdout=subprocess.PIPE, text=True)
+                                  str(args.world_fs), str(args.cpu_budget_s / 4)],
+                                 stdout=subprocess.PIPE, text=True)
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
             if res.returncode == 0 and lines:
                 extra["world"]["cpu_baseline_pool"] = json.loads(lines[-1])
@@ -816,9 +887,12 @@ def main():
         if share_gpu:
             out["shared_gpu"] = ("functional check only: {} ranks on ONE device, collectives over "
                                  "gloo -- not a measurement".format(world))
+        if args.force_dist:
+            out["forced_collectives"] = ("RCCL initialised with {} rank(s); every collective of the "
+                                         "N > 1 path was issued".format(world))
         out.update(extra)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -92,6 +92,7 @@ extern "C" int itts_wav2world(const double* d_x, const int64_t* h_x_off, const i
   ITTS_REQUIRE(d_x && d_f0 && (d_sp || d_ap), "null pointer");
   if (fft_size <= 0) fft_size = itts_cheaptrick_fft_size(fs, 71.0);
   hipStream_t s = itts::as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   double* d_f0_raw = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_f0_raw, (size_t)h_f_off[n_utts] * sizeof(double), s));
   int rc = itts_dio(d_x, h_x_off, h_f_off, n_utts, fs, frame_period_ms, 71.0, 800.0, 2.0, 0.1, d_f0_raw,

@@ -85,6 +85,27 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t s);
 hipError_t scratch_free(void* p, hipStream_t s);
 
+// Every entry point that takes scratch opens a ScratchScope first: blocks obtained (on this thread)
+// while it is alive and not handed back by scratch_free -- the early returns of ITTS_REQUIRE /
+// ITTS_HIP_CHECK / ITTS_LAUNCH_CHECK between a scratch_malloc and its scratch_free -- are released
+// by its destructor, behind the work already queued on the stream.  Scopes nest (an entry point
+// calling another one).
+class ScratchScope {
+ public:
+  explicit ScratchScope(hipStream_t s);
+  ~ScratchScope();
+  ScratchScope(const ScratchScope&) = delete;
+  ScratchScope& operator=(const ScratchScope&) = delete;
+  void track(void* p);
+  void untrack(void* p);
+
+ private:
+  hipStream_t stream_;
+  ScratchScope* prev_;
+  void* live_[64];
+  int n_live_ = 0;
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace itts

@@ -95,7 +95,35 @@ static void scratch_evict(ScratchCache& c, size_t limit) {
   }
 }
 
+static thread_local ScratchScope* t_scope = nullptr;
+
+ScratchScope::ScratchScope(hipStream_t s) : stream_(s), prev_(t_scope) { t_scope = this; }
+ScratchScope::~ScratchScope() {
+  t_scope = prev_;   // first: the frees below must not come back to this scope
+  for (int i = 0; i < n_live_; ++i)
+    if (live_[i]) (void)scratch_free(live_[i], stream_);
+}
+void ScratchScope::track(void* p) {
+  if (n_live_ < 64) live_[n_live_++] = p;   // beyond 64 live blocks: as before (explicit frees only)
+}
+void ScratchScope::untrack(void* p) {
+  for (int i = n_live_ - 1; i >= 0; --i)
+    if (live_[i] == p) {
+      live_[i] = nullptr;
+      while (n_live_ > 0 && live_[n_live_ - 1] == nullptr) --n_live_;
+      return;
+    }
+  if (prev_) prev_->untrack(p);   // obtained under an outer scope
+}
+
+static hipError_t scratch_malloc_impl(void** out, size_t bytes, hipStream_t s);
 hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t s) {
+  const hipError_t e = scratch_malloc_impl(out, bytes, s);
+  if (e == hipSuccess && *out && t_scope) t_scope->track(*out);
+  return e;
+}
+
+static hipError_t scratch_malloc_impl(void** out, size_t bytes, hipStream_t s) {
   *out = nullptr;
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
@@ -138,6 +166,7 @@ hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t s) {
 
 hipError_t scratch_free(void* p, hipStream_t s) {
   if (!p) return hipSuccess;
+  if (t_scope) t_scope->untrack(p);
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   for (auto& kv : g_scratch)
     for (ScratchBlock& b : kv.second.blocks)

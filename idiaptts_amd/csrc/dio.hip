@@ -422,6 +422,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
   ITTS_REQUIRE(f0_floor > 0 && f0_ceil > f0_floor && channels_in_octave > 0, "bad f0 range");
   if (n_utts == 0) return ITTS_OK;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   DioParams p{};
   p.fs = fs; p.frame_period = frame_period_ms; p.f0_floor = f0_floor; p.f0_ceil = f0_ceil;
   p.allowed_range = allowed_range;

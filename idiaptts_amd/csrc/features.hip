@@ -349,6 +349,7 @@ extern "C" int itts_assemble_cmp_f32(const float* d_sp, int64_t ld_sp, int n_sp,
   ITTS_REQUIRE(d_lf0 && d_vuv && d_out && (n_sp == 0 || d_sp) && (n_bap == 0 || d_bap),
                "null pointer");
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   int64_t* d_off = nullptr;
   int rc = upload_i64(h_f_off, n_utts + 1, &d_off, s);
   if (rc != ITTS_OK) return rc;
@@ -378,6 +379,7 @@ extern "C" int itts_feature_stats(const float* d_x, int64_t ld_x, int64_t n_rows
   ITTS_REQUIRE(width > 0 && col0 >= 0 && ld_x >= col0 + width && n_rows >= 0, "bad sizes");
   ITTS_REQUIRE(d_sum && d_second && d_workspace && (n_rows == 0 || d_x), "null pointer");
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   if (n_rows == 0) {
     if (!accumulate) {
       ITTS_HIP_CHECK(hipMemsetAsync(d_sum, 0, width * sizeof(double), s));

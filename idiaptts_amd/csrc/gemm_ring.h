@@ -604,5 +604,25 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_
   }
 }
 
+// Two independent GEMMs in one launch (the weight-gradient and the input-gradient product of a
+// layer both start from dz): every persistent workgroup walks its tiles of the first problem, then
+// its tiles of the second.  One launch boundary less per layer (ramp, drain and the end-of-kernel
+// wait cost ~10 us each on this chip) and the workgroups that run out of tiles of the first
+// problem start the second right away instead of idling to the end of the launch.
+template <bool A1, bool B1, int E1, int W1, bool A2, bool B2, int E2, int W2>
+__global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_pair_kernel(Args g1, Args g2) {
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_p)lds;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= 4) {
+    loader_wave<A1, B1, 64 * W1, 32 * (4 / W1)>(g1, lds, lds0, lane, E1 == EPI_MSE, wid - 4);
+    loader_wave<A2, B2, 64 * W2, 32 * (4 / W2)>(g2, lds, lds0, lane, E2 == EPI_MSE, wid - 4);
+  } else {
+    compute_waves<A1, B1, E1, 64 * W1, 32 * (4 / W1)>(g1, lds, wid, lane);
+    compute_waves<A2, B2, E2, 64 * W2, 32 * (4 / W2)>(g2, lds, wid, lane);
+  }
+}
+
 }  // namespace ring
 }  // namespace itts

@@ -1153,6 +1153,7 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
   ITTS_REQUIRE(!(d_dbg_raw || d_dbg_cand || d_dbg_score || d_dbg_best) || n_utts == 1,
                "the per-stage outputs are for a single utterance");
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
 

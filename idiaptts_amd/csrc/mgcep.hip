@@ -447,6 +447,7 @@ extern "C" int itts_mgc2sp_gamma(const double* d_mgc, int64_t T, int order, doub
   const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
   if (!ft) return ITTS_E_HIP;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   const int K = fftlen / 2 + 1;
   const int64_t ld_cep = (K + 1) & ~1;
   double* d_cep = nullptr;

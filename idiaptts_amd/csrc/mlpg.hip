@@ -964,31 +964,6 @@ void mlpg_fused_kernel(FusedArgs g) {
 #undef FU_STAMP
 }
 
-// np.gradient(x, axis=0) in float32 (misc/utils.py:103-105): one-sided at the ends, central
-// inside; a single-frame utterance yields 0 (numpy raises there; the reference never hits it).
-__global__ void gradient_f32_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int dim,
-                                    const int64_t* offsets) {
-  const int u = blockIdx.y;
-  const int64_t t0 = offsets[u], T = offsets[u + 1] - t0;
-  const int64_t n = T * dim;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = i / dim;
-    const int d = (int)(i - t * dim);
-    const float* c = x + (t0 + t) * ldx + d;
-    float g;
-    if (T == 1) {
-      g = 0.f;
-    } else if (t == 0) {
-      g = c[ldx] - c[0];
-    } else if (t == T - 1) {
-      g = c[0] - c[-ldx];
-    } else {
-      g = (c[ldx] - c[-ldx]) / 2.0f;
-    }
-    out[(t0 + t) * ldo + d] = g;
-  }
-}
 
 }  // namespace itts
 
@@ -1021,6 +996,7 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   ITTS_REQUIRE(n_utts <= t_total + 1, "more utterances than frames");
   if (t_total == 0) return ITTS_OK;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   double* scratch = reinterpret_cast<double*>(d_scratch);
   int64_t* d_off = reinterpret_cast<int64_t*>(scratch + 3 * t_total * (int64_t)dim);
   ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
@@ -1143,26 +1119,5 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   hipLaunchKernelGGL((mlpg_chunk_kernel<0, true>), cg, dim3(64), 0, s, a, (int)t_max);
   hipLaunchKernelGGL((mlpg_chunk_kernel<1, true>), cg, dim3(64), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
-  return ITTS_OK;
-}
-
-extern "C" int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_out,
-                                 int dim, const int64_t* h_offsets, int n_utts, void* stream) {
-  ITTS_REQUIRE(h_offsets && (n_utts == 0 || (d_x && d_out)), "null pointer");
-  ITTS_REQUIRE(dim > 0 && ld_x >= dim && ld_out >= dim && n_utts >= 0, "bad sizes");
-  if (n_utts == 0 || h_offsets[n_utts] == 0) return ITTS_OK;
-  hipStream_t s = as_stream(stream);
-  int64_t* d_off = nullptr;
-  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_off, (n_utts + 1) * sizeof(int64_t), s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
-                                hipMemcpyHostToDevice, s));
-  int64_t maxT = 0;
-  for (int u = 0; u < n_utts; ++u) maxT = std::max(maxT, h_offsets[u + 1] - h_offsets[u]);
-  int bx = (int)std::min<int64_t>((maxT * dim + 255) / 256, 64);
-  if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(gradient_f32_kernel, dim3(bx, n_utts), dim3(256), 0, s, d_x, ld_x, d_out,
-                     ld_out, dim, d_off);
-  ITTS_LAUNCH_CHECK();
-  ITTS_HIP_CHECK(itts::scratch_free(d_off, s));
   return ITTS_OK;
 }

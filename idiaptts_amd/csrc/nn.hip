@@ -272,8 +272,15 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
     double lsum = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (i > 0) {   // the reads of the previous block are done before it is overwritten
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * rh) * 36 + cl] = acc[i][0][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the lanes of this wave exchange the block through LDS
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int col = colb + c4;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -315,8 +322,15 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm_f32_kernel(Gemm
     const int colb = n0 + wn * 32;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (i > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * rh) * 36 + cl] = acc[i][0][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the lanes of this wave exchange the block through LDS
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int col = colb + c4;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool full = col + 3 < g.N;
@@ -463,6 +477,32 @@ template <bool A_ROW, bool B_ROW, int EPI>
 static int launch_ring(const GemmArgs& g, int splitk, hipStream_t s) {
   if (ring_wm(g.M, g.N) == 1) return launch_ring_wm<A_ROW, B_ROW, EPI, 1>(g, splitk, s);
   return launch_ring_wm<A_ROW, B_ROW, EPI, 2>(g, splitk, s);
+}
+
+template <int WM>
+static ring::Args ring_args(const GemmArgs& g, int splitk) {
+  constexpr int BMT = 64 * WM, BNT = 32 * (4 / WM);
+  ring::Args r{};
+  r.A = g.A; r.B = g.B; r.C = g.C; r.bias = g.bias; r.aux = g.aux;
+  r.row_valid = g.row_valid; r.loss_partial = g.loss_partial; r.bias_part = g.bias_part;
+  r.slab_stride = g.slab_stride; r.bias_part_stride = g.bias_part_stride;
+  r.lda = (int)g.lda; r.ldb = (int)g.ldb; r.ldc = (int)g.ldc; r.ldaux = (int)g.ldaux;
+  r.M = (int)g.M; r.N = g.N; r.K = (int)g.K; r.kchunk = (int)g.kchunk; r.splitk = splitk;
+  r.tiles_m = (int)((g.M + BMT - 1) / BMT);
+  r.tiles_n = (g.N + BNT - 1) / BNT;
+  r.act = g.act; r.gscale = g.gscale;
+  return r;
+}
+
+// weight-gradient GEMM (col x col, split-K slabs) and input-gradient GEMM (row x col, activation
+// derivative in the epilogue) of one layer in ONE launch
+template <int WM_W, int EPI_X>
+static int launch_ring_bwd_pair(const GemmArgs& gw, int splitk, const GemmArgs& gx, hipStream_t s) {
+  const ring::Args rw = ring_args<WM_W>(gw, splitk), rx = ring_args<2>(gx, 1);
+  hipLaunchKernelGGL((ring::gemm_ring_pair_kernel<false, false, EPI_STORE, WM_W, true, false, EPI_X, 2>),
+                     dim3(kRingGrid), dim3(ring::THREADS), 0, s, rw, rx);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
 }
 
 template <bool A_ROW, bool B_ROW, int EPI>
@@ -969,6 +1009,57 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
     if (rc) return rc;
   }
   return ITTS_OK;
+}
+
+// Weight gradient (+ bias gradient) and input gradient of one layer from one call: with operands
+// that allow the LDS-DMA kernel the two GEMMs share a launch (gemm_ring_pair_kernel), otherwise
+// this is itts_linear_bwd_weight followed by itts_linear_bwd_input.  Same results either way
+// (bit for bit: the tiles, the split-K chunks and their order are those of the separate calls).
+extern "C" int itts_linear_bwd(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx,
+                               const float* d_w, float* d_dw, float* d_db, float* d_dx, int64_t lddx,
+                               const float* d_yprev, int64_t ldyp, int act_prev, int64_t M, int N, int K,
+                               void* d_workspace, int accumulate, void* stream) {
+  ITTS_REQUIRE(d_w && d_dw && d_workspace && (M == 0 || (d_dz && d_x && d_dx)), "null pointer");
+  ITTS_REQUIRE(M >= 0 && N > 0 && K > 0 && lddz >= N && ldx >= K && lddx >= K, "bad sizes");
+  ITTS_REQUIRE(!d_yprev || ldyp >= K, "ldyp too small");
+  hipStream_t s = as_stream(stream);
+  const bool vec_ok = (lddz % 4 == 0) && aligned16(d_dz) && (ldx % 4 == 0) && aligned16(d_x) && (K % 4 == 0) &&
+                      aligned16(d_w);
+  const int64_t n = (int64_t)N * K;
+  const bool merged = d_db && d_db == d_dw + n && N % 4 == 0 && n % 4 == 0;
+  static const int pair_on = [] { const char* e = getenv("ITTS_GEMM_PAIR"); return e ? atoi(e) : 1; }();
+  bool fused = pair_on && ring_enabled() && vec_ok && M > 0 && (merged || !d_db) && (lddx % 4 == 0) &&
+               aligned16(d_dx) && (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
+  GemmArgs gw{}, gx{};
+  int S_eff = 1;
+  if (fused) {
+    const int S = choose_splitk_ring(M, N, K);
+    int64_t kchunk = (M + S - 1) / S;
+    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    S_eff = (int)((M + kchunk - 1) / kchunk);
+    float* slabs = reinterpret_cast<float*>(d_workspace);
+    gw.A = d_dz; gw.lda = lddz; gw.B = d_x; gw.ldb = ldx; gw.C = slabs; gw.ldc = K;
+    gw.M = N; gw.N = K; gw.K = M; gw.kchunk = kchunk; gw.vecA = gw.vecB = 1;
+    const int64_t stride = merged ? n + N : n;
+    gw.slab_stride = stride;
+    if (merged) { gw.bias_part = slabs + n; gw.bias_part_stride = stride; }
+    gx.A = d_dz; gx.lda = lddz; gx.B = d_w; gx.ldb = K; gx.C = d_dx; gx.ldc = lddx;
+    gx.M = M; gx.N = K; gx.K = N; gx.aux = d_yprev; gx.ldaux = ldyp; gx.act = act_prev;
+    gx.kchunk = ((N + BK - 1) / BK) * BK; gx.vecA = gx.vecB = 1;
+    fused = ring_ok<false, false>(gw, S_eff, EPI_STORE) && ring_ok<true, false>(gx, 1, d_yprev ? EPI_DACT : EPI_STORE);
+  }
+  if (!fused) {
+    int rc = itts_linear_bwd_weight(d_dz, lddz, d_x, ldx, d_dw, d_db, M, N, K, d_workspace, accumulate, stream);
+    if (rc) return rc;
+    return itts_linear_bwd_input(d_dz, lddz, d_w, d_dx, lddx, d_yprev, ldyp, act_prev, M, N, K, stream);
+  }
+  int rc;
+  const int wm = ring_wm(gw.M, gw.N);
+  if (d_yprev) rc = wm == 1 ? launch_ring_bwd_pair<1, EPI_DACT>(gw, S_eff, gx, s) : launch_ring_bwd_pair<2, EPI_DACT>(gw, S_eff, gx, s);
+  else rc = wm == 1 ? launch_ring_bwd_pair<1, EPI_STORE>(gw, S_eff, gx, s) : launch_ring_bwd_pair<2, EPI_STORE>(gw, S_eff, gx, s);
+  if (rc) return rc;
+  float* slabs = reinterpret_cast<float*>(d_workspace);
+  return launch_reduce_slabs(slabs, S_eff, merged ? n + N : n, d_dw, accumulate, s);
 }
 
 static int mse_blocks(int64_t M, int D) {

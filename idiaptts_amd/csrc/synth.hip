@@ -419,6 +419,7 @@ struct PulseArgs {
   double* y;
   SynParams p;
   const double2* g_tw;
+  const double* dcr;   // [h + 1]: the Hann half window of RemoveDCComponent, dcr[h] = its doubled sum
 };
 
 // minimum phase spectrum of the log-amplitude lg[0..h] (in z.x of the first h+1 entries is NOT
@@ -449,6 +450,23 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
     mp[k] = make_double2(t * cs, t * sn);
   }
   __syncthreads();
+}
+
+// WORLD's dc_remover window depends on the transform size only: one workgroup tabulates
+// hann(i) = 0.5 - 0.5 cos(2 pi (i + 1) / (1 + fft)), i < fft / 2, and the normaliser (the doubled sum,
+// reduced in the order the pulse kernel used when every pulse recomputed it: same bits).  Three
+// fp64 cosines per bin and pulse less.
+__global__ __launch_bounds__(NT) void syn_dcr_table_kernel(int fft, double* __restrict__ dcr) {
+  __shared__ double red[16];
+  const int h = fft / 2;
+  double dsum = 0.0;
+  for (int i = tid(); i < h; i += NT) {
+    const double w = 0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft));
+    dcr[i] = w;
+    dsum += w * 2.0;
+  }
+  dsum = bsum(dsum, red);
+  if (tid() == 0) dcr[h] = dsum;
 }
 
 // 28 KB of LDS at fft 1024: five workgroups fit a CU when a wave needs <= 102 VGPRs
@@ -534,15 +552,13 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
       double dc = 0.0;
       for (int i = tid(); i < h; i += NT) dc += zr[i];  // shifted index i+h <- zr[i]
       dc = bsum(dc, red);
-      // dc_remover[i] = hann(i) / sum, symmetric
-      double dsum = 0.0;
-      for (int i = tid(); i < h; i += NT) dsum += (0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft))) * 2.0;
-      dsum = bsum(dsum, red);
+      // dc_remover[i] = hann(i) / sum, symmetric (tabulated per transform size)
+      const double dsum = a.dcr[h];
       // shifted response minus its DC share: y[i] = x[i+h] - dc * dcr (i < h; x is zero there, so
       // that half is recomputed at the overlap-add), y[i] = x[i-h] - dc * dcr (i >= h; kept)
       for (int i = tid(); i < h; i += NT) {
         const int m = h - 1 - i;                  // = fft - 1 - (i + h)
-        const double dcr = (0.5 - 0.5 * cos(2.0 * kPi * (m + 1.0) / (1.0 + fft))) / dsum;
+        const double dcr = a.dcr[m] / dsum;
         per[i] = zr[i] - dc * dcr;
       }
       per_dc = dc;
@@ -591,7 +607,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
         double pv = 0.0;
         if (has_per) {
           if (j < h) {
-            const double dcr = (0.5 - 0.5 * cos(2.0 * kPi * (j + 1.0) / (1.0 + fft))) / per_dsum;
+            const double dcr = a.dcr[j] / per_dsum;
             pv = -per_dc * dcr;
           } else {
             pv = per[j - h];
@@ -660,6 +676,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
                "fft_size must be 2^k in [256, 4096]");
   if (n_utts == 0) return ITTS_OK;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
   const JumpTable* jt = get_jump_table(ctx);
@@ -751,9 +768,13 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   const int64_t n_pulses = *h_total;
   ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
   if (n_pulses > 0) {
-    PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
-                ctx->tw_compact[p.logfft]};
     const int h = fft_size / 2;
+    double* d_dcr = nullptr;
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_dcr, (size_t)(h + 1) * 8, s));
+    hipLaunchKernelGGL(syn_dcr_table_kernel, dim3(1), dim3(NT), 0, s, fft_size, d_dcr);
+    ITTS_LAUNCH_CHECK();
+    PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
+                ctx->tw_compact[p.logfft], d_dcr};
     const size_t lds = 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
                        (size_t)h * 8 + 16 * 8;            // 28.2 KB at fft 1024: 5 workgroups per CU
     ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
@@ -761,6 +782,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(syn_pulse_kernel, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
+    ITTS_HIP_CHECK(itts::scratch_free(d_dcr, s));
   }
   if (preemphasis == 0.0) {
     hipLaunchKernelGGL(syn_cast_kernel, dim3((unsigned)std::min<int64_t>((y_total + 255) / 256, 8192)), dim3(256),

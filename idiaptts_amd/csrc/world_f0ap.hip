@@ -647,6 +647,7 @@ extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const d
   int rc = check_offsets(h_x_off, h_f_off, n_utts, fs, frame_period_ms);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
   int64_t *d_xo = nullptr, *d_fo = nullptr;
@@ -694,6 +695,7 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   int rc = check_offsets(h_x_off, h_f_off, n_utts, fs, frame_period_ms);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
   D4cArgs a{};

@@ -634,6 +634,7 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
                  "frame offsets do not match int(1000*n/fs/frame_period)+1");
   }
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
   FrameArgs a{};
@@ -742,6 +743,7 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
   if (!ft) return ITTS_E_HIP;
   hipStream_t s = as_stream(stream);
+  itts::ScratchScope scratch_scope(s);
   const int K = fftlen / 2 + 1;
   const int64_t ld_cep = (K + 1) & ~1;
   double* d_cep = nullptr;

@@ -46,7 +46,6 @@ _SIGNATURES = {
     "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),
-    "itts_gradient_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, POINTER(c_int64), c_int, _P]),
     "itts_lf0_vuv": (c_int, [_P, POINTER(c_int64), c_int, c_double, c_float, _P, _P, _P]),
     "itts_interpolate_lin_f32": (c_int, [_P, POINTER(c_int64), c_int, _P, _P, _P]),
     "itts_assemble_cmp_f32": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int64, c_int,
@@ -65,6 +64,8 @@ _SIGNATURES = {
     "itts_linear_bwd_weight_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "itts_linear_bwd_weight": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, c_int,
                                        _P, c_int, _P]),
+    "itts_linear_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, c_int,
+                                c_int64, c_int, c_int, _P, c_int, _P]),
     "itts_masked_mse_workspace_bytes": (c_int64, [c_int64, c_int]),
     "itts_masked_mse": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_double, c_float,
                                 _P, _P, c_int64, _P, _P]),

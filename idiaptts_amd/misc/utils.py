@@ -4,8 +4,8 @@
 in the reference); it reproduces the reference's quirks bit for bit:
 the output aliases the scanned array, the interpolation target is reached one frame early, and a
 gap whose next voiced frame is the LAST frame is filled with the last voiced value (overwriting
-that frame).  `compute_deltas` = np.gradient in float32; the batched GPU form is
-idiaptts_amd.ops.gradient_f32.
+that frame).  `compute_deltas` = np.gradient in float32; on the device it is part of
+idiaptts_amd.ops.assemble_cmp (itts_assemble_cmp_f32: static, delta and delta-delta columns at once).
 """
 import numpy as np
 

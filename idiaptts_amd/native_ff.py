@@ -165,9 +165,13 @@ class FlatFFModel:
             acts.append(h)
         return acts
 
-    def loss_and_backward(self, x, target, row_valid, n_valid_global):
+    def loss_and_backward(self, x, target, row_valid, n_valid_global, reduce_group=None, reduce=False):
         """Fills self.grads with d(loss)/d(params) of this rank's frames; returns loss tensor
-        (this rank's contribution, already divided by the global frame count)."""
+        (this rank's contribution, already divided by the global frame count).  reduce=True (data
+        parallel): the sum all-reduce of a layer's gradient segment is issued as soon as its weight
+        gradient is queued -- it runs on the collective's own stream under the remaining GEMMs --
+        and the handles are left in self._pending for train_step to wait on before Adam."""
+        self._pending = []
         x = self.pack_input(x)
         M = x.shape[0]
         n = len(self.layout)
@@ -185,13 +189,23 @@ class FlatFFModel:
                                       grad=self._rows_buffer("dz_out", M, self.dims[-1]))
         for i in range(n - 1, -1, -1):
             inp = hs[i - 1] if i > 0 else x
-            ops.linear_bwd_weight(dz, inp, dw=self.weight_padded(i, self.grads),
-                                  db=self.bias(i, self.grads))
+            dz_in = None
             if i > 0:
-                dz = ops.linear_bwd_input(dz, self.weight_padded(i), yprev=hs[i - 1],
-                                          act_prev=self.acts[i - 1],
-                                          out=self._rows_buffer("dz%d" % (i & 1), M,
-                                                                self.layout[i][3]))
+                # dW, db and the input gradient of the layer in one call (one launch)
+                dz_in = self._rows_buffer("dz%d" % (i & 1), M, self.layout[i][3])
+                ops.linear_bwd(dz, inp, self.weight_padded(i), self.weight_padded(i, self.grads),
+                               self.bias(i, self.grads), dz_in, yprev=hs[i - 1], act_prev=self.acts[i - 1])
+            else:
+                ops.linear_bwd_weight(dz, inp, dw=self.weight_padded(i, self.grads),
+                                      db=self.bias(i, self.grads))
+            if reduce:
+                from .parallel import allreduce_flat_
+                w_off, b_off, N, _, _ = self.layout[i]
+                work = allreduce_flat_(self.grads[w_off:b_off + _pad4(N)], reduce_group, async_op=True)
+                if work is not None:
+                    self._pending.append(work)
+            if i > 0:
+                dz = dz_in
         return loss
 
     def train_step(self, x, target, row_valid, n_valid_global, lr=1e-3, betas=(0.9, 0.999),
@@ -202,10 +216,13 @@ class FlatFFModel:
         (infinity) clips the gradient norm to clip_max_norm, clip_value clamps the elements,
         ema_shadow (flat, this model's layout) is updated with ema_decay -- all inside the one
         Adam pass (itts_adam_step_fused)."""
-        loss = self.loss_and_backward(x, target, row_valid, n_valid_global)
-        if world_size > 1:
-            from .parallel import allreduce_flat_
-            allreduce_flat_(self.grads, process_group)
+        from . import parallel
+        dist_on = world_size > 1 or parallel._active(process_group)
+        loss = self.loss_and_backward(x, target, row_valid, n_valid_global, reduce_group=process_group,
+                                      reduce=dist_on)
+        for work in self._pending:   # the optimiser's stream waits for the collectives
+            work.wait()
+        self._pending = []
         self.step_count += 1
         if clip_norm_kind is None and not clip_value and ema_shadow is None:
             ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count,

@@ -60,19 +60,6 @@ def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0):
     return out
 
 
-def gradient_f32(x, offsets, out=None):
-    """np.gradient(x, axis=0) per utterance in float32 (misc/utils.py:103-105)."""
-    L = _lib.load()
-    _need(x, torch.float32, "x")
-    ld = _rows(x, "x")
-    if out is None:
-        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-    _lib.check(L.itts_gradient_f32(_ptr(x), ld, _ptr(out), _rows(out, "out"), x.shape[1],
-                                   _lib.offsets_array(offsets), len(offsets) - 1, _stream()),
-               "itts_gradient_f32")
-    return out
-
-
 def lf0_vuv(f0, offsets, f0_silence_threshold=30.0, lf0_zero=0.0):
     """f0 [Ttot] f64 -> (lf0 [Ttot] f32 interpolated, vuv [Ttot] f32): WorldFeatLabelGen.py:798-802
     (float32 log, threshold, interpolate_lin) per utterance."""
@@ -232,6 +219,27 @@ def linear_bwd_weight(dz, x, dw=None, db=None, accumulate=False, want_bias=True)
                                         1 if accumulate else 0, _stream()),
                "itts_linear_bwd_weight")
     return dw, db
+
+
+def linear_bwd(dz, x, w, dw, db, dx, yprev=None, act_prev=ACT_NONE, accumulate=False):
+    """dw [N, K] (+ db [N]) and dx [M, K] of a linear layer from dz [M, N], its input x [M, K] and its
+    weight w [N, K] in one call (one launch when the buffers allow 16-byte rows); dx is multiplied by
+    the derivative of the previous layer's activation when yprev (that layer's output) is given."""
+    L = _lib.load()
+    _need(dz, torch.float32, "dz")
+    _need(x, torch.float32, "x")
+    _need(w, torch.float32, "w")
+    M, N = dz.shape
+    K = x.shape[1]
+    if w.shape != (N, K) or not w.is_contiguous() or not dw.is_contiguous() or dw.shape != (N, K):
+        raise ValueError("w and dw must be contiguous [N, K]")
+    ws = _workspace(L.itts_linear_bwd_weight_workspace_bytes(M, N, K), dz.device)
+    _lib.check(L.itts_linear_bwd(_ptr(dz), _rows(dz, "dz"), _ptr(x), _rows(x, "x"), _ptr(w), _ptr(dw),
+                                 _ptr(db), _ptr(dx), _rows(dx, "dx"), _ptr(yprev),
+                                 _rows(yprev, "yprev") if yprev is not None else 0,
+                                 int(act_prev if act_prev is not None else ACT_NONE), M, N, K, _ptr(ws),
+                                 1 if accumulate else 0, _stream()), "itts_linear_bwd")
+    return dw, db, dx
 
 
 def masked_mse(pred, target, row_valid, n_valid, loss_weight=1.0, want_grad=True, grad=None):

@@ -11,9 +11,30 @@ concatenated batch.
 * normalisation statistics are additive (MeanStdDevExtractor.combine_stats :163-204): one
   all-reduce(sum) of (count, sum x, sum x^2 | sum x x^T).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+# A world of ONE rank normally skips every collective.  With this switch on (ITTS_FORCE_DIST=1 or
+# force_collectives(True)) they are issued anyway -- a one-rank sum / broadcast is the identity --
+# which is how the RCCL path (library load, communicator, stream ordering against the kernels'
+# streams, teardown) is exercised on a one-GPU box: tests/test_gpu_dp.py, `bench.py --force-dist`.
+_FORCE = os.environ.get("ITTS_FORCE_DIST", "0") == "1"
+
+
+def force_collectives(on=True):
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def _active(group=None):
+    """True when a collective has to be issued: a process group exists and it has more than one
+    rank (or the one-rank switch is on)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return _FORCE or dist.get_world_size(group) > 1
 
 
 def shard_by_length(lengths, world_size):
@@ -31,18 +52,21 @@ def shard_by_length(lengths, world_size):
 
 def global_sum(value, group=None, device=None):
     """Sum of a python number over all ranks (e.g. the global valid-frame count of a step)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item())
 
 
-def allreduce_flat_(buf, group=None):
-    """In-place sum all-reduce of a flat buffer (gradients or statistics)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return buf
+def allreduce_flat_(buf, group=None, async_op=False):
+    """In-place sum all-reduce of a flat buffer (gradients or statistics).  async_op: returns the
+    work handle (None when no collective is needed); the caller waits before it reads `buf`."""
+    if _active(group):
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            return work
+    return None if async_op else buf
 
 
 def allreduce_stats_(extractor, group=None, device=None):
@@ -52,7 +76,7 @@ def allreduce_stats_(extractor, group=None, device=None):
         else "sum_product_frames"
     a = np.atleast_1d(np.asarray(extractor.sum_frames, dtype=np.float64))
     b = np.atleast_1d(np.asarray(getattr(extractor, second), dtype=np.float64))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dims = torch.tensor([a.shape[-1], b.ndim], dtype=torch.int64)
         if device is not None:
             dims = dims.to(device)
@@ -88,8 +112,7 @@ def allreduce_module_grads_(params, local_weight, group=None):
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
-    _, world = dp_rank_world(group)
-    if world == 1:
+    if not _active(group):
         return
     flat = torch._utils._flatten_dense_tensors(grads)
     flat.mul_(float(local_weight))
@@ -100,7 +123,7 @@ def allreduce_module_grads_(params, local_weight, group=None):
 
 def broadcast_int(value, src=0, group=None, device=None):
     """The integer `value` of rank `src` on every rank (e.g. the seed of the epoch's shuffling)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group):
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.broadcast(t, src=src, group=group)
@@ -110,19 +133,27 @@ def broadcast_int(value, src=0, group=None, device=None):
 def broadcast_tensors_(tensors, src=0, group=None):
     """In-place broadcast of a list of tensors from rank `src` (model parameters, buffers,
     optimiser state after create / load): one flat message per dtype and device."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group):
         return
+    # RCCL moves device memory only, gloo in these tests host memory only: tensors that live on the
+    # other side (torch.optim.Adam keeps state['step'] on the host) travel through a staging copy
+    nccl = dist.get_backend(group) == "nccl"
+    stage_dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
     buckets = {}
     for t in tensors:
         if torch.is_tensor(t) and t.numel() > 0:
             buckets.setdefault((t.dtype, t.device), []).append(t)
-    for ts in buckets.values():
+    for (dtype, device), ts in buckets.items():
         flat = torch._utils._flatten_dense_tensors([t.detach() for t in ts])
-        dist.broadcast(flat, src=src, group=group)
+        moved = (device.type == "cuda") != nccl
+        wire = flat.to(stage_dev) if moved else flat
+        dist.broadcast(wire, src=src, group=group)
+        if moved:
+            flat = wire.to(device)
         for t, synced in zip(ts, torch._utils._unflatten_dense_tensors(flat, ts)):
             t.detach().copy_(synced)
 
 
 def barrier(group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.barrier(group=group)

@@ -220,29 +220,37 @@ class HTSLabelNormalisation(object):
         extractor = MinMaxExtractor()
         dict_labels = OrderedDict()
         if self._handle is not None and len(id_list) > 0:
-            # native batch: all label files in one call, all archives in one call
-            files = [os.path.join(dir_labels, i + self.htk_label_extension) for i in id_list]
-            block, off = self.generate_batch(files)
+            # native path, a bounded number of files per call: a chunk's [frames, dim] float64 block
+            # (+ its float32 copy for the archives) is all that is alive at a time, so the memory
+            # does not grow with the corpus (the reference works file by file); blocks are only
+            # kept when the caller asks for the dictionary
+            L = self._lib.load()
+            chunk = max(1, int(os.environ.get("ITTS_LABEL_CHUNK_FILES", "256")))
             if dir_out is not None:
-                block = block.astype(np.float32)          # what extract_linguistic_features saves
                 os.makedirs(dir_out, exist_ok=True)
-                L = self._lib.load()
-                n = len(id_list)
-                paths = (ctypes.c_char_p * n)(*[os.fsencode(os.path.join(dir_out, i + ".npz"))
-                                                for i in id_list])
-                for i in id_list:
-                    os.makedirs(os.path.dirname(os.path.join(dir_out, i)) or ".", exist_ok=True)
-                offs = (ctypes.c_int64 * (n + 1))(*[int(o) for o in off])
-                self._lib.check(L.itts_write_feature_archives(
-                    block.ctypes.data, self.dimension, offs, n, paths, 1, (ctypes.c_int * 1)(0),
-                    (ctypes.c_int * 1)(self.dimension), (ctypes.c_int * 1)(1),
-                    (ctypes.c_char_p * 1)(b"questions"), self.n_threads, None),
-                    "itts_write_feature_archives")
-            for k, file_id in enumerate(id_list):
-                labels = block[off[k]:off[k + 1]]
-                extractor.add_sample(labels)
-                if return_dict:
-                    dict_labels[file_id] = labels
+            for c0 in range(0, len(id_list), chunk):
+                ids = id_list[c0:c0 + chunk]
+                files = [os.path.join(dir_labels, i + self.htk_label_extension) for i in ids]
+                block, off = self.generate_batch(files)
+                if dir_out is not None:
+                    block = block.astype(np.float32)          # what extract_linguistic_features saves
+                    n = len(ids)
+                    paths = (ctypes.c_char_p * n)(*[os.fsencode(os.path.join(dir_out, i + ".npz"))
+                                                    for i in ids])
+                    for i in ids:
+                        os.makedirs(os.path.dirname(os.path.join(dir_out, i)) or ".", exist_ok=True)
+                    offs = (ctypes.c_int64 * (n + 1))(*[int(o) for o in off])
+                    self._lib.check(L.itts_write_feature_archives(
+                        block.ctypes.data, self.dimension, offs, n, paths, 1, (ctypes.c_int * 1)(0),
+                        (ctypes.c_int * 1)(self.dimension), (ctypes.c_int * 1)(1),
+                        (ctypes.c_char_p * 1)(b"questions"), self.n_threads, None),
+                        "itts_write_feature_archives")
+                for k, file_id in enumerate(ids):
+                    labels = block[off[k]:off[k + 1]]
+                    extractor.add_sample(labels)
+                    if return_dict:
+                        dict_labels[file_id] = labels.copy() if len(id_list) > chunk else labels
+                del block
             id_list = []
         for file_id in id_list:
             out = os.path.join(dir_out, file_id + self.questions_label_extension) \

@@ -167,11 +167,10 @@ class HipAdam(torch.optim.Optimizer):
         False without an arena."""
         if self._arenas is None:
             return False
-        import torch.distributed as dist
         for a in self._arenas:
             if a is not None:
                 a['g'].mul_(float(local_weight))
-                dist.all_reduce(a['g'], op=dist.ReduceOp.SUM, group=group)
+                parallel.allreduce_flat_(a['g'], group)
         return True
 
     @torch.no_grad()
@@ -674,13 +673,19 @@ class ModularModelHandlerPyTorch(object):
         if optimiser and self.optimiser is not None:
             for st in self.optimiser.state.values():
                 tensors += [v for v in st.values() if torch.is_tensor(v)]
-        if self._dist_device() is None:       # gloo moves host memory
-            host = [t.detach().cpu() for t in tensors]
-            parallel.broadcast_tensors_(host)
-            for t, h in zip(tensors, host):
-                t.detach().copy_(h)
-        else:
-            parallel.broadcast_tensors_(tensors)
+        # every tensor travels on the side the backend moves (RCCL: device memory, gloo: host
+        # memory); broadcast_tensors_ stages the others (torch.optim keeps state['step'] on the host)
+        parallel.broadcast_tensors_(tensors)
+        if optimiser and self.optimiser is not None:
+            # step counters kept as python integers (HipAdam / HipSGD, per parameter and per arena):
+            # the bias corrections of the replicas must agree as well
+            dev = self._dist_device()
+            for st in self.optimiser.state.values():
+                if isinstance(st.get("step"), int):
+                    st["step"] = parallel.broadcast_int(st["step"], device=dev)
+            for a in getattr(self.optimiser, "_arenas", None) or []:
+                if a is not None and isinstance(a.get("step"), int):
+                    a["step"] = parallel.broadcast_int(a["step"], device=dev)
         if self._resident is not None:
             self._resident["synced"] = False
 
@@ -739,14 +744,20 @@ class ModularModelHandlerPyTorch(object):
             self.ema.fused = False
 
     def _reseed_ema(self):
-        """After parameters were loaded the shadow restarts from them (reference: the EMA is
-        created from the model it averages, ExponentialMovingAverage.py:13-30)."""
+        """After parameters were loaded the shadow restarts from them.  Deliberate deviation from the
+        reference, which creates its EMA once from the model (ExponentialMovingAverage.py:13-30) and
+        does not touch it in load_checkpoint: here checkpoints hold the AVERAGED parameters, so a
+        shadow left at its pre-load values would pull the loaded model back towards the discarded
+        one (tests/test_gpu_optim.py).  The flat copy of the shadow kept by the resident-dataset
+        path is dropped with it and rebuilt from the reseeded EMA at the next step."""
         if self.ema is None:
             return
         with torch.no_grad():
             for name, p in self.model.named_parameters():
                 if name in self.ema.shadow:
                     self.ema.shadow[name].copy_(p.data)
+        if self._resident is not None:
+            self._resident["ema_shadow"] = None
 
     def set_scheduler(self, hparams, current_epoch=None, current_step=None, reset=False):
         """reference :585-656: Plateau (stepped with the validation loss), Exponential and Noam

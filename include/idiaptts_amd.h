@@ -119,9 +119,8 @@ int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int di
                          void* stream);
 
 /* ---- frame utilities (misc/utils.py:40-105) --------------------------------------------- */
-/* compute_deltas == np.gradient(x, axis=0) in float32, per utterance (utils.py:103-105). */
-int itts_gradient_f32(const float* d_x, int64_t ld_x, float* d_out, int64_t ld_out, int dim,
-                      const int64_t* h_offsets, int n_utts, void* stream);
+/* compute_deltas == np.gradient(x, axis=0) in float32 (utils.py:103-105): part of
+ * itts_assemble_cmp_f32 below (static, delta, delta-delta columns of every stream in one pass). */
 
 /* lf0 / V-UV of WorldFeatLabelGen.world_extract_features (world/WorldFeatLabelGen.py:798-802):
  *   lf0 = float32 log(clip(f0, 1e-10)); lf0[lf0 <= log(f0_silence_threshold)] = lf0_zero;
@@ -195,6 +194,15 @@ int64_t itts_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
 int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx,
                            float* d_dw, float* d_db, int64_t M, int N, int K,
                            void* d_workspace, int accumulate, void* stream);
+/* Both gradients of a layer from dz in one call (autograd's backward of torch.nn.Linear in
+ * rnn_dyn/FFWrapper.py:63-73): dw / db as itts_linear_bwd_weight, dx as itts_linear_bwd_input
+ * (d_yprev != NULL: times the derivative of the previous layer's activation).  With 16-byte rows
+ * the two GEMMs share one launch; the results equal the separate calls bit for bit.  d_workspace
+ * as for itts_linear_bwd_weight. */
+int itts_linear_bwd(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx, const float* d_w,
+                    float* d_dw, float* d_db, float* d_dx, int64_t lddx, const float* d_yprev,
+                    int64_t ldyp, int act_prev, int64_t M, int N, int K, void* d_workspace,
+                    int accumulate, void* stream);
 
 /* ---- masked MSE, reduction 'mean_per_frame' (loss/NamedLoss.py:70-117) -------------------- */
 /*

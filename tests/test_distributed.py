@@ -264,3 +264,38 @@ def test_replicas_loaders_and_checkpoints_do_not_depend_on_per_rank_seeds(tmp_pa
     assert np.array_equal(loaded0, loaded1)                   # both loaded rank 0's file
     assert np.array_equal(loaded0, flat0)                     # ... which held rank 0's (+0) weights
     assert "params_e1" in files0 and not any(f.endswith(".tmp") for f in files0)
+
+
+def _optim_state_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    torch.manual_seed(100 + rank)                 # replicas start different on purpose
+    h = Handler()
+    h.model = torch.nn.Linear(6, 4)
+    h.optimiser = torch.optim.Adam(h.model.parameters(), lr=1e-2)
+    for _ in range(2 + rank):                     # rank 1 has taken one more step: other `step`, other moments
+        h.optimiser.zero_grad()
+        h.model(torch.randn(5, 6)).pow(2).sum().backward()
+        h.optimiser.step()
+    h.sync_from_rank0()
+    flat = [p.detach().clone() for p in h.model.parameters()]
+    for st in h.optimiser.state.values():
+        flat += [v.detach().clone().float().reshape(-1) if torch.is_tensor(v) else torch.tensor([float(v)])
+                 for v in (st["step"], st["exp_avg"], st["exp_avg_sq"])]
+    ret[rank] = torch.cat([t.reshape(-1).double() for t in flat]).numpy()
+    dist.destroy_process_group()
+
+
+def test_sync_from_rank0_carries_torch_optimiser_state_including_host_side_step():
+    """torch.optim.Adam keeps state['step'] as a host tensor next to its moments: after
+    sync_from_rank0 both replicas hold rank 0's parameters, moments AND step count (a rank that
+    loaded another checkpoint, or took another number of steps, would otherwise use different bias
+    corrections from then on)."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_optim_state_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert np.array_equal(ret[0], ret[1])
+    assert ret[0][-1] != 0

@@ -177,3 +177,87 @@ def test_bench_starts_its_own_ranks(gpu):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and "shared_gpu" in out and out["value"] > 0
     assert out["world"]["n_gpus"] == 2 and out["bilstm"]["n_gpus"] == 2
+
+
+def _rccl_one_rank_worker(ret_path):
+    """Child process: RCCL with ONE rank on cuda:0, every collective of the N > 1 path forced on."""
+    import torch.distributed as dist
+    from idiaptts_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    x, y, _ = _ff_case()
+    ref_params, ref_g1, ref_losses = _ff_steps(dev, x, y, x.shape[0], 1)     # no process group yet
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    parallel.force_collectives(True)
+    assert parallel._active()
+    params, g1, losses = _ff_steps(dev, x, y, x.shape[0], 1)                 # all-reduce branch taken
+    # HipAdam on flat arenas: the in-place all-reduce of the arena, then a step
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import HipAdam
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 32).to(dev)
+    lin2 = torch.nn.Linear(64, 32).to(dev)
+    lin2.load_state_dict(lin.state_dict())
+    xin = torch.randn(16, 64, device=dev)
+    outs = []
+    for m, sync in ((lin, False), (lin2, True)):
+        opt = HipAdam(m.parameters(), lr=1e-2)
+        for _ in range(3):
+            opt.zero_grad()
+            m(xin).pow(2).mean().backward()
+            if sync:
+                assert opt.allreduce_grads_(1.0) or True
+            opt.step()
+        outs.append(torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy())
+    # broadcast of mixed host / device state (torch.optim.Adam keeps `step` on the host)
+    adam = torch.optim.Adam(lin.parameters(), lr=1e-3)
+    lin(xin).sum().backward()
+    adam.step()
+    state = [v for st in adam.state.values() for v in st.values() if torch.is_tensor(v)]
+    before = [t.detach().cpu().clone() for t in state]
+    parallel.broadcast_tensors_(state)
+    assert any(t.device.type == "cpu" for t in state)
+    same_state = all(torch.equal(a, b.detach().cpu()) for a, b in zip(before, state))
+    total = parallel.global_sum(3.5, device=dev)
+    seed = parallel.broadcast_int(1234, device=dev)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    with open(ret_path, "w") as f:
+        json.dump({"ff_params_equal": bool(np.array_equal(params, ref_params)),
+                   "ff_grads_equal": bool(np.array_equal(g1, ref_g1)),
+                   "ff_losses_equal": losses == ref_losses,
+                   "hipadam_equal": bool(np.array_equal(outs[0], outs[1])),
+                   "state_unchanged": bool(same_state), "global_sum": total, "seed": seed}, f)
+
+
+def test_rccl_with_one_rank_takes_every_collective_branch(gpu, tmp_path):
+    """RCCL proven as far as one GPU allows: init_process_group('nccl', world_size=1), then the flat
+    FF step with its per-layer asynchronous all-reduces, HipAdam.allreduce_grads_, the staged
+    broadcast of mixed host / device optimiser state, global_sum / broadcast_int / barrier and
+    destroy_process_group -- results bit-equal to the run without a process group (a one-rank sum
+    is the identity).  Runs in a fresh interpreter: the communicator must not leak into the other
+    tests of this process."""
+    ret = os.path.join(str(tmp_path), "ret.json")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "import test_gpu_dp as t; t._rccl_one_rank_worker(%r)" % (ROOT, os.path.join(ROOT, "tests"), ret))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    out = json.load(open(ret))
+    assert out["ff_params_equal"] and out["ff_grads_equal"] and out["ff_losses_equal"], out
+    assert out["hipadam_equal"] and out["state_unchanged"], out
+    assert out["global_sum"] == 3.5 and out["seed"] == 1234
+
+
+def test_bench_counts_devices_without_touching_hip():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.visible_gpus()
+    assert n == torch.cuda.device_count()

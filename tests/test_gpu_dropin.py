@@ -33,11 +33,22 @@ def test_world_extract_and_resynth_bounds(gpu, golden_dir):
 
 def test_gen_data_matches_reference_cmp_and_roundtrips(gpu, golden_dir, tmp_path):
     from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
-    ids = ["LJ001-0002", "LJ001-0008"]
+    ids = ["LJ001-000%d" % i for i in range(1, 10)]   # every fixture utterance of the reference
     gen = WorldFeatLabelGen(str(tmp_path), add_deltas=True, preemphasis=0.97, num_coded_sps=20,
                             mgc_alpha=0.58)
     label_dict, mean, cov = gen.gen_data(golden_dir, str(tmp_path), "ids.txt", id_list=ids,
                                          return_dict=True)
+    # normalisation statistics of the nine utterances (itts_feature_stats: sum x, sum x x^T in fp64 on
+    # the device) against the reference-held WORLD/cmp_mcep20/<feat>-mean-covariance.bin (made with
+    # float32 sums: agreement to their rounding)
+    import struct
+    for k, feat in ((0, "mcep20"), (1, "lf0"), (3, "bap")):
+        with open(os.path.join(golden_dir, "stats", feat + "-mean-covariance.bin"), "rb") as f:
+            n_frames, size = struct.unpack("ii", f.read(8))
+            ref = np.fromfile(f, dtype=np.float64).reshape(size, -1)
+        assert n_frames == sum(len(v) for v in label_dict.values())
+        assert np.abs(np.asarray(mean[k]).ravel() - ref[0]).max() < 5e-6
+        assert np.abs(np.asarray(cov[k]) - ref[1:]).max() < 5e-5 * max(1.0, np.abs(ref[1:]).max())
     for n in ids:
         cmp_ = np.fromfile(os.path.join(golden_dir, n + ".cmp"), dtype=np.float32).reshape(-1, 67)
         got = label_dict[n]

@@ -154,3 +154,34 @@ def test_a_batch_larger_than_the_scratch_budget_is_processed_in_chunks(gpu):
         assert torch.equal(single, f0[f_off[u]:f_off[u + 1]])
     ref, _ = capi.harvest(xs[111], fs)
     _close(f0[f_off[111]:f_off[112]].cpu().numpy(), ref, 1e-7)
+
+
+def test_failed_calls_hand_their_scratch_back(gpu):
+    """An entry point that returns early (bad frame offsets are detected after the first scratch
+    blocks have been taken) must not leave those blocks marked busy: a data-preparation loop that
+    catches the error and goes on would otherwise leak once per bad file.  The blocks are released
+    by the entry point's ScratchScope."""
+    import ctypes
+    from idiaptts_amd import lib as _lib, ops
+    L = _lib.load()
+
+    def used():
+        r, u, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L.itts_scratch_pool_stats(ctypes.byref(r), ctypes.byref(u), ctypes.byref(k)), "stats")
+        return u.value
+
+    fs = 16000
+    x = torch.from_numpy(np.random.default_rng(0).normal(size=fs) * 0.1).to(gpu)
+    T = ops.harvest_num_frames(fs, fs)
+    ops.harvest(x, [0, fs], [0, T], fs)                  # a good call: everything handed back
+    torch.cuda.synchronize()
+    base = used()
+    for _ in range(5):
+        with pytest.raises(_lib.IttsError):
+            ops.harvest(x, [0, fs], [0, T + 3], fs)      # frame offsets do not match the frame count
+        with pytest.raises(_lib.IttsError):
+            ops.dio(x, [0, fs], [0, T + 3], fs)
+    torch.cuda.synchronize()
+    assert used() == base
+    f0 = ops.harvest(x, [0, fs], [0, T], fs)             # and the library still works
+    assert f0.shape[0] == T

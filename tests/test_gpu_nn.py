@@ -280,3 +280,41 @@ def test_weight_and_bias_gradients_in_one_flat_arena(gpu, M, N, K):
     # the separate-buffer form gives the same bits
     dw2, db2 = ops.linear_bwd_weight(dz.to(gpu), x.to(gpu))
     assert torch.equal(dw2.reshape(-1), first[:N * K]) and torch.equal(db2, first[N * K:])
+
+
+@pytest.mark.parametrize("M,N,K,with_prev", [(3001, 187, 512, True), (2500, 512, 512, True), (777, 64, 96, False),
+                                             (130, 187, 425, True)])
+def test_fused_backward_equals_the_separate_calls_bit_for_bit(gpu, M, N, K, with_prev):
+    """itts_linear_bwd (weight + bias + input gradient of a layer in one launch) against
+    itts_linear_bwd_weight + itts_linear_bwd_input and against torch in float64."""
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    Kp = (K + 3) // 4 * 4
+    x = torch.zeros(M, Kp)
+    x[:, :K] = torch.tanh(torch.randn(M, K, generator=g))
+    dz = torch.randn(M, N, generator=g)
+    w = torch.zeros(N, Kp)
+    w[:, :K] = torch.randn(N, K, generator=g) * 0.1
+    xg, wg = x.to(gpu), w.to(gpu)
+    Np = (N + 3) // 4 * 4
+    dzg = torch.zeros(M, Np, device=gpu)[:, :N]
+    dzg.copy_(dz)
+    flat = torch.zeros(N * Kp + Np, device=gpu)       # db right behind dw: the merged slab reduction
+    dw, db = flat[:N * Kp].view(N, Kp), flat[N * Kp:N * Kp + N]
+    dx = torch.zeros(M, Kp, device=gpu)
+    yprev = xg if with_prev else None
+    ops.linear_bwd(dzg, xg, wg, dw, db, dx, yprev=yprev, act_prev=ops.ACT_TANH if with_prev else ops.ACT_NONE)
+    flat2 = torch.zeros_like(flat)
+    dw2, db2 = flat2[:N * Kp].view(N, Kp), flat2[N * Kp:N * Kp + N]
+    ops.linear_bwd_weight(dzg, xg, dw=dw2, db=db2)
+    dx2 = ops.linear_bwd_input(dzg, wg, yprev=yprev, act_prev=ops.ACT_TANH if with_prev else ops.ACT_NONE,
+                               out=torch.zeros(M, Kp, device=gpu))
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+    dw_ref = dz.double().t() @ x.double()
+    dx_ref = dz.double() @ w.double()
+    if with_prev:
+        dx_ref = dx_ref * (1 - x.double() ** 2)
+    assert (dw.cpu().double() - dw_ref).abs().max() < 2e-4 * max(1.0, dw_ref.abs().max().item())
+    assert (db.cpu().double() - dz.double().sum(0)).abs().max() < 2e-4 * max(1.0, dz.double().sum(0).abs().max().item())
+    assert (dx.cpu().double() - dx_ref).abs().max() < 1e-5 * max(1.0, dx_ref.abs().max().item())

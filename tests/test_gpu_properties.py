@@ -112,16 +112,19 @@ def test_bilstm_output_does_not_depend_on_the_order_of_the_batch(gpu):
         assert float(out[lengths[b]:, b].abs().max()) == 0.0 if lengths[b] < T else True
 
 
-@pytest.mark.parametrize("name", ["LJ001-0002", "LJ001-0008"])
+ALL_FIXTURES = ["LJ001-000%d" % i for i in range(1, 10)]
+
+
+@pytest.mark.parametrize("name", ALL_FIXTURES)
 def test_closed_loop_through_the_reference_held_features(gpu, golden_dir, name):
     """Synthesis-side parity cannot be pinned to a reference waveform (the reference holds none),
     but the loop can be closed through the PINNED half: the reference's golden `.cmp` features
     (mcep20 / lf0 / V-UV / bap) -> decode_sp -> world_features_to_raw (HIP synthesis with
     de-pre-emphasis) -> get_raw-style pre-emphasis -> HIP analysis as the fixtures were made
     (alpha 0.58, order 19) -> compared with the `.cmp` again, next to the same loop through the C
-    oracle.  Measured for the oracle loop on these fixtures: V/UV agreement 0.70 (one-sided: the
+    oracle.  Measured for the oracle loop on these fixtures: V/UV agreement 0.70 - 0.74 (one-sided: the
     fixture contours hold runs of 390-465 Hz octave-jump frames labelled voiced, which a
-    re-analysis of the clean resynthesis calls unvoiced; a single frame goes the other way), lf0
+    re-analysis of the clean resynthesis calls unvoiced; 1 - 18 frames per utterance go the other way), lf0
     RMSE on commonly voiced frames 28-40 cents, MCD 3.1-3.3 dB (order-19 envelope re-estimated from
     its own resynthesis).  The HIP loop must reproduce the oracle loop, and both must stay inside
     those figures."""
@@ -173,11 +176,11 @@ def test_closed_loop_through_the_reference_held_features(gpu, golden_dir, name):
     # both inside what the fixtures allow
     for agree, extra, cents, mcd in ((agree_h, extra_h, cents_h, mcd_h),
                                      (agree_o, extra_o, cents_o, mcd_o)):
-        assert agree > 0.65 and extra <= 3
+        assert agree > 0.65 and extra <= max(3, 0.02 * T)   # (0.6 - 1.8 % of the frames on the nine fixtures)
         assert cents < 60.0 and mcd < 4.0
 
 
-@pytest.mark.parametrize("name", ["LJ001-0002", "LJ001-0008"])
+@pytest.mark.parametrize("name", ALL_FIXTURES)
 def test_copy_synthesis_bound_of_the_reference_on_every_fixture_wav(gpu, golden_dir, name):
     """test_WorldFeatLabelGen.py:761-763: sum (original - WORLD resynthesis)^2 < 10000, through
     the HIP analysis + synthesis, for every committed fixture wav."""

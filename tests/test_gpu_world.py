@@ -180,7 +180,7 @@ def test_full_analysis_chain_matches_reference_cmp(gpu, golden_dir):
     import math
     from idiaptts_amd import ops
     from idiaptts_amd.misc.utils import interpolate_lin
-    names = ["LJ001-0008", "LJ001-0002"]
+    names = ["LJ001-000%d" % i for i in range(1, 10)]   # every fixture utterance of the reference
     xs = [_read(golden_dir, n)[0] for n in names]
     fs = 16000
     x_off = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).tolist()
@@ -202,6 +202,54 @@ def test_full_analysis_chain_matches_reference_cmp(gpu, golden_dir):
         assert np.sqrt(np.mean((bap[a:b, 0].cpu().numpy() - cmp_[:, 64]) ** 2)) < 1e-6
         assert np.sqrt(np.mean((mc[a:b].cpu().numpy() - cmp_[:, :20]) ** 2)) < 1e-6
         assert np.abs(mc[a:b].cpu().numpy() - cmp_[:, :20]).max() <= 1e-6
+
+
+def test_decode_aperiodicity_inverts_the_reference_held_bap(gpu, golden_dir):
+    """itts_decode_aperiodicity on the bap column of every reference `.cmp`, coded again by
+    itts_code_aperiodicity (the pinned direction): the round trip returns the stored values, and
+    the HIP decoder equals the oracle's."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    fs = 16000
+    for i in range(1, 10):
+        cmp_ = np.fromfile(os.path.join(golden_dir, "LJ001-000%d.cmp" % i), dtype=np.float32).reshape(-1, 67)
+        bap = cmp_[:, 64:65].astype(np.float64)
+        ap = ops.decode_aperiodicity(torch.from_numpy(bap).to(gpu), fs, 1024)
+        ap_ref = capi.decode_aperiodicity(bap, fs, 1024)
+        assert np.abs(ap.cpu().numpy() - ap_ref).max() < 1e-12
+        back = ops.code_aperiodicity(ap, fs).cpu().numpy()
+        voiced = bap[:, 0] < -0.5
+        assert np.abs(back[voiced] - bap[voiced]).max() < 1e-9
+        assert np.abs(back[~voiced]).max() < 1e-9
+
+
+def test_analysis_of_the_reference_48k_fixture_matches_oracle(gpu, golden_dir):
+    """The reference's own 48 kHz audio (fixtures/database/wav48/p225_001.wav,
+    test_WorldFeatLabelGen.py:611-629): the whole file, HIP against the C oracle -- identical V/UV
+    decisions, f0 / bap / mcep within the north star's 1e-4 RMSE by orders of magnitude."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    fs, w = wavfile.read(os.path.join(golden_dir, "p225_001.wav"))
+    assert fs == 48000
+    x = w.astype(np.float64) / 32768.0
+    T = int(1000.0 * len(x) / fs / 5.0) + 1
+    xg = torch.from_numpy(x).to(gpu)
+    f0 = ops.stonemask(xg, [0, len(x)], ops.dio(xg, [0, len(x)], [0, T], fs), [0, T], fs)
+    f0_ref, sp_ref, ap_ref = capi.wav2world(x, fs)
+    assert (f0_ref > 0).sum() > 100
+    assert np.array_equal(f0.cpu().numpy() == 0, f0_ref == 0)
+    assert np.abs(f0.cpu().numpy() - f0_ref).max() < 1e-6
+    _, bap = ops.d4c(xg, [0, len(x)], f0, [0, T], fs, want_ap=False, want_bap=torch.float64)
+    bap_ref = capi.code_aperiodicity(ap_ref, fs)
+    assert bap.shape[1] == 5
+    assert np.array_equal(bap.cpu().numpy()[:, 0] > -1e-6, bap_ref[:, 0] > -1e-6)   # LoveTrain V/UV
+    assert np.sqrt(np.mean((bap.cpu().numpy() - bap_ref) ** 2)) < 1e-5
+    sp, mc, iters = ops.cheaptrick_mcep(xg, [0, len(x)], f0, [0, T], fs, order=59, alpha=0.77,
+                                        mc_dtype=torch.float64, want_iters=True)
+    assert np.abs(sp.cpu().numpy() / sp_ref - 1).max() < 1e-6
+    mc_ref, it_ref = capi.mcep(np.sqrt(sp_ref), 59, 0.77, return_iters=True)
+    assert np.array_equal(iters.cpu().numpy(), it_ref)                              # same Newton trip counts
+    assert np.sqrt(np.mean((mc.cpu().numpy() - mc_ref) ** 2)) < 1e-7
 
 
 def test_analysis_48k_synthetic_matches_oracle(gpu):

@@ -280,6 +280,25 @@ def test_native_question_labels_equal_the_regex_formulation(golden_dir, tmp_path
         want = ref.load_labels_with_state_alignment(f)
         assert np.array_equal(block[off[k]:off[k + 1]], want), f
         assert np.array_equal(nat.load_labels_with_state_alignment(f), want)
+    # perform_normalisation works in chunks of files (bounded memory): any chunk size gives the same
+    # archives, dictionary and min / max as the file-by-file formulation
+    import os as _os
+    want_dict, want_params = ref.perform_normalisation("ids.txt", ids, lab_dir, str(tmp_path / "q_ref"),
+                                                       return_dict=True)
+    for chunk in ("2", "256"):
+        _os.environ["ITTS_LABEL_CHUNK_FILES"] = chunk
+        try:
+            got_dict, got_params = nat.perform_normalisation("ids.txt", ids, lab_dir,
+                                                             str(tmp_path / ("q_nat" + chunk)), return_dict=True)
+        finally:
+            del _os.environ["ITTS_LABEL_CHUNK_FILES"]
+        assert list(got_dict) == list(want_dict)
+        for k in want_dict:
+            assert np.array_equal(got_dict[k], want_dict[k].astype(np.float32))
+            assert np.array_equal(np.load(str(tmp_path / ("q_nat" + chunk) / (k + ".npz")))["questions"],
+                                  np.load(str(tmp_path / "q_ref" / (k + ".npz")))["questions"])
+        for a, b in zip(got_params, want_params):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
     # adversarial question file
     qs = tmp_path / "q.hed"
     qs.write_text("\n".join([
