@@ -810,7 +810,7 @@ def main():
     out = None
     if rank == 0:
         # dominant kernel roofline: the fp32-MFMA GEMM launches of one step, timed live with
-        # events on the launch stream around a GEMM-only replay of the step's 8 GEMM launches.
+        # events on the launch stream around a GEMM-only replay of the six GEMM launches of the step.
         from idiaptts_amd import ops
         x, y, valid, nloc = batches[0]
         hs = model.forward(x)
@@ -824,11 +824,12 @@ def main():
             h1 = ops.linear_fwd(x, W(0), model.bias(0), 1, out=buf("h0", M, dims[1]))
             h2 = ops.linear_fwd(h1, W(1), model.bias(1), 1, out=buf("h1", M, dims[2]))
             ops.linear_fwd(h2, W(2), model.bias(2), 0, out=buf("h2", M, dims[3]))
-            ops.linear_bwd_weight(dz3, h2, dw=W(2, G), want_bias=False)
-            dz2 = ops.linear_bwd_input(dz3, W(2), yprev=h2, act_prev=1, out=buf("dz0", M, dims[2]))
-            ops.linear_bwd_weight(dz2, h1, dw=W(1, G), want_bias=False)
-            dz1 = ops.linear_bwd_input(dz2, W(1), yprev=h1, act_prev=1, out=buf("dz1", M, dims[1]))
-            ops.linear_bwd_weight(dz1, x, dw=W(0, G), want_bias=False)
+            # the backward launches of the step (native_ff.loss_and_backward): weight, bias and input
+            # gradient of a layer share one launch
+            dz2, dz1 = buf("dz0", M, dims[2]), buf("dz1", M, dims[1])
+            ops.linear_bwd(dz3, h2, W(2), W(2, G), model.bias(2, G), dz2, yprev=h2, act_prev=1)
+            ops.linear_bwd(dz2, h1, W(1), W(1, G), model.bias(1, G), dz1, yprev=h1, act_prev=1)
+            ops.linear_bwd_weight(dz1, x, dw=W(0, G), db=model.bias(0, G))
 
         for _ in range(20):      # the RNN sections above leave the clocks low: ramp up first
             gemms()
@@ -837,17 +838,20 @@ def main():
         flops = flops_per_frame(dims) * nloc
         achieved = flops / (ms * 1e-3) / 1e12
         # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # see profiles/r2m_gemm_traffic.json); not re-measured inside bench.py.
+        # see profiles/r3_gemm_traffic.json); not re-measured inside bench.py.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2m_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
         if os.path.isfile(tpath) and args.utts_per_gpu == 32:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (8 launches per step)",
+        n_launch = 6    # fwd1, fwd2, fwd3 + MSE, (dW3, db3, dX2), (dW2, db2, dX1), (dW1, db1)
+        roofline = {"bound": "mfma",
+                    "kernel": "gemm_ring_kernel / gemm_ring_pair_kernel (6 GEMM launches per step; their "
+                              "split-K slab reductions are inside the timed region)",
                     "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
-                    "algorithmic_flops_per_launch": flops / 8.0,
-                    "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / 8.0}
+                    "algorithmic_flops_per_launch": flops / n_launch,
+                    "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / n_launch}
         cpu = None
         if want_cpu:   # CPU baseline: rank 0 at N = 1 only
             cpu = cpu_baseline_ff(args.utts_per_gpu, max_seconds=min(20.0, args.cpu_budget_s / 4))

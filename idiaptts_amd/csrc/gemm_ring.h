@@ -423,7 +423,16 @@ __device__ __forceinline__ void epilogue(const Args& g, const Tile& pc, const f3
         v.z *= dact1<ACT>(y[2]); v.w *= dact1<ACT>(y[3]);
       }
       if (EPI == EPI_MSE) {
-        const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rx, xofs, rl * g.ldaux * 4, 0);
+        // the target may have any pitch (e.g. 187 floats): four dword loads, not one 16-byte load
+        f32x4 t;
+        {
+          const uint32_t so = (uint32_t)(rl * g.ldaux * 4);
+          const uint32_t tofs = (uint32_t)((rloc * g.ldaux + col) * 4);
+          t[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, tofs, so, 0));
+          t[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, tofs + 4, so, 0));
+          t[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, tofs + 8, so, 0));
+          t[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, tofs + 12, so, 0));
+        }
         const int row = pc.m0 + rloc + rl;
         const bool ok = row < g.M && g.row_valid[row < g.M ? row : 0] != 0;
         const float d0 = ok && k0 ? (v.x + bv.x) - t[0] : 0.f;

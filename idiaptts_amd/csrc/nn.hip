@@ -435,7 +435,7 @@ template <bool A_ROW, bool B_ROW>
 static bool ring_ok(const GemmArgs& g, int splitk, int epi) {
   if (!ring_enabled() || !g.vecA || !g.vecB) return false;
   if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || g.slab_stride % 4 || !aligned16(g.C)) return false;
-  if ((epi == EPI_DACT || epi == EPI_MSE) && (g.ldaux % 4 || !aligned16(g.aux))) return false;
+  if (epi == EPI_DACT && (g.ldaux % 4 || !aligned16(g.aux))) return false;   // the MSE target is read dword-wise
   const int64_t lim = (int64_t)1 << 30;   // 32-bit byte offsets inside the buffer descriptors
   if (g.M >= lim || g.K >= lim || g.lda >= lim / 256 || g.ldb >= lim / 256 || g.ldc >= lim / 256 ||
       g.ldaux >= lim / 256)
@@ -893,7 +893,7 @@ extern "C" int itts_linear_fwd_mse(const float* d_x, int64_t ldx, const float* d
   g.loss_partial = reinterpret_cast<double*>(d_workspace);
   int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
   int rc;
-  if (ring_ok<true, true>(g, 1, EPI_MSE) && (ldt % 4 == 0) && aligned16(d_target)) {
+  if (ring_ok<true, true>(g, 1, EPI_MSE)) {
     tiles = std::min<int64_t>(kRingGrid, (tiles + 7) / 8 * 8);   // partial sums per persistent workgroup
     rc = launch_ring_wm<true, true, EPI_MSE, 2>(g, 1, s);
   } else {
@@ -1028,8 +1028,8 @@ extern "C" int itts_linear_bwd(const float* d_dz, int64_t lddz, const float* d_x
   const int64_t n = (int64_t)N * K;
   const bool merged = d_db && d_db == d_dw + n && N % 4 == 0 && n % 4 == 0;
   static const int pair_on = [] { const char* e = getenv("ITTS_GEMM_PAIR"); return e ? atoi(e) : 1; }();
-  bool fused = pair_on && ring_enabled() && vec_ok && M > 0 && (merged || !d_db) && (lddx % 4 == 0) &&
-               aligned16(d_dx) && (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
+  bool fused = pair_on && ring_enabled() && vec_ok && M > 0 && (lddx % 4 == 0) && aligned16(d_dx) &&
+               (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
   GemmArgs gw{}, gx{};
   int S_eff = 1;
   if (fused) {
@@ -1043,6 +1043,7 @@ extern "C" int itts_linear_bwd(const float* d_dz, int64_t lddz, const float* d_x
     const int64_t stride = merged ? n + N : n;
     gw.slab_stride = stride;
     if (merged) { gw.bias_part = slabs + n; gw.bias_part_stride = stride; }
+    else if (d_db) { gw.bias_part = slabs + (int64_t)S_eff * n; gw.bias_part_stride = N; }
     gx.A = d_dz; gx.lda = lddz; gx.B = d_w; gx.ldb = K; gx.C = d_dx; gx.ldc = lddx;
     gx.M = M; gx.N = K; gx.K = N; gx.aux = d_yprev; gx.ldaux = ldyp; gx.act = act_prev;
     gx.kchunk = ((N + BK - 1) / BK) * BK; gx.vecA = gx.vecB = 1;
@@ -1059,7 +1060,9 @@ extern "C" int itts_linear_bwd(const float* d_dz, int64_t lddz, const float* d_x
   else rc = wm == 1 ? launch_ring_bwd_pair<1, EPI_STORE>(gw, S_eff, gx, s) : launch_ring_bwd_pair<2, EPI_STORE>(gw, S_eff, gx, s);
   if (rc) return rc;
   float* slabs = reinterpret_cast<float*>(d_workspace);
-  return launch_reduce_slabs(slabs, S_eff, merged ? n + N : n, d_dw, accumulate, s);
+  rc = launch_reduce_slabs(slabs, S_eff, merged ? n + N : n, d_dw, accumulate, s);
+  if (rc || merged || !d_db) return rc;
+  return launch_reduce_slabs(slabs + (int64_t)S_eff * n, S_eff, (int64_t)N, d_db, accumulate, s);
 }
 
 static int mse_blocks(int64_t M, int D) {

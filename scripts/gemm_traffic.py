@@ -12,7 +12,7 @@ def total(d, counter):
     f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[-1]
     s, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if "gemm_f32_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if ("gemm_ring" in r["Kernel_Name"] or "gemm_f32_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
     return s, n, f
@@ -21,7 +21,7 @@ def total(d, counter):
 fetch, n, ff = total(sys.argv[1], "FETCH_SIZE")
 write, n2, wf = total(sys.argv[2], "WRITE_SIZE")
 assert n == n2 and n > 0
-out = {"kernel": "gemm_f32_kernel", "launches": n, "fetch_size_kb_sum": fetch,
+out = {"kernel": "gemm_ring_kernel + gemm_ring_pair_kernel (the GEMM launches of the FF step)", "launches": n, "fetch_size_kb_sum": fetch,
        "write_size_kb_sum": write,
        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n,
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `" + sys.argv[4] +
