@@ -401,6 +401,22 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                                     "frac": gbs / PEAK_HBM_GBS / n_ranks, "traffic": ml_traffic,
                                     "algorithmic_bytes_per_launch": ml_frames / n_ranks * 2000,
                                     "algorithmic_bytes_per_frame": 2000}}
+        # the same solve at larger batches: where the kernel stops being bound by how long one round
+        # of workgroups holds its registers and starts to stream
+        curve = []
+        for n_u in (1024, 4096):
+            off_b = world.offsets(utterance_lengths(n_u, seed=5).tolist())
+            fr = off_b[-1]
+            feat_b = torch.randn(fr, 186, dtype=torch.float64, device=dev)
+            ops.mlpg_generation(feat_b, var, 62, off_b)
+            sync()
+            ms_b = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat_b, var, 62, off_b),
+                                                  stream, 5), dist.ReduceOp.MAX)
+            curve.append({"utterances": n_u, "frames": fr, "ms": ms_b,
+                          "algorithmic_GBps": fr * 2000 / (ms_b * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": fr * 2000 / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS})
+            del feat_b
+        res["mlpg"]["batch_curve"] = curve
     if with_cpu:
         from oracle import capi
         t0 = time.perf_counter()
