@@ -544,12 +544,18 @@ __global__ __launch_bounds__(64) void mlpg_chunk_kernel(MlpgArgs a, int t_max) {
 // and read until the two words are complements -- a torn or missing pair never validates.
 constexpr int FU_MAX_SC = 64;      // super-chunks per utterance the fused path accepts
 
+struct alignas(32) FuRecord {
+  long long t0;          // first frame of the utterance in the batch
+  int T;                 // its length
+  int k0;                // first chunk of the super-chunk (index inside the utterance)
+  int sc_first, sc_end;  // the utterance's super-chunks are [sc_first, sc_end)
+  int pad[2];
+};
+
 struct FusedArgs {
   MlpgArgs a;
   int t_max;
-  const int* sc_utt;     // [n_sc] utterance of the super-chunk
-  const int* sc_k0;      // [n_sc] its first chunk (index inside the utterance)
-  const int* utt_sc0;    // [U+1] first super-chunk of every utterance
+  const FuRecord* rec;   // [n_sc] one record per super-chunk (everything a workgroup needs to start)
   int n_sc, nblk;
   unsigned* ticket;
   unsigned long long* agg;   // [n_sc][12][2][nblk * 64]
@@ -595,16 +601,9 @@ __device__ __forceinline__ double fu_consume(const unsigned long long* p, int64_
 __device__ __forceinline__ void fu_consume6(const unsigned long long* p, int64_t stride,
                                             const unsigned long long* flag, double (&v)[6],
                                             int& budget, int* err) {
-  if ((threadIdx.x & 63) == 0) {
-    for (;;) {
-      const unsigned long long x = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long y = __hip_atomic_load(flag + stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (x == ~y || --budget <= 0) break;
-      __builtin_amdgcn_s_sleep(32);
-    }
-  }
-  budget = __shfl(budget, 0, 64);
   for (;;) {
+    // optimistic: the owner usually published before this wave got here, so ask for all twelve
+    // words at once (one trip to memory instead of a poll followed by the fetch)
     unsigned long long x[6], y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -621,7 +620,45 @@ __device__ __forceinline__ void fu_consume6(const unsigned long long* p, int64_t
       if ((threadIdx.x & 63) == 0) atomicExch(err, 1);
       return;
     }
-    __builtin_amdgcn_s_sleep(16);
+    if ((threadIdx.x & 63) == 0) {
+      for (;;) {
+        const unsigned long long fx = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long fy = __hip_atomic_load(flag + stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fx == ~fy || --budget <= 0) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+    }
+    budget = __shfl(budget, 0, 64);
+  }
+}
+
+// The entry state of a workgroup: the aggregates (M, e) of the utterance's other super-chunks
+// `first`, first + step, ... (count of them) folded in that order into (s1, s2).  The waves share
+// the work -- wave w fetches aggregate w of every round of FW, so the trips to memory run side by
+// side instead of one after the other, and each aggregate is fetched once per workgroup instead
+// of once per wave -- and meet in LDS; every wave then folds the same values in the same order.
+template <int FW>
+__device__ __forceinline__ void fu_gather_state(const FusedArgs& g, double (*xch)[6][64], int first, int step,
+                                                int count, int64_t word0, int64_t Dp, int64_t ccol,
+                                                int64_t flag_col, int w, int lane, int& budget,
+                                                double& s1, double& s2) {
+  for (int base = 0; base < count; base += FW) {
+    const int here = count - base < FW ? count - base : FW;
+    if (base > 0) __syncthreads();
+    if (w < here) {
+      const int p = first + (base + w) * step;
+      const unsigned long long* pa = g.agg + (int64_t)p * 24 * Dp + word0 * Dp;
+      double av[6];
+      fu_consume6(pa + ccol, Dp, pa + 10 * Dp + flag_col, av, budget, g.err);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xch[w][i][lane] = av[i];
+    }
+    __syncthreads();
+    for (int i = 0; i < here; ++i) {
+      const double n1 = xch[i][0][lane] * s1 + xch[i][1][lane] * s2 + xch[i][4][lane];
+      const double n2 = xch[i][2][lane] * s1 + xch[i][3][lane] * s2 + xch[i][5][lane];
+      s1 = n1; s2 = n2;
+    }
   }
 }
 
@@ -754,41 +791,57 @@ __global__ __launch_bounds__(FW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 void mlpg_fused_kernel(FusedArgs g) {
   __shared__ double lds_f[FW][6][64];
   __shared__ double lds_b[FW][6][64];
-  __shared__ unsigned s_ticket;
+  __shared__ double lds_x[FW][6][64];
+  __shared__ unsigned s_ticket[2];
   const MlpgArgs& a = g.a;
-  if (threadIdx.x == 0) s_ticket = atomicAdd(g.ticket, 1u);
-  __syncthreads();
-  const int sc = (int)(s_ticket / (unsigned)g.nblk), db = (int)(s_ticket % (unsigned)g.nblk);
+  // Persistent workgroups: the grid is what the chip holds at once and every workgroup takes
+  // super-chunks off the ticket counter until none is left -- no dispatch, kernel-argument and
+  // constant traffic between two super-chunks, and the next ticket is requested while the last
+  // sweep of the current one runs.
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int D = a.dim;
-  const bool dok = db * 64 + lane < D;
-  const int d = dok ? db * 64 + lane : D - 1;
-  const int u = g.sc_utt[sc];
-  const int64_t t0 = a.offsets[u];
-  const int64_t T = a.offsets[u + 1] - t0;
+  const int64_t Dp = (int64_t)g.nblk * 64;
+  const unsigned n_tickets = (unsigned)g.n_sc * (unsigned)g.nblk;
+  if (threadIdx.x == 0) s_ticket[0] = atomicAdd(g.ticket, 1u);
+  __syncthreads();
+  unsigned ticket = s_ticket[0];
+  int parity = 0, db_have = -1;
+  bool dok = false;
+  int d = 0;
+  double v0 = 1.0, v1 = 1.0, v2 = 1.0;
+  FuFac c;
+  const int64_t plane = (int64_t)g.t_max * D;
+  while (ticket < n_tickets) {
+  const int sc = (int)(ticket / (unsigned)g.nblk), db = (int)(ticket % (unsigned)g.nblk);
+  const FuRecord rec = g.rec[sc];
+  if (db != db_have) {          // per-dimension constants: once per workgroup when dim <= 64
+    db_have = db;
+    dok = db * 64 + lane < D;
+    d = dok ? db * 64 + lane : D - 1;
+    v0 = a.var[d]; v1 = a.var[D + d]; v2 = a.var[2 * D + d];
+    c.fd = a.scratch + d; c.fl1 = c.fd + plane; c.fl2 = c.fl1 + plane;
+    c.ncv = a.nconv[d]; c.D = D;
+    c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
+  }
+  const int64_t t0 = rec.t0;
+  const int64_t T = rec.T;
   const int K = fu_num_chunks<FU_FL>(T);
-  const int k = g.sc_k0[sc] + w;
+  const int k = rec.k0 + w;
   const bool wact = k < K;
   const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
   const int n = wact ? (int)(j1 - j0) : 0;
-  const int64_t Dp = (int64_t)g.nblk * 64;
   const int64_t dcol = (int64_t)db * 64 + lane;
-  unsigned long long* tr = g.trace ? g.trace + ((int64_t)s_ticket * FW + w) * 8 : nullptr;
+  unsigned long long* tr = g.trace ? g.trace + ((int64_t)ticket * FW + w) * 8 : nullptr;
 #define FU_STAMP(i) do { if (tr && lane == 0) tr[i] = wall_clock64(); } while (0)
   FU_STAMP(0);
-  if (g.stagger_n > 0 && (int)s_ticket < g.stagger_n) {
+  if (g.stagger_n > 0 && (int)ticket < g.stagger_n) {
     // first round only: spread the start of the resident workgroups (they would otherwise all
     // load, all compute and all wait at the same time, round after round)
-    const int steps = (int)((int64_t)s_ticket * g.stagger_steps / g.stagger_n);
+    const int steps = (int)((int64_t)ticket * g.stagger_steps / g.stagger_n);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
-  const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
-  FuFac c;
-  const int64_t plane = (int64_t)g.t_max * D;
-  c.fd = a.scratch + d; c.fl1 = c.fd + plane; c.fl2 = c.fl1 + plane;
-  c.ncv = a.nconv[d]; c.n_shared = T >= 3 ? T - 2 : 0; c.T = T; c.D = D;
-  c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
+  c.n_shared = T >= 3 ? T - 2 : 0; c.T = T;
 
   double b[FU_FL];
   double M[4] = {1.0, 0.0, 0.0, 1.0}, e[2] = {0.0, 0.0}, tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
@@ -888,15 +941,8 @@ void mlpg_fused_kernel(FusedArgs g) {
   double s1 = 0.0, s2 = 0.0;
   int budget = 1 << 21;          // ~2 s of polling at most
   const int64_t ccol = (int64_t)db * 64 + (dok ? lane : 0);     // idle lanes re-read column 0
-  if (wact) {
-    for (int p = g.utt_sc0[u]; p < sc; ++p) {
-      const unsigned long long* pa = g.agg + (int64_t)p * 24 * Dp + ccol;
-      double av[6];
-      fu_consume6(pa, Dp, g.agg + (int64_t)p * 24 * Dp + 10 * Dp + (int64_t)db * 64, av, budget, g.err);
-      const double n1 = av[0] * s1 + av[1] * s2 + av[4], n2 = av[2] * s1 + av[3] * s2 + av[5];
-      s1 = n1; s2 = n2;
-    }
-  }
+  fu_gather_state<FW>(g, lds_x, rec.sc_first, 1, sc - rec.sc_first, 0, Dp, ccol, (int64_t)db * 64, w, lane,
+                      budget, s1, s2);
   {
     const double n1 = Pw[0] * s1 + Pw[1] * s2 + qw[0], n2 = Pw[2] * s1 + Pw[3] * s2 + qw[1];
     s1 = n1; s2 = n2;
@@ -942,25 +988,27 @@ void mlpg_fused_kernel(FusedArgs g) {
   }
   FU_STAMP(6);
   s1 = s2 = 0.0;
-  if (wact) {
-    for (int p = g.utt_sc0[u + 1] - 1; p > sc; --p) {
-      const unsigned long long* pa = g.agg + (int64_t)p * 24 * Dp + 12 * Dp + ccol;
-      double av[6];
-      fu_consume6(pa, Dp, g.agg + (int64_t)p * 24 * Dp + 22 * Dp + (int64_t)db * 64, av, budget, g.err);
-      const double n1 = av[0] * s1 + av[1] * s2 + av[4], n2 = av[2] * s1 + av[3] * s2 + av[5];
-      s1 = n1; s2 = n2;
-    }
-  }
+  // (lds_x is free again: every wave passed the barrier above after its forward fold)
+  fu_gather_state<FW>(g, lds_x, rec.sc_end - 1, -1, rec.sc_end - 1 - sc, 12, Dp, ccol,
+                      (int64_t)db * 64, w, lane, budget, s1, s2);
   {
     const double n1 = Pw[0] * s1 + Pw[1] * s2 + qw[0], n2 = Pw[2] * s1 + Pw[3] * s2 + qw[1];
     s1 = n1; s2 = n2;
   }
+  // every wait of this super-chunk is over: take the next ticket now (not earlier -- a workgroup
+  // that holds a ticket it has not started could be the one its own wait is for), its trip to the
+  // counter runs under the last sweep
+  if (threadIdx.x == 0) s_ticket[parity ^ 1] = atomicAdd(g.ticket, 1u);
   if (wact) {
     double* o = a.out + t0 * a.ld_out + a.ocol0 + d;
     if (cst) fu_bwd<FU_FL, true, false>(c, b, j0, n, s1, s2, M, e, tl, o, a.ld_out, dok);
     else fu_bwd<FU_FL, false, false>(c, b, j0, n, s1, s2, M, e, tl, o, a.ld_out, dok);
   }
   FU_STAMP(7);
+  __syncthreads();
+  parity ^= 1;
+  ticket = s_ticket[parity];
+  }
 #undef FU_STAMP
 }
 
@@ -1008,7 +1056,8 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   hipLaunchKernelGGL(mlpg_factor_kernel, dim3((dim + 63) / 64), dim3(64), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
   const int kchunks = mlpg_num_chunks(t_max);
-  if (kchunks < 3) {      // short utterances: the sequential sweeps are as fast
+  const char* seq = getenv("ITTS_MLPG_SEQ");
+  if (kchunks < 3 || (seq && seq[0] == '1')) {      // short utterances: the sequential sweeps are as fast
     dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
     hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
     ITTS_LAUNCH_CHECK();
@@ -1018,43 +1067,41 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   // is so long that its super-chunks could exhaust the resident workgroups (see the kernel)
   // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW> picks one of the
   // compiled variants; experiments)
-  int FL = 16, FW = 16;
-  if (const char* geom = getenv("ITTS_MLPG_GEOM")) sscanf(geom, "%dx%d", &FL, &FW);
+  int FL = 8, FW = 16, WPE = 0;
+  if (const char* geom = getenv("ITTS_MLPG_GEOM")) sscanf(geom, "%dx%dx%d", &FL, &FW, &WPE);
   const int64_t sc_frames = (int64_t)FL * FW;
   const char* force = getenv("ITTS_MLPG_MULTIPASS");
   if (t_max <= sc_frames * FU_MAX_SC && !(force && force[0] == '1')) {
-    std::vector<int> tab;
-    std::vector<int> sc_utt, sc_k0, utt_sc0(n_utts + 1, 0);
+    std::vector<FuRecord> recs;
     for (int u = 0; u < n_utts; ++u) {
       const int64_t T = h_offsets[u + 1] - h_offsets[u];
-      utt_sc0[u] = (int)sc_utt.size();
+      const int first = (int)recs.size();
       const int K = T > 0 ? (int)((T + FL - 1) / FL) : 0;
       for (int k0 = 0; k0 < K; k0 += FW) {
-        sc_utt.push_back(u);
-        sc_k0.push_back(k0);
+        FuRecord r{};
+        r.t0 = h_offsets[u];
+        r.T = (int)T;
+        r.k0 = k0;
+        r.sc_first = first;
+        recs.push_back(r);
       }
+      for (size_t i = first; i < recs.size(); ++i) recs[i].sc_end = (int)recs.size();
     }
-    utt_sc0[n_utts] = (int)sc_utt.size();
-    const int n_sc = (int)sc_utt.size();
+    const int n_sc = (int)recs.size();
     const int nblk = (dim + 63) / 64;
-    tab.insert(tab.end(), sc_utt.begin(), sc_utt.end());
-    tab.insert(tab.end(), sc_k0.begin(), sc_k0.end());
-    tab.insert(tab.end(), utt_sc0.begin(), utt_sc0.end());
-    tab.push_back(0);                                           // ticket counter
-    tab.push_back(0);                                           // error flag
-    const size_t tab_bytes = (tab.size() * sizeof(int) + 15) / 16 * 16;
+    // [records | ticket counter, error flag | aggregates (zeroed)]
+    const size_t rec_bytes = recs.size() * sizeof(FuRecord);
+    const size_t tab_bytes = rec_bytes + 32;
     const size_t agg_bytes = (size_t)n_sc * 24 * nblk * 64 * sizeof(unsigned long long);
     char* blk = nullptr;
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, tab_bytes + agg_bytes, s));
-    ITTS_HIP_CHECK(hipMemcpyAsync(blk, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    ITTS_HIP_CHECK(hipMemsetAsync(blk + tab_bytes, 0, agg_bytes, s));
+    ITTS_HIP_CHECK(hipMemcpyAsync(blk, recs.data(), rec_bytes, hipMemcpyHostToDevice, s));
+    ITTS_HIP_CHECK(hipMemsetAsync(blk + rec_bytes, 0, 32 + agg_bytes, s));
     FusedArgs g;
     g.a = a;
     g.t_max = (int)t_max;
-    g.sc_utt = reinterpret_cast<const int*>(blk);
-    g.sc_k0 = g.sc_utt + n_sc;
-    g.utt_sc0 = g.sc_k0 + n_sc;
-    g.ticket = reinterpret_cast<unsigned*>(const_cast<int*>(g.utt_sc0 + n_utts + 1));
+    g.rec = reinterpret_cast<const FuRecord*>(blk);
+    g.ticket = reinterpret_cast<unsigned*>(blk + rec_bytes);
     g.err = reinterpret_cast<int*>(g.ticket + 1);
     g.n_sc = n_sc;
     g.nblk = nblk;
@@ -1068,9 +1115,23 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
       ITTS_HIP_CHECK(hipMalloc((void**)&g.trace, trace_words * 8));
       ITTS_HIP_CHECK(hipMemset(g.trace, 0, trace_words * 8));
     }
-    const dim3 grid(n_sc * nblk);
+    // persistent grid: as many workgroups as the device holds at once (never more tickets than
+    // there are)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ITTS_HIP_CHECK(hipGetDevice(&dev));
+      ITTS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      n_cu = prop.multiProcessorCount;
+    }
+    const int64_t n_tickets = (int64_t)n_sc * nblk;
 #define FU_LAUNCH(fl, fw, wpe)                                                                  \
-  if (FL == fl && FW == fw) {                                                                    \
+  if (!launched && FL == fl && FW == fw && (WPE == 0 || WPE == wpe)) {                           \
+    int per_cu = 0;                                                                              \
+    ITTS_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(                                 \
+        &per_cu, mlpg_fused_kernel<fl, fw, wpe>, fw * 64, 0));                                   \
+    const dim3 grid((unsigned)std::min<int64_t>(n_tickets, (int64_t)std::max(per_cu, 1) * n_cu)); \
     hipLaunchKernelGGL((mlpg_fused_kernel<fl, fw, wpe>), grid, dim3(fw * 64), 0, s, g);          \
     launched = true;                                                                             \
   }
@@ -1078,6 +1139,9 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
     FU_LAUNCH(16, 16, 4)
     FU_LAUNCH(32, 16, 4)
     FU_LAUNCH(16, 8, 2)
+    FU_LAUNCH(16, 8, 4)
+    FU_LAUNCH(8, 16, 4)
+    FU_LAUNCH(8, 8, 4)
     FU_LAUNCH(24, 8, 2)
     FU_LAUNCH(16, 4, 2)
 #undef FU_LAUNCH

@@ -1,0 +1,48 @@
+"""MLPG solve time against batch size, fused scan vs sequential sweeps (ITTS_MLPG_SEQ=1).
+Usage (GPU box): python scripts/mlpg_curve.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from idiaptts_amd import ops, world                     # noqa: E402
+from idiaptts_amd.bench_support import utterance_lengths  # noqa: E402
+
+
+def timed(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+
+
+dev = torch.device("cuda", 0)
+var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
+for n_u in (256, 1024, 4096):
+    off = world.offsets(utterance_lengths(n_u, seed=5).tolist())
+    fr = off[-1]
+    feat = torch.randn(fr, 186, dtype=torch.float64, device=dev)
+    outs = {}
+    for mode in sys.argv[1:] or ("fused", "seq"):
+        os.environ.pop("ITTS_MLPG_SEQ", None)
+        os.environ.pop("ITTS_MLPG_STREAM", None)
+        if mode == "seq":
+            os.environ["ITTS_MLPG_SEQ"] = "1"
+        if mode == "stream":
+            os.environ["ITTS_MLPG_STREAM"] = "1"
+        ms = timed(lambda: ops.mlpg_generation(feat, var, 62, off))
+        outs[mode] = ops.mlpg_generation(feat, var, 62, off)
+        print("%5d utts %8d frames %-6s %8.3f ms  %6.1f GB/s algorithmic (%.1f %% of 8 TB/s)" % (
+            n_u, fr, mode, ms, fr * 2000 / ms / 1e6, fr * 2000 / ms / 1e6 / 80.0), flush=True)
+    keys = list(outs)
+    for k in keys[1:]:
+        print("      max |%s - %s| = %.3e" % (k, keys[0], float((outs[k] - outs[keys[0]]).abs().max())))
+    del feat, outs
