@@ -385,24 +385,23 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                                                stream, 7), dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
         gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
-        # HBM bytes of one solve from the committed PMC passes (profiles/r2k_mlpg_traffic.json:
+        # HBM bytes of one solve from the committed PMC passes (profiles/r3c_mlpg_traffic.json:
         # FETCH_SIZE x 2 + WRITE_SIZE on this same workload); not re-measured inside bench.py
         ml_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2k_mlpg_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3c_mlpg_traffic.json")
         if os.path.isfile(tpath):
             with open(tpath) as f:
-                ml_traffic = json.load(f)["kernels"]["mlpg_fused_kernel"]["hbm_bytes_per_solve"]
+                ml_traffic = json.load(f)["paths"]["stream"]["hbm_bytes_per_solve"]
         res["mlpg"] = {"utterances": 256 * n_ranks, "frames": ml_frames, "ms": ms_ml,
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
                        "algorithmic_GBps": gbs,
                        "frac_of_hbm_peak": gbs / PEAK_HBM_GBS / n_ranks,
-                       "roofline": {"bound": "hbm", "kernel": "mlpg_fused_kernel",
+                       "roofline": {"bound": "hbm", "kernel": "mlpg_reduce_kernel + mlpg_scan_kernel + mlpg_solve_kernel",
                                     "achieved": gbs / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": gbs / PEAK_HBM_GBS / n_ranks, "traffic": ml_traffic,
                                     "algorithmic_bytes_per_launch": ml_frames / n_ranks * 2000,
                                     "algorithmic_bytes_per_frame": 2000}}
-        # the same solve at larger batches: where the kernel stops being bound by how long one round
-        # of workgroups holds its registers and starts to stream
+        # the same solve at larger batches
         curve = []
         for n_u in (1024, 4096):
             off_b = world.offsets(utterance_lengths(n_u, seed=5).tolist())

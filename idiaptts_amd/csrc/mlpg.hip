@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -565,7 +566,7 @@ struct FusedArgs {
 };
 
 template <int FU_FL>
-__device__ __forceinline__ int fu_num_chunks(int64_t T) { return (int)((T + FU_FL - 1) / FU_FL); }
+__device__ __host__ __forceinline__ int fu_num_chunks(int64_t T) { return (int)((T + FU_FL - 1) / FU_FL); }
 // the last chunk always holds both re-derived tail frames: a one-frame remainder takes a frame
 // from the chunk before it
 template <int FU_FL>
@@ -692,6 +693,13 @@ struct FuFac {
   }
 };
 
+// how many of the chunk's n frames starting at j0 take the shared factor (the rest -- at most the
+// utterance's last two -- are re-derived)
+__device__ __forceinline__ int fu_shared_frames(const FuFac& c, int64_t j0, int n) {
+  const int64_t m = c.n_shared - j0;
+  return m <= 0 ? 0 : (m < n ? (int)m : n);
+}
+
 // Forward sweep over the chunk [j0, j0 + n).  PASS_A: zero-state response e and the two unit
 // responses M, b untouched; else: from (s1, s2), y replaces b.  tl: factors of frames T-2, T-1.
 template <int FU_FL, bool CONST, bool PASS_A>
@@ -709,20 +717,19 @@ __device__ __forceinline__ void fu_fwd(const FuFac& c, double (&b)[FU_FL], int64
     if (c.n_shared == 0) l1p = l2p = cprev = 0.0;
   }
   double y1 = s1, y2 = s2, u1 = 1.0, u2 = 0.0, v1 = 0.0, v2 = 1.0;
+  // frames that take the shared factor first (unrolled), then the utterance's last two, whose
+  // factor is re-derived (a rolled loop: one copy of the square root and divisions in the code)
+  const int n_main = CONST ? FU_FL : fu_shared_frames(c, j0, n);
 #pragma unroll
   for (int i = 0; i < FU_FL; ++i) {
-    if (CONST || i < n) {
+    if (CONST || i < n_main) {
       const int64_t j = j0 + i;
       double dd, l1, l2;
       if (CONST) {
         dd = kd; l1 = k1; l2 = k2;
-      } else if (j < c.n_shared) {
+      } else {
         const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;
         dd = c.fd[jc]; l1 = c.fl1[jc]; l2 = c.fl2[jc];
-      } else {
-        c.derive(j, l1p, l2p, cprev, dd, l1, l2);
-        if (j == c.T - 1) { tl[3] = dd; tl[4] = l1; tl[5] = l2; }
-        else { tl[0] = dd; tl[1] = l1; tl[2] = l2; }
       }
       const double y = (b[i] - l1p * y1 - l2p * y2) * dd;
       if (PASS_A) {
@@ -731,6 +738,30 @@ __device__ __forceinline__ void fu_fwd(const FuFac& c, double (&b)[FU_FL], int64
         u2 = u1; u1 = u; v2 = v1; v1 = v;
       } else {
         b[i] = y;
+      }
+      y2 = y1; y1 = y;
+      l2p = cprev; l1p = l1; cprev = l2;
+    }
+  }
+  if (!CONST) {
+#pragma unroll 1
+    for (int i = n_main; i < n; ++i) {
+      const int64_t j = j0 + i;
+      double dd, l1, l2;
+      c.derive(j, l1p, l2p, cprev, dd, l1, l2);
+      if (j == c.T - 1) { tl[3] = dd; tl[4] = l1; tl[5] = l2; }
+      else { tl[0] = dd; tl[1] = l1; tl[2] = l2; }
+      double bi = 0.0;
+#pragma unroll
+      for (int r = 0; r < FU_FL; ++r) bi = r == i ? b[r] : bi;
+      const double y = (bi - l1p * y1 - l2p * y2) * dd;
+      if (PASS_A) {
+        const double u = (-l1p * u1 - l2p * u2) * dd;
+        const double v = (-l1p * v1 - l2p * v2) * dd;
+        u2 = u1; u1 = u; v2 = v1; v1 = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < FU_FL; ++r) b[r] = r == i ? y : b[r];
       }
       y2 = y1; y1 = y;
       l2p = cprev; l1p = l1; cprev = l2;
@@ -783,6 +814,68 @@ __device__ __forceinline__ void fu_bwd(const FuFac& c, double (&b)[FU_FL], int64
   if (PASS_A) {
     M[0] = u1; M[1] = v1; M[2] = u2; M[3] = v2;
     e[0] = x1; e[1] = x2;
+  }
+}
+
+// b = W^T (mean / var) of the frames [j0, j0 + n) of one utterance (mlpg.py:123) for this lane's
+// dimension; f: the lane's column in the utterance's first row.  `interior`: rows j0-1 .. j0+FL
+// all exist and none is an edge frame (no clamping, no edge variances).
+template <int FU_FL>
+__device__ __forceinline__ void fu_form_b(const MlpgArgs& a, const double* f, int64_t j0, int n, int64_t T,
+                                          bool interior, double v0, double v1, double v2,
+                                          double (&b)[FU_FL]) {
+  const int D = a.dim;
+  const bool cst = interior;
+  const double rv0 = 1.0 / v0, rv1 = 1.0 / v1, rv2 = 1.0 / v2, rvb = 1.0 / kBigVar;
+  if (cst) {
+    // interior chunk: rows j0-1 .. j0+FU_FL all exist and none is an edge frame
+    const double* r0 = f + j0 * a.ld_feat;
+#pragma unroll
+    for (int i = 0; i < FU_FL; ++i) b[i] = r0[(int64_t)i * a.ld_feat] * rv0;
+    {
+      double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+      for (int i = -1; i <= FU_FL; ++i) {
+        const double v = r0[(int64_t)i * a.ld_feat + D] * rv1;
+        if (i >= 1) b[i - 1] += 0.5 * (m2 - v);
+        m2 = m1; m1 = v;
+      }
+    }
+    {
+      double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+      for (int i = -1; i <= FU_FL; ++i) {
+        const double v = r0[(int64_t)i * a.ld_feat + 2 * D] * rv2;
+        if (i >= 1) b[i - 1] += (m2 - 2.0 * m1 + v);
+        m2 = m1; m1 = v;
+      }
+    }
+  } else {
+    auto rowp = [&](int64_t r) { return f + (r < 0 ? 0 : (r >= T ? T - 1 : r)) * a.ld_feat; };
+#pragma unroll
+    for (int i = 0; i < FU_FL; ++i) b[i] = i < n ? rowp(j0 + i)[0] * rv0 : 0.0;
+    {
+      double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+      for (int i = -1; i <= FU_FL; ++i) {
+        const int64_t r = j0 + i;
+        double v = 0.0;
+        if (i <= n && r >= 0 && r < T) v = rowp(r)[D] * ((r == 0 || r == T - 1) ? rvb : rv1);
+        if (i >= 1 && i - 1 < n) b[i - 1] += 0.5 * (m2 - v);
+        m2 = m1; m1 = v;
+      }
+    }
+    {
+      double m2 = 0.0, m1 = 0.0;
+#pragma unroll
+      for (int i = -1; i <= FU_FL; ++i) {
+        const int64_t r = j0 + i;
+        double v = 0.0;
+        if (i <= n && r >= 0 && r < T) v = rowp(r)[2 * D] * ((r == 0 || r == T - 1) ? rvb : rv2);
+        if (i >= 1 && i - 1 < n) b[i - 1] += (m2 - 2.0 * m1 + v);
+        m2 = m1; m1 = v;
+      }
+    }
   }
 }
 
@@ -851,58 +944,7 @@ void mlpg_fused_kernel(FusedArgs g) {
   const bool cst = __all(cst_lane || !wact) && wact;
 
   if (wact) {
-    const double rv0 = 1.0 / v0, rv1 = 1.0 / v1, rv2 = 1.0 / v2, rvb = 1.0 / kBigVar;
-    const double* f = a.feat + t0 * a.ld_feat + a.col0 + d;
-    if (cst) {
-      // interior chunk: rows j0-1 .. j0+FU_FL all exist and none is an edge frame
-      const double* r0 = f + j0 * a.ld_feat;
-#pragma unroll
-      for (int i = 0; i < FU_FL; ++i) b[i] = r0[(int64_t)i * a.ld_feat] * rv0;
-      {
-        double m2 = 0.0, m1 = 0.0;
-#pragma unroll
-        for (int i = -1; i <= FU_FL; ++i) {
-          const double v = r0[(int64_t)i * a.ld_feat + D] * rv1;
-          if (i >= 1) b[i - 1] += 0.5 * (m2 - v);
-          m2 = m1; m1 = v;
-        }
-      }
-      {
-        double m2 = 0.0, m1 = 0.0;
-#pragma unroll
-        for (int i = -1; i <= FU_FL; ++i) {
-          const double v = r0[(int64_t)i * a.ld_feat + 2 * D] * rv2;
-          if (i >= 1) b[i - 1] += (m2 - 2.0 * m1 + v);
-          m2 = m1; m1 = v;
-        }
-      }
-    } else {
-      auto rowp = [&](int64_t r) { return f + (r < 0 ? 0 : (r >= T ? T - 1 : r)) * a.ld_feat; };
-#pragma unroll
-      for (int i = 0; i < FU_FL; ++i) b[i] = i < n ? rowp(j0 + i)[0] * rv0 : 0.0;
-      {
-        double m2 = 0.0, m1 = 0.0;
-#pragma unroll
-        for (int i = -1; i <= FU_FL; ++i) {
-          const int64_t r = j0 + i;
-          double v = 0.0;
-          if (i <= n && r >= 0 && r < T) v = rowp(r)[D] * ((r == 0 || r == T - 1) ? rvb : rv1);
-          if (i >= 1 && i - 1 < n) b[i - 1] += 0.5 * (m2 - v);
-          m2 = m1; m1 = v;
-        }
-      }
-      {
-        double m2 = 0.0, m1 = 0.0;
-#pragma unroll
-        for (int i = -1; i <= FU_FL; ++i) {
-          const int64_t r = j0 + i;
-          double v = 0.0;
-          if (i <= n && r >= 0 && r < T) v = rowp(r)[2 * D] * ((r == 0 || r == T - 1) ? rvb : rv2);
-          if (i >= 1 && i - 1 < n) b[i - 1] += (m2 - 2.0 * m1 + v);
-          m2 = m1; m1 = v;
-        }
-      }
-    }
+    fu_form_b<FU_FL>(a, a.feat + t0 * a.ld_feat + a.col0 + d, j0, n, T, cst, v0, v1, v2, b);
     FU_STAMP(1);
     if (cst) fu_fwd<FU_FL, true, true>(c, b, j0, n, 0.0, 0.0, M, e, tl);
     else fu_fwd<FU_FL, false, true>(c, b, j0, n, 0.0, 0.0, M, e, tl);
@@ -1013,9 +1055,557 @@ void mlpg_fused_kernel(FusedArgs g) {
 }
 
 
+
+// ---- dependency-free solve: reduce -> scan -> solve ----------------------------------------------
+// The fused kernel above reads the input once, but its workgroups spend two thirds of their life
+// waiting for each other (every wait ends with the slowest load among the waves it depends on)
+// while their registers hold the chunk, and the registers bound how much of the batch is in
+// flight: 15-19 % of the HBM peak at any batch size.  This form has no
+// wait at all.  It rests on two facts: the forward sweep is linear in (b, entry state), and the
+// chunk-local backward sweep x = L_cc^-T y has the adjoint form x_0 = (L_cc^-1 e_0) . y,
+// x_1 = (L_cc^-1 e_1) . y -- so what the backward sweep of a chunk contributes to the chunk in
+// front of it can be accumulated WHILE WALKING FORWARD, as two dot products with the forward
+// impulse responses P = L_cc^-1 e_0 and R = L_cc^-1 e_1, without keeping y:
+//   reduce  every chunk, from a zero entry state: e_f = (y0_{n-1}, y0_{n-2}), e_b0 = (P.y0, R.y0);
+//           one streaming read of the input, four doubles out per (chunk, dimension), no state
+//   scan    per (utterance, dimension): s_in(k+1) = M_f s_in(k) + e_f(k), then backwards
+//           t_in(k-1) = M_b t_in(k) + e_b0(k) + C s_in(k); the matrices are data-independent --
+//           M_f = the entry state's image (a combination of the last two P, R), M_b = the exit
+//           state's image (P, R at the last two frames times the factor's off-diagonals),
+//           C = [P R]^T [U V] from the Gram sums P.P, P.R, R.R -- one set per dimension for the
+//           stationary chunks, recomputed in place for the few others (utterance start / tail)
+//   solve   every chunk again, now from its true states: input re-read, y in registers, x stored
+// HBM bytes per frame: 2 x 1496 (input twice) + 496 (output) + the aggregates (128 B per chunk
+// and dimension, written and read once each) against 2000 algorithmic.
+struct alignas(32) StRecord {
+  long long t0;      // first frame of the utterance in the batch
+  int T;             // its length
+  int k0;            // first chunk of this group (index inside the utterance)
+  int chunk;         // batch-wide index of that chunk
+  int pad[3];
+};
+
+struct StreamArgs {
+  MlpgArgs a;
+  int t_max;
+  const StRecord* rec;   // [n_groups] groups of ST_GW consecutive chunks of one utterance
+  const int* chunk0;     // [U+1] batch-wide index of every utterance's first chunk
+  int n_groups, nblk;
+  double* agg;           // [n_chunks][4][Dp]: e_f (2), e_b0 (2)
+  double* st;            // [n_chunks][4][Dp]: forward entry state (2), backward entry state (2)
+  unsigned long long* scan_trace;   // optional [U * nblk][ST_SW][8] wall-clock stamps (ITTS_MLPG_SCAN_TRACE)
+  int scan_sequential;   // test switch (ITTS_MLPG_SCAN_SEQ=1): every utterance takes st_scan_sequential
+};
+
+__device__ __forceinline__ bool getenv_scan_sequential(const StreamArgs& g) { return g.scan_sequential != 0; }
+
+constexpr int ST_GW = 4;       // chunks (= waves) per workgroup of the reduce / solve kernels
+
+struct FuMats { double Mf[4], Mb[4], C[4]; };
+
+// One forward walk over the chunk [j0, j0 + n) from a zero entry state, nothing kept.
+// DATA: e = (y0_{n-1}, y0_{n-2}, P.y0, R.y0).  MATS: the chunk's data-independent matrices.
+// PRELOAD (with !CONST): the chunk's factor rows are requested together before the walk instead of
+// inside its (lane-divergent) branches -- one trip to memory per chunk instead of one per frame.
+template <int FU_FL, bool CONST, bool DATA, bool MATS, bool PRELOAD = false>
+__device__ __forceinline__ void fu_reduce(const FuFac& c, const double (&b)[FU_FL], int64_t j0, int n,
+                                          double (&tl)[6], double (&e)[4], FuMats& m) {
+  double kd = 0.0, k1 = 0.0, k2 = 0.0;
+  double l1p, l2p, cprev;
+  double pd[PRELOAD ? FU_FL : 1], p1[PRELOAD ? FU_FL : 1], p2[PRELOAD ? FU_FL : 1];
+  if (PRELOAD && !CONST) {
+#pragma unroll
+    for (int i = 0; i < FU_FL; ++i) {
+      const int64_t j = j0 + i;
+      const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;      // always a valid row of the factor
+      pd[i] = c.fd[jc]; p1[i] = c.fl1[jc]; p2[i] = c.fl2[jc];
+    }
+  }
+  if (CONST) {
+    kd = c.fd[c.ncv * c.D];
+    k1 = c.fl1[c.ncv * c.D];
+    k2 = c.fl2[c.ncv * c.D];
+    l1p = k1; l2p = k2; cprev = k2;
+  } else {
+    l1p = c.F(c.fl1, j0 - 1); l2p = c.F(c.fl2, j0 - 2); cprev = c.F(c.fl2, j0 - 1);
+    if (c.n_shared == 0) l1p = l2p = cprev = 0.0;
+  }
+  double y1 = 0.0, y2 = 0.0, P1 = 0.0, P2 = 0.0, R1 = 0.0, R2 = 0.0;
+  double spy = 0.0, sry = 0.0, spp = 0.0, spr = 0.0, srr = 0.0;
+  double rho0u = 0.0, rho0v = 0.0, rho1u = 0.0;      // what the entry state adds to frames 0 and 1
+  double l1_last = 0.0, l2_last = 0.0, l2_prev = 0.0;  // own factor entries of frames n-1 and n-2
+  const int n_main = CONST ? FU_FL : fu_shared_frames(c, j0, n);
+  // one step of the walk; `first` / `second`: frame 0 / 1 of the chunk
+  auto step = [&](bool first, bool second, double dd, double l1, double l2, double bi) {
+    if (first) { rho0u = -l1p; rho0v = -l2p; }
+    if (second) rho1u = -l2p;
+    const double P = ((first ? 1.0 : 0.0) - l1p * P1 - l2p * P2) * dd;
+    const double R = ((second ? 1.0 : 0.0) - l1p * R1 - l2p * R2) * dd;
+    if (DATA) {
+      const double y = (bi - l1p * y1 - l2p * y2) * dd;
+      spy += P * y; sry += R * y;
+      y2 = y1; y1 = y;
+    }
+    if (MATS) { spp += P * P; spr += P * R; srr += R * R; }
+    P2 = P1; P1 = P; R2 = R1; R1 = R;
+    l2_prev = l2_last; l1_last = l1; l2_last = l2;
+    l2p = cprev; l1p = l1; cprev = l2;
+  };
+#pragma unroll
+  for (int i = 0; i < FU_FL; ++i) {
+    if (CONST || i < n_main) {
+      const int64_t j = j0 + i;
+      double dd, l1, l2;
+      if (CONST) {
+        dd = kd; l1 = k1; l2 = k2;
+      } else if (PRELOAD) {
+        dd = pd[i]; l1 = p1[i]; l2 = p2[i];
+      } else {
+        const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;
+        dd = c.fd[jc]; l1 = c.fl1[jc]; l2 = c.fl2[jc];
+      }
+      step(i == 0, i == 1, dd, l1, l2, DATA ? b[i] : 0.0);
+    }
+  }
+  if (!CONST) {      // the utterance's last two frames: factor re-derived (rolled: one copy)
+#pragma unroll 1
+    for (int i = n_main; i < n; ++i) {
+      const int64_t j = j0 + i;
+      double dd, l1, l2;
+      c.derive(j, l1p, l2p, cprev, dd, l1, l2);
+      if (j == c.T - 1) { tl[3] = dd; tl[4] = l1; tl[5] = l2; }
+      else { tl[0] = dd; tl[1] = l1; tl[2] = l2; }
+      double bi = 0.0;
+      if (DATA) {
+#pragma unroll
+        for (int r = 0; r < FU_FL; ++r) bi = r == i ? b[r] : bi;
+      }
+      step(i == 0, i == 1, dd, l1, l2, bi);
+    }
+  }
+  if (DATA) { e[0] = y1; e[1] = y2; e[2] = spy; e[3] = sry; }
+  if (MATS) {
+    m.Mf[0] = rho0u * P1 + rho1u * R1; m.Mf[1] = rho0v * P1;
+    m.Mf[2] = rho0u * P2 + rho1u * R2; m.Mf[3] = rho0v * P2;
+    m.Mb[0] = -l1_last * P1 - l2_prev * P2; m.Mb[1] = -l2_last * P1;
+    m.Mb[2] = -l1_last * R1 - l2_prev * R2; m.Mb[3] = -l2_last * R1;
+    m.C[0] = rho0u * spp + rho1u * spr; m.C[1] = rho0v * spp;
+    m.C[2] = rho0u * spr + rho1u * srr; m.C[3] = rho0v * spr;
+  }
+}
+
+// what the reduce and the solve kernel share: which chunk this wave owns, its lane's constants
+template <int FU_FL>
+struct StChunk {
+  int64_t t0, T, j0, j1;
+  int K, k, n, chunk, d;
+  bool dok, cst;
+  double v0, v1, v2;
+  FuFac c;
+  __device__ __forceinline__ bool open(const StreamArgs& g) {
+    const MlpgArgs& a = g.a;
+    const int grp = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const StRecord rec = g.rec[grp];
+    t0 = rec.t0; T = rec.T;
+    K = fu_num_chunks<FU_FL>(T);
+    k = rec.k0 + w;
+    if (k >= K) return false;
+    chunk = rec.chunk + w;
+    const int D = a.dim;
+    dok = db * 64 + lane < D;
+    d = dok ? db * 64 + lane : D - 1;
+    j0 = fu_chunk_start<FU_FL>(k, K, T); j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
+    n = (int)(j1 - j0);
+    v0 = a.var[d]; v1 = a.var[D + d]; v2 = a.var[2 * D + d];
+    const int64_t plane = (int64_t)g.t_max * D;
+    c.fd = a.scratch + d; c.fl1 = c.fd + plane; c.fl2 = c.fl1 + plane;
+    c.ncv = a.nconv[d]; c.n_shared = T >= 3 ? T - 2 : 0; c.T = T; c.D = D;
+    c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
+    const bool cst_lane = (j0 - 2 >= c.ncv) && (j1 <= c.n_shared) && n == FU_FL;
+    cst = __all(cst_lane);
+    return true;
+  }
+};
+
+template <int FU_FL>
+__global__ __launch_bounds__(ST_GW * 64) void mlpg_reduce_kernel(StreamArgs g) {
+  StChunk<FU_FL> q;
+  if (!q.open(g)) return;
+  if (q.K == 1) return;          // a one-chunk utterance has nobody to hand a state to
+  const MlpgArgs& a = g.a;
+  double b[FU_FL];
+  fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
+  double e[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+  FuMats unused;
+  if (q.cst) fu_reduce<FU_FL, true, true, false>(q.c, b, q.j0, q.n, tl, e, unused);
+  else fu_reduce<FU_FL, false, true, false>(q.c, b, q.j0, q.n, tl, e, unused);
+  if (q.dok) {
+    const int64_t Dp = (int64_t)g.nblk * 64;
+    double* o = g.agg + (int64_t)q.chunk * 4 * Dp + (blockIdx.x % (unsigned)g.nblk) * 64 + (threadIdx.x & 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[(int64_t)i * Dp] = e[i];
+  }
+}
+
+// the data-independent matrices of chunk k of an utterance (any chunk; not inlined: the scan kernel
+// calls it from many places and must stay small enough for the instruction cache)
+template <int FU_FL>
+__device__ __noinline__ void st_chunk_mats(const FuFac& c, int K, int64_t T, int k, FuMats& m) {
+  double none[FU_FL], e4[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+  const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
+  fu_reduce<FU_FL, false, false, true, true>(c, none, j0, (int)(j1 - j0), tl, e4, m);
+}
+
+// The plain sequential scan of one (utterance, 64 dimensions) by one wave: the road the scan
+// kernel takes when the factor settles so slowly that the utterance has more non-stationary
+// leading chunks than the workgroup has waves to give them.  Correct for anything; not fast.
+template <int FU_FL>
+__device__ __noinline__ void st_scan_sequential(const FuFac& c, int K, int64_t T, const double* ag, double* st,
+                                                int64_t Dp, bool dok) {
+  auto lane_cst = [&](int k) {
+    const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
+    return (j0 - 2 >= c.ncv) && (j1 <= c.n_shared) && (int)(j1 - j0) == FU_FL;
+  };
+  FuMats mc;
+  {
+    double none[FU_FL], e4[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+    fu_reduce<FU_FL, true, false, true>(c, none, 0, FU_FL, tl, e4, mc);
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < K; ++k) {
+    if (dok) { st[((int64_t)k * 4 + 0) * Dp] = s1; st[((int64_t)k * 4 + 1) * Dp] = s2; }
+    FuMats m = mc;
+    if (!__all(lane_cst(k))) st_chunk_mats<FU_FL>(c, K, T, k, m);
+    const double n1 = m.Mf[0] * s1 + m.Mf[1] * s2 + ag[((int64_t)k * 4 + 0) * Dp];
+    const double n2 = m.Mf[2] * s1 + m.Mf[3] * s2 + ag[((int64_t)k * 4 + 1) * Dp];
+    s1 = n1; s2 = n2;
+  }
+  double t1 = 0.0, t2 = 0.0;
+  for (int k = K - 1; k >= 0; --k) {
+    const double si0 = dok ? st[((int64_t)k * 4 + 0) * Dp] : 0.0, si1 = dok ? st[((int64_t)k * 4 + 1) * Dp] : 0.0;
+    if (dok) { st[((int64_t)k * 4 + 2) * Dp] = t1; st[((int64_t)k * 4 + 3) * Dp] = t2; }
+    FuMats m = mc;
+    if (!__all(lane_cst(k))) st_chunk_mats<FU_FL>(c, K, T, k, m);
+    const double e0 = ag[((int64_t)k * 4 + 2) * Dp] + m.C[0] * si0 + m.C[1] * si1;
+    const double e1 = ag[((int64_t)k * 4 + 3) * Dp] + m.C[2] * si0 + m.C[3] * si1;
+    const double n1 = m.Mb[0] * t1 + m.Mb[1] * t2 + e0;
+    const double n2 = m.Mb[2] * t1 + m.Mb[3] * t2 + e1;
+    t1 = n1; t2 = n2;
+  }
+}
+
+// One workgroup per (utterance, 64 dimensions): the two affine recurrences over the utterance's
+// chunks, as a two-level scan.  The chunks are cut into SW segments in time order, one per wave:
+// every non-stationary chunk (the leading ones until all lanes' factors have settled, the last
+// two) is a segment of its own, whose wave computes that chunk's matrices; the stationary middle
+// is split evenly over the remaining waves, which only ever multiply by the one stationary set.
+// A wave folds its segment into (A, q); the SW aggregates meet in LDS; every wave takes the state
+// that enters its segment and walks the segment again, now storing.  The chain a wave runs is
+// ~K / SW chunks long instead of K, and the aggregates of SB chunks are requested together.
+constexpr int ST_SW = 16;      // waves (= segments) per workgroup of the scan kernel
+
+template <int FU_FL>
+__global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
+  constexpr int SW = ST_SW;
+  __shared__ double lds_s[SW][6][64];
+  const MlpgArgs& a = g.a;
+  const int u = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long* tr = g.scan_trace ? g.scan_trace + ((int64_t)blockIdx.x * ST_SW + w) * 8 : nullptr;
+#define ST_STAMP(i) do { if (tr && lane == 0) tr[i] = wall_clock64(); } while (0)
+  ST_STAMP(0);
+  const int D = a.dim;
+  const bool dok = db * 64 + lane < D;
+  const int d = dok ? db * 64 + lane : D - 1;
+  const int64_t T = a.offsets[u + 1] - a.offsets[u];
+  if (T <= 0) return;
+  const int K = fu_num_chunks<FU_FL>(T);
+  const int64_t Dp = (int64_t)g.nblk * 64;
+  const int64_t col = (int64_t)db * 64 + lane;
+  const int64_t base = g.chunk0[u];
+  double* st = g.st + base * 4 * Dp + col;
+  const double* ag = g.agg + base * 4 * Dp + col;
+  if (K == 1) {
+    if (dok && w == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st[(int64_t)i * Dp] = 0.0;
+    }
+    return;
+  }
+  const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
+  FuFac c;
+  const int64_t plane = (int64_t)g.t_max * D;
+  c.fd = a.scratch + d; c.fl1 = c.fd + plane; c.fl2 = c.fl1 + plane;
+  c.ncv = a.nconv[d]; c.n_shared = T >= 3 ? T - 2 : 0; c.T = T; c.D = D;
+  c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
+  auto lane_cst = [&](int k) {
+    const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
+    return (j0 - 2 >= c.ncv) && (j1 <= c.n_shared) && (int)(j1 - j0) == FU_FL;
+  };
+  // segments: [0, n_lead) one leading chunk each | n_mid waves over [n_lead, tail0) | the last chunks
+  int k_settled = 0;                      // first chunk that is stationary for every lane
+  while (k_settled < K && !__all(lane_cst(k_settled))) ++k_settled;
+  const int tail0 = K - 2 > 0 ? K - 2 : 0;
+  const int n_tail = K - tail0;                                    // 1 or 2
+  const int n_lead = k_settled < tail0 ? k_settled : tail0;
+  if (n_lead > SW - n_tail - 1 || getenv_scan_sequential(g)) {     // see st_scan_sequential
+    if (w == 0) st_scan_sequential<FU_FL>(c, K, T, ag, st, Dp, dok);
+    return;
+  }
+  const int n_mid = SW - n_lead - n_tail;
+  const int mid_chunks = tail0 - n_lead;
+  const int L = (mid_chunks + n_mid - 1) / (n_mid > 0 ? n_mid : 1);
+  int k_lo, k_hi;                          // this wave's segment
+  const bool single = w < n_lead || w >= n_lead + n_mid;
+  if (w < n_lead) { k_lo = w; k_hi = w + 1; }
+  else if (w >= n_lead + n_mid) { k_lo = tail0 + (w - n_lead - n_mid); k_hi = k_lo + 1; }
+  else {
+    const int mw = w - n_lead;
+    k_lo = n_lead + mw * L; k_hi = k_lo + L;
+    if (k_lo > tail0) k_lo = tail0;
+    if (k_hi > tail0) k_hi = tail0;
+  }
+  FuMats mm;      // single-chunk wave: that chunk's matrices; middle wave: the stationary set
+  if (single) {
+    st_chunk_mats<FU_FL>(c, K, T, k_lo, mm);
+  } else {
+    double none[FU_FL], e4[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+    fu_reduce<FU_FL, true, false, true>(c, none, 0, FU_FL, tl, e4, mm);
+  }
+  auto mats = [&](int, FuMats& m) { m = mm; };
+  constexpr int SB = 8;
+  ST_STAMP(1);
+
+  // ---- forward: s_in(k + 1) = M_f(k) s_in(k) + e_f(k)
+  double A[4] = {1.0, 0.0, 0.0, 1.0}, q[2] = {0.0, 0.0};
+  for (int kb = k_lo; kb < k_hi; kb += SB) {
+    double ef[SB][2];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb + i < k_hi ? kb + i : k_hi - 1;
+      ef[i][0] = ag[((int64_t)k * 4 + 0) * Dp];
+      ef[i][1] = ag[((int64_t)k * 4 + 1) * Dp];
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      if (kb + i < k_hi) {
+        FuMats m;
+        mats(kb + i, m);
+        const double a0 = m.Mf[0] * A[0] + m.Mf[1] * A[2], a1 = m.Mf[0] * A[1] + m.Mf[1] * A[3];
+        const double a2 = m.Mf[2] * A[0] + m.Mf[3] * A[2], a3 = m.Mf[2] * A[1] + m.Mf[3] * A[3];
+        const double q0 = m.Mf[0] * q[0] + m.Mf[1] * q[1] + ef[i][0];
+        const double q1 = m.Mf[2] * q[0] + m.Mf[3] * q[1] + ef[i][1];
+        A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; q[0] = q0; q[1] = q1;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lds_s[w][i][lane] = A[i];
+  lds_s[w][4][lane] = q[0];
+  lds_s[w][5][lane] = q[1];
+  ST_STAMP(2);
+  __syncthreads();
+  ST_STAMP(3);
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < w; ++i) {
+    const double n1 = lds_s[i][0][lane] * s1 + lds_s[i][1][lane] * s2 + lds_s[i][4][lane];
+    const double n2 = lds_s[i][2][lane] * s1 + lds_s[i][3][lane] * s2 + lds_s[i][5][lane];
+    s1 = n1; s2 = n2;
+  }
+  for (int kb = k_lo; kb < k_hi; kb += SB) {
+    double ef[SB][2];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb + i < k_hi ? kb + i : k_hi - 1;
+      ef[i][0] = ag[((int64_t)k * 4 + 0) * Dp];
+      ef[i][1] = ag[((int64_t)k * 4 + 1) * Dp];
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb + i;
+      if (k < k_hi) {
+        if (dok) { st[((int64_t)k * 4 + 0) * Dp] = s1; st[((int64_t)k * 4 + 1) * Dp] = s2; }
+        FuMats m;
+        mats(k, m);
+        const double n1 = m.Mf[0] * s1 + m.Mf[1] * s2 + ef[i][0];
+        const double n2 = m.Mf[2] * s1 + m.Mf[3] * s2 + ef[i][1];
+        s1 = n1; s2 = n2;
+      }
+    }
+  }
+
+  ST_STAMP(4);
+  // ---- backward: t_in(k - 1) = M_b(k) t_in(k) + e_b0(k) + C(k) s_in(k)
+  // (a lane reads back the s_in it stored above: same thread, same address, program order)
+  A[0] = 1.0; A[1] = 0.0; A[2] = 0.0; A[3] = 1.0; q[0] = q[1] = 0.0;
+  for (int kb = k_hi - 1; kb >= k_lo; kb -= SB) {
+    double eb[SB][2], si[SB][2];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb - i >= k_lo ? kb - i : k_lo;
+      eb[i][0] = ag[((int64_t)k * 4 + 2) * Dp];
+      eb[i][1] = ag[((int64_t)k * 4 + 3) * Dp];
+      si[i][0] = dok ? st[((int64_t)k * 4 + 0) * Dp] : 0.0;
+      si[i][1] = dok ? st[((int64_t)k * 4 + 1) * Dp] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      if (kb - i >= k_lo) {
+        FuMats m;
+        mats(kb - i, m);
+        const double e0 = eb[i][0] + m.C[0] * si[i][0] + m.C[1] * si[i][1];
+        const double e1 = eb[i][1] + m.C[2] * si[i][0] + m.C[3] * si[i][1];
+        const double a0 = m.Mb[0] * A[0] + m.Mb[1] * A[2], a1 = m.Mb[0] * A[1] + m.Mb[1] * A[3];
+        const double a2 = m.Mb[2] * A[0] + m.Mb[3] * A[2], a3 = m.Mb[2] * A[1] + m.Mb[3] * A[3];
+        const double q0 = m.Mb[0] * q[0] + m.Mb[1] * q[1] + e0;
+        const double q1 = m.Mb[2] * q[0] + m.Mb[3] * q[1] + e1;
+        A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; q[0] = q0; q[1] = q1;
+      }
+    }
+  }
+  ST_STAMP(5);
+  __syncthreads();      // every wave has read the forward segment aggregates
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lds_s[w][i][lane] = A[i];
+  lds_s[w][4][lane] = q[0];
+  lds_s[w][5][lane] = q[1];
+  __syncthreads();
+  ST_STAMP(6);
+  double t1 = 0.0, t2 = 0.0;
+  for (int i = SW - 1; i > w; --i) {
+    const double n1 = lds_s[i][0][lane] * t1 + lds_s[i][1][lane] * t2 + lds_s[i][4][lane];
+    const double n2 = lds_s[i][2][lane] * t1 + lds_s[i][3][lane] * t2 + lds_s[i][5][lane];
+    t1 = n1; t2 = n2;
+  }
+  for (int kb = k_hi - 1; kb >= k_lo; kb -= SB) {
+    double eb[SB][2], si[SB][2];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb - i >= k_lo ? kb - i : k_lo;
+      eb[i][0] = ag[((int64_t)k * 4 + 2) * Dp];
+      eb[i][1] = ag[((int64_t)k * 4 + 3) * Dp];
+      si[i][0] = dok ? st[((int64_t)k * 4 + 0) * Dp] : 0.0;
+      si[i][1] = dok ? st[((int64_t)k * 4 + 1) * Dp] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb - i;
+      if (k >= k_lo) {
+        if (dok) { st[((int64_t)k * 4 + 2) * Dp] = t1; st[((int64_t)k * 4 + 3) * Dp] = t2; }
+        FuMats m;
+        mats(k, m);
+        const double e0 = eb[i][0] + m.C[0] * si[i][0] + m.C[1] * si[i][1];
+        const double e1 = eb[i][1] + m.C[2] * si[i][0] + m.C[3] * si[i][1];
+        const double n1 = m.Mb[0] * t1 + m.Mb[1] * t2 + e0;
+        const double n2 = m.Mb[2] * t1 + m.Mb[3] * t2 + e1;
+        t1 = n1; t2 = n2;
+      }
+    }
+  }
+  ST_STAMP(7);
+#undef ST_STAMP
+}
+
+template <int FU_FL>
+__global__ __launch_bounds__(ST_GW * 64) void mlpg_solve_kernel(StreamArgs g) {
+  StChunk<FU_FL> q;
+  if (!q.open(g)) return;
+  const MlpgArgs& a = g.a;
+  const int64_t Dp = (int64_t)g.nblk * 64;
+  const double* st = g.st + (int64_t)q.chunk * 4 * Dp + (blockIdx.x % (unsigned)g.nblk) * 64 + (threadIdx.x & 63);
+  const double s1 = st[0], s2 = st[Dp], t1 = st[2 * Dp], t2 = st[3 * Dp];
+  double b[FU_FL];
+  fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
+  double M[4], e[2], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+  double* o = a.out + q.t0 * a.ld_out + a.ocol0 + q.d;
+  if (q.cst) {
+    fu_fwd<FU_FL, true, false>(q.c, b, q.j0, q.n, s1, s2, M, e, tl);
+    fu_bwd<FU_FL, true, false>(q.c, b, q.j0, q.n, t1, t2, M, e, tl, o, a.ld_out, q.dok);
+  } else {
+    fu_fwd<FU_FL, false, false>(q.c, b, q.j0, q.n, s1, s2, M, e, tl);
+    fu_bwd<FU_FL, false, false>(q.c, b, q.j0, q.n, t1, t2, M, e, tl, o, a.ld_out, q.dok);
+  }
+}
+
 }  // namespace itts
 
 using namespace itts;
+
+
+// reduce -> scan -> solve (see above)
+template <int FL>
+static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n_utts, int dim, int64_t t_max,
+                              hipStream_t s) {
+  std::vector<StRecord> recs;
+  std::vector<int> chunk0(n_utts + 1, 0);
+  int n_chunks = 0;
+  for (int u = 0; u < n_utts; ++u) {
+    const int64_t T = h_offsets[u + 1] - h_offsets[u];
+    chunk0[u] = n_chunks;
+    const int K = T > 0 ? fu_num_chunks<FL>(T) : 0;
+    for (int k0 = 0; k0 < K; k0 += ST_GW) {
+      StRecord r{};
+      r.t0 = h_offsets[u];
+      r.T = (int)T;
+      r.k0 = k0;
+      r.chunk = n_chunks + k0;
+      recs.push_back(r);
+    }
+    n_chunks += K;
+  }
+  chunk0[n_utts] = n_chunks;
+  const int nblk = (dim + 63) / 64;
+  const size_t rec_bytes = recs.size() * sizeof(StRecord);
+  const size_t c0_bytes = (chunk0.size() * sizeof(int) + 31) / 32 * 32;
+  const size_t plane_bytes = (size_t)n_chunks * 4 * nblk * 64 * sizeof(double);
+  char* blk = nullptr;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, rec_bytes + c0_bytes + 2 * plane_bytes, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(blk, recs.data(), rec_bytes, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(blk + rec_bytes, chunk0.data(), chunk0.size() * sizeof(int),
+                                hipMemcpyHostToDevice, s));
+  StreamArgs g;
+  g.a = a;
+  g.t_max = (int)t_max;
+  g.rec = reinterpret_cast<const StRecord*>(blk);
+  g.chunk0 = reinterpret_cast<const int*>(blk + rec_bytes);
+  g.n_groups = (int)recs.size();
+  g.nblk = nblk;
+  g.agg = reinterpret_cast<double*>(blk + rec_bytes + c0_bytes);
+  g.st = g.agg + plane_bytes / sizeof(double);
+  g.scan_trace = nullptr;
+  const char* scan_trace_path = getenv("ITTS_MLPG_SCAN_TRACE");
+  const size_t scan_trace_words = (size_t)n_utts * nblk * ST_SW * 8;
+  if (scan_trace_path && scan_trace_path[0]) {
+    ITTS_HIP_CHECK(hipMalloc((void**)&g.scan_trace, scan_trace_words * 8));
+    ITTS_HIP_CHECK(hipMemset(g.scan_trace, 0, scan_trace_words * 8));
+  }
+  {
+    const char* sq = getenv("ITTS_MLPG_SCAN_SEQ");
+    g.scan_sequential = sq && sq[0] == '1';
+  }
+  const dim3 grid((unsigned)(recs.size() * nblk));
+  hipLaunchKernelGGL(mlpg_reduce_kernel<FL>, grid, dim3(ST_GW * 64), 0, s, g);
+  hipLaunchKernelGGL(mlpg_scan_kernel<FL>, dim3((unsigned)(n_utts * nblk)), dim3(ST_SW * 64), 0, s, g);
+  hipLaunchKernelGGL(mlpg_solve_kernel<FL>, grid, dim3(ST_GW * 64), 0, s, g);
+  ITTS_LAUNCH_CHECK();
+  if (g.scan_trace) {          // debugging aid: per-wave phase stamps of the scan kernel as text
+    std::vector<unsigned long long> h(scan_trace_words);
+    ITTS_HIP_CHECK(hipStreamSynchronize(s));
+    ITTS_HIP_CHECK(hipMemcpy(h.data(), g.scan_trace, scan_trace_words * 8, hipMemcpyDeviceToHost));
+    ITTS_HIP_CHECK(hipFree(g.scan_trace));
+    if (FILE* tf = fopen(scan_trace_path, "w")) {
+      for (size_t r = 0; r < scan_trace_words / 8; ++r) {
+        fprintf(tf, "%zu %zu", r / ST_SW, r % ST_SW);
+        for (int i = 0; i < 8; ++i) fprintf(tf, " %llu", h[r * 8 + i]);
+        fprintf(tf, "\n");
+      }
+      fclose(tf);
+    }
+  }
+  ITTS_HIP_CHECK(itts::scratch_free(blk, s));
+  return ITTS_OK;
+}
 
 extern "C" int64_t itts_mlpg_scratch_bytes(int64_t t_total, int dim) {
   if (t_total < 0 || dim <= 0) return 0;
@@ -1056,22 +1646,31 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   hipLaunchKernelGGL(mlpg_factor_kernel, dim3((dim + 63) / 64), dim3(64), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
   const int kchunks = mlpg_num_chunks(t_max);
-  const char* seq = getenv("ITTS_MLPG_SEQ");
-  if (kchunks < 3 || (seq && seq[0] == '1')) {      // short utterances: the sequential sweeps are as fast
+  // which solve (ITTS_MLPG_PATH, for A/B runs and the tests): "stream" = reduce -> scan -> solve
+  // with 16-frame chunks (the default; "stream8" / "stream32": 8 / 32 frames), "fused" = the
+  // single-pass kernel with cross-workgroup waits, "multipass" = the four chunk passes,
+  // "seq" = the sequential sweeps (always taken for batches of short utterances)
+  const char* path_env = getenv("ITTS_MLPG_PATH");
+  const std::string path = path_env ? path_env : "stream";
+  ITTS_REQUIRE(path == "stream" || path == "stream8" || path == "stream32" || path == "fused" ||
+               path == "multipass" || path == "seq", "unknown ITTS_MLPG_PATH");
+  if (kchunks < 3 || path == "seq") {      // short utterances: the sequential sweeps are as fast
     dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
     hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
     ITTS_LAUNCH_CHECK();
     return ITTS_OK;
   }
+  if (path == "stream") return mlpg_stream_launch<16>(a, h_offsets, n_utts, dim, t_max, s);
+  if (path == "stream32") return mlpg_stream_launch<32>(a, h_offsets, n_utts, dim, t_max, s);
+  if (path == "stream8") return mlpg_stream_launch<8>(a, h_offsets, n_utts, dim, t_max, s);
   // fused single-pass solve (one read of the input, one write of the output) unless an utterance
   // is so long that its super-chunks could exhaust the resident workgroups (see the kernel)
-  // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW> picks one of the
-  // compiled variants; experiments)
+  // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW>[x<waves per SIMD>]
+  // picks one of the compiled variants; experiments)
   int FL = 8, FW = 16, WPE = 0;
   if (const char* geom = getenv("ITTS_MLPG_GEOM")) sscanf(geom, "%dx%dx%d", &FL, &FW, &WPE);
   const int64_t sc_frames = (int64_t)FL * FW;
-  const char* force = getenv("ITTS_MLPG_MULTIPASS");
-  if (t_max <= sc_frames * FU_MAX_SC && !(force && force[0] == '1')) {
+  if (path == "fused" && t_max <= sc_frames * FU_MAX_SC) {
     std::vector<FuRecord> recs;
     for (int u = 0; u < n_utts; ++u) {
       const int64_t T = h_offsets[u + 1] - h_offsets[u];

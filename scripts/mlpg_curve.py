@@ -1,4 +1,4 @@
-"""MLPG solve time against batch size, fused scan vs sequential sweeps (ITTS_MLPG_SEQ=1).
+"""MLPG solve time against batch size for the solves the library holds (ITTS_MLPG_PATH).
 Usage (GPU box): python scripts/mlpg_curve.py"""
 import os
 import sys
@@ -26,18 +26,13 @@ def timed(fn, n=5):
 
 dev = torch.device("cuda", 0)
 var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
-for n_u in (256, 1024, 4096):
+for n_u in [int(v) for v in os.environ.get("MLPG_SIZES", "256,1024,4096").split(",")]:
     off = world.offsets(utterance_lengths(n_u, seed=5).tolist())
     fr = off[-1]
     feat = torch.randn(fr, 186, dtype=torch.float64, device=dev)
     outs = {}
-    for mode in sys.argv[1:] or ("fused", "seq"):
-        os.environ.pop("ITTS_MLPG_SEQ", None)
-        os.environ.pop("ITTS_MLPG_STREAM", None)
-        if mode == "seq":
-            os.environ["ITTS_MLPG_SEQ"] = "1"
-        if mode == "stream":
-            os.environ["ITTS_MLPG_STREAM"] = "1"
+    for mode in sys.argv[1:] or ("stream", "fused", "multipass", "seq"):
+        os.environ["ITTS_MLPG_PATH"] = mode
         ms = timed(lambda: ops.mlpg_generation(feat, var, 62, off))
         outs[mode] = ops.mlpg_generation(feat, var, 62, off)
         print("%5d utts %8d frames %-6s %8.3f ms  %6.1f GB/s algorithmic (%.1f %% of 8 TB/s)" % (

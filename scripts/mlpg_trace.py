@@ -9,7 +9,8 @@ from idiaptts_amd import ops, world
 from idiaptts_amd.bench_support import utterance_lengths
 
 dev = torch.device("cuda:0")
-os.environ["ITTS_MLPG_GEOM"] = sys.argv[1] if len(sys.argv) > 1 else "32x4"
+os.environ["ITTS_MLPG_PATH"] = "fused"
+os.environ["ITTS_MLPG_GEOM"] = sys.argv[1] if len(sys.argv) > 1 else "8x16x4"
 N_UTT = int(os.environ.get("MLPG_UTTS", "256"))
 ml_off = world.offsets(utterance_lengths(N_UTT, seed=5).tolist())
 n = ml_off[-1]

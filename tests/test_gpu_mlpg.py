@@ -20,9 +20,13 @@ def _case(rng, lengths, dim, extra_cols=0, col0=0):
     # time-parallel path: utterance lengths around the 64-frame chunk boundaries, mixed with short ones
     ([194, 195, 257, 258, 259, 130, 66, 3, 1, 322], 4, 0), ([193, 2], 2, 0), ([4098], 1, 0),
 ])
-def test_mlpg_matches_oracle(gpu, lengths, dim, col0):
+@pytest.mark.parametrize("path", ["stream", "stream8", "stream32", "fused", "multipass", "seq"])
+def test_mlpg_matches_oracle(gpu, lengths, dim, col0, path, monkeypatch):
+    """Every solve the library holds (ITTS_MLPG_PATH; "stream" is what runs by default) against the
+    C oracle."""
     from idiaptts_amd import ops
     from oracle import capi
+    monkeypatch.setenv("ITTS_MLPG_PATH", path)
     rng = np.random.default_rng(7)
     feat, var, offsets = _case(rng, lengths, dim, extra_cols=2, col0=col0)
     out = ops.mlpg_generation(torch.from_numpy(feat).to(gpu), torch.from_numpy(var).to(gpu), dim,
@@ -70,3 +74,25 @@ def test_mlpg_full_size_property(gpu):
             g = r0 + 0.5 * (r1p[:-2] - r1p[2:]) + (r2p[:-2] - 2 * r2p[1:-1] + r2p[2:])
             scale = np.abs(tau[:, 0] * m[:, 0]).max() + 1.0
             assert np.abs(g).max() / scale < 1e-9
+
+
+@pytest.mark.parametrize("scan_seq", ["0", "1"])
+def test_mlpg_slowly_settling_factor(gpu, scan_seq, monkeypatch):
+    """Delta variances 1e6 times smaller than the static ones: the Cholesky factor needs hundreds of
+    frames to become stationary, so most chunks of an utterance carry their own matrices (the scan
+    kernel's single-chunk segments, or its sequential road when there are more such chunks than
+    waves -- forced with ITTS_MLPG_SCAN_SEQ=1 as well)."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    monkeypatch.setenv("ITTS_MLPG_SCAN_SEQ", scan_seq)
+    rng = np.random.default_rng(3)
+    lengths, dim = [700, 90, 333], 3
+    feat, var, offsets = _case(rng, lengths, dim)
+    var[dim:] *= 1e-6
+    out = ops.mlpg_generation(torch.from_numpy(feat).to(gpu), torch.from_numpy(var).to(gpu), dim,
+                              offsets.tolist()).cpu().numpy()
+    for u in range(len(lengths)):
+        a, b = offsets[u], offsets[u + 1]
+        ref = capi.mlpg(feat[a:b], var, dim)
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(out[a:b] - ref).max() <= 1e-9 * scale, (u, np.abs(out[a:b] - ref).max())

@@ -125,7 +125,7 @@ def test_closed_loop_through_the_reference_held_features(gpu, golden_dir, name):
     oracle.  Measured for the oracle loop on these fixtures: V/UV agreement 0.70 - 0.74 (one-sided: the
     fixture contours hold runs of 390-465 Hz octave-jump frames labelled voiced, which a
     re-analysis of the clean resynthesis calls unvoiced; 1 - 18 frames per utterance go the other way), lf0
-    RMSE on commonly voiced frames 28-40 cents, MCD 3.1-3.3 dB (order-19 envelope re-estimated from
+    RMSE on commonly voiced frames 24-35 cents (without the 0 - 5.3 % octave-type errors), MCD 3.1-3.3 dB (order-19 envelope re-estimated from
     its own resynthesis).  The HIP loop must reproduce the oracle loop, and both must stay inside
     those figures."""
     import scipy.signal
@@ -140,11 +140,13 @@ def test_closed_loop_through_the_reference_held_features(gpu, golden_dir, name):
     def metrics(mc_b, f0_b):
         vb = (f0_b > 0).astype(np.float32)
         both = (vb == 1) & (vuv == 1)
-        lf0_rmse = np.sqrt(np.mean((np.log(f0_b[both]) - lf0[both].astype(np.float64)) ** 2))
+        cents = (np.log(f0_b[both]) - lf0[both].astype(np.float64)) * 1200 / np.log(2)
+        gross = np.abs(cents) > 300          # octave-type errors: counted, not averaged
+        lf0_rmse = np.sqrt(np.mean(cents[~gross] ** 2))
         mcd = (10 / np.log(10)) * np.sqrt(2 * ((mc_b[:, 1:] - mc[:, 1:].astype(np.float64)) ** 2)
                                           .sum(1)).mean()
         return vb, float((vb == vuv).mean()), int(((vuv == 0) & (vb == 1)).sum()), \
-            lf0_rmse * 1200 / np.log(2), mcd
+            lf0_rmse, mcd, float(gross.mean())
 
     # HIP loop through the drop-in API
     amp_sp = AudioProcessing.decode_sp(mc.astype(np.float64), "mcep", fs, alpha)
@@ -155,7 +157,7 @@ def test_closed_loop_through_the_reference_held_features(gpu, golden_dir, name):
     res = WorldFeatLabelGen.extract_features_batch([raw], fs, num_coded_sps=20, mgc_alpha=alpha)[0]
     mc_h, lf0_h, vuv_h = res[0][:T].astype(np.float64), res[1][:T, 0], res[2][:T, 0]
     f0_h = np.exp(lf0_h.astype(np.float64)) * vuv_h
-    vb_h, agree_h, extra_h, cents_h, mcd_h = metrics(mc_h, f0_h)
+    vb_h, agree_h, extra_h, cents_h, mcd_h, gross_h = metrics(mc_h, f0_h)
     # the same loop through the C oracle
     pw = np.exp(capi.mgc2sp_logamp(mc.astype(np.float64), alpha, 1024).astype(np.float32)) \
         .astype(np.float64) ** 2
@@ -168,16 +170,18 @@ def test_closed_loop_through_the_reference_held_features(gpu, golden_dir, name):
     raw_o = np.append(y[0], y[1:] - pre * y[:-1])
     f0_o, sp_o, _ = capi.wav2world(raw_o, fs)
     mc_o = capi.mcep(np.sqrt(sp_o), 19, alpha)[:T]
-    vb_o, agree_o, extra_o, cents_o, mcd_o = metrics(mc_o, f0_o[:T])
+    vb_o, agree_o, extra_o, cents_o, mcd_o, gross_o = metrics(mc_o, f0_o[:T])
     # HIP loop == oracle loop
     assert np.sqrt(np.mean((wav - y) ** 2)) < 1e-6
     assert (vb_h == vb_o).mean() >= 0.995
-    assert abs(cents_h - cents_o) < 0.5 and abs(mcd_h - mcd_o) < 0.02
+    assert abs(cents_h - cents_o) < 0.5 and abs(mcd_h - mcd_o) < 0.02 and abs(gross_h - gross_o) < 0.004
     # both inside what the fixtures allow
-    for agree, extra, cents, mcd in ((agree_h, extra_h, cents_h, mcd_h),
-                                     (agree_o, extra_o, cents_o, mcd_o)):
+    for agree, extra, cents, mcd, gross in ((agree_h, extra_h, cents_h, mcd_h, gross_h),
+                                            (agree_o, extra_o, cents_o, mcd_o, gross_o)):
         assert agree > 0.65 and extra <= max(3, 0.02 * T)   # (0.6 - 1.8 % of the frames on the nine fixtures)
-        assert cents < 60.0 and mcd < 4.0
+        # lf0: 24 - 35 cents RMSE over the commonly voiced frames, leaving out the 0 - 5.3 % of them
+        # that are more than 300 cents off (octave-type errors of the re-analysis, LJ001-0005: 29 of 546)
+        assert cents < 40.0 and gross <= 0.06 and mcd < 4.0
 
 
 @pytest.mark.parametrize("name", ALL_FIXTURES)
