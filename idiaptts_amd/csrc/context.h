@@ -91,6 +91,12 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
 // One of the context's page-locked host slots (round robin) for a read-back of a few bytes.
 int64_t* pinned_slot(DeviceContext* ctx);
 
+// Host -> device copy on stream s through a ring of page-locked staging buffers: the host returns
+// as soon as the bytes are in the staging buffer (a copy from pageable memory makes the runtime
+// stage it synchronously, which holds back the launches queued behind it).  `src` may be reused at
+// once.
+int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s);
+
 // Small stream-ordered device copy of a host int64 array (offsets). Caller frees with
 // scratch_free on the same stream.
 int upload_i64(const int64_t* h, int n, int64_t** d_out, hipStream_t s);

@@ -3,6 +3,7 @@
 
 #include "context.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -472,10 +473,51 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
   return &t;
 }
 
+namespace {
+struct StageSlot {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+struct StageRing {
+  StageSlot slot[4];
+  unsigned next = 0;
+};
+std::mutex g_stage_mutex;
+std::map<int, StageRing> g_stage;
+}  // namespace
+
+int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return ITTS_OK;
+  int dev = 0;
+  ITTS_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_stage_mutex);
+  StageRing& ring = g_stage[dev];
+  StageSlot& sl = ring.slot[ring.next++ & 3u];
+  if (sl.pending) {                       // the copy that last used this slot has left it
+    ITTS_HIP_CHECK(hipEventSynchronize(sl.ev));
+    sl.pending = false;
+  }
+  if (sl.cap < bytes) {
+    if (sl.p) ITTS_HIP_CHECK(hipHostFree(sl.p));
+    sl.p = nullptr;
+    sl.cap = 0;
+    const size_t cap = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
+    ITTS_HIP_CHECK(hipHostMalloc(&sl.p, cap, hipHostMallocDefault));
+    sl.cap = cap;
+  }
+  if (!sl.ev) ITTS_HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  std::memcpy(sl.p, src, bytes);
+  ITTS_HIP_CHECK(hipMemcpyAsync(d_dst, sl.p, bytes, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipEventRecord(sl.ev, s));
+  sl.pending = true;
+  return ITTS_OK;
+}
+
 int upload_i64(const int64_t* h, int n, int64_t** d_out, hipStream_t s) {
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)d_out, (size_t)n * sizeof(int64_t), s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(*d_out, h, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, s));
-  return ITTS_OK;
+  return staged_upload(*d_out, h, (size_t)n * sizeof(int64_t), s);
 }
 
 }  // namespace itts

@@ -16,10 +16,12 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "common.h"
+#include "context.h"
 
 namespace itts {
 
@@ -1561,9 +1563,13 @@ static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n
   const size_t plane_bytes = (size_t)n_chunks * 4 * nblk * 64 * sizeof(double);
   char* blk = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, rec_bytes + c0_bytes + 2 * plane_bytes, s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(blk, recs.data(), rec_bytes, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(blk + rec_bytes, chunk0.data(), chunk0.size() * sizeof(int),
-                                hipMemcpyHostToDevice, s));
+  {      // records and chunk table in one asynchronous upload
+    std::vector<char> host(rec_bytes + c0_bytes, 0);
+    std::memcpy(host.data(), recs.data(), rec_bytes);
+    std::memcpy(host.data() + rec_bytes, chunk0.data(), chunk0.size() * sizeof(int));
+    const int rc = itts::staged_upload(blk, host.data(), host.size(), s);
+    if (rc) return rc;
+  }
   StreamArgs g;
   g.a = a;
   g.t_max = (int)t_max;
@@ -1637,8 +1643,10 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   itts::ScratchScope scratch_scope(s);
   double* scratch = reinterpret_cast<double*>(d_scratch);
   int64_t* d_off = reinterpret_cast<int64_t*>(scratch + 3 * t_total * (int64_t)dim);
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_off, h_offsets, (n_utts + 1) * sizeof(int64_t),
-                                hipMemcpyHostToDevice, s));
+  {
+    const int rc = itts::staged_upload(d_off, h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t), s);
+    if (rc) return rc;
+  }
   int* d_nconv = reinterpret_cast<int*>(d_off + (t_total + 2));
   MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total, d_nconv};
   int64_t t_max = 0;
