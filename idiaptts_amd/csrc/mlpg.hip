@@ -1101,7 +1101,6 @@ struct StreamArgs {
 
 __device__ __forceinline__ bool getenv_scan_sequential(const StreamArgs& g) { return g.scan_sequential != 0; }
 
-constexpr int ST_GW = 4;       // chunks (= waves) per workgroup of the reduce / solve kernels
 
 struct FuMats { double Mf[4], Mb[4], C[4]; };
 
@@ -1212,7 +1211,8 @@ struct StChunk {
     t0 = rec.t0; T = rec.T;
     K = fu_num_chunks<FU_FL>(T);
     k = rec.k0 + w;
-    if (k >= K) return false;
+    const bool active = k < K;
+    if (!active) k = K - 1;          // an idle wave computes on the last chunk's geometry and stores nothing
     chunk = rec.chunk + w;
     const int D = a.dim;
     dok = db * 64 + lane < D;
@@ -1226,18 +1226,133 @@ struct StChunk {
     c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
     const bool cst_lane = (j0 - 2 >= c.ncv) && (j1 <= c.n_shared) && n == FU_FL;
     cst = __all(cst_lane);
-    return true;
+    return active;
   }
 };
 
+// Stages the rows [jlo, jhi) of one utterance -- the three 64-column pieces (static, delta,
+// delta-delta) of this workgroup's dimension block -- into LDS as tile[row][w * 64 + lane], with
+// every thread of the workgroup loading: the pieces of a row are contiguous in memory, so the loads
+// are full-width (16 bytes per lane when the row pitch, the first column and the dimension count are
+// even) and a row that two neighbouring chunks need is fetched once.  The waves then form b from
+// LDS through fu_form_b with pitch ST_W.
+constexpr int ST_W = 192;      // doubles per staged row
+
+template <int NTHR, int MAXR>
+__device__ __forceinline__ void st_stage_rows(const MlpgArgs& a, int db, int64_t t0, int64_t jlo, int rows,
+                                              double* tile) {
+  const int D = a.dim;
+  const int dblk = D - db * 64 < 64 ? D - db * 64 : 64;
+  const double* src0 = a.feat + (t0 + jlo) * a.ld_feat + a.col0 + db * 64;
+  const bool wide = ((a.ld_feat | (int64_t)a.col0 | (int64_t)D) & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.feat) & 15) == 0;
+  if (wide) {
+    constexpr int CPR = 96;                               // 16-byte chunks per staged row
+    constexpr int NLD = (MAXR * CPR + NTHR - 1) / NTHR;
+    double2 v[NLD];
+    const int total = rows * CPR;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = (int)threadIdx.x + i * NTHR;
+      const int row = idx / CPR, rem = idx - row * CPR, w = rem >> 5, c = rem & 31;
+      v[i] = make_double2(0.0, 0.0);
+      if (idx < total && 2 * c < dblk)
+        v[i] = *reinterpret_cast<const double2*>(src0 + (int64_t)row * a.ld_feat + w * D + 2 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = (int)threadIdx.x + i * NTHR;
+      const int row = idx / CPR, rem = idx - row * CPR, w = rem >> 5, c = rem & 31;
+      if (idx < total) *reinterpret_cast<double2*>(tile + row * ST_W + w * 64 + 2 * c) = v[i];
+    }
+  } else {
+    constexpr int CPR = 192;
+    constexpr int NLD = (MAXR * CPR + NTHR - 1) / NTHR;
+    const int total = rows * CPR;
+    for (int i0 = 0; i0 < NLD; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = (int)threadIdx.x + (i0 + i) * NTHR;
+        const int row = idx / CPR, rem = idx - row * CPR, w = rem >> 6, c = rem & 63;
+        v[i] = 0.0;
+        if (idx < total && c < dblk) v[i] = src0[(int64_t)row * a.ld_feat + w * D + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = (int)threadIdx.x + (i0 + i) * NTHR;
+        const int row = idx / CPR, rem = idx - row * CPR, w = rem >> 6, c = rem & 63;
+        if (idx < total) tile[row * ST_W + w * 64 + c] = v[i];
+      }
+    }
+  }
+}
+
+// b of this wave's chunk from the staged rows (the same code path as from memory: fu_form_b with
+// the tile's pitch and piece offsets)
 template <int FU_FL>
-__global__ __launch_bounds__(ST_GW * 64) void mlpg_reduce_kernel(StreamArgs g) {
-  StChunk<FU_FL> q;
-  if (!q.open(g)) return;
-  if (q.K == 1) return;          // a one-chunk utterance has nobody to hand a state to
+__device__ __forceinline__ void st_form_b_staged(const double* tile, int64_t jlo, const StChunk<FU_FL>& q,
+                                                 double (&b)[FU_FL]) {
+  MlpgArgs la{};
+  la.ld_feat = ST_W;
+  la.dim = 64;
+  const double* f = tile - jlo * ST_W + (threadIdx.x & 63);
+  fu_form_b<FU_FL>(la, f, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
+}
+
+// one record per group of GW chunks, expanded on the device from the per-utterance tables
+template <int GW>
+__global__ __launch_bounds__(64) void mlpg_records_kernel(const int64_t* __restrict__ offsets,
+                                                          const int* __restrict__ chunk0,
+                                                          const int* __restrict__ group0,
+                                                          StRecord* __restrict__ rec) {
+  const int u = blockIdx.x;
+  const int g0 = group0[u], ng = group0[u + 1] - g0;
+  const int64_t t0 = offsets[u];
+  const int T = (int)(offsets[u + 1] - t0);
+  for (int i = threadIdx.x; i < ng; i += 64) {
+    StRecord r{};
+    r.t0 = t0;
+    r.T = T;
+    r.k0 = i * GW;
+    r.chunk = chunk0[u] + i * GW;
+    rec[g0 + i] = r;
+  }
+}
+
+// frames [jlo, jhi) a group of GW chunks starting at chunk k0 needs (one halo row on either side)
+template <int FU_FL, int GW>
+__device__ __forceinline__ void st_group_rows(const StRecord& rec, int64_t& jlo, int& rows) {
+  const int64_t T = rec.T;
+  const int K = fu_num_chunks<FU_FL>(T);
+  const int kend = rec.k0 + GW < K ? rec.k0 + GW : K;
+  jlo = fu_chunk_start<FU_FL>(rec.k0, K, T) - 1;
+  if (jlo < 0) jlo = 0;
+  int64_t jhi = fu_chunk_start<FU_FL>(kend, K, T) + 1;
+  if (jhi > T) jhi = T;
+  rows = (int)(jhi - jlo);
+}
+
+template <int FU_FL, int GW, bool STAGE>
+__global__ __launch_bounds__(GW * 64) void mlpg_reduce_kernel(StreamArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double st_tile[];
   const MlpgArgs& a = g.a;
+  int64_t jlo = 0;
+  StChunk<FU_FL> q;
+  const bool active = q.open(g);      // its loads (constants, factor) fly together with the staging loads
+  if (q.K == 1) return;               // (uniform) a one-chunk utterance has nobody to hand a state to
+  if (STAGE) {
+    const int grp = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
+    const StRecord rec = g.rec[grp];
+    int rows;
+    st_group_rows<FU_FL, GW>(rec, jlo, rows);
+    st_stage_rows<GW * 64, GW * FU_FL + 2>(a, db, rec.t0, jlo, rows, st_tile);
+    __syncthreads();
+  }
+  if (!active) return;
   double b[FU_FL];
-  fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
+  if (STAGE) st_form_b_staged<FU_FL>(st_tile, jlo, q, b);
+  else fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
   double e[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
   FuMats unused;
   if (q.cst) fu_reduce<FU_FL, true, true, false>(q.c, b, q.j0, q.n, tl, e, unused);
@@ -1509,16 +1624,29 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
 #undef ST_STAMP
 }
 
-template <int FU_FL>
-__global__ __launch_bounds__(ST_GW * 64) void mlpg_solve_kernel(StreamArgs g) {
-  StChunk<FU_FL> q;
-  if (!q.open(g)) return;
+template <int FU_FL, int GW, bool STAGE>
+__global__ __launch_bounds__(GW * 64) void mlpg_solve_kernel(StreamArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double st_tile[];
   const MlpgArgs& a = g.a;
+  int64_t jlo = 0;
+  StChunk<FU_FL> q;
+  const bool active = q.open(g);      // its loads (constants, factor, entry states) fly with the staging loads
   const int64_t Dp = (int64_t)g.nblk * 64;
-  const double* st = g.st + (int64_t)q.chunk * 4 * Dp + (blockIdx.x % (unsigned)g.nblk) * 64 + (threadIdx.x & 63);
+  const double* st = g.st + (int64_t)(active ? q.chunk : 0) * 4 * Dp + (blockIdx.x % (unsigned)g.nblk) * 64 +
+                     (threadIdx.x & 63);
   const double s1 = st[0], s2 = st[Dp], t1 = st[2 * Dp], t2 = st[3 * Dp];
+  if (STAGE) {
+    const int grp = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
+    const StRecord rec = g.rec[grp];
+    int rows;
+    st_group_rows<FU_FL, GW>(rec, jlo, rows);
+    st_stage_rows<GW * 64, GW * FU_FL + 2>(a, db, rec.t0, jlo, rows, st_tile);
+    __syncthreads();
+  }
+  if (!active) return;
   double b[FU_FL];
-  fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
+  if (STAGE) st_form_b_staged<FU_FL>(st_tile, jlo, q, b);
+  else fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
   double M[4], e[2], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
   double* o = a.out + q.t0 * a.ld_out + a.ocol0 + q.d;
   if (q.cst) {
@@ -1536,46 +1664,46 @@ using namespace itts;
 
 
 // reduce -> scan -> solve (see above)
-template <int FL>
+template <int FL, int GW, bool STAGE>
 static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n_utts, int dim, int64_t t_max,
                               hipStream_t s) {
-  std::vector<StRecord> recs;
-  std::vector<int> chunk0(n_utts + 1, 0);
-  int n_chunks = 0;
+  // per utterance: first chunk and first group (batch-wide indices); the per-group records are
+  // expanded from them on the device (at 4 096 utterances the host would otherwise build and
+  // upload 2.4 - 4.9 MB of records per call)
+  std::vector<int> tab(2 * (size_t)(n_utts + 1), 0);
+  int* chunk0 = tab.data();
+  int* group0 = tab.data() + (n_utts + 1);
+  int n_chunks = 0, n_groups = 0;
   for (int u = 0; u < n_utts; ++u) {
     const int64_t T = h_offsets[u + 1] - h_offsets[u];
     chunk0[u] = n_chunks;
+    group0[u] = n_groups;
     const int K = T > 0 ? fu_num_chunks<FL>(T) : 0;
-    for (int k0 = 0; k0 < K; k0 += ST_GW) {
-      StRecord r{};
-      r.t0 = h_offsets[u];
-      r.T = (int)T;
-      r.k0 = k0;
-      r.chunk = n_chunks + k0;
-      recs.push_back(r);
-    }
     n_chunks += K;
+    n_groups += (K + GW - 1) / GW;
   }
   chunk0[n_utts] = n_chunks;
+  group0[n_utts] = n_groups;
   const int nblk = (dim + 63) / 64;
-  const size_t rec_bytes = recs.size() * sizeof(StRecord);
-  const size_t c0_bytes = (chunk0.size() * sizeof(int) + 31) / 32 * 32;
+  const size_t rec_bytes = (size_t)n_groups * sizeof(StRecord);
+  const size_t c0_bytes = (tab.size() * sizeof(int) + 31) / 32 * 32;
   const size_t plane_bytes = (size_t)n_chunks * 4 * nblk * 64 * sizeof(double);
   char* blk = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, rec_bytes + c0_bytes + 2 * plane_bytes, s));
-  {      // records and chunk table in one asynchronous upload
-    std::vector<char> host(rec_bytes + c0_bytes, 0);
-    std::memcpy(host.data(), recs.data(), rec_bytes);
-    std::memcpy(host.data() + rec_bytes, chunk0.data(), chunk0.size() * sizeof(int));
-    const int rc = itts::staged_upload(blk, host.data(), host.size(), s);
+  {
+    const int rc = itts::staged_upload(blk + rec_bytes, tab.data(), tab.size() * sizeof(int), s);
     if (rc) return rc;
   }
+  hipLaunchKernelGGL(mlpg_records_kernel<GW>, dim3((unsigned)n_utts), dim3(64), 0, s, a.offsets,
+                     reinterpret_cast<const int*>(blk + rec_bytes),
+                     reinterpret_cast<const int*>(blk + rec_bytes) + (n_utts + 1),
+                     reinterpret_cast<StRecord*>(blk));
   StreamArgs g;
   g.a = a;
   g.t_max = (int)t_max;
   g.rec = reinterpret_cast<const StRecord*>(blk);
   g.chunk0 = reinterpret_cast<const int*>(blk + rec_bytes);
-  g.n_groups = (int)recs.size();
+  g.n_groups = n_groups;
   g.nblk = nblk;
   g.agg = reinterpret_cast<double*>(blk + rec_bytes + c0_bytes);
   g.st = g.agg + plane_bytes / sizeof(double);
@@ -1590,10 +1718,21 @@ static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n
     const char* sq = getenv("ITTS_MLPG_SCAN_SEQ");
     g.scan_sequential = sq && sq[0] == '1';
   }
-  const dim3 grid((unsigned)(recs.size() * nblk));
-  hipLaunchKernelGGL(mlpg_reduce_kernel<FL>, grid, dim3(ST_GW * 64), 0, s, g);
+  const dim3 grid((unsigned)((size_t)n_groups * nblk));
+  const size_t tile_bytes = STAGE ? (size_t)(GW * FL + 2) * ST_W * sizeof(double) : 0;
+  if (STAGE) {
+    static bool attr_set = false;      // more than 64 KB of dynamic LDS needs the attribute once per kernel
+    if (!attr_set) {
+      ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlpg_reduce_kernel<FL, GW, STAGE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
+      ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlpg_solve_kernel<FL, GW, STAGE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((mlpg_reduce_kernel<FL, GW, STAGE>), grid, dim3(GW * 64), tile_bytes, s, g);
   hipLaunchKernelGGL(mlpg_scan_kernel<FL>, dim3((unsigned)(n_utts * nblk)), dim3(ST_SW * 64), 0, s, g);
-  hipLaunchKernelGGL(mlpg_solve_kernel<FL>, grid, dim3(ST_GW * 64), 0, s, g);
+  hipLaunchKernelGGL((mlpg_solve_kernel<FL, GW, STAGE>), grid, dim3(GW * 64), tile_bytes, s, g);
   ITTS_LAUNCH_CHECK();
   if (g.scan_trace) {          // debugging aid: per-wave phase stamps of the scan kernel as text
     std::vector<unsigned long long> h(scan_trace_words);
@@ -1655,22 +1794,25 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   ITTS_LAUNCH_CHECK();
   const int kchunks = mlpg_num_chunks(t_max);
   // which solve (ITTS_MLPG_PATH, for A/B runs and the tests): "stream" = reduce -> scan -> solve
-  // with 16-frame chunks (the default; "stream8" / "stream32": 8 / 32 frames), "fused" = the
+  // with 16-frame chunks, two chunks per workgroup, input rows staged through LDS (the default);
+  // "direct" = the same with every wave loading its own rows (four chunks per workgroup; "stream8" /
+  // "stream32": 8 / 32 frames per chunk), "fused" = the
   // single-pass kernel with cross-workgroup waits, "multipass" = the four chunk passes,
   // "seq" = the sequential sweeps (always taken for batches of short utterances)
   const char* path_env = getenv("ITTS_MLPG_PATH");
   const std::string path = path_env ? path_env : "stream";
   ITTS_REQUIRE(path == "stream" || path == "stream8" || path == "stream32" || path == "fused" ||
-               path == "multipass" || path == "seq", "unknown ITTS_MLPG_PATH");
+               path == "multipass" || path == "seq" || path == "direct", "unknown ITTS_MLPG_PATH");
   if (kchunks < 3 || path == "seq") {      // short utterances: the sequential sweeps are as fast
     dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
     hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
     ITTS_LAUNCH_CHECK();
     return ITTS_OK;
   }
-  if (path == "stream") return mlpg_stream_launch<16>(a, h_offsets, n_utts, dim, t_max, s);
-  if (path == "stream32") return mlpg_stream_launch<32>(a, h_offsets, n_utts, dim, t_max, s);
-  if (path == "stream8") return mlpg_stream_launch<8>(a, h_offsets, n_utts, dim, t_max, s);
+  if (path == "stream") return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
+  if (path == "direct") return mlpg_stream_launch<16, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
+  if (path == "stream32") return mlpg_stream_launch<32, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
+  if (path == "stream8") return mlpg_stream_launch<8, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
   // fused single-pass solve (one read of the input, one write of the output) unless an utterance
   // is so long that its super-chunks could exhaust the resident workgroups (see the kernel)
   // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW>[x<waves per SIMD>]

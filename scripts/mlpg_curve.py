@@ -31,7 +31,7 @@ for n_u in [int(v) for v in os.environ.get("MLPG_SIZES", "256,1024,4096").split(
     fr = off[-1]
     feat = torch.randn(fr, 186, dtype=torch.float64, device=dev)
     outs = {}
-    for mode in sys.argv[1:] or ("stream", "fused", "multipass", "seq"):
+    for mode in sys.argv[1:] or ("stream", "direct", "fused", "multipass", "seq"):
         os.environ["ITTS_MLPG_PATH"] = mode
         ms = timed(lambda: ops.mlpg_generation(feat, var, 62, off))
         outs[mode] = ops.mlpg_generation(feat, var, 62, off)

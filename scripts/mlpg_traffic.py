@@ -9,7 +9,7 @@ import glob
 import json
 import sys
 
-GROUPS = {"stream": ("mlpg_reduce_kernel", "mlpg_scan_kernel", "mlpg_solve_kernel"),
+GROUPS = {"stream": ("mlpg_records_kernel<2>", "mlpg_reduce_kernel<16, 2, true>", "mlpg_scan_kernel", "mlpg_solve_kernel<16, 2, true>"),
           "fused": ("mlpg_fused_kernel",),
           "multipass": ("mlpg_transfer_kernel", "mlpg_chunk_kernel")}
 

@@ -20,7 +20,7 @@ def _case(rng, lengths, dim, extra_cols=0, col0=0):
     # time-parallel path: utterance lengths around the 64-frame chunk boundaries, mixed with short ones
     ([194, 195, 257, 258, 259, 130, 66, 3, 1, 322], 4, 0), ([193, 2], 2, 0), ([4098], 1, 0),
 ])
-@pytest.mark.parametrize("path", ["stream", "stream8", "stream32", "fused", "multipass", "seq"])
+@pytest.mark.parametrize("path", ["stream", "direct", "stream8", "stream32", "fused", "multipass", "seq"])
 def test_mlpg_matches_oracle(gpu, lengths, dim, col0, path, monkeypatch):
     """Every solve the library holds (ITTS_MLPG_PATH; "stream" is what runs by default) against the
     C oracle."""
