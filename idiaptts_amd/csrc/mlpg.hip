@@ -1300,23 +1300,30 @@ __device__ __forceinline__ void st_form_b_staged(const double* tile, int64_t jlo
   fu_form_b<FU_FL>(la, f, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
 }
 
-// one record per group of GW chunks, expanded on the device from the per-utterance tables
-template <int GW>
+// one record per group of GA (reduce kernel) and of GB (solve kernel) chunks, expanded on the device
+// from the per-utterance tables
+template <int GA, int GB>
 __global__ __launch_bounds__(64) void mlpg_records_kernel(const int64_t* __restrict__ offsets,
                                                           const int* __restrict__ chunk0,
-                                                          const int* __restrict__ group0,
-                                                          StRecord* __restrict__ rec) {
+                                                          const int* __restrict__ group_a,
+                                                          const int* __restrict__ group_b,
+                                                          StRecord* __restrict__ rec_a,
+                                                          StRecord* __restrict__ rec_b) {
   const int u = blockIdx.x;
-  const int g0 = group0[u], ng = group0[u + 1] - g0;
   const int64_t t0 = offsets[u];
   const int T = (int)(offsets[u + 1] - t0);
-  for (int i = threadIdx.x; i < ng; i += 64) {
+  const int c0 = chunk0[u];
+  const int a0 = group_a[u], na = group_a[u + 1] - a0;
+  const int b0 = group_b[u], nb = group_b[u + 1] - b0;
+  for (int i = threadIdx.x; i < na + nb; i += 64) {
+    const bool second = i >= na;
+    const int gi = second ? i - na : i, gw = second ? GB : GA;
     StRecord r{};
     r.t0 = t0;
     r.T = T;
-    r.k0 = i * GW;
-    r.chunk = chunk0[u] + i * GW;
-    rec[g0 + i] = r;
+    r.k0 = gi * gw;
+    r.chunk = c0 + gi * gw;
+    (second ? rec_b : rec_a)[(second ? b0 : a0) + gi] = r;
   }
 }
 
@@ -1340,7 +1347,6 @@ __global__ __launch_bounds__(GW * 64) void mlpg_reduce_kernel(StreamArgs g) {
   int64_t jlo = 0;
   StChunk<FU_FL> q;
   const bool active = q.open(g);      // its loads (constants, factor) fly together with the staging loads
-  if (q.K == 1) return;               // (uniform) a one-chunk utterance has nobody to hand a state to
   if (STAGE) {
     const int grp = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
     const StRecord rec = g.rec[grp];
@@ -1353,6 +1359,15 @@ __global__ __launch_bounds__(GW * 64) void mlpg_reduce_kernel(StreamArgs g) {
   double b[FU_FL];
   if (STAGE) st_form_b_staged<FU_FL>(st_tile, jlo, q, b);
   else fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
+  // b goes to the output rows: the solve kernel reads 496 B per frame from there instead of forming
+  // b again from 1 488 B of input (and overwrites it with x, chunk by chunk, in place)
+  if (q.dok) {
+    double* o = a.out + q.t0 * a.ld_out + a.ocol0 + q.d;
+#pragma unroll
+    for (int i = 0; i < FU_FL; ++i)
+      if (q.cst || i < q.n) o[(q.j0 + i) * a.ld_out] = b[i];
+  }
+  if (q.K == 1) return;               // a one-chunk utterance has nobody to hand a state to
   double e[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
   FuMats unused;
   if (q.cst) fu_reduce<FU_FL, true, true, false>(q.c, b, q.j0, q.n, tl, e, unused);
@@ -1624,31 +1639,19 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
 #undef ST_STAMP
 }
 
-template <int FU_FL, int GW, bool STAGE>
+template <int FU_FL, int GW>
 __global__ __launch_bounds__(GW * 64) void mlpg_solve_kernel(StreamArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double st_tile[];
   const MlpgArgs& a = g.a;
-  int64_t jlo = 0;
   StChunk<FU_FL> q;
-  const bool active = q.open(g);      // its loads (constants, factor, entry states) fly with the staging loads
+  if (!q.open(g)) return;
   const int64_t Dp = (int64_t)g.nblk * 64;
-  const double* st = g.st + (int64_t)(active ? q.chunk : 0) * 4 * Dp + (blockIdx.x % (unsigned)g.nblk) * 64 +
-                     (threadIdx.x & 63);
+  const double* st = g.st + (int64_t)q.chunk * 4 * Dp + (blockIdx.x % (unsigned)g.nblk) * 64 + (threadIdx.x & 63);
   const double s1 = st[0], s2 = st[Dp], t1 = st[2 * Dp], t2 = st[3 * Dp];
-  if (STAGE) {
-    const int grp = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
-    const StRecord rec = g.rec[grp];
-    int rows;
-    st_group_rows<FU_FL, GW>(rec, jlo, rows);
-    st_stage_rows<GW * 64, GW * FU_FL + 2>(a, db, rec.t0, jlo, rows, st_tile);
-    __syncthreads();
-  }
-  if (!active) return;
-  double b[FU_FL];
-  if (STAGE) st_form_b_staged<FU_FL>(st_tile, jlo, q, b);
-  else fu_form_b<FU_FL>(a, a.feat + q.t0 * a.ld_feat + a.col0 + q.d, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
-  double M[4], e[2], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
   double* o = a.out + q.t0 * a.ld_out + a.ocol0 + q.d;
+  double b[FU_FL];      // left in the output rows by the reduce kernel
+#pragma unroll
+  for (int i = 0; i < FU_FL; ++i) b[i] = (q.cst || i < q.n) ? o[(q.j0 + i) * a.ld_out] : 0.0;
+  double M[4], e[2], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
   if (q.cst) {
     fu_fwd<FU_FL, true, false>(q.c, b, q.j0, q.n, s1, s2, M, e, tl);
     fu_bwd<FU_FL, true, false>(q.c, b, q.j0, q.n, t1, t2, M, e, tl, o, a.ld_out, q.dok);
@@ -1670,22 +1673,28 @@ static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n
   // per utterance: first chunk and first group (batch-wide indices); the per-group records are
   // expanded from them on the device (at 4 096 utterances the host would otherwise build and
   // upload 2.4 - 4.9 MB of records per call)
-  std::vector<int> tab(2 * (size_t)(n_utts + 1), 0);
+  constexpr int GS = 4;      // chunks per workgroup of the solve kernel (no LDS there: four waves)
+  std::vector<int> tab(3 * (size_t)(n_utts + 1), 0);
   int* chunk0 = tab.data();
   int* group0 = tab.data() + (n_utts + 1);
-  int n_chunks = 0, n_groups = 0;
+  int* sgroup0 = tab.data() + 2 * (n_utts + 1);
+  int n_chunks = 0, n_groups = 0, n_sgroups = 0;
   for (int u = 0; u < n_utts; ++u) {
     const int64_t T = h_offsets[u + 1] - h_offsets[u];
     chunk0[u] = n_chunks;
     group0[u] = n_groups;
+    sgroup0[u] = n_sgroups;
     const int K = T > 0 ? fu_num_chunks<FL>(T) : 0;
     n_chunks += K;
     n_groups += (K + GW - 1) / GW;
+    n_sgroups += (K + GS - 1) / GS;
   }
   chunk0[n_utts] = n_chunks;
   group0[n_utts] = n_groups;
+  sgroup0[n_utts] = n_sgroups;
   const int nblk = (dim + 63) / 64;
-  const size_t rec_bytes = (size_t)n_groups * sizeof(StRecord);
+  const size_t rrec_bytes = (size_t)n_groups * sizeof(StRecord);
+  const size_t rec_bytes = rrec_bytes + (size_t)n_sgroups * sizeof(StRecord);
   const size_t c0_bytes = (tab.size() * sizeof(int) + 31) / 32 * 32;
   const size_t plane_bytes = (size_t)n_chunks * 4 * nblk * 64 * sizeof(double);
   char* blk = nullptr;
@@ -1694,10 +1703,10 @@ static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n
     const int rc = itts::staged_upload(blk + rec_bytes, tab.data(), tab.size() * sizeof(int), s);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(mlpg_records_kernel<GW>, dim3((unsigned)n_utts), dim3(64), 0, s, a.offsets,
-                     reinterpret_cast<const int*>(blk + rec_bytes),
-                     reinterpret_cast<const int*>(blk + rec_bytes) + (n_utts + 1),
-                     reinterpret_cast<StRecord*>(blk));
+  const int* d_tab = reinterpret_cast<const int*>(blk + rec_bytes);
+  hipLaunchKernelGGL((mlpg_records_kernel<GW, GS>), dim3((unsigned)n_utts), dim3(64), 0, s, a.offsets, d_tab,
+                     d_tab + (n_utts + 1), d_tab + 2 * (n_utts + 1), reinterpret_cast<StRecord*>(blk),
+                     reinterpret_cast<StRecord*>(blk + rrec_bytes));
   StreamArgs g;
   g.a = a;
   g.t_max = (int)t_max;
@@ -1725,14 +1734,15 @@ static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n
     if (!attr_set) {
       ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlpg_reduce_kernel<FL, GW, STAGE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
-      ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlpg_solve_kernel<FL, GW, STAGE>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
       attr_set = true;
     }
   }
   hipLaunchKernelGGL((mlpg_reduce_kernel<FL, GW, STAGE>), grid, dim3(GW * 64), tile_bytes, s, g);
   hipLaunchKernelGGL(mlpg_scan_kernel<FL>, dim3((unsigned)(n_utts * nblk)), dim3(ST_SW * 64), 0, s, g);
-  hipLaunchKernelGGL((mlpg_solve_kernel<FL, GW, STAGE>), grid, dim3(GW * 64), tile_bytes, s, g);
+  g.rec = reinterpret_cast<const StRecord*>(blk + rrec_bytes);
+  g.n_groups = n_sgroups;
+  hipLaunchKernelGGL((mlpg_solve_kernel<FL, GS>), dim3((unsigned)((size_t)n_sgroups * nblk)), dim3(GS * 64), 0, s,
+                     g);
   ITTS_LAUNCH_CHECK();
   if (g.scan_trace) {          // debugging aid: per-wave phase stamps of the scan kernel as text
     std::vector<unsigned long long> h(scan_trace_words);

@@ -15,3 +15,12 @@ rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INST
 python3 $R/scripts/pmc_summary.py $O/pmc_m gemm_ring > $O/gemm_mfma_busy.txt 2>&1
 find $O -name "*counter_collection.csv" -size +20M -delete
 ls -la $O
+# the whole default bench: line + per-kernel statistics of every section
+python3 $R/bench.py 2> $O/full_stderr.txt | tail -1 > $O/full_bench_line.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/full_raw -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>&1
+cp $(ls $O/full_raw/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
+rm -rf $O/full_raw
+# MLPG: HBM traffic of the solves
+bash $R/scripts/mlpg_pmc.sh $1 > $O/mlpg_pmc.txt 2>&1
+mv $R/gpurun_out/$1_mlpg_traffic.json $O/mlpg_traffic.json
+ls -la $O
