@@ -62,8 +62,8 @@ __device__ __host__ inline int mlpg_num_chunks(int64_t T) {
 // only); the per-utterance solve reads it and only re-derives the last two frames.  The solve is
 // then two first-order-dependent sweeps of ~3 FMAs per frame instead of a sqrt and three
 // divisions per frame in the dependency chain.
-__global__ __launch_bounds__(64) void mlpg_factor_kernel(MlpgArgs a, int t_max) {
-  const int d = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void mlpg_factor_block(const MlpgArgs& a, int t_max, int block) {
+  const int d = block * 64 + threadIdx.x;
   if (d >= a.dim) return;
   const int D = a.dim;
   const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
@@ -80,10 +80,12 @@ __global__ __launch_bounds__(64) void mlpg_factor_kernel(MlpgArgs a, int t_max) 
     const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) + (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
     const double pj1 = -2.0 * (tau2(j) + tau2(j + 1));
     const double pj2 = tau2(j + 1) - 0.25 * tau1(j + 1);
-    const double dd = sqrt(pjj - l1p * l1p - l2p * l2p);
-    const double l1 = (pj1 - cprev * l1p) / dd;
-    const double l2 = pj2 / dd;
-    fd[(int64_t)j * D] = 1.0 / dd;   // reciprocal: the solve multiplies instead of dividing
+    // one square root and one division per frame: this loop is a pure latency chain (one wave per
+    // 64 dimensions) in front of every solve
+    const double inv = 1.0 / sqrt(pjj - l1p * l1p - l2p * l2p);
+    const double l1 = (pj1 - cprev * l1p) * inv;
+    const double l2 = pj2 * inv;
+    fd[(int64_t)j * D] = inv;        // reciprocal: the solve multiplies instead of dividing
     fl1[(int64_t)j * D] = l1;
     fl2[(int64_t)j * D] = l2;
     // P is constant for j >= 2, so the recurrence is a fixed map of (l1p, l2p, cprev): once the
@@ -99,6 +101,10 @@ __global__ __launch_bounds__(64) void mlpg_factor_kernel(MlpgArgs a, int t_max) 
     if (fixed) break;
   }
   a.nconv[d] = j < t_max ? j : t_max - 1;
+}
+
+__global__ __launch_bounds__(64) void mlpg_factor_kernel(MlpgArgs a, int t_max) {
+  mlpg_factor_block(a, t_max, blockIdx.x);
 }
 
 // Latency-bound sequential sweeps: what limits throughput is the number of independent chains in
@@ -1300,18 +1306,22 @@ __device__ __forceinline__ void st_form_b_staged(const double* tile, int64_t jlo
   fu_form_b<FU_FL>(la, f, q.j0, q.n, q.T, q.cst, q.v0, q.v1, q.v2, b);
 }
 
-// one record per group of GA (reduce kernel) and of GB (solve kernel) chunks, expanded on the device
-// from the per-utterance tables
+// First launch of the stream path: the shared factor (blocks < nblk) and, beside it, one record per
+// group of GA (reduce kernel) and of GB (solve kernel) chunks, expanded from the per-utterance tables
 template <int GA, int GB>
-__global__ __launch_bounds__(64) void mlpg_records_kernel(const int64_t* __restrict__ offsets,
-                                                          const int* __restrict__ chunk0,
-                                                          const int* __restrict__ group_a,
-                                                          const int* __restrict__ group_b,
-                                                          StRecord* __restrict__ rec_a,
-                                                          StRecord* __restrict__ rec_b) {
-  const int u = blockIdx.x;
-  const int64_t t0 = offsets[u];
-  const int T = (int)(offsets[u + 1] - t0);
+__global__ __launch_bounds__(64) void mlpg_prep_kernel(MlpgArgs a, int t_max, int nblk,
+                                                       const int* __restrict__ chunk0,
+                                                       const int* __restrict__ group_a,
+                                                       const int* __restrict__ group_b,
+                                                       StRecord* __restrict__ rec_a,
+                                                       StRecord* __restrict__ rec_b) {
+  if ((int)blockIdx.x < nblk) {        // the shared Cholesky factor of 64 dimensions
+    mlpg_factor_block(a, t_max, blockIdx.x);
+    return;
+  }
+  const int u = blockIdx.x - nblk;
+  const int64_t t0 = a.offsets[u];
+  const int T = (int)(a.offsets[u + 1] - t0);
   const int c0 = chunk0[u];
   const int a0 = group_a[u], na = group_a[u + 1] - a0;
   const int b0 = group_b[u], nb = group_b[u + 1] - b0;
@@ -1668,7 +1678,7 @@ using namespace itts;
 
 // reduce -> scan -> solve (see above)
 template <int FL, int GW, bool STAGE>
-static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n_utts, int dim, int64_t t_max,
+static int mlpg_stream_launch(MlpgArgs a, const int64_t* h_offsets, int n_utts, int dim, int64_t t_max,
                               hipStream_t s) {
   // per utterance: first chunk and first group (batch-wide indices); the per-group records are
   // expanded from them on the device (at 4 096 utterances the host would otherwise build and
@@ -1695,23 +1705,30 @@ static int mlpg_stream_launch(const MlpgArgs& a, const int64_t* h_offsets, int n
   const int nblk = (dim + 63) / 64;
   const size_t rrec_bytes = (size_t)n_groups * sizeof(StRecord);
   const size_t rec_bytes = rrec_bytes + (size_t)n_sgroups * sizeof(StRecord);
-  const size_t c0_bytes = (tab.size() * sizeof(int) + 31) / 32 * 32;
+  // [records | offsets (int64) | chunk / group tables (int) | aggregates | entry states]; offsets and
+  // tables travel in ONE upload
+  const size_t off_bytes = ((size_t)(n_utts + 1) * sizeof(int64_t) + 31) / 32 * 32;
+  const size_t c0_bytes = off_bytes + (tab.size() * sizeof(int) + 31) / 32 * 32;
   const size_t plane_bytes = (size_t)n_chunks * 4 * nblk * 64 * sizeof(double);
   char* blk = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, rec_bytes + c0_bytes + 2 * plane_bytes, s));
   {
-    const int rc = itts::staged_upload(blk + rec_bytes, tab.data(), tab.size() * sizeof(int), s);
+    std::vector<char> host(off_bytes + tab.size() * sizeof(int), 0);
+    std::memcpy(host.data(), h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t));
+    std::memcpy(host.data() + off_bytes, tab.data(), tab.size() * sizeof(int));
+    const int rc = itts::staged_upload(blk + rec_bytes, host.data(), host.size(), s);
     if (rc) return rc;
   }
-  const int* d_tab = reinterpret_cast<const int*>(blk + rec_bytes);
-  hipLaunchKernelGGL((mlpg_records_kernel<GW, GS>), dim3((unsigned)n_utts), dim3(64), 0, s, a.offsets, d_tab,
-                     d_tab + (n_utts + 1), d_tab + 2 * (n_utts + 1), reinterpret_cast<StRecord*>(blk),
-                     reinterpret_cast<StRecord*>(blk + rrec_bytes));
+  a.offsets = reinterpret_cast<const int64_t*>(blk + rec_bytes);
+  const int* d_tab = reinterpret_cast<const int*>(blk + rec_bytes + off_bytes);
+  hipLaunchKernelGGL((mlpg_prep_kernel<GW, GS>), dim3((unsigned)(nblk + n_utts)), dim3(64), 0, s, a, (int)t_max,
+                     nblk, d_tab, d_tab + (n_utts + 1), d_tab + 2 * (n_utts + 1),
+                     reinterpret_cast<StRecord*>(blk), reinterpret_cast<StRecord*>(blk + rrec_bytes));
   StreamArgs g;
   g.a = a;
   g.t_max = (int)t_max;
   g.rec = reinterpret_cast<const StRecord*>(blk);
-  g.chunk0 = reinterpret_cast<const int*>(blk + rec_bytes);
+  g.chunk0 = d_tab;
   g.n_groups = n_groups;
   g.nblk = nblk;
   g.agg = reinterpret_cast<double*>(blk + rec_bytes + c0_bytes);
@@ -1792,16 +1809,10 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   itts::ScratchScope scratch_scope(s);
   double* scratch = reinterpret_cast<double*>(d_scratch);
   int64_t* d_off = reinterpret_cast<int64_t*>(scratch + 3 * t_total * (int64_t)dim);
-  {
-    const int rc = itts::staged_upload(d_off, h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t), s);
-    if (rc) return rc;
-  }
   int* d_nconv = reinterpret_cast<int*>(d_off + (t_total + 2));
   MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total, d_nconv};
   int64_t t_max = 0;
   for (int u = 0; u < n_utts; ++u) t_max = std::max(t_max, h_offsets[u + 1] - h_offsets[u]);
-  hipLaunchKernelGGL(mlpg_factor_kernel, dim3((dim + 63) / 64), dim3(64), 0, s, a, (int)t_max);
-  ITTS_LAUNCH_CHECK();
   const int kchunks = mlpg_num_chunks(t_max);
   // which solve (ITTS_MLPG_PATH, for A/B runs and the tests): "stream" = reduce -> scan -> solve
   // with 16-frame chunks, two chunks per workgroup, input rows staged through LDS (the default);
@@ -1813,16 +1824,24 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   const std::string path = path_env ? path_env : "stream";
   ITTS_REQUIRE(path == "stream" || path == "stream8" || path == "stream32" || path == "fused" ||
                path == "multipass" || path == "seq" || path == "direct", "unknown ITTS_MLPG_PATH");
+  if (kchunks >= 3) {      // the stream paths upload their own tables and compute the factor in their first launch
+    if (path == "stream") return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
+    if (path == "direct") return mlpg_stream_launch<16, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
+    if (path == "stream32") return mlpg_stream_launch<32, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
+    if (path == "stream8") return mlpg_stream_launch<8, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
+  }
+  {
+    const int rc = itts::staged_upload(d_off, h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t), s);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(mlpg_factor_kernel, dim3((dim + 63) / 64), dim3(64), 0, s, a, (int)t_max);
+  ITTS_LAUNCH_CHECK();
   if (kchunks < 3 || path == "seq") {      // short utterances: the sequential sweeps are as fast
     dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
     hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
     ITTS_LAUNCH_CHECK();
     return ITTS_OK;
   }
-  if (path == "stream") return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
-  if (path == "direct") return mlpg_stream_launch<16, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
-  if (path == "stream32") return mlpg_stream_launch<32, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
-  if (path == "stream8") return mlpg_stream_launch<8, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
   // fused single-pass solve (one read of the input, one write of the output) unless an utterance
   // is so long that its super-chunks could exhaust the resident workgroups (see the kernel)
   // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW>[x<waves per SIMD>]

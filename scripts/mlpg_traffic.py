@@ -9,7 +9,7 @@ import glob
 import json
 import sys
 
-GROUPS = {"stream": ("mlpg_records_kernel<2>", "mlpg_reduce_kernel<16, 2, true>", "mlpg_scan_kernel", "mlpg_solve_kernel<16, 2, true>"),
+GROUPS = {"stream": ("mlpg_prep_kernel", "mlpg_reduce_kernel", "mlpg_scan_kernel", "mlpg_solve_kernel"),
           "fused": ("mlpg_fused_kernel",),
           "multipass": ("mlpg_transfer_kernel", "mlpg_chunk_kernel")}
 
