@@ -96,3 +96,24 @@ def test_mlpg_slowly_settling_factor(gpu, scan_seq, monkeypatch):
         ref = capi.mlpg(feat[a:b], var, dim)
         scale = max(1.0, np.abs(ref).max())
         assert np.abs(out[a:b] - ref).max() <= 1e-9 * scale, (u, np.abs(out[a:b] - ref).max())
+
+
+@pytest.mark.parametrize("path", ["stream", "direct", "fused", "multipass"])
+def test_mlpg_more_than_64_dimensions_and_an_output_slice(gpu, path, monkeypatch):
+    """Two 64-dimension blocks (dim = 70) and a result written into columns 3 .. 72 of a wider
+    array whose other columns must stay untouched (the stream path also parks b in those rows)."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    monkeypatch.setenv("ITTS_MLPG_PATH", path)
+    rng = np.random.default_rng(21)
+    lengths, dim = [300, 17, 500], 70
+    feat, var, offsets = _case(rng, lengths, dim)
+    out = torch.full((int(offsets[-1]), dim + 5), -7.0, dtype=torch.float64, device=gpu)
+    ops.mlpg_generation(torch.from_numpy(feat).to(gpu), torch.from_numpy(var).to(gpu), dim, offsets.tolist(),
+                        out=out, ocol0=3)
+    got = out.cpu().numpy()
+    assert (got[:, :3] == -7.0).all() and (got[:, 3 + dim:] == -7.0).all()
+    for u in range(len(lengths)):
+        a, b = offsets[u], offsets[u + 1]
+        ref = capi.mlpg(feat[a:b], var, dim)
+        assert np.abs(got[a:b, 3:3 + dim] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
