@@ -642,6 +642,62 @@ def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
                                "epoch_ms": dt * 1e3, "valid_frames_per_s": n / dt}}
 
 
+class SclkSampler:
+    """Shader clock of GPU `index` while a section runs (sysfs pp_dpm_sclk, the level marked '*',
+    sampled every 20 ms by a thread): boxes of the pool sustain different clocks under the fp32-MFMA
+    load, and the roofline fraction is quoted against the 2.4 GHz peak."""
+
+    def __init__(self, index=0):
+        import glob
+        self.path = None
+        self.samples = []
+        self._stop = False
+        self._thread = None
+        try:       # the sysfs card of torch device `index`: match its PCI address
+            props = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+            for card in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(card).endswith(addr) and os.path.isfile(card + "/pp_dpm_sclk"):
+                    self.path = card + "/pp_dpm_sclk"
+        except (AttributeError, RuntimeError, OSError):
+            pass
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                for line in f:
+                    if "*" in line:
+                        return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError, TypeError):
+            pass
+        return None
+
+    def __enter__(self):
+        import threading
+        if self.path is not None:
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v is not None:
+                        self.samples.append(v)
+                    time.sleep(0.02)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1],
+                "samples": len(v)}
+
+
 def visible_gpus():
     """Number of GPUs this process may use, WITHOUT touching HIP: the compute nodes of the KFD
     topology (sysfs) that have SIMDs, cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
@@ -784,11 +840,13 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
+    clock = SclkSampler(local_rank)
+    with clock:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        dt = time.perf_counter() - t0
     if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -866,7 +924,8 @@ def main():
                     "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
                     "algorithmic_flops_per_launch": flops / n_launch,
-                    "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / n_launch}
+                    "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / n_launch,
+                    "shader_clock_during_timed_steps": clock.summary()}
         cpu = None
         if want_cpu:   # CPU baseline: rank 0 at N = 1 only
             cpu = cpu_baseline_ff(args.utts_per_gpu, max_seconds=min(20.0, args.cpu_budget_s / 4))
