@@ -522,13 +522,12 @@ static int launch_gemm(GemmArgs g, int splitk, hipStream_t s) {
 // columns, its 4 waves take every 4th slab each (all loads of a thread independent -> in flight
 // together) and the four partial sums meet in LDS in a fixed order.  n % 4 == 0 and 16-byte
 // aligned buffers take this path, anything else the scalar tail kernel.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int S,
-                                                           int64_t n, float* __restrict__ out,
-                                                           int accumulate) {
-  __shared__ float4 part[3][64];
+__device__ __forceinline__ void reduce_slabs_vec_body(const float* __restrict__ slabs, int S, int64_t n,
+                                                      float* __restrict__ out, int accumulate, int64_t block,
+                                                      float4 (*part)[64]) {
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t n4 = n >> 2;
-  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t c = block * 64 + tx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < n4) {
     const float4* p = reinterpret_cast<const float4*>(slabs) + c;
@@ -556,12 +555,11 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 // same split of the work for buffers that cannot be read as float4 (n % 4 != 0, e.g. 187 biases)
-__global__ __launch_bounds__(256) void reduce_slabs_scalar_kernel(const float* __restrict__ slabs, int S,
-                                                                  int64_t n, float* __restrict__ out,
-                                                                  int accumulate) {
-  __shared__ float part[3][64];
+__device__ __forceinline__ void reduce_slabs_scalar_body(const float* __restrict__ slabs, int S, int64_t n,
+                                                         float* __restrict__ out, int accumulate,
+                                                         int64_t block, float (*part)[64]) {
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t c = block * 64 + tx;
   float s = 0.f;
   if (c < n) {
 #pragma unroll 8
@@ -577,9 +575,101 @@ __global__ __launch_bounds__(256) void reduce_slabs_scalar_kernel(const float* _
   }
 }
 
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int S,
+                                                           int64_t n, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ float4 part[3][64];
+  reduce_slabs_vec_body(slabs, S, n, out, accumulate, blockIdx.x, part);
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_scalar_kernel(const float* __restrict__ slabs, int S,
+                                                                  int64_t n, float* __restrict__ out,
+                                                                  int accumulate) {
+  __shared__ float part[3][64];
+  reduce_slabs_scalar_body(slabs, S, n, out, accumulate, blockIdx.x, part);
+}
+
+// Several reductions in ONE launch (itts_defer_reductions / itts_reduce_deferred): a training step
+// owes one slab reduction per layer (plus odd-sized bias vectors and the loss partial sums), each a
+// 5 us launch of its own that the next GEMM then waits for; queued, they run as segments of one
+// grid.  Same arithmetic per element as the single kernels above (bit-identical results).
+constexpr int kMaxDeferred = 16;
+struct ReduceSeg {
+  const void* src;      // slabs (float) or partial sums (double, kind 2)
+  void* out;
+  int64_t n;            // floats per slab / number of partial sums
+  double scale;         // kind 2
+  int S;
+  int accumulate;
+  int kind;             // 0: float4 columns, 1: scalar columns, 2: sum of doubles -> one float
+  int first_block;
+};
+struct ReduceMulti {
+  ReduceSeg seg[kMaxDeferred];
+  int nseg;
+};
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceMulti d) {
+  __shared__ float4 part4[3][64];
+  __shared__ double red[16];
+  int i = 0;
+  while (i + 1 < d.nseg && (int)blockIdx.x >= d.seg[i + 1].first_block) ++i;
+  const ReduceSeg& g = d.seg[i];
+  const int64_t block = (int64_t)blockIdx.x - g.first_block;
+  if (g.kind == 0) {
+    reduce_slabs_vec_body(static_cast<const float*>(g.src), g.S, g.n, static_cast<float*>(g.out), g.accumulate,
+                          block, part4);
+  } else if (g.kind == 1) {
+    reduce_slabs_scalar_body(static_cast<const float*>(g.src), g.S, g.n, static_cast<float*>(g.out),
+                             g.accumulate, block, reinterpret_cast<float (*)[64]>(part4));
+  } else {
+    const double* partial = static_cast<const double*>(g.src);
+    double s = 0.0;
+    for (int k = threadIdx.x; k < (int)g.n; k += 256) s += partial[k];   // fixed order: deterministic
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *static_cast<float*>(g.out) = (float)(s * g.scale);
+  }
+}
+
+static thread_local bool t_defer = false;
+static thread_local ReduceMulti t_pending{};
+
+static int flush_deferred(hipStream_t s) {
+  if (t_pending.nseg == 0) return ITTS_OK;
+  const ReduceSeg& last = t_pending.seg[t_pending.nseg - 1];
+  const int64_t per = last.kind == 0 ? (last.n / 4 + 63) / 64 : (last.kind == 1 ? (last.n + 63) / 64 : 1);
+  const int64_t blocks = last.first_block + per;
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t_pending);
+  t_pending.nseg = 0;
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+static int queue_deferred(ReduceSeg g, hipStream_t s) {
+  if (t_pending.nseg == kMaxDeferred) {
+    const int rc = flush_deferred(s);
+    if (rc) return rc;
+  }
+  int64_t first = 0;
+  if (t_pending.nseg > 0) {
+    const ReduceSeg& p = t_pending.seg[t_pending.nseg - 1];
+    first = p.first_block + (p.kind == 0 ? (p.n / 4 + 63) / 64 : (p.kind == 1 ? (p.n + 63) / 64 : 1));
+  }
+  ITTS_REQUIRE(first < ((int64_t)1 << 30), "too many deferred reduction blocks");
+  g.first_block = (int)first;
+  t_pending.seg[t_pending.nseg++] = g;
+  return ITTS_OK;
+}
+
 static int launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, int accumulate,
                                hipStream_t s) {
-  if (n % 4 == 0 && aligned16(slabs) && aligned16(out))
+  const bool vec = n % 4 == 0 && aligned16(slabs) && aligned16(out);
+  if (t_defer) {
+    ReduceSeg g{};
+    g.src = slabs; g.out = out; g.n = n; g.S = S; g.accumulate = accumulate; g.kind = vec ? 0 : 1;
+    return queue_deferred(g, s);
+  }
+  if (vec)
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, S,
                        n, out, accumulate);
   else
@@ -587,6 +677,18 @@ static int launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out,
                        S, n, out, accumulate);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
+}
+
+extern "C" int itts_defer_reductions(int on) {
+  ITTS_REQUIRE(on || t_pending.nseg == 0,
+               "queued reductions must be run (itts_reduce_deferred) before deferral is switched off");
+  t_defer = on != 0;
+  return ITTS_OK;
+}
+
+extern "C" int itts_reduce_deferred(void* stream) {
+  t_defer = false;
+  return flush_deferred(as_stream(stream));
 }
 
 // column sums of dz[M,N] over a row slice -> partial[z][n]
@@ -654,6 +756,18 @@ __global__ __launch_bounds__(256) void masked_mse_final_kernel(const double* __r
   s = block_sum(s, red);
   if (threadIdx.x == 0) *loss = (float)(s * scale);
 }
+
+static int launch_mse_final(const double* partial, int nb, double scale, float* loss, hipStream_t s) {
+  if (t_defer) {
+    ReduceSeg g{};
+    g.src = partial; g.out = loss; g.n = nb; g.scale = scale; g.S = 1; g.kind = 2;
+    return queue_deferred(g, s);
+  }
+  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, scale, loss);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
 
 // ---- row-weighted elementwise losses (the other NamedLoss types / reductions) ------------------
 // loss = sum_r w[r] sum_c e(pred - target), e = squared (kind 0, MSELoss) or absolute (kind 1,
@@ -900,10 +1014,7 @@ extern "C" int itts_linear_fwd_mse(const float* d_x, int64_t ldx, const float* d
     rc = launch_gemm_tn<true, true, EPI_MSE, 1, 1>(g, 1, s);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
-                     reinterpret_cast<const double*>(d_workspace), (int)tiles, scale, d_loss);
-  ITTS_LAUNCH_CHECK();
-  return ITTS_OK;
+  return launch_mse_final(reinterpret_cast<const double*>(d_workspace), (int)tiles, scale, d_loss, s);
 }
 
 extern "C" int itts_act_bwd(const float* d_dy, const float* d_y, float* d_dz, int64_t n_elem,
@@ -1092,10 +1203,7 @@ extern "C" int itts_masked_mse(const float* d_pred, int64_t ldp, const float* d_
                      d_row_valid, M, D, (float)(2.0 * scale), d_grad, ldg,
                      reinterpret_cast<double*>(d_workspace));
   ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(masked_mse_final_kernel, dim3(1), dim3(256), 0, s,
-                     reinterpret_cast<const double*>(d_workspace), nb, scale, d_loss);
-  ITTS_LAUNCH_CHECK();
-  return ITTS_OK;
+  return launch_mse_final(reinterpret_cast<const double*>(d_workspace), nb, scale, d_loss, s);
 }
 
 extern "C" int itts_weighted_loss(const float* d_pred, int64_t ldp, const float* d_target, int64_t ldt,

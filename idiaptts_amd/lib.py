@@ -24,6 +24,8 @@ _SIGNATURES = {
     "itts_last_error": (c_char_p, []),
     "itts_device_count": (c_int, []),
     "itts_release_scratch": (c_int, []),
+    "itts_defer_reductions": (c_int, [c_int]),
+    "itts_reduce_deferred": (c_int, [_P]),
     "itts_scratch_pool_stats": (c_int, [POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "itts_cheaptrick_fft_size": (c_int, [c_int, c_double]),
     "itts_num_aperiodicities": (c_int, [c_int]),

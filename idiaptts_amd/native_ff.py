@@ -173,6 +173,15 @@ class FlatFFModel:
         and the handles are left in self._pending for train_step to wait on before Adam."""
         self._pending = []
         x = self.pack_input(x)
+        if reduce or os.environ.get("ITTS_FF_DEFER", "1") == "0":
+            return self._loss_and_backward(x, target, row_valid, n_valid_global, reduce_group, reduce)
+        # one process: the loss sum and the layers' split-K slab reductions are queued and run as ONE
+        # launch at the end (five launches less per step); with data parallelism every layer's
+        # gradient is reduced at once, because its all-reduce starts right behind it
+        with ops.deferred_reductions():
+            return self._loss_and_backward(x, target, row_valid, n_valid_global, reduce_group, False)
+
+    def _loss_and_backward(self, x, target, row_valid, n_valid_global, reduce_group, reduce):
         M = x.shape[0]
         n = len(self.layout)
         if self.acts[-1] in (None, ops.ACT_NONE) and n > 1 and self.fuse_output_loss:

@@ -154,8 +154,7 @@ def linear_fwd_mse(x, w, b, target, row_valid, n_valid, loss_weight=1.0, grad=No
     loss = torch.empty((1,), dtype=torch.float32, device=x.device)
     if grad is None:
         grad = torch.zeros((M, (N + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :N]
-    ws = torch.empty(max(L.itts_linear_fwd_mse_workspace_bytes(M, N), 8), dtype=torch.uint8,
-                     device=x.device)
+    ws = _workspace(max(L.itts_linear_fwd_mse_workspace_bytes(M, N), 8), x.device)
     _lib.check(L.itts_linear_fwd_mse(_ptr(x), _rows(x, "x"), _ptr(w), _ptr(b), _ptr(target),
                                      _rows(target, "target"), _ptr(row_valid), float(n_valid),
                                      float(loss_weight), M, N, K, _ptr(loss), _ptr(grad),
@@ -190,17 +189,40 @@ def linear_bwd_input(dz, w, yprev=None, act_prev=ACT_NONE, out=None):
 
 
 _ws_cache = {}
+_defer = {"on": False, "next": 0}
 
 
 def _workspace(nbytes, device):
-    """Scratch of the current (device, stream): two streams never share a workspace."""
+    """Scratch of the current (device, stream): two streams never share a workspace.  Inside
+    `deferred_reductions()` every call gets a workspace of its own (the partial results it leaves
+    there are read by the one reduction launch at the end)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
+    if _defer["on"]:
+        key = key + (_defer["next"],)
+        _defer["next"] += 1
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+class deferred_reductions:
+    """with ops.deferred_reductions(): the loss and gradient entry points called inside leave their
+    partial sums / split-K slabs in place, and ONE launch reduces them all when the block ends
+    (itts_defer_reductions / itts_reduce_deferred; results bit-identical to the separate launches).
+    Nothing inside the block may read a loss or a weight / bias gradient produced inside it."""
+
+    def __enter__(self):
+        _lib.check(_lib.load().itts_defer_reductions(1), "itts_defer_reductions")
+        _defer["on"], _defer["next"] = True, 0
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _defer["on"] = False
+        _lib.check(_lib.load().itts_reduce_deferred(_stream()), "itts_reduce_deferred")
+        return False
 
 
 def linear_bwd_weight(dz, x, dw=None, db=None, accumulate=False, want_bias=True):
@@ -252,8 +274,7 @@ def masked_mse(pred, target, row_valid, n_valid, loss_weight=1.0, want_grad=True
     loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
     if want_grad and grad is None:
         grad = torch.empty((M, D), dtype=torch.float32, device=pred.device)
-    ws = torch.empty(max(L.itts_masked_mse_workspace_bytes(M, D), 8), dtype=torch.uint8,
-                     device=pred.device)
+    ws = _workspace(max(L.itts_masked_mse_workspace_bytes(M, D), 8), pred.device)
     _lib.check(L.itts_masked_mse(_ptr(pred), _rows(pred, "pred"), _ptr(target),
                                  _rows(target, "target"), _ptr(row_valid), M, D, float(n_valid),
                                  float(loss_weight), _ptr(loss),

@@ -44,6 +44,17 @@ int itts_scratch_pool_stats(int64_t* reserved, int64_t* used, int64_t* keep_thre
  * a block handed back on one stream is reused on another only behind an event), up to
  * ITTS_POOL_KEEP_GB (environment, default 64) between calls.  This synchronises the device and hands
  * every idle block back, e.g. between a feature-extraction job and training in one process. */
+/* Deferred reductions (this host thread): while on, itts_linear_fwd_mse / itts_masked_mse /
+ * itts_linear_bwd / itts_linear_bwd_weight leave their partial results (loss partial sums, split-K
+ * slabs of the weight and bias gradients) in the workspace they were given and queue the reduction
+ * they owe; itts_reduce_deferred then runs every queued reduction in ONE launch (bit-identical
+ * results) and switches deferral off.  The caller keeps each call's workspace alive and separate
+ * until then.  A training step of the dense stack owes five such reductions, each a launch of its own
+ * otherwise (FFWrapper.py:63-73 backward + NamedLoss.py:113-117; torch launches one kernel per
+ * gradient as well). */
+int itts_defer_reductions(int on);
+int itts_reduce_deferred(void* stream);
+
 int itts_release_scratch(void);
 
 /* ---- integer / scalar helpers (host, no GPU) ------------------------------------------- */

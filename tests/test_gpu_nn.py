@@ -318,3 +318,44 @@ def test_fused_backward_equals_the_separate_calls_bit_for_bit(gpu, M, N, K, with
     assert (dw.cpu().double() - dw_ref).abs().max() < 2e-4 * max(1.0, dw_ref.abs().max().item())
     assert (db.cpu().double() - dz.double().sum(0)).abs().max() < 2e-4 * max(1.0, dz.double().sum(0).abs().max().item())
     assert (dx.cpu().double() - dx_ref).abs().max() < 1e-5 * max(1.0, dx_ref.abs().max().item())
+
+
+def test_deferred_reductions_equal_the_separate_launches_bit_for_bit(gpu):
+    """ops.deferred_reductions(): loss partial sums, merged weight + bias slabs, a separate odd-sized
+    bias vector (187) and more reductions than one launch holds (17 > 16), all reduced at the end of
+    the block -- every result bit-equal to the immediate launches; and the dense stack's
+    loss_and_backward (which defers) against its undeferred body."""
+    from idiaptts_amd import ops
+    from idiaptts_amd.native_ff import FlatFFModel
+    g = torch.Generator().manual_seed(5)
+
+    def one_layer(M, N, K, defer):
+        x = torch.tanh(torch.randn(M, K, generator=torch.Generator().manual_seed(M))).to(gpu)
+        dz = torch.zeros(M, (N + 3) // 4 * 4, device=gpu)[:, :N]
+        dz.copy_(torch.randn(M, N, generator=torch.Generator().manual_seed(N)))
+        dw = torch.zeros(N, K, device=gpu)
+        db = torch.zeros(N, device=gpu)
+        ops.linear_bwd_weight(dz, x, dw=dw, db=db)
+        return dw, db
+
+    shapes = [(3001, 187, 512), (2500, 512, 512)] + [(400 + 37 * i, 64, 96) for i in range(15)]
+    ref = [one_layer(*s, defer=False) for s in shapes]
+    with ops.deferred_reductions():
+        got = [one_layer(*s, defer=True) for s in shapes]
+    torch.cuda.synchronize()
+    for (dw, db), (dw2, db2) in zip(ref, got):
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+    model = FlatFFModel([425, 512, 512, 187], ["tanh", "tanh", None], device=gpu, seed=3)
+    M = 2001
+    x = torch.randn(M, 425, generator=g).to(gpu)
+    y = torch.randn(M, 187, generator=g).to(gpu)
+    valid = (torch.rand(M, generator=g) > 0.1).to(torch.uint8).to(gpu)
+    nv = float(valid.sum().item())
+    loss_d = model.loss_and_backward(x, y, valid, nv).clone()
+    grads_d = model.grads.clone()
+    model.grads.zero_()
+    loss_i = model._loss_and_backward(model.pack_input(x), y, valid, nv, None, False).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_d, loss_i) and torch.equal(grads_d, model.grads)
+    assert float(loss_d) > 0
