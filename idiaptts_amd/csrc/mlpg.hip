@@ -1,18 +1,30 @@
 // MLPG: maximum-likelihood parameter generation for the reference's three windows.
 // Replaces MLPG.generation (idiaptts/misc/mlpg.py:94-127), i.e. the 62 python-level bandmat
-// calls per utterance (build_poe :57-92, bla.solveh :125), by ONE launch over all
+// calls per utterance (build_poe :57-92, bla.solveh :125), by one call over all
 // (utterance, dimension) pairs of a batch.
 //
 // Math (per dimension, T frames): P x = b with the symmetric pentadiagonal precision matrix
 //   P = diag(t0) + W1^T diag(t1) W1 + W2^T diag(t2) W2,   b = W0^T(m0 t0) + W1^T(m1 t1) + W2^T(m2 t2)
 // W1 = [-.5 0 .5], W2 = [1 -2 1] Toeplitz, t_w = 1/var_w with the delta variances of the first
 // and last frame forced to 1e11 (mlpg.py:114-117).  Solved by banded Cholesky (what
-// bandmat.linalg.solveh does): forward sweep stores (d, l1, l2, y) per frame, backward sweep
-// substitutes.  One lane owns one (utterance, dimension); a wave owns 64 neighbouring
-// dimensions so every row access is one coalesced 512-B segment.
+// bandmat.linalg.solveh does): forward sweep y = L^-1 b, backward sweep x = L^-T y.  One lane owns
+// one (utterance, dimension); a wave owns 64 neighbouring dimensions so every row access is one
+// coalesced 512-B segment.
+//
+// What is in this file, in the order it was built (ITTS_MLPG_PATH selects; the last is the default):
+//   mlpg_factor_kernel          the data-independent Cholesky factor, once per dimension, shared by
+//                               all utterances (stops when it repeats)
+//   mlpg_kernel ("seq")         the two sweeps frame by frame (batches of short utterances)
+//   mlpg_transfer / mlpg_chunk  ("multipass") both sweeps as affine scans over 64-frame chunks, four
+//                               passes over memory
+//   mlpg_fused_kernel ("fused") one pass: chunks held in registers, aggregates exchanged between
+//                               workgroups through memory (ticket order, polling)
+//   mlpg_prep / reduce / scan / solve ("stream") no wait anywhere: the backward contribution of a
+//                               chunk is accumulated while walking forward (adjoint identity), a
+//                               two-level scan gives every chunk its entry states, a second pass solves
 //
 // Roofline: HBM.  Algorithmic bytes per frame = 187*8 read + 63*8 written = 2000 B
-// (SURVEY.md section 8d); the factor scratch adds 3 f64 written + 4 read per (frame, dim).
+// (SURVEY.md section 8d); measured traffic and rates: DESIGN.md section 11c.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
