@@ -911,9 +911,9 @@ def main():
         flops = flops_per_frame(dims) * nloc
         achieved = flops / (ms * 1e-3) / 1e12
         # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # see profiles/r3_gemm_traffic.json); not re-measured inside bench.py.
+        # see profiles/r3f_gemm_traffic.json); not re-measured inside bench.py.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3f_gemm_traffic.json")
         if os.path.isfile(tpath) and args.utts_per_gpu == 32:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
