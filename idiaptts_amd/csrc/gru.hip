@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "rnn_common.h"
+#include "rnn_persist.h"
 
 namespace itts {
 
@@ -279,6 +280,15 @@ extern "C" int itts_gru_layer_fwd(const float* d_gin, const float* d_whh, const 
   int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
+  {
+    RnnPersistArgs p{};
+    p.gin = d_gin; p.whh = d_whh; p.bhh = d_bhh; p.h0 = d_h0; p.lengths = d_lengths; p.row_off = d_row_off;
+    p.rev_row = d_rev_row; p.y = d_y; p.gates = d_gates; p.hn = d_hn;
+    p.T = T; p.B = B; p.ndir = ndir;
+    const int done = rnn_persist_forward<3>(p, H, s);      // rnn_persist.h
+    if (done < 0) return ITTS_E_HIP;
+    if (done) return ITTS_OK;
+  }
   GruArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row; a.gin = d_gin;
   a.bhh = d_bhh; a.y = d_y; a.gates = d_gates;

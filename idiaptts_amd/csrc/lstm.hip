@@ -31,8 +31,8 @@
 #include <cstdio>
 #include <vector>
 
-#include "context.h"
 #include "rnn_common.h"
+#include "rnn_persist.h"
 
 namespace itts {
 
@@ -320,251 +320,6 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
 }
 
 
-// ---- persistent forward recurrence, one (direction, 16-row batch tile) per XCD --------------------
-// Taken when H = 512, the batch has at most 8 / ndir tiles of 16 rows and the device has 256 CUs
-// (ITTS_LSTM_PERSISTENT=0 keeps the step kernels).  The
-// step kernels above pay 3.4 us of launch boundary per step for the grid-wide exchange of h; here
-// the 32 workgroups an XCD holds (blockIdx % 8 = XCD under round-robin dispatch) keep one
-// recurrence to themselves for all T steps: workgroup c owns hidden units 16 c .. 16 c + 15 (all four
-// gates: a 128 KB image of its W_hh rows stays in LDS in the order the MFMA lanes read it), the
-// cell state stays in registers, and h travels through the XCD's L2 as self-validating pairs
-// (P, P ^ mask(step)) of 16-byte granules that a consumer lane re-reads until they match -- no
-// counter, no fence (measured in scripts/handoff_lab: 1.2 us per step, no stale or torn granule in
-// 1e10 reads).  A polling budget turns a missing workgroup into an abort
-// flag instead of a hang.
-constexpr int PH = 512;                          // hidden size this kernel is built for
-constexpr int P_W_BYTES = 4 * 4 * 8 * 64 * 16;   // W_hh image: [gate][k quarter][quad][lane] float4
-constexpr int P_PART_FLOATS = 4 * 4 * 16 * 17;   // partial gate sums [wave][gate][row][unit + pad]
-constexpr int P_LDS_BYTES = P_W_BYTES + P_PART_FLOATS * 4 + 16 * 16 * 4;
-
-struct LstmPersistArgs {
-  const float* gin;
-  const float* whh;
-  const float* h0;
-  const float* c0;
-  const int* lengths;
-  const int* row_off;
-  const int* rev_row;
-  float* y;
-  float* gates;
-  float* csave;
-  float* hn;
-  float* cn;
-  uint4* xchg;      // [8 groups][4 step slots][32 producers][P | C][64 lanes]
-  int* abort_flag;
-  int T, B, ndir, ntiles;
-};
-
-// asm operands must be native 128-bit vectors (a struct type such as uint4 gives the register
-// allocator no reason to keep its four components in consecutive registers)
-typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned persist_mask(int step) { return ((unsigned)(step + 1) * 0x9E3779B1u) | 1u; }
-
-// sixteen 16-byte L1-bypassing loads in flight together (eight producers' P and C granules), waited
-// for inside the statement (the compiler cannot see that the result of a bare load asm is not
-// there yet)
-__device__ __forceinline__ void persist_load16(const uint4* p, int stride, pu32x4 (&v)[8], pu32x4 (&c)[8]) {
-  const uint4 *p0 = p, *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride, *p4 = p + 4 * stride,
-              *p5 = p + 5 * stride, *p6 = p + 6 * stride, *p7 = p + 7 * stride;
-  asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %17, off sc1\n\t"
-               "global_load_dwordx4 %2, %18, off sc1\n\tglobal_load_dwordx4 %3, %19, off sc1\n\t"
-               "global_load_dwordx4 %4, %20, off sc1\n\tglobal_load_dwordx4 %5, %21, off sc1\n\t"
-               "global_load_dwordx4 %6, %22, off sc1\n\tglobal_load_dwordx4 %7, %23, off sc1\n\t"
-               "global_load_dwordx4 %8, %16, off offset:1024 sc1\n\tglobal_load_dwordx4 %9, %17, off offset:1024 sc1\n\t"
-               "global_load_dwordx4 %10, %18, off offset:1024 sc1\n\tglobal_load_dwordx4 %11, %19, off offset:1024 sc1\n\t"
-               "global_load_dwordx4 %12, %20, off offset:1024 sc1\n\tglobal_load_dwordx4 %13, %21, off offset:1024 sc1\n\t"
-               "global_load_dwordx4 %14, %22, off offset:1024 sc1\n\tglobal_load_dwordx4 %15, %23, off offset:1024 sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-                 "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
-               : "memory");
-}
-
-// the first (P, C) granule pair of one producer: 32 bytes per lane address, what a waiting wave
-// re-reads (sixteen full-width loads per poll from every waiting wave of 32 CUs crowd the L2 the
-// producers' stores have to get through)
-__device__ __forceinline__ void persist_load_pair(const uint4* p, pu32x4& v, pu32x4& c) {
-  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(v), "=&v"(c)
-               : "v"(p)
-               : "memory");
-}
-
-#ifndef PERSIST_TRACE
-#define PERSIST_TRACE 0
-#endif
-__global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(LstmPersistArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char psm[];
-  float4* Wl = reinterpret_cast<float4*>(psm);
-  float* Pp = reinterpret_cast<float*>(psm + P_W_BYTES);
-  float* hsh = Pp + P_PART_FLOATS;
-  const int group = blockIdx.x & 7, cu = blockIdx.x >> 3;
-  const int tiles_per_dir = 8 / a.ndir;
-  const int dir = group / tiles_per_dir, tile = group % tiles_per_dir;
-  if (tile >= a.ntiles) return;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int H = PH, G4 = 4 * PH;
-  const int j0 = cu * 16;
-
-  // the image of this workgroup's W_hh rows
-  {
-    const float* W = a.whh + (size_t)dir * G4 * H;
-    for (int idx = threadIdx.x; idx < 4 * 4 * 8 * 64; idx += 256) {
-      const int ln = idx & 63, qd = (idx >> 6) & 7, w2 = (idx >> 9) & 3, gg = idx >> 11;
-      const float* src = W + (size_t)(gg * H + j0 + (ln & 15)) * H + 128 * w2 + 16 * qd + (ln >> 4);
-      Wl[idx] = make_float4(src[0], src[4], src[8], src[12]);
-    }
-  }
-  // this thread's (row, unit) of the cell update
-  const int r = threadIdx.x >> 4, u = threadIdx.x & 15;
-  const int b = tile * 16 + r, j = j0 + u;
-  const bool valid = b < a.B;
-  const int len = valid ? a.lengths[b] : 0;
-  const int t_tile = a.lengths[tile * 16];          // the tile's longest row: how long this group runs
-  float c = (valid && a.c0) ? a.c0[dir * H + j] : 0.f;
-  float h = (valid && a.h0) ? a.h0[dir * H + j] : 0.f;
-  uint4* xg = a.xchg + (size_t)group * 4 * 32 * 128;
-  auto publish = [&](int step) {        // hsh holds h; wave 0 writes the (P, C) pair of this workgroup
-    if (wv == 0) {
-      const int rr = lane & 15, kq = lane >> 4;
-      float4 p4 = make_float4(hsh[rr * 16 + kq], hsh[rr * 16 + 4 + kq], hsh[rr * 16 + 8 + kq], hsh[rr * 16 + 12 + kq]);
-      const unsigned m = persist_mask(step);
-      uint4 P = make_uint4(__float_as_uint(p4.x), __float_as_uint(p4.y), __float_as_uint(p4.z), __float_as_uint(p4.w));
-      uint4 C = make_uint4(P.x ^ m, P.y ^ m, P.z ^ m, P.w ^ m);
-      uint4* dst = xg + ((size_t)(step & 3) * 32 + cu) * 128 + lane;
-      dst[0] = P;
-      dst[64] = C;
-    }
-  };
-  hsh[r * 16 + u] = h;
-  __syncthreads();
-  publish(0);
-
-  const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
-  auto row_at = [&](int st) -> size_t {
-    return dir == 0 ? (size_t)(a.row_off[st] + b) : (size_t)a.rev_row[(size_t)st * a.B + b];
-  };
-  size_t row_cur = 0, row_n1 = 0;
-  float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gc3 = 0.f;
-  if (0 < len) {
-    row_cur = row_at(0);
-    const float* gi = a.gin + row_cur * ldg + (size_t)dir * G4 + j;
-    gc0 = gi[0]; gc1 = gi[H]; gc2 = gi[2 * H]; gc3 = gi[3 * H];
-  }
-  if (1 < len) row_n1 = row_at(1);
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
-#define PT(i) do { if (PERSIST_TRACE) { const unsigned long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
-  if (PERSIST_TRACE) tprev = wall_clock64();
-  for (int s = 0; s < t_tile; ++s) {
-    const bool act = s < len;
-    // packed row and input projections of this thread's element: requested one and two steps ahead,
-    // BEHIND the poll of the step before (the poll's wait covers every load in flight, so a load
-    // issued in front of it would hold it back by a trip to HBM)
-    const size_t row = row_cur;
-    const float g0 = gc0, g1 = gc1, g2 = gc2, g3 = gc3;
-    // h_{s-1} of the whole tile: this wave's k quarter comes from producers 8 wv .. 8 wv + 7
-    pu32x4 pv[8], cv[8];
-    {
-      const uint4* src = xg + ((size_t)(s & 3) * 32 + 8 * wv) * 128 + lane;
-      const unsigned m = persist_mask(s);
-      int budget = 1 << 16;      // ~50 ms of polling at most
-      for (;;) {
-        // optimistic: usually everything is there (one trip); otherwise wait on one granule pair per
-        // producer (lane i & 7 watches producer 8 wv + (i & 7)) and fetch again
-        persist_load16(src, 128, pv, cv);
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          ok = ok && (pv[i].x ^ cv[i].x) == m && (pv[i].y ^ cv[i].y) == m && (pv[i].z ^ cv[i].z) == m &&
-               (pv[i].w ^ cv[i].w) == m;
-        if (__all(ok)) break;
-        const uint4* watch = xg + ((size_t)(s & 3) * 32 + 8 * wv + (lane & 7)) * 128;
-        bool gave_up = false;
-        for (;;) {
-          pu32x4 wp, wc;
-          persist_load_pair(watch, wp, wc);
-          if (__all((wp.x ^ wc.x) == m)) break;
-          if (--budget <= 0 || *reinterpret_cast<volatile int*>(a.abort_flag)) { gave_up = true; break; }
-          __builtin_amdgcn_s_sleep(4);
-        }
-        if (gave_up || --budget <= 0) {
-          if (lane == 0) atomicExch(a.abort_flag, 1);
-          break;
-        }
-      }
-    }
-    // step s + 1's input projections (their row index arrived a step ago) and step s + 2's row index
-    float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gn3 = 0.f;
-    size_t row_n2 = 0;
-    if (s + 1 < len) {
-      const float* gi = a.gin + row_n1 * ldg + (size_t)dir * G4 + j;
-      gn0 = gi[0]; gn1 = gi[H]; gn2 = gi[2 * H]; gn3 = gi[3 * H];
-    }
-    if (s + 2 < len) row_n2 = row_at(s + 2);
-    PT(0);
-    f32x4 acc[4];
-#pragma unroll
-    for (int gg = 0; gg < 4; ++gg) acc[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int qd = 0; qd < 8; ++qd) {
-      const float ax = __uint_as_float(pv[qd].x), ay = __uint_as_float(pv[qd].y), az = __uint_as_float(pv[qd].z),
-                  aw = __uint_as_float(pv[qd].w);
-      float4 bw[4];
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) bw[gg] = Wl[((gg * 4 + wv) * 8 + qd) * 64 + lane];
-      // the four gates are four independent accumulator chains: an MFMA never waits for the one before it
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bw[gg].x, acc[gg], 0, 0, 0);
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bw[gg].y, acc[gg], 0, 0, 0);
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bw[gg].z, acc[gg], 0, 0, 0);
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bw[gg].w, acc[gg], 0, 0, 0);
-    }
-#pragma unroll
-    for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) Pp[((wv * 4 + gg) * 16 + 4 * (lane >> 4) + e) * 17 + (lane & 15)] = acc[gg][e];
-    PT(1);
-    __syncthreads();
-    PT(2);
-    if (act) {
-      auto pre = [&](int gg) {
-        return (Pp[((0 * 4 + gg) * 16 + r) * 17 + u] + Pp[((1 * 4 + gg) * 16 + r) * 17 + u]) +
-               (Pp[((2 * 4 + gg) * 16 + r) * 17 + u] + Pp[((3 * 4 + gg) * 16 + r) * 17 + u]);
-      };
-      const float ig = sigmoid_acc(pre(0) + g0), fg = sigmoid_acc(pre(1) + g1), gg_ = tanhf(pre(2) + g2),
-                  og = sigmoid_acc(pre(3) + g3);
-      c = fg * c + ig * gg_;
-      h = og * tanhf(c);
-      a.y[row * ldh + (size_t)dir * H + j] = h;
-      if (a.gates) {
-        reinterpret_cast<float4*>(a.gates)[(row * a.ndir + dir) * H + j] = make_float4(ig, fg, gg_, og);
-        a.csave[row * ldh + (size_t)dir * H + j] = c;
-      }
-      if (s == len - 1) {
-        if (a.hn) a.hn[((size_t)dir * a.B + b) * H + j] = h;
-        if (a.cn) a.cn[((size_t)dir * a.B + b) * H + j] = c;
-      }
-    }
-    hsh[r * 16 + u] = h;
-    row_cur = row_n1; row_n1 = row_n2;
-    gc0 = gn0; gc1 = gn1; gc2 = gn2; gc3 = gn3;
-    PT(3);
-    __syncthreads();
-    if (s + 1 < t_tile) publish(s + 1);
-    PT(4);
-  }
-  if (PERSIST_TRACE && lane == 0 && (blockIdx.x < 8 || blockIdx.x == 100) )
-    printf("block %3d wave %d: steps %d  poll %.2f  mfma %.2f  barrier %.2f  cell %.2f  barrier+publish %.2f us per step\n", (int)blockIdx.x, wv, t_tile,
-           tacc[0] / 100.0 / t_tile, tacc[1] / 100.0 / t_tile, tacc[2] / 100.0 / t_tile, tacc[3] / 100.0 / t_tile, tacc[4] / 100.0 / t_tile);
-#undef PT
-}
-
 }  // namespace itts
 
 using namespace itts;
@@ -589,52 +344,13 @@ extern "C" int itts_lstm_layer_fwd(const float* d_gin, const float* d_whh, const
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   {
-    // The persistent per-XCD kernel (above) where it applies; ITTS_LSTM_PERSISTENT=0 keeps the step
-    // kernels.  It needs all 256 workgroups resident at once, which nobody can promise (another
-    // process may hold CUs): every wait carries a budget, the launch is followed by a read-back of
-    // the abort flag, and a launch that gave up is redone by the step kernels and switches the
-    // persistent path off for the rest of the process.
-    static std::atomic<bool> persist_usable{true};
-    const char* pe = getenv("ITTS_LSTM_PERSISTENT");      // read per call: tests switch it
-    const bool wanted = !(pe && pe[0] == '0');
-    const int ntiles = (B + 15) / 16;
-    if (wanted && persist_usable.load() && H == PH && ntiles <= 8 / ndir) {
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ITTS_HIP_CHECK(hipGetDevice(&dev));
-        ITTS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
-        n_cu = prop.multiProcessorCount;
-      }
-      DeviceContext* ctx = n_cu == 256 ? get_context() : nullptr;
-      if (ctx) {
-        const size_t xbytes = (size_t)8 * 4 * 32 * 128 * sizeof(uint4);
-        char* blk = nullptr;
-        itts::ScratchScope scope(s);
-        ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, xbytes + 64, s));
-        ITTS_HIP_CHECK(hipMemsetAsync(blk, 0, xbytes + 64, s));
-        LstmPersistArgs p{};
-        p.gin = d_gin; p.whh = d_whh; p.h0 = d_h0; p.c0 = d_c0; p.lengths = d_lengths; p.row_off = d_row_off;
-        p.rev_row = d_rev_row; p.y = d_y; p.gates = d_gates; p.csave = d_csave; p.hn = d_hn; p.cn = d_cn;
-        p.xchg = reinterpret_cast<uint4*>(blk);
-        p.abort_flag = reinterpret_cast<int*>(blk + xbytes);
-        p.T = T; p.B = B; p.ndir = ndir; p.ntiles = ntiles;
-        hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(256), dim3(256), P_LDS_BYTES, s, p);
-        ITTS_LAUNCH_CHECK();
-        int64_t* slot = pinned_slot(ctx);
-        *slot = 0;
-        ITTS_HIP_CHECK(hipMemcpyAsync(slot, p.abort_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-        ITTS_HIP_CHECK(hipStreamSynchronize(s));
-        ITTS_HIP_CHECK(itts::scratch_free(blk, s));
-        if ((int)*slot == 0) return ITTS_OK;
-        persist_usable.store(false);
-        fprintf(stderr, "libidiaptts_amd: the persistent LSTM recurrence gave up waiting (are all 256 CUs "
-                        "available to this process?); using the per-step kernels from now on\n");
-      }
-    }
+    RnnPersistArgs p{};
+    p.gin = d_gin; p.whh = d_whh; p.h0 = d_h0; p.c0 = d_c0; p.lengths = d_lengths; p.row_off = d_row_off;
+    p.rev_row = d_rev_row; p.y = d_y; p.gates = d_gates; p.csave = d_csave; p.hn = d_hn; p.cn = d_cn;
+    p.T = T; p.B = B; p.ndir = ndir;
+    const int done = rnn_persist_forward<4>(p, H, s);      // rnn_common.h
+    if (done < 0) return ITTS_E_HIP;
+    if (done) return ITTS_OK;
   }
   LstmArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row; a.gin = d_gin;

@@ -1,4 +1,4 @@
-"""Persistent per-XCD LSTM forward (ITTS_LSTM_PERSISTENT=1) against the per-step kernels: results and
+"""Persistent per-XCD LSTM forward (ITTS_RNN_PERSISTENT=1) against the per-step kernels: results and
 time of one bidirectional 512-unit layer at the bench's batch.  usage (GPU box): python scripts/exp_lstm_persist.py"""
 import os
 import sys
@@ -20,7 +20,7 @@ for B, seed in ((64, 5), (17, 3), (48, 9)):
     x = torch.randn(T, B, 1024, device=dev)
 
     def run(mode, n=3):
-        os.environ["ITTS_LSTM_PERSISTENT"] = mode
+        os.environ["ITTS_RNN_PERSISTENT"] = mode
         with torch.no_grad():
             out, (hn, cn) = layer(x, None, lens)
             torch.cuda.synchronize()

@@ -1,0 +1,38 @@
+"""Stress of the persistent LSTM / GRU forward: random ragged batches, every launch compared with the step
+kernels (ITTS_RNN_PERSISTENT=0).  usage (GPU box): python scripts/stress_lstm_persist.py [launches]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from idiaptts_amd import nn as inn
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(3)
+worst = 0.0
+for it in range(n):
+    bidir = bool(rng.integers(0, 2))
+    B = int(rng.integers(1, 65 if bidir else 129))
+    T = int(rng.choice([1, 2, 17, 100, 400, 1200]))
+    lens = rng.integers(1, T + 1, size=B)
+    lens[rng.integers(0, B)] = T
+    lens = torch.from_numpy(lens.astype(np.int64))
+    torch.manual_seed(it)
+    in_dim = int(rng.choice([64, 425, 1024]))
+    cell = "LSTM" if rng.random() < 0.5 else "GRU"
+    layer = getattr(inn, cell)(in_dim, 512, 1, bidirectional=bidir).to(dev)
+    x = torch.randn(T, B, in_dim, device=dev)
+    outs = []
+    for mode in ("0", "1"):
+        os.environ["ITTS_RNN_PERSISTENT"] = mode
+        with torch.no_grad():
+            o, st = layer(x, None, lens)
+        outs.append((o,) + (tuple(st) if isinstance(st, (tuple, list)) else (st,)))
+    torch.cuda.synchronize()
+    d = max(float((a - b).abs().max()) for a, b in zip(outs[0], outs[1]))
+    assert d < 5e-6, (it, B, T, bidir, d)
+    worst = max(worst, d)
+print("launches", n, "worst difference to the step kernels %.2e" % worst)
