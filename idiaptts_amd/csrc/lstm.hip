@@ -6,9 +6,11 @@
 // Split of the work (per layer):
 //   * gin = X W_ih^T + (b_ih + b_hh) for ALL time steps and both directions is ONE fp32-MFMA GEMM
 //     (nn.hip), so are dX, dW_ih, dW_hh and the bias gradients in the backward pass;
-//   * only the true recurrence h_{t-1} W_hh^T runs per time step.  One launch per step, both
-//     directions in it: the kernel boundary is the grid-wide dependency (~1.5 us; an in-kernel
-//     grid barrier costs 4-7 us on this chip).  A workgroup owns a slice of hidden units and
+//   * only the true recurrence h_{t-1} W_hh^T runs per time step.  Forward: one persistent launch
+//     per layer where it applies (rnn_persist.h: H = 512, every recurrence inside one XCD).
+//     Otherwise, and always backward: one launch per step, both directions in it: the kernel
+//     boundary is the grid-wide dependency (an in-kernel grid barrier ACROSS XCDs costs 2.3-2.5 us
+//     on this chip, scripts/handoff_lab).  A workgroup owns a slice of hidden units and
 //     streams its W_hh rows and h_{t-1} [B, H] from L2 through v_mfma_f32_16x16x4_f32
 //     (exact fp32, same K-permutation trick as the GEMM: one 16-byte load feeds 4 MFMAs).
 //   * packed-sequence semantics: row b is active for step s < len_b; the forward direction
