@@ -385,10 +385,10 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                                                stream, 7), dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
         gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
-        # HBM bytes of one solve from the committed PMC passes (profiles/r3f_mlpg_traffic.json:
+        # HBM bytes of one solve from the committed PMC passes (profiles/r3g_mlpg_traffic.json:
         # FETCH_SIZE x 2 + WRITE_SIZE on this same workload); not re-measured inside bench.py
         ml_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3f_mlpg_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3g_mlpg_traffic.json")
         if os.path.isfile(tpath):
             with open(tpath) as f:
                 ml_traffic = json.load(f)["paths"]["stream"]["hbm_bytes_per_solve"]
@@ -911,9 +911,9 @@ def main():
         flops = flops_per_frame(dims) * nloc
         achieved = flops / (ms * 1e-3) / 1e12
         # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # see profiles/r3f_gemm_traffic.json); not re-measured inside bench.py.
+        # see profiles/r3g_gemm_traffic.json); not re-measured inside bench.py.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3f_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3g_gemm_traffic.json")
         if os.path.isfile(tpath) and args.utts_per_gpu == 32:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")

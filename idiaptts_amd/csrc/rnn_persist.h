@@ -302,6 +302,8 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   if (hipMemsetAsync(blk, 0, xbytes + 64, s) != hipSuccess) return -1;
   p.xchg = reinterpret_cast<uint4*>(blk);
   p.abort_flag = reinterpret_cast<int*>(blk + xbytes);
+  if (getenv("ITTS_RNN_PERSIST_TEST_ABORT"))       // test hook: the launch finds the abort flag raised
+    if (hipMemsetAsync(p.abort_flag, 1, sizeof(int), s) != hipSuccess) return -1;
   hipLaunchKernelGGL(rnn_persist_fwd_kernel<G>, dim3(256), dim3(256), persist_lds_bytes(G), s, p);
   if (hipGetLastError() != hipSuccess) return -1;
   int64_t* slot = pinned_slot(ctx);

@@ -156,3 +156,45 @@ def test_config3_handler_step_matches_reference_stack(gpu, golden_dir):
         assert np.abs(new - g["psamp_" + k])[solid].max() < 2e-5, k
         assert np.abs(new - g["psamp_" + k]).max() < 2.1e-3, k
         assert not torch.equal(before[k], p.detach()), k
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_persistent_forward_equals_the_step_kernels_and_falls_back(gpu, cell):
+    """The persistent per-XCD forward recurrence (csrc/rnn_persist.h; taken by default at H = 512)
+    against the per-step kernels on a ragged bidirectional batch, and its safety net: a launch that
+    finds the abort flag raised (test hook) is redone by the step kernels, with a message, and the
+    result is the same.  Child processes: a launch that gave up switches the path off for the
+    rest of its process."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from idiaptts_amd import nn as inn
+dev = torch.device("cuda", 0)
+torch.manual_seed(7)
+lens = torch.tensor([301, 280, 280, 150, 97, 96, 31, 30, 17, 16, 15, 5, 4, 3, 2, 2, 1, 1], dtype=torch.int64)
+layer = getattr(inn, %r)(96, 512, 1, bidirectional=True).to(dev)
+x = torch.randn(int(lens.max()), len(lens), 96, device=dev)
+outs = []
+for mode in ("0", "1"):
+    os.environ["ITTS_RNN_PERSISTENT"] = mode
+    with torch.no_grad():
+        o, st = layer(x, None, lens)
+    outs.append([o] + (list(st) if isinstance(st, (tuple, list)) else [st]))
+torch.cuda.synchronize()
+d = max(float((a - b).abs().max()) for a, b in zip(*outs))
+assert d < 2e-6, d
+print("max difference %%.2e" %% d)
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cell)
+    env = dict(os.environ)
+    env.pop("ITTS_RNN_PERSIST_TEST_ABORT", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "gave up" not in res.stderr
+    env["ITTS_RNN_PERSIST_TEST_ABORT"] = "1"
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "gave up" in res.stderr
