@@ -23,7 +23,7 @@ namespace itts {
 constexpr int PH = 512;                          // hidden size this kernel is built for
 constexpr int P_PART_FLOATS = 4 * 4 * 16 * 17;   // partial gate sums [wave][gate][row][unit + pad]
 constexpr int persist_w_bytes(int G) { return G * 4 * 8 * 64 * 16; }   // W_hh image: [gate][k quarter][quad][lane] float4
-constexpr int persist_lds_bytes(int G) { return persist_w_bytes(G) + P_PART_FLOATS * 4 + 16 * 16 * 4; }
+constexpr int persist_lds_bytes(int G) { return persist_w_bytes(G) + P_PART_FLOATS * 4; }
 
 struct RnnPersistArgs {
   const float* gin;
@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
   extern __shared__ __attribute__((aligned(16))) char psm[];
   float4* Wl = reinterpret_cast<float4*>(psm);
   float* Pp = reinterpret_cast<float*>(psm + persist_w_bytes(G));
-  float* hsh = Pp + P_PART_FLOATS;
   const int group = blockIdx.x & 7, cu = blockIdx.x >> 3;
   const int tiles_per_dir = 8 / a.ndir;
   const int dir = group / tiles_per_dir, tile = group % tiles_per_dir;
@@ -120,21 +119,25 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
   if (G == 3 && a.bhh) { bh0 = a.bhh[dir * G4 + j]; bh1 = a.bhh[dir * G4 + H + j]; bh2 = a.bhh[dir * G4 + 2 * H + j]; }
   (void)bh0; (void)bh1; (void)bh2;
   uint4* xg = a.xchg + (size_t)group * 4 * 32 * 128;
-  auto publish = [&](int step) {        // hsh holds h; wave 0 writes the (P, C) pair of this workgroup
-    if (wv == 0) {
-      const int rr = lane & 15, kq = lane >> 4;
-      float4 p4 = make_float4(hsh[rr * 16 + kq], hsh[rr * 16 + 4 + kq], hsh[rr * 16 + 8 + kq], hsh[rr * 16 + 12 + kq]);
+  // Every wave publishes the h of its own four rows: thread (r, u) = lane (r & 3) * 16 + u of wave
+  // r >> 2 holds h[r][u]; granule (row r', k quarter kq) of this workgroup's block wants units
+  // kq, 4 + kq, 8 + kq, 12 + kq of row r' -- four lanes of the same wave, fetched by shuffles; lanes
+  // 0 .. 15 store the wave's sixteen granules (P and the check copy).  No LDS, no barrier: a wave
+  // of this workgroup cannot get past its next poll before all four have published.
+  auto publish = [&](int step, float hval) {
+    const int rl = (lane >> 2) & 3, kq = lane & 3;          // meaningful for lanes 0 .. 15
+    const float p0 = __shfl(hval, rl * 16 + kq, 64), p1 = __shfl(hval, rl * 16 + 4 + kq, 64),
+                p2 = __shfl(hval, rl * 16 + 8 + kq, 64), p3 = __shfl(hval, rl * 16 + 12 + kq, 64);
+    if (lane < 16) {
       const unsigned m = persist_mask(step);
-      uint4 P = make_uint4(__float_as_uint(p4.x), __float_as_uint(p4.y), __float_as_uint(p4.z), __float_as_uint(p4.w));
-      uint4 C = make_uint4(P.x ^ m, P.y ^ m, P.z ^ m, P.w ^ m);
-      uint4* dst = xg + ((size_t)(step & 3) * 32 + cu) * 128 + lane;
+      const uint4 P = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
+      const uint4 C = make_uint4(P.x ^ m, P.y ^ m, P.z ^ m, P.w ^ m);
+      uint4* dst = xg + ((size_t)(step & 3) * 32 + cu) * 128 + kq * 16 + 4 * wv + rl;
       dst[0] = P;
       dst[64] = C;
     }
   };
-  hsh[r * 16 + u] = h;
-  __syncthreads();
-  publish(0);
+  publish(0, h);
 
   const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
   auto row_at = [&](int st) -> size_t {
@@ -255,12 +258,10 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
         if (G == 4 && a.cn) a.cn[((size_t)dir * a.B + b) * H + j] = c;
       }
     }
-    hsh[r * 16 + u] = h;
     row_cur = row_n1; row_n1 = row_n2;
     gc0 = gn0; gc1 = gn1; gc2 = gn2; gc3 = gn3;
     PT(3);
-    __syncthreads();
-    if (s + 1 < t_tile) publish(s + 1);
+    if (s + 1 < t_tile) publish(s + 1, h);
     PT(4);
   }
   if (PERSIST_TRACE && lane == 0 && (blockIdx.x < 8 || blockIdx.x == 100) )
