@@ -42,6 +42,7 @@ struct RnnPersistArgs {
   uint4* xchg;      // [8 groups][4 step slots][32 producers][P | C][64 lanes]
   int* abort_flag;
   int T, B, ndir, ntiles;
+  int tile0;        // first batch tile of this launch (batches of more than 8 / ndir tiles take several)
 };
 
 // asm operands must be native 128-bit vectors (a struct type such as uint4 gives the register
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
   float* Pp = reinterpret_cast<float*>(psm + persist_w_bytes(G));
   const int group = blockIdx.x & 7, cu = blockIdx.x >> 3;
   const int tiles_per_dir = 8 / a.ndir;
-  const int dir = group / tiles_per_dir, tile = group % tiles_per_dir;
+  const int dir = group / tiles_per_dir, tile = a.tile0 + group % tiles_per_dir;
   if (tile >= a.ntiles) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int H = PH, G4 = G * PH;      // (G4: gate rows per direction)
@@ -283,7 +284,7 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   const char* pe = getenv("ITTS_RNN_PERSISTENT");       // read per call: tests switch it
   if ((pe && pe[0] == '0') || !usable.load()) return 0;
   p.ntiles = (p.B + 15) / 16;
-  if (H != PH || p.ntiles > 8 / p.ndir) return 0;
+  if (H != PH) return 0;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -305,8 +306,16 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   p.abort_flag = reinterpret_cast<int*>(blk + xbytes);
   if (getenv("ITTS_RNN_PERSIST_TEST_ABORT"))       // test hook: the launch finds the abort flag raised
     if (hipMemsetAsync(p.abort_flag, 1, sizeof(int), s) != hipSuccess) return -1;
-  hipLaunchKernelGGL(rnn_persist_fwd_kernel<G>, dim3(256), dim3(256), persist_lds_bytes(G), s, p);
-  if (hipGetLastError() != hipSuccess) return -1;
+  // 8 / ndir batch tiles per launch (one XCD each); a larger batch takes its tiles in rounds, longest
+  // rows first (the exchange slots of a round are all overwritten before anybody of the next round
+  // can mistake them: its first wait is for step 0's mask, which no later step of the round before
+  // left behind -- masks are unique per step -- unless that round was one step long; the buffer is
+  // therefore cleared between rounds)
+  for (p.tile0 = 0; p.tile0 < p.ntiles; p.tile0 += 8 / p.ndir) {
+    if (p.tile0 > 0 && hipMemsetAsync(blk, 0, xbytes, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(rnn_persist_fwd_kernel<G>, dim3(256), dim3(256), persist_lds_bytes(G), s, p);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
   int64_t* slot = pinned_slot(ctx);
   *slot = 0;
   if (hipMemcpyAsync(slot, p.abort_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;

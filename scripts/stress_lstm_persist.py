@@ -15,7 +15,7 @@ rng = np.random.default_rng(3)
 worst = 0.0
 for it in range(n):
     bidir = bool(rng.integers(0, 2))
-    B = int(rng.integers(1, 65 if bidir else 129))
+    B = int(rng.integers(1, 200))
     T = int(rng.choice([1, 2, 17, 100, 400, 1200]))
     lens = rng.integers(1, T + 1, size=B)
     lens[rng.integers(0, B)] = T
