@@ -1,4 +1,7 @@
-// Persistent forward recurrence of the LSTM / GRU layers (included by lstm.hip and gru.hip).
+// Persistent forward recurrence of the LSTM / GRU layers (included by lstm.hip and gru.hip): what
+// torch.nn.LSTM / GRU do between pack_padded_sequence and pad_packed_sequence in
+// rnn_dyn/RNNWrapper.py:89-102, forward direction of time only (the backward pass stays on the step
+// kernels of lstm.hip / gru.hip).
 #pragma once
 #include <atomic>
 #include <cstdio>
@@ -9,9 +12,9 @@
 namespace itts {
 
 // ---- persistent forward recurrence, one (direction, 16-row batch tile) per XCD --------------------
-// Taken when H = 512, the batch has at most 8 / ndir tiles of 16 rows and the device has 256 CUs
-// (ITTS_RNN_PERSISTENT=0 keeps the step kernels); G = 4: LSTM, G = 3: GRU.  The
-// step kernels above pay 3.4 us of launch boundary per step for the grid-wide exchange of h; here
+// Taken when H = 512 and the device has 256 CUs (ITTS_RNN_PERSISTENT=0 keeps the step kernels);
+// 8 / ndir batch tiles of 16 rows per launch, larger batches in rounds; G = 4: LSTM, G = 3: GRU.  The
+// step kernels pay 3.4 us of launch boundary per step for the grid-wide exchange of h; here
 // the 32 workgroups an XCD holds (blockIdx % 8 = XCD under round-robin dispatch) keep one
 // recurrence to themselves for all T steps: workgroup c owns hidden units 16 c .. 16 c + 15 (all G
 // gates: a G x 32 KB image of its W_hh rows stays in LDS in the order the MFMA lanes read it), the
