@@ -402,6 +402,14 @@ extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const 
   int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
+  {
+    LstmPersistBwdArgs p{};
+    p.dy = d_dy; p.whh = d_whh; p.c0 = d_c0; p.gates = d_gates; p.csave = d_csave; p.row_off = d_row_off;
+    p.rev_row = d_rev_row; p.dg = d_dg; p.dc0 = d_dc0; p.T = T; p.B = B; p.ndir = ndir;
+    const int done = lstm_persist_backward(p, h_lengths, H, s);     // rnn_persist.h (opt-in)
+    if (done < 0) return ITTS_E_HIP;
+    if (done) return ITTS_OK;
+  }
   LstmArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row;
   a.c0 = d_c0; a.gates = const_cast<float*>(d_gates); a.csave = const_cast<float*>(d_csave); a.dy = d_dy;

@@ -331,4 +331,235 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   return 0;
 }
 
+
+// ---- persistent backward recurrence of the LSTM, same placement ---------------------------------
+// Step s (T_tile - 1 ... 0) of row b:  dh = dy + dG(s + 1) W_hh,  then the cell gradients
+// (lstm.hip, lstm_step_bwd_kernel).  dG is four gates wide, so handing it around as the forward
+// kernel hands h around would quadruple the exchange; instead the product is split along K:
+// workgroup c multiplies ITS OWN 64 gate values per row (kept in LDS, never exchanged) with its
+// 64 rows of W_hh (a 128 KB LDS image: [column tile 32][gate 4][lane] float4) into a PARTIAL
+// dh for all 512 units, publishes the 16 x 16 tile of every unit block to the workgroup that
+// owns it (reduce-scatter: 32 KB + check copies out, 32 KB + check copies in, per CU and step),
+// and sums the 32 partial tiles it receives.  Granule pairs, polling, budget and fallback as above.
+struct LstmPersistBwdArgs {
+  const float* dy;
+  const float* whh;
+  const float* c0;
+  const float* gates;
+  const float* csave;
+  const int* lengths;
+  const int* row_off;
+  const int* rev_row;
+  float* dg;
+  float* dc0;       // [ndir][B][H] or NULL
+  uint4* xchg;      // [8 groups][2 slots][32 consumers][32 producers][P | C][64 lanes]
+  int* abort_flag;
+  int T, B, ndir, ntiles, tile0;
+};
+
+constexpr int P_BWD_LDS_BYTES = 32 * 4 * 64 * 16 + 4 * 16 * 17 * 4 + 4 * 16 * 16 * 4;
+
+static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersistBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  float4* Wb = reinterpret_cast<float4*>(psm);                               // [ct 32][gate 4][lane 64]
+  float* Pp = reinterpret_cast<float*>(psm + 32 * 4 * 64 * 16);              // [wave 4][row 16][17]
+  float* dgs = Pp + 4 * 16 * 17;                                             // [gate 4][row 16][unit 16]
+  const int group = blockIdx.x & 7, cu = blockIdx.x >> 3;
+  const int tiles_per_dir = 8 / a.ndir;
+  const int dir = group / tiles_per_dir, tile = a.tile0 + group % tiles_per_dir;
+  if (tile >= a.ntiles) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int H = PH, G4 = 4 * PH;
+  const int j0 = cu * 16;
+  {
+    // image of this workgroup's 64 rows of W_hh: lane (col, kq) of column tile ct, gate g holds
+    // W[g H + j0 + 4 i + kq][16 ct + col], i = 0 .. 3
+    const float* W = a.whh + (size_t)dir * G4 * H;
+    for (int idx = threadIdx.x; idx < 32 * 4 * 64; idx += 256) {
+      const int ln = idx & 63, gg = (idx >> 6) & 3, ct = idx >> 8;
+      const float* src = W + (size_t)(gg * H + j0 + (ln >> 4)) * H + 16 * ct + (ln & 15);
+      Wb[idx] = make_float4(src[0], src[4 * (size_t)H], src[8 * (size_t)H], src[12 * (size_t)H]);
+    }
+  }
+  const int r = threadIdx.x >> 4, u = threadIdx.x & 15;
+  const int b = tile * 16 + r, j = j0 + u;
+  const bool valid = b < a.B;
+  const int len = valid ? a.lengths[b] : 0;
+  const int t_tile = a.lengths[tile * 16];
+  const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
+  uint4* xg = a.xchg + (size_t)group * 2 * 32 * 32 * 128;
+  auto row_at = [&](int st) -> size_t {
+    return dir == 0 ? (size_t)(a.row_off[st] + b) : (size_t)a.rev_row[(size_t)st * a.B + b];
+  };
+  const float c_init = (valid && a.c0) ? a.c0[dir * H + j] : 0.f;
+  // pipeline registers: values of the step being processed, requested a step earlier
+  const int s0 = t_tile - 1;
+  size_t row_cur = 0, row_m1 = 0, row_m2 = 0;
+  float4 gcur = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dycur = 0.f, ctcur = 0.f, cpcur = 0.f;
+  if (s0 < len) {
+    row_cur = row_at(s0);
+    gcur = reinterpret_cast<const float4*>(a.gates)[(row_cur * a.ndir + dir) * H + j];
+    dycur = a.dy[row_cur * ldh + (size_t)dir * H + j];
+    ctcur = a.csave[row_cur * ldh + (size_t)dir * H + j];
+  }
+  if (s0 - 1 >= 0 && s0 - 1 < len) row_m1 = row_at(s0 - 1);
+  if (s0 - 2 >= 0 && s0 - 2 < len) row_m2 = row_at(s0 - 2);
+  if (s0 < len) cpcur = s0 > 0 ? a.csave[row_m1 * ldh + (size_t)dir * H + j] : c_init;
+  float carry = 0.f;       // dc * f of the step processed before (s + 1)
+  __syncthreads();         // the W image is complete
+
+  for (int s = s0; s >= 0; --s) {
+    const bool act = s < len;
+    // dh_rec: the 32 partial tiles published at step s + 1
+    float dhr = 0.f;
+    if (s < s0) {
+      pu32x4 pv[8], cv[8];
+      const uint4* src = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv) * 128 + lane;
+      const unsigned m = persist_mask(s + 1);
+      int budget = 1 << 16;
+      for (;;) {
+        persist_load16(src, 128, pv, cv);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          ok = ok && (pv[i].x ^ cv[i].x) == m && (pv[i].y ^ cv[i].y) == m && (pv[i].z ^ cv[i].z) == m &&
+               (pv[i].w ^ cv[i].w) == m;
+        if (__all(ok)) break;
+        const uint4* watch = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv + (lane & 7)) * 128;
+        bool gave_up = false;
+        for (;;) {
+          pu32x4 wp, wc;
+          persist_load_pair(watch, wp, wc);
+          if (__all((wp.x ^ wc.x) == m)) break;
+          if (--budget <= 0 || *reinterpret_cast<volatile int*>(a.abort_flag)) { gave_up = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (gave_up || --budget <= 0) {
+          if (lane == 0) atomicExch(a.abort_flag, 1);
+          break;
+        }
+      }
+      // this wave's eight tiles summed (rows 4 kq + e, column lane & 15), then across the waves
+      float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sx += __uint_as_float(pv[i].x); sy += __uint_as_float(pv[i].y);
+        sz += __uint_as_float(pv[i].z); sw += __uint_as_float(pv[i].w);
+      }
+      const int rq = 4 * (lane >> 4), cc = lane & 15;
+      Pp[(wv * 16 + rq + 0) * 17 + cc] = sx; Pp[(wv * 16 + rq + 1) * 17 + cc] = sy;
+      Pp[(wv * 16 + rq + 2) * 17 + cc] = sz; Pp[(wv * 16 + rq + 3) * 17 + cc] = sw;
+    }
+    // values of step s - 1 (their row indices arrived a step ago) and the row index of step s - 3
+    float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dynext = 0.f, cpnext = 0.f, ctnext = cpcur;     // c_t of step s - 1 is c_{t-1} of step s ...
+    size_t row_m3 = 0;
+    if (s - 1 >= 0 && s - 1 < len) {
+      gnext = reinterpret_cast<const float4*>(a.gates)[(row_m1 * a.ndir + dir) * H + j];
+      dynext = a.dy[row_m1 * ldh + (size_t)dir * H + j];
+      cpnext = s - 1 > 0 ? a.csave[row_m2 * ldh + (size_t)dir * H + j] : c_init;
+      if (!act) ctnext = a.csave[row_m1 * ldh + (size_t)dir * H + j];   // ... unless the row only starts there
+    }
+    if (s - 3 >= 0 && s - 3 < len) row_m3 = row_at(s - 3);
+    __syncthreads();
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    if (act) {
+      if (s < s0 && s + 1 < len)
+        dhr = (Pp[(0 * 16 + r) * 17 + u] + Pp[(1 * 16 + r) * 17 + u]) + (Pp[(2 * 16 + r) * 17 + u] + Pp[(3 * 16 + r) * 17 + u]);
+      const float ig = gcur.x, fg = gcur.y, gg = gcur.z, og = gcur.w;
+      const float tc = tanhf(ctcur);
+      const float dh = dycur + dhr;
+      const float dcv = dh * og * (1.f - tc * tc) + carry;
+      d0 = dcv * gg * ig * (1.f - ig); d1 = dcv * cpcur * fg * (1.f - fg);
+      d2 = dcv * ig * (1.f - gg * gg); d3 = dh * tc * og * (1.f - og);
+      float* dgo = a.dg + row_cur * ldg + (size_t)dir * G4 + j;
+      dgo[0] = d0; dgo[H] = d1; dgo[2 * H] = d2; dgo[3 * H] = d3;
+      carry = dcv * fg;
+      if (s == 0 && a.dc0) a.dc0[((size_t)dir * a.B + b) * H + j] = carry;
+    }
+    dgs[(0 * 16 + r) * 16 + u] = d0; dgs[(1 * 16 + r) * 16 + u] = d1;
+    dgs[(2 * 16 + r) * 16 + u] = d2; dgs[(3 * 16 + r) * 16 + u] = d3;
+    __syncthreads();
+    if (s > 0) {
+      // partial dh of step s - 1: [16 rows x 64 own gate values] x [64 x 512], this wave's 8 column tiles
+      const int rr = lane & 15, kq = lane >> 4;
+      float4 af[4];
+#pragma unroll
+      for (int gg2 = 0; gg2 < 4; ++gg2)
+        af[gg2] = make_float4(dgs[(gg2 * 16 + rr) * 16 + kq], dgs[(gg2 * 16 + rr) * 16 + 4 + kq],
+                              dgs[(gg2 * 16 + rr) * 16 + 8 + kq], dgs[(gg2 * 16 + rr) * 16 + 12 + kq]);
+      const unsigned m = persist_mask(s);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ct = 8 * wv + i;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gg2 = 0; gg2 < 4; ++gg2) {
+          const float4 bw = Wb[(ct * 4 + gg2) * 64 + lane];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].x, bw.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].y, bw.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].z, bw.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].w, bw.w, acc, 0, 0, 0);
+        }
+        const uint4 P = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                                   __float_as_uint(acc[3]));
+        const uint4 C = make_uint4(P.x ^ m, P.y ^ m, P.z ^ m, P.w ^ m);
+        uint4* dst = xg + (((size_t)(s & 1) * 32 + ct) * 32 + cu) * 128 + lane;
+        dst[0] = P;
+        dst[64] = C;
+      }
+    }
+    // rotate the pipeline
+    row_cur = row_m1; row_m1 = row_m2; row_m2 = row_m3;
+    gcur = gnext; dycur = dynext; ctcur = ctnext; cpcur = cpnext;
+  }
+}
+
+// Backward counterpart of rnn_persist_forward (LSTM only): 1 = done, 0 = run the step kernels.
+static int lstm_persist_backward(LstmPersistBwdArgs p, const int* h_lengths, int H, hipStream_t s) {
+  static std::atomic<bool> usable{true};
+  const char* pe = getenv("ITTS_RNN_PERSISTENT_BWD");
+  if (!(pe && pe[0] == '1') || !usable.load()) return 0;       // opt-in until it has earned the default
+  p.ntiles = (p.B + 15) / 16;
+  if (H != PH) return 0;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, P_BWD_LDS_BYTES) != hipSuccess)
+      return -1;
+    n_cu = prop.multiProcessorCount;
+  }
+  DeviceContext* ctx = n_cu == 256 ? get_context() : nullptr;
+  if (!ctx) return 0;
+  const size_t xbytes = (size_t)8 * 2 * 32 * 32 * 128 * sizeof(uint4);
+  const size_t lbytes = ((size_t)p.B * sizeof(int) + 63) / 64 * 64;
+  char* blk = nullptr;
+  itts::ScratchScope scope(s);
+  if (itts::scratch_malloc((void**)&blk, xbytes + 64 + lbytes, s) != hipSuccess) return -1;
+  if (hipMemsetAsync(blk, 0, xbytes + 64, s) != hipSuccess) return -1;
+  if (staged_upload(blk + xbytes + 64, h_lengths, (size_t)p.B * sizeof(int), s) != ITTS_OK) return -1;
+  p.xchg = reinterpret_cast<uint4*>(blk);
+  p.abort_flag = reinterpret_cast<int*>(blk + xbytes);
+  p.lengths = reinterpret_cast<const int*>(blk + xbytes + 64);
+  for (p.tile0 = 0; p.tile0 < p.ntiles; p.tile0 += 8 / p.ndir) {
+    if (p.tile0 > 0 && hipMemsetAsync(blk, 0, xbytes, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(256), dim3(256), P_BWD_LDS_BYTES, s, p);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
+  int64_t* slot = pinned_slot(ctx);
+  *slot = 0;
+  if (hipMemcpyAsync(slot, p.abort_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  if (itts::scratch_free(blk, s) != hipSuccess) return -1;
+  if ((int)*slot == 0) return 1;
+  usable.store(false);
+  fprintf(stderr, "libidiaptts_amd: the persistent backward recurrence gave up waiting; using the per-step "
+                  "kernels from now on\n");
+  return 0;
+}
+
 }  // namespace itts
