@@ -519,8 +519,9 @@ static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersis
 // Backward counterpart of rnn_persist_forward (LSTM only): 1 = done, 0 = run the step kernels.
 static int lstm_persist_backward(LstmPersistBwdArgs p, const int* h_lengths, int H, hipStream_t s) {
   static std::atomic<bool> usable{true};
-  const char* pe = getenv("ITTS_RNN_PERSISTENT_BWD");
-  if (!(pe && pe[0] == '1') || !usable.load()) return 0;       // opt-in until it has earned the default
+  const char* pe = getenv("ITTS_RNN_PERSISTENT");          // read per call: tests switch it
+  const char* pb = getenv("ITTS_RNN_PERSISTENT_BWD");      // ... and this one keeps the forward half on
+  if ((pe && pe[0] == '0') || (pb && pb[0] == '0') || !usable.load()) return 0;
   p.ntiles = (p.B + 15) / 16;
   if (H != PH) return 0;
   static int n_cu = 0;
@@ -545,6 +546,8 @@ static int lstm_persist_backward(LstmPersistBwdArgs p, const int* h_lengths, int
   p.xchg = reinterpret_cast<uint4*>(blk);
   p.abort_flag = reinterpret_cast<int*>(blk + xbytes);
   p.lengths = reinterpret_cast<const int*>(blk + xbytes + 64);
+  if (getenv("ITTS_RNN_PERSIST_TEST_ABORT"))       // test hook: the launch finds the abort flag raised
+    if (hipMemsetAsync(p.abort_flag, 1, sizeof(int), s) != hipSuccess) return -1;
   for (p.tile0 = 0; p.tile0 < p.ntiles; p.tile0 += 8 / p.ndir) {
     if (p.tile0 > 0 && hipMemsetAsync(blk, 0, xbytes, s) != hipSuccess) return -1;
     hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(256), dim3(256), P_BWD_LDS_BYTES, s, p);

@@ -159,9 +159,10 @@ def test_config3_handler_step_matches_reference_stack(gpu, golden_dir):
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
-def test_persistent_forward_equals_the_step_kernels_and_falls_back(gpu, cell):
-    """The persistent per-XCD forward recurrence (csrc/rnn_persist.h; taken by default at H = 512)
-    against the per-step kernels on a ragged bidirectional batch, and its safety net: a launch that
+def test_persistent_recurrence_equals_the_step_kernels_and_falls_back(gpu, cell):
+    """The persistent per-XCD recurrences (csrc/rnn_persist.h; taken by default at H = 512: forward
+    for both cells, backward for the LSTM) against the per-step kernels on a ragged bidirectional
+    batch -- outputs, final states and every gradient --, and their safety net: a launch that
     finds the abort flag raised (test hook) is redone by the step kernels, with a message, and the
     result is the same.  Child processes: a launch that gave up switches the path off for the
     rest of its process."""
@@ -175,16 +176,19 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(7)
 lens = torch.tensor([301, 280, 280, 150, 97, 96, 31, 30, 17, 16, 15, 5, 4, 3, 2, 2, 1, 1], dtype=torch.int64)
 layer = getattr(inn, %r)(96, 512, 1, bidirectional=True).to(dev)
-x = torch.randn(int(lens.max()), len(lens), 96, device=dev)
+x = torch.randn(int(lens.max()), len(lens), 96, device=dev, requires_grad=True)
+w_out = torch.randn(int(lens.max()), len(lens), 1024, device=dev) / 8
 outs = []
 for mode in ("0", "1"):
     os.environ["ITTS_RNN_PERSISTENT"] = mode
-    with torch.no_grad():
-        o, st = layer(x, None, lens)
-    outs.append([o] + (list(st) if isinstance(st, (tuple, list)) else [st]))
+    o, st = layer(x, None, lens)
+    st = list(st) if isinstance(st, (tuple, list)) else [st]
+    loss = (o * w_out).sum()
+    grads = torch.autograd.grad(loss, [x] + list(layer.parameters()))
+    outs.append([o.detach()] + [q.detach() for q in st] + list(grads))
 torch.cuda.synchronize()
-d = max(float((a - b).abs().max()) for a, b in zip(*outs))
-assert d < 2e-6, d
+d = max(float((a - b).abs().max() / max(1.0, float(b.abs().max()))) for a, b in zip(*outs))
+assert d < 1e-5, d
 print("max difference %%.2e" %% d)
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cell)
     env = dict(os.environ)
