@@ -335,6 +335,14 @@ extern "C" int itts_gru_layer_bwd(const float* d_dy, const float* d_whh, const f
   int rc = rnn_check(h_lengths, T, B, H, ndir);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
+  {
+    RnnPersistBwdArgs p{};
+    p.dy = d_dy; p.whh = d_whh; p.gates = d_gates; p.aux = d_hprev; p.row_off = d_row_off;
+    p.rev_row = d_rev_row; p.dg = d_dgi; p.dg2 = d_dgh; p.d0 = d_dh0; p.T = T; p.B = B; p.ndir = ndir;
+    const int done = rnn_persist_backward<3>(p, h_lengths, H, s);     // rnn_persist.h
+    if (done < 0) return ITTS_E_HIP;
+    if (done) return ITTS_OK;
+  }
   GruArgs a{};
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.row_off = d_row_off; a.rev_row = d_rev_row;
   a.gates = const_cast<float*>(d_gates); a.hprev = d_hprev; a.dy = d_dy; a.dgi = d_dgi; a.dgh = d_dgh;

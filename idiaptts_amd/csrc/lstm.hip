@@ -403,10 +403,10 @@ extern "C" int itts_lstm_layer_bwd(const float* d_dy, const float* d_whh, const 
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   {
-    LstmPersistBwdArgs p{};
-    p.dy = d_dy; p.whh = d_whh; p.c0 = d_c0; p.gates = d_gates; p.csave = d_csave; p.row_off = d_row_off;
-    p.rev_row = d_rev_row; p.dg = d_dg; p.dc0 = d_dc0; p.T = T; p.B = B; p.ndir = ndir;
-    const int done = lstm_persist_backward(p, h_lengths, H, s);     // rnn_persist.h (opt-in)
+    RnnPersistBwdArgs p{};
+    p.dy = d_dy; p.whh = d_whh; p.c0 = d_c0; p.gates = d_gates; p.aux = d_csave; p.row_off = d_row_off;
+    p.rev_row = d_rev_row; p.dg = d_dg; p.d0 = d_dc0; p.T = T; p.B = B; p.ndir = ndir;
+    const int done = rnn_persist_backward<4>(p, h_lengths, H, s);     // rnn_persist.h
     if (done < 0) return ITTS_E_HIP;
     if (done) return ITTS_OK;
   }

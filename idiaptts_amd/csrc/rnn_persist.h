@@ -332,51 +332,54 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
 }
 
 
-// ---- persistent backward recurrence of the LSTM, same placement ---------------------------------
-// Step s (T_tile - 1 ... 0) of row b:  dh = dy + dG(s + 1) W_hh,  then the cell gradients
-// (lstm.hip, lstm_step_bwd_kernel).  dG is four gates wide, so handing it around as the forward
-// kernel hands h around would quadruple the exchange; instead the product is split along K:
-// workgroup c multiplies ITS OWN 64 gate values per row (kept in LDS, never exchanged) with its
-// 64 rows of W_hh (a 128 KB LDS image: [column tile 32][gate 4][lane] float4) into a PARTIAL
-// dh for all 512 units, publishes the 16 x 16 tile of every unit block to the workgroup that
-// owns it (reduce-scatter: 32 KB + check copies out, 32 KB + check copies in, per CU and step),
-// and sums the 32 partial tiles it receives.  Granule pairs, polling, budget and fallback as above.
-struct LstmPersistBwdArgs {
+// ---- persistent backward recurrence, same placement (G = 4: LSTM, G = 3: GRU) ---------------------
+// Step s (T_tile - 1 ... 0) of row b:  dh = dy + dG(s + 1) W_hh (+ the GRU's dh z carry),  then the
+// cell gradients (lstm.hip, lstm_step_bwd_kernel; gru.hip, gru_step_bwd_kernel).  dG is G gates
+// wide, so handing it around as the forward kernel hands h around would multiply the exchange by G;
+// instead the product is split along K: workgroup c multiplies ITS OWN 16 G gate values per row (kept
+// in LDS, never exchanged) with its 16 G rows of W_hh (a G x 32 KB LDS image: [column tile 32][gate]
+// [lane] float4) into a PARTIAL dh for all 512 units, publishes the 16 x 16 tile of every unit block
+// to the workgroup that owns it (reduce-scatter: 32 KB + check copies out, 32 KB + check copies in,
+// per CU and step), and sums the 32 partial tiles it receives.  Granule pairs, polling, budget and
+// fallback as above.
+struct RnnPersistBwdArgs {
   const float* dy;
   const float* whh;
-  const float* c0;
-  const float* gates;
-  const float* csave;
+  const float* c0;      // LSTM: initial cell state [ndir][H] or NULL
+  const float* gates;   // LSTM (i, f, g, o), GRU (r, z, n, hn_pre) per row, direction, unit
+  const float* aux;     // LSTM: the saved cell states; GRU: h_prev per packed row
   const int* lengths;
   const int* row_off;
   const int* rev_row;
-  float* dg;
-  float* dc0;       // [ndir][B][H] or NULL
-  uint4* xchg;      // [8 groups][2 slots][32 consumers][32 producers][P | C][64 lanes]
+  float* dg;            // LSTM: dG; GRU: dGi
+  float* dg2;           // GRU: dGh (da_n * r in the third gate)
+  float* d0;            // [ndir][B][H] or NULL: LSTM dc * f, GRU dh * z after step 0
+  uint4* xchg;          // [8 groups][2 slots][32 consumers][32 producers][P | C][64 lanes]
   int* abort_flag;
   int T, B, ndir, ntiles, tile0;
 };
 
-constexpr int P_BWD_LDS_BYTES = 32 * 4 * 64 * 16 + 4 * 16 * 17 * 4 + 4 * 16 * 16 * 4;
+constexpr int persist_bwd_lds_bytes(int G) { return 32 * G * 64 * 16 + 4 * 16 * 17 * 4 + G * 16 * 16 * 4; }
 
-static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersistBwdArgs a) {
+template <int G>
+__global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
-  float4* Wb = reinterpret_cast<float4*>(psm);                               // [ct 32][gate 4][lane 64]
-  float* Pp = reinterpret_cast<float*>(psm + 32 * 4 * 64 * 16);              // [wave 4][row 16][17]
-  float* dgs = Pp + 4 * 16 * 17;                                             // [gate 4][row 16][unit 16]
+  float4* Wb = reinterpret_cast<float4*>(psm);                               // [ct 32][gate G][lane 64]
+  float* Pp = reinterpret_cast<float*>(psm + 32 * G * 64 * 16);              // [wave 4][row 16][17]
+  float* dgs = Pp + 4 * 16 * 17;                                             // [gate G][row 16][unit 16]
   const int group = blockIdx.x & 7, cu = blockIdx.x >> 3;
   const int tiles_per_dir = 8 / a.ndir;
   const int dir = group / tiles_per_dir, tile = a.tile0 + group % tiles_per_dir;
   if (tile >= a.ntiles) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int H = PH, G4 = 4 * PH;
+  const int H = PH, GH = G * PH;
   const int j0 = cu * 16;
   {
-    // image of this workgroup's 64 rows of W_hh: lane (col, kq) of column tile ct, gate g holds
+    // image of this workgroup's 16 G rows of W_hh: lane (col, kq) of column tile ct, gate g holds
     // W[g H + j0 + 4 i + kq][16 ct + col], i = 0 .. 3
-    const float* W = a.whh + (size_t)dir * G4 * H;
-    for (int idx = threadIdx.x; idx < 32 * 4 * 64; idx += 256) {
-      const int ln = idx & 63, gg = (idx >> 6) & 3, ct = idx >> 8;
+    const float* W = a.whh + (size_t)dir * GH * H;
+    for (int idx = threadIdx.x; idx < 32 * G * 64; idx += 256) {
+      const int ln = idx & 63, gg = (idx >> 6) % G, ct = (idx >> 6) / G;
       const float* src = W + (size_t)(gg * H + j0 + (ln >> 4)) * H + 16 * ct + (ln & 15);
       Wb[idx] = make_float4(src[0], src[4 * (size_t)H], src[8 * (size_t)H], src[12 * (size_t)H]);
     }
@@ -386,27 +389,28 @@ static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersis
   const bool valid = b < a.B;
   const int len = valid ? a.lengths[b] : 0;
   const int t_tile = a.lengths[tile * 16];
-  const size_t ldg = (size_t)a.ndir * G4, ldh = (size_t)a.ndir * H;
+  const size_t ldg = (size_t)a.ndir * GH, ldh = (size_t)a.ndir * H;
   uint4* xg = a.xchg + (size_t)group * 2 * 32 * 32 * 128;
   auto row_at = [&](int st) -> size_t {
     return dir == 0 ? (size_t)(a.row_off[st] + b) : (size_t)a.rev_row[(size_t)st * a.B + b];
   };
-  const float c_init = (valid && a.c0) ? a.c0[dir * H + j] : 0.f;
-  // pipeline registers: values of the step being processed, requested a step earlier
+  const float c_init = (G == 4 && valid && a.c0) ? a.c0[dir * H + j] : 0.f;
+  // pipeline registers: values of the step being processed, requested a step earlier.
+  // LSTM: v1 = c_t, v2 = c_{t-1} (the saved cell state of the step before); GRU: v1 = h_prev
   const int s0 = t_tile - 1;
   size_t row_cur = 0, row_m1 = 0, row_m2 = 0;
   float4 gcur = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dycur = 0.f, ctcur = 0.f, cpcur = 0.f;
+  float dycur = 0.f, v1cur = 0.f, v2cur = 0.f;
   if (s0 < len) {
     row_cur = row_at(s0);
     gcur = reinterpret_cast<const float4*>(a.gates)[(row_cur * a.ndir + dir) * H + j];
     dycur = a.dy[row_cur * ldh + (size_t)dir * H + j];
-    ctcur = a.csave[row_cur * ldh + (size_t)dir * H + j];
+    v1cur = a.aux[row_cur * ldh + (size_t)dir * H + j];
   }
   if (s0 - 1 >= 0 && s0 - 1 < len) row_m1 = row_at(s0 - 1);
   if (s0 - 2 >= 0 && s0 - 2 < len) row_m2 = row_at(s0 - 2);
-  if (s0 < len) cpcur = s0 > 0 ? a.csave[row_m1 * ldh + (size_t)dir * H + j] : c_init;
-  float carry = 0.f;       // dc * f of the step processed before (s + 1)
+  if (G == 4 && s0 < len) v2cur = s0 > 0 ? a.aux[row_m1 * ldh + (size_t)dir * H + j] : c_init;
+  float carry = 0.f;       // LSTM: dc * f, GRU: dh * z of the step processed before (s + 1)
   __syncthreads();         // the W image is complete
 
   for (int s = s0; s >= 0; --s) {
@@ -453,40 +457,62 @@ static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersis
     }
     // values of step s - 1 (their row indices arrived a step ago) and the row index of step s - 3
     float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dynext = 0.f, cpnext = 0.f, ctnext = cpcur;     // c_t of step s - 1 is c_{t-1} of step s ...
+    float dynext = 0.f, v1next = v2cur, v2next = 0.f;     // LSTM: c_t of step s - 1 is c_{t-1} of step s ...
     size_t row_m3 = 0;
     if (s - 1 >= 0 && s - 1 < len) {
       gnext = reinterpret_cast<const float4*>(a.gates)[(row_m1 * a.ndir + dir) * H + j];
       dynext = a.dy[row_m1 * ldh + (size_t)dir * H + j];
-      cpnext = s - 1 > 0 ? a.csave[row_m2 * ldh + (size_t)dir * H + j] : c_init;
-      if (!act) ctnext = a.csave[row_m1 * ldh + (size_t)dir * H + j];   // ... unless the row only starts there
+      if (G == 4) {
+        v2next = s - 1 > 0 ? a.aux[row_m2 * ldh + (size_t)dir * H + j] : c_init;
+        if (!act) v1next = a.aux[row_m1 * ldh + (size_t)dir * H + j];   // ... unless the row only starts there
+      } else {
+        v1next = a.aux[row_m1 * ldh + (size_t)dir * H + j];
+      }
     }
     if (s - 3 >= 0 && s - 3 < len) row_m3 = row_at(s - 3);
     __syncthreads();
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
     if (act) {
       if (s < s0 && s + 1 < len)
         dhr = (Pp[(0 * 16 + r) * 17 + u] + Pp[(1 * 16 + r) * 17 + u]) + (Pp[(2 * 16 + r) * 17 + u] + Pp[(3 * 16 + r) * 17 + u]);
-      const float ig = gcur.x, fg = gcur.y, gg = gcur.z, og = gcur.w;
-      const float tc = tanhf(ctcur);
-      const float dh = dycur + dhr;
-      const float dcv = dh * og * (1.f - tc * tc) + carry;
-      d0 = dcv * gg * ig * (1.f - ig); d1 = dcv * cpcur * fg * (1.f - fg);
-      d2 = dcv * ig * (1.f - gg * gg); d3 = dh * tc * og * (1.f - og);
-      float* dgo = a.dg + row_cur * ldg + (size_t)dir * G4 + j;
-      dgo[0] = d0; dgo[H] = d1; dgo[2 * H] = d2; dgo[3 * H] = d3;
-      carry = dcv * fg;
-      if (s == 0 && a.dc0) a.dc0[((size_t)dir * a.B + b) * H + j] = carry;
+      if (G == 4) {
+        const float ig = gcur.x, fg = gcur.y, gg = gcur.z, og = gcur.w;
+        const float tc = tanhf(v1cur);
+        const float dh = dycur + dhr;
+        const float dcv = dh * og * (1.f - tc * tc) + carry;
+        d[0] = dcv * gg * ig * (1.f - ig); d[1] = dcv * v2cur * fg * (1.f - fg);
+        d[2] = dcv * ig * (1.f - gg * gg); d[3] = dh * tc * og * (1.f - og);
+        float* dgo = a.dg + row_cur * ldg + (size_t)dir * GH + j;
+        dgo[0] = d[0]; dgo[H] = d[1]; dgo[2 * H] = d[2]; dgo[3 * H] = d[3];
+        carry = dcv * fg;
+      } else {
+        const float rg = gcur.x, zg = gcur.y, ng = gcur.z, hnp = gcur.w;
+        const float dh = dycur + dhr + carry;
+        const float dn = dh * (1.f - zg);
+        const float dz = dh * (v1cur - ng);
+        const float dan = dn * (1.f - ng * ng);
+        const float dar = dan * hnp * rg * (1.f - rg);
+        const float daz = dz * zg * (1.f - zg);
+        float* gi = a.dg + row_cur * ldg + (size_t)dir * GH + j;
+        float* gh = a.dg2 + row_cur * ldg + (size_t)dir * GH + j;
+        gi[0] = dar; gi[H] = daz; gi[2 * H] = dan;
+        d[0] = dar; d[1] = daz; d[2] = dan * rg;
+        gh[0] = d[0]; gh[H] = d[1]; gh[2 * H] = d[2];
+        carry = dh * zg;
+      }
+    } else {
+      carry = 0.f;      // (only ever read once the row is active; rows are active from their last frame down)
     }
-    dgs[(0 * 16 + r) * 16 + u] = d0; dgs[(1 * 16 + r) * 16 + u] = d1;
-    dgs[(2 * 16 + r) * 16 + u] = d2; dgs[(3 * 16 + r) * 16 + u] = d3;
+    if (s == 0 && valid && a.d0) a.d0[((size_t)dir * a.B + b) * H + j] = carry;
+#pragma unroll
+    for (int gg2 = 0; gg2 < G; ++gg2) dgs[(gg2 * 16 + r) * 16 + u] = d[gg2];
     __syncthreads();
     if (s > 0) {
-      // partial dh of step s - 1: [16 rows x 64 own gate values] x [64 x 512], this wave's 8 column tiles
+      // partial dh of step s - 1: [16 rows x 16 G own gate values] x [16 G x 512], this wave's 8 column tiles
       const int rr = lane & 15, kq = lane >> 4;
-      float4 af[4];
+      float4 af[G];
 #pragma unroll
-      for (int gg2 = 0; gg2 < 4; ++gg2)
+      for (int gg2 = 0; gg2 < G; ++gg2)
         af[gg2] = make_float4(dgs[(gg2 * 16 + rr) * 16 + kq], dgs[(gg2 * 16 + rr) * 16 + 4 + kq],
                               dgs[(gg2 * 16 + rr) * 16 + 8 + kq], dgs[(gg2 * 16 + rr) * 16 + 12 + kq]);
       const unsigned m = persist_mask(s);
@@ -495,8 +521,8 @@ static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersis
         const int ct = 8 * wv + i;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int gg2 = 0; gg2 < 4; ++gg2) {
-          const float4 bw = Wb[(ct * 4 + gg2) * 64 + lane];
+        for (int gg2 = 0; gg2 < G; ++gg2) {
+          const float4 bw = Wb[(ct * G + gg2) * 64 + lane];
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].x, bw.x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].y, bw.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].z, bw.z, acc, 0, 0, 0);
@@ -512,12 +538,13 @@ static __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(LstmPersis
     }
     // rotate the pipeline
     row_cur = row_m1; row_m1 = row_m2; row_m2 = row_m3;
-    gcur = gnext; dycur = dynext; ctcur = ctnext; cpcur = cpnext;
+    gcur = gnext; dycur = dynext; v1cur = v1next; v2cur = v2next;
   }
 }
 
-// Backward counterpart of rnn_persist_forward (LSTM only): 1 = done, 0 = run the step kernels.
-static int lstm_persist_backward(LstmPersistBwdArgs p, const int* h_lengths, int H, hipStream_t s) {
+// Backward counterpart of rnn_persist_forward: 1 = done, 0 = run the step kernels.
+template <int G>
+static int rnn_persist_backward(RnnPersistBwdArgs p, const int* h_lengths, int H, hipStream_t s) {
   static std::atomic<bool> usable{true};
   const char* pe = getenv("ITTS_RNN_PERSISTENT");          // read per call: tests switch it
   const char* pb = getenv("ITTS_RNN_PERSISTENT_BWD");      // ... and this one keeps the forward half on
@@ -529,8 +556,8 @@ static int lstm_persist_backward(LstmPersistBwdArgs p, const int* h_lengths, int
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, P_BWD_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_persist_bwd_kernel<G>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, persist_bwd_lds_bytes(G)) != hipSuccess)
       return -1;
     n_cu = prop.multiProcessorCount;
   }
@@ -550,7 +577,7 @@ static int lstm_persist_backward(LstmPersistBwdArgs p, const int* h_lengths, int
     if (hipMemsetAsync(p.abort_flag, 1, sizeof(int), s) != hipSuccess) return -1;
   for (p.tile0 = 0; p.tile0 < p.ntiles; p.tile0 += 8 / p.ndir) {
     if (p.tile0 > 0 && hipMemsetAsync(blk, 0, xbytes, s) != hipSuccess) return -1;
-    hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(256), dim3(256), P_BWD_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(rnn_persist_bwd_kernel<G>, dim3(256), dim3(256), persist_bwd_lds_bytes(G), s, p);
     if (hipGetLastError() != hipSuccess) return -1;
   }
   int64_t* slot = pinned_slot(ctx);
