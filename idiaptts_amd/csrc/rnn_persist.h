@@ -86,6 +86,13 @@ __device__ __forceinline__ void persist_load_pair(const uint4* p, pu32x4& v, pu3
                : "memory");
 }
 
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also waits for every
+// global load and store in flight (vmcnt(0)), which puts a trip to HBM in front of the barrier when
+// loads for the NEXT step were just requested.
+__device__ __forceinline__ void persist_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 #ifndef PERSIST_TRACE
 #define PERSIST_TRACE 0
 #endif
@@ -147,14 +154,21 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
   auto row_at = [&](int st) -> size_t {
     return dir == 0 ? (size_t)(a.row_off[st] + b) : (size_t)a.rev_row[(size_t)st * a.B + b];
   };
-  size_t row_cur = 0, row_n1 = 0;
+  // The row index of a step is requested two steps ahead as ONE load of a raw int (forward direction:
+  // row_off[step], + b when it is used; reverse: rev_row[step][b]): anything computed from it at once
+  // would wait for it at once -- in front of the products, with the projections' loads in flight.
+  const int* rtab = dir == 0 ? a.row_off : a.rev_row + b;
+  const size_t rstride = dir == 0 ? 1 : (size_t)a.B;
+  const int radd = dir == 0 ? b : 0;
+  size_t row_cur = 0;
+  int rnew = 0;
   float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gc3 = 0.f;
   if (0 < len) {
     row_cur = row_at(0);
     const float* gi = a.gin + row_cur * ldg + (size_t)dir * G4 + j;
     gc0 = gi[0]; gc1 = gi[H]; gc2 = gi[2 * H]; gc3 = G == 4 ? gi[3 * H] : 0.f;
   }
-  if (1 < len) row_n1 = row_at(1);
+  if (1 < len) rnew = rtab[rstride];
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
 #define PT(i) do { if (PERSIST_TRACE) { const unsigned long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   if (PERSIST_TRACE) tprev = wall_clock64();
@@ -196,14 +210,18 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
         }
       }
     }
-    // step s + 1's input projections (their row index arrived a step ago) and step s + 2's row index
+    // step s + 1's input projections (their row index arrived a step ago; pinned HERE, where the poll
+    // has just waited for everything in flight -- the compiler does not know that and would otherwise
+    // wait at its first use, behind the loads below) and step s + 2's row index
+    int rraw = rnew;
+    asm volatile("" : "+v"(rraw));
+    const size_t row_n1 = (size_t)(rraw + radd);
     float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gn3 = 0.f;
-    size_t row_n2 = 0;
     if (s + 1 < len) {
       const float* gi = a.gin + row_n1 * ldg + (size_t)dir * G4 + j;
       gn0 = gi[0]; gn1 = gi[H]; gn2 = gi[2 * H]; gn3 = G == 4 ? gi[3 * H] : 0.f;
     }
-    if (s + 2 < len) row_n2 = row_at(s + 2);
+    if (s + 2 < len) rnew = rtab[(size_t)(s + 2) * rstride];
     PT(0);
     f32x4 acc[G];
 #pragma unroll
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
 #pragma unroll
       for (int e = 0; e < 4; ++e) Pp[((wv * 4 + gg) * 16 + 4 * (lane >> 4) + e) * 17 + (lane & 15)] = acc[gg][e];
     PT(1);
-    __syncthreads();
+    persist_lds_barrier();
     PT(2);
     if (act) {
       auto pre = [&](int gg) {
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
         if (G == 4 && a.cn) a.cn[((size_t)dir * a.B + b) * H + j] = c;
       }
     }
-    row_cur = row_n1; row_n1 = row_n2;
+    row_cur = row_n1;
     gc0 = gn0; gc1 = gn1; gc2 = gn2; gc3 = gn3;
     PT(3);
     if (s + 1 < t_tile) publish(s + 1, h);
@@ -361,6 +379,9 @@ struct RnnPersistBwdArgs {
 
 constexpr int persist_bwd_lds_bytes(int G) { return 32 * G * 64 * 16 + 4 * 16 * 17 * 4 + G * 16 * 16 * 4; }
 
+#ifndef PERSIST_BWD_TRACE
+#define PERSIST_BWD_TRACE 0
+#endif
 template <int G>
 __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
@@ -395,25 +416,35 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
     return dir == 0 ? (size_t)(a.row_off[st] + b) : (size_t)a.rev_row[(size_t)st * a.B + b];
   };
   const float c_init = (G == 4 && valid && a.c0) ? a.c0[dir * H + j] : 0.f;
-  // pipeline registers: values of the step being processed, requested a step earlier.
+  // Two sets of pipeline registers used alternately (no copy of a value still in flight: a copy would
+  // wait for the load): the current step's values in one, the next step's requested into the other.
   // LSTM: v1 = c_t, v2 = c_{t-1} (the saved cell state of the step before); GRU: v1 = h_prev
+  struct Vals { float4 g; float dy, v1, v2; size_t row; };
   const int s0 = t_tile - 1;
-  size_t row_cur = 0, row_m1 = 0, row_m2 = 0;
-  float4 gcur = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dycur = 0.f, v1cur = 0.f, v2cur = 0.f;
+  Vals va{make_float4(0.f, 0.f, 0.f, 0.f), 0.f, 0.f, 0.f, 0}, vb = va;
+  // the row index of a step is requested three steps ahead as ONE load of a raw int (forward
+  // direction: row_off[step], + b when it is used; reverse: rev_row[step][b]) -- anything computed from
+  // it at once would wait for it at once
+  const int* rtab = dir == 0 ? a.row_off : a.rev_row + b;
+  const size_t rstride = dir == 0 ? 1 : (size_t)a.B;
+  const int radd = dir == 0 ? b : 0;
+  int rnew = 0;
   if (s0 < len) {
-    row_cur = row_at(s0);
-    gcur = reinterpret_cast<const float4*>(a.gates)[(row_cur * a.ndir + dir) * H + j];
-    dycur = a.dy[row_cur * ldh + (size_t)dir * H + j];
-    v1cur = a.aux[row_cur * ldh + (size_t)dir * H + j];
+    va.row = row_at(s0);
+    va.g = reinterpret_cast<const float4*>(a.gates)[(va.row * a.ndir + dir) * H + j];
+    va.dy = a.dy[va.row * ldh + (size_t)dir * H + j];
+    va.v1 = a.aux[va.row * ldh + (size_t)dir * H + j];
   }
-  if (s0 - 1 >= 0 && s0 - 1 < len) row_m1 = row_at(s0 - 1);
-  if (s0 - 2 >= 0 && s0 - 2 < len) row_m2 = row_at(s0 - 2);
-  if (G == 4 && s0 < len) v2cur = s0 > 0 ? a.aux[row_m1 * ldh + (size_t)dir * H + j] : c_init;
+  if (s0 - 1 >= 0 && s0 - 1 < len) vb.row = row_at(s0 - 1);
+  if (s0 - 2 >= 0 && s0 - 2 < len) rnew = rtab[(size_t)(s0 - 2) * rstride];
+  if (G == 4 && s0 < len) va.v2 = s0 > 0 ? a.aux[vb.row * ldh + (size_t)dir * H + j] : c_init;
   float carry = 0.f;       // LSTM: dc * f, GRU: dh * z of the step processed before (s + 1)
   __syncthreads();         // the W image is complete
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
+#define PTB(i) do { if (PERSIST_BWD_TRACE) { const unsigned long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  if (PERSIST_BWD_TRACE) tprev = wall_clock64();
 
-  for (int s = s0; s >= 0; --s) {
+  auto step = [&](const int s, Vals& X, Vals& Y) __attribute__((always_inline)) {
     const bool act = s < len;
     // dh_rec: the 32 partial tiles published at step s + 1
     float dhr = 0.f;
@@ -455,46 +486,39 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
       Pp[(wv * 16 + rq + 0) * 17 + cc] = sx; Pp[(wv * 16 + rq + 1) * 17 + cc] = sy;
       Pp[(wv * 16 + rq + 2) * 17 + cc] = sz; Pp[(wv * 16 + rq + 3) * 17 + cc] = sw;
     }
-    // values of step s - 1 (their row indices arrived a step ago) and the row index of step s - 3
-    float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dynext = 0.f, v1next = v2cur, v2next = 0.f;     // LSTM: c_t of step s - 1 is c_{t-1} of step s ...
-    size_t row_m3 = 0;
-    if (s - 1 >= 0 && s - 1 < len) {
-      gnext = reinterpret_cast<const float4*>(a.gates)[(row_m1 * a.ndir + dir) * H + j];
-      dynext = a.dy[row_m1 * ldh + (size_t)dir * H + j];
-      if (G == 4) {
-        v2next = s - 1 > 0 ? a.aux[row_m2 * ldh + (size_t)dir * H + j] : c_init;
-        if (!act) v1next = a.aux[row_m1 * ldh + (size_t)dir * H + j];   // ... unless the row only starts there
-      } else {
-        v1next = a.aux[row_m1 * ldh + (size_t)dir * H + j];
-      }
-    }
-    if (s - 3 >= 0 && s - 3 < len) row_m3 = row_at(s - 3);
-    __syncthreads();
+    // row of step s - 2, requested a step ago; pinned HERE, where the poll has just waited for everything
+    // in flight (the compiler does not know that, and would otherwise wait at the first use below,
+    // behind this step's stores)
+    int rraw = rnew;
+    asm volatile("" : "+v"(rraw));
+    const size_t r2 = (size_t)(rraw + radd);
+    PTB(0);
+    persist_lds_barrier();
+    PTB(1);
     float d[4] = {0.f, 0.f, 0.f, 0.f};
     if (act) {
       if (s < s0 && s + 1 < len)
         dhr = (Pp[(0 * 16 + r) * 17 + u] + Pp[(1 * 16 + r) * 17 + u]) + (Pp[(2 * 16 + r) * 17 + u] + Pp[(3 * 16 + r) * 17 + u]);
       if (G == 4) {
-        const float ig = gcur.x, fg = gcur.y, gg = gcur.z, og = gcur.w;
-        const float tc = tanhf(v1cur);
-        const float dh = dycur + dhr;
+        const float ig = X.g.x, fg = X.g.y, gg = X.g.z, og = X.g.w;
+        const float tc = tanhf(X.v1);
+        const float dh = X.dy + dhr;
         const float dcv = dh * og * (1.f - tc * tc) + carry;
-        d[0] = dcv * gg * ig * (1.f - ig); d[1] = dcv * v2cur * fg * (1.f - fg);
+        d[0] = dcv * gg * ig * (1.f - ig); d[1] = dcv * X.v2 * fg * (1.f - fg);
         d[2] = dcv * ig * (1.f - gg * gg); d[3] = dh * tc * og * (1.f - og);
-        float* dgo = a.dg + row_cur * ldg + (size_t)dir * GH + j;
+        float* dgo = a.dg + X.row * ldg + (size_t)dir * GH + j;
         dgo[0] = d[0]; dgo[H] = d[1]; dgo[2 * H] = d[2]; dgo[3 * H] = d[3];
         carry = dcv * fg;
       } else {
-        const float rg = gcur.x, zg = gcur.y, ng = gcur.z, hnp = gcur.w;
-        const float dh = dycur + dhr + carry;
+        const float rg = X.g.x, zg = X.g.y, ng = X.g.z, hnp = X.g.w;
+        const float dh = X.dy + dhr + carry;
         const float dn = dh * (1.f - zg);
-        const float dz = dh * (v1cur - ng);
+        const float dz = dh * (X.v1 - ng);
         const float dan = dn * (1.f - ng * ng);
         const float dar = dan * hnp * rg * (1.f - rg);
         const float daz = dz * zg * (1.f - zg);
-        float* gi = a.dg + row_cur * ldg + (size_t)dir * GH + j;
-        float* gh = a.dg2 + row_cur * ldg + (size_t)dir * GH + j;
+        float* gi = a.dg + X.row * ldg + (size_t)dir * GH + j;
+        float* gh = a.dg2 + X.row * ldg + (size_t)dir * GH + j;
         gi[0] = dar; gi[H] = daz; gi[2 * H] = dan;
         d[0] = dar; d[1] = daz; d[2] = dan * rg;
         gh[0] = d[0]; gh[H] = d[1]; gh[2 * H] = d[2];
@@ -506,7 +530,25 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
     if (s == 0 && valid && a.d0) a.d0[((size_t)dir * a.B + b) * H + j] = carry;
 #pragma unroll
     for (int gg2 = 0; gg2 < G; ++gg2) dgs[(gg2 * 16 + r) * 16 + u] = d[gg2];
-    __syncthreads();
+    persist_lds_barrier();
+    PTB(2);
+    // values of step s - 1 (their row indices arrived a step ago) and the row index of step s - 3:
+    // requested here, in front of the products, so that neither a barrier nor the next poll waits for them
+    Y.g = make_float4(0.f, 0.f, 0.f, 0.f);
+    Y.dy = 0.f; Y.v2 = 0.f;
+    Y.v1 = X.v2;                   // LSTM: c_t of step s - 1 is c_{t-1} of step s ...
+    if (s - 1 >= 0 && s - 1 < len) {
+      Y.g = reinterpret_cast<const float4*>(a.gates)[(Y.row * a.ndir + dir) * H + j];
+      Y.dy = a.dy[Y.row * ldh + (size_t)dir * H + j];
+      if (G == 4) {
+        Y.v2 = s - 1 > 0 ? a.aux[r2 * ldh + (size_t)dir * H + j] : c_init;
+        if (!act) Y.v1 = a.aux[Y.row * ldh + (size_t)dir * H + j];   // ... unless the row only starts there
+      } else {
+        Y.v1 = a.aux[Y.row * ldh + (size_t)dir * H + j];
+      }
+    }
+    X.row = r2;                    // X is the current set again at step s - 2
+    if (s - 3 >= 0 && s - 3 < len) rnew = rtab[(size_t)(s - 3) * rstride];
     if (s > 0) {
       // partial dh of step s - 1: [16 rows x 16 G own gate values] x [16 G x 512], this wave's 8 column tiles
       const int rr = lane & 15, kq = lane >> 4;
@@ -536,10 +578,17 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
         dst[64] = C;
       }
     }
-    // rotate the pipeline
-    row_cur = row_m1; row_m1 = row_m2; row_m2 = row_m3;
-    gcur = gnext; dycur = dynext; v1cur = v1next; v2cur = v2next;
+    PTB(3);
+  };
+  for (int s = s0; s >= 0; s -= 2) {
+    step(s, va, vb);
+    if (s >= 1) step(s - 1, vb, va);
   }
+  if (PERSIST_BWD_TRACE && lane == 0 && (blockIdx.x < 8 || blockIdx.x == 100))
+    printf("bwd block %3d wave %d: steps %d  poll %.2f  loads+barrier %.2f  cell+barrier %.2f  mfma+publish %.2f us per step\n",
+           (int)blockIdx.x, wv, t_tile, tacc[0] / 100.0 / t_tile, tacc[1] / 100.0 / t_tile, tacc[2] / 100.0 / t_tile,
+           tacc[3] / 100.0 / t_tile);
+#undef PTB
 }
 
 // Backward counterpart of rnn_persist_forward: 1 = done, 0 = run the step kernels.
