@@ -86,6 +86,43 @@ __device__ __forceinline__ void persist_load_pair(const uint4* p, pu32x4& v, pu3
                : "memory");
 }
 
+// Tagged form for the backward kernel's partial tiles (a tile = 64 granules (v0, v1, v2, tag) + 22
+// granules carrying the lanes' fourth values three at a time, 88 granules reserved): sixteen loads
+// in flight, the second eight at per-lane addresses of their own.
+__device__ __forceinline__ void persist_load16t(const uint4* pa, const uint4* pb, int stride, pu32x4 (&v)[8],
+                                                pu32x4 (&c)[8]) {
+  const uint4 *p0 = pa, *p1 = pa + stride, *p2 = pa + 2 * stride, *p3 = pa + 3 * stride, *p4 = pa + 4 * stride,
+              *p5 = pa + 5 * stride, *p6 = pa + 6 * stride, *p7 = pa + 7 * stride;
+  const uint4 *q0 = pb, *q1 = pb + stride, *q2 = pb + 2 * stride, *q3 = pb + 3 * stride, *q4 = pb + 4 * stride,
+              *q5 = pb + 5 * stride, *q6 = pb + 6 * stride, *q7 = pb + 7 * stride;
+  asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %17, off sc1\n\t"
+               "global_load_dwordx4 %2, %18, off sc1\n\tglobal_load_dwordx4 %3, %19, off sc1\n\t"
+               "global_load_dwordx4 %4, %20, off sc1\n\tglobal_load_dwordx4 %5, %21, off sc1\n\t"
+               "global_load_dwordx4 %6, %22, off sc1\n\tglobal_load_dwordx4 %7, %23, off sc1\n\t"
+               "global_load_dwordx4 %8, %24, off sc1\n\tglobal_load_dwordx4 %9, %25, off sc1\n\t"
+               "global_load_dwordx4 %10, %26, off sc1\n\tglobal_load_dwordx4 %11, %27, off sc1\n\t"
+               "global_load_dwordx4 %12, %28, off sc1\n\tglobal_load_dwordx4 %13, %29, off sc1\n\t"
+               "global_load_dwordx4 %14, %30, off sc1\n\tglobal_load_dwordx4 %15, %31, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                 "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7),
+                 "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7)
+               : "memory");
+}
+
+__device__ __forceinline__ void persist_load_one(const uint4* p, pu32x4& v) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+}
+
+// Loads and stores of data touched once (gates, gradients): marked non-temporal so that they do not
+// push the exchange tiles, which are re-used every other step, out of the XCD's L2.
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 persist_stream_load4(const float4* p) {
+  const pf32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pf32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also waits for every
 // global load and store in flight (vmcnt(0)), which puts a trip to HBM in front of the barrier when
 // loads for the NEXT step were just requested.
@@ -357,9 +394,12 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
 // instead the product is split along K: workgroup c multiplies ITS OWN 16 G gate values per row (kept
 // in LDS, never exchanged) with its 16 G rows of W_hh (a G x 32 KB LDS image: [column tile 32][gate]
 // [lane] float4) into a PARTIAL dh for all 512 units, publishes the 16 x 16 tile of every unit block
-// to the workgroup that owns it (reduce-scatter: 32 KB + check copies out, 32 KB + check copies in,
-// per CU and step), and sums the 32 partial tiles it receives.  Granule pairs, polling, budget and
-// fallback as above.
+// to the workgroup that owns it (reduce-scatter: 32 KB out, 32 KB in, per CU and step), and sums the
+// 32 partial tiles it receives.  Polling, budget and fallback as above, but the granules carry their
+// tag INSIDE (three values + mask(step); a tile's 256 values take 86 granules): with a check copy
+// per granule the two step slots of an XCD's 32 x 32 tiles are 4 MB, the size of its L2, and every
+// step's exchange went through HBM (measured: 22.8 GB written, 14 GB read per layer and launch
+// against 3 GB of gate and gradient data); tagged they are 2.75 MB and stay.
 struct RnnPersistBwdArgs {
   const float* dy;
   const float* whh;
@@ -372,11 +412,12 @@ struct RnnPersistBwdArgs {
   float* dg;            // LSTM: dG; GRU: dGi
   float* dg2;           // GRU: dGh (da_n * r in the third gate)
   float* d0;            // [ndir][B][H] or NULL: LSTM dc * f, GRU dh * z after step 0
-  uint4* xchg;          // [8 groups][2 slots][32 consumers][32 producers][P | C][64 lanes]
+  uint4* xchg;          // [8 groups][2 slots][32 consumers][32 producers][PT granules]
   int* abort_flag;
   int T, B, ndir, ntiles, tile0;
 };
 
+constexpr int PT = 88;    // granules reserved per partial tile: 64 + 22, padded to whole 128-byte lines
 constexpr int persist_bwd_lds_bytes(int G) { return 32 * G * 64 * 16 + 4 * 16 * 17 * 4 + G * 16 * 16 * 4; }
 
 #ifndef PERSIST_BWD_TRACE
@@ -411,7 +452,7 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
   const int len = valid ? a.lengths[b] : 0;
   const int t_tile = a.lengths[tile * 16];
   const size_t ldg = (size_t)a.ndir * GH, ldh = (size_t)a.ndir * H;
-  uint4* xg = a.xchg + (size_t)group * 2 * 32 * 32 * 128;
+  uint4* xg = a.xchg + (size_t)group * 2 * 32 * 32 * PT;
   auto row_at = [&](int st) -> size_t {
     return dir == 0 ? (size_t)(a.row_off[st] + b) : (size_t)a.rev_row[(size_t)st * a.B + b];
   };
@@ -450,23 +491,22 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
     float dhr = 0.f;
     if (s < s0) {
       pu32x4 pv[8], cv[8];
-      const uint4* src = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv) * 128 + lane;
+      const uint4* src = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv) * PT;
       const unsigned m = persist_mask(s + 1);
+      const int l3 = lane / 3, lm = lane - 3 * l3;
       int budget = 1 << 16;
       for (;;) {
-        persist_load16(src, 128, pv, cv);
+        persist_load16t(src + lane, src + 64 + l3, PT, pv, cv);
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          ok = ok && (pv[i].x ^ cv[i].x) == m && (pv[i].y ^ cv[i].y) == m && (pv[i].z ^ cv[i].z) == m &&
-               (pv[i].w ^ cv[i].w) == m;
+        for (int i = 0; i < 8; ++i) ok = ok && pv[i].w == m && cv[i].w == m;
         if (__all(ok)) break;
-        const uint4* watch = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv + (lane & 7)) * 128;
+        const uint4* watch = src + (lane & 7) * PT;
         bool gave_up = false;
         for (;;) {
-          pu32x4 wp, wc;
-          persist_load_pair(watch, wp, wc);
-          if (__all((wp.x ^ wc.x) == m)) break;
+          pu32x4 wp;
+          persist_load_one(watch, wp);
+          if (__all(wp.w == m)) break;
           if (--budget <= 0 || *reinterpret_cast<volatile int*>(a.abort_flag)) { gave_up = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
@@ -479,8 +519,8 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
       float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        sx += __uint_as_float(pv[i].x); sy += __uint_as_float(pv[i].y);
-        sz += __uint_as_float(pv[i].z); sw += __uint_as_float(pv[i].w);
+        sx += __uint_as_float(pv[i].x); sy += __uint_as_float(pv[i].y); sz += __uint_as_float(pv[i].z);
+        sw += __uint_as_float(lm == 0 ? cv[i].x : (lm == 1 ? cv[i].y : cv[i].z));
       }
       const int rq = 4 * (lane >> 4), cc = lane & 15;
       Pp[(wv * 16 + rq + 0) * 17 + cc] = sx; Pp[(wv * 16 + rq + 1) * 17 + cc] = sy;
@@ -507,7 +547,8 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
         d[0] = dcv * gg * ig * (1.f - ig); d[1] = dcv * X.v2 * fg * (1.f - fg);
         d[2] = dcv * ig * (1.f - gg * gg); d[3] = dh * tc * og * (1.f - og);
         float* dgo = a.dg + X.row * ldg + (size_t)dir * GH + j;
-        dgo[0] = d[0]; dgo[H] = d[1]; dgo[2 * H] = d[2]; dgo[3 * H] = d[3];
+        __builtin_nontemporal_store(d[0], dgo); __builtin_nontemporal_store(d[1], dgo + H);
+        __builtin_nontemporal_store(d[2], dgo + 2 * H); __builtin_nontemporal_store(d[3], dgo + 3 * H);
         carry = dcv * fg;
       } else {
         const float rg = X.g.x, zg = X.g.y, ng = X.g.z, hnp = X.g.w;
@@ -519,9 +560,9 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
         const float daz = dz * zg * (1.f - zg);
         float* gi = a.dg + X.row * ldg + (size_t)dir * GH + j;
         float* gh = a.dg2 + X.row * ldg + (size_t)dir * GH + j;
-        gi[0] = dar; gi[H] = daz; gi[2 * H] = dan;
+        __builtin_nontemporal_store(dar, gi); __builtin_nontemporal_store(daz, gi + H); __builtin_nontemporal_store(dan, gi + 2 * H);
         d[0] = dar; d[1] = daz; d[2] = dan * rg;
-        gh[0] = d[0]; gh[H] = d[1]; gh[2 * H] = d[2];
+        __builtin_nontemporal_store(d[0], gh); __builtin_nontemporal_store(d[1], gh + H); __builtin_nontemporal_store(d[2], gh + 2 * H);
         carry = dh * zg;
       }
     } else {
@@ -538,13 +579,13 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
     Y.dy = 0.f; Y.v2 = 0.f;
     Y.v1 = X.v2;                   // LSTM: c_t of step s - 1 is c_{t-1} of step s ...
     if (s - 1 >= 0 && s - 1 < len) {
-      Y.g = reinterpret_cast<const float4*>(a.gates)[(Y.row * a.ndir + dir) * H + j];
-      Y.dy = a.dy[Y.row * ldh + (size_t)dir * H + j];
+      Y.g = persist_stream_load4(reinterpret_cast<const float4*>(a.gates) + (Y.row * a.ndir + dir) * H + j);
+      Y.dy = __builtin_nontemporal_load(a.dy + Y.row * ldh + (size_t)dir * H + j);
       if (G == 4) {
-        Y.v2 = s - 1 > 0 ? a.aux[r2 * ldh + (size_t)dir * H + j] : c_init;
-        if (!act) Y.v1 = a.aux[Y.row * ldh + (size_t)dir * H + j];   // ... unless the row only starts there
+        Y.v2 = s - 1 > 0 ? __builtin_nontemporal_load(a.aux + r2 * ldh + (size_t)dir * H + j) : c_init;
+        if (!act) Y.v1 = __builtin_nontemporal_load(a.aux + Y.row * ldh + (size_t)dir * H + j);   // ... unless the row only starts there
       } else {
-        Y.v1 = a.aux[Y.row * ldh + (size_t)dir * H + j];
+        Y.v1 = __builtin_nontemporal_load(a.aux + Y.row * ldh + (size_t)dir * H + j);
       }
     }
     X.row = r2;                    // X is the current set again at step s - 2
@@ -570,12 +611,12 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].z, bw.z, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].w, bw.w, acc, 0, 0, 0);
         }
-        const uint4 P = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
-                                   __float_as_uint(acc[3]));
-        const uint4 C = make_uint4(P.x ^ m, P.y ^ m, P.z ^ m, P.w ^ m);
-        uint4* dst = xg + (((size_t)(s & 1) * 32 + ct) * 32 + cu) * 128 + lane;
-        dst[0] = P;
-        dst[64] = C;
+        // lanes 0 .. 21 also carry the fourth values of lanes 3 l, 3 l + 1, 3 l + 2
+        const float q0 = __shfl(acc[3], min(3 * lane, 63), 64), q1 = __shfl(acc[3], min(3 * lane + 1, 63), 64),
+                    q2 = __shfl(acc[3], min(3 * lane + 2, 63), 64);
+        uint4* dst = xg + (((size_t)(s & 1) * 32 + ct) * 32 + cu) * PT;
+        dst[lane] = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), m);
+        if (lane < 22) dst[64 + lane] = make_uint4(__float_as_uint(q0), __float_as_uint(q1), __float_as_uint(q2), m);
       }
     }
     PTB(3);
@@ -612,7 +653,7 @@ static int rnn_persist_backward(RnnPersistBwdArgs p, const int* h_lengths, int H
   }
   DeviceContext* ctx = n_cu == 256 ? get_context() : nullptr;
   if (!ctx) return 0;
-  const size_t xbytes = (size_t)8 * 2 * 32 * 32 * 128 * sizeof(uint4);
+  const size_t xbytes = (size_t)8 * 2 * 32 * 32 * PT * sizeof(uint4);
   const size_t lbytes = ((size_t)p.B * sizeof(int) + 63) / 64 * 64;
   char* blk = nullptr;
   itts::ScratchScope scope(s);
