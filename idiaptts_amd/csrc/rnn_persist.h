@@ -599,24 +599,44 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
         af[gg2] = make_float4(dgs[(gg2 * 16 + rr) * 16 + kq], dgs[(gg2 * 16 + rr) * 16 + 4 + kq],
                               dgs[(gg2 * 16 + rr) * 16 + 8 + kq], dgs[(gg2 * 16 + rr) * 16 + 12 + kq]);
       const unsigned m = persist_mask(s);
+      // Software pipeline over the tiles: the values of tile i - 1 are collected, tagged and stored
+      // BETWEEN the products of tile i (a wave issues in order: behind the last product of a chain the
+      // read of its result, the three shuffles and the stores would otherwise leave the matrix unit
+      // idle for ~250 clocks per tile)
+      const int sl0 = min(3 * lane, 63), sl1 = min(3 * lane + 1, 63), sl2 = min(3 * lane + 2, 63);
+      f32x4 accp = {0.f, 0.f, 0.f, 0.f};
+      const float4* wsrc = Wb + (size_t)(8 * wv * G) * 64 + lane;      // this wave's 8 G operand quadruples
+      float4 bw = wsrc[0];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i <= 8; ++i) {
         const int ct = 8 * wv + i;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+        uint4* dst = xg + (((size_t)(s & 1) * 32 + (ct - 1)) * 32 + cu) * PT;
 #pragma unroll
         for (int gg2 = 0; gg2 < G; ++gg2) {
-          const float4 bw = Wb[(ct * G + gg2) * 64 + lane];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].x, bw.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].y, bw.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].z, bw.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].w, bw.w, acc, 0, 0, 0);
+          float4 bwn = bw;
+          if (i * G + gg2 + 1 < 8 * G) bwn = wsrc[(i * G + gg2 + 1) * 64];      // requested one group ahead
+          if (i < 8) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].x, bw.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].y, bw.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].z, bw.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].w, bw.w, acc, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (i > 0) {
+            if (gg2 == 0) {
+              // lanes 0 .. 21 also carry the fourth values of lanes 3 l, 3 l + 1, 3 l + 2
+              q0 = __shfl(accp[3], sl0, 64); q1 = __shfl(accp[3], sl1, 64); q2 = __shfl(accp[3], sl2, 64);
+              dst[lane] = make_uint4(__float_as_uint(accp[0]), __float_as_uint(accp[1]), __float_as_uint(accp[2]), m);
+            } else if (gg2 == 1) {
+              if (lane < 22) dst[64 + lane] = make_uint4(__float_as_uint(q0), __float_as_uint(q1), __float_as_uint(q2), m);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bw = bwn;
         }
-        // lanes 0 .. 21 also carry the fourth values of lanes 3 l, 3 l + 1, 3 l + 2
-        const float q0 = __shfl(acc[3], min(3 * lane, 63), 64), q1 = __shfl(acc[3], min(3 * lane + 1, 63), 64),
-                    q2 = __shfl(acc[3], min(3 * lane + 2, 63), 64);
-        uint4* dst = xg + (((size_t)(s & 1) * 32 + ct) * 32 + cu) * PT;
-        dst[lane] = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), m);
-        if (lane < 22) dst[64 + lane] = make_uint4(__float_as_uint(q0), __float_as_uint(q1), __float_as_uint(q2), m);
+        accp = acc;
       }
     }
     PTB(3);
