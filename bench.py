@@ -532,8 +532,8 @@ def bilstm_section(dev, n_utts=64, steps=6, cell="LSTM", rank=0, world=1, key=No
         "timing": "HIP events on the launch stream, 2 warm-up steps",
         "ms_per_step": dt * 1e3, "valid_frames_per_s": frames / dt,
         "loss": ld["MSELoss_acoustic_features"],
-        "roofline": {"bound": "mfma", "kernel": "gemm_ring_kernel + rnn_persist_fwd_kernel + {}_step_bwd_kernel".format(
-                         cell.lower()),
+        "roofline": {"bound": "mfma", "kernel": "gemm_ring_kernel + rnn_persist_fwd_kernel<{0}> + rnn_persist_bwd_kernel<{0}>".format(
+                         gates),
                      "achieved": tflops / world, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / world / PEAK_MFMA_F32_TFLOPS, "traffic": None,
                      "algorithmic_flops_per_frame": rnn_flops_per_frame(gates=gates)}}}

@@ -6,9 +6,9 @@
 // Split of the work (per layer):
 //   * gin = X W_ih^T + (b_ih + b_hh) for ALL time steps and both directions is ONE fp32-MFMA GEMM
 //     (nn.hip), so are dX, dW_ih, dW_hh and the bias gradients in the backward pass;
-//   * only the true recurrence h_{t-1} W_hh^T runs per time step.  Forward: one persistent launch
-//     per layer where it applies (rnn_persist.h: H = 512, every recurrence inside one XCD).
-//     Otherwise, and always backward: one launch per step, both directions in it: the kernel
+//   * only the true recurrence h_{t-1} W_hh^T runs per time step.  Forward and backward: one
+//     persistent launch per layer each where it applies (rnn_persist.h: H = 512, every recurrence
+//     inside one XCD).  Otherwise: one launch per step, both directions in it: the kernel
 //     boundary is the grid-wide dependency (an in-kernel grid barrier ACROSS XCDs costs 2.3-2.5 us
 //     on this chip, scripts/handoff_lab).  A workgroup owns a slice of hidden units and
 //     streams its W_hh rows and h_{t-1} [B, H] from L2 through v_mfma_f32_16x16x4_f32

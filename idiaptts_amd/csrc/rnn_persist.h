@@ -1,7 +1,8 @@
-// Persistent forward recurrence of the LSTM / GRU layers (included by lstm.hip and gru.hip): what
+// Persistent recurrences of the LSTM / GRU layers (included by lstm.hip and gru.hip): what
 // torch.nn.LSTM / GRU do between pack_padded_sequence and pad_packed_sequence in
-// rnn_dyn/RNNWrapper.py:89-102, forward direction of time only (the backward pass stays on the step
-// kernels of lstm.hip / gru.hip).
+// rnn_dyn/RNNWrapper.py:89-102 and what autograd does on the way back -- one launch per layer for
+// the forward recurrence, one for the backward recurrence (the step kernels of lstm.hip / gru.hip
+// remain for other sizes and as the fallback).
 #pragma once
 #include <atomic>
 #include <cstdio>
