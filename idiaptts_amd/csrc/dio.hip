@@ -64,9 +64,43 @@ __global__ __launch_bounds__(NT) void dio_mean_kernel(const double* __restrict__
   if (threadIdx.x == 0) mean[blockIdx.x] = s / (double)(u.xl + 1);
 }
 
-// ---- FIR: out[n] = a0*in(n) - sum_k taps[k] * in(n + shift - k) --------------------------------
-// Generic tiled FIR with the input given by a functor. TILE outputs per block.
-constexpr int TILE = 1024;
+// ---- FIR: out[o] = sum_k taps[k] * in[o + (L - 1) - k] ----------------------------------------------
+// Register-blocked: a thread owns FR consecutive outputs and walks the taps in blocks of FK; per
+// block it reads the FR + FK - 1 inputs it needs ONCE from LDS and feeds FR * FK multiply-adds from
+// registers, the taps arrive through the scalar cache (uniform address).  One LDS read per multiply-add
+// (the first version: every product fetched its sample again) held the kernels at 2.5 % of the
+// fp64 rate.  The tile is stored de-interleaved -- element j in plane j % FR at position j / FR --
+// so that the lanes of a wave (thread t reads element FR t + const) touch consecutive addresses.
+// The tap arrays are padded with zeros to a multiple of FK (a zero tap adds +-0: no value changes)
+// and the order of the additions per output is the plain k = 0, 1, 2, ... of the direct sum.
+constexpr int FR = 8, FK = 16;
+constexpr int TILE = NT * FR;
+static_assert(FK % FR == 0, "the plane of a window element must not depend on the tap block");
+
+__host__ __device__ inline int fir_pad_taps(int L) { return (L + FK - 1) / FK * FK; }
+// plane length for a tile of TILE outputs and Lp (padded) taps: a multiple of 32 plus 8, which spreads
+// the eight planes over the banks when the tile is written
+__host__ __device__ inline int fir_plane_len(int Lp) { return ((TILE + Lp - 1 + FR - 1) / FR + 31) / 32 * 32 + 8; }
+__host__ __device__ inline size_t fir_lds_bytes(int Lp) { return (size_t)FR * fir_plane_len(Lp) * 8; }
+
+__device__ __forceinline__ void fir_store(double* sy2, int PL, int j, double v) { sy2[(j % FR) * PL + j / FR] = v; }
+
+__device__ __forceinline__ void fir_blocked(const double* sy2, int PL, const double* __restrict__ taps, int Lp,
+                                            double (&acc)[FR]) {
+  const double* base = sy2 + threadIdx.x;
+  for (int k0 = 0; k0 < Lp; k0 += FK) {
+    const double* src = base + (Lp - FK - k0) / FR;
+    double win[FR + FK - 1];
+#pragma unroll
+    for (int j = 0; j < FR + FK - 1; ++j) win[j] = src[(j % FR) * PL + j / FR];
+#pragma unroll
+    for (int kk = 0; kk < FK; ++kk) {
+      const double w = taps[k0 + kk];
+#pragma unroll
+      for (int r = 0; r < FR; ++r) acc[r] += w * win[r + FK - 1 - kk];
+    }
+  }
+}
 
 // low-cut: ylc[n] = y[n] - sum_{k=0}^{N-1} wn[k] * y[n + half - k],  n in [-pad, yl+pad)
 __global__ __launch_bounds__(NT) void dio_lowcut_kernel(const double* __restrict__ x,
@@ -75,40 +109,36 @@ __global__ __launch_bounds__(NT) void dio_lowcut_kernel(const double* __restrict
                                                         const double* __restrict__ taps,
                                                         DioParams p, double* __restrict__ ylc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* st = reinterpret_cast<double*>(smem);  // taps [N]
-  double* sy = st + p.lowcut_n;                  // input tile [TILE + N - 1]
+  double* sy2 = reinterpret_cast<double*>(smem);
   const DioUtt u = utts[blockIdx.y];
   const int yl = u.xl + 1;
   const int total = yl + 2 * p.pad;
   const int o0 = blockIdx.x * TILE;  // index into the padded output
   if (o0 >= total) return;
-  const int N = p.lowcut_n, half = (N - 1) / 2;
+  const int N = p.lowcut_n, half = (N - 1) / 2, Np = fir_pad_taps(N);
+  const int PL = fir_plane_len(Np);
   const double m = mean[blockIdx.y];
   const double* xs = x + u.x_off;
-  for (int k = threadIdx.x; k < N; k += NT) st[k] = taps[k];
-  // input sample index of tile element j: n = (o0 - pad) + j - half
-  const int nbase = o0 - p.pad - half;
-  for (int j = threadIdx.x; j < TILE + N - 1; j += NT) {
+  // input sample index of tile element j: n = (o0 - pad) + j - half - (Np - N)
+  const int nbase = o0 - p.pad - half - (Np - N);
+  for (int j = threadIdx.x; j < TILE + Np - 1; j += NT) {
     const int n = nbase + j;
     double v = 0.0;
     if (n >= 0 && n < u.xl) v = xs[n] - m;
     else if (n == u.xl) v = -m;
-    sy[j] = v;
+    fir_store(sy2, PL, j, v);
   }
   __syncthreads();
-  double acc[TILE / NT];
+  double acc[FR];
 #pragma unroll
-  for (int r = 0; r < TILE / NT; ++r) acc[r] = 0.0;
-  // out index o = threadIdx + NT*r ; y[n + half - k] = sy[o + 2*half - k]
-  for (int k = 0; k < N; ++k) {
-    const double w = st[k];
+  for (int r = 0; r < FR; ++r) acc[r] = 0.0;
+  fir_blocked(sy2, PL, taps, Np, acc);
+  const int c0 = half + (Np - N);      // tile element of output o's own sample: o + c0
 #pragma unroll
-    for (int r = 0; r < TILE / NT; ++r) acc[r] += w * sy[threadIdx.x + NT * r + (N - 1) - k];
-  }
-#pragma unroll
-  for (int r = 0; r < TILE / NT; ++r) {
-    const int o = o0 + threadIdx.x + NT * r;
-    if (o < total) ylc[u.ylc_off + o] = sy[threadIdx.x + NT * r + half] - acc[r];
+  for (int r = 0; r < FR; ++r) {
+    const int o = FR * threadIdx.x + r;
+    const int jc = o + c0;
+    if (o0 + o < total) ylc[u.ylc_off + o0 + o] = sy2[(jc % FR) * PL + jc / FR] - acc[r];
   }
 }
 
@@ -121,36 +151,31 @@ __global__ __launch_bounds__(NT) void dio_band_kernel(const DioUtt* __restrict__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z;
   const int hal = p.hal[b];
-  const int L = 4 * hal;
-  double* st = reinterpret_cast<double*>(smem);  // taps [L]
-  double* sy = st + L;                           // tile [TILE + L - 1]
+  const int Lp = fir_pad_taps(4 * hal);
+  const int PL = fir_plane_len(Lp);
+  double* sy2 = reinterpret_cast<double*>(smem);
   const DioUtt u = utts[blockIdx.y];
   const int yl = u.xl + 1;
   const int n0 = blockIdx.x * TILE;
   if (n0 >= yl) return;
   const double* taps = lpf_all + lpf_off[b];
-  for (int k = threadIdx.x; k < L; k += NT) st[k] = taps[k];
-  // tile element j <-> ylc index (n0 + j - (L-1) + 2hal) ; stored ylc has `pad` leading zeros
+  // tile element j <-> ylc index (n0 + j - (Lp-1) + 2hal) ; stored ylc has `pad` leading zeros
   const double* src = ylc + u.ylc_off + p.pad;
   const int total = yl + p.pad;  // valid indices: [-pad, yl+pad)
-  const int base = n0 - (L - 1) + 2 * hal;
-  for (int j = threadIdx.x; j < TILE + L - 1; j += NT) {
+  const int base = n0 - (Lp - 1) + 2 * hal;
+  for (int j = threadIdx.x; j < TILE + Lp - 1; j += NT) {
     const int n = base + j;
-    sy[j] = (n >= -p.pad && n < total) ? src[n] : 0.0;
+    fir_store(sy2, PL, j, (n >= -p.pad && n < total) ? src[n] : 0.0);
   }
   __syncthreads();
-  double acc[TILE / NT];
+  double acc[FR];
 #pragma unroll
-  for (int r = 0; r < TILE / NT; ++r) acc[r] = 0.0;
-  for (int k = 0; k < L; ++k) {
-    const double w = st[k];
-#pragma unroll
-    for (int r = 0; r < TILE / NT; ++r) acc[r] += w * sy[threadIdx.x + NT * r + (L - 1) - k];
-  }
+  for (int r = 0; r < FR; ++r) acc[r] = 0.0;
+  fir_blocked(sy2, PL, taps, Lp, acc);
   double* out = sig + u.sig_off + (int64_t)b * yl;
 #pragma unroll
-  for (int r = 0; r < TILE / NT; ++r) {
-    const int n = n0 + threadIdx.x + NT * r;
+  for (int r = 0; r < FR; ++r) {
+    const int n = n0 + FR * threadIdx.x + r;
     if (n < yl) out[n] = acc[r];
   }
 }
@@ -435,19 +460,19 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
     p.hal[i] = mround_h((double)fs / p.bnd[i] / 2.0);
     ITTS_REQUIRE(p.hal[i] >= 1, "sampling rate too low for the DIO bands");
     lpf_off[i] = lpf_total;
-    lpf_total += 4 * p.hal[i];
+    lpf_total += fir_pad_taps(4 * p.hal[i]);      // zero taps up to a whole tap block
   }
   p.lowcut_n = mround_h((double)fs / 50.0) * 2 + 1;
   p.pad = 2 * p.hal[0] + 2;
   // filter taps (host, tiny)
-  std::vector<double> taps(p.lowcut_n), lpf(lpf_total);
+  std::vector<double> taps(fir_pad_taps(p.lowcut_n), 0.0), lpf(lpf_total, 0.0);
   {
     double wsum = 0.0;
     for (int i = 1; i <= p.lowcut_n; ++i) {
       taps[i - 1] = 0.5 - 0.5 * std::cos(i * 2.0 * M_PI / (p.lowcut_n + 1));
       wsum += taps[i - 1];
     }
-    for (auto& t : taps) t = t / wsum;
+    for (int i = 0; i < p.lowcut_n; ++i) taps[i] = taps[i] / wsum;
     for (int b = 0; b < p.nb; ++b) {
       const int n = 4 * p.hal[b];
       for (int i = 0; i < n; ++i) {
@@ -516,7 +541,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
     ITTS_LAUNCH_CHECK();
     {
       const int total = max_yl + 2 * p.pad;
-      const size_t lds = (size_t)(p.lowcut_n + TILE + p.lowcut_n - 1) * 8;
+      const size_t lds = fir_lds_bytes(fir_pad_taps(p.lowcut_n));
       ITTS_REQUIRE(lds <= 160 * 1024, "sampling rate too high for the DIO low-cut tile");
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)dio_lowcut_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -525,8 +550,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
       ITTS_LAUNCH_CHECK();
     }
     {
-      const int Lmax = 4 * p.hal[0];
-      const size_t lds = (size_t)(Lmax + TILE + Lmax - 1) * 8;
+      const size_t lds = fir_lds_bytes(fir_pad_taps(4 * p.hal[0]));
       ITTS_REQUIRE(lds <= 160 * 1024, "sampling rate too high for the DIO band tile");
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)dio_band_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -23,7 +23,11 @@ using namespace wd;
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// C[rows, N] = A[rows, K] . B[K, N]; all row-major f64. Workgroup: 64 rows x 64 cols, wave: 16 x 64.
+// C[rows, N] = A[rows, K] . B[K, N]; all row-major f64. Workgroup: 128 rows x 64 cols, wave: 32 x 64
+// (two 16-row blocks share every B value a lane loads: B is 80 % of a wave's operand bytes), the
+// operands of K chunk s + 1 are requested before the products of chunk s (two register sets used
+// alternately).  The first version -- 16 rows per wave, load / wait / multiply per chunk -- ran at
+// 27 % of the fp64 MFMA rate.
 // `rows` (optional) lists the physical row of every logical row: the Newton rounds only touch the
 // frames that have not converged yet.  VEC_A: a lane's four consecutive k of a chunk come as two
 // 16-byte loads (needs an even lda and a 16-byte aligned base; rows may be read up to 3 doubles
@@ -35,32 +39,42 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
                                                        int N, int K, const int* __restrict__ rows) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * 64 + wv * 16;
+  const int64_t r0 = (int64_t)blockIdx.x * 128 + wv * 32;
+  if (r0 >= T) return;
   const int c0 = blockIdx.y * 64;
-  const int64_t row = r0 + lr;
-  const bool rok = row < T;
-  const int64_t prow = rok ? (rows ? rows[row] : row) : 0;
-  const double* ap = A + prow * lda;
-  f64x4 acc[4];
+  bool rok[2];
+  const double* ap[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int h = 0; h < 2; ++h) {
+    const int64_t row = r0 + 16 * h + lr;
+    rok[h] = row < T;
+    const int64_t prow = rok[h] ? (rows ? rows[row] : row) : 0;
+    ap[h] = A + prow * lda;
+  }
+  f64x4 acc[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[h][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
   // MFMA q of a lane group covers the columns c0 + 4 lr + q: a lane's four B values of one k are
   // four consecutive columns (one 32-byte load instead of four 8-byte ones) and its four results
   // of one output row likewise (one 32-byte store).
   const int cb = c0 + 4 * lr;
   const bool cfull = cb + 3 < N;               // all four columns inside the matrix
+  struct Ops { double av[2][4]; double bv[4][4]; };
   // K permutation: lane (lr, kg) supplies k = 16 s + 4 kg + j on MFMA j of chunk s
-  for (int s = 0; s < K; s += 16) {
-    double av[4];
-    double bv[4][4];
+  auto load = [&](int s, Ops& o) {
     if (VEC_A) {
       const int k0 = s + 4 * kg;
-      const double2* p2 = reinterpret_cast<const double2*>(ap + (k0 < K ? k0 : 0));
-      const double2 v0 = p2[0], v1 = p2[1];
-      av[0] = (rok && k0 < K) ? v0.x : 0.0;
-      av[1] = (rok && k0 + 1 < K) ? v0.y : 0.0;
-      av[2] = (rok && k0 + 2 < K) ? v1.x : 0.0;
-      av[3] = (rok && k0 + 3 < K) ? v1.y : 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double2* p2 = reinterpret_cast<const double2*>(ap[h] + (k0 < K ? k0 : 0));
+        const double2 v0 = p2[0], v1 = p2[1];
+        o.av[h][0] = (rok[h] && k0 < K) ? v0.x : 0.0;
+        o.av[h][1] = (rok[h] && k0 + 1 < K) ? v0.y : 0.0;
+        o.av[h][2] = (rok[h] && k0 + 2 < K) ? v1.x : 0.0;
+        o.av[h][3] = (rok[h] && k0 + 3 < K) ? v1.y : 0.0;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -68,43 +82,62 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
       const bool kok = k < K;
       const int kc = kok ? k : 0;
       if (!VEC_A) {
-        const double a = ap[kc];
-        av[j] = (kok && rok) ? a : 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double a = ap[h][kc];
+          o.av[h][j] = (kok && rok[h]) ? a : 0.0;
+        }
       }
       const double* brow = Bm + (int64_t)kc * ldb;
       if (cfull) {
         const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb);   // global: dword alignment suffices
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[j][q] = kok ? b4[q] : 0.0;
+        for (int q = 0; q < 4; ++q) o.bv[j][q] = kok ? b4[q] : 0.0;
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const double b = brow[cb + q < N ? cb + q : 0];
-          bv[j][q] = (kok && cb + q < N) ? b : 0.0;
+          o.bv[j][q] = (kok && cb + q < N) ? b : 0.0;
         }
       }
     }
+  };
+  auto multiply = [&](const Ops& o) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j][q], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[h][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[h][j], o.bv[j][q], acc[h][q], 0, 0, 0);
+  };
+  Ops oa, ob;
+  load(0, oa);
+  for (int s = 0; s < K; s += 32) {
+    if (s + 16 < K) load(s + 16, ob);
+    multiply(oa);
+    if (s + 16 < K) {
+      if (s + 32 < K) load(s + 32, oa);
+      multiply(ob);
+    }
   }
   // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t orow = r0 + kg + 4 * r;
-    if (orow >= T) continue;
-    const int64_t prow_o = rows ? rows[orow] : orow;
-    double* crow = C + prow_o * ldc + cb;
-    if (cfull) {
-      *reinterpret_cast<f64x4*>(crow) = (f64x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-    } else {
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (cb + q < N) crow[q] = acc[q][r];
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = r0 + 16 * h + kg + 4 * r;
+      if (orow >= T) continue;
+      const int64_t prow_o = rows ? rows[orow] : orow;
+      double* crow = C + prow_o * ldc + cb;
+      if (cfull) {
+        *reinterpret_cast<f64x4*>(crow) = (f64x4){acc[h][0][r], acc[h][1][r], acc[h][2][r], acc[h][3][r]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (cb + q < N) crow[q] = acc[h][q][r];
+      }
     }
-  }
 }
 
 // list of the frames that are still iterating (order irrelevant: frames are independent)
@@ -378,7 +411,7 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
                     int64_t ldc, int64_t T, int N, int K, const int* rows, hipStream_t s,
                     bool a_has_slack) {
   if (T <= 0) return ITTS_OK;
-  dim3 grid((unsigned)((T + 63) / 64), (unsigned)((N + 63) / 64));
+  dim3 grid((unsigned)((T + 127) / 128), (unsigned)((N + 63) / 64));
   // the 16-byte loads of A cover k .. k+3: past the end of a row (and of the last row's buffer)
   // unless K is a multiple of 4 or the caller's buffer has that slack
   if (lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (a_has_slack || K % 4 == 0))

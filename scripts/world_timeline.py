@@ -1,6 +1,6 @@
 """Timeline of the LAST WORLD analysis pass found in a rocprofv3 kernel trace (csv): span, time with
 at least one kernel running, per-kernel totals inside the window.
-usage: python3 scripts/world_timeline.py <dir with *kernel_trace.csv>"""
+usage: python3 scripts/world_timeline.py <dir with *kernel_trace.csv> [true|false [pass index]]"""
 import collections
 import csv
 import glob
@@ -25,6 +25,8 @@ for q in passes:
 # the pass looked at: the last one of the requested kind (argv[2]: "true" / "false" = d4c_kernel<...>)
 kind = "d4c_kernel<%s>" % (sys.argv[2] if len(sys.argv) > 2 else "true")
 p = [q for q in passes if any(kind in r[2] for r in q)][-1]
+if len(sys.argv) > 3:
+    p = passes[int(sys.argv[3])]
 t0, t1 = p[0][0], max(r[1] for r in p)
 ev = sorted([(r[0], 1) for r in p] + [(r[1], -1) for r in p])
 busy, depth, last = 0, 0, t0
