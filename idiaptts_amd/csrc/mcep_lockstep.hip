@@ -13,6 +13,7 @@
 // step per round; converged frames are frozen by a flag and skipped by the per-frame kernels.
 // The arithmetic per frame is the same as in mcep_frame up to summation order (<= 1e-15 rel.).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "context.h"
@@ -26,8 +27,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // C[rows, N] = A[rows, K] . B[K, N]; all row-major f64. Workgroup: 128 rows x 64 cols, wave: 32 x 64
 // (two 16-row blocks share every B value a lane loads: B is 80 % of a wave's operand bytes), the
 // operands of K chunk s + 1 are requested before the products of chunk s (two register sets used
-// alternately).  The first version -- 16 rows per wave, load / wait / multiply per chunk -- ran at
-// 27 % of the fp64 MFMA rate.
+// alternately).  Used for short K and small row counts; long K: gemm_f64_staged_kernel below.
 // `rows` (optional) lists the physical row of every logical row: the Newton rounds only touch the
 // frames that have not converged yet.  VEC_A: a lane's four consecutive k of a chunk come as two
 // 16-byte loads (needs an even lda and a 16-byte aligned base; rows may be read up to 3 doubles
@@ -121,6 +121,144 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
       multiply(ob);
     }
   }
+  // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = r0 + 16 * h + kg + 4 * r;
+      if (orow >= T) continue;
+      const int64_t prow_o = rows ? rows[orow] : orow;
+      double* crow = C + prow_o * ldc + cb;
+      if (cfull) {
+        *reinterpret_cast<f64x4*>(crow) = (f64x4){acc[h][0][r], acc[h][1][r], acc[h][2][r], acc[h][3][r]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (cb + q < N) crow[q] = acc[h][q][r];
+      }
+    }
+}
+
+// The same product for long K (the [T x 513] operands of the mel-cepstrum: 1.3 GB per launch), staged:
+// a stage is 64 k.  Every wave requests the A values of the whole NEXT stage (32 rows x 64 k = 16 KB)
+// before it multiplies the current one, and B goes through LDS (two 32 KB stage buffers, filled by
+// the workgroup) so that the products wait for LDS only (the loads in flight all count on vmcnt,
+// which completes in order: a B value fetched just in time would wait for the whole A prefetch).
+// Zeros for k >= K / rows >= T / columns >= N are put in where the values are USED: a select right
+// behind a load waits for the load there and then.  Same K permutation and order of accumulation as
+// above: bit-identical results.  Measured (314 881 rows, K = 513): 0.75 ms at N = 60, 1.2 ms at
+// N = 119, i.e. 28 - 36 of the 77.6 TFLOP/s scripts/handoff_lab/mfma_f64_rate.hip reaches with the
+// same instruction, and 1.8 - 2.2 TB/s of A: the kernel above (one 16-k chunk per wave in flight) took
+// 0.86 / 1.5 ms.  What holds it now is the request pattern of A (a lane fetches 2 x 16 bytes of its
+// own row: every 128-byte line is asked for by two instructions, four lanes each); loading whole
+// lines and transposing through LDS is the next step.
+template <bool VEC_A>
+__global__ __launch_bounds__(256) void gemm_f64_staged_kernel(const double* __restrict__ A, int64_t lda,
+                                                              const double* __restrict__ Bm, int64_t ldb,
+                                                              double* __restrict__ C, int64_t ldc, int64_t T,
+                                                              int N, int K, const int* __restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  double* Bs = reinterpret_cast<double*>(gsm);          // [2][64 k][64 cols]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 128 + wv * 32;
+  const int c0 = blockIdx.y * 64;
+  bool rok[2];
+  const double* ap[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t row = r0 + 16 * h + lr;
+    rok[h] = row < T;
+    const int64_t prow = rok[h] ? (rows ? rows[row] : row) : 0;
+    ap[h] = A + prow * lda;
+  }
+  f64x4 acc[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[h][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  struct AOps { double av[4][2][4]; };      // [chunk of the stage][row block][j]
+  // The loads deliver RAW values (clamped addresses); zeros for k >= K / rows >= T / columns >= N are put
+  // in where the values are used: a select right behind a load would wait for the load there and then,
+  // and nothing would be in flight during the products.
+  auto load_a = [&](int ks, AOps& o) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k0 = ks + 16 * c + 4 * kg;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (VEC_A) {
+          const double2* p2 = reinterpret_cast<const double2*>(ap[h] + (k0 < K ? k0 : 0));
+          const double2 v0 = p2[0], v1 = p2[1];
+          o.av[c][h][0] = v0.x; o.av[c][h][1] = v0.y; o.av[c][h][2] = v1.x; o.av[c][h][3] = v1.y;
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) o.av[c][h][jj] = ap[h][k0 + jj < K ? k0 + jj : 0];
+        }
+      }
+    }
+  };
+  // B stage [64 k][64 cols]: thread t fetches elements t + 256 i (consecutive lanes: consecutive columns)
+  auto load_b = [&](int ks, double (&br)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int k = ks + (idx >> 6), col = c0 + (idx & 63);
+      br[i] = Bm[(k < K && col < N) ? (int64_t)k * ldb + col : 0];
+    }
+  };
+  auto store_b = [&](int buf, int ks, const double (&br)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const bool ok = ks + (idx >> 6) < K && c0 + (idx & 63) < N;
+      Bs[buf * 4096 + idx] = ok ? br[i] : 0.0;
+    }
+  };
+  auto multiply = [&](const AOps& o, int buf, int ks) {
+    const double* bs = Bs + buf * 4096 + 4 * lr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (ks + 16 * c >= K) break;          // the last stage may hold fewer than four chunks
+      f64x4 bv[4];
+      double am[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) am[h][jj] = (rok[h] && ks + 16 * c + 4 * kg + jj < K) ? o.av[c][h][jj] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) bv[jj] = *reinterpret_cast<const f64x4*>(bs + (16 * c + 4 * kg + jj) * 64);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[h][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[h][jj], bv[jj][q], acc[h][q], 0, 0, 0);
+    }
+  };
+  AOps oa, ob;
+  double br[16];
+  load_a(0, oa);
+  load_b(0, br);
+  store_b(0, 0, br);
+  __syncthreads();
+  const int nst = (K + 63) / 64;
+  for (int st = 0; st < nst; st += 2) {
+    // even stage: operands oa, B buffer 0; the next stage goes to ob / buffer 1
+    if (st + 1 < nst) { load_a((st + 1) * 64, ob); load_b((st + 1) * 64, br); }
+    multiply(oa, 0, st * 64);
+    if (st + 1 < nst) store_b(1, (st + 1) * 64, br);
+    __syncthreads();
+    if (st + 1 >= nst) break;
+    if (st + 2 < nst) { load_a((st + 2) * 64, oa); load_b((st + 2) * 64, br); }
+    multiply(ob, 1, (st + 1) * 64);
+    if (st + 2 < nst) store_b(0, (st + 2) * 64, br);
+    __syncthreads();
+  }
+  const int cb = c0 + 4 * lr;
+  const bool cfull = cb + 3 < N;
   // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -414,7 +552,22 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
   dim3 grid((unsigned)((T + 127) / 128), (unsigned)((N + 63) / 64));
   // the 16-byte loads of A cover k .. k+3: past the end of a row (and of the last row's buffer)
   // unless K is a multiple of 4 or the caller's buffer has that slack
-  if (lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (a_has_slack || K % 4 == 0))
+  const bool vec = lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (a_has_slack || K % 4 == 0);
+  static const bool staged_on = [] { const char* e = getenv("ITTS_GEMM_F64_STAGED"); return !(e && e[0] == '0'); }();
+  if (staged_on && K > 64 && T >= 1024) {      // long K, enough rows to fill the chip: the staged kernel
+    static bool attr_set = false;
+    if (!attr_set) {
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_staged_kernel<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_staged_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      attr_set = true;
+    }
+    if (vec)
+      hipLaunchKernelGGL(gemm_f64_staged_kernel<true>, grid, dim3(256), 65536, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
+    else
+      hipLaunchKernelGGL(gemm_f64_staged_kernel<false>, grid, dim3(256), 65536, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
+  } else if (vec)
     hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
   else
     hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
