@@ -197,12 +197,17 @@ struct Stream {
       int rows = out_dim - out0;
       rows = rows < BT ? rows : BT;
       step = RBK * 4;
-      // row >= rows: beyond the descriptor -> zeros
-      rsrc = make_rsrc(P + (int64_t)out0 * ld + c.kbeg, (uint32_t)(((int64_t)rows * ld - c.kbeg) * 4));
+      // row >= rows: beyond the descriptor -> zeros.  The descriptor ends at the LAST VALID ELEMENT (last
+      // row, column kbeg + klen - 1), not at the end of that row's pitch: the operand may be a column
+      // slice of a wider tensor, whose last pitch reaches past the end of the allocation by the
+      // slice's column offset (a fault when the tensor ends where the mapping ends).
+      rsrc = make_rsrc(P + (int64_t)out0 * ld + c.kbeg, (uint32_t)(((int64_t)(rows - 1) * ld + ((c.klen + 3) & ~3)) * 4));
     } else {
       step = (uint32_t)(RBK * ld * 4);
-      // k >= kend: beyond the descriptor -> zeros
-      rsrc = make_rsrc(P + (int64_t)c.kbeg * ld + out0, (uint32_t)(((int64_t)c.klen * ld - out0) * 4));
+      // k >= kend: beyond the descriptor -> zeros; it ends at the last valid element (see above; rounded up
+      // to the 16-byte chunk, which stays inside the row: bases and pitches are multiples of 16 bytes)
+      rsrc = make_rsrc(P + (int64_t)c.kbeg * ld + out0,
+                       (uint32_t)(((int64_t)(c.klen - 1) * ld + ((out_dim - out0 + 3) & ~3)) * 4));
     }
     soff = 0;
   }

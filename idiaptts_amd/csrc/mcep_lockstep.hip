@@ -278,6 +278,141 @@ __global__ __launch_bounds__(256) void gemm_f64_staged_kernel(const double* __re
     }
 }
 
+// Long K with 16-byte aligned rows: A and B both through LDS.  The workgroup fetches the A stage
+// [128 rows x 64 k] as WHOLE rows of 512 bytes (32 lanes x 16 bytes per row: every 128-byte line is
+// asked for once, by one instruction) into registers while it multiplies the stage before, then --
+// behind a barrier -- parks it in LDS (row pitch 66 doubles: the lanes of an MFMA operand read fall
+// on different banks) with the zeros for k >= K / rows >= T filled in.  Same K permutation and order
+// of accumulation as the kernels above: bit-identical results.  Measured: the long-K launches of an
+// analysis 5.1 -> 4.5 ms (0.65 ms at N = 60, 1.05 ms at N = 119 for 314 881 rows: 33 - 40 TFLOP/s).
+// Serving A from L2 (a test with 1 024 distinct rows) does not change the time, nor does the bank
+// spread of B: a stage takes 7.2 us against 4.1 us of products; where the rest goes is not measured yet.
+constexpr int GA_PITCH = 66;
+// B stage in LDS: the four rows k = 4 g .. 4 g + 3 that one lane group (kg) of an MFMA chunk reads form a
+// block of 4 x 64 doubles + 4 of padding, so that the four lane groups of a read fall on different banks
+constexpr int GB_BLOCK = 4 * 64 + 4;
+constexpr int GEMM_LDS_BYTES = (128 * GA_PITCH + 16 * GB_BLOCK) * 8;
+__global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ Bm, int64_t ldb,
+                                                           double* __restrict__ C, int64_t ldc, int64_t T,
+                                                           int N, int K, const int* __restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  double* As = reinterpret_cast<double*>(gsm);          // [128 rows][GA_PITCH]
+  double* Bs = As + 128 * GA_PITCH;                     // [16 blocks of 4 k][GB_BLOCK]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  // 1-D grid, column tile fastest: the workgroups that share a row block of A run next to each other
+  // (its second reader finds it in L2)
+  const int ny = (N + 63) / 64;
+  const int64_t rw0 = (int64_t)(blockIdx.x / ny) * 128;
+  const int c0 = (int)(blockIdx.x % ny) * 64;
+  // loader role: rows 8 i + (t >> 5), i = 0 .. 15, 16-byte segment t & 31 of the stage's 64 k
+  const int lrow = threadIdx.x >> 5, seg = threadIdx.x & 31;
+  const double* arow[16];
+  unsigned rmask = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t row = rw0 + 8 * i + lrow;
+    const bool ok = row < T;
+    rmask |= ok ? (1u << i) : 0u;
+    arow[i] = A + (ok ? (rows ? rows[row] : row) : 0) * lda;
+  }
+  f64x4 acc[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[h][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double2 ar[16];
+  double br[16];
+  auto load_stage = [&](int ks) {          // raw values from clamped addresses; zeros go in at the LDS write
+    const int k0 = ks + 2 * seg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ar[i] = *reinterpret_cast<const double2*>(arow[i] + (k0 < K ? k0 : 0));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int k = ks + (idx >> 6), col = c0 + (idx & 63);
+      br[i] = Bm[(k < K && col < N) ? (int64_t)k * ldb + col : 0];
+    }
+  };
+  auto park_stage = [&](int ks) {
+    const int k0 = ks + 2 * seg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool rv = (rmask >> i) & 1u;
+      double2 v;
+      v.x = (rv && k0 < K) ? ar[i].x : 0.0;
+      v.y = (rv && k0 + 1 < K) ? ar[i].y : 0.0;
+      *reinterpret_cast<double2*>(As + (8 * i + lrow) * GA_PITCH + 2 * seg) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const bool ok = ks + (idx >> 6) < K && c0 + (idx & 63) < N;
+      Bs[(idx >> 8) * GB_BLOCK + (idx & 255)] = ok ? br[i] : 0.0;
+    }
+  };
+  // (chunk by chunk with a branch each: the straight-line form of the four chunks -- operands of chunk
+  // c + 1 fetched during the products of chunk c -- produced NaNs with this compiler and is not used)
+  auto multiply = [&](int ks) {
+    const double* bs = Bs + kg * GB_BLOCK + 4 * lr;
+    const double* as = As + (32 * wv + lr) * GA_PITCH + 4 * kg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (ks + 16 * c >= K) break;          // the last stage may hold fewer than four chunks
+      f64x4 bv[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) bv[jj] = *reinterpret_cast<const f64x4*>(bs + 4 * c * GB_BLOCK + jj * 64);
+      double am[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double2 v0 = *reinterpret_cast<const double2*>(as + 16 * h * GA_PITCH + 16 * c);
+        const double2 v1 = *reinterpret_cast<const double2*>(as + 16 * h * GA_PITCH + 16 * c + 2);
+        am[h][0] = v0.x; am[h][1] = v0.y; am[h][2] = v1.x; am[h][3] = v1.y;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[h][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[h][jj], bv[jj][q], acc[h][q], 0, 0, 0);
+    }
+  };
+  load_stage(0);
+  park_stage(0);
+  __syncthreads();
+  const int nst = (K + 63) / 64;
+  for (int st = 0; st < nst; ++st) {
+    if (st + 1 < nst) load_stage((st + 1) * 64);
+    multiply(st * 64);
+    if (st + 1 >= nst) break;
+    __syncthreads();                // everybody has read this stage (and the loads above have landed)
+    park_stage((st + 1) * 64);
+    __syncthreads();
+  }
+  const int64_t r0 = rw0 + wv * 32;
+  const int cb = c0 + 4 * lr;
+  const bool cfull = cb + 3 < N;
+  // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = r0 + 16 * h + kg + 4 * r;
+      if (orow >= T) continue;
+      const int64_t prow_o = rows ? rows[orow] : orow;
+      double* crow = C + prow_o * ldc + cb;
+      if (cfull) {
+        *reinterpret_cast<f64x4*>(crow) = (f64x4){acc[h][0][r], acc[h][1][r], acc[h][2][r], acc[h][3][r]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (cb + q < N) crow[q] = acc[h][q][r];
+      }
+    }
+}
+
 // list of the frames that are still iterating (order irrelevant: frames are independent)
 __global__ void mcls_compact_kernel(const int* __restrict__ done, int64_t T, int* __restrict__ rows,
                                     int* __restrict__ count) {
@@ -563,7 +698,16 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
       attr_set = true;
     }
-    if (vec)
+    static const bool lds_on = [] { const char* e = getenv("ITTS_GEMM_F64_LDS"); return !(e && e[0] == '0'); }();
+    if (vec && lds_on) {
+      static bool attr2 = false;
+      if (!attr2) {
+        ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_lds_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        attr2 = true;
+      }
+      hipLaunchKernelGGL(gemm_f64_lds_kernel, dim3(grid.x * grid.y), dim3(256), GEMM_LDS_BYTES, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
+    } else if (vec)
       hipLaunchKernelGGL(gemm_f64_staged_kernel<true>, grid, dim3(256), 65536, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
     else
       hipLaunchKernelGGL(gemm_f64_staged_kernel<false>, grid, dim3(256), 65536, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
