@@ -39,9 +39,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
                                                        int N, int K, const int* __restrict__ rows) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * 128 + wv * 32;
+  // 1-D grid, column tile fastest: the workgroups that share a row block of A run next to each other
+  // (with K = 60 and N = 513 the nine readers of a row block otherwise fetch it from HBM nine times)
+  const int ny = (N + 63) / 64;
+  const int64_t r0 = (int64_t)(blockIdx.x / ny) * 128 + wv * 32;
   if (r0 >= T) return;
-  const int c0 = blockIdx.y * 64;
+  const int c0 = (int)(blockIdx.x % ny) * 64;
   bool rok[2];
   const double* ap[2];
 #pragma unroll
@@ -712,9 +715,9 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
     else
       hipLaunchKernelGGL(gemm_f64_staged_kernel<false>, grid, dim3(256), 65536, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
   } else if (vec)
-    hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
+    hipLaunchKernelGGL(gemm_f64_kernel<true>, dim3(grid.x * grid.y), dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
   else
-    hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
+    hipLaunchKernelGGL(gemm_f64_kernel<false>, dim3(grid.x * grid.y), dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
