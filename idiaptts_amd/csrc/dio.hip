@@ -59,7 +59,8 @@ __global__ __launch_bounds__(NT) void dio_mean_kernel(const double* __restrict__
   const DioUtt u = utts[blockIdx.x];
   const double* xs = x + u.x_off;
   double s = 0.0;
-  for (int i = threadIdx.x; i < u.xl; i += NT) s += xs[i];
+#pragma unroll 8
+  for (int i = threadIdx.x; i < u.xl; i += NT) s += xs[i];      // (unrolled: eight loads in flight, same order of additions)
   s = bsum(s, red);
   if (threadIdx.x == 0) mean[blockIdx.x] = s / (double)(u.xl + 1);
 }
@@ -181,56 +182,114 @@ __global__ __launch_bounds__(NT) void dio_band_kernel(const DioUtt* __restrict__
 }
 
 // ---- zero-crossing events -> compacted "fine" edge positions --------------------------------------
-// grid (4 types, nb, U); one workgroup walks the band signal in order.
-__global__ __launch_bounds__(NT) void dio_events_kernel(const DioUtt* __restrict__ utts, DioParams p,
+// grid (nb, U); one workgroup walks the band signal in order and fills the lists of all four event
+// types from ONE read of it (one workgroup per type read the 1.4 GB of band signals four times: the
+// kernel ran at HBM speed, 2.4 ms per analysis).  The walk is sequential per signal, so its time is the
+// number of trips of the longest utterance times the latency of a trip: 512 threads and ER chunks
+// of ET samples per trip, all their loads in flight together, one barrier per trip; the running edge counts live in every thread's registers,
+// the per-wave counts alternate between two LDS buffers.
+// v(i): type 0: s[i]; 1: -s[i]; 2: s[i+1]-s[i] (written as WORLD does: (-s[i]) - (-s[i+1])); 3: its negation
+constexpr int ET = 512;       // threads of an events workgroup (1 024 leave 128 registers per thread: spills)
+__global__ __launch_bounds__(ET) void dio_events_kernel(const DioUtt* __restrict__ utts, DioParams p,
                                                         const double* __restrict__ sig,
                                                         double* __restrict__ fine,
                                                         int* __restrict__ counts) {
-  __shared__ int wcnt[4];
-  __shared__ int base_s;
-  const int type = blockIdx.x, b = blockIdx.y;
-  const DioUtt u = utts[blockIdx.z];
+  constexpr int ER = 4, EW = ET / 64;
+  constexpr int SCAP = 512;                // edges of one type staged per trip (more: computed in place)
+  // per-wave edge counts of the four types packed into one word, 16 bits each (a trip has at most
+  // ER * ET = 4 096 samples): one prefix over the waves serves all four types
+  __shared__ unsigned long long wpk[2][ER][EW];      // [buffer][chunk][wave]
+  __shared__ double2 stage_ac[4][SCAP];    // (a, c) of the trip's edges, compacted, per type
+  __shared__ int stage_e[4][SCAP];
+  const int b = blockIdx.x;
+  const DioUtt u = utts[blockIdx.y];
   const int yl = u.xl + 1;
   const double* s = sig + u.sig_off + (int64_t)b * yl;
-  double* out = fine + u.fine_off + (int64_t)(b * 4 + type) * u.cap;
-  const int n = (type < 2) ? yl : yl - 1;  // length of the analysed sequence
-  // v(i): type 0: s[i]; 1: -s[i]; 2: s[i+1]-s[i]; 3: -(s[i+1]-s[i])
-  auto val = [&](int i) -> double {
-    switch (type) {
-      case 0: return s[i];
-      case 1: return -s[i];
-      case 2: return (-s[i]) - (-s[i + 1]);
-      default: return -((-s[i]) - (-s[i + 1]));
-    }
-  };
-  if (threadIdx.x == 0) base_s = 0;
-  __syncthreads();
+  double* out0 = fine + u.fine_off + (int64_t)(b * 4) * u.cap;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i0 = 0; i0 < n - 1; i0 += NT) {
-    const int i = i0 + threadIdx.x;
-    bool edge = false;
-    double a = 0.0, c = 0.0;
-    if (i < n - 1) {
-      a = val(i);
-      c = val(i + 1);
-      edge = (a > 0.0) && (c <= 0.0);
+  int base[4] = {0, 0, 0, 0};
+  // types 0 / 1 look at i < yl - 1, types 2 / 3 (differences) at i < yl - 2
+  for (int i0 = 0, it = 0; i0 < yl - 1; i0 += ER * ET, ++it) {
+    double a[ER][2], c[ER][2];           // [chunk][0: the signal, 1: the differences] of type 0 / 2 (1 / 3: negated)
+#pragma unroll
+    for (int r = 0; r < ER; ++r) {
+      const int i = i0 + r * ET + threadIdx.x;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      if (i < yl - 1) { s0 = s[i]; s1 = s[i + 1]; }
+      if (i < yl - 2) s2 = s[i + 2];
+      a[r][0] = s0; c[r][0] = s1;
+      a[r][1] = (-s0) - (-s1); c[r][1] = (-s1) - (-s2);
     }
-    const unsigned long long bal = __ballot(edge);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wcnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = base_s;
-    for (int q = 0; q < wv; ++q) off += wcnt[q];
-    if (edge) {
-      const int e = i + 1;
-      const int slot = off + before;
-      if (slot < u.cap) out[slot] = (double)e - a / (c - a);
+    bool edge[ER][4];
+    int before[ER][4];
+#pragma unroll
+    for (int r = 0; r < ER; ++r) {
+      const int i = i0 + r * ET + threadIdx.x;
+      unsigned long long pk = 0;
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) {
+        const bool in = i < (ty < 2 ? yl - 1 : yl - 2);
+        const double av = (ty & 1) ? -a[r][ty >> 1] : a[r][ty >> 1];
+        const double cv = (ty & 1) ? -c[r][ty >> 1] : c[r][ty >> 1];
+        edge[r][ty] = in && (av > 0.0) && (cv <= 0.0);
+        const unsigned long long bal = __ballot(edge[r][ty]);
+        before[r][ty] = __popcll(bal & ((1ull << lane) - 1ull));
+        pk |= (unsigned long long)__popcll(bal) << (16 * ty);
+      }
+      if (lane == 0) wpk[it & 1][r][wv] = pk;
     }
     __syncthreads();
-    if (threadIdx.x == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    // The interpolation e - a / (c - a) is NOT evaluated where the edge was found (an fp64 division in
+    // sixteen branches that nearly every wave enters for a handful of lanes): the trip's edges are
+    // compacted into LDS and divided by dense lanes afterwards.
+    unsigned long long run = 0;          // edges of the trip's chunks before r, four 16-bit fields
+    int sl[ER][4];
+#pragma unroll
+    for (int r = 0; r < ER; ++r) {
+      const unsigned long long* w = wpk[it & 1][r];
+      unsigned long long off = run, tot = 0;
+#pragma unroll
+      for (int q = 0; q < EW; ++q) {
+        const unsigned long long v = w[q];
+        off += q < wv ? v : 0ull;
+        tot += v;
+      }
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) sl[r][ty] = (int)((off >> (16 * ty)) & 0xffffull) + before[r][ty];
+      run += tot;
+    }
+    int trip[4];
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      trip[ty] = (int)((run >> (16 * ty)) & 0xffffull);
+#pragma unroll
+      for (int r = 0; r < ER; ++r) {
+        if (edge[r][ty]) {
+          const double av = (ty & 1) ? -a[r][ty >> 1] : a[r][ty >> 1];
+          const double cv = (ty & 1) ? -c[r][ty >> 1] : c[r][ty >> 1];
+          const int e = i0 + r * ET + threadIdx.x + 1;
+          const int sp = sl[r][ty];                     // position among this trip's edges of the type
+          if (sp < SCAP) {
+            stage_ac[ty][sp] = make_double2(av, cv);
+            stage_e[ty][sp] = e;
+          } else if (base[ty] + sp < u.cap) {           // beyond the staging area: in place
+            out0[(int64_t)ty * u.cap + base[ty] + sp] = (double)e - av / (cv - av);
+          }
+        }
+      }
+    }
     __syncthreads();
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      const int nst = trip[ty] < SCAP ? trip[ty] : SCAP;
+      if ((int)threadIdx.x < nst && base[ty] + (int)threadIdx.x < u.cap) {
+        const double2 ac = stage_ac[ty][threadIdx.x];
+        out0[(int64_t)ty * u.cap + base[ty] + threadIdx.x] = (double)stage_e[ty][threadIdx.x] - ac.x / (ac.y - ac.x);
+      }
+      base[ty] += trip[ty];
+    }
   }
-  if (threadIdx.x == 0) counts[u.cnt_off + b * 4 + type] = base_s;
+  if (threadIdx.x < 4) counts[u.cnt_off + b * 4 + threadIdx.x] = base[threadIdx.x];
 }
 
 // ---- per (band, frame) candidate and score ----------------------------------------------------------
@@ -558,7 +617,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
                          d_utts, d_lpf, d_lpf_off, p, d_ylc, d_sig);
       ITTS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(dio_events_kernel, dim3(4, p.nb, U), dim3(NT), 0, s, d_utts, p, d_sig, d_fine, d_cnt);
+    hipLaunchKernelGGL(dio_events_kernel, dim3(p.nb, U), dim3(ET), 0, s, d_utts, p, d_sig, d_fine, d_cnt);
     ITTS_LAUNCH_CHECK();
     hipLaunchKernelGGL(dio_candidates_kernel, dim3((max_T + NT - 1) / NT, p.nb, U), dim3(NT), 0, s, d_utts,
                        p, d_fine, d_cnt, d_cand, d_score);
