@@ -359,3 +359,21 @@ def test_deferred_reductions_equal_the_separate_launches_bit_for_bit(gpu):
     torch.cuda.synchronize()
     assert torch.equal(loss_d, loss_i) and torch.equal(grads_d, model.grads)
     assert float(loss_d) > 0
+
+
+def test_gemm_operands_that_end_where_their_mapping_ends(gpu):
+    """Column slices of a [4096 x 128] float tensor that is its own 2 MiB allocation as operands of
+    the weight-gradient GEMM (what the recurrent layers pass: dG[:, d * 4H:], h_prev[:, d * H:]): the
+    ring kernel's operand descriptors must end at the last valid element -- ending at the last
+    row's pitch they reached past the allocation by the slice's column offset and the launch died
+    with a memory access fault.  Child process: the allocator has to be switched to one hipMalloc per
+    tensor before torch starts, and a regression kills the process."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts",
+                          "desc_end_of_mapping.py")
+    env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1")
+    res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
