@@ -5,6 +5,7 @@
 // remain for other sizes and as the fallback).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 
 #include "context.h"
@@ -337,6 +338,27 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
 // once, which nobody can promise (another process may hold CUs): every wait carries a budget, the
 // launch is followed by a read-back of the abort flag, and a launch that gave up switches the
 // persistent path off for the rest of the process.
+// Read-back of a launch's abort flag: the copy is queued behind the kernel, and the host spins on the
+// page-locked word it lands in instead of blocking in hipStreamSynchronize (which wakes up tens of
+// microseconds after the event: six such waits per training step); 0.2 s without the word changing
+// and it blocks after all.  Returns the flag, or -1 on a runtime error.
+static int persist_read_flag(int64_t* slot, const int* d_flag, hipStream_t s) {
+  volatile int* w = reinterpret_cast<volatile int*>(slot);
+  constexpr int kPending = 0x7fffffff;
+  w[0] = kPending;
+  if (hipMemcpyAsync(slot, d_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; w[0] == kPending; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0xffff) == 0xffff &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.2) {
+      if (hipStreamSynchronize(s) != hipSuccess) return -1;
+      break;
+    }
+  }
+  return w[0] == kPending ? -1 : w[0];
+}
+
 template <int G>
 static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   static std::atomic<bool> usable{true};
@@ -375,12 +397,10 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
     hipLaunchKernelGGL(rnn_persist_fwd_kernel<G>, dim3(256), dim3(256), persist_lds_bytes(G), s, p);
     if (hipGetLastError() != hipSuccess) return -1;
   }
-  int64_t* slot = pinned_slot(ctx);
-  *slot = 0;
-  if (hipMemcpyAsync(slot, p.abort_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  const int gave_up = persist_read_flag(pinned_slot(ctx), p.abort_flag, s);
+  if (gave_up < 0) return -1;
   if (itts::scratch_free(blk, s) != hipSuccess) return -1;
-  if ((int)*slot == 0) return 1;
+  if (gave_up == 0) return 1;
   usable.store(false);
   fprintf(stderr, "libidiaptts_amd: the persistent recurrence gave up waiting (are all 256 CUs available to "
                   "this process?); using the per-step kernels from now on\n");
@@ -691,12 +711,10 @@ static int rnn_persist_backward(RnnPersistBwdArgs p, const int* h_lengths, int H
     hipLaunchKernelGGL(rnn_persist_bwd_kernel<G>, dim3(256), dim3(256), persist_bwd_lds_bytes(G), s, p);
     if (hipGetLastError() != hipSuccess) return -1;
   }
-  int64_t* slot = pinned_slot(ctx);
-  *slot = 0;
-  if (hipMemcpyAsync(slot, p.abort_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  const int gave_up = persist_read_flag(pinned_slot(ctx), p.abort_flag, s);
+  if (gave_up < 0) return -1;
   if (itts::scratch_free(blk, s) != hipSuccess) return -1;
-  if ((int)*slot == 0) return 1;
+  if (gave_up == 0) return 1;
   usable.store(false);
   fprintf(stderr, "libidiaptts_amd: the persistent backward recurrence gave up waiting; using the per-step "
                   "kernels from now on\n");
