@@ -2,6 +2,8 @@
 device memory and streams; every forward / backward computation below is a C-ABI call)."""
 import ctypes
 
+import collections
+
 import torch
 
 from .. import lib as _lib
@@ -49,6 +51,27 @@ class PackedBatch(object):
     row b = row_off[t] + b.  `flat_index` maps every packed row to its row in the padded tensor
     flattened over (time, batch) -- or (batch, time) when batch_first -- so packing is one
     index_select and unpacking one index_copy."""
+
+    _cache = collections.OrderedDict()      # (lengths, padded_time, batch_first, device) -> instance
+    _cache_max = 16
+
+    @classmethod
+    def get(cls, lengths, padded_time, batch_first, device):
+        """The bookkeeping of a batch whose lengths were seen recently is reused (its tables are ~1 ms of
+        numpy and eight small uploads during which the GPU has nothing to do: validation passes and
+        trainers that keep their batches fixed over the epochs meet the same length vectors again)."""
+        import numpy as np
+        lens = np.asarray(torch.as_tensor(lengths).cpu(), dtype=np.int64)
+        key = (lens.tobytes(), int(padded_time), bool(batch_first), str(device))
+        pb = cls._cache.get(key)
+        if pb is None:
+            pb = cls(lens, padded_time, batch_first, device)
+            cls._cache[key] = pb
+            while len(cls._cache) > cls._cache_max:
+                cls._cache.popitem(last=False)
+        else:
+            cls._cache.move_to_end(key)
+        return pb
 
     def __init__(self, lengths, padded_time, batch_first, device):
         import numpy as np

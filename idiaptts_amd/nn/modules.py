@@ -98,7 +98,7 @@ class LSTM(nn.Module):
         if lengths is None:
             lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
         # pack once (valid frames only, rows sorted by length), run all layers on packed rows
-        pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
+        pb = PackedBatch.get(lengths, input_.shape[time_dim], self.batch_first, input_.device)
         x = pb.pack(input_)
         h0 = c0 = None
         if hx is not None:
@@ -164,7 +164,7 @@ class GRU(nn.Module):
         time_dim, batch_dim = (1, 0) if self.batch_first else (0, 1)
         if lengths is None:
             lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
-        pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
+        pb = PackedBatch.get(lengths, input_.shape[time_dim], self.batch_first, input_.device)
         x = pb.pack(input_)
         _shared_initial_state(hx)
         hn_all = []
@@ -260,7 +260,7 @@ class RNN(nn.Module):
         time_dim, batch_dim = (1, 0) if self.batch_first else (0, 1)
         if lengths is None:
             lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
-        pb = PackedBatch(lengths, input_.shape[time_dim], self.batch_first, input_.device)
+        pb = PackedBatch.get(lengths, input_.shape[time_dim], self.batch_first, input_.device)
         x = pb.pack(input_)
         hn_all = []
         for layer in range(self.num_layers):
