@@ -27,7 +27,15 @@ print("LSTM window: %.1f steps, span %.2f ms (%.2f per step), some kernel runnin
 gaps.sort(reverse=True)
 print("gaps > 20 us: %d, sum %.2f ms; largest (us):" % (len(gaps), sum(g for g, _ in gaps) / 1e6), [round(g / 1e3) for g, _ in gaps[:12]])
 # what runs right after the largest gaps
-for g, at in gaps[:6]:
+import collections
+by = collections.defaultdict(lambda: [0, 0])
+for g, at in gaps:
+    if g > 5e6:
+        continue                      # set-up between the sections, not part of a step
     nxt = next(r for r in seg if r[0] >= at + g - 1)
     prv = max((r for r in seg if r[1] <= at + 1), key=lambda r: r[1])
-    print("  %5d us between %s and %s" % (g / 1e3, prv[2], nxt[2]))
+    k = prv[2][-26:] + " -> " + nxt[2][-26:]
+    by[k][0] += g
+    by[k][1] += 1
+for k, (ns, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:14]:
+    print("  %7.2f ms in %3d gaps: %s" % (ns / 1e6, n, k))
