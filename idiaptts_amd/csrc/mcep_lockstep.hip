@@ -327,16 +327,16 @@ __global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restr
     for (int q = 0; q < 4; ++q) acc[h][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
   double2 ar[16];
   double br[16];
-  auto load_stage = [&](int ks) {          // raw values from clamped addresses; zeros go in at the LDS write
+  auto load_piece = [&](int ks, int g) {
     const int k0 = ks + 2 * seg;
+    ar[g] = *reinterpret_cast<const double2*>(arow[g] + (k0 < K ? k0 : 0));
+    const int idx = threadIdx.x + 256 * g;
+    const int k = ks + (idx >> 6), col = c0 + (idx & 63);
+    br[g] = Bm[(k < K && col < N) ? (int64_t)k * ldb + col : 0];
+  };
+  auto load_stage = [&](int ks) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ar[i] = *reinterpret_cast<const double2*>(arow[i] + (k0 < K ? k0 : 0));
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int k = ks + (idx >> 6), col = c0 + (idx & 63);
-      br[i] = Bm[(k < K && col < N) ? (int64_t)k * ldb + col : 0];
-    }
+    for (int g = 0; g < 16; ++g) load_piece(ks, g);
   };
   auto park_stage = [&](int ks) {
     const int k0 = ks + 2 * seg;
@@ -355,9 +355,12 @@ __global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restr
       Bs[(idx >> 8) * GB_BLOCK + (idx & 255)] = ok ? br[i] : 0.0;
     }
   };
-  // (chunk by chunk with a branch each: the straight-line form of the four chunks -- operands of chunk
-  // c + 1 fetched during the products of chunk c -- produced NaNs with this compiler and is not used)
-  auto multiply = [&](int ks) {
+  // Chunk by chunk with a branch each; pf: the 32 requests of the NEXT stage go out in four groups, one
+  // behind each chunk's products (issued in one go in front of the products they took 1.2 - 2.5 us per
+  // stage -- in-kernel stamps -- during which the matrix unit had nothing to do).  Two finer forms --
+  // the four chunks as straight-line code, and two requests behind every eight products pinned by
+  // sched_barrier -- produced NaNs in a few frames with this compiler (not understood) and are not used.
+  auto multiply = [&](int ks, bool pf) {
     const double* bs = Bs + kg * GB_BLOCK + 4 * lr;
     const double* as = As + (32 * wv + lr) * GA_PITCH + 4 * kg;
 #pragma unroll
@@ -380,6 +383,10 @@ __global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restr
 #pragma unroll
           for (int h = 0; h < 2; ++h)
             acc[h][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[h][jj], bv[jj][q], acc[h][q], 0, 0, 0);
+      if (pf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_piece(ks + 64, 4 * c + g);
+      }
     }
   };
   load_stage(0);
@@ -387,8 +394,7 @@ __global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restr
   __syncthreads();
   const int nst = (K + 63) / 64;
   for (int st = 0; st < nst; ++st) {
-    if (st + 1 < nst) load_stage((st + 1) * 64);
-    multiply(st * 64);
+    multiply(st * 64, st + 1 < nst);
     if (st + 1 >= nst) break;
     __syncthreads();                // everybody has read this stage (and the loads above have landed)
     park_stage((st + 1) * 64);
