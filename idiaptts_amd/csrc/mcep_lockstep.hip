@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
   const bool cfull = cb + 3 < N;               // all four columns inside the matrix
   struct Ops { double av[2][4]; double bv[4][4]; };
   // K permutation: lane (lr, kg) supplies k = 16 s + 4 kg + j on MFMA j of chunk s
+  // The loads deliver RAW values from clamped addresses; the zeros for k >= K, rows >= T and columns >= N
+  // are put in where the values are used (a select right behind a load waits for the load there and then:
+  // with the selects in here the chunk requested ahead was waited for before the products started).
   auto load = [&](int s, Ops& o) {
     if (VEC_A) {
       const int k0 = s + 4 * kg;
@@ -73,55 +76,51 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
       for (int h = 0; h < 2; ++h) {
         const double2* p2 = reinterpret_cast<const double2*>(ap[h] + (k0 < K ? k0 : 0));
         const double2 v0 = p2[0], v1 = p2[1];
-        o.av[h][0] = (rok[h] && k0 < K) ? v0.x : 0.0;
-        o.av[h][1] = (rok[h] && k0 + 1 < K) ? v0.y : 0.0;
-        o.av[h][2] = (rok[h] && k0 + 2 < K) ? v1.x : 0.0;
-        o.av[h][3] = (rok[h] && k0 + 3 < K) ? v1.y : 0.0;
+        o.av[h][0] = v0.x; o.av[h][1] = v0.y; o.av[h][2] = v1.x; o.av[h][3] = v1.y;
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = s + 4 * kg + j;
-      const bool kok = k < K;
-      const int kc = kok ? k : 0;
+      const int kc = k < K ? k : 0;
       if (!VEC_A) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const double a = ap[h][kc];
-          o.av[h][j] = (kok && rok[h]) ? a : 0.0;
-        }
+        for (int h = 0; h < 2; ++h) o.av[h][j] = ap[h][kc];
       }
       const double* brow = Bm + (int64_t)kc * ldb;
       if (cfull) {
         const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb);   // global: dword alignment suffices
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o.bv[j][q] = kok ? b4[q] : 0.0;
+        for (int q = 0; q < 4; ++q) o.bv[j][q] = b4[q];
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double b = brow[cb + q < N ? cb + q : 0];
-          o.bv[j][q] = (kok && cb + q < N) ? b : 0.0;
-        }
+        for (int q = 0; q < 4; ++q) o.bv[j][q] = brow[cb + q < N ? cb + q : 0];
       }
     }
   };
-  auto multiply = [&](const Ops& o) {
+  auto multiply = [&](const Ops& o, int s) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const bool kok = s + 4 * kg + j < K;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q) {
+        const double b = (kok && (cfull || cb + q < N)) ? o.bv[j][q] : 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          acc[h][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[h][j], o.bv[j][q], acc[h][q], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+          const double a = (kok && rok[h]) ? o.av[h][j] : 0.0;
+          acc[h][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[h][q], 0, 0, 0);
+        }
+      }
+    }
   };
   Ops oa, ob;
   load(0, oa);
   for (int s = 0; s < K; s += 32) {
     if (s + 16 < K) load(s + 16, ob);
-    multiply(oa);
+    multiply(oa, s);
     if (s + 16 < K) {
       if (s + 32 < K) load(s + 32, oa);
-      multiply(ob);
+      multiply(ob, s + 16);
     }
   }
   // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
