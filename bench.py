@@ -18,6 +18,35 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def usable_cores():
+    """Cores this process may actually run on: the scheduler affinity mask cut down by the cgroup
+    CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us).  os.cpu_count() is the machine's
+    logical CPU count whatever the container was given and is reported beside it, never used."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def _oracle_utterance(args):
     """Pool worker: one synthetic utterance through the C oracle (analysis, then synthesis)."""
     fs, seed, seconds = args
@@ -47,30 +76,40 @@ def _pool_warm(_):
     return os.getpid()
 
 
-def cpu_baseline_world_pool(fs=16000, seconds=4.0, budget_s=40.0):
+def cpu_baseline_world_pool(fs=16000, seconds=3.0, budget_s=40.0, single_core_analysis_rtf=None):
     """the reference's feature extraction is an embarrassingly parallel loop
     over files (WorldFeatLabelGen.py:996); its best case on this host is a pool of single-threaded
-    worker processes.  The figure reported is the best of a sweep over the pool size (all logical
-    CPUs, half, a quarter, ...): workers are started and warmed first, then every worker gets four
-    utterances (C oracle: analysis + synthesis) and the pool's wall time over the pool's audio is
-    taken.  Runs in an interpreter that never loads torch or touches HIP; bounded by budget_s."""
+    worker processes.  The pool sizes are swept SMALLEST FIRST (1, 2, 4, ... up to the usable
+    cores: affinity mask and cgroup quota, not os.cpu_count()) and every point is recorded; a point
+    is only started while the budget lasts (its cost is predicted from the point before it, which
+    had the same work per worker).  Workers are started and warmed first, then every worker gets
+    one utterance of the same length (C oracle: analysis + synthesis) and the pool's wall time over
+    the pool's audio is taken.  Runs in an interpreter that never loads torch or touches HIP."""
     import multiprocessing as mp
     for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         os.environ[var] = "1"
-    n = os.cpu_count() or 1
-    sizes = sorted({n, max(1, n // 2), max(1, n // 4), max(1, min(n, 32))}, reverse=True)
+    n = usable_cores()
+    sizes, p = [], 1
+    while p < n:
+        sizes.append(p)
+        p *= 4
+    sizes = sorted(set(sizes + [max(1, n // 2), n]))
     rng = np.random.default_rng(5)
     sweep, best = [], None
     t_start = time.perf_counter()
+    last_cost = 0.0
     for p in sizes:
-        if sweep and time.perf_counter() - t_start > budget_s:
+        left = budget_s - (time.perf_counter() - t_start)
+        if sweep and left < 1.3 * last_cost:
             break
-        jobs = [(fs, 7000 + i, float(seconds * rng.uniform(0.8, 1.2))) for i in range(4 * p)]
+        t_point = time.perf_counter()
+        jobs = [(fs, 7000 + i, float(seconds)) for i in range(p)]
         with mp.get_context("fork").Pool(p) as pool:
             pool.map(_pool_warm, range(p), chunksize=1)
             t0 = time.perf_counter()
             res = pool.map(_oracle_utterance, jobs, chunksize=1)
             wall = time.perf_counter() - t0
+        last_cost = time.perf_counter() - t_point
         audio = sum(r[0] for r in res)
         row = {"processes": p, "utterances": len(jobs), "audio_s": audio, "wall_s": wall,
                "analysis_plus_synthesis_rtf": wall / audio,
@@ -79,18 +118,27 @@ def cpu_baseline_world_pool(fs=16000, seconds=4.0, budget_s=40.0):
         sweep.append(row)
         if best is None or row["analysis_plus_synthesis_rtf"] < best["analysis_plus_synthesis_rtf"]:
             best = row
+    one = single_core_analysis_rtf or sweep[0]["per_core_analysis_rtf"]
+    degr = best["per_core_analysis_rtf"] / one
     out = {"kind": "port", "cores": best["processes"], "processes": best["processes"],
-           "logical_cpus": n,
-           "sample": "best of a sweep over the pool size: {} single-threaded worker processes, {} "
-                     "utterances ({:.0f} s of audio, four per worker), C oracle analysis + synthesis, "
-                     "workers started and warmed before the clock".format(
-                         best["processes"], best["utterances"], best["audio_s"]),
+           "usable_cores": n, "logical_cpus": os.cpu_count(),
+           "sample": "best of a sweep over the pool size (smallest first, {} points: {}): {} "
+                     "single-threaded worker processes, {} utterances ({:.0f} s of audio, one per "
+                     "worker), C oracle analysis + synthesis, workers started and warmed before the "
+                     "clock".format(len(sweep), [r["processes"] for r in sweep], best["processes"],
+                                    best["utterances"], best["audio_s"]),
            "analysis_plus_synthesis_rtf": best["analysis_plus_synthesis_rtf"],
            "per_core_analysis_rtf": best["per_core_analysis_rtf"],
            "per_core_synthesis_rtf": best["per_core_synthesis_rtf"],
+           "per_worker_slowdown_vs_one_core": degr,
+           "sweep_complete": len(sweep) == len(sizes),
            "sweep": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in sweep]}
+    if degr > 1.5:
+        out["warning"] = ("a worker of the best pool ran {:.1f}x slower than the same code alone on one "
+                          "core: the pool is limited by shared resources of the host (memory bandwidth, "
+                          "SMT siblings, or fewer real cores than the affinity mask shows), not by the "
+                          "code".format(degr))
     return out
-
 
 
 if __name__ == "__main__" and "--cpu-pool-worker" in sys.argv:
@@ -98,7 +146,9 @@ if __name__ == "__main__" and "--cpu-pool-worker" in sys.argv:
     # loads torch or touches HIP (forking 256 workers out of the benchmark process itself, before
     # its GPU sections, slowed the launch-bound BiGRU section by 10 %)
     _a = sys.argv[sys.argv.index("--cpu-pool-worker") + 1:]
-    print(json.dumps(cpu_baseline_world_pool(int(_a[0]), budget_s=float(_a[1]) if len(_a) > 1 else 40.0)))
+    print(json.dumps(cpu_baseline_world_pool(
+        int(_a[0]), budget_s=float(_a[1]) if len(_a) > 1 else 40.0,
+        single_core_analysis_rtf=float(_a[2]) if len(_a) > 2 and float(_a[2]) > 0 else None)))
     sys.exit(0)
 
 import torch  # noqa: E402
@@ -116,27 +166,32 @@ def host_info():
             model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return {"cpu_model": model, "logical_cpus": os.cpu_count()}
+    return {"cpu_model": model, "usable_cores": usable_cores(), "logical_cpus": os.cpu_count()}
 
 
-def cpu_baseline_bilstm(n_utts=4, max_seconds=20.0):
+def cpu_baseline_bilstm(max_seconds=25.0, threads=None):
     """The reference's config-3 stack on the host: torch.nn.LSTM(425, 512, 3, bidirectional) on a
     PackedSequence (rnn_dyn/RNNWrapper.py:45-107) + Linear(1024, 187), masked MSE mean_per_frame,
-    Adam; a bounded sample (a few steps on a small padded batch)."""
+    Adam.  Bounded sample: one training step on 16 of config 3's 64 padded utterances (after a
+    warm-up step on two); if four times that step fits what is left of the budget, one step on the
+    full 64-utterance batch is run and reported instead.  The sample says which."""
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     from idiaptts_amd.bench_support import make_ff_batch, pad_batch
     torch.manual_seed(0)
     lstm = torch.nn.LSTM(425, 512, 3, bidirectional=True)
     fc = torch.nn.Linear(1024, 187)
     opt = torch.optim.Adam(list(lstm.parameters()) + list(fc.parameters()), lr=1e-3)
-    x, y, lengths = make_ff_batch(n_utts, seed=7)
-    lt = torch.from_numpy(lengths)
-    xp, yp = pad_batch(x, lt).transpose(0, 1).contiguous(), pad_batch(y, lt).transpose(0, 1).contiguous()
-    T = xp.shape[0]
-    mask = (torch.arange(T)[:, None] < lt[None, :]).unsqueeze(-1).float()
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(threads or min(usable_cores(), 32))
+    x, y, lengths = make_ff_batch(64, seed=7)       # the batch of the GPU section
+    offs = np.concatenate([[0], np.cumsum(lengths)])
 
-    def step():
+    def step(n_utts):
+        lt = torch.from_numpy(lengths[:n_utts])
+        xs, ys = x[:offs[n_utts]], y[:offs[n_utts]]
+        xp, yp = pad_batch(xs, lt).transpose(0, 1).contiguous(), pad_batch(ys, lt).transpose(0, 1).contiguous()
+        T = xp.shape[0]
+        mask = (torch.arange(T)[:, None] < lt[None, :]).unsqueeze(-1).float()
+        t = time.perf_counter()
         out, _ = lstm(pack_padded_sequence(xp, lt, enforce_sorted=False))
         out, _ = pad_packed_sequence(out, total_length=T)
         pred = fc(out)
@@ -144,18 +199,23 @@ def cpu_baseline_bilstm(n_utts=4, max_seconds=20.0):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        return time.perf_counter() - t, int(lt.sum())
 
-    step()
-    t0 = time.perf_counter()
-    steps = 0
-    while steps < 3 and time.perf_counter() - t0 < max_seconds:
-        step()
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"kind": "port", "cores": torch.get_num_threads(), "value": float(lengths.sum()) * steps / dt,
-            "unit": "valid frames/s",
-            "sample": "{} training steps of torch.nn.LSTM(425,512,3,bidirectional)+Linear on {} "
-                      "padded utterances ({} valid frames)".format(steps, n_utts, int(lengths.sum()))}
+    t_start = time.perf_counter()
+    step(2)
+    dt, frames = step(16)
+    n_used = 16
+    if 4.2 * dt < max_seconds - (time.perf_counter() - t_start):
+        dt, frames = step(64)
+        n_used = 64
+    note = "config 3's full batch" if n_used == 64 else \
+        ("16 of config 3's 64 utterances: the full batch was predicted at {:.0f} s, beyond the budget; the "
+         "host's cost is linear in the frames (same T, a quarter of the rows per step), so the rate "
+         "stands for the full batch to within the GEMMs' batch efficiency".format(4 * dt))
+    return {"kind": "port", "cores": torch.get_num_threads(), "value": frames / dt,
+            "unit": "valid frames/s", "utterances": n_used,
+            "sample": "1 training step of torch.nn.LSTM(425,512,3,bidirectional)+Linear on {} padded "
+                      "utterances ({} valid frames, {:.1f} s; {})".format(n_used, frames, dt, note)}
 
 
 def hip_event_time_ms(fn, stream, iters):
@@ -206,7 +266,7 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
     batch exactly like process_dataloader; bounded sample."""
     from idiaptts_amd.bench_support import (TorchRefFF, make_ff_batch, pad_batch, torch_ref_step)
     from idiaptts_amd.native_ff import FlatFFModel
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cores()
     dims, acts = (425, 512, 512, 187), ("tanh", "tanh", None)
     ref = TorchRefFF(FlatFFModel.reference_init(dims, 0), acts)
     opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
@@ -215,13 +275,15 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
     xp, yp = pad_batch(x, lt), pad_batch(y, lt)
     # torch's intra-op pool over-subscribes badly with all hardware threads of a big host:
     # take the best of a short sweep (one step each) as the baseline's thread count.
-    best, cores = None, ncpu
-    for nt in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32), min(ncpu, 16)}):
+    best, cores, sweep = None, ncpu, []
+    for nt in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 64), min(ncpu, 32),
+                      min(ncpu, 16), min(ncpu, 8)}):
         torch.set_num_threads(nt)
         torch_ref_step(ref, opt, xp, yp, lt)  # warm-up for this pool size
         t = time.perf_counter()
         torch_ref_step(ref, opt, xp, yp, lt)
         t = time.perf_counter() - t
+        sweep.append({"threads": nt, "step_s": round(t, 4)})
         if best is None or t < best:
             best, cores = t, nt
     torch.set_num_threads(cores)
@@ -234,7 +296,7 @@ def cpu_baseline_ff(n_utts, max_seconds=20.0):
             break
     dt = time.perf_counter() - t0
     return {"value": float(lengths.sum()) * steps / dt, "unit": "valid frames/s", "cores": cores,
-            "kind": "port",
+            "kind": "port", "thread_sweep": sweep,
             "sample": "{} training steps of the torch-CPU reference stack (nn.Linear/Tanh, masked "
                       "MSE mean_per_frame, Adam) on one {}-utterance padded batch ({} valid "
                       "frames)".format(steps, n_utts, int(lengths.sum()))}
@@ -647,8 +709,9 @@ class SclkSampler:
     sampled every 20 ms by a thread): boxes of the pool sustain different clocks under the fp32-MFMA
     load, and the roofline fraction is quoted against the 2.4 GHz peak."""
 
-    def __init__(self, index=0):
+    def __init__(self, index=0, period_s=0.02):
         import glob
+        self.period_s = period_s
         self.path = None
         self.samples = []
         self._stop = False
@@ -680,7 +743,7 @@ class SclkSampler:
                     v = self._read()
                     if v is not None:
                         self.samples.append(v)
-                    time.sleep(0.02)
+                    time.sleep(self.period_s)
             self._thread = threading.Thread(target=loop, daemon=True)
             self._thread.start()
         return self
@@ -749,6 +812,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--utts-per-gpu", type=int, default=32)
+    ap.add_argument("--ramp-steps", type=int, default=80,
+                    help="untimed steps run before the --warmup steps so that the shader clock has "
+                         "settled (about 1 ms each; 0 = none); reported as clock_ramp in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0,
                     help="wall-time budget of ALL host baselines together (FF stack, BiLSTM stack, "
@@ -831,26 +897,45 @@ def main():
         return model.train_step(x, y, valid, global_counts[i % n_batches], lr=1e-3,
                                 world_size=world)
 
-    for i in range(args.warmup):
-        step(i)
-
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    clock = SclkSampler(local_rank)
+    # Clock ramp, declared in the JSON line ("clock_ramp"): the chip takes tens of milliseconds of
+    # load to reach the shader clock it then holds, and `--warmup 5`
+    # is 5.6 ms of work.  args.ramp_steps untimed steps run first; the W
+    # warm-up steps of the contract follow, then the barrier, then EXACTLY K timed steps.
+    ramp_steps = int(args.ramp_steps)      # the same count on every rank (a step holds collectives)
+    t_ramp = time.perf_counter()
+    for i in range(ramp_steps):
+        step(i)
+    torch.cuda.synchronize()
+    t_ramp = time.perf_counter() - t_ramp
+    for i in range(args.warmup):
+        step(i)
+
+    # everything the timed region needs is created BEFORE the barrier: between the synchronize and the
+    # first launch the GPU idles, and every millisecond of that costs clock afterwards
+    stream = torch.cuda.current_stream()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    clock = SclkSampler(local_rank, period_s=0.001)
     with clock:
+        barrier()
         t0 = time.perf_counter()
+        evs[0].record(stream)
         for i in range(args.steps):
             step(i)
+            evs[i + 1].record(stream)
+        t_launched = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
+    dt_events = evs[0].elapsed_time(evs[-1]) * 1e-3
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, dt_events], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+        dt, dt_events = tt.tolist()
     frames = sum(global_counts[i % n_batches] for i in range(args.steps))
     value = frames / dt
 
@@ -932,7 +1017,7 @@ def main():
             cpu.update(host_info())
             if args.bilstm_utts > 0:
                 rnn_extra["bilstm"]["cpu_baseline"] = cpu_baseline_bilstm(
-                    max_seconds=min(20.0, args.cpu_budget_s / 4))
+                    max_seconds=min(30.0, args.cpu_budget_s / 4), threads=cpu["cores"])
         extra = dict(world_extra)
         extra.update(rnn_extra)
         if want_cpu and "world" in extra:
@@ -940,7 +1025,8 @@ def main():
             # interpreter of its own
             import subprocess
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-pool-worker",
-                                  str(args.world_fs), str(args.cpu_budget_s / 4)],
+                                  str(args.world_fs), str(args.cpu_budget_s / 4),
+                                  str(extra["world"].get("cpu_baseline", {}).get("analysis_rtf", 0.0))],
                                  stdout=subprocess.PIPE, text=True)
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
             if res.returncode == 0 and lines:
@@ -954,6 +1040,18 @@ def main():
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_hip_events": dt_events / args.steps * 1e3,
+            "timed_region": {"wall_ms": dt * 1e3, "hip_events_ms": dt_events * 1e3,
+                             "host_launch_ms": t_launched * 1e3,
+                             "step_ms_first8": [round(v, 4) for v in step_ms[:8]],
+                             "step_ms_median": float(np.median(step_ms)),
+                             "step_ms_max": float(np.max(step_ms)),
+                             "note": "value and ms_per_step are the wall clock (barrier + synchronize on "
+                                     "both sides, max over ranks); the event pair brackets the same K "
+                                     "steps on the launch stream"},
+            "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "ramp_ms": t_ramp * 1e3,
+                           "why": "the shader clock needs tens of ms of load to settle; the W warm-up "
+                                  "steps of the contract run after it"},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "FF acoustic model 425->512(tanh)->512(tanh)->187 train step "
                                    "(fwd + masked MSE + bwd + Adam), {} utterances/GPU/step of "

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
     if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
     const double x = v * v + a.eps;
     a.xp[g * a.ldk + k] = x;
-    z[k] = make_double2(log(x), 0.0);
+    z[k] = make_double2(wd::log_pos(x), 0.0);
   }
   __syncthreads();
   irfft_lds(z, a.flng, a.logflng, tw, a.flng);

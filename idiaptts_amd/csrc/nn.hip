@@ -423,17 +423,12 @@ static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>
 
 // ---- the LDS-DMA ring kernel (gemm_ring.h) -----------------------------------------------------
 // Takes every call whose operands allow 16-byte row accesses (the trainer's buffers all do); the
-// register-staged kernel above stays the general path (odd pitches, unaligned bases) and the A/B
-// checker (ITTS_GEMM_RING=0).
-static int ring_enabled() {
-  static const int on = [] { const char* e = getenv("ITTS_GEMM_RING"); return e ? atoi(e) : 1; }();
-  return on;
-}
+// register-staged kernel above stays the general path (odd pitches, unaligned bases).
 constexpr int kRingGrid = 512;   // persistent workgroups: 2 per CU
 
 template <bool A_ROW, bool B_ROW>
 static bool ring_ok(const GemmArgs& g, int splitk, int epi) {
-  if (!ring_enabled() || !g.vecA || !g.vecB) return false;
+  if (!g.vecA || !g.vecB) return false;
   if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || g.slab_stride % 4 || !aligned16(g.C)) return false;
   if (epi == EPI_DACT && (g.ldaux % 4 || !aligned16(g.aux))) return false;   // the MSE target is read dword-wise
   const int64_t lim = (int64_t)1 << 30;   // 32-bit byte offsets inside the buffer descriptors
@@ -691,34 +686,6 @@ extern "C" int itts_reduce_deferred(void* stream) {
   return flush_deferred(as_stream(stream));
 }
 
-// column sums of dz[M,N] over a row slice -> partial[z][n]
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz,
-                                                             int64_t ld, int64_t M, int N,
-                                                             int64_t rows_per_slice,
-                                                             float* __restrict__ partial) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
-  const int64_t r1 = std::min<int64_t>(M, r0 + rows_per_slice);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col < N) {
-    int64_t r = r0 + ty;
-    for (; r + 12 < r1; r += 16) {  // 4 independent loads in flight per thread
-      s0 += dz[r * ld + col];
-      s1 += dz[(r + 4) * ld + col];
-      s2 += dz[(r + 8) * ld + col];
-      s3 += dz[(r + 12) * ld + col];
-    }
-    for (; r < r1; r += 4) s0 += dz[r * ld + col];
-  }
-  const float s = (s0 + s1) + (s2 + s3);
-  red[ty][tx] = s;
-  __syncthreads();
-  if (ty == 0 && col < N)
-    partial[(int64_t)blockIdx.y * N + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-}
-
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                float* __restrict__ dz, int64_t n, int act) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -963,10 +930,7 @@ extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, 
   g.kchunk = ((K + BK - 1) / BK) * BK; g.slab_stride = 0;
   g.vecA = (ldx % 4 == 0) && aligned16(d_x);
   g.vecB = (K % 4 == 0) && aligned16(d_w);
-  {
-    static const int wide = [] { const char* e = getenv("ITTS_GEMM_WIDE"); return e ? atoi(e) : 1; }();
-    g.wide_out = wide && (ldy % 4 == 0) && aligned16(d_y) && (!d_b || aligned16(d_b));
-  }
+  g.wide_out = (ldy % 4 == 0) && aligned16(d_y) && (!d_b || aligned16(d_b));
   return launch_gemm<true, true, EPI_BIAS_ACT>(g, 1, as_stream(stream));
 }
 
@@ -1043,11 +1007,7 @@ extern "C" int itts_linear_bwd_input(const float* d_dz, int64_t lddz, const floa
   g.kchunk = ((N + BK - 1) / BK) * BK; g.slab_stride = 0;
   g.vecA = (lddz % 4 == 0) && aligned16(d_dz);
   g.vecB = (K % 4 == 0) && aligned16(d_w);
-  {
-    static const int wide = [] { const char* e = getenv("ITTS_GEMM_WIDE"); return e ? atoi(e) : 1; }();
-    g.wide_out = wide && (lddx % 4 == 0) && aligned16(d_dx) &&
-                 (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
-  }
+  g.wide_out = (lddx % 4 == 0) && aligned16(d_dx) && (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
   if (d_yprev) {
     ITTS_REQUIRE(ldyp >= K, "ldyp too small");
     return launch_gemm<true, false, EPI_DACT>(g, 1, as_stream(stream));
@@ -1075,21 +1035,19 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
     return ITTS_OK;
   }
   const bool vec_ok = (lddz % 4 == 0) && aligned16(d_dz) && (ldx % 4 == 0) && aligned16(d_x) && (K % 4 == 0);
-  const int S = (ring_enabled() && vec_ok) ? choose_splitk_ring(M, N, K) : choose_splitk(M, N, K);
+  const int S = vec_ok ? choose_splitk_ring(M, N, K) : choose_splitk(M, N, K);
   int64_t kchunk = (M + S - 1) / S;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   const int S_eff = (int)((M + kchunk - 1) / kchunk);
   float* slabs = reinterpret_cast<float*>(d_workspace);
-  float* bpart = slabs + (int64_t)S * ((int64_t)N * K + N);
   // dw[N,K] = dz^T x: A = dz as col form [k=M][out=N]; B = x as col form [k=M][out=K]
   GemmArgs g{};
   g.A = d_dz; g.lda = lddz; g.B = d_x; g.ldb = ldx; g.C = slabs; g.ldc = K;
   g.M = N; g.N = K; g.K = M; g.kchunk = kchunk; g.slab_stride = (int64_t)N * K;
   g.vecA = (lddz % 4 == 0) && aligned16(d_dz);
   g.vecB = (ldx % 4 == 0) && aligned16(d_x);
-  static const int fuse_db = [] { const char* e = getenv("ITTS_GEMM_FUSE_DB"); return e ? atoi(e) : 1; }();
   const int64_t n = (int64_t)N * K;
-  if (d_db && fuse_db) {
+  if (d_db) {
     // The bias gradient (column sums of dz) comes out of the same launch: the workgroups of the
     // first column tile add up their resident dz tiles.  When db follows dw in memory (the flat
     // gradient arenas) and both lengths are multiples of 4, one reduction serves both.
@@ -1107,19 +1065,7 @@ extern "C" int itts_linear_bwd_weight(const float* d_dz, int64_t lddz, const flo
   }
   int rc = launch_gemm<false, false, EPI_STORE>(g, S_eff, s);
   if (rc) return rc;
-  rc = launch_reduce_slabs(slabs, S_eff, n, d_dw, accumulate, s);
-  if (rc) return rc;
-  if (d_db) {
-    int64_t rows = (M + kColsumSlices - 1) / kColsumSlices;
-    rows = std::max<int64_t>(rows, 16);
-    const int cs = (int)((M + rows - 1) / rows);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, cs), dim3(256), 0, s, d_dz,
-                       lddz, M, N, rows, bpart);
-    ITTS_LAUNCH_CHECK();
-    rc = launch_reduce_slabs(bpart, cs, (int64_t)N, d_db, accumulate, s);
-    if (rc) return rc;
-  }
-  return ITTS_OK;
+  return launch_reduce_slabs(slabs, S_eff, n, d_dw, accumulate, s);
 }
 
 // Weight gradient (+ bias gradient) and input gradient of one layer from one call: with operands
@@ -1138,8 +1084,7 @@ extern "C" int itts_linear_bwd(const float* d_dz, int64_t lddz, const float* d_x
                       aligned16(d_w);
   const int64_t n = (int64_t)N * K;
   const bool merged = d_db && d_db == d_dw + n && N % 4 == 0 && n % 4 == 0;
-  static const int pair_on = [] { const char* e = getenv("ITTS_GEMM_PAIR"); return e ? atoi(e) : 1; }();
-  bool fused = pair_on && ring_enabled() && vec_ok && M > 0 && (lddx % 4 == 0) && aligned16(d_dx) &&
+  bool fused = vec_ok && M > 0 && (lddx % 4 == 0) && aligned16(d_dx) &&
                (!d_yprev || ((ldyp % 4 == 0) && aligned16(d_yprev)));
   GemmArgs gw{}, gx{};
   int S_eff = 1;

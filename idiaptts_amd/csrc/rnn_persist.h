@@ -438,7 +438,10 @@ struct RnnPersistBwdArgs {
   int T, B, ndir, ntiles, tile0;
 };
 
-constexpr int PT = 88;    // granules reserved per partial tile: 64 + 22, padded to whole 128-byte lines
+#ifndef PERSIST_BWD_PT
+#define PERSIST_BWD_PT 88
+#endif
+constexpr int PT = PERSIST_BWD_PT;    // granules reserved per partial tile: 64 + 22, padded to whole 128-byte lines
 constexpr int persist_bwd_lds_bytes(int G) { return 32 * G * 64 * 16 + 4 * 16 * 17 * 4 + G * 16 * 16 * 4; }
 
 #ifndef PERSIST_BWD_TRACE

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "context.h"
+#include "wave_fft.h"
 #include "world_dev.h"
 
 namespace itts {
@@ -446,7 +447,7 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
   for (int k = tid(); k <= h; k += NT) {
     const double t = exp(z[k].x / fft);
     double sn, cs;
-    sincos(z[k].y / fft, &sn, &cs);
+    sincos_mid(z[k].y / fft, &sn, &cs);
     mp[k] = make_double2(t * cs, t * sn);
   }
   __syncthreads();
@@ -536,12 +537,12 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     const bool has_per = !(vuv <= 0.5 || ar[0] > 0.999);
     double per_dc = 0.0, per_dsum = 1.0;
     if (has_per) {
-      for (int k = tid(); k < K; k += NT) lg[k] = log(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
+      for (int k = tid(); k < K; k += NT) lg[k] = log_pos(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
       __syncthreads();
       min_phase(lg, fft, logfft, z, tw, mp);
       const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
       for (int k = tid(); k < K; k += NT) {
-        const double re2 = cos(coef * k);
+        const double re2 = cos_mid(coef * k);
         const double im2 = sqrt(1.0 - re2 * re2);
         const double2 m = mp[k];
         z[k] = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     // ---- aperiodic response: minimum-phase spectrum first (into mp), then the noise spectrum in z,
     // multiplied in place
     for (int k = tid(); k < K; k += NT)
-      lg[k] = (vuv != 0.0) ? log(se[k] * ar[k]) / 2.0 : log(se[k]) / 2.0;
+      lg[k] = log_pos((vuv != 0.0) ? se[k] * ar[k] : se[k]) / 2.0;
     __syncthreads();
     min_phase(lg, fft, logfft, z, tw, mp);
     {
@@ -618,6 +619,237 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
       }
     }
     __syncthreads();
+  }
+}
+
+// ---- one WAVE per pulse (fft = 1024: 16 .. 24 kHz) ------------------------------------------------
+// The same pulse as syn_pulse_kernel, by one wavefront: the 513 bins of a spectrum live eight per
+// lane in registers (bin lane + 64 q in register q; bin 512 is carried by every lane), the seven real
+// transforms are wf::rfft1024 / irfft1024 (wave_fft.h: register passes, the wave's own 8.5 KB of LDS
+// for the transposes, no workgroup barrier), the responses stay in registers up to the overlap-add.
+// Persistent: 8 waves per CU take the pulses in turn, so the host no longer needs the pulse count.
+// Spectra and responses are those of syn_pulse_kernel bit for bit; the two wave-wide sums (DC of the
+// periodic response, mean of the noise) add up in another order.
+__device__ __forceinline__ double wave_bcast0(double v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+// minimum phase spectrum of the log-amplitude lg (layout A + bin 512) -> mp (same layout)
+__device__ __forceinline__ void min_phase_wave(const double (&lg)[8], const double lg512, const wf::Plan512& P,
+                                               double2 (&mp)[8], double2& mp512) {
+  constexpr int fft = 1024;
+  double2 z[8], x512;
+  wf::pack_real<true>(lg, lg512, z, P);
+  wf::rfft1024(z, x512, P);            // real even input -> real spectrum = fft * cepstrum
+  // fold: c[0], 2 c[1 .. h-1], c[h], zeros
+  double c[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) c[q] = z[q].x * ((q == 0 && wf::lane_id() == 0) ? 1.0 : 2.0);
+  const double c512 = wave_bcast0(x512.x) * 1.0;
+  wf::pack_real<false>(c, c512, z, P);
+  wf::rfft1024(z, x512, P);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double t = exp(z[q].x / fft);
+    double sn, cs;
+    sincos_mid(z[q].y / fft, &sn, &cs);
+    mp[q] = make_double2(t * cs, t * sn);
+    __builtin_amdgcn_sched_barrier(0);      // one bin at a time: eight interleaved bins do not fit the registers
+  }
+  {
+    const double xr = wave_bcast0(x512.x), xi = wave_bcast0(x512.y);
+    const double t = exp(xr / fft);
+    double sn, cs;
+    sincos_mid(xi / fft, &sn, &cs);
+    mp512 = make_double2(t * cs, t * sn);
+  }
+}
+
+#ifndef SYN_WAVE_OCC
+#define SYN_WAVE_OCC 1
+#endif
+__global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int fft = 1024, h = 512, K = 513;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l = wf::lane_id();
+  wf::Plan512 P;
+  wf::table512_init(smem, a.g_tw);
+  wf::plan512_init(P, a.g_tw, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
+  const int64_t total = a.gpoff[a.p.n_utts];
+  const int64_t nw = (int64_t)gridDim.x * (NT / 64);
+  int lo = 0;
+  for (int64_t g = (int64_t)blockIdx.x * (NT / 64) + wv; g < total; g += nw) {
+    while (a.gpoff[lo + 1] <= g) ++lo;          // utterance of flat pulse g (g only grows)
+    const SynUtt u = a.utts[lo];
+    const int Pn = (int)a.ptot[lo];
+    const int qi = (int)(g - a.gpoff[lo]);
+    const int* pidx = a.pidx + u.s_off;
+    const int idx = pidx[qi];
+    const int idx_next = pidx[min(Pn - 1, qi + 1)];
+    const int noise_size = idx_next - idx;
+    const double* wrap = a.wrap + u.s_off;
+    const double y1 = wrap[idx] - 2.0 * kPi, y2 = wrap[idx + 1];
+    const double tshift = (-y1 / (y2 - y1)) / a.p.fs;
+    const double t = idx / (double)a.p.fs;
+    const double vuv = a.vuv[u.s_off + idx] ? 1.0 : 0.0;
+    const int T = u.T;
+    int fl = (int)floor(t / a.p.fp), ce = (int)ceil(t / a.p.fp);
+    if (fl > T - 1) fl = T - 1;
+    if (ce > T - 1) ce = T - 1;
+    const double al = t / a.p.fp - fl;
+    const double* sp0 = a.sp + (u.f_off + fl) * K;
+    const double* sp1 = a.sp + (u.f_off + ce) * K;
+    const double* ap0 = a.ap + (u.f_off + fl) * K;
+    const double* ap1 = a.ap + (u.f_off + ce) * K;
+    // spectral envelope and aperiodicity ratio of bin k at the pulse (requested twice: the registers
+    // are worth more than two reads from L2)
+    auto se_ar = [&](int k, double& se, double& ar) {
+      const double s0 = fabs(sp0[k]);
+      double a0 = ap0[k];
+      a0 = a0 > 0.999999999999 ? 0.999999999999 : a0;
+      a0 = a0 < 0.001 ? 0.001 : a0;
+      if (fl == ce) {
+        se = s0;
+        ar = a0 * a0;
+      } else {
+        const double s1 = fabs(sp1[k]);
+        double a1 = ap1[k];
+        a1 = a1 > 0.999999999999 ? 0.999999999999 : a1;
+        a1 = a1 < 0.001 ? 0.001 : a1;
+        se = (1.0 - al) * s0 + al * s1;
+        ar = (1.0 - al) * (a0 * a0) + al * (a1 * a1);
+      }
+    };
+    double se0, ar0;
+    se_ar(0, se0, ar0);
+    const bool has_per = !(vuv <= 0.5 || ar0 > 0.999);
+    double2 per[4];
+    double per_dc = 0.0;
+    const double per_dsum = a.dcr[h];
+    // ---- periodic response
+    if (has_per) {
+      double lg[8], lg512;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        double se, ar;
+        se_ar(l + 64 * q, se, ar);
+        lg[q] = log_pos(se * (1.0 - ar) + kEps) / 2.0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        double se, ar;
+        se_ar(h, se, ar);
+        lg512 = log_pos(se * (1.0 - ar) + kEps) / 2.0;
+      }
+      double2 mp[8], mp512;
+      min_phase_wave(lg, lg512, P, mp, mp512);
+      const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
+      double2 z[8], x512;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = l + 64 * q;
+        const double re2 = cos_mid(coef * k);
+        const double im2 = sqrt(1.0 - re2 * re2);
+        const double2 m = mp[q];
+        z[q] = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const double re2 = cos_mid(coef * h);
+        const double im2 = sqrt(1.0 - re2 * re2);
+        x512 = make_double2(mp512.x * re2 + mp512.y * im2, mp512.y * re2 - mp512.x * im2);
+      }
+      wf::irfft1024(z, x512, P);       // z[q] = (x[2m], x[2m+1]), m = lane + 64 q
+      // fftshift + DC removal: the kept half of the shifted response is x[0 .. h)
+      double dc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dc += z[q].x + z[q].y;
+      dc = wave_sum(dc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 2 * (l + 64 * q);
+        per[q] = make_double2(z[q].x - dc * (a.dcr[h - 1 - i] / per_dsum), z[q].y - dc * (a.dcr[h - 2 - i] / per_dsum));
+      }
+      per_dc = dc;
+    }
+    // ---- aperiodic response: minimum-phase spectrum times the spectrum of the noise
+    double2 mp[8], mp512;
+    {
+      double lg[8], lg512;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        double se, ar;
+        se_ar(l + 64 * q, se, ar);
+        lg[q] = log_pos((vuv != 0.0) ? se * ar : se) / 2.0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        double se, ar;
+        se_ar(h, se, ar);
+        lg512 = log_pos((vuv != 0.0) ? se * ar : se) / 2.0;
+      }
+      min_phase_wave(lg, lg512, P, mp, mp512);
+    }
+    double2 z[8], x512;
+    {
+      const double* R = a.R + u.s_off + (idx - pidx[0]);
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = 2 * (l + 64 * q);
+        const double v0 = (i < noise_size) ? R[i] : 0.0;
+        const double v1 = (i + 1 < noise_size) ? R[i + 1] : 0.0;
+        z[q] = make_double2(v0, v1);
+        sacc += v0 + v1;
+      }
+      sacc = wave_sum(sacc);
+      if (noise_size > 0) {
+        const double avg = sacc / noise_size;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = 2 * (l + 64 * q);
+          if (i < noise_size) z[q].x -= avg;
+          if (i + 1 < noise_size) z[q].y -= avg;
+        }
+      }
+      wf::rfft1024(z, x512, P);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double2 m = mp[q], n = z[q];
+      z[q] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
+    }
+    {
+      const double nx = wave_bcast0(x512.x), ny = wave_bcast0(x512.y);
+      x512 = make_double2(mp512.x * nx - mp512.y * ny, mp512.x * ny + mp512.y * nx);
+    }
+    wf::irfft1024(z, x512, P);
+    // ---- overlap-add: sample i of the response lands at j = (i + h) mod fft (fftshift)
+    const double sq = sqrt((double)noise_size);
+    const int off = idx - h + 1;
+    double* y = a.y + u.y_off;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int i = 2 * (l + 64 * q) + c;
+        const int j = q < 4 ? i + h : i - h;
+        const int tgt = j + off;
+        if (tgt >= 0 && tgt < u.yl) {
+          const double apv = c ? z[q].y : z[q].x;
+          double pv = 0.0;
+          if (has_per) {
+            if (q >= 4) pv = -per_dc * (a.dcr[j] / per_dsum);
+            else pv = c ? per[q].y : per[q].x;
+          }
+          const double v = (has_per ? pv * sq : 0.0) + apv;
+          atomicAdd(&y[tgt], v);
+        }
+      }
+    }
   }
 }
 
@@ -743,47 +975,55 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(syn_pulse_offsets_kernel, dim3(1), dim3(64), 0, s, d_ptot, n_utts, d_gpoff);
   ITTS_LAUNCH_CHECK();
-  // The pulse kernel runs one workgroup per pulse, so the host needs the pulse count: it is copied
-  // to a page-locked slot right here and awaited (polling) only after the noise generator has
-  // been queued, which keeps the GPU busy meanwhile.  (A persistent-workgroup loop over the pulses
-  // avoided the read-back but made every loop-invariant address and fp64 constant of the seven
-  // FFTs live across the whole kernel: 239 VGPRs instead of 94.)
-  int64_t* h_total = pinned_slot(ctx);
-  hipEvent_t ev_total;
-  ITTS_HIP_CHECK(hipEventCreateWithFlags(&ev_total, hipEventDisableTiming));
-  ITTS_HIP_CHECK(hipMemcpyAsync(h_total, d_gpoff + n_utts, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  ITTS_HIP_CHECK(hipEventRecord(ev_total, s));
+  const int h = fft_size / 2;
+  double* d_dcr = nullptr;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_dcr, (size_t)(h + 1) * 8, s));
+  hipLaunchKernelGGL(syn_dcr_table_kernel, dim3(1), dim3(NT), 0, s, fft_size, d_dcr);
+  ITTS_LAUNCH_CHECK();
+  PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
+              ctx->tw_compact[p.logfft], d_dcr};
   {
     const int nchunks = (max_yl + RCHUNK - 1) / RCHUNK;
     hipLaunchKernelGGL(syn_randn_kernel, dim3((nchunks + NT - 1) / NT, n_utts), dim3(NT), 0, s, d_utts, jt, d_R);
     ITTS_LAUNCH_CHECK();
   }
-  {
-    hipError_t e;
-    while ((e = hipEventQuery(ev_total)) == hipErrorNotReady) {
+  if (fft_size == 2 * wf::WF_N) {
+    // 16 .. 24 kHz: one wave per pulse, persistent waves (two workgroups of four waves per CU); the
+    // pulse count stays on the device
+    int dev = 0, n_cu = 256;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const size_t lds = wf::WF_TABLE_BYTES + (size_t)(NT / 64) * wf::WF_LDS_BYTES;
+    hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds, s, a);
+    ITTS_LAUNCH_CHECK();
+  } else {
+    // other transform sizes: one workgroup per pulse, so the host needs the pulse count (copied to a
+    // page-locked slot and awaited by polling; the noise generator queued above keeps the GPU busy)
+    int64_t* h_total = pinned_slot(ctx);
+    hipEvent_t ev_total;
+    ITTS_HIP_CHECK(hipEventCreateWithFlags(&ev_total, hipEventDisableTiming));
+    ITTS_HIP_CHECK(hipMemcpyAsync(h_total, d_gpoff + n_utts, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    ITTS_HIP_CHECK(hipEventRecord(ev_total, s));
+    {
+      hipError_t e;
+      while ((e = hipEventQuery(ev_total)) == hipErrorNotReady) {
+      }
+      (void)hipEventDestroy(ev_total);
+      ITTS_HIP_CHECK(e);
     }
-    (void)hipEventDestroy(ev_total);
-    ITTS_HIP_CHECK(e);
+    const int64_t n_pulses = *h_total;
+    ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
+    if (n_pulses > 0) {
+      const size_t lds = 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
+                         (size_t)h * 8 + 16 * 8;
+      ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(syn_pulse_kernel, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      ITTS_LAUNCH_CHECK();
+    }
   }
-  const int64_t n_pulses = *h_total;
-  ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
-  if (n_pulses > 0) {
-    const int h = fft_size / 2;
-    double* d_dcr = nullptr;
-    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_dcr, (size_t)(h + 1) * 8, s));
-    hipLaunchKernelGGL(syn_dcr_table_kernel, dim3(1), dim3(NT), 0, s, fft_size, d_dcr);
-    ITTS_LAUNCH_CHECK();
-    PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
-                ctx->tw_compact[p.logfft], d_dcr};
-    const size_t lds = 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
-                       (size_t)h * 8 + 16 * 8;            // 28.2 KB at fft 1024: 5 workgroups per CU
-    ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(syn_pulse_kernel, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
-    ITTS_LAUNCH_CHECK();
-    ITTS_HIP_CHECK(itts::scratch_free(d_dcr, s));
-  }
+  ITTS_HIP_CHECK(itts::scratch_free(d_dcr, s));
   if (preemphasis == 0.0) {
     hipLaunchKernelGGL(syn_cast_kernel, dim3((unsigned)std::min<int64_t>((y_total + 255) / 256, 8192)), dim3(256),
                        0, s, d_y, y_total, d_y_f32, d_y_f64);

@@ -10,6 +10,7 @@
 //   dc_correction / linear_smoothing / interp1Q: WORLD common.cpp + matlabfunctions.cpp
 #pragma once
 #include "common.h"
+#include "fastmath.h"
 
 namespace itts {
 namespace wd {
@@ -28,6 +29,25 @@ __device__ __forceinline__ int tid() {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
   return t;
+}
+
+// log / sincos / cos of the per-bin loops: the short forms of fastmath.h on their domains (positive
+// normal numbers; |x| <= 1e5), the library call otherwise (a branch no lane takes on speech).
+__device__ __forceinline__ double log_pos(double x) {
+  if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) return log(x);
+  return fm::flog(x);
+}
+__device__ __forceinline__ void sincos_mid(double x, double* sn, double* cs) {
+  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) { sincos(x, sn, cs); return; }
+  fm::fsincos(x, sn, cs);
+}
+__device__ __forceinline__ double cos_mid(double x) {
+  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) return cos(x);
+  return fm::fcos(x);
+}
+__device__ __forceinline__ double sin_mid(double x) {
+  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) return sin(x);
+  return fm::fsin(x);
 }
 
 __device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }

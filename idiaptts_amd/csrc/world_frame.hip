@@ -99,7 +99,7 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
   // smoothing with recovery (cepstral liftering)
   for (int k = threadIdx.x; k <= h; k += NT) {
     const double nz = fabs(randn_of(rn[n + k])) * 2.2204460492503131e-16;
-    const double lp = log(L.P[k] + nz);
+    const double lp = log_pos(L.P[k] + nz);
     zr[k] = lp;
     if (k > 0 && k < h) zr[fft - k] = lp;
   }
@@ -113,8 +113,8 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
     double sl = 1.0, cl = 1.0;
     if (k > 0) {
       const double q = (double)k / fs;
-      sl = sin(kPi * f0 * q) / (kPi * f0 * q);
-      cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * q * f0);
+      sl = sin_mid(kPi * f0 * q) / (kPi * f0 * q);
+      cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos_mid(2.0 * kPi * q * f0);
     }
     L.z[k] = make_double2(L.z[k].x * sl * cl, 0.0);
   }

@@ -69,6 +69,50 @@ def allreduce_flat_(buf, group=None, async_op=False):
     return None if async_op else buf
 
 
+class NativeComm:
+    """RCCL communicator held by libidiaptts_amd itself (include/idiaptts_amd.h: itts_comm_* /
+    itts_allreduce_flat) -- what a maintainer binding only the C ABI uses for the gradient exchange
+    that torch.nn.DataParallel does in the reference (ModularModelHandlerPyTorch.py:732-735).  The
+    128-byte id travels from rank 0 over `broadcast_bytes` (default: torch.distributed's store of
+    the existing process group; a one-rank communicator needs none).  The device is the current one."""
+
+    def __init__(self, rank=0, world=1, broadcast_bytes=None):
+        import ctypes
+        from . import lib
+        self._lib = lib
+        L = lib.load()
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            lib.check(L.itts_comm_unique_id(ctypes.cast(ident, ctypes.c_void_p)), "itts_comm_unique_id")
+        if world > 1:
+            if broadcast_bytes is None:
+                def broadcast_bytes(b):
+                    obj = [bytes(b) if rank == 0 else None]
+                    dist.broadcast_object_list(obj, src=0)
+                    return obj[0]
+            ident = ctypes.create_string_buffer(broadcast_bytes(ident.raw), 128)
+        comm = ctypes.c_void_p()
+        lib.check(L.itts_comm_init_rank(ctypes.cast(ident, ctypes.c_void_p), int(world), int(rank),
+                                        ctypes.byref(comm)), "itts_comm_init_rank")
+        self.comm, self.rank, self.world = comm, rank, world
+
+    def allreduce_flat_(self, buf, op="sum", stream=None):
+        """In-place reduction of a contiguous float32 / float64 device tensor over the ranks,
+        asynchronous on `stream` (default: torch's current stream)."""
+        lib = self._lib
+        assert buf.is_cuda and buf.is_contiguous() and buf.dtype in (torch.float32, torch.float64)
+        s = stream.cuda_stream if stream is not None else lib.current_stream()
+        lib.check(lib.load().itts_allreduce_flat(
+            buf.data_ptr(), buf.numel(), 0 if buf.dtype == torch.float32 else 1,
+            {"sum": 0, "max": 1, "avg": 2}[op], self.comm, s), "itts_allreduce_flat")
+        return buf
+
+    def close(self):
+        if self.comm is not None:
+            self._lib.check(self._lib.load().itts_comm_destroy(self.comm), "itts_comm_destroy")
+            self.comm = None
+
+
 def allreduce_stats_(extractor, group=None, device=None):
     """Merges Mean{StdDev,Covariance}Extractor statistics across ranks in place.  A rank whose
     shard was empty (no add_sample yet: scalar zeros) takes the shapes of the others."""

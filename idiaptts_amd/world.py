@@ -132,13 +132,7 @@ class StreamStats(object):
         if name not in self.sums:
             return
         first, second = (t.cpu().numpy() for t in self.sums[name])
-        extractor.sum_length += self.count
-        if self.want_cov:
-            extractor.sum_frames = extractor.sum_frames + first[None, :]
-            extractor.sum_product_frames = extractor.sum_product_frames + second
-        else:
-            extractor.sum_frames = extractor.sum_frames + first
-            extractor.sum_squared_frames = extractor.sum_squared_frames + second
+        extractor.add_sums(self.count, first[None, :] if self.want_cov else first, second)
 
 
 def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alpha=None,

@@ -44,6 +44,8 @@ int itts_scratch_pool_stats(int64_t* reserved, int64_t* used, int64_t* keep_thre
  * a block handed back on one stream is reused on another only behind an event), up to
  * ITTS_POOL_KEEP_GB (environment, default 64) between calls.  This synchronises the device and hands
  * every idle block back, e.g. between a feature-extraction job and training in one process. */
+int itts_release_scratch(void);
+
 /* Deferred reductions (this host thread): while on, itts_linear_fwd_mse / itts_masked_mse /
  * itts_linear_bwd / itts_linear_bwd_weight leave their partial results (loss partial sums, split-K
  * slabs of the weight and bias gradients) in the workspace they were given and queue the reduction
@@ -55,7 +57,26 @@ int itts_scratch_pool_stats(int64_t* reserved, int64_t* used, int64_t* keep_thre
 int itts_defer_reductions(int on);
 int itts_reduce_deferred(void* stream);
 
-int itts_release_scratch(void);
+/* ---- gradient exchange of data-parallel training (csrc/collective.cpp) --------------------------
+ * Replaces torch.nn.DataParallel's scatter / gather / gradient reduction
+ * (src/neural_networks/pytorch/ModularModelHandlerPyTorch.py:732-735, :757-763) by one process per GPU
+ * and an in-place all-reduce of a flat device buffer (the gradient arena, or the additive
+ * normalisation sums of gen_data) over RCCL / xGMI on the caller's stream.  RCCL is resolved at run
+ * time from the copy the process already holds (PyTorch's), else the system's; ITTS_E_UNSUPPORTED when
+ * there is none.  A communicator is either the caller's own ncclComm_t or one made here:
+ *   itts_comm_unique_id   rank 0 fills 128 bytes, sends them to the others by any means
+ *   itts_comm_init_rank   collective over the n_ranks processes (device = the current HIP device)
+ *   itts_allreduce_flat   d_buf[0..n) <- reduction over the ranks, in place, asynchronous on `stream`
+ *   itts_comm_destroy */
+#define ITTS_F32 0
+#define ITTS_F64 1
+#define ITTS_REDUCE_SUM 0
+#define ITTS_REDUCE_MAX 1
+#define ITTS_REDUCE_AVG 2
+int itts_comm_unique_id(void* h_id128);
+int itts_comm_init_rank(const void* h_id128, int n_ranks, int rank, void** comm_out);
+int itts_comm_destroy(void* comm);
+int itts_allreduce_flat(void* d_buf, int64_t n, int dtype, int op, void* comm, void* stream);
 
 /* ---- integer / scalar helpers (host, no GPU) ------------------------------------------- */
 /* pyworld.get_cheaptrick_fft_size(fs, f0_floor=71)  -- src/data_preparation/audio/AudioProcessing.py:60 */

@@ -50,3 +50,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(lib.IttsError):
         lib.load()
+
+
+def test_allreduce_flat_rejects_bad_arguments_without_touching_a_gpu():
+    """itts_allreduce_flat (reference hook ModularModelHandlerPyTorch.py:732-735):
+    argument errors come back as ITTS_E_INVALID with a message, before RCCL is looked up."""
+    L = lib.load()
+    assert L.itts_allreduce_flat(None, 16, 0, 0, None, None) == -1
+    assert b"itts_allreduce_flat" in L.itts_last_error()
+    assert L.itts_allreduce_flat(None, 0, 7, 0, ctypes.c_void_p(1), None) == -1      # unknown dtype
+    assert L.itts_allreduce_flat(None, 0, 0, 9, ctypes.c_void_p(1), None) == -1      # unknown reduction
+    assert L.itts_allreduce_flat(None, 0, 0, 0, ctypes.c_void_p(1), None) == 0       # empty buffer: no-op
+    assert L.itts_comm_init_rank(None, 1, 0, None) == -1
+    assert L.itts_comm_destroy(None) == 0

@@ -254,6 +254,53 @@ def test_rccl_with_one_rank_takes_every_collective_branch(gpu, tmp_path):
     assert out["global_sum"] == 3.5 and out["seed"] == 1234
 
 
+def _native_comm_worker(ret_path):
+    from idiaptts_amd import lib, parallel
+    lib.require_gpu()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    comm = parallel.NativeComm(rank=0, world=1)
+    g = torch.Generator(device=dev).manual_seed(0)
+    grads = torch.randn(581_307, generator=g, device=dev)          # the FF model's flat gradient arena
+    stats = torch.randn(1 + 187 + 187 * 187, generator=g, device=dev, dtype=torch.float64)
+    want_g, want_s = grads.clone(), stats.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.allreduce_flat_(grads)                                    # current stream
+    comm.allreduce_flat_(stats, op="sum", stream=side)             # a stream of the caller's
+    comm.allreduce_flat_(grads, op="avg")
+    comm.allreduce_flat_(grads, op="max")
+    comm.allreduce_flat_(grads[:0])                                # empty: no-op
+    torch.cuda.synchronize()
+    ok_g, ok_s = bool(torch.equal(grads, want_g)), bool(torch.equal(stats, want_s))
+    bad = None
+    try:
+        lib.check(lib.load().itts_allreduce_flat(grads.data_ptr(), 4, 5, 0, comm.comm, None), "x")
+    except lib.IttsError as e:
+        bad = str(e)
+    comm.close()
+    with open(ret_path, "w") as f:
+        json.dump({"grads_equal": ok_g, "stats_equal": ok_s, "bad_dtype": bad}, f)
+
+
+def test_allreduce_flat_export_with_a_one_rank_communicator(gpu, tmp_path):
+    """SURVEY.md section 8(b) `allreduce_flat`: the library's own RCCL communicator (unique id, init,
+    in-place all-reduce of float32 / float64 buffers on the current and on a caller's stream, every
+    reduction, destroy).  A one-rank reduction is the identity -- what one GPU can prove is that RCCL
+    is found, the communicator works on the caller's streams and the buffers come back unchanged."""
+    ret = os.path.join(str(tmp_path), "ret.json")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "import test_gpu_dp as t; t._native_comm_worker(%r)" % (ROOT, os.path.join(ROOT, "tests"), ret))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    out = json.load(open(ret))
+    assert out["grads_equal"] and out["stats_equal"], out
+    assert out["bad_dtype"] and "dtype" in out["bad_dtype"], out
+
+
 def test_bench_counts_devices_without_touching_hip():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))

@@ -76,3 +76,51 @@ def test_long_sequences_match_torch_float64(gpu, cell, B, T):
     for k, v in report.items():
         if k.startswith("d"):
             assert v < GRAD_REL, (k, v, report)
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_config3_bench_shape_matches_torch_float64(gpu, cell):
+    """BASELINE config 3 at the EXACT shape bench.py times (`bilstm` / `bigru`): 3 x 512 bidirectional
+    layers, 425 inputs, the 64 utterances of make_ff_batch(64, seed=7) (T = 1977, 73 138 valid
+    frames): four 16-row tiles per direction on all eight XCDs, ~2 000 steps of the polling exchange,
+    forward and backward, against torch.nn.LSTM / GRU in float64 on the GPU.  Same budget as above."""
+    from idiaptts_amd import nn as inn
+    from idiaptts_amd.bench_support import utterance_lengths
+    in_dim, H, layers = 425, 512, 3
+    lens = torch.from_numpy(utterance_lengths(64, seed=7))
+    B, T = 64, int(lens.max())
+    assert T == 1977 and int(lens.sum()) == 73138
+    torch.manual_seed(64 + T)
+    mine = getattr(inn, cell)(in_dim, H, layers, bidirectional=True).to(gpu)
+    ref = getattr(torch.nn, cell)(in_dim, H, layers, bidirectional=True).double().to(gpu)
+    ref.load_state_dict({k: v.detach().double() for k, v in mine.state_dict().items()})
+    x = torch.randn(T, B, in_dim)
+    for b, l in enumerate(lens.tolist()):
+        x[l:, b] = 3.0
+    w = torch.randn(T, B, 2 * H) / np.sqrt(T)
+    xr = x.double().to(gpu).requires_grad_(True)
+    out_p, hn_ref = ref(pack_padded_sequence(xr, lens, enforce_sorted=False))
+    out_ref, _ = pad_packed_sequence(out_p, total_length=T)
+    (out_ref * w.double().to(gpu)).sum().backward()
+    out_ref = out_ref.detach().cpu()
+    hn_r = (hn_ref if cell == "GRU" else hn_ref[0]).detach().cpu()
+    xr_grad = xr.grad.cpu()
+
+    xg = x.to(gpu).requires_grad_(True)
+    out, hn = mine(xg, None, lens)
+    (out * w.to(gpu)).sum().backward()
+    torch.cuda.synchronize()
+    report = {"cell": cell, "B": B, "T": T, "layers": layers}
+    report["out_abs"] = (out.detach().cpu().double() - out_ref).abs().max().item()
+    report["hn_abs"] = ((hn if cell == "GRU" else hn[0]).cpu().double() - hn_r).abs().max().item()
+    report["dx_rel"] = ((xg.grad.cpu().double() - xr_grad).abs().max() / xr_grad.abs().max()).item()
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        report["d" + n] = ((pm.grad.cpu().double() - pr.grad.cpu()).abs().max() / pr.grad.abs().max().cpu()).item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "rnn_config3_%s.json" % cell), "w") as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps(report))
+    assert report["out_abs"] < OUT_ABS and report["hn_abs"] < OUT_ABS, report
+    for k, v in report.items():
+        if k.startswith("d"):
+            assert v < GRAD_REL, (k, v, report)
