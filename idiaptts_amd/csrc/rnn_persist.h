@@ -88,31 +88,6 @@ __device__ __forceinline__ void persist_load_pair(const uint4* p, pu32x4& v, pu3
                : "memory");
 }
 
-// Tagged form for the backward kernel's partial tiles (a tile = 64 granules (v0, v1, v2, tag) + 22
-// granules carrying the lanes' fourth values three at a time, 88 granules reserved): sixteen loads
-// in flight, the second eight at per-lane addresses of their own.
-__device__ __forceinline__ void persist_load16t(const uint4* pa, const uint4* pb, int stride, pu32x4 (&v)[8],
-                                                pu32x4 (&c)[8]) {
-  const uint4 *p0 = pa, *p1 = pa + stride, *p2 = pa + 2 * stride, *p3 = pa + 3 * stride, *p4 = pa + 4 * stride,
-              *p5 = pa + 5 * stride, *p6 = pa + 6 * stride, *p7 = pa + 7 * stride;
-  const uint4 *q0 = pb, *q1 = pb + stride, *q2 = pb + 2 * stride, *q3 = pb + 3 * stride, *q4 = pb + 4 * stride,
-              *q5 = pb + 5 * stride, *q6 = pb + 6 * stride, *q7 = pb + 7 * stride;
-  asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %17, off sc1\n\t"
-               "global_load_dwordx4 %2, %18, off sc1\n\tglobal_load_dwordx4 %3, %19, off sc1\n\t"
-               "global_load_dwordx4 %4, %20, off sc1\n\tglobal_load_dwordx4 %5, %21, off sc1\n\t"
-               "global_load_dwordx4 %6, %22, off sc1\n\tglobal_load_dwordx4 %7, %23, off sc1\n\t"
-               "global_load_dwordx4 %8, %24, off sc1\n\tglobal_load_dwordx4 %9, %25, off sc1\n\t"
-               "global_load_dwordx4 %10, %26, off sc1\n\tglobal_load_dwordx4 %11, %27, off sc1\n\t"
-               "global_load_dwordx4 %12, %28, off sc1\n\tglobal_load_dwordx4 %13, %29, off sc1\n\t"
-               "global_load_dwordx4 %14, %30, off sc1\n\tglobal_load_dwordx4 %15, %31, off sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-                 "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7),
-                 "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7)
-               : "memory");
-}
-
 __device__ __forceinline__ void persist_load_one(const uint4* p, pu32x4& v) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
 }
@@ -417,10 +392,17 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
 // [lane] float4) into a PARTIAL dh for all 512 units, publishes the 16 x 16 tile of every unit block
 // to the workgroup that owns it (reduce-scatter: 32 KB out, 32 KB in, per CU and step), and sums the
 // 32 partial tiles it receives.  Polling, budget and fallback as above, but the granules carry their
-// tag INSIDE (three values + mask(step); a tile's 256 values take 86 granules): with a check copy
-// per granule the two step slots of an XCD's 32 x 32 tiles are 4 MB, the size of its L2, and every
-// step's exchange went through HBM (measured: 22.8 GB written, 14 GB read per layer and launch
-// against 3 GB of gate and gradient data); tagged they are 2.75 MB and stay.
+// tag INSIDE: the lowest mantissa bit of each of a granule's four values holds one bit of a 4-bit
+// step tag (15 states, never 0; consecutive uses of a slot differ), so a tile's 256 values are 64
+// granules and the two step slots of an XCD's 32 x 32 tiles are 2 MB of its 4 MB L2.  History
+// (profiles/r3h_rnn_traffic.txt, r4a_rnn_bwd_variants.txt; one layer, 64 rows, T = 1981, against
+// 3 GB of gate and gradient data): value + check-copy pairs, 4 MB per XCD: 22.8 GB written and 14 GB
+// read per launch -- every step's exchange went through HBM; three values + a tag word per granule,
+// 2.75 MB: reads fit (1.8 GB) but 15.8 GB were still written back -- the slots and the streamed
+// gates / gradients together overflow the L2's ways; at 2 MB the write-back drops to 4.0 GB.  The
+// price is the last bit of each PARTIAL sum (<= 1 ulp of a 64-term fp32 dot product that already
+// carries several ulp of rounding; 32 such partials are added per element): the layer's gradients
+// stay inside the budget of tests/test_gpu_rnn_long.py unchanged.
 struct RnnPersistBwdArgs {
   const float* dy;
   const float* whh;
@@ -438,10 +420,24 @@ struct RnnPersistBwdArgs {
   int T, B, ndir, ntiles, tile0;
 };
 
-#ifndef PERSIST_BWD_PT
-#define PERSIST_BWD_PT 88
-#endif
-constexpr int PT = PERSIST_BWD_PT;    // granules reserved per partial tile: 64 + 22, padded to whole 128-byte lines
+constexpr int PT = 64;    // granules per partial tile: one per lane, four values each, tag in the four low mantissa bits
+__device__ __forceinline__ unsigned persist_tag4(int step) { return (unsigned)((step >> 1) % 15) + 1u; }
+__device__ __forceinline__ unsigned persist_tag_of(const pu32x4 g) {
+  return (g.x & 1u) | ((g.y & 1u) << 1) | ((g.z & 1u) << 2) | ((g.w & 1u) << 3);
+}
+// eight 16-byte L1-bypassing loads in flight together (one granule of each of eight producers' tiles)
+__device__ __forceinline__ void persist_load8(const uint4* p, int stride, pu32x4 (&v)[8]) {
+  const uint4 *p0 = p, *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride, *p4 = p + 4 * stride,
+              *p5 = p + 5 * stride, *p6 = p + 6 * stride, *p7 = p + 7 * stride;
+  asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+               "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+               "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+               "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+               : "memory");
+}
 constexpr int persist_bwd_lds_bytes(int G) { return 32 * G * 64 * 16 + 4 * 16 * 17 * 4 + G * 16 * 16 * 4; }
 
 #ifndef PERSIST_BWD_TRACE
@@ -514,23 +510,22 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
     // dh_rec: the 32 partial tiles published at step s + 1
     float dhr = 0.f;
     if (s < s0) {
-      pu32x4 pv[8], cv[8];
+      pu32x4 pv[8];
       const uint4* src = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv) * PT;
-      const unsigned m = persist_mask(s + 1);
-      const int l3 = lane / 3, lm = lane - 3 * l3;
+      const unsigned m = persist_tag4(s + 1);
       int budget = 1 << 16;
       for (;;) {
-        persist_load16t(src + lane, src + 64 + l3, PT, pv, cv);
+        persist_load8(src + lane, PT, pv);
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ok = ok && pv[i].w == m && cv[i].w == m;
+        for (int i = 0; i < 8; ++i) ok = ok && persist_tag_of(pv[i]) == m;
         if (__all(ok)) break;
         const uint4* watch = src + (lane & 7) * PT;
         bool gave_up = false;
         for (;;) {
           pu32x4 wp;
           persist_load_one(watch, wp);
-          if (__all(wp.w == m)) break;
+          if (__all(persist_tag_of(wp) == m)) break;
           if (--budget <= 0 || *reinterpret_cast<volatile int*>(a.abort_flag)) { gave_up = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
@@ -544,7 +539,7 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         sx += __uint_as_float(pv[i].x); sy += __uint_as_float(pv[i].y); sz += __uint_as_float(pv[i].z);
-        sw += __uint_as_float(lm == 0 ? cv[i].x : (lm == 1 ? cv[i].y : cv[i].z));
+        sw += __uint_as_float(pv[i].w);
       }
       const int rq = 4 * (lane >> 4), cc = lane & 15;
       Pp[(wv * 16 + rq + 0) * 17 + cc] = sx; Pp[(wv * 16 + rq + 1) * 17 + cc] = sy;
@@ -622,12 +617,11 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
       for (int gg2 = 0; gg2 < G; ++gg2)
         af[gg2] = make_float4(dgs[(gg2 * 16 + rr) * 16 + kq], dgs[(gg2 * 16 + rr) * 16 + 4 + kq],
                               dgs[(gg2 * 16 + rr) * 16 + 8 + kq], dgs[(gg2 * 16 + rr) * 16 + 12 + kq]);
-      const unsigned m = persist_mask(s);
-      // Software pipeline over the tiles: the values of tile i - 1 are collected, tagged and stored
-      // BETWEEN the products of tile i (a wave issues in order: behind the last product of a chain the
-      // read of its result, the three shuffles and the stores would otherwise leave the matrix unit
-      // idle for ~250 clocks per tile)
-      const int sl0 = min(3 * lane, 63), sl1 = min(3 * lane + 1, 63), sl2 = min(3 * lane + 2, 63);
+      const unsigned m = persist_tag4(s);
+      const unsigned t0 = m & 1u, t1 = (m >> 1) & 1u, t2 = (m >> 2) & 1u, t3 = (m >> 3) & 1u;
+      // Software pipeline over the tiles: the values of tile i - 1 are tagged and stored BETWEEN the
+      // products of tile i (a wave issues in order: behind the last product of a chain the read of its
+      // result and the store would otherwise leave the matrix unit idle)
       f32x4 accp = {0.f, 0.f, 0.f, 0.f};
       const float4* wsrc = Wb + (size_t)(8 * wv * G) * 64 + lane;      // this wave's 8 G operand quadruples
       float4 bw = wsrc[0];
@@ -635,7 +629,6 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
       for (int i = 0; i <= 8; ++i) {
         const int ct = 8 * wv + i;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
         uint4* dst = xg + (((size_t)(s & 1) * 32 + (ct - 1)) * 32 + cu) * PT;
 #pragma unroll
         for (int gg2 = 0; gg2 < G; ++gg2) {
@@ -648,15 +641,9 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg2].w, bw.w, acc, 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (i > 0) {
-            if (gg2 == 0) {
-              // lanes 0 .. 21 also carry the fourth values of lanes 3 l, 3 l + 1, 3 l + 2
-              q0 = __shfl(accp[3], sl0, 64); q1 = __shfl(accp[3], sl1, 64); q2 = __shfl(accp[3], sl2, 64);
-              dst[lane] = make_uint4(__float_as_uint(accp[0]), __float_as_uint(accp[1]), __float_as_uint(accp[2]), m);
-            } else if (gg2 == 1) {
-              if (lane < 22) dst[64 + lane] = make_uint4(__float_as_uint(q0), __float_as_uint(q1), __float_as_uint(q2), m);
-            }
-          }
+          if (i > 0 && gg2 == 0)
+            dst[lane] = make_uint4((__float_as_uint(accp[0]) & ~1u) | t0, (__float_as_uint(accp[1]) & ~1u) | t1,
+                                   (__float_as_uint(accp[2]) & ~1u) | t2, (__float_as_uint(accp[3]) & ~1u) | t3);
           __builtin_amdgcn_sched_barrier(0);
           bw = bwn;
         }

@@ -630,45 +630,61 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
 // Persistent: 8 waves per CU take the pulses in turn, so the host no longer needs the pulse count.
 // Spectra and responses are those of syn_pulse_kernel bit for bit; the two wave-wide sums (DC of the
 // periodic response, mean of the noise) add up in another order.
+// wave-uniform values said so (the pulse's scalars then live in SGPRs instead of one VGPR each)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double uni(double v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+template <class T>
+__device__ __forceinline__ const T* uni(const T* p) { return reinterpret_cast<const T*>(uni((int64_t)reinterpret_cast<uintptr_t>(p))); }
+
 __device__ __forceinline__ double wave_bcast0(double v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v));
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
   return __hiloint2double((int)hi, (int)lo);
 }
 
-// minimum phase spectrum of the log-amplitude lg (layout A + bin 512) -> mp (same layout)
-__device__ __forceinline__ void min_phase_wave(const double (&lg)[8], const double lg512, const wf::Plan512& P,
-                                               double2 (&mp)[8], double2& mp512) {
+// minimum phase spectrum of the log-amplitude v (layout A; v[8] = bin 512, the same in every lane) ->
+// mp (same layout).  The two real transforms run as two trips through one copy of the code.
+__device__ __forceinline__ void min_phase_wave(double (&v)[9], const wf::Plan512& P, double2 (&mp)[9]) {
   constexpr int fft = 1024;
   double2 z[8], x512;
-  wf::pack_real<true>(lg, lg512, z, P);
-  wf::rfft1024(z, x512, P);            // real even input -> real spectrum = fft * cepstrum
-  // fold: c[0], 2 c[1 .. h-1], c[h], zeros
-  double c[8];
+#pragma unroll 1
+  for (int r = 0; r < 2; ++r) {
+    double v8[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) c[q] = z[q].x * ((q == 0 && wf::lane_id() == 0) ? 1.0 : 2.0);
-  const double c512 = wave_bcast0(x512.x) * 1.0;
-  wf::pack_real<false>(c, c512, z, P);
-  wf::rfft1024(z, x512, P);
+    for (int q = 0; q < 8; ++q) v8[q] = v[q];
+    wf::pack_real(v8, v[8], z, P, r == 0);
+    wf::rfft1024(z, x512, P);            // r = 0: real even input -> real spectrum = fft * cepstrum
+    if (r == 0) {
+      // fold: c[0], 2 c[1 .. h-1], c[h], zeros
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const double t = exp(z[q].x / fft);
-    double sn, cs;
-    sincos_mid(z[q].y / fft, &sn, &cs);
-    mp[q] = make_double2(t * cs, t * sn);
-    __builtin_amdgcn_sched_barrier(0);      // one bin at a time: eight interleaved bins do not fit the registers
+      for (int q = 0; q < 8; ++q) v[q] = z[q].x * ((q == 0 && wf::lane_id() == 0) ? 1.0 : 2.0);
+      v[8] = wave_bcast0(x512.x) * 1.0;
+    }
   }
-  {
-    const double xr = wave_bcast0(x512.x), xi = wave_bcast0(x512.y);
-    const double t = exp(xr / fft);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double zr = q < 8 ? z[q].x : wave_bcast0(x512.x), zi = q < 8 ? z[q].y : wave_bcast0(x512.y);
+    const double t = exp(zr / fft);
     double sn, cs;
-    sincos_mid(xi / fft, &sn, &cs);
-    mp512 = make_double2(t * cs, t * sn);
+    sincos_mid(zi / fft, &sn, &cs);
+    mp[q] = make_double2(t * cs, t * sn);
+    if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);     // three bins in flight are enough; nine do not fit the registers
   }
 }
 
 #ifndef SYN_WAVE_OCC
-#define SYN_WAVE_OCC 1
+#define SYN_WAVE_OCC 2
+#endif
+#ifndef SYN_WAVE_DIAG
+#define SYN_WAVE_DIAG 0
 #endif
 __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -676,36 +692,46 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int l = wf::lane_id();
   wf::Plan512 P;
+  // the DC remover's window over its sum (what every pulse divides out again and again), once per workgroup
+  double* dcrn = reinterpret_cast<double*>(smem + wf::WF_TABLE_BYTES);
+  {
+    const double dsum = a.dcr[h];
+    for (int i = threadIdx.x; i < h; i += NT) dcrn[i] = a.dcr[i] / dsum;
+  }
   wf::table512_init(smem, a.g_tw);
-  wf::plan512_init(P, a.g_tw, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
+  constexpr int kWaveLds = wf::WF_LDS_BYTES + (h + 4) * 8;      // exchange buffer + the stash of 513 log amplitudes
+  char* wave_lds = smem + wf::WF_TABLE_BYTES + h * 8 + (size_t)wv * kWaveLds;
+  double* lgs = reinterpret_cast<double*>(wave_lds + wf::WF_LDS_BYTES);
+  wf::plan512_init(P, a.g_tw, wave_lds, smem);
+  const double2* dcrn2 = reinterpret_cast<const double2*>(dcrn);
   const int64_t total = a.gpoff[a.p.n_utts];
   const int64_t nw = (int64_t)gridDim.x * (NT / 64);
   int lo = 0;
   for (int64_t g = (int64_t)blockIdx.x * (NT / 64) + wv; g < total; g += nw) {
-    while (a.gpoff[lo + 1] <= g) ++lo;          // utterance of flat pulse g (g only grows)
-    const SynUtt u = a.utts[lo];
-    const int Pn = (int)a.ptot[lo];
-    const int qi = (int)(g - a.gpoff[lo]);
-    const int* pidx = a.pidx + u.s_off;
-    const int idx = pidx[qi];
-    const int idx_next = pidx[min(Pn - 1, qi + 1)];
+    while (uni(a.gpoff[lo + 1]) <= g) ++lo;          // utterance of flat pulse g (g only grows)
+    const int64_t u_foff = uni(a.utts[lo].f_off), u_yoff = uni(a.utts[lo].y_off), u_soff = uni(a.utts[lo].s_off);
+    const int T = uni(a.utts[lo].T), u_yl = uni(a.utts[lo].yl);
+    const int Pn = uni((int)a.ptot[lo]);
+    const int qi = (int)(g - uni(a.gpoff[lo]));
+    const int* pidx = a.pidx + u_soff;
+    const int idx = uni(pidx[qi]);
+    const int idx_next = uni(pidx[min(Pn - 1, qi + 1)]);
+    const int idx_first = uni(pidx[0]);
     const int noise_size = idx_next - idx;
-    const double* wrap = a.wrap + u.s_off;
-    const double y1 = wrap[idx] - 2.0 * kPi, y2 = wrap[idx + 1];
-    const double tshift = (-y1 / (y2 - y1)) / a.p.fs;
+    const double* wrap = a.wrap + u_soff;
+    const double y1 = uni(wrap[idx]) - 2.0 * kPi, y2 = uni(wrap[idx + 1]);
+    const double tshift = uni((-y1 / (y2 - y1)) / a.p.fs);
     const double t = idx / (double)a.p.fs;
-    const double vuv = a.vuv[u.s_off + idx] ? 1.0 : 0.0;
-    const int T = u.T;
-    int fl = (int)floor(t / a.p.fp), ce = (int)ceil(t / a.p.fp);
+    const double vuv = uni((int)a.vuv[u_soff + idx]) ? 1.0 : 0.0;
+    int fl = uni((int)floor(t / a.p.fp)), ce = uni((int)ceil(t / a.p.fp));
     if (fl > T - 1) fl = T - 1;
     if (ce > T - 1) ce = T - 1;
-    const double al = t / a.p.fp - fl;
-    const double* sp0 = a.sp + (u.f_off + fl) * K;
-    const double* sp1 = a.sp + (u.f_off + ce) * K;
-    const double* ap0 = a.ap + (u.f_off + fl) * K;
-    const double* ap1 = a.ap + (u.f_off + ce) * K;
-    // spectral envelope and aperiodicity ratio of bin k at the pulse (requested twice: the registers
-    // are worth more than two reads from L2)
+    const double al = uni(t / a.p.fp - fl);
+    const double* sp0 = a.sp + (u_foff + fl) * K;
+    const double* sp1 = a.sp + (u_foff + ce) * K;
+    const double* ap0 = a.ap + (u_foff + fl) * K;
+    const double* ap1 = a.ap + (u_foff + ce) * K;
+    // spectral envelope and aperiodicity ratio of bin k at the pulse
     auto se_ar = [&](int k, double& se, double& ar) {
       const double s0 = fabs(sp0[k]);
       double a0 = ap0[k];
@@ -726,129 +752,132 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
     double se0, ar0;
     se_ar(0, se0, ar0);
     const bool has_per = !(vuv <= 0.5 || ar0 > 0.999);
-    double2 per[4];
+    const double coef = uni(2.0 * kPi * tshift * a.p.fs / fft);
+    double2 per[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
     double per_dc = 0.0;
-    const double per_dsum = a.dcr[h];
-    // ---- periodic response
-    if (has_per) {
-      double lg[8], lg512;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        double se, ar;
-        se_ar(l + 64 * q, se, ar);
-        lg[q] = log_pos(se * (1.0 - ar) + kEps) / 2.0;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {
-        double se, ar;
-        se_ar(h, se, ar);
-        lg512 = log_pos(se * (1.0 - ar) + kEps) / 2.0;
-      }
-      double2 mp[8], mp512;
-      min_phase_wave(lg, lg512, P, mp, mp512);
-      const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
-      double2 z[8], x512;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = l + 64 * q;
-        const double re2 = cos_mid(coef * k);
-        const double im2 = sqrt(1.0 - re2 * re2);
-        const double2 m = mp[q];
-        z[q] = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {
-        const double re2 = cos_mid(coef * h);
-        const double im2 = sqrt(1.0 - re2 * re2);
-        x512 = make_double2(mp512.x * re2 + mp512.y * im2, mp512.y * re2 - mp512.x * im2);
-      }
-      wf::irfft1024(z, x512, P);       // z[q] = (x[2m], x[2m+1]), m = lane + 64 q
-      // fftshift + DC removal: the kept half of the shifted response is x[0 .. h)
-      double dc = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dc += z[q].x + z[q].y;
-      dc = wave_sum(dc);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = 2 * (l + 64 * q);
-        per[q] = make_double2(z[q].x - dc * (a.dcr[h - 1 - i] / per_dsum), z[q].y - dc * (a.dcr[h - 2 - i] / per_dsum));
-      }
-      per_dc = dc;
-    }
-    // ---- aperiodic response: minimum-phase spectrum times the spectrum of the noise
-    double2 mp[8], mp512;
-    {
-      double lg[8], lg512;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        double se, ar;
-        se_ar(l + 64 * q, se, ar);
-        lg[q] = log_pos((vuv != 0.0) ? se * ar : se) / 2.0;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {
-        double se, ar;
-        se_ar(h, se, ar);
-        lg512 = log_pos((vuv != 0.0) ? se * ar : se) / 2.0;
-      }
-      min_phase_wave(lg, lg512, P, mp, mp512);
-    }
     double2 z[8], x512;
-    {
-      const double* R = a.R + u.s_off + (idx - pidx[0]);
-      double sacc = 0.0;
+    // two trips through one copy of the code: the periodic response (skipped for unvoiced pulses), then
+    // the aperiodic one -- [log amplitude -> minimum phase] x [time shift | spectrum of the noise] -> response
+#pragma unroll 1
+    for (int half = has_per ? 0 : 1; half < 2; ++half) {
+      double v[9];
+      if (half == 1 && has_per) {
+        // the aperiodic log amplitudes were formed on the first trip (one read of the four rows)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = 2 * (l + 64 * q);
-        const double v0 = (i < noise_size) ? R[i] : 0.0;
-        const double v1 = (i + 1 < noise_size) ? R[i + 1] : 0.0;
-        z[q] = make_double2(v0, v1);
-        sacc += v0 + v1;
+        for (int q = 0; q < 8; ++q) v[q] = lgs[l + 64 * q];
+        v[8] = lgs[h];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          double se, ar;
+          se_ar(q < 8 ? l + 64 * q : h, se, ar);
+          const double xa = (vuv != 0.0) ? se * ar : se;
+          if (half == 0) {
+            v[q] = log_pos(se * (1.0 - ar) + kEps) / 2.0;
+            const double w = log_pos(xa) / 2.0;
+            if (q < 8) lgs[l + 64 * q] = w; else lgs[h] = w;
+          } else {
+            v[q] = log_pos(xa) / 2.0;
+          }
+          if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        wf::wave_sync();
       }
-      sacc = wave_sum(sacc);
-      if (noise_size > 0) {
-        const double avg = sacc / noise_size;
+      double2 mp[9];
+      min_phase_wave(v, P, mp);
+      if (half == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int k = q < 8 ? l + 64 * q : h;
+          const double re2 = cos_mid(coef * k);
+          const double im2 = sqrt(1.0 - re2 * re2);
+          const double2 m = mp[q];
+          const double2 r = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);
+          if (q < 8) z[q] = r; else x512 = r;
+          if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        const double* R = a.R + u_soff + (idx - idx_first);
+        double sacc = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int i = 2 * (l + 64 * q);
-          if (i < noise_size) z[q].x -= avg;
-          if (i + 1 < noise_size) z[q].y -= avg;
+          const double v0 = (i < noise_size) ? R[i] : 0.0;
+          const double v1 = (i + 1 < noise_size) ? R[i + 1] : 0.0;
+          z[q] = make_double2(v0, v1);
+          sacc += v0 + v1;
         }
-      }
-      wf::rfft1024(z, x512, P);
-    }
+        sacc = wave_sum(sacc);
+        if (noise_size > 0) {
+          const double avg = sacc / noise_size;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const double2 m = mp[q], n = z[q];
-      z[q] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
+          for (int q = 0; q < 8; ++q) {
+            const int i = 2 * (l + 64 * q);
+            if (i < noise_size) z[q].x -= avg;
+            if (i + 1 < noise_size) z[q].y -= avg;
+          }
+        }
+        wf::rfft1024(z, x512, P);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const double2 m = mp[q], n = z[q];
+          z[q] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
+        }
+        const double nx = wave_bcast0(x512.x), ny = wave_bcast0(x512.y);
+        x512 = make_double2(mp[8].x * nx - mp[8].y * ny, mp[8].x * ny + mp[8].y * nx);
+      }
+      wf::irfft1024(z, x512, P);       // z[q] = (x[2m], x[2m+1]), m = lane + 64 q
+      if (half == 0) {
+        // fftshift + DC removal: the kept half of the shifted response is x[0 .. h)
+        double dc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dc += z[q].x + z[q].y;
+        dc = wave_sum(dc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double2 d = dcrn2[255 - l - 64 * q];         // (dcr[h - 2 - i], dcr[h - 1 - i]) / sum, i = 2 (l + 64 q)
+          per[q] = make_double2(z[q].x - dc * d.y, z[q].y - dc * d.x);
+        }
+        per_dc = dc;
+      }
     }
-    {
-      const double nx = wave_bcast0(x512.x), ny = wave_bcast0(x512.y);
-      x512 = make_double2(mp512.x * nx - mp512.y * ny, mp512.x * ny + mp512.y * nx);
-    }
-    wf::irfft1024(z, x512, P);
-    // ---- overlap-add: sample i of the response lands at j = (i + h) mod fft (fftshift)
+    // ---- overlap-add: sample i of a response lands at j = (i + h) mod fft (fftshift).  The sums go
+    // through the wave's LDS once so that an atomic instruction covers 64 consecutive samples.
     const double sq = sqrt((double)noise_size);
     const int off = idx - h + 1;
-    double* y = a.y + u.y_off;
+    double* y = a.y + u_yoff;
+    {
+      double2* s2 = reinterpret_cast<double2*>(wave_lds);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int i = 2 * (l + 64 * q) + c;
-        const int j = q < 4 ? i + h : i - h;
-        const int tgt = j + off;
-        if (tgt >= 0 && tgt < u.yl) {
-          const double apv = c ? z[q].y : z[q].x;
-          double pv = 0.0;
-          if (has_per) {
-            if (q >= 4) pv = -per_dc * (a.dcr[j] / per_dsum);
-            else pv = c ? per[q].y : per[q].x;
+      for (int q = 0; q < 8; ++q) {
+        double2 pv = make_double2(0.0, 0.0);
+        if (has_per) {
+          if (q >= 4) {
+            const double2 d = dcrn2[l + 64 * (q - 4)];      // j = i - h = 2 (l + 64 (q - 4))
+            pv = make_double2(-per_dc * d.x, -per_dc * d.y);
+          } else {
+            pv = per[q];
           }
-          const double v = (has_per ? pv * sq : 0.0) + apv;
+        }
+        const double2 v = make_double2((has_per ? pv.x * sq : 0.0) + z[q].x, (has_per ? pv.y * sq : 0.0) + z[q].y);
+        s2[l + 64 * ((q + 4) & 7)] = v;                     // slot j / 2
+      }
+      wf::wave_sync();
+      const double* s1 = reinterpret_cast<const double*>(wave_lds);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 64 * r + l;
+        const int tgt = j + off;
+        const double v = s1[j];
+        if (tgt >= 0 && tgt < u_yl) {
+#if SYN_WAVE_DIAG == 1
+          if (v == 1.2345e300) y[tgt] = v;
+#else
           atomicAdd(&y[tgt], v);
+#endif
         }
       }
+      wf::wave_sync();
     }
   }
 }
@@ -993,7 +1022,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
     int dev = 0, n_cu = 256;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    const size_t lds = wf::WF_TABLE_BYTES + (size_t)(NT / 64) * wf::WF_LDS_BYTES;
+    const size_t lds = wf::WF_TABLE_BYTES + (size_t)h * 8 + (size_t)(NT / 64) * (wf::WF_LDS_BYTES + (h + 4) * 8);
     hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
   } else {

@@ -25,7 +25,7 @@ namespace wf {
 constexpr int WF_N = 512;                    // complex points per transform
 constexpr int WF_PITCH = 68;                 // 16-byte slots per row of the first exchange (64 + 4: conflict-free reads)
 constexpr int WF_LDS_BYTES = 8 * WF_PITCH * 16;   // 8704 B per wave
-constexpr int WF_TABLE_BYTES = 7 * (8 + 64) * 16; // 8064 B per workgroup: [7][8] pass 2, [7][64] pass 3
+constexpr int WF_TABLE_BYTES = (7 * (8 + 64) + 264) * 16;   // 12288 B per workgroup: [7][8] pass 2, [7][64] pass 3, tw[0 .. 256]
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int bitrev3(int x) { return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1); }
@@ -42,8 +42,8 @@ struct Plan512 {
   const double2* t2;    // pass 2, a = lane & 7: t2[8 i], i = 0 .. 6 = tw[64 a]; tw[32 a], tw[32 a + 256]; tw[16 a + {0, 128, 256, 384}]
   const double2* t3;    // pass 3, M = lane:     t3[64 i]            = tw[8 M];  tw[4 M],  tw[4 M + 256];  tw[2 M + {0, 128, 256, 384}]
   double2 c128, c256, c384;   // pass 1 (wave-uniform): tw[128], tw[256], tw[384]  (tw[0] = 1 is not multiplied)
-  const double2* tw_lo;       // tw + lane:        post / pre-processing twiddles of registers 0 .. 3 (+ 64 q)
-  const double2* tw_hi;       // tw + (64 - lane): ... of registers 4 .. 7 (+ 64 (7 - q))
+  const double2* tw_lo;       // (table) tw + lane:        post / pre-processing twiddles of registers 0 .. 3 (+ 64 q)
+  const double2* tw_hi;       // (table) tw + (64 - lane): ... of registers 4 .. 7 (+ 64 (7 - q))
   double2* x1w;         // exchange 1, store base: slot lane             (+ bitrev3(q) * PITCH)
   double2* x1r;         // exchange 1, load base:  slot (lane & 7) * PITCH + (lane >> 3)   (+ 8 q)
   double2* x2w;         // exchange 2, store base: slot (lane & 7) + 64 bitrev3(lane >> 3) (+ 8 bitrev3(q))
@@ -65,6 +65,7 @@ __device__ __forceinline__ void table512_init(void* table, const double2* __rest
     const int idx = e == 0 ? 8 * m : (e < 3 ? 4 * m + 256 * (e - 1) : 2 * m + 128 * (e - 3));
     t[56 + i] = tw[idx];
   }
+  for (int i = threadIdx.x; i <= 256; i += blockDim.x) t[504 + i] = tw[i];
   __syncthreads();
 }
 
@@ -76,8 +77,8 @@ __device__ __forceinline__ void plan512_init(Plan512& p, const double2* __restri
   p.c128 = tw[128];
   p.c256 = tw[256];
   p.c384 = tw[384];
-  p.tw_lo = tw + l;
-  p.tw_hi = tw + (64 - l);
+  p.tw_lo = reinterpret_cast<const double2*>(table) + 504 + l;
+  p.tw_hi = reinterpret_cast<const double2*>(table) + 504 + (64 - l);
   double2* s = reinterpret_cast<double2*>(lds);
   p.x1w = s + l;
   p.x1r = s + a * WF_PITCH + (l >> 3);
@@ -87,14 +88,14 @@ __device__ __forceinline__ void plan512_init(Plan512& p, const double2* __restri
 }
 
 // the one complex product every stage uses (same expression as wd::fft_lds: same contraction)
-template <int SIGN>
-__device__ __forceinline__ double2 twmul(const double2 v, const double2 w) {
-  const double wi = SIGN < 0 ? -w.y : w.y;
+// (the sign of the transform is a run-time +-1.0 so that forward and inverse transforms share one copy
+// of the code: w.y * -1.0 is exactly -w.y)
+__device__ __forceinline__ double2 twmul(const double2 v, const double2 w, const double sgn) {
+  const double wi = w.y * sgn;
   return make_double2(v.x * w.x - v.y * wi, v.x * wi + v.y * w.x);
 }
-template <int SIGN>
-__device__ __forceinline__ void bfly(double2& a, double2& b, const double2 w) {
-  const double2 x = twmul<SIGN>(b, w);
+__device__ __forceinline__ void bfly(double2& a, double2& b, const double2 w, const double sgn) {
+  const double2 x = twmul(b, w, sgn);
   const double2 a0 = a;
   a = make_double2(a0.x + x.x, a0.y + x.y);
   b = make_double2(a0.x - x.x, a0.y - x.y);
@@ -106,13 +107,12 @@ __device__ __forceinline__ void bfly1(double2& a, double2& b) {
   b = make_double2(a0.x - x.x, a0.y - x.y);
 }
 
-// In-place 512-point complex FFT of layout A.  SIGN = -1: forward, +1: unnormalised inverse.
-template <int SIGN>
-__device__ __forceinline__ void cfft512(double2 (&z)[8], const Plan512& p) {
+// In-place 512-point complex FFT of layout A.  sgn = -1.0: forward, +1.0: unnormalised inverse.
+__device__ __forceinline__ void cfft512(double2 (&z)[8], const Plan512& p, const double sgn) {
   // pass 1 (stages 1 .. 3): register q holds local position bitrev3(q) of eight consecutive points
   bfly1(z[0], z[4]); bfly1(z[2], z[6]); bfly1(z[1], z[5]); bfly1(z[3], z[7]);
-  bfly1(z[0], z[2]); bfly<SIGN>(z[4], z[6], p.c256); bfly1(z[1], z[3]); bfly<SIGN>(z[5], z[7], p.c256);
-  bfly1(z[0], z[1]); bfly<SIGN>(z[4], z[5], p.c128); bfly<SIGN>(z[2], z[3], p.c256); bfly<SIGN>(z[6], z[7], p.c384);
+  bfly1(z[0], z[2]); bfly(z[4], z[6], p.c256, sgn); bfly1(z[1], z[3]); bfly(z[5], z[7], p.c256, sgn);
+  bfly1(z[0], z[1]); bfly(z[4], z[5], p.c128, sgn); bfly(z[2], z[3], p.c256, sgn); bfly(z[6], z[7], p.c384, sgn);
   // exchange 1
   p.x1w[0 * WF_PITCH] = z[0]; p.x1w[4 * WF_PITCH] = z[1]; p.x1w[2 * WF_PITCH] = z[2]; p.x1w[6 * WF_PITCH] = z[3];
   p.x1w[1 * WF_PITCH] = z[4]; p.x1w[5 * WF_PITCH] = z[5]; p.x1w[3 * WF_PITCH] = z[6]; p.x1w[7 * WF_PITCH] = z[7];
@@ -122,11 +122,11 @@ __device__ __forceinline__ void cfft512(double2 (&z)[8], const Plan512& p) {
   // pass 2 (stages 4 .. 6), same register pairing
   {
     const double2 w0 = p.t2[0];
-    bfly<SIGN>(z[0], z[4], w0); bfly<SIGN>(z[2], z[6], w0); bfly<SIGN>(z[1], z[5], w0); bfly<SIGN>(z[3], z[7], w0);
+    bfly(z[0], z[4], w0, sgn); bfly(z[2], z[6], w0, sgn); bfly(z[1], z[5], w0, sgn); bfly(z[3], z[7], w0, sgn);
     const double2 w1 = p.t2[8], w2 = p.t2[16];
-    bfly<SIGN>(z[0], z[2], w1); bfly<SIGN>(z[4], z[6], w2); bfly<SIGN>(z[1], z[3], w1); bfly<SIGN>(z[5], z[7], w2);
+    bfly(z[0], z[2], w1, sgn); bfly(z[4], z[6], w2, sgn); bfly(z[1], z[3], w1, sgn); bfly(z[5], z[7], w2, sgn);
     const double2 w3 = p.t2[24], w4 = p.t2[32], w5 = p.t2[40], w6 = p.t2[48];
-    bfly<SIGN>(z[0], z[1], w3); bfly<SIGN>(z[4], z[5], w4); bfly<SIGN>(z[2], z[3], w5); bfly<SIGN>(z[6], z[7], w6);
+    bfly(z[0], z[1], w3, sgn); bfly(z[4], z[5], w4, sgn); bfly(z[2], z[3], w5, sgn); bfly(z[6], z[7], w6, sgn);
   }
   wave_sync();          // every lane has its exchange-1 values before the buffer is rewritten
   // exchange 2 (natural order: slot = position)
@@ -138,46 +138,53 @@ __device__ __forceinline__ void cfft512(double2 (&z)[8], const Plan512& p) {
   // pass 3 (stages 7 .. 9): register c holds position lane + 64 c
   {
     const double2 w0 = p.t3[0];
-    bfly<SIGN>(z[0], z[1], w0); bfly<SIGN>(z[2], z[3], w0); bfly<SIGN>(z[4], z[5], w0); bfly<SIGN>(z[6], z[7], w0);
+    bfly(z[0], z[1], w0, sgn); bfly(z[2], z[3], w0, sgn); bfly(z[4], z[5], w0, sgn); bfly(z[6], z[7], w0, sgn);
     const double2 w1 = p.t3[64], w2 = p.t3[128];
-    bfly<SIGN>(z[0], z[2], w1); bfly<SIGN>(z[1], z[3], w2); bfly<SIGN>(z[4], z[6], w1); bfly<SIGN>(z[5], z[7], w2);
+    bfly(z[0], z[2], w1, sgn); bfly(z[1], z[3], w2, sgn); bfly(z[4], z[6], w1, sgn); bfly(z[5], z[7], w2, sgn);
     const double2 w3 = p.t3[192], w4 = p.t3[256], w5 = p.t3[320], w6 = p.t3[384];
-    bfly<SIGN>(z[0], z[4], w3); bfly<SIGN>(z[1], z[5], w4); bfly<SIGN>(z[2], z[6], w5); bfly<SIGN>(z[3], z[7], w6);
+    bfly(z[0], z[4], w3, sgn); bfly(z[1], z[5], w4, sgn); bfly(z[2], z[6], w5, sgn); bfly(z[3], z[7], w6, sgn);
   }
   wave_sync();          // the buffer is free for the caller (and for the next transform)
 }
 
-// Stores layout A to the natural slots and fetches every register's mirror partner 512 - m
-// (lane 0, register 0 reads slot 512: unused by the callers).
-__device__ __forceinline__ void partners(const double2 (&z)[8], double2 (&pz)[8], const Plan512& p) {
+// Stores layout A to the natural slots; partner(q) then fetches the mirror element 512 - m of register q
+// (lane 0, register 0 reads slot 512: unused by the callers).  The callers fetch the partners four at
+// a time (eight more complex registers in flight do not fit beside a frame kernel's own state).
+__device__ __forceinline__ void partners_store(const double2 (&z)[8], const Plan512& p) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) p.x2r[64 * q] = z[q];
   wave_sync();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) pz[q] = p.xpr[64 * (7 - q)];
-  wave_sync();
 }
+__device__ __forceinline__ double2 partner(const Plan512& p, int q) { return p.xpr[64 * (7 - q)]; }
 
 // Real transform of 1024 samples x, packed as z[m] = (x[2m], x[2m+1]) in layout A.  On return
 // z[q] = X[lane + 64 q] (numpy.fft.rfft), and x512 = X[512] (valid in lane 0, computed by all).
 __device__ __forceinline__ void rfft1024(double2 (&z)[8], double2& x512, const Plan512& p) {
-  cfft512<-1>(z, p);
-  double2 pz[8];
-  partners(z, pz, p);
+  cfft512(z, p, -1.0);
+  partners_store(z, p);
   const int l = lane_id();
   const double2 z0 = z[0];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const bool lo = q < 4;                        // m < 256: the "k" output of the pair (k, 512 - k); else its "j" output
-    const double2 zk = lo ? z[q] : pz[q], zj = lo ? pz[q] : z[q];
-    const double2 w = lo ? p.tw_lo[64 * q] : p.tw_hi[64 * (7 - q)];
-    const double er = 0.5 * (zk.x + zj.x), ei = 0.5 * (zk.y - zj.y);
-    const double dr = 0.5 * (zk.x - zj.x), di = 0.5 * (zk.y + zj.y);
-    const double orr = di, oi = -dr;  // O = -i D
-    const double wr = w.x, wi = -w.y;  // w^k = e^{-2 pi i k / n}
-    const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
-    z[q] = lo ? make_double2(er + tr, ei + ti) : make_double2(er - tr, -(ei - ti));
+  for (int q0 = 0; q0 < 8; q0 += 4) {
+    double2 pz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pz[i] = partner(p, q0 + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + i;
+      const bool lo = q < 4;                        // m < 256: the "k" output of the pair (k, 512 - k); else its "j" output
+      const double2 zk = lo ? z[q] : pz[i], zj = lo ? pz[i] : z[q];
+      const double2 w = lo ? p.tw_lo[64 * q] : p.tw_hi[64 * (7 - q)];
+      const double er = 0.5 * (zk.x + zj.x), ei = 0.5 * (zk.y - zj.y);
+      const double dr = 0.5 * (zk.x - zj.x), di = 0.5 * (zk.y + zj.y);
+      const double orr = di, oi = -dr;  // O = -i D
+      const double wr = w.x, wi = -w.y;  // w^k = e^{-2 pi i k / n}
+      const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
+      z[q] = lo ? make_double2(er + tr, ei + ti) : make_double2(er - tr, -(ei - ti));
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  wave_sync();
   if (l == 0) z[0] = make_double2(z0.x + z0.y, 0.0);
   x512 = make_double2(z0.x - z0.y, 0.0);
 }
@@ -186,26 +193,32 @@ __device__ __forceinline__ void rfft1024(double2 (&z)[8], double2& x512, const P
 // packed as z[m] = (x[2m], x[2m+1]) in layout A, normalised like numpy.fft.irfft.
 __device__ __forceinline__ void irfft1024(double2 (&z)[8], const double2 x512, const Plan512& p) {
   const int l = lane_id();
-  double2 pz[8];
-  partners(z, pz, p);
-  if (l == 0) {          // k = 0: the imaginary parts of X[0] and X[512] are ignored
-    z[0].y = 0.0;
-    pz[0] = make_double2(x512.x, 0.0);
-  }
+  partners_store(z, p);
+  if (l == 0) z[0].y = 0.0;          // k = 0: the imaginary parts of X[0] and X[512] are ignored
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const bool lo = q < 4;
-    const double2 xk = lo ? z[q] : pz[q], xj = lo ? pz[q] : z[q];
-    const double2 w = lo ? p.tw_lo[64 * q] : p.tw_hi[64 * (7 - q)];  // conj(w^k) = e^{+2 pi i k / n}
-    const double er = 0.5 * (xk.x + xj.x), ei = 0.5 * (xk.y - xj.y);
-    const double dr = 0.5 * (xk.x - xj.x), di = 0.5 * (xk.y + xj.y);
-    const double orr = dr * w.x - di * w.y, oi = dr * w.y + di * w.x;
-    const double2 zk = make_double2(er - oi, ei + orr);
-    const double2 zj = make_double2(er + oi, -ei + orr);
-    // m = 256 (lane 0, register 4) pairs with itself and takes the "k" form, like every m <= 256
-    z[q] = (lo || (q == 4 && l == 0)) ? zk : zj;
+  for (int q0 = 0; q0 < 8; q0 += 4) {
+    double2 pz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pz[i] = partner(p, q0 + i);
+    if (q0 == 0 && l == 0) pz[0] = make_double2(x512.x, 0.0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + i;
+      const bool lo = q < 4;
+      const double2 xk = lo ? z[q] : pz[i], xj = lo ? pz[i] : z[q];
+      const double2 w = lo ? p.tw_lo[64 * q] : p.tw_hi[64 * (7 - q)];  // conj(w^k) = e^{+2 pi i k / n}
+      const double er = 0.5 * (xk.x + xj.x), ei = 0.5 * (xk.y - xj.y);
+      const double dr = 0.5 * (xk.x - xj.x), di = 0.5 * (xk.y + xj.y);
+      const double orr = dr * w.x - di * w.y, oi = dr * w.y + di * w.x;
+      const double2 zk = make_double2(er - oi, ei + orr);
+      const double2 zj = make_double2(er + oi, -ei + orr);
+      // m = 256 (lane 0, register 4) pairs with itself and takes the "k" form, like every m <= 256
+      z[q] = (lo || (q == 4 && l == 0)) ? zk : zj;
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  cfft512<+1>(z, p);
+  wave_sync();
+  cfft512(z, p, +1.0);
   const double s = 1.0 / (double)WF_N;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -214,12 +227,13 @@ __device__ __forceinline__ void irfft1024(double2 (&z)[8], const double2 x512, c
   }
 }
 
-// A real sequence given per spectral index in layout A (v[q] = x[lane + 64 q], v512 = x[512], zero
-// beyond unless `even`: x[1024 - n] = x[n]) -> packed z[m] = (x[2m], x[2m+1]) in layout A.
-template <bool EVEN>
-__device__ __forceinline__ void pack_real(const double (&v)[8], const double v512, double2 (&z)[8], const Plan512& p) {
-  double* s = reinterpret_cast<double*>(p.x2r) - lane_id() * 2;      // the wave's buffer as doubles
+// A real sequence given per spectral index in layout A (v[q] = x[lane + 64 q], v512 = x[512]) ->
+// packed z[m] = (x[2m], x[2m+1]) in layout A.  even: x[1024 - n] = x[n]; otherwise zero beyond 512.
+// (`even` is a run-time flag so that the two transforms of a minimum-phase construction share code.)
+__device__ __forceinline__ void pack_real(const double (&v)[8], const double v512, double2 (&z)[8], const Plan512& p,
+                                          const bool even) {
   const int l = lane_id();
+  double* s = reinterpret_cast<double*>(p.x2r) - l * 2;      // the wave's buffer as doubles
 #pragma unroll
   for (int q = 0; q < 8; ++q) s[l + 64 * q] = v[q];
   if (l == 0) { s[512] = v512; s[513] = 0.0; }
@@ -227,17 +241,13 @@ __device__ __forceinline__ void pack_real(const double (&v)[8], const double v51
   const double2* s2 = reinterpret_cast<const double2*>(s);
 #pragma unroll
   for (int q = 0; q < 4; ++q) z[q] = s2[l + 64 * q];                  // m < 256: (x[2m], x[2m+1])
-  if (EVEN) {
-    // m >= 256: (x[1024 - 2m], x[1023 - 2m]); m = 256 (lane 0): (x[512], x[511])
+  // m >= 256, even: (x[1024 - 2m], x[1023 - 2m]); m = 256 (lane 0): (x[512], x[511] or 0)
 #pragma unroll
-    for (int q = 4; q < 8; ++q) {
-      const int n = 1024 - 2 * (l + 64 * q);        // 512 .. 2
-      z[q] = make_double2(s[n], s[n - 1]);
-    }
-  } else {
-#pragma unroll
-    for (int q = 4; q < 8; ++q) z[q] = make_double2(0.0, 0.0);
-    if (l == 0) z[4] = make_double2(s[512], 0.0);
+  for (int q = 4; q < 8; ++q) {
+    const int n = 1024 - 2 * (l + 64 * q);        // 512 .. 2
+    const double a = s[n], b = s[n - 1];
+    const bool first = q == 4 && l == 0;          // m = 256
+    z[q] = make_double2((even || first) ? a : 0.0, even ? b : 0.0);
   }
   wave_sync();
 }

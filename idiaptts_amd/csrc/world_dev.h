@@ -31,22 +31,40 @@ __device__ __forceinline__ int tid() {
   return t;
 }
 
-// log / sincos / cos of the per-bin loops: the short forms of fastmath.h on their domains (positive
-// normal numbers; |x| <= 1e5), the library call otherwise (a branch no lane takes on speech).
+// log / sincos / cos of the per-bin loops: the short forms of fastmath.h.  log_pos is total (zero,
+// negative, subnormal, infinite and NaN arguments give what log() gives) through a few selects; the
+// trigonometric ones hand arguments beyond 1e5 radians to the library in ONE out-of-line copy per
+// function (inlined at every call site the never-taken slow paths were 45 % of the pulse kernel's
+// code, which no longer fitted the instruction cache).
 __device__ __forceinline__ double log_pos(double x) {
-  if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) return log(x);
-  return fm::flog(x);
+  const bool sub = x < 2.2250738585072014e-308;                    // subnormal (or <= 0: fixed below)
+  const double r0 = fm::flog(sub ? x * 18014398509481984.0 : x);   // 2^54
+  double r = sub ? r0 - 37.429947750237048 : r0;                   // 54 ln 2
+  r = x == 0.0 ? -__builtin_huge_val() : r;
+  r = x < 0.0 ? __builtin_nan("") : r;
+  r = x == __builtin_huge_val() ? x : r;
+  return r;
+}
+__device__ __attribute__((noinline)) double2 sincos_far(double x) {
+  double s, c;
+  sincos(x, &s, &c);
+  return make_double2(s, c);
 }
 __device__ __forceinline__ void sincos_mid(double x, double* sn, double* cs) {
-  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) { sincos(x, sn, cs); return; }
+  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) {
+    const double2 r = sincos_far(x);
+    *sn = r.x;
+    *cs = r.y;
+    return;
+  }
   fm::fsincos(x, sn, cs);
 }
 __device__ __forceinline__ double cos_mid(double x) {
-  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) return cos(x);
+  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) return sincos_far(x).y;
   return fm::fcos(x);
 }
 __device__ __forceinline__ double sin_mid(double x) {
-  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) return sin(x);
+  if (__builtin_expect(!(fabs(x) <= 1e5), 0)) return sincos_far(x).x;
   return fm::fsin(x);
 }
 

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256, 2) void new_kernel(const double2* in, double2*
     for (int q = 0; q < 8; ++q) z[q] = in[(size_t)item * 513 + l + 64 * q];
     if (mode == 3) x512 = in[(size_t)item * 513 + 512];
     for (int r = 0; r < reps; ++r) {
-      if (mode == 0) wf::cfft512<-1>(z, p);
-      else if (mode == 1) wf::cfft512<+1>(z, p);
+      if (mode == 0) wf::cfft512(z, p, -1.0);
+      else if (mode == 1) wf::cfft512(z, p, +1.0);
       else if (mode == 2) wf::rfft1024(z, x512, p);
       else wf::irfft1024(z, x512, p);
     }
