@@ -172,9 +172,9 @@ def host_info():
 def cpu_baseline_bilstm(max_seconds=25.0, threads=None):
     """The reference's config-3 stack on the host: torch.nn.LSTM(425, 512, 3, bidirectional) on a
     PackedSequence (rnn_dyn/RNNWrapper.py:45-107) + Linear(1024, 187), masked MSE mean_per_frame,
-    Adam.  Bounded sample: one training step on 16 of config 3's 64 padded utterances (after a
-    warm-up step on two); if four times that step fits what is left of the budget, one step on the
-    full 64-utterance batch is run and reported instead.  The sample says which."""
+    Adam.  Bounded sample: one training step on the first utterances of config 3's batch, as many as
+    the budget allows at the ~50 frames/s torch's CPU LSTM reaches; the sample says how many and what
+    the full batch extrapolates to."""
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     from idiaptts_amd.bench_support import make_ff_batch, pad_batch
     torch.manual_seed(0)
@@ -201,17 +201,25 @@ def cpu_baseline_bilstm(max_seconds=25.0, threads=None):
         opt.step()
         return time.perf_counter() - t, int(lt.sum())
 
+    # torch's CPU LSTM runs ~50 valid frames/s on these hosts (16 threads; measured in this repository's
+    # rounds 3 and 4 on 4 and 16 utterances): config 3's 73 138-frame batch would take over twenty
+    # minutes per step.  The bounded sample: a tiny warm-up batch (thread pool, allocations), then one
+    # timed step on as many of the batch's utterances as the budget allows at that rate (at least one).
     t_start = time.perf_counter()
+    lengths_all = lengths
+    lengths = np.minimum(lengths_all, 40)
+    offs = np.concatenate([[0], np.cumsum(lengths)])
     step(2)
-    dt, frames = step(16)
-    n_used = 16
-    if 4.2 * dt < max_seconds - (time.perf_counter() - t_start):
-        dt, frames = step(64)
-        n_used = 64
+    lengths = lengths_all
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    budget_frames = max(0.0, max_seconds - (time.perf_counter() - t_start)) * 50.0
+    n_used = int(max(1, min(64, np.searchsorted(np.cumsum(lengths), budget_frames))))
+    dt, frames = step(n_used)
     note = "config 3's full batch" if n_used == 64 else \
-        ("16 of config 3's 64 utterances: the full batch was predicted at {:.0f} s, beyond the budget; the "
-         "host's cost is linear in the frames (same T, a quarter of the rows per step), so the rate "
-         "stands for the full batch to within the GEMMs' batch efficiency".format(4 * dt))
+        ("{} of config 3's 64 utterances: at this rate the full batch of 73 138 frames takes {:.0f} s per "
+         "step; the host's cost is linear in the frames (the recurrence is sequential in T whatever the "
+         "batch), larger batches amortise slightly better (rounds 3 / 4: 44 frames/s on 4 utterances, 55 on "
+         "16)".format(n_used, 73138.0 * dt / frames))
     return {"kind": "port", "cores": torch.get_num_threads(), "value": frames / dt,
             "unit": "valid frames/s", "utterances": n_used,
             "sample": "1 training step of torch.nn.LSTM(425,512,3,bidirectional)+Linear on {} padded "
@@ -762,19 +770,34 @@ class SclkSampler:
 
 
 def visible_gpus():
-    """Number of GPUs this process may use, WITHOUT touching HIP: the compute nodes of the KFD
-    topology (sysfs) that have SIMDs, cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
-    CUDA_VISIBLE_DEVICES when one of them is set."""
+    """Number of GPUs this process may use, WITHOUT touching HIP in this process: the compute nodes of
+    the KFD topology (sysfs) that have SIMDs AND whose render node this user can open (a container or
+    cgroup may show the topology of the whole machine but grant only some /dev/dri/renderD* nodes), cut
+    down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them is set.
+    When sysfs gives no answer a child interpreter asks torch.cuda.device_count()."""
     import glob
     n = 0
     for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
         try:
             with open(path) as f:
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            if int(props.get("simd_count", "0")) > 0:
-                n += 1
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            node = "/dev/dri/renderD%d" % minor
+            if minor >= 0 and os.path.exists("/dev/dri") and not os.access(node, os.R_OK | os.W_OK):
+                continue
+            n += 1
         except (OSError, ValueError):
             pass
+    if n == 0:
+        import subprocess
+        try:
+            res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+            n = int(res.stdout.strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+            n = 0
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -812,6 +835,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--utts-per-gpu", type=int, default=32)
+    ap.add_argument("--dump-steps", action="store_true", help="every timed step's duration in the JSON line")
     ap.add_argument("--ramp-steps", type=int, default=80,
                     help="untimed steps run before the --warmup steps so that the shader clock has "
                          "settled (about 1 ms each; 0 = none); reported as clock_ramp in the JSON line")
@@ -915,21 +939,28 @@ def main():
     for i in range(args.warmup):
         step(i)
 
-    # everything the timed region needs is created BEFORE the barrier: between the synchronize and the
-    # first launch the GPU idles, and every millisecond of that costs clock afterwards
+    # everything the timed region needs is created BEFORE the barrier
     stream = torch.cuda.current_stream()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    clock = SclkSampler(local_rank, period_s=0.001)
+    barrier()
+    t0 = time.perf_counter()
+    evs[0].record(stream)
+    for i in range(args.steps):
+        step(i)
+        evs[i + 1].record(stream)
+    t_launched = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+    # The shader clock is sampled AFTER the timed region, over 60 more steps of the same load.  Rounds 2
+    # and 3 sampled it (sysfs pp_dpm_sclk, from a thread) DURING the timed steps, and that was the "fixed
+    # 2 ms" of the driver's 20-step protocol: the first ~20 ms of such reads slow every step by 10-40 %
+    # (per-step events, profiles/r4m_step_traces.txt: 1.13 ms per step with the sampler, 1.007 without,
+    # same box, same binary) -- the instrument was perturbing the measurement.
+    clock = SclkSampler(local_rank, period_s=0.002)
     with clock:
-        barrier()
-        t0 = time.perf_counter()
-        evs[0].record(stream)
-        for i in range(args.steps):
+        for i in range(60):
             step(i)
-            evs[i + 1].record(stream)
-        t_launched = time.perf_counter() - t0
-        barrier()
-        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
     dt_events = evs[0].elapsed_time(evs[-1]) * 1e-3
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if dist_on:
@@ -1010,7 +1041,7 @@ def main():
                     "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
                     "algorithmic_flops_per_launch": flops / n_launch,
                     "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / n_launch,
-                    "shader_clock_during_timed_steps": clock.summary()}
+                    "shader_clock_under_the_same_load_after_the_timed_steps": clock.summary()}
         cpu = None
         if want_cpu:   # CPU baseline: rank 0 at N = 1 only
             cpu = cpu_baseline_ff(args.utts_per_gpu, max_seconds=min(20.0, args.cpu_budget_s / 4))
@@ -1046,6 +1077,7 @@ def main():
                              "step_ms_first8": [round(v, 4) for v in step_ms[:8]],
                              "step_ms_median": float(np.median(step_ms)),
                              "step_ms_max": float(np.max(step_ms)),
+                             **({"step_ms_all": [round(v, 4) for v in step_ms]} if args.dump_steps else {}),
                              "note": "value and ms_per_step are the wall clock (barrier + synchronize on "
                                      "both sides, max over ranks); the event pair brackets the same K "
                                      "steps on the launch stream"},

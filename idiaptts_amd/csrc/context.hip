@@ -474,14 +474,18 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
 }
 
 namespace {
+// A ring of page-locked staging slots per device.  32 slots: an entry point uploads two or three
+// small tables, so the host may run ~10 entry points ahead of the GPU before it has to wait for a slot.
+constexpr unsigned kStageSlots = 32;
 struct StageSlot {
   void* p = nullptr;
   size_t cap = 0;
   hipEvent_t ev = nullptr;
-  bool pending = false;
+  bool pending = false;    // a copy out of this slot may still be in flight (ev marks its end)
+  bool busy = false;       // a thread is filling this slot right now
 };
 struct StageRing {
-  StageSlot slot[4];
+  StageSlot slot[kStageSlots];
   unsigned next = 0;
 };
 std::mutex g_stage_mutex;
@@ -492,26 +496,62 @@ int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return ITTS_OK;
   int dev = 0;
   ITTS_HIP_CHECK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_stage_mutex);
-  StageRing& ring = g_stage[dev];
-  StageSlot& sl = ring.slot[ring.next++ & 3u];
-  if (sl.pending) {                       // the copy that last used this slot has left it
-    ITTS_HIP_CHECK(hipEventSynchronize(sl.ev));
-    sl.pending = false;
+  StageSlot* sl = nullptr;
+  hipEvent_t wait_for = nullptr;
+  {
+    // the mutex only covers the choice of a slot: waiting for the slot's last copy (another stream's
+    // queue may be long) and growing it happen outside, so that other threads keep uploading
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    StageRing& ring = g_stage[dev];
+    for (unsigned tries = 0; tries < kStageSlots && !sl; ++tries) {
+      StageSlot& c = ring.slot[ring.next++ % kStageSlots];
+      if (!c.busy) sl = &c;
+    }
+    if (!sl) {
+      set_error("staged_upload: every staging slot is being filled by another thread");
+      return ITTS_E_HIP;
+    }
+    sl->busy = true;
+    if (sl->pending) wait_for = sl->ev;
   }
-  if (sl.cap < bytes) {
-    if (sl.p) ITTS_HIP_CHECK(hipHostFree(sl.p));
-    sl.p = nullptr;
-    sl.cap = 0;
+  auto release = [&](bool pending) {
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    sl->pending = pending;
+    sl->busy = false;
+  };
+  hipError_t e = hipSuccess;
+  if (wait_for) e = hipEventSynchronize(wait_for);        // the copy that last used this slot has left it
+  if (e == hipSuccess && sl->cap < bytes) {
+    if (sl->p) (void)hipHostFree(sl->p);
+    sl->p = nullptr;
+    sl->cap = 0;
     const size_t cap = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
-    ITTS_HIP_CHECK(hipHostMalloc(&sl.p, cap, hipHostMallocDefault));
-    sl.cap = cap;
+    e = hipHostMalloc(&sl->p, cap, hipHostMallocDefault);
+    if (e == hipSuccess) sl->cap = cap;
   }
-  if (!sl.ev) ITTS_HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-  std::memcpy(sl.p, src, bytes);
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_dst, sl.p, bytes, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipEventRecord(sl.ev, s));
-  sl.pending = true;
+  if (e == hipSuccess && !sl->ev) e = hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    release(false);
+    set_error(std::string("staged_upload: ") + hipGetErrorString(e));
+    return ITTS_E_HIP;
+  }
+  std::memcpy(sl->p, src, bytes);
+  e = hipMemcpyAsync(d_dst, sl->p, bytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    release(false);
+    set_error(std::string("staged_upload: ") + hipGetErrorString(e));
+    return ITTS_E_HIP;
+  }
+  // from here on the slot is in use by the queued copy whatever happens next: if the event cannot be
+  // recorded the copy is waited for on the spot rather than leaving the slot to be overwritten under it
+  e = hipEventRecord(sl->ev, s);
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(s);
+    release(false);
+    set_error(std::string("staged_upload: ") + hipGetErrorString(e));
+    return ITTS_E_HIP;
+  }
+  release(true);
   return ITTS_OK;
 }
 

@@ -696,8 +696,7 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
   // the 16-byte loads of A cover k .. k+3: past the end of a row (and of the last row's buffer)
   // unless K is a multiple of 4 or the caller's buffer has that slack
   const bool vec = lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (a_has_slack || K % 4 == 0);
-  static const bool staged_on = [] { const char* e = getenv("ITTS_GEMM_F64_STAGED"); return !(e && e[0] == '0'); }();
-  if (staged_on && K > 64 && T >= 1024) {      // long K, enough rows to fill the chip: the staged kernel
+  if (K > 64 && T >= 1024) {      // long K, enough rows to fill the chip: the staged kernel
     static bool attr_set = false;
     if (!attr_set) {
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_staged_kernel<true>,
@@ -706,8 +705,7 @@ int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
       attr_set = true;
     }
-    static const bool lds_on = [] { const char* e = getenv("ITTS_GEMM_F64_LDS"); return !(e && e[0] == '0'); }();
-    if (vec && lds_on) {
+    if (vec) {
       static bool attr2 = false;
       if (!attr2) {
         ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_lds_kernel,

@@ -11,17 +11,15 @@
 // one (utterance, dimension); a wave owns 64 neighbouring dimensions so every row access is one
 // coalesced 512-B segment.
 //
-// What is in this file, in the order it was built (ITTS_MLPG_PATH selects; the last is the default):
+// What is in this file:
 //   mlpg_factor_kernel          the data-independent Cholesky factor, once per dimension, shared by
 //                               all utterances (stops when it repeats)
-//   mlpg_kernel ("seq")         the two sweeps frame by frame (batches of short utterances)
-//   mlpg_transfer / mlpg_chunk  ("multipass") both sweeps as affine scans over 64-frame chunks, four
-//                               passes over memory
-//   mlpg_fused_kernel ("fused") one pass: chunks held in registers, aggregates exchanged between
-//                               workgroups through memory (ticket order, polling)
-//   mlpg_prep / reduce / scan / solve ("stream") no wait anywhere: the backward contribution of a
-//                               chunk is accumulated while walking forward (adjoint identity), a
+//   mlpg_kernel                 the two sweeps frame by frame: batches of short utterances
+//   mlpg_prep / reduce / scan / solve   everything else, no wait anywhere: the backward contribution of
+//                               a chunk is accumulated while walking forward (adjoint identity), a
 //                               two-level scan gives every chunk its entry states, a second pass solves
+// (Rounds 2 and 3 also carried a four-pass chunked solve and a single-pass kernel with cross-workgroup
+// waits; both measured slower -- DESIGN.md section 11c -- and left the library in round 4.)
 //
 // Roofline: HBM.  Algorithmic bytes per frame = 187*8 read + 63*8 written = 2000 B
 // (SURVEY.md section 8d); measured traffic and rates: DESIGN.md section 11c.
@@ -52,20 +50,9 @@ struct MlpgArgs {
   double* scratch;  // 3 planes [Ttot, dim]: 1/d, l1, l2 (shared factor) + nconv
   int64_t t_total;
   int* nconv;       // [dim] frame index where the shared factor becomes stationary
-  // time-parallel solve (see mlpg_chunk_kernel)
-  double* mf;       // [kmax][4][dim] forward transfer matrices of the shared-factor chunks
-  double* mb;       // [kmax][4][dim] backward transfer matrices
-  double* ends;     // [slots][2][dim] chunk end states of the sweep in progress
-  int kmax;
 };
 
-constexpr int MLPG_CL = 64;   // frames per chunk of the time-parallel solve
-
-// chunks of an utterance of T frames: all of length MLPG_CL except the last one, which takes the
-// remainder plus a full chunk so that it always holds the two re-derived tail frames
-__device__ __host__ inline int mlpg_num_chunks(int64_t T) {
-  return (int)std::max<int64_t>(1, (T - 2) / MLPG_CL);
-}
+constexpr int MLPG_SEQ_BELOW = 194;   // utterances shorter than this take the sequential sweeps (three 64-frame chunks + tail)
 
 // The Cholesky factor of P depends on the variances and on the frame index only (not on the
 // data), and -- because the delta variances are constant except in the first and last frame --
@@ -281,310 +268,8 @@ __global__ __launch_bounds__(MLPG_LANES) void mlpg_kernel(MlpgArgs a, int t_max)
   }
 }
 
-// ---- time-parallel solve -------------------------------------------------------------------------
-// Both sweeps are second-order linear recurrences, y_j = (b_j - l1p_j y_{j-1} - l2p_j y_{j-2}) / d_j
-// and its mirror image, so they parallelise over time as an affine prefix scan: cut every
-// utterance into chunks of MLPG_CL frames; a chunk maps the two values that enter it to the two
-// that leave it by  s_out = M s_in + e,  where M (2 x 2) only depends on the factor -- i.e. on
-// (dimension, chunk index), the factor being shared by all utterances -- and e is what the
-// chunk produces from a zero state.
-//   pass A  every chunk runs the recurrence from zero and keeps e           (parallel)
-//   pass B  every chunk folds the (M, e) of the chunks before it into its true entry state (at
-//           most ~30 tiny steps) and runs the recurrence again, now writing    (parallel)
-// Twice the arithmetic of the sequential sweep, ~T/64 times the parallelism: a batch of 256
-// utterances x 62 dimensions keeps ~300 k lanes busy instead of 16 k.  The arithmetic inside a
-// chunk is the sequential algorithm's; only the entry state of a chunk is rounded differently.
-__global__ __launch_bounds__(64) void mlpg_transfer_kernel(MlpgArgs a, int t_max) {
-  const int d = blockIdx.x * 64 + threadIdx.x;
-  const int k = blockIdx.y;
-  if (d >= a.dim) return;
-  const int D = a.dim;
-  const int64_t plane = (int64_t)t_max * D;
-  const double* fd = a.scratch + d;
-  const double* fl1 = fd + plane;
-  const double* fl2 = fl1 + plane;
-  const int64_t ncv = a.nconv[d];
-  auto F = [&](const double* pl, int64_t j) { return j < 0 ? 0.0 : pl[(j < ncv ? j : ncv) * D]; };
-  const int64_t j0 = (int64_t)k * MLPG_CL, j1 = j0 + MLPG_CL;
-  // forward: columns of M are the images of (y_{j0-1}, y_{j0-2}) = (1,0), (0,1)
-  for (int c = 0; c < 2; ++c) {
-    double y1 = c == 0 ? 1.0 : 0.0, y2 = c == 0 ? 0.0 : 1.0;
-    for (int64_t j = j0; j < j1; ++j) {
-      const double y = (-F(fl1, j - 1) * y1 - F(fl2, j - 2) * y2) * F(fd, j);
-      y2 = y1;
-      y1 = y;
-    }
-    a.mf[((int64_t)k * 4 + c) * D + d] = y1;        // M[0][c]
-    a.mf[((int64_t)k * 4 + 2 + c) * D + d] = y2;    // M[1][c]
-  }
-  // backward: images of (x_{j1}, x_{j1+1}) on (x_{j0}, x_{j0+1})
-  for (int c = 0; c < 2; ++c) {
-    double x1 = c == 0 ? 1.0 : 0.0, x2 = c == 0 ? 0.0 : 1.0;
-    for (int64_t j = j1 - 1; j >= j0; --j) {
-      const double x = (-F(fl1, j) * x1 - F(fl2, j) * x2) * F(fd, j);
-      x2 = x1;
-      x1 = x;
-    }
-    a.mb[((int64_t)k * 4 + c) * D + d] = x1;
-    a.mb[((int64_t)k * 4 + 2 + c) * D + d] = x2;
-  }
-}
-
-// PASS 0: chunk end states from a zero entry state; PASS 1: true entry state, results written.
-// BWD false: forward substitution (writes y into out); true: backward substitution (out: y -> x).
-template <int PASS, bool BWD>
-__global__ __launch_bounds__(64) void mlpg_chunk_kernel(MlpgArgs a, int t_max) {
-  const int d = blockIdx.x * 64 + threadIdx.x;
-  const int k = blockIdx.y, u = blockIdx.z;
-  if (d >= a.dim) return;
-  const int64_t t0 = a.offsets[u];
-  const int64_t T = a.offsets[u + 1] - t0;
-  if (T <= 0) return;
-  const int K = mlpg_num_chunks(T);
-  if (k >= K) return;
-  if (PASS == 0 && ((!BWD && k == K - 1) || (BWD && k == 0))) return;   // nobody reads that end state
-  const int D = a.dim;
-  const int64_t j0 = (int64_t)k * MLPG_CL, j1 = k == K - 1 ? T : j0 + MLPG_CL;
-  const int64_t slot = t0 / MLPG_CL + u;                 // first end-state slot of this utterance
-  double* E = a.ends + (slot * 2) * D + d;               // E[(c * 2 + i) * D]
-  const int64_t plane = (int64_t)t_max * D;
-  const double* fd = a.scratch + d;
-  const double* fl1 = fd + plane;
-  const double* fl2 = fl1 + plane;
-  const int64_t ncv = a.nconv[d];
-  const int64_t n_shared = T >= 3 ? T - 2 : 0;
-  auto F = [&](const double* pl, int64_t j) { return j < 0 ? 0.0 : pl[(j < ncv ? j : ncv) * D]; };
-  double* o = a.out + t0 * a.ld_out + a.ocol0 + d;
-
-  // entry state: fold the chunks before this one (in sweep order)
-  double s1 = 0.0, s2 = 0.0;
-  if (PASS == 1) {
-    if (!BWD) {
-      for (int c = 0; c < k; ++c) {
-        const double* M = a.mf + (int64_t)c * 4 * D + d;
-        const double n1 = M[0] * s1 + M[D] * s2 + E[(c * 2) * D];
-        const double n2 = M[2 * D] * s1 + M[3 * D] * s2 + E[(c * 2 + 1) * D];
-        s1 = n1;
-        s2 = n2;
-      }
-    } else {
-      for (int c = K - 1; c > k; --c) {
-        const double* M = a.mb + (int64_t)c * 4 * D + d;
-        // the last chunk starts from zero, its M (which would need the tail factor) is not used
-        const double m00 = c == K - 1 ? 0.0 : M[0], m01 = c == K - 1 ? 0.0 : M[D];
-        const double m10 = c == K - 1 ? 0.0 : M[2 * D], m11 = c == K - 1 ? 0.0 : M[3 * D];
-        const double n1 = m00 * s1 + m01 * s2 + E[(c * 2) * D];
-        const double n2 = m10 * s1 + m11 * s2 + E[(c * 2 + 1) * D];
-        s1 = n1;
-        s2 = n2;
-      }
-    }
-  }
-
-  const double v0 = a.var[d], v1 = a.var[D + d], v2 = a.var[2 * D + d];
-  const double tau0 = 1.0 / v0, tau1_in = 1.0 / v1, tau2_in = 1.0 / v2, tau_edge = 1.0 / kBigVar;
-  auto tau1 = [&](int64_t t) -> double {
-    if (t < 0 || t >= T) return 0.0;
-    return (t == 0 || t == T - 1) ? tau_edge : tau1_in;
-  };
-  auto tau2 = [&](int64_t t) -> double {
-    if (t < 0 || t >= T) return 0.0;
-    return (t == 0 || t == T - 1) ? tau_edge : tau2_in;
-  };
-  // factor of frame j: shared table for j < n_shared, re-derived with the true edge variances for
-  // the last two frames (always inside the last chunk)
-  auto factor = [&](int64_t j, double l1p, double l2p, double cprev, double& dd, double& l1, double& l2) {
-    if (j < n_shared) {
-      dd = F(fd, j);
-      l1 = F(fl1, j);
-      l2 = F(fl2, j);
-    } else {
-      const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) + (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
-      const double pj1 = (j + 1 < T) ? -2.0 * (tau2(j) + tau2(j + 1)) : 0.0;
-      const double pj2 = (j + 2 < T) ? (tau2(j + 1) - 0.25 * tau1(j + 1)) : 0.0;
-      dd = 1.0 / sqrt(pjj - l1p * l1p - l2p * l2p);
-      l1 = (pj1 - cprev * l1p) * dd;
-      l2 = pj2 * dd;
-    }
-  };
-
-  if (!BWD) {
-    const double* f = a.feat + t0 * a.ld_feat + a.col0 + d;
-    const double rv0 = 1.0 / v0, rv1 = 1.0 / v1, rv2 = 1.0 / v2, rvb = 1.0 / kBigVar;
-    auto rvar1 = [&](int64_t t) { return (t == 0 || t == T - 1) ? rvb : rv1; };
-    auto rvar2 = [&](int64_t t) { return (t == 0 || t == T - 1) ? rvb : rv2; };
-    // b-frame terms of rows j-1 (p), j (c), j+1 (n)
-    double p1 = 0.0, p2 = 0.0;
-    if (j0 > 0) {
-      const double* r = f + (j0 - 1) * a.ld_feat;
-      p1 = r[D] * rvar1(j0 - 1);
-      p2 = r[2 * D] * rvar2(j0 - 1);
-    }
-    const double* rc = f + j0 * a.ld_feat;
-    double c0 = rc[0] * rv0, c1 = rc[D] * rvar1(j0), c2 = rc[2 * D] * rvar2(j0);
-    // Cholesky state entering row j0: L[j0,j0-1], L[j0,j0-2] and L[j0+1,j0-1]
-    double l1p = F(fl1, j0 - 1), l2p = F(fl2, j0 - 2), cprev = F(fl2, j0 - 1);
-    double y1 = s1, y2 = s2;
-    // rows are prefetched PF at a time, the next block's loads issued before this block's chain
-    constexpr int PF = 8;
-    double nb0[PF], nb1[PF], nb2[PF], nd[PF], nl1[PF], nl2[PF];
-    auto load_block = [&](int64_t jb, double (&b0)[PF], double (&b1)[PF], double (&b2)[PF],
-                          double (&bd)[PF], double (&bl1)[PF], double (&bl2)[PF]) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int64_t t = jb + 1 + i;                      // data row j + 1
-        const double* r = f + (t < T ? t : T - 1) * a.ld_feat;
-        b0[i] = r[0];
-        b1[i] = r[D];
-        b2[i] = r[2 * D];
-        const int64_t jf = jb + i;                         // factor of frame j
-        const int64_t jc = jf < n_shared ? (jf < ncv ? jf : ncv) : 0;
-        bd[i] = fd[jc * D];
-        bl1[i] = fl1[jc * D];
-        bl2[i] = fl2[jc * D];
-      }
-    };
-    load_block(j0, nb0, nb1, nb2, nd, nl1, nl2);
-    for (int64_t jb = j0; jb < j1; jb += PF) {
-      double fb0[PF], fb1[PF], fb2[PF], fbd[PF], fbl1[PF], fbl2[PF];
-      load_block(jb + PF, fb0, fb1, fb2, fbd, fbl1, fbl2);
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int64_t j = jb + i;
-        if (j < j1) {
-          double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-          if (j + 1 < T) {
-            n0 = nb0[i] * rv0;
-            n1 = nb1[i] * rvar1(j + 1);
-            n2 = nb2[i] * rvar2(j + 1);
-          }
-          const double b = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
-          double dd = nd[i], l1 = nl1[i], l2 = nl2[i];
-          if (j >= n_shared) factor(j, l1p, l2p, cprev, dd, l1, l2);
-          const double y = (b - l1p * y1 - l2p * y2) * dd;
-          if (PASS == 1) o[j * a.ld_out] = y;
-          l2p = cprev;
-          l1p = l1;
-          cprev = l2;
-          y2 = y1;
-          y1 = y;
-          p1 = c1;
-          p2 = c2;
-          c0 = n0;
-          c1 = n1;
-          c2 = n2;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        nb0[i] = fb0[i]; nb1[i] = fb1[i]; nb2[i] = fb2[i];
-        nd[i] = fbd[i]; nl1[i] = fbl1[i]; nl2[i] = fbl2[i];
-      }
-    }
-    if (PASS == 0) {
-      E[(k * 2) * D] = y1;
-      E[(k * 2 + 1) * D] = y2;
-    }
-  } else {
-    // the tail factors (frames T-2, T-1) need the Cholesky state that reaches them: two steps
-    double tl_d[2] = {1.0, 1.0}, tl_1[2] = {0.0, 0.0}, tl_2[2] = {0.0, 0.0};
-    if (k == K - 1) {
-      double l1p = F(fl1, n_shared - 1), l2p = F(fl2, n_shared - 2), cprev = F(fl2, n_shared - 1);
-      if (n_shared == 0) l1p = l2p = cprev = 0.0;
-      for (int64_t j = n_shared; j < T; ++j) {
-        double dd, l1, l2;
-        factor(j, l1p, l2p, cprev, dd, l1, l2);
-        const int q = (T - 1 - j) == 0 ? 1 : 0;     // frame T-1 -> slot 1, frame T-2 -> slot 0
-        tl_d[q] = dd; tl_1[q] = l1; tl_2[q] = l2;
-        l2p = cprev;
-        l1p = l1;
-        cprev = l2;
-      }
-    }
-    double x1 = s1, x2 = s2;
-    constexpr int PF = 8;
-    for (int64_t jb = j1 - 1; jb >= j0; jb -= PF) {
-      double rd[PF], r1[PF], r2[PF], ry[PF];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int64_t j = jb - i;
-        if (j >= j0) {
-          const int64_t jc = j < n_shared ? (j < ncv ? j : ncv) : 0;
-          rd[i] = fd[jc * D];
-          r1[i] = fl1[jc * D];
-          r2[i] = fl2[jc * D];
-          ry[i] = o[j * a.ld_out];
-          if (j >= n_shared) {
-            const int q = (j == T - 1) ? 1 : 0;
-            rd[i] = tl_d[q];
-            r1[i] = tl_1[q];
-            r2[i] = tl_2[q];
-          }
-        } else {
-          rd[i] = 1.0;
-          r1[i] = r2[i] = ry[i] = 0.0;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int64_t j = jb - i;
-        if (j >= j0) {
-          const double x = (ry[i] - r1[i] * x1 - r2[i] * x2) * rd[i];
-          if (PASS == 1) o[j * a.ld_out] = x;
-          x2 = x1;
-          x1 = x;
-        }
-      }
-    }
-    if (PASS == 0) {
-      E[(k * 2) * D] = x1;
-      E[(k * 2 + 1) * D] = x2;
-    }
-  }
-}
-
-// ---- fused single-pass solve ----------------------------------------------------------------------
-// The four chunk passes above read the input twice and send the forward-sweep result through HBM
-// (2.3x the algorithmic bytes).  Here a wave keeps its FU_FL frames x 64 dimensions in registers
-// from the first load to the last store, so the input is read ONCE and the output written ONCE:
-//   1  b_j from the three input columns; forward sweep from a zero state together with the two
-//      unit responses -> this chunk's (M, e)                                   [registers]
-//   2  (M, e) of the workgroup's FW chunks meet in LDS; every wave folds the ones before it; the
-//      workgroup's aggregate is published; aggregates of the EARLIER super-chunks of the utterance
-//      (other workgroups) are folded in -> true entry state; forward sweep again, y replaces b
-//   3  the same backwards over y: (M, e) -> LDS -> aggregate published -> aggregates of the LATER
-//      super-chunks folded in -> true entry state
-//   4  backward sweep from the true state, x written out
-// Cross-workgroup exchange: a workgroup takes its super-chunk from a ticket counter (so every
-// super-chunk with a lower ticket is held by a RUNNING workgroup), publishes aggregates without
-// waiting for anybody, and waits only for aggregates -- forward ones of lower tickets, backward
-// ones of the same utterance, whose owners need nothing but forward aggregates: no cycle, at most
-// (super-chunks per utterance - 1) workgroups can be parked on a ticket that is not handed out yet.
-// Values travel without fences (an agent-scope release writes the L2 back on this chip): every
-// double is stored as the pair (bits, ~bits) with relaxed agent-scope atomics into zeroed memory
-// and read until the two words are complements -- a torn or missing pair never validates.
-constexpr int FU_MAX_SC = 64;      // super-chunks per utterance the fused path accepts
-
-struct alignas(32) FuRecord {
-  long long t0;          // first frame of the utterance in the batch
-  int T;                 // its length
-  int k0;                // first chunk of the super-chunk (index inside the utterance)
-  int sc_first, sc_end;  // the utterance's super-chunks are [sc_first, sc_end)
-  int pad[2];
-};
-
-struct FusedArgs {
-  MlpgArgs a;
-  int t_max;
-  const FuRecord* rec;   // [n_sc] one record per super-chunk (everything a workgroup needs to start)
-  int n_sc, nblk;
-  unsigned* ticket;
-  unsigned long long* agg;   // [n_sc][12][2][nblk * 64]
-  int stagger_n, stagger_steps;
-  int* err;                  // set when a wait ran out of its polling budget
-  unsigned long long* trace; // optional [tickets][FW][8] wall-clock stamps (ITTS_MLPG_TRACE)
-};
-
+// ---- chunk geometry, factor access and the two sweeps of one chunk -------------------------------
+// (shared by the reduce and the solve kernel below)
 template <int FU_FL>
 __device__ __host__ __forceinline__ int fu_num_chunks(int64_t T) { return (int)((T + FU_FL - 1) / FU_FL); }
 // the last chunk always holds both re-derived tail frames: a one-frame remainder takes a frame
@@ -594,93 +279,6 @@ __device__ __forceinline__ int64_t fu_chunk_start(int k, int K, int64_t T) {
   int64_t s = (int64_t)k * FU_FL;
   if (k == K - 1 && K > 1 && T - s == 1) s -= 1;
   return k >= K ? T : s;
-}
-
-__device__ __forceinline__ void fu_publish(unsigned long long* p, int64_t pair_stride, double v) {
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-  __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(p + pair_stride, ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double fu_consume(const unsigned long long* p, int64_t pair_stride) {
-  unsigned long long x, y;
-  for (;;) {
-    x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    y = __hip_atomic_load(p + pair_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (x == ~y) break;
-    __builtin_amdgcn_s_sleep(4);
-  }
-  return __longlong_as_double((long long)x);
-}
-
-// The six doubles of one aggregate (M00, M01, M10, M11, e0, e1) at p[2 * i * stride] for this
-// lane.  Waiting is done by ONE lane on ONE pair (`flag`: the last pair the owner's lane 0 writes)
-// with a sleep between polls -- thousands of waves polling every word flood the memory system and
-// starve the producers -- then all twelve words of every lane are requested together and checked,
-// which is retried in the rare case that some pair has not landed yet.  `budget` bounds the total
-// number of polls of this wave: when it runs out the wave stops waiting (the result is then wrong
-// and *err is set) instead of hanging the device.
-__device__ __forceinline__ void fu_consume6(const unsigned long long* p, int64_t stride,
-                                            const unsigned long long* flag, double (&v)[6],
-                                            int& budget, int* err) {
-  for (;;) {
-    // optimistic: the owner usually published before this wave got here, so ask for all twelve
-    // words at once (one trip to memory instead of a poll followed by the fetch)
-    unsigned long long x[6], y[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      x[i] = __hip_atomic_load(p + (int64_t)(2 * i) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      y[i] = __hip_atomic_load(p + (int64_t)(2 * i + 1) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ok = ok && (x[i] == ~y[i]);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = __longlong_as_double((long long)x[i]);
-    if (__all(ok)) return;
-    if (--budget <= 0) {
-      if ((threadIdx.x & 63) == 0) atomicExch(err, 1);
-      return;
-    }
-    if ((threadIdx.x & 63) == 0) {
-      for (;;) {
-        const unsigned long long fx = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long fy = __hip_atomic_load(flag + stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fx == ~fy || --budget <= 0) break;
-        __builtin_amdgcn_s_sleep(32);
-      }
-    }
-    budget = __shfl(budget, 0, 64);
-  }
-}
-
-// The entry state of a workgroup: the aggregates (M, e) of the utterance's other super-chunks
-// `first`, first + step, ... (count of them) folded in that order into (s1, s2).  The waves share
-// the work -- wave w fetches aggregate w of every round of FW, so the trips to memory run side by
-// side instead of one after the other, and each aggregate is fetched once per workgroup instead
-// of once per wave -- and meet in LDS; every wave then folds the same values in the same order.
-template <int FW>
-__device__ __forceinline__ void fu_gather_state(const FusedArgs& g, double (*xch)[6][64], int first, int step,
-                                                int count, int64_t word0, int64_t Dp, int64_t ccol,
-                                                int64_t flag_col, int w, int lane, int& budget,
-                                                double& s1, double& s2) {
-  for (int base = 0; base < count; base += FW) {
-    const int here = count - base < FW ? count - base : FW;
-    if (base > 0) __syncthreads();
-    if (w < here) {
-      const int p = first + (base + w) * step;
-      const unsigned long long* pa = g.agg + (int64_t)p * 24 * Dp + word0 * Dp;
-      double av[6];
-      fu_consume6(pa + ccol, Dp, pa + 10 * Dp + flag_col, av, budget, g.err);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) xch[w][i][lane] = av[i];
-    }
-    __syncthreads();
-    for (int i = 0; i < here; ++i) {
-      const double n1 = xch[i][0][lane] * s1 + xch[i][1][lane] * s2 + xch[i][4][lane];
-      const double n2 = xch[i][2][lane] * s1 + xch[i][3][lane] * s2 + xch[i][5][lane];
-      s1 = n1; s2 = n2;
-    }
-  }
 }
 
 struct FuFac {
@@ -898,183 +496,6 @@ __device__ __forceinline__ void fu_form_b(const MlpgArgs& a, const double* f, in
     }
   }
 }
-
-template <int FU_FL, int FW, int WPE>
-__global__ __launch_bounds__(FW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void mlpg_fused_kernel(FusedArgs g) {
-  __shared__ double lds_f[FW][6][64];
-  __shared__ double lds_b[FW][6][64];
-  __shared__ double lds_x[FW][6][64];
-  __shared__ unsigned s_ticket[2];
-  const MlpgArgs& a = g.a;
-  // Persistent workgroups: the grid is what the chip holds at once and every workgroup takes
-  // super-chunks off the ticket counter until none is left -- no dispatch, kernel-argument and
-  // constant traffic between two super-chunks, and the next ticket is requested while the last
-  // sweep of the current one runs.
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int D = a.dim;
-  const int64_t Dp = (int64_t)g.nblk * 64;
-  const unsigned n_tickets = (unsigned)g.n_sc * (unsigned)g.nblk;
-  if (threadIdx.x == 0) s_ticket[0] = atomicAdd(g.ticket, 1u);
-  __syncthreads();
-  unsigned ticket = s_ticket[0];
-  int parity = 0, db_have = -1;
-  bool dok = false;
-  int d = 0;
-  double v0 = 1.0, v1 = 1.0, v2 = 1.0;
-  FuFac c;
-  const int64_t plane = (int64_t)g.t_max * D;
-  while (ticket < n_tickets) {
-  const int sc = (int)(ticket / (unsigned)g.nblk), db = (int)(ticket % (unsigned)g.nblk);
-  const FuRecord rec = g.rec[sc];
-  if (db != db_have) {          // per-dimension constants: once per workgroup when dim <= 64
-    db_have = db;
-    dok = db * 64 + lane < D;
-    d = dok ? db * 64 + lane : D - 1;
-    v0 = a.var[d]; v1 = a.var[D + d]; v2 = a.var[2 * D + d];
-    c.fd = a.scratch + d; c.fl1 = c.fd + plane; c.fl2 = c.fl1 + plane;
-    c.ncv = a.nconv[d]; c.D = D;
-    c.tau0 = 1.0 / v0; c.tau1_in = 1.0 / v1; c.tau2_in = 1.0 / v2;
-  }
-  const int64_t t0 = rec.t0;
-  const int64_t T = rec.T;
-  const int K = fu_num_chunks<FU_FL>(T);
-  const int k = rec.k0 + w;
-  const bool wact = k < K;
-  const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
-  const int n = wact ? (int)(j1 - j0) : 0;
-  const int64_t dcol = (int64_t)db * 64 + lane;
-  unsigned long long* tr = g.trace ? g.trace + ((int64_t)ticket * FW + w) * 8 : nullptr;
-#define FU_STAMP(i) do { if (tr && lane == 0) tr[i] = wall_clock64(); } while (0)
-  FU_STAMP(0);
-  if (g.stagger_n > 0 && (int)ticket < g.stagger_n) {
-    // first round only: spread the start of the resident workgroups (they would otherwise all
-    // load, all compute and all wait at the same time, round after round)
-    const int steps = (int)((int64_t)ticket * g.stagger_steps / g.stagger_n);
-    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
-  c.n_shared = T >= 3 ? T - 2 : 0; c.T = T;
-
-  double b[FU_FL];
-  double M[4] = {1.0, 0.0, 0.0, 1.0}, e[2] = {0.0, 0.0}, tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
-  // a chunk whose frames (and the two before it) all lie in the stationary part of the shared
-  // factor runs with the factor in three registers
-  const bool cst_lane = wact && (j0 - 2 >= c.ncv) && (j1 <= c.n_shared) && n == FU_FL;
-  const bool cst = __all(cst_lane || !wact) && wact;
-
-  if (wact) {
-    fu_form_b<FU_FL>(a, a.feat + t0 * a.ld_feat + a.col0 + d, j0, n, T, cst, v0, v1, v2, b);
-    FU_STAMP(1);
-    if (cst) fu_fwd<FU_FL, true, true>(c, b, j0, n, 0.0, 0.0, M, e, tl);
-    else fu_fwd<FU_FL, false, true>(c, b, j0, n, 0.0, 0.0, M, e, tl);
-  }
-  FU_STAMP(2);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) lds_f[w][i][lane] = M[i];
-  lds_f[w][4][lane] = e[0];
-  lds_f[w][5][lane] = e[1];
-  __syncthreads();
-  // state = P s_in + q after the chunks in front of this wave; the whole workgroup for wave 0
-  double P[4] = {1.0, 0.0, 0.0, 1.0}, q[2] = {0.0, 0.0};
-  double Pw[4] = {1.0, 0.0, 0.0, 1.0}, qw[2] = {0.0, 0.0};
-  for (int cidx = 0; cidx < FW; ++cidx) {
-    if (cidx == w) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Pw[i] = P[i];
-      qw[0] = q[0]; qw[1] = q[1];
-      if (w != 0) break;
-    }
-    const double m00 = lds_f[cidx][0][lane], m01 = lds_f[cidx][1][lane], m10 = lds_f[cidx][2][lane],
-                 m11 = lds_f[cidx][3][lane], e0 = lds_f[cidx][4][lane], e1 = lds_f[cidx][5][lane];
-    const double p0 = m00 * P[0] + m01 * P[2], p1 = m00 * P[1] + m01 * P[3];
-    const double p2 = m10 * P[0] + m11 * P[2], p3 = m10 * P[1] + m11 * P[3];
-    const double q0 = m00 * q[0] + m01 * q[1] + e0, q1 = m10 * q[0] + m11 * q[1] + e1;
-    P[0] = p0; P[1] = p1; P[2] = p2; P[3] = p3; q[0] = q0; q[1] = q1;
-  }
-  unsigned long long* my_agg = g.agg + (int64_t)sc * 24 * Dp + dcol;
-  if (w == 0 && dok) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fu_publish(my_agg + (int64_t)(2 * i) * Dp, Dp, P[i]);
-    fu_publish(my_agg + (int64_t)8 * Dp, Dp, q[0]);
-    fu_publish(my_agg + (int64_t)10 * Dp, Dp, q[1]);
-  }
-  FU_STAMP(3);
-  double s1 = 0.0, s2 = 0.0;
-  int budget = 1 << 21;          // ~2 s of polling at most
-  const int64_t ccol = (int64_t)db * 64 + (dok ? lane : 0);     // idle lanes re-read column 0
-  fu_gather_state<FW>(g, lds_x, rec.sc_first, 1, sc - rec.sc_first, 0, Dp, ccol, (int64_t)db * 64, w, lane,
-                      budget, s1, s2);
-  {
-    const double n1 = Pw[0] * s1 + Pw[1] * s2 + qw[0], n2 = Pw[2] * s1 + Pw[3] * s2 + qw[1];
-    s1 = n1; s2 = n2;
-  }
-  M[0] = 1.0; M[1] = 0.0; M[2] = 0.0; M[3] = 1.0; e[0] = e[1] = 0.0;
-  FU_STAMP(4);
-  if (wact) {
-    if (cst) fu_fwd<FU_FL, true, false>(c, b, j0, n, s1, s2, M, e, tl);
-    else fu_fwd<FU_FL, false, false>(c, b, j0, n, s1, s2, M, e, tl);
-    // backwards: the chunk's (M, e); the stationary test now needs frames j0 .. j1-1 only, which
-    // the forward test already covers
-    if (cst) fu_bwd<FU_FL, true, true>(c, b, j0, n, 0.0, 0.0, M, e, tl, nullptr, 0, false);
-    else fu_bwd<FU_FL, false, true>(c, b, j0, n, 0.0, 0.0, M, e, tl, nullptr, 0, false);
-  }
-  FU_STAMP(5);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) lds_b[w][i][lane] = M[i];
-  lds_b[w][4][lane] = e[0];
-  lds_b[w][5][lane] = e[1];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { P[i] = (i == 0 || i == 3) ? 1.0 : 0.0; Pw[i] = P[i]; }
-  q[0] = q[1] = qw[0] = qw[1] = 0.0;
-  for (int cidx = FW - 1; cidx >= 0; --cidx) {
-    if (cidx == w) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Pw[i] = P[i];
-      qw[0] = q[0]; qw[1] = q[1];
-      if (w != 0) break;
-    }
-    const double m00 = lds_b[cidx][0][lane], m01 = lds_b[cidx][1][lane], m10 = lds_b[cidx][2][lane],
-                 m11 = lds_b[cidx][3][lane], e0 = lds_b[cidx][4][lane], e1 = lds_b[cidx][5][lane];
-    const double p0 = m00 * P[0] + m01 * P[2], p1 = m00 * P[1] + m01 * P[3];
-    const double p2 = m10 * P[0] + m11 * P[2], p3 = m10 * P[1] + m11 * P[3];
-    const double q0 = m00 * q[0] + m01 * q[1] + e0, q1 = m10 * q[0] + m11 * q[1] + e1;
-    P[0] = p0; P[1] = p1; P[2] = p2; P[3] = p3; q[0] = q0; q[1] = q1;
-  }
-  if (w == 0 && dok) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fu_publish(my_agg + (int64_t)(12 + 2 * i) * Dp, Dp, P[i]);
-    fu_publish(my_agg + (int64_t)20 * Dp, Dp, q[0]);
-    fu_publish(my_agg + (int64_t)22 * Dp, Dp, q[1]);
-  }
-  FU_STAMP(6);
-  s1 = s2 = 0.0;
-  // (lds_x is free again: every wave passed the barrier above after its forward fold)
-  fu_gather_state<FW>(g, lds_x, rec.sc_end - 1, -1, rec.sc_end - 1 - sc, 12, Dp, ccol,
-                      (int64_t)db * 64, w, lane, budget, s1, s2);
-  {
-    const double n1 = Pw[0] * s1 + Pw[1] * s2 + qw[0], n2 = Pw[2] * s1 + Pw[3] * s2 + qw[1];
-    s1 = n1; s2 = n2;
-  }
-  // every wait of this super-chunk is over: take the next ticket now (not earlier -- a workgroup
-  // that holds a ticket it has not started could be the one its own wait is for), its trip to the
-  // counter runs under the last sweep
-  if (threadIdx.x == 0) s_ticket[parity ^ 1] = atomicAdd(g.ticket, 1u);
-  if (wact) {
-    double* o = a.out + t0 * a.ld_out + a.ocol0 + d;
-    if (cst) fu_bwd<FU_FL, true, false>(c, b, j0, n, s1, s2, M, e, tl, o, a.ld_out, dok);
-    else fu_bwd<FU_FL, false, false>(c, b, j0, n, s1, s2, M, e, tl, o, a.ld_out, dok);
-  }
-  FU_STAMP(7);
-  __syncthreads();
-  parity ^= 1;
-  ticket = s_ticket[parity];
-  }
-#undef FU_STAMP
-}
-
-
 
 // ---- dependency-free solve: reduce -> scan -> solve ----------------------------------------------
 // The fused kernel above reads the input once, but its workgroups spend two thirds of their life
@@ -1746,16 +1167,7 @@ static int mlpg_stream_launch(MlpgArgs a, const int64_t* h_offsets, int n_utts, 
   g.agg = reinterpret_cast<double*>(blk + rec_bytes + c0_bytes);
   g.st = g.agg + plane_bytes / sizeof(double);
   g.scan_trace = nullptr;
-  const char* scan_trace_path = getenv("ITTS_MLPG_SCAN_TRACE");
-  const size_t scan_trace_words = (size_t)n_utts * nblk * ST_SW * 8;
-  if (scan_trace_path && scan_trace_path[0]) {
-    ITTS_HIP_CHECK(hipMalloc((void**)&g.scan_trace, scan_trace_words * 8));
-    ITTS_HIP_CHECK(hipMemset(g.scan_trace, 0, scan_trace_words * 8));
-  }
-  {
-    const char* sq = getenv("ITTS_MLPG_SCAN_SEQ");
-    g.scan_sequential = sq && sq[0] == '1';
-  }
+  g.scan_sequential = 0;
   const dim3 grid((unsigned)((size_t)n_groups * nblk));
   const size_t tile_bytes = STAGE ? (size_t)(GW * FL + 2) * ST_W * sizeof(double) : 0;
   if (STAGE) {
@@ -1773,33 +1185,14 @@ static int mlpg_stream_launch(MlpgArgs a, const int64_t* h_offsets, int n_utts, 
   hipLaunchKernelGGL((mlpg_solve_kernel<FL, GS>), dim3((unsigned)((size_t)n_sgroups * nblk)), dim3(GS * 64), 0, s,
                      g);
   ITTS_LAUNCH_CHECK();
-  if (g.scan_trace) {          // debugging aid: per-wave phase stamps of the scan kernel as text
-    std::vector<unsigned long long> h(scan_trace_words);
-    ITTS_HIP_CHECK(hipStreamSynchronize(s));
-    ITTS_HIP_CHECK(hipMemcpy(h.data(), g.scan_trace, scan_trace_words * 8, hipMemcpyDeviceToHost));
-    ITTS_HIP_CHECK(hipFree(g.scan_trace));
-    if (FILE* tf = fopen(scan_trace_path, "w")) {
-      for (size_t r = 0; r < scan_trace_words / 8; ++r) {
-        fprintf(tf, "%zu %zu", r / ST_SW, r % ST_SW);
-        for (int i = 0; i < 8; ++i) fprintf(tf, " %llu", h[r * 8 + i]);
-        fprintf(tf, "\n");
-      }
-      fclose(tf);
-    }
-  }
   ITTS_HIP_CHECK(itts::scratch_free(blk, s));
   return ITTS_OK;
 }
 
 extern "C" int64_t itts_mlpg_scratch_bytes(int64_t t_total, int dim) {
   if (t_total < 0 || dim <= 0) return 0;
-  // 3 factor planes + device copy of the offsets (<= t_total + 1 entries, padded) + nconv, then the
-  // time-parallel solve's transfer matrices (2 x kmax x 4 x dim) and chunk end states
-  // (slots x 2 x dim with slots <= t_total / CL + n_utts + 1 <= t_total / CL + t_total + 2)
-  const int64_t kmax = t_total / itts::MLPG_CL + 2;
-  const int64_t slots = t_total / itts::MLPG_CL + t_total + 3;
-  return 3 * t_total * (int64_t)dim * 8 + (t_total + 2) * 8 + ((int64_t)dim * 4 + 16) / 8 * 8 + 8 +
-         (2 * kmax * 4 + slots * 2) * (int64_t)dim * 8;
+  // 3 factor planes + device copy of the offsets (<= t_total + 1 entries, padded) + nconv
+  return 3 * t_total * (int64_t)dim * 8 + (t_total + 2) * 8 + ((int64_t)dim * 4 + 16) / 8 * 8 + 8;
 }
 
 extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int dim,
@@ -1825,153 +1218,18 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total, d_nconv};
   int64_t t_max = 0;
   for (int u = 0; u < n_utts; ++u) t_max = std::max(t_max, h_offsets[u + 1] - h_offsets[u]);
-  const int kchunks = mlpg_num_chunks(t_max);
-  // which solve (ITTS_MLPG_PATH, for A/B runs and the tests): "stream" = reduce -> scan -> solve
-  // with 16-frame chunks, two chunks per workgroup, input rows staged through LDS (the default);
-  // "direct" = the same with every wave loading its own rows (four chunks per workgroup; "stream8" /
-  // "stream32": 8 / 32 frames per chunk), "fused" = the
-  // single-pass kernel with cross-workgroup waits, "multipass" = the four chunk passes,
-  // "seq" = the sequential sweeps (always taken for batches of short utterances)
-  const char* path_env = getenv("ITTS_MLPG_PATH");
-  const std::string path = path_env ? path_env : "stream";
-  ITTS_REQUIRE(path == "stream" || path == "stream8" || path == "stream32" || path == "fused" ||
-               path == "multipass" || path == "seq" || path == "direct", "unknown ITTS_MLPG_PATH");
-  if (kchunks >= 3) {      // the stream paths upload their own tables and compute the factor in their first launch
-    if (path == "stream") return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
-    if (path == "direct") return mlpg_stream_launch<16, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
-    if (path == "stream32") return mlpg_stream_launch<32, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
-    if (path == "stream8") return mlpg_stream_launch<8, 4, false>(a, h_offsets, n_utts, dim, t_max, s);
-  }
+  // reduce -> scan -> solve with 16-frame chunks, two chunks per workgroup, input rows staged through
+  // LDS (uploads its own tables and computes the factor in its first launch); batches of short
+  // utterances: the sequential sweeps are as fast
+  if (t_max >= MLPG_SEQ_BELOW) return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
   {
     const int rc = itts::staged_upload(d_off, h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t), s);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(mlpg_factor_kernel, dim3((dim + 63) / 64), dim3(64), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
-  if (kchunks < 3 || path == "seq") {      // short utterances: the sequential sweeps are as fast
-    dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
-    hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
-    ITTS_LAUNCH_CHECK();
-    return ITTS_OK;
-  }
-  // fused single-pass solve (one read of the input, one write of the output) unless an utterance
-  // is so long that its super-chunks could exhaust the resident workgroups (see the kernel)
-  // geometry: frames per wave x waves per workgroup (ITTS_MLPG_GEOM=<FL>x<FW>[x<waves per SIMD>]
-  // picks one of the compiled variants; experiments)
-  int FL = 8, FW = 16, WPE = 0;
-  if (const char* geom = getenv("ITTS_MLPG_GEOM")) sscanf(geom, "%dx%dx%d", &FL, &FW, &WPE);
-  const int64_t sc_frames = (int64_t)FL * FW;
-  if (path == "fused" && t_max <= sc_frames * FU_MAX_SC) {
-    std::vector<FuRecord> recs;
-    for (int u = 0; u < n_utts; ++u) {
-      const int64_t T = h_offsets[u + 1] - h_offsets[u];
-      const int first = (int)recs.size();
-      const int K = T > 0 ? (int)((T + FL - 1) / FL) : 0;
-      for (int k0 = 0; k0 < K; k0 += FW) {
-        FuRecord r{};
-        r.t0 = h_offsets[u];
-        r.T = (int)T;
-        r.k0 = k0;
-        r.sc_first = first;
-        recs.push_back(r);
-      }
-      for (size_t i = first; i < recs.size(); ++i) recs[i].sc_end = (int)recs.size();
-    }
-    const int n_sc = (int)recs.size();
-    const int nblk = (dim + 63) / 64;
-    // [records | ticket counter, error flag | aggregates (zeroed)]
-    const size_t rec_bytes = recs.size() * sizeof(FuRecord);
-    const size_t tab_bytes = rec_bytes + 32;
-    const size_t agg_bytes = (size_t)n_sc * 24 * nblk * 64 * sizeof(unsigned long long);
-    char* blk = nullptr;
-    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&blk, tab_bytes + agg_bytes, s));
-    ITTS_HIP_CHECK(hipMemcpyAsync(blk, recs.data(), rec_bytes, hipMemcpyHostToDevice, s));
-    ITTS_HIP_CHECK(hipMemsetAsync(blk + rec_bytes, 0, 32 + agg_bytes, s));
-    FusedArgs g;
-    g.a = a;
-    g.t_max = (int)t_max;
-    g.rec = reinterpret_cast<const FuRecord*>(blk);
-    g.ticket = reinterpret_cast<unsigned*>(blk + rec_bytes);
-    g.err = reinterpret_cast<int*>(g.ticket + 1);
-    g.n_sc = n_sc;
-    g.nblk = nblk;
-    g.agg = reinterpret_cast<unsigned long long*>(blk + tab_bytes);
-    g.stagger_n = g.stagger_steps = 0;
-    if (const char* st = getenv("ITTS_MLPG_STAGGER")) sscanf(st, "%d,%d", &g.stagger_n, &g.stagger_steps);
-    g.trace = nullptr;
-    const char* trace_path = getenv("ITTS_MLPG_TRACE");
-    const size_t trace_words = (size_t)n_sc * nblk * FW * 8;
-    if (trace_path && trace_path[0]) {
-      ITTS_HIP_CHECK(hipMalloc((void**)&g.trace, trace_words * 8));
-      ITTS_HIP_CHECK(hipMemset(g.trace, 0, trace_words * 8));
-    }
-    // persistent grid: as many workgroups as the device holds at once (never more tickets than
-    // there are)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      ITTS_HIP_CHECK(hipGetDevice(&dev));
-      ITTS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-      n_cu = prop.multiProcessorCount;
-    }
-    const int64_t n_tickets = (int64_t)n_sc * nblk;
-#define FU_LAUNCH(fl, fw, wpe)                                                                  \
-  if (!launched && FL == fl && FW == fw && (WPE == 0 || WPE == wpe)) {                           \
-    int per_cu = 0;                                                                              \
-    ITTS_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(                                 \
-        &per_cu, mlpg_fused_kernel<fl, fw, wpe>, fw * 64, 0));                                   \
-    const dim3 grid((unsigned)std::min<int64_t>(n_tickets, (int64_t)std::max(per_cu, 1) * n_cu)); \
-    hipLaunchKernelGGL((mlpg_fused_kernel<fl, fw, wpe>), grid, dim3(fw * 64), 0, s, g);          \
-    launched = true;                                                                             \
-  }
-    bool launched = false;
-    FU_LAUNCH(16, 16, 4)
-    FU_LAUNCH(32, 16, 4)
-    FU_LAUNCH(16, 8, 2)
-    FU_LAUNCH(16, 8, 4)
-    FU_LAUNCH(8, 16, 4)
-    FU_LAUNCH(8, 8, 4)
-    FU_LAUNCH(24, 8, 2)
-    FU_LAUNCH(16, 4, 2)
-#undef FU_LAUNCH
-    ITTS_REQUIRE(launched, "unknown ITTS_MLPG_GEOM");
-    ITTS_LAUNCH_CHECK();
-    if (getenv("ITTS_MLPG_CHECK")) {      // debugging aid: did a wait give up?
-      int herr = 0;
-      ITTS_HIP_CHECK(hipStreamSynchronize(s));
-      ITTS_HIP_CHECK(hipMemcpy(&herr, g.err, sizeof(int), hipMemcpyDeviceToHost));
-      ITTS_REQUIRE(herr == 0, "fused solve: a workgroup ran out of its polling budget");
-    }
-    if (g.trace) {          // debugging aid: per-wave phase stamps (100 MHz wall clock) as text
-      std::vector<unsigned long long> h(trace_words);
-      ITTS_HIP_CHECK(hipStreamSynchronize(s));
-      ITTS_HIP_CHECK(hipMemcpy(h.data(), g.trace, trace_words * 8, hipMemcpyDeviceToHost));
-      ITTS_HIP_CHECK(hipFree(g.trace));
-      if (FILE* tf = fopen(trace_path, "w")) {
-        for (size_t r = 0; r < trace_words / 8; ++r) {
-          fprintf(tf, "%zu %zu", r / FW, r % FW);
-          for (int i = 0; i < 8; ++i) fprintf(tf, " %llu", h[r * 8 + i]);
-          fprintf(tf, "\n");
-        }
-        fclose(tf);
-      }
-    }
-    ITTS_HIP_CHECK(itts::scratch_free(blk, s));
-    return ITTS_OK;
-  }
-  double* extra = reinterpret_cast<double*>(reinterpret_cast<char*>(d_nconv) + ((int64_t)dim * 4 + 16) / 8 * 8 + 8);
-  a.kmax = (int)(t_total / MLPG_CL + 2);
-  a.mf = extra;
-  a.mb = a.mf + (int64_t)a.kmax * 4 * dim;
-  a.ends = a.mb + (int64_t)a.kmax * 4 * dim;
-  const dim3 tg((dim + 63) / 64, kchunks);
-  hipLaunchKernelGGL(mlpg_transfer_kernel, tg, dim3(64), 0, s, a, (int)t_max);
-  const dim3 cg((dim + 63) / 64, kchunks, n_utts);
-  hipLaunchKernelGGL((mlpg_chunk_kernel<0, false>), cg, dim3(64), 0, s, a, (int)t_max);
-  hipLaunchKernelGGL((mlpg_chunk_kernel<1, false>), cg, dim3(64), 0, s, a, (int)t_max);
-  hipLaunchKernelGGL((mlpg_chunk_kernel<0, true>), cg, dim3(64), 0, s, a, (int)t_max);
-  hipLaunchKernelGGL((mlpg_chunk_kernel<1, true>), cg, dim3(64), 0, s, a, (int)t_max);
+  dim3 grid((dim + MLPG_LANES - 1) / MLPG_LANES, n_utts);
+  hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }

@@ -7,6 +7,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <map>
+#include <mutex>
 
 #include "context.h"
 #include "rnn_common.h"
@@ -334,24 +336,57 @@ static int persist_read_flag(int64_t* slot, const int* d_flag, hipStream_t s) {
   return w[0] == kPending ? -1 : w[0];
 }
 
+// Per-device bookkeeping of a persistent kernel: CU count, the dynamic-LDS attribute (set once per
+// device, not once per process), and a cool-down -- a launch that gave up waiting (CUs briefly held by
+// another stream or process) sends the next kPersistCooldown calls to the step kernels and is then
+// tried again, instead of switching the path off for the life of the process.
+constexpr int kPersistCooldown = 64;
+struct PersistDevice {
+  int n_cu = 0;
+  bool attr_set = false;
+  int cooldown = 0;
+};
+// Returns 1 when the persistent kernel may be launched on the current device, 0 when the caller has to
+// take the step kernels (fewer than 256 CUs, cooling down, or the attribute could not be set).
+static int persist_device_ready(const void* kernel, int lds_bytes, std::map<int, PersistDevice>& table, std::mutex& mu,
+                                int* dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  *dev_out = dev;
+  std::lock_guard<std::mutex> lock(mu);
+  PersistDevice& d = table[dev];
+  if (d.n_cu == 0) {
+    if (hipDeviceGetAttribute(&d.n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { d.n_cu = 0; return 0; }
+  }
+  if (d.n_cu != 256) return 0;
+  if (d.cooldown > 0) { --d.cooldown; return 0; }
+  if (!d.attr_set) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    d.attr_set = true;
+  }
+  return 1;
+}
+static void persist_cool_down(std::map<int, PersistDevice>& table, std::mutex& mu, int dev) {
+  std::lock_guard<std::mutex> lock(mu);
+  table[dev].cooldown = kPersistCooldown;
+}
+
 template <int G>
 static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
-  static std::atomic<bool> usable{true};
+  static std::map<int, PersistDevice> devices;
+  static std::mutex devices_mu;
   const char* pe = getenv("ITTS_RNN_PERSISTENT");       // read per call: tests switch it
-  if ((pe && pe[0] == '0') || !usable.load()) return 0;
+  if (pe && pe[0] == '0') return 0;
   p.ntiles = (p.B + 15) / 16;
   if (H != PH) return 0;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_persist_fwd_kernel<G>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, persist_lds_bytes(G)) != hipSuccess)
-      return -1;
-    n_cu = prop.multiProcessorCount;
-  }
-  DeviceContext* ctx = n_cu == 256 ? get_context() : nullptr;
+  int dev = 0;
+  if (!persist_device_ready(reinterpret_cast<const void*>(&rnn_persist_fwd_kernel<G>), persist_lds_bytes(G), devices,
+                            devices_mu, &dev))
+    return 0;
+  DeviceContext* ctx = get_context();
   if (!ctx) return 0;
   const size_t xbytes = (size_t)8 * 4 * 32 * 128 * sizeof(uint4);
   char* blk = nullptr;
@@ -370,15 +405,18 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   for (p.tile0 = 0; p.tile0 < p.ntiles; p.tile0 += 8 / p.ndir) {
     if (p.tile0 > 0 && hipMemsetAsync(blk, 0, xbytes, s) != hipSuccess) return -1;
     hipLaunchKernelGGL(rnn_persist_fwd_kernel<G>, dim3(256), dim3(256), persist_lds_bytes(G), s, p);
-    if (hipGetLastError() != hipSuccess) return -1;
+    if (hipGetLastError() != hipSuccess) {          // nothing of this round ran: the step kernels redo the layer
+      persist_cool_down(devices, devices_mu, dev);
+      return 0;
+    }
   }
   const int gave_up = persist_read_flag(pinned_slot(ctx), p.abort_flag, s);
   if (gave_up < 0) return -1;
   if (itts::scratch_free(blk, s) != hipSuccess) return -1;
   if (gave_up == 0) return 1;
-  usable.store(false);
+  persist_cool_down(devices, devices_mu, dev);
   fprintf(stderr, "libidiaptts_amd: the persistent recurrence gave up waiting (are all 256 CUs available to "
-                  "this process?); using the per-step kernels from now on\n");
+                  "this process?); per-step kernels for the next %d calls\n", kPersistCooldown);
   return 0;
 }
 
@@ -666,23 +704,18 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
 // Backward counterpart of rnn_persist_forward: 1 = done, 0 = run the step kernels.
 template <int G>
 static int rnn_persist_backward(RnnPersistBwdArgs p, const int* h_lengths, int H, hipStream_t s) {
-  static std::atomic<bool> usable{true};
+  static std::map<int, PersistDevice> devices;
+  static std::mutex devices_mu;
   const char* pe = getenv("ITTS_RNN_PERSISTENT");          // read per call: tests switch it
   const char* pb = getenv("ITTS_RNN_PERSISTENT_BWD");      // ... and this one keeps the forward half on
-  if ((pe && pe[0] == '0') || (pb && pb[0] == '0') || !usable.load()) return 0;
+  if ((pe && pe[0] == '0') || (pb && pb[0] == '0')) return 0;
   p.ntiles = (p.B + 15) / 16;
   if (H != PH) return 0;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_persist_bwd_kernel<G>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, persist_bwd_lds_bytes(G)) != hipSuccess)
-      return -1;
-    n_cu = prop.multiProcessorCount;
-  }
-  DeviceContext* ctx = n_cu == 256 ? get_context() : nullptr;
+  int dev = 0;
+  if (!persist_device_ready(reinterpret_cast<const void*>(&rnn_persist_bwd_kernel<G>), persist_bwd_lds_bytes(G),
+                            devices, devices_mu, &dev))
+    return 0;
+  DeviceContext* ctx = get_context();
   if (!ctx) return 0;
   const size_t xbytes = (size_t)8 * 2 * 32 * 32 * PT * sizeof(uint4);
   const size_t lbytes = ((size_t)p.B * sizeof(int) + 63) / 64 * 64;
@@ -699,15 +732,18 @@ static int rnn_persist_backward(RnnPersistBwdArgs p, const int* h_lengths, int H
   for (p.tile0 = 0; p.tile0 < p.ntiles; p.tile0 += 8 / p.ndir) {
     if (p.tile0 > 0 && hipMemsetAsync(blk, 0, xbytes, s) != hipSuccess) return -1;
     hipLaunchKernelGGL(rnn_persist_bwd_kernel<G>, dim3(256), dim3(256), persist_bwd_lds_bytes(G), s, p);
-    if (hipGetLastError() != hipSuccess) return -1;
+    if (hipGetLastError() != hipSuccess) {
+      persist_cool_down(devices, devices_mu, dev);
+      return 0;
+    }
   }
   const int gave_up = persist_read_flag(pinned_slot(ctx), p.abort_flag, s);
   if (gave_up < 0) return -1;
   if (itts::scratch_free(blk, s) != hipSuccess) return -1;
   if (gave_up == 0) return 1;
-  usable.store(false);
-  fprintf(stderr, "libidiaptts_amd: the persistent backward recurrence gave up waiting; using the per-step "
-                  "kernels from now on\n");
+  persist_cool_down(devices, devices_mu, dev);
+  fprintf(stderr, "libidiaptts_amd: the persistent backward recurrence gave up waiting; per-step kernels for the "
+                  "next %d calls\n", kPersistCooldown);
   return 0;
 }
 

@@ -655,9 +655,8 @@ extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const d
   if ((rc = upload_i64(h_f_off, n_utts + 1, &d_fo, s))) return rc;
   SmArgs a{d_x, d_xo, d_f0_in, d_fo, n_utts, fs, frame_period_ms, d_f0_out, ctx->twiddles, 0};
   a.nmax = 2 * (int)(1.5 * fs / 40.0 + 1.0) + 1 + 3;
-  static const int block_form = [] { const char* e = getenv("ITTS_STONEMASK_BLOCK"); return e ? atoi(e) : 0; }();
   const size_t per_wave = (size_t)a.nmax * 2 * 8;
-  if (!block_form && per_wave <= 80 * 1024) {
+  if (per_wave <= 80 * 1024) {
     // as many frames per workgroup as keep two workgroups on a CU (one wave each at 48 kHz)
     const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (80 * 1024) / per_wave));
     const size_t lds = per_wave * waves;

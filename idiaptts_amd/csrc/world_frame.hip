@@ -124,178 +124,6 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
   __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// SPTK mcep (itype 3: amplitude spectrum in, etype 1) for one frame.
-// in:  xp[0..f2] = amp^2 + eps (periodogram, half)      out: mc[0..m]
-// LDS: z [f2+1] cplx (flng real), mc[m+1], cr[2m+1], al unused, A [(m+1)*(m+2)], fcol[m+1], misc[8]
-struct McLds {
-  const double2* tw;   // twiddles of an flng-point transform (flng/2 entries)
-  double2* z;
-  double* xp;
-  double* mc;
-  double* cr;
-  double* part;  // 4*(2m+1) partial sums
-  double* A;     // augmented system, row stride m+2
-  double* fcol;
-  double* misc;
-};
-
-__device__ inline int mcep_frame(const McLds& L, const FreqtTables& ft, int flng, int logflng, int m,
-                                 double alpha, int itr1, int itr2, double dd) {
-  const int f2 = flng / 2, m1 = m + 1, m2 = 2 * m, ld = m + 2;
-  double* zr = reinterpret_cast<double*>(L.z);
-  const int tid = threadIdx.x;
-  // c = irfft(log x): real even cepstrum
-  for (int k = tid; k <= f2; k += NT) L.z[k] = make_double2(log(L.xp[k]), 0.0);
-  __syncthreads();
-  irfft_lds(L.z, flng, logflng, L.tw, flng);
-  if (tid == 0) {
-    zr[0] /= 2;
-    zr[f2] /= 2;
-  }
-  __syncthreads();
-  // mc = freqt(c, f2 -> m, alpha): wave w sums input rows [w*per, (w+1)*per), lane l owns outputs
-  // l, l+64 (coalesced 512-B row segments of the warping matrix, several loads in flight)
-  const int wv = tid >> 6, ln = tid & 63;
-  {
-    const int per = (f2 + 1 + 3) / 4;
-    const int i0 = wv * per, i1 = min(f2 + 1, i0 + per);
-    double a0 = 0.0, a1 = 0.0;
-    const bool h0 = ln < m1, h1 = ln + 64 < m1;
-    const double* row = ft.fwdT + (size_t)i0 * m1;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i, row += m1) {
-      const double zi = zr[i];
-      const double r0 = row[h0 ? ln : 0], r1 = row[h1 ? ln + 64 : 0];
-      a0 += r0 * zi;
-      a1 += r1 * zi;
-    }
-    if (h0) L.part[wv * m1 + ln] = a0;
-    if (h1) L.part[wv * m1 + ln + 64] = a1;
-    __syncthreads();
-    for (int jj = tid; jj < m1; jj += NT)
-      L.mc[jj] = (L.part[jj] + L.part[m1 + jj]) + (L.part[2 * m1 + jj] + L.part[3 * m1 + jj]);
-    if (tid == 0) L.misc[0] = zr[0];  // s = c[0]
-    __syncthreads();
-  }
-  int it;
-  for (it = 1; it <= itr2; ++it) {
-    // c' = freqt(mc, m -> f2, -alpha), zero padded to flng: thread t owns outputs t + 256 q
-    {
-      constexpr int NQ = 5;  // (f2 + 1) <= 1280 -> fftlen <= 2048
-      double acc[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-      const double* row = ft.invT;
-#pragma unroll 4
-      for (int j = 0; j < m1; ++j, row += (f2 + 1)) {
-        const double mj = L.mc[j];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int i = tid + NT * q;
-          acc[q] += row[i <= f2 ? i : 0] * mj;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        if (i < flng + 2) zr[i] = (i <= f2) ? acc[q] : 0.0;
-      }
-      for (int i = tid + NT * NQ; i < flng + 2; i += NT) zr[i] = 0.0;
-    }
-    __syncthreads();
-    rfft_lds(L.z, flng, logflng, L.tw, flng);
-    for (int k = tid; k <= f2; k += NT) L.z[k] = make_double2(L.xp[k] / exp(2.0 * L.z[k].x), 0.0);
-    __syncthreads();
-    irfft_lds(L.z, flng, logflng, L.tw, flng);
-    // cr = frqtr(r, f2 -> 2m, alpha): wave w sums input rows [w*per, (w+1)*per), lane l owns
-    // outputs l + 64 q
-    {
-      const int n_out = m2 + 1;
-      const int per = (f2 + 1 + 3) / 4;
-      const int i0 = wv * per, i1 = min(f2 + 1, i0 + per);
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      const bool h0 = ln < n_out, h1 = ln + 64 < n_out, h2 = ln + 128 < n_out, h3 = ln + 192 < n_out;
-      const double* row = ft.frqT + (size_t)i0 * n_out;
-      if (n_out <= 128) {
-#pragma unroll 8
-        for (int i = i0; i < i1; ++i, row += n_out) {
-          const double zi = zr[i];
-          a0 += row[h0 ? ln : 0] * zi;
-          a1 += row[h1 ? ln + 64 : 0] * zi;
-        }
-      } else {
-#pragma unroll 4
-        for (int i = i0; i < i1; ++i, row += n_out) {
-          const double zi = zr[i];
-          a0 += row[h0 ? ln : 0] * zi;
-          a1 += row[h1 ? ln + 64 : 0] * zi;
-          a2 += row[h2 ? ln + 128 : 0] * zi;
-          a3 += row[h3 ? ln + 192 : 0] * zi;
-        }
-      }
-      if (h0) L.part[wv * n_out + ln] = a0;
-      if (h1) L.part[wv * n_out + ln + 64] = a1;
-      if (h2) L.part[wv * n_out + ln + 128] = a2;
-      if (h3) L.part[wv * n_out + ln + 192] = a3;
-      __syncthreads();
-      for (int jj = tid; jj < n_out; jj += NT)
-        L.cr[jj] = (L.part[jj] + L.part[n_out + jj]) + (L.part[2 * n_out + jj] + L.part[3 * n_out + jj]);
-      __syncthreads();
-    }
-    const double t = L.cr[0];
-    if (it >= itr1) {
-      const double s = L.misc[0];
-      if (fabs((t - s) / t) < dd) break;  // uniform: every thread reads the same LDS values
-      __syncthreads();
-      if (tid == 0) L.misc[0] = t;
-    }
-    // Toeplitz + Hankel normal equations, augmented with b = cr[0..m] - (-alpha)^i
-    for (int idx = tid; idx < m1 * (m1 + 1); idx += NT) {
-      const int i = idx / (m1 + 1), k = idx - i * (m1 + 1);
-      double v;
-      if (k == m1) {
-        v = L.cr[i] - pow(-alpha, (double)i);
-      } else {
-        const int df = i > k ? i - k : k - i;
-        double tv = L.cr[df];
-        if (df == 0 || (df % 2 == 0)) tv += L.cr[0];   // t[0] = 2 cr[0]; even lags get + cr[0]
-        double hv = L.cr[i + k];
-        if (((i + k) & 1) == 0) hv -= L.cr[0];
-        v = tv + hv;
-      }
-      L.A[i * ld + k] = v;
-    }
-    __syncthreads();
-    // Gaussian elimination (system is symmetric positive definite: no pivoting)
-    for (int c = 0; c < m1; ++c) {
-      const double piv = L.A[c * ld + c];
-      for (int r = c + 1 + tid; r < m1; r += NT) L.fcol[r] = L.A[r * ld + c] / piv;
-      __syncthreads();
-      const int w = m1 - c;  // columns c+1 .. m1 (rhs)
-      for (int idx = tid; idx < (m1 - 1 - c) * w; idx += NT) {
-        const int r = c + 1 + idx / w, k = c + 1 + idx % w;
-        L.A[r * ld + k] -= L.fcol[r] * L.A[c * ld + k];
-      }
-      __syncthreads();
-    }
-    // back substitution by one wave (m1 <= 128): lane j owns x[j]
-    if (tid < 64) {
-      for (int r = m1 - 1; r >= 0; --r) {
-        double s = 0.0;
-        for (int k = r + 1 + tid; k < m1; k += 64) s += L.A[r * ld + k] * L.fcol[k];
-        s = wave_sum(s);
-        if (tid == 0) L.fcol[r] = (L.A[r * ld + m1] - s) / L.A[r * ld + r];
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    __syncthreads();
-    for (int j = tid; j < m1; j += NT) L.mc[j] += L.fcol[j];
-    __syncthreads();
-  }
-  return it > itr2 ? itr2 : it;
-}
-
 struct FrameArgs {
   const double* x;          // concatenated waveforms
   const int64_t* x_off;     // [U+1] sample offsets (device)
@@ -385,109 +213,25 @@ static size_t ct_lds_bytes(int fft, int bmax, bool tw_in_lds) {
   return (tw_in_lds ? (size_t)(fft / 2) * 16 : 0) + (size_t)(fft / 2 + 1) * 16 + (size_t)(fft / 2 + 2) * 8 +
          (size_t)(fft + 2 * bmax + 2) * 8 + (size_t)(NT + 8) * 8;
 }
-__device__ inline void carve_mc(char*& p, int m, McLds& L) {
-  const int m1 = m + 1;
-  L.mc = reinterpret_cast<double*>(p); p += (size_t)(m1 + 1) * 8;
-  L.cr = reinterpret_cast<double*>(p); p += (size_t)(2 * m + 2) * 8;
-  L.part = reinterpret_cast<double*>(p); p += (size_t)(4 * (2 * m + 2)) * 8;
-  L.A = reinterpret_cast<double*>(p); p += (size_t)m1 * (m + 2) * 8;
-  L.fcol = reinterpret_cast<double*>(p); p += (size_t)(m1 + 1) * 8;
-  L.misc = reinterpret_cast<double*>(p); p += 8 * 8;
-}
-static size_t mc_lds_bytes(int m) {
-  const int m1 = m + 1;
-  return (size_t)(m1 + 1) * 8 + (size_t)(2 * m + 2) * 8 + (size_t)(4 * (2 * m + 2)) * 8 +
-         (size_t)m1 * (m + 2) * 8 + (size_t)(m1 + 1) * 8 + 64;
-}
-
-// CheapTrick (+ optional fused mcep) -- one workgroup per frame.  Two instantiations: the fused
-// Newton loop needs ~240 VGPRs, plain CheapTrick far fewer (twice the workgroups per CU).
-template <bool DO_MCEP>
+// CheapTrick -- one workgroup per frame; the twiddles come through the cache from the compact table
+// (8 KB of LDS less: six workgroups per CU instead of five).
 __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* p = smem;
   CtLds L;
-  // plain CheapTrick reads its twiddles through the cache from the compact table (8 KB of LDS less:
-  // six workgroups per CU instead of five); the fused variant keeps them in LDS for the Newton loop
-  carve_ct(p, a.fft, a.bmax, L, DO_MCEP);
-  McLds M;
-  if (DO_MCEP) carve_mc(p, a.m, M);
+  carve_ct(p, a.fft, a.bmax, L, false);
   const int64_t g = blockIdx.x;
   const int u = find_utt(a.f_off, a.n_utts, g);
   const int64_t t = g - a.f_off[u];
   const double* x = a.x + a.x_off[u];
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
-  if (DO_MCEP) {
-    load_twiddles(const_cast<double2*>(L.tw), a.g_tw, a.fft);
-    __syncthreads();
-  } else {
-    L.tw = a.g_tw_compact;
-  }
+  L.tw = a.g_tw_compact;
   const double f0 = ct_frame_f0(a.f0[g], a.fs, a.fft);
   const double pos = (double)t * a.frame_period / 1000.0;
   cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L,
                    a.rn + a.f_off[u] * a.rn_pitch + a.rn_pos[g]);
   const int K = a.fft / 2 + 1;
-  if (a.sp)
-    for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
-  if (DO_MCEP) {
-    // amp = sqrt(pow) (WorldFeatLabelGen.py:795), periodogram = amp^2 + eps (SPTK mcep itype 3)
-    for (int k = threadIdx.x; k < K; k += NT) {
-      const double amp = sqrt(L.P[k]);
-      L.P[k] = amp * amp + a.eps;
-    }
-    __syncthreads();
-    M.tw = L.tw;
-    M.z = L.z;
-    M.xp = L.P;
-    const int it = mcep_frame(M, a.ft, a.fft, a.logfft, a.m, a.alpha, a.itr1, a.itr2, a.dd);
-    for (int j = threadIdx.x; j <= a.m; j += NT) {
-      if (a.mc_f32) a.mc_f32[g * a.ld_mc + j] = (float)M.mc[j];
-      if (a.mc_f64) a.mc_f64[g * (a.m + 1) + j] = M.mc[j];
-    }
-    if (a.iters && threadIdx.x == 0) a.iters[g] = it;
-  }
-}
-
-// mcep from a given amplitude spectrum [T, K] (AudioProcessing.extract_mcep)
-struct McepArgs {
-  const double* amp;
-  int64_t T;
-  int flng, logflng;
-  FreqtTables ft;
-  int m;
-  double alpha, eps;
-  int itr1, itr2;
-  double dd;
-  float* mc_f32;
-  double* mc_f64;
-  int64_t ld_mc;
-  int* iters;
-  const double2* g_tw;
-};
-
-__global__ __launch_bounds__(NT) void mcep_kernel(McepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* p = smem;
-  McLds M;
-  M.tw = reinterpret_cast<double2*>(p); p += (size_t)(a.flng / 2) * 16;
-  M.z = reinterpret_cast<double2*>(p); p += (size_t)(a.flng / 2 + 1) * 16;
-  M.xp = reinterpret_cast<double*>(p); p += (size_t)(a.flng / 2 + 2) * 8;
-  carve_mc(p, a.m, M);
-  const int64_t g = blockIdx.x;
-  const int K = a.flng / 2 + 1;
-  load_twiddles(const_cast<double2*>(M.tw), a.g_tw, a.flng);
-  for (int k = threadIdx.x; k < K; k += NT) {
-    const double v = a.amp[g * K + k];
-    M.xp[k] = v * v + a.eps;
-  }
-  __syncthreads();
-  const int it = mcep_frame(M, a.ft, a.flng, a.logflng, a.m, a.alpha, a.itr1, a.itr2, a.dd);
-  for (int j = threadIdx.x; j <= a.m; j += NT) {
-    if (a.mc_f32) a.mc_f32[g * a.ld_mc + j] = (float)M.mc[j];
-    if (a.mc_f64) a.mc_f64[g * (a.m + 1) + j] = M.mc[j];
-  }
-  if (a.iters && threadIdx.x == 0) a.iters[g] = it;
+  for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
 }
 
 // mgc2sp(gamma = 0): c = freqt(mc, -alpha) to order fftlen/2, FFT, real part; optional exp.
@@ -590,11 +334,6 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
                   double alpha, double eps, int miniter, int maxiter, double threshold, float* d_mc_f32,
                   int64_t ld_mc, double* d_mc_f64, int* d_iters, hipStream_t s);
 
-static bool use_fused_mcep() {
-  const char* e = getenv("ITTS_MCEP_FUSED");  // A/B switch: per-frame fused kernel instead of lockstep
-  return e && e[0] == '1';
-}
-
 static int smoothing_bmax(int fs, int fft, double max_width) { return (int)(max_width * fft / fs) + 2; }
 
 }  // namespace itts
@@ -638,15 +377,9 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
   FrameArgs a{};
-  const bool fused = do_mcep && use_fused_mcep();
-  if (fused) {
-    const FreqtTables* ft = get_freqt(ctx, order, fft_size / 2, alpha, true);
-    if (!ft) return ITTS_E_HIP;
-    a.ft = *ft;
-  }
   // lockstep mcep needs the envelope in memory: use the caller's buffer or a temporary
   double* sp_buf = d_sp;
-  if (do_mcep && !fused && !sp_buf)
+  if (do_mcep && !sp_buf)
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&sp_buf, (size_t)t_total * (fft_size / 2 + 1) * 8, s));
   int64_t *d_xo = nullptr, *d_fo = nullptr;
   int rc = upload_i64(h_x_off, n_utts + 1, &d_xo, s);
@@ -655,7 +388,7 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   if (rc) return rc;
   a.x = d_x; a.x_off = d_xo; a.f0 = d_f0; a.f_off = d_fo; a.n_utts = n_utts; a.fs = fs;
   a.frame_period = frame_period_ms; a.fft = fft_size; a.logfft = ilog2_host(fft_size); a.q1 = q1;
-  a.sp = fused ? d_sp : sp_buf; a.do_mcep = fused ? 1 : 0; a.m = order; a.alpha = alpha; a.eps = eps;
+  a.sp = sp_buf; a.do_mcep = 0; a.m = order; a.alpha = alpha; a.eps = eps;
   a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64;
   a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
   a.g_tw_compact = ctx->tw_compact[a.logfft];
@@ -677,23 +410,17 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   rc = launch_randn_u32(ctx, d_roff, d_rlen, n_utts, t_max * rn_pitch, d_rn, s);
   if (rc) return rc;
   a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch;
-  size_t lds = ct_lds_bytes(fft_size, a.bmax, fused) + (fused ? mc_lds_bytes(order) : 0);
+  size_t lds = ct_lds_bytes(fft_size, a.bmax, false);
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-  if (fused) {
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(cheaptrick_kernel<true>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
-  } else {
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(cheaptrick_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
-  }
+  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(cheaptrick_kernel, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_fo, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_rpos, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_rn, s));
-  if (do_mcep && !fused) {
+  if (do_mcep) {
     rc = mcep_lockstep(ctx, sp_buf, 1, t_total, fft_size / 2 + 1, order, alpha, eps, miniter, maxiter,
                        threshold, d_mc_f32, ld_mc, d_mc_f64, d_iters, s);
     if (sp_buf != d_sp) ITTS_HIP_CHECK(itts::scratch_free(sp_buf, s));
@@ -713,23 +440,8 @@ extern "C" int itts_mcep(const double* d_amp_sp, int64_t T, int K, int order, do
   if (T == 0) return ITTS_OK;
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
-  if (!use_fused_mcep())
-    return mcep_lockstep(ctx, d_amp_sp, 0, T, K, order, alpha, eps, miniter, maxiter, threshold,
-                         d_mc_f32, ld_mc, d_mc_f64, d_iters, as_stream(stream));
-  const FreqtTables* ft = get_freqt(ctx, order, flng / 2, alpha, true);
-  if (!ft) return ITTS_E_HIP;
-  McepArgs a{};
-  a.amp = d_amp_sp; a.T = T; a.flng = flng; a.logflng = ilog2_host(flng); a.ft = *ft; a.m = order;
-  a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold;
-  a.mc_f32 = d_mc_f32; a.mc_f64 = d_mc_f64; a.ld_mc = ld_mc; a.iters = d_iters; a.g_tw = ctx->twiddles;
-  size_t lds = (size_t)(flng / 2) * 16 + (size_t)(flng / 2 + 1) * 16 + (size_t)(flng / 2 + 2) * 8 +
-               mc_lds_bytes(order);
-  ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcep_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mcep_kernel, dim3((unsigned)T), dim3(NT), lds, as_stream(stream), a);
-  ITTS_LAUNCH_CHECK();
-  return ITTS_OK;
+  return mcep_lockstep(ctx, d_amp_sp, 0, T, K, order, alpha, eps, miniter, maxiter, threshold,
+                       d_mc_f32, ld_mc, d_mc_f64, d_iters, as_stream(stream));
 }
 
 extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alpha, int fftlen,

@@ -4,6 +4,7 @@ Every function takes CUDA(HIP) tensors, passes raw device pointers + the current
 libidiaptts_amd.so and raises on any failure.  Nothing here computes on the CPU.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -189,7 +190,14 @@ def linear_bwd_input(dz, w, yprev=None, act_prev=ACT_NONE, out=None):
 
 
 _ws_cache = {}
-_defer = {"on": False, "next": 0}
+class _DeferState(threading.local):
+    """Per host thread, like the library's own deferral switch (thread_local on the C side): calls made
+    from another thread -- the autograd worker -- are neither deferred nor counted here."""
+    on = False
+    next = 0
+
+
+_defer = _DeferState()
 
 
 def _workspace(nbytes, device):
@@ -198,9 +206,9 @@ def _workspace(nbytes, device):
     there are read by the one reduction launch at the end)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
-    if _defer["on"]:
-        key = key + (_defer["next"],)
-        _defer["next"] += 1
+    if _defer.on:
+        key = key + (_defer.next,)
+        _defer.next += 1
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -212,15 +220,18 @@ class deferred_reductions:
     """with ops.deferred_reductions(): the loss and gradient entry points called inside leave their
     partial sums / split-K slabs in place, and ONE launch reduces them all when the block ends
     (itts_defer_reductions / itts_reduce_deferred; results bit-identical to the separate launches).
-    Nothing inside the block may read a loss or a weight / bias gradient produced inside it."""
+    Nothing inside the block may read a loss or a weight / bias gradient produced inside it.
+    Blocks do not nest (the inner block's workspaces would be the outer block's still-pending slabs)."""
 
     def __enter__(self):
+        if _defer.on:
+            raise RuntimeError("deferred_reductions() blocks do not nest")
         _lib.check(_lib.load().itts_defer_reductions(1), "itts_defer_reductions")
-        _defer["on"], _defer["next"] = True, 0
+        _defer.on, _defer.next = True, 0
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        _defer["on"] = False
+        _defer.on = False
         _lib.check(_lib.load().itts_reduce_deferred(_stream()), "itts_reduce_deferred")
         return False
 

@@ -671,21 +671,49 @@ class ModularModelHandlerPyTorch(object):
             return
         tensors = [p.data for p in self.model.parameters()] + [b for b in self.model.buffers()]
         if optimiser and self.optimiser is not None:
-            for st in self.optimiser.state.values():
-                tensors += [v for v in st.values() if torch.is_tensor(v)]
+            # ONE object broadcast first: rank 0's optimiser state as a manifest -- per parameter (in
+            # param_groups order, the same on every rank) the tensor entries with their shapes and the
+            # python-valued entries (step counters of HipAdam / HipSGD), plus the arenas' counters.  The
+            # other ranks shape their state after it (optimisers create state lazily: a rank that has
+            # not stepped yet holds none), so that every rank then issues the SAME tensor broadcasts.
+            import torch.distributed as dist
+            rank = parallel.dp_rank_world()[0]
+            opt = self.optimiser
+            params = [p for g in opt.param_groups for p in g["params"]]
+            arenas = getattr(opt, "_arenas", None) or []
+            manifest = None
+            if rank == 0:
+                per_param = []
+                for p in params:
+                    entry = {}
+                    for k, v in opt.state.get(p, {}).items():
+                        entry[k] = ("tensor", tuple(v.shape), str(v.dtype).replace("torch.", ""), v.is_cuda) \
+                            if torch.is_tensor(v) else ("value", v)
+                    per_param.append(entry)
+                manifest = (per_param, [None if a is None else a.get("step") for a in arenas])
+            box = [manifest]
+            dist.broadcast_object_list(box, src=0)
+            per_param, arena_steps = box[0]
+            for p, entry in zip(params, per_param):
+                if not entry and p not in opt.state:
+                    continue
+                st = opt.state[p]
+                for k in [k for k in st if k not in entry]:
+                    del st[k]
+                for k, spec in entry.items():
+                    if spec[0] == "value":
+                        st[k] = spec[1]
+                    elif not (torch.is_tensor(st.get(k)) and tuple(st[k].shape) == spec[1]):
+                        st[k] = torch.zeros(spec[1], dtype=getattr(torch, spec[2]),
+                                            device=p.device if spec[3] else "cpu")
+            for a, step in zip(arenas, arena_steps):
+                if a is not None and step is not None:
+                    a["step"] = step
+            for p in params:
+                tensors += [v for v in opt.state.get(p, {}).values() if torch.is_tensor(v)]
         # every tensor travels on the side the backend moves (RCCL: device memory, gloo: host
         # memory); broadcast_tensors_ stages the others (torch.optim keeps state['step'] on the host)
         parallel.broadcast_tensors_(tensors)
-        if optimiser and self.optimiser is not None:
-            # step counters kept as python integers (HipAdam / HipSGD, per parameter and per arena):
-            # the bias corrections of the replicas must agree as well
-            dev = self._dist_device()
-            for st in self.optimiser.state.values():
-                if isinstance(st.get("step"), int):
-                    st["step"] = parallel.broadcast_int(st["step"], device=dev)
-            for a in getattr(self.optimiser, "_arenas", None) or []:
-                if a is not None and isinstance(a.get("step"), int):
-                    a["step"] = parallel.broadcast_int(a["step"], device=dev)
         if self._resident is not None:
             self._resident["synced"] = False
 

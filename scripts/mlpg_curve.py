@@ -1,4 +1,4 @@
-"""MLPG solve time against batch size for the solves the library holds (ITTS_MLPG_PATH).
+"""MLPG solve time against batch size.
 Usage (GPU box): python scripts/mlpg_curve.py"""
 import os
 import sys
@@ -30,14 +30,7 @@ for n_u in [int(v) for v in os.environ.get("MLPG_SIZES", "256,1024,4096").split(
     off = world.offsets(utterance_lengths(n_u, seed=5).tolist())
     fr = off[-1]
     feat = torch.randn(fr, 186, dtype=torch.float64, device=dev)
-    outs = {}
-    for mode in sys.argv[1:] or ("stream", "direct", "fused", "multipass", "seq"):
-        os.environ["ITTS_MLPG_PATH"] = mode
-        ms = timed(lambda: ops.mlpg_generation(feat, var, 62, off))
-        outs[mode] = ops.mlpg_generation(feat, var, 62, off)
-        print("%5d utts %8d frames %-6s %8.3f ms  %6.1f GB/s algorithmic (%.1f %% of 8 TB/s)" % (
-            n_u, fr, mode, ms, fr * 2000 / ms / 1e6, fr * 2000 / ms / 1e6 / 80.0), flush=True)
-    keys = list(outs)
-    for k in keys[1:]:
-        print("      max |%s - %s| = %.3e" % (k, keys[0], float((outs[k] - outs[keys[0]]).abs().max())))
-    del feat, outs
+    ms = timed(lambda: ops.mlpg_generation(feat, var, 62, off))
+    print("%5d utts %8d frames %8.3f ms  %6.1f GB/s algorithmic (%.1f %% of 8 TB/s)" % (
+        n_u, fr, ms, fr * 2000 / ms / 1e6, fr * 2000 / ms / 1e6 / 80.0), flush=True)
+    del feat
