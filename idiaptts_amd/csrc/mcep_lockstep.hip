@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "context.h"
+#include "wave_fft.h"
 #include "world_dev.h"
 
 namespace itts {
@@ -502,6 +503,84 @@ __global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
   for (int k = threadIdx.x; k <= f2; k += NT) row[k] = zr[k];
 }
 
+// ---- the same two kernels with one WAVE per frame (flng = 1024: 16 .. 24 kHz) ----------------------
+// wave_fft.h: the 513 bins of a frame live eight per lane in registers, the transforms need no
+// workgroup barrier; one persistent workgroup of sixteen waves per CU.  Same butterflies, same
+// twiddles, same per-bin arithmetic as the workgroup-per-frame kernels above: results bit-identical.
+__device__ __forceinline__ double ls_bcast0(double v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+constexpr int LSW = 1024;      // threads per workgroup of the wave kernels: sixteen frames in flight per CU, one twiddle table
+
+__global__ __launch_bounds__(LSW) void mcls_init_wave_kernel(LsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int f2 = 512, K = 513;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
+  wf::Plan512 P;
+  wf::table512_init(smem, a.g_tw_compact);
+  wf::plan512_init(P, a.g_tw_compact, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
+  for (int64_t g = (int64_t)blockIdx.x * (LSW / 64) + wv; g < a.T; g += (int64_t)gridDim.x * (LSW / 64)) {
+    const double* in = a.in + g * K;
+    double* xp = a.xp + g * a.ldk;
+    double2 z[8], x512;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int k = q < 8 ? l + 64 * q : f2;
+      double v = in[k];
+      if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
+      const double x = v * v + a.eps;
+      if (q < 8 || l == 0) xp[k] = x;
+      const double2 r = make_double2(wd::log_pos(x), 0.0);
+      if (q < 8) z[q] = r; else x512 = r;
+    }
+    wf::irfft1024(z, x512, P);          // z[q] = (c[2m], c[2m+1]), m = lane + 64 q
+    double* row = a.cbuf + g * a.ldk;
+    if (l == 0) {
+      a.sprev[g] = z[0].x / 2;
+      a.done[g] = 0;
+      a.iters[g] = 0;
+      z[0].x /= 2;                       // c[0] /= 2, c[f2] /= 2
+      row[f2] = z[4].x / 2;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
+  }
+}
+
+__global__ __launch_bounds__(LSW) void mcls_spec_wave_kernel(LsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int f2 = 512;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
+  wf::Plan512 P;
+  wf::table512_init(smem, a.g_tw_compact);
+  wf::plan512_init(P, a.g_tw_compact, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
+  const int64_t n = a.rows ? a.n_rows : a.T;
+  for (int64_t r = (int64_t)blockIdx.x * (LSW / 64) + wv; r < n; r += (int64_t)gridDim.x * (LSW / 64)) {
+    const int64_t g = a.rows ? a.rows[r] : r;
+    if (a.done[g]) continue;
+    double* row = a.cbuf + g * a.ldk;
+    const double* xp = a.xp + g * a.ldk;
+    // the real sequence c'[0 .. f2], zero beyond, packed two samples per complex point
+    double2 z[8], x512;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = *reinterpret_cast<const double2*>(row + 2 * (l + 64 * q));
+#pragma unroll
+    for (int q = 4; q < 8; ++q) z[q] = make_double2(0.0, 0.0);
+    if (l == 0) z[4] = make_double2(row[f2], 0.0);
+    wf::rfft1024(z, x512, P);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) z[q] = make_double2(xp[l + 64 * q] / exp(2.0 * z[q].x), 0.0);
+    x512 = make_double2(xp[f2] / exp(2.0 * ls_bcast0(x512.x)), 0.0);
+    wf::irfft1024(z, x512, P);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
+    if (l == 0) row[f2] = z[4].x;
+  }
+}
+
 // convergence test + Newton update of one frame from cr
 __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -762,7 +841,24 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
-  hipLaunchKernelGGL(mcls_init_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
+  // 1024-point transforms (16 .. 24 kHz): one wave per frame, one persistent workgroup per CU
+  const bool wave = flng == 2 * wf::WF_N;
+  const size_t lds_wave = wf::WF_TABLE_BYTES + (size_t)(LSW / 64) * wf::WF_LDS_BYTES;
+  int n_cu = 256;
+  if (wave) {
+    int dev = 0;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  if (wave) {
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_wave));
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_spec_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_wave));
+  }
+  const dim3 wave_grid((unsigned)std::min<int64_t>((T + LSW / 64 - 1) / (LSW / 64), (int64_t)n_cu));
+  if (wave) hipLaunchKernelGGL(mcls_init_wave_kernel, wave_grid, dim3(LSW), lds_wave, s, a);
+  else hipLaunchKernelGGL(mcls_init_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
   ITTS_LAUNCH_CHECK();
   int rc = launch_gemm_f64(cbuf, Kp, ft->fwdT, m1, mc, m1, T, m1, K, nullptr, s);
   if (rc) return rc;
@@ -770,7 +866,12 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     a.iter = it;
     const int64_t nr = a.n_rows;      // frames still iterating (their list is a.rows)
     if ((rc = launch_gemm_f64(mc, m1, ft->invT, K, cbuf, Kp, nr, K, m1, a.rows, s))) return rc;
-    hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)nr), dim3(NT), lds_fft, s, a);
+    if (wave) {
+      const dim3 grid((unsigned)std::min<int64_t>((nr + LSW / 64 - 1) / (LSW / 64), (int64_t)n_cu));
+      hipLaunchKernelGGL(mcls_spec_wave_kernel, grid, dim3(LSW), lds_wave, s, a);
+    } else {
+      hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)nr), dim3(NT), lds_fft, s, a);
+    }
     ITTS_LAUNCH_CHECK();
     if ((rc = launch_gemm_f64(cbuf, Kp, ft->frqT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
     const dim3 wgrid((unsigned)((nr + 3) / 4));

@@ -286,6 +286,7 @@ struct D4cArgs {
   const double2* g_tw;    // compact table of the largest transform (DeviceContext::tw_compact)
   int bmax;
   const int* order;       // workgroup -> frame: voiced frames first (they do all the work)
+  const double* nwin;     // [wl] Nuttall window of the coarse-aperiodicity bands (d4c_nuttall_kernel)
 };
 
 // Voiced frames to the front of the launch order, unvoiced ones (which only write constants) to the
@@ -313,60 +314,112 @@ struct D4cLds {
   double* red;
 };
 
-// windowed segment written to zr[0..n) (zero padded to `pad`): x*win - win*mean. Returns n.
-// normalise: divide by sqrt(sum of squares) (D4C centroid). `ramp`: multiply sample i by (i+1).
-__device__ inline int windowed_to(const double* __restrict__ x, int64_t xl, int fs, double f0, double pos,
-                                  int blackman, double ratio, double* zr, int pad, bool normalise,
-                                  bool ramp, double* red) {
-  const int half = mround(ratio * fs / f0 / 2.0);
-  const int n = 2 * half + 1;
-  const int64_t c = mround(pos * fs + 0.001);
-  auto winv = [&](int i) {
-    const int b = i - half;
+// The analysis window of a frame, kept in registers: thread t owns the samples t + 256 j.  D4C windows
+// a frame's segment six times (LoveTrain, four times for the centroid, once for the power spectrum)
+// and every pass needs the window twice (the segment, then the mean removal): evaluated on the spot
+// that was 21 n fp64 cosines per frame (n = 4 fs / f0 + 1 samples) -- as many instructions as the seven
+// transforms.  Now each distinct window is evaluated once (4.5 n) with the short cosine of fastmath.h.
+template <int PER>
+struct Win {
+  double w[PER];
+  int half, n;
+};
+template <int PER>
+__device__ __forceinline__ void win_make(Win<PER>& W, int fs, double f0, int blackman, double ratio) {
+  W.half = mround(ratio * fs / f0 / 2.0);
+  W.n = 2 * W.half + 1;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * NT;
+    const int b = i - W.half;
     const double p = (2.0 * b / ratio) / fs;
-    return blackman ? 0.42 + 0.5 * cos(kPi * p * f0) + 0.08 * cos(kPi * p * f0 * 2)
-                    : 0.5 * cos(kPi * p * f0) + 0.5;
-  };
+    double w = 0.0;
+    if (i < W.n)
+      w = blackman ? 0.42 + 0.5 * cos_mid(kPi * p * f0) + 0.08 * cos_mid(kPi * p * f0 * 2)
+                   : 0.5 * cos_mid(kPi * p * f0) + 0.5;
+    W.w[j] = w;
+  }
+}
+
+// windowed segment written to zr[0..n) (zero padded to `pad`): x*win - win*mean; v keeps this thread's
+// values.  normalise: divide by sqrt(sum of squares) (D4C centroid).  `ramp`: multiply sample i by (i+1).
+template <int PER>
+__device__ inline void windowed_to(const double* __restrict__ x, int64_t xl, int fs, double pos, const Win<PER>& W,
+                                   double* zr, int pad, bool normalise, bool ramp, double* red, double (&v)[PER]) {
+  const int half = W.half, n = W.n;
+  const int64_t c = mround(pos * fs + 0.001);
   double swf = 0.0, sw = 0.0;
-  for (int i = threadIdx.x; i < pad; i += NT) {
-    double v = 0.0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * NT;
+    v[j] = 0.0;
     if (i < n) {
-      const double w = winv(i);
       int64_t idx = c + i - half;
       idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
-      v = x[idx] * w;
-      swf += v;
-      sw += w;
+      v[j] = x[idx] * W.w[j];
+      swf += v[j];
+      sw += W.w[j];
     }
-    zr[i] = v;
   }
   swf = bsum(swf, red);
   sw = bsum(sw, red);
   const double mean = swf / sw;
   double pw = 0.0;
-  for (int i = threadIdx.x; i < n; i += NT) {
-    const double v = zr[i] - winv(i) * mean;
-    zr[i] = v;
-    pw += v * v;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * NT;
+    if (i < n) {
+      const double u = v[j] - W.w[j] * mean;
+      v[j] = u;
+      pw += u * u;
+    }
   }
   if (normalise) {
     pw = sqrt(bsum(pw, red));
-    for (int i = threadIdx.x; i < n; i += NT) {
-      double v = zr[i] / pw;
-      if (ramp) v *= (i + 1.0);
-      zr[i] = v;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = (int)threadIdx.x + j * NT;
+      if (i < n) v[j] = v[j] / pw;
     }
   }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * NT;
+    if (i < pad) zr[i] = (ramp && i < n) ? v[j] * (i + 1.0) : v[j];
+  }
+  for (int i = (int)threadIdx.x + PER * NT; i < pad; i += NT) zr[i] = 0.0;
   __syncthreads();
-  return n;
+}
+
+// the same segment again, multiplied by the ramp (i + 1): what a second windowed_to(..., ramp = true)
+// would recompute from scratch
+template <int PER>
+__device__ inline void ramped_to(const Win<PER>& W, const double (&v)[PER], double* zr, int pad) {
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * NT;
+    if (i < pad) zr[i] = i < W.n ? v[j] * (i + 1.0) : v[j];
+  }
+  for (int i = (int)threadIdx.x + PER * NT; i < pad; i += NT) zr[i] = 0.0;
+  __syncthreads();
 }
 
 // AREG: the centroid accumulates in registers and only two bin arrays live in LDS (needed to get
 // two workgroups per CU with the 4096-point transforms of 48 kHz; costs ~60 VGPRs, so the
 // 2048-point case keeps three arrays and stays at three workgroups per CU).
+// The Nuttall window of the coarse-aperiodicity bands only depends on the transform size and the
+// sampling rate: tabulated once per call (three fp64 cosines per sample and band and frame less).
+__global__ void d4c_nuttall_kernel(int wl, double* __restrict__ nwin) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < wl; i += gridDim.x * blockDim.x) {
+    const double tt = (double)i / (wl - 1.0);
+    nwin[i] = 0.355768 - 0.487396 * cos(2.0 * kPi * tt) + 0.144232 * cos(4.0 * kPi * tt) - 0.012604 * cos(6.0 * kPi * tt);
+  }
+}
+
 template <bool AREG>
-__global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
+__global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PER = AREG ? 16 : 8;           // window samples per thread: n < fftd = 256 PER
   const int fmax = max(a.fftd, a.fftl);
   const int hmax = fmax / 2;
   D4cLds L;
@@ -409,8 +462,10 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
       const int fft = a.fftl;
       const int b0 = (int)ceil(100.0 * fft / fs), b1 = (int)ceil(4000.0 * fft / fs),
                 b2 = (int)ceil(7900.0 * fft / fs);
-      windowed_to(x, xl, fs, f0raw > 40.0 ? f0raw : 40.0, pos, 1, 3.0, zr,
-                  fft + 2, false, false, L.red);
+      Win<PER> W;
+      double seg[PER];
+      win_make(W, fs, f0raw > 40.0 ? f0raw : 40.0, 1, 3.0);
+      windowed_to(x, xl, fs, pos, W, zr, fft + 2, false, false, L.red, seg);
       rfft_lds(L.z, fft, a.logfftl, L.tw, fmax);
       double s1 = 0.0, s2 = 0.0;
       for (int k = threadIdx.x; k <= b2; k += NT) {
@@ -438,16 +493,19 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
     constexpr int APER = 9;                     // (4096 / 2 + 1) / 256 rounded up
     double acc_a[AREG ? APER : 1];
     double* im1 = AREG ? L.A : L.C;
+    Win<PER> W;
+    double seg[PER];
+    win_make(W, fs, f0, 1, 4.0);               // one Blackman window serves all four centroid transforms
     for (int side = 0; side < 2; ++side) {
       const double cpos = side == 0 ? pos - 0.25 / f0 : pos + 0.25 / f0;
-      windowed_to(x, xl, fs, f0, cpos, 1, 4.0, zr, fft + 2, true, false, L.red);
+      windowed_to(x, xl, fs, cpos, W, zr, fft + 2, true, false, L.red, seg);
       rfft();
       for (int k = threadIdx.x; k <= h; k += NT) {
         L.B[k] = L.z[k].x;
         im1[k] = L.z[k].y;
       }
       __syncthreads();
-      windowed_to(x, xl, fs, f0, cpos, 1, 4.0, zr, fft + 2, true, true, L.red);
+      ramped_to(W, seg, zr, fft + 2);
       rfft();
       if (AREG) {
 #pragma unroll
@@ -476,7 +534,8 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
     }
     dc_correction(L.A, f0, fs, fft);
     // --- smoothed power spectrum
-    windowed_to(x, xl, fs, f0, pos, 0, 4.0, zr, fft + 2, false, false, L.red);
+    win_make(W, fs, f0, 0, 4.0);
+    windowed_to(x, xl, fs, pos, W, zr, fft + 2, false, false, L.red, seg);
     rfft();
     for (int k = threadIdx.x; k <= h; k += NT) {
       const double2 v = L.z[k];
@@ -502,10 +561,7 @@ __global__ __launch_bounds__(NT) void d4c_kernel(D4cArgs a) {
       for (int i = threadIdx.x; i < fft + 2; i += NT) {
         double v = 0.0;
         if (i <= halfw * 2) {
-          const double tt = (double)i / (wl - 1.0);
-          const double nw = 0.355768 - 0.487396 * cos(2.0 * kPi * tt) + 0.144232 * cos(4.0 * kPi * tt) -
-                            0.012604 * cos(6.0 * kPi * tt);
-          v = L.C[center - halfw + i] * nw;
+          v = L.C[center - halfw + i] * a.nwin[i];      // Nuttall window of the band, tabulated per call
         }
         zr[i] = v;
       }
@@ -729,11 +785,18 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
                      0, s, d_f0, t_total, d_order, d_order + t_total);
   ITTS_LAUNCH_CHECK();
   a.order = d_order;
+  const int wl = (int)(3000.0 * a.fftd / fs) * 2 + 1;
+  double* d_nwin = nullptr;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_nwin, (size_t)wl * 8, s));
+  hipLaunchKernelGGL(d4c_nuttall_kernel, dim3((wl + 255) / 256), dim3(256), 0, s, wl, d_nwin);
+  ITTS_LAUNCH_CHECK();
+  a.nwin = d_nwin;
   if (areg)
     hipLaunchKernelGGL(d4c_kernel<true>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   else
     hipLaunchKernelGGL(d4c_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
+  ITTS_HIP_CHECK(itts::scratch_free(d_nwin, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_order, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_fo, s));

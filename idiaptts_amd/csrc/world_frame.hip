@@ -15,6 +15,7 @@
 #include <cmath>
 
 #include "context.h"
+#include "wave_fft.h"
 #include "world_dev.h"
 
 namespace itts {
@@ -62,7 +63,7 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
   double e = 0.0;
   for (int i = threadIdx.x; i < n; i += NT) {
     const int b = i - half;
-    const double w = 0.5 * cos(kPi * ((double)b / 1.5 / fs) * f0) + 0.5;
+    const double w = 0.5 * cos_mid(kPi * ((double)b / 1.5 / fs) * f0) + 0.5;
     win[i] = w;
     e += w * w;
   }
@@ -270,6 +271,38 @@ __global__ __launch_bounds__(NT) void mgc2sp_kernel(Mgc2spArgs a) {
   }
 }
 
+// The same with one WAVE per frame (fftlen = 1024; wave_fft.h): sixteen frames in flight per CU, no
+// workgroup barrier, bit-identical spectra.
+constexpr int MGW = 1024;
+__global__ __launch_bounds__(MGW) void mgc2sp_wave_kernel(Mgc2spArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int f2 = 512;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
+  wf::Plan512 P;
+  wf::table512_init(smem, a.g_tw);
+  wf::plan512_init(P, a.g_tw, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
+  for (int64_t g = (int64_t)blockIdx.x * (MGW / 64) + wv; g < a.T; g += (int64_t)gridDim.x * (MGW / 64)) {
+    const double* c = a.cep + g * a.ld_cep;          // rows are 16-byte aligned (even pitch)
+    double2 z[8], x512;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = *reinterpret_cast<const double2*>(c + 2 * (l + 64 * q));
+#pragma unroll
+    for (int q = 4; q < 8; ++q) z[q] = make_double2(0.0, 0.0);
+    if (l == 0) z[4] = make_double2(c[f2], 0.0);
+    wf::rfft1024(z, x512, P);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (q == 8 && l != 0) break;
+      const int k = q < 8 ? l + 64 * q : f2;
+      const double re = q < 8 ? z[q].x : x512.x;
+      if (a.out_f64) a.out_f64[g * (f2 + 1) + k] = re;
+      const float amp = expf((float)re);
+      if (a.out_f32) a.out_f32[g * (f2 + 1) + k] = amp;
+      if (a.out_pow) a.out_pow[g * (f2 + 1) + k] = (double)amp * (double)amp;
+    }
+  }
+}
+
 // ---- aperiodicity coding -----------------------------------------------------------------------
 // WORLD interp1 (with histc index semantics) on a short monotone knot vector, one query.
 __device__ __forceinline__ double interp1_small(const double* xk, const double* yk, int n, double xi) {
@@ -465,10 +498,22 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   if (rc) return rc;
   Mgc2spArgs a{d_cep, ld_cep, T, order, fftlen, ilog2_host(fftlen), d_amp_f32, d_logamp_f64, d_pow_f64,
                ctx->twiddles};
-  size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16;
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mgc2sp_kernel, dim3((unsigned)T), dim3(NT), lds, s, a);
+  if (fftlen == 2 * wf::WF_N) {
+    int dev = 0, n_cu = 256;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    a.g_tw = ctx->tw_compact[a.logfft];
+    const size_t lds = wf::WF_TABLE_BYTES + (size_t)(MGW / 64) * wf::WF_LDS_BYTES;
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_wave_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mgc2sp_wave_kernel, dim3((unsigned)std::min<int64_t>((T + MGW / 64 - 1) / (MGW / 64), n_cu)),
+                       dim3(MGW), lds, s, a);
+  } else {
+    size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16;
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mgc2sp_kernel, dim3((unsigned)T), dim3(NT), lds, s, a);
+  }
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(itts::scratch_free(d_cep, s));
   return ITTS_OK;
