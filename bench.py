@@ -240,6 +240,32 @@ def hip_event_time_ms(fn, stream, iters):
     return start.elapsed_time(end) / iters
 
 
+def committed_traffic(section):
+    """HBM bytes per pass / step of a secondary section from the committed PMC passes of this round
+    (profiles/r4_section_traffic.json: scripts/section_traffic.sh); None when the file is absent.
+    Not re-measured inside bench.py (the counters need their own profiler runs)."""
+    path = os.path.join(ROOT, "profiles", "r4_section_traffic.json")
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        row = json.load(f).get("sections", {}).get(section)
+    return row["hbm_bytes"] if row else None
+
+
+def committed_fractions(kernel_substring):
+    """VALU-issue / LDS / wait fractions of a WORLD kernel from the committed SQ counter passes
+    (profiles/r4_world_pmc_fractions.json: scripts/pmc_fractions.py); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r4_world_pmc_fractions.json")
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        rows = json.load(f)
+    for k, v in rows.items():
+        if kernel_substring in k:
+            return dict(v, kernel=k)
+    return None
+
+
 def scratch_pool_stats(L):
     """reserved / used bytes and release threshold of the stream-ordered scratch pool: a section
     that ran with a pool below its working set shows up here (and 5x slower)"""
@@ -429,15 +455,23 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     w["analysis_roofline"] = {
         "bound": "hbm", "kernel": "mcls_solve_wave_kernel + d4c_kernel + gemm_f64_kernel (see profiles/)",
         "achieved": w["analysis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-        "frac": w["analysis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS, "traffic": None,
+        "frac": w["analysis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS,
+        "traffic": committed_traffic("analysis_%d" % fs) if n_utts == (256 if fs <= 24000 else 64) else None,
+        "what_binds_it": "fp64 VALU issue and LDS latency, not HBM: see issue_fractions (share of the chip's VALU "
+                         "issue slots / LDS cycles in use, share of a wave's life spent waiting; SQ counters, "
+                         "profiles/r4_world_pmc_fractions.json)",
+        "issue_fractions": {k: committed_fractions(k) for k in ("mcls_solve_wave", "d4c_kernel", "cheaptrick",
+                                                                 "mcls_spec", "gemm_f64_lds")} if fs <= 24000 else None,
         "algorithmic_bytes_per_frame": fs // 200 * 8 + (61 + nap) * 4,
         "fp64_tflops": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks,
         "fp64_frac_of_peak": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS,
         "fp64_flops_per_frame_estimate": an_flops}
     w["synthesis_roofline"] = {
-        "bound": "hbm", "kernel": "syn_pulse_kernel",
+        "bound": "hbm", "kernel": "syn_pulse_wave_kernel" if n_fft == 1024 else "syn_pulse_kernel",
         "achieved": w["synthesis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-        "frac": w["synthesis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS, "traffic": None,
+        "frac": w["synthesis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS,
+        "traffic": committed_traffic("synthesis_%d" % fs) if n_utts == (256 if fs <= 24000 else 64) else None,
+        "issue_fractions": {k: committed_fractions(k) for k in ("syn_pulse", "mgc2sp")} if fs <= 24000 else None,
         "algorithmic_bytes_per_frame": (n_fft // 2 + 1) * 16 + 8 + fs // 200 * 4,
         "fp64_tflops": frames * sy_flops / (ms_sy * 1e-3) / 1e12 / n_ranks,
         "fp64_frac_of_peak": frames * sy_flops / (ms_sy * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS}
@@ -455,13 +489,9 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                                                stream, 7), dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
         gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
-        # HBM bytes of one solve from the committed PMC passes (profiles/r3g_mlpg_traffic.json:
+        # HBM bytes of one solve from the committed PMC passes (profiles/r4_section_traffic.json:
         # FETCH_SIZE x 2 + WRITE_SIZE on this same workload); not re-measured inside bench.py
-        ml_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3g_mlpg_traffic.json")
-        if os.path.isfile(tpath):
-            with open(tpath) as f:
-                ml_traffic = json.load(f)["paths"]["stream"]["hbm_bytes_per_solve"]
+        ml_traffic = committed_traffic("mlpg")
         res["mlpg"] = {"utterances": 256 * n_ranks, "frames": ml_frames, "ms": ms_ml,
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
                        "algorithmic_GBps": gbs,
@@ -605,7 +635,8 @@ def bilstm_section(dev, n_utts=64, steps=6, cell="LSTM", rank=0, world=1, key=No
         "roofline": {"bound": "mfma", "kernel": "gemm_ring_kernel + rnn_persist_fwd_kernel<{0}> + rnn_persist_bwd_kernel<{0}>".format(
                          gates),
                      "achieved": tflops / world, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / world / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                     "frac": tflops / world / PEAK_MFMA_F32_TFLOPS,
+                     "traffic": committed_traffic("bi" + cell.lower()) if n_utts == 64 else None,
                      "algorithmic_flops_per_frame": rnn_flops_per_frame(gates=gates)}}}
 
 
@@ -767,6 +798,42 @@ class SclkSampler:
         v = sorted(self.samples)
         return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1],
                 "samples": len(v)}
+
+
+def exchange_plan(n, ff_params, rnn_params, ff_step_ms, rnn_step_ms):
+    """What every section exchanges per step / call at n GPUs and what that is expected to cost, so that
+    a SCALE record can be checked against it.  Ring all-reduce over xGMI: each
+    rank moves 2 (n - 1) / n of the buffer; 7 links x ~153 GB/s per GPU are point to point, a ring uses
+    one link each way (~100 GB/s effective is assumed), ~5 us per hop of latency, 2 (n - 1) hops."""
+    if n <= 1:
+        return None
+
+    def ring(bytes_):
+        return 2.0 * (n - 1) / n * bytes_ / 100e9 + 2 * (n - 1) * 5e-6
+
+    ff_b, rnn_b = 4 * ff_params, 4 * rnn_params
+    ff_t, rnn_t = ring(ff_b), ring(rnn_b)
+    # FF: three per-layer all-reduces issued behind each layer's weight-gradient launch; only the last
+    # (first layer's 0.87 MB) has nothing to hide behind
+    ff_exposed = ring(4 * (428 * 512 + 512))
+    stats_b = 8 * (1 + 187 + 187 * 187)
+    return {
+        "n_gpus": n, "assumed_ring_GBps": 100.0, "assumed_hop_latency_us": 5.0,
+        "ff_train_step": {"collective": "3 all-reduce(sum) of the flat fp32 gradient segments, asynchronous",
+                          "bytes_per_rank_per_step": ff_b, "all_reduce_ms": ff_t * 1e3,
+                          "predicted_exposed_ms": ff_exposed * 1e3,
+                          "predicted_efficiency": ff_step_ms / (ff_step_ms + ff_exposed * 1e3)},
+        "bilstm_bigru_step": {"collective": "1 all-reduce(sum) of the flat gradient arena after backward",
+                              "bytes_per_rank_per_step": rnn_b, "all_reduce_ms": rnn_t * 1e3,
+                              "predicted_exposed_ms": rnn_t * 1e3,
+                              "predicted_efficiency": (rnn_step_ms / (rnn_step_ms + rnn_t * 1e3)) if rnn_step_ms else None,
+                              "what_config_3_means_here": "weak scaling, 64 utterances per GPU and step; the "
+                              "64-utterances-in-all form (bilstm_global_batch, 8 rows per GPU) is reported for "
+                              "completeness and does not scale: the recurrence costs 4-5 us per step whatever the batch"},
+        "world_analysis_synthesis_mlpg": {"collective": "none in the data path", "bytes_per_rank_per_step": 0,
+                                          "predicted_efficiency": 1.0},
+        "gen_data": {"collective": "1 all-reduce(sum) of the normalisation sums per call",
+                     "bytes_per_rank_per_call": stats_b, "predicted_exposed_ms": ring(stats_b) * 1e3}}
 
 
 def visible_gpus():
@@ -1027,9 +1094,11 @@ def main():
         flops = flops_per_frame(dims) * nloc
         achieved = flops / (ms * 1e-3) / 1e12
         # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # see profiles/r3g_gemm_traffic.json); not re-measured inside bench.py.
+        # see profiles/r4_gemm_traffic.json); not re-measured inside bench.py.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3g_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r4_gemm_traffic.json")
+        if not os.path.isfile(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r3g_gemm_traffic.json")
         if os.path.isfile(tpath) and args.utts_per_gpu == 32:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
@@ -1087,11 +1156,18 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "FF acoustic model 425->512(tanh)->512(tanh)->187 train step "
                                    "(fwd + masked MSE + bwd + Adam), {} utterances/GPU/step of "
-                                   "2-10 s at 5 ms frames, packed valid frames".format(
-                                       args.utts_per_gpu),
+                                   "2-10 s at 5 ms frames, packed valid frames; weak scaling under --gpus N "
+                                   "(every rank its own {} utterances; config 3 likewise: 64 per GPU)".format(
+                                       args.utts_per_gpu, args.utts_per_gpu),
                        "utts_per_gpu": args.utts_per_gpu, "parallelism": "dp{}".format(world)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        rnn_params = 2 * (4 * 512 * (428 + 512) + 8 * 512) + 2 * 2 * (4 * 512 * (1024 + 512) + 8 * 512) + 1024 * 187 + 187
+        out["exchange_plan"] = exchange_plan(
+            world if world > 1 else 8, model.numel, rnn_params, dt / args.steps * 1e3,
+            rnn_extra.get("bilstm", {}).get("ms_per_step"))
+        if world == 1:
+            out["exchange_plan"]["note"] = "prediction for 8 GPUs from this run's single-GPU step times (nothing here has run on more than one GPU)"
         if share_gpu:
             out["shared_gpu"] = ("functional check only: {} ranks on ONE device, collectives over "
                                  "gloo -- not a measurement".format(world))

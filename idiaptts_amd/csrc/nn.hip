@@ -934,6 +934,51 @@ extern "C" int itts_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, 
   return launch_gemm<true, true, EPI_BIAS_ACT>(g, 1, as_stream(stream));
 }
 
+// ---- row gather: pack_padded_sequence / pad_packed_sequence / the h_{t-1} shift of the recurrent layers
+// dst row r = src row idx[r] (its first `width` columns), the fill row (or zeros) where idx[r] is outside
+// [0, n_src); columns width .. dst_width - 1 of every dst row are zeroed (row pitches of 16 bytes for the
+// GEMMs).  One kernel for what the reference leaves to torch.nn.utils.rnn (rnn_dyn/RNNWrapper.py:89-102)
+// and autograd: index_select + pad on the way in, index_copy into zeros on the way out, cat + index_select
+// for the shifted state.
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ src, int64_t ld_src, int64_t n_src,
+                                                          const int64_t* __restrict__ idx, int64_t n_out, int width,
+                                                          const float* __restrict__ fill, float* __restrict__ dst,
+                                                          int64_t ld_dst, int dst_width, int vec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wn = (int64_t)gridDim.x * 4;
+  for (int64_t r = w0; r < n_out; r += wn) {          // one wave per row
+    const int64_t i = idx[r];
+    const float* s = (i >= 0 && i < n_src) ? src + i * ld_src : fill;
+    float* d = dst + r * ld_dst;
+    if (vec) {
+      const int w4 = width >> 2, d4 = dst_width >> 2;
+      for (int c = lane; c < d4; c += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < w4 && s) v = reinterpret_cast<const float4*>(s)[c];
+        reinterpret_cast<float4*>(d)[c] = v;
+      }
+    } else {
+      for (int c = lane; c < dst_width; c += 64) d[c] = (c < width && s) ? s[c] : 0.f;
+    }
+  }
+}
+
+extern "C" int itts_rows_gather_f32(const float* d_src, int64_t ld_src, int64_t n_src, const int64_t* d_idx,
+                                    int64_t n_out, int width, const float* d_fill_row, float* d_dst, int64_t ld_dst,
+                                    int dst_width, void* stream) {
+  ITTS_REQUIRE(n_out == 0 || (d_idx && d_dst && (d_src || n_src == 0)), "null pointer");
+  ITTS_REQUIRE(n_out >= 0 && n_src >= 0 && width >= 0 && dst_width >= width && ld_src >= width && ld_dst >= dst_width,
+               "bad sizes");
+  if (n_out == 0 || dst_width == 0) return ITTS_OK;
+  const int vec = width % 4 == 0 && dst_width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(d_src) &&
+                  aligned16(d_dst) && (!d_fill_row || aligned16(d_fill_row));
+  const unsigned grid = (unsigned)std::min<int64_t>((n_out + 3) / 4, 16384);
+  hipLaunchKernelGGL(rows_gather_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_src, ld_src, n_src, d_idx, n_out,
+                     width, d_fill_row, d_dst, ld_dst, dst_width, vec);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
 extern "C" int64_t itts_linear_fwd_mse_workspace_bytes(int64_t M, int N) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64);
   return std::max<int64_t>(tiles, kRingGrid) * 8;   // one partial sum per tile, or per persistent workgroup

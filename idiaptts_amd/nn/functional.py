@@ -97,6 +97,10 @@ class PackedBatch(object):
         rev = row_off[t_rev] + np.arange(self.B)[None, :]
         self.d_rev_row = torch.from_numpy(np.ascontiguousarray(rev, dtype=np.int32)).to(device)
         self.flat_index = torch.from_numpy(flat.astype(np.int64)).to(device)
+        # padded position -> packed row (-1: padding), for the way back
+        inv = np.full(self.B * int(padded_time), -1, dtype=np.int64)
+        inv[flat] = np.arange(self.N)
+        self.inv_flat = torch.from_numpy(inv).to(device)
         # packed row of the previous frame of the same sequence in each direction's visiting order
         # (forward: t - 1, reverse: t + 1); first frames point at row N, where shift() puts h0
         prev_f = np.where(t_of > 0, row_off[np.maximum(t_of - 1, 0)] + b_of, self.N)
@@ -106,24 +110,25 @@ class PackedBatch(object):
         self.perm = torch.from_numpy(perm.astype(np.int64)).to(device)
         self.inv_perm = torch.from_numpy(np.argsort(perm).astype(np.int64)).to(device)
 
-    def pack(self, padded):
-        """[T, B, F] (or [B, T, F]) -> [N, F]"""
-        return padded.reshape(-1, padded.shape[-1]).index_select(0, self.flat_index)
+    def pack(self, padded, pad_cols=False):
+        """[T, B, F] (or [B, T, F]) -> [N, F]; pad_cols: -> [N, F rounded up to a multiple of 4] with zero
+        columns (rows of 16-byte multiples let the GEMM entry points take their LDS-DMA kernel)."""
+        flat2 = padded.reshape(-1, padded.shape[-1])
+        F = flat2.shape[1]
+        return RowsGatherFunction.apply(flat2, self.flat_index, self.inv_flat, (F + 3) // 4 * 4 if pad_cols else F)
 
     def unpack(self, packed, padded_shape):
         """[N, D] -> zero-padded [T, B, D] / [B, T, D] (pad_packed_sequence)"""
-        out = packed.new_zeros((padded_shape[0] * padded_shape[1], packed.shape[-1]))
-        return out.index_copy(0, self.flat_index, packed).reshape(
-            padded_shape[0], padded_shape[1], packed.shape[-1])
+        out = RowsGatherFunction.apply(packed, self.inv_flat, self.flat_index, packed.shape[-1])
+        return out.reshape(padded_shape[0], padded_shape[1], packed.shape[-1])
 
     def shift(self, y, h0, ndir, H):
         """h_{t-1} of every packed frame: the layer output [N, ndir*H] moved by one frame along each
         sequence (per direction), the initial state h0 [ndir, H] (or zeros) at the first frame."""
         out = torch.empty_like(y)
         for d in range(ndir):
-            first = h0[d:d + 1] if h0 is not None else y.new_zeros((1, H))
-            src = torch.cat((y[:, d * H:(d + 1) * H], first), dim=0)
-            out[:, d * H:(d + 1) * H] = src.index_select(0, self.prev_row[d])
+            ops.rows_gather(y[:, d * H:(d + 1) * H], self.prev_row[d], fill_row=h0[d] if h0 is not None else None,
+                            out=out[:, d * H:(d + 1) * H])
         return out
 
     def first_rows(self, d):
@@ -136,6 +141,25 @@ class PackedBatch(object):
 
     def _hptr(self):
         return ctypes.c_void_p(self.h_lengths.data_ptr())
+
+
+class RowsGatherFunction(torch.autograd.Function):
+    """out[r] = src[idx[r]] (zeros where idx[r] < 0), optionally widened by zero columns; the gradient
+    is the gather through the inverse map `idx_back` (pack and unpack are each other's adjoint)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, idx_back, out_width):
+        ctx.save_for_backward(idx_back)
+        ctx.width = src.shape[1]
+        if src.stride(-1) != 1:
+            src = src.contiguous()
+        return ops.rows_gather(src, idx, out_width=out_width)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx_back,) = ctx.saved_tensors
+        g = grad if grad.stride(-1) == 1 else grad.contiguous()
+        return ops.rows_gather(g, idx_back, width=ctx.width), None, None, None
 
 
 def _pad4_cols(t):
@@ -155,9 +179,11 @@ class LSTMLayerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, pb, w_ih, w_hh, b_ih, b_hh, h0, c0, training):
         L = _lib.load()
-        N, F = x2.shape
+        N = x2.shape[0]
+        F = w_ih.shape[-1]               # x2 may arrive with its rows already padded to 16-byte multiples
         ndir, G4, H = w_hh.shape
         T, B = pb.T, pb.B
+        pre_padded = x2.shape[1] != F
         x2 = _pad4_cols(x2.contiguous())
         w_ih_cat = _pad4_cols(w_ih.reshape(ndir * G4, F))
         gin = ops.linear_fwd(x2, w_ih_cat, (b_ih + b_hh).reshape(-1), ops.ACT_NONE)
@@ -186,7 +212,7 @@ class LSTMLayerFunction(torch.autograd.Function):
                                   h0c if h0c is not None else empty,
                                   c0c if c0c is not None else empty)
             ctx.pb = pb
-            ctx.dims = (F, H, ndir, h0c is not None, c0c is not None)
+            ctx.dims = (F, H, ndir, h0c is not None, c0c is not None, pre_padded)
         return y, hn, cn
 
     @staticmethod
@@ -199,7 +225,7 @@ class LSTMLayerFunction(torch.autograd.Function):
         if dy is None:
             dy = torch.zeros_like(y)
         pb = ctx.pb
-        F, H, ndir, has_h0, has_c0 = ctx.dims
+        F, H, ndir, has_h0, has_c0, pre_padded = ctx.dims
         hprev = pb.shift(y, h0 if has_h0 else None, ndir, H)
         G4 = 4 * H
         dev = dy.device
@@ -217,8 +243,9 @@ class LSTMLayerFunction(torch.autograd.Function):
         # by all rows -> sum over the rows; dh0 = W_hh^T dG at the first processed frame
         dh0 = dc0 = None
         if want_h0:
-            dh0 = torch.stack([dg[:, d * G4:(d + 1) * G4].index_select(0, pb.first_rows(d)).sum(0)
-                               @ w_hh[d] for d in range(ndir)], dim=0)
+            dh0 = torch.stack([ops.linear_bwd_input(
+                ops.rows_gather(dg[:, d * G4:(d + 1) * G4], pb.first_rows(d)).sum(0, keepdim=True), w_hh[d])[0]
+                for d in range(ndir)], dim=0)
         if want_c0:
             dc0 = dc0_rows.sum(dim=1)
         dw_ih, db = ops.linear_bwd_weight(dg, x2)                      # [ndir*4H, F], [ndir*4H]
@@ -228,7 +255,9 @@ class LSTMLayerFunction(torch.autograd.Function):
                                   dw=dw_hh[d], want_bias=False)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bwd_input(dg, w_ih_cat)[:, :F]
+            dx = ops.linear_bwd_input(dg, w_ih_cat)
+            if not pre_padded:
+                dx = dx[:, :F]
         db = db.reshape(ndir, G4)
         return dx, None, dw_ih[:, :F].reshape(ndir, G4, F), dw_hh, db, db.clone(), dh0, dc0, None
 
@@ -240,9 +269,11 @@ class GRULayerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, pb, w_ih, w_hh, b_ih, b_hh, h0, training):
         L = _lib.load()
-        N, F = x2.shape
+        N = x2.shape[0]
+        F = w_ih.shape[-1]               # x2 may arrive with its rows already padded to 16-byte multiples
         ndir, G3, H = w_hh.shape
         T, B = pb.T, pb.B
+        pre_padded = x2.shape[1] != F
         x2 = _pad4_cols(x2.contiguous())
         w_ih_cat = _pad4_cols(w_ih.reshape(ndir * G3, F))
         gin = ops.linear_fwd(x2, w_ih_cat, b_ih.reshape(-1), ops.ACT_NONE)
@@ -266,7 +297,7 @@ class GRULayerFunction(torch.autograd.Function):
             ctx.save_for_backward(x2, w_ih_cat, w_hh_c, gates, y,
                                   h0c if h0c is not None else torch.empty(0, device=dev))
             ctx.pb = pb
-            ctx.dims = (F, H, ndir, h0c is not None)
+            ctx.dims = (F, H, ndir, h0c is not None, pre_padded)
         return y, hn
 
     @staticmethod
@@ -279,7 +310,7 @@ class GRULayerFunction(torch.autograd.Function):
         if dy is None:
             dy = torch.zeros_like(y)
         pb = ctx.pb
-        F, H, ndir, has_h0 = ctx.dims
+        F, H, ndir, has_h0, pre_padded = ctx.dims
         hprev = pb.shift(y, h0 if has_h0 else None, ndir, H)
         G3 = 3 * H
         dev = dy.device
@@ -296,9 +327,9 @@ class GRULayerFunction(torch.autograd.Function):
                    "itts_gru_layer_bwd")
         dh0 = None
         if want_h0:      # direct part dh * z from the kernel + recurrent part W_hh^T dGh, summed over rows
-            dh0 = dh0_rows.sum(dim=1) + torch.stack(
-                [dgh[:, d * G3:(d + 1) * G3].index_select(0, pb.first_rows(d)).sum(0) @ w_hh[d]
-                 for d in range(ndir)], dim=0)
+            dh0 = dh0_rows.sum(dim=1) + torch.stack([ops.linear_bwd_input(
+                ops.rows_gather(dgh[:, d * G3:(d + 1) * G3], pb.first_rows(d)).sum(0, keepdim=True), w_hh[d])[0]
+                for d in range(ndir)], dim=0)
         dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]
         dw_hh = torch.empty((ndir, G3, H), dtype=torch.float32, device=dev)
         db_hh = torch.empty((ndir, G3), dtype=torch.float32, device=dev)
@@ -308,6 +339,8 @@ class GRULayerFunction(torch.autograd.Function):
             db_hh[d] = db
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bwd_input(dgi, w_ih_cat)[:, :F]
+            dx = ops.linear_bwd_input(dgi, w_ih_cat)
+            if not pre_padded:
+                dx = dx[:, :F]
         return dx, None, dw_ih[:, :F].reshape(ndir, G3, F), dw_hh, db_ih.reshape(ndir, G3), db_hh, \
             dh0, None

@@ -99,7 +99,7 @@ class LSTM(nn.Module):
             lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
         # pack once (valid frames only, rows sorted by length), run all layers on packed rows
         pb = PackedBatch.get(lengths, input_.shape[time_dim], self.batch_first, input_.device)
-        x = pb.pack(input_)
+        x = pb.pack(input_, pad_cols=True)
         h0 = c0 = None
         if hx is not None:
             h0, c0 = hx      # [num_layers*ndir, B, H]; RNNWrapper expands one vector per row
@@ -165,7 +165,7 @@ class GRU(nn.Module):
         if lengths is None:
             lengths = torch.full((input_.shape[batch_dim],), input_.shape[time_dim])
         pb = PackedBatch.get(lengths, input_.shape[time_dim], self.batch_first, input_.device)
-        x = pb.pack(input_)
+        x = pb.pack(input_, pad_cols=True)
         _shared_initial_state(hx)
         hn_all = []
         for layer in range(self.num_layers):

@@ -175,6 +175,29 @@ def act_bwd(dy, y, act, out=None):
     return out
 
 
+def rows_gather(src, idx, width=None, fill_row=None, out=None, out_width=None):
+    """out[r, :width] = src[idx[r], :width] (the fill row, or zeros, where idx[r] is outside
+    [0, len(src))); columns width .. out_width - 1 are zeroed.  src: float32 [R, >= width] with unit
+    column stride (any row pitch: column slices of a wider tensor are fine), idx: int64 [n_out]."""
+    L = _lib.load()
+    assert src.dtype == torch.float32 and src.dim() == 2 and (src.shape[1] <= 1 or src.stride(1) == 1)
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    width = src.shape[1] if width is None else int(width)
+    out_width = width if out_width is None else int(out_width)
+    n_out = idx.numel()
+    if out is None:
+        out = torch.empty((n_out, out_width), dtype=torch.float32, device=src.device)
+    assert out.dtype == torch.float32 and out.dim() == 2 and out.shape[0] == n_out and \
+        (out.shape[1] <= 1 or out.stride(1) == 1) and out.shape[1] >= out_width
+    ld_src = src.stride(0) if src.shape[0] > 1 else max(src.shape[1], 1)
+    ld_dst = out.stride(0) if n_out > 1 else max(out.shape[1], 1)
+    fill = fill_row.contiguous() if fill_row is not None else None
+    _lib.check(L.itts_rows_gather_f32(_ptr(src), ld_src, src.shape[0], _ptr(idx), n_out, width,
+                                      _ptr(fill) if fill is not None else None, _ptr(out), ld_dst, out_width,
+                                      _stream()), "itts_rows_gather_f32")
+    return out
+
+
 def linear_bwd_input(dz, w, yprev=None, act_prev=ACT_NONE, out=None):
     L = _lib.load()
     _need(dz, torch.float32, "dz")

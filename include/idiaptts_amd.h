@@ -189,6 +189,14 @@ int itts_feature_stats(const float* d_x, int64_t ld_x, int64_t n_rows, int col0,
                        int want_cov, int accumulate, double* d_sum, double* d_second,
                        void* d_workspace, void* stream);
 
+/* Row gather of the recurrent layers' packed layout -- pack_padded_sequence / pad_packed_sequence and
+ * their gradients (rnn_dyn/RNNWrapper.py:89-102), and the h_{t-1} shift of the weight gradient:
+ * d_dst[r, :width] = d_src[d_idx[r], :width] where 0 <= d_idx[r] < n_src, else d_fill_row[:width] (zeros when
+ * NULL); columns width .. dst_width - 1 of every row of d_dst are zeroed (16-byte row pitches for the GEMMs). */
+int itts_rows_gather_f32(const float* d_src, int64_t ld_src, int64_t n_src, const int64_t* d_idx, int64_t n_out,
+                         int width, const float* d_fill_row, float* d_dst, int64_t ld_dst, int dst_width,
+                         void* stream);
+
 /* ---- acoustic model: dense layers (rnn_dyn/FFWrapper.py:63-73 -> torch.nn.Linear + act) --- */
 #define ITTS_ACT_NONE 0
 #define ITTS_ACT_TANH 1
