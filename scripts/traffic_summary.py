@@ -29,8 +29,7 @@ out = {"note": "HBM bytes per pass (WORLD sections, MLPG) or per training step (
                "FETCH_SIZE and --pmc WRITE_SIZE in separate runs at 3 and at 5 passes of scripts/traffic_driver.py, "
                "(counters at 5 - counters at 3) / 2; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request)",
        "sections": {}}
-names = sorted({os.path.basename(p).rsplit("_", 3)[0] + "_" + os.path.basename(p).rsplit("_", 3)[1]
-                for p in glob.glob(root + "/*_FETCH_SIZE")})
+names = sorted({os.path.basename(p)[:-len("_FETCH_SIZE")].rsplit("_", 1)[0] for p in glob.glob(root + "/*_FETCH_SIZE")})
 for name in names:
     row = {}
     kern = collections.defaultdict(float)

@@ -377,3 +377,38 @@ def test_gemm_operands_that_end_where_their_mapping_ends(gpu):
     res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=600)
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_rows_gather_is_pack_unpack_and_shift(gpu):
+    """itts_rows_gather_f32 behind PackedBatch (pack_padded_sequence / pad_packed_sequence of
+    rnn_dyn/RNNWrapper.py:89-102 and their gradients): against torch's own packing, padded widths,
+    fill rows, column slices as operands, and the gradient through pack -> unpack."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from idiaptts_amd import ops
+    from idiaptts_amd.nn.functional import PackedBatch
+    torch.manual_seed(0)
+    T, B, F = 23, 5, 425
+    lens = torch.tensor([23, 7, 15, 1, 19])
+    x = torch.randn(T, B, F, device=gpu, requires_grad=True)
+    pb = PackedBatch(lens, T, False, gpu)
+    packed = pb.pack(x, pad_cols=True)
+    assert packed.shape == (int(lens.sum()), 428) and bool((packed[:, 425:] == 0).all())
+    ref = pack_padded_sequence(x.detach().cpu(), lens, enforce_sorted=False)
+    assert torch.equal(packed[:, :F].detach().cpu(), ref.data)
+    out = pb.unpack(packed[:, :F] * 2.0, x.shape)
+    want, _ = pad_packed_sequence(torch.nn.utils.rnn.PackedSequence(ref.data * 2.0, ref.batch_sizes, ref.sorted_indices,
+                                                                     ref.unsorted_indices), total_length=T)
+    assert torch.equal(out.detach().cpu(), want)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    mask = (torch.arange(T)[:, None] < lens[None, :]).to(gpu)[..., None]
+    assert torch.equal(x.grad, (2.0 * w * mask))
+    # plain gather with a fill row, out-of-range indices and a column slice as the source
+    src = torch.randn(10, 64, device=gpu)
+    idx = torch.tensor([3, 10, 0, -1, 9], device=gpu)
+    fill = torch.randn(16, device=gpu)
+    got = ops.rows_gather(src[:, 16:32], idx, fill_row=fill, out_width=20)
+    want = torch.zeros(5, 20, device=gpu)
+    for r, i in enumerate(idx.tolist()):
+        want[r, :16] = src[i, 16:32] if 0 <= i < 10 else fill
+    assert torch.equal(got, want)
