@@ -503,9 +503,9 @@ __global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
   for (int k = threadIdx.x; k <= f2; k += NT) row[k] = zr[k];
 }
 
-// ---- the same two kernels with one WAVE per frame (flng = 1024: 16 .. 24 kHz) ----------------------
+// ---- the same two kernels with one WAVE per frame (flng = 1024 or 2048) ---------------------------------
 // wave_fft.h: the 513 bins of a frame live eight per lane in registers, the transforms need no
-// workgroup barrier; one persistent workgroup of sixteen waves per CU.  Same butterflies, same
+// workgroup barrier; one persistent workgroup per CU.  Same butterflies, same
 // twiddles, same per-bin arithmetic as the workgroup-per-frame kernels above: results bit-identical.
 __device__ __forceinline__ double ls_bcast0(double v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v));
@@ -513,71 +513,75 @@ __device__ __forceinline__ double ls_bcast0(double v) {
   return __hiloint2double((int)hi, (int)lo);
 }
 
-constexpr int LSW = 1024;      // threads per workgroup of the wave kernels: sixteen frames in flight per CU, one twiddle table
+// threads per workgroup of the wave kernels: one workgroup per CU, one twiddle table per workgroup, as many
+// frames in flight as the LDS holds exchange buffers (sixteen at 1024 points, eight at 2048)
+template <int R> constexpr int lsw() { return R == 8 ? 1024 : 512; }
 
-__global__ __launch_bounds__(LSW) void mcls_init_wave_kernel(LsArgs a) {
+template <int R>
+__global__ __launch_bounds__(lsw<R>()) void mcls_init_wave_kernel(LsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int f2 = 512, K = 513;
+  constexpr int f2 = 64 * R, K = f2 + 1, NW = lsw<R>() / 64;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
-  wf::Plan512 P;
-  wf::table512_init(smem, a.g_tw_compact);
-  wf::plan512_init(P, a.g_tw_compact, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
-  for (int64_t g = (int64_t)blockIdx.x * (LSW / 64) + wv; g < a.T; g += (int64_t)gridDim.x * (LSW / 64)) {
+  typename wf::PlanOf<R>::type P;
+  wf::table_init<R>(smem, a.g_tw_compact);
+  wf::plan_init(P, a.g_tw_compact, smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>(), smem);
+  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < a.T; g += (int64_t)gridDim.x * NW) {
     const double* in = a.in + g * K;
     double* xp = a.xp + g * a.ldk;
-    double2 z[8], x512;
+    double2 z[R], xh;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int k = q < 8 ? l + 64 * q : f2;
+    for (int q = 0; q <= R; ++q) {
+      const int k = q < R ? l + 64 * q : f2;
       double v = in[k];
       if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
       const double x = v * v + a.eps;
-      if (q < 8 || l == 0) xp[k] = x;
+      if (q < R || l == 0) xp[k] = x;
       const double2 r = make_double2(wd::log_pos(x), 0.0);
-      if (q < 8) z[q] = r; else x512 = r;
+      if (q < R) z[q < R ? q : 0] = r; else xh = r;
     }
-    wf::irfft1024(z, x512, P);          // z[q] = (c[2m], c[2m+1]), m = lane + 64 q
+    wf::irfft<R>(z, xh, P);          // z[q] = (c[2m], c[2m+1]), m = lane + 64 q
     double* row = a.cbuf + g * a.ldk;
     if (l == 0) {
       a.sprev[g] = z[0].x / 2;
       a.done[g] = 0;
       a.iters[g] = 0;
       z[0].x /= 2;                       // c[0] /= 2, c[f2] /= 2
-      row[f2] = z[4].x / 2;
+      row[f2] = z[R / 2].x / 2;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
+    for (int q = 0; q < R / 2; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
   }
 }
 
-__global__ __launch_bounds__(LSW) void mcls_spec_wave_kernel(LsArgs a) {
+template <int R>
+__global__ __launch_bounds__(lsw<R>()) void mcls_spec_wave_kernel(LsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int f2 = 512;
+  constexpr int f2 = 64 * R, NW = lsw<R>() / 64;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
-  wf::Plan512 P;
-  wf::table512_init(smem, a.g_tw_compact);
-  wf::plan512_init(P, a.g_tw_compact, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
+  typename wf::PlanOf<R>::type P;
+  wf::table_init<R>(smem, a.g_tw_compact);
+  wf::plan_init(P, a.g_tw_compact, smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>(), smem);
   const int64_t n = a.rows ? a.n_rows : a.T;
-  for (int64_t r = (int64_t)blockIdx.x * (LSW / 64) + wv; r < n; r += (int64_t)gridDim.x * (LSW / 64)) {
+  for (int64_t r = (int64_t)blockIdx.x * NW + wv; r < n; r += (int64_t)gridDim.x * NW) {
     const int64_t g = a.rows ? a.rows[r] : r;
     if (a.done[g]) continue;
     double* row = a.cbuf + g * a.ldk;
     const double* xp = a.xp + g * a.ldk;
     // the real sequence c'[0 .. f2], zero beyond, packed two samples per complex point
-    double2 z[8], x512;
+    double2 z[R], xh;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = *reinterpret_cast<const double2*>(row + 2 * (l + 64 * q));
+    for (int q = 0; q < R / 2; ++q) z[q] = *reinterpret_cast<const double2*>(row + 2 * (l + 64 * q));
 #pragma unroll
-    for (int q = 4; q < 8; ++q) z[q] = make_double2(0.0, 0.0);
-    if (l == 0) z[4] = make_double2(row[f2], 0.0);
-    wf::rfft1024(z, x512, P);
+    for (int q = R / 2; q < R; ++q) z[q] = make_double2(0.0, 0.0);
+    if (l == 0) z[R / 2] = make_double2(row[f2], 0.0);
+    wf::rfft<R>(z, xh, P);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) z[q] = make_double2(xp[l + 64 * q] / exp(2.0 * z[q].x), 0.0);
-    x512 = make_double2(xp[f2] / exp(2.0 * ls_bcast0(x512.x)), 0.0);
-    wf::irfft1024(z, x512, P);
+    for (int q = 0; q < R; ++q) z[q] = make_double2(xp[l + 64 * q] / exp(2.0 * z[q].x), 0.0);
+    xh = make_double2(xp[f2] / exp(2.0 * ls_bcast0(xh.x)), 0.0);
+    wf::irfft<R>(z, xh, P);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
-    if (l == 0) row[f2] = z[4].x;
+    for (int q = 0; q < R / 2; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
+    if (l == 0) row[f2] = z[R / 2].x;
   }
 }
 
@@ -841,23 +845,28 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
-  // 1024-point transforms (16 .. 24 kHz): one wave per frame, one persistent workgroup per CU
-  const bool wave = flng == 2 * wf::WF_N;
-  const size_t lds_wave = wf::WF_TABLE_BYTES + (size_t)(LSW / 64) * wf::WF_LDS_BYTES;
+  // 1024- and 2048-point transforms: one wave per frame, one persistent workgroup per CU
+  const int wave_r = flng == 1024 ? 8 : (flng == 2048 ? 16 : 0);
+  const bool wave = wave_r != 0;
+  const int wthreads = wave_r == 8 ? lsw<8>() : lsw<16>();
+  const size_t lds_wave = wave_r == 8 ? wf::table_bytes<8>() + (size_t)(lsw<8>() / 64) * wf::lds_bytes<8>()
+                                      : wf::table_bytes<16>() + (size_t)(lsw<16>() / 64) * wf::lds_bytes<16>();
   int n_cu = 256;
   if (wave) {
     int dev = 0;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const void* kernels[4] = {(const void*)mcls_init_wave_kernel<8>, (const void*)mcls_spec_wave_kernel<8>,
+                              (const void*)mcls_init_wave_kernel<16>, (const void*)mcls_spec_wave_kernel<16>};
+    for (int i = (wave_r == 8 ? 0 : 2); i < (wave_r == 8 ? 2 : 4); ++i)
+      ITTS_HIP_CHECK(hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
   }
-  if (wave) {
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_wave));
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_spec_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_wave));
-  }
-  const dim3 wave_grid((unsigned)std::min<int64_t>((T + LSW / 64 - 1) / (LSW / 64), (int64_t)n_cu));
-  if (wave) hipLaunchKernelGGL(mcls_init_wave_kernel, wave_grid, dim3(LSW), lds_wave, s, a);
+  auto wave_grid = [&](int64_t frames) {
+    const int64_t per = wthreads / 64;
+    return dim3((unsigned)std::min<int64_t>((frames + per - 1) / per, (int64_t)n_cu));
+  };
+  if (wave_r == 8) hipLaunchKernelGGL(mcls_init_wave_kernel<8>, wave_grid(T), dim3(wthreads), lds_wave, s, a);
+  else if (wave_r == 16) hipLaunchKernelGGL(mcls_init_wave_kernel<16>, wave_grid(T), dim3(wthreads), lds_wave, s, a);
   else hipLaunchKernelGGL(mcls_init_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
   ITTS_LAUNCH_CHECK();
   int rc = launch_gemm_f64(cbuf, Kp, ft->fwdT, m1, mc, m1, T, m1, K, nullptr, s);
@@ -866,9 +875,10 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     a.iter = it;
     const int64_t nr = a.n_rows;      // frames still iterating (their list is a.rows)
     if ((rc = launch_gemm_f64(mc, m1, ft->invT, K, cbuf, Kp, nr, K, m1, a.rows, s))) return rc;
-    if (wave) {
-      const dim3 grid((unsigned)std::min<int64_t>((nr + LSW / 64 - 1) / (LSW / 64), (int64_t)n_cu));
-      hipLaunchKernelGGL(mcls_spec_wave_kernel, grid, dim3(LSW), lds_wave, s, a);
+    if (wave_r == 8) {
+      hipLaunchKernelGGL(mcls_spec_wave_kernel<8>, wave_grid(nr), dim3(wthreads), lds_wave, s, a);
+    } else if (wave_r == 16) {
+      hipLaunchKernelGGL(mcls_spec_wave_kernel<16>, wave_grid(nr), dim3(wthreads), lds_wave, s, a);
     } else {
       hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)nr), dim3(NT), lds_fft, s, a);
     }

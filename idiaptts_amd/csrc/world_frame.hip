@@ -271,30 +271,31 @@ __global__ __launch_bounds__(NT) void mgc2sp_kernel(Mgc2spArgs a) {
   }
 }
 
-// The same with one WAVE per frame (fftlen = 1024; wave_fft.h): sixteen frames in flight per CU, no
-// workgroup barrier, bit-identical spectra.
-constexpr int MGW = 1024;
-__global__ __launch_bounds__(MGW) void mgc2sp_wave_kernel(Mgc2spArgs a) {
+// The same with one WAVE per frame (fftlen = 1024 or 2048; wave_fft.h): sixteen / eight frames in flight
+// per CU, no workgroup barrier, bit-identical spectra.
+template <int R> constexpr int mgw() { return R == 8 ? 1024 : 512; }
+template <int R>
+__global__ __launch_bounds__(mgw<R>()) void mgc2sp_wave_kernel(Mgc2spArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int f2 = 512;
+  constexpr int f2 = 64 * R, NW = mgw<R>() / 64;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
-  wf::Plan512 P;
-  wf::table512_init(smem, a.g_tw);
-  wf::plan512_init(P, a.g_tw, smem + wf::WF_TABLE_BYTES + (size_t)wv * wf::WF_LDS_BYTES, smem);
-  for (int64_t g = (int64_t)blockIdx.x * (MGW / 64) + wv; g < a.T; g += (int64_t)gridDim.x * (MGW / 64)) {
+  typename wf::PlanOf<R>::type P;
+  wf::table_init<R>(smem, a.g_tw);
+  wf::plan_init(P, a.g_tw, smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>(), smem);
+  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < a.T; g += (int64_t)gridDim.x * NW) {
     const double* c = a.cep + g * a.ld_cep;          // rows are 16-byte aligned (even pitch)
-    double2 z[8], x512;
+    double2 z[R], xh;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = *reinterpret_cast<const double2*>(c + 2 * (l + 64 * q));
+    for (int q = 0; q < R / 2; ++q) z[q] = *reinterpret_cast<const double2*>(c + 2 * (l + 64 * q));
 #pragma unroll
-    for (int q = 4; q < 8; ++q) z[q] = make_double2(0.0, 0.0);
-    if (l == 0) z[4] = make_double2(c[f2], 0.0);
-    wf::rfft1024(z, x512, P);
+    for (int q = R / 2; q < R; ++q) z[q] = make_double2(0.0, 0.0);
+    if (l == 0) z[R / 2] = make_double2(c[f2], 0.0);
+    wf::rfft<R>(z, xh, P);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      if (q == 8 && l != 0) break;
-      const int k = q < 8 ? l + 64 * q : f2;
-      const double re = q < 8 ? z[q].x : x512.x;
+    for (int q = 0; q <= R; ++q) {
+      if (q == R && l != 0) break;
+      const int k = q < R ? l + 64 * q : f2;
+      const double re = q < R ? z[q < R ? q : 0].x : xh.x;
       if (a.out_f64) a.out_f64[g * (f2 + 1) + k] = re;
       const float amp = expf((float)re);
       if (a.out_f32) a.out_f32[g * (f2 + 1) + k] = amp;
@@ -498,16 +499,22 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   if (rc) return rc;
   Mgc2spArgs a{d_cep, ld_cep, T, order, fftlen, ilog2_host(fftlen), d_amp_f32, d_logamp_f64, d_pow_f64,
                ctx->twiddles};
-  if (fftlen == 2 * wf::WF_N) {
+  if (fftlen == 1024 || fftlen == 2048) {
     int dev = 0, n_cu = 256;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     a.g_tw = ctx->tw_compact[a.logfft];
-    const size_t lds = wf::WF_TABLE_BYTES + (size_t)(MGW / 64) * wf::WF_LDS_BYTES;
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_wave_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mgc2sp_wave_kernel, dim3((unsigned)std::min<int64_t>((T + MGW / 64 - 1) / (MGW / 64), n_cu)),
-                       dim3(MGW), lds, s, a);
+    if (fftlen == 1024) {
+      constexpr int NW = mgw<8>() / 64;
+      const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(mgc2sp_wave_kernel<8>, dim3((unsigned)std::min<int64_t>((T + NW - 1) / NW, n_cu)), dim3(mgw<8>()), lds, s, a);
+    } else {
+      constexpr int NW = mgw<16>() / 64;
+      const size_t lds = wf::table_bytes<16>() + (size_t)NW * wf::lds_bytes<16>();
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(mgc2sp_wave_kernel<16>, dim3((unsigned)std::min<int64_t>((T + NW - 1) / NW, n_cu)), dim3(mgw<16>()), lds, s, a);
+    }
   } else {
     size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16;
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,

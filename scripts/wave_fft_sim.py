@@ -12,7 +12,7 @@ usage: python scripts/wave_fft_sim.py
 """
 import sys
 
-N, LOGN, LANES = 512, 9, 64
+N, LOGN, LANES = 512, 9, 64      # reference() and wave_schedule() follow these; main() also runs the 1024-point plan
 
 
 def bitrev(x, bits):
@@ -22,8 +22,8 @@ def bitrev(x, bits):
     return r
 
 
-def tw_index(stage, r, tw_n=2 * N):
-    return r * tw_n >> stage          # r * tw_n / 2^stage
+def tw_index(stage, r, tw_n=None):
+    return r * (tw_n or 2 * N) >> stage          # r * tw_n / 2^stage
 
 
 def bfly(a, b, twi):
@@ -127,6 +127,85 @@ def wave_schedule(check=True):
     return out, extra, (pos1, pos2, pos3)
 
 
+def wave_schedule_1024():
+    """The 1024-point plan (2048-point real transforms): sixteen points per lane, passes of 4 + 3 + 3
+    stages; passes 2 and 3 work on two independent groups of eight per lane."""
+    global N, LOGN
+    N, LOGN = 1024, 10
+    P1 = 66
+    reg = [[hash(("in", l + 64 * q)) for q in range(16)] for l in range(LANES)]
+    extra = 0
+
+    def run_pass(pos, stages):
+        for s in stages:
+            h = 1 << (s - 1)
+            for l in range(LANES):
+                byp = {pos[l][q]: q for q in range(16)}
+                for p, q in sorted(byp.items()):
+                    if p & h:
+                        continue
+                    qb = byp[p + h]
+                    reg[l][q], reg[l][qb] = bfly(reg[l][q], reg[l][qb], tw_index(s, p & (h - 1), 2 * N))
+    pos1 = [[16 * bitrev(l, 6) + bitrev(q, 4) for q in range(16)] for l in range(LANES)]
+    for l in range(LANES):
+        for q in range(16):
+            assert bitrev(pos1[l][q], LOGN) == l + 64 * q
+    run_pass(pos1, (1, 2, 3, 4))
+    lds = {}
+    for q in range(16):
+        slots = [bitrev(q, 4) * P1 + l for l in range(LANES)]
+        extra += conflicts(slots, WRITE_GROUPS, 8)
+        for l in range(LANES):
+            lds[slots[l]] = reg[l][q]
+    # pass 2: lane L = a + 16 hh holds bits 0-3 = a, (bit 8, bit 9) = bitrev2(hh); register q = b + 8 e: bits 4-6 = bitrev3(b), bit 7 = e
+    def p2(L, q):
+        a, cc = L & 15, bitrev(L >> 4, 2)
+        b, e = bitrev(q & 7, 3), q >> 3
+        return a + 16 * b + 128 * e + 256 * (cc & 1) + 512 * (cc >> 1)
+    pos2 = [[p2(L, q) for q in range(16)] for L in range(LANES)]
+    for q in range(16):
+        base = [(L & 15) * P1 + (L >> 4) for L in range(LANES)]
+        # slot of position p = j * P1 + bitrev6(p >> 4); must be base(L) + immediate(q)
+        slots = [(pos2[L][q] & 15) * P1 + bitrev(pos2[L][q] >> 4, 6) for L in range(LANES)]
+        imm = slots[0] - base[0]
+        assert all(slots[L] - base[L] == imm for L in range(LANES)) and imm == 8 * (q & 7) + 4 * (q >> 3), q
+        extra += conflicts(slots, READ_GROUPS, 16)
+        for L in range(LANES):
+            reg[L][q] = lds[slots[L]]
+    run_pass(pos2, (5, 6, 7))
+    lds = {}
+    for q in range(16):
+        slots = [pos2[L][q] for L in range(LANES)]
+        base = [pos2[L][0] for L in range(LANES)]
+        assert all(slots[L] - base[L] == slots[0] - base[0] for L in range(LANES))
+        extra += conflicts(slots, WRITE_GROUPS, 8)
+        for L in range(LANES):
+            lds[slots[L]] = reg[L][q]
+    pos3 = [[M + 64 * c for c in range(16)] for M in range(LANES)]
+    for c in range(16):
+        slots = [M + 64 * c for M in range(LANES)]
+        extra += conflicts(slots, READ_GROUPS, 16)
+        for M in range(LANES):
+            reg[M][c] = lds[slots[M]]
+    run_pass(pos3, (8, 9, 10))
+    out = [None] * N
+    for M in range(LANES):
+        for c in range(16):
+            out[M + 64 * c] = reg[M][c]
+    ref = reference()
+    tables = []
+    for name, p, stages in (("pass 1", pos1, (1, 2, 3, 4)), ("pass 2", pos2, (5, 6, 7)), ("pass 3", pos3, (8, 9, 10))):
+        for s in stages:
+            h = 1 << (s - 1)
+            for l in (0, 1, 17, 63):
+                byp = {p[l][q]: q for q in range(16)}
+                items = [(q, byp[pp + h], tw_index(s, pp & (h - 1), 2 * N)) for pp, q in sorted(byp.items()) if not pp & h]
+                tables.append("  %s stage %2d lane %2d: %s" % (name, s, l, items))
+    imms = [((pos2[0][q] & 15) * P1 + bitrev(pos2[0][q] >> 4, 6), pos2[0][q] - pos2[0][0]) for q in range(16)]
+    N, LOGN = 512, 9
+    return out == ref, extra, tables, imms
+
+
 def twiddle_tables(pos):
     """per pass: the (stage, register pair, table index) lists, to read the per-lane tables off"""
     for name, p, stages in (("pass 2", pos[1], (4, 5, 6)), ("pass 3", pos[2], (7, 8, 9))):
@@ -147,7 +226,11 @@ if __name__ == "__main__":
     ref = reference()
     out, extra, pos = wave_schedule()
     ok = out == ref
-    print("same computation DAG as fft_lds:", ok, "| extra LDS cycles from bank conflicts:", extra)
+    print("512 points: same computation DAG as fft_lds:", ok, "| extra LDS cycles from bank conflicts:", extra)
+    ok2, extra2, tables, imms = wave_schedule_1024()
+    print("1024 points: same computation DAG as fft_lds:", ok2, "| extra LDS cycles from bank conflicts:", extra2)
     if "-v" in sys.argv:
         twiddle_tables(pos)
-    sys.exit(0 if ok and extra == 0 else 1)
+        print("\n".join(tables))
+        print("1024: exchange-1 load immediates / exchange-2 store immediates per register:", imms)
+    sys.exit(0 if ok and extra == 0 and ok2 and extra2 == 0 else 1)
