@@ -534,11 +534,7 @@ struct StreamArgs {
   int n_groups, nblk;
   double* agg;           // [n_chunks][4][Dp]: e_f (2), e_b0 (2)
   double* st;            // [n_chunks][4][Dp]: forward entry state (2), backward entry state (2)
-  unsigned long long* scan_trace;   // optional [U * nblk][ST_SW][8] wall-clock stamps (ITTS_MLPG_SCAN_TRACE)
-  int scan_sequential;   // test switch (ITTS_MLPG_SCAN_SEQ=1): every utterance takes st_scan_sequential
 };
-
-__device__ __forceinline__ bool getenv_scan_sequential(const StreamArgs& g) { return g.scan_sequential != 0; }
 
 
 struct FuMats { double Mf[4], Mb[4], C[4]; };
@@ -887,9 +883,6 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
   const MlpgArgs& a = g.a;
   const int u = (int)(blockIdx.x / (unsigned)g.nblk), db = (int)(blockIdx.x % (unsigned)g.nblk);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned long long* tr = g.scan_trace ? g.scan_trace + ((int64_t)blockIdx.x * ST_SW + w) * 8 : nullptr;
-#define ST_STAMP(i) do { if (tr && lane == 0) tr[i] = wall_clock64(); } while (0)
-  ST_STAMP(0);
   const int D = a.dim;
   const bool dok = db * 64 + lane < D;
   const int d = dok ? db * 64 + lane : D - 1;
@@ -924,7 +917,7 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
   const int tail0 = K - 2 > 0 ? K - 2 : 0;
   const int n_tail = K - tail0;                                    // 1 or 2
   const int n_lead = k_settled < tail0 ? k_settled : tail0;
-  if (n_lead > SW - n_tail - 1 || getenv_scan_sequential(g)) {     // see st_scan_sequential
+  if (n_lead > SW - n_tail - 1) {     // see st_scan_sequential
     if (w == 0) st_scan_sequential<FU_FL>(c, K, T, ag, st, Dp, dok);
     return;
   }
@@ -950,7 +943,6 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
   }
   auto mats = [&](int, FuMats& m) { m = mm; };
   constexpr int SB = 8;
-  ST_STAMP(1);
 
   // ---- forward: s_in(k + 1) = M_f(k) s_in(k) + e_f(k)
   double A[4] = {1.0, 0.0, 0.0, 1.0}, q[2] = {0.0, 0.0};
@@ -979,9 +971,7 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
   for (int i = 0; i < 4; ++i) lds_s[w][i][lane] = A[i];
   lds_s[w][4][lane] = q[0];
   lds_s[w][5][lane] = q[1];
-  ST_STAMP(2);
   __syncthreads();
-  ST_STAMP(3);
   double s1 = 0.0, s2 = 0.0;
   for (int i = 0; i < w; ++i) {
     const double n1 = lds_s[i][0][lane] * s1 + lds_s[i][1][lane] * s2 + lds_s[i][4][lane];
@@ -1009,8 +999,6 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
       }
     }
   }
-
-  ST_STAMP(4);
   // ---- backward: t_in(k - 1) = M_b(k) t_in(k) + e_b0(k) + C(k) s_in(k)
   // (a lane reads back the s_in it stored above: same thread, same address, program order)
   A[0] = 1.0; A[1] = 0.0; A[2] = 0.0; A[3] = 1.0; q[0] = q[1] = 0.0;
@@ -1039,14 +1027,12 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
       }
     }
   }
-  ST_STAMP(5);
   __syncthreads();      // every wave has read the forward segment aggregates
 #pragma unroll
   for (int i = 0; i < 4; ++i) lds_s[w][i][lane] = A[i];
   lds_s[w][4][lane] = q[0];
   lds_s[w][5][lane] = q[1];
   __syncthreads();
-  ST_STAMP(6);
   double t1 = 0.0, t2 = 0.0;
   for (int i = SW - 1; i > w; --i) {
     const double n1 = lds_s[i][0][lane] * t1 + lds_s[i][1][lane] * t2 + lds_s[i][4][lane];
@@ -1078,8 +1064,6 @@ __global__ __launch_bounds__(ST_SW * 64) void mlpg_scan_kernel(StreamArgs g) {
       }
     }
   }
-  ST_STAMP(7);
-#undef ST_STAMP
 }
 
 template <int FU_FL, int GW>
@@ -1166,8 +1150,6 @@ static int mlpg_stream_launch(MlpgArgs a, const int64_t* h_offsets, int n_utts, 
   g.nblk = nblk;
   g.agg = reinterpret_cast<double*>(blk + rec_bytes + c0_bytes);
   g.st = g.agg + plane_bytes / sizeof(double);
-  g.scan_trace = nullptr;
-  g.scan_sequential = 0;
   const dim3 grid((unsigned)((size_t)n_groups * nblk));
   const size_t tile_bytes = STAGE ? (size_t)(GW * FL + 2) * ST_W * sizeof(double) : 0;
   if (STAGE) {

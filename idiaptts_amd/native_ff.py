@@ -16,7 +16,6 @@ parameters, gradients and Adam moments in ONE flat fp32 buffer each:
   opt   one fused Adam launch over the flat buffers
 """
 import math
-import os
 
 import torch
 
@@ -56,7 +55,6 @@ class FlatFFModel:
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.step_count = 0
         self._buffers = {}
-        self.fuse_output_loss = os.environ.get("ITTS_FF_FUSE_LOSS", "1") != "0"
         if state_dict is None:
             state_dict = self.reference_init(self.dims, seed)
         self.load_layers(state_dict)
@@ -173,7 +171,7 @@ class FlatFFModel:
         and the handles are left in self._pending for train_step to wait on before Adam."""
         self._pending = []
         x = self.pack_input(x)
-        if reduce or os.environ.get("ITTS_FF_DEFER", "1") == "0":
+        if reduce:
             return self._loss_and_backward(x, target, row_valid, n_valid_global, reduce_group, reduce)
         # one process: the loss sum and the layers' split-K slab reductions are queued and run as ONE
         # launch at the end (five launches less per step); with data parallelism every layer's
@@ -184,7 +182,7 @@ class FlatFFModel:
     def _loss_and_backward(self, x, target, row_valid, n_valid_global, reduce_group, reduce):
         M = x.shape[0]
         n = len(self.layout)
-        if self.acts[-1] in (None, ops.ACT_NONE) and n > 1 and self.fuse_output_loss:
+        if self.acts[-1] in (None, ops.ACT_NONE) and n > 1:
             # the output layer never materialises: its GEMM epilogue forms the masked difference
             # to the target, the loss partial sums and d loss / d output
             hs = self.forward(x, n_layers=n - 1)

@@ -74,10 +74,17 @@ def test_packed_batch_matches_torch_packed_sequence():
     """PackedBatch (the index bookkeeping in front of the recurrent kernels) reproduces
     pack_padded_sequence(enforce_sorted=False) / pad_packed_sequence, the calls of
     rnn_dyn/RNNWrapper.py:89-102: same row order, same per-step batch sizes, same padding; and its
-    shifted-frame index gives h_{t-1} of every packed frame."""
+    shifted-frame index gives h_{t-1} of every packed frame.  The tables are applied here with the
+    definition of the native row gather (out[r] = src[idx[r]], the fill row where idx[r] is negative
+    or one past the end); the kernel itself: tests/test_gpu_nn.py::test_rows_gather_is_pack_unpack_and_shift."""
     import torch
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     from idiaptts_amd.nn.functional import PackedBatch
+
+    def gather(src, idx, fill=None):
+        fill = torch.zeros(src.shape[1]) if fill is None else fill
+        ext = torch.cat([src, fill[None, :]])
+        return ext[torch.where((idx < 0) | (idx >= src.shape[0]), torch.tensor(src.shape[0]), idx)]
     g = torch.Generator().manual_seed(5)
     for batch_first in (False, True):
         for lens in ([5, 9, 1, 9, 3], [4], [2, 2, 2], list(range(1, 18))):
@@ -86,19 +93,20 @@ def test_packed_batch_matches_torch_packed_sequence():
             pb = PackedBatch(lens, T, batch_first, "cpu")
             ref = pack_padded_sequence(x, torch.tensor(lens), batch_first=batch_first,
                                        enforce_sorted=False)
-            assert torch.equal(pb.pack(x), ref.data)
+            packed = gather(x.reshape(-1, 3), pb.flat_index)
+            assert torch.equal(packed, ref.data)
             sizes = np.diff(np.concatenate([pb.d_row_off.numpy(), [pb.N]]))
             assert list(sizes) == list(ref.batch_sizes.numpy())
             assert torch.equal(pb.perm, ref.sorted_indices) and pb.T == max(lens)
             back, _ = pad_packed_sequence(ref, batch_first=batch_first, total_length=T)
-            assert torch.equal(pb.unpack(pb.pack(x), x.shape), back)
+            assert torch.equal(gather(packed, pb.inv_flat).reshape(x.shape), back)
             # reverse-direction row table and the h_{t-1} shift, against explicit loops
             sl = pb.h_lengths.numpy()
             off = pb.d_row_off.numpy()
             rev = pb.d_rev_row.numpy()
             y = torch.arange(pb.N * 2, dtype=torch.float32).reshape(pb.N, 2) + 1.0
             h0 = torch.tensor([[-1.0], [-2.0]])
-            hp = pb.shift(y, h0, 2, 1)
+            hp = torch.cat([gather(y[:, d:d + 1], pb.prev_row[d], h0[d]) for d in range(2)], dim=1)
             for b in range(B):
                 for t in range(sl[b]):
                     s = sl[b] - 1 - t
