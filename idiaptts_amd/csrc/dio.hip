@@ -551,7 +551,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
   ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf_off, lpf_off.data(), lpf_off.size() * 4, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(itts_spin_sync(s));  // host staging vectors die with this frame
 
-  const int64_t budget = (int64_t)3 << 30;  // scratch bytes per sub-batch
+  const int64_t budget = (int64_t)24 << 30;  // scratch bytes per sub-batch (one sub-batch for 256 utterances: the per-utterance kernels then fill all CUs)
   int u0 = 0;
   while (u0 < n_utts) {
     std::vector<DioUtt> utts;

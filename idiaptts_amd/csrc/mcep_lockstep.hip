@@ -675,6 +675,17 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
 // matrix.  A segment therefore updates W - 8 S entries (compile-time width: static register
 // indices), about half of the full-width work over the whole elimination; the dropped operations
 // are 0 - f * 0.  The segments follow each other as straight-line code (template recursion).
+#ifndef LS_READLANE_16THS
+#define LS_READLANE_16THS 4
+#endif
+// the value lane l (wave-uniform) holds, in scalar registers
+__device__ __forceinline__ double lane_value(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <int W, int S>
 __device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double& d, double* P,
                                             int lane, int m1) {
@@ -689,11 +700,25 @@ __device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double&
       const bool is_piv = lane == c;
       if (is_piv) d = pc;
       const double f = is_piv ? 0.0 : row[0] * (1.0 / pc);   // 1/pc is wave-uniform: one division per step
-      // uniform-address LDS reads: this is what bounds the kernel (a broadcast read still delivers
-      // 16 bytes to each of the 64 lanes)
+      // uniform-address LDS reads are what bounds the kernel (a broadcast read still delivers 16 bytes
+      // to each of the 64 lanes: 4 clocks of the CU's one LDS pipe per pair of pivot-row entries,
+      // against 2 clocks' worth of FMAs on its four SIMDs).  The first JR entries therefore come
+      // through the scalar registers instead (v_readlane of the owner's leading element, an SGPR
+      // pair as the FMA's operand: VALU work, no LDS): at a quarter both pipes carry the same load.
       const double* p = P + c;
+      constexpr int JR = 1 + ((WW - 1) * LS_READLANE_16THS) / 16;
+      const double r0 = row[0];
 #pragma unroll
-      for (int j = 1; j < WW; ++j) row[j - 1] = row[j] - f * p[j];
+      for (int j = 1; j < WW; ++j) {
+        double pj;
+        if (j < JR) {
+          const double v = lane_value(r0, (c + j) & 63);
+          pj = c + j < 64 ? v : 0.0;
+        } else {
+          pj = p[j];
+        }
+        row[j - 1] = row[j] - f * pj;
+      }
       row[WW - 1] = 0.0;
       b -= f * bc;
       __builtin_amdgcn_wave_barrier();

@@ -22,8 +22,9 @@ namespace itts {
 // the 32 workgroups an XCD holds (blockIdx % 8 = XCD under round-robin dispatch) keep one
 // recurrence to themselves for all T steps: workgroup c owns hidden units 16 c .. 16 c + 15 (all G
 // gates: a G x 32 KB image of its W_hh rows stays in LDS in the order the MFMA lanes read it), the
-// cell state stays in registers, and h travels through the XCD's L2 as self-validating pairs
-// (P, P ^ mask(step)) of 16-byte granules that a consumer lane re-reads until they match -- no
+// cell state stays in registers, and h travels through the XCD's L2 as self-validating 16-byte
+// granules (four values, a 4-bit step tag in their lowest mantissa bits; until round 4: pairs
+// (P, P ^ mask(step))) that a consumer lane re-reads until the tag is the step's -- no
 // counter, no fence (measured in scripts/handoff_lab: 1.2 us per step, no stale or torn granule in
 // 1e10 reads).  A polling budget turns a missing workgroup into an abort
 // flag instead of a hang.
@@ -46,7 +47,7 @@ struct RnnPersistArgs {
   float* csave;
   float* hn;
   float* cn;
-  uint4* xchg;      // [8 groups][4 step slots][32 producers][P | C][64 lanes]
+  uint4* xchg;      // [8 groups][4 step slots][32 producers][64 granules]
   int* abort_flag;
   int T, B, ndir, ntiles;
   int tile0;        // first batch tile of this launch (batches of more than 8 / ndir tiles take several)
@@ -56,42 +57,30 @@ struct RnnPersistArgs {
 // allocator no reason to keep its four components in consecutive registers)
 typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned persist_mask(int step) { return ((unsigned)(step + 1) * 0x9E3779B1u) | 1u; }
-
-// sixteen 16-byte L1-bypassing loads in flight together (eight producers' P and C granules), waited
-// for inside the statement (the compiler cannot see that the result of a bare load asm is not
-// there yet)
-__device__ __forceinline__ void persist_load16(const uint4* p, int stride, pu32x4 (&v)[8], pu32x4 (&c)[8]) {
-  const uint4 *p0 = p, *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride, *p4 = p + 4 * stride,
-              *p5 = p + 5 * stride, *p6 = p + 6 * stride, *p7 = p + 7 * stride;
-  asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %17, off sc1\n\t"
-               "global_load_dwordx4 %2, %18, off sc1\n\tglobal_load_dwordx4 %3, %19, off sc1\n\t"
-               "global_load_dwordx4 %4, %20, off sc1\n\tglobal_load_dwordx4 %5, %21, off sc1\n\t"
-               "global_load_dwordx4 %6, %22, off sc1\n\tglobal_load_dwordx4 %7, %23, off sc1\n\t"
-               "global_load_dwordx4 %8, %16, off offset:1024 sc1\n\tglobal_load_dwordx4 %9, %17, off offset:1024 sc1\n\t"
-               "global_load_dwordx4 %10, %18, off offset:1024 sc1\n\tglobal_load_dwordx4 %11, %19, off offset:1024 sc1\n\t"
-               "global_load_dwordx4 %12, %20, off offset:1024 sc1\n\tglobal_load_dwordx4 %13, %21, off offset:1024 sc1\n\t"
-               "global_load_dwordx4 %14, %22, off offset:1024 sc1\n\tglobal_load_dwordx4 %15, %23, off offset:1024 sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-                 "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
-               : "memory");
-}
-
-// the first (P, C) granule pair of one producer: 32 bytes per lane address, what a waiting wave
-// re-reads (sixteen full-width loads per poll from every waiting wave of 32 CUs crowd the L2 the
-// producers' stores have to get through)
-__device__ __forceinline__ void persist_load_pair(const uint4* p, pu32x4& v, pu32x4& c) {
-  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(v), "=&v"(c)
-               : "v"(p)
-               : "memory");
-}
-
+// one granule of one producer: what a waiting wave re-reads (full-width loads per poll from every waiting
+// wave of 32 CUs crowd the L2 the producers' stores have to get through)
 __device__ __forceinline__ void persist_load_one(const uint4* p, pu32x4& v) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+}
+
+// In-band step tags (both recurrences): the lowest mantissa bit of each of a granule's four values holds one
+// bit of a 4-bit tag (15 states, never 0: a cleared buffer is never valid; consecutive uses of a slot differ).
+__device__ __forceinline__ unsigned persist_tag4(int step) { return (unsigned)((step >> 1) % 15) + 1u; }
+__device__ __forceinline__ unsigned persist_tag_of(const pu32x4 g) {
+  return (g.x & 1u) | ((g.y & 1u) << 1) | ((g.z & 1u) << 2) | ((g.w & 1u) << 3);
+}
+// eight 16-byte L1-bypassing loads in flight together (one granule of each of eight producers' tiles)
+__device__ __forceinline__ void persist_load8(const uint4* p, int stride, pu32x4 (&v)[8]) {
+  const uint4 *p0 = p, *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride, *p4 = p + 4 * stride,
+              *p5 = p + 5 * stride, *p6 = p + 6 * stride, *p7 = p + 7 * stride;
+  asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+               "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+               "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+               "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+               : "memory");
 }
 
 // Loads and stores of data touched once (gates, gradients): marked non-temporal so that they do not
@@ -145,7 +134,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
   float bh0 = 0.f, bh1 = 0.f, bh2 = 0.f;
   if (G == 3 && a.bhh) { bh0 = a.bhh[dir * G4 + j]; bh1 = a.bhh[dir * G4 + H + j]; bh2 = a.bhh[dir * G4 + 2 * H + j]; }
   (void)bh0; (void)bh1; (void)bh2;
-  uint4* xg = a.xchg + (size_t)group * 4 * 32 * 128;
+  uint4* xg = a.xchg + (size_t)group * 4 * 32 * 64;
   // Every wave publishes the h of its own four rows: thread (r, u) = lane (r & 3) * 16 + u of wave
   // r >> 2 holds h[r][u]; granule (row r', k quarter kq) of this workgroup's block wants units
   // kq, 4 + kq, 8 + kq, 12 + kq of row r' -- four lanes of the same wave, fetched by shuffles; lanes
@@ -156,12 +145,13 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
     const float p0 = __shfl(hval, rl * 16 + kq, 64), p1 = __shfl(hval, rl * 16 + 4 + kq, 64),
                 p2 = __shfl(hval, rl * 16 + 8 + kq, 64), p3 = __shfl(hval, rl * 16 + 12 + kq, 64);
     if (lane < 16) {
-      const unsigned m = persist_mask(step);
-      const uint4 P = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
-      const uint4 C = make_uint4(P.x ^ m, P.y ^ m, P.z ^ m, P.w ^ m);
-      uint4* dst = xg + ((size_t)(step & 3) * 32 + cu) * 128 + kq * 16 + 4 * wv + rl;
+      // the step tag rides in the lowest mantissa bit of the four values (round 4; until then a check copy
+      // P ^ mask(step) travelled beside every granule: twice the bytes to poll)
+      const unsigned t = persist_tag4(step);
+      const uint4 P = make_uint4((__float_as_uint(p0) & ~1u) | (t & 1u), (__float_as_uint(p1) & ~1u) | ((t >> 1) & 1u),
+                                 (__float_as_uint(p2) & ~1u) | ((t >> 2) & 1u), (__float_as_uint(p3) & ~1u) | ((t >> 3) & 1u));
+      uint4* dst = xg + ((size_t)(step & 3) * 32 + cu) * 64 + kq * 16 + 4 * wv + rl;
       dst[0] = P;
-      dst[64] = C;
     }
   };
   publish(0, h);
@@ -196,27 +186,25 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
     const size_t row = row_cur;
     const float g0 = gc0, g1 = gc1, g2 = gc2, g3 = gc3;
     // h_{s-1} of the whole tile: this wave's k quarter comes from producers 8 wv .. 8 wv + 7
-    pu32x4 pv[8], cv[8];
+    pu32x4 pv[8];
     {
-      const uint4* src = xg + ((size_t)(s & 3) * 32 + 8 * wv) * 128 + lane;
-      const unsigned m = persist_mask(s);
+      const uint4* src = xg + ((size_t)(s & 3) * 32 + 8 * wv) * 64 + lane;
+      const unsigned m = persist_tag4(s);
       int budget = 1 << 16;      // ~50 ms of polling at most
       for (;;) {
-        // optimistic: usually everything is there (one trip); otherwise wait on one granule pair per
+        // optimistic: usually everything is there (one trip); otherwise wait on one granule per
         // producer (lane i & 7 watches producer 8 wv + (i & 7)) and fetch again
-        persist_load16(src, 128, pv, cv);
+        persist_load8(src, 64, pv);
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          ok = ok && (pv[i].x ^ cv[i].x) == m && (pv[i].y ^ cv[i].y) == m && (pv[i].z ^ cv[i].z) == m &&
-               (pv[i].w ^ cv[i].w) == m;
+        for (int i = 0; i < 8; ++i) ok = ok && persist_tag_of(pv[i]) == m;
         if (__all(ok)) break;
-        const uint4* watch = xg + ((size_t)(s & 3) * 32 + 8 * wv + (lane & 7)) * 128;
+        const uint4* watch = xg + ((size_t)(s & 3) * 32 + 8 * wv + (lane & 7)) * 64;
         bool gave_up = false;
         for (;;) {
-          pu32x4 wp, wc;
-          persist_load_pair(watch, wp, wc);
-          if (__all((wp.x ^ wc.x) == m)) break;
+          pu32x4 wp;
+          persist_load_one(watch, wp);
+          if (__all(persist_tag_of(wp) == m)) break;
           if (--budget <= 0 || *reinterpret_cast<volatile int*>(a.abort_flag)) { gave_up = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
@@ -388,7 +376,7 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
     return 0;
   DeviceContext* ctx = get_context();
   if (!ctx) return 0;
-  const size_t xbytes = (size_t)8 * 4 * 32 * 128 * sizeof(uint4);
+  const size_t xbytes = (size_t)8 * 4 * 32 * 64 * sizeof(uint4);
   char* blk = nullptr;
   itts::ScratchScope scope(s);
   if (itts::scratch_malloc((void**)&blk, xbytes + 64, s) != hipSuccess) return -1;
@@ -459,23 +447,6 @@ struct RnnPersistBwdArgs {
 };
 
 constexpr int PT = 64;    // granules per partial tile: one per lane, four values each, tag in the four low mantissa bits
-__device__ __forceinline__ unsigned persist_tag4(int step) { return (unsigned)((step >> 1) % 15) + 1u; }
-__device__ __forceinline__ unsigned persist_tag_of(const pu32x4 g) {
-  return (g.x & 1u) | ((g.y & 1u) << 1) | ((g.z & 1u) << 2) | ((g.w & 1u) << 3);
-}
-// eight 16-byte L1-bypassing loads in flight together (one granule of each of eight producers' tiles)
-__device__ __forceinline__ void persist_load8(const uint4* p, int stride, pu32x4 (&v)[8]) {
-  const uint4 *p0 = p, *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride, *p4 = p + 4 * stride,
-              *p5 = p + 5 * stride, *p6 = p + 6 * stride, *p7 = p + 7 * stride;
-  asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
-               "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
-               "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-               "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
-               : "memory");
-}
 constexpr int persist_bwd_lds_bytes(int G) { return 32 * G * 64 * 16 + 4 * 16 * 17 * 4 + G * 16 * 16 * 4; }
 
 #ifndef PERSIST_BWD_TRACE

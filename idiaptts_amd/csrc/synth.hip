@@ -674,7 +674,12 @@ __device__ __forceinline__ void min_phase_wave(double (&v)[9], const wf::Plan512
     const double zr = q < 8 ? z[q].x : wave_bcast0(x512.x), zi = q < 8 ? z[q].y : wave_bcast0(x512.y);
     const double t = exp(zr / fft);
     double sn, cs;
-    sincos_mid(zi / fft, &sn, &cs);
+    // The short reduction of fastmath.h directly: sincos_mid's out-of-line fallback for |x| > 1e5 is a CALL,
+    // and one call in the kernel costs its whole register allocation (75 -> 19 spilled registers
+    // without it).  The phase cannot get there: it is the conjugate function of the log amplitude lg,
+    // |phase| <= (4 / pi) (1 + 1/3 + ... + 1/511) max|lg| < 5.3 max|lg|, and |lg| <= 373 for anything a
+    // double holds -- below 2 000 rad.  (A NaN or an infinite phase gives NaN here as it does there.)
+    fm::fsincos(zi / fft, &sn, &cs);
     mp[q] = make_double2(t * cs, t * sn);
     if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);     // three bins in flight are enough; nine do not fit the registers
   }
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int fft = 1024, h = 512, K = 513;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int l = wf::lane_id();
+  const int l0 = wf::lane_id();
   wf::Plan512 P;
   // the DC remover's window over its sum (what every pulse divides out again and again), once per workgroup
   double* dcrn = reinterpret_cast<double*>(smem + wf::WF_TABLE_BYTES);
@@ -708,6 +713,10 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
   const int64_t nw = (int64_t)gridDim.x * (NT / 64);
   int lo = 0;
   for (int64_t g = (int64_t)blockIdx.x * (NT / 64) + wv; g < total; g += nw) {
+    // opaque per pulse: what derives from the lane number is a few integer operations; hoisted out of the
+    // loop it is a dozen registers held for the whole kernel
+    int l = l0;
+    asm volatile("" : "+v"(l));
     while (uni(a.gpoff[lo + 1]) <= g) ++lo;          // utterance of flat pulse g (g only grows)
     const int64_t u_foff = uni(a.utts[lo].f_off), u_yoff = uni(a.utts[lo].y_off), u_soff = uni(a.utts[lo].s_off);
     const int T = uni(a.utts[lo].T), u_yl = uni(a.utts[lo].yl);
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           const int k = q < 8 ? l + 64 * q : h;
-          const double re2 = cos_mid(coef * k);
+          const double re2 = fm::fcos(coef * k);        // |coef * k| <= pi: the time shift is below one sample
           const double im2 = sqrt(1.0 - re2 * re2);
           const double2 m = mp[q];
           const double2 r = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);

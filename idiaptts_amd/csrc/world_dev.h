@@ -68,6 +68,21 @@ __device__ __forceinline__ double sin_mid(double x) {
   return fm::fsin(x);
 }
 
+// Lane shuffles whose addresses are computed where they are used, from the caller's lane number:
+// __shfl_xor / __shfl_up derive theirs from the hardware lane id, which the compiler hoists out of a
+// persistent kernel's loop -- a dozen registers held (and spilled) for the whole kernel.
+__device__ __forceinline__ double lane_shfl(double v, int src_lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_at(double v, int lane) {   // same butterfly as wave_sum: same bits
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += lane_shfl(v, lane ^ off);
+  return v;
+}
+
 __device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
 __device__ __forceinline__ int ilog2(int n) { return 31 - __clz(n); }
 

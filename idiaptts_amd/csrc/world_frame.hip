@@ -153,12 +153,19 @@ struct FrameArgs {
   const uint32_t* rn;       // safeguard-noise streams, utterance u at rn + f_off[u] * rn_pitch
   const int64_t* rn_pos;    // [Ttot] position of each frame inside its utterance's stream
   int64_t rn_pitch;         // bound on the normals one frame consumes
+  int64_t t_total;          // frames of the call
+  int far_only;             // cheaptrick_kernel: only the frames the wave kernel leaves (ct_far)
 };
 
 __device__ __forceinline__ double ct_frame_f0(double f0, int fs, int fft) {
   const double floor_f0 = 3.0 * fs / (fft - 3.0);
   return f0 > floor_f0 ? f0 : 500.0;  // WORLD kDefaultF0
 }
+
+// F0 values at or beyond the Nyquist frequency (an input error: WORLD's own DC correction reads past
+// its arrays there) stay with the workgroup kernel: the wave kernel's scratch and its short sine /
+// cosine reductions (arguments up to 2 pi * 512 * f0 / fs, valid to 1e5) are sized for F0 below it.
+__device__ __forceinline__ bool ct_far(double f0, int fs) { return !(f0 < 0.5 * fs); }
 
 // Stream positions: frame t of an utterance starts where frames 0..t-1 stopped; each consumes its
 // window length (2 * round(1.5 fs / f0) + 1) plus fft/2+1 normals.  One workgroup per utterance,
@@ -221,18 +228,253 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   char* p = smem;
   CtLds L;
   carve_ct(p, a.fft, a.bmax, L, false);
-  const int64_t g = blockIdx.x;
-  const int u = find_utt(a.f_off, a.n_utts, g);
-  const int64_t t = g - a.f_off[u];
-  const double* x = a.x + a.x_off[u];
-  const int64_t xl = a.x_off[u + 1] - a.x_off[u];
   L.tw = a.g_tw_compact;
-  const double f0 = ct_frame_f0(a.f0[g], a.fs, a.fft);
-  const double pos = (double)t * a.frame_period / 1000.0;
-  cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L,
-                   a.rn + a.f_off[u] * a.rn_pitch + a.rn_pos[g]);
-  const int K = a.fft / 2 + 1;
-  for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
+  if (a.far_only) {
+    // normally no frame is left: the workgroup's F0 values are looked at side by side, once
+    bool any = false;
+    for (int64_t g = blockIdx.x + (int64_t)threadIdx.x * gridDim.x; g < a.t_total; g += (int64_t)NT * gridDim.x)
+      any = any || ct_far(ct_frame_f0(a.f0[g], a.fs, a.fft), a.fs);
+    if (!__syncthreads_or(any)) return;
+  }
+  for (int64_t g = blockIdx.x; g < a.t_total; g += gridDim.x) {
+    const double f0 = ct_frame_f0(a.f0[g], a.fs, a.fft);
+    if (a.far_only && !ct_far(f0, a.fs)) continue;       // workgroup-uniform
+    const int u = find_utt(a.f_off, a.n_utts, g);
+    const int64_t t = g - a.f_off[u];
+    const double* x = a.x + a.x_off[u];
+    const int64_t xl = a.x_off[u + 1] - a.x_off[u];
+    const double pos = (double)t * a.frame_period / 1000.0;
+    cheaptrick_frame(x, xl, a.fs, f0, pos, a.fft, a.logfft, a.q1, L,
+                     a.rn + a.f_off[u] * a.rn_pitch + a.rn_pos[g]);
+    const int K = a.fft / 2 + 1;
+    for (int k = threadIdx.x; k < K; k += NT) a.sp[g * K + k] = L.P[k];
+    __syncthreads();
+  }
+}
+
+// CheapTrick with one WAVE per frame (fft_size 1024: 16 / 22.05 kHz; wave_fft.h).  The three real
+// transforms run in registers (eight complex points per lane); everything between them that needs
+// random access -- the DC correction's interpolation, the mirrored running sum of the smoothing --
+// lives in the wave's OWN 8.5 KB of exchange rows, which are idle between transforms: sixteen frames
+// in flight per CU, no workgroup barrier.  Same expressions per sample and per bin as
+// cheaptrick_frame; the sums (window energy, mean, running sum) associate differently -- the
+// envelope agrees with it to rounding (tests: 1e-8 relative against the oracle, as before).
+// The cosines and sines take fastmath.h's short forms directly: their arguments are bounded by
+// 2 pi * 512 * f0 / fs here, far inside the reduction's range, and the out-of-line fallback of
+// cos_mid / sin_mid -- a call the kernel never takes -- would cost the register allocation of the whole kernel.
+#ifndef CTW_THREADS_N
+#define CTW_THREADS_N 512     // eight frames in flight per CU, 218 registers per lane (twelve at 168 spill 49 of them: 5.1 against 4.4 ms)
+#endif
+constexpr int CTW_THREADS = CTW_THREADS_N;
+constexpr int CTW_SCAN = 17;          // running-sum elements per lane: 64 * 17 = the 1088 doubles of the rows
+static_assert(wf::WF_LDS_BYTES / 8 == 64 * CTW_SCAN, "the smoothing's scratch is the wave's exchange rows");
+
+__device__ __forceinline__ double ct_bcast0(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs a, int64_t t_total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 8, FFT = 1024, H = 512, K = H + 1, NW = CTW_THREADS / 64;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l0 = wf::lane_id();
+  wf::Plan512 P;
+  wf::table_init<R>(smem, a.g_tw_compact);
+  char* rows = smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>();
+  wf::plan_init(P, a.g_tw_compact, rows, smem);
+  double* S = reinterpret_cast<double*>(rows);       // the exchange rows as 1088 doubles of scratch
+  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < t_total; g += (int64_t)gridDim.x * NW) {
+    // opaque per frame: what derives from the lane number, the sampling rate and q1 is a handful of
+    // integer and fp64 operations -- hoisted out of the loop it is sixty registers held for the
+    // whole kernel
+    int l = l0, fs = a.fs;
+    double q1 = a.q1;
+    asm volatile("" : "+v"(l), "+s"(fs), "+s"(q1));
+    const int u = __builtin_amdgcn_readfirstlane(find_utt(a.f_off, a.n_utts, g));
+    const int64_t fo = a.f_off[u];
+    const double* x = a.x + a.x_off[u];
+    const int64_t xl = a.x_off[u + 1] - a.x_off[u];
+    const double f0 = ct_frame_f0(a.f0[g], fs, FFT);
+    if (ct_far(f0, fs)) continue;                   // wave-uniform; cheaptrick_kernel(far_only) takes the frame
+    const double pos = (double)(g - fo) * a.frame_period / 1000.0;
+    const uint32_t* rn = a.rn + fo * a.rn_pitch + a.rn_pos[g];
+    const int half = __builtin_amdgcn_readfirstlane(mround(1.5 * fs / f0));
+    const int n = 2 * half + 1;
+    const int64_t c = mround(pos * fs + 0.001);
+    // ---- windowed waveform, two samples per complex point: sample i = 2 (l + 64 q) + s
+    double2 z[R], xh;
+    {
+      // the window of sample i waits in S[l + 64 j] between the three passes (energy, mean, removal):
+      // sixteen doubles per lane that the registers do not have beside the samples
+      double e = 0.0;
+#pragma unroll
+      for (int j = 0; j < 2 * R; ++j) {
+        const int i = 2 * (l + 64 * (j >> 1)) + (j & 1);
+        if (128 * (j >> 1) < n) {                   // wave-uniform: registers beyond the window are skipped
+          double wj = 0.0;
+          if (i < n) {
+            const int b = i - half;
+            wj = 0.5 * fm::fcos(kPi * ((double)b / 1.5 / fs) * f0) + 0.5;
+            e += wj * wj;
+          }
+          S[l + 64 * j] = wj;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      e = sqrt(wave_sum_at(e, l));
+      double swf = 0.0, sw = 0.0;
+      double v[2 * R];
+#pragma unroll
+      for (int j = 0; j < 2 * R; ++j) {
+        const int i = 2 * (l + 64 * (j >> 1)) + (j & 1);
+        double vj = 0.0;
+        if (128 * (j >> 1) < n) {
+          if (i < n) {
+            const double wn = S[l + 64 * j] / e;
+            S[l + 64 * j] = wn;
+            int64_t idx = c + i - half;
+            idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+            vj = x[idx] * wn;
+            const double nz = randn_of(rn[i]) * 1e-12;
+            vj = vj + nz;
+            swf += vj;
+            sw += wn;
+          }
+        }
+        v[j] = vj;
+      }
+      swf = wave_sum_at(swf, l);
+      sw = wave_sum_at(sw, l);
+      const double mean = swf / sw;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int i = 2 * (l + 64 * q);
+        double a0 = v[2 * q], a1 = v[2 * q + 1];
+        if (128 * q < n) {
+          if (i < n) a0 = a0 - S[l + 64 * (2 * q)] * mean;
+          if (i + 1 < n) a1 = a1 - S[l + 64 * (2 * q + 1)] * mean;
+        }
+        z[q] = make_double2(a0, a1);
+      }
+      wf::wave_sync();
+    }
+    wf::rfft<R>(z, xh, P);
+    double pw[R], p512;
+#pragma unroll
+    for (int q = 0; q < R; ++q) pw[q] = z[q].x * z[q].x + z[q].y * z[q].y;
+    p512 = ct_bcast0(xh.x * xh.x + xh.y * xh.y);
+    // ---- DC correction (wd::dc_correction): the replica is interpolated from the uncorrected bins
+#pragma unroll
+    for (int q = 0; q < R; ++q) S[l + 64 * q] = pw[q];
+    if (l == 0) S[H] = p512;
+    wf::wave_sync();
+    {
+      const int upper = 2 + (int)(f0 * FFT / fs);
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int ii = l + 64 * q;
+        if (64 * q < upper - 1) {          // wave-uniform: one register of bins at speech F0
+          if (ii < upper - 1) pw[q] += interp1q(f0, -(double)fs / FFT, S, upper + 1, (double)ii * fs / FFT);
+        }
+      }
+      if (H < upper - 1) p512 += interp1q(f0, -(double)fs / FFT, S, upper + 1, (double)H * fs / FFT);
+    }
+    wf::wave_sync();
+    // ---- linear smoothing over f0 * 2 / 3 (wd::linear_smoothing): mirrored copy, running sum, two
+    // interpolated reads per bin
+    const double width = f0 * 2.0 / 3.0;
+    const int boundary = __builtin_amdgcn_readfirstlane((int)(width * FFT / fs) + 1);
+    const int ml = H + boundary * 2 + 1;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int k = l + 64 * q;
+      const double val = pw[q] * fs / FFT;
+      S[boundary + k] = val;
+      if (k >= 1 && k <= boundary) S[boundary - k] = val;
+      if (k >= H - boundary) S[H + boundary + (H - k)] = val;
+    }
+    if (l == 0) S[H + boundary] = p512 * fs / FFT;
+    wf::wave_sync();
+    {
+      const int chunk = (ml + 63) >> 6;            // <= CTW_SCAN
+      const int lo = l * chunk;
+      double cs[CTW_SCAN];
+      double run = 0.0;
+#pragma unroll
+      for (int j = 0; j < CTW_SCAN; ++j) {
+        double t = 0.0;
+        if (j < chunk && lo + j < ml) t = S[lo + j];
+        run += t;
+        cs[j] = run;
+      }
+      double incl = run;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double o = lane_shfl(incl, l - off);       // lanes below `off` fetch from a wrapped lane and drop it
+        if (l >= off) incl += o;
+      }
+      const double excl = incl - run;
+      wf::wave_sync();
+#pragma unroll
+      for (int j = 0; j < CTW_SCAN; ++j)
+        if (j < chunk && lo + j < ml) S[lo + j] = excl + cs[j];
+      wf::wave_sync();
+    }
+    {
+      const double org = -((double)boundary - 0.5) * fs / FFT;
+      const double dfi = (double)fs / FFT;
+#pragma unroll
+      for (int q = 0; q <= R; ++q) {
+        const int k = q < R ? l + 64 * q : H;
+        const double fa = (double)k / FFT * fs - width / 2.0;
+        const double lo = interp1q(org, dfi, S, ml, fa);
+        const double hi = interp1q(org, dfi, S, ml, fa + width);
+        const double o = (hi - lo) / width;
+        if (q < R) pw[q < R ? q : 0] = o; else p512 = o;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wf::wave_sync();
+    // ---- smoothing with recovery (cepstral liftering)
+    {
+      double lp[R], lp512;
+#pragma unroll
+      for (int q = 0; q <= R; ++q) {
+        const int k = q < R ? l + 64 * q : H;
+        const double nz = fabs(randn_of(rn[n + k])) * 2.2204460492503131e-16;
+        const double v = log_pos((q < R ? pw[q < R ? q : 0] : p512) + nz);
+        if (q < R) lp[q < R ? q : 0] = v; else lp512 = v;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wf::pack_real(lp, lp512, z, P, true);
+    }
+    wf::rfft<R>(z, xh, P);
+#pragma unroll
+    for (int q = 0; q <= R; ++q) {
+      const int k = q < R ? l + 64 * q : H;
+      double sl = 1.0, cl = 1.0;
+      if (k > 0) {
+        const double qq = (double)k / fs;
+        sl = fm::fsin(kPi * f0 * qq) / (kPi * f0 * qq);
+        cl = (1.0 - 2.0 * q1) + 2.0 * q1 * fm::fcos(2.0 * kPi * qq * f0);
+      }
+      if (q < R) z[q < R ? q : 0] = make_double2(z[q < R ? q : 0].x * sl * cl, 0.0);
+      else xh = make_double2(xh.x * sl * cl, 0.0);     // X[512]: lane 0's value is the one irfft reads
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wf::irfft<R>(z, xh, P);
+    double* out = a.sp + g * K;
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+      const int k = 2 * (l + 64 * q);
+      out[k] = exp(z[q].x);
+      out[k + 1] = exp(z[q].y);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (l == 0) out[H] = exp(z[R / 2].x);
+  }
 }
 
 // mgc2sp(gamma = 0): c = freqt(mc, -alpha) to order fftlen/2, FFT, real part; optional exp.
@@ -443,12 +685,29 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   ITTS_LAUNCH_CHECK();
   rc = launch_randn_u32(ctx, d_roff, d_rlen, n_utts, t_max * rn_pitch, d_rn, s);
   if (rc) return rc;
-  a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch;
-  size_t lds = ct_lds_bytes(fft_size, a.bmax, false);
-  ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(cheaptrick_kernel, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch; a.t_total = t_total; a.far_only = 0;
+  // the smoothing boundary of the wave kernel is bounded by its scratch: 513 + 2 b <= 1088 doubles
+  if (fft_size == 1024 && 513 + 2 * ((int)(1000.0 * 2.0 / 3.0 * fft_size / fs) + 1) <= 64 * CTW_SCAN) {
+    int dev = 0, n_cu = 256;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    constexpr int NW = CTW_THREADS / 64;
+    const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(cheaptrick_wave_kernel, dim3((unsigned)std::min<int64_t>((t_total + NW - 1) / NW, n_cu)),
+                       dim3(CTW_THREADS), lds, s, a, t_total);
+    ITTS_LAUNCH_CHECK();
+    a.far_only = 1;     // frames with an F0 at or beyond fs / 2: a pass that reads the F0 values and normally finds none
+  }
+  {
+    size_t lds = ct_lds_bytes(fft_size, a.bmax, false);
+    ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(cheaptrick_kernel, dim3((unsigned)(a.far_only ? std::min<int64_t>(t_total, 256) : t_total)),
+                       dim3(NT), lds, s, a);
+  }
   ITTS_LAUNCH_CHECK();
   ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_fo, s));

@@ -62,7 +62,18 @@ def test_cheaptrick_and_fused_mcep_match_oracle(gpu, utts, golden_dir):
     for u, (xu, _, f0u, tpu) in enumerate(utts):
         a, b = f_off[u], f_off[u + 1]
         sp_ref = capi.cheaptrick(xu, fs, tpu, f0u)
-        assert np.abs(sp[a:b] / sp_ref - 1).max() < 1e-8
+        # The smoothing differences running sums over the whole spectrum: a bin 1e-7 below its frame's
+        # peak carries the rounding of the sums, eps * 1e7 in relative terms, in the oracle (sequential
+        # sum) as in the kernels (blocked sums).  scripts/ct_error_probe.py: the worst bin of this
+        # fixture is 1.2e-8 off for the wave kernel AND for the workgroup kernel (at fft 2048), at
+        # sp = 3e-10 against a frame peak of 6e-3; median 1e-14, 99 % below 2e-10, 99.99 % below 7e-9.
+        # So: the relative bound with room for that worst bin, a tight one for the bulk, and every bin
+        # within 1e-11 of its frame's peak.
+        err = np.abs(sp[a:b] - sp_ref)
+        peak = sp_ref.max(axis=1, keepdims=True)
+        assert (err / sp_ref).max() < 3e-8
+        assert np.quantile(err / sp_ref, 0.999) < 2e-9
+        assert (err / peak).max() < 1e-11
         mc_ref, it_ref = capi.mcep(np.sqrt(sp_ref), 19, 0.58, return_iters=True)
         assert np.array_equal(iters[a:b], it_ref)            # same Newton trip counts
         assert np.abs(mc[a:b] - mc_ref).max() < 1e-8
@@ -422,6 +433,26 @@ def test_ragged_batch_with_silence_and_very_short_utterances(gpu):
     assert ap0.shape == (0, 513)
     y0, y0_off = ops.world_synthesize(e, sp0, ap0, [0], fs)
     assert y0.numel() == 0 and y0_off == [0]
+
+
+def test_cheaptrick_frames_with_f0_beyond_nyquist_take_the_workgroup_kernel(gpu, utts):
+    """F0 at or above fs / 2 is an input error (WORLD's DC correction reads past its arrays there, so the
+    oracle has no answer to compare with); the wave-per-frame kernel leaves such frames to the
+    workgroup kernel (csrc/world_frame.hip: ct_far).  The call must go through, and every other frame
+    must come out bit for bit as it does without the stray value -- the last frame of an utterance is
+    changed, so that no other frame's position in the safeguard-noise stream moves."""
+    from idiaptts_amd import ops
+    x, f0, x_off, f_off = _batch(utts, gpu)
+    fs = utts[0][1]
+    sp_a, _, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs)
+    f0_b = f0.clone()
+    last = f_off[1] - 1
+    f0_b[last] = 0.6 * fs
+    sp_b, _, _ = ops.cheaptrick_mcep(x, x_off, f0_b, f_off, fs)
+    keep = torch.ones(f0.numel(), dtype=torch.bool, device=gpu)
+    keep[last] = False
+    assert torch.equal(sp_a[keep], sp_b[keep])
+    assert not torch.equal(sp_a[last], sp_b[last])
 
 
 def test_long_utterances_exercise_the_large_size_paths(gpu):
