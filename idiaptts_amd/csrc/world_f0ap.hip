@@ -14,6 +14,7 @@
 
 #include "context.h"
 #include "world_dev.h"
+#include "select_largest.h"
 
 namespace itts {
 using namespace wd;
@@ -567,20 +568,28 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
       }
       __syncthreads();
       rfft();
-      // power spectrum: each thread keeps its (<= 9) bins; pop the boundary+1 largest of the block
-      constexpr int PER = 9;  // (4096/2+1)/256 rounded up
-      double mine[PER];
+      // power spectrum: each thread keeps its bins (sorted); the boundary + 1 largest of the frame are left
+      // out of `rest` (d4c.cpp, D4CGeneralBody's sort)
+      constexpr int MPER = AREG ? 9 : 5;  // (fft / 2 + 1) / 256 rounded up
+      double mine[MPER];
       int cnt = 0;
-      for (int k = threadIdx.x; k <= h; k += NT) {
-        const double2 v = L.z[k];
-        mine[cnt++] = v.x * v.x + v.y * v.y;
-      }
-      // sort descending (tiny insertion sort in registers)
 #pragma unroll
-      for (int i = 1; i < PER; ++i) {
+      for (int i = 0; i < MPER; ++i) {
+        const int k = (int)threadIdx.x + i * NT;
+        double v = -1.0;
+        if (k <= h) {
+          const double2 zz = L.z[k];
+          v = zz.x * zz.x + zz.y * zz.y;
+          ++cnt;
+        }
+        mine[i] = v;
+      }
+      // sort descending (tiny insertion sort in registers; the -1 fillers stay behind)
+#pragma unroll
+      for (int i = 1; i < MPER; ++i) {
 #pragma unroll
         for (int j = i; j > 0; --j) {
-          if (j < cnt && mine[j] > mine[j - 1]) {
+          if (mine[j] > mine[j - 1]) {
             const double tswap = mine[j];
             mine[j] = mine[j - 1];
             mine[j - 1] = tswap;
@@ -589,52 +598,10 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
       }
       double total = 0.0;
 #pragma unroll
-      for (int i = 0; i < PER; ++i)
+      for (int i = 0; i < MPER; ++i)
         if (i < cnt) total += mine[i];
-      total = bsum(total, L.red);
-      int popped = 0;
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-      double* cand = L.red;        // [4] wave maxima
-      int* candi = reinterpret_cast<int*>(L.red + 8);
-      for (int round = 0; round <= boundary; ++round) {
-        double v = -1.0;
-#pragma unroll
-        for (int i = 0; i < PER; ++i)
-          if (i == popped && i < cnt) v = mine[i];
-        // wave arg-max
-        double best = v;
-        int who = threadIdx.x;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const double ov = __shfl_xor(best, off, 64);
-          const int ow = __shfl_xor(who, off, 64);
-          if (ov > best || (ov == best && ow < who)) {
-            best = ov;
-            who = ow;
-          }
-        }
-        __syncthreads();
-        if (lane == 0) {
-          cand[wv] = best;
-          candi[wv] = who;
-        }
-        __syncthreads();
-        double bb = cand[0];
-        int bw = candi[0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-          if (cand[q] > bb || (cand[q] == bb && candi[q] < bw)) {
-            bb = cand[q];
-            bw = candi[q];
-          }
-        if (bw == (int)threadIdx.x) ++popped;
-      }
-      __syncthreads();
-      double rest = 0.0;
-#pragma unroll
-      for (int i = PER - 1; i >= 0; --i)
-        if (i < cnt && i >= popped) rest += mine[i];
-      rest = bsum(rest, L.red);
+      total = bsum(total, L.red);          // (its barriers: everybody has read z, which now holds the lists)
+      const double rest = d4c_rest_without_largest<MPER>(mine, cnt, boundary + 1, zr, L.red);
       const double ca = 10.0 * log10(rest / total);
       const double cv = ca + (f0 - 100.0) / 50.0;
       coarse[b] = cv < 0.0 ? cv : 0.0;
