@@ -515,9 +515,11 @@ __device__ __forceinline__ void fu_form_b(const MlpgArgs& a, const double* f, in
 //           state's image (P, R at the last two frames times the factor's off-diagonals),
 //           C = [P R]^T [U V] from the Gram sums P.P, P.R, R.R -- one set per dimension for the
 //           stationary chunks, recomputed in place for the few others (utterance start / tail)
-//   solve   every chunk again, now from its true states: input re-read, y in registers, x stored
-// HBM bytes per frame: 2 x 1496 (input twice) + 496 (output) + the aggregates (128 B per chunk
-// and dimension, written and read once each) against 2000 algorithmic.
+//   solve   every chunk again, now from its true states: b read back from the output rows (where the
+//           reduce kernel left it), y in registers, x stored over b
+// HBM bytes per frame: 1496 (input once) + 3 x 496 (b out, b in, x out) + the aggregates (128 B per
+// chunk and dimension, written and read once each) = 3.1 kB against 2000 algorithmic; measured with the
+// halo rows and partial lines 4.4 kB (profiles/r4_section_traffic.json).
 struct alignas(32) StRecord {
   long long t0;      // first frame of the utterance in the batch
   int T;             // its length
