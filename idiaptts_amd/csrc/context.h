@@ -16,6 +16,11 @@ struct FreqtTables {
   double* fwdT = nullptr;  // [f2+1][m+1]   mc[j]  = sum_i fwdT[i][j] * c[i]      freqt(c, f2 -> m, +a)
   double* invT = nullptr;  // [m+1][f2+1]   c'[i]  = sum_j invT[j][i] * mc[j]    freqt(mc, m -> f2, -a)
   double* frqT = nullptr;  // [f2+1][2m+1]  cr[j]  = sum_i frqT[i][j] * r[i]     frqtr(r, f2 -> 2m, +a)
+  // The Newton loop of mcep never needs c' or r themselves, only the log spectrum Re FFT(c') and the
+  // warped autocorrelation of IFFT(d): both transforms are linear, so they are folded into the
+  // warping matrices (round 4; the loop lost its two FFTs per frame and iteration):
+  double* specT = nullptr; // [m+1][f2+1]   S[k]   = sum_j specT[j][k] * mc[j]    = Re rfft(freqt(mc, -a))[k]
+  double* crT = nullptr;   // [f2+1][2m+1]  cr[j]  = sum_k crT[k][j] * d[k]       = frqtr(irfft(d))[j], d real
   // SPTK mgcep's own transform b2c (freqt without the `+ a d[0]` in the zeroth term):
   double* b1T = nullptr;   // [m+1][f2+1]   c[i]   = sum_j b1T[j][i] * b[j]      b2c(b, m -> f2, -a)
   double* p2T = nullptr;   // [f2+1][2m+1]  p~[j]  = sum_i p2T[i][j] * p[i]      b2c(p, f2 -> 2m, +a)

@@ -33,11 +33,15 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // frames that have not converged yet.  VEC_A: a lane's four consecutive k of a chunk come as two
 // 16-byte loads (needs an even lda and a 16-byte aligned base; rows may be read up to 3 doubles
 // past K, the callers' buffers have that slack).
-template <bool VEC_A>
+// RATIO: the result is not stored as it is but as  aux[row][col] / exp(2 * result)  -- the Newton loop's
+// spectral ratio |X|^2 / |H|^2 formed where the log spectrum leaves the matrix core (aux: the
+// periodogram rows, same pitch and row list as C), instead of in a pass of its own over 1.3 GB.
+template <bool VEC_A, bool RATIO = false>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
                                                        const double* __restrict__ Bm, int64_t ldb,
                                                        double* __restrict__ C, int64_t ldc, int64_t T,
-                                                       int N, int K, const int* __restrict__ rows) {
+                                                       int N, int K, const int* __restrict__ rows,
+                                                       const double* __restrict__ aux = nullptr) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   // 1-D grid, column tile fastest: the workgroups that share a row block of A run next to each other
@@ -133,12 +137,27 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
       if (orow >= T) continue;
       const int64_t prow_o = rows ? rows[orow] : orow;
       double* crow = C + prow_o * ldc + cb;
+      double o4[4] = {acc[h][0][r], acc[h][1][r], acc[h][2][r], acc[h][3][r]};
+      if (RATIO) {
+        const double* xrow = aux + prow_o * ldc + cb;
+        double x4[4];
+        if (cfull) {
+          const f64x4 xv = *reinterpret_cast<const f64x4*>(xrow);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x4[q] = xv[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x4[q] = xrow[cb + q < N ? q : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o4[q] = x4[q] / exp(2.0 * o4[q]);
+      }
       if (cfull) {
-        *reinterpret_cast<f64x4*>(crow) = (f64x4){acc[h][0][r], acc[h][1][r], acc[h][2][r], acc[h][3][r]};
+        *reinterpret_cast<f64x4*>(crow) = (f64x4){o4[0], o4[1], o4[2], o4[3]};
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (cb + q < N) crow[q] = acc[h][q][r];
+          if (cb + q < N) crow[q] = o4[q];
       }
     }
 }
@@ -483,25 +502,6 @@ __global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
   }
 }
 
-// r = irfft( xp / exp(2 Re rfft(c')) ), in place on cbuf rows of active frames
-__global__ __launch_bounds__(NT) void mcls_spec_kernel(LsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t g = a.rows ? a.rows[blockIdx.x] : blockIdx.x;
-  if (a.done[g]) return;
-  const int f2 = a.flng / 2;
-  const double2* tw = a.g_tw_compact;        // read through the cache: the LDS pipe only carries data
-  double2* z = reinterpret_cast<double2*>(smem);
-  double* zr = reinterpret_cast<double*>(z);
-  double* row = a.cbuf + g * a.ldk;
-  for (int i = threadIdx.x; i < a.flng + 2; i += NT) zr[i] = (i <= f2) ? row[i] : 0.0;
-  __syncthreads();
-  rfft_lds(z, a.flng, a.logflng, tw, a.flng);
-  const double* xp = a.xp + g * a.ldk;
-  for (int k = threadIdx.x; k <= f2; k += NT) z[k] = make_double2(xp[k] / exp(2.0 * z[k].x), 0.0);
-  __syncthreads();
-  irfft_lds(z, a.flng, a.logflng, tw, a.flng);
-  for (int k = threadIdx.x; k <= f2; k += NT) row[k] = zr[k];
-}
 
 // ---- the same two kernels with one WAVE per frame (flng = 1024 or 2048) ---------------------------------
 // wave_fft.h: the 513 bins of a frame live eight per lane in registers, the transforms need no
@@ -553,37 +553,6 @@ __global__ __launch_bounds__(lsw<R>()) void mcls_init_wave_kernel(LsArgs a) {
   }
 }
 
-template <int R>
-__global__ __launch_bounds__(lsw<R>()) void mcls_spec_wave_kernel(LsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int f2 = 64 * R, NW = lsw<R>() / 64;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
-  typename wf::PlanOf<R>::type P;
-  wf::table_init<R>(smem, a.g_tw_compact);
-  wf::plan_init(P, a.g_tw_compact, smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>(), smem);
-  const int64_t n = a.rows ? a.n_rows : a.T;
-  for (int64_t r = (int64_t)blockIdx.x * NW + wv; r < n; r += (int64_t)gridDim.x * NW) {
-    const int64_t g = a.rows ? a.rows[r] : r;
-    if (a.done[g]) continue;
-    double* row = a.cbuf + g * a.ldk;
-    const double* xp = a.xp + g * a.ldk;
-    // the real sequence c'[0 .. f2], zero beyond, packed two samples per complex point
-    double2 z[R], xh;
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) z[q] = *reinterpret_cast<const double2*>(row + 2 * (l + 64 * q));
-#pragma unroll
-    for (int q = R / 2; q < R; ++q) z[q] = make_double2(0.0, 0.0);
-    if (l == 0) z[R / 2] = make_double2(row[f2], 0.0);
-    wf::rfft<R>(z, xh, P);
-#pragma unroll
-    for (int q = 0; q < R; ++q) z[q] = make_double2(xp[l + 64 * q] / exp(2.0 * z[q].x), 0.0);
-    xh = make_double2(xp[f2] / exp(2.0 * ls_bcast0(xh.x)), 0.0);
-    wf::irfft<R>(z, xh, P);
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
-    if (l == 0) row[f2] = z[R / 2].x;
-  }
-}
 
 // convergence test + Newton update of one frame from cr
 __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
@@ -796,6 +765,41 @@ __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, i
   }
 }
 
+// rows of C (the active ones): C = aux / exp(2 C), k < N -- the same expression as the RATIO epilogue of
+// gemm_f64_kernel, for the products that do not run on that kernel (order > 63)
+__global__ void mcls_ratio_kernel(double* __restrict__ C, const double* __restrict__ aux, int64_t ldc, int64_t T,
+                                  int N, const int* __restrict__ rows) {
+  const int64_t n = T * N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / N;
+    const int k = (int)(i - r * N);
+    const int64_t g = rows ? rows[r] : r;
+    C[g * ldc + k] = aux[g * ldc + k] / exp(2.0 * C[g * ldc + k]);
+  }
+}
+
+// C = aux / exp(2 A B): launch_gemm_f64 with the ratio formed in the epilogue where the kernel allows it
+int launch_gemm_f64_ratio(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                          int64_t T, int N, int K, const int* rows, const double* aux, hipStream_t s) {
+  if (T <= 0) return ITTS_OK;
+  const bool vec = lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && K % 4 == 0;
+  if (K <= 64) {
+    const unsigned grid = (unsigned)((T + 127) / 128) * (unsigned)((N + 63) / 64);
+    if (vec)
+      hipLaunchKernelGGL((gemm_f64_kernel<true, true>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows, aux);
+    else
+      hipLaunchKernelGGL((gemm_f64_kernel<false, true>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, C, ldc, T, N, K, rows, aux);
+    ITTS_LAUNCH_CHECK();
+    return ITTS_OK;
+  }
+  const int rc = launch_gemm_f64(A, lda, B, ldb, C, ldc, T, N, K, rows, s, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mcls_ratio_kernel, dim3((unsigned)std::min<int64_t>((T * N + 255) / 256, 16384)), dim3(256), 0, s,
+                     C, aux, ldc, T, N, rows);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
 int launch_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                     int64_t ldc, int64_t T, int N, int K, const int* rows, hipStream_t s,
                     bool a_has_slack) {
@@ -866,8 +870,6 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_spec_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
   // 1024- and 2048-point transforms: one wave per frame, one persistent workgroup per CU
@@ -881,10 +883,9 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     int dev = 0;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    const void* kernels[4] = {(const void*)mcls_init_wave_kernel<8>, (const void*)mcls_spec_wave_kernel<8>,
-                              (const void*)mcls_init_wave_kernel<16>, (const void*)mcls_spec_wave_kernel<16>};
-    for (int i = (wave_r == 8 ? 0 : 2); i < (wave_r == 8 ? 2 : 4); ++i)
-      ITTS_HIP_CHECK(hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+    ITTS_HIP_CHECK(hipFuncSetAttribute(wave_r == 8 ? (const void*)mcls_init_wave_kernel<8>
+                                                   : (const void*)mcls_init_wave_kernel<16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
   }
   auto wave_grid = [&](int64_t frames) {
     const int64_t per = wthreads / 64;
@@ -899,16 +900,11 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   for (int it = 1; it <= maxiter; ++it) {
     a.iter = it;
     const int64_t nr = a.n_rows;      // frames still iterating (their list is a.rows)
-    if ((rc = launch_gemm_f64(mc, m1, ft->invT, K, cbuf, Kp, nr, K, m1, a.rows, s))) return rc;
-    if (wave_r == 8) {
-      hipLaunchKernelGGL(mcls_spec_wave_kernel<8>, wave_grid(nr), dim3(wthreads), lds_wave, s, a);
-    } else if (wave_r == 16) {
-      hipLaunchKernelGGL(mcls_spec_wave_kernel<16>, wave_grid(nr), dim3(wthreads), lds_wave, s, a);
-    } else {
-      hipLaunchKernelGGL(mcls_spec_kernel, dim3((unsigned)nr), dim3(NT), lds_fft, s, a);
-    }
-    ITTS_LAUNCH_CHECK();
-    if ((rc = launch_gemm_f64(cbuf, Kp, ft->frqT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
+    // log spectrum of the current model and the ratio to the periodogram in one product (the two
+    // transforms of the reference's loop are folded into the warping matrices: FreqtTables), then the
+    // warped autocorrelation of the ratio
+    if ((rc = launch_gemm_f64_ratio(mc, m1, ft->specT, K, cbuf, Kp, nr, K, m1, a.rows, xp, s))) return rc;
+    if ((rc = launch_gemm_f64(cbuf, Kp, ft->crT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
     const dim3 wgrid((unsigned)((nr + 3) / 4));
     if (m1 <= 20) hipLaunchKernelGGL(mcls_solve_wave_kernel<20>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_wave_kernel<24>, wgrid, dim3(256), 0, s, a);
