@@ -77,9 +77,14 @@ struct DeviceContext {
 // failure.
 DeviceContext* get_context();
 // Returns warping tables for (order m, f2 = fftlen/2, alpha); nullptr + error on failure.
-// need_fwd_frq = false builds only invT (enough for mgc2sp).
+// need_fwd_frq = false builds only invT; need_spec adds specT (mgc2sp's folded form; need_fwd_frq implies it).
 const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq,
-                             bool need_mgc = false);
+                             bool need_mgc = false, bool need_spec = false);
+
+// C = A B as launch_gemm_f64, K <= 64, with mgc2sp's outputs formed in the epilogue instead of C: the raw
+// value (o64), exp(float(value)) (o32) and its square as double (opow), any of them, rows of pitch N.
+int launch_gemm_f64_mgc2sp(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t T, int N, int K,
+                           float* o32, double* o64, double* opow, hipStream_t s);
 
 // Jump matrices of the randn() generator on the context's device; nullptr + error on failure.
 const JumpTable* get_jump_table(DeviceContext* ctx);

@@ -427,7 +427,7 @@ static int upload(const std::vector<double>& h, double** d) {
 }
 
 const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bool need_fwd_frq,
-                             bool need_mgc) {
+                             bool need_mgc, bool need_spec) {
   long long abits;
   std::memcpy(&abits, &alpha, sizeof(abits));
   const auto key = std::make_tuple(m, f2, abits);
@@ -456,22 +456,13 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
     }
     if (upload(fwd, &t.fwdT) != ITTS_OK) return nullptr;
     if (upload(frq, &t.frqT) != ITTS_OK) return nullptr;
-    // specT = inv . C with C[n][k] = cos(2 pi k n / 2 f2): the real part of the one-sided transform of
-    // c'[0 .. f2]; crT = Ci^T . frq with Ci[n][k] = w_k cos(2 pi k n / 2 f2) / (2 f2), w_0 = w_f2 = 1,
-    // otherwise 2: the inverse transform of a real spectrum, sample n <= f2.  Cosines from the reduced
-    // integer argument, sums in long double.
+    // crT = Ci^T . frq with Ci[n][k] = w_k cos(2 pi k n / 2 f2) / (2 f2), w_0 = w_f2 = 1, otherwise 2: the
+    // inverse transform of a real spectrum, sample n <= f2.  Cosines from the reduced integer
+    // argument, sums in long double.
     const int nfft = 2 * f2;
     std::vector<long double> cs(nfft);
     for (int i = 0; i < nfft; ++i) cs[i] = cosl(2.0L * 3.14159265358979323846264338327950288L * i / nfft);
-    std::vector<double> spec((size_t)(m + 1) * (f2 + 1)), crt((size_t)(f2 + 1) * (m2 + 1));
-    for (int j = 0; j <= m; ++j) {
-      freqt_unit(j, f2, -alpha, g.data(), d.data());
-      for (int k = 0; k <= f2; ++k) {
-        long double acc = 0.0L;
-        for (int n = 0; n <= f2; ++n) acc += (long double)g[n] * cs[(size_t)((int64_t)k * n % nfft)];
-        spec[(size_t)j * (f2 + 1) + k] = (double)acc;
-      }
-    }
+    std::vector<double> crt((size_t)(f2 + 1) * (m2 + 1));
     std::vector<long double> accj(m2 + 1);
     for (int k = 0; k <= f2; ++k) {
       const long double wk = (k == 0 || k == f2) ? 1.0L : 2.0L;
@@ -483,8 +474,24 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
       }
       for (int j = 0; j <= m2; ++j) crt[(size_t)k * (m2 + 1) + j] = (double)(accj[j] * wk / nfft);
     }
-    if (upload(spec, &t.specT) != ITTS_OK) return nullptr;
     if (upload(crt, &t.crT) != ITTS_OK) return nullptr;
+  }
+  if ((need_spec || need_fwd_frq) && !t.specT) {
+    // specT = inv . C with C[n][k] = cos(2 pi k n / 2 f2): the real part of the one-sided transform of
+    // c'[0 .. f2] (same cosines, same sums)
+    const int nfft = 2 * f2;
+    std::vector<long double> cs(nfft);
+    for (int i = 0; i < nfft; ++i) cs[i] = cosl(2.0L * 3.14159265358979323846264338327950288L * i / nfft);
+    std::vector<double> spec((size_t)(m + 1) * (f2 + 1));
+    for (int j = 0; j <= m; ++j) {
+      freqt_unit(j, f2, -alpha, g.data(), d.data());
+      for (int k = 0; k <= f2; ++k) {
+        long double acc = 0.0L;
+        for (int n = 0; n <= f2; ++n) acc += (long double)g[n] * cs[(size_t)((int64_t)k * n % nfft)];
+        spec[(size_t)j * (f2 + 1) + k] = (double)acc;
+      }
+    }
+    if (upload(spec, &t.specT) != ITTS_OK) return nullptr;
   }
   if (need_mgc && !t.b1T) {
     std::vector<double> b1((size_t)(m + 1) * (f2 + 1)), p2((size_t)(f2 + 1) * (m2 + 1));

@@ -36,12 +36,20 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // RATIO: the result is not stored as it is but as  aux[row][col] / exp(2 * result)  -- the Newton loop's
 // spectral ratio |X|^2 / |H|^2 formed where the log spectrum leaves the matrix core (aux: the
 // periodogram rows, same pitch and row list as C), instead of in a pass of its own over 1.3 GB.
-template <bool VEC_A, bool RATIO = false>
+// MGC2SP: nothing is stored to C; the value goes to o64, exp(float(value)) to o32 and its square as a
+// double to opow (any of the three, rows of pitch N): mgc2sp's outputs (AudioProcessing.py:252-256, :925).
+struct GemmOut {
+  float* o32;
+  double* o64;
+  double* opow;
+};
+template <bool VEC_A, bool RATIO = false, bool MGC2SP = false>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
                                                        const double* __restrict__ Bm, int64_t ldb,
                                                        double* __restrict__ C, int64_t ldc, int64_t T,
                                                        int N, int K, const int* __restrict__ rows,
-                                                       const double* __restrict__ aux = nullptr) {
+                                                       const double* __restrict__ aux = nullptr,
+                                                       GemmOut out = GemmOut{nullptr, nullptr, nullptr}) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   // 1-D grid, column tile fastest: the workgroups that share a row block of A run next to each other
@@ -152,7 +160,18 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
 #pragma unroll
         for (int q = 0; q < 4; ++q) o4[q] = x4[q] / exp(2.0 * o4[q]);
       }
-      if (cfull) {
+      if (MGC2SP) {
+        const int64_t o = prow_o * N + cb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (cfull || cb + q < N) {
+            if (out.o64) out.o64[o + q] = o4[q];
+            const float amp = expf((float)o4[q]);
+            if (out.o32) out.o32[o + q] = amp;
+            if (out.opow) out.opow[o + q] = (double)amp * (double)amp;
+          }
+        }
+      } else if (cfull) {
         *reinterpret_cast<f64x4*>(crow) = (f64x4){o4[0], o4[1], o4[2], o4[3]};
       } else {
 #pragma unroll
@@ -763,6 +782,23 @@ __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, i
     if (o64) o64[i] = v;
     if (iters_out && j == 0) iters_out[t] = iters_in[t];
   }
+}
+
+int launch_gemm_f64_mgc2sp(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t T, int N, int K,
+                           float* o32, double* o64, double* opow, hipStream_t s) {
+  if (T <= 0) return ITTS_OK;
+  ITTS_REQUIRE(K <= 64, "launch_gemm_f64_mgc2sp: K <= 64");
+  const bool vec = lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && K % 4 == 0;
+  const unsigned grid = (unsigned)((T + 127) / 128) * (unsigned)((N + 63) / 64);
+  const GemmOut out{o32, o64, opow};
+  if (vec)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb,
+                       (double*)nullptr, (int64_t)0, T, N, K, (const int*)nullptr, (const double*)nullptr, out);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb,
+                       (double*)nullptr, (int64_t)0, T, N, K, (const int*)nullptr, (const double*)nullptr, out);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
 }
 
 // rows of C (the active ones): C = aux / exp(2 C), k < N -- the same expression as the RATIO epilogue of

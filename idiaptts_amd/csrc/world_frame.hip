@@ -513,38 +513,6 @@ __global__ __launch_bounds__(NT) void mgc2sp_kernel(Mgc2spArgs a) {
   }
 }
 
-// The same with one WAVE per frame (fftlen = 1024 or 2048; wave_fft.h): sixteen / eight frames in flight
-// per CU, no workgroup barrier, bit-identical spectra.
-template <int R> constexpr int mgw() { return R == 8 ? 1024 : 512; }
-template <int R>
-__global__ __launch_bounds__(mgw<R>()) void mgc2sp_wave_kernel(Mgc2spArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int f2 = 64 * R, NW = mgw<R>() / 64;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
-  typename wf::PlanOf<R>::type P;
-  wf::table_init<R>(smem, a.g_tw);
-  wf::plan_init(P, a.g_tw, smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>(), smem);
-  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < a.T; g += (int64_t)gridDim.x * NW) {
-    const double* c = a.cep + g * a.ld_cep;          // rows are 16-byte aligned (even pitch)
-    double2 z[R], xh;
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) z[q] = *reinterpret_cast<const double2*>(c + 2 * (l + 64 * q));
-#pragma unroll
-    for (int q = R / 2; q < R; ++q) z[q] = make_double2(0.0, 0.0);
-    if (l == 0) z[R / 2] = make_double2(c[f2], 0.0);
-    wf::rfft<R>(z, xh, P);
-#pragma unroll
-    for (int q = 0; q <= R; ++q) {
-      if (q == R && l != 0) break;
-      const int k = q < R ? l + 64 * q : f2;
-      const double re = q < R ? z[q < R ? q : 0].x : xh.x;
-      if (a.out_f64) a.out_f64[g * (f2 + 1) + k] = re;
-      const float amp = expf((float)re);
-      if (a.out_f32) a.out_f32[g * (f2 + 1) + k] = amp;
-      if (a.out_pow) a.out_pow[g * (f2 + 1) + k] = (double)amp * (double)amp;
-    }
-  }
-}
 
 // ---- aperiodicity coding -----------------------------------------------------------------------
 // WORLD interp1 (with histc index semantics) on a short monotone knot vector, one query.
@@ -745,11 +713,21 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   if (T == 0) return ITTS_OK;
   DeviceContext* ctx = get_context();
   if (!ctx) return ITTS_E_HIP;
-  const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
-  if (!ft) return ITTS_E_HIP;
   hipStream_t s = as_stream(stream);
   itts::ScratchScope scratch_scope(s);
   const int K = fftlen / 2 + 1;
+  // Orders up to 63 at transform sizes up to 2048: de-warping, transform and real part are ONE linear map
+  // (FreqtTables::specT), so the log amplitude is one fp64-MFMA product and exp / square ride in its
+  // epilogue -- no cepstrum array, no transform kernel (round 4; until then a GEMM to [T x K] cepstra
+  // and one transform per frame).
+  if (order + 1 <= 64 && fftlen <= 2048) {
+    const FreqtTables* fts = get_freqt(ctx, order, fftlen / 2, alpha, false, false, true);
+    if (!fts) return ITTS_E_HIP;
+    return launch_gemm_f64_mgc2sp(d_mc, order + 1, fts->specT, K, T, K, order + 1, d_amp_f32, d_logamp_f64,
+                                  d_pow_f64, s);
+  }
+  const FreqtTables* ft = get_freqt(ctx, order, fftlen / 2, alpha, false);
+  if (!ft) return ITTS_E_HIP;
   const int64_t ld_cep = (K + 1) & ~1;
   double* d_cep = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cep, (size_t)T * ld_cep * 8, s));
@@ -758,23 +736,7 @@ extern "C" int itts_mgc2sp(const double* d_mc, int64_t T, int order, double alph
   if (rc) return rc;
   Mgc2spArgs a{d_cep, ld_cep, T, order, fftlen, ilog2_host(fftlen), d_amp_f32, d_logamp_f64, d_pow_f64,
                ctx->twiddles};
-  if (fftlen == 1024 || fftlen == 2048) {
-    int dev = 0, n_cu = 256;
-    ITTS_HIP_CHECK(hipGetDevice(&dev));
-    ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    a.g_tw = ctx->tw_compact[a.logfft];
-    if (fftlen == 1024) {
-      constexpr int NW = mgw<8>() / 64;
-      const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(mgc2sp_wave_kernel<8>, dim3((unsigned)std::min<int64_t>((T + NW - 1) / NW, n_cu)), dim3(mgw<8>()), lds, s, a);
-    } else {
-      constexpr int NW = mgw<16>() / 64;
-      const size_t lds = wf::table_bytes<16>() + (size_t)NW * wf::lds_bytes<16>();
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(mgc2sp_wave_kernel<16>, dim3((unsigned)std::min<int64_t>((T + NW - 1) / NW, n_cu)), dim3(mgw<16>()), lds, s, a);
-    }
-  } else {
+  {
     size_t lds = (size_t)(fftlen / 2) * 16 + (size_t)(fftlen / 2 + 1) * 16;
     ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mgc2sp_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
