@@ -182,114 +182,190 @@ __global__ __launch_bounds__(NT) void dio_band_kernel(const DioUtt* __restrict__
 }
 
 // ---- zero-crossing events -> compacted "fine" edge positions --------------------------------------
-// grid (nb, U); one workgroup walks the band signal in order and fills the lists of all four event
-// types from ONE read of it (one workgroup per type read the 1.4 GB of band signals four times: the
-// kernel ran at HBM speed, 2.4 ms per analysis).  The walk is sequential per signal, so its time is the
-// number of trips of the longest utterance times the latency of a trip: 512 threads and ER chunks
-// of ET samples per trip, all their loads in flight together, one barrier per trip; the running edge counts live in every thread's registers,
-// the per-wave counts alternate between two LDS buffers.
-// v(i): type 0: s[i]; 1: -s[i]; 2: s[i+1]-s[i] (written as WORLD does: (-s[i]) - (-s[i+1])); 3: its negation
-constexpr int ET = 512;       // threads of an events workgroup (1 024 leave 128 registers per thread: spills)
-__global__ __launch_bounds__(ET) void dio_events_kernel(const DioUtt* __restrict__ utts, DioParams p,
-                                                        const double* __restrict__ sig,
-                                                        double* __restrict__ fine,
-                                                        int* __restrict__ counts) {
-  constexpr int ER = 4, EW = ET / 64;
-  constexpr int SCAP = 512;                // edges of one type staged per trip (more: computed in place)
-  // per-wave edge counts of the four types packed into one word, 16 bits each (a trip has at most
-  // ER * ET = 4 096 samples): one prefix over the waves serves all four types
-  __shared__ unsigned long long wpk[2][ER][EW];      // [buffer][chunk][wave]
-  __shared__ double2 stage_ac[4][SCAP];    // (a, c) of the trip's edges, compacted, per type
-  __shared__ int stage_e[4][SCAP];
-  const int b = blockIdx.x;
-  const DioUtt u = utts[blockIdx.y];
-  const int yl = u.xl + 1;
-  const double* s = sig + u.sig_off + (int64_t)b * yl;
-  double* out0 = fine + u.fine_off + (int64_t)(b * 4) * u.cap;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int base[4] = {0, 0, 0, 0};
-  // types 0 / 1 look at i < yl - 1, types 2 / 3 (differences) at i < yl - 2
-  for (int i0 = 0, it = 0; i0 < yl - 1; i0 += ER * ET, ++it) {
-    double a[ER][2], c[ER][2];           // [chunk][0: the signal, 1: the differences] of type 0 / 2 (1 / 3: negated)
+// Four event types per band signal s: v(i) of type 0: s[i]; 1: -s[i]; 2: s[i+1]-s[i] (written as WORLD
+// does: (-s[i]) - (-s[i+1])); 3: its negation; an edge of a type sits at i where v(i) > 0 >= v(i+1), and its
+// fine position is (i + 1) - v(i) / (v(i+1) - v(i)).  The lists must come out in order, so a list entry's
+// slot is the number of edges in front of it.  Rounds 2-3 walked every signal with one workgroup (running
+// counts in registers: 49 dependent trips of 2 048 samples, 1.8 ms per analysis at a quarter of the VALU's
+// issue rate); now two passes over chunks of ER * ET samples with nothing sequential in them: the
+// counts per chunk and type (one read of the 1.4 GB of band signals at HBM speed), a scan of the counts
+// per signal, then every chunk again -- its edges compacted and divided by dense lanes.
+constexpr int ET = 512;       // threads of an events workgroup
+constexpr int ER = 2;         // samples per thread: chunks of 1 024 samples (four per thread: 120 registers, two workgroups per CU)
+constexpr int ECH = ER * ET;
+
+// edges of this thread's ER samples of chunk `ch`: a / c = v(i) / v(i+1) of types 0 and 2 (1 and 3: negated),
+// the flags, and per wave and sample row the packed counts (16 bits per type)
+struct EdgeRow {
+  double a[ER][2], c[ER][2];
+  bool edge[ER][4];
+  int before[ER][4];                 // edges of the type at lower lanes of the wave, same row
+  unsigned long long pk[ER];         // the wave's counts of the row, four 16-bit fields
+};
+__device__ __forceinline__ void edge_rows(const double* __restrict__ s, int yl, int i0, EdgeRow& e) {
+  const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int r = 0; r < ER; ++r) {
-      const int i = i0 + r * ET + threadIdx.x;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-      if (i < yl - 1) { s0 = s[i]; s1 = s[i + 1]; }
-      if (i < yl - 2) s2 = s[i + 2];
-      a[r][0] = s0; c[r][0] = s1;
-      a[r][1] = (-s0) - (-s1); c[r][1] = (-s1) - (-s2);
-    }
-    bool edge[ER][4];
-    int before[ER][4];
+  for (int r = 0; r < ER; ++r) {
+    const int i = i0 + r * ET + (int)threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (i < yl - 1) { s0 = s[i]; s1 = s[i + 1]; }
+    if (i < yl - 2) s2 = s[i + 2];
+    e.a[r][0] = s0; e.c[r][0] = s1;
+    e.a[r][1] = (-s0) - (-s1); e.c[r][1] = (-s1) - (-s2);
+  }
 #pragma unroll
-    for (int r = 0; r < ER; ++r) {
-      const int i = i0 + r * ET + threadIdx.x;
-      unsigned long long pk = 0;
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        const bool in = i < (ty < 2 ? yl - 1 : yl - 2);
-        const double av = (ty & 1) ? -a[r][ty >> 1] : a[r][ty >> 1];
-        const double cv = (ty & 1) ? -c[r][ty >> 1] : c[r][ty >> 1];
-        edge[r][ty] = in && (av > 0.0) && (cv <= 0.0);
-        const unsigned long long bal = __ballot(edge[r][ty]);
-        before[r][ty] = __popcll(bal & ((1ull << lane) - 1ull));
-        pk |= (unsigned long long)__popcll(bal) << (16 * ty);
-      }
-      if (lane == 0) wpk[it & 1][r][wv] = pk;
-    }
-    __syncthreads();
-    // The interpolation e - a / (c - a) is NOT evaluated where the edge was found (an fp64 division in
-    // sixteen branches that nearly every wave enters for a handful of lanes): the trip's edges are
-    // compacted into LDS and divided by dense lanes afterwards.
-    unsigned long long run = 0;          // edges of the trip's chunks before r, four 16-bit fields
-    int sl[ER][4];
-#pragma unroll
-    for (int r = 0; r < ER; ++r) {
-      const unsigned long long* w = wpk[it & 1][r];
-      unsigned long long off = run, tot = 0;
-#pragma unroll
-      for (int q = 0; q < EW; ++q) {
-        const unsigned long long v = w[q];
-        off += q < wv ? v : 0ull;
-        tot += v;
-      }
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) sl[r][ty] = (int)((off >> (16 * ty)) & 0xffffull) + before[r][ty];
-      run += tot;
-    }
-    int trip[4];
+  for (int r = 0; r < ER; ++r) {
+    const int i = i0 + r * ET + (int)threadIdx.x;
+    unsigned long long pk = 0;
 #pragma unroll
     for (int ty = 0; ty < 4; ++ty) {
-      trip[ty] = (int)((run >> (16 * ty)) & 0xffffull);
+      // types 0 / 1 look at i < yl - 1, types 2 / 3 (differences) at i < yl - 2
+      const bool in = i < (ty < 2 ? yl - 1 : yl - 2);
+      const double av = (ty & 1) ? -e.a[r][ty >> 1] : e.a[r][ty >> 1];
+      const double cv = (ty & 1) ? -e.c[r][ty >> 1] : e.c[r][ty >> 1];
+      e.edge[r][ty] = in && (av > 0.0) && (cv <= 0.0);
+      const unsigned long long bal = __ballot(e.edge[r][ty]);
+      e.before[r][ty] = __popcll(bal & ((1ull << lane) - 1ull));
+      pk |= (unsigned long long)__popcll(bal) << (16 * ty);
+    }
+    e.pk[r] = pk;
+  }
+}
+
+// pass 1: chunk_counts[((u * nb + b) * nch + ch)] = the chunk's edges of the four types (16 bits each)
+__global__ __launch_bounds__(ET) void dio_edge_count_kernel(const DioUtt* __restrict__ utts, int nch,
+                                                            const double* __restrict__ sig,
+                                                            unsigned long long* __restrict__ chunk_counts) {
+  constexpr int EW = ET / 64;
+  __shared__ unsigned long long wpk[EW];
+  const int b = blockIdx.y, nb = gridDim.y;
+  const DioUtt u = utts[blockIdx.z];
+  const int yl = u.xl + 1;
+  const int i0 = blockIdx.x * ECH;
+  if (i0 >= yl - 1) return;
+  EdgeRow e;
+  edge_rows(sig + u.sig_off + (int64_t)b * yl, yl, i0, e);
+  unsigned long long tot = 0;
 #pragma unroll
-      for (int r = 0; r < ER; ++r) {
-        if (edge[r][ty]) {
-          const double av = (ty & 1) ? -a[r][ty >> 1] : a[r][ty >> 1];
-          const double cv = (ty & 1) ? -c[r][ty >> 1] : c[r][ty >> 1];
-          const int e = i0 + r * ET + threadIdx.x + 1;
-          const int sp = sl[r][ty];                     // position among this trip's edges of the type
-          if (sp < SCAP) {
-            stage_ac[ty][sp] = make_double2(av, cv);
-            stage_e[ty][sp] = e;
-          } else if (base[ty] + sp < u.cap) {           // beyond the staging area: in place
-            out0[(int64_t)ty * u.cap + base[ty] + sp] = (double)e - av / (cv - av);
-          }
+  for (int r = 0; r < ER; ++r) tot += e.pk[r];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wpk[wv] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int q = 0; q < EW; ++q) t += wpk[q];
+    chunk_counts[((int64_t)blockIdx.z * nb + b) * nch + blockIdx.x] = t;
+  }
+}
+
+// between the passes: per signal (one wave each), the edges in front of every chunk and the totals
+__global__ __launch_bounds__(64) void dio_edge_scan_kernel(const DioUtt* __restrict__ utts, int nb, int nch,
+                                                           const unsigned long long* __restrict__ chunk_counts,
+                                                           int4* __restrict__ bases, int* __restrict__ counts) {
+  const int sgn = blockIdx.x, lane = threadIdx.x;
+  const DioUtt u = utts[sgn / nb];
+  const int b = sgn % nb;
+  const int n = (u.xl + ECH - 1) / ECH;                  // chunks of this signal: i0 < yl - 1 = xl
+  unsigned long long clo = 0, chi = 0;                   // running totals: types 0, 1 / 2, 3 as 32-bit fields
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int c = c0 + lane;
+    const unsigned long long v = c < n ? chunk_counts[(int64_t)sgn * nch + c] : 0ull;
+    const unsigned long long lo = (v & 0xffffull) | (((v >> 16) & 0xffffull) << 32);
+    const unsigned long long hi = ((v >> 32) & 0xffffull) | (((v >> 48) & 0xffffull) << 32);
+    unsigned long long ilo = lo, ihi = hi;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long a = __shfl_up(ilo, off, 64), d = __shfl_up(ihi, off, 64);
+      if (lane >= off) { ilo += a; ihi += d; }
+    }
+    const unsigned long long elo = clo + ilo - lo, ehi = chi + ihi - hi;
+    if (c < n)
+      bases[(int64_t)sgn * nch + c] = make_int4((int)(elo & 0xffffffffull), (int)(elo >> 32), (int)(ehi & 0xffffffffull),
+                                               (int)(ehi >> 32));
+    clo += __shfl(ilo, 63, 64);
+    chi += __shfl(ihi, 63, 64);
+  }
+  if (lane == 0) {
+    int* cnt = counts + u.cnt_off + b * 4;
+    cnt[0] = (int)(clo & 0xffffffffull); cnt[1] = (int)(clo >> 32);
+    cnt[2] = (int)(chi & 0xffffffffull); cnt[3] = (int)(chi >> 32);
+  }
+}
+
+// pass 2: the fine positions, in order
+__global__ __launch_bounds__(ET) void dio_edge_emit_kernel(const DioUtt* __restrict__ utts, int nch,
+                                                           const double* __restrict__ sig,
+                                                           const int4* __restrict__ bases,
+                                                           double* __restrict__ fine) {
+  constexpr int EW = ET / 64;
+  constexpr int SCAP = ECH / 4;            // edges of one type staged per chunk (more: computed in place)
+  __shared__ unsigned long long wpk[ER][EW];
+  __shared__ double2 stage_ac[4][SCAP];    // (a, c) of the chunk's edges, compacted, per type
+  __shared__ int stage_e[4][SCAP];
+  const int b = blockIdx.y, nb = gridDim.y;
+  const DioUtt u = utts[blockIdx.z];
+  const int yl = u.xl + 1;
+  const int i0 = blockIdx.x * ECH;
+  if (i0 >= yl - 1) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int4 b4 = bases[((int64_t)blockIdx.z * nb + b) * nch + blockIdx.x];     // in flight with the samples
+  EdgeRow e;
+  edge_rows(sig + u.sig_off + (int64_t)b * yl, yl, i0, e);
+  const int base[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+  for (int r = 0; r < ER; ++r)
+    if (lane == 0) wpk[r][wv] = e.pk[r];
+  __syncthreads();
+  // The interpolation e - a / (c - a) is NOT evaluated where the edge was found (an fp64 division in
+  // sixteen branches that nearly every wave enters for a handful of lanes): the chunk's edges are
+  // compacted into LDS and divided by dense lanes afterwards.
+  unsigned long long run = 0;          // edges of the chunk's rows before r, four 16-bit fields
+  int sl[ER][4];
+#pragma unroll
+  for (int r = 0; r < ER; ++r) {
+    const unsigned long long* w = wpk[r];
+    unsigned long long off = run, tot = 0;
+#pragma unroll
+    for (int q = 0; q < EW; ++q) {
+      const unsigned long long v = w[q];
+      off += q < wv ? v : 0ull;
+      tot += v;
+    }
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) sl[r][ty] = (int)((off >> (16 * ty)) & 0xffffull) + e.before[r][ty];
+    run += tot;
+  }
+  double* out0 = fine + u.fine_off + (int64_t)(b * 4) * u.cap;
+  int trip[4];
+#pragma unroll
+  for (int ty = 0; ty < 4; ++ty) {
+    trip[ty] = (int)((run >> (16 * ty)) & 0xffffull);
+#pragma unroll
+    for (int r = 0; r < ER; ++r) {
+      if (e.edge[r][ty]) {
+        const double av = (ty & 1) ? -e.a[r][ty >> 1] : e.a[r][ty >> 1];
+        const double cv = (ty & 1) ? -e.c[r][ty >> 1] : e.c[r][ty >> 1];
+        const int ei = i0 + r * ET + (int)threadIdx.x + 1;
+        const int sp = sl[r][ty];                     // position among this chunk's edges of the type
+        if (sp < SCAP) {
+          stage_ac[ty][sp] = make_double2(av, cv);
+          stage_e[ty][sp] = ei;
+        } else if (base[ty] + sp < u.cap) {           // beyond the staging area: in place
+          out0[(int64_t)ty * u.cap + base[ty] + sp] = (double)ei - av / (cv - av);
         }
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
 #pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
-      const int nst = trip[ty] < SCAP ? trip[ty] : SCAP;
-      if ((int)threadIdx.x < nst && base[ty] + (int)threadIdx.x < u.cap) {
-        const double2 ac = stage_ac[ty][threadIdx.x];
-        out0[(int64_t)ty * u.cap + base[ty] + threadIdx.x] = (double)stage_e[ty][threadIdx.x] - ac.x / (ac.y - ac.x);
-      }
-      base[ty] += trip[ty];
+  for (int ty = 0; ty < 4; ++ty) {
+    const int nst = trip[ty] < SCAP ? trip[ty] : SCAP;
+    if ((int)threadIdx.x < nst && base[ty] + (int)threadIdx.x < u.cap) {
+      const double2 ac = stage_ac[ty][threadIdx.x];
+      out0[(int64_t)ty * u.cap + base[ty] + threadIdx.x] = (double)stage_e[ty][threadIdx.x] - ac.x / (ac.y - ac.x);
     }
   }
-  if (threadIdx.x < 4) counts[u.cnt_off + b * 4 + threadIdx.x] = base[threadIdx.x];
 }
 
 // ---- per (band, frame) candidate and score ----------------------------------------------------------
@@ -617,8 +693,21 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
                          d_utts, d_lpf, d_lpf_off, p, d_ylc, d_sig);
       ITTS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(dio_events_kernel, dim3(p.nb, U), dim3(ET), 0, s, d_utts, p, d_sig, d_fine, d_cnt);
-    ITTS_LAUNCH_CHECK();
+    {
+      const int nch = (max_yl - 1 + ECH - 1) / ECH;        // chunks of the longest signal
+      unsigned long long* d_cc = nullptr;
+      ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cc, (size_t)U * p.nb * nch * sizeof(unsigned long long), s));
+      int4* d_bases = nullptr;
+      ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_bases, (size_t)U * p.nb * nch * sizeof(int4), s));
+      hipLaunchKernelGGL(dio_edge_count_kernel, dim3(nch, p.nb, U), dim3(ET), 0, s, d_utts, nch, d_sig, d_cc);
+      ITTS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(dio_edge_scan_kernel, dim3(U * p.nb), dim3(64), 0, s, d_utts, p.nb, nch, d_cc, d_bases, d_cnt);
+      ITTS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(dio_edge_emit_kernel, dim3(nch, p.nb, U), dim3(ET), 0, s, d_utts, nch, d_sig, d_bases, d_fine);
+      ITTS_LAUNCH_CHECK();
+      ITTS_HIP_CHECK(itts::scratch_free(d_cc, s));
+      ITTS_HIP_CHECK(itts::scratch_free(d_bases, s));
+    }
     hipLaunchKernelGGL(dio_candidates_kernel, dim3((max_T + NT - 1) / NT, p.nb, U), dim3(NT), 0, s, d_utts,
                        p, d_fine, d_cnt, d_cand, d_score);
     ITTS_LAUNCH_CHECK();

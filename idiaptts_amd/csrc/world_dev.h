@@ -289,6 +289,21 @@ __device__ __forceinline__ double bsum(double v, double* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Two block-wide sums behind one pair of barriers (each with bsum's order of additions: same bits).
+// red: >= 8 doubles of LDS.
+__device__ __forceinline__ void bsum2(double& a, double& b, double* red) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();
+  if ((tid() & 63) == 0) {
+    red[tid() >> 6] = a;
+    red[4 + (tid() >> 6)] = b;
+  }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
 // In-place inclusive prefix sum of a[0..n) in LDS. red: >= NT+8 doubles. Ends with a barrier.
 __device__ inline void block_scan(double* a, int n, double* red) {
   const int chunk = (n + NT - 1) / NT;

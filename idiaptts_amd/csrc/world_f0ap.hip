@@ -362,8 +362,7 @@ __device__ inline void windowed_to(const double* __restrict__ x, int64_t xl, int
       sw += W.w[j];
     }
   }
-  swf = bsum(swf, red);
-  sw = bsum(sw, red);
+  bsum2(swf, sw, red);
   const double mean = swf / sw;
   double pw = 0.0;
 #pragma unroll
@@ -477,8 +476,7 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
           if (k <= b1) s1 += ps;
         }
       }
-      s1 = bsum(s1, L.red);
-      s2 = bsum(s2, L.red);
+      bsum2(s1, s2, L.red);
       voiced = (s1 / s2) > a.threshold;
       __syncthreads();
     }

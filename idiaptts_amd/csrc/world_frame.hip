@@ -84,8 +84,7 @@ __device__ inline void cheaptrick_frame(const double* __restrict__ x, int64_t xl
     }
     zr[i] = v;
   }
-  swf = bsum(swf, L.red);
-  sw = bsum(sw, L.red);
+  bsum2(swf, sw, L.red);
   const double mean = swf / sw;
   for (int i = threadIdx.x; i < n; i += NT) zr[i] -= win[i] * mean;
   __syncthreads();
