@@ -460,8 +460,8 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         "what_binds_it": "fp64 VALU issue and LDS latency, not HBM: see issue_fractions (share of the chip's VALU "
                          "issue slots / LDS cycles in use, share of a wave's life spent waiting; SQ counters, "
                          "profiles/r4_world_pmc_fractions.json)",
-        "issue_fractions": {k: committed_fractions(k) for k in ("mcls_solve_wave", "d4c_kernel", "cheaptrick",
-                                                                 "mcls_spec", "gemm_f64_lds")} if fs <= 24000 else None,
+        "issue_fractions": {k: committed_fractions(k) for k in ("mcls_solve_wave", "d4c_kernel", "cheaptrick_wave",
+                                                                 "gemm_f64_kernel<true, true", "gemm_f64_lds")} if fs <= 24000 else None,
         "algorithmic_bytes_per_frame": fs // 200 * 8 + (61 + nap) * 4,
         "fp64_tflops": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks,
         "fp64_frac_of_peak": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS,
@@ -471,7 +471,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         "achieved": w["synthesis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
         "frac": w["synthesis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS,
         "traffic": committed_traffic("synthesis_%d" % fs) if n_utts == (256 if fs <= 24000 else 64) else None,
-        "issue_fractions": {k: committed_fractions(k) for k in ("syn_pulse", "mgc2sp")} if fs <= 24000 else None,
+        "issue_fractions": {k: committed_fractions(k) for k in ("syn_pulse_wave", "gemm_f64_kernel<true, false, true")} if fs <= 24000 else None,
         "algorithmic_bytes_per_frame": (n_fft // 2 + 1) * 16 + 8 + fs // 200 * 4,
         "fp64_tflops": frames * sy_flops / (ms_sy * 1e-3) / 1e12 / n_ranks,
         "fp64_frac_of_peak": frames * sy_flops / (ms_sy * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS}
