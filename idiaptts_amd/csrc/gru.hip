@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruArgs a) {
         const float rg = sigmoid_acc(g0 + proj(u) + bh0);
         const float zg = sigmoid_acc(g1 + proj(4 + u) + bh1);
         const float hnp = proj(8 + u) + bh2;
-        const float ng = tanhf(g2 + rg * hnp);
+        const float ng = tanh_cell(g2 + rg * hnp);
         hn = (1.f - zg) * ng + zg * hp_v;
         const size_t oh = r * (size_t)(a.ndir * H) + (size_t)dir * H + j;
         a.y[oh] = hn;

@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmArgs a) {
           return (P[qq][0][bl][n] + P[qq][1][bl][n]) + (P[qq][2][bl][n] + P[qq][3][bl][n]);
         };
         const float ig = sigmoid_acc(gate(u) + g0), fg = sigmoid_acc(gate(4 + u) + g1),
-                    gg = tanhf(gate(8 + u) + g2), og = sigmoid_acc(gate(12 + u) + g3);
+                    gg = tanh_cell(gate(8 + u) + g2), og = sigmoid_acc(gate(12 + u) + g3);
         cn = fg * cp_v + ig * gg;
-        hn = og * tanhf(cn);
+        hn = og * tanh_cell(cn);
         a.y[r * (size_t)(a.ndir * H) + (size_t)dir * H + j] = hn;
         if (a.gates) {
           reinterpret_cast<float4*>(a.gates)[(r * a.ndir + dir) * H + j] = make_float4(ig, fg, gg, og);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(LstmArgs a) {
     if (act) {
       float dhr = 0.f;
       for (int w = 0; w < a.ksplit; ++w) dhr += P[w][bl][n];
-      const float tc = tanhf(ct);
+      const float tc = tanh_cell(ct);
       const float dh = dyv + dhr;
       const float dcv = dh * og * (1.f - tc * tc) + dcin;
       const float d0 = dcv * gg * ig * (1.f - ig), d1 = dcv * cp * fg * (1.f - fg),

@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
                (Pp[((2 * 4 + gg) * 16 + r) * 17 + u] + Pp[((3 * 4 + gg) * 16 + r) * 17 + u]);
       };
       if (G == 4) {
-        const float ig = sigmoid_acc(pre(0) + g0), fg = sigmoid_acc(pre(1) + g1), gg_ = tanhf(pre(2) + g2),
+        const float ig = sigmoid_acc(pre(0) + g0), fg = sigmoid_acc(pre(1) + g1), gg_ = tanh_cell(pre(2) + g2),
                     og = sigmoid_acc(pre(3) + g3);
         c = fg * c + ig * gg_;
-        h = og * tanhf(c);
+        h = og * tanh_cell(c);
         a.y[row * ldh + (size_t)dir * H + j] = h;
         if (a.gates) {
           reinterpret_cast<float4*>(a.gates)[(row * a.ndir + dir) * H + j] = make_float4(ig, fg, gg_, og);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
         // backward as (r, z, n, W_hn h + b_hn)
         const float rg = sigmoid_acc(g0 + pre(0) + bh0), zg = sigmoid_acc(g1 + pre(1) + bh1);
         const float hnp = pre(2) + bh2;
-        const float ng = tanhf(g2 + rg * hnp);
+        const float ng = tanh_cell(g2 + rg * hnp);
         h = (1.f - zg) * ng + zg * h;
         a.y[row * ldh + (size_t)dir * H + j] = h;
         if (a.gates) reinterpret_cast<float4*>(a.gates)[(row * a.ndir + dir) * H + j] = make_float4(rg, zg, ng, hnp);
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
         dhr = (Pp[(0 * 16 + r) * 17 + u] + Pp[(1 * 16 + r) * 17 + u]) + (Pp[(2 * 16 + r) * 17 + u] + Pp[(3 * 16 + r) * 17 + u]);
       if (G == 4) {
         const float ig = X.g.x, fg = X.g.y, gg = X.g.z, og = X.g.w;
-        const float tc = tanhf(X.v1);
+        const float tc = tanh_cell(X.v1);
         const float dh = X.dy + dhr;
         const float dcv = dh * og * (1.f - tc * tc) + carry;
         d[0] = dcv * gg * ig * (1.f - ig); d[1] = dcv * X.v2 * fg * (1.f - fg);
