@@ -672,7 +672,7 @@ __device__ __forceinline__ void min_phase_wave(double (&v)[9], const wf::Plan512
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     const double zr = q < 8 ? z[q].x : wave_bcast0(x512.x), zi = q < 8 ? z[q].y : wave_bcast0(x512.y);
-    const double t = exp(zr / fft);
+    const double t = fm::fexp(zr / fft);      // (the log amplitude of a spectrum: within +-373)
     double sn, cs;
     // The short reduction of fastmath.h directly: sincos_mid's out-of-line fallback for |x| > 1e5 is a CALL,
     // and one call in the kernel costs its whole register allocation (75 -> 19 spilled registers

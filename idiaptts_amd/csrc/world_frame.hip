@@ -468,11 +468,11 @@ __global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs 
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) {
       const int k = 2 * (l + 64 * q);
-      out[k] = exp(z[q].x);
-      out[k + 1] = exp(z[q].y);
+      out[k] = fm::fexp(z[q].x);
+      out[k + 1] = fm::fexp(z[q].y);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (l == 0) out[H] = exp(z[R / 2].x);
+    if (l == 0) out[H] = fm::fexp(z[R / 2].x);
   }
 }
 
