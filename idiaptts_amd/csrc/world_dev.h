@@ -242,6 +242,133 @@ __device__ inline void rfft_lds(double2* z, int n, int logn, const double2* tw, 
   __syncthreads();
 }
 
+// TWO transforms of the same size in lockstep (arrays z0, z1): one set of barriers, index arithmetic and
+// twiddle loads serves both -- the workgroup transforms are bound by exactly those (61 %
+// of the instructions).  Per array the butterflies, twiddle entries and order of operations are those of
+// fft_lds: the results are bit-identical.  64 <= n <= FFT_SWZ_MAX (the swizzled path only).
+__device__ inline void fft_lds_pair(double2* z0, double2* z1, int n, int logn, const double2* tw, int tw_n, int sign) {
+  double2* zz[2] = {z0, z1};
+  const int tshift = ilog2(tw_n) - 1;
+  auto twmul = [&](const double2 v, const double2 w) {
+    const double wi = sign < 0 ? -w.y : w.y;
+    return make_double2(v.x * w.x - v.y * wi, v.x * wi + v.y * w.x);
+  };
+  {
+    const int u = tid();
+    const bool on = u < n / 4;
+    double2 q0[2], q1[2], q2[2], q3[2];
+    if (on) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        q0[a] = zz[a][u];
+        q1[a] = zz[a][u + n / 2];
+        q2[a] = zz[a][u + n / 4];
+        q3[a] = zz[a][u + n / 2 + n / 4];
+      }
+    }
+    __syncthreads();
+    if (on) {
+      const int a0 = 4 * (int)(__brev((unsigned)u) >> (32 - (logn - 2)));
+      const double2 w1 = tw[0];
+      const double2 w2 = tw[0];
+      const double2 w3 = tw[1 << (tshift - 1)];
+      const int p0 = fft_phys(a0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double2 x1 = twmul(q1[a], w1), x3 = twmul(q3[a], w1);
+        const double2 y0 = make_double2(q0[a].x + x1.x, q0[a].y + x1.y), y1 = make_double2(q0[a].x - x1.x, q0[a].y - x1.y);
+        const double2 y2 = make_double2(q2[a].x + x3.x, q2[a].y + x3.y), y3 = make_double2(q2[a].x - x3.x, q2[a].y - x3.y);
+        const double2 u2 = twmul(y2, w2), u3 = twmul(y3, w3);
+        zz[a][p0] = make_double2(y0.x + u2.x, y0.y + u2.y);
+        zz[a][p0 ^ 2] = make_double2(y0.x - u2.x, y0.y - u2.y);
+        zz[a][p0 ^ 1] = make_double2(y1.x + u3.x, y1.y + u3.y);
+        zz[a][p0 ^ 3] = make_double2(y1.x - u3.x, y1.y - u3.y);
+      }
+    }
+    __syncthreads();
+  }
+  int s = 3;
+  for (; s + 1 <= logn; s += 2) {
+    const int h = 1 << (s - 1);
+    const bool last = s + 1 == logn;
+    const int c1 = fft_phys(h), c2 = fft_phys(2 * h);
+    for (int t = tid(); t < n / 4; t += NT) {
+      const int r = t & (h - 1);
+      const int a0 = ((t >> (s - 1)) << (s + 1)) + r;
+      const int a1 = a0 + h, a2 = a0 + 2 * h, a3 = a0 + 3 * h;
+      const double2 w1 = tw[r << (tshift - (s - 1))];
+      const double2 w2 = tw[r << (tshift - s)];
+      const double2 w3 = tw[(r + h) << (tshift - s)];
+      const int p0 = fft_phys(a0), p1 = p0 ^ c1, p2 = p0 ^ c2, p3 = p1 ^ c2;
+      const int o0 = last ? a0 : p0, o1 = last ? a1 : p1, o2 = last ? a2 : p2, o3 = last ? a3 : p3;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double2 q0 = zz[a][p0], q1 = zz[a][p1], q2 = zz[a][p2], q3 = zz[a][p3];
+        const double2 x1 = twmul(q1, w1), x3 = twmul(q3, w1);
+        const double2 y0 = make_double2(q0.x + x1.x, q0.y + x1.y), y1 = make_double2(q0.x - x1.x, q0.y - x1.y);
+        const double2 y2 = make_double2(q2.x + x3.x, q2.y + x3.y), y3 = make_double2(q2.x - x3.x, q2.y - x3.y);
+        const double2 u2 = twmul(y2, w2), u3 = twmul(y3, w3);
+        zz[a][o0] = make_double2(y0.x + u2.x, y0.y + u2.y);
+        zz[a][o2] = make_double2(y0.x - u2.x, y0.y - u2.y);
+        zz[a][o1] = make_double2(y1.x + u3.x, y1.y + u3.y);
+        zz[a][o3] = make_double2(y1.x - u3.x, y1.y - u3.y);
+      }
+    }
+    __syncthreads();
+  }
+  for (; s <= logn; ++s) {   // odd log2(n): one plain radix-2 stage is left (always the last pass)
+    const int h = 1 << (s - 1);
+    for (int t = tid(); t < n / 2; t += NT) {
+      const int r = t & (h - 1);
+      const int ia = ((t >> (s - 1)) << s) + r;
+      const int ib = ia + h;
+      const int pa = fft_phys(ia), pb = pa ^ fft_phys(h);
+      const double2 w = tw[r << (tshift - (s - 1))];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double2 x = twmul(zz[a][pb], w);
+        const double2 za = zz[a][pa];
+        zz[a][ib] = make_double2(za.x - x.x, za.y - x.y);
+        zz[a][ia] = make_double2(za.x + x.x, za.y + x.y);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Two real transforms in lockstep (see rfft_lds): z0 / z1 hold n real samples each on entry, X[0 .. n/2] on return.
+__device__ inline void rfft_lds_pair(double2* z0, double2* z1, int n, int logn, const double2* tw, int tw_n) {
+  const int h = n / 2;
+  fft_lds_pair(z0, z1, h, logn - 1, tw, tw_n, -1);
+  double2* zz[2] = {z0, z1};
+  const int tstride = tw_n / n;
+  for (int k = tid(); k <= h / 2; k += NT) {
+    if (k == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double2 q0 = zz[a][0];
+        zz[a][0] = make_double2(q0.x + q0.y, 0.0);
+        zz[a][h] = make_double2(q0.x - q0.y, 0.0);
+      }
+    } else {
+      const int j = h - k;
+      const double2 w = tw[k * tstride];
+      const double wr = w.x, wi = -w.y;  // w^k = e^{-2 pi i k / n}
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double2 zk = zz[a][k], zj = zz[a][j];
+        const double er = 0.5 * (zk.x + zj.x), ei = 0.5 * (zk.y - zj.y);
+        const double dr = 0.5 * (zk.x - zj.x), di = 0.5 * (zk.y + zj.y);
+        const double orr = di, oi = -dr;  // O = -i D
+        const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
+        zz[a][k] = make_double2(er + tr, ei + ti);
+        zz[a][j] = make_double2(er - tr, -(ei - ti));
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // Inverse real FFT: z[k] = X[k], k = 0..n/2 (imag of X[0], X[n/2] ignored) -> z viewed as n real
 // samples, normalised like numpy.fft.irfft.
 template <bool SWZ = true>

@@ -346,7 +346,8 @@ __device__ __forceinline__ void win_make(Win<PER>& W, int fs, double f0, int bla
 // values.  normalise: divide by sqrt(sum of squares) (D4C centroid).  `ramp`: multiply sample i by (i+1).
 template <int PER>
 __device__ inline void windowed_to(const double* __restrict__ x, int64_t xl, int fs, double pos, const Win<PER>& W,
-                                   double* zr, int pad, bool normalise, bool ramp, double* red, double (&v)[PER]) {
+                                   double* zr, int pad, bool normalise, bool ramp, double* red, double (&v)[PER],
+                                   double* zr_ramped = nullptr) {
   const int half = W.half, n = W.n;
   const int64_t c = mround(pos * fs + 0.001);
   double swf = 0.0, sw = 0.0;
@@ -385,9 +386,15 @@ __device__ inline void windowed_to(const double* __restrict__ x, int64_t xl, int
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int i = (int)threadIdx.x + j * NT;
-    if (i < pad) zr[i] = (ramp && i < n) ? v[j] * (i + 1.0) : v[j];
+    if (i < pad) {
+      zr[i] = (ramp && i < n) ? v[j] * (i + 1.0) : v[j];
+      if (zr_ramped) zr_ramped[i] = i < n ? v[j] * (i + 1.0) : v[j];      // what ramped_to would write
+    }
   }
-  for (int i = (int)threadIdx.x + PER * NT; i < pad; i += NT) zr[i] = 0.0;
+  for (int i = (int)threadIdx.x + PER * NT; i < pad; i += NT) {
+    zr[i] = 0.0;
+    if (zr_ramped) zr_ramped[i] = 0.0;
+  }
   __syncthreads();
 }
 
@@ -497,6 +504,20 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
     win_make(W, fs, f0, 1, 4.0);               // one Blackman window serves all four centroid transforms
     for (int side = 0; side < 2; ++side) {
       const double cpos = side == 0 ? pos - 0.25 / f0 : pos + 0.25 / f0;
+      if (!AREG && h <= FFT_SWZ_MAX) {
+        // the segment and its ramped copy transformed in LOCKSTEP (the ramped one in B / C's storage,
+        // which only held the first spectrum until it was multiplied in): one set of barriers, index
+        // arithmetic and twiddle loads for two transforms; same values bit for bit
+        double2* z2 = reinterpret_cast<double2*>(L.B);
+        windowed_to(x, xl, fs, cpos, W, zr, fft + 2, true, false, L.red, seg, reinterpret_cast<double*>(z2));
+        rfft_lds_pair(L.z, z2, fft, logfft, L.tw, fmax);
+        for (int k = threadIdx.x; k <= h; k += NT) {
+          const double v = z2[k].x * L.z[k].x + L.z[k].y * z2[k].y;
+          L.A[k] = side == 0 ? v : L.A[k] + v;
+        }
+        __syncthreads();
+        continue;
+      }
       windowed_to(x, xl, fs, cpos, W, zr, fft + 2, true, false, L.red, seg);
       rfft();
       for (int k = threadIdx.x; k <= h; k += NT) {
