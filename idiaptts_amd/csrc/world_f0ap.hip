@@ -336,8 +336,10 @@ __device__ __forceinline__ void win_make(Win<PER>& W, int fs, double f0, int bla
     const double p = (2.0 * b / ratio) / fs;
     double w = 0.0;
     if (i < W.n)
-      w = blackman ? 0.42 + 0.5 * cos_mid(kPi * p * f0) + 0.08 * cos_mid(kPi * p * f0 * 2)
-                   : 0.5 * cos_mid(kPi * p * f0) + 0.5;
+      // (|pi p f0| <= pi inside the window: the short cosine of fastmath.h directly -- cos_mid's out-of-line
+      // fallback for |x| > 1e5 is a call this kernel never takes)
+      w = blackman ? 0.42 + 0.5 * fm::fcos(kPi * p * f0) + 0.08 * fm::fcos(kPi * p * f0 * 2)
+                   : 0.5 * fm::fcos(kPi * p * f0) + 0.5;
     W.w[j] = w;
   }
 }
