@@ -21,6 +21,7 @@ struct FreqtTables {
   // warping matrices (round 4; the loop lost its two FFTs per frame and iteration):
   double* specT = nullptr; // [m+1][f2+1]   S[k]   = sum_j specT[j][k] * mc[j]    = Re rfft(freqt(mc, -a))[k]
   double* crT = nullptr;   // [f2+1][2m+1]  cr[j]  = sum_k crT[k][j] * d[k]       = frqtr(irfft(d))[j], d real
+  double* initT = nullptr; // [f2+1][m+1]   mc0[j] = sum_k initT[k][j] * lg[k]    = freqt(c, +a), c = irfft(lg) with c[0], c[f2] halved
   // SPTK mgcep's own transform b2c (freqt without the `+ a d[0]` in the zeroth term):
   double* b1T = nullptr;   // [m+1][f2+1]   c[i]   = sum_j b1T[j][i] * b[j]      b2c(b, m -> f2, -a)
   double* p2T = nullptr;   // [f2+1][2m+1]  p~[j]  = sum_i p2T[i][j] * p[i]      b2c(p, f2 -> 2m, +a)

@@ -475,6 +475,21 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
       for (int j = 0; j <= m2; ++j) crt[(size_t)k * (m2 + 1) + j] = (double)(accj[j] * wk / nfft);
     }
     if (upload(crt, &t.crT) != ITTS_OK) return nullptr;
+    // initT = (H Ci)^T . fwd, H = diag(1/2, 1, ..., 1, 1/2): the initial mel-cepstrum from the log periodogram
+    // (mcep.c: c = ifft(log x); c[0] /= 2; c[f2] /= 2; mc = freqt(c, +alpha))
+    std::vector<double> ini((size_t)(f2 + 1) * (m + 1));
+    std::vector<long double> accm(m + 1);
+    for (int k = 0; k <= f2; ++k) {
+      const long double wk = (k == 0 || k == f2) ? 1.0L : 2.0L;
+      std::fill(accm.begin(), accm.end(), 0.0L);
+      for (int n = 0; n <= f2; ++n) {
+        const long double c = cs[(size_t)((int64_t)k * n % nfft)] * ((n == 0 || n == f2) ? 0.5L : 1.0L);
+        const double* fw = fwd.data() + (size_t)n * (m + 1);
+        for (int j = 0; j <= m; ++j) accm[j] += c * (long double)fw[j];
+      }
+      for (int j = 0; j <= m; ++j) ini[(size_t)k * (m + 1) + j] = (double)(accm[j] * wk / nfft);
+    }
+    if (upload(ini, &t.initT) != ITTS_OK) return nullptr;
   }
   if ((need_spec || need_fwd_frq) && !t.specT) {
     // specT = inv . C with C[n][k] = cos(2 pi k n / 2 f2): the real part of the one-sided transform of

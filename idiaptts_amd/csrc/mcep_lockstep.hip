@@ -1,23 +1,23 @@
 // SPTK mcep (pysptk.mcep, AudioProcessing.py:146-152) in LOCKSTEP over all frames of a batch.
 //
-// The per-frame kernel (world_frame.hip: mcep_frame) re-reads the three frequency-warping
-// matrices (735 KB at order 59) from L2 for every frame and Newton iteration and was bound by
-// exactly that traffic (4.3 TB/s aggregate, 118 us per iteration and workgroup).  The warping
-// steps are linear maps, so over a batch they are matrix products with T rows:
-//     mc   = C  [T x 513] . Fwd [513 x 60]          once
-//     c'   = MC [T x 60 ] . Inv [60 x 513]          per iteration
-//     cr   = R  [T x 513] . Frq [513 x 119]         per iteration
-// evaluated here with fp64 MFMA (v_mfma_f64_16x16x4_f64; GEMM-shaped fp64 work is what the
-// matrix core is for), while the per-frame pieces (2 real FFTs + exp, convergence test, the
-// 60x60 Toeplitz-plus-Hankel solve) stay one workgroup per frame.  All frames advance one Newton
-// step per round; converged frames are frozen by a flag and skipped by the per-frame kernels.
-// The arithmetic per frame is the same as in mcep_frame up to summation order (<= 1e-15 rel.).
+// The reference's Newton iteration per frame: c' = freqt(mc, -a), FFT, d = x / exp(2 Re C'), inverse FFT,
+// cr = frqtr(r, +a), a 60 x 60 Toeplitz-plus-Hankel solve; initial value mc = freqt(ifft(log x), +a).
+// Everything but the ratio and the solve is LINEAR, so over a batch of T frames it is three matrix
+// products on the fp64 matrix core (v_mfma_f64_16x16x4_f64), the transforms folded into the warping
+// matrices (FreqtTables in context.h):
+//     mc0 = LG [T x 513] . initT [513 x 60]                      once      (LG = log periodogram)
+//     d   = X / exp(2 MC [T x 60] . specT [60 x 513])            per iteration, ratio in the epilogue
+//     cr  = D  [T x 513] . crT  [513 x 119]                      per iteration
+// with the solve one WAVE per frame (mcls_solve_wave_kernel).  All frames advance one Newton step per
+// round; converged frames are frozen by a flag and dropped from the work list.  History: round 1 ran
+// one workgroup per frame (bound by re-reading 735 KB of warping matrices per frame and iteration),
+// round 2 made the warping steps products, rounds 2-4 kept two transforms per frame and iteration in a
+// kernel of their own (7.7 ms per analysis, 3.4 ms on wave_fft.h) until round 4 folded them away.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
 
 #include "context.h"
-#include "wave_fft.h"
 #include "world_dev.h"
 
 namespace itts {
@@ -506,88 +506,37 @@ struct LsArgs {
   int64_t ldk;           // row pitch of xp / cbuf (K rounded up to even: 16-byte aligned rows)
   const int* rows;       // frames still iterating (NULL: all T)
   int64_t n_rows;
-  const double2* g_tw;
-  const double2* g_tw_compact;   // DeviceContext::tw_compact of the transform size
 };
 
-// x = amp^2 + eps; c = irfft(log x), c[0] /= 2, c[f2] /= 2
-__global__ __launch_bounds__(NT) void mcls_init_kernel(LsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+
+// Periodogram and its logarithm of every frame, one wave per frame: xp = |X|^2 + eps (kept for the loop),
+// lg = log xp into cbuf (the initial mel-cepstrum is lg x initT: FreqtTables), and the loop's first
+// reference value c[0] / 2 = mean log periodogram / 2 (c = irfft(lg): c[0] = (lg[0] + lg[f2] + 2 sum lg[k]) / flng)
+__global__ __launch_bounds__(256) void mcls_init_flat_kernel(LsArgs a) {
+  const int lane = threadIdx.x & 63;
   const int f2 = a.flng / 2, K = f2 + 1;
-  double2* tw = reinterpret_cast<double2*>(smem);
-  double2* z = tw + f2;
-  double* zr = reinterpret_cast<double*>(z);
-  const int64_t g = blockIdx.x;
-  load_twiddles(tw, a.g_tw, a.flng);
-  for (int k = threadIdx.x; k < K; k += NT) {
-    double v = a.in[g * K + k];
-    if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
-    const double x = v * v + a.eps;
-    a.xp[g * a.ldk + k] = x;
-    z[k] = make_double2(wd::log_pos(x), 0.0);
-  }
-  __syncthreads();
-  irfft_lds(z, a.flng, a.logflng, tw, a.flng);
-  for (int k = threadIdx.x; k < K; k += NT) {
-    double v = zr[k];
-    if (k == 0 || k == f2) v /= 2;
-    a.cbuf[g * a.ldk + k] = v;
-  }
-  if (threadIdx.x == 0) {
-    a.sprev[g] = zr[0] / 2;
-    a.done[g] = 0;
-    a.iters[g] = 0;
-  }
-}
-
-
-// ---- the same two kernels with one WAVE per frame (flng = 1024 or 2048) ---------------------------------
-// wave_fft.h: the 513 bins of a frame live eight per lane in registers, the transforms need no
-// workgroup barrier; one persistent workgroup per CU.  Same butterflies, same
-// twiddles, same per-bin arithmetic as the workgroup-per-frame kernels above: results bit-identical.
-__device__ __forceinline__ double ls_bcast0(double v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v));
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
-  return __hiloint2double((int)hi, (int)lo);
-}
-
-// threads per workgroup of the wave kernels: one workgroup per CU, one twiddle table per workgroup, as many
-// frames in flight as the LDS holds exchange buffers (sixteen at 1024 points, eight at 2048)
-template <int R> constexpr int lsw() { return R == 8 ? 1024 : 512; }
-
-template <int R>
-__global__ __launch_bounds__(lsw<R>()) void mcls_init_wave_kernel(LsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int f2 = 64 * R, K = f2 + 1, NW = lsw<R>() / 64;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = wf::lane_id();
-  typename wf::PlanOf<R>::type P;
-  wf::table_init<R>(smem, a.g_tw_compact);
-  wf::plan_init(P, a.g_tw_compact, smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>(), smem);
-  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < a.T; g += (int64_t)gridDim.x * NW) {
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < a.T; g += nw) {
     const double* in = a.in + g * K;
     double* xp = a.xp + g * a.ldk;
-    double2 z[R], xh;
-#pragma unroll
-    for (int q = 0; q <= R; ++q) {
-      const int k = q < R ? l + 64 * q : f2;
+    double* lg = a.cbuf + g * a.ldk;
+    double acc = 0.0;
+    for (int k = lane; k < K; k += 64) {
       double v = in[k];
       if (a.in_is_power) v = sqrt(v);  // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
       const double x = v * v + a.eps;
-      if (q < R || l == 0) xp[k] = x;
-      const double2 r = make_double2(wd::log_pos(x), 0.0);
-      if (q < R) z[q < R ? q : 0] = r; else xh = r;
+      const double l = wd::log_pos(x);
+      xp[k] = x;
+      lg[k] = l;
+      acc += (k == 0 || k == f2) ? l : 2.0 * l;
     }
-    wf::irfft<R>(z, xh, P);          // z[q] = (c[2m], c[2m+1]), m = lane + 64 q
-    double* row = a.cbuf + g * a.ldk;
-    if (l == 0) {
-      a.sprev[g] = z[0].x / 2;
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      a.sprev[g] = acc / (double)a.flng / 2;
       a.done[g] = 0;
       a.iters[g] = 0;
-      z[0].x /= 2;                       // c[0] /= 2, c[f2] /= 2
-      row[f2] = z[R / 2].x / 2;
     }
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) *reinterpret_cast<double2*>(row + 2 * (l + 64 * q)) = z[q];
   }
 }
 
@@ -920,37 +869,13 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   a.in = d_in; a.in_is_power = in_is_power; a.T = T; a.flng = flng; a.logflng = logflng; a.m = order;
   a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.xp = xp;
   a.cbuf = cbuf; a.mc = mc; a.cr = cr; a.sprev = sprev; a.done = done; a.iters = iters;
-  a.n_active = n_active; a.g_tw = ctx->twiddles; a.g_tw_compact = ctx->tw_compact[logflng]; a.ldk = Kp; a.rows = nullptr; a.n_rows = T;
-  const size_t lds_fft = (size_t)f2 * 16 + (size_t)(f2 + 1) * 16;
+  a.n_active = n_active; a.ldk = Kp; a.rows = nullptr; a.n_rows = T;
   const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
-  ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fft));
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
-  // 1024- and 2048-point transforms: one wave per frame, one persistent workgroup per CU
-  const int wave_r = flng == 1024 ? 8 : (flng == 2048 ? 16 : 0);
-  const bool wave = wave_r != 0;
-  const int wthreads = wave_r == 8 ? lsw<8>() : lsw<16>();
-  const size_t lds_wave = wave_r == 8 ? wf::table_bytes<8>() + (size_t)(lsw<8>() / 64) * wf::lds_bytes<8>()
-                                      : wf::table_bytes<16>() + (size_t)(lsw<16>() / 64) * wf::lds_bytes<16>();
-  int n_cu = 256;
-  if (wave) {
-    int dev = 0;
-    ITTS_HIP_CHECK(hipGetDevice(&dev));
-    ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    ITTS_HIP_CHECK(hipFuncSetAttribute(wave_r == 8 ? (const void*)mcls_init_wave_kernel<8>
-                                                   : (const void*)mcls_init_wave_kernel<16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
-  }
-  auto wave_grid = [&](int64_t frames) {
-    const int64_t per = wthreads / 64;
-    return dim3((unsigned)std::min<int64_t>((frames + per - 1) / per, (int64_t)n_cu));
-  };
-  if (wave_r == 8) hipLaunchKernelGGL(mcls_init_wave_kernel<8>, wave_grid(T), dim3(wthreads), lds_wave, s, a);
-  else if (wave_r == 16) hipLaunchKernelGGL(mcls_init_wave_kernel<16>, wave_grid(T), dim3(wthreads), lds_wave, s, a);
-  else hipLaunchKernelGGL(mcls_init_kernel, dim3((unsigned)T), dim3(NT), lds_fft, s, a);
+  hipLaunchKernelGGL(mcls_init_flat_kernel, dim3((unsigned)std::min<int64_t>((T + 3) / 4, 8192)), dim3(256), 0, s, a);
   ITTS_LAUNCH_CHECK();
-  int rc = launch_gemm_f64(cbuf, Kp, ft->fwdT, m1, mc, m1, T, m1, K, nullptr, s);
+  int rc = launch_gemm_f64(cbuf, Kp, ft->initT, m1, mc, m1, T, m1, K, nullptr, s);
   if (rc) return rc;
   for (int it = 1; it <= maxiter; ++it) {
     a.iter = it;
