@@ -567,7 +567,10 @@ __global__ void decode_aperiodicity_kernel(const double* __restrict__ bap, int64
   double v = 1.0 - kEps;
   if (!(mean > -0.5)) {  // WORLD codec.cpp CheckVUV: mean band aperiodicity > -0.5 dB => unvoiced
     const double f = (double)fs / fft_size * k;
-    v = pow(10.0, interp1_small(cfa, cap, nap + 2, f) / 20.0);
+    // 10^(y / 20), y in [-60, 0] dB, as exp(y ln 10 / 20) with fastmath.h's exp: the library's pow is
+    // ~150 instructions per bin, which made this pass (one value per bin, 1.3 GB out) VALU-bound at
+    // 0.69 ms; relative difference to pow below 2e-15
+    v = fm::fexp(interp1_small(cfa, cap, nap + 2, f) * (2.30258509299404568402 / 20.0));
   }
   ap[i] = v;
 }
