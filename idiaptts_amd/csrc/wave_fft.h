@@ -407,6 +407,30 @@ __device__ __forceinline__ void rfft(double2 (&z)[R], double2& xh, const Plan& p
   xh = make_double2(z0.x - z0.y, 0.0);
 }
 
+// pack_real for either size: a real sequence per spectral index in layout A (v[q] = x[lane + 64 q], vh = x[64 R])
+// -> packed z[m] = (x[2m], x[2m+1]) in layout A.  even: x[128 R - n] = x[n]; otherwise zero beyond 64 R.
+template <int R, class Plan>
+__device__ __forceinline__ void pack_real_r(const double (&v)[R], const double vh, double2 (&z)[R], const Plan& p,
+                                            const bool even) {
+  const int l = lane_id();
+  double* s = reinterpret_cast<double*>(p.x2r) - l * 2;      // the wave's buffer as doubles
+#pragma unroll
+  for (int q = 0; q < R; ++q) s[l + 64 * q] = v[q];
+  if (l == 0) { s[64 * R] = vh; s[64 * R + 1] = 0.0; }
+  wave_sync();
+  const double2* s2 = reinterpret_cast<const double2*>(s);
+#pragma unroll
+  for (int q = 0; q < R / 2; ++q) z[q] = s2[l + 64 * q];
+#pragma unroll
+  for (int q = R / 2; q < R; ++q) {
+    const int n = 128 * R - 2 * (l + 64 * q);
+    const double a = s[n], b = s[n - 1];
+    const bool first = q == R / 2 && l == 0;      // m = 32 R
+    z[q] = make_double2((even || first) ? a : 0.0, even ? b : 0.0);
+  }
+  wave_sync();
+}
+
 // Inverse: z[q] = X[lane + 64 q], xh = X[64 R] (read in lane 0) -> 128 R real samples packed in layout A.
 template <int R, class Plan>
 __device__ __forceinline__ void irfft(double2 (&z)[R], const double2 xh, const Plan& p) {

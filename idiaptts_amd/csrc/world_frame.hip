@@ -265,8 +265,9 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
 #define CTW_THREADS_N 512     // eight frames in flight per CU, 218 registers per lane (twelve at 168 spill 49 of them: 5.1 against 4.4 ms)
 #endif
 constexpr int CTW_THREADS = CTW_THREADS_N;
-constexpr int CTW_SCAN = 17;          // running-sum elements per lane: 64 * 17 = the 1088 doubles of the rows
-static_assert(wf::WF_LDS_BYTES / 8 == 64 * CTW_SCAN, "the smoothing's scratch is the wave's exchange rows");
+// running-sum elements per lane: the smoothing's scratch is the wave's exchange rows (64 * 17 = 1088 doubles at
+// 1024 points, 64 * 33 = 2112 at 2048)
+template <int R> constexpr int ctw_scan() { return wf::lds_bytes<R>() / 8 / 64; }
 
 __device__ __forceinline__ double ct_bcast0(double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -275,11 +276,12 @@ __device__ __forceinline__ double ct_bcast0(double v) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+template <int R>
 __global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs a, int64_t t_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = 8, FFT = 1024, H = 512, K = H + 1, NW = CTW_THREADS / 64;
+  constexpr int FFT = 128 * R, H = 64 * R, K = H + 1, NW = CTW_THREADS / 64, CTW_SCAN = ctw_scan<R>();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l0 = wf::lane_id();
-  wf::Plan512 P;
+  typename wf::PlanOf<R>::type P;
   wf::table_init<R>(smem, a.g_tw_compact);
   char* rows = smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>();
   wf::plan_init(P, a.g_tw_compact, rows, smem);
@@ -323,26 +325,30 @@ __global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs 
         __builtin_amdgcn_sched_barrier(0);
       }
       e = sqrt(wave_sum_at(e, l));
+      // the windowed samples are formed twice -- for the mean, then for the transform -- from the same
+      // loads and the same expressions (same bits): kept in registers between the passes they were the
+      // kernel's largest array
+      auto sample = [&](int j, double wn) -> double {
+        const int i = 2 * (l + 64 * (j >> 1)) + (j & 1);
+        int64_t idx = c + i - half;
+        idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+        double vj = x[idx] * wn;
+        const double nz = randn_of(rn[i]) * 1e-12;
+        vj = vj + nz;
+        return vj;
+      };
       double swf = 0.0, sw = 0.0;
-      double v[2 * R];
 #pragma unroll
       for (int j = 0; j < 2 * R; ++j) {
         const int i = 2 * (l + 64 * (j >> 1)) + (j & 1);
-        double vj = 0.0;
         if (128 * (j >> 1) < n) {
           if (i < n) {
             const double wn = S[l + 64 * j] / e;
             S[l + 64 * j] = wn;
-            int64_t idx = c + i - half;
-            idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
-            vj = x[idx] * wn;
-            const double nz = randn_of(rn[i]) * 1e-12;
-            vj = vj + nz;
-            swf += vj;
+            swf += sample(j, wn);
             sw += wn;
           }
         }
-        v[j] = vj;
       }
       swf = wave_sum_at(swf, l);
       sw = wave_sum_at(sw, l);
@@ -350,10 +356,16 @@ __global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs 
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         const int i = 2 * (l + 64 * q);
-        double a0 = v[2 * q], a1 = v[2 * q + 1];
+        double a0 = 0.0, a1 = 0.0;
         if (128 * q < n) {
-          if (i < n) a0 = a0 - S[l + 64 * (2 * q)] * mean;
-          if (i + 1 < n) a1 = a1 - S[l + 64 * (2 * q + 1)] * mean;
+          if (i < n) {
+            const double wn = S[l + 64 * (2 * q)];
+            a0 = sample(2 * q, wn) - wn * mean;
+          }
+          if (i + 1 < n) {
+            const double wn = S[l + 64 * (2 * q + 1)];
+            a1 = sample(2 * q + 1, wn) - wn * mean;
+          }
         }
         z[q] = make_double2(a0, a1);
       }
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs 
         if (q < R) lp[q < R ? q : 0] = v; else lp512 = v;
         __builtin_amdgcn_sched_barrier(0);
       }
-      wf::pack_real(lp, lp512, z, P, true);
+      wf::pack_real_r<R>(lp, lp512, z, P, true);
     }
     wf::rfft<R>(z, xh, P);
 #pragma unroll
@@ -657,16 +669,25 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   if (rc) return rc;
   a.rn = d_rn; a.rn_pos = d_rpos; a.rn_pitch = rn_pitch; a.t_total = t_total; a.far_only = 0;
   // the smoothing boundary of the wave kernel is bounded by its scratch: 513 + 2 b <= 1088 doubles
-  if (fft_size == 1024 && 513 + 2 * ((int)(1000.0 * 2.0 / 3.0 * fft_size / fs) + 1) <= 64 * CTW_SCAN) {
+  const int wave_r = fft_size == 1024 ? 8 : (fft_size == 2048 ? 16 : 0);
+  if (wave_r != 0 && fft_size / 2 + 1 + 2 * ((int)(1000.0 * 2.0 / 3.0 * fft_size / fs) + 1) <=
+                         64 * (wave_r == 8 ? ctw_scan<8>() : ctw_scan<16>())) {
     int dev = 0, n_cu = 256;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     constexpr int NW = CTW_THREADS / 64;
-    const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(cheaptrick_wave_kernel, dim3((unsigned)std::min<int64_t>((t_total + NW - 1) / NW, n_cu)),
-                       dim3(CTW_THREADS), lds, s, a, t_total);
+    const dim3 grid((unsigned)std::min<int64_t>((t_total + NW - 1) / NW, n_cu));
+    if (wave_r == 8) {
+      const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel<8>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(cheaptrick_wave_kernel<8>, grid, dim3(CTW_THREADS), lds, s, a, t_total);
+    } else {
+      const size_t lds = wf::table_bytes<16>() + (size_t)NW * wf::lds_bytes<16>();
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel<16>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(cheaptrick_wave_kernel<16>, grid, dim3(CTW_THREADS), lds, s, a, t_total);
+    }
     ITTS_LAUNCH_CHECK();
     a.far_only = 1;     // frames with an F0 at or beyond fs / 2: a pass that reads the F0 values and normally finds none
   }
