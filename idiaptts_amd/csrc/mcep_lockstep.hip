@@ -631,25 +631,6 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
 // matrix.  A segment therefore updates W - 8 S entries (compile-time width: static register
 // indices), about half of the full-width work over the whole elimination; the dropped operations
 // are 0 - f * 0.  The segments follow each other as straight-line code (template recursion).
-#ifndef LS_SEG
-#define LS_SEG 8            // pivot steps per segment of fixed row width (see ls_segments)
-#endif
-#ifndef LS_RCP
-#define LS_RCP 0
-#endif
-// 1 / x of a pivot (positive, normal)
-__device__ __forceinline__ double ls_recip(double x) {
-#if LS_RCP
-  // the hardware's estimate and two Newton steps: within an ulp, five instructions in the dependency chain of
-  // every pivot step instead of the twelve of an IEEE division
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(r, fma(-x, r, 1.0), r);
-  r = fma(r, fma(-x, r, 1.0), r);
-  return r;
-#else
-  return 1.0 / x;
-#endif
-}
 #ifndef LS_READLANE_16THS
 #define LS_READLANE_16THS 4
 #endif
@@ -664,17 +645,17 @@ __device__ __forceinline__ double lane_value(double v, int l) {
 template <int W, int S>
 __device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double& d, double* P,
                                             int lane, int m1) {
-  if constexpr (LS_SEG * S < W) {
-    constexpr int WW = W - LS_SEG * S;
+  if constexpr (8 * S < W) {
+    constexpr int WW = W - 8 * S;
 #pragma unroll 1
-    for (int c = LS_SEG * S; c < LS_SEG * S + LS_SEG && c < m1; ++c) {
+    for (int c = 8 * S; c < 8 * S + 8 && c < m1; ++c) {
       P[lane] = row[0];
       __builtin_amdgcn_wave_barrier();
       const double pc = P[c];                                            // pivot A[c][c]
       const double bc = __shfl(b, c);
       const bool is_piv = lane == c;
       if (is_piv) d = pc;
-      const double f = is_piv ? 0.0 : row[0] * ls_recip(pc);   // 1/pc is wave-uniform: one reciprocal per step
+      const double f = is_piv ? 0.0 : row[0] * (1.0 / pc);   // 1/pc is wave-uniform: one division per step
       // uniform-address LDS reads are what bounds the kernel (a broadcast read still delivers 16 bytes
       // to each of the 64 lanes: 4 clocks of the CU's one LDS pipe per pair of pivot-row entries,
       // against 2 clocks' worth of FMAs on its four SIMDs).  The first JR entries therefore come
