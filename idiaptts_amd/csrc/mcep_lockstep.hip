@@ -625,12 +625,14 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
 //   * rows above the pivot are eliminated too (Gauss-Jordan), so no U factor is stored and no
 //     back substitution runs: lane r keeps its pivot d_r and ends with x_r = b_r / d_r.
 // 61 FMAs per step and lane, 60 steps; measured 29 ns per solve chip-wide (was 200 ns).
-// Pivot steps 8 S .. 8 S + 7 of the barrier-free Gauss-Jordan elimination below.  The rows are kept
+// Pivot steps 4 S .. 4 S + 3 of the barrier-free Gauss-Jordan elimination below.  The rows are kept
 // shifted (row[0] is always the current column), so after c steps only their first W - c entries
 // can be non-zero -- zeros are shifted in from the right, and the pivot row is zero beyond the
-// matrix.  A segment therefore updates W - 8 S entries (compile-time width: static register
+// matrix.  A segment therefore updates W - 4 S entries (compile-time width: static register
 // indices), about half of the full-width work over the whole elimination; the dropped operations
-// are 0 - f * 0.  The segments follow each other as straight-line code (template recursion).
+// are 0 - f * 0.  The segments follow each other as straight-line code (template recursion).  (Four steps per
+// segment with three waves per SIMD forced -- 168 registers, two spilled --: 1 635 against 1 675 us per launch with
+// eight; without the bound it took 170 registers and two waves per SIMD: 1 890 us.)
 #ifndef LS_READLANE_16THS
 #define LS_READLANE_16THS 4
 #endif
@@ -645,10 +647,10 @@ __device__ __forceinline__ double lane_value(double v, int l) {
 template <int W, int S>
 __device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double& d, double* P,
                                             int lane, int m1) {
-  if constexpr (8 * S < W) {
-    constexpr int WW = W - 8 * S;
+  if constexpr (4 * S < W) {
+    constexpr int WW = W - 4 * S;
 #pragma unroll 1
-    for (int c = 8 * S; c < 8 * S + 8 && c < m1; ++c) {
+    for (int c = 4 * S; c < 4 * S + 4 && c < m1; ++c) {
       P[lane] = row[0];
       __builtin_amdgcn_wave_barrier();
       const double pc = P[c];                                            // pivot A[c][c]
@@ -684,7 +686,7 @@ __device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double&
 }
 
 template <int W>   // W >= m + 1: register row length (20, 24, 32, 48, 60 or 64)
-__global__ __launch_bounds__(256) void mcls_solve_wave_kernel(LsArgs a) {
+__global__ __launch_bounds__(256, 3) void mcls_solve_wave_kernel(LsArgs a) {
   __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
   __shared__ double piv[4][64 + W];   // leading elements of all rows (the pivot row), zero padded
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
