@@ -176,6 +176,39 @@ class RowsGatherFunction(torch.autograd.Function):
         return ops.rows_gather(g, idx_back, width=ctx.width), None, None, None
 
 
+class StatesToCallerOrder(torch.autograd.Function):
+    """The final states of the layers -- each [ndir, B, Hl] in the batch's sorted row order, Hl >= H when the
+    hidden size was padded -- as ONE [layers * ndir, B, H] tensor in the caller's row order (what torch.nn.LSTM /
+    GRU return as h_n / c_n): one native row gather per layer straight into its slice (the index_select per
+    layer and the torch.cat over the layers were the last torch kernels between the recurrent layers)."""
+
+    @staticmethod
+    def forward(ctx, inv_perm, perm, H, *states):
+        ndir, B = states[0].shape[0], states[0].shape[1]
+        out = torch.empty((len(states) * ndir, B, H), dtype=torch.float32, device=states[0].device)
+        o2 = out.view(-1, H)
+        for i, st in enumerate(states):
+            st = st if st.is_contiguous() else st.contiguous()
+            for d in range(ndir):
+                ops.rows_gather(st[d], inv_perm, width=H, out=o2[(i * ndir + d) * B:(i * ndir + d + 1) * B])
+        ctx.save_for_backward(perm)
+        ctx.meta = (ndir, B, H, [st.shape[2] for st in states])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (perm,) = ctx.saved_tensors
+        ndir, B, H, widths = ctx.meta
+        g2 = (grad if grad.is_contiguous() else grad.contiguous()).view(-1, H)
+        outs = []
+        for i, Hl in enumerate(widths):
+            g = torch.empty((ndir, B, Hl), dtype=torch.float32, device=grad.device)
+            for d in range(ndir):
+                ops.rows_gather(g2[(i * ndir + d) * B:(i * ndir + d + 1) * B], perm, width=H, out=g[d], out_width=Hl)
+            outs.append(g)
+        return (None, None, None) + tuple(outs)
+
+
 def _pad4_cols(t):
     """[R, F] -> [R, F rounded up to a multiple of 4] (zero columns): rows of 16-byte multiples let
     the GEMM entry points take their LDS-DMA kernel; F = 425 (the question labels) otherwise sends

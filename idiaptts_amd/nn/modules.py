@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .functional import GRULayerFunction, LinearActFunction, LSTMLayerFunction, PackedBatch
+from .functional import GRULayerFunction, LinearActFunction, LSTMLayerFunction, PackedBatch, StatesToCallerOrder
 
 
 class LinearAct(nn.Linear):
@@ -118,13 +118,15 @@ class LSTM(nn.Module):
                 [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl, cl], 4, H)
             x, hn, cn = LSTMLayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl, cl,
                                                 torch.is_grad_enabled())
-            x, hn, cn = _unpad_rows(x, ndir, H, Hp), hn[:, :, :H], cn[:, :, :H]
+            x = _unpad_rows(x, ndir, H, Hp)
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = torch.nn.functional.dropout(x, self.dropout, True)
-            hn_all.append(hn.index_select(1, pb.inv_perm))      # back to the caller's row order
-            cn_all.append(cn.index_select(1, pb.inv_perm))
+            hn_all.append(hn)
+            cn_all.append(cn)
         out = pb.unpack(x, input_.shape)
-        return out, (torch.cat(hn_all, 0), torch.cat(cn_all, 0))
+        # back to the caller's row order, stacked over the layers
+        return out, (StatesToCallerOrder.apply(pb.inv_perm, pb.perm, self.hidden_size, *hn_all),
+                     StatesToCallerOrder.apply(pb.inv_perm, pb.perm, self.hidden_size, *cn_all))
 
 
 class GRU(nn.Module):
@@ -177,12 +179,12 @@ class GRU(nn.Module):
                 [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl], 3, H)
             x, hn = GRULayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl,
                                            torch.is_grad_enabled())
-            x, hn = _unpad_rows(x, ndir, H, Hp), hn[:, :, :H]
+            x = _unpad_rows(x, ndir, H, Hp)
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = torch.nn.functional.dropout(x, self.dropout, True)
-            hn_all.append(hn.index_select(1, pb.inv_perm))
+            hn_all.append(hn)
         out = pb.unpack(x, input_.shape)
-        return out, torch.cat(hn_all, 0)
+        return out, StatesToCallerOrder.apply(pb.inv_perm, pb.perm, self.hidden_size, *hn_all)
 
 
 class RNN(nn.Module):
