@@ -15,6 +15,7 @@
 // kernel of their own (7.7 ms per analysis, 3.4 ms on wave_fft.h) until round 4 folded them away.
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "context.h"
@@ -740,6 +741,132 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_wave_kernel(LsArgs a) {
   }
 }
 
+// ---- the same elimination with the pivot row in REGISTERS (orders up to 63) ----------------------------
+// mcls_solve_wave_kernel is bound by the LDS return path: every product fetches its pivot-row entry as a
+// broadcast read (16 bytes to each of 64 lanes per pair of entries).  gfx90a+ can take a 64-bit VALU operand
+// from lane n of the reader's own row of 16 lanes (DPP row_newbcast), so here the pivot row p[k] = A[k][c]
+// (the leading elements of the lanes, by the symmetry of the trailing block) is laid out ONCE per step as four
+// registers P_m, lane 16 rho + i holding p[16 m + i] in every row rho -- one 8-byte store and at most four
+// 8-byte loads per lane through the wave's 512 bytes of LDS instead of W - c broadcasts -- and a product is one
+// v_fmac_f64_dpp: row[k] += P_{k / 16}[lane k % 16 of the row] * (-f).  The rows are not shifted (the step loop
+// is unrolled: every register index and broadcast lane is an immediate).  Per element the same multiply-adds
+// with the same operands in the same order as in mcls_solve_wave_kernel: the same bits.
+#ifndef MCLS_DPP
+#define MCLS_DPP 1
+#endif
+#if MCLS_DPP
+#define MCLS_SOLVE_KERNEL mcls_solve_dpp_kernel
+#else
+#define MCLS_SOLVE_KERNEL mcls_solve_wave_kernel
+#endif
+template <int N>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, const double p, const double nf) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(nf), "n"(N));
+}
+
+// columns LO .. W - 1 of every row beyond column C: one product each
+template <int W, int C, int LO, int... Ks>
+__device__ __forceinline__ void ls_dpp_update(double (&row)[W], const double (&Pm)[4], const double nf,
+                                              std::integer_sequence<int, Ks...>) {
+  (((Ks > C && Ks >= LO) ? fmac_row_bcast<(Ks & 15)>(row[Ks], Pm[Ks >> 4], nf) : (void)0), ...);
+}
+
+// the pivot row of step C: the leading elements row[C] of all lanes, laid out for the broadcasts, and the pivot
+template <int W, int C>
+__device__ __forceinline__ void ls_dpp_fetch(const double (&row)[W], double* lead, int lane, double (&Pm)[4], double& pc) {
+  lead[lane] = row[C];
+  __builtin_amdgcn_wave_barrier();
+  constexpr int M0 = (C + 1) >> 4;              // first register of the pivot row with a column beyond C
+#pragma unroll
+  for (int mm = 0; mm < 4; ++mm)
+    if (mm >= M0 && 16 * mm < W) Pm[mm] = lead[16 * mm + (lane & 15)];
+  pc = lead[C];                                 // pivot A[C][C] (uniform address)
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Step C with the pivot row Pm / pivot pc already in registers; the NEXT step's are fetched behind this step's
+// first product (column C + 1 is final then), so the trip through LDS runs under the remaining products.
+template <int W, int C>
+__device__ __forceinline__ void ls_dpp_steps(double (&row)[W], double& b, double& d, double* lead, int lane, int m1,
+                                             const double (&Pm)[4], const double pc) {
+  if constexpr (C < W) {
+    if (C < m1) {                                   // wave-uniform
+      const double bc = lane_value(b, C);
+      const bool is_piv = lane == C;
+      if (is_piv) d = pc;
+      const double f = is_piv ? 0.0 : row[C] * (1.0 / pc);
+      const double nf = -f;
+      // (a VALU write of a DPP source needs two wait states before the DPP read; the compiler cannot see into
+      // the asm statements, so the distance is put here once per step -- the P registers come from LDS loads,
+      // but a register copy in front of the sequence would be a VALU write)
+      asm volatile("s_nop 1" ::: "memory");
+      double Pn[4] = {0.0, 0.0, 0.0, 0.0}, pcn = 1.0;
+      if constexpr (C + 1 < W) {
+        fmac_row_bcast<((C + 1) & 15)>(row[C + 1], Pm[(C + 1) >> 4], nf);
+        if (C + 1 < m1) ls_dpp_fetch<W, C + 1>(row, lead, lane, Pn, pcn);
+      }
+      ls_dpp_update<W, C, C + 2>(row, Pm, nf, std::make_integer_sequence<int, W>{});
+      b -= f * bc;
+      ls_dpp_steps<W, C + 1>(row, b, d, lead, lane, m1, Pn, pcn);
+    }
+  }
+}
+
+template <int W>   // W >= m + 1, W <= 64
+__global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
+  __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
+  __shared__ double leads[4][64];     // the leading elements of the step (the pivot row)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t slot = (int64_t)blockIdx.x * 4 + wv;
+  if (slot >= a.n_rows) return;                      // wave-uniform
+  const int64_t g = a.rows ? a.rows[slot] : slot;
+  if (a.done[g]) return;
+  const int m = a.m, m1 = m + 1, m2 = 2 * m;
+  double* cr = crs[wv];
+  for (int j = lane; j <= m2; j += 64) cr[j] = a.cr[g * (m2 + 1) + j];
+  __builtin_amdgcn_wave_barrier();
+  const double t = cr[0];
+  if (a.iter >= a.itr1) {
+    const double sp = a.sprev[g];
+    if (fabs((t - sp) / t) < a.dd) {                 // uniform
+      if (lane == 0) {
+        a.done[g] = 1;
+        a.iters[g] = a.iter;
+        atomicSub(a.n_active, 1);
+      }
+      return;
+    }
+    if (lane == 0) a.sprev[g] = t;
+  }
+  const int r = lane;
+  const bool rowok = r < m1;
+  double row[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    double v = 0.0;
+    if (rowok && k < m1) {
+      const int df = r > k ? r - k : k - r;
+      double tv = cr[df];
+      if ((df & 1) == 0) tv += t;
+      double hv = cr[r + k];
+      if (((r + k) & 1) == 0) hv -= t;
+      v = tv + hv;
+    }
+    row[k] = v;
+  }
+  double b = rowok ? cr[r] - pow(-a.alpha, (double)r) : 0.0;
+  double d = 1.0;
+  double P0[4] = {0.0, 0.0, 0.0, 0.0}, pc0 = 1.0;
+  ls_dpp_fetch<W, 0>(row, leads[wv], lane, P0, pc0);
+  ls_dpp_steps<W, 0>(row, b, d, leads[wv], lane, m1, P0, pc0);
+  if (rowok) a.mc[g * m1 + r] += b / d;
+  if (lane == 0 && a.iter == a.itr2) {
+    a.done[g] = 1;
+    a.iters[g] = a.itr2;
+    atomicSub(a.n_active, 1);
+  }
+}
+
 __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, int m1,
                                      float* __restrict__ o32, int64_t ld32, double* __restrict__ o64,
                                      const int* __restrict__ iters_in, int* __restrict__ iters_out) {
@@ -888,12 +1015,12 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     if ((rc = launch_gemm_f64_ratio(mc, m1, ft->specT, K, cbuf, Kp, nr, K, m1, a.rows, xp, s))) return rc;
     if ((rc = launch_gemm_f64(cbuf, Kp, ft->crT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
     const dim3 wgrid((unsigned)((nr + 3) / 4));
-    if (m1 <= 20) hipLaunchKernelGGL(mcls_solve_wave_kernel<20>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_wave_kernel<24>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 32) hipLaunchKernelGGL(mcls_solve_wave_kernel<32>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 48) hipLaunchKernelGGL(mcls_solve_wave_kernel<48>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 60) hipLaunchKernelGGL(mcls_solve_wave_kernel<60>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 64) hipLaunchKernelGGL(mcls_solve_wave_kernel<64>, wgrid, dim3(256), 0, s, a);
+    if (m1 <= 20) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<20>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 24) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<24>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 32) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<32>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 48) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<48>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 60) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<60>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 64) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<64>, wgrid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)nr), dim3(NT), lds_solve, s, a);
     ITTS_LAUNCH_CHECK();
     if (it >= miniter && it < maxiter) {
