@@ -453,14 +453,14 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     sy_flops = 7 * fft * 1.3 + 2 * 60 * K
     nap = L.itts_num_aperiodicities(fs) if n_ranks >= 1 else 1
     w["analysis_roofline"] = {
-        "bound": "hbm", "kernel": "mcls_solve_wave_kernel + d4c_kernel + gemm_f64_kernel (see profiles/)",
+        "bound": "hbm", "kernel": "mcls_solve_dpp_kernel + d4c_kernel + gemm_f64_kernel (see profiles/)",
         "achieved": w["analysis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
         "frac": w["analysis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS,
         "traffic": committed_traffic("analysis_%d" % fs) if n_utts == (256 if fs <= 24000 else 64) else None,
         "what_binds_it": "fp64 VALU issue and LDS latency, not HBM: see issue_fractions (share of the chip's VALU "
                          "issue slots / LDS cycles in use, share of a wave's life spent waiting; SQ counters, "
                          "profiles/r4_world_pmc_fractions.json)",
-        "issue_fractions": {k: committed_fractions(k) for k in ("mcls_solve_wave", "d4c_kernel", "cheaptrick_wave",
+        "issue_fractions": {k: committed_fractions(k) for k in ("mcls_solve_dpp", "d4c_kernel", "cheaptrick_wave",
                                                                  "gemm_f64_kernel<true, true", "gemm_f64_lds")} if fs <= 24000 else None,
         "algorithmic_bytes_per_frame": fs // 200 * 8 + (61 + nap) * 4,
         "fp64_tflops": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks,

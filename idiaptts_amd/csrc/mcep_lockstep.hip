@@ -8,7 +8,7 @@
 //     mc0 = LG [T x 513] . initT [513 x 60]                      once      (LG = log periodogram)
 //     d   = X / exp(2 MC [T x 60] . specT [60 x 513])            per iteration, ratio in the epilogue
 //     cr  = D  [T x 513] . crT  [513 x 119]                      per iteration
-// with the solve one WAVE per frame (mcls_solve_wave_kernel).  All frames advance one Newton step per
+// with the solve one WAVE per frame (mcls_solve_dpp_kernel).  All frames advance one Newton step per
 // round; converged frames are frozen by a flag and dropped from the work list.  History: round 1 ran
 // one workgroup per frame (bound by re-reading 735 KB of warping matrices per frame and iteration),
 // round 2 made the warping steps products, rounds 2-4 kept two transforms per frame and iteration in a
@@ -617,26 +617,13 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
 // workgroup-per-frame elimination above spends its time in 2 x 60 block barriers and index
 // arithmetic (77 us per solve).  Here lane r owns row r in REGISTERS and the wave runs a
 // Gauss-Jordan elimination without a single barrier:
-//   * at pivot step c every lane drops its leading element: the row is kept SHIFTED so that
-//     a[j] always means column c + j, and the update a[j-1] = a[j] - f * p[j] doubles as the shift
-//     (all register indices are compile-time constants, the step loop is a real loop);
-//   * the pivot row is never broadcast lane by lane: the trailing block is symmetric, so
-//     p[j] = A[c][c+j] = A[c+j][c] is the leading element of lane c+j -- one ds_write_b64 of a[0]
-//     by the whole wave publishes the pivot row, uniform-address LDS reads return it;
 //   * rows above the pivot are eliminated too (Gauss-Jordan), so no U factor is stored and no
-//     back substitution runs: lane r keeps its pivot d_r and ends with x_r = b_r / d_r.
-// 61 FMAs per step and lane, 60 steps; measured 29 ns per solve chip-wide (was 200 ns).
-// Pivot steps 4 S .. 4 S + 3 of the barrier-free Gauss-Jordan elimination below.  The rows are kept
-// shifted (row[0] is always the current column), so after c steps only their first W - c entries
-// can be non-zero -- zeros are shifted in from the right, and the pivot row is zero beyond the
-// matrix.  A segment therefore updates W - 4 S entries (compile-time width: static register
-// indices), about half of the full-width work over the whole elimination; the dropped operations
-// are 0 - f * 0.  The segments follow each other as straight-line code (template recursion).  (Four steps per
-// segment with three waves per SIMD forced -- 168 registers, two spilled --: 1 635 against 1 675 us per launch with
-// eight; without the bound it took 170 registers and two waves per SIMD: 1 890 us.)
-#ifndef LS_READLANE_16THS
-#define LS_READLANE_16THS 4
-#endif
+//     back substitution runs: lane r keeps its pivot d_r and ends with x_r = b_r / d_r;
+//   * the pivot row is never broadcast lane by lane: the trailing block is symmetric, so
+//     p[k] = A[c][k] = A[k][c] is the entry of column c that lane k holds.
+// Rounds 2-4 published that column through LDS and read it back as uniform-address (broadcast) loads, one per
+// product: the kernel was bound by the LDS return path (0.80 busy; a quarter of the entries through v_readlane
+// and SGPR operands balanced it against the VALU at 0.69 / 0.63: 1 635 us per launch at the bench size).
 // the value lane l (wave-uniform) holds, in scalar registers
 __device__ __forceinline__ double lane_value(double v, int l) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -645,120 +632,14 @@ __device__ __forceinline__ double lane_value(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <int W, int S>
-__device__ __forceinline__ void ls_segments(double (&row)[W], double& b, double& d, double* P,
-                                            int lane, int m1) {
-  if constexpr (4 * S < W) {
-    constexpr int WW = W - 4 * S;
-#pragma unroll 1
-    for (int c = 4 * S; c < 4 * S + 4 && c < m1; ++c) {
-      P[lane] = row[0];
-      __builtin_amdgcn_wave_barrier();
-      const double pc = P[c];                                            // pivot A[c][c]
-      const double bc = __shfl(b, c);
-      const bool is_piv = lane == c;
-      if (is_piv) d = pc;
-      const double f = is_piv ? 0.0 : row[0] * (1.0 / pc);   // 1/pc is wave-uniform: one division per step
-      // uniform-address LDS reads are what bounds the kernel (a broadcast read still delivers 16 bytes
-      // to each of the 64 lanes: 4 clocks of the CU's one LDS pipe per pair of pivot-row entries,
-      // against 2 clocks' worth of FMAs on its four SIMDs).  The first JR entries therefore come
-      // through the scalar registers instead (v_readlane of the owner's leading element, an SGPR
-      // pair as the FMA's operand: VALU work, no LDS): at a quarter both pipes carry the same load.
-      const double* p = P + c;
-      constexpr int JR = 1 + ((WW - 1) * LS_READLANE_16THS) / 16;
-      const double r0 = row[0];
-#pragma unroll
-      for (int j = 1; j < WW; ++j) {
-        double pj;
-        if (j < JR) {
-          const double v = lane_value(r0, (c + j) & 63);
-          pj = c + j < 64 ? v : 0.0;
-        } else {
-          pj = p[j];
-        }
-        row[j - 1] = row[j] - f * pj;
-      }
-      row[WW - 1] = 0.0;
-      b -= f * bc;
-      __builtin_amdgcn_wave_barrier();
-    }
-    ls_segments<W, S + 1>(row, b, d, P, lane, m1);
-  }
-}
-
-template <int W>   // W >= m + 1: register row length (20, 24, 32, 48, 60 or 64)
-__global__ __launch_bounds__(256, 3) void mcls_solve_wave_kernel(LsArgs a) {
-  __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
-  __shared__ double piv[4][64 + W];   // leading elements of all rows (the pivot row), zero padded
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t slot = (int64_t)blockIdx.x * 4 + wv;
-  if (slot >= a.n_rows) return;                      // wave-uniform
-  const int64_t g = a.rows ? a.rows[slot] : slot;
-  if (a.done[g]) return;
-  const int m = a.m, m1 = m + 1, m2 = 2 * m;
-  double* cr = crs[wv];
-  double* P = piv[wv];
-  for (int j = lane; j <= m2; j += 64) cr[j] = a.cr[g * (m2 + 1) + j];
-  for (int j = lane; j < W; j += 64) P[64 + j] = 0.0;
-  __builtin_amdgcn_wave_barrier();
-  const double t = cr[0];
-  if (a.iter >= a.itr1) {
-    const double sp = a.sprev[g];
-    if (fabs((t - sp) / t) < a.dd) {                 // uniform
-      if (lane == 0) {
-        a.done[g] = 1;
-        a.iters[g] = a.iter;
-        atomicSub(a.n_active, 1);
-      }
-      return;
-    }
-    if (lane == 0) a.sprev[g] = t;
-  }
-  const int r = lane;
-  const bool rowok = r < m1;
-  double row[W];
-#pragma unroll
-  for (int k = 0; k < W; ++k) {
-    double v = 0.0;
-    if (rowok && k < m1) {
-      const int df = r > k ? r - k : k - r;
-      double tv = cr[df];
-      if ((df & 1) == 0) tv += t;
-      double hv = cr[r + k];
-      if (((r + k) & 1) == 0) hv -= t;
-      v = tv + hv;
-    }
-    row[k] = v;
-  }
-  double b = rowok ? cr[r] - pow(-a.alpha, (double)r) : 0.0;
-  double d = 1.0;
-  ls_segments<W, 0>(row, b, d, P, lane, m1);
-  if (rowok) a.mc[g * m1 + r] += b / d;
-  if (lane == 0 && a.iter == a.itr2) {
-    a.done[g] = 1;
-    a.iters[g] = a.itr2;
-    atomicSub(a.n_active, 1);
-  }
-}
-
-// ---- the same elimination with the pivot row in REGISTERS (orders up to 63) ----------------------------
-// mcls_solve_wave_kernel is bound by the LDS return path: every product fetches its pivot-row entry as a
-// broadcast read (16 bytes to each of 64 lanes per pair of entries).  gfx90a+ can take a 64-bit VALU operand
+// What runs now keeps the pivot row in REGISTERS.  gfx90a+ can take a 64-bit VALU operand
 // from lane n of the reader's own row of 16 lanes (DPP row_newbcast), so here the pivot row p[k] = A[k][c]
 // (the leading elements of the lanes, by the symmetry of the trailing block) is laid out ONCE per step as four
 // registers P_m, lane 16 rho + i holding p[16 m + i] in every row rho -- one 8-byte store and at most four
 // 8-byte loads per lane through the wave's 512 bytes of LDS instead of W - c broadcasts -- and a product is one
 // v_fmac_f64_dpp: row[k] += P_{k / 16}[lane k % 16 of the row] * (-f).  The rows are not shifted (the step loop
 // is unrolled: every register index and broadcast lane is an immediate).  Per element the same multiply-adds
-// with the same operands in the same order as in mcls_solve_wave_kernel: the same bits.
-#ifndef MCLS_DPP
-#define MCLS_DPP 1
-#endif
-#if MCLS_DPP
-#define MCLS_SOLVE_KERNEL mcls_solve_dpp_kernel
-#else
-#define MCLS_SOLVE_KERNEL mcls_solve_wave_kernel
-#endif
+// with the same operands in the same order as in the LDS-broadcast kernel it replaced: the same bits (1 163 us).
 template <int N>
 __device__ __forceinline__ void fmac_row_bcast(double& acc, const double p, const double nf) {
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(nf), "n"(N));
@@ -794,16 +675,17 @@ __device__ __forceinline__ void ls_dpp_steps(double (&row)[W], double& b, double
       const double bc = lane_value(b, C);
       const bool is_piv = lane == C;
       if (is_piv) d = pc;
-      const double f = is_piv ? 0.0 : row[C] * (1.0 / pc);
+      const double inv = 1.0 / pc;                  // wave-uniform: one division per step
+      const double f = is_piv ? 0.0 : row[C] * inv;
       const double nf = -f;
       // (a VALU write of a DPP source needs two wait states before the DPP read; the compiler cannot see into
       // the asm statements, so the distance is put here once per step -- the P registers come from LDS loads,
       // but a register copy in front of the sequence would be a VALU write)
       asm volatile("s_nop 1" ::: "memory");
-      double Pn[4] = {0.0, 0.0, 0.0, 0.0}, pcn = 1.0;
+      double Pn[4], pcn = 1.0;        // (only the registers with columns beyond C + 1 are loaded, and only those are used)
       if constexpr (C + 1 < W) {
         fmac_row_bcast<((C + 1) & 15)>(row[C + 1], Pm[(C + 1) >> 4], nf);
-        if (C + 1 < m1) ls_dpp_fetch<W, C + 1>(row, lead, lane, Pn, pcn);
+        ls_dpp_fetch<W, C + 1>(row, lead, lane, Pn, pcn);      // (unconditional: one idle fetch behind the last step)
       }
       ls_dpp_update<W, C, C + 2>(row, Pm, nf, std::make_integer_sequence<int, W>{});
       b -= f * bc;
@@ -856,7 +738,7 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
   }
   double b = rowok ? cr[r] - pow(-a.alpha, (double)r) : 0.0;
   double d = 1.0;
-  double P0[4] = {0.0, 0.0, 0.0, 0.0}, pc0 = 1.0;
+  double P0[4], pc0 = 1.0;
   ls_dpp_fetch<W, 0>(row, leads[wv], lane, P0, pc0);
   ls_dpp_steps<W, 0>(row, b, d, leads[wv], lane, m1, P0, pc0);
   if (rowok) a.mc[g * m1 + r] += b / d;
@@ -1015,12 +897,12 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     if ((rc = launch_gemm_f64_ratio(mc, m1, ft->specT, K, cbuf, Kp, nr, K, m1, a.rows, xp, s))) return rc;
     if ((rc = launch_gemm_f64(cbuf, Kp, ft->crT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
     const dim3 wgrid((unsigned)((nr + 3) / 4));
-    if (m1 <= 20) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<20>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 24) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<24>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 32) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<32>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 48) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<48>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 60) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<60>, wgrid, dim3(256), 0, s, a);
-    else if (m1 <= 64) hipLaunchKernelGGL(MCLS_SOLVE_KERNEL<64>, wgrid, dim3(256), 0, s, a);
+    if (m1 <= 20) hipLaunchKernelGGL(mcls_solve_dpp_kernel<20>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_dpp_kernel<24>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 32) hipLaunchKernelGGL(mcls_solve_dpp_kernel<32>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 48) hipLaunchKernelGGL(mcls_solve_dpp_kernel<48>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 60) hipLaunchKernelGGL(mcls_solve_dpp_kernel<60>, wgrid, dim3(256), 0, s, a);
+    else if (m1 <= 64) hipLaunchKernelGGL(mcls_solve_dpp_kernel<64>, wgrid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)nr), dim3(NT), lds_solve, s, a);
     ITTS_LAUNCH_CHECK();
     if (it >= miniter && it < maxiter) {

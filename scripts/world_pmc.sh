@@ -13,7 +13,7 @@ cd $GRAFT_REPO_ROOT
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-want = ("syn_pulse_wave_kernel", "mcls_solve_wave", "gemm_f64_kernel", "d4c_kernel", "cheaptrick_wave_kernel", "gemm_f64_lds")
+want = ("syn_pulse_wave_kernel", "mcls_solve_dpp", "gemm_f64_kernel", "d4c_kernel", "cheaptrick_wave_kernel", "gemm_f64_lds")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
