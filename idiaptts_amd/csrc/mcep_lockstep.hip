@@ -639,7 +639,8 @@ __device__ __forceinline__ double lane_value(double v, int l) {
 // 8-byte loads per lane through the wave's 512 bytes of LDS instead of W - c broadcasts -- and a product is one
 // v_fmac_f64_dpp: row[k] += P_{k / 16}[lane k % 16 of the row] * (-f).  The rows are not shifted (the step loop
 // is unrolled: every register index and broadcast lane is an immediate).  Per element the same multiply-adds
-// with the same operands in the same order as in the LDS-broadcast kernel it replaced: the same bits (1 163 us).
+// with the same operands in the same order as in the LDS-broadcast kernel it replaced (the same bits with an IEEE
+// division for 1 / pivot: 1 156 us per launch; with the reciprocal below the multipliers may differ in the last place).
 template <int N>
 __device__ __forceinline__ void fmac_row_bcast(double& acc, const double p, const double nf) {
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(nf), "n"(N));
@@ -675,7 +676,11 @@ __device__ __forceinline__ void ls_dpp_steps(double (&row)[W], double& b, double
       const double bc = lane_value(b, C);
       const bool is_piv = lane == C;
       if (is_piv) d = pc;
-      const double inv = 1.0 / pc;                  // wave-uniform: one division per step
+      // 1 / pivot (positive, normal; wave-uniform): the hardware's estimate and two Newton steps -- within an ulp,
+      // five instructions instead of the eleven of the IEEE division, which were a seventh of a step
+      double inv = __builtin_amdgcn_rcp(pc);
+      inv = fma(inv, fma(-pc, inv, 1.0), inv);
+      inv = fma(inv, fma(-pc, inv, 1.0), inv);
       const double f = is_piv ? 0.0 : row[C] * inv;
       const double nf = -f;
       // (a VALU write of a DPP source needs two wait states before the DPP read; the compiler cannot see into
