@@ -507,6 +507,7 @@ struct LsArgs {
   int64_t ldk;           // row pitch of xp / cbuf (K rounded up to even: 16-byte aligned rows)
   const int* rows;       // frames still iterating (NULL: all T)
   int64_t n_rows;
+  const double* apow;    // [m + 1] (-alpha)^r: the right-hand side's constant part, tabulated once per call
 };
 
 
@@ -701,7 +702,11 @@ __device__ __forceinline__ void ls_dpp_steps(double (&row)[W], double& b, double
 
 template <int W>   // W >= m + 1, W <= 64
 __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
-  __shared__ double crs[4][2 * 64];   // cr[0 .. 2m] of the wave's frame
+  // cr[0 .. 2m] of the wave's frame with the reference's parity terms applied once (theq's matrix is
+  // A[r][k] = (cr[|r - k|] (+ t)) + (cr[r + k] (- t)), the t's where the index is even, t = cr[0]): 119 entries
+  // prepared per solve instead of 3 600 parity tests
+  __shared__ double crp[4][2 * 64];   // cr[j] + t [j even]
+  __shared__ double crm[4][2 * 64];   // cr[j] - t [j even]
   __shared__ double leads[4][64];     // the leading elements of the step (the pivot row)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t slot = (int64_t)blockIdx.x * 4 + wv;
@@ -709,10 +714,8 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
   const int64_t g = a.rows ? a.rows[slot] : slot;
   if (a.done[g]) return;
   const int m = a.m, m1 = m + 1, m2 = 2 * m;
-  double* cr = crs[wv];
-  for (int j = lane; j <= m2; j += 64) cr[j] = a.cr[g * (m2 + 1) + j];
-  __builtin_amdgcn_wave_barrier();
-  const double t = cr[0];
+  const double* crg = a.cr + g * (m2 + 1);
+  const double t = crg[0];
   if (a.iter >= a.itr1) {
     const double sp = a.sprev[g];
     if (fabs((t - sp) / t) < a.dd) {                 // uniform
@@ -725,23 +728,23 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
     }
     if (lane == 0) a.sprev[g] = t;
   }
+  for (int j = lane; j <= m2; j += 64) {
+    const double c = crg[j];
+    const bool even = (j & 1) == 0;
+    crp[wv][j] = even ? c + t : c;
+    crm[wv][j] = even ? c - t : c;
+  }
+  __builtin_amdgcn_wave_barrier();
   const int r = lane;
   const bool rowok = r < m1;
   double row[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) {
     double v = 0.0;
-    if (rowok && k < m1) {
-      const int df = r > k ? r - k : k - r;
-      double tv = cr[df];
-      if ((df & 1) == 0) tv += t;
-      double hv = cr[r + k];
-      if (((r + k) & 1) == 0) hv -= t;
-      v = tv + hv;
-    }
+    if (rowok && k < m1) v = crp[wv][r > k ? r - k : k - r] + crm[wv][r + k];
     row[k] = v;
   }
-  double b = rowok ? cr[r] - pow(-a.alpha, (double)r) : 0.0;
+  double b = rowok ? crg[r] - a.apow[r] : 0.0;     // (the library's pow per lane and solve was 150 instructions)
   double d = 1.0;
   double P0[4], pc0 = 1.0;
   ls_dpp_fetch<W, 0>(row, leads[wv], lane, P0, pc0);
@@ -752,6 +755,11 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
     a.iters[g] = a.itr2;
     atomicSub(a.n_active, 1);
   }
+}
+
+__global__ void mcls_alpha_pow_kernel(double alpha, int m1, double* __restrict__ apow) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < m1) apow[r] = pow(-alpha, (double)r);
 }
 
 __global__ void mcls_finalize_kernel(const double* __restrict__ mc, int64_t T, int m1,
@@ -879,13 +887,17 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&iters, (size_t)T * 4, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&rows, (size_t)T * 4, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&n_active, 8, s));   // [0] active frames, [1] list cursor
+  double* apow = nullptr;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&apow, (size_t)m1 * 8, s));
+  hipLaunchKernelGGL(mcls_alpha_pow_kernel, dim3((m1 + 63) / 64), dim3(64), 0, s, alpha, m1, apow);
+  ITTS_LAUNCH_CHECK();
   const int tcount[2] = {(int)T, 0};
   ITTS_HIP_CHECK(hipMemcpyAsync(n_active, tcount, 8, hipMemcpyHostToDevice, s));
   LsArgs a{};
   a.in = d_in; a.in_is_power = in_is_power; a.T = T; a.flng = flng; a.logflng = logflng; a.m = order;
   a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.xp = xp;
   a.cbuf = cbuf; a.mc = mc; a.cr = cr; a.sprev = sprev; a.done = done; a.iters = iters;
-  a.n_active = n_active; a.ldk = Kp; a.rows = nullptr; a.n_rows = T;
+  a.n_active = n_active; a.ldk = Kp; a.rows = nullptr; a.n_rows = T; a.apow = apow;
   const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
@@ -937,6 +949,7 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   ITTS_HIP_CHECK(itts::scratch_free(done, s));
   ITTS_HIP_CHECK(itts::scratch_free(iters, s));
   ITTS_HIP_CHECK(itts::scratch_free(n_active, s));
+  ITTS_HIP_CHECK(itts::scratch_free(apow, s));
   ITTS_HIP_CHECK(itts::scratch_free(rows, s));
   return ITTS_OK;
 }
