@@ -654,7 +654,17 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
     while (k > 0 && (double)k * fs / a.fft_size > cf) --k;
     if (k > K - 2) k = K - 2;
     const double x0 = (double)k * fs / a.fft_size, x1 = (double)(k + 1) * fs / a.fft_size;
-    const double y0 = 20.0 * log10(ap_at(k)), y1 = 20.0 * log10(ap_at(k + 1));
+    // the aperiodicity of the two bins in dB: ap_at's exponent itself (20 log10(10^(y / 20)) went through the
+    // library's pow and log10 for every band and frame on one wave while the other three waited: 600 instructions)
+    auto db_at = [&](int kb) -> double {
+      if (!voiced) return 20.0 * log10(1.0 - kEps);
+      const double f = (double)kb * fs / a.fft_size;
+      int kk = 1;
+      while (kk < nap + 1 && f >= cfa[kk]) ++kk;
+      const double sfr = (f - cfa[kk - 1]) / (cfa[kk] - cfa[kk - 1]);
+      return cap[kk - 1] + sfr * (cap[kk] - cap[kk - 1]);
+    };
+    const double y0 = db_at(k), y1 = db_at(k + 1);
     const double v = y0 + (cf - x0) / (x1 - x0) * (y1 - y0);
     if (a.bap_f64) a.bap_f64[g * nap + b] = v;
     if (a.bap_f32) a.bap_f32[g * a.ld_bap + b] = (float)v;
