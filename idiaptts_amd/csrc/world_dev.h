@@ -83,6 +83,29 @@ __device__ __forceinline__ double wave_sum_at(double v, int lane) {   // same bu
   return v;
 }
 
+// Utterance of global frame g (off[u] <= g < off[u + 1]) for a WHOLE WAVE asking about the same g (all 64 lanes
+// active): the offsets are compared 64 at a time -- loads that do not depend on each other -- instead of by a
+// binary search, whose eight dependent trips to the cache were 4 us at the start of every frame's life (a third
+// of StoneMask's time, an eighth of a CheapTrick / D4C frame).  Beyond 1 024 utterances: the binary search.
+__device__ __forceinline__ int find_utt_wave(const int64_t* __restrict__ off, int n_utts, int64_t g) {
+  if (n_utts > 1024) {
+    int lo = 0, hi = n_utts;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+  }
+  const int lane = (int)(threadIdx.x & 63);
+  int below = 0;                                        // offsets off[0 .. n_utts) that are <= g (off[0] = 0 always is)
+  for (int i0 = 0; i0 < n_utts; i0 += 64) {
+    const int i = i0 + lane;
+    const bool le = i < n_utts && off[i] <= g;
+    below += __popcll(__ballot(le));
+  }
+  return below - 1;
+}
+
 __device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
 __device__ __forceinline__ int ilog2(int n) { return 31 - __clz(n); }
 

@@ -19,15 +19,6 @@
 namespace itts {
 using namespace wd;
 
-__device__ __forceinline__ int find_utt2(const int64_t* __restrict__ off, int n_utts, int64_t g) {
-  int lo = 0, hi = n_utts;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (off[mid] <= g) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // exp(-2 pi i k / n) for 0 <= k < n from the master table exp(+2 pi i j / TW_N), j < TW_N/2.
 // For n > TW_N the angle is computed directly.
 __device__ __forceinline__ double2 twiddle_neg(const double2* __restrict__ g_tw, int k, int n) {
@@ -66,7 +57,7 @@ __global__ __launch_bounds__(NT) void stonemask_kernel(SmArgs a) {
   double* mw = sd + a.nmax;                       // main window
   double* red = mw + a.nmax;                      // 4 * 32 doubles
   const int64_t g = blockIdx.x;
-  const int u = find_utt2(a.f_off, a.n_utts, g);
+  const int u = find_utt_wave(a.f_off, a.n_utts, g);
   const double* x = a.x + a.x_off[u];
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
   const int fs = a.fs;
@@ -176,7 +167,7 @@ __global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves)
   if (g >= a.f_off[a.n_utts]) return;
   double* sm = reinterpret_cast<double*>(smem) + (size_t)wv * 2 * a.nmax;  // x * main window
   double* sd = sm + a.nmax;                                                  // x * diff window
-  const int u = find_utt2(a.f_off, a.n_utts, g);
+  const int u = find_utt_wave(a.f_off, a.n_utts, g);
   const double* x = a.x + a.x_off[u];
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
   const int fs = a.fs;
@@ -453,7 +444,7 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
   L.red = reinterpret_cast<double*>(p);
 
   const int64_t g = a.order[blockIdx.x];
-  const int u = find_utt2(a.f_off, a.n_utts, g);
+  const int u = find_utt_wave(a.f_off, a.n_utts, g);
   const double* x = a.x + a.x_off[u];
   const int64_t xl = a.x_off[u + 1] - a.x_off[u];
   const int fs = a.fs;

@@ -21,16 +21,6 @@
 namespace itts {
 using namespace wd;
 
-// locate the utterance of global frame g: offsets[u] <= g < offsets[u+1]
-__device__ __forceinline__ int find_utt(const int64_t* __restrict__ off, int n_utts, int64_t g) {
-  int lo = 0, hi = n_utts;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (off[mid] <= g) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // ------------------------------------------------------------------------------------------------
 // CheapTrick for one frame. Result (power spectral envelope, fft/2+1 bins) is left in P.
 // LDS: z [fft/2+1] complex, P [fft/2+1], mir [fft/2 + 2*bmax + 1], red [NT+8], tw [fft/2] cplx
@@ -238,7 +228,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(FrameArgs a) {
   for (int64_t g = blockIdx.x; g < a.t_total; g += gridDim.x) {
     const double f0 = ct_frame_f0(a.f0[g], a.fs, a.fft);
     if (a.far_only && !ct_far(f0, a.fs)) continue;       // workgroup-uniform
-    const int u = find_utt(a.f_off, a.n_utts, g);
+    const int u = find_utt_wave(a.f_off, a.n_utts, g);
     const int64_t t = g - a.f_off[u];
     const double* x = a.x + a.x_off[u];
     const int64_t xl = a.x_off[u + 1] - a.x_off[u];
@@ -293,7 +283,7 @@ __global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs 
     int l = l0, fs = a.fs;
     double q1 = a.q1;
     asm volatile("" : "+v"(l), "+s"(fs), "+s"(q1));
-    const int u = __builtin_amdgcn_readfirstlane(find_utt(a.f_off, a.n_utts, g));
+    const int u = __builtin_amdgcn_readfirstlane(find_utt_wave(a.f_off, a.n_utts, g));
     const int64_t fo = a.f_off[u];
     const double* x = a.x + a.x_off[u];
     const int64_t xl = a.x_off[u + 1] - a.x_off[u];
