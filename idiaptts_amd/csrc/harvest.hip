@@ -487,27 +487,45 @@ __global__ __launch_bounds__(NT) void hv_detect_kernel(const HvUtt* __restrict__
 // harmonic bins of both spectra, (4) two short butterfly reductions.
 __device__ __forceinline__ double hv_xor_sum(double v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
+// The window's two rotations (by 64 samples and by one) depend on the half width hw only: tabulated per
+// call with the expressions the refinement used per slot (same values bit for bit), so that a slot
+// costs one sincospi instead of three.  rot[hw] = {sin, cos of 2 pi 64 / bl; sin, cos of 2 pi / bl}.
+__global__ __launch_bounds__(64) void hv_rot_table_kernel(double fs, int hw_max, double4* __restrict__ rot) {
+  const int hw = blockIdx.x * 64 + threadIdx.x;
+  if (hw > hw_max) return;
+  const double wlt = (2.0 * hw + 1.0) / fs;
+  double rs, rc, ds1, dc1;
+  sincospi(2.0 * 64.0 / (fs * wlt), &rs, &rc);
+  sincospi(2.0 / (fs * wlt), &ds1, &dc1);
+  rot[hw] = make_double4(rs, rc, ds1, dc1);
+}
+
 __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__ utts, HvParams p,
                                                        const double2* __restrict__ g_tw,
+                                                       const double4* __restrict__ rot,
                                                        const double* __restrict__ ypad,
                                                        const double* __restrict__ base,
                                                        const int* __restrict__ ncand,
                                                        double* __restrict__ cand,
                                                        double* __restrict__ score) {
   extern __shared__ __attribute__((aligned(16))) char smem_rf[];
-  double2* tw = reinterpret_cast<double2*>(smem_rf);                   // [fft_max / 2]
-  double* ws_all = reinterpret_cast<double*>(tw + p.fft_max / 2);       // [4][2][bl_max + 2]
+  double2* tw = reinterpret_cast<double2*>(smem_rf);                   // [fft_max]: exp(-2 pi i j / fft_max)
+  double2* ws_all = tw + p.fft_max;                                     // [4][bl_max + 2]: (windowed, derivative-windowed)
   const HvUtt u = utts[blockIdx.y];
   const int f0i = blockIdx.x * HV_REFINE_FRAMES;
   if (f0i >= u.T1) return;
-  for (int k = threadIdx.x; k < p.fft_max / 2; k += NT) tw[k] = g_tw[k];
+  // the whole circle from the half table exp(+2 pi i k / fft_max), k < fft_max / 2 (sign flips only: the
+  // values the half table gave), so that the harmonic loop fetches a factor without a case split
+  for (int k = threadIdx.x; k < p.fft_max / 2; k += NT) {
+    const double2 w = g_tw[k];
+    tw[k] = make_double2(w.x, -w.y);
+    tw[k + p.fft_max / 2] = make_double2(-w.x, w.y);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = f0i + wv;
   if (i >= u.T1) return;
-  const int wstride = p.bl_max + 2;
-  double* ams = ws_all + (size_t)wv * 2 * wstride;
-  double* ads = ams + wstride;
+  double2* wsamp = ws_all + (size_t)wv * (p.bl_max + 2);
   const int nc0 = ncand[blockIdx.y];
   const int nc = nc0 * 7;
   const double* y = ypad + u.y_off + p.pad;
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
     const int jl = __builtin_ctzll(todo);
     const int j = j0 + jl;
     const double f0 = __shfl(fl, jl, 64);
-    const int hw = (int)(1.5 * fs / f0 + 1.0);
+    const int hw = __builtin_amdgcn_readfirstlane((int)(1.5 * fs / f0 + 1.0));   // f0 is the same in every lane
     const int bl = hw * 2 + 1;
     const double wlt = (2.0 * hw + 1.0) / fs;
     const int lg = 2 + ilog2(bl);  // bl is odd: floor(log2) is exact
@@ -548,49 +566,68 @@ __global__ __launch_bounds__(NT) void hv_refine_kernel(const HvUtt* __restrict__
     {  // window theta_k = 2 pi t_k / wlt, t_k = (basic + k - 1) / fs - pos: one sincos per lane, then
        // rotations by 64 samples; the neighbours the derivative window needs are rotations by one
       const double t = ((basic + lane) - 1.0) / fs - pos;
-      double sn, cs, rs, rc, ds1, dc1;
+      double sn, cs;
       sincospi(2.0 * t / wlt, &sn, &cs);
-      sincospi(2.0 * 64.0 / (fs * wlt), &rs, &rc);
-      sincospi(2.0 / (fs * wlt), &ds1, &dc1);
+      const double4 rt = rot[hw];
+      const double rs = rt.x, rc = rt.y, ds1 = rt.z, dc1 = rt.w;
       auto win = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
-      for (int k = lane; k < bl; k += 64) {
-        int si = basic + k - 1;
-        si = si < 0 ? 0 : (si > u.yl - 1 ? u.yl - 1 : si);
-        const double xv = y[si];
-        const double mw = win(cs);
-        const double up = win(cs * dc1 - sn * ds1), dn = win(cs * dc1 + sn * ds1);  // mw[k + 1], mw[k - 1]
-        double dw;
-        if (k == 0) dw = -up / 2.0;
-        else if (k == bl - 1) dw = dn / 2.0;
-        else dw = -(up - dn) / 2.0;
-        ams[k] = xv * mw;
-        ads[k] = xv * dw;
-        const double c2 = cs * rc - sn * rs;
-        sn = sn * rc + cs * rs;
-        cs = c2;
+      // four rows of 64 samples at a time, their loads in flight together (one trip to the cache per
+      // slot for windows of up to 256 samples instead of one per row)
+      for (int k0 = lane; k0 < bl; k0 += 256) {
+        double xq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int si = basic + (k0 + 64 * q) - 1;
+          si = si < 0 ? 0 : (si > u.yl - 1 ? u.yl - 1 : si);
+          xq[q] = y[si];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = k0 + 64 * q;
+          if (k < bl) {
+            const double xv = xq[q];
+            const double mw = win(cs);
+            const double up = win(cs * dc1 - sn * ds1), dn = win(cs * dc1 + sn * ds1);  // mw[k + 1], mw[k - 1]
+            double dw;
+            if (k == 0) dw = -up / 2.0;
+            else if (k == bl - 1) dw = dn / 2.0;
+            else dw = -(up - dn) / 2.0;
+            wsamp[k] = make_double2(xv * mw, xv * dw);
+            const double c2 = cs * rc - sn * rs;
+            sn = sn * rc + cs * rs;
+            cs = c2;
+          }
+        }
       }
     }
     const int nh = min((int)(fs / 2.0 / f0), 6);
     const int idx = min(mround(f0 * fft / fs * (hh + 1)), fft / 2);
     double mr = 0.0, mi = 0.0, dr = 0.0, di = 0.0;
     if (hh < nh) {
-      const int step = (idx * 8) & (fft - 1);
-      int m = (idx * g) & (fft - 1);
-      for (int k = g; k < bl; k += 8) {
-        double2 w;  // exp(-2 pi i m / fft)
-        if (m < fft / 2) {
-          w = tw[m * tstride];
-          w.y = -w.y;
-        } else {
-          w = tw[(m - fft / 2) * tstride];
-          w.x = -w.x;
-        }
-        const double am = ams[k], ad = ads[k];
-        mr += am * w.x;
-        mi += am * w.y;
-        dr += ad * w.x;
-        di += ad * w.y;
-        m = (m + step) & (fft - 1);
+      // factor of sample k and bin idx: entry (idx k mod fft) * tstride of the circle, walked as a byte
+      // offset; four samples per trip with their LDS reads in flight together, the sums keep their
+      // order in k
+      const uint32_t maskb = (uint32_t)p.fft_max * 16u - 1u;
+      const uint32_t stepb = (uint32_t)(((idx * 8) & (fft - 1)) * tstride) * 16u;
+      uint32_t mb = (uint32_t)(((idx * g) & (fft - 1)) * tstride) * 16u;
+      const char* twb = reinterpret_cast<const char*>(tw);
+      auto factor = [&](uint32_t ofs) { return *reinterpret_cast<const double2*>(twb + ofs); };
+      int k = g;
+      for (; k + 24 < bl; k += 32) {
+        const uint32_t m1 = (mb + stepb) & maskb, m2 = (m1 + stepb) & maskb, m3 = (m2 + stepb) & maskb;
+        const double2 w0 = factor(mb), w1 = factor(m1), w2 = factor(m2), w3 = factor(m3);
+        const double2 s0 = wsamp[k], s1 = wsamp[k + 8], s2 = wsamp[k + 16], s3 = wsamp[k + 24];
+        mb = (m3 + stepb) & maskb;
+        mr += s0.x * w0.x; mi += s0.x * w0.y; dr += s0.y * w0.x; di += s0.y * w0.y;
+        mr += s1.x * w1.x; mi += s1.x * w1.y; dr += s1.y * w1.x; di += s1.y * w1.y;
+        mr += s2.x * w2.x; mi += s2.x * w2.y; dr += s2.y * w2.x; di += s2.y * w2.y;
+        mr += s3.x * w3.x; mi += s3.x * w3.y; dr += s3.y * w3.x; di += s3.y * w3.y;
+      }
+      for (; k < bl; k += 8) {
+        const double2 w0 = factor(mb);
+        const double2 s0 = wsamp[k];
+        mb = (mb + stepb) & maskb;
+        mr += s0.x * w0.x; mi += s0.x * w0.y; dr += s0.y * w0.x; di += s0.y * w0.y;
       }
     }
 #pragma unroll
@@ -1292,6 +1329,8 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
            *d_base = nullptr, *d_cand = nullptr, *d_ctr = nullptr, *d_mc = nullptr, *d_sm = nullptr;
     int *d_cnt = nullptr, *d_nc = nullptr;
     double* d_coef = nullptr;
+    double4* d_rot = nullptr;
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_rot, (size_t)(p.bl_max / 2 + 1) * sizeof(double4), s));
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_coef, (size_t)U * p.nch * 3 * 8, s));
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_utts, U * sizeof(HvUtt), s));
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_y, y_n * 8, s));
@@ -1335,12 +1374,15 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
                        d_base, d_nc);
     ITTS_LAUNCH_CHECK();
     {
-      const size_t lds = (size_t)(p.fft_max / 2) * 16 + (size_t)HV_REFINE_FRAMES * 2 * (p.bl_max + 2) * 8;
+      const int hw_max = p.bl_max / 2;
+      hipLaunchKernelGGL(hv_rot_table_kernel, dim3(hw_max / 64 + 1), dim3(64), 0, s, p.afs, hw_max, d_rot);
+      ITTS_LAUNCH_CHECK();
+      const size_t lds = (size_t)p.fft_max * 16 + (size_t)HV_REFINE_FRAMES * (p.bl_max + 2) * 16;
       ITTS_REQUIRE(lds <= 160 * 1024, "refinement window does not fit the LDS");
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)hv_refine_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(hv_refine_kernel, dim3((max_T1 + HV_REFINE_FRAMES - 1) / HV_REFINE_FRAMES, U),
-                         dim3(NT), lds, s, d_utts, p, ctx->tw_compact[p.log_fft_max], d_y, d_base, d_nc,
+                         dim3(NT), lds, s, d_utts, p, ctx->tw_compact[p.log_fft_max], d_rot, d_y, d_base, d_nc,
                          d_cand, d_score);
       ITTS_LAUNCH_CHECK();
     }
@@ -1385,6 +1427,7 @@ extern "C" int itts_harvest(const double* d_x, const int64_t* h_x_off, const int
     ITTS_HIP_CHECK(itts::scratch_free(d_cnt, s));
     ITTS_HIP_CHECK(itts::scratch_free(d_nc, s));
     ITTS_HIP_CHECK(itts::scratch_free(d_coef, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_rot, s));
     u0 = u1;
   }
   int64_t* slot = pinned_slot(ctx);
