@@ -86,6 +86,7 @@ struct Args {
   int kchunk;                 // reduction elements per split-K slab (multiple of 32)
   int splitk;
   int tiles_m, tiles_n;
+  int gn;                     // column tiles per group of the tile order (decode_tile); >= tiles_n: one group
   int act;
   float gscale;               // EPI_MSE
 };
@@ -156,8 +157,18 @@ __device__ __forceinline__ Tile decode_tile(const Args& g, int t, int bmt, int b
   const int per_z = g.tiles_m * g.tiles_n;
   c.z = t / per_z;
   const int rem = t - c.z * per_z;
-  const int tm = rem / g.tiles_n;
-  c.tn = rem - tm * g.tiles_n;
+  // order inside a slab: groups of gn column tiles; inside a group row by row.  The workgroups of an XCD
+  // walk neighbouring tiles at the same time, so a group's B panels (gn x bnt x K) stay in its L2 while
+  // the A panels stream past once per group -- with one group (gn >= tiles_n) it is B that streams past
+  // every pair of A panels, which costs a wide, deep B (the recurrent layers' 4096 x 1024 weights: 16 MB
+  // against 4 MB of L2) a trip beyond the L2 per tile.
+  const int per_group = g.tiles_m * g.gn;
+  const int grp = rem / per_group;
+  const int rem2 = rem - grp * per_group;
+  const int left = g.tiles_n - grp * g.gn;
+  const int width = left < g.gn ? left : g.gn;
+  const int tm = rem2 / width;
+  c.tn = grp * g.gn + (rem2 - tm * width);
   c.m0 = tm * bmt;
   c.n0 = c.tn * bnt;
   c.kbeg = c.z * g.kchunk;

@@ -441,6 +441,8 @@ static bool ring_ok(const GemmArgs& g, int splitk, int epi) {
   return true;
 }
 
+static int ring_group(int tiles_n, int bnt, int64_t K, bool row_row);
+
 template <bool A_ROW, bool B_ROW, int EPI, int WM>
 static int launch_ring_wm(const GemmArgs& g, int splitk, hipStream_t s) {
   constexpr int BMT = 64 * WM, BNT = 32 * (4 / WM);
@@ -452,6 +454,7 @@ static int launch_ring_wm(const GemmArgs& g, int splitk, hipStream_t s) {
   r.M = (int)g.M; r.N = g.N; r.K = (int)g.K; r.kchunk = (int)g.kchunk; r.splitk = splitk;
   r.tiles_m = (int)((g.M + BMT - 1) / BMT);
   r.tiles_n = (g.N + BNT - 1) / BNT;
+  r.gn = ring_group(r.tiles_n, BNT, g.K, A_ROW && B_ROW);
   r.act = g.act; r.gscale = g.gscale;
   const int64_t ntiles = (int64_t)r.tiles_m * r.tiles_n * splitk;
   ITTS_REQUIRE(ntiles < ((int64_t)1 << 31), "too many tiles");
@@ -459,6 +462,17 @@ static int launch_ring_wm(const GemmArgs& g, int splitk, hipStream_t s) {
   hipLaunchKernelGGL((ring::gemm_ring_kernel<A_ROW, B_ROW, EPI, WM>), dim3(grid), dim3(ring::THREADS), 0, s, r);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
+}
+
+// Column tiles per group of the tile order (ring::decode_tile).  Forward products (row x row) whose weight
+// matrix is larger than an XCD's L2 -- the recurrent layers' [4096 x 1024] input projections, 16 MB -- walk
+// groups of ~4 MB of weight panels (4.78 -> 4.54 ms for 73 138 rows, scripts/ring_order_probe.py); every
+// other product keeps one group (the weight-gradient products measured 2-3 % slower in groups).
+static int ring_group(int tiles_n, int bnt, int64_t K, bool row_row) {
+  if (!row_row) return tiles_n;
+  const int64_t panel = (int64_t)bnt * K * 4;
+  const int64_t gn = std::max<int64_t>(1, ((int64_t)4 << 20) / std::max<int64_t>(panel, 1));
+  return (int)std::min<int64_t>(gn, tiles_n);
 }
 
 // tile shape of the ring kernel for an [M x N] output: 128 x 64 or 64 x 128, whichever wastes less
@@ -485,6 +499,7 @@ static ring::Args ring_args(const GemmArgs& g, int splitk) {
   r.M = (int)g.M; r.N = g.N; r.K = (int)g.K; r.kchunk = (int)g.kchunk; r.splitk = splitk;
   r.tiles_m = (int)((g.M + BMT - 1) / BMT);
   r.tiles_n = (g.N + BNT - 1) / BNT;
+  r.gn = r.tiles_n;
   r.act = g.act; r.gscale = g.gscale;
   return r;
 }

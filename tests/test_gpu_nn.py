@@ -31,6 +31,22 @@ def test_linear_fwd(gpu, M, N, K, act):
     assert (y - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(3000, 2500, 1024), (700, 4096, 1028), (1500, 1100, 2048)])
+def test_linear_fwd_with_weights_larger_than_the_l2_walks_column_groups(gpu, M, N, K):
+    """Weight matrices above ~4 MB change the tile order of the forward product (groups of column
+    tiles, nn.hip ring_group / ring::decode_tile); N is chosen so that the last group is narrower.
+    Every output element is checked (reference: torch fp64 on the GPU)."""
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.rand(M, K, generator=g).to(gpu)
+    w = ((torch.rand(N, K, generator=g) - 0.5) * (2.0 / K ** 0.5)).to(gpu)
+    b = (torch.rand(N, generator=g) - 0.5).to(gpu)
+    ref = torch.tanh(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+    y = ops.linear_fwd(x, w, b, 1).double()
+    assert _rel(y, ref) < 2e-6
+    assert (y - ref).abs().max().item() < 2e-5
+
+
 def test_linear_fwd_strided_rows(gpu):
     from idiaptts_amd import ops
     g = torch.Generator().manual_seed(3)
