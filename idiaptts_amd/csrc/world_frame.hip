@@ -547,13 +547,22 @@ __global__ void code_aperiodicity_kernel(const double* __restrict__ ap, int64_t 
   if (bap_f32) bap_f32[i] = (float)v;
 }
 
-__global__ void decode_aperiodicity_kernel(const double* __restrict__ bap, int64_t T, int fs, int fft_size,
-                                           int nap, double* __restrict__ ap) {
+// A workgroup owns DA_FRAMES consecutive frames (contiguous in the output); element e of its range is
+// bin k of its frame tl with e = tl (2^lg + 1) + k -- a shift and a correction instead of the 64-bit
+// division a flat element index needs (the pass was VALU-bound on it: 0.54 ms for 1.3 GB out).
+constexpr int DA_FRAMES = 8;
+__global__ __launch_bounds__(256) void decode_aperiodicity_kernel(const double* __restrict__ bap, int64_t T, int fs,
+                                                                  int fft_size, int lg, int nap,
+                                                                  double* __restrict__ ap) {
   const int K = fft_size / 2 + 1;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= T * K) return;
-  const int64_t t = i / K;
-  const int k = (int)(i - t * K);
+  const int64_t t0 = (int64_t)blockIdx.x * DA_FRAMES;
+  const int nfr = (int)(T - t0 < DA_FRAMES ? T - t0 : DA_FRAMES);
+  for (int e = threadIdx.x; e < nfr * K; e += 256) {
+  int tl = e >> lg;
+  int k = (e & ((1 << lg) - 1)) - tl;
+  if (k < 0) { --tl; k += K; }
+  const int64_t t = t0 + tl;
+  const int64_t i = t * K + k;
   double cfa[8], cap[8];
   double mean = 0.0;
   for (int b = 0; b < nap; ++b) {
@@ -575,6 +584,7 @@ __global__ void decode_aperiodicity_kernel(const double* __restrict__ bap, int64
     v = fm::fexp(interp1_small(cfa, cap, nap + 2, f) * (2.30258509299404568402 / 20.0));
   }
   ap[i] = v;
+  }
 }
 
 // mcep_lockstep.hip
@@ -779,9 +789,9 @@ extern "C" int itts_decode_aperiodicity(const double* d_bap, int64_t T, int fs, 
   const int nap = itts_num_aperiodicities(fs);
   ITTS_REQUIRE(T >= 0 && nap >= 1 && nap <= 5 && is_pow2(fft_size), "bad sizes");
   if (T == 0) return ITTS_OK;
-  const int64_t n = T * (fft_size / 2 + 1);
-  hipLaunchKernelGGL(decode_aperiodicity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     as_stream(stream), d_bap, T, fs, fft_size, nap, d_ap);
+  ITTS_REQUIRE(fft_size >= 32 && (T + DA_FRAMES - 1) / DA_FRAMES < ((int64_t)1 << 31), "bad sizes");
+  hipLaunchKernelGGL(decode_aperiodicity_kernel, dim3((unsigned)((T + DA_FRAMES - 1) / DA_FRAMES)), dim3(256), 0,
+                     as_stream(stream), d_bap, T, fs, fft_size, ilog2_host(fft_size / 2), nap, d_ap);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
