@@ -152,6 +152,7 @@ struct Tile {
   int kbeg, klen, nk;
 };
 
+template <bool GROUPED>
 __device__ __forceinline__ Tile decode_tile(const Args& g, int t, int bmt, int bnt) {
   Tile c;
   const int per_z = g.tiles_m * g.tiles_n;
@@ -162,13 +163,19 @@ __device__ __forceinline__ Tile decode_tile(const Args& g, int t, int bmt, int b
   // the A panels stream past once per group -- with one group (gn >= tiles_n) it is B that streams past
   // every pair of A panels, which costs a wide, deep B (the recurrent layers' 4096 x 1024 weights: 16 MB
   // against 4 MB of L2) a trip beyond the L2 per tile.
-  const int per_group = g.tiles_m * g.gn;
-  const int grp = rem / per_group;
-  const int rem2 = rem - grp * per_group;
-  const int left = g.tiles_n - grp * g.gn;
-  const int width = left < g.gn ? left : g.gn;
-  const int tm = rem2 / width;
-  c.tn = grp * g.gn + (rem2 - tm * width);
+  int tm;
+  if (!GROUPED) {                   // one group: column tile fastest
+    tm = rem / g.tiles_n;
+    c.tn = rem - tm * g.tiles_n;
+  } else {
+    const int per_group = g.tiles_m * g.gn;
+    const int grp = rem / per_group;
+    const int rem2 = rem - grp * per_group;
+    const int left = g.tiles_n - grp * g.gn;
+    const int width = left < g.gn ? left : g.gn;
+    tm = rem2 / width;
+    c.tn = grp * g.gn + (rem2 - tm * width);
+  }
   c.m0 = tm * bmt;
   c.n0 = c.tn * bnt;
   c.kbeg = c.z * g.kchunk;
@@ -285,7 +292,7 @@ __device__ __forceinline__ void zero_tail(char* tile, int krem, int tid) {
   }
 }
 
-template <bool A_ROW, bool B_ROW, int BMT, int BNT>
+template <bool A_ROW, bool B_ROW, int BMT, int BNT, bool GROUPED = false>
 __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t lds0, int lane, bool mse, int part) {
   constexpr int A_BYTES = BMT * 128;
   const Walk w = my_tiles(g);
@@ -300,7 +307,7 @@ __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t l
   uint32_t pdst = lds0;
   bool pvalid = pt < w.end;
   auto open = [&]() {
-    const Tile c = decode_tile(g, pt, BMT, BNT);
+    const Tile c = decode_tile<GROUPED>(g, pt, BMT, BNT);
     sa.open(g.A, g.lda, c.m0, g.M, c);
     sb.open(g.B, g.ldb, c.n0, g.N, c);
     pnk = c.nk;
@@ -328,7 +335,7 @@ __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t l
   int ct = w.first, kt = 0, cslot = 0;
   bool have = ct < w.end;
   Tile c{};
-  if (have) c = decode_tile(g, ct, BMT, BNT);
+  if (have) c = decode_tile<GROUPED>(g, ct, BMT, BNT);
   while (have) {
     // the pieces of this step have landed (those of the next one stay in flight)
     if (ahead >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PIECES) : "memory");
@@ -346,7 +353,7 @@ __device__ __forceinline__ void loader_wave(const Args& g, char* lds, uint32_t l
       kt = 0;
       ct += w.stride;
       have = ct < w.end;
-      if (have) c = decode_tile(g, ct, BMT, BNT);
+      if (have) c = decode_tile<GROUPED>(g, ct, BMT, BNT);
     }
   }
   // barriers beyond the K-steps: the entry of the last epilogue, EPI_MSE's reduction
@@ -476,7 +483,7 @@ __device__ __forceinline__ void epilogue(const Args& g, const Tile& pc, const f3
   }
 }
 
-template <bool A_ROW, bool B_ROW, int EPI, int BMT, int BNT>
+template <bool A_ROW, bool B_ROW, int EPI, int BMT, int BNT, bool GROUPED = false>
 __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid, int lane) {
   constexpr int WN = BNT / 32;
   constexpr int A_BYTES = BMT * 128;
@@ -502,7 +509,7 @@ __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid,
   int ct = w.first;
   bool have = ct < w.end;
   Tile c{};
-  if (have) c = decode_tile(g, ct, BMT, BNT);
+  if (have) c = decode_tile<GROUPED>(g, ct, BMT, BNT);
   int kt = 0;
   while (have || pending) {
     // step entry: behind the barrier the slot of this step is complete and everybody has left the
@@ -593,7 +600,7 @@ __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid,
       kt = 0;
       ct += w.stride;
       have = ct < w.end;
-      if (have) c = decode_tile(g, ct, BMT, BNT);
+      if (have) c = decode_tile<GROUPED>(g, ct, BMT, BNT);
     }
   }
   if (EPI == EPI_MSE) {
@@ -608,7 +615,9 @@ __device__ __forceinline__ void compute_waves(const Args& g, char* lds, int wid,
 }
 
 // WM = compute waves along the A (row) dimension: 2 -> 128 x 64 tile, 1 -> 64 x 128 tile.
-template <bool A_ROW, bool B_ROW, int EPI, int WM>
+// GROUPED: the tile order in groups of g.gn column tiles (decode_tile); a kernel of its own so that the
+// plain order's code is untouched (as a run-time branch it cost the FF step 1 %, same box, same day).
+template <bool A_ROW, bool B_ROW, int EPI, int WM, bool GROUPED = false>
 __global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_kernel(Args g) {
   constexpr int BMT = 64 * WM, BNT = 32 * (4 / WM);
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -618,9 +627,9 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS + 255) / 256) void gemm_ring_
   uint64_t t0c = 0, t0r = 0;
   if (g.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
   if (wid >= 4) {
-    loader_wave<A_ROW, B_ROW, BMT, BNT>(g, lds, lds0, lane, EPI == EPI_MSE, wid - 4);
+    loader_wave<A_ROW, B_ROW, BMT, BNT, GROUPED>(g, lds, lds0, lane, EPI == EPI_MSE, wid - 4);
   } else {
-    compute_waves<A_ROW, B_ROW, EPI, BMT, BNT>(g, lds, wid, lane);
+    compute_waves<A_ROW, B_ROW, EPI, BMT, BNT, GROUPED>(g, lds, wid, lane);
   }
   if (g.stamps && threadIdx.x == 0) {
     g.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;

@@ -459,7 +459,11 @@ static int launch_ring_wm(const GemmArgs& g, int splitk, hipStream_t s) {
   const int64_t ntiles = (int64_t)r.tiles_m * r.tiles_n * splitk;
   ITTS_REQUIRE(ntiles < ((int64_t)1 << 31), "too many tiles");
   const int grid = (int)std::min<int64_t>(kRingGrid, (ntiles + 7) / 8 * 8);
-  hipLaunchKernelGGL((ring::gemm_ring_kernel<A_ROW, B_ROW, EPI, WM>), dim3(grid), dim3(ring::THREADS), 0, s, r);
+  if (A_ROW && B_ROW && EPI == ring::EPI_BIAS_ACT && r.gn < r.tiles_n)
+    hipLaunchKernelGGL((ring::gemm_ring_kernel<A_ROW, B_ROW, EPI, WM, A_ROW && B_ROW && EPI == ring::EPI_BIAS_ACT>),
+                       dim3(grid), dim3(ring::THREADS), 0, s, r);
+  else
+    hipLaunchKernelGGL((ring::gemm_ring_kernel<A_ROW, B_ROW, EPI, WM>), dim3(grid), dim3(ring::THREADS), 0, s, r);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }
