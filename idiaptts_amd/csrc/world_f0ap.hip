@@ -189,21 +189,33 @@ __global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves)
     sincospi(2.0 * 64.0 / (fs * wlt), &rs, &rc);
     sincospi(2.0 / (fs * wlt), &ds1, &dc1);
     auto win = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
-    for (int i = lane; i < n; i += 64) {
-      int64_t idx = i0 + i - 1;
-      idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
-      const double xv = x[idx];
-      const double mw = win(cs);
-      const double up = win(cs * dc1 - sn * ds1), dn = win(cs * dc1 + sn * ds1);
-      double dw;
-      if (i == 0) dw = -up / 2.0;
-      else if (i == n - 1) dw = dn / 2.0;
-      else dw = -(up - dn) / 2.0;
-      sm[i] = xv * mw;
-      sd[i] = xv * dw;
-      const double c2 = cs * rc - sn * rs;
-      sn = sn * rc + cs * rs;
-      cs = c2;
+    // four rows of 64 samples per trip, their loads in flight together
+    for (int ib = lane; ib < n; ib += 256) {
+      double xq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int64_t idx = i0 + (ib + 64 * q) - 1;
+        idx = idx < 0 ? 0 : (idx > xl - 1 ? xl - 1 : idx);
+        xq[q] = x[idx];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib + 64 * q;
+        if (i < n) {
+          const double xv = xq[q];
+          const double mw = win(cs);
+          const double up = win(cs * dc1 - sn * ds1), dn = win(cs * dc1 + sn * ds1);
+          double dw;
+          if (i == 0) dw = -up / 2.0;
+          else if (i == n - 1) dw = dn / 2.0;
+          else dw = -(up - dn) / 2.0;
+          sm[i] = xv * mw;
+          sd[i] = xv * dw;
+          const double c2 = cs * rc - sn * rs;
+          sn = sn * rc + cs * rs;
+          cs = c2;
+        }
+      }
     }
   }
   // spectra (main M, diff D) at `nh` harmonic bins of `base`; lanes = 2^hb harmonics x 2^(6-hb) phases
@@ -215,7 +227,29 @@ __global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves)
     if (hq < nh) {
       const int step = (int)(((long long)bin * phases) % fft);
       int k = (int)(((long long)bin * ph) % fft);
-      for (int i = ph; i < n; i += phases) {
+      // four samples per trip: their factors (a gather from the 128-KB master table: a trip to the L2
+      // each) and samples are requested together; the sums keep their order in i
+      int i = ph;
+      for (; i + 3 * phases < n; i += 4 * phases) {
+        double2 w[4];
+        double vm[4], vd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w[q] = twiddle_neg(a.g_tw, k, fft);
+          vm[q] = sm[i + q * phases];
+          vd[q] = sd[i + q * phases];
+          k += step;
+          if (k >= fft) k -= fft;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          mr += vm[q] * w[q].x;
+          mi += vm[q] * w[q].y;
+          dr += vd[q] * w[q].x;
+          di += vd[q] * w[q].y;
+        }
+      }
+      for (; i < n; i += phases) {
         const double2 w = twiddle_neg(a.g_tw, k, fft);
         const double vm = sm[i], vd = sd[i];
         mr += vm * w.x;
