@@ -565,15 +565,20 @@ __device__ __forceinline__ void fu_reduce(const FuFac& c, const double (&b)[FU_F
                                           double (&tl)[6], double (&e)[4], FuMats& m) {
   double kd = 0.0, k1 = 0.0, k2 = 0.0;
   double l1p, l2p, cprev;
-  double pd[PRELOAD ? FU_FL : 1], p1[PRELOAD ? FU_FL : 1], p2[PRELOAD ? FU_FL : 1];
-  if (PRELOAD && !CONST) {
+  // (in two halves: the scan kernel that uses this runs sixteen waves per workgroup, 128 registers each,
+  // and 3 x 16 doubles of factor rows on top of the walk's state spilled -- 836 bytes of scratch per lane,
+  // 14-17 us for the matrices of ONE chunk; two trips to memory instead of one, no spill)
+  constexpr int PH = PRELOAD ? FU_FL / 2 : 1;
+  double pd[PH], p1[PH], p2[PH];
+  auto preload = [&](int h) {
 #pragma unroll
-    for (int i = 0; i < FU_FL; ++i) {
-      const int64_t j = j0 + i;
+    for (int i = 0; i < PH; ++i) {
+      const int64_t j = j0 + h * PH + i;
       const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;      // always a valid row of the factor
       pd[i] = c.fd[jc]; p1[i] = c.fl1[jc]; p2[i] = c.fl2[jc];
     }
-  }
+  };
+  if (PRELOAD && !CONST) preload(0);
   if (CONST) {
     kd = c.fd[c.ncv * c.D];
     k1 = c.fl1[c.ncv * c.D];
@@ -606,13 +611,14 @@ __device__ __forceinline__ void fu_reduce(const FuFac& c, const double (&b)[FU_F
   };
 #pragma unroll
   for (int i = 0; i < FU_FL; ++i) {
+    if (PRELOAD && !CONST && i == PH) preload(1);
     if (CONST || i < n_main) {
       const int64_t j = j0 + i;
       double dd, l1, l2;
       if (CONST) {
         dd = kd; l1 = k1; l2 = k2;
       } else if (PRELOAD) {
-        dd = pd[i]; l1 = p1[i]; l2 = p2[i];
+        dd = pd[i % PH]; l1 = p1[i % PH]; l2 = p2[i % PH];
       } else {
         const int64_t jc = (j < c.ncv ? j : c.ncv) * c.D;
         dd = c.fd[jc]; l1 = c.fl1[jc]; l2 = c.fl2[jc];
@@ -839,7 +845,7 @@ __global__ __launch_bounds__(GW * 64) void mlpg_reduce_kernel(StreamArgs g) {
 // the data-independent matrices of chunk k of an utterance (any chunk; not inlined: the scan kernel
 // calls it from many places and must stay small enough for the instruction cache)
 template <int FU_FL>
-__device__ __noinline__ void st_chunk_mats(const FuFac& c, int K, int64_t T, int k, FuMats& m) {
+__device__ __forceinline__ void st_chunk_mats(const FuFac& c, int K, int64_t T, int k, FuMats& m) {
   double none[FU_FL], e4[4], tl[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
   const int64_t j0 = fu_chunk_start<FU_FL>(k, K, T), j1 = fu_chunk_start<FU_FL>(k + 1, K, T);
   fu_reduce<FU_FL, false, false, true, true>(c, none, j0, (int)(j1 - j0), tl, e4, m);
