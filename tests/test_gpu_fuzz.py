@@ -59,3 +59,12 @@ def test_gemm_random_shapes(gpu):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:]
     assert "cases 60" in res.stdout
+
+
+def test_grouped_tile_order_random_shapes(gpu):
+    """Forward products with more than ~4 MB of weights walk groups of column tiles (nn.hip ring_group):
+    25 random shapes, every output element against torch fp64 (scripts/grouped_order_fuzz.py)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "grouped_order_fuzz.py"), "25"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert "cases 25" in res.stdout
