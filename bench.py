@@ -169,12 +169,15 @@ def host_info():
     return {"cpu_model": model, "usable_cores": usable_cores(), "logical_cpus": os.cpu_count()}
 
 
-def cpu_baseline_bilstm(max_seconds=25.0, threads=None):
+def cpu_baseline_bilstm(max_seconds=25.0, threads=None, n_utts=16):
     """The reference's config-3 stack on the host: torch.nn.LSTM(425, 512, 3, bidirectional) on a
     PackedSequence (rnn_dyn/RNNWrapper.py:45-107) + Linear(1024, 187), masked MSE mean_per_frame,
-    Adam.  Bounded sample: one training step on the first utterances of config 3's batch, as many as
-    the budget allows at the ~50 frames/s torch's CPU LSTM reaches; the sample says how many and what
-    the full batch extrapolates to."""
+    Adam.  Bounded sample: ONE training step on the first `n_utts` (16) utterances of config 3's batch of
+    64, each cut to its first `cap` frames -- the host's cost is one set of small GEMMs per time step and
+    layer whatever the batch width, so a step is linear in the padded length; `cap` is chosen from a
+    pilot step so that the timed step fits the budget.  The extrapolation to the configuration (64
+    utterances, 1 977 time steps) is stated beside the sample's own rate and is an UPPER bound for the
+    host (it prices the 64-row step at the 16-row step's cost per time step)."""
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     from idiaptts_amd.bench_support import make_ff_batch, pad_batch
     torch.manual_seed(0)
@@ -184,10 +187,12 @@ def cpu_baseline_bilstm(max_seconds=25.0, threads=None):
     torch.set_num_threads(threads or min(usable_cores(), 32))
     x, y, lengths = make_ff_batch(64, seed=7)       # the batch of the GPU section
     offs = np.concatenate([[0], np.cumsum(lengths)])
+    full_T, full_frames = int(lengths.max()), int(lengths.sum())
 
-    def step(n_utts):
-        lt = torch.from_numpy(lengths[:n_utts])
-        xs, ys = x[:offs[n_utts]], y[:offs[n_utts]]
+    def step(n, cap):
+        lt = torch.from_numpy(np.minimum(lengths[:n], cap))
+        xs = torch.cat([x[offs[i]:offs[i] + int(lt[i])] for i in range(n)])
+        ys = torch.cat([y[offs[i]:offs[i] + int(lt[i])] for i in range(n)])
         xp, yp = pad_batch(xs, lt).transpose(0, 1).contiguous(), pad_batch(ys, lt).transpose(0, 1).contiguous()
         T = xp.shape[0]
         mask = (torch.arange(T)[:, None] < lt[None, :]).unsqueeze(-1).float()
@@ -199,31 +204,37 @@ def cpu_baseline_bilstm(max_seconds=25.0, threads=None):
         opt.zero_grad()
         loss.backward()
         opt.step()
-        return time.perf_counter() - t, int(lt.sum())
+        return time.perf_counter() - t, int(lt.sum()), T
 
-    # torch's CPU LSTM runs ~50 valid frames/s on these hosts (16 threads; measured in this repository's
-    # rounds 3 and 4 on 4 and 16 utterances): config 3's 73 138-frame batch would take over twenty
-    # minutes per step.  The bounded sample: a tiny warm-up batch (thread pool, allocations), then one
-    # timed step on as many of the batch's utterances as the budget allows at that rate (at least one).
+    # The cost per time step grows with the padded length (autograd keeps every step's tensors, the host's caches
+    # give out), so the length is doubled from 32 frames until the NEXT doubling would not fit what is left of the
+    # budget at twice the last cost per time step; the last completed step is the sample.
     t_start = time.perf_counter()
-    lengths_all = lengths
-    lengths = np.minimum(lengths_all, 40)
-    offs = np.concatenate([[0], np.cumsum(lengths)])
-    step(2)
-    lengths = lengths_all
-    offs = np.concatenate([[0], np.cumsum(lengths)])
-    budget_frames = max(0.0, max_seconds - (time.perf_counter() - t_start)) * 50.0
-    n_used = int(max(1, min(64, np.searchsorted(np.cumsum(lengths), budget_frames))))
-    dt, frames = step(n_used)
-    note = "config 3's full batch" if n_used == 64 else \
-        ("{} of config 3's 64 utterances: at this rate the full batch of 73 138 frames takes {:.0f} s per "
-         "step; the host's cost is linear in the frames (the recurrence is sequential in T whatever the "
-         "batch), larger batches amortise slightly better (rounds 3 / 4: 44 frames/s on 4 utterances, 55 on "
-         "16)".format(n_used, 73138.0 * dt / frames))
+    step(n_utts, 16)                             # thread pool, allocations, oneDNN primitives of this width
+    cap = 32
+    dt, frames, T = step(n_utts, cap)
+    while cap < full_T:
+        left = max_seconds - (time.perf_counter() - t_start)
+        nxt = min(2 * cap, full_T)
+        if 2.0 * (dt / T) * nxt > left:
+            break
+        cap = nxt
+        dt, frames, T = step(n_utts, cap)
+    per_time_step = dt / T
+    full_step_s = per_time_step * full_T
     return {"kind": "port", "cores": torch.get_num_threads(), "value": frames / dt,
-            "unit": "valid frames/s", "utterances": n_used,
-            "sample": "1 training step of torch.nn.LSTM(425,512,3,bidirectional)+Linear on {} padded "
-                      "utterances ({} valid frames, {:.1f} s; {})".format(n_used, frames, dt, note)}
+            "unit": "valid frames/s", "utterances": n_utts, "time_steps": T,
+            "seconds_per_time_step": per_time_step,
+            "extrapolated_config3_step_s": full_step_s,
+            "extrapolated_config3_valid_frames_per_s_upper_bound": full_frames / full_step_s,
+            "sample": "1 training step of torch.nn.LSTM(425,512,3,bidirectional)+Linear on the first {} of "
+                      "config 3's 64 padded utterances, each cut to its first {} frames ({} valid frames, "
+                      "{:.1f} s, {:.1f} ms per time step).  Extrapolation: the configuration's {} time steps "
+                      "at this cost per time step = {:.0f} s per step of {} valid frames, i.e. at most {:.0f} "
+                      "valid frames/s for the 64-utterance batch (an upper bound for the host: a 64-row step "
+                      "costs at least what a 16-row step does)".format(
+                          n_utts, cap, frames, dt, per_time_step * 1e3, full_T, full_step_s, full_frames,
+                          full_frames / full_step_s)}
 
 
 def hip_event_time_ms(fn, stream, iters):
@@ -613,9 +624,12 @@ def bilstm_section(dev, n_utts=64, steps=6, cell="LSTM", rank=0, world=1, key=No
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for s in range(steps):
-        ld, _ = h.process_batch(data, lens, s + 2, training=True)
+        # blocking=False: the NaN guard of a step is looked at when the next one has been queued
+        ld, _ = h.process_batch(data, lens, s + 2, training=True, blocking=False)
     e1.record(stream)
     e1.synchronize()
+    h.finish_batches()
+    ld = {k: float(v) for k, v in ld.items()}
     dt = e0.elapsed_time(e1) * 1e-3 / steps
     barrier()
     if world > 1:
@@ -741,6 +755,100 @@ def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
     return {"resident_epoch": {"utterances": n_utts, "frames": n, "batch_utts": batch_utts,
                                "shard_GB": (x.numel() + y.numel()) * 4 / 1e9,
                                "epoch_ms": dt * 1e3, "valid_frames_per_s": n / dt}}
+
+
+def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
+    """One epoch of `AcousticModelTrainer.train` over `n_utts` synthetic LJSpeech-shaped utterances through
+    the PUBLIC API (reference model_trainers/ModularTrainer.py:379-560, AcousticModelTrainer.py), files on
+    disk in the legacy layout the reference's tests use (`<id>.questions` [T, 425] and `cmp_mcep60/<id>.cmp`
+    [T, 187] raw float32 + min-max / mean-covariance `.bin` files): (i) the module path --
+    PyTorchDatareadersDataset + DataLoader + collate + RNNDyn modules + NamedLoss + fused HIP Adam, every
+    utterance read and normalised again each epoch as the reference does; (ii) `hparams.resident_dataset`
+    -- readers run once, the normalised frames stay in HBM, flat feed-forward step.  Two epochs each; the
+    SECOND epoch's `handler.train` call is the one reported (wall clock, device synchronised)."""
+    import logging
+    import shutil
+    import tempfile
+    from idiaptts_amd.bench_support import utterance_lengths
+    from idiaptts_amd.src.model_trainers.AcousticModelTrainer import AcousticModelTrainer
+    root = tempfile.mkdtemp(prefix="itts_trainer_epoch_")
+    out = {"utterances": n_utts, "batch_utts": batch_utts, "model": "RNNDYN-2_TANH_512-1_FC_187"}
+    try:
+        lengths = utterance_lengths(n_utts + n_val, seed=11)
+        ids = ["utt%05d" % i for i in range(n_utts + n_val)]
+        qdir, wdir = os.path.join(root, "questions"), os.path.join(root, "WORLD")
+        os.makedirs(qdir)
+        os.makedirs(os.path.join(wdir, "cmp_mcep60"))
+        rng = np.random.default_rng(17)
+        t0 = time.perf_counter()
+        for i, T in zip(ids, lengths):
+            rng.random((int(T), 425), dtype=np.float32).tofile(os.path.join(qdir, i + ".questions"))
+            rng.standard_normal((int(T), 187), dtype=np.float32).tofile(os.path.join(wdir, "cmp_mcep60", i + ".cmp"))
+        np.stack([np.zeros(425), np.ones(425)]).astype(np.float64).tofile(os.path.join(qdir, "min-max.bin"))
+        for stream, D in (("mcep60", 180), ("lf0", 3), ("bap", 3)):      # mean 0, covariance I: the data is N(0, 1)
+            path = os.path.join(wdir, "cmp_mcep60", stream + "-mean-covariance.bin")
+            with open(path, "wb") as f:
+                np.array([0, D + 1], dtype=np.int32).tofile(f)
+                np.concatenate([np.zeros((1, D)), np.eye(D)]).astype(np.float64).tofile(f)
+        out["files_GB"] = float(lengths.sum()) * (425 + 187) * 4 / 1e9
+        out["files_written_s"] = time.perf_counter() - t0
+        logging.getLogger().setLevel(logging.WARNING)
+        for key, resident in (("module_path", False), ("resident_dataset", True)):
+            hp = AcousticModelTrainer.create_hparams()
+            hp.num_questions = 425
+            hp.voice = "full"
+            hp.out_dir = os.path.join(root, key)
+            hp.frame_size_ms = 5
+            hp.num_coded_sps = 60
+            hp.seed = 1
+            hp.epochs = 2
+            hp.use_gpu = True
+            hp.dataset_num_workers_gpu = 0
+            hp.model_type = "RNNDYN-2_TANH_512-1_FC_187"
+            hp.batch_size_train = batch_utts
+            hp.batch_size_val = n_val
+            hp.val_set_perc = n_val / float(n_utts + n_val)
+            hp.test_set_perc = 0.0
+            hp.start_with_test = False
+            hp.epochs_per_test = 1
+            hp.epochs_per_checkpoint = 1000      # (no per-epoch checkpoints; the final model is saved once)
+            hp.use_best_as_final_model = False
+            hp.optimiser_args["lr"] = 0.001
+            hp.model_name = "bench_model"
+            hp.world_dir = wdir
+            hp.resident_dataset = resident
+            trainer = AcousticModelTrainer(**AcousticModelTrainer.legacy_support_init(wdir, qdir, ids, 425, hp))
+            trainer.init(hp)
+            handler = trainer.model_handler
+            epochs = []
+            inner = handler.train
+
+            def timed_train(*a, _inner=inner, **kw):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                r = _inner(*a, **kw)
+                torch.cuda.synchronize()
+                epochs.append(time.perf_counter() - t)
+                return r
+
+            handler.train = timed_train
+            t0 = time.perf_counter()
+            trainer.train(hp)
+            total = time.perf_counter() - t0
+            frames = int(sum(lengths[ids.index(i)] for i in trainer.id_list_train))
+            out[key] = {"train_utterances": len(trainer.id_list_train), "train_frames": frames,
+                        "epoch_s": epochs[-1], "epoch_s_all": [round(e, 4) for e in epochs],
+                        "valid_frames_per_s": frames / epochs[-1],
+                        "train_call_s": total,
+                        "what": "second epoch's handler.train (the first holds warm-up{}); train_call_s is the whole "
+                                "trainer.train call: 2 epochs + 2 validation passes + final checkpoint".format(
+                                    " and the one-off staging of the shards to HBM" if resident else "")}
+            del trainer, handler
+    except Exception as e:      # a bench row must not take the headline line down with it
+        out["error"] = "{}: {}".format(type(e).__name__, e)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return {"trainer_epoch": out}
 
 
 class SclkSampler:
@@ -919,6 +1027,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: initialise RCCL with one rank and issue every collective of "
                          "the N > 1 path anyway (a one-rank sum is the identity)")
+    ap.add_argument("--trainer-utts", type=int, default=1024,
+                    help="utterances of the trainer_epoch row (AcousticModelTrainer.train through the public "
+                         "API on synthetic files in a temporary directory, ~3 GB at 1024; 0 = skip)")
     ap.add_argument("--bilstm-utts", type=int, default=64,
                     help="utterances per GPU of the BiLSTM / BiGRU (config 3) section (0 = skip)")
     args = ap.parse_args()
@@ -1018,6 +1129,36 @@ def main():
     t_launched = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    # GEMM-only replay of the six GEMM launches of a step, RIGHT BEHIND the timed region (same clocks, same
+    # batches in the same order, events on the launch stream): how much of a step its dominant kernel is.
+    # (Round 4 ran this replay after the RNN sections, on batch 0 only: its 1.022 ms per step exceeded the
+    # 1.0095 ms step it was supposed to be a part of.)
+    from idiaptts_amd import ops
+
+    def gemms(i):
+        x, y, valid, nloc = batches[i % n_batches]
+        M = x.shape[0]
+        buf = model._rows_buffer       # the step's own padded-pitch activation buffers
+        W, G = model.weight_padded, model.grads
+        h1 = ops.linear_fwd(x, W(0), model.bias(0), 1, out=buf("h0", M, dims[1]))
+        h2 = ops.linear_fwd(h1, W(1), model.bias(1), 1, out=buf("h1", M, dims[2]))
+        ops.linear_fwd(h2, W(2), model.bias(2), 0, out=buf("h2", M, dims[3]))
+        # the backward launches of the step (native_ff.loss_and_backward): weight, bias and input
+        # gradient of a layer share one launch; dz_out holds the last timed step's loss gradient
+        dz3, dz2, dz1 = buf("dz_out", M, dims[3]), buf("dz0", M, dims[2]), buf("dz1", M, dims[1])
+        ops.linear_bwd(dz3, h2, W(2), W(2, G), model.bias(2, G), dz2, yprev=h2, act_prev=1)
+        ops.linear_bwd(dz2, h1, W(1), W(1, G), model.bias(1, G), dz1, yprev=h1, act_prev=1)
+        ops.linear_bwd_weight(dz1, x, dw=W(0, G), db=model.bias(0, G))
+
+    replay_ms = []
+    for _ in range(3):
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for i in range(args.steps):
+            gemms(i)
+        r1.record(stream)
+        r1.synchronize()
+        replay_ms.append(r0.elapsed_time(r1) / args.steps)
     # The shader clock is sampled AFTER the timed region, over 60 more steps of the same load.  Rounds 2
     # and 3 sampled it (sysfs pp_dpm_sclk, from a thread) DURING the timed steps, and that was the "fixed
     # 2 ms" of the driver's 20-step protocol: the first ~20 ms of such reads slow every step by 10-40 %
@@ -1065,51 +1206,44 @@ def main():
 
     out = None
     if rank == 0:
-        # dominant kernel roofline: the fp32-MFMA GEMM launches of one step, timed live with
-        # events on the launch stream around a GEMM-only replay of the six GEMM launches of the step.
-        from idiaptts_amd import ops
-        x, y, valid, nloc = batches[0]
-        hs = model.forward(x)
-        M = x.shape[0]
-        buf = model._rows_buffer       # the step's own padded-pitch activation buffers
-        _, dz3 = ops.masked_mse(hs[-1], y, valid, float(nloc), grad=buf("dz_out", M, dims[3]))
-        stream = torch.cuda.current_stream()
-
-        def gemms():
-            W, G = model.weight_padded, model.grads
-            h1 = ops.linear_fwd(x, W(0), model.bias(0), 1, out=buf("h0", M, dims[1]))
-            h2 = ops.linear_fwd(h1, W(1), model.bias(1), 1, out=buf("h1", M, dims[2]))
-            ops.linear_fwd(h2, W(2), model.bias(2), 0, out=buf("h2", M, dims[3]))
-            # the backward launches of the step (native_ff.loss_and_backward): weight, bias and input
-            # gradient of a layer share one launch
-            dz2, dz1 = buf("dz0", M, dims[2]), buf("dz1", M, dims[1])
-            ops.linear_bwd(dz3, h2, W(2), W(2, G), model.bias(2, G), dz2, yprev=h2, act_prev=1)
-            ops.linear_bwd(dz2, h1, W(1), W(1, G), model.bias(1, G), dz1, yprev=h1, act_prev=1)
-            ops.linear_bwd_weight(dz1, x, dw=W(0, G), db=model.bias(0, G))
-
-        for _ in range(20):      # the RNN sections above leave the clocks low: ramp up first
-            gemms()
-        torch.cuda.synchronize()
-        ms = hip_event_time_ms(gemms, stream, 50)
-        flops = flops_per_frame(dims) * nloc
-        achieved = flops / (ms * 1e-3) / 1e12
+        # dominant kernel roofline FROM THE TIMED STEPS: algorithmic flops of the K timed batches (this rank's
+        # frames) over the event time of the K timed steps on the launch stream -- the six GEMM launches plus
+        # everything else a step holds (loss reduction, split-K slab sums, Adam), so `achieved` is a lower
+        # bound of the rate the GEMM launches run at; `gemm_replay` is the GEMM-only replay of the same
+        # batches queued right behind the timed region.
+        local_frames = sum(batches[i % n_batches][3] for i in range(args.steps))
+        flops = flops_per_frame(dims) * local_frames
+        ms_step_events = dt_events / args.steps * 1e3
+        achieved = flops / dt_events / 1e12
+        gemm_ms = float(np.median(replay_ms))
         # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
         # see profiles/r4_gemm_traffic.json); not re-measured inside bench.py.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r4_gemm_traffic.json")
-        if not os.path.isfile(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r3g_gemm_traffic.json")
-        if os.path.isfile(tpath) and args.utts_per_gpu == 32:
-            with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        for name in ("r5_gemm_traffic.json", "r4_gemm_traffic.json", "r3g_gemm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.isfile(tpath) and args.utts_per_gpu == 32:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                break
         n_launch = 6    # fwd1, fwd2, fwd3 + MSE, (dW3, db3, dX2), (dW2, db2, dX1), (dW1, db1)
         roofline = {"bound": "mfma",
-                    "kernel": "gemm_ring_kernel / gemm_ring_pair_kernel (6 GEMM launches per step; their "
-                              "split-K slab reductions are inside the timed region)",
+                    "kernel": "gemm_ring_kernel / gemm_ring_pair_kernel (6 GEMM launches per step)",
                     "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
-                    "algorithmic_flops_per_launch": flops / n_launch,
-                    "gemm_ms_per_step": ms, "avg_launch_us": ms * 1e3 / n_launch,
+                    "from": "the {} timed steps: {:.4g} GFLOP of GEMM work per step over {:.4f} ms per step "
+                            "(HIP events on the launch stream around the timed region)".format(
+                                args.steps, flops / args.steps / 1e9, ms_step_events),
+                    "algorithmic_flops_per_launch": flops / args.steps / n_launch,
+                    "avg_launch_us": ms_step_events * 1e3 / n_launch,
+                    "gemm_replay": {
+                        "what": "the six GEMM launches alone, same batches and order, queued right behind the "
+                                "timed region; median of 3 passes of {} steps".format(args.steps),
+                        "gemm_ms_per_step": gemm_ms, "passes_ms_per_step": [round(v, 4) for v in replay_ms],
+                        "achieved": flops / args.steps / (gemm_ms * 1e-3) / 1e12,
+                        "frac": flops / args.steps / (gemm_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
+                        "avg_launch_us": gemm_ms * 1e3 / n_launch,
+                        "share_of_step": gemm_ms / ms_step_events,
+                        "consistent": bool(gemm_ms <= ms_step_events)},
                     "shader_clock_under_the_same_load_after_the_timed_steps": clock.summary()}
         cpu = None
         if want_cpu:   # CPU baseline: rank 0 at N = 1 only
@@ -1133,12 +1267,19 @@ def main():
                 extra["world"]["cpu_baseline_pool"] = json.loads(lines[-1])
         if world == 1 and args.world_utts > 0:
             extra.update(resident_epoch_section(dev))
+            if args.trainer_utts > 0:
+                extra.update(trainer_epoch_section(dev, args.trainer_utts))
+                if "resident_epoch" in extra and "error" not in extra["trainer_epoch"]:
+                    extra["trainer_epoch"]["bare_flat_step_valid_frames_per_s"] = value
+                    extra["trainer_epoch"]["resident_epoch_section_valid_frames_per_s"] = \
+                        extra["resident_epoch"]["valid_frames_per_s"]
             extra.update(duration_mlpg_section(dev))
             extra.update(gen_data_section(min(128, max(8, args.world_utts // 2)),
                                           min(64, max(4, args.world_utts // 4))))
         out = {
             "metric": "acoustic frames/sec (train)", "value": value, "unit": "valid frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "effective_warmup": ramp_steps + args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "ms_per_step_hip_events": dt_events / args.steps * 1e3,
             "timed_region": {"wall_ms": dt * 1e3, "hip_events_ms": dt_events * 1e3,

@@ -30,6 +30,7 @@ using fn_init_rank = int (*)(comm_t*, int, UniqueId, int);
 using fn_destroy = int (*)(comm_t);
 using fn_allreduce = int (*)(const void*, void*, size_t, int, int, comm_t, void*);
 using fn_errstr = const char* (*)(int);
+using fn_version = int (*)(int*);
 
 struct Rccl {
   void* handle = nullptr;
@@ -38,6 +39,7 @@ struct Rccl {
   fn_destroy destroy = nullptr;
   fn_allreduce allreduce = nullptr;
   fn_errstr errstr = nullptr;
+  int version = 0;
   std::string why;
 };
 
@@ -59,7 +61,14 @@ Rccl* rccl() {
     r.destroy = reinterpret_cast<fn_destroy>(dlsym(r.handle, "ncclCommDestroy"));
     r.allreduce = reinterpret_cast<fn_allreduce>(dlsym(r.handle, "ncclAllReduce"));
     r.errstr = reinterpret_cast<fn_errstr>(dlsym(r.handle, "ncclGetErrorString"));
-    if (!r.get_id || !r.init_rank || !r.destroy || !r.allreduce) r.why = "librccl.so.1 lacks the nccl* entry points";
+    if (!r.get_id || !r.init_rank || !r.destroy || !r.allreduce) { r.why = "librccl.so.1 lacks the nccl* entry points"; return; }
+    // The enum values and the by-value unique id above are the ABI of NCCL / RCCL 2.10 and later (ncclAvg = 4
+    // appeared in 2.10; version codes are 10000 major + 100 minor + patch from 2.9 on): anything else is
+    // refused rather than called with constants it may read differently.
+    const fn_version get_version = reinterpret_cast<fn_version>(dlsym(r.handle, "ncclGetVersion"));
+    if (!get_version || get_version(&r.version) != 0 || r.version < 21000 || r.version >= 30000)
+      r.why = "librccl.so.1 reports version code " + std::to_string(r.version) +
+              "; this binding was written against the 2.10 ... 2.x ABI (rccl.h)";
   });
   return &r;
 }
@@ -79,6 +88,11 @@ int fail(const Rccl* r, const char* what, int code) {
   }
 
 }  // namespace
+
+extern "C" int itts_comm_version(void) {
+  Rccl* r = rccl();
+  return r->why.empty() ? r->version : 0;
+}
 
 extern "C" int itts_comm_unique_id(void* id128) {
   if (!id128) { itts::set_error("itts_comm_unique_id: null pointer"); return ITTS_E_INVALID; }

@@ -14,6 +14,7 @@
 // round 2 made the warping steps products, rounds 2-4 kept two transforms per frame and iteration in a
 // kernel of their own (7.7 ms per analysis, 3.4 ms on wave_fft.h) until round 4 folded them away.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -480,6 +481,181 @@ __global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restr
     }
 }
 
+// One Newton round's TWO products in one kernel (round 5):  cr = (X / exp(2 MC . specT)) . crT.
+// The [rows x K] ratio D never exists in memory.  Until round 4 the first product (gemm_f64_kernel<.., RATIO>)
+// wrote it and the second (gemm_f64_lds_kernel) read it back: 2 x 4.1 KB per frame and round on top of the 4.1 KB
+// of the periodogram, 26 GB of the analysis' 44 GB, the first launch bound by HBM (6 TB/s) and the second at two
+// thirds of the fp64 matrix rate.  Here a wave owns 32 frames and walks the K spectral bins in chunks of 64:
+//   P1  S[32 x 64]   = MC[32 x m1] . specT[m1 x 64 of K]       128 MFMAs (m1 <= 64), operands from L1 / L2
+//       D[32 x 64]   = X / exp(2 S)                            the epilogue of round 4, values straight to LDS in the
+//                                                              layout of an A operand (the wave's own 16.9 KB)
+//   P2  cr[32 x N2] += D[32 x 64] . crT[64 of K x N2]          256 MFMAs at N2 = 119, accumulators live across chunks
+// so HBM sees the periodogram rows once (4.1 KB per frame and round) and 0.95 KB of cr.  No workgroup barrier: the
+// exchange through LDS is inside a wave (its LDS operations execute in order).  specT (246 KB) and crT (488 KB) are
+// read from L2 by every wave: 96 KB per chunk against 24 576 cycles of MFMA work, 4 B per cycle and wave.  Same K
+// permutation and order of accumulation as the two kernels it replaces, same expression in the epilogue: the
+// results are bit-identical (tests/test_gpu_world.py runs both; ITTS_MCEP_FUSED=0 keeps the two launches).
+constexpr int FP_PITCH = 66;                                     // doubles per parked row (as GA_PITCH)
+constexpr int FUSED_LDS_BYTES = 4 * 32 * FP_PITCH * 8;
+template <int NT2>   // column tiles of 64 in cr: 1 (orders up to 32) or 2 (up to 63)
+__global__ __launch_bounds__(256, 2) void mcls_fused_products_kernel(
+    const double* __restrict__ mc, int m1, const double* __restrict__ specT, const double* __restrict__ xp,
+    int64_t ldk, const double* __restrict__ crT, double* __restrict__ cr, int64_t nr, int K, int N2,
+    const int* __restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) char fsm[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  double* Ds = reinterpret_cast<double*>(fsm) + (size_t)wv * 32 * FP_PITCH;
+  const int64_t r0 = (int64_t)blockIdx.x * 128 + wv * 32;
+  if (r0 >= nr) return;                       // (no workgroup barrier anywhere below)
+  // rows of the A operand (row lr of block h) and rows of the results (row kg + 4 r of block h)
+  const double* mrow[2];
+  bool rok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t row = r0 + 16 * h + lr;
+    rok[h] = row < nr;
+    mrow[h] = mc + (rok[h] ? (rows ? (int64_t)rows[row] : row) : 0) * m1;
+  }
+  int erow[2][4];          // (frame indices fit 32 bits: the work list is an int array)
+  unsigned emask = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = r0 + 16 * h + kg + 4 * r;
+      const bool ok = row < nr;
+      emask |= ok ? (1u << (4 * h + r)) : 0u;
+      erow[h][r] = ok ? (rows ? rows[row] : (int)row) : 0;
+    }
+  f64x4 acc2[2][NT2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[h][t][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  const int nchunk = (K + 63) / 64;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * 64, cb = c0 + 4 * lr;
+    const bool cfull = cb + 3 < K;
+    // ---- P1 (log spectrum of the model at bins c0 .. c0 + 63) and the ratio to the periodogram, parked as this
+    // wave's A operand of P2 (rows kg + 4 r, columns 4 lr .. 4 lr + 3) -- one 16-row block after the other
+    // (sched_barrier): both at once hold 64 more registers than the 256 two waves per SIMD leave
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) __builtin_amdgcn_sched_barrier(0);
+      f64x4 acc1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc1[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < m1; s += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = s + 4 * kg + j;
+          const bool kok = k < m1;
+          const int kc = kok ? k : 0;
+          const double a = mrow[h][kc];
+          const double* brow = specT + (int64_t)kc * K;
+          double b[4];
+          if (cfull) {
+            const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = b4[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = brow[cb + q < K ? cb + q : 0];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok[h]) ? a : 0.0,
+                                                           (kok && (cfull || cb + q < K)) ? b[q] : 0.0, acc1[q], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rv = (emask >> (4 * h + r)) & 1u;
+        const double* xrow = xp + (int64_t)erow[h][r] * ldk + cb;
+        double x4[4];
+        if (cfull) {
+          const f64x4 xv = *reinterpret_cast<const f64x4*>(xrow);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x4[q] = xv[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x4[q] = xrow[cb + q < K ? q : 0];
+        }
+        double d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)      // (the reference's expression, oracle/c/sptk.c:135)
+          d[q] = (rv && (cfull || cb + q < K)) ? x4[q] / exp(2.0 * acc1[q][r]) : 0.0;
+        double* dst = Ds + (16 * h + kg + 4 * r) * FP_PITCH + 4 * lr;
+        *reinterpret_cast<double2*>(dst) = make_double2(d[0], d[1]);
+        *reinterpret_cast<double2*>(dst + 2) = make_double2(d[2], d[3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes, read back below in another layout
+    // ---- P2: warped autocorrelation, this chunk's share
+    const double* as = Ds + lr * FP_PITCH + 4 * kg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c0 + 16 * c >= K) break;            // the last chunk may hold fewer than four groups of 16 k
+      double am[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double2 v0 = *reinterpret_cast<const double2*>(as + 16 * h * FP_PITCH + 16 * c);
+        const double2 v1 = *reinterpret_cast<const double2*>(as + 16 * h * FP_PITCH + 16 * c + 2);
+        am[h][0] = v0.x; am[h][1] = v0.y; am[h][2] = v1.x; am[h][3] = v1.y;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int k = c0 + 16 * c + 4 * kg + jj;
+        const bool kok = k < K;
+        const double* brow = crT + (int64_t)(kok ? k : 0) * N2;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+          const int cb2 = 64 * t + 4 * lr;
+          double b[4];
+          if (cb2 + 3 < N2) {
+            const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = b4[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = brow[cb2 + q < N2 ? cb2 + q : 0];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double bq = (kok && cb2 + q < N2) ? b[q] : 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              acc2[h][t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[h][jj], bq, acc2[h][t][q], 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("" ::: "memory");            // the next chunk's park comes behind these reads (LDS runs a wave's
+                                              // operations in order)
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!((emask >> (4 * h + r)) & 1u)) continue;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const int cb2 = 64 * t + 4 * lr;
+        double* crow = cr + (int64_t)erow[h][r] * N2 + cb2;
+        if (cb2 + 3 < N2) {
+          *reinterpret_cast<f64x4*>(crow) = (f64x4){acc2[h][t][0][r], acc2[h][t][1][r], acc2[h][t][2][r], acc2[h][t][3][r]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cb2 + q < N2) crow[q] = acc2[h][t][q][r];
+        }
+      }
+    }
+}
+
 // list of the frames that are still iterating (order irrelevant: frames are independent)
 __global__ void mcls_compact_kernel(const int* __restrict__ done, int64_t T, int* __restrict__ rows,
                                     int* __restrict__ count) {
@@ -905,14 +1081,40 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   ITTS_LAUNCH_CHECK();
   int rc = launch_gemm_f64(cbuf, Kp, ft->initT, m1, mc, m1, T, m1, K, nullptr, s);
   if (rc) return rc;
+  // both products of a round in one kernel where its accumulators fit (order <= 63); ITTS_MCEP_FUSED=0: two launches
+  const char* fenv = getenv("ITTS_MCEP_FUSED");
+  const bool fused = m1 <= 64 && m2 + 1 <= 128 && !(fenv && fenv[0] == '0');
+  if (fused) {
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_fused_products_kernel<1>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_fused_products_kernel<2>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+      if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
+    }
+  }
   for (int it = 1; it <= maxiter; ++it) {
     a.iter = it;
     const int64_t nr = a.n_rows;      // frames still iterating (their list is a.rows)
     // log spectrum of the current model and the ratio to the periodogram in one product (the two
     // transforms of the reference's loop are folded into the warping matrices: FreqtTables), then the
     // warped autocorrelation of the ratio
-    if ((rc = launch_gemm_f64_ratio(mc, m1, ft->specT, K, cbuf, Kp, nr, K, m1, a.rows, xp, s))) return rc;
-    if ((rc = launch_gemm_f64(cbuf, Kp, ft->crT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
+    if (fused) {
+      const dim3 fgrid((unsigned)((nr + 127) / 128));
+      if (m2 + 1 <= 64)
+        hipLaunchKernelGGL(mcls_fused_products_kernel<1>, fgrid, dim3(256), FUSED_LDS_BYTES, s, mc, m1, ft->specT, xp, Kp,
+                           ft->crT, cr, nr, K, m2 + 1, a.rows);
+      else
+        hipLaunchKernelGGL(mcls_fused_products_kernel<2>, fgrid, dim3(256), FUSED_LDS_BYTES, s, mc, m1, ft->specT, xp, Kp,
+                           ft->crT, cr, nr, K, m2 + 1, a.rows);
+      ITTS_LAUNCH_CHECK();
+    } else {
+      if ((rc = launch_gemm_f64_ratio(mc, m1, ft->specT, K, cbuf, Kp, nr, K, m1, a.rows, xp, s))) return rc;
+      if ((rc = launch_gemm_f64(cbuf, Kp, ft->crT, m2 + 1, cr, m2 + 1, nr, m2 + 1, K, a.rows, s))) return rc;
+    }
     const dim3 wgrid((unsigned)((nr + 3) / 4));
     if (m1 <= 20) hipLaunchKernelGGL(mcls_solve_dpp_kernel<20>, wgrid, dim3(256), 0, s, a);
     else if (m1 <= 24) hipLaunchKernelGGL(mcls_solve_dpp_kernel<24>, wgrid, dim3(256), 0, s, a);

@@ -23,10 +23,9 @@ namespace itts {
 // recurrence to themselves for all T steps: workgroup c owns hidden units 16 c .. 16 c + 15 (all G
 // gates: a G x 32 KB image of its W_hh rows stays in LDS in the order the MFMA lanes read it), the
 // cell state stays in registers, and h travels through the XCD's L2 as self-validating 16-byte
-// granules (four values, a 4-bit step tag in their lowest mantissa bits; until round 4: pairs
-// (P, P ^ mask(step))) that a consumer lane re-reads until the tag is the step's -- no
-// counter, no fence (measured in scripts/handoff_lab: 1.2 us per step, no stale or torn granule in
-// 1e10 reads).  A polling budget turns a missing workgroup into an abort
+// granules (four values, each carrying a validity bit in its lowest mantissa bit -- persist_use_tag below;
+// until round 4: pairs (P, P ^ mask(step))) that a consumer lane re-reads until all four bits are the
+// current use's -- no counter, no fence (scripts/handoff_lab: 1.2 us per step).  A polling budget turns a missing workgroup into an abort
 // flag instead of a hang.
 constexpr int PH = 512;                          // hidden size this kernel is built for
 constexpr int P_PART_FLOATS = 4 * 4 * 16 * 17;   // partial gate sums [wave][gate][row][unit + pad]
@@ -63,9 +62,18 @@ __device__ __forceinline__ void persist_load_one(const uint4* p, pu32x4& v) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
 }
 
-// In-band step tags (both recurrences): the lowest mantissa bit of each of a granule's four values holds one
-// bit of a 4-bit tag (15 states, never 0: a cleared buffer is never valid; consecutive uses of a slot differ).
-__device__ __forceinline__ unsigned persist_tag4(int step) { return (unsigned)((step >> 1) % 15) + 1u; }
+// In-band validity bits (both recurrences): the lowest mantissa bit of EACH of a granule's four values says which
+// use of its slot the value belongs to -- consecutive uses of a slot carry complementary bits (0xF, 0x0, 0xF ... over
+// the granule, the first use after a clear being 0xF), so every one of the four words is validated by itself: a torn
+// or partly stale 16-byte read, whatever mixture of the previous and the current use it holds, fails the check in the
+// stale words.  (Round 4 used a 4-bit counter spread over the words; consecutive uses differed in ONE word only, so a
+// torn read could pass -- ADVICE r4.)  A value from TWO uses back carries the current bit again; a reader cannot see
+// one: it has itself read the use in between from the same address, and reads of one location served by the L2
+// (sc1: the L1 is bypassed) never go back in that location's modification order.  A cleared buffer reads as 0x0 and
+// is what the second use expects -- by then every reader has seen the first use's 0xF at that address, same argument.
+// Assumes nothing about 16-byte single-copy atomicity (scripts/handoff_lab re-run on this format: profiles/r5_handoff_lab.txt).
+// Inf in an exchanged value becomes NaN when its bit is set: a recurrence that produced Inf is lost either way.
+__device__ __forceinline__ unsigned persist_use_tag(int use) { return (use & 1) ? 0u : 0xFu; }
 __device__ __forceinline__ unsigned persist_tag_of(const pu32x4 g) {
   return (g.x & 1u) | ((g.y & 1u) << 1) | ((g.z & 1u) << 2) | ((g.w & 1u) << 3);
 }
@@ -145,9 +153,9 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
     const float p0 = __shfl(hval, rl * 16 + kq, 64), p1 = __shfl(hval, rl * 16 + 4 + kq, 64),
                 p2 = __shfl(hval, rl * 16 + 8 + kq, 64), p3 = __shfl(hval, rl * 16 + 12 + kq, 64);
     if (lane < 16) {
-      // the step tag rides in the lowest mantissa bit of the four values (round 4; until then a check copy
+      // the validity bit rides in the lowest mantissa bit of each of the four values (until round 4 a check copy
       // P ^ mask(step) travelled beside every granule: twice the bytes to poll)
-      const unsigned t = persist_tag4(step);
+      const unsigned t = persist_use_tag(step >> 2);
       const uint4 P = make_uint4((__float_as_uint(p0) & ~1u) | (t & 1u), (__float_as_uint(p1) & ~1u) | ((t >> 1) & 1u),
                                  (__float_as_uint(p2) & ~1u) | ((t >> 2) & 1u), (__float_as_uint(p3) & ~1u) | ((t >> 3) & 1u));
       uint4* dst = xg + ((size_t)(step & 3) * 32 + cu) * 64 + kq * 16 + 4 * wv + rl;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(RnnPersistArgs a) 
     pu32x4 pv[8];
     {
       const uint4* src = xg + ((size_t)(s & 3) * 32 + 8 * wv) * 64 + lane;
-      const unsigned m = persist_tag4(s);
+      const unsigned m = persist_use_tag(s >> 2);
       int budget = 1 << 16;      // ~50 ms of polling at most
       for (;;) {
         // optimistic: usually everything is there (one trip); otherwise wait on one granule per
@@ -325,14 +333,18 @@ static int persist_read_flag(int64_t* slot, const int* d_flag, hipStream_t s) {
 }
 
 // Per-device bookkeeping of a persistent kernel: CU count, the dynamic-LDS attribute (set once per
-// device, not once per process), and a cool-down -- a launch that gave up waiting (CUs briefly held by
-// another stream or process) sends the next kPersistCooldown calls to the step kernels and is then
-// tried again, instead of switching the path off for the life of the process.
-constexpr int kPersistCooldown = 64;
+// device, not once per process), and a cool-down -- a launch that gave up waiting (CUs held by another
+// stream or process) sends the next calls to the step kernels and is then tried again: 64 calls after
+// the first give-up, twice as many after every further one in a row (cap 1 << 16: a device whose CUs
+// are masked or shared for good costs one 50-ms polling budget every 65 536 calls, not every 65th),
+// back to 64 after a launch that ran.  The message is printed for the first three give-ups in a row only.
+constexpr int kPersistCooldown = 64, kPersistCooldownCap = 1 << 16;
 struct PersistDevice {
   int n_cu = 0;
   bool attr_set = false;
   int cooldown = 0;
+  int next_cooldown = kPersistCooldown;
+  int give_ups = 0;       // in a row
 };
 // Returns 1 when the persistent kernel may be launched on the current device, 0 when the caller has to
 // take the step kernels (fewer than 256 CUs, cooling down, or the attribute could not be set).
@@ -357,9 +369,21 @@ static int persist_device_ready(const void* kernel, int lds_bytes, std::map<int,
   }
   return 1;
 }
-static void persist_cool_down(std::map<int, PersistDevice>& table, std::mutex& mu, int dev) {
+// A launch gave up (or could not be made): returns the number of calls the step kernels take now, negative when the
+// message for it should not be printed any more.
+static int persist_cool_down(std::map<int, PersistDevice>& table, std::mutex& mu, int dev) {
   std::lock_guard<std::mutex> lock(mu);
-  table[dev].cooldown = kPersistCooldown;
+  PersistDevice& d = table[dev];
+  d.cooldown = d.next_cooldown;
+  d.next_cooldown = std::min(2 * d.next_cooldown, kPersistCooldownCap);
+  ++d.give_ups;
+  return d.give_ups <= 3 ? d.cooldown : -d.cooldown;
+}
+static void persist_ran(std::map<int, PersistDevice>& table, std::mutex& mu, int dev) {
+  std::lock_guard<std::mutex> lock(mu);
+  PersistDevice& d = table[dev];
+  d.next_cooldown = kPersistCooldown;
+  d.give_ups = 0;
 }
 
 template <int G>
@@ -401,10 +425,11 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
   const int gave_up = persist_read_flag(pinned_slot(ctx), p.abort_flag, s);
   if (gave_up < 0) return -1;
   if (itts::scratch_free(blk, s) != hipSuccess) return -1;
-  if (gave_up == 0) return 1;
-  persist_cool_down(devices, devices_mu, dev);
-  fprintf(stderr, "libidiaptts_amd: the persistent recurrence gave up waiting (are all 256 CUs available to "
-                  "this process?); per-step kernels for the next %d calls\n", kPersistCooldown);
+  if (gave_up == 0) { persist_ran(devices, devices_mu, dev); return 1; }
+  const int calls = persist_cool_down(devices, devices_mu, dev);
+  if (calls > 0)
+    fprintf(stderr, "libidiaptts_amd: the persistent recurrence gave up waiting (are all 256 CUs available to "
+                    "this process?); per-step kernels for the next %d calls\n", calls);
   return 0;
 }
 
@@ -418,8 +443,8 @@ static int rnn_persist_forward(RnnPersistArgs p, int H, hipStream_t s) {
 // [lane] float4) into a PARTIAL dh for all 512 units, publishes the 16 x 16 tile of every unit block
 // to the workgroup that owns it (reduce-scatter: 32 KB out, 32 KB in, per CU and step), and sums the
 // 32 partial tiles it receives.  Polling, budget and fallback as above, but the granules carry their
-// tag INSIDE: the lowest mantissa bit of each of a granule's four values holds one bit of a 4-bit
-// step tag (15 states, never 0; consecutive uses of a slot differ), so a tile's 256 values are 64
+// tag INSIDE: the lowest mantissa bit of each of a granule's four values is that value's validity bit
+// (persist_use_tag: complementary between consecutive uses of a slot), so a tile's 256 values are 64
 // granules and the two step slots of an XCD's 32 x 32 tiles are 2 MB of its 4 MB L2.  History
 // (profiles/r3h_rnn_traffic.txt, r4a_rnn_bwd_variants.txt; one layer, 64 rows, T = 1981, against
 // 3 GB of gate and gradient data): value + check-copy pairs, 4 MB per XCD: 22.8 GB written and 14 GB
@@ -521,7 +546,7 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
     if (s < s0) {
       pu32x4 pv[8];
       const uint4* src = xg + (((size_t)((s + 1) & 1) * 32 + cu) * 32 + 8 * wv) * PT;
-      const unsigned m = persist_tag4(s + 1);
+      const unsigned m = persist_use_tag((s0 - (s + 1)) >> 1);
       int budget = 1 << 16;
       for (;;) {
         persist_load8(src + lane, PT, pv);
@@ -626,7 +651,7 @@ __global__ __launch_bounds__(256) void rnn_persist_bwd_kernel(RnnPersistBwdArgs 
       for (int gg2 = 0; gg2 < G; ++gg2)
         af[gg2] = make_float4(dgs[(gg2 * 16 + rr) * 16 + kq], dgs[(gg2 * 16 + rr) * 16 + 4 + kq],
                               dgs[(gg2 * 16 + rr) * 16 + 8 + kq], dgs[(gg2 * 16 + rr) * 16 + 12 + kq]);
-      const unsigned m = persist_tag4(s);
+      const unsigned m = persist_use_tag((s0 - s) >> 1);
       const unsigned t0 = m & 1u, t1 = (m >> 1) & 1u, t2 = (m >> 2) & 1u, t3 = (m >> 3) & 1u;
       // Software pipeline over the tiles: the values of tile i - 1 are tagged and stored BETWEEN the
       // products of tile i (a wave issues in order: behind the last product of a chain the read of its
@@ -711,10 +736,11 @@ static int rnn_persist_backward(RnnPersistBwdArgs p, const int* h_lengths, int H
   const int gave_up = persist_read_flag(pinned_slot(ctx), p.abort_flag, s);
   if (gave_up < 0) return -1;
   if (itts::scratch_free(blk, s) != hipSuccess) return -1;
-  if (gave_up == 0) return 1;
-  persist_cool_down(devices, devices_mu, dev);
-  fprintf(stderr, "libidiaptts_amd: the persistent backward recurrence gave up waiting; per-step kernels for the "
-                  "next %d calls\n", kPersistCooldown);
+  if (gave_up == 0) { persist_ran(devices, devices_mu, dev); return 1; }
+  const int calls = persist_cool_down(devices, devices_mu, dev);
+  if (calls > 0)
+    fprintf(stderr, "libidiaptts_amd: the persistent backward recurrence gave up waiting; per-step kernels for the "
+                    "next %d calls\n", calls);
   return 0;
 }
 

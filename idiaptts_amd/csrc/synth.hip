@@ -15,6 +15,7 @@
 //      (4 real FFTs for the two minimum-phase spectra, 1 for the noise, 2 inverse) and
 //      overlap-adds them with f64 atomics.
 // PARITY: the reference has no golden waveform; checked against oracle/c/synth.c.
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1032,6 +1033,16 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const size_t lds = wf::WF_TABLE_BYTES + (size_t)h * 8 + (size_t)(NT / 64) * (wf::WF_LDS_BYTES + (h + 4) * 8);
+    ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+    {
+      // more than 64 KB of dynamic LDS: the attribute once per device (runtimes that enforce it fail the launch otherwise)
+      static std::atomic<uint64_t> attr_done{0};
+      if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
+        ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_wave_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
+      }
+    }
     hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
   } else {

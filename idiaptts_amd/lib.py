@@ -27,6 +27,7 @@ _SIGNATURES = {
     "itts_defer_reductions": (c_int, [c_int]),
     "itts_reduce_deferred": (c_int, [_P]),
     "itts_scratch_pool_stats": (c_int, [POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "itts_comm_version": (c_int, []),
     "itts_comm_unique_id": (c_int, [_P]),
     "itts_comm_init_rank": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
     "itts_comm_destroy": (c_int, [c_void_p]),

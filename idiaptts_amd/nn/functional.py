@@ -25,7 +25,9 @@ class LinearActFunction(torch.autograd.Function):
         N = weight.shape[0]
         out = None
         if N % 4:
-            out = torch.empty((x2.shape[0], (N + 3) // 4 * 4), dtype=torch.float32, device=x2.device)[:, :N]
+            full = torch.empty((x2.shape[0], (N + 3) // 4 * 4), dtype=torch.float32, device=x2.device)
+            full[:, N:] = 0          # pad columns: read again by act_bwd over the whole rows
+            out = full[:, :N]
         y = ops.linear_fwd(x2, weight.contiguous(), bias, act, out=out)
         ctx.save_for_backward(x2, weight, y)
         ctx.act = act

@@ -164,8 +164,29 @@ def linear_fwd_mse(x, w, b, target, row_valid, n_valid, loss_weight=1.0, grad=No
     return loss, grad
 
 
+def _full_rows(t):
+    """The [M, pitch] tensor a column-slice view t = buf[:, :N] was cut from (None when t is not one)."""
+    if t.dim() != 2 or t.shape[0] == 0 or t.stride(1) != 1 or t.stride(0) <= t.shape[1]:
+        return None
+    M, P = t.shape[0], t.stride(0)
+    if t.storage_offset() + M * P > t.untyped_storage().nbytes() // t.element_size():
+        return None
+    return torch.as_strided(t, (M, P), (P, 1))
+
+
 def act_bwd(dy, y, act, out=None):
+    """dz = dy * act'(y).  Rows with a padded pitch (views buf[:, :N] of [M, pitch] buffers whose pad columns
+    are zero, as LinearActFunction makes them for N % 4 != 0) keep their pitch: the kernel runs over the
+    whole buffers (0 * act'(0) = 0 in the pad columns) and the result is the same kind of view, so the GEMMs
+    behind it still see 16-byte rows."""
     L = _lib.load()
+    if out is None and dy.shape == y.shape:
+        fdy, fy = _full_rows(dy), _full_rows(y)
+        if fdy is not None and fy is not None and fdy.shape == fy.shape:
+            full = torch.empty_like(fdy)
+            _lib.check(L.itts_act_bwd(_ptr(fdy), _ptr(fy), _ptr(full), fdy.numel(), act, _stream()),
+                       "itts_act_bwd")
+            return full[:, :dy.shape[1]]
     dy = dy.contiguous()
     y = y.contiguous()
     if out is None:

@@ -80,6 +80,7 @@ class NativeComm:
         import ctypes
         from . import lib
         self._lib = lib
+        self.comm = None
         L = lib.load()
         ident = ctypes.create_string_buffer(128)
         if rank == 0:
@@ -109,8 +110,20 @@ class NativeComm:
 
     def close(self):
         if self.comm is not None:
-            self._lib.check(self._lib.load().itts_comm_destroy(self.comm), "itts_comm_destroy")
-            self.comm = None
+            comm, self.comm = self.comm, None
+            self._lib.check(self._lib.load().itts_comm_destroy(comm), "itts_comm_destroy")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):            # a communicator dropped without close() (an exception on the way) is not leaked
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def allreduce_stats_(extractor, group=None, device=None):

@@ -9,11 +9,13 @@ arguments and return values:
   save_checkpoint / load_checkpoint / load_best_model / get_model_path (:305-368)
 
 Everything that computes runs on the HIP kernels through the model handler, the data readers and
-the Synthesiser; TensorBoard and figure generation are not part of the accelerated path."""
+the Synthesiser; loss scalars go to TensorBoard when it is installed (idiaptts_amd/misc/logging_sinks.py:
+a JSON-lines file otherwise), figure generation is not part of the accelerated path."""
 import copy
 import logging
 import os
 import random
+import resource
 from datetime import datetime, timedelta
 from functools import partial
 from timeit import default_timer as timer
@@ -21,6 +23,7 @@ from typing import Dict, List
 
 import numpy as np
 
+from idiaptts_amd.misc import logging_sinks
 from idiaptts_amd.src.data_preparation.PyTorchDatareadersDataset import \
     PyTorchDatareadersDataset
 from idiaptts_amd.src.ExtendedHParams import ExtendedHParams
@@ -128,11 +131,19 @@ class ModularTrainer(object):
             values = unsorted
         return values
 
+    def log_memory(self, use_gpu):
+        """reference :253-256, with torch.cuda.mem_get_info in place of the nvidia-smi probe."""
+        self.logger.info("CPU memory: {} MB.".format(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e3))
+        if use_gpu:
+            self.logger.info("GPU memory: {} MB.".format(logging_sinks.get_gpu_memory_map()))
+
     # ---------------------------------------------------------------------------------- init
     def init(self, hparams, model_config=None, loss_configs=None, data_reader_configs=None):
         assert hparams.has_value("model_name"), "hparams.model_name is required."
         os.makedirs(os.path.join(hparams.out_dir, hparams.model_name, hparams.networks_dir),
                     exist_ok=True)
+        self.log_memory(hparams.use_gpu)                                # reference :193
+        self.tb_writer = logging_sinks.open_scalar_writer(hparams)      # reference :198-214
         self.datareaders = dict()
         if data_reader_configs is not None:
             self._data_reader_configs = copy.deepcopy(data_reader_configs)
@@ -273,7 +284,10 @@ class ModularTrainer(object):
             self.logger.info("Number of training epochs is {}. Skipping training."
                              .format(hparams.epochs))
             return list(), list(), self.model_handler
+        if self.tb_writer is not None:                                  # reference :391-392
+            self.tb_writer.add_text("HParams", "<pre>" + hparams.get_debug_string() + "</pre>")
         self.logger.info("Training set size: {}".format(len(self.id_list_train)))
+        self.log_memory(hparams.use_gpu)                                # reference :422
 
         handler = self.model_handler
         handler.async_checkpoint = bool(hparams.get_value("async_checkpoint", False))

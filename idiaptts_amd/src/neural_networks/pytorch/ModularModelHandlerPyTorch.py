@@ -28,6 +28,7 @@ from torch.optim.lr_scheduler import ExponentialLR, LambdaLR, ReduceLROnPlateau
 from torch.utils.data import DataLoader
 
 from idiaptts_amd import ops, parallel
+from idiaptts_amd.misc import logging_sinks
 from idiaptts_amd.src.neural_networks.pytorch import config_json
 
 
@@ -356,6 +357,7 @@ class ModularModelHandlerPyTorch(object):
         self.dataloader_train = None
         self.dataloader_val = None
         self._resident = None          # HBM-resident training state (set_dataset, resident_dataset)
+        self._batch_guard = None       # deferred NaN guard of process_batch(blocking=False)
 
     @staticmethod
     def cuda_is_available():
@@ -607,6 +609,10 @@ class ModularModelHandlerPyTorch(object):
         loss_name = self.losses[0].name
         rank, world = parallel.dp_rank_world()
         total = None
+        scalars = logging_sinks.DeferredScalars(logging_sinks.open_scalar_writer(hparams))
+        guard = logging_sinks.DeferredLossCheck(self._device(), check_inf=False)
+        if hparams.log_memory_consumption:
+            self.logger.info(logging_sinks.memory_message(hparams.use_gpu))
         for batch_index, indices in enumerate(dataloader):
             if world > 1:                      # this rank's utterances of the global batch
                 indices = indices[:len(indices) - len(indices) % world][rank::world]
@@ -634,15 +640,20 @@ class ModularModelHandlerPyTorch(object):
                 finally:
                     flat.params = live
             loss = parallel.allreduce_flat_(loss.clone())[0]
-            if torch.isnan(loss):
-                raise ValueError("Found NaN in {} loss.".format(loss_name))
+            guard.submit({loss_name: loss})          # looked at one step late: no host stall per step
             if training:
                 current_iter = self._get_current_iteration(
                     batch_index=batch_index, current_epoch=current_epoch,
                     dataloader_length=len(dataloader), hparams=hparams, total_epoch=total_epoch)
                 self.run_scheduler(hparams=hparams, loss=loss, current_iter=current_iter)
+                scalars.add_scalars("Train loss", {loss_name: loss}, total_steps)
             total = loss if total is None else total + loss
-        return {loss_name: (total / len(dataloader)).cpu().numpy()}
+        guard.finish()
+        mean = total / len(dataloader)
+        if not training:
+            scalars.add_scalars("Validation loss", {loss_name: mean}, total_steps)
+        scalars.flush()
+        return {loss_name: mean.cpu().numpy()}
 
     # -------------------------------------------------------------------------------- model
     def create_model(self, model_config, use_gpu=True):
@@ -923,6 +934,12 @@ class ModularModelHandlerPyTorch(object):
         device = self._device()
         logging_batch_index = (len(dataloader) // hparams.logging_batch_index_perc) + 1
         total_losses = dict()
+        # reference :694-705, :726-729: scalar writer and the memory line of a pass; the per-step NaN / Inf guard
+        # (:778-781) is looked at one step late instead of stalling the host on every loss (logging_sinks)
+        scalars = logging_sinks.DeferredScalars(logging_sinks.open_scalar_writer(hparams))
+        guard = logging_sinks.DeferredLossCheck(device, check_inf=not hparams.replace_inf_grads_by_zero)
+        if hparams.log_memory_consumption:
+            self.logger.info(logging_sinks.memory_message(hparams.use_gpu))
         # clipping inside the optimiser's fused step when it can (HipAdam, norm types 2 / inf)
         fused_clip = False
         if training and hasattr(self.optimiser, "configure_clipping"):
@@ -938,13 +955,10 @@ class ModularModelHandlerPyTorch(object):
                 losses = {}
                 for loss_fn in self.losses:
                     for loss_name, l in loss_fn(data_dict, lengths, total_steps).items():
-                        if torch.isnan(l):
-                            raise ValueError("Found NaN in {} loss.".format(loss_name))
-                        if not hparams.replace_inf_grads_by_zero and torch.isinf(l):
-                            raise ValueError("Found +/-Inf in {} loss.".format(loss_name))
                         if loss_name in losses:
                             raise KeyError("Loss with name {} defined twice.".format(loss_name))
                         losses[loss_name] = l
+                guard.submit(losses)
                 backprop_loss = self.get_summed_losses_subset(hparams.backprop_loss_names, losses)
             if hparams.backprop_loss_names is None and hparams.scheduler_loss_names is None:
                 scheduler_loss = backprop_loss.detach()
@@ -978,15 +992,25 @@ class ModularModelHandlerPyTorch(object):
                 self.run_scheduler(hparams=hparams, loss=scheduler_loss,
                                    current_iter=current_iter)
             if batch_index % logging_batch_index == 0:
-                self.logger.info("{} mini batch [{}/{}]\tLoss: {}".format(
+                self.logger.info("{} mini batch [{}/{}]\tLoss: {}{}".format(
                     "Train" if training else "Test", batch_index + 1, len(dataloader),
-                    " ".join("{}: {:.3f}".format(k, float(l.detach())) for k, l in losses.items())))
+                    " ".join("{}: {:.3f}".format(k, float(l.detach())) for k, l in losses.items()),
+                    "\t" + logging_sinks.memory_message(hparams.use_gpu)
+                    if hparams.log_memory_consumption else ""))
+            step_losses = {}
             for key, loss in losses.items():
                 loss = loss.detach()
                 if dp_weight is not None:        # loss of the global batch
                     loss = parallel.allreduce_flat_(loss * dp_weight)
+                step_losses[key] = loss
                 total_losses[key] = loss if key not in total_losses else total_losses[key] + loss
+            if training:
+                scalars.add_scalars("Train loss", step_losses, total_steps)     # reference :858-859
+        guard.finish()
         total_losses = {k: v / len(dataloader) for k, v in total_losses.items()}
+        if not training:
+            scalars.add_scalars("Validation loss", total_losses, total_steps)   # reference :866-867
+        scalars.flush()
         if not training:
             self.logger.info('Validation set: Total loss: {}\nAverage loss:\n\t{}\n'.format(
                 float(sum(total_losses.values())),
@@ -1012,8 +1036,11 @@ class ModularModelHandlerPyTorch(object):
             if p.grad is not None:
                 p.grad[torch.isinf(p.grad)] = 0.0
 
-    def process_batch(self, data, lengths, step, training=True, grad_clip_norm=None):
-        """One iteration of process_dataloader (:745-831) on a caller-supplied batch."""
+    def process_batch(self, data, lengths, step, training=True, grad_clip_norm=None, blocking=True):
+        """One iteration of process_dataloader (:745-831) on a caller-supplied batch.  Returns
+        ({loss name: float}, data).  With blocking=False nothing waits for the device: the losses come
+        back as 0-dim device tensors and the NaN guard (reference :778-781) of this step is looked at when
+        the next call has queued its work -- `finish_batches()` looks at the last one."""
         device = self._device()
         data = self._to_device(data, device)
         max_lengths = {k: int(v.max()) for k, v in lengths.items()}
@@ -1026,8 +1053,14 @@ class ModularModelHandlerPyTorch(object):
             for loss_fn in self.losses:
                 loss_dict.update(loss_fn(data, lengths, step))
             total = sum(loss_dict.values())
-            if torch.isnan(total):
-                raise ValueError("Found NaN in loss.")       # reference :778-781
+            if blocking:
+                if torch.isnan(total):
+                    raise ValueError("Found NaN in loss.")       # reference :778-781
+            else:
+                if self._batch_guard is None:
+                    self._batch_guard = logging_sinks.DeferredLossCheck(device, check_inf=False,
+                                                                       nan_message="Found NaN in loss.")
+                self._batch_guard.submit({"summed": total})
             dp_weight = self._dp_weight(lengths, device)
             if training:
                 self.optimiser.zero_grad()
@@ -1044,7 +1077,14 @@ class ModularModelHandlerPyTorch(object):
         if dp_weight is not None:
             loss_dict = {k: parallel.allreduce_flat_(v.detach() * dp_weight)
                          for k, v in loss_dict.items()}
+        if not blocking:
+            return {k: v.detach() for k, v in loss_dict.items()}, data
         return {k: float(v.detach()) for k, v in loss_dict.items()}, data
+
+    def finish_batches(self):
+        """The deferred NaN guard of the last process_batch(blocking=False) call."""
+        if self._batch_guard is not None:
+            self._batch_guard.finish()
 
     # ----------------------------------------------------------------------------- inference
     def inference(self, data, hparams, seq_lengths):

@@ -67,12 +67,15 @@ int itts_reduce_deferred(void* stream);
  *   itts_comm_unique_id   rank 0 fills 128 bytes, sends them to the others by any means
  *   itts_comm_init_rank   collective over the n_ranks processes (device = the current HIP device)
  *   itts_allreduce_flat   d_buf[0..n) <- reduction over the ranks, in place, asynchronous on `stream`
- *   itts_comm_destroy */
+ *   itts_comm_destroy
+ *   itts_comm_version     the library's ncclGetVersion code (e.g. 22707), 0 when no usable RCCL was found: the
+ *                         binding passes enum values of the 2.10+ ABI and refuses any other version */
 #define ITTS_F32 0
 #define ITTS_F64 1
 #define ITTS_REDUCE_SUM 0
 #define ITTS_REDUCE_MAX 1
 #define ITTS_REDUCE_AVG 2
+int itts_comm_version(void);
 int itts_comm_unique_id(void* h_id128);
 int itts_comm_init_rank(const void* h_id128, int n_ranks, int rank, void** comm_out);
 int itts_comm_destroy(void* comm);

@@ -66,6 +66,7 @@ struct Args {
   u32x4* buf;            // [8 groups][2 parities][32 producers][64 granules]
   unsigned* counter;     // [8 groups], 64 B apart
   unsigned long long* stale;   // [256] per workgroup
+  unsigned long long* torn;    // [256] per workgroup (inband_kernel)
   unsigned* xcc;         // [256] XCC_ID seen
   unsigned* gave_up;
   int steps;
@@ -164,9 +165,65 @@ __global__ __launch_bounds__(256) void tagged_kernel(Args a) {
   if (lane == 0 && wave == 0) a.xcc[blockIdx.x] = (unsigned)(polls / (unsigned long long)(a.steps > 0 ? a.steps : 1));
 }
 
-template <bool ST_SC1, bool LD_SC1, bool TAGGED = false>
+
+// Round 5: the product's in-band format (csrc/rnn_persist.h, persist_use_tag).  Every 32-bit word of a granule
+// gives its lowest bit to a validity bit that is complementary between consecutive uses of a slot (1, 0, 1 ...;
+// a cleared buffer reads 0 and the first use writes 1), so each word is validated by itself.  A consumer polls
+// until all four bits are the current use's and then compares the payload: `stale` counts granules that passed
+// the check with a wrong payload (must be 0, with or without 16-byte single-copy atomicity), `torn` counts
+// polls that saw a granule whose four words did not all belong to the same use (information only).
+template <bool ST_SC1, bool LD_SC1>
+__global__ __launch_bounds__(256) void inband_kernel(Args a) {
+  const int group = blockIdx.x & 7, rank = blockIdx.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long stale = 0, torn = 0, polls = 0;
+  auto payload = [](int s, int p, int ln, int k) -> unsigned {
+    return ((unsigned)s * 2654435761u + (unsigned)p * 40503u + (unsigned)ln * 97u + (unsigned)k * 0x9E3779B1u) & ~1u;
+  };
+  for (int s = 0; s < a.steps; ++s) {
+    const unsigned bit = ((s >> 1) & 1) ? 0u : 1u;         // use index of parity slot s & 1 is s >> 1
+    u32x4* base = a.buf + ((size_t)(group * 2 + (s & 1)) * 32) * 64;
+    if (wave == 0) {
+      u32x4 v = {payload(s, rank, lane, 0) | bit, payload(s, rank, lane, 1) | bit, payload(s, rank, lane, 2) | bit,
+                 payload(s, rank, lane, 3) | bit};
+      store16<ST_SC1>(base + rank * 64 + lane, v);
+    }
+    {
+      int budget = 1 << 20;
+      u32x4 v[8];
+      for (;;) {
+        load16x8<LD_SC1>(base + wave * 64 + lane, 4 * 64, v);
+        ++polls;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned bits = (v[i].x & 1u) + (v[i].y & 1u) + (v[i].z & 1u) + (v[i].w & 1u);
+          ok = ok && bits == 4u * bit;
+          if (bits != 0u && bits != 4u) ++torn;
+        }
+        if (__all(ok) || --budget <= 0) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (budget <= 0 && lane == 0) atomicExch(a.gave_up, 1u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = wave + 4 * i;
+        if (v[i].x != (payload(s, p, lane, 0) | bit) || v[i].y != (payload(s, p, lane, 1) | bit) ||
+            v[i].z != (payload(s, p, lane, 2) | bit) || v[i].w != (payload(s, p, lane, 3) | bit)) ++stale;
+      }
+    }
+    __syncthreads();
+    if (*a.gave_up) break;
+  }
+  for (int off = 32; off > 0; off >>= 1) { stale += __shfl_xor(stale, off, 64); torn += __shfl_xor(torn, off, 64); }
+  if (lane == 0) { atomicAdd(a.stale + blockIdx.x, stale); atomicAdd(a.torn + blockIdx.x, torn); }
+  if (lane == 0 && wave == 0) a.xcc[blockIdx.x] = (unsigned)(polls / (unsigned long long)(a.steps > 0 ? a.steps : 1));
+}
+
+template <bool ST_SC1, bool LD_SC1, int TAGGED = 0>
 static void run(const char* name, Args a) {
-  CHECK(hipMemset(a.buf, 0xff, (size_t)8 * 2 * 32 * 64 * 16));
+  CHECK(hipMemset(a.buf, TAGGED == 2 ? 0 : 0xff, (size_t)8 * 2 * 32 * 64 * 16));
+  CHECK(hipMemset(a.torn, 0, 256 * 8));
   CHECK(hipMemset(a.counter, 0, 8 * 64));
   CHECK(hipMemset(a.stale, 0, 256 * 8));
   CHECK(hipMemset(a.gave_up, 0, 4));
@@ -174,7 +231,8 @@ static void run(const char* name, Args a) {
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   CHECK(hipEventRecord(e0));
-  if (TAGGED) hipLaunchKernelGGL((tagged_kernel<ST_SC1, LD_SC1>), dim3(256), dim3(256), 0, 0, a);
+  if (TAGGED == 2) hipLaunchKernelGGL((inband_kernel<ST_SC1, LD_SC1>), dim3(256), dim3(256), 0, 0, a);
+  else if (TAGGED) hipLaunchKernelGGL((tagged_kernel<ST_SC1, LD_SC1>), dim3(256), dim3(256), 0, 0, a);
   else hipLaunchKernelGGL((handoff_kernel<ST_SC1, LD_SC1>), dim3(256), dim3(256), 0, 0, a);
   CHECK(hipEventRecord(e1));
   CHECK(hipDeviceSynchronize());
@@ -191,6 +249,16 @@ static void run(const char* name, Args a) {
   int mismapped = 0;
   if (!TAGGED) for (int b = 0; b < 256; ++b) mismapped += (xcc[b] != xcc[b & 7]);   // same group -> same XCC?
   if (TAGGED) mismapped = (int)xcc[0];      // polls per step of workgroup 0's first wave instead
+  if (TAGGED == 2) {
+    std::vector<unsigned long long> tn(256);
+    CHECK(hipMemcpy(tn.data(), a.torn, 256 * 8, hipMemcpyDeviceToHost));
+    unsigned long long torn = 0;
+    for (auto v : tn) torn += v;
+    printf("%-28s steps %d  %.2f us/step  granules that passed the check with a wrong payload %llu of %llu  "
+           "(polls that saw a granule with mixed validity bits: %llu; polls per step %d, gave up: %u)\n",
+           name, a.steps, ms * 1e3 / a.steps, total, (unsigned long long)a.steps * 256 * 32 * 64, torn, mismapped, gave);
+    return;
+  }
   printf("%-28s steps %d  %.2f us/step  stale granules %llu of %llu  (groups split over XCCs: %d workgroups, gave up: %u)\n",
          name, a.steps, ms * 1e3 / a.steps, total, (unsigned long long)a.steps * 256 * 32 * 64, mismapped, gave);
 }
@@ -201,6 +269,7 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc((void**)&a.buf, (size_t)8 * 2 * 32 * 64 * 16));
   CHECK(hipMalloc((void**)&a.counter, 8 * 64));
   CHECK(hipMalloc((void**)&a.stale, 256 * 8));
+  CHECK(hipMalloc((void**)&a.torn, 256 * 8));
   CHECK(hipMalloc((void**)&a.xcc, 256 * 4));
   CHECK(hipMalloc((void**)&a.gave_up, 4));
   for (int rep = 0; rep < 2; ++rep) {
@@ -208,8 +277,10 @@ int main(int argc, char** argv) {
     run<false, true>("stores plain, loads sc1", a);
     run<false, false>("stores plain, loads plain", a);
     run<true, false>("stores sc1,   loads plain", a);
-    run<true, true, true>("tagged: sc1 / sc1", a);
-    run<false, true, true>("tagged: plain / sc1", a);
+    run<true, true, 1>("tagged: sc1 / sc1", a);
+    run<false, true, 1>("tagged: plain / sc1", a);
+    run<false, true, 2>("in-band bits: plain / sc1", a);
+    run<true, true, 2>("in-band bits: sc1 / sc1", a);
   }
   return 0;
 }

@@ -308,3 +308,63 @@ def test_bench_counts_devices_without_touching_hip():
     spec.loader.exec_module(bench)
     n = bench.visible_gpus()
     assert n == torch.cuda.device_count()
+
+
+def _native_comm_two_rank_worker(rank, port, ret_dir):
+    """One of two processes, each on its own GPU: the library's communicator against torch.distributed's."""
+    import torch.distributed as dist
+    from idiaptts_amd import lib, parallel
+    lib.require_gpu()
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+    out = {"version": int(lib.load().itts_comm_version())}
+    with parallel.NativeComm(rank=rank, world=2) as comm:         # id broadcast over the process group's store
+        g = torch.Generator(device=dev).manual_seed(10 + rank)
+        for name, dtype, n in (("f32", torch.float32, 581_307), ("f64", torch.float64, 1 + 187 + 187 * 187)):
+            mine = torch.randn(n, generator=g, device=dev, dtype=dtype)
+            for op, ref_op in (("sum", dist.ReduceOp.SUM), ("avg", dist.ReduceOp.AVG), ("max", dist.ReduceOp.MAX)):
+                a, b = mine.clone(), mine.clone()
+                comm.allreduce_flat_(a, op=op)
+                dist.all_reduce(b, op=ref_op)
+                torch.cuda.synchronize()
+                out["{}_{}".format(name, op)] = bool(torch.equal(a, b)) and not bool(torch.equal(a, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(os.path.join(ret_dir, "rank{}.json".format(rank)), "w") as f:
+        json.dump(out, f)
+
+
+def test_native_comm_two_ranks_equal_torch_distributed(gpu, tmp_path):
+    """a one-rank reduction is the identity and proves nothing about the id broadcast, the
+    multi-rank ncclCommInitRank, or the enum values the binding hard-codes.  Two processes on two GPUs: sum,
+    average and maximum of float32 / float64 buffers through itts_allreduce_flat equal torch.distributed's
+    bit for bit.  Skipped where fewer than two GPUs are visible (the one-GPU boxes of the test pool)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for rank in range(2):
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_dp as t; "
+                "t._native_comm_two_rank_worker(%d, %d, %r)" % (ROOT, os.path.join(ROOT, "tests"), rank, port, str(tmp_path)))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+    for rank in range(2):
+        res = json.load(open(os.path.join(str(tmp_path), "rank{}.json".format(rank))))
+        assert res.pop("version") >= 21000
+        assert all(res.values()), res
+
+
+def test_rccl_version_is_one_the_binding_knows(gpu):
+    from idiaptts_amd import lib
+    v = int(lib.load().itts_comm_version())
+    assert 21000 <= v < 30000, v

@@ -83,6 +83,32 @@ def test_cheaptrick_and_fused_mcep_match_oracle(gpu, utts, golden_dir):
     assert np.abs(mc[:n0].astype(np.float32) - cmp_[:, :20]).max() <= 4.8e-7
 
 
+@pytest.mark.parametrize("order", [19, 24, 59])
+def test_fused_newton_products_equal_the_two_launches_bit_for_bit(gpu, utts, order):
+    """csrc/mcep_lockstep.hip, mcls_fused_products_kernel (round 5): a Newton round's two products in one kernel
+    -- the [frames x 513] ratio stays in LDS -- against the two launches it replaces (ITTS_MCEP_FUSED=0): same K
+    permutation, same order of accumulation, same epilogue expression, so the mel-cepstra are the same bits and
+    the trip counts the same numbers (orders 19 / 24: one column tile of cr, 59: two; 79 has no fused form)."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    amp = torch.from_numpy(np.concatenate([np.sqrt(capi.cheaptrick(xu, fs, tpu, f0u)) for xu, fs, f0u, tpu in utts[:2]])).to(gpu)
+    res = {}
+    old = os.environ.get("ITTS_MCEP_FUSED")
+    try:
+        for mode in ("0", "1"):
+            os.environ["ITTS_MCEP_FUSED"] = mode
+            mc, iters = ops.mcep(amp, order, 0.41, dtype=torch.float64, want_iters=True)
+            res[mode] = (mc.cpu().numpy(), iters.cpu().numpy())
+    finally:
+        if old is None:
+            os.environ.pop("ITTS_MCEP_FUSED", None)
+        else:
+            os.environ["ITTS_MCEP_FUSED"] = old
+    assert np.array_equal(res["0"][1], res["1"][1])
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert res["1"][1].max() > 2            # the loop did iterate
+
+
 @pytest.mark.parametrize("order,alpha", [(59, 0.41), (24, 0.41), (79, 0.58)])
 def test_mcep_from_amp_and_mgc2sp_roundtrip(gpu, utts, order, alpha):
     from idiaptts_amd import ops
