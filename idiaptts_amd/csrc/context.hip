@@ -475,6 +475,13 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
       for (int j = 0; j <= m2; ++j) crt[(size_t)k * (m2 + 1) + j] = (double)(accj[j] * wk / nfft);
     }
     if (upload(crt, &t.crT) != ITTS_OK) return nullptr;
+    if (m <= 63) {
+      t.kpad = (f2 + 1 + 63) / 64 * 64;
+      std::vector<double> crp((size_t)t.kpad * 128, 0.0);
+      for (int k = 0; k <= f2; ++k)
+        for (int j = 0; j <= m2; ++j) crp[(size_t)k * 128 + j] = crt[(size_t)k * (m2 + 1) + j];
+      if (upload(crp, &t.crP) != ITTS_OK) return nullptr;
+    }
     // initT = (H Ci)^T . fwd, H = diag(1/2, 1, ..., 1, 1/2): the initial mel-cepstrum from the log periodogram
     // (mcep.c: c = ifft(log x); c[0] /= 2; c[f2] /= 2; mc = freqt(c, +alpha))
     std::vector<double> ini((size_t)(f2 + 1) * (m + 1));
@@ -507,6 +514,13 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
       }
     }
     if (upload(spec, &t.specT) != ITTS_OK) return nullptr;
+    if (m <= 63) {
+      const int kpad = (f2 + 1 + 63) / 64 * 64;
+      std::vector<double> sp((size_t)64 * kpad, 0.0);
+      for (int j = 0; j <= m; ++j)
+        for (int k = 0; k <= f2; ++k) sp[(size_t)j * kpad + k] = spec[(size_t)j * (f2 + 1) + k];
+      if (upload(sp, &t.specP) != ITTS_OK) return nullptr;
+    }
   }
   if (need_mgc && !t.b1T) {
     std::vector<double> b1((size_t)(m + 1) * (f2 + 1)), p2((size_t)(f2 + 1) * (m2 + 1));

@@ -485,175 +485,168 @@ __global__ __launch_bounds__(256) void gemm_f64_lds_kernel(const double* __restr
 // The [rows x K] ratio D never exists in memory.  Until round 4 the first product (gemm_f64_kernel<.., RATIO>)
 // wrote it and the second (gemm_f64_lds_kernel) read it back: 2 x 4.1 KB per frame and round on top of the 4.1 KB
 // of the periodogram, 26 GB of the analysis' 44 GB, the first launch bound by HBM (6 TB/s) and the second at two
-// thirds of the fp64 matrix rate.  Here a wave owns 32 frames and walks the K spectral bins in chunks of 64:
-//   P1  S[32 x 64]   = MC[32 x m1] . specT[m1 x 64 of K]       128 MFMAs (m1 <= 64), operands from L1 / L2
-//       D[32 x 64]   = X / exp(2 S)                            the epilogue of round 4, values straight to LDS in the
-//                                                              layout of an A operand (the wave's own 16.9 KB)
-//   P2  cr[32 x N2] += D[32 x 64] . crT[64 of K x N2]          256 MFMAs at N2 = 119, accumulators live across chunks
-// so HBM sees the periodogram rows once (4.1 KB per frame and round) and 0.95 KB of cr.  No workgroup barrier: the
-// exchange through LDS is inside a wave (its LDS operations execute in order).  specT (246 KB) and crT (488 KB) are
-// read from L2 by every wave: 96 KB per chunk against 24 576 cycles of MFMA work, 4 B per cycle and wave.  Same K
-// permutation and order of accumulation as the two kernels it replaces, same expression in the epilogue: the
-// results are bit-identical (tests/test_gpu_world.py runs both; ITTS_MCEP_FUSED=0 keeps the two launches).
-constexpr int FP_PITCH = 66;                                     // doubles per parked row (as GA_PITCH)
-constexpr int FUSED_LDS_BYTES = 4 * 32 * FP_PITCH * 8;
-template <int NT2>   // column tiles of 64 in cr: 1 (orders up to 32) or 2 (up to 63)
-__global__ __launch_bounds__(256, 2) void mcls_fused_products_kernel(
-    const double* __restrict__ mc, int m1, const double* __restrict__ specT, const double* __restrict__ xp,
-    int64_t ldk, const double* __restrict__ crT, double* __restrict__ cr, int64_t nr, int K, int N2,
+// thirds of the fp64 matrix rate: 7.35 ms per analysis of 256 utterances.  Forms tried on the way (DESIGN.md
+// section 13b): a wave of 32 frames with the ratio tile parked in its own LDS and the table operands straight from
+// L2 (8.9 ms: every operand an L2 round trip in front of its products; with the periodogram by DMA, padded tables
+// and explicit operand prefetch 5.9 ms, but 256 registers and a quarter of the accumulators in scratch); then the
+// form below, 4.9 ms.
+typedef __attribute__((address_space(3))) char* mcls_lds_p;
+__device__ __forceinline__ void mcls_dma_piece(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t dst) {
+  // lane l fetches 16 bytes at rsrc.base + voff + soff; the wave's 64 pieces land at LDS byte address dst + 16 l
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(dst)
+               : "memory");
+}
+
+// The OPERAND TABLES go through LDS, the ratio stays in registers.
+// One workgroup of eight waves per CU; a wave owns 16 frames.  Per chunk of 64 spectral bins the workgroup holds the
+// chunk's slice of specP [64 k x 64 bins, 32 KB] and of crP [64 bins x 128, 64 KB] in LDS -- brought by DMA (no
+// registers, 1-KB pieces; the slice of the NEXT chunk is requested as soon as the last wave has
+// read this one's) and read by all twelve waves, so the L2 sees each table once per workgroup and chunk instead of once
+// per wave (all eight waves read the same slice), and an operand is an LDS read away from its product instead of an L2 round trip.
+//   P1  the log spectrum TRANSPOSED, S^T[bins x frames] = specP^T . MC^T: the lane that ends up with
+//       S[frame j][bins 16 t + 4 kg + r] is the lane that must supply D[frame j][k = 16 t + 4 kg + r] as the A operand
+//       of P2 -- the rows of the A operand of P1 are handed the bins in that order (perm below) -- so the ratio
+//       D = X / exp(2 S) is formed in registers and stays there: no tile in LDS, no exchange.
+//   P2  cr[frames x N2] += D . crP, B operand from LDS.
+// Same k of the same lane group on the same product, same order of accumulation as in the two-launch form.
+
+constexpr int F3_SPEC_BYTES = 64 * 64 * 8, F3_CR_BYTES = 64 * 128 * 8, F3_LDS_BYTES = F3_SPEC_BYTES + F3_CR_BYTES;
+constexpr int F3_WAVES = 8;          // (twelve -- three per SIMD, 168 registers -- spill the accumulators: 6.1 ms)
+template <int NTILES>   // 16-column tiles of cr: 8 (N2 <= 128) or 4 (N2 <= 64)
+__global__ __launch_bounds__(64 * F3_WAVES, F3_WAVES / 4) void mcls_fused3_kernel(
+    const double* __restrict__ mc, int m1, const double* __restrict__ specP, const double* __restrict__ xp, int64_t ldk,
+    const double* __restrict__ crP, double* __restrict__ cr, int64_t nr, int K, int kpad, int N2,
     const int* __restrict__ rows) {
-  extern __shared__ __attribute__((aligned(16))) char fsm[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int lr = lane & 15, kg = lane >> 4;
-  double* Ds = reinterpret_cast<double*>(fsm) + (size_t)wv * 32 * FP_PITCH;
-  const int64_t r0 = (int64_t)blockIdx.x * 128 + wv * 32;
-  if (r0 >= nr) return;                       // (no workgroup barrier anywhere below)
-  // rows of the A operand (row lr of block h) and rows of the results (row kg + 4 r of block h)
-  const double* mrow[2];
-  bool rok[2];
+  extern __shared__ __attribute__((aligned(1024))) char fsm[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, kg = lane >> 4;
+  const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mcls_lds_p)fsm);
+  const double* specL = reinterpret_cast<const double*>(fsm);
+  const double* crL = reinterpret_cast<const double*>(fsm + F3_SPEC_BYTES);
+  const bool spec_wave = wv < 4;       // waves 0 .. 3 fetch the specP slices (8 pieces each), the others the crP slices
+  constexpr int CR_PIECES = 64 / (F3_WAVES - 4);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(specP), 0, 64 * kpad * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(crP), 0, kpad * 1024, 0x00020000);
+  // specP piece p (0 .. 31): rows k = 2 p, 2 p + 1 of the slice, lane l brings 16 bytes (l & 31) of row 2 p + (l >> 5)
+  // crP piece q (0 .. 63): row (bin) q of the slice, lane l brings its 16 bytes l
+  auto request_tables = [&](int ch) {
+    if (spec_wave) {
+      const uint32_t voff = (uint32_t)(lane >> 5) * (uint32_t)kpad * 8u + 16u * (uint32_t)(lane & 31);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int64_t row = r0 + 16 * h + lr;
-    rok[h] = row < nr;
-    mrow[h] = mc + (rok[h] ? (rows ? (int64_t)rows[row] : row) : 0) * m1;
-  }
-  int erow[2][4];          // (frame indices fit 32 bits: the work list is an int array)
-  unsigned emask = 0;
+      for (int i = 0; i < 8; ++i) {
+        const int p = 8 * wv + i;
+        mcls_dma_piece(srs, voff, (uint32_t)(2 * p) * (uint32_t)kpad * 8u + (uint32_t)ch * 512u, l0 + 1024u * p);
+      }
+    } else {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = r0 + 16 * h + kg + 4 * r;
-      const bool ok = row < nr;
-      emask |= ok ? (1u << (4 * h + r)) : 0u;
-      erow[h][r] = ok ? (rows ? rows[row] : (int)row) : 0;
+      for (int i = 0; i < CR_PIECES; ++i) {
+        const int q = CR_PIECES * (wv - 4) + i;
+        mcls_dma_piece(crs, 16u * (uint32_t)lane, ((uint32_t)ch * 64u + q) * 1024u, l0 + F3_SPEC_BYTES + 1024u * q);
+      }
     }
-  f64x4 acc2[2][NT2][4];
+  };
+  const int64_t f0 = (int64_t)blockIdx.x * (16 * F3_WAVES) + wv * 16;
+  auto phys = [&](int64_t f) -> int64_t { return rows[f < nr ? f : nr - 1]; };   // (never NULL; frames past the end repeat the last)
+  const double* mrow = mc + phys(f0 + j) * m1 + 4 * kg;
+  const double* xrow = xp + phys(f0 + j) * ldk + 4 * kg;
+  f64x4 acc2[NTILES];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int nt = 0; nt < NTILES; ++nt) acc2[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // periodogram values of a chunk: bins c0 + 16 t + 4 kg .. + 3 of this lane's frame
+  f64x4 xv[4];
+  auto request_x = [&](int ch) {
 #pragma unroll
-    for (int t = 0; t < NT2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc2[h][t][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  const int nchunk = (K + 63) / 64;
+    for (int t = 0; t < 4; ++t) xv[t] = *reinterpret_cast<const f64x4*>(xrow + ch * 64 + 16 * t);
+  };
+  request_tables(0);       // (a spec wave holds specP pieces, the others crP pieces: each waits for its own below)
+  request_x(0);
+  const int nchunk = kpad / 64;
+  const int perm = 4 * (j & 3) + (j >> 2);          // row j of the A operand of P1 stands for bin 16 t + perm
+  if (spec_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the first specP slice have landed
+  __syncthreads();                                                    // ... and everybody else's
+  // Two barriers per chunk.  A wave's products wait for nothing but LDS; what a wave has to WAIT for from memory was
+  // requested at least a product phase earlier: the specP slice of chunk c + 1 during the second phase of chunk c,
+  // the crP slice of chunk c + 1 during the first phase of chunk c + 1, the periodogram values of chunk c + 1 tile by
+  // tile as the ratio of chunk c has consumed them.
   for (int ch = 0; ch < nchunk; ++ch) {
-    const int c0 = ch * 64, cb = c0 + 4 * lr;
-    const bool cfull = cb + 3 < K;
-    // ---- P1 (log spectrum of the model at bins c0 .. c0 + 63) and the ratio to the periodogram, parked as this
-    // wave's A operand of P2 (rows kg + 4 r, columns 4 lr .. 4 lr + 3) -- one 16-row block after the other
-    // (sched_barrier): both at once hold 64 more registers than the 256 two waves per SIMD leave
+    const int c0 = ch * 64;
+    // ---- P1 (transposed)
+    f64x4 d[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1) __builtin_amdgcn_sched_barrier(0);
-      f64x4 acc1[4];
+    for (int t = 0; t < 4; ++t) d[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    {
+      const double* sa = specL + (4 * kg) * 64 + perm;
+      f64x4 mv[2];
+      mv[0] = *reinterpret_cast<const f64x4*>(mrow);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc1[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
-      for (int s = 0; s < m1; s += 16) {
+      for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) mv[(s + 1) & 1] = *reinterpret_cast<const f64x4*>(mrow + 16 * (s + 1));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = s + 4 * kg + j;
-          const bool kok = k < m1;
-          const int kc = kok ? k : 0;
-          const double a = mrow[h][kc];
-          const double* brow = specT + (int64_t)kc * K;
-          double b[4];
-          if (cfull) {
-            const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb);
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = b4[q];
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = brow[cb + q < K ? cb + q : 0];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok[h]) ? a : 0.0,
-                                                           (kok && (cfull || cb + q < K)) ? b[q] : 0.0, acc1[q], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool rv = (emask >> (4 * h + r)) & 1u;
-        const double* xrow = xp + (int64_t)erow[h][r] * ldk + cb;
-        double x4[4];
-        if (cfull) {
-          const f64x4 xv = *reinterpret_cast<const f64x4*>(xrow);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) x4[q] = xv[q];
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) x4[q] = xrow[cb + q < K ? q : 0];
-        }
-        double d[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)      // (the reference's expression, oracle/c/sptk.c:135)
-          d[q] = (rv && (cfull || cb + q < K)) ? x4[q] / exp(2.0 * acc1[q][r]) : 0.0;
-        double* dst = Ds + (16 * h + kg + 4 * r) * FP_PITCH + 4 * lr;
-        *reinterpret_cast<double2*>(dst) = make_double2(d[0], d[1]);
-        *reinterpret_cast<double2*>(dst + 2) = make_double2(d[2], d[3]);
+          for (int t = 0; t < 4; ++t)
+            d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[(16 * s + jj) * 64 + 16 * t], mv[s & 1][jj], d[t], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes, read back below in another layout
-    // ---- P2: warped autocorrelation, this chunk's share
-    const double* as = Ds + lr * FP_PITCH + 4 * kg;
+    if (!spec_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the crP slice have landed
+    __syncthreads();          // everybody has read the specP slice (the next one may come) and the crP slice is whole
+    if (spec_wave && ch + 1 < nchunk) request_tables(ch + 1);
+    // ---- the ratio, in registers, tile by tile: d[t][r] = S[frame j][bin c0 + 16 t + 4 kg + r] -> D (the reference's
+    // expression, oracle/c/sptk.c:135) -- and P2 behind it: group tcl, step r: k = c0 + 16 tcl + 4 kg + r, the bin
+    // d[tcl][r] belongs to.  The ratio of tile t + 1 (some 300 fp64 instructions) is written in front of the 32 products
+    // of group t: the two do not depend on each other and issue side by side.
+    const bool more = ch + 1 < nchunk;
+    const double* xnext = xrow + (more ? ch + 1 : ch) * 64;          // (the last chunk re-reads itself: no branch in the blocks below)
+    auto ratio = [&](int t) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c0 + 16 * c >= K) break;            // the last chunk may hold fewer than four groups of 16 k
-      double am[2][4];
+      for (int r = 0; r < 4; ++r) d[t][r] = xv[t][r] / exp(2.0 * d[t][r]);
+      xv[t] = *reinterpret_cast<const f64x4*>(xnext + 16 * t);       // consumed after the next chunk's P1
+    };
+    {
+      const double* cb = crL + (4 * kg) * 128 + j;
+      const int ngroups = min(4, (K - c0 + 15) / 16);        // the last chunk may hold fewer than four groups of 16 k
+      ratio(0);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const double2 v0 = *reinterpret_cast<const double2*>(as + 16 * h * FP_PITCH + 16 * c);
-        const double2 v1 = *reinterpret_cast<const double2*>(as + 16 * h * FP_PITCH + 16 * c + 2);
-        am[h][0] = v0.x; am[h][1] = v0.y; am[h][2] = v1.x; am[h][3] = v1.y;
-      }
+      for (int tcl = 0; tcl < 4; ++tcl) {
+        if (tcl < ngroups) {
+          // one basic block: the ratio of the next tile and the 4 NTILES products of this group do not depend on
+          // each other; the scheduler is told to take them in turn (left alone it puts the ratio in front)
+          if (tcl + 1 < 4) ratio(tcl + 1);
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int k = c0 + 16 * c + 4 * kg + jj;
-        const bool kok = k < K;
-        const double* brow = crT + (int64_t)(kok ? k : 0) * N2;
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) {
-          const int cb2 = 64 * t + 4 * lr;
-          double b[4];
-          if (cb2 + 3 < N2) {
-            const f64x4 b4 = *reinterpret_cast<const f64x4*>(brow + cb2);
+            for (int nt = 0; nt < NTILES; ++nt)
+              acc2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[tcl][r], cb[(16 * tcl + r) * 128 + 16 * nt], acc2[nt], 0, 0, 0);
+          if (tcl + 1 < 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = b4[q];
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = brow[cb2 + q < N2 ? cb2 + q : 0];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const double bq = (kok && cb2 + q < N2) ? b[q] : 0.0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-              acc2[h][t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[h][jj], bq, acc2[h][t][q], 0, 0, 0);
+            for (int i = 0; i < 4 * NTILES; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, 128 / (4 * NTILES) + 1, 0);   // VALU of the ratio
+            }
           }
         }
       }
     }
-    asm volatile("" ::: "memory");            // the next chunk's park comes behind these reads (LDS runs a wave's
-                                              // operations in order)
+    if (spec_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the next specP slice have landed
+    __syncthreads();          // everybody has read the crP slice, and the next specP slice is whole
+    if (!spec_wave && more) request_tables(ch + 1);
   }
+  // acc2[nt][r]: frame kg + 4 r of the wave, column 16 nt + j
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int r = 0; r < 4; ++r) {
+    const int64_t f = f0 + kg + 4 * r;
+    if (f >= nr) continue;
+    double* crow = cr + (int64_t)rows[f] * N2 + j;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (!((emask >> (4 * h + r)) & 1u)) continue;
-#pragma unroll
-      for (int t = 0; t < NT2; ++t) {
-        const int cb2 = 64 * t + 4 * lr;
-        double* crow = cr + (int64_t)erow[h][r] * N2 + cb2;
-        if (cb2 + 3 < N2) {
-          *reinterpret_cast<f64x4*>(crow) = (f64x4){acc2[h][t][0][r], acc2[h][t][1][r], acc2[h][t][2][r], acc2[h][t][3][r]};
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (cb2 + q < N2) crow[q] = acc2[h][t][q][r];
-        }
-      }
-    }
+    for (int nt = 0; nt < NTILES; ++nt)
+      if (16 * nt + j < N2) crow[16 * nt] = acc2[nt][r];
+  }
+}
+
+__global__ void mcls_iota_kernel(int* __restrict__ rows, int64_t T) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < T; i += (int64_t)gridDim.x * blockDim.x) rows[i] = (int)i;
 }
 
 // list of the frames that are still iterating (order irrelevant: frames are independent)
@@ -709,6 +702,9 @@ __global__ __launch_bounds__(256) void mcls_init_flat_kernel(LsArgs a) {
       lg[k] = l;
       acc += (k == 0 || k == f2) ? l : 2.0 * l;
     }
+    // the pad columns of the row (even pitch): the fused kernel's tiles cover them (they meet zero rows of crP,
+    // which only an Inf or NaN would survive)
+    for (int k = K + lane; k < a.ldk; k += 64) xp[k] = 1.0;
     acc = wave_sum(acc);
     if (lane == 0) {
       a.sprev[g] = acc / (double)a.flng / 2;
@@ -1053,10 +1049,15 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   double *xp = nullptr, *cbuf = nullptr, *mc = nullptr, *cr = nullptr, *sprev = nullptr;
   int *done = nullptr, *iters = nullptr, *n_active = nullptr, *rows = nullptr;
   const int64_t Kp = K + (K & 1);   // even pitch: 16-byte aligned rows for the vector loads
-  const size_t slack = 64;          // the vector loads may run up to 3 doubles past a row's end
+  // the vector loads may run up to 3 doubles past a row's end; the fused kernel's operand loads of the last
+  // mel-cepstrum row up to 64 values (they meet zero rows of specP / crP: the slack is cleared, an Inf or NaN
+  // would survive the zero)
+  const size_t slack = 512;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&xp, (size_t)T * Kp * 8 + slack, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&cbuf, (size_t)T * Kp * 8 + slack, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&mc, (size_t)T * m1 * 8 + slack, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(xp) + (size_t)T * Kp * 8, 0, slack, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(mc) + (size_t)T * m1 * 8, 0, slack, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&cr, (size_t)T * (m2 + 1) * 8, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&sprev, (size_t)T * 8, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&done, (size_t)T * 4, s));
@@ -1083,16 +1084,20 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   if (rc) return rc;
   // both products of a round in one kernel where its accumulators fit (order <= 63); ITTS_MCEP_FUSED=0: two launches
   const char* fenv = getenv("ITTS_MCEP_FUSED");
-  const bool fused = m1 <= 64 && m2 + 1 <= 128 && !(fenv && fenv[0] == '0');
+  const bool fused = m1 <= 64 && m2 + 1 <= 128 && ft->specP && ft->crP && !(fenv && fenv[0] == '0');
+  int* rows_all = nullptr;          // the identity list the fused kernel walks while no frame has converged yet
+  if (fused) {
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&rows_all, (size_t)T * 4, s));
+    hipLaunchKernelGGL(mcls_iota_kernel, dim3((unsigned)std::min<int64_t>((T + 255) / 256, 2048)), dim3(256), 0, s, rows_all, T);
+    ITTS_LAUNCH_CHECK();
+  }
   if (fused) {
     static std::atomic<uint64_t> attr_done{0};
     int dev = 0;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_fused_products_kernel<1>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_fused_products_kernel<2>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_fused3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_fused3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES));
       if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
     }
   }
@@ -1103,13 +1108,14 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     // transforms of the reference's loop are folded into the warping matrices: FreqtTables), then the
     // warped autocorrelation of the ratio
     if (fused) {
-      const dim3 fgrid((unsigned)((nr + 127) / 128));
+      const dim3 fgrid((unsigned)((nr + 16 * F3_WAVES - 1) / (16 * F3_WAVES))), fblock(64 * F3_WAVES);
+      const int* rl = a.rows ? a.rows : rows_all;
       if (m2 + 1 <= 64)
-        hipLaunchKernelGGL(mcls_fused_products_kernel<1>, fgrid, dim3(256), FUSED_LDS_BYTES, s, mc, m1, ft->specT, xp, Kp,
-                           ft->crT, cr, nr, K, m2 + 1, a.rows);
+        hipLaunchKernelGGL(mcls_fused3_kernel<4>, fgrid, fblock, F3_LDS_BYTES, s, mc, m1, ft->specP, xp, Kp, ft->crP, cr, nr, K,
+                           ft->kpad, m2 + 1, rl);
       else
-        hipLaunchKernelGGL(mcls_fused_products_kernel<2>, fgrid, dim3(256), FUSED_LDS_BYTES, s, mc, m1, ft->specT, xp, Kp,
-                           ft->crT, cr, nr, K, m2 + 1, a.rows);
+        hipLaunchKernelGGL(mcls_fused3_kernel<8>, fgrid, fblock, F3_LDS_BYTES, s, mc, m1, ft->specP, xp, Kp, ft->crP, cr, nr, K,
+                           ft->kpad, m2 + 1, rl);
       ITTS_LAUNCH_CHECK();
     } else {
       if ((rc = launch_gemm_f64_ratio(mc, m1, ft->specT, K, cbuf, Kp, nr, K, m1, a.rows, xp, s))) return rc;
@@ -1153,6 +1159,7 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   ITTS_HIP_CHECK(itts::scratch_free(n_active, s));
   ITTS_HIP_CHECK(itts::scratch_free(apow, s));
   ITTS_HIP_CHECK(itts::scratch_free(rows, s));
+  if (rows_all) ITTS_HIP_CHECK(itts::scratch_free(rows_all, s));
   return ITTS_OK;
 }
 

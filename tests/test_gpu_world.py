@@ -85,10 +85,11 @@ def test_cheaptrick_and_fused_mcep_match_oracle(gpu, utts, golden_dir):
 
 @pytest.mark.parametrize("order", [19, 24, 59])
 def test_fused_newton_products_equal_the_two_launches_bit_for_bit(gpu, utts, order):
-    """csrc/mcep_lockstep.hip, mcls_fused_products_kernel (round 5): a Newton round's two products in one kernel
-    -- the [frames x 513] ratio stays in LDS -- against the two launches it replaces (ITTS_MCEP_FUSED=0): same K
-    permutation, same order of accumulation, same epilogue expression, so the mel-cepstra are the same bits and
-    the trip counts the same numbers (orders 19 / 24: one column tile of cr, 59: two; 79 has no fused form)."""
+    """csrc/mcep_lockstep.hip, mcls_fused3_kernel (round 5): a Newton round's two
+    products in one kernel -- the [frames x 513] ratio never leaves the CU -- against the two launches it replaces
+    (ITTS_MCEP_FUSED=0): same K permutation, same order of accumulation, same epilogue expression, so the
+    mel-cepstra are the same bits and the trip counts the same numbers (orders 19 / 24: cr is up to 64 wide, 59: up
+    to 128; 79 has no fused form)."""
     from idiaptts_amd import ops
     from oracle import capi
     amp = torch.from_numpy(np.concatenate([np.sqrt(capi.cheaptrick(xu, fs, tpu, f0u)) for xu, fs, f0u, tpu in utts[:2]])).to(gpu)
