@@ -24,6 +24,7 @@ struct FreqtTables {
   // zero-padded copies for mcls_fused_products_kernel (m <= 63): every operand load a whole, aligned 32-byte vector
   double* specP = nullptr; // [64][kpad]    specT with rows m+1 .. 63 and columns f2+1 .. kpad-1 zero; kpad = f2+1 rounded up to 64
   double* crP = nullptr;   // [kpad][128]   crT with rows f2+1 .. kpad-1 and columns 2m+1 .. 127 zero
+  double* initP = nullptr; // [kpad][64]    initT with rows f2+1 .. kpad-1 and columns m+1 .. 63 zero
   int kpad = 0;
   double* initT = nullptr; // [f2+1][m+1]   mc0[j] = sum_k initT[k][j] * lg[k]    = freqt(c, +a), c = irfft(lg) with c[0], c[f2] halved
   // SPTK mgcep's own transform b2c (freqt without the `+ a d[0]` in the zeroth term):

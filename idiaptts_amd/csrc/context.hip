@@ -497,6 +497,13 @@ const FreqtTables* get_freqt(DeviceContext* ctx, int m, int f2, double alpha, bo
       for (int j = 0; j <= m; ++j) ini[(size_t)k * (m + 1) + j] = (double)(accm[j] * wk / nfft);
     }
     if (upload(ini, &t.initT) != ITTS_OK) return nullptr;
+    if (m <= 63) {
+      const int kpad = (f2 + 1 + 63) / 64 * 64;
+      std::vector<double> ip((size_t)kpad * 64, 0.0);
+      for (int k = 0; k <= f2; ++k)
+        for (int j = 0; j <= m; ++j) ip[(size_t)k * 64 + j] = ini[(size_t)k * (m + 1) + j];
+      if (upload(ip, &t.initP) != ITTS_OK) return nullptr;
+    }
   }
   if ((need_spec || need_fwd_frq) && !t.specT) {
     // specT = inv . C with C[n][k] = cos(2 pi k n / 2 f2): the real part of the one-sided transform of

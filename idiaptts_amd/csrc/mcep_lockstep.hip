@@ -715,6 +715,119 @@ __global__ __launch_bounds__(256) void mcls_init_flat_kernel(LsArgs a) {
 }
 
 
+// The start of the loop in ONE kernel (round 5; until then mcls_init_flat_kernel wrote the periodogram AND its
+// logarithm -- 2 x 1.3 GB for 256 utterances -- and a product read the logarithms back): a wave owns 16 frames and
+// walks the bins in chunks of 64 as mcls_fused3_kernel does; the logarithms of a chunk are formed in the registers of
+// the lanes that supply them as the A operand of  mc0 += LG . initP  (the chunk's slice of initP, 32 KB, in LDS by
+// DMA, two buffers), the periodogram is written for the loop, the loop's first reference value (the mean log
+// periodogram / 2) is summed on the way.  Same k of the same lane group on the same product, same order of
+// accumulation as the product it replaces: the same initial mel-cepstrum bit for bit.  The reference value's sum
+// runs in another order (it is only compared against when miniter < 2; pysptk's default is 2).
+constexpr int FI_WAVES = 8, FI_SLICE_BYTES = 64 * 64 * 8, FI_LDS_BYTES = 2 * FI_SLICE_BYTES;
+__global__ __launch_bounds__(64 * FI_WAVES, 4) void mcls_init_fused_kernel(LsArgs a, const double* __restrict__ initP, int kpad) {
+  extern __shared__ __attribute__((aligned(1024))) char fsm[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, kg = lane >> 4;
+  const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mcls_lds_p)fsm);
+  const int f2 = a.flng / 2, K = f2 + 1, m1 = a.m + 1;
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(initP), 0, kpad * 512, 0x00020000);
+  // slice of chunk ch: rows (bins) 64 ch .. + 63 of initP, 512 bytes each: piece p = rows 2 p, 2 p + 1; waves 0 .. 3 fetch
+  auto request_slice = [&](int ch) {
+    if (wv < 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = 8 * wv + i;
+        mcls_dma_piece(irs, 16u * (uint32_t)lane, ((uint32_t)ch * 64u + 2u * p) * 512u, l0 + (uint32_t)(ch & 1) * FI_SLICE_BYTES + 1024u * p);
+      }
+    }
+  };
+  const int64_t f0 = (int64_t)blockIdx.x * (16 * FI_WAVES) + wv * 16;
+  const int64_t fj = f0 + j < a.T ? f0 + j : a.T - 1;              // (frames past the end repeat the last and are not stored)
+  const bool fvalid = f0 + j < a.T;
+  const double* irow = a.in + fj * K + 4 * kg;
+  double* xrow = a.xp + fj * a.ldk + 4 * kg;
+  f64x4 acc2[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc2[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double lsum = 0.0;
+  const int nchunk = kpad / 64;
+  request_slice(0);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * 64;
+    // this chunk's amplitudes -> periodogram -> logarithms, in the layout of the A operand (lane (j, kg): bins
+    // c0 + 16 t + 4 kg + r of frame j)
+    f64x4 lg[4];
+    const bool whole = c0 + 64 <= K;             // (uniform) all 64 bins inside the spectrum
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double v[4];
+      if (whole) {
+        typedef double f64x4u __attribute__((ext_vector_type(4), aligned(8)));      // rows of K = 513 doubles: 8-byte aligned
+        const f64x4u q = *reinterpret_cast<const f64x4u*>(irow + c0 + 16 * t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = q[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = c0 + 16 * t + 4 * kg + r < K ? irow[c0 + 16 * t + r] : 1.0;
+      }
+      double x[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = c0 + 16 * t + 4 * kg + r;
+        if (a.in_is_power) v[r] = sqrt(v[r]);    // amp_sp = sqrt(pow_sp), WorldFeatLabelGen.py:795
+        x[r] = v[r] * v[r] + a.eps;
+        const double l = wd::log_pos(x[r]);
+        const bool in = k < K;
+        lg[t][r] = in ? l : 0.0;
+        if (!in) x[r] = 1.0;                     // pad columns of the row: finite (they meet zero rows of crP in the loop)
+        lsum += in ? ((k == 0 || k == f2) ? l : 2.0 * l) : 0.0;
+      }
+      if (fvalid) {
+        if (whole) {
+          *reinterpret_cast<double2*>(xrow + c0 + 16 * t) = make_double2(x[0], x[1]);
+          *reinterpret_cast<double2*>(xrow + c0 + 16 * t + 2) = make_double2(x[2], x[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (c0 + 16 * t + 4 * kg + r < a.ldk) xrow[c0 + 16 * t + r] = x[r];
+        }
+      }
+    }
+    if (wv < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the slice have landed
+    __syncthreads();                                                  // ... everybody's; and everybody is done with the other buffer
+    if (ch + 1 < nchunk) request_slice(ch + 1);
+    const double* ib = reinterpret_cast<const double*>(fsm + (ch & 1) * FI_SLICE_BYTES) + (4 * kg) * 64 + j;
+    const int ngroups = min(4, (K - c0 + 15) / 16);
+#pragma unroll
+    for (int tcl = 0; tcl < 4; ++tcl) {
+      if (tcl < ngroups) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(lg[tcl][r], ib[(16 * tcl + r) * 64 + 16 * nt], acc2[nt], 0, 0, 0);
+      }
+    }
+  }
+  // the frame's sum: its bins are spread over the four lanes (j, kg = 0 .. 3)
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (fvalid && kg == 0) {
+    a.sprev[fj] = lsum / (double)a.flng / 2;
+    a.done[fj] = 0;
+    a.iters[fj] = 0;
+  }
+  // acc2[nt][r]: frame kg + 4 r of the wave, column 16 nt + j
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t f = f0 + kg + 4 * r;
+    if (f >= a.T) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (16 * nt + j < m1) a.mc[f * m1 + 16 * nt + j] = acc2[nt][r];
+  }
+}
+
 // convergence test + Newton update of one frame from cr
 __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1078,13 +1191,27 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   const size_t lds_solve = (size_t)(m2 + 2 + (size_t)m1 * (order + 2) + m1 + 2) * 8;
   ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_solve_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
-  hipLaunchKernelGGL(mcls_init_flat_kernel, dim3((unsigned)std::min<int64_t>((T + 3) / 4, 8192)), dim3(256), 0, s, a);
-  ITTS_LAUNCH_CHECK();
-  int rc = launch_gemm_f64(cbuf, Kp, ft->initT, m1, mc, m1, T, m1, K, nullptr, s);
-  if (rc) return rc;
-  // both products of a round in one kernel where its accumulators fit (order <= 63); ITTS_MCEP_FUSED=0: two launches
+  // both products of a round in one kernel where its accumulators fit (order <= 63), and the start of the loop in
+  // one kernel likewise; ITTS_MCEP_FUSED=0: the separate launches
   const char* fenv = getenv("ITTS_MCEP_FUSED");
-  const bool fused = m1 <= 64 && m2 + 1 <= 128 && ft->specP && ft->crP && !(fenv && fenv[0] == '0');
+  const bool fused = m1 <= 64 && m2 + 1 <= 128 && ft->specP && ft->crP && ft->initP && !(fenv && fenv[0] == '0');
+  int rc = ITTS_OK;
+  if (fused) {
+    static std::atomic<uint64_t> iattr{0};
+    int dev = 0;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((iattr.load() >> dev) & 1)) {
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mcls_init_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FI_LDS_BYTES));
+      if (dev < 64) iattr.fetch_or(uint64_t(1) << dev);
+    }
+    hipLaunchKernelGGL(mcls_init_fused_kernel, dim3((unsigned)((T + 16 * FI_WAVES - 1) / (16 * FI_WAVES))), dim3(64 * FI_WAVES),
+                       FI_LDS_BYTES, s, a, ft->initP, ft->kpad);
+    ITTS_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(mcls_init_flat_kernel, dim3((unsigned)std::min<int64_t>((T + 3) / 4, 8192)), dim3(256), 0, s, a);
+    ITTS_LAUNCH_CHECK();
+    if ((rc = launch_gemm_f64(cbuf, Kp, ft->initT, m1, mc, m1, T, m1, K, nullptr, s))) return rc;
+  }
   int* rows_all = nullptr;          // the identity list the fused kernel walks while no frame has converged yet
   if (fused) {
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&rows_all, (size_t)T * 4, s));

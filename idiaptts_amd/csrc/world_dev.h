@@ -133,8 +133,12 @@ constexpr int FFT_SWZ_MAX = 4 * NT;  // largest transform whose first pass is on
 // In-place complex FFT of z[0..n) (n = 2^logn <= tw_n). tw holds exp(+2 pi i k / tw_n).
 // sign = -1: forward (e^{-i..}), +1: unnormalised inverse. Ends with a barrier.  Input and output
 // are in natural order; in between the elements live at fft_phys(i) (64 <= n <= FFT_SWZ_MAX).
-template <bool SWZ = true>
-__device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, int tw_n, int sign) {
+// CLOGN / CTSHIFT > 0: n = 2^CLOGN and log2(tw_n) - 1 = CTSHIFT are compile-time constants (the passes unroll, their
+// shifts, masks and swizzle constants fold: about a third of a pass's integer instructions go) -- same butterflies,
+// same twiddle entries, same order: same bits.
+template <bool SWZ = true, int CLOGN = 0, int CTSHIFT = 0>
+__device__ inline void fft_lds(double2* z, int n_rt, int logn_rt, const double2* tw, int tw_n, int sign) {
+  const int n = CLOGN ? (1 << CLOGN) : n_rt, logn = CLOGN ? CLOGN : logn_rt;
   const bool swz = SWZ && n >= 64 && n <= FFT_SWZ_MAX;
   if (!swz) {
     for (int i = tid(); i < n; i += NT) {
@@ -147,7 +151,7 @@ __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, i
     }
     __syncthreads();
   }
-  const int tshift = ilog2(tw_n) - 1;  // twiddle index of w_{2h}^r in the tw_n table: r * tw_n/(2h)
+  const int tshift = CTSHIFT ? CTSHIFT : ilog2(tw_n) - 1;  // twiddle index of w_{2h}^r in the tw_n table: r * tw_n/(2h)
   // complex product with the (possibly conjugated) twiddle, the one expression every stage uses
   auto twmul = [&](const double2 v, const double2 w) {
     const double wi = sign < 0 ? -w.y : w.y;
@@ -194,6 +198,7 @@ __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, i
   // butterflies, same twiddle-table entries, same operation order as two separate radix-2
   // passes -- the results are bit-identical -- with 11 instead of 20 LDS accesses per four
   // elements and half the barriers (these kernels are bound by LDS traffic).
+#pragma unroll
   for (; s + 1 <= logn; s += 2) {
     const int h = 1 << (s - 1);
     const bool last = s + 1 == logn;   // the final pass stores in natural order
@@ -239,10 +244,11 @@ __device__ inline void fft_lds(double2* z, int n, int logn, const double2* tw, i
 
 // Real FFT: z viewed as n real samples (z[k] = (x[2k], x[2k+1])), needs n/2+1 complex slots.
 // On return z[k] = X[k], k = 0..n/2 (numpy.fft.rfft).
-template <bool SWZ = true>
-__device__ inline void rfft_lds(double2* z, int n, int logn, const double2* tw, int tw_n) {
+template <bool SWZ = true, int CLOGN = 0, int CTSHIFT = 0>     // (CLOGN: log2 of the REAL transform's size)
+__device__ inline void rfft_lds(double2* z, int n_rt, int logn, const double2* tw, int tw_n_rt) {
+  const int n = CLOGN ? (1 << CLOGN) : n_rt, tw_n = CTSHIFT ? (2 << CTSHIFT) : tw_n_rt;
   const int h = n / 2;
-  fft_lds<SWZ>(z, h, logn - 1, tw, tw_n, -1);
+  fft_lds<SWZ, CLOGN ? CLOGN - 1 : 0, CTSHIFT>(z, h, logn - 1, tw, tw_n, -1);
   const int tstride = tw_n / n;
   for (int k = tid(); k <= h / 2; k += NT) {
     if (k == 0) {
@@ -269,9 +275,11 @@ __device__ inline void rfft_lds(double2* z, int n, int logn, const double2* tw, 
 // twiddle loads serves both -- the workgroup transforms are bound by exactly those (61 %
 // of the instructions).  Per array the butterflies, twiddle entries and order of operations are those of
 // fft_lds: the results are bit-identical.  64 <= n <= FFT_SWZ_MAX (the swizzled path only).
-__device__ inline void fft_lds_pair(double2* z0, double2* z1, int n, int logn, const double2* tw, int tw_n, int sign) {
+template <int CLOGN = 0, int CTSHIFT = 0>
+__device__ inline void fft_lds_pair(double2* z0, double2* z1, int n_rt, int logn_rt, const double2* tw, int tw_n, int sign) {
+  const int n = CLOGN ? (1 << CLOGN) : n_rt, logn = CLOGN ? CLOGN : logn_rt;
   double2* zz[2] = {z0, z1};
-  const int tshift = ilog2(tw_n) - 1;
+  const int tshift = CTSHIFT ? CTSHIFT : ilog2(tw_n) - 1;
   auto twmul = [&](const double2 v, const double2 w) {
     const double wi = sign < 0 ? -w.y : w.y;
     return make_double2(v.x * w.x - v.y * wi, v.x * wi + v.y * w.x);
@@ -311,6 +319,7 @@ __device__ inline void fft_lds_pair(double2* z0, double2* z1, int n, int logn, c
     __syncthreads();
   }
   int s = 3;
+#pragma unroll
   for (; s + 1 <= logn; s += 2) {
     const int h = 1 << (s - 1);
     const bool last = s + 1 == logn;
@@ -360,9 +369,11 @@ __device__ inline void fft_lds_pair(double2* z0, double2* z1, int n, int logn, c
 }
 
 // Two real transforms in lockstep (see rfft_lds): z0 / z1 hold n real samples each on entry, X[0 .. n/2] on return.
-__device__ inline void rfft_lds_pair(double2* z0, double2* z1, int n, int logn, const double2* tw, int tw_n) {
+template <int CLOGN = 0, int CTSHIFT = 0>
+__device__ inline void rfft_lds_pair(double2* z0, double2* z1, int n_rt, int logn, const double2* tw, int tw_n_rt) {
+  const int n = CLOGN ? (1 << CLOGN) : n_rt, tw_n = CTSHIFT ? (2 << CTSHIFT) : tw_n_rt;
   const int h = n / 2;
-  fft_lds_pair(z0, z1, h, logn - 1, tw, tw_n, -1);
+  fft_lds_pair<CLOGN ? CLOGN - 1 : 0, CTSHIFT>(z0, z1, h, logn - 1, tw, tw_n, -1);
   double2* zz[2] = {z0, z1};
   const int tstride = tw_n / n;
   for (int k = tid(); k <= h / 2; k += NT) {

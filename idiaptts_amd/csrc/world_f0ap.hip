@@ -450,8 +450,10 @@ __global__ void d4c_nuttall_kernel(int wl, double* __restrict__ nwin) {
   }
 }
 
-template <bool AREG>
+// CFFT: log2 of BOTH transform sizes (fftd = fftl = 2^CFFT: 11 at 16 .. 24 kHz) as a compile-time constant, 0: any sizes.
+template <bool AREG, int CFFT = 0>
 __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
+  constexpr int CTS = CFFT ? CFFT - 1 : 0;       // log2 of the twiddle table's size - 1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PER = AREG ? 16 : 8;           // window samples per thread: n < fftd = 256 PER
   const int fmax = max(a.fftd, a.fftl);
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
       double seg[PER];
       win_make(W, fs, f0raw > 40.0 ? f0raw : 40.0, 1, 3.0);
       windowed_to(x, xl, fs, pos, W, zr, fft + 2, false, false, L.red, seg);
-      rfft_lds(L.z, fft, a.logfftl, L.tw, fmax);
+      rfft_lds<true, CFFT, CTS>(L.z, fft, a.logfftl, L.tw, fmax);
       double s1 = 0.0, s2 = 0.0;
       for (int k = threadIdx.x; k <= b2; k += NT) {
         if (k > b0) {
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
     const int fft = a.fftd, logfft = a.logfftd, h = fft / 2;
     const double f0 = f0raw > 47.0 ? f0raw : 47.0;  // kFloorF0D4C
     // twiddles in LDS are those of the largest transform (fmax); smaller ones stride through it
-    auto rfft = [&](void) { rfft_lds(L.z, fft, logfft, L.tw, fmax); };
+    auto rfft = [&](void) { rfft_lds<true, CFFT, CTS>(L.z, fft, logfft, L.tw, fmax); };
     // --- static centroid (two time-shifted analyses): the first spectrum of a side waits in
     // B (re) and C (im) -- with AREG in B and A, the centroid then accumulates in registers (a thread
     // always owns the bins tid + 256 i) and moves to A when both sides are done
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
         // arithmetic and twiddle loads for two transforms; same values bit for bit
         double2* z2 = reinterpret_cast<double2*>(L.B);
         windowed_to(x, xl, fs, cpos, W, zr, fft + 2, true, false, L.red, seg, reinterpret_cast<double*>(z2));
-        rfft_lds_pair(L.z, z2, fft, logfft, L.tw, fmax);
+        rfft_lds_pair<CFFT, CTS>(L.z, z2, fft, logfft, L.tw, fmax);
         for (int k = threadIdx.x; k <= h; k += NT) {
           const double v = z2[k].x * L.z[k].x + L.z[k].y * z2[k].y;
           L.A[k] = side == 0 ? v : L.A[k] + v;
@@ -797,8 +799,12 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   const bool areg = hmax > 1024;            // 4096-point transforms: two bin arrays, see the kernel
   const size_t lds = z_bytes + (areg ? 2 : 3) * (size_t)(hmax + 2) * 8 + 32 * 8;
   ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-  ITTS_HIP_CHECK(hipFuncSetAttribute(areg ? (const void*)d4c_kernel<true> : (const void*)d4c_kernel<false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // both transforms of the usual sizes (2048 at 16 .. 24 kHz, 4096 at 44.1 / 48 kHz) have a kernel with the size
+  // compiled in (ITTS_D4C_GENERIC=1: the any-size kernel, for the A/B test)
+  const bool sized = a.fftd == a.fftl && a.logfftd == (areg ? 12 : 11) && !getenv("ITTS_D4C_GENERIC");
+  const void* kern = areg ? (sized ? (const void*)d4c_kernel<true, 12> : (const void*)d4c_kernel<true>)
+                          : (sized ? (const void*)d4c_kernel<false, 11> : (const void*)d4c_kernel<false>);
+  ITTS_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t t_total = h_f_off[n_utts];
   ITTS_REQUIRE(t_total < ((int64_t)1 << 31), "too many frames in one call");
   int* d_order = nullptr;
@@ -814,8 +820,12 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   hipLaunchKernelGGL(d4c_nuttall_kernel, dim3((wl + 255) / 256), dim3(256), 0, s, wl, d_nwin);
   ITTS_LAUNCH_CHECK();
   a.nwin = d_nwin;
-  if (areg)
+  if (areg && sized)
+    hipLaunchKernelGGL((d4c_kernel<true, 12>), dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  else if (areg)
     hipLaunchKernelGGL(d4c_kernel<true>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
+  else if (sized)
+    hipLaunchKernelGGL((d4c_kernel<false, 11>), dim3((unsigned)t_total), dim3(NT), lds, s, a);
   else
     hipLaunchKernelGGL(d4c_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
   ITTS_LAUNCH_CHECK();
