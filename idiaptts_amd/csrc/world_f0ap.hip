@@ -9,6 +9,7 @@
 // the FFTs are replaced by direct DFT sums at those bins (twiddles from the same master table)
 // -- no LDS FFT buffer, any f0-dependent FFT size.  D4C keeps every spectrum in LDS.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cmath>
 
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(NT) void stonemask_kernel(SmArgs a) {
 // a different order.
 __device__ __forceinline__ double sm_xor_sum(double v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
-__global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves) {
+// f0_from / f0_to: the launch takes the frames with f0_from < f0 <= f0_to (their windows fit its LDS blocks: a.nmax is
+// sized for f0_from); frames outside (40 Hz, fs / 12] get their zero from the launch with f0_to = infinity.
+__global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves, double f0_from, double f0_to) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (wv >= waves) return;
@@ -174,9 +177,10 @@ __global__ __launch_bounds__(NT) void stonemask_wave_kernel(SmArgs a, int waves)
   const double f0 = a.f0_in[g];
   const double pos = (double)(g - a.f_off[u]) * a.frame_period / 1000.0;
   if (f0 <= 40.0 || f0 > fs / 12.0) {
-    if (lane == 0) a.f0_out[g] = 0.0;
+    if (lane == 0 && f0_to > 1e300) a.f0_out[g] = 0.0;
     return;
   }
+  if (!(f0 > f0_from && f0 <= f0_to)) return;      // the other launch's frame
   const int half = (int)(1.5 * fs / f0 + 1.0);
   const double wlt = (2.0 * half + 1.0) / fs;
   const int n = 2 * half + 1;
@@ -738,15 +742,32 @@ extern "C" int itts_stonemask(const double* d_x, const int64_t* h_x_off, const d
   a.nmax = 2 * (int)(1.5 * fs / 40.0 + 1.0) + 1 + 3;
   const size_t per_wave = (size_t)a.nmax * 2 * 8;
   if (per_wave <= 80 * 1024) {
-    // as many frames per workgroup as keep two workgroups on a CU (one wave each at 48 kHz)
-    const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (80 * 1024) / per_wave));
-    const size_t lds = per_wave * waves;
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_wave_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // A wave's LDS block holds the window of its frame: 3 periods of f0.  The interface admits f0 down to 40 Hz
+    // (3 606 samples at 48 kHz: 58 KB per wave, one wave per workgroup, two per CU), DIO's floor is 71 Hz: the main
+    // launch is sized for f0 > 70 Hz (33 KB per wave at 48 kHz, 11 KB at 16 kHz: twice / 1.5 times the waves per CU)
+    // and a second launch with the long blocks takes the frames below -- none, after DIO; its waves then leave at once.
+    const double kSplit = 70.0;
     const int64_t T = h_f_off[n_utts];
-    hipLaunchKernelGGL(stonemask_wave_kernel, dim3((unsigned)((T + waves - 1) / waves)), dim3(64 * waves), lds,
-                       s, a, waves);
-    ITTS_LAUNCH_CHECK();
+    static std::atomic<int> lds_attr{0};
+    auto launch = [&](double from, double to) -> int {
+      SmArgs b = a;
+      b.nmax = 2 * (int)(1.5 * fs / from + 1.0) + 1 + 3;
+      const size_t pw = (size_t)b.nmax * 2 * 8;
+      // as many frames per workgroup as keep two workgroups on a CU
+      const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (80 * 1024) / pw));
+      const size_t lds = pw * waves;
+      if ((int)lds > lds_attr.load()) {
+        ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)stonemask_wave_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+        lds_attr.store(80 * 1024);
+      }
+      hipLaunchKernelGGL(stonemask_wave_kernel, dim3((unsigned)((T + waves - 1) / waves)), dim3(64 * waves), lds,
+                         s, b, waves, from, to);
+      ITTS_LAUNCH_CHECK();
+      return ITTS_OK;
+    };
+    if ((rc = launch(kSplit, 1e308))) return rc;
+    if ((rc = launch(40.0, kSplit))) return rc;
   } else {
     const size_t lds = (size_t)a.nmax * 3 * 8 + 128 * 8;
     ITTS_REQUIRE(lds <= 160 * 1024, "sampling rate too high for the StoneMask LDS budget");

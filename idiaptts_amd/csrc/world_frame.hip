@@ -266,10 +266,14 @@ __device__ __forceinline__ double ct_bcast0(double v) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <int R>
-__global__ __launch_bounds__(CTW_THREADS) void cheaptrick_wave_kernel(FrameArgs a, int64_t t_total) {
+// TH: threads per workgroup = 64 x frames in flight per CU.  2048-point transforms (R = 16: 44.1 / 48 kHz) hold twice
+// the bins per lane: with eight waves per CU (256 registers) 146 of them live in scratch; four waves per CU (one per
+// SIMD, 256 + 98 registers, no scratch) measured SLOWER (round 5: 3.48 against 3.05 ms for 64 utterances): the second
+// wave of a SIMD covers more than the scratch traffic costs.
+template <int R, int TH = CTW_THREADS>
+__global__ __launch_bounds__(TH) void cheaptrick_wave_kernel(FrameArgs a, int64_t t_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int FFT = 128 * R, H = 64 * R, K = H + 1, NW = CTW_THREADS / 64, CTW_SCAN = ctw_scan<R>();
+  constexpr int FFT = 128 * R, H = 64 * R, K = H + 1, NW = TH / 64, CTW_SCAN = ctw_scan<R>();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l0 = wf::lane_id();
   typename wf::PlanOf<R>::type P;
   wf::table_init<R>(smem, a.g_tw_compact);
@@ -675,7 +679,8 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
     int dev = 0, n_cu = 256;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    constexpr int NW = CTW_THREADS / 64;
+    constexpr int TH16 = CTW_THREADS;          // (R = 16 at one wave per SIMD -- 256 threads, no scratch -- took 3.48 ms against 3.05)
+    const int NW = (wave_r == 8 ? CTW_THREADS : TH16) / 64;
     const dim3 grid((unsigned)std::min<int64_t>((t_total + NW - 1) / NW, n_cu));
     if (wave_r == 8) {
       const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
@@ -684,9 +689,9 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
       hipLaunchKernelGGL(cheaptrick_wave_kernel<8>, grid, dim3(CTW_THREADS), lds, s, a, t_total);
     } else {
       const size_t lds = wf::table_bytes<16>() + (size_t)NW * wf::lds_bytes<16>();
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel<16>,
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel<16, TH16>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(cheaptrick_wave_kernel<16>, grid, dim3(CTW_THREADS), lds, s, a, t_total);
+      hipLaunchKernelGGL((cheaptrick_wave_kernel<16, TH16>), grid, dim3(TH16), lds, s, a, t_total);
     }
     ITTS_LAUNCH_CHECK();
     a.far_only = 1;     // frames with an F0 at or beyond fs / 2: a pass that reads the F0 values and normally finds none

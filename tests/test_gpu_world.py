@@ -194,6 +194,32 @@ def test_dio_stonemask_match_oracle(gpu, utts):
         assert np.abs(f0r[a:b] - f0_ref).max() < 1e-7
 
 
+@pytest.mark.parametrize("fs_name", ["16k", "48k"])
+def test_stonemask_below_dios_floor_takes_the_second_launch(gpu, utts, golden_dir, fs_name):
+    """itts_stonemask sizes the LDS blocks of its main launch for f0 > 70 Hz (DIO's floor is 71 Hz) and gives the
+    frames in (40 Hz, 70 Hz] -- which the interface admits and only a caller's own contour can hold -- to a second
+    launch with the long blocks: a contour with such frames (and some outside (40 Hz, fs / 12]) against the oracle."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    if fs_name == "16k":
+        xu, fs, _, tpu = utts[0]
+    else:
+        from scipy.io import wavfile
+        fs, w = wavfile.read(os.path.join(golden_dir, "p225_001.wav"))      # the reference's own 48 kHz fixture
+        assert fs == 48000
+        xu = w.astype(np.float64) / 32768.0
+    T = int(1000.0 * len(xu) / fs / 5.0) + 1
+    tp = np.arange(T) * 0.005
+    rng = np.random.default_rng(11)
+    f0 = rng.choice([0.0, 30.0, 41.0, 47.5, 55.0, 69.9, 70.0, 70.1, 95.0, 180.0, fs / 12.0 + 1.0], size=T)
+    ref = capi.stonemask(np.ascontiguousarray(xu), fs, tp, f0)
+    got = ops.stonemask(torch.from_numpy(np.ascontiguousarray(xu)).to(gpu), [0, len(xu)],
+                        torch.from_numpy(f0).to(gpu), [0, T], fs).cpu().numpy()
+    assert np.array_equal(got == 0, ref == 0)
+    assert np.abs(got - ref).max() < 1e-7
+    assert (got[(f0 > 40) & (f0 <= 70)] > 0).any()        # the second launch did refine something
+
+
 def test_d4c_matches_oracle(gpu, utts):
     from idiaptts_amd import ops
     from oracle import capi
