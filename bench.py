@@ -253,9 +253,11 @@ def hip_event_time_ms(fn, stream, iters):
 
 def committed_traffic(section):
     """HBM bytes per pass / step of a secondary section from the committed PMC passes of this round
-    (profiles/r4_section_traffic.json: scripts/section_traffic.sh); None when the file is absent.
+    (profiles/r5_section_traffic.json: scripts/section_traffic.sh); None when the file is absent.
     Not re-measured inside bench.py (the counters need their own profiler runs)."""
-    path = os.path.join(ROOT, "profiles", "r4_section_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r5_section_traffic.json")
+    if not os.path.isfile(path):
+        path = os.path.join(ROOT, "profiles", "r4_section_traffic.json")
     if not os.path.isfile(path):
         return None
     with open(path) as f:
@@ -265,8 +267,10 @@ def committed_traffic(section):
 
 def committed_fractions(kernel_substring):
     """VALU-issue / LDS / wait fractions of a WORLD kernel from the committed SQ counter passes
-    (profiles/r4_world_pmc_fractions.json: scripts/pmc_fractions.py); None when absent."""
-    path = os.path.join(ROOT, "profiles", "r4_world_pmc_fractions.json")
+    (profiles/r5_world_pmc_fractions.json: scripts/pmc_fractions.py); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r5_world_pmc_fractions.json")
+    if not os.path.isfile(path):
+        path = os.path.join(ROOT, "profiles", "r4_world_pmc_fractions.json")
     if not os.path.isfile(path):
         return None
     with open(path) as f:
@@ -464,15 +468,15 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     sy_flops = 7 * fft * 1.3 + 2 * 60 * K
     nap = L.itts_num_aperiodicities(fs) if n_ranks >= 1 else 1
     w["analysis_roofline"] = {
-        "bound": "hbm", "kernel": "mcls_solve_dpp_kernel + d4c_kernel + gemm_f64_kernel (see profiles/)",
+        "bound": "hbm", "kernel": "mcls_solve_dpp_kernel + d4c_kernel + mcls_fused3_kernel (see profiles/)",
         "achieved": w["analysis_algorithmic_GBps"] / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
         "frac": w["analysis_algorithmic_GBps"] / n_ranks / PEAK_HBM_GBS,
         "traffic": committed_traffic("analysis_%d" % fs) if n_utts == (256 if fs <= 24000 else 64) else None,
         "what_binds_it": "fp64 VALU issue and LDS latency, not HBM: see issue_fractions (share of the chip's VALU "
                          "issue slots / LDS cycles in use, share of a wave's life spent waiting; SQ counters, "
-                         "profiles/r4_world_pmc_fractions.json)",
+                         "profiles/r5_world_pmc_fractions.json)",
         "issue_fractions": {k: committed_fractions(k) for k in ("mcls_solve_dpp", "d4c_kernel", "cheaptrick_wave",
-                                                                 "gemm_f64_kernel<true, true", "gemm_f64_lds")} if fs <= 24000 else None,
+                                                                 "mcls_fused3", "mcls_init_fused")} if fs <= 24000 else None,
         "algorithmic_bytes_per_frame": fs // 200 * 8 + (61 + nap) * 4,
         "fp64_tflops": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks,
         "fp64_frac_of_peak": frames * an_flops / (ms_an * 1e-3) / 1e12 / n_ranks / PEAK_F64_TFLOPS,
@@ -500,7 +504,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                                                stream, 7), dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
         gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
-        # HBM bytes of one solve from the committed PMC passes (profiles/r4_section_traffic.json:
+        # HBM bytes of one solve from the committed PMC passes (profiles/r5_section_traffic.json:
         # FETCH_SIZE x 2 + WRITE_SIZE on this same workload); not re-measured inside bench.py
         ml_traffic = committed_traffic("mlpg")
         res["mlpg"] = {"utterances": 256 * n_ranks, "frames": ml_frames, "ms": ms_ml,
