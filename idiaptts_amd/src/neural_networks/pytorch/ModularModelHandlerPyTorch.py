@@ -54,6 +54,8 @@ class HipAdam(torch.optim.Optimizer):
         self._clip = None            # (norm_kind | None, max_norm, clip_value | None)
         self._ema = None
         self._norm_accum = None
+        self._overlap = None         # state of the bucket reductions started during backward
+        self.last_overlap = None
         self._flat = flat
         self._build_arenas()
 
@@ -165,14 +167,78 @@ class HipAdam(torch.optim.Optimizer):
 
     def allreduce_grads_(self, local_weight, group=None):
         """Data-parallel gradient step on the flat buffers (see parallel.allreduce_module_grads_);
-        False without an arena."""
+        False without an arena.  After `begin_overlapped_allreduce` this only waits for the bucket
+        reductions that backward has already started and reduces what is left."""
         if self._arenas is None:
             return False
-        for a in self._arenas:
-            if a is not None:
+        ov, self._overlap = self._overlap, None
+        for ai, a in enumerate(self._arenas):
+            if a is None:
+                continue
+            if ov is None:
                 a['g'].mul_(float(local_weight))
                 parallel.allreduce_flat_(a['g'], group)
+                continue
+            for bi, (lo, hi, _) in enumerate(a['buckets']):
+                if (ai, bi) not in ov['issued']:      # a bucket some parameter of which got no gradient this step
+                    a['g'][lo:hi].mul_(ov['weight'])
+                    ov['work'].append(parallel.allreduce_flat_(a['g'][lo:hi], ov['group'], async_op=True))
+        if ov is not None:
+            for w in ov['work']:
+                if w is not None:
+                    w.wait()
+            self.last_overlap = {"buckets_during_backward": len(ov['issued']), "collectives": len(ov['work'])}
         return True
+
+    # -------------------------------------------------------------- communication beside backward
+    # SURVEY.md section 8(e): "overlap layer-3 gradient communication with layer-1/2 backward".  The flat gradient
+    # arena is cut into buckets of whole parameters in arena order (>= `bucket_elems` values each: about a layer of the
+    # recurrent models); a post-accumulate hook per parameter counts a bucket's gradients as autograd delivers them --
+    # output layer first -- and the moment a bucket is complete its slice is scaled by this rank's share of the global
+    # frame count and goes into an asynchronous sum all-reduce, while backward carries on with the layers in front.
+    # Every rank builds the same graph, so the buckets complete -- and the collectives are issued -- in the same order.
+    overlap_bucket_elems = 1 << 20        # values per bucket (about a layer of the recurrent models); tests lower it
+
+    def begin_overlapped_allreduce(self, local_weight, group=None, bucket_elems=None):
+        """Call between zero_grad() and backward(); `allreduce_grads_` afterwards waits.  False (and nothing armed)
+        without an arena or outside a data-parallel run."""
+        self._overlap = None
+        if self._arenas is None or not parallel._active(group):
+            return False
+        bucket_elems = int(bucket_elems or self.overlap_bucket_elems)
+        for ai, a in enumerate(self._arenas):
+            if a is None or 'buckets' in a:
+                continue
+            buckets, lo, off, members = [], 0, 0, []
+            for p in a['params']:
+                members.append(p)
+                off += p.numel()
+                if off - lo >= bucket_elems:
+                    buckets.append((lo, off, members))
+                    lo, members = off, []
+            if members:
+                buckets.append((lo, off, members))
+            a['buckets'] = buckets
+            for bi, (_, _, ps) in enumerate(buckets):
+                for p in ps:
+                    p.register_post_accumulate_grad_hook(
+                        lambda _p, ai=ai, bi=bi: self._bucket_hook(ai, bi))
+        self._overlap = {"weight": float(local_weight), "group": group, "issued": set(), "work": [],
+                         "count": {}}
+        return True
+
+    def _bucket_hook(self, ai, bi):
+        ov = self._overlap
+        if ov is None:
+            return
+        a = self._arenas[ai]
+        lo, hi, ps = a['buckets'][bi]
+        n = ov['count'].get((ai, bi), 0) + 1
+        ov['count'][(ai, bi)] = n
+        if n == len(ps) and (ai, bi) not in ov['issued']:
+            ov['issued'].add((ai, bi))
+            a['g'][lo:hi].mul_(ov['weight'])
+            ov['work'].append(parallel.allreduce_flat_(a['g'][lo:hi], ov['group'], async_op=True))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -968,6 +1034,8 @@ class ModularModelHandlerPyTorch(object):
             dp_weight = self._dp_weight(lengths, device)
             if training:
                 self.optimiser.zero_grad()
+                if dp_weight is not None and hasattr(self.optimiser, "begin_overlapped_allreduce"):
+                    self.optimiser.begin_overlapped_allreduce(dp_weight)     # bucket reductions beside backward
                 backprop_loss.backward(retain_graph=hparams.backward_retain_graph)
                 total_steps += 1
                 if dp_weight is not None:
@@ -1064,6 +1132,8 @@ class ModularModelHandlerPyTorch(object):
             dp_weight = self._dp_weight(lengths, device)
             if training:
                 self.optimiser.zero_grad()
+                if dp_weight is not None and hasattr(self.optimiser, "begin_overlapped_allreduce"):
+                    self.optimiser.begin_overlapped_allreduce(dp_weight)     # bucket reductions beside backward
                 total.backward()
                 if dp_weight is not None:
                     flat_sync = getattr(self.optimiser, "allreduce_grads_", None)

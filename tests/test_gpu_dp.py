@@ -127,6 +127,7 @@ def _bilstm_handler(dev):
 
 def _bilstm_steps(dev, shard, steps=3):
     h, Handler = _bilstm_handler(dev)
+    h.optimiser.overlap_bucket_elems = 2000        # several buckets in this small model (the default is a layer's worth)
     data, lengths = Handler.prepare_batch(_bilstm_case(), common_divisor=2, batch_first=False,
                                           mask_keys=("acoustic_features",), shard=shard)
     losses, g1 = [], None
@@ -138,6 +139,10 @@ def _bilstm_steps(dev, shard, steps=3):
             g1 = torch.cat([p.grad.reshape(-1) for p in h.model.parameters()]).cpu().numpy()
     torch.cuda.synchronize()
     params = torch.cat([p.detach().reshape(-1) for p in h.model.parameters()]).cpu().numpy()
+    if shard is not None:
+        # the gradient buckets went into their all-reduce WHILE backward ran (hooks), not after it
+        ov = h.optimiser.last_overlap
+        assert ov is not None and ov["buckets_during_backward"] >= 3 and ov["collectives"] == ov["buckets_during_backward"], ov
     return params, g1, losses
 
 
