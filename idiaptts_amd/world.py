@@ -152,7 +152,10 @@ def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alph
         x_off = offsets([len(r) for r in raws])
         samples = np.concatenate(raws) if len(raws) else np.empty(0)
     f_off = offsets([num_frames(b - a, fs, hop_ms) for a, b in zip(x_off[:-1], x_off[1:])])
-    x = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float64)).to(dev)
+    if isinstance(samples, torch.Tensor):     # float64 samples of gen_data's readers: page-locked (fetched asynchronously)
+        x = samples if samples.is_cuda else samples.to(dev, non_blocking=True)     # or uploaded by the reader already
+    else:
+        x = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float64)).to(dev)
     f0 = estimate_f0(x, x_off, f_off, fs, hop_ms, f0_method)
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
