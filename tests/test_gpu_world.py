@@ -110,6 +110,38 @@ def test_fused_newton_products_equal_the_two_launches_bit_for_bit(gpu, utts, ord
     assert res["1"][1].max() > 2            # the loop did iterate
 
 
+@pytest.mark.parametrize("n_frames", [1, 2, 15, 16, 17, 127, 128, 129, 300])
+def test_fused_newton_products_on_ragged_frame_counts(gpu, utts, n_frames):
+    """The fused kernels own 16 frames per wave and 128 per workgroup: frame counts around those sizes (a lone frame,
+    one short of / one past a wave and a workgroup) against the two-launch form, bit for bit -- rows past the end
+    repeat the last frame inside the kernels and must not be stored."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    xu, fs, f0u, tpu = utts[0]
+    amp_all = np.sqrt(capi.cheaptrick(xu, fs, tpu, f0u))
+    amp = torch.from_numpy(np.ascontiguousarray(amp_all[40:40 + n_frames])).to(gpu)
+    guard = torch.full((n_frames + 8, 60), 7.25, dtype=torch.float64, device=gpu)      # nothing may be written past the rows
+    res = {}
+    old = os.environ.get("ITTS_MCEP_FUSED")
+    try:
+        for mode in ("0", "1"):
+            os.environ["ITTS_MCEP_FUSED"] = mode
+            mc, iters = ops.mcep(amp, 59, 0.41, dtype=torch.float64, want_iters=True)
+            res[mode] = (mc.cpu().numpy(), iters.cpu().numpy())
+    finally:
+        if old is None:
+            os.environ.pop("ITTS_MCEP_FUSED", None)
+        else:
+            os.environ["ITTS_MCEP_FUSED"] = old
+    assert res["1"][0].shape == (n_frames, 60) and np.isfinite(res["1"][0]).all()
+    assert np.array_equal(res["0"][1], res["1"][1])
+    assert np.array_equal(res["0"][0], res["1"][0])
+    mc_ref, it_ref = capi.mcep(amp_all[40:40 + n_frames], 59, 0.41, return_iters=True)
+    assert np.array_equal(res["1"][1], it_ref)
+    assert np.abs(res["1"][0] - mc_ref).max() < 1e-8
+    assert float(guard.min()) == 7.25
+
+
 @pytest.mark.parametrize("order,alpha", [(59, 0.41), (24, 0.41), (79, 0.58)])
 def test_mcep_from_amp_and_mgc2sp_roundtrip(gpu, utts, order, alpha):
     from idiaptts_amd import ops
