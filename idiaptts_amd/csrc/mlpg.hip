@@ -24,6 +24,8 @@
 // Roofline: HBM.  Algorithmic bytes per frame = 187*8 read + 63*8 written = 2000 B
 // (SURVEY.md section 8d); measured traffic and rates: DESIGN.md section 11c.
 #include <algorithm>
+#include <atomic>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -280,6 +282,413 @@ __global__ __launch_bounds__(MLPG_LANES) void mlpg_kernel(MlpgArgs a, int t_max)
         x1 = x;
       }
     }
+  }
+}
+
+// ---- one pass: the right-hand side never leaves the CU (round 5) ----------------------------------------------------
+// A workgroup owns (utterance, 64 dimensions: all of them for the usual 60 + 1 + 1 streams).  Wave 0 walks the two
+// sweeps frame by frame, a lane a dimension; the b / y / x rows it works on live in LDS -- a ring of RING_CAP frames x
+// 64 doubles (147 KB) -- so that the recurrences' operands are LDS reads issued ahead of the chain (what mlpg_kernel
+// pays per frame in memory latency is gone) and the input rows are read ONCE.  Seven helper waves work 24-frame
+// segments around the sweep -- forward: the input rows of a segment a ring's length ahead -> b into the ring, after
+// moving the y that occupied those slots (RING_CAP frames back) out to the output rows; backward: the finished
+// segment's x out to the output rows, then the y of a ring's length further down back into the slots.  Progress words in
+// LDS instead of barriers, no hand-off between workgroups, no scratch, ONE launch: the sweep derives the factor's
+// moving head (the first 30 - 50 rows, until it repeats) itself while it walks them -- the same arithmetic as
+// mlpg_factor_kernel, row by row -- and leaves the rows in the factor table for the way back.
+//
+// What shaped it (scripts/lat_lab, profiles/r5_mlpg_ring.md):
+//  * a lone wave issues an instruction every 5 - 7 cycles whatever its width, so the sweep costs the same for 16
+//    lanes as for 64: the first form of this kernel (16 dimensions x 1 152 frames a workgroup, the whole y of most
+//    utterances in LDS) spent 4 x the sweep time of this one to save the y round trip.  Here y makes the trip (out and
+//    back through the output rows, last in first out): 48 bytes per frame and dimension where the algorithm needs
+//    32 and the three launch form moves 65;
+//  * what a frame costs the sweep is its instruction COUNT: a segment that lies on the stationary factor altogether
+//    is straight-line code, 4 instructions a frame; everything else (the head, the segment with the tail frames)
+//    runs in ROLLED loops -- unrolled they were 40 KB of code that runs once a workgroup, every line of it an
+//    instruction-cache miss behind the helpers' streams (40 us for the first segment);
+//  * the CU has ONE memory pipeline: a load the sweep waits for queues behind whatever the seven helpers have asked
+//    for (5 us).  The sweep therefore never loads: the head's factor rows are derived on the way forward and, for
+//    the way back, put into the upper part of the ring by the helpers once those slots are free;
+//  * the helpers' segment, row and edge arithmetic belongs on the scalar unit (wave number through readfirstlane).
+// Arithmetic: mlpg_kernel's, expression for expression.
+constexpr int RING_LANES = 64, RING_SEG = 24, RING_CAP = 288, RING_HELPERS = 7, RING_THREADS = 64 * (1 + RING_HELPERS);
+constexpr int RING_LDS_BYTES = RING_CAP * RING_LANES * 8 + 128;     // + progress words
+// the factor's head rows for the end of the backward sweep: 3 planes x RING_HEAD_ROWS rows x 64 lanes in slots
+// RING_HEAD_SLOT .. of the ring (those of segments 5 .. 11: free once the sweep is below segment 5)
+constexpr int RING_HEAD_SLOT = 5 * RING_SEG, RING_HEAD_ROWS = (RING_CAP - RING_HEAD_SLOT) / 3;
+static_assert(RING_CAP % RING_SEG == 0 && RING_SEG % 8 == 0, "ring geometry");
+struct RingArgs {
+  MlpgArgs a;
+  const int* order;       // utterances, longest first
+  int t_max;
+};
+// progress words in LDS (one writer each; release / acquire at workgroup scope)
+__device__ __forceinline__ void ring_post(int* w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int ring_peek(const int* w) { return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char rsm[];
+  double* ring = reinterpret_cast<double*>(rsm);          // [RING_CAP][64]
+  int* prog = reinterpret_cast<int*>(rsm + RING_CAP * RING_LANES * 8);
+  // prog[0]: forward sweep: segments finished            prog[1 + h]: helper h, forward: its segments prepared (count)
+  // prog[8]: the backward sweep has begun                prog[9 + h]: helper h, backward: its segments stored / refilled (count)
+  // prog[16]: backward sweep: lowest segment finished (n_segments: none yet)
+  // prog[17]: helpers that have put their factor rows into the ring     prog[18]: rows of the factor's head (0: too many)
+  const MlpgArgs& a = g.a;
+  const int u = g.order[blockIdx.y];
+  const int blk = blockIdx.x;
+  const int64_t t0 = a.offsets[u];
+  const int T = (int)(a.offsets[u + 1] - t0);            // (frames of one utterance: 32 bits)
+  if (T <= 0) return;
+  const int D = a.dim;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const double rvb = 1.0 / kBigVar;
+  const int nseg = (T + RING_SEG - 1) / RING_SEG;
+  constexpr int ring_segs = RING_CAP / RING_SEG;
+  // slot of the first frame of segment sgm (the ring holds a whole number of segments: the frames of a segment sit in
+  // consecutive slots)
+  auto seg_slot = [](int sgm) { return (sgm % ring_segs) * RING_SEG; };
+  const int dc = blk * RING_LANES + lane < D ? blk * RING_LANES + lane : D - 1;
+  double* hfac = ring + RING_HEAD_SLOT * RING_LANES;          // [3][RING_HEAD_ROWS][64]
+  const int64_t plane = (int64_t)g.t_max * D;                 // the factor table: three planes of t_max rows
+  if (tid < 32) prog[tid] = 0;
+  __syncthreads();
+
+  if (wave != 0) {
+    // ================= helper wave h: segments q = h, h + H, h + 2 H ..  (a lane: one dimension)
+    // (the wave number through readfirstlane: segment numbers, row numbers and the edge tests are then the scalar
+    // unit's work and the branches on them branches of the wave -- left as threadIdx arithmetic they were vector
+    // selects around every load and every frame: 600 cycles a frame, 15 us a segment)
+    const int h = wave - 1;
+    const int hd = blk * RING_LANES + lane;
+    const double hrv0 = 1.0 / a.var[dc], hrv1 = 1.0 / a.var[D + dc], hrv2 = 1.0 / a.var[2 * D + dc];
+    const double* hf = a.feat + t0 * a.ld_feat + a.col0 + dc;
+    double* o = a.out + t0 * a.ld_out + a.ocol0 + dc;
+    auto r1 = [&](int t) { return (t == 0 || t == T - 1) ? rvb : hrv1; };
+    auto r2 = [&](int t) { return (t == 0 || t == T - 1) ? rvb : hrv2; };
+    // ---- forward: input rows -> b into the ring, never more than a ring's length ahead of the sweep
+    int mine = 0;
+    // one segment; INNER: no frame of it is, or neighbours, an edge of the utterance (no row clamps, no edge variances)
+    auto forward_segment = [&](int q, auto inner_tag) {
+      constexpr bool INNER = decltype(inner_tag)::value;
+      const int j0 = q * RING_SEG;
+      double* base = ring + seg_slot(q) * RING_LANES + lane;
+      // the whole segment's loads in flight together, and BEFORE the wait for its slots (registers are the only place
+      // they need; seven helpers x 24 frames under way whatever the sweep is doing): the static column of rows j0 ..
+      // j0 + 23, the delta and delta-delta columns of rows j0 - 1 .. j0 + 24 (each row serves as a frame's own and as
+      // both its neighbours'), row numbers held inside the utterance
+      double st[RING_SEG], d1[RING_SEG + 2], d2[RING_SEG + 2];
+#pragma unroll
+      for (int i = 0; i < RING_SEG + 2; ++i) {
+        int r = j0 - 1 + i;
+        if (!INNER) r = r < 0 ? 0 : (r < T ? r : T - 1);
+        const double* row = hf + (int64_t)r * a.ld_feat;
+        d1[i] = row[D];
+        d2[i] = row[2 * D];
+        if (i >= 1 && i <= RING_SEG) st[i - 1] = row[0];
+      }
+      while (q - ring_peek(prog) >= ring_segs) __builtin_amdgcn_s_sleep(2);      // the sweep has left segment q - ring_segs
+      if (j0 >= RING_CAP && hd < D) {                   // the y of frames j0 - RING_CAP .. leave the ring
+#pragma unroll
+        for (int i = 0; i < RING_SEG; ++i)
+          if (INNER || j0 + i < T) o[(int64_t)(j0 + i - RING_CAP) * a.ld_out] = base[i * RING_LANES];
+      }
+#pragma unroll
+      for (int i = 0; i < RING_SEG; ++i) {
+        const int j = j0 + i;
+        if (INNER || j < T) {
+          double bj;
+          if (INNER) {
+            const double c0 = st[i] * hrv0, c2 = d2[i + 1] * hrv2;
+            const double p1 = d1[i] * hrv1, p2 = d2[i] * hrv2;
+            const double n1 = d1[i + 2] * hrv1, n2 = d2[i + 2] * hrv2;
+            bj = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
+          } else {
+            const double c0 = st[i] * hrv0, c2 = d2[i + 1] * r2(j);
+            const double p1 = j > 0 ? d1[i] * r1(j - 1) : 0.0, p2 = j > 0 ? d2[i] * r2(j - 1) : 0.0;
+            const double n1 = j + 1 < T ? d1[i + 2] * r1(j + 1) : 0.0, n2 = j + 1 < T ? d2[i + 2] * r2(j + 1) : 0.0;
+            bj = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
+          }
+          base[i * RING_LANES] = hd < D ? bj : 0.0;
+        }
+      }
+      ++mine;
+      if (lane == 0) ring_post(prog + 1 + h, mine);          // (a wave's LDS operations execute in order: the segment is in the ring)
+    };
+    for (int q = h; q < nseg; q += RING_HELPERS) {
+      if (q >= 1 && q * RING_SEG + RING_SEG <= T - 2) forward_segment(q, std::true_type{});
+      else forward_segment(q, std::false_type{});
+    }
+    // ---- backward: x of a finished segment out, then the y of a ring's length further down back into its slots
+    int fetched = 0;
+    // this wave's segments, highest first
+    int qtop = nseg - 1;
+    while (qtop >= 0 && qtop % RING_HELPERS != h) --qtop;
+    // the factor's head rows for the end of the backward sweep (the sweep left them in the table on its way forward;
+    // prog[18] says how many): every helper asks for its share as the way back begins and keeps it in registers until
+    // the slots are free -- the sweep through segment 5 and every helper's segments from there up stored (no y comes
+    // back into those slots: that ends with segment 12) -- which it checks when it gets to the first of its segments
+    // below that, or runs out of segments
+    constexpr int first_seg = RING_HEAD_SLOT / RING_SEG;
+    constexpr int rs_rows = (3 * RING_HEAD_ROWS + RING_HELPERS - 1) / RING_HELPERS;
+    double hv[rs_rows];
+    while (ring_peek(prog + 8) == 0) __builtin_amdgcn_s_sleep(2);
+    const int nh = ring_peek(prog + 18);
+    bool restaged = nh == 0;
+    if (!restaged) {
+      const double* tab = a.scratch + dc;
+#pragma unroll
+      for (int i = 0; i < rs_rows; ++i) {
+        const int r = h + i * RING_HELPERS;          // plane r / RING_HEAD_ROWS, row r % RING_HEAD_ROWS
+        if (r % RING_HEAD_ROWS < nh) hv[i] = tab[(r / RING_HEAD_ROWS) * plane + (int64_t)(r % RING_HEAD_ROWS) * D];
+      }
+    }
+    auto restage_write = [&]() {
+      while (ring_peek(prog + 16) > first_seg) __builtin_amdgcn_s_sleep(2);
+      for (int hh = 0; hh < RING_HELPERS; ++hh) {
+        const int qmin = first_seg + ((hh - first_seg) % RING_HELPERS + RING_HELPERS) % RING_HELPERS;
+        const int need = qmin <= nseg - 1 ? (nseg - 1 - qmin) / RING_HELPERS + 1 : 0;
+        while (ring_peek(prog + 9 + hh) < need) __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int i = 0; i < rs_rows; ++i) {
+        const int r = h + i * RING_HELPERS;
+        if (r < 3 * RING_HEAD_ROWS && r % RING_HEAD_ROWS < nh) hfac[r * RING_LANES + lane] = hv[i];
+      }
+      if (lane == 0) __hip_atomic_fetch_add(prog + 17, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      restaged = true;
+    };
+    for (int q = qtop; q >= 0; q -= RING_HELPERS) {
+      if (!restaged && q < first_seg) restage_write();
+      const int j0 = q * RING_SEG;
+      double* base = ring + seg_slot(q) * RING_LANES + lane;
+      const int qf = q - ring_segs;          // its frames went out on the way forward iff frame + RING_CAP < T
+      // (the bytes read here were written in the forward phase, before prog[8] was posted -- no later store of this
+      // workgroup touches them before this load -- so the loads need not wait for the sweep either)
+      double yv[RING_SEG];
+      if (qf >= 0 && hd < D) {
+#pragma unroll
+        for (int k = 0; k < RING_SEG; ++k) {
+          const int j = qf * RING_SEG + k;
+          yv[k] = (j + RING_CAP < T) ? o[(int64_t)j * a.ld_out] : 0.0;
+        }
+      }
+      while (ring_peek(prog + 16) > q) __builtin_amdgcn_s_sleep(2);     // the backward sweep has finished segment q
+      if (hd < D) {
+#pragma unroll
+        for (int k = 0; k < RING_SEG; ++k)
+          if (j0 + k < T) o[(int64_t)(j0 + k) * a.ld_out] = base[k * RING_LANES];
+        if (qf >= 0) {
+#pragma unroll
+          for (int k = 0; k < RING_SEG; ++k) {
+            const int j = qf * RING_SEG + k;
+            if (j + RING_CAP < T) base[k * RING_LANES] = yv[k];
+          }
+        }
+      }
+      ++fetched;
+      if (lane == 0) ring_post(prog + 9 + h, fetched);
+    }
+    if (!restaged) restage_write();
+    return;
+  }
+
+  // ================= wave 0: the two sweeps, a lane a dimension
+  const double v0 = a.var[dc], v1 = a.var[D + dc], v2 = a.var[2 * D + dc];
+  const double tau0 = 1.0 / v0, tau1_in = 1.0 / v1, tau2_in = 1.0 / v2, tau_edge = 1.0 / kBigVar;
+  auto tau1 = [&](int t) -> double {
+    if (t < 0 || t >= T) return 0.0;
+    return (t == 0 || t == T - 1) ? tau_edge : tau1_in;
+  };
+  auto tau2 = [&](int t) -> double {
+    if (t < 0 || t >= T) return 0.0;
+    return (t == 0 || t == T - 1) ? tau_edge : tau2_in;
+  };
+  // the shared factor's view of the variances ("T = infinity": an edge at frame 0 only), as mlpg_factor_block has it
+  auto tau1f = [&](int t) -> double { return t < 0 ? 0.0 : (t == 0 ? tau_edge : tau1_in); };
+  auto tau2f = [&](int t) -> double { return t < 0 ? 0.0 : (t == 0 ? tau_edge : tau2_in); };
+  double* fd = a.scratch + dc;
+  double* fl1 = fd + plane;
+  double* fl2 = fl1 + plane;
+  const int n_shared = T >= 3 ? T - 2 : 0;
+  // the factor: rows 0 .. ncvmax derived on the way forward (a lane's entries stay put from its own row of repetition
+  // on: mlpg_factor_block's rule), the stationary entries in three registers from there
+  double sd = 0.0, sl1 = 0.0, sl2 = 0.0;
+  bool lane_settled = false;             // this lane's factor has repeated: (sd, sl1, sl2) hold
+  bool settled = false;                  // every lane's has
+  int ncvmax = 0x7fffffff;               // the row at which the last lane's did
+  double tl_d0 = 1.0, tl_d1 = 1.0, tl_10 = 0.0, tl_11 = 0.0, tl_20 = 0.0, tl_21 = 0.0;      // frames T - 2, T - 1
+  double l1p = 0.0, l2p = 0.0, cprev = 0.0, y1 = 0.0, y2 = 0.0;
+  double* lane_ring = ring + lane;
+
+  __builtin_amdgcn_s_setprio(3);         // (the SIMD is shared with a helper wave: the sweep goes first)
+  auto relaxed = [](const int* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+  // ---- forward
+  int hsel = 0, hcnt = 0, slot = 0;       // segment sgm: helper sgm % H, its (sgm / H + 1)-th; first ring slot
+  int seen = relaxed(prog + 1);
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    // (what the sweep needs to know about the segment after this one -- is it in the ring yet? -- is asked for before
+    // the chain and looked at after it)
+    if (seen <= hcnt)
+      while (ring_peek(prog + 1 + hsel) <= hcnt) __builtin_amdgcn_s_sleep(1);   // segment sgm is in the ring
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int hsel_n = hsel + 1 == RING_HELPERS ? 0 : hsel + 1, hcnt_n = hsel + 1 == RING_HELPERS ? hcnt + 1 : hcnt;
+    seen = relaxed(prog + 1 + hsel_n);
+    const int j0 = sgm * RING_SEG;
+    const int jend = j0 + RING_SEG < T ? j0 + RING_SEG : T;
+    double* sl = lane_ring + slot * RING_LANES;         // slot of frame j: sl[(j - j0) * 64]
+    if (settled && j0 >= ncvmax + 2 && j0 + RING_SEG <= n_shared) {
+      // the whole segment on the stationary factor, two stationary frames behind it: straight-line code, the 24
+      // right-hand sides read at once, the chain, the writes
+      double v[RING_SEG];
+#pragma unroll
+      for (int i = 0; i < RING_SEG; ++i) v[i] = sl[i * RING_LANES];
+#pragma unroll
+      for (int i = 0; i < RING_SEG; ++i) {
+        const double y = (v[i] - sl1 * y1 - sl2 * y2) * sd;
+        sl[i * RING_LANES] = y;
+        y2 = y1;
+        y1 = y;
+      }
+    } else {
+      // the head (the factor still moves: derived here, row by row, and left in the table for the way back), the
+      // frames between it and the first whole stationary segment, the segment with the two re-derived tail frames:
+      // a rolled loop, the right-hand side of the frame after asked for first
+      double nb = sl[0];
+#pragma unroll 1
+      for (int j = j0; j < jend; ++j) {
+        const int jn = j + 1 < jend ? j + 1 : j;
+        const double nb_n = sl[(jn - j0) * RING_LANES];
+        double dd = sd, l1 = sl1, l2 = sl2;                    // dd holds 1 / L[j,j]
+        if (j >= n_shared) {
+          const double pjj = tau0 + 0.25 * (tau1(j - 1) + tau1(j + 1)) + (tau2(j - 1) + 4.0 * tau2(j) + tau2(j + 1));
+          const double pj1 = (j + 1 < T) ? -2.0 * (tau2(j) + tau2(j + 1)) : 0.0;
+          const double pj2 = (j + 2 < T) ? (tau2(j + 1) - 0.25 * tau1(j + 1)) : 0.0;
+          dd = 1.0 / sqrt(pjj - l1p * l1p - l2p * l2p);
+          l1 = (pj1 - cprev * l1p) * dd;
+          l2 = pj2 * dd;
+          const int q = j - (T - 2);
+          if (q == 0) { tl_d0 = dd; tl_10 = l1; tl_20 = l2; }
+          else { tl_d1 = dd; tl_11 = l1; tl_21 = l2; }
+        } else if (!settled) {
+          if (!lane_settled) {
+            const double pjj = tau0 + 0.25 * (tau1f(j - 1) + tau1f(j + 1)) + (tau2f(j - 1) + 4.0 * tau2f(j) + tau2f(j + 1));
+            const double pj1 = -2.0 * (tau2f(j) + tau2f(j + 1));
+            const double pj2 = tau2f(j + 1) - 0.25 * tau1f(j + 1);
+            dd = factor_rsqrt(pjj - l1p * l1p - l2p * l2p);
+            l1 = (pj1 - cprev * l1p) * dd;
+            l2 = pj2 * dd;
+            auto same = [](double x, double y) { return fabs(x - y) <= 8.9e-16 * fabs(y); };
+            if (j >= 3 && same(l1, l1p) && same(l2, cprev) && same(cprev, l2p)) {
+              lane_settled = true;
+              sd = dd; sl1 = l1; sl2 = l2;
+            }
+          }
+          fd[(int64_t)j * D] = dd;           // (every workgroup leaves the same values here)
+          fl1[(int64_t)j * D] = l1;
+          fl2[(int64_t)j * D] = l2;
+          if (__all(lane_settled)) {
+            settled = true;
+            ncvmax = j;
+          }
+        }
+        const double y = (nb - l1p * y1 - l2p * y2) * dd;
+        sl[(j - j0) * RING_LANES] = y;
+        l2p = cprev;
+        l1p = l1;
+        cprev = l2;
+        y2 = y1;
+        y1 = y;
+        nb = nb_n;
+      }
+    }
+    if (lane == 0) ring_post(prog, sgm + 1);
+    hsel = hsel_n; hcnt = hcnt_n; slot = slot + RING_SEG == RING_CAP ? 0 : slot + RING_SEG;
+  }
+  // the helpers have prepared everything (the sweep consumed it); their counters start again for the way back
+  // ---- backward: L^T x = y, segments from the last to the first
+  // the head's rows: 0 .. ncvmax - 1 where the factor settled (row ncvmax on is the registers'), else every shared row
+  const int head_rows = settled ? ncvmax : n_shared;
+  const bool staged = head_rows <= RING_HEAD_ROWS;     // the helpers put them into the ring; else from the table
+  if (lane == 0) {
+    ring_post(prog + 18, staged ? head_rows : 0);
+    ring_post(prog + 16, nseg);          // lowest finished segment: none yet
+    ring_post(prog + 8, 1);
+  }
+  double x1 = 0.0, x2 = 0.0;
+  // segment sgm's y is still in the ring, or comes back with the helper that stores segment qs = sgm + ring_segs: helper
+  // qs % H, whose count stands at (nseg - 1 - qs) / H + 1 after that segment (it takes its segments from the top)
+  slot = ((nseg - 1) % ring_segs) * RING_SEG;
+  int bq = 0, bh = 0, bneed = 0;           // for the segment at hand: bq >= 0: it has to wait, for helper bh to count bneed
+  auto counters_for = [&](int sgm) {
+    const int qs = sgm + ring_segs;
+    bh = qs % RING_HELPERS;
+    bq = nseg - 1 - qs;
+    bneed = bq >= 0 ? bq / RING_HELPERS + 1 : 0;
+  };
+  counters_for(nseg - 1);
+  int seen_b = bq >= 0 ? relaxed(prog + 9 + bh) : 0;
+  for (int sgm = nseg - 1; sgm >= 0; --sgm) {
+    if (bq >= 0 && seen_b < bneed)
+      while (ring_peek(prog + 9 + bh) < bneed) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (sgm > 0) {
+      counters_for(sgm - 1);
+      seen_b = bq >= 0 ? relaxed(prog + 9 + bh) : 0;
+    }
+    const int j0 = sgm * RING_SEG;
+    const int jtop = (j0 + RING_SEG < T ? j0 + RING_SEG : T) - 1;
+    double* sl = lane_ring + slot * RING_LANES;
+    if (j0 >= head_rows && j0 + RING_SEG <= n_shared) {
+      double v[RING_SEG];
+#pragma unroll
+      for (int i = 0; i < RING_SEG; ++i) v[i] = sl[(RING_SEG - 1 - i) * RING_LANES];
+#pragma unroll
+      for (int i = 0; i < RING_SEG; ++i) {
+        const double x = (v[i] - sl1 * x1 - sl2 * x2) * sd;
+        sl[(RING_SEG - 1 - i) * RING_LANES] = x;
+        x2 = x1;
+        x1 = x;
+      }
+    } else {
+      // rolled, as on the way forward; the head's rows from the ring once every helper has put its share there
+      if (staged && j0 < head_rows)
+        while (ring_peek(prog + 17) < RING_HELPERS) __builtin_amdgcn_s_sleep(1);
+      auto fetch = [&](int j, double& qd, double& q1, double& q2) {
+        qd = sd; q1 = sl1; q2 = sl2;
+        if (j >= n_shared) {
+          const bool last = j == T - 1;
+          qd = last ? tl_d1 : tl_d0; q1 = last ? tl_11 : tl_10; q2 = last ? tl_21 : tl_20;
+        } else if (j < head_rows) {
+          // (two sources, two branches: behind one generic pointer the rows in the ring would be flat loads, which
+          // take the memory pipeline's queue like any global load)
+          if (staged) {
+            const double* row = hfac + j * RING_LANES + lane;
+            qd = row[0]; q1 = row[RING_HEAD_ROWS * RING_LANES]; q2 = row[2 * RING_HEAD_ROWS * RING_LANES];
+          } else {
+            qd = fd[(int64_t)j * D]; q1 = fl1[(int64_t)j * D]; q2 = fl2[(int64_t)j * D];
+          }
+        }
+      };
+      double ny = sl[(jtop - j0) * RING_LANES], cd, c1, c2;
+      fetch(jtop, cd, c1, c2);
+#pragma unroll 1
+      for (int j = jtop; j >= j0; --j) {
+        const int jn = j - 1 >= j0 ? j - 1 : j;
+        const double ny_n = sl[(jn - j0) * RING_LANES];
+        double nd, n1, n2;
+        fetch(jn, nd, n1, n2);
+        const double x = (ny - c1 * x1 - c2 * x2) * cd;
+        sl[(j - j0) * RING_LANES] = x;
+        x2 = x1;
+        x1 = x;
+        ny = ny_n; cd = nd; c1 = n1; c2 = n2;
+      }
+    }
+    if (lane == 0) ring_post(prog + 16, sgm);
+    slot = slot == 0 ? RING_CAP - RING_SEG : slot - RING_SEG;
   }
 }
 
@@ -1226,7 +1635,39 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   // reduce -> scan -> solve with 16-frame chunks, two chunks per workgroup, input rows staged through
   // LDS (uploads its own tables and computes the factor in its first launch); batches of short
   // utterances: the sequential sweeps are as fast
-  if (t_max >= MLPG_SEQ_BELOW) return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
+  if (t_max >= MLPG_SEQ_BELOW && getenv("ITTS_MLPG_STREAM")) return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
+  if (t_max >= MLPG_SEQ_BELOW) {
+    // one pass with the right-hand side in LDS (mlpg_ring_kernel); ITTS_MLPG_STREAM=1: the three-launch form above
+    const int nblk = (dim + RING_LANES - 1) / RING_LANES;
+    std::vector<int> order(n_utts);
+    for (int u = 0; u < n_utts; ++u) order[u] = u;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
+    });
+    const size_t off_bytes = ((size_t)(n_utts + 1) * sizeof(int64_t) + 31) / 32 * 32;
+    std::vector<char> host(off_bytes + (size_t)n_utts * sizeof(int), 0);
+    std::memcpy(host.data(), h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t));
+    std::memcpy(host.data() + off_bytes, order.data(), (size_t)n_utts * sizeof(int));
+    char* tab = nullptr;
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&tab, host.size(), s));
+    {
+      const int rc = itts::staged_upload(tab, host.data(), host.size(), s);
+      if (rc) return rc;
+    }
+    a.offsets = reinterpret_cast<const int64_t*>(tab);
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
+    }
+    RingArgs g{a, reinterpret_cast<const int*>(tab + off_bytes), (int)t_max};
+    hipLaunchKernelGGL(mlpg_ring_kernel, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
+    ITTS_LAUNCH_CHECK();
+    ITTS_HIP_CHECK(itts::scratch_free(tab, s));
+    return ITTS_OK;
+  }
   {
     const int rc = itts::staged_upload(d_off, h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t), s);
     if (rc) return rc;

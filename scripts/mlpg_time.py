@@ -1,0 +1,34 @@
+"""Time itts_mlpg_generation on the traffic_driver's MLPG batch (256 utterances, 186 -> 62 columns).
+
+usage: python3 scripts/mlpg_time.py [passes] [utterances]      ITTS_MLPG_STREAM=1 selects the three-launch form"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from idiaptts_amd import ops, world                             # noqa: E402
+from idiaptts_amd.bench_support import utterance_lengths       # noqa: E402
+
+passes = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+dev = torch.device("cuda", 0)
+n_utts = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+off = world.offsets(utterance_lengths(n_utts, seed=5).tolist())
+feat = torch.randn(off[-1], 186, dtype=torch.float64, device=dev)
+var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
+for _ in range(5):
+    ops.mlpg_generation(feat, var, 62, off)
+torch.cuda.synchronize()
+times = []
+for _ in range(passes):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.mlpg_generation(feat, var, 62, off)
+    e1.record()
+    e1.synchronize()
+    times.append(e0.elapsed_time(e1) * 1e3)
+times.sort()
+frames = int(off[-1])
+alg = frames * (186 + 62) * 8
+print("utterances %d  frames %d  median %.1f us  min %.1f us  p90 %.1f us  algorithmic %.3f GB -> %.2f TB/s at the median"
+      % (n_utts, frames, times[len(times) // 2], times[0], times[int(len(times) * 0.9)], alg / 1e9, alg / times[len(times) // 2] / 1e6))
