@@ -511,7 +511,7 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
                        "algorithmic_GBps": gbs,
                        "frac_of_hbm_peak": gbs / PEAK_HBM_GBS / n_ranks,
-                       "roofline": {"bound": "hbm", "kernel": "mlpg_reduce_kernel + mlpg_scan_kernel + mlpg_solve_kernel",
+                       "roofline": {"bound": "hbm", "kernel": "mlpg_ring_kernel (one launch; whole call by events, host side included)",
                                     "achieved": gbs / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": gbs / PEAK_HBM_GBS / n_ranks, "traffic": ml_traffic,
                                     "algorithmic_bytes_per_launch": ml_frames / n_ranks * 2000,

@@ -113,6 +113,17 @@ int64_t* pinned_slot(DeviceContext* ctx);
 // once.
 int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s);
 
+// A small host table the kernels of ONE launch sequence read in place: copied into a page-locked staging slot (the
+// device reads host memory at the same address), no copy on the stream.  For a few loads per workgroup -- a table
+// every thread walks belongs in device memory (staged_upload).  pinned_table_end after the last consumer has been
+// queued on s, on every path (it keeps the slot from being reused before that work has run).
+struct PinnedTable {
+  void* p = nullptr;
+  void* slot = nullptr;
+};
+int pinned_table_begin(const void* src, size_t bytes, PinnedTable* t);
+int pinned_table_end(PinnedTable* t, hipStream_t s);
+
 // Small stream-ordered device copy of a host int64 array (offsets). Caller frees with
 // scratch_free on the same stream.
 int upload_i64(const int64_t* h, int n, int64_t** d_out, hipStream_t s);

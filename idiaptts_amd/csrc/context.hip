@@ -564,8 +564,8 @@ std::mutex g_stage_mutex;
 std::map<int, StageRing> g_stage;
 }  // namespace
 
-int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
-  if (bytes == 0) return ITTS_OK;
+// A free staging slot of the current device holding at least `bytes` (its last use waited for), marked busy.
+static int stage_acquire(size_t bytes, const char* who, StageSlot** out) {
   int dev = 0;
   ITTS_HIP_CHECK(hipGetDevice(&dev));
   StageSlot* sl = nullptr;
@@ -580,19 +580,14 @@ int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
       if (!c.busy) sl = &c;
     }
     if (!sl) {
-      set_error("staged_upload: every staging slot is being filled by another thread");
+      set_error(std::string(who) + ": every staging slot is being filled by another thread");
       return ITTS_E_HIP;
     }
     sl->busy = true;
     if (sl->pending) wait_for = sl->ev;
   }
-  auto release = [&](bool pending) {
-    std::lock_guard<std::mutex> lock(g_stage_mutex);
-    sl->pending = pending;
-    sl->busy = false;
-  };
   hipError_t e = hipSuccess;
-  if (wait_for) e = hipEventSynchronize(wait_for);        // the copy that last used this slot has left it
+  if (wait_for) e = hipEventSynchronize(wait_for);        // the work that last used this slot has left it
   if (e == hipSuccess && sl->cap < bytes) {
     if (sl->p) (void)hipHostFree(sl->p);
     sl->p = nullptr;
@@ -603,28 +598,71 @@ int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
   }
   if (e == hipSuccess && !sl->ev) e = hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming);
   if (e != hipSuccess) {
-    release(false);
-    set_error(std::string("staged_upload: ") + hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    sl->pending = false;
+    sl->busy = false;
+    set_error(std::string(who) + ": " + hipGetErrorString(e));
     return ITTS_E_HIP;
+  }
+  *out = sl;
+  return ITTS_OK;
+}
+
+// Hands the slot back: `pending` = work queued on s still reads it (an event marks its end).  If the event cannot
+// be recorded the work is waited for on the spot rather than leaving the slot to be overwritten under it.
+static int stage_release(StageSlot* sl, bool pending, hipStream_t s, const char* who) {
+  hipError_t e = hipSuccess;
+  if (pending) {
+    e = hipEventRecord(sl->ev, s);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(s);
+      pending = false;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    sl->pending = pending;
+    sl->busy = false;
+  }
+  if (e != hipSuccess) {
+    set_error(std::string(who) + ": " + hipGetErrorString(e));
+    return ITTS_E_HIP;
+  }
+  return ITTS_OK;
+}
+
+int staged_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return ITTS_OK;
+  StageSlot* sl = nullptr;
+  {
+    const int rc = stage_acquire(bytes, "staged_upload", &sl);
+    if (rc) return rc;
   }
   std::memcpy(sl->p, src, bytes);
-  e = hipMemcpyAsync(d_dst, sl->p, bytes, hipMemcpyHostToDevice, s);
+  const hipError_t e = hipMemcpyAsync(d_dst, sl->p, bytes, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) {
-    release(false);
+    (void)stage_release(sl, false, s, "staged_upload");
     set_error(std::string("staged_upload: ") + hipGetErrorString(e));
     return ITTS_E_HIP;
   }
-  // from here on the slot is in use by the queued copy whatever happens next: if the event cannot be
-  // recorded the copy is waited for on the spot rather than leaving the slot to be overwritten under it
-  e = hipEventRecord(sl->ev, s);
-  if (e != hipSuccess) {
-    (void)hipStreamSynchronize(s);
-    release(false);
-    set_error(std::string("staged_upload: ") + hipGetErrorString(e));
-    return ITTS_E_HIP;
-  }
-  release(true);
+  return stage_release(sl, true, s, "staged_upload");
+}
+
+int pinned_table_begin(const void* src, size_t bytes, PinnedTable* t) {
+  StageSlot* sl = nullptr;
+  const int rc = stage_acquire(bytes ? bytes : 1, "pinned_table", &sl);
+  if (rc) return rc;
+  std::memcpy(sl->p, src, bytes);
+  t->p = sl->p;
+  t->slot = sl;
   return ITTS_OK;
+}
+
+int pinned_table_end(PinnedTable* t, hipStream_t s) {
+  if (!t->slot) return ITTS_OK;
+  StageSlot* sl = static_cast<StageSlot*>(t->slot);
+  t->slot = nullptr;
+  return stage_release(sl, true, s, "pinned_table");
 }
 
 int upload_i64(const int64_t* h, int n, int64_t** d_out, hipStream_t s) {

@@ -55,6 +55,7 @@ struct MlpgArgs {
 };
 
 constexpr int MLPG_SEQ_BELOW = 194;   // utterances shorter than this take the sequential sweeps (three 64-frame chunks + tail)
+constexpr int MLPG_RING_FROM = 128;     // (utterance, 64-dimension block) units from which the one-pass kernel takes over
 
 // The Cholesky factor of P depends on the variances and on the frame index only (not on the
 // data), and -- because the delta variances are constant except in the first and last frame --
@@ -336,13 +337,22 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   // prog[16]: backward sweep: lowest segment finished (n_segments: none yet)
   // prog[17]: helpers that have put their factor rows into the ring     prog[18]: rows of the factor's head (0: too many)
   const MlpgArgs& a = g.a;
-  const int u = g.order[blockIdx.y];
   const int blk = blockIdx.x;
-  const int64_t t0 = a.offsets[u];
-  const int T = (int)(a.offsets[u + 1] - t0);            // (frames of one utterance: 32 bits)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // the order and offsets tables are read in place from page-locked host memory (no copy on the stream in front of
+  // the launch): one thread fetches this workgroup's three numbers, the others get them through LDS
+  int64_t* bounds = reinterpret_cast<int64_t*>(prog + 24);
+  if (tid == 0) {
+    const int u = g.order[blockIdx.y];
+    bounds[0] = a.offsets[u];
+    bounds[1] = a.offsets[u + 1];
+  }
+  if (tid < 24) prog[tid] = 0;
+  __syncthreads();
+  const int64_t t0 = bounds[0];
+  const int T = (int)(bounds[1] - t0);            // (frames of one utterance: 32 bits)
   if (T <= 0) return;
   const int D = a.dim;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const double rvb = 1.0 / kBigVar;
   const int nseg = (T + RING_SEG - 1) / RING_SEG;
   constexpr int ring_segs = RING_CAP / RING_SEG;
@@ -352,8 +362,6 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   const int dc = blk * RING_LANES + lane < D ? blk * RING_LANES + lane : D - 1;
   double* hfac = ring + RING_HEAD_SLOT * RING_LANES;          // [3][RING_HEAD_ROWS][64]
   const int64_t plane = (int64_t)g.t_max * D;                 // the factor table: three planes of t_max rows
-  if (tid < 32) prog[tid] = 0;
-  __syncthreads();
 
   if (wave != 0) {
     // ================= helper wave h: segments q = h, h + H, h + 2 H ..  (a lane: one dimension)
@@ -1635,10 +1643,23 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   // reduce -> scan -> solve with 16-frame chunks, two chunks per workgroup, input rows staged through
   // LDS (uploads its own tables and computes the factor in its first launch); batches of short
   // utterances: the sequential sweeps are as fast
-  if (t_max >= MLPG_SEQ_BELOW && getenv("ITTS_MLPG_STREAM")) return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
+  // .. or, from about half a chip's worth of (utterance, 64 dimensions) units, one pass with the right-hand side in LDS
+  // (mlpg_ring_kernel: a sequential sweep per unit -- 200 us for a 2 000-frame utterance however few there are --
+  // so small batches stay with the form above, which also divides an utterance among workgroups: 16 utterances 132
+  // against 225 us, 64: 174 / 201, 256: 372 / 307, 4 096: 4 520 / 3 608).  ITTS_MLPG_STREAM=1 / ITTS_MLPG_RING=1 force one.
+  const int nblk = (dim + RING_LANES - 1) / RING_LANES;
+  const char* force_stream = getenv("ITTS_MLPG_STREAM");
+  const char* force_ring = getenv("ITTS_MLPG_RING");
+  const bool ring = force_ring ? true : (force_stream ? false : (int64_t)n_utts * nblk >= MLPG_RING_FROM);
+  if (t_max >= MLPG_SEQ_BELOW && !ring) return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
   if (t_max >= MLPG_SEQ_BELOW) {
-    // one pass with the right-hand side in LDS (mlpg_ring_kernel); ITTS_MLPG_STREAM=1: the three-launch form above
-    const int nblk = (dim + RING_LANES - 1) / RING_LANES;
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    ITTS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
+    }
     std::vector<int> order(n_utts);
     for (int u = 0; u < n_utts; ++u) order[u] = u;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
@@ -1648,25 +1669,22 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
     std::vector<char> host(off_bytes + (size_t)n_utts * sizeof(int), 0);
     std::memcpy(host.data(), h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t));
     std::memcpy(host.data() + off_bytes, order.data(), (size_t)n_utts * sizeof(int));
-    char* tab = nullptr;
-    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&tab, host.size(), s));
+    itts::PinnedTable table;          // (nothing between here and the launch returns early: the slot goes back after it)
     {
-      const int rc = itts::staged_upload(tab, host.data(), host.size(), s);
+      const int rc = itts::pinned_table_begin(host.data(), host.size(), &table);
       if (rc) return rc;
     }
+    const char* tab = static_cast<const char*>(table.p);
     a.offsets = reinterpret_cast<const int64_t*>(tab);
-    static std::atomic<uint64_t> attr_done{0};
-    int dev = 0;
-    ITTS_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-      if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
-    }
     RingArgs g{a, reinterpret_cast<const int*>(tab + off_bytes), (int)t_max};
     hipLaunchKernelGGL(mlpg_ring_kernel, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
-    ITTS_LAUNCH_CHECK();
-    ITTS_HIP_CHECK(itts::scratch_free(tab, s));
-    return ITTS_OK;
+    const hipError_t launched = hipGetLastError();
+    const int rc_table = itts::pinned_table_end(&table, s);
+    if (launched != hipSuccess) {
+      itts::set_error(std::string("mlpg_ring_kernel: ") + hipGetErrorString(launched));
+      return ITTS_E_HIP;
+    }
+    return rc_table;
   }
   {
     const int rc = itts::staged_upload(d_off, h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t), s);

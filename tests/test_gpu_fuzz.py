@@ -13,12 +13,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_mlpg_random_shapes(gpu):
-    """80 random batches: empty, one-frame and chunk-boundary lengths, 1 .. 129 dimensions (one to three
+@pytest.mark.parametrize("solve", ["auto", "ring"])
+def test_mlpg_random_shapes(gpu, solve, monkeypatch):
+    """(under the library's own choice of solve, and with the one-pass ring kernel forced for every batch whose
+    longest utterance has 194 frames or more)
+    80 random batches: empty, one-frame and chunk-boundary lengths, 1 .. 129 dimensions (one to three
     64-dimension blocks), input / output column offsets, slowly settling factors; untouched columns
     of the output array must stay untouched (misc/mlpg.py:94-127 per utterance is the reference)."""
     from idiaptts_amd import ops
     from oracle import capi
+    monkeypatch.delenv("ITTS_MLPG_STREAM", raising=False)
+    if solve == "ring":
+        monkeypatch.setenv("ITTS_MLPG_RING", "1")
+    else:
+        monkeypatch.delenv("ITTS_MLPG_RING", raising=False)
     rng = np.random.default_rng(5)
     worst = 0.0
     for case in range(80):

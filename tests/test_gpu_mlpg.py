@@ -6,6 +6,21 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "ring", "stream"])
+def solve(request, monkeypatch):
+    """The library picks between its solves by batch shape (sequential sweeps under 194 frames; above that the
+    one-pass ring kernel from 128 (utterance, 64-dimension) units, reduce -> scan -> solve below): these tests run
+    under its own choice and with each of the two long-utterance forms forced (csrc/mlpg.hip reads the variables
+    at every call)."""
+    monkeypatch.delenv("ITTS_MLPG_RING", raising=False)
+    monkeypatch.delenv("ITTS_MLPG_STREAM", raising=False)
+    if request.param == "ring":
+        monkeypatch.setenv("ITTS_MLPG_RING", "1")
+    elif request.param == "stream":
+        monkeypatch.setenv("ITTS_MLPG_STREAM", "1")
+    return request.param
+
+
 def _case(rng, lengths, dim, extra_cols=0, col0=0):
     T = int(sum(lengths))
     feat = rng.normal(size=(T, col0 + 3 * dim + extra_cols))
@@ -19,10 +34,13 @@ def _case(rng, lengths, dim, extra_cols=0, col0=0):
     ([50, 0, 75], 1, 2), ([640, 1300], 62, 1),
     # time-parallel path: utterance lengths around the 64-frame chunk boundaries, mixed with short ones
     ([194, 195, 257, 258, 259, 130, 66, 3, 1, 322], 4, 0), ([193, 2], 2, 0), ([4098], 1, 0),
+    # ring kernel: around its 24-frame segments, the five segments under the staged factor rows, the 288-frame ring
+    ([200, 23, 24, 25, 47, 48, 49, 119, 120, 121, 143, 144, 145], 62, 0), ([287, 288, 289, 311, 312, 313, 575, 576, 577], 7, 0),
+    ([2000, 600, 601], 64, 1),
 ])
-def test_mlpg_matches_oracle(gpu, lengths, dim, col0):
-    """Both solves the library holds -- the sequential sweeps for batches whose longest utterance is
-    under 194 frames, reduce -> scan -> solve otherwise -- against the C oracle."""
+def test_mlpg_matches_oracle(gpu, solve, lengths, dim, col0):
+    """The solves the library holds -- the sequential sweeps for batches whose longest utterance is
+    under 194 frames, the one-pass ring kernel or reduce -> scan -> solve otherwise -- against the C oracle."""
     from idiaptts_amd import ops
     from oracle import capi
     rng = np.random.default_rng(7)
@@ -39,7 +57,7 @@ def test_mlpg_matches_oracle(gpu, lengths, dim, col0):
         assert rmse <= 1e-10 and err <= 1e-9, (u, err, rmse)  # north-star bar: 1e-4 RMSE
 
 
-def test_mlpg_full_size_property(gpu):
+def test_mlpg_full_size_property(gpu, solve):
     """BASELINE config 4 shape (187-dim cmp, 256 utterances): P x = b must hold to fp64
     round-off for the solution returned, checked through the normal equations on a sample."""
     from idiaptts_amd import ops
@@ -75,7 +93,7 @@ def test_mlpg_full_size_property(gpu):
 
 
 @pytest.mark.parametrize("lengths,ratio", [([700, 90, 333], 1e-6), ([700, 90, 333], 1e-3), ([3000, 260], 1e-7)])
-def test_mlpg_slowly_settling_factor(gpu, lengths, ratio):
+def test_mlpg_slowly_settling_factor(gpu, solve, lengths, ratio):
     """Delta variances up to 1e7 times smaller than the static ones: the Cholesky factor needs hundreds
     of frames to become stationary, so most chunks of an utterance carry their own matrices (the scan
     kernel's single-chunk segments, and -- at 3 000 frames -- its sequential road, taken when there
@@ -95,7 +113,7 @@ def test_mlpg_slowly_settling_factor(gpu, lengths, ratio):
         assert np.abs(out[a:b] - ref).max() <= 1e-9 * scale, (u, np.abs(out[a:b] - ref).max())
 
 
-def test_mlpg_more_than_64_dimensions_and_an_output_slice(gpu):
+def test_mlpg_more_than_64_dimensions_and_an_output_slice(gpu, solve):
     """Two 64-dimension blocks (dim = 70) and a result written into columns 3 .. 72 of a wider
     array whose other columns must stay untouched (the solve also parks b in those rows)."""
     from idiaptts_amd import ops
