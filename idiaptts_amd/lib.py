@@ -156,8 +156,14 @@ def check(status, what=""):
 
 
 def offsets_array(offsets):
-    arr = (c_int64 * len(offsets))(*[int(o) for o in offsets])
-    return arr
+    """A host int64 array for the `const int64_t*` offset parameters, from a list / tuple / numpy array (through
+    numpy: a quarter of the time of converting element by element -- 10 instead of 36 us for 257 offsets, which is
+    inside every timed call of the short entry points)."""
+    import numpy as np
+    arr = np.array(offsets, dtype=np.int64, order="C", ndmin=1)      # (a private, writable copy: from_buffer needs one)
+    if arr.ndim != 1:
+        raise ValueError("offsets must be one-dimensional")
+    return (c_int64 * arr.shape[0]).from_buffer(arr)
 
 
 def current_stream():
