@@ -516,6 +516,16 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                                     "frac": gbs / PEAK_HBM_GBS / n_ranks, "traffic": ml_traffic,
                                     "algorithmic_bytes_per_launch": ml_frames / n_ranks * 2000,
                                     "algorithmic_bytes_per_frame": 2000}}
+        # the same batch with float32 rows (the acoustic model's output type; widened in the solve's loads):
+        # 744 + 496 algorithmic bytes per frame
+        feat32 = feat.float()
+        ops.mlpg_generation(feat32, var, 62, ml_off)
+        sync()
+        ms_32 = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat32, var, 62, ml_off),
+                                               stream, 7), dist.ReduceOp.MAX)
+        res["mlpg"]["float32_rows"] = {"ms": ms_32, "algorithmic_bytes_per_frame": 1240,
+                                       "algorithmic_GBps": ml_frames * 1240 / (ms_32 * 1e-3) / 1e9}
+        del feat32
         # the same solve at larger batches
         curve = []
         for n_u in (1024, 4096):

@@ -323,11 +323,14 @@ struct RingArgs {
   MlpgArgs a;
   const int* order;       // utterances, longest first
   int t_max;
+  const float* feat32;    // the input rows when they are float32 (itts_mlpg_generation_f32): a.feat is unused then
 };
 // progress words in LDS (one writer each; release / acquire at workgroup scope)
 __device__ __forceinline__ void ring_post(int* w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int ring_peek(const int* w) { return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// FT: the type of the input rows (double, or float: the network's own output type -- converted in the load, which is exact)
+template <typename FT>
 __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   extern __shared__ __attribute__((aligned(16))) char rsm[];
   double* ring = reinterpret_cast<double*>(rsm);          // [RING_CAP][64]
@@ -371,7 +374,8 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
     const int h = wave - 1;
     const int hd = blk * RING_LANES + lane;
     const double hrv0 = 1.0 / a.var[dc], hrv1 = 1.0 / a.var[D + dc], hrv2 = 1.0 / a.var[2 * D + dc];
-    const double* hf = a.feat + t0 * a.ld_feat + a.col0 + dc;
+    const FT* hf = (std::is_same<FT, float>::value ? reinterpret_cast<const FT*>(g.feat32) : reinterpret_cast<const FT*>(a.feat)) +
+                   t0 * a.ld_feat + a.col0 + dc;
     double* o = a.out + t0 * a.ld_out + a.ocol0 + dc;
     auto r1 = [&](int t) { return (t == 0 || t == T - 1) ? rvb : hrv1; };
     auto r2 = [&](int t) { return (t == 0 || t == T - 1) ? rvb : hrv2; };
@@ -391,10 +395,10 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
       for (int i = 0; i < RING_SEG + 2; ++i) {
         int r = j0 - 1 + i;
         if (!INNER) r = r < 0 ? 0 : (r < T ? r : T - 1);
-        const double* row = hf + (int64_t)r * a.ld_feat;
-        d1[i] = row[D];
-        d2[i] = row[2 * D];
-        if (i >= 1 && i <= RING_SEG) st[i - 1] = row[0];
+        const FT* row = hf + (int64_t)r * a.ld_feat;
+        d1[i] = (double)row[D];
+        d2[i] = (double)row[2 * D];
+        if (i >= 1 && i <= RING_SEG) st[i - 1] = (double)row[0];
       }
       while (q - ring_peek(prog) >= ring_segs) __builtin_amdgcn_s_sleep(2);      // the sweep has left segment q - ring_segs
       if (j0 >= RING_CAP && hd < D) {                   // the y of frames j0 - RING_CAP .. leave the ring
@@ -1617,11 +1621,22 @@ extern "C" int64_t itts_mlpg_scratch_bytes(int64_t t_total, int dim) {
   return 3 * t_total * (int64_t)dim * 8 + (t_total + 2) * 8 + ((int64_t)dim * 4 + 16) / 8 * 8 + 8;
 }
 
-extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int dim,
-                                    const double* d_var, const int64_t* h_offsets, int n_utts,
-                                    double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
-                                    void* stream) {
-  ITTS_REQUIRE(d_var && h_offsets && (n_utts == 0 || (d_feat && d_out && d_scratch)), "null pointer");
+// float32 rows -> the float64 columns col0 .. col0 + 3 dim - 1 in a compact array (for the solves that read doubles)
+__global__ void mlpg_widen_kernel(const float* __restrict__ src, int64_t ld, int col0, int cols, int64_t rows, double* __restrict__ dst) {
+  const int64_t n = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    dst[i] = (double)src[r * ld + col0 + (i - r * cols)];
+  }
+}
+
+// d_feat32 != nullptr: the input rows are float32 (d_feat unused); d_scratch then holds a [Ttot, 3 dim] float64
+// array behind the usual scratch, for the batches that do not take the one-pass kernel
+static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int64_t ld_feat, int col0, int dim,
+                                const double* d_var, const int64_t* h_offsets, int n_utts,
+                                double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
+                                void* stream) {
+  ITTS_REQUIRE(d_var && h_offsets && (n_utts == 0 || ((d_feat || d_feat32) && d_out && d_scratch)), "null pointer");
   ITTS_REQUIRE(dim > 0 && n_utts >= 0 && col0 >= 0 && ocol0 >= 0, "bad sizes");
   ITTS_REQUIRE(ld_feat >= col0 + 3 * (int64_t)dim && ld_out >= ocol0 + (int64_t)dim,
                "leading dimension too small");
@@ -1651,13 +1666,25 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   const char* force_stream = getenv("ITTS_MLPG_STREAM");
   const char* force_ring = getenv("ITTS_MLPG_RING");
   const bool ring = force_ring ? true : (force_stream ? false : (int64_t)n_utts * nblk >= MLPG_RING_FROM);
+  if (d_feat32 && !(t_max >= MLPG_SEQ_BELOW && ring)) {
+    // the other solves read doubles: widen the three column blocks once, behind the usual scratch
+    double* wide = reinterpret_cast<double*>(reinterpret_cast<char*>(d_scratch) + itts_mlpg_scratch_bytes(t_total, dim));
+    const int cols = 3 * dim;
+    hipLaunchKernelGGL(mlpg_widen_kernel, dim3((unsigned)std::min<int64_t>((t_total * cols + 255) / 256, 8192)), dim3(256), 0, s,
+                       d_feat32, ld_feat, col0, cols, t_total, wide);
+    ITTS_LAUNCH_CHECK();
+    a.feat = wide;
+    a.ld_feat = cols;
+    a.col0 = 0;
+  }
   if (t_max >= MLPG_SEQ_BELOW && !ring) return mlpg_stream_launch<16, 2, true>(a, h_offsets, n_utts, dim, t_max, s);
   if (t_max >= MLPG_SEQ_BELOW) {
     static std::atomic<uint64_t> attr_done{0};
     int dev = 0;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
       if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
     }
     std::vector<int> order(n_utts);
@@ -1676,8 +1703,9 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
     }
     const char* tab = static_cast<const char*>(table.p);
     a.offsets = reinterpret_cast<const int64_t*>(tab);
-    RingArgs g{a, reinterpret_cast<const int*>(tab + off_bytes), (int)t_max};
-    hipLaunchKernelGGL(mlpg_ring_kernel, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
+    RingArgs g{a, reinterpret_cast<const int*>(tab + off_bytes), (int)t_max, d_feat32};
+    if (d_feat32) hipLaunchKernelGGL(mlpg_ring_kernel<float>, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
+    else hipLaunchKernelGGL(mlpg_ring_kernel<double>, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
     const hipError_t launched = hipGetLastError();
     const int rc_table = itts::pinned_table_end(&table, s);
     if (launched != hipSuccess) {
@@ -1696,4 +1724,25 @@ extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int c
   hipLaunchKernelGGL(mlpg_kernel, grid, dim3(MLPG_LANES), 0, s, a, (int)t_max);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
+}
+
+extern "C" int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int dim,
+                                    const double* d_var, const int64_t* h_offsets, int n_utts,
+                                    double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
+                                    void* stream) {
+  ITTS_REQUIRE(n_utts == 0 || d_feat, "null pointer");
+  return mlpg_generation_impl(d_feat, nullptr, ld_feat, col0, dim, d_var, h_offsets, n_utts, d_out, ld_out, ocol0, d_scratch, stream);
+}
+
+extern "C" int64_t itts_mlpg_scratch_bytes_f32(int64_t t_total, int dim) {
+  if (t_total < 0 || dim <= 0) return 0;
+  return itts_mlpg_scratch_bytes(t_total, dim) + t_total * 3 * (int64_t)dim * 8;
+}
+
+extern "C" int itts_mlpg_generation_f32(const float* d_feat, int64_t ld_feat, int col0, int dim,
+                                        const double* d_var, const int64_t* h_offsets, int n_utts,
+                                        double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
+                                        void* stream) {
+  ITTS_REQUIRE(n_utts == 0 || d_feat, "null pointer");
+  return mlpg_generation_impl(nullptr, d_feat, ld_feat, col0, dim, d_var, h_offsets, n_utts, d_out, ld_out, ocol0, d_scratch, stream);
 }

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),
+    "itts_mlpg_scratch_bytes_f32": (c_int64, [c_int64, c_int]),
+    "itts_mlpg_generation_f32": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
+                                         c_int64, c_int, _P, _P]),
     "itts_lf0_vuv": (c_int, [_P, POINTER(c_int64), c_int, c_double, c_float, _P, _P, _P]),
     "itts_interpolate_lin_f32": (c_int, [_P, POINTER(c_int64), c_int, _P, _P, _P]),
     "itts_assemble_cmp_f32": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int64, c_int,

@@ -33,7 +33,7 @@ class MLPG(object):
     def generation_streams(self, matrices, streams, device=None):
         """Several MLPG problems on the SAME rows in one host -> device -> host round trip: `matrices` is a list of
         [T_u, C] arrays (the de-normalised network outputs of a batch of utterances), `streams` a list of
-        (first column, covariance [3 D, 3 D], D).  The rows go to the device once (in their own dtype; float64 there),
+        (first column, covariance [3 D, 3 D], D).  The rows go to the device once (in their own dtype; float32 stays float32, anything else becomes float64 there),
         every stream is one launch over all utterances reading its columns in place, all trajectories come back in
         one [sum T_u, sum D] copy.  Returns, per stream, the list of [T_u, D] float64 trajectories (views of that
         copy) -- what `generation_batch` returns for the stream's column block."""
@@ -44,7 +44,9 @@ class MLPG(object):
         for n in lengths:
             off.append(off[-1] + n)
         host = np.concatenate([np.asarray(m) for m in matrices], axis=0) if len(matrices) > 1 else np.asarray(matrices[0])
-        feats = torch.from_numpy(np.ascontiguousarray(host)).to(dev).double()
+        feats = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+        if feats.dtype != torch.float32:          # (float32 rows are widened in the solve's loads)
+            feats = feats.double()
         total = sum(int(d) for _, _, d in streams)
         out = torch.empty((off[-1], total), dtype=torch.float64, device=dev)
         o0 = 0

@@ -39,10 +39,12 @@ def _rows(t, name):
 
 # ---------------------------------------------------------------------------------------- MLPG
 def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0):
-    """Batched MLPG (misc/mlpg.py:94-127). feat [Ttot, >=col0+3*dim] f64, variances [3*dim] f64,
+    """Batched MLPG (misc/mlpg.py:94-127). feat [Ttot, >=col0+3*dim] f64 -- or f32, the acoustic model's own output
+    type: widened in the solve's loads, the result is that of the f64 rows --, variances [3*dim] f64,
     offsets: python list of U+1 frame offsets. Returns out [Ttot, dim] f64 (or writes into out)."""
     L = _lib.load()
-    _need(feat, torch.float64, "feat")
+    f32 = feat.dtype == torch.float32
+    _need(feat, torch.float32 if f32 else torch.float64, "feat")
     _need(variances, torch.float64, "variances")
     ld = _rows(feat, "feat")
     t_total = int(offsets[-1])
@@ -52,12 +54,13 @@ def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0):
         out = torch.empty((t_total, dim), dtype=torch.float64, device=feat.device)
     _need(out, torch.float64, "out")
     ldo = _rows(out, "out")
-    nbytes = L.itts_mlpg_scratch_bytes(t_total, dim)
+    nbytes = (L.itts_mlpg_scratch_bytes_f32 if f32 else L.itts_mlpg_scratch_bytes)(t_total, dim)
     scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=feat.device)
     offs = _lib.offsets_array(offsets)
-    _lib.check(L.itts_mlpg_generation(_ptr(feat), ld, col0, dim, _ptr(variances.contiguous()),
-                                      offs, len(offsets) - 1, _ptr(out), ldo, ocol0,
-                                      _ptr(scratch), _stream()), "itts_mlpg_generation")
+    entry = L.itts_mlpg_generation_f32 if f32 else L.itts_mlpg_generation
+    _lib.check(entry(_ptr(feat), ld, col0, dim, _ptr(variances.contiguous()),
+                     offs, len(offsets) - 1, _ptr(out), ldo, ocol0,
+                     _ptr(scratch), _stream()), "itts_mlpg_generation")
     return out
 
 

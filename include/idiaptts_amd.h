@@ -152,6 +152,14 @@ int itts_mlpg_generation(const double* d_feat, int64_t ld_feat, int col0, int di
                          const double* d_var, const int64_t* h_offsets, int n_utts,
                          double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
                          void* stream);
+/* The same with float32 input rows -- the type the acoustic model's output has where mlpg.py:119-121 assigns it
+ * into float64 arrays: the conversion happens in the solve's loads (exact), the result is that of
+ * itts_mlpg_generation on the widened rows.   d_scratch >= itts_mlpg_scratch_bytes_f32(Ttot, D) bytes. */
+int64_t itts_mlpg_scratch_bytes_f32(int64_t t_total, int dim);
+int itts_mlpg_generation_f32(const float* d_feat, int64_t ld_feat, int col0, int dim,
+                             const double* d_var, const int64_t* h_offsets, int n_utts,
+                             double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
+                             void* stream);
 
 /* ---- frame utilities (misc/utils.py:40-105) --------------------------------------------- */
 /* compute_deltas == np.gradient(x, axis=0) in float32 (utils.py:103-105): part of

@@ -130,3 +130,25 @@ def test_mlpg_more_than_64_dimensions_and_an_output_slice(gpu, solve):
         a, b = offsets[u], offsets[u + 1]
         ref = capi.mlpg(feat[a:b], var, dim)
         assert np.abs(got[a:b, 3:3 + dim] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("lengths,dim", [([300, 40, 1000], 62), ([250] * 130, 5), ([120, 60], 3)])
+def test_mlpg_float32_rows(gpu, solve, lengths, dim):
+    """float32 input rows (the acoustic model's output type; mlpg.py:119-121 assigns them into float64 arrays): the
+    result is that of the widened rows, whichever solve takes the batch -- the one-pass kernel converts in its loads,
+    the others read a widened copy."""
+    from idiaptts_amd import ops
+    from oracle import capi
+    rng = np.random.default_rng(17)
+    feat, var, offsets = _case(rng, lengths, dim, extra_cols=3, col0=2)
+    feat32 = feat.astype(np.float32)
+    wide = feat32.astype(np.float64)
+    got = ops.mlpg_generation(torch.from_numpy(feat32).to(gpu), torch.from_numpy(var).to(gpu), dim,
+                              offsets.tolist(), col0=2).cpu().numpy()
+    same = ops.mlpg_generation(torch.from_numpy(wide).to(gpu), torch.from_numpy(var).to(gpu), dim,
+                               offsets.tolist(), col0=2).cpu().numpy()
+    assert np.array_equal(got, same)
+    for u in (0, len(lengths) - 1):
+        a, b = offsets[u], offsets[u + 1]
+        ref = capi.mlpg(wide[a:b], var, dim, col0=2)
+        assert np.abs(got[a:b] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
