@@ -330,7 +330,8 @@ __device__ __forceinline__ void ring_post(int* w, int v) { __hip_atomic_store(w,
 __device__ __forceinline__ int ring_peek(const int* w) { return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // FT: the type of the input rows (double, or float: the network's own output type -- converted in the load, which is exact)
-template <typename FT>
+// WIDE: the helpers move two dimensions a lane and two rows an instruction (an even number of dimensions)
+template <typename FT, bool WIDE>
 __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   extern __shared__ __attribute__((aligned(16))) char rsm[];
   double* ring = reinterpret_cast<double*>(rsm);          // [RING_CAP][64]
@@ -428,9 +429,119 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
       ++mine;
       if (lane == 0) ring_post(prog + 1 + h, mine);          // (a wave's LDS operations execute in order: the segment is in the ring)
     };
+    // ---- the same with 16-byte accesses: a lane owns TWO dimensions (2 L, 2 L + 1 of the block; L = lane & 31) and a
+    // memory instruction covers two rows (lanes 0 .. 31 the even row of a pair, 32 .. 63 the odd one): half the
+    // memory instructions for the same bytes.  Pays where the instructions, not the bytes, are what the way forward
+    // waits for: float32 rows at many rounds of workgroups (the host chooses; see the launch).  The rows a frame needs
+    // from the other half of the wave -- its neighbours -- come over with v_permlane32_swap.
+    typedef double V2d __attribute__((ext_vector_type(2), aligned(8)));       // (rows are 8-byte aligned, not 16)
+    typedef FT V2f __attribute__((ext_vector_type(2), aligned(sizeof(FT))));
+    const int wh = lane >> 5, wl = lane & 31;
+    const int wd0 = blk * RING_LANES + 2 * wl;                   // this lane's dimensions wd0, wd0 + 1 (D even: both live or neither)
+    const bool wlive = wd0 < D;
+    const int wdc = wlive ? wd0 : 0;
+    V2d wrv0, wrv1, wrv2;
+    const FT* whf = nullptr;
+    double* wo = nullptr;
+    if constexpr (WIDE) {
+      wrv0 = V2d{1.0 / a.var[wdc], 1.0 / a.var[wdc + 1]};
+      wrv1 = V2d{1.0 / a.var[D + wdc], 1.0 / a.var[D + wdc + 1]};
+      wrv2 = V2d{1.0 / a.var[2 * D + wdc], 1.0 / a.var[2 * D + wdc + 1]};
+      whf = (std::is_same<FT, float>::value ? reinterpret_cast<const FT*>(g.feat32) : reinterpret_cast<const FT*>(a.feat)) +
+            t0 * a.ld_feat + a.col0 + wdc;
+      wo = a.out + t0 * a.ld_out + a.ocol0 + wdc;
+    }
+    auto widen = [](V2f v) { return V2d{(double)v.x, (double)v.y}; };
+    // the other half's value of x in this lane (lanes < 32 get what lanes >= 32 hold and the other way round), as the
+    // pair (lower half's view, upper half's view) the selections below pick from
+    auto swap1 = [](double x, double& from_upper, double& from_lower) {
+      const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+      const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      // r[0]: lanes 32 .. 63 now hold the lower half's values; r[1]: lanes 0 .. 31 hold the upper half's
+      from_lower = __hiloint2double((int)rh[0], (int)rl[0]);
+      from_upper = __hiloint2double((int)rh[1], (int)rl[1]);
+    };
+    auto swap_halves = [&](V2d x, V2d& from_upper, V2d& from_lower) {
+      double ux, uy, lx, ly;
+      swap1(x.x, ux, lx);
+      swap1(x.y, uy, ly);
+      from_upper = V2d{ux, uy};
+      from_lower = V2d{lx, ly};
+    };
+    auto forward_segment_wide = [&](int q, auto inner_tag) {
+      constexpr bool INNER = decltype(inner_tag)::value;
+      constexpr int NP = RING_SEG / 2;                 // row pairs of the segment: pair p = rows j0 + 2 p - 2, j0 + 2 p - 1
+      const int j0 = q * RING_SEG;
+      double* base = ring + seg_slot(q) * RING_LANES + 2 * wl;
+      V2d st[NP], d1[NP + 2], d2[NP + 2];
+#pragma unroll
+      for (int p = 0; p < NP + 2; ++p) {
+        int r = j0 - 2 + 2 * p + wh;
+        if (!INNER) r = r < 0 ? 0 : (r < T ? r : T - 1);
+        const FT* row = whf + (int64_t)r * a.ld_feat;
+        d1[p] = widen(*reinterpret_cast<const V2f*>(row + D));
+        d2[p] = widen(*reinterpret_cast<const V2f*>(row + 2 * D));
+        if (p >= 1 && p <= NP) st[p - 1] = widen(*reinterpret_cast<const V2f*>(row));
+      }
+      while (q - ring_peek(prog) >= ring_segs) __builtin_amdgcn_s_sleep(2);      // the sweep has left segment q - ring_segs
+      if (j0 >= RING_CAP && wlive) {                   // the y of frames j0 - RING_CAP .. leave the ring
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int i = 2 * k + wh;
+          if (INNER || j0 + i < T)
+            *reinterpret_cast<V2d*>(wo + (int64_t)(j0 + i - RING_CAP) * a.ld_out) = *reinterpret_cast<const V2d*>(base + i * RING_LANES);
+        }
+      }
+      // u[p] (delta: u1, delta-delta: u2): the entries of row j0 + 2 p - 3 + wh -- for the frame of pair p in this lane
+      // (row j0 + 2 p - 2 + wh) the row before it, for the frame of pair p - 1 the row after it.  Formed pair by pair
+      // and used at once (all of them held would be 112 registers): frame k = p - 2 wants u[p - 1] and u[p].
+      V2d up1 = V2d{0.0, 0.0}, up2 = up1;              // pair p - 1 as the lower half sees the upper one (its odd row)
+      V2d uq1 = up1, uq2 = up1;                        // u[p - 1]
+#pragma unroll
+      for (int p = 0; p < NP + 2; ++p) {
+        V2d fu1, fl1, fu2, fl2;
+        swap_halves(d1[p], fu1, fl1);
+        swap_halves(d2[p], fu2, fl2);
+        const V2d uc1 = wh ? fl1 : up1, uc2 = wh ? fl2 : up2;      // u[p] (p >= 1)
+        up1 = fu1;
+        up2 = fu2;
+        if (p >= 2) {
+          const int k = p - 2, i = 2 * k + wh, j = j0 + i;
+          if (INNER || j < T) {
+            V2d bj;
+            if (INNER) {
+              const V2d c0 = st[k] * wrv0, c2 = d2[k + 1] * wrv2;
+              const V2d p1 = uq1 * wrv1, p2 = uq2 * wrv2;
+              const V2d n1 = uc1 * wrv1, n2 = uc2 * wrv2;
+              bj = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
+            } else {
+              const V2d zero = V2d{0.0, 0.0}, edge = V2d{rvb, rvb};
+              auto e1 = [&](int t) { return (t == 0 || t == T - 1) ? edge : wrv1; };
+              auto e2 = [&](int t) { return (t == 0 || t == T - 1) ? edge : wrv2; };
+              const V2d c0 = st[k] * wrv0, c2 = d2[k + 1] * e2(j);
+              const V2d p1 = j > 0 ? uq1 * e1(j - 1) : zero, p2 = j > 0 ? uq2 * e2(j - 1) : zero;
+              const V2d n1 = j + 1 < T ? uc1 * e1(j + 1) : zero, n2 = j + 1 < T ? uc2 * e2(j + 1) : zero;
+              bj = c0 + 0.5 * (p1 - n1) + (p2 - 2.0 * c2 + n2);
+            }
+            *reinterpret_cast<V2d*>(base + i * RING_LANES) = wlive ? bj : V2d{0.0, 0.0};
+          }
+        }
+        uq1 = uc1;
+        uq2 = uc2;
+      }
+      ++mine;
+      if (lane == 0) ring_post(prog + 1 + h, mine);
+    };
     for (int q = h; q < nseg; q += RING_HELPERS) {
-      if (q >= 1 && q * RING_SEG + RING_SEG <= T - 2) forward_segment(q, std::true_type{});
-      else forward_segment(q, std::false_type{});
+      const bool inner = q >= 1 && q * RING_SEG + RING_SEG <= T - 2;
+      if constexpr (WIDE) {
+        if (inner) forward_segment_wide(q, std::true_type{});
+        else forward_segment_wide(q, std::false_type{});
+      } else {
+        if (inner) forward_segment(q, std::true_type{});
+        else forward_segment(q, std::false_type{});
+      }
     }
     // ---- backward: x of a finished segment out, then the y of a ring's length further down back into its slots
     int fetched = 0;
@@ -478,6 +589,33 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
       const int qf = q - ring_segs;          // its frames went out on the way forward iff frame + RING_CAP < T
       // (the bytes read here were written in the forward phase, before prog[8] was posted -- no later store of this
       // workgroup touches them before this load -- so the loads need not wait for the sweep either)
+      if constexpr (WIDE) {
+        constexpr int NP = RING_SEG / 2;
+        double* wbase = ring + seg_slot(q) * RING_LANES + 2 * wl;
+        V2d yw[NP];
+        if (qf >= 0 && wlive) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const int j = qf * RING_SEG + 2 * k + wh;
+            yw[k] = (j + RING_CAP < T) ? *reinterpret_cast<const V2d*>(wo + (int64_t)j * a.ld_out) : V2d{0.0, 0.0};
+          }
+        }
+        while (ring_peek(prog + 16) > q) __builtin_amdgcn_s_sleep(2);     // the backward sweep has finished segment q
+        if (wlive) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const int i = 2 * k + wh;
+            if (j0 + i < T) *reinterpret_cast<V2d*>(wo + (int64_t)(j0 + i) * a.ld_out) = *reinterpret_cast<const V2d*>(wbase + i * RING_LANES);
+          }
+          if (qf >= 0) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              const int i = 2 * k + wh;
+              if (qf * RING_SEG + i + RING_CAP < T) *reinterpret_cast<V2d*>(wbase + i * RING_LANES) = yw[k];
+            }
+          }
+        }
+      } else {
       double yv[RING_SEG];
       if (qf >= 0 && hd < D) {
 #pragma unroll
@@ -498,6 +636,7 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
             if (j + RING_CAP < T) base[k * RING_LANES] = yv[k];
           }
         }
+      }
       }
       ++fetched;
       if (lane == 0) ring_post(prog + 9 + h, fetched);
@@ -1683,8 +1822,10 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
     int dev = 0;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
       if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
     }
     std::vector<int> order(n_utts);
@@ -1704,8 +1845,17 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
     const char* tab = static_cast<const char*>(table.p);
     a.offsets = reinterpret_cast<const int64_t*>(tab);
     RingArgs g{a, reinterpret_cast<const int*>(tab + off_bytes), (int)t_max, d_feat32};
-    if (d_feat32) hipLaunchKernelGGL(mlpg_ring_kernel<float>, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
-    else hipLaunchKernelGGL(mlpg_ring_kernel<double>, dim3((unsigned)nblk, (unsigned)n_utts), dim3(RING_THREADS), RING_LDS_BYTES, s, g);
+    // two dimensions a lane in the helpers (half the memory instructions) where that is what the kernel waits for: float32
+    // rows in batches of many rounds of workgroups -- 4 096 utterances 2.68 against 3.23 ms.  With float64 rows the
+    // kernel moves 3.8 - 4.1 TB/s either way (3.62 / 3.61 ms), and at 256 utterances the exchange's extra arithmetic
+    // costs 3 - 5 % (317 / 301 us; float32 231 / 223).  ITTS_MLPG_WIDE=1 / ITTS_MLPG_NARROW=1 force one (even dim only).
+    const bool wide = dim % 2 == 0 && !getenv("ITTS_MLPG_NARROW") &&
+                      (getenv("ITTS_MLPG_WIDE") || (d_feat32 && (int64_t)n_utts * nblk >= 1024));
+    const dim3 rgrid((unsigned)nblk, (unsigned)n_utts), rblock(RING_THREADS);
+    if (d_feat32 && wide) hipLaunchKernelGGL((mlpg_ring_kernel<float, true>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else if (d_feat32) hipLaunchKernelGGL((mlpg_ring_kernel<float, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else if (wide) hipLaunchKernelGGL((mlpg_ring_kernel<double, true>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else hipLaunchKernelGGL((mlpg_ring_kernel<double, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
     const hipError_t launched = hipGetLastError();
     const int rc_table = itts::pinned_table_end(&table, s);
     if (launched != hipSuccess) {

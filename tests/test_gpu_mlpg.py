@@ -152,3 +152,25 @@ def test_mlpg_float32_rows(gpu, solve, lengths, dim):
         a, b = offsets[u], offsets[u + 1]
         ref = capi.mlpg(wide[a:b], var, dim, col0=2)
         assert np.abs(got[a:b] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_mlpg_wide_helpers(gpu, monkeypatch, dtype):
+    """The one-pass kernel's helpers with two dimensions a lane and two rows a memory instruction (the library takes
+    them for float32 rows from 1 024 units; forced here): the same values as with one dimension a lane, bit for bit,
+    on lengths around the segment / ring boundaries, 62 and 70 dimensions (one and two blocks), column offsets that
+    leave the rows 8- but not 16-byte aligned."""
+    from idiaptts_amd import ops
+    rng = np.random.default_rng(29)
+    for lengths, dim, col0 in (([700, 25, 24, 289, 1, 2, 600, 313], 62, 1), ([400, 333], 70, 0), ([2100], 2, 3)):
+        feat, var, offsets = _case(rng, lengths, dim, extra_cols=1, col0=col0)
+        feat = feat.astype(dtype)
+        f, v = torch.from_numpy(feat).to(gpu), torch.from_numpy(var).to(gpu)
+        monkeypatch.setenv("ITTS_MLPG_RING", "1")
+        monkeypatch.setenv("ITTS_MLPG_NARROW", "1")
+        narrow = ops.mlpg_generation(f, v, dim, offsets.tolist(), col0=col0).cpu().numpy()
+        monkeypatch.delenv("ITTS_MLPG_NARROW")
+        monkeypatch.setenv("ITTS_MLPG_WIDE", "1")
+        wide = ops.mlpg_generation(f, v, dim, offsets.tolist(), col0=col0).cpu().numpy()
+        monkeypatch.delenv("ITTS_MLPG_WIDE")
+        assert np.array_equal(narrow, wide), (lengths, dim)
