@@ -815,7 +815,13 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
         out["files_GB"] = float(lengths.sum()) * (425 + 187) * 4 / 1e9
         out["files_written_s"] = time.perf_counter() - t0
         logging.getLogger().setLevel(logging.WARNING)
-        for key, resident in (("module_path", False), ("resident_dataset", True)):
+        # module path twice: hparams.dataset_num_workers_gpu = 4 as the reference's default (reader threads here:
+        # hparams.dataset_worker_kind; torch's forked workers took 6.5 s an epoch on this stack), and no workers
+        only = os.environ.get("ITTS_TRAINER_EPOCH_ONLY")          # (scripts/prof_trainer_epoch.py)
+        for key, resident, workers in (("module_path", False, 4), ("module_path_no_workers", False, 0),
+                                       ("resident_dataset", True, 0)):
+            if only and key != only:
+                continue
             hp = AcousticModelTrainer.create_hparams()
             hp.num_questions = 425
             hp.voice = "full"
@@ -825,7 +831,7 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
             hp.seed = 1
             hp.epochs = 2
             hp.use_gpu = True
-            hp.dataset_num_workers_gpu = 0
+            hp.dataset_num_workers_gpu = workers
             hp.model_type = "RNNDYN-2_TANH_512-1_FC_187"
             hp.batch_size_train = batch_utts
             hp.batch_size_val = n_val
@@ -859,6 +865,7 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
             total = time.perf_counter() - t0
             frames = int(sum(lengths[ids.index(i)] for i in trainer.id_list_train))
             out[key] = {"train_utterances": len(trainer.id_list_train), "train_frames": frames,
+                        "dataloader_workers": workers,
                         "epoch_s": epochs[-1], "epoch_s_all": [round(e, 4) for e in epochs],
                         "valid_frames_per_s": frames / epochs[-1],
                         "train_call_s": total,

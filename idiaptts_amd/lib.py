@@ -50,6 +50,7 @@ _SIGNATURES = {
     "itts_labels_count_frames": (c_int, [POINTER(c_char_p), c_int, POINTER(c_int64), c_int]),
     "itts_labels_generate": (c_int, [c_void_p, POINTER(c_char_p), c_int, POINTER(c_int64), _P,
                                      c_int64, c_int]),
+    "itts_normalise_rows_f32": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "itts_mlpg_scratch_bytes": (c_int64, [c_int64, c_int]),
     "itts_mlpg_generation": (c_int, [_P, c_int64, c_int, c_int, _P, POINTER(c_int64), c_int, _P,
                                      c_int64, c_int, _P, _P]),
@@ -167,6 +168,29 @@ def offsets_array(offsets):
     if arr.ndim != 1:
         raise ValueError("offsets must be one-dimensional")
     return (c_int64 * arr.shape[0]).from_buffer(arr)
+
+
+def normalise_rows(sample, sub, div):
+    """`((sample - sub) / div).astype(np.float32)` for the data readers' `preprocess_sample`: a float32 [rows, cols]
+    sample with float64 per-column parameters goes through one pass of native code (itts_normalise_rows_f32: the same
+    bits, without the float64 temporaries); anything else through numpy as written."""
+    import numpy as np
+    sub, div = np.asarray(sub), np.asarray(div)
+    if (isinstance(sample, np.ndarray) and sample.dtype == np.float32 and sample.ndim == 2
+            and sample.flags.c_contiguous and sub.dtype == np.float64 and div.dtype == np.float64
+            and sub.shape == (sample.shape[1],) and div.shape == (sample.shape[1],)):
+        try:
+            L = load()
+        except Exception:                        # library not built (documentation builds, linting): numpy
+            L = None
+        if L is not None:
+            sub, div = np.ascontiguousarray(sub), np.ascontiguousarray(div)
+            out = np.empty_like(sample)
+            check(L.itts_normalise_rows_f32(sample.ctypes.data, sample.shape[0], sample.shape[1],
+                                            sub.ctypes.data, div.ctypes.data, out.ctypes.data),
+                  "itts_normalise_rows_f32")
+            return out
+    return ((sample - sub) / div).astype(np.float32, copy=False)
 
 
 def current_stream():

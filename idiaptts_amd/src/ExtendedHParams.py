@@ -94,7 +94,7 @@ class ExtendedHParams(object):
             num_gpus=1, batch_first=False, shuffle_train_set=True, shuffle_val_set=False,
             batch_size_train=1, batch_size_test=48, batch_size_val=48, batch_size_benchmark=48,
             batch_size_synth=48, batch_size_gen_figure=48,
-            dataset_type="PyTorchDatareadersDataset", dataset_num_workers_gpu=4,
+            dataset_type="PyTorchDatareadersDataset", dataset_num_workers_gpu=4, dataset_worker_kind="thread",
             dataset_num_workers_cpu=0, dataset_pin_memory=True, dataset_load_async=True,
             teacher_forcing_in_test=False, preload_next_batch_to_gpu=False,
             # not in the reference: keep the (normalised, length matched) training data resident in

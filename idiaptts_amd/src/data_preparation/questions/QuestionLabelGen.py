@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 
+from idiaptts_amd import lib as _lib
 from idiaptts_amd.src.data_preparation.DataReaders import ReaderBase
 
 
@@ -63,7 +64,7 @@ class QuestionLabelGen(ReaderBase):
 
     def preprocess_sample(self, sample, norm_params=None):
         min_, max_ = self.norm_params if norm_params is None else norm_params
-        return ((sample - min_) / self._range(min_, max_)).astype(np.float32, copy=False)
+        return _lib.normalise_rows(sample, min_, self._range(min_, max_))
 
     def postprocess_sample(self, sample, norm_params=None):
         min_, max_ = self.norm_params if norm_params is None else norm_params

@@ -19,6 +19,7 @@ from typing import List, Union
 
 import numpy as np
 
+from .... import lib as _lib
 from .... import parallel as _parallel
 from .... import world as _world
 from ....misc.mlpg import MLPG
@@ -716,7 +717,7 @@ class WorldFeatLabelGen(ReaderBase):
     def preprocess_sample(self, sample, norm_params=None):
         """(x - mean) / std_dev, float32 (NpzDataReader.preprocess_sample :347-371)."""
         mean, std_dev = self.norm_params if norm_params is None else norm_params
-        return ((sample - mean) / std_dev).astype(np.float32, copy=False)
+        return _lib.normalise_rows(sample, mean, std_dev)
 
     def postprocess_sample(self, sample, norm_params=None, apply_mlpg=None):
         """De-normalise, then MLPG per stream (reference :338-355 / NpzDataReader :399-420)."""

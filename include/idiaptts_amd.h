@@ -117,6 +117,12 @@ int itts_write_feature_archives(const float* h_feat, int64_t ld, const int64_t* 
                                 const int* h_width, const int* h_parts, const char* const* h_keys,
                                 int n_threads, unsigned char* h_needs_merge);
 
+/* Per-item normalisation of the data readers (NpzDataReader.preprocess_sample :347-371): h_out[r][c] =
+ * (float)(((double)h_x[r][c] - h_sub[c]) / h_div[c]) -- numpy's `((x - sub) / div).astype(float32)` for float32 x and
+ * float64 parameters, bit for bit, in one pass.  Host memory, no GPU. */
+int itts_normalise_rows_f32(const float* h_x, int64_t rows, int cols, const double* h_sub,
+                            const double* h_div, float* h_out);
+
 /* ---- question labels (host, no GPU; csrc/labels.cpp) ------------------------------------------------
  * HTSLabelNormalisation (src/data_preparation/questions/label_normalisation.py): question-set
  * loading :817-897 (patterns compiled once per question), pattern matching :753-791,
