@@ -819,7 +819,7 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
         # hparams.dataset_worker_kind; torch's forked workers took 6.5 s an epoch on this stack), and no workers
         only = os.environ.get("ITTS_TRAINER_EPOCH_ONLY")          # (scripts/prof_trainer_epoch.py)
         for key, resident, workers in (("module_path", False, 4), ("module_path_no_workers", False, 0),
-                                       ("resident_dataset", True, 0)):
+                                       ("resident_dataset", True, 4)):
             if only and key != only:
                 continue
             hp = AcousticModelTrainer.create_hparams()

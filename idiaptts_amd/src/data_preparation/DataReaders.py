@@ -135,6 +135,14 @@ class ReaderBase(object):
             items = [self.pad(i, chunk_padding(i, self.chunk_size)) for i in items]
         out = dict(zip(self.output_names, items))
         out["_id_list"] = id_name
+        if id_name not in self._length_cache:
+            # what get_length would work out from this very item: the dataset asks for the length of every reader it
+            # matches another one to right after loading both, and used to load each of them a second time for it
+            c = self.chunk_size
+            try:
+                self._length_cache[id_name] = ((max(len(v) for v in items) + c - 1) // c) * c
+            except TypeError:        # an output without a length: get_length will say so if it is ever asked
+                pass
         return out
 
     def get_length(self, id_name):

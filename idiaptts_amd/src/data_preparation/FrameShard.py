@@ -41,13 +41,20 @@ class FrameShard(object):
 
     # ------------------------------------------------------------------------------ building
     @staticmethod
-    def from_dataset(dataset, input_name, target_name, meta=None):
+    def from_dataset(dataset, input_name, target_name, meta=None, threads=0):
         """Runs the data readers once per id (load, normalise, symmetric length matching: exactly
         what a training step would have seen, PyTorchDatareadersDataset.get_id_name) and packs the
-        results."""
+        results.  threads > 0: the items are read by that many threads (order kept; only for datasets whose
+        items draw no random numbers -- the caller's business, as in ModularModelHandlerPyTorch._get_dataloader)."""
         xs, ys = [], []
+        if threads > 0 and len(dataset) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=int(threads), thread_name_prefix="itts_shard") as pool:
+                items = list(pool.map(dataset.__getitem__, range(len(dataset))))
+        else:
+            items = None
         for i in range(len(dataset)):
-            item, _ = dataset[i]
+            item, _ = items[i] if items is not None else dataset[i]
             xi, yi = item[input_name], item[target_name]
             if len(xi) != len(yi):
                 raise ValueError("{}: {} and {} differ in length ({} vs {}); give the readers a "

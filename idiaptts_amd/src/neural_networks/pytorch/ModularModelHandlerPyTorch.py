@@ -620,7 +620,10 @@ class ModularModelHandlerPyTorch(object):
             if ds is None:
                 continue
             target = self._resident_target_name(ds, in_name)
-            shards[key] = FrameShard.from_dataset(ds, in_name, target).to(device)
+            threads = hparams.dataset_num_workers_gpu \
+                if hparams.get_value("dataset_worker_kind", "thread") == "thread" \
+                and not self._items_draw_random_numbers(ds) else 0
+            shards[key] = FrameShard.from_dataset(ds, in_name, target, threads=threads).to(device)
         common = dict(num_workers=0, collate_fn=list, pin_memory=False)
         self.dataloader_train = DataLoader(self._IndexDataset(len(shards["train"])),
                                            batch_size=hparams.batch_size_train,
