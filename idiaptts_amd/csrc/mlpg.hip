@@ -1804,7 +1804,8 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
   const int nblk = (dim + RING_LANES - 1) / RING_LANES;
   const char* force_stream = getenv("ITTS_MLPG_STREAM");
   const char* force_ring = getenv("ITTS_MLPG_RING");
-  const bool ring = force_ring ? true : (force_stream ? false : (int64_t)n_utts * nblk >= MLPG_RING_FROM);
+  const bool ring = n_utts <= 65535 &&          // (an utterance per blockIdx.y)
+                    (force_ring ? true : (force_stream ? false : (int64_t)n_utts * nblk >= MLPG_RING_FROM));
   if (d_feat32 && !(t_max >= MLPG_SEQ_BELOW && ring)) {
     // the other solves read doubles: widen the three column blocks once, behind the usual scratch
     double* wide = reinterpret_cast<double*>(reinterpret_cast<char*>(d_scratch) + itts_mlpg_scratch_bytes(t_total, dim));
