@@ -10,6 +10,13 @@ from torch import nn
 from idiaptts_amd import ops
 
 
+
+def _total(lengths):
+    """float(sum(lengths)) -- on a tensor without walking it element by element through Python."""
+    import torch
+    return float(lengths.sum()) if torch.is_tensor(lengths) else float(sum(lengths))
+
+
 class MaskedMSEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, row_valid, n_valid):
@@ -111,7 +118,7 @@ class NamedLoss(nn.Module):
         else:
             w = data_mask = torch.ones(lead, dtype=torch.float32, device=a.device)
         if self.reduction == "mean_per_frame":
-            w = data_mask / (float(sum(length_dict[self.seq_mask])) * D)
+            w = data_mask / (_total(length_dict[self.seq_mask]) * D)
         elif self.reduction == "mean_per_sample":
             lens = torch.as_tensor(length_dict[self.seq_mask], dtype=torch.float32, device=a.device)
             batch_dim = 0 if self.batch_first else 1
@@ -128,7 +135,7 @@ class NamedLoss(nn.Module):
         if self.kind == 0 and self.reduction == "mean_per_frame":
             mask = data[self.seq_mask]                   # [.., .., 1] float, 1 inside the sequence
             row_valid = (mask.reshape(-1) > 0).to(torch.uint8)
-            total_num_frames = float(sum(length_dict[self.seq_mask]))
+            total_num_frames = _total(length_dict[self.seq_mask])
             # MSE is symmetric: differentiate through whichever input needs it
             if b.requires_grad or not a.requires_grad:
                 loss = MaskedMSEFunction.apply(b, a.detach(), row_valid, total_num_frames)
