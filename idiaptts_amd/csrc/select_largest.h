@@ -43,38 +43,82 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
   return fmax(fmax(lane_value64(v, 0), lane_value64(v, 16)), fmax(lane_value64(v, 32), lane_value64(v, 48)));
 }
 
-// mine[0 .. cnt): this thread's bins, sorted descending (fillers -1 behind them).  lists: 4 R doubles of
+// uniform lane index -> that lane's value
+__device__ __forceinline__ double lane_value64u(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// mine[0 .. cnt): this thread's bins, sorted descending (fillers -1 behind them).  lists: 4 R + 4 doubles of
 // LDS nobody else uses until the call returns; red: >= 4 doubles.  Returns the sum in every thread.
+//
+// Round 5: a wave no longer pops its largest bins ONE a round.  Every head that is larger than every lane's
+// SECOND bin is larger than everything that is not a head, so all such heads are the wave's next largest at
+// once: one round takes them all, ranks them among themselves (a loop over the set lanes of the ballot) and
+// appends them to the list in order.  A band's large bins are neighbours in frequency -- one to a lane -- so
+// its 22 (16 kHz) or 65 (48 kHz) largest go in one or two rounds per wave instead of 22 or 65; when no head
+// is strictly larger than the largest second bin (ties, or a lane that owns two of the largest) the round
+// pops one bin as before.  Waves now hold lists of different lengths (counts behind the lists).
 template <int MPER>
 __device__ __forceinline__ double d4c_rest_without_largest(const double (&mine)[MPER], int cnt, int R, double* lists,
                                                            double* red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double* own = lists + wv * R;
-  // 1. + 2.  For large R in batches of about R / 3 rounds: a wave whose list is not admitted whole has
+  int* counts = reinterpret_cast<int*>(lists + 4 * R);      // entries in each wave's list
+  // 1. + 2.  For large R in steps of about R / 3 entries: a wave whose list is not admitted whole has
   // nothing further to offer (its next bins are no larger, the lists only grow), so the rounds stop as
-  // soon as that holds for all four -- after R / 3 or 2 R / 3 rounds for all but freak spectra.  (Each
-  // batch pays a barrier and a pass of binary searches: below 32 rounds one batch is faster --
-  // d4c_kernel at 16 kHz, R = 22: 8.86 against 9.00 ms; at 48 kHz, R = 65: 39.4 against 37.1 ms.)
+  // soon as that holds for all four -- after R / 3 or 2 R / 3 entries for all but freak spectra.
   const int batch = R <= 32 ? R : (R + 2) / 3;
-  int popped = 0, K = 0, n_w = 0;
+  int popped = 0, K = 0, n_w = 0, target = 0;
   double head = mine[0];                       // -1 when the thread has no bin
   for (;;) {
-    const int K1 = K + batch < R ? K + batch : R;
-    for (int round = K; round < K1; ++round) {
-      const double m = wave_max_dpp(head);
-      const unsigned long long who = __ballot(head == m && popped < cnt);
-      if (who != 0ull && lane == __ffsll((long long)who) - 1) {
-        ++popped;
-        head = -1.0;
+    target = target + batch < R ? target + batch : R;
+    while (K < target) {
+      if (__ballot(popped < cnt) == 0ull) break;             // the wave has nothing left
+      double second = -1.0;
 #pragma unroll
-        for (int i = 1; i < MPER; ++i)
-          if (i == popped && i < cnt) head = mine[i];
+      for (int i = 1; i < MPER; ++i)
+        if (i == popped + 1 && i < cnt) second = mine[i];
+      const double m2 = wave_max_dpp(second);
+      const bool cand = popped < cnt && head > m2;
+      const unsigned long long mask = __ballot(cand);
+      if (mask == 0ull) {
+        // the largest head ties with a second bin: one bin this round
+        const double m = wave_max_dpp(head);
+        const unsigned long long who = __ballot(head == m && popped < cnt);
+        if (lane == __ffsll((long long)who) - 1) {
+          ++popped;
+          head = -1.0;
+#pragma unroll
+          for (int i = 1; i < MPER; ++i)
+            if (i == popped && i < cnt) head = mine[i];
+        }
+        if (lane == 0) own[K] = m;
+        K += 1;
+      } else {
+        int rank = 0;
+        for (unsigned long long mm = mask; mm != 0ull; mm &= mm - 1ull) {
+          const int bl = __ffsll((long long)mm) - 1;
+          const double hb = lane_value64u(head, bl);
+          rank += (hb > head || (hb == head && bl < lane)) ? 1 : 0;
+        }
+        if (cand) {
+          if (K + rank < R) own[K + rank] = head;
+          ++popped;
+          head = -1.0;
+#pragma unroll
+          for (int i = 1; i < MPER; ++i)
+            if (i == popped && i < cnt) head = mine[i];
+        }
+        const int n = __popcll(mask);
+        K = K + n < R ? K + n : R;
       }
-      if (lane == 0) own[round] = who != 0ull ? m : -1.0;
     }
-    K = K1;
+    if (lane == 0) counts[wv] = K;
     __syncthreads();
-    // how many of this wave's K entries are among the R largest of the 4 K
+    // how many of this wave's K entries are among the R largest of all the lists
     n_w = 0;
     for (int r0 = 0; r0 < K; r0 += 64) {
       const int r = r0 + lane;
@@ -86,11 +130,12 @@ __device__ __forceinline__ double d4c_rest_without_largest(const double (&mine)[
         for (int o = 1; o < 4; ++o) {
           const int w2 = (wv + o) & 3;
           const double* other = lists + w2 * R;
-          int lo = 0, hi = K;
+          const int Ko = counts[w2];
+          int lo = 0, hi = Ko;
 #pragma unroll
-          for (int it = 0; it < 7; ++it) {             // K <= R <= 66 < 128
+          for (int it = 0; it < 7; ++it) {             // Ko <= R <= 66 < 128
             const int mid = (lo + hi) >> 1;
-            const double e = other[mid < K ? mid : K - 1];
+            const double e = Ko > 0 ? other[mid < Ko ? mid : Ko - 1] : -1.0;
             const bool ahead = e > c || (e == c && w2 < wv);
             if (lo < hi) {
               if (ahead) lo = mid + 1; else hi = mid;
@@ -102,8 +147,10 @@ __device__ __forceinline__ double d4c_rest_without_largest(const double (&mine)[
       }
       n_w += __popcll(__ballot(in_cut));
     }
-    if (K == R) break;
-    if (!__syncthreads_or(n_w == K)) break;      // (also: every wave has read the lists before the next batch extends them)
+    if (target == R) break;
+    // a wave whose list went in whole and that has more to offer must go on
+    const bool more = n_w == K && K < R && __ballot(popped < cnt) != 0ull;
+    if (!__syncthreads_or(more)) break;      // (also: every wave has read the lists before the next batch extends them)
   }
   // 3. this wave's bins outside the cut
   const double v_last = n_w > 0 ? own[n_w - 1] : 0.0;
