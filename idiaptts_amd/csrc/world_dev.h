@@ -128,7 +128,8 @@ __device__ __forceinline__ int fft_phys(int i) {
   return i ^ (((i >> 4) ^ (int)(__brev((unsigned)(i >> 6)) >> 28)) & 15);
 }
 
-constexpr int FFT_SWZ_MAX = 4 * NT;  // largest transform whose first pass is one butterfly per thread
+constexpr int FFT_PAIR_MAX = 4 * NT;  // largest transform whose first pass is one butterfly per thread (fft_lds_pair)
+constexpr int FFT_SWZ_MAX = 8 * NT;   // .. two per thread: the swizzled layout up to 2 048 complex points (the 4 096-point real transforms of D4C at 48 kHz)
 
 // In-place complex FFT of z[0..n) (n = 2^logn <= tw_n). tw holds exp(+2 pi i k / tw_n).
 // sign = -1: forward (e^{-i..}), +1: unnormalised inverse. Ends with a barrier.  Input and output
@@ -165,30 +166,40 @@ __device__ inline void fft_lds(double2* z, int n_rt, int logn_rt, const double2*
     // consecutive-lane (conflict-free) addresses and, after everyone has read, stores the results
     // at the swizzled positions of 4 t + {0, 1, 2, 3}.  Same butterflies and twiddle entries as the
     // generic pass below with h = 1.
-    const int u = tid();
-    const bool on = u < n / 4;
-    double2 z0, z1, z2, z3;
-    if (on) {
-      z0 = z[u];
-      z1 = z[u + n / 2];
-      z2 = z[u + n / 4];
-      z3 = z[u + n / 2 + n / 4];
+    // (one butterfly per thread up to 4 NT points, two from there to 8 NT: everything is read before anything is
+    // written)
+    constexpr int FIRST = FFT_SWZ_MAX / (4 * NT);
+    double2 f0[FIRST], f1[FIRST], f2[FIRST], f3[FIRST];
+#pragma unroll
+    for (int rep = 0; rep < FIRST; ++rep) {
+      const int u = tid() + rep * NT;
+      if (u < n / 4) {
+        f0[rep] = z[u];
+        f1[rep] = z[u + n / 2];
+        f2[rep] = z[u + n / 4];
+        f3[rep] = z[u + n / 2 + n / 4];
+      }
     }
     __syncthreads();
-    if (on) {
-      const int a0 = 4 * (int)(__brev((unsigned)u) >> (32 - (logn - 2)));
-      const double2 w1 = tw[0];
-      const double2 w2 = tw[0];
-      const double2 w3 = tw[1 << (tshift - 1)];
-      const double2 x1 = twmul(z1, w1), x3 = twmul(z3, w1);
-      const double2 y0 = make_double2(z0.x + x1.x, z0.y + x1.y), y1 = make_double2(z0.x - x1.x, z0.y - x1.y);
-      const double2 y2 = make_double2(z2.x + x3.x, z2.y + x3.y), y3 = make_double2(z2.x - x3.x, z2.y - x3.y);
-      const double2 u2 = twmul(y2, w2), u3 = twmul(y3, w3);
-      const int p0 = fft_phys(a0);  // the swizzle is linear over GF(2) and leaves 1, 2, 3 alone
-      z[p0] = make_double2(y0.x + u2.x, y0.y + u2.y);
-      z[p0 ^ 2] = make_double2(y0.x - u2.x, y0.y - u2.y);
-      z[p0 ^ 1] = make_double2(y1.x + u3.x, y1.y + u3.y);
-      z[p0 ^ 3] = make_double2(y1.x - u3.x, y1.y - u3.y);
+#pragma unroll
+    for (int rep = 0; rep < FIRST; ++rep) {
+      const int u = tid() + rep * NT;
+      if (u < n / 4) {
+        const double2 z0 = f0[rep], z1 = f1[rep], z2 = f2[rep], z3 = f3[rep];
+        const int a0 = 4 * (int)(__brev((unsigned)u) >> (32 - (logn - 2)));
+        const double2 w1 = tw[0];
+        const double2 w2 = tw[0];
+        const double2 w3 = tw[1 << (tshift - 1)];
+        const double2 x1 = twmul(z1, w1), x3 = twmul(z3, w1);
+        const double2 y0 = make_double2(z0.x + x1.x, z0.y + x1.y), y1 = make_double2(z0.x - x1.x, z0.y - x1.y);
+        const double2 y2 = make_double2(z2.x + x3.x, z2.y + x3.y), y3 = make_double2(z2.x - x3.x, z2.y - x3.y);
+        const double2 u2 = twmul(y2, w2), u3 = twmul(y3, w3);
+        const int p0 = fft_phys(a0);  // the swizzle is linear over GF(2) and leaves 1, 2, 3 alone
+        z[p0] = make_double2(y0.x + u2.x, y0.y + u2.y);
+        z[p0 ^ 2] = make_double2(y0.x - u2.x, y0.y - u2.y);
+        z[p0 ^ 1] = make_double2(y1.x + u3.x, y1.y + u3.y);
+        z[p0 ^ 3] = make_double2(y1.x - u3.x, y1.y - u3.y);
+      }
     }
     __syncthreads();
     s = 3;
@@ -274,7 +285,7 @@ __device__ inline void rfft_lds(double2* z, int n_rt, int logn, const double2* t
 // TWO transforms of the same size in lockstep (arrays z0, z1): one set of barriers, index arithmetic and
 // twiddle loads serves both -- the workgroup transforms are bound by exactly those (61 %
 // of the instructions).  Per array the butterflies, twiddle entries and order of operations are those of
-// fft_lds: the results are bit-identical.  64 <= n <= FFT_SWZ_MAX (the swizzled path only).
+// fft_lds: the results are bit-identical.  64 <= n <= FFT_PAIR_MAX (the swizzled path only).
 template <int CLOGN = 0, int CTSHIFT = 0>
 __device__ inline void fft_lds_pair(double2* z0, double2* z1, int n_rt, int logn_rt, const double2* tw, int tw_n, int sign) {
   const int n = CLOGN ? (1 << CLOGN) : n_rt, logn = CLOGN ? CLOGN : logn_rt;

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
     win_make(W, fs, f0, 1, 4.0);               // one Blackman window serves all four centroid transforms
     for (int side = 0; side < 2; ++side) {
       const double cpos = side == 0 ? pos - 0.25 / f0 : pos + 0.25 / f0;
-      if (!AREG && h <= FFT_SWZ_MAX) {
+      if (!AREG && h <= FFT_PAIR_MAX) {
         // the segment and its ramped copy transformed in LOCKSTEP (the ramped one in B / C's storage,
         // which only held the first spectrum until it was multiplied in): one set of barriers, index
         // arithmetic and twiddle loads for two transforms; same values bit for bit
