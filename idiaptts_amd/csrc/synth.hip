@@ -480,8 +480,10 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
   double2* z = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
   double2* mp = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
   double* lg = reinterpret_cast<double*>(mp);      // input of min_phase, dead before mp is written
-  double* se = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
-  double* ar = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
+  // the aperiodic response's log amplitudes, formed together with the periodic ones from ONE read of the four
+  // spectrum rows (rounds 1-4 kept the interpolated envelope and aperiodicity ratio in two LDS arrays instead:
+  // 8 KB more at fft 2048, i.e. two workgroups per CU where three fit now)
+  double* lgs = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
   double* per = reinterpret_cast<double*>(q); q += (size_t)h * 8;
   double* red = reinterpret_cast<double*>(q);
   double* zr = reinterpret_cast<double*>(z);
@@ -516,30 +518,37 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     const double* sp1 = a.sp + (u.f_off + ce) * K;
     const double* ap0 = a.ap + (u.f_off + fl) * K;
     const double* ap1 = a.ap + (u.f_off + ce) * K;
-    for (int k = tid(); k < K; k += NT) {
+    // spectral envelope and aperiodicity ratio of bin k at the pulse
+    auto se_ar = [&](int k, double& se, double& ar) {
       const double s0 = fabs(sp0[k]);
       double a0 = ap0[k];
       a0 = a0 > 0.999999999999 ? 0.999999999999 : a0;
       a0 = a0 < 0.001 ? 0.001 : a0;
       if (fl == ce) {
-        se[k] = s0;
-        ar[k] = a0 * a0;                    // pow(x, 2.0): compilers fold it to x * x
+        se = s0;
+        ar = a0 * a0;                    // pow(x, 2.0): compilers fold it to x * x
       } else {
         const double s1 = fabs(sp1[k]);
         double a1 = ap1[k];
         a1 = a1 > 0.999999999999 ? 0.999999999999 : a1;
         a1 = a1 < 0.001 ? 0.001 : a1;
-        se[k] = (1.0 - al) * s0 + al * s1;
-        ar[k] = (1.0 - al) * (a0 * a0) + al * (a1 * a1);
+        se = (1.0 - al) * s0 + al * s1;
+        ar = (1.0 - al) * (a0 * a0) + al * (a1 * a1);
       }
+    };
+    double se0, ar0;
+    se_ar(0, se0, ar0);
+    // ---- periodic response
+    const bool has_per = !(vuv <= 0.5 || ar0 > 0.999);
+    for (int k = tid(); k < K; k += NT) {
+      double se, ar;
+      se_ar(k, se, ar);
+      if (has_per) lg[k] = log_pos(se * (1.0 - ar) + kEps) / 2.0;
+      lgs[k] = log_pos((vuv != 0.0) ? se * ar : se) / 2.0;
     }
     __syncthreads();
-    // ---- periodic response
-    const bool has_per = !(vuv <= 0.5 || ar[0] > 0.999);
     double per_dc = 0.0, per_dsum = 1.0;
     if (has_per) {
-      for (int k = tid(); k < K; k += NT) lg[k] = log_pos(se[k] * (1.0 - ar[k]) + kEps) / 2.0;
-      __syncthreads();
       min_phase(lg, fft, logfft, z, tw, mp);
       const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
       for (int k = tid(); k < K; k += NT) {
@@ -569,10 +578,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     }
     // ---- aperiodic response: minimum-phase spectrum first (into mp), then the noise spectrum in z,
     // multiplied in place
-    for (int k = tid(); k < K; k += NT)
-      lg[k] = log_pos((vuv != 0.0) ? se[k] * ar[k] : se[k]) / 2.0;
-    __syncthreads();
-    min_phase(lg, fft, logfft, z, tw, mp);
+    min_phase(lgs, fft, logfft, z, tw, mp);
     {
       const double* R = a.R + u.s_off + (idx - pidx[0]);
       double s = 0.0;
@@ -1063,7 +1069,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
     const int64_t n_pulses = *h_total;
     ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
     if (n_pulses > 0) {
-      const size_t lds = 2 * (size_t)(h + 1) * 16 + 2 * (size_t)(h + 2) * 8 +
+      const size_t lds = 2 * (size_t)(h + 1) * 16 + (size_t)(h + 2) * 8 +
                          (size_t)h * 8 + 16 * 8;
       ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
