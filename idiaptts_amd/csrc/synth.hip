@@ -427,8 +427,10 @@ struct PulseArgs {
 // minimum phase spectrum of the log-amplitude lg[0..h] (in z.x of the first h+1 entries is NOT
 // assumed): input array `lg`, output mp[0..h] complex. Uses z as FFT scratch.  lg is consumed by
 // the first loop, so it may live inside mp's storage.
-__device__ inline void min_phase(const double* lg, int fft, int logfft, double2* z, const double2* tw,
+template <int CFFT = 0>      // CFFT: log2 of the transform size as a compile-time constant (0: any)
+__device__ inline void min_phase(const double* lg, int fft_rt, int logfft, double2* z, const double2* tw,
                                  double2* mp) {
+  const int fft = CFFT ? (1 << CFFT) : fft_rt;
   const int h = fft / 2;
   double* zr = reinterpret_cast<double*>(z);
   for (int k = tid(); k <= h; k += NT) {
@@ -437,14 +439,14 @@ __device__ inline void min_phase(const double* lg, int fft, int logfft, double2*
     if (k > 0 && k < h) zr[fft - k] = v;
   }
   __syncthreads();
-  rfft_lds(z, fft, logfft, tw, fft);  // real even input -> real spectrum = fft * cepstrum
+  rfft_lds<true, CFFT, CFFT ? CFFT - 1 : 0>(z, fft, logfft, tw, fft);  // real even input -> real spectrum = fft * cepstrum
   // fold: c[0], 2 c[1..h-1], c[h], zeros; keep the (real) values, build the real sequence
   for (int k = tid(); k <= h; k += NT) mp[k].x = z[k].x * ((k == 0 || k == h) ? 1.0 : 2.0);
   __syncthreads();
   for (int k = tid(); k <= h; k += NT) zr[k] = mp[k].x;
   for (int k = h + 1 + tid(); k < fft + 2; k += NT) zr[k] = 0.0;
   __syncthreads();
-  rfft_lds(z, fft, logfft, tw, fft);
+  rfft_lds<true, CFFT, CFFT ? CFFT - 1 : 0>(z, fft, logfft, tw, fft);
   for (int k = tid(); k <= h; k += NT) {
     const double t = exp(z[k].x / fft);
     double sn, cs;
@@ -472,9 +474,10 @@ __global__ __launch_bounds__(NT) void syn_dcr_table_kernel(int fft, double* __re
 }
 
 // 28 KB of LDS at fft 1024: five workgroups fit a CU when a wave needs <= 102 VGPRs
+template <int CFFT>      // log2 of the transform size as a compile-time constant (11 at 32 .. 48 kHz), 0: any size
 __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int fft = a.p.fft, logfft = a.p.logfft, h = fft / 2, K = h + 1;
+  const int fft = CFFT ? (1 << CFFT) : a.p.fft, logfft = CFFT ? CFFT : a.p.logfft, h = fft / 2, K = h + 1;
   char* q = smem;
   const double2* tw = a.g_tw;          // compact table read through the cache: 8 KB of LDS less
   double2* z = reinterpret_cast<double2*>(q); q += (size_t)(h + 1) * 16;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     __syncthreads();
     double per_dc = 0.0, per_dsum = 1.0;
     if (has_per) {
-      min_phase(lg, fft, logfft, z, tw, mp);
+      min_phase<CFFT>(lg, fft, logfft, z, tw, mp);
       const double coef = 2.0 * kPi * tshift * a.p.fs / fft;
       for (int k = tid(); k < K; k += NT) {
         const double re2 = cos_mid(coef * k);
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
         z[k] = make_double2(m.x * re2 + m.y * im2, m.y * re2 - m.x * im2);
       }
       __syncthreads();
-      irfft_lds(z, fft, logfft, tw, fft);
+      irfft_lds<true, CFFT, CFFT ? CFFT - 1 : 0>(z, fft, logfft, tw, fft);
       // fftshift + DC removal
       double dc = 0.0;
       for (int i = tid(); i < h; i += NT) dc += zr[i];  // shifted index i+h <- zr[i]
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     }
     // ---- aperiodic response: minimum-phase spectrum first (into mp), then the noise spectrum in z,
     // multiplied in place
-    min_phase(lgs, fft, logfft, z, tw, mp);
+    min_phase<CFFT>(lgs, fft, logfft, z, tw, mp);
     {
       const double* R = a.R + u.s_off + (idx - pidx[0]);
       double s = 0.0;
@@ -596,14 +599,14 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
         for (int i = tid(); i < noise_size && i < fft; i += NT) zr[i] -= avg;
       }
       __syncthreads();
-      rfft_lds(z, fft, logfft, tw, fft);
+      rfft_lds<true, CFFT, CFFT ? CFFT - 1 : 0>(z, fft, logfft, tw, fft);
     }
     for (int k = tid(); k < K; k += NT) {
       const double2 m = mp[k], n = z[k];
       z[k] = make_double2(m.x * n.x - m.y * n.y, m.x * n.y + m.y * n.x);
     }
     __syncthreads();
-    irfft_lds(z, fft, logfft, tw, fft);
+    irfft_lds<true, CFFT, CFFT ? CFFT - 1 : 0>(z, fft, logfft, tw, fft);
     // ---- overlap-add
     const double sq = sqrt((double)noise_size);
     const int off = idx - h + 1;
@@ -1072,9 +1075,11 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
       const size_t lds = 2 * (size_t)(h + 1) * 16 + (size_t)(h + 2) * 8 +
                          (size_t)h * 8 + 16 * 8;
       ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_kernel,
+      const bool sized = 2 * h == 2048 && !getenv("ITTS_SYN_GENERIC");
+      ITTS_HIP_CHECK(hipFuncSetAttribute(sized ? (const void*)syn_pulse_kernel<11> : (const void*)syn_pulse_kernel<0>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(syn_pulse_kernel, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      if (sized) hipLaunchKernelGGL(syn_pulse_kernel<11>, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      else hipLaunchKernelGGL(syn_pulse_kernel<0>, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
       ITTS_LAUNCH_CHECK();
     }
   }

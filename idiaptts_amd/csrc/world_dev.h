@@ -416,8 +416,9 @@ __device__ inline void rfft_lds_pair(double2* z0, double2* z1, int n_rt, int log
 
 // Inverse real FFT: z[k] = X[k], k = 0..n/2 (imag of X[0], X[n/2] ignored) -> z viewed as n real
 // samples, normalised like numpy.fft.irfft.
-template <bool SWZ = true>
-__device__ inline void irfft_lds(double2* z, int n, int logn, const double2* tw, int tw_n) {
+template <bool SWZ = true, int CLOGN = 0, int CTSHIFT = 0>     // (CLOGN: log2 of the REAL transform's size, as rfft_lds)
+__device__ inline void irfft_lds(double2* z, int n_rt, int logn, const double2* tw, int tw_n_rt) {
+  const int n = CLOGN ? (1 << CLOGN) : n_rt, tw_n = CTSHIFT ? (2 << CTSHIFT) : tw_n_rt;
   const int h = n / 2;
   const int tstride = tw_n / n;
   for (int k = tid(); k <= h / 2; k += NT) {
@@ -441,7 +442,7 @@ __device__ inline void irfft_lds(double2* z, int n, int logn, const double2* tw,
     }
   }
   __syncthreads();
-  fft_lds<SWZ>(z, h, logn - 1, tw, tw_n, +1);
+  fft_lds<SWZ, CLOGN ? CLOGN - 1 : 0, CTSHIFT>(z, h, logn - 1, tw, tw_n, +1);
   const double s = 1.0 / (double)h;
   for (int k = tid(); k < h; k += NT) {
     double2 v = z[k];
