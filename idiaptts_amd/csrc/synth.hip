@@ -494,12 +494,9 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
   const int64_t total = a.gpoff[a.p.n_utts];
   const int64_t g = blockIdx.x;           // one pulse per workgroup (the host reads the pulse count)
   if (g < total) {
-    // utterance of flat pulse g
-    int lo = 0, hi = a.p.n_utts;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (a.gpoff[mid] <= g) lo = mid; else hi = mid;
-    }
+    // utterance of flat pulse g: every wave reads the offsets 64 at a time and counts (a binary search is log2(U)
+    // dependent trips to memory in front of everything else the pulse does)
+    const int lo = find_utt_wave(a.gpoff, a.p.n_utts, g);
     const SynUtt u = a.utts[lo];
     const int P = (int)a.ptot[lo];
     const int qi = (int)(g - a.gpoff[lo]);
@@ -539,15 +536,24 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
         ar = (1.0 - al) * (a0 * a0) + al * (a1 * a1);
       }
     };
-    double se0, ar0;
-    se_ar(0, se0, ar0);
     // ---- periodic response
-    const bool has_per = !(vuv <= 0.5 || ar0 > 0.999);
-    for (int k = tid(); k < K; k += NT) {
-      double se, ar;
-      se_ar(k, se, ar);
-      if (has_per) lg[k] = log_pos(se * (1.0 - ar) + kEps) / 2.0;
-      lgs[k] = log_pos((vuv != 0.0) ? se * ar : se) / 2.0;
+    bool has_per = false;
+    if (vuv != 0.0) {
+      double se0, ar0;
+      se_ar(0, se0, ar0);
+      has_per = !(ar0 > 0.999);
+      for (int k = tid(); k < K; k += NT) {
+        double se, ar;
+        se_ar(k, se, ar);
+        if (has_per) lg[k] = log_pos(se * (1.0 - ar) + kEps) / 2.0;
+        lgs[k] = log_pos(se * ar) / 2.0;
+      }
+    } else {
+      // an unvoiced pulse: the envelope alone (the aperiodicity rows are not read)
+      for (int k = tid(); k < K; k += NT) {
+        const double s0 = fabs(sp0[k]);
+        lgs[k] = log_pos(fl == ce ? s0 : (1.0 - al) * s0 + al * fabs(sp1[k])) / 2.0;
+      }
     }
     __syncthreads();
     double per_dc = 0.0, per_dsum = 1.0;
@@ -753,6 +759,12 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
     // spectral envelope and aperiodicity ratio of bin k at the pulse
     auto se_ar = [&](int k, double& se, double& ar) {
       const double s0 = fabs(sp0[k]);
+      if (vuv == 0.0) {
+        // an unvoiced pulse: the envelope alone (its aperiodicity ratio is never used: the rows are not read)
+        se = fl == ce ? s0 : (1.0 - al) * s0 + al * fabs(sp1[k]);
+        ar = 1.0;
+        return;
+      }
       double a0 = ap0[k];
       a0 = a0 > 0.999999999999 ? 0.999999999999 : a0;
       a0 = a0 < 0.001 ? 0.001 : a0;

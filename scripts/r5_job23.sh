@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd "$R" || exit 1
-timeout 1200 python -m pytest tests/test_gpu_world.py -m gpu -x -q 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_world.py tests/test_gpu_properties.py -m gpu -x -q 2>&1 | tail -3
 O=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/sp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -- python3 $R/scripts/traffic_driver.py synthesis 4 48000 64 > /dev/null 2>&1
-python3 $R/scripts/kstats.py /tmp/sp 20 | tee $O/r5t_synthesis_48k_kstats.txt | grep -v "mcls\|d4c\|cheaptrick\|dio_\|stonemask" | head -4
+rm -rf /tmp/sp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -- python3 $R/scripts/traffic_driver.py synthesis 4 16000 256 > /dev/null 2>&1
+python3 $R/scripts/kstats.py /tmp/sp 20 | tee $O/r5t_synthesis_16k_kstats.txt | grep "syn_\|total"
