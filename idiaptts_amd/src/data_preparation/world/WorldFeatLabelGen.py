@@ -523,44 +523,74 @@ class WorldFeatLabelGen(ReaderBase):
                             [cmp_u[:, cols[k][0]:cols[k][0] + cols[k][1]] for k in loaded], axis=1) \
                             if loaded else None
 
-            for bi, names in enumerate(batches):
-                t_a = _time.perf_counter()
+            # The analysis of a batch is driven by the host (the Newton rounds of the mel-cepstrum read a count back
+            # between launches) and a 64-utterance batch leaves the chip partly idle at the tails of its kernels: two
+            # batches are analysed at a time, by two threads on two streams (the library's calls release the
+            # interpreter lock; its scratch blocks and tables are stream-ordered and behind mutexes).  Results are
+            # taken in batch order: the statistics add up in the order they always did.
+            analysis_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+            def analyse(bi):
                 samples, x_off, fss, arrived = pending_reads[bi].result()
-                if arrived is not None:
-                    torch.cuda.current_stream().wait_event(arrived)
-                    samples.record_stream(torch.cuda.current_stream())
-                t_b = _time.perf_counter()
                 pending_reads[bi] = None
-                if bi + depth < len(batches):
-                    pending_reads.append(readers.submit(read, batches[bi + depth]))
                 assert len(set(fss)) == 1, "All files of a batch need the same sampling rate."
                 fs = fss[0]
-                if cols is None:      # WORLD fixes the number of bap bands by the sampling rate
-                    cols = self._cmp_columns(AudioProcessing.fs_to_num_bap(fs))
-                    stats = _world.StreamStats({k: cols[k] for k in loaded if k != "vuv"},
-                                               self.add_deltas)
                 alpha = self.mgc_alpha if self.mgc_alpha is not None \
                     else AudioProcessing.fs_to_mgc_alpha(fs)
-                cmp_dev, f_off = _world.extract_cmp_batch(
-                    (samples, x_off), fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1,
-                    alpha, WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
-                    self.add_deltas,
-                    mgc_gamma=AudioProcessing.mgc_gamma if self.sp_type == "mgc" else None,
-                    f0_method=self.f0_estimator)
-                stats.add(cmp_dev)
-                ready = torch.cuda.current_stream().record_event()
-                host = torch.empty(cmp_dev.shape, dtype=torch.float32, pin_memory=True)
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(ready)
-                    host.copy_(cmp_dev, non_blocking=True)
-                    done = copy_stream.record_event()
-                cmp_dev.record_stream(copy_stream)
-                if in_copy is not None:
-                    hand_over(in_copy)      # the batch before: its copy ran beside this batch's analysis
-                in_copy = (names, host, f_off, done)
-                if trace:
-                    print("gen_data batch {}: waited {:.1f} ms for the reader, device {:.1f} ms"
-                          .format(bi, (t_b - t_a) * 1e3, (_time.perf_counter() - t_b) * 1e3))
+                st = analysis_streams[bi % 2]
+                with torch.cuda.stream(st):
+                    if arrived is not None:
+                        st.wait_event(arrived)
+                        samples.record_stream(st)
+                    cmp_dev, f_off = _world.extract_cmp_batch(
+                        (samples, x_off), fs, self.hop_size_ms, self.n_fft, self.num_coded_sps - 1,
+                        alpha, WorldFeatLabelGen.f0_silence_threshold, WorldFeatLabelGen.lf0_zero,
+                        self.add_deltas,
+                        mgc_gamma=AudioProcessing.mgc_gamma if self.sp_type == "mgc" else None,
+                        f0_method=self.f0_estimator)
+                    ready = st.record_event()
+                return cmp_dev, f_off, ready, fs
+
+            with cf.ThreadPoolExecutor(2) as analysers:
+                analyses = {}
+
+                def start(bi):
+                    analyses[bi] = analysers.submit(analyse, bi)
+                    if bi + depth < len(batches):
+                        pending_reads.append(readers.submit(read, batches[bi + depth]))
+
+                for bi, names in enumerate(batches):
+                    t_a = _time.perf_counter()
+                    if bi not in analyses:
+                        start(bi)
+                    if bi == 0:
+                        # the first batch alone: it builds the device's tables (on its stream)
+                        analyses[0].result()
+                        torch.cuda.synchronize()
+                    if bi + 1 < len(batches) and bi + 1 not in analyses:
+                        start(bi + 1)
+                    cmp_dev, f_off, ready, fs = analyses.pop(bi).result()
+                    t_b = _time.perf_counter()
+                    main = torch.cuda.current_stream()
+                    main.wait_event(ready)
+                    cmp_dev.record_stream(main)
+                    if cols is None:      # WORLD fixes the number of bap bands by the sampling rate
+                        cols = self._cmp_columns(AudioProcessing.fs_to_num_bap(fs))
+                        stats = _world.StreamStats({k: cols[k] for k in loaded if k != "vuv"},
+                                                   self.add_deltas)
+                    stats.add(cmp_dev)
+                    ready = main.record_event()
+                    host = torch.empty(cmp_dev.shape, dtype=torch.float32, pin_memory=True)
+                    with torch.cuda.stream(copy_stream):
+                        copy_stream.wait_event(ready)
+                        host.copy_(cmp_dev, non_blocking=True)
+                        done = copy_stream.record_event()
+                    cmp_dev.record_stream(copy_stream)
+                    if in_copy is not None:
+                        hand_over(in_copy)      # the batch before: its copy ran beside this batch's analysis
+                    in_copy = (names, host, f_off, done)
+                    if trace:
+                        print("gen_data batch {}: waited {:.1f} ms for its analysis".format(bi, (t_b - t_a) * 1e3))
             if in_copy is not None:
                 hand_over(in_copy)
             t_a = _time.perf_counter()
