@@ -52,7 +52,7 @@ struct GemmOut {
   double* opow;
 };
 template <bool VEC_A, bool RATIO = false, bool MGC2SP = false>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, MGC2SP ? 3 : 2) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
                                                        const double* __restrict__ Bm, int64_t ldb,
                                                        double* __restrict__ C, int64_t ldc, int64_t T,
                                                        int N, int K, const int* __restrict__ rows,
@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
       }
     }
   };
+  if (MGC2SP) {
+    // output bound (K <= 64, a [rows, 513] array out): one operand set instead of two alternating ones keeps the
+    // kernel at three workgroups per CU, whose stores and loads cover each other (136 registers; 0.70 -> 0.61 ms for
+    // 315 k frames; four per CU at 128 registers spill eight: 0.67 ms; the alternating sets at three: 31 spilled, 0.82 ms)
+    Ops oa;
+    for (int s = 0; s < K; s += 16) {
+      load(s, oa);
+      multiply(oa, s);
+    }
+  } else {
   Ops oa, ob;
   load(0, oa);
   for (int s = 0; s < K; s += 32) {
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
       if (s + 32 < K) load(s + 32, oa);
       multiply(ob, s + 16);
     }
+  }
   }
   // C/D map (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
