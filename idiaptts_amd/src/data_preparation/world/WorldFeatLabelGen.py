@@ -528,7 +528,8 @@ class WorldFeatLabelGen(ReaderBase):
             # batches are analysed at a time, by two threads on two streams (the library's calls release the
             # interpreter lock; its scratch blocks and tables are stream-ordered and behind mutexes).  Results are
             # taken in batch order: the statistics add up in the order they always did.
-            analysis_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            n_flight = max(1, int(os.environ.get("ITTS_GEN_DATA_INFLIGHT", "2")))
+            analysis_streams = [torch.cuda.Stream() for _ in range(n_flight)]
 
             def analyse(bi):
                 samples, x_off, fss, arrived = pending_reads[bi].result()
@@ -537,7 +538,7 @@ class WorldFeatLabelGen(ReaderBase):
                 fs = fss[0]
                 alpha = self.mgc_alpha if self.mgc_alpha is not None \
                     else AudioProcessing.fs_to_mgc_alpha(fs)
-                st = analysis_streams[bi % 2]
+                st = analysis_streams[bi % n_flight]
                 with torch.cuda.stream(st):
                     if arrived is not None:
                         st.wait_event(arrived)
@@ -551,7 +552,7 @@ class WorldFeatLabelGen(ReaderBase):
                     ready = st.record_event()
                 return cmp_dev, f_off, ready, fs
 
-            with cf.ThreadPoolExecutor(2) as analysers:
+            with cf.ThreadPoolExecutor(n_flight) as analysers:
                 analyses = {}
 
                 def start(bi):
@@ -567,8 +568,9 @@ class WorldFeatLabelGen(ReaderBase):
                         # the first batch alone: it builds the device's tables (on its stream)
                         analyses[0].result()
                         torch.cuda.synchronize()
-                    if bi + 1 < len(batches) and bi + 1 not in analyses:
-                        start(bi + 1)
+                    for ahead in range(1, n_flight):
+                        if bi + ahead < len(batches) and bi + ahead not in analyses:
+                            start(bi + ahead)
                     cmp_dev, f_off, ready, fs = analyses.pop(bi).result()
                     t_b = _time.perf_counter()
                     main = torch.cuda.current_stream()

@@ -1,6 +1,6 @@
 """Time itts_mlpg_generation on the traffic_driver's MLPG batch (256 utterances, 186 -> 62 columns).
 
-usage: python3 scripts/mlpg_time.py [passes] [utterances] [f32]      ITTS_MLPG_STREAM=1 selects the three-launch form"""
+usage: python3 scripts/mlpg_time.py [passes] [utterances] [f32|f64] [dim]      ITTS_MLPG_STREAM=1 selects the three-launch form"""
 import os
 import sys
 
@@ -15,21 +15,22 @@ dev = torch.device("cuda", 0)
 n_utts = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 off = world.offsets(utterance_lengths(n_utts, seed=5).tolist())
 f32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
-feat = torch.randn(off[-1], 186, dtype=torch.float32 if f32 else torch.float64, device=dev)
-var = torch.rand(186, dtype=torch.float64, device=dev) * 0.99 + 0.01
+dim = int(sys.argv[4]) if len(sys.argv) > 4 else 62
+feat = torch.randn(off[-1], 3 * dim, dtype=torch.float32 if f32 else torch.float64, device=dev)
+var = torch.rand(3 * dim, dtype=torch.float64, device=dev) * 0.99 + 0.01
 for _ in range(5):
-    ops.mlpg_generation(feat, var, 62, off)
+    ops.mlpg_generation(feat, var, dim, off)
 torch.cuda.synchronize()
 times = []
 for _ in range(passes):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.mlpg_generation(feat, var, 62, off)
+    ops.mlpg_generation(feat, var, dim, off)
     e1.record()
     e1.synchronize()
     times.append(e0.elapsed_time(e1) * 1e3)
 times.sort()
 frames = int(off[-1])
-alg = frames * (186 * (4 if f32 else 8) + 62 * 8)
-print(("float32 rows  " if f32 else "") + "utterances %d  frames %d  median %.1f us  min %.1f us  p90 %.1f us  algorithmic %.3f GB -> %.2f TB/s at the median"
+alg = frames * (3 * dim * (4 if f32 else 8) + dim * 8)
+print(("float32 rows  " if f32 else "") + ("dim %d  " % dim) + "utterances %d  frames %d  median %.1f us  min %.1f us  p90 %.1f us  algorithmic %.3f GB -> %.2f TB/s at the median"
       % (n_utts, frames, times[len(times) // 2], times[0], times[int(len(times) * 0.9)], alg / 1e9, alg / times[len(times) // 2] / 1e6))
