@@ -417,9 +417,13 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
     f0s = f0.clone()
 
     def synthesis():
-        pw = ops.mgc2sp(mc64, alpha, n_fft, want_pow=True)
-        apd = ops.decode_aperiodicity(bap64, fs, n_fft)
-        return ops.world_synthesize(f0s, pw, apd, f_off, fs, hop)
+        # as the product does it (world.synthesise_features): mel-cepstrum -> power spectrum and coded -> decoded
+        # aperiodicity on the side stream while the synthesis works through what it does on f0 alone
+        if os.environ.get("ITTS_BENCH_SYNTH_SIDE", "1") == "0":
+            pw = ops.mgc2sp(mc64, alpha, n_fft, want_pow=True)
+            apd = ops.decode_aperiodicity(bap64, fs, n_fft)
+            return ops.world_synthesize(f0s, pw, apd, f_off, fs, hop)
+        return world.synthesise_features(f0s, f_off, fs, n_fft, mc=mc64, alpha=alpha, bap=bap64, hop_ms=hop)
 
     synthesis()
     sync()

@@ -974,10 +974,15 @@ __global__ __launch_bounds__(64) void syn_deemph_kernel(const double* __restrict
 
 using namespace itts;
 
-extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* d_ap,
-                                     const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
-                                     double frame_period_ms, int fft_size, double preemphasis,
-                                     float* d_y_f32, double* d_y_f64, void* stream) {
+// spectra_ready: an event behind which d_sp and d_ap are complete (or null: they are, on `stream`).  Everything up to
+// the pulse kernel -- the per-sample phase, the pulse positions, the noise -- reads d_f0 only (a third of a 16 kHz
+// synthesis by launches, latency-bound, the chip mostly idle); the stream waits for the event right in front of the
+// pulse kernel, so a caller can produce the spectra (mgc2sp, decode_aperiodicity: bound by their 1.3-GB outputs) on
+// another stream meanwhile.
+static int world_synthesize_impl(const double* d_f0, const double* d_sp, const double* d_ap,
+                                 const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
+                                 double frame_period_ms, int fft_size, double preemphasis,
+                                 float* d_y_f32, double* d_y_f64, void* stream, hipEvent_t spectra_ready) {
   ITTS_REQUIRE(h_f_off && h_y_off && (n_utts == 0 || (d_f0 && d_sp && d_ap && (d_y_f32 || d_y_f64))), "null pointer");
   ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
   ITTS_REQUIRE(fft_size >= 256 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0,
@@ -1080,6 +1085,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
         if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
       }
     }
+    if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
     hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds, s, a);
     ITTS_LAUNCH_CHECK();
   } else {
@@ -1103,6 +1109,7 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
       const size_t lds = 2 * (size_t)(h + 1) * 16 + (size_t)(h + 2) * 8 +
                          (size_t)h * 8 + 16 * 8;
       ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+      if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
       const bool sized = 2 * h == 2048 && !getenv("ITTS_SYN_GENERIC");
       ITTS_HIP_CHECK(hipFuncSetAttribute(sized ? (const void*)syn_pulse_kernel<11> : (const void*)syn_pulse_kernel<0>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1138,4 +1145,20 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
   ITTS_HIP_CHECK(itts::scratch_free(d_gpoff, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_y, s));
   return ITTS_OK;
+}
+
+extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* d_ap,
+                                     const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
+                                     double frame_period_ms, int fft_size, double preemphasis,
+                                     float* d_y_f32, double* d_y_f64, void* stream) {
+  return world_synthesize_impl(d_f0, d_sp, d_ap, h_f_off, h_y_off, n_utts, fs, frame_period_ms, fft_size,
+                               preemphasis, d_y_f32, d_y_f64, stream, nullptr);
+}
+
+extern "C" int itts_world_synthesize_after(const double* d_f0, const double* d_sp, const double* d_ap,
+                                           const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
+                                           double frame_period_ms, int fft_size, double preemphasis,
+                                           float* d_y_f32, double* d_y_f64, void* stream, void* spectra_ready_event) {
+  return world_synthesize_impl(d_f0, d_sp, d_ap, h_f_off, h_y_off, n_utts, fs, frame_period_ms, fft_size,
+                               preemphasis, d_y_f32, d_y_f64, stream, reinterpret_cast<hipEvent_t>(spectra_ready_event));
 }

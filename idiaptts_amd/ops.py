@@ -658,10 +658,21 @@ def d4c(x, x_off, f0, f_off, fs, frame_period=5.0, fft_size=None, threshold=0.85
     return ap, bap
 
 
+def synth_offsets(f_off, fs, frame_period=5.0):
+    """Sample offsets of the synthesised utterances for the frame offsets f_off (pyworld.synthesize's output lengths)."""
+    L = _lib.load()
+    y_off = [0]
+    for u in range(len(f_off) - 1):
+        y_off.append(y_off[-1] + L.itts_world_synth_length(int(f_off[u + 1] - f_off[u]), fs,
+                                                           float(frame_period)))
+    return y_off
+
+
 def world_synthesize(f0, sp, ap, f_off, fs, frame_period=5.0, preemphasis=0.0,
-                     dtype=torch.float32):
+                     dtype=torch.float32, spectra_ready=None, y_off=None):
     """pyworld.synthesize + float32 cast + de-pre-emphasis for utterances stored back to back.
-    Returns (y [Ytot], y_off list)."""
+    Returns (y [Ytot], y_off list).  spectra_ready: a torch.cuda.Event recorded behind the producers of sp and ap when
+    they run on another stream (the part of the synthesis in front of the pulse kernel needs f0 only and does not wait)."""
     L = _lib.load()
     for t, n in ((f0, "f0"), (sp, "sp"), (ap, "ap")):
         _need(t, torch.float64, n)
@@ -669,15 +680,20 @@ def world_synthesize(f0, sp, ap, f_off, fs, frame_period=5.0, preemphasis=0.0,
     ap = ap.contiguous()
     K = sp.shape[1]
     fft_size = (K - 1) * 2
-    y_off = [0]
-    for u in range(len(f_off) - 1):
-        y_off.append(y_off[-1] + L.itts_world_synth_length(int(f_off[u + 1] - f_off[u]), fs,
-                                                           float(frame_period)))
+    if y_off is None:
+        y_off = synth_offsets(f_off, fs, frame_period)
     y = torch.empty((y_off[-1],), dtype=dtype, device=f0.device)
-    _lib.check(L.itts_world_synthesize(_ptr(f0), _ptr(sp), _ptr(ap), _lib.offsets_array(f_off),
-                                       _lib.offsets_array(y_off), len(f_off) - 1, fs,
-                                       float(frame_period), fft_size, float(preemphasis),
-                                       _ptr(y) if dtype == torch.float32 else None,
-                                       _ptr(y) if dtype == torch.float64 else None, _stream()),
-               "itts_world_synthesize")
+    args = (_ptr(f0), _ptr(sp), _ptr(ap), _lib.offsets_array(f_off),
+            _lib.offsets_array(y_off), len(f_off) - 1, fs,
+            float(frame_period), fft_size, float(preemphasis),
+            _ptr(y) if dtype == torch.float32 else None,
+            _ptr(y) if dtype == torch.float64 else None, _stream())
+    if spectra_ready is None:
+        _lib.check(L.itts_world_synthesize(*args), "itts_world_synthesize")
+    else:
+        _lib.check(L.itts_world_synthesize_after(*args, ctypes.c_void_p(spectra_ready.cuda_event)),
+                   "itts_world_synthesize_after")
+        cur = torch.cuda.current_stream(f0.device)
+        sp.record_stream(cur)
+        ap.record_stream(cur)
     return y, y_off

@@ -177,6 +177,34 @@ def extract_cmp_batch(raws, fs, hop_ms=5.0, n_fft=None, mcep_order=59, mcep_alph
     return ops.assemble_cmp(mc, lf0, vuv, bap, f_off, add_deltas=add_deltas), f_off
 
 
+def synthesise_features(f0, f_off, fs, n_fft, mc=None, alpha=None, sp=None, bap=None, ap=None, hop_ms=5.0,
+                        preemphasis=0.0, dtype=torch.float32):
+    """Device tensors in, waveform out: f0 [Ttot] f64 of utterances stored back to back, the envelope as mel-cepstra
+    `mc` [Ttot, order + 1] f64 (with `alpha`) or as power spectra `sp`, the aperiodicity coded (`bap`) or decoded (`ap`).
+    What has to be decoded first -- mc -> sp (WorldFeatLabelGen.py:925 through mgc2sp), bap -> ap (:940-941) -- runs on
+    the side stream WHILE the synthesis works through everything it does on f0 alone (per-sample phase, pulse positions,
+    noise): the two [Ttot, K] arrays are only needed by the pulse kernel.  Returns (y [Ytot], y_off)."""
+    dev = f0.device
+    main = torch.cuda.current_stream(dev)
+    ready = None
+    y_off = ops.synth_offsets(f_off, fs, hop_ms)      # (host work first: nothing between the two streams' launches)
+    if mc is not None or ap is None:
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if mc is not None:
+                sp = ops.mgc2sp(mc, alpha, n_fft, want_pow=True)
+            if ap is None:
+                ap = ops.decode_aperiodicity(bap, fs, n_fft)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        for t in (mc, bap):
+            if t is not None:
+                t.record_stream(side)
+    return ops.world_synthesize(f0, sp, ap, f_off, fs, hop_ms, preemphasis, dtype=dtype, spectra_ready=ready,
+                                y_off=y_off)
+
+
 def synthesise_batch(f0s, sps, baps, fs, n_fft, hop_ms=5.0, preemphasis=0.0, device=None,
                      out_dtype=np.float64):
     """f0s: list of [T] f64; sps: list of [T,K] f64 POWER spectra; baps: list of [T,nap] f64 coded
@@ -187,9 +215,7 @@ def synthesise_batch(f0s, sps, baps, fs, n_fft, hop_ms=5.0, preemphasis=0.0, dev
     f0 = torch.from_numpy(np.ascontiguousarray(np.concatenate(f0s), dtype=np.float64)).to(dev)
     sp = torch.from_numpy(np.ascontiguousarray(np.concatenate(sps), dtype=np.float64)).to(dev)
     bap = torch.from_numpy(np.ascontiguousarray(np.concatenate(baps), dtype=np.float64)).to(dev)
-    ap = ops.decode_aperiodicity(bap, fs, n_fft)
-    y, y_off = ops.world_synthesize(f0, sp, ap, f_off, fs, hop_ms, preemphasis,
-                                    dtype=torch.float64 if out_dtype == np.float64
-                                    else torch.float32)
+    y, y_off = synthesise_features(f0, f_off, fs, n_fft, sp=sp, bap=bap, hop_ms=hop_ms, preemphasis=preemphasis,
+                                   dtype=torch.float64 if out_dtype == np.float64 else torch.float32)
     y = y.cpu().numpy()
     return [y[y_off[u]:y_off[u + 1]] for u in range(len(f0s))]
