@@ -56,3 +56,29 @@ def test_handler_thread_loader_equals_dataloader(gpu, shuffle):
     for (x0, y0, l0), (x1, y1, l1) in zip(ref, got):
         assert torch.equal(x0, x1) and torch.equal(y0, y1) and torch.equal(l0, l1)
     assert all(d["x"].is_pinned() for d, _ in thr_loader)
+
+
+def test_synthesis_with_spectra_on_the_side_stream_equals_the_sequential_calls(gpu):
+    """world.synthesise_features (mgc2sp / decode_aperiodicity on the side stream, itts_world_synthesize_after waiting
+    for their event right before the pulse kernel) against the three calls in a row on one stream: the same samples
+    (reference call sites: WorldFeatLabelGen.py:925, 940-945)."""
+    from idiaptts_amd import lib, ops, world
+    from idiaptts_amd.bench_support import make_audio_batch
+    L = lib.load()
+    fs, hop = 16000, 5.0
+    raws = make_audio_batch(6, fs, seed=3)
+    n_fft = L.itts_cheaptrick_fft_size(fs, 71.0)
+    alpha = L.itts_mcep_alpha(fs)
+    x_off = world.offsets([len(r) for r in raws])
+    f_off = world.offsets([world.num_frames(len(r), fs, hop) for r in raws])
+    x = torch.from_numpy(np.concatenate(raws)).to(gpu)
+    f0 = ops.stonemask(x, x_off, ops.dio(x, x_off, f_off, fs, hop), f_off, fs, hop)
+    _, bap = ops.d4c(x, x_off, f0, f_off, fs, hop, n_fft, want_ap=False, want_bap=torch.float32)
+    _, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop, n_fft, want_sp=False, order=24, alpha=alpha)
+    mc64, bap64 = mc.double(), bap.double()
+    pw = ops.mgc2sp(mc64, alpha, n_fft, want_pow=True)
+    apd = ops.decode_aperiodicity(bap64, fs, n_fft)
+    want, off0 = ops.world_synthesize(f0, pw, apd, f_off, fs, hop)
+    for _ in range(3):
+        got, off1 = world.synthesise_features(f0, f_off, fs, n_fft, mc=mc64, alpha=alpha, bap=bap64, hop_ms=hop)
+        assert off0 == off1 and torch.equal(want, got)
