@@ -310,6 +310,23 @@ def hip_event_median_ms(fn, stream, iters):
     return float(np.median(times))
 
 
+def hip_event_queued_ms(fn, stream, calls, iters):
+    """Median over `iters` passes of (one event pair around `calls` back-to-back fn()) / calls: a launch's
+    duration as the stream sees it, the host side of a call hidden behind the launch before it."""
+    times = []
+    with torch.cuda.stream(stream):
+        for _ in range(iters):
+            start = torch.cuda.Event(enable_timing=True)
+            end = torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+            for _ in range(calls):
+                fn()
+            end.record(stream)
+            end.synchronize()
+            times.append(start.elapsed_time(end) / calls)
+    return float(np.median(times))
+
+
 def cpu_baseline_ff(n_utts, max_seconds=20.0):
     """Reference stack (torch.nn.Linear/Tanh + MSELoss*mask + Adam) on the host cores, padded
     batch exactly like process_dataloader; bounded sample."""
@@ -506,8 +523,13 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         sync()
         ms_ml = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off),
                                                stream, 7), dist.ReduceOp.MAX)
+        # the launch itself: 8 calls queued back to back, events around them on the launch stream (a lone call holds
+        # 40-50 us of host side -- allocations, sort, table, launch -- between its events, the device idle)
+        ms_ml_q = over_ranks(hip_event_queued_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off), stream, 8, 5),
+                             dist.ReduceOp.MAX)
         ml_frames *= n_ranks                      # same lengths on every rank
         gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
+        gbs_q = ml_frames * 2000 / (ms_ml_q * 1e-3) / 1e9
         # HBM bytes of one solve from the committed PMC passes (profiles/r5_section_traffic.json:
         # FETCH_SIZE x 2 + WRITE_SIZE on this same workload); not re-measured inside bench.py
         ml_traffic = committed_traffic("mlpg")
@@ -515,9 +537,13 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
                        "algorithmic_GBps": gbs,
                        "frac_of_hbm_peak": gbs / PEAK_HBM_GBS / n_ranks,
-                       "roofline": {"bound": "hbm", "kernel": "mlpg_ring_kernel (one launch; whole call by events, host side included)",
-                                    "achieved": gbs / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": gbs / PEAK_HBM_GBS / n_ranks, "traffic": ml_traffic,
+                       "ms_queued": ms_ml_q,
+                       "roofline": {"bound": "hbm", "kernel": "mlpg_ring_kernel (one launch)",
+                                    "from": "8 calls queued back to back, HIP events around them on the launch stream, / 8 "
+                                            "(`ms`, `frac_of_hbm_peak`: one call alone between its events, host side included)",
+                                    "achieved": gbs_q / n_ranks, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": gbs_q / PEAK_HBM_GBS / n_ranks, "traffic": ml_traffic,
+                                    "avg_launch_us": ms_ml_q * 1e3,
                                     "algorithmic_bytes_per_launch": ml_frames / n_ranks * 2000,
                                     "algorithmic_bytes_per_frame": 2000}}
         # the same batch with float32 rows (the acoustic model's output type; widened in the solve's loads):
@@ -540,9 +566,12 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
             sync()
             ms_b = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat_b, var, 62, off_b),
                                                   stream, 5), dist.ReduceOp.MAX)
-            curve.append({"utterances": n_u, "frames": fr, "ms": ms_b,
+            ms_bq = over_ranks(hip_event_queued_ms(lambda: ops.mlpg_generation(feat_b, var, 62, off_b), stream, 4, 3),
+                               dist.ReduceOp.MAX)
+            curve.append({"utterances": n_u, "frames": fr, "ms": ms_b, "ms_queued": ms_bq,
                           "algorithmic_GBps": fr * 2000 / (ms_b * 1e-3) / 1e9,
-                          "frac_of_hbm_peak": fr * 2000 / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                          "frac_of_hbm_peak": fr * 2000 / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                          "frac_of_hbm_peak_queued": fr * 2000 / (ms_bq * 1e-3) / 1e9 / PEAK_HBM_GBS})
             del feat_b
         res["mlpg"]["batch_curve"] = curve
     if with_cpu:

@@ -313,6 +313,15 @@ __global__ __launch_bounds__(MLPG_LANES) void mlpg_kernel(MlpgArgs a, int t_max)
 //    the way back, put into the upper part of the ring by the helpers once those slots are free;
 //  * the helpers' segment, row and edge arithmetic belongs on the scalar unit (wave number through readfirstlane).
 // Arithmetic: mlpg_kernel's, expression for expression.
+#ifndef MLPG_RING_NT
+#define MLPG_RING_NT 0
+#endif
+// cache policy of the streams (bits: 1 input rows, 2 x stores, 4 y read back, 8 y parked): non-temporal where set.
+// Measured (scripts/r5_job27.sh, every variant on one box, same variances): none of them matters at 4 096 utterances or
+// with float32 rows; float64 rows at 256 utterances 258 -> 247 us with the INPUT rows non-temporal -- the y that is
+// out (156 MB) then survives in the 256-MB memory-side cache until it comes back.  The kernel's NT_IN takes that.
+#define RING_LD(bit, p) (((MLPG_RING_NT & (bit)) || ((bit) == 1 && NT_IN)) ? __builtin_nontemporal_load(p) : *(p))
+#define RING_ST(bit, p, v) do { if (MLPG_RING_NT & (bit)) __builtin_nontemporal_store((v), (p)); else *(p) = (v); } while (0)
 constexpr int RING_LANES = 64, RING_SEG = 24, RING_CAP = 288, RING_HELPERS = 7, RING_THREADS = 64 * (1 + RING_HELPERS);
 constexpr int RING_LDS_BYTES = RING_CAP * RING_LANES * 8 + 128;     // + progress words
 // the factor's head rows for the end of the backward sweep: 3 planes x RING_HEAD_ROWS rows x 64 lanes in slots
@@ -321,7 +330,7 @@ constexpr int RING_HEAD_SLOT = 5 * RING_SEG, RING_HEAD_ROWS = (RING_CAP - RING_H
 static_assert(RING_CAP % RING_SEG == 0 && RING_SEG % 8 == 0, "ring geometry");
 struct RingArgs {
   MlpgArgs a;
-  const int* order;       // utterances, longest first
+  const int64_t* bounds;  // [workgroup rank][2]: first frame, end frame of its utterance (utterances longest first)
   int t_max;
   const float* feat32;    // the input rows when they are float32 (itts_mlpg_generation_f32): a.feat is unused then
 };
@@ -331,7 +340,8 @@ __device__ __forceinline__ int ring_peek(const int* w) { return __hip_atomic_loa
 
 // FT: the type of the input rows (double, or float: the network's own output type -- converted in the load, which is exact)
 // WIDE: the helpers move two dimensions a lane and two rows an instruction (an even number of dimensions)
-template <typename FT, bool WIDE>
+// NT_IN: the input rows are read with the non-temporal hint (see RING_LD)
+template <typename FT, bool WIDE, bool NT_IN>
 __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   extern __shared__ __attribute__((aligned(16))) char rsm[];
   double* ring = reinterpret_cast<double*>(rsm);          // [RING_CAP][64]
@@ -343,13 +353,15 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   const MlpgArgs& a = g.a;
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // the order and offsets tables are read in place from page-locked host memory (no copy on the stream in front of
-  // the launch): one thread fetches this workgroup's three numbers, the others get them through LDS
+  // the utterances' bounds are read in place from page-locked host memory (no copy on the stream in front of the
+  // launch): one thread fetches this workgroup's pair -- one 16-byte load, one trip over the bus --, the others get it
+  // through LDS
   int64_t* bounds = reinterpret_cast<int64_t*>(prog + 24);
   if (tid == 0) {
-    const int u = g.order[blockIdx.y];
-    bounds[0] = a.offsets[u];
-    bounds[1] = a.offsets[u + 1];
+    typedef int64_t Pair __attribute__((ext_vector_type(2)));
+    const Pair b = reinterpret_cast<const Pair*>(g.bounds)[blockIdx.y];
+    bounds[0] = b.x;
+    bounds[1] = b.y;
   }
   if (tid < 24) prog[tid] = 0;
   __syncthreads();
@@ -397,15 +409,15 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
         int r = j0 - 1 + i;
         if (!INNER) r = r < 0 ? 0 : (r < T ? r : T - 1);
         const FT* row = hf + (int64_t)r * a.ld_feat;
-        d1[i] = (double)row[D];
-        d2[i] = (double)row[2 * D];
-        if (i >= 1 && i <= RING_SEG) st[i - 1] = (double)row[0];
+        d1[i] = (double)RING_LD(1, row + D);
+        d2[i] = (double)RING_LD(1, row + 2 * D);
+        if (i >= 1 && i <= RING_SEG) st[i - 1] = (double)RING_LD(1, row);
       }
       while (q - ring_peek(prog) >= ring_segs) __builtin_amdgcn_s_sleep(2);      // the sweep has left segment q - ring_segs
       if (j0 >= RING_CAP && hd < D) {                   // the y of frames j0 - RING_CAP .. leave the ring
 #pragma unroll
         for (int i = 0; i < RING_SEG; ++i)
-          if (INNER || j0 + i < T) o[(int64_t)(j0 + i - RING_CAP) * a.ld_out] = base[i * RING_LANES];
+          if (INNER || j0 + i < T) RING_ST(8, o + (int64_t)(j0 + i - RING_CAP) * a.ld_out, base[i * RING_LANES]);
       }
 #pragma unroll
       for (int i = 0; i < RING_SEG; ++i) {
@@ -480,9 +492,9 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
         int r = j0 - 2 + 2 * p + wh;
         if (!INNER) r = r < 0 ? 0 : (r < T ? r : T - 1);
         const FT* row = whf + (int64_t)r * a.ld_feat;
-        d1[p] = widen(*reinterpret_cast<const V2f*>(row + D));
-        d2[p] = widen(*reinterpret_cast<const V2f*>(row + 2 * D));
-        if (p >= 1 && p <= NP) st[p - 1] = widen(*reinterpret_cast<const V2f*>(row));
+        d1[p] = widen(RING_LD(1, reinterpret_cast<const V2f*>(row + D)));
+        d2[p] = widen(RING_LD(1, reinterpret_cast<const V2f*>(row + 2 * D)));
+        if (p >= 1 && p <= NP) st[p - 1] = widen(RING_LD(1, reinterpret_cast<const V2f*>(row)));
       }
       while (q - ring_peek(prog) >= ring_segs) __builtin_amdgcn_s_sleep(2);      // the sweep has left segment q - ring_segs
       if (j0 >= RING_CAP && wlive) {                   // the y of frames j0 - RING_CAP .. leave the ring
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
         for (int k = 0; k < NP; ++k) {
           const int i = 2 * k + wh;
           if (INNER || j0 + i < T)
-            *reinterpret_cast<V2d*>(wo + (int64_t)(j0 + i - RING_CAP) * a.ld_out) = *reinterpret_cast<const V2d*>(base + i * RING_LANES);
+            RING_ST(8, reinterpret_cast<V2d*>(wo + (int64_t)(j0 + i - RING_CAP) * a.ld_out), *reinterpret_cast<const V2d*>(base + i * RING_LANES));
         }
       }
       // u[p] (delta: u1, delta-delta: u2): the entries of row j0 + 2 p - 3 + wh -- for the frame of pair p in this lane
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
 #pragma unroll
           for (int k = 0; k < NP; ++k) {
             const int j = qf * RING_SEG + 2 * k + wh;
-            yw[k] = (j + RING_CAP < T) ? *reinterpret_cast<const V2d*>(wo + (int64_t)j * a.ld_out) : V2d{0.0, 0.0};
+            yw[k] = (j + RING_CAP < T) ? RING_LD(4, reinterpret_cast<const V2d*>(wo + (int64_t)j * a.ld_out)) : V2d{0.0, 0.0};
           }
         }
         while (ring_peek(prog + 16) > q) __builtin_amdgcn_s_sleep(2);     // the backward sweep has finished segment q
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
 #pragma unroll
           for (int k = 0; k < NP; ++k) {
             const int i = 2 * k + wh;
-            if (j0 + i < T) *reinterpret_cast<V2d*>(wo + (int64_t)(j0 + i) * a.ld_out) = *reinterpret_cast<const V2d*>(wbase + i * RING_LANES);
+            if (j0 + i < T) RING_ST(2, reinterpret_cast<V2d*>(wo + (int64_t)(j0 + i) * a.ld_out), *reinterpret_cast<const V2d*>(wbase + i * RING_LANES));
           }
           if (qf >= 0) {
 #pragma unroll
@@ -621,14 +633,14 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
 #pragma unroll
         for (int k = 0; k < RING_SEG; ++k) {
           const int j = qf * RING_SEG + k;
-          yv[k] = (j + RING_CAP < T) ? o[(int64_t)j * a.ld_out] : 0.0;
+          yv[k] = (j + RING_CAP < T) ? RING_LD(4, o + (int64_t)j * a.ld_out) : 0.0;
         }
       }
       while (ring_peek(prog + 16) > q) __builtin_amdgcn_s_sleep(2);     // the backward sweep has finished segment q
       if (hd < D) {
 #pragma unroll
         for (int k = 0; k < RING_SEG; ++k)
-          if (j0 + k < T) o[(int64_t)(j0 + k) * a.ld_out] = base[k * RING_LANES];
+          if (j0 + k < T) RING_ST(2, o + (int64_t)(j0 + k) * a.ld_out, base[k * RING_LANES]);
         if (qf >= 0) {
 #pragma unroll
           for (int k = 0; k < RING_SEG; ++k) {
@@ -662,6 +674,9 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   double* fd = a.scratch + dc;
   double* fl1 = fd + plane;
   double* fl2 = fl1 + plane;
+  const double pjj_in = tau0 + 0.25 * (tau1f(1) + tau1f(3)) + (tau2f(1) + 4.0 * tau2f(2) + tau2f(3));
+  const double pj1_in = -2.0 * (tau2f(2) + tau2f(3));
+  const double pj2_in = tau2f(1) - 0.25 * tau1f(1);          // (row 0's too)
   const int n_shared = T >= 3 ? T - 2 : 0;
   // the factor: rows 0 .. ncvmax derived on the way forward (a lane's entries stay put from its own row of repetition
   // on: mlpg_factor_block's rule), the stationary entries in three registers from there
@@ -725,12 +740,15 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
           else { tl_d1 = dd; tl_11 = l1; tl_21 = l2; }
         } else if (!settled) {
           if (!lane_settled) {
-            const double pjj = tau0 + 0.25 * (tau1f(j - 1) + tau1f(j + 1)) + (tau2f(j - 1) + 4.0 * tau2f(j) + tau2f(j + 1));
-            const double pj1 = -2.0 * (tau2f(j) + tau2f(j + 1));
-            const double pj2 = tau2f(j + 1) - 0.25 * tau1f(j + 1);
+            // (P's entries are those of row 2 from there on: the same expressions on the same values)
+            double pjj = pjj_in, pj1 = pj1_in;
+            if (j < 2) {
+              pjj = tau0 + 0.25 * (tau1f(j - 1) + tau1f(j + 1)) + (tau2f(j - 1) + 4.0 * tau2f(j) + tau2f(j + 1));
+              pj1 = -2.0 * (tau2f(j) + tau2f(j + 1));
+            }
             dd = factor_rsqrt(pjj - l1p * l1p - l2p * l2p);
             l1 = (pj1 - cprev * l1p) * dd;
-            l2 = pj2 * dd;
+            l2 = pj2_in * dd;
             auto same = [](double x, double y) { return fabs(x - y) <= 8.9e-16 * fabs(y); };
             if (j >= 3 && same(l1, l1p) && same(l2, cprev) && same(cprev, l2p)) {
               lane_settled = true;
@@ -781,6 +799,31 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   };
   counters_for(nseg - 1);
   int seen_b = bq >= 0 ? relaxed(prog + 9 + bh) : 0;
+  // A head too long for the ring (more than RING_HEAD_ROWS rows) is read from the table -- this workgroup's own rows of
+  // it, a sweep's length old.  A trip to the L2 is 0.5 - 1 us, five to ten frames of this sweep: a segment that lies in
+  // the head altogether is therefore straight-line code in two halves of twelve rows, the rows of a half (1 / L[j,j]
+  // and L[j+1,j]; L[j+2,j] is pj2 times the first, as it was formed) asked for while the half before it is worked.
+  constexpr int HALF = RING_SEG / 2;
+  double ud[HALF], u1[HALF], wd[HALF], w1[HALF];        // upper half (rows j0 + 23 .. j0 + 12), lower half (j0 + 11 .. j0)
+  auto table_seg = [&](int sg) {
+    return !staged && sg >= 0 && sg * RING_SEG + RING_SEG <= head_rows && sg * RING_SEG + RING_SEG <= n_shared;
+  };
+  auto load_upper = [&](int sg) {
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const int64_t r = (int64_t)(sg * RING_SEG + RING_SEG - 1 - i) * D;
+      ud[i] = fd[r];
+      u1[i] = fl1[r];
+    }
+  };
+  auto load_lower = [&](int sg) {
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const int64_t r = (int64_t)(sg * RING_SEG + HALF - 1 - i) * D;
+      wd[i] = fd[r];
+      w1[i] = fl1[r];
+    }
+  };
   for (int sgm = nseg - 1; sgm >= 0; --sgm) {
     if (bq >= 0 && seen_b < bneed)
       while (ring_peek(prog + 9 + bh) < bneed) __builtin_amdgcn_s_sleep(1);
@@ -792,7 +835,31 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
     const int j0 = sgm * RING_SEG;
     const int jtop = (j0 + RING_SEG < T ? j0 + RING_SEG : T) - 1;
     double* sl = lane_ring + slot * RING_LANES;
-    if (j0 >= head_rows && j0 + RING_SEG <= n_shared) {
+    const bool cur_tab = table_seg(sgm), next_tab = table_seg(sgm - 1);
+    if (!cur_tab && next_tab) load_upper(sgm - 1);
+    if (cur_tab) {
+      load_lower(sgm);
+      double v[HALF];
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) v[i] = sl[(RING_SEG - 1 - i) * RING_LANES];
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) {
+        const double x = (v[i] - u1[i] * x1 - (pj2_in * ud[i]) * x2) * ud[i];
+        sl[(RING_SEG - 1 - i) * RING_LANES] = x;
+        x2 = x1;
+        x1 = x;
+      }
+      if (next_tab) load_upper(sgm - 1);
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) v[i] = sl[(HALF - 1 - i) * RING_LANES];
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) {
+        const double x = (v[i] - w1[i] * x1 - (pj2_in * wd[i]) * x2) * wd[i];
+        sl[(HALF - 1 - i) * RING_LANES] = x;
+        x2 = x1;
+        x1 = x;
+      }
+    } else if (j0 >= head_rows && j0 + RING_SEG <= n_shared) {
       double v[RING_SEG];
 #pragma unroll
       for (int i = 0; i < RING_SEG; ++i) v[i] = sl[(RING_SEG - 1 - i) * RING_LANES];
@@ -1823,10 +1890,11 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
     int dev = 0;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<double, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+      ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
       if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
     }
     std::vector<int> order(n_utts);
@@ -1834,18 +1902,18 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
       return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
     });
-    const size_t off_bytes = ((size_t)(n_utts + 1) * sizeof(int64_t) + 31) / 32 * 32;
-    std::vector<char> host(off_bytes + (size_t)n_utts * sizeof(int), 0);
-    std::memcpy(host.data(), h_offsets, (size_t)(n_utts + 1) * sizeof(int64_t));
-    std::memcpy(host.data() + off_bytes, order.data(), (size_t)n_utts * sizeof(int));
+    std::vector<int64_t> host(2 * (size_t)n_utts);
+    for (int y = 0; y < n_utts; ++y) {
+      host[2 * y] = h_offsets[order[y]];
+      host[2 * y + 1] = h_offsets[order[y] + 1];
+    }
     itts::PinnedTable table;          // (nothing between here and the launch returns early: the slot goes back after it)
     {
-      const int rc = itts::pinned_table_begin(host.data(), host.size(), &table);
+      const int rc = itts::pinned_table_begin(host.data(), host.size() * sizeof(int64_t), &table);
       if (rc) return rc;
     }
-    const char* tab = static_cast<const char*>(table.p);
-    a.offsets = reinterpret_cast<const int64_t*>(tab);
-    RingArgs g{a, reinterpret_cast<const int*>(tab + off_bytes), (int)t_max, d_feat32};
+    a.offsets = nullptr;          // (the kernel has its bounds in the table)
+    RingArgs g{a, static_cast<const int64_t*>(table.p), (int)t_max, d_feat32};
     // two dimensions a lane in the helpers (half the memory instructions) where that is what the kernel waits for: float32
     // rows in batches of many rounds of workgroups -- 4 096 utterances 2.68 against 3.23 ms.  With float64 rows the
     // kernel moves 3.8 - 4.1 TB/s either way (3.62 / 3.61 ms), and at 256 utterances the exchange's extra arithmetic
@@ -1853,10 +1921,13 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
     const bool wide = dim % 2 == 0 && !getenv("ITTS_MLPG_NARROW") &&
                       (getenv("ITTS_MLPG_WIDE") || (d_feat32 && (int64_t)n_utts * nblk >= 1024));
     const dim3 rgrid((unsigned)nblk, (unsigned)n_utts), rblock(RING_THREADS);
-    if (d_feat32 && wide) hipLaunchKernelGGL((mlpg_ring_kernel<float, true>), rgrid, rblock, RING_LDS_BYTES, s, g);
-    else if (d_feat32) hipLaunchKernelGGL((mlpg_ring_kernel<float, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
-    else if (wide) hipLaunchKernelGGL((mlpg_ring_kernel<double, true>), rgrid, rblock, RING_LDS_BYTES, s, g);
-    else hipLaunchKernelGGL((mlpg_ring_kernel<double, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    // (float64 rows, y small enough to wait in the memory-side cache: input rows non-temporal -- see RING_LD)
+    const bool nt_in = !getenv("ITTS_MLPG_NO_NT") && (int64_t)t_total * dim * 8 <= (int64_t)192 << 20;
+    if (d_feat32 && wide) hipLaunchKernelGGL((mlpg_ring_kernel<float, true, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else if (d_feat32) hipLaunchKernelGGL((mlpg_ring_kernel<float, false, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else if (wide) hipLaunchKernelGGL((mlpg_ring_kernel<double, true, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else if (nt_in) hipLaunchKernelGGL((mlpg_ring_kernel<double, false, true>), rgrid, rblock, RING_LDS_BYTES, s, g);
+    else hipLaunchKernelGGL((mlpg_ring_kernel<double, false, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
     const hipError_t launched = hipGetLastError();
     const int rc_table = itts::pinned_table_end(&table, s);
     if (launched != hipSuccess) {
