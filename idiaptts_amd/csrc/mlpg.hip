@@ -309,8 +309,11 @@ __global__ __launch_bounds__(MLPG_LANES) void mlpg_kernel(MlpgArgs a, int t_max)
 //    runs in ROLLED loops -- unrolled they were 40 KB of code that runs once a workgroup, every line of it an
 //    instruction-cache miss behind the helpers' streams (40 us for the first segment);
 //  * the CU has ONE memory pipeline: a load the sweep waits for queues behind whatever the seven helpers have asked
-//    for (5 us).  The sweep therefore never loads: the head's factor rows are derived on the way forward and, for
-//    the way back, put into the upper part of the ring by the helpers once those slots are free;
+//    for (5 us on the way forward).  The sweep therefore does not wait for loads: the head's factor rows are derived on
+//    the way forward; on the way back -- the helpers only store by then, a trip is the L2's 0.5 - 1 us -- they come
+//    from the table twelve rows ahead of their use;
+//  * every row of the factor's head is a frame off the straight-line path: what a solve takes followed the VARIANCES
+//    (21 to 270 rows until the factor repeats) until the head's own cost was cut (last paragraph);
 //  * the helpers' segment, row and edge arithmetic belongs on the scalar unit (wave number through readfirstlane).
 // Arithmetic: mlpg_kernel's, expression for expression.
 #ifndef MLPG_RING_NT
@@ -324,9 +327,6 @@ __global__ __launch_bounds__(MLPG_LANES) void mlpg_kernel(MlpgArgs a, int t_max)
 #define RING_ST(bit, p, v) do { if (MLPG_RING_NT & (bit)) __builtin_nontemporal_store((v), (p)); else *(p) = (v); } while (0)
 constexpr int RING_LANES = 64, RING_SEG = 24, RING_CAP = 288, RING_HELPERS = 7, RING_THREADS = 64 * (1 + RING_HELPERS);
 constexpr int RING_LDS_BYTES = RING_CAP * RING_LANES * 8 + 128;     // + progress words
-// the factor's head rows for the end of the backward sweep: 3 planes x RING_HEAD_ROWS rows x 64 lanes in slots
-// RING_HEAD_SLOT .. of the ring (those of segments 5 .. 11: free once the sweep is below segment 5)
-constexpr int RING_HEAD_SLOT = 5 * RING_SEG, RING_HEAD_ROWS = (RING_CAP - RING_HEAD_SLOT) / 3;
 static_assert(RING_CAP % RING_SEG == 0 && RING_SEG % 8 == 0, "ring geometry");
 struct RingArgs {
   MlpgArgs a;
@@ -349,7 +349,6 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   // prog[0]: forward sweep: segments finished            prog[1 + h]: helper h, forward: its segments prepared (count)
   // prog[8]: the backward sweep has begun                prog[9 + h]: helper h, backward: its segments stored / refilled (count)
   // prog[16]: backward sweep: lowest segment finished (n_segments: none yet)
-  // prog[17]: helpers that have put their factor rows into the ring     prog[18]: rows of the factor's head (0: too many)
   const MlpgArgs& a = g.a;
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -376,7 +375,6 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   // consecutive slots)
   auto seg_slot = [](int sgm) { return (sgm % ring_segs) * RING_SEG; };
   const int dc = blk * RING_LANES + lane < D ? blk * RING_LANES + lane : D - 1;
-  double* hfac = ring + RING_HEAD_SLOT * RING_LANES;          // [3][RING_HEAD_ROWS][64]
   const int64_t plane = (int64_t)g.t_max * D;                 // the factor table: three planes of t_max rows
 
   if (wave != 0) {
@@ -560,42 +558,8 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
     // this wave's segments, highest first
     int qtop = nseg - 1;
     while (qtop >= 0 && qtop % RING_HELPERS != h) --qtop;
-    // the factor's head rows for the end of the backward sweep (the sweep left them in the table on its way forward;
-    // prog[18] says how many): every helper asks for its share as the way back begins and keeps it in registers until
-    // the slots are free -- the sweep through segment 5 and every helper's segments from there up stored (no y comes
-    // back into those slots: that ends with segment 12) -- which it checks when it gets to the first of its segments
-    // below that, or runs out of segments
-    constexpr int first_seg = RING_HEAD_SLOT / RING_SEG;
-    constexpr int rs_rows = (3 * RING_HEAD_ROWS + RING_HELPERS - 1) / RING_HELPERS;
-    double hv[rs_rows];
     while (ring_peek(prog + 8) == 0) __builtin_amdgcn_s_sleep(2);
-    const int nh = ring_peek(prog + 18);
-    bool restaged = nh == 0;
-    if (!restaged) {
-      const double* tab = a.scratch + dc;
-#pragma unroll
-      for (int i = 0; i < rs_rows; ++i) {
-        const int r = h + i * RING_HELPERS;          // plane r / RING_HEAD_ROWS, row r % RING_HEAD_ROWS
-        if (r % RING_HEAD_ROWS < nh) hv[i] = tab[(r / RING_HEAD_ROWS) * plane + (int64_t)(r % RING_HEAD_ROWS) * D];
-      }
-    }
-    auto restage_write = [&]() {
-      while (ring_peek(prog + 16) > first_seg) __builtin_amdgcn_s_sleep(2);
-      for (int hh = 0; hh < RING_HELPERS; ++hh) {
-        const int qmin = first_seg + ((hh - first_seg) % RING_HELPERS + RING_HELPERS) % RING_HELPERS;
-        const int need = qmin <= nseg - 1 ? (nseg - 1 - qmin) / RING_HELPERS + 1 : 0;
-        while (ring_peek(prog + 9 + hh) < need) __builtin_amdgcn_s_sleep(2);
-      }
-#pragma unroll
-      for (int i = 0; i < rs_rows; ++i) {
-        const int r = h + i * RING_HELPERS;
-        if (r < 3 * RING_HEAD_ROWS && r % RING_HEAD_ROWS < nh) hfac[r * RING_LANES + lane] = hv[i];
-      }
-      if (lane == 0) __hip_atomic_fetch_add(prog + 17, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      restaged = true;
-    };
     for (int q = qtop; q >= 0; q -= RING_HELPERS) {
-      if (!restaged && q < first_seg) restage_write();
       const int j0 = q * RING_SEG;
       double* base = ring + seg_slot(q) * RING_LANES + lane;
       const int qf = q - ring_segs;          // its frames went out on the way forward iff frame + RING_CAP < T
@@ -653,7 +617,6 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
       ++fetched;
       if (lane == 0) ring_post(prog + 9 + h, fetched);
     }
-    if (!restaged) restage_write();
     return;
   }
 
@@ -780,9 +743,8 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   // ---- backward: L^T x = y, segments from the last to the first
   // the head's rows: 0 .. ncvmax - 1 where the factor settled (row ncvmax on is the registers'), else every shared row
   const int head_rows = settled ? ncvmax : n_shared;
-  const bool staged = head_rows <= RING_HEAD_ROWS;     // the helpers put them into the ring; else from the table
+  const int head_last = settled ? ncvmax : n_shared - 1;      // the last row of the table (settled: the stationary one)
   if (lane == 0) {
-    ring_post(prog + 18, staged ? head_rows : 0);
     ring_post(prog + 16, nseg);          // lowest finished segment: none yet
     ring_post(prog + 8, 1);
   }
@@ -799,19 +761,23 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   };
   counters_for(nseg - 1);
   int seen_b = bq >= 0 ? relaxed(prog + 9 + bh) : 0;
-  // A head too long for the ring (more than RING_HEAD_ROWS rows) is read from the table -- this workgroup's own rows of
-  // it, a sweep's length old.  A trip to the L2 is 0.5 - 1 us, five to ten frames of this sweep: a segment that lies in
-  // the head altogether is therefore straight-line code in two halves of twelve rows, the rows of a half (1 / L[j,j]
-  // and L[j+1,j]; L[j+2,j] is pj2 times the first, as it was formed) asked for while the half before it is worked.
+  // The head's rows come back from the table -- this workgroup's own rows of it, a sweep's length old.  A trip to the
+  // L2 is 0.5 - 1 us, five to ten frames of this sweep: a segment that reaches into the head (and holds none of the
+  // two tail frames) is therefore straight-line code in two halves of twelve rows, the rows of a half (1 / L[j,j] and
+  // L[j+1,j]; L[j+2,j] is pj2 times the first, as it was formed) asked for while the half before it is worked; frames
+  // of it above the head read the table's last row, which holds the stationary entries.  (Until late in round 5 the
+  // helpers put heads of up to 56 rows into free slots of the ring for a rolled loop to read: slower than this for 50
+  // rows -- 2.84 against 2.76 ms at 4 096 utterances -- and a progress protocol of its own.)
   constexpr int HALF = RING_SEG / 2;
   double ud[HALF], u1[HALF], wd[HALF], w1[HALF];        // upper half (rows j0 + 23 .. j0 + 12), lower half (j0 + 11 .. j0)
   auto table_seg = [&](int sg) {
-    return !staged && sg >= 0 && sg * RING_SEG + RING_SEG <= head_rows && sg * RING_SEG + RING_SEG <= n_shared;
+    return sg >= 0 && sg * RING_SEG < head_rows && sg * RING_SEG + RING_SEG <= n_shared;
   };
   auto load_upper = [&](int sg) {
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
-      const int64_t r = (int64_t)(sg * RING_SEG + RING_SEG - 1 - i) * D;
+      const int row = sg * RING_SEG + RING_SEG - 1 - i;
+      const int64_t r = (int64_t)(row < head_last ? row : head_last) * D;
       ud[i] = fd[r];
       u1[i] = fl1[r];
     }
@@ -819,7 +785,8 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   auto load_lower = [&](int sg) {
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
-      const int64_t r = (int64_t)(sg * RING_SEG + HALF - 1 - i) * D;
+      const int row = sg * RING_SEG + HALF - 1 - i;
+      const int64_t r = (int64_t)(row < head_last ? row : head_last) * D;
       wd[i] = fd[r];
       w1[i] = fl1[r];
     }
@@ -871,23 +838,15 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
         x1 = x;
       }
     } else {
-      // rolled, as on the way forward; the head's rows from the ring once every helper has put its share there
-      if (staged && j0 < head_rows)
-        while (ring_peek(prog + 17) < RING_HELPERS) __builtin_amdgcn_s_sleep(1);
+      // rolled, as on the way forward (the segment with the tail frames; head rows in it -- an utterance shorter than
+      // the head + a segment -- from the table, a row ahead)
       auto fetch = [&](int j, double& qd, double& q1, double& q2) {
         qd = sd; q1 = sl1; q2 = sl2;
         if (j >= n_shared) {
           const bool last = j == T - 1;
           qd = last ? tl_d1 : tl_d0; q1 = last ? tl_11 : tl_10; q2 = last ? tl_21 : tl_20;
         } else if (j < head_rows) {
-          // (two sources, two branches: behind one generic pointer the rows in the ring would be flat loads, which
-          // take the memory pipeline's queue like any global load)
-          if (staged) {
-            const double* row = hfac + j * RING_LANES + lane;
-            qd = row[0]; q1 = row[RING_HEAD_ROWS * RING_LANES]; q2 = row[2 * RING_HEAD_ROWS * RING_LANES];
-          } else {
-            qd = fd[(int64_t)j * D]; q1 = fl1[(int64_t)j * D]; q2 = fl2[(int64_t)j * D];
-          }
+          qd = fd[(int64_t)j * D]; q1 = fl1[(int64_t)j * D]; q2 = fl2[(int64_t)j * D];
         }
       };
       double ny = sl[(jtop - j0) * RING_LANES], cd, c1, c2;
