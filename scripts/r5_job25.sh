@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r5v; mkdir -p $O
+O=gpurun_out/${TAG:-r5v}; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest.txt
 cat $O/pytest.txt
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench.err
@@ -8,6 +8,6 @@ echo "bench rc $?"
 python3 -c "
 import json
 j=json.loads(open('$O/bench_20_5.json').read().strip().splitlines()[-1])
-print(j['value'], j['ms_per_step'], j['roofline']['frac'], j['world']['analysis_ms'], j['world']['synthesis_ms'], j['world_48k']['analysis_ms'], j['world_48k']['synthesis_ms'], j['mlpg']['ms'])
+print(j['value'], j['ms_per_step'], j['roofline']['frac'], j['world']['analysis_ms'], j['world']['synthesis_ms'], j['world_48k']['analysis_ms'], j['world_48k']['synthesis_ms'], j['mlpg']['ms'], j['mlpg']['ms_queued'], j['mlpg']['roofline']['frac'], [(c['utterances'], round(c['ms'],3), round(c['frac_of_hbm_peak'],3), round(c['frac_of_hbm_peak_queued'],3)) for c in j['mlpg']['batch_curve']])
 "
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
