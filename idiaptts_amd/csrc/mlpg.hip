@@ -1856,11 +1856,20 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
       if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
     }
+    // utterances longest first, equal lengths in their own order: a counting sort over the lengths (a comparison sort
+    // of 4 096 utterances was 0.15 ms of host time in front of a 2.8-ms launch)
     std::vector<int> order(n_utts);
-    for (int u = 0; u < n_utts; ++u) order[u] = u;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-      return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
-    });
+    if (t_max <= (int64_t)1 << 20) {
+      std::vector<int> start((size_t)t_max + 2, 0);
+      for (int u = 0; u < n_utts; ++u) ++start[(size_t)(t_max - (h_offsets[u + 1] - h_offsets[u])) + 1];
+      for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+      for (int u = 0; u < n_utts; ++u) order[start[(size_t)(t_max - (h_offsets[u + 1] - h_offsets[u]))]++] = u;
+    } else {
+      for (int u = 0; u < n_utts; ++u) order[u] = u;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
+      });
+    }
     std::vector<int64_t> host(2 * (size_t)n_utts);
     for (int y = 0; y < n_utts; ++y) {
       host[2 * y] = h_offsets[order[y]];
