@@ -869,6 +869,9 @@ __global__ __launch_bounds__(RING_THREADS) void mlpg_ring_kernel(RingArgs g) {
   }
 }
 
+#undef RING_LD
+#undef RING_ST
+
 // ---- chunk geometry, factor access and the two sweeps of one chunk -------------------------------
 // (shared by the reduce and the solve kernel below)
 template <int FU_FL>
