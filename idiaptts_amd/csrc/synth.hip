@@ -188,8 +188,13 @@ __device__ __forceinline__ double fmod_2pi(double t) {
 // 48 kHz, where an utterance had 71 rounds of 4 096 and only 64 of the 256 CUs have an utterance; unchanged at 16 kHz:
 // 0.59 ms).
 constexpr int PST = 512, PSW = PST / 64;
+// The pulses -- sample i with |wrap[i + 1] - wrap[i]| > pi -- leave with the round that wraps them: counted per thread
+// over its sixteen samples, numbered by one scan over the workgroup, written in order to the utterance's list (what
+// syn_pulse_count_kernel / syn_scan_blocks_kernel / syn_pulse_emit_kernel did in three more passes over the array:
+// 0.29 of the 2 ms in front of the pulse kernel).
 __global__ __launch_bounds__(PST) void syn_phase_scan_kernel(const SynUtt* __restrict__ utts,
-                                                            double* __restrict__ inc_wrap) {
+                                                            double* __restrict__ inc_wrap, int* __restrict__ pidx_all,
+                                                            double* __restrict__ ptot) {
   constexpr int PER = 16, BLK = PST * PER;
   // sample i of the round sits at PH(i) = i + i / 16: a thread's sixteen consecutive samples are read and written 17
   // doubles apart from its neighbour's (at 16 apart -- 128 bytes -- all 64 lanes of a wave hit the same bank: every such
@@ -198,12 +203,24 @@ __global__ __launch_bounds__(PST) void syn_phase_scan_kernel(const SynUtt* __res
   auto PH = [](int i) { return i + (i >> 4); };
   __shared__ PhaseMap wagg[PSW];
   __shared__ int wcut[PSW];
+  __shared__ int wpc[PSW];
   __shared__ double s_total;
   const SynUtt u = utts[blockIdx.x];
   double* a = inc_wrap + u.s_off;
+  int* pidx = pidx_all + u.s_off;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double total = 0.0;      // uniform running sum (value after sample `pos - 1`)
   int pos = 0;
+  int pc = 0;              // pulses so far (uniform)
+  double wprev = 0.0;      // wrapped phase of sample pos - 1 (uniform)
+  // a sample wrapped by the whole workgroup at once (the plain-addition paths): its pair with the sample before it
+  auto single = [&](double wnew) {
+    if (pos >= 1 && fabs(wnew - wprev) > kPi) {
+      if (tid == 0) pidx[pc] = pos - 1;
+      ++pc;
+    }
+    wprev = wnew;
+  };
   int have = -1;           // first sample of the increments held in `pre` (prefetched), or -1
   double pre[PER];
   while (pos < u.yl) {
@@ -234,7 +251,9 @@ __global__ __launch_bounds__(PST) void syn_phase_scan_kernel(const SynUtt* __res
     if (!(total > 0.0) || !(first < ldexp(1.0, e + 2)) || !(first >= 0.0) || e < -900) {
       // a total of zero or a sample that does not fit the integer picture: plain addition
       total = __dadd_rn(total, first);
-      if (tid == 0) a[pos] = fmod(total, 2.0 * kPi);
+      const double wnew = fmod(total, 2.0 * kPi);
+      if (tid == 0) a[pos] = wnew;
+      single(wnew);
       ++pos;
       have = -1;
       __syncthreads();
@@ -316,6 +335,44 @@ __global__ __launch_bounds__(PST) void syn_phase_scan_kernel(const SynUtt* __res
       }
     }
     __syncthreads();
+    {
+      // the round's pulses: pair (li - 1, li) of this thread's samples, the first one against its neighbour's last
+      // (or the round before's)
+      unsigned mask = 0;
+      int myc = 0;
+      double pw = tid > 0 ? buf[PH(tid * PER - 1)] : wprev;
+#pragma unroll
+      for (int r = 0; r < PER; ++r) {
+        const int li = tid * PER + r;
+        if (li < n_ok) {
+          const double cw = buf[PH(li)];
+          const bool pl = (pos + li >= 1) && fabs(cw - pw) > kPi;
+          mask |= (pl ? 1u : 0u) << r;
+          myc += pl ? 1 : 0;
+          pw = cw;
+        }
+      }
+      int incl = myc;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wpc[wv] = incl;
+      __syncthreads();
+      int before = pc + incl - myc, round_total = 0;
+#pragma unroll
+      for (int w = 0; w < PSW; ++w) {
+        const int c = wpc[w];
+        if (w < wv) before += c;
+        round_total += c;
+      }
+#pragma unroll
+      for (int r = 0; r < PER; ++r)
+        if ((mask >> r) & 1u) pidx[before++] = pos + tid * PER + r - 1;
+      pc += round_total;
+      if (n_ok > 0) wprev = buf[PH(n_ok - 1)];
+    }
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
       const int li = r * PST + tid;
@@ -327,12 +384,15 @@ __global__ __launch_bounds__(PST) void syn_phase_scan_kernel(const SynUtt* __res
       have = -1;                         // the prefetched round no longer lines up
       if (pos < u.yl) {                  // the sample that crosses the binade: one real addition
         total = __dadd_rn(total, crossing_inc);
-        if (tid == 0) a[pos] = fmod(total, 2.0 * kPi);
+        const double wnew = fmod(total, 2.0 * kPi);
+        if (tid == 0) a[pos] = wnew;
+        single(wnew);
         ++pos;
       }
     }
     __syncthreads();
   }
+  if (tid == 0) ptot[blockIdx.x] = (double)pc;
 }
 
 // K4: pulses per block (pulse at sample i when |wrap[i+1]-wrap[i]| > pi, i <= yl-2)
@@ -1043,16 +1103,19 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   hipLaunchKernelGGL(syn_inc_kernel, gblk, dim3(NT), 0, s, d_f0, d_utts, p, d_wrap, d_vuv, d_bs);
   ITTS_LAUNCH_CHECK();
   const bool seq_phase = getenv("ITTS_SYNTH_SEQ_PHASE") != nullptr;   // A/B switch for the tests
-  if (seq_phase)
+  if (seq_phase) {
+    // the checker: sequential phase, then the pulses in three passes of their own
     hipLaunchKernelGGL(syn_phase_seq_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_wrap);
-  else
-    hipLaunchKernelGGL(syn_phase_scan_kernel, dim3(n_utts), dim3(PST), 0, s, d_utts, d_wrap);
-  ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syn_pulse_count_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc);
-  ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syn_scan_blocks_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_pc, d_ptot);
-  ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syn_pulse_emit_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc, d_pidx, p);
+    ITTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(syn_pulse_count_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc);
+    ITTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(syn_scan_blocks_kernel, dim3(n_utts), dim3(64), 0, s, d_utts, d_pc, d_ptot);
+    ITTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(syn_pulse_emit_kernel, gblk, dim3(NT), 0, s, d_utts, d_wrap, d_pc, d_pidx, p);
+  } else {
+    // the phase scan leaves the pulse lists and their lengths as it goes
+    hipLaunchKernelGGL(syn_phase_scan_kernel, dim3(n_utts), dim3(PST), 0, s, d_utts, d_wrap, d_pidx, d_ptot);
+  }
   ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(syn_pulse_offsets_kernel, dim3(1), dim3(64), 0, s, d_ptot, n_utts, d_gpoff);
   ITTS_LAUNCH_CHECK();
