@@ -94,6 +94,7 @@ _SIGNATURES = {
     "itts_mgc2sp_gamma": (c_int, [_P, c_int64, c_int, c_double, c_double, c_int, _P, _P, _P, _P]),
     "itts_code_aperiodicity": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P]),
     "itts_decode_aperiodicity": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "itts_decode_aperiodicity_voiced": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "itts_stonemask": (c_int, [_P, POINTER(c_int64), _P, POINTER(c_int64), c_int, c_int, c_double,
                                _P, _P]),
     "itts_d4c": (c_int, [_P, POINTER(c_int64), _P, POINTER(c_int64), c_int, c_int, c_double, c_int,

@@ -556,12 +556,22 @@ def code_aperiodicity(ap, fs, dtype=torch.float64):
     return out
 
 
-def decode_aperiodicity(bap, fs, fft_size):
+def decode_aperiodicity(bap, fs, fft_size, voiced_f0=None):
+    """pyworld.decode_aperiodicity: bap [T, nap] f64 -> ap [T, fft_size / 2 + 1] f64.  With `voiced_f0` (f0 [T] f64)
+    only the rows the synthesis of that contour can read -- voiced frames and their neighbours -- are decoded, the
+    others are uninitialised memory: for world_synthesize and nothing else."""
     L = _lib.load()
     _need(bap, torch.float64, "bap")
     bap = bap.contiguous()
     T = bap.shape[0]
     out = torch.empty((T, fft_size // 2 + 1), dtype=torch.float64, device=bap.device)
+    if voiced_f0 is not None:
+        _need(voiced_f0, torch.float64, "voiced_f0")
+        if voiced_f0.numel() != T:
+            raise ValueError("voiced_f0 and bap differ in frames")
+        _lib.check(L.itts_decode_aperiodicity_voiced(_ptr(bap), _ptr(voiced_f0.contiguous()), T, fs, fft_size,
+                                                     _ptr(out), _stream()), "itts_decode_aperiodicity_voiced")
+        return out
     _lib.check(L.itts_decode_aperiodicity(_ptr(bap), T, fs, fft_size, _ptr(out), _stream()),
                "itts_decode_aperiodicity")
     return out

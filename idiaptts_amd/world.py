@@ -23,6 +23,8 @@ _side_streams = {}
 def _side_stream(dev):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _side_streams:
+        # (stream priorities: this stack has two levels, default and high -- measured, the side stream high or not
+        # makes no difference to where the two streams' kernels end: scripts/r5_job36.sh)
         _side_streams[key] = torch.cuda.Stream(device=dev)
     return _side_streams[key]
 
@@ -195,10 +197,10 @@ def synthesise_features(f0, f_off, fs, n_fft, mc=None, alpha=None, sp=None, bap=
             if mc is not None:
                 sp = ops.mgc2sp(mc, alpha, n_fft, want_pow=True)
             if ap is None:
-                ap = ops.decode_aperiodicity(bap, fs, n_fft)
+                ap = ops.decode_aperiodicity(bap, fs, n_fft, voiced_f0=f0)      # (only the rows a voiced pulse reads)
             ready = torch.cuda.Event()
             ready.record(side)
-        for t in (mc, bap):
+        for t in (mc, bap, f0):
             if t is not None:
                 t.record_stream(side)
     return ops.world_synthesize(f0, sp, ap, f_off, fs, hop_ms, preemphasis, dtype=dtype, spectra_ready=ready,

@@ -378,6 +378,10 @@ int itts_code_aperiodicity(const double* d_ap, int64_t T, int fft_size, int fs, 
                            float* d_bap_f32, void* stream);
 int itts_decode_aperiodicity(const double* d_bap, int64_t T, int fs, int fft_size, double* d_ap,
                              void* stream);
+/* The same for the synthesis that follows (WorldFeatLabelGen.py:940-945): only the rows a voiced pulse can read --
+ * frames with f0 > 0 and their two neighbours, d_f0 [T] f64 -- are written; the rest of d_ap is left untouched. */
+int itts_decode_aperiodicity_voiced(const double* d_bap, const double* d_f0, int64_t T, int fs,
+                                    int fft_size, double* d_ap, void* stream);
 
 /* StoneMask F0 refinement (pyworld.stonemask; second stage of wav2world; also
  * src/data_preparation/world/LF0LabelGen.py:263-264). d_f0_in / d_f0_out [Ttot] f64. */

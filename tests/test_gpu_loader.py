@@ -82,3 +82,24 @@ def test_synthesis_with_spectra_on_the_side_stream_equals_the_sequential_calls(g
     for _ in range(3):
         got, off1 = world.synthesise_features(f0, f_off, fs, n_fft, mc=mc64, alpha=alpha, bap=bap64, hop_ms=hop)
         assert off0 == off1 and torch.equal(want, got)
+
+
+def test_voiced_only_aperiodicity_decode_writes_the_rows_a_voiced_pulse_reads(gpu):
+    """ops.decode_aperiodicity(..., voiced_f0=f0): frames with f0 > 0 and their two neighbours carry exactly what the
+    full decode gives; the synthesis never reads the others (the equality test above is the proof of that)."""
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(11)
+    T, fs, n_fft = 1237, 16000, 1024
+    f0 = torch.zeros(T, dtype=torch.float64)
+    for a, b in ((0, 3), (40, 41), (100, 350), (777, 778), (1230, 1237)):
+        f0[a:b] = 120.0
+    bap = -torch.rand(T, 1, dtype=torch.float64, generator=g) * 30.0
+    bap[5::7] = -0.2          # frames the codec takes for unvoiced (mean above -0.5 dB)
+    full = ops.decode_aperiodicity(bap.to(gpu), fs, n_fft).cpu()
+    part = ops.decode_aperiodicity(bap.to(gpu), fs, n_fft, voiced_f0=f0.to(gpu)).cpu()
+    v = f0 > 0
+    need = v.clone()
+    need[1:] |= v[:-1]
+    need[:-1] |= v[1:]
+    assert 0 < int(need.sum()) < T
+    assert torch.equal(full[need], part[need])
