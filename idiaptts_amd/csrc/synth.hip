@@ -498,7 +498,50 @@ struct PulseArgs {
   SynParams p;
   const double2* g_tw;
   const double* dcr;   // [h + 1]: the Hann half window of RemoveDCComponent, dcr[h] = its doubled sum
+  const int* kq;           // syn_pulse_wave_kernel: the pulses of its kind, per utterance (see syn_pulse_split_kernel)
+  const int64_t* kgpoff;   //                        [n_utts + 1] flat numbering of that kind over the batch
 };
+
+// The pulses by kind (syn_pulse_wave_kernel has a kernel per kind).  kq holds, in the utterance's own stretch of a
+// per-sample int array (yl entries; an utterance has fewer pulses than samples), the numbers -- positions in the
+// utterance's pulse list -- of its unvoiced pulses from the front and of its voiced ones from the back; kcnt[u],
+// kcnt[n_utts + u] count them.  A wave's records go behind one atomic; the order inside a kind is that of the appends
+// (the overlap-add is a sum of atomics either way).
+__global__ __launch_bounds__(NT) void syn_pulse_split_kernel(const SynUtt* __restrict__ utts, const double* __restrict__ ptot,
+                                                             const int* __restrict__ pidx, const uint8_t* __restrict__ vuv,
+                                                             int n_utts, int* __restrict__ kq, int* __restrict__ kcnt) {
+  const int ui = blockIdx.y;
+  const SynUtt u = utts[ui];
+  const int Pn = (int)ptot[ui];
+  const int lane = threadIdx.x & 63;
+  for (int q0 = blockIdx.x * NT; q0 < Pn; q0 += gridDim.x * NT) {
+    const int qi = q0 + (int)threadIdx.x;
+    const bool live = qi < Pn;
+    const bool voiced = live && vuv[u.s_off + pidx[u.s_off + qi]] != 0;
+    for (int kind = 0; kind < 2; ++kind) {
+      const bool mine = live && (voiced == (kind == 1));
+      const unsigned long long bal = __ballot(mine);
+      if (bal == 0) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(kcnt + kind * n_utts + ui, __popcll(bal));
+      base = __shfl(base, 0) + __popcll(bal & ((1ull << lane) - 1ull));
+      if (mine) kq[u.s_off + (kind == 0 ? base : u.yl - 1 - base)] = qi;
+    }
+  }
+}
+
+// flat numbering of each kind over the batch: kgp[kind][u] = sum over u' < u, kgp[kind][n_utts] = total
+__global__ void syn_kind_offsets_kernel(const int* __restrict__ kcnt, int n_utts, int64_t* __restrict__ kgp) {
+  if (threadIdx.x < 2 && blockIdx.x == 0) {
+    const int kind = threadIdx.x;
+    int64_t run = 0;
+    for (int u = 0; u < n_utts; ++u) {
+      kgp[kind * (n_utts + 1) + u] = run;
+      run += kcnt[kind * n_utts + u];
+    }
+    kgp[kind * (n_utts + 1) + n_utts] = run;
+  }
+}
 
 // minimum phase spectrum of the log-amplitude lg[0..h] (in z.x of the first h+1 entries is NOT
 // assumed): input array `lg`, output mp[0..h] complex. Uses z as FFT scratch.  lg is consumed by
@@ -783,7 +826,16 @@ __device__ __forceinline__ void min_phase_wave(double (&v)[9], const wf::Plan512
 #ifndef SYN_WAVE_DIAG
 #define SYN_WAVE_DIAG 0
 #endif
-__global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseArgs a) {
+// A kernel per kind of pulse (round 5): UNV = the unvoiced ones -- nine in ten for speech: a pulse every 2 ms in
+// unvoiced frames, one per pitch period in voiced ones --, which have no periodic response: without its registers (and
+// the DC remover's table and the stash of log amplitudes in LDS) the kernel fits THREE waves per SIMD (168 registers,
+// 47 KB a workgroup) where the general one spills 124 registers at that size; the voiced pulses keep the kernel as it
+// was, at two.  The pulses of a kind come as a list (syn_pulse_split_kernel).
+constexpr int syn_wave_lds_bytes(bool unv) {
+  return wf::WF_TABLE_BYTES + (unv ? 0 : 512 * 8) + (NT / 64) * (wf::WF_LDS_BYTES + (unv ? 0 : (512 + 4) * 8));
+}
+template <bool UNV>
+__global__ __launch_bounds__(NT, UNV ? 3 : SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int fft = 1024, h = 512, K = 513;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -791,17 +843,17 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
   wf::Plan512 P;
   // the DC remover's window over its sum (what every pulse divides out again and again), once per workgroup
   double* dcrn = reinterpret_cast<double*>(smem + wf::WF_TABLE_BYTES);
-  {
+  if (!UNV) {
     const double dsum = a.dcr[h];
     for (int i = threadIdx.x; i < h; i += NT) dcrn[i] = a.dcr[i] / dsum;
   }
   wf::table512_init(smem, a.g_tw);
-  constexpr int kWaveLds = wf::WF_LDS_BYTES + (h + 4) * 8;      // exchange buffer + the stash of 513 log amplitudes
-  char* wave_lds = smem + wf::WF_TABLE_BYTES + h * 8 + (size_t)wv * kWaveLds;
-  double* lgs = reinterpret_cast<double*>(wave_lds + wf::WF_LDS_BYTES);
+  constexpr int kWaveLds = wf::WF_LDS_BYTES + (UNV ? 0 : (h + 4) * 8);      // exchange buffer + the stash of 513 log amplitudes
+  char* wave_lds = smem + wf::WF_TABLE_BYTES + (UNV ? 0 : h * 8) + (size_t)wv * kWaveLds;
+  double* lgs = reinterpret_cast<double*>(wave_lds + wf::WF_LDS_BYTES);      // (not there, and not touched, with UNV)
   wf::plan512_init(P, a.g_tw, wave_lds, smem);
   const double2* dcrn2 = reinterpret_cast<const double2*>(dcrn);
-  const int64_t total = a.gpoff[a.p.n_utts];
+  const int64_t total = a.kgpoff[a.p.n_utts];
   const int64_t nw = (int64_t)gridDim.x * (NT / 64);
   int lo = 0;
   for (int64_t g = (int64_t)blockIdx.x * (NT / 64) + wv; g < total; g += nw) {
@@ -809,11 +861,12 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
     // loop it is a dozen registers held for the whole kernel
     int l = l0;
     asm volatile("" : "+v"(l));
-    while (uni(a.gpoff[lo + 1]) <= g) ++lo;          // utterance of flat pulse g (g only grows)
+    while (uni(a.kgpoff[lo + 1]) <= g) ++lo;          // utterance of pulse g of this kind (g only grows)
     const int64_t u_foff = uni(a.utts[lo].f_off), u_yoff = uni(a.utts[lo].y_off), u_soff = uni(a.utts[lo].s_off);
     const int T = uni(a.utts[lo].T), u_yl = uni(a.utts[lo].yl);
     const int Pn = uni((int)a.ptot[lo]);
-    const int qi = (int)(g - uni(a.gpoff[lo]));
+    const int kn = (int)(g - uni(a.kgpoff[lo]));
+    const int qi = uni(a.kq[u_soff + (UNV ? kn : u_yl - 1 - kn)]);
     const int* pidx = a.pidx + u_soff;
     const int idx = uni(pidx[qi]);
     const int idx_next = uni(pidx[min(Pn - 1, qi + 1)]);
@@ -823,7 +876,7 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
     const double y1 = uni(wrap[idx]) - 2.0 * kPi, y2 = uni(wrap[idx + 1]);
     const double tshift = uni((-y1 / (y2 - y1)) / a.p.fs);
     const double t = idx / (double)a.p.fs;
-    const double vuv = uni((int)a.vuv[u_soff + idx]) ? 1.0 : 0.0;
+    const double vuv = UNV ? 0.0 : 1.0;                 // (the kind of the list)
     int fl = uni((int)floor(t / a.p.fp)), ce = uni((int)ceil(t / a.p.fp));
     if (fl > T - 1) fl = T - 1;
     if (ce > T - 1) ce = T - 1;
@@ -858,7 +911,7 @@ __global__ __launch_bounds__(NT, SYN_WAVE_OCC) void syn_pulse_wave_kernel(PulseA
     };
     double se0, ar0;
     se_ar(0, se0, ar0);
-    const bool has_per = !(vuv <= 0.5 || ar0 > 0.999);
+    const bool has_per = UNV ? false : !(ar0 > 0.999);
     const double coef = uni(2.0 * kPi * tshift * a.p.fs / fft);
     double2 per[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
     double per_dc = 0.0;
@@ -1125,7 +1178,7 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   hipLaunchKernelGGL(syn_dcr_table_kernel, dim3(1), dim3(NT), 0, s, fft_size, d_dcr);
   ITTS_LAUNCH_CHECK();
   PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
-              ctx->tw_compact[p.logfft], d_dcr};
+              ctx->tw_compact[p.logfft], d_dcr, nullptr, nullptr};
   {
     const int nchunks = (max_yl + RCHUNK - 1) / RCHUNK;
     hipLaunchKernelGGL(syn_randn_kernel, dim3((nchunks + NT - 1) / NT, n_utts), dim3(NT), 0, s, d_utts, jt, d_R);
@@ -1137,20 +1190,42 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
     int dev = 0, n_cu = 256;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    const size_t lds = wf::WF_TABLE_BYTES + (size_t)h * 8 + (size_t)(NT / 64) * (wf::WF_LDS_BYTES + (h + 4) * 8);
-    ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+    constexpr size_t lds_v = syn_wave_lds_bytes(false), lds_u = syn_wave_lds_bytes(true);
+    static_assert(SYN_WAVE_OCC * lds_v <= 160 * 1024 && 3 * lds_u <= 160 * 1024, "LDS budget exceeded");
     {
       // more than 64 KB of dynamic LDS: the attribute once per device (runtimes that enforce it fail the launch otherwise)
       static std::atomic<uint64_t> attr_done{0};
       if (dev >= 64 || !((attr_done.load() >> dev) & 1)) {
-        ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_wave_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_wave_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+        ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)syn_pulse_wave_kernel<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_u));
         if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
       }
     }
-    if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
-    hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds, s, a);
+    // the pulses by kind, then a kernel per kind: the unvoiced ones at three waves per SIMD, the voiced ones at two
+    int *d_kq = nullptr, *d_kcnt = nullptr;
+    int64_t* d_kgp = nullptr;
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kq, s_n * 4, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kcnt, (size_t)2 * n_utts * 4, s));
+    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kgp, (size_t)2 * (n_utts + 1) * 8, s));
+    ITTS_HIP_CHECK(hipMemsetAsync(d_kcnt, 0, (size_t)2 * n_utts * 4, s));
+    hipLaunchKernelGGL(syn_pulse_split_kernel, dim3(8, n_utts), dim3(NT), 0, s, d_utts, d_ptot, d_pidx, d_vuv, n_utts,
+                       d_kq, d_kcnt);
     ITTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(syn_kind_offsets_kernel, dim3(1), dim3(64), 0, s, d_kcnt, n_utts, d_kgp);
+    ITTS_LAUNCH_CHECK();
+    if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
+    a.kq = d_kq;
+    a.kgpoff = d_kgp;
+    hipLaunchKernelGGL(syn_pulse_wave_kernel<true>, dim3((unsigned)(3 * n_cu)), dim3(NT), lds_u, s, a);
+    ITTS_LAUNCH_CHECK();
+    a.kgpoff = d_kgp + (n_utts + 1);
+    hipLaunchKernelGGL(syn_pulse_wave_kernel<false>, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds_v, s, a);
+    ITTS_LAUNCH_CHECK();
+    ITTS_HIP_CHECK(itts::scratch_free(d_kq, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_kcnt, s));
+    ITTS_HIP_CHECK(itts::scratch_free(d_kgp, s));
   } else {
     // other transform sizes: one workgroup per pulse, so the host needs the pulse count (copied to a
     // page-locked slot and awaited by polling; the noise generator queued above keeps the GPU busy)
