@@ -593,7 +593,13 @@ __global__ __launch_bounds__(NT) void syn_dcr_table_kernel(int fft, double* __re
 }
 
 // 28 KB of LDS at fft 1024: five workgroups fit a CU when a wave needs <= 102 VGPRs
-template <int CFFT>      // log2 of the transform size as a compile-time constant (11 at 32 .. 48 kHz), 0: any size
+// UNV: the kernel of the unvoiced pulses (see syn_pulse_wave_kernel: a kernel per kind): no periodic response, so no
+// `per` array, and the log amplitudes go straight to min_phase's input inside mp -- 33 KB instead of 49 at fft 2048, four
+// workgroups per CU instead of three for nine pulses in ten
+constexpr size_t syn_pulse_lds_bytes(int h, bool unv) {
+  return 2 * (size_t)(h + 1) * 16 + (unv ? 0 : (size_t)(h + 2) * 8 + (size_t)h * 8) + 16 * 8;
+}
+template <int CFFT, bool UNV>      // CFFT: log2 of the transform size as a compile-time constant (11 at 32 .. 48 kHz), 0: any size
 __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int fft = CFFT ? (1 << CFFT) : a.p.fft, logfft = CFFT ? CFFT : a.p.logfft, h = fft / 2, K = h + 1;
@@ -605,20 +611,25 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
   // the aperiodic response's log amplitudes, formed together with the periodic ones from ONE read of the four
   // spectrum rows (rounds 1-4 kept the interpolated envelope and aperiodicity ratio in two LDS arrays instead:
   // 8 KB more at fft 2048, i.e. two workgroups per CU where three fit now)
-  double* lgs = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
-  double* per = reinterpret_cast<double*>(q); q += (size_t)h * 8;
+  double* lgs = lg;
+  double* per = nullptr;
+  if (!UNV) {
+    lgs = reinterpret_cast<double*>(q); q += (size_t)(K + 1) * 8;
+    per = reinterpret_cast<double*>(q); q += (size_t)h * 8;
+  }
   double* red = reinterpret_cast<double*>(q);
   double* zr = reinterpret_cast<double*>(z);
 
-  const int64_t total = a.gpoff[a.p.n_utts];
-  const int64_t g = blockIdx.x;           // one pulse per workgroup (the host reads the pulse count)
+  const int64_t total = a.kgpoff[a.p.n_utts];
+  const int64_t g = blockIdx.x;           // one pulse of this kind per workgroup (the host reads the counts)
   if (g < total) {
-    // utterance of flat pulse g: every wave reads the offsets 64 at a time and counts (a binary search is log2(U)
-    // dependent trips to memory in front of everything else the pulse does)
-    const int lo = find_utt_wave(a.gpoff, a.p.n_utts, g);
+    // utterance of pulse g of this kind: every wave reads the offsets 64 at a time and counts (a binary search is
+    // log2(U) dependent trips to memory in front of everything else the pulse does)
+    const int lo = find_utt_wave(a.kgpoff, a.p.n_utts, g);
     const SynUtt u = a.utts[lo];
     const int P = (int)a.ptot[lo];
-    const int qi = (int)(g - a.gpoff[lo]);
+    const int kn = (int)(g - a.kgpoff[lo]);
+    const int qi = a.kq[u.s_off + (UNV ? kn : u.yl - 1 - kn)];
     const int* pidx = a.pidx + u.s_off;
     const int idx = pidx[qi];
     const int idx_next = pidx[min(P - 1, qi + 1)];
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
     const double y1 = wrap[idx] - 2.0 * kPi, y2 = wrap[idx + 1];
     const double tshift = (-y1 / (y2 - y1)) / a.p.fs;
     const double t = idx / (double)a.p.fs;
-    const double vuv = a.vuv[u.s_off + idx] ? 1.0 : 0.0;
+    const double vuv = UNV ? 0.0 : 1.0;            // (the kind of the list)
     const int T = u.T;
     int fl = (int)floor(t / a.p.fp), ce = (int)ceil(t / a.p.fp);
     if (fl > T - 1) fl = T - 1;
@@ -1177,16 +1188,42 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_dcr, (size_t)(h + 1) * 8, s));
   hipLaunchKernelGGL(syn_dcr_table_kernel, dim3(1), dim3(NT), 0, s, fft_size, d_dcr);
   ITTS_LAUNCH_CHECK();
+  // the pulses by kind (a pulse kernel per kind: the unvoiced ones without what only a periodic response needs)
+  int *d_kq = nullptr, *d_kcnt = nullptr;
+  int64_t* d_kgp = nullptr;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kq, s_n * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kcnt, (size_t)2 * n_utts * 4, s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kgp, (size_t)2 * (n_utts + 1) * 8, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(d_kcnt, 0, (size_t)2 * n_utts * 4, s));
+  hipLaunchKernelGGL(syn_pulse_split_kernel, dim3(8, n_utts), dim3(NT), 0, s, d_utts, d_ptot, d_pidx, d_vuv, n_utts,
+                     d_kq, d_kcnt);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(syn_kind_offsets_kernel, dim3(1), dim3(64), 0, s, d_kcnt, n_utts, d_kgp);
+  ITTS_LAUNCH_CHECK();
+  const bool wave_kernels = fft_size == 2 * wf::WF_N;
+  int64_t* h_totals[2] = {nullptr, nullptr};
+  hipEvent_t ev_total = nullptr;
+  if (!wave_kernels) {
+    // one workgroup per pulse: the host needs the two counts (copied to page-locked slots and awaited by polling
+    // further down; the noise generator queued behind the copies keeps the GPU busy meanwhile)
+    ITTS_HIP_CHECK(hipEventCreateWithFlags(&ev_total, hipEventDisableTiming));
+    for (int kind = 0; kind < 2; ++kind) {
+      h_totals[kind] = pinned_slot(ctx);
+      ITTS_HIP_CHECK(hipMemcpyAsync(h_totals[kind], d_kgp + kind * (n_utts + 1) + n_utts, sizeof(int64_t),
+                                    hipMemcpyDeviceToHost, s));
+    }
+    ITTS_HIP_CHECK(hipEventRecord(ev_total, s));
+  }
   PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
-              ctx->tw_compact[p.logfft], d_dcr, nullptr, nullptr};
+              ctx->tw_compact[p.logfft], d_dcr, d_kq, d_kgp};
   {
     const int nchunks = (max_yl + RCHUNK - 1) / RCHUNK;
     hipLaunchKernelGGL(syn_randn_kernel, dim3((nchunks + NT - 1) / NT, n_utts), dim3(NT), 0, s, d_utts, jt, d_R);
     ITTS_LAUNCH_CHECK();
   }
-  if (fft_size == 2 * wf::WF_N) {
-    // 16 .. 24 kHz: one wave per pulse, persistent waves (two workgroups of four waves per CU); the
-    // pulse count stays on the device
+  if (wave_kernels) {
+    // 16 .. 24 kHz: one wave per pulse, persistent waves (three or two workgroups of four waves per CU); the
+    // pulse counts stay on the device
     int dev = 0, n_cu = 256;
     ITTS_HIP_CHECK(hipGetDevice(&dev));
     ITTS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1203,37 +1240,15 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
         if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
       }
     }
-    // the pulses by kind, then a kernel per kind: the unvoiced ones at three waves per SIMD, the voiced ones at two
-    int *d_kq = nullptr, *d_kcnt = nullptr;
-    int64_t* d_kgp = nullptr;
-    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kq, s_n * 4, s));
-    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kcnt, (size_t)2 * n_utts * 4, s));
-    ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kgp, (size_t)2 * (n_utts + 1) * 8, s));
-    ITTS_HIP_CHECK(hipMemsetAsync(d_kcnt, 0, (size_t)2 * n_utts * 4, s));
-    hipLaunchKernelGGL(syn_pulse_split_kernel, dim3(8, n_utts), dim3(NT), 0, s, d_utts, d_ptot, d_pidx, d_vuv, n_utts,
-                       d_kq, d_kcnt);
-    ITTS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(syn_kind_offsets_kernel, dim3(1), dim3(64), 0, s, d_kcnt, n_utts, d_kgp);
-    ITTS_LAUNCH_CHECK();
+    // a kernel per kind: the unvoiced pulses at three waves per SIMD, the voiced ones at two
     if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
-    a.kq = d_kq;
-    a.kgpoff = d_kgp;
     hipLaunchKernelGGL(syn_pulse_wave_kernel<true>, dim3((unsigned)(3 * n_cu)), dim3(NT), lds_u, s, a);
     ITTS_LAUNCH_CHECK();
     a.kgpoff = d_kgp + (n_utts + 1);
     hipLaunchKernelGGL(syn_pulse_wave_kernel<false>, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds_v, s, a);
     ITTS_LAUNCH_CHECK();
-    ITTS_HIP_CHECK(itts::scratch_free(d_kq, s));
-    ITTS_HIP_CHECK(itts::scratch_free(d_kcnt, s));
-    ITTS_HIP_CHECK(itts::scratch_free(d_kgp, s));
   } else {
-    // other transform sizes: one workgroup per pulse, so the host needs the pulse count (copied to a
-    // page-locked slot and awaited by polling; the noise generator queued above keeps the GPU busy)
-    int64_t* h_total = pinned_slot(ctx);
-    hipEvent_t ev_total;
-    ITTS_HIP_CHECK(hipEventCreateWithFlags(&ev_total, hipEventDisableTiming));
-    ITTS_HIP_CHECK(hipMemcpyAsync(h_total, d_gpoff + n_utts, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    ITTS_HIP_CHECK(hipEventRecord(ev_total, s));
+    // other transform sizes: one workgroup per pulse
     {
       hipError_t e;
       while ((e = hipEventQuery(ev_total)) == hipErrorNotReady) {
@@ -1241,22 +1256,31 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
       (void)hipEventDestroy(ev_total);
       ITTS_HIP_CHECK(e);
     }
-    const int64_t n_pulses = *h_total;
-    ITTS_REQUIRE(n_pulses >= 0 && n_pulses <= y_total, "corrupt pulse count");
-    if (n_pulses > 0) {
-      const size_t lds = 2 * (size_t)(h + 1) * 16 + (size_t)(h + 2) * 8 +
-                         (size_t)h * 8 + 16 * 8;
+    const int64_t n_unv = *h_totals[0], n_voi = *h_totals[1];
+    ITTS_REQUIRE(n_unv >= 0 && n_voi >= 0 && n_unv + n_voi <= y_total, "corrupt pulse count");
+    if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
+    const bool sized = 2 * h == 2048 && !getenv("ITTS_SYN_GENERIC");
+    for (int kind = 0; kind < 2; ++kind) {
+      const int64_t n_pulses = kind == 0 ? n_unv : n_voi;
+      if (n_pulses == 0) continue;
+      const bool unv = kind == 0;
+      const size_t lds = syn_pulse_lds_bytes(h, unv);
       ITTS_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
-      if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
-      const bool sized = 2 * h == 2048 && !getenv("ITTS_SYN_GENERIC");
-      ITTS_HIP_CHECK(hipFuncSetAttribute(sized ? (const void*)syn_pulse_kernel<11> : (const void*)syn_pulse_kernel<0>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (sized) hipLaunchKernelGGL(syn_pulse_kernel<11>, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
-      else hipLaunchKernelGGL(syn_pulse_kernel<0>, dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      const void* kern = sized ? (unv ? (const void*)syn_pulse_kernel<11, true> : (const void*)syn_pulse_kernel<11, false>)
+                               : (unv ? (const void*)syn_pulse_kernel<0, true> : (const void*)syn_pulse_kernel<0, false>);
+      ITTS_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      a.kgpoff = d_kgp + kind * (n_utts + 1);
+      if (sized && unv) hipLaunchKernelGGL((syn_pulse_kernel<11, true>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      else if (sized) hipLaunchKernelGGL((syn_pulse_kernel<11, false>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      else if (unv) hipLaunchKernelGGL((syn_pulse_kernel<0, true>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
+      else hipLaunchKernelGGL((syn_pulse_kernel<0, false>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
       ITTS_LAUNCH_CHECK();
     }
   }
   ITTS_HIP_CHECK(itts::scratch_free(d_dcr, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_kq, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_kcnt, s));
+  ITTS_HIP_CHECK(itts::scratch_free(d_kgp, s));
   if (preemphasis == 0.0) {
     hipLaunchKernelGGL(syn_cast_kernel, dim3((unsigned)std::min<int64_t>((y_total + 255) / 256, 8192)), dim3(256),
                        0, s, d_y, y_total, d_y_f32, d_y_f64);
