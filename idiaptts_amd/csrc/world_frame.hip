@@ -567,12 +567,17 @@ __global__ __launch_bounds__(256) void decode_aperiodicity_kernel(const double* 
   const int nfr = (int)(T - t0 < DA_FRAMES ? T - t0 : DA_FRAMES);
   unsigned need = 0xffu;          // bit tl: frame t0 + tl has to be decoded
   if (f0) {
-    need = 0;
-    for (int tl = 0; tl < nfr; ++tl) {
-      const int64_t t = t0 + tl;
-      const bool v = f0[t] > 0.0 || (t > 0 && f0[t - 1] > 0.0) || (t + 1 < T && f0[t + 1] > 0.0);
-      need |= (v ? 1u : 0u) << tl;
+    // the ten flags f0[t0 - 1 .. t0 + 8] > 0 by ten lanes at once (a thread walking them was 8 - 24 dependent trips to
+    // memory in front of everything a workgroup does)
+    __shared__ unsigned s_need;
+    if (threadIdx.x < 64) {
+      const int64_t t = t0 - 1 + (int)threadIdx.x;
+      const bool v = (int)threadIdx.x < nfr + 2 && t >= 0 && t < T && f0[t] > 0.0;
+      const unsigned vb = (unsigned)__ballot(v);           // bit i: frame t0 - 1 + i is voiced
+      if (threadIdx.x == 0) s_need = (vb | (vb >> 1) | (vb >> 2)) & ((1u << nfr) - 1u);
     }
+    __syncthreads();
+    need = s_need;
     if (need == 0) return;
   }
   for (int e = threadIdx.x; e < nfr * K; e += 256) {

@@ -39,10 +39,8 @@ if section in ("analysis", "synthesis"):
         # the set-up (one analysis) is the same whatever `passes` is: it cancels in the difference
         f0, mc, bap = analysis()
         mc64, bap64 = mc.double(), bap.double()
-        for _ in range(passes):
-            pw = ops.mgc2sp(mc64, alpha, n_fft, want_pow=True)
-            apd = ops.decode_aperiodicity(bap64, fs, n_fft)
-            ops.world_synthesize(f0, pw, apd, f_off, fs, 5.0)
+        for _ in range(passes):          # (as the bench runs it: spectra on the side stream, voiced-only decode)
+            world.synthesise_features(f0, f_off, fs, n_fft, mc=mc64, alpha=alpha, bap=bap64)
 elif section in ("bilstm", "bigru"):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
