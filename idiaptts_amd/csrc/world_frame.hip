@@ -554,7 +554,9 @@ __global__ void code_aperiodicity_kernel(const double* __restrict__ ap, int64_t 
 // A workgroup owns DA_FRAMES consecutive frames (contiguous in the output); element e of its range is
 // bin k of its frame tl with e = tl (2^lg + 1) + k -- a shift and a correction instead of the 64-bit
 // division a flat element index needs (the pass was VALU-bound on it: 0.54 ms for 1.3 GB out).
-constexpr int DA_FRAMES = 8;
+// (32 frames a workgroup: with 8 the launch of 39 000 workgroups -- 11 ns each -- was what the pass took, 0.43 ms whether
+// it wrote every row or a third of them)
+constexpr int DA_FRAMES = 32;
 // f0 (or null): only the rows a VOICED pulse of the synthesis can read are decoded -- a pulse is voiced when the V/UV
 // flags of the two frames around it interpolate above one half, so one of them has f0 > 0, and it reads exactly those
 // two rows: row t is needed iff one of f0[t - 1], f0[t], f0[t + 1] is positive (a superset at the seams between
@@ -565,16 +567,16 @@ __global__ __launch_bounds__(256) void decode_aperiodicity_kernel(const double* 
   const int K = fft_size / 2 + 1;
   const int64_t t0 = (int64_t)blockIdx.x * DA_FRAMES;
   const int nfr = (int)(T - t0 < DA_FRAMES ? T - t0 : DA_FRAMES);
-  unsigned need = 0xffu;          // bit tl: frame t0 + tl has to be decoded
+  unsigned need = 0xffffffffu;    // bit tl: frame t0 + tl has to be decoded
   if (f0) {
-    // the ten flags f0[t0 - 1 .. t0 + 8] > 0 by ten lanes at once (a thread walking them was 8 - 24 dependent trips to
-    // memory in front of everything a workgroup does)
+    // the flags f0[t0 - 1 .. t0 + DA_FRAMES] > 0 by as many lanes at once (a thread walking them was dozens of dependent
+    // trips to memory in front of everything a workgroup does)
     __shared__ unsigned s_need;
     if (threadIdx.x < 64) {
       const int64_t t = t0 - 1 + (int)threadIdx.x;
       const bool v = (int)threadIdx.x < nfr + 2 && t >= 0 && t < T && f0[t] > 0.0;
-      const unsigned vb = (unsigned)__ballot(v);           // bit i: frame t0 - 1 + i is voiced
-      if (threadIdx.x == 0) s_need = (vb | (vb >> 1) | (vb >> 2)) & ((1u << nfr) - 1u);
+      const unsigned long long vb = __ballot(v);           // bit i: frame t0 - 1 + i is voiced
+      if (threadIdx.x == 0) s_need = (unsigned)((vb | (vb >> 1) | (vb >> 2)) & ((1ull << nfr) - 1ull));
     }
     __syncthreads();
     need = s_need;

@@ -26,6 +26,13 @@ _, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, 5.0, n_fft, want_sp=Fals
 mc64, bap64 = mc.double(), bap.double()
 print("voiced frames: %.3f of %d" % (float((f0 > 0).double().mean()), f0.numel()))
 torch.cuda.synchronize()
+times = []
 for _ in range(passes):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     y, y_off = world.synthesise_features(f0, f_off, fs, n_fft, mc=mc64, alpha=alpha, bap=bap64)
+    e1.record()
     torch.cuda.synchronize()
+    times.append(e0.elapsed_time(e1))
+times.sort()
+print("synthesis: median %.3f ms  min %.3f ms  (%d passes)" % (times[len(times) // 2], times[0], passes))
