@@ -315,7 +315,8 @@ struct D4cArgs {
   int64_t ld_bap;
   const double2* g_tw;    // compact table of the largest transform (DeviceContext::tw_compact)
   int bmax;
-  const int* order;       // workgroup -> frame: voiced frames first (they do all the work)
+  const int* order;       // frames with f0 != 0 first (one workgroup each), order[t_total] = how many
+  int64_t t_total;
   const double* nwin;     // [wl] Nuttall window of the coarse-aperiodicity bands (d4c_nuttall_kernel)
 };
 
@@ -702,6 +703,32 @@ __global__ __launch_bounds__(NT, AREG ? 2 : 3) void d4c_kernel(D4cArgs a) {
   }
 }
 
+// The frames with f0 = 0 -- seven in ten of a speech-like batch --: aperiodicity 1 - eps in every bin, its coded form
+// 20 log10(1 - eps) in every band (what d4c_kernel writes for a frame it finds unvoiced).  They used to get a workgroup
+// of d4c_kernel each, 41 KB of LDS held for a few loads: over a millisecond of dispatching and retiring at 16 kHz.
+__global__ __launch_bounds__(256) void d4c_unvoiced_kernel(D4cArgs a) {
+  const int K = a.fft_size / 2 + 1;
+  const int n_active = a.order[a.t_total];
+  const int64_t n_rest = a.t_total - n_active;
+  const double apv = 1.0 - kEps;
+  const double bv = 20.0 * log10(1.0 - kEps);
+  if (a.ap) {
+    // a wave per frame: rows of K values
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rest; r += (int64_t)gridDim.x * 4) {
+      const int64_t g = a.order[n_active + r];
+      for (int k = lane; k < K; k += 64) a.ap[g * K + k] = apv;
+    }
+  }
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rest; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = a.order[n_active + r];
+    for (int b = 0; b < a.nap; ++b) {
+      if (a.bap_f64) a.bap_f64[g * a.nap + b] = bv;
+      if (a.bap_f32) a.bap_f32[g * a.ld_bap + b] = (float)bv;
+    }
+  }
+}
+
 }  // namespace itts
 
 using namespace itts;
@@ -841,15 +868,37 @@ extern "C" int itts_d4c(const double* d_x, const int64_t* h_x_off, const double*
   hipLaunchKernelGGL(d4c_nuttall_kernel, dim3((wl + 255) / 256), dim3(256), 0, s, wl, d_nwin);
   ITTS_LAUNCH_CHECK();
   a.nwin = d_nwin;
-  if (areg && sized)
-    hipLaunchKernelGGL((d4c_kernel<true, 12>), dim3((unsigned)t_total), dim3(NT), lds, s, a);
-  else if (areg)
-    hipLaunchKernelGGL(d4c_kernel<true>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
-  else if (sized)
-    hipLaunchKernelGGL((d4c_kernel<false, 11>), dim3((unsigned)t_total), dim3(NT), lds, s, a);
-  else
-    hipLaunchKernelGGL(d4c_kernel<false>, dim3((unsigned)t_total), dim3(NT), lds, s, a);
-  ITTS_LAUNCH_CHECK();
+  a.t_total = t_total;
+  // how many frames have f0 != 0: the host asks (a page-locked slot, awaited by polling while the kernel of the other
+  // frames and whatever the caller queued on its other streams run) and launches a workgroup for exactly those
+  int64_t* h_active = pinned_slot(ctx);
+  {
+    hipEvent_t ev = nullptr;
+    ITTS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // (cnt[0] and cnt[1] are ints next to each other: one 8-byte copy, the low word is the count)
+    ITTS_HIP_CHECK(hipMemcpyAsync(h_active, d_order + t_total, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    ITTS_HIP_CHECK(hipEventRecord(ev, s));
+    hipLaunchKernelGGL(d4c_unvoiced_kernel, dim3((unsigned)std::min<int64_t>((t_total + 255) / 256, 2048)), dim3(256), 0, s, a);
+    hipError_t e;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
+    }
+    (void)hipEventDestroy(ev);
+    ITTS_HIP_CHECK(e);
+    ITTS_LAUNCH_CHECK();
+  }
+  const int64_t n_active = (int64_t)(uint32_t)(*h_active & 0xffffffff);
+  ITTS_REQUIRE(n_active >= 0 && n_active <= t_total, "corrupt frame count");
+  if (n_active > 0) {
+    if (areg && sized)
+      hipLaunchKernelGGL((d4c_kernel<true, 12>), dim3((unsigned)n_active), dim3(NT), lds, s, a);
+    else if (areg)
+      hipLaunchKernelGGL(d4c_kernel<true>, dim3((unsigned)n_active), dim3(NT), lds, s, a);
+    else if (sized)
+      hipLaunchKernelGGL((d4c_kernel<false, 11>), dim3((unsigned)n_active), dim3(NT), lds, s, a);
+    else
+      hipLaunchKernelGGL(d4c_kernel<false>, dim3((unsigned)n_active), dim3(NT), lds, s, a);
+    ITTS_LAUNCH_CHECK();
+  }
   ITTS_HIP_CHECK(itts::scratch_free(d_nwin, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_order, s));
   ITTS_HIP_CHECK(itts::scratch_free(d_xo, s));
