@@ -1125,15 +1125,16 @@ __global__ __launch_bounds__(64) void syn_deemph_kernel(const double* __restrict
 
 using namespace itts;
 
-// spectra_ready: an event behind which d_sp and d_ap are complete (or null: they are, on `stream`).  Everything up to
-// the pulse kernel -- the per-sample phase, the pulse positions, the noise -- reads d_f0 only (a third of a 16 kHz
-// synthesis by launches, latency-bound, the chip mostly idle); the stream waits for the event right in front of the
-// pulse kernel, so a caller can produce the spectra (mgc2sp, decode_aperiodicity: bound by their 1.3-GB outputs) on
-// another stream meanwhile.
+// spectra_ready / ap_ready: events behind which d_sp / d_ap are complete (or null: it is, on `stream`).  Everything up
+// to the pulse kernels -- the per-sample phase, the pulse positions, the noise -- reads d_f0 only (a third of a 16 kHz
+// synthesis by launches, latency-bound); the stream waits for the envelope right in front of the kernel of the unvoiced
+// pulses and for the aperiodicity, which only a voiced pulse reads, in front of the kernel of the voiced ones, so a
+// caller can produce the two arrays (mgc2sp, decode_aperiodicity) on another stream meanwhile.
 static int world_synthesize_impl(const double* d_f0, const double* d_sp, const double* d_ap,
                                  const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
                                  double frame_period_ms, int fft_size, double preemphasis,
-                                 float* d_y_f32, double* d_y_f64, void* stream, hipEvent_t spectra_ready) {
+                                 float* d_y_f32, double* d_y_f64, void* stream, hipEvent_t spectra_ready,
+                                 hipEvent_t ap_ready) {
   ITTS_REQUIRE(h_f_off && h_y_off && (n_utts == 0 || (d_f0 && d_sp && d_ap && (d_y_f32 || d_y_f64))), "null pointer");
   ITTS_REQUIRE(n_utts >= 0 && fs > 0 && frame_period_ms > 0, "bad sizes");
   ITTS_REQUIRE(fft_size >= 256 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0,
@@ -1267,9 +1268,11 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
       }
     }
     // a kernel per kind: the unvoiced pulses at three waves per SIMD, the voiced ones at two
+    // (the unvoiced pulses read the envelope only: the aperiodicity may still be on its way while their kernel runs)
     if (spectra_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, spectra_ready, 0));
     hipLaunchKernelGGL(syn_pulse_wave_kernel<true>, dim3((unsigned)(3 * n_cu)), dim3(NT), lds_u, s, a);
     ITTS_LAUNCH_CHECK();
+    if (ap_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, ap_ready, 0));
     a.kgpoff = d_kgp + (n_utts + 1);
     hipLaunchKernelGGL(syn_pulse_wave_kernel<false>, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds_v, s, a);
     ITTS_LAUNCH_CHECK();
@@ -1296,6 +1299,7 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
                                : (unv ? (const void*)syn_pulse_kernel<0, true> : (const void*)syn_pulse_kernel<0, false>);
       ITTS_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       a.kgpoff = d_kgp + kind * (n_utts + 1);
+      if (!unv && ap_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, ap_ready, 0));
       if (sized && unv) hipLaunchKernelGGL((syn_pulse_kernel<11, true>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
       else if (sized) hipLaunchKernelGGL((syn_pulse_kernel<11, false>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
       else if (unv) hipLaunchKernelGGL((syn_pulse_kernel<0, true>), dim3((unsigned)n_pulses), dim3(NT), lds, s, a);
@@ -1339,13 +1343,15 @@ extern "C" int itts_world_synthesize(const double* d_f0, const double* d_sp, con
                                      double frame_period_ms, int fft_size, double preemphasis,
                                      float* d_y_f32, double* d_y_f64, void* stream) {
   return world_synthesize_impl(d_f0, d_sp, d_ap, h_f_off, h_y_off, n_utts, fs, frame_period_ms, fft_size,
-                               preemphasis, d_y_f32, d_y_f64, stream, nullptr);
+                               preemphasis, d_y_f32, d_y_f64, stream, nullptr, nullptr);
 }
 
 extern "C" int itts_world_synthesize_after(const double* d_f0, const double* d_sp, const double* d_ap,
                                            const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
                                            double frame_period_ms, int fft_size, double preemphasis,
-                                           float* d_y_f32, double* d_y_f64, void* stream, void* spectra_ready_event) {
+                                           float* d_y_f32, double* d_y_f64, void* stream, void* envelope_ready_event,
+                                           void* aperiodicity_ready_event) {
   return world_synthesize_impl(d_f0, d_sp, d_ap, h_f_off, h_y_off, n_utts, fs, frame_period_ms, fft_size,
-                               preemphasis, d_y_f32, d_y_f64, stream, reinterpret_cast<hipEvent_t>(spectra_ready_event));
+                               preemphasis, d_y_f32, d_y_f64, stream, reinterpret_cast<hipEvent_t>(envelope_ready_event),
+                               reinterpret_cast<hipEvent_t>(aperiodicity_ready_event));
 }

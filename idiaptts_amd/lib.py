@@ -109,7 +109,7 @@ _SIGNATURES = {
     "itts_world_synthesize": (c_int, [_P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int,
                                       c_double, c_int, c_double, _P, _P, _P]),
     "itts_world_synthesize_after": (c_int, [_P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int,
-                                      c_double, c_int, c_double, _P, _P, _P, _P]),
+                                      c_double, c_int, c_double, _P, _P, _P, _P, _P]),
     "itts_lstm_state_bytes": (c_int64, [c_int, c_int, c_int]),
     "itts_lstm_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P,
                                     _P, _P, _P, _P, _P, _P]),

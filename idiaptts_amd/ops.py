@@ -679,10 +679,11 @@ def synth_offsets(f_off, fs, frame_period=5.0):
 
 
 def world_synthesize(f0, sp, ap, f_off, fs, frame_period=5.0, preemphasis=0.0,
-                     dtype=torch.float32, spectra_ready=None, y_off=None):
+                     dtype=torch.float32, spectra_ready=None, y_off=None, ap_ready=None):
     """pyworld.synthesize + float32 cast + de-pre-emphasis for utterances stored back to back.
-    Returns (y [Ytot], y_off list).  spectra_ready: a torch.cuda.Event recorded behind the producers of sp and ap when
-    they run on another stream (the part of the synthesis in front of the pulse kernel needs f0 only and does not wait)."""
+    Returns (y [Ytot], y_off list).  spectra_ready: a torch.cuda.Event recorded behind the producer of sp (and of ap,
+    unless ap_ready is given: an event of its own behind the producer of ap) when they run on another stream: the part
+    of the synthesis in front of the pulse kernels needs f0 only, the unvoiced pulses the envelope only."""
     L = _lib.load()
     for t, n in ((f0, "f0"), (sp, "sp"), (ap, "ap")):
         _need(t, torch.float64, n)
@@ -701,7 +702,9 @@ def world_synthesize(f0, sp, ap, f_off, fs, frame_period=5.0, preemphasis=0.0,
     if spectra_ready is None:
         _lib.check(L.itts_world_synthesize(*args), "itts_world_synthesize")
     else:
-        _lib.check(L.itts_world_synthesize_after(*args, ctypes.c_void_p(spectra_ready.cuda_event)),
+        ap_ev = ap_ready if ap_ready is not None else spectra_ready
+        _lib.check(L.itts_world_synthesize_after(*args, ctypes.c_void_p(spectra_ready.cuda_event),
+                                                 ctypes.c_void_p(ap_ev.cuda_event)),
                    "itts_world_synthesize_after")
         cur = torch.cuda.current_stream(f0.device)
         sp.record_stream(cur)

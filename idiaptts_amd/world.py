@@ -188,24 +188,27 @@ def synthesise_features(f0, f_off, fs, n_fft, mc=None, alpha=None, sp=None, bap=
     noise): the two [Ttot, K] arrays are only needed by the pulse kernel.  Returns (y [Ytot], y_off)."""
     dev = f0.device
     main = torch.cuda.current_stream(dev)
-    ready = None
+    ready = ap_ready = None
     y_off = ops.synth_offsets(f_off, fs, hop_ms)      # (host work first: nothing between the two streams' launches)
     if mc is not None or ap is None:
         side = _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            # (the product first, the short decode behind it: 9.30 against 9.52 ms for a synthesis the other way round)
+            # (the envelope first -- the kernel of the unvoiced pulses waits for it alone --, the decode behind it with
+            # an event of its own for the kernel of the voiced ones)
             if mc is not None:
                 sp = ops.mgc2sp(mc, alpha, n_fft, want_pow=True)
-            if ap is None:
-                ap = ops.decode_aperiodicity(bap, fs, n_fft, voiced_f0=f0)      # (only the rows a voiced pulse reads)
             ready = torch.cuda.Event()
             ready.record(side)
+            if ap is None:
+                ap = ops.decode_aperiodicity(bap, fs, n_fft, voiced_f0=f0)      # (only the rows a voiced pulse reads)
+                ap_ready = torch.cuda.Event()
+                ap_ready.record(side)
         for t in (mc, bap, f0):
             if t is not None:
                 t.record_stream(side)
     return ops.world_synthesize(f0, sp, ap, f_off, fs, hop_ms, preemphasis, dtype=dtype, spectra_ready=ready,
-                                y_off=y_off)
+                                y_off=y_off, ap_ready=ap_ready)
 
 
 def synthesise_batch(f0s, sps, baps, fs, n_fft, hop_ms=5.0, preemphasis=0.0, device=None,

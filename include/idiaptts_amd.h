@@ -434,14 +434,16 @@ int itts_world_synthesize(const double* d_f0, const double* d_sp, const double* 
                           const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
                           double frame_period_ms, int fft_size, double preemphasis, float* d_y_f32,
                           double* d_y_f64, void* stream);
-/* The same, with the spectra still being produced when the call is made: everything in front of the pulse kernel (the
- * per-sample phase, the pulse positions, the noise: a third of the launches, bound by latency) needs d_f0 only, and
- * `stream` waits for `spectra_ready_event` (a hipEvent_t recorded behind the producers of d_sp and d_ap on whatever
- * stream they ran; NULL: as itts_world_synthesize) right before the pulse kernel. */
+/* The same, with the spectra still being produced when the call is made: everything in front of the pulse kernels (the
+ * per-sample phase, the pulse positions, the noise: a third of the launches, bound by latency) needs d_f0 only.  `stream`
+ * waits for `envelope_ready_event` (a hipEvent_t recorded behind the producer of d_sp on whatever stream it ran) right
+ * before the kernel of the unvoiced pulses, which read the envelope only, and for `aperiodicity_ready_event` (behind
+ * the producer of d_ap) before the kernel of the voiced ones.  NULL: that array is complete on `stream`. */
 int itts_world_synthesize_after(const double* d_f0, const double* d_sp, const double* d_ap,
                                 const int64_t* h_f_off, const int64_t* h_y_off, int n_utts, int fs,
                                 double frame_period_ms, int fft_size, double preemphasis,
-                                float* d_y_f32, double* d_y_f64, void* stream, void* spectra_ready_event);
+                                float* d_y_f32, double* d_y_f64, void* stream, void* envelope_ready_event,
+                                void* aperiodicity_ready_event);
 
 /* ---- acoustic model: (Bi)LSTM recurrence (torch.nn.LSTM inside rnn_dyn/RNNWrapper.py:45-107) ------
  * Packed rows, the layout pack_padded_sequence produces (RNNWrapper.py:89-92): the B sequences are
