@@ -527,6 +527,7 @@ struct PulseArgs {
   const double* dcr;   // [h + 1]: the Hann half window of RemoveDCComponent, dcr[h] = its doubled sum
   const int* kq;           // syn_pulse_wave_kernel: the pulses of its kind, per utterance (see syn_pulse_split_kernel)
   const int64_t* kgpoff;   //                        [n_utts + 1] flat numbering of that kind over the batch
+  int* next;               //                        the kind's pulses handed out so far (zero at launch)
 };
 
 // The pulses by kind (syn_pulse_wave_kernel has a kernel per kind).  kq holds, in the utterance's own stretch of a
@@ -864,6 +865,13 @@ __device__ __forceinline__ void min_phase_wave(double (&v)[9], const wf::Plan512
 #ifndef SYN_WAVE_DIAG
 #define SYN_WAVE_DIAG 0
 #endif
+// pulses a wave takes from its kind's list at a time (0: dealt by stride, as until late in round 5)
+#ifndef SYN_WAVE_DEAL_UNV
+#define SYN_WAVE_DEAL_UNV 4
+#endif
+#ifndef SYN_WAVE_DEAL_VOI
+#define SYN_WAVE_DEAL_VOI 2
+#endif
 // A kernel per kind of pulse (round 5): UNV = the unvoiced ones -- nine in ten for speech: a pulse every 2 ms in
 // unvoiced frames, one per pitch period in voiced ones --, which have no periodic response: without its registers (and
 // the DC remover's table and the stash of log amplitudes in LDS) the kernel fits THREE waves per SIMD (168 registers,
@@ -894,7 +902,27 @@ __global__ __launch_bounds__(NT, UNV ? 3 : SYN_WAVE_OCC) void syn_pulse_wave_ker
   const int64_t total = a.kgpoff[a.p.n_utts];
   const int64_t nw = (int64_t)gridDim.x * (NT / 64);
   int lo = 0;
+  constexpr int kDeal = UNV ? SYN_WAVE_DEAL_UNV : SYN_WAVE_DEAL_VOI;
+#if SYN_WAVE_DEAL_UNV && SYN_WAVE_DEAL_VOI
+  // The pulses are handed out kDeal at a time behind a counter (a wave's pulses still only grow).  Dealt by stride
+  // -- pulse g to wave g mod nw -- the kernel lasted as long as its last workgroup to START: one that finds its CU
+  // taken by the tail of another stream's kernel (the caller's decode_aperiodicity) starts when some workgroup has
+  // FINISHED its share, and does its own share behind everybody else's (7.2 instead of 5.4 ms when the two met,
+  // profiles/r5ap_timeline_noise_on_side_stream.txt).
+  (void)nw;
+  int64_t g = 0, g_end = 0;
+  for (;; ++g) {
+    if (g >= g_end) {
+      int base = 0;
+      if (l0 == 0) base = atomicAdd(a.next, kDeal);
+      g = uni(base);
+      if (g >= total) break;
+      g_end = min(g + kDeal, total);
+    }
+#else
+  (void)kDeal;
   for (int64_t g = (int64_t)blockIdx.x * (NT / 64) + wv; g < total; g += nw) {
+#endif
     // opaque per pulse: what derives from the lane number is a few integer operations; hoisted out of the
     // loop it is a dozen registers held for the whole kernel
     int l = l0;
@@ -1219,9 +1247,11 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   int *d_kq = nullptr, *d_kcnt = nullptr;
   int64_t* d_kgp = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kq, s_n * 4, s));
-  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kcnt, (size_t)2 * n_utts * 4, s));
+  // (+ the two pulse kernels' counters; a multiple of 256 bytes: one fill instead of two)
+  const size_t kcnt_bytes = (((size_t)(2 * n_utts + 2) * 4 + 255) / 256) * 256;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kcnt, kcnt_bytes, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kgp, (size_t)2 * (n_utts + 1) * 8, s));
-  ITTS_HIP_CHECK(hipMemsetAsync(d_kcnt, 0, (size_t)2 * n_utts * 4, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(d_kcnt, 0, kcnt_bytes, s));
   hipLaunchKernelGGL(syn_pulse_split_kernel, dim3(8, n_utts), dim3(NT), 0, s, d_utts, d_ptot, d_pidx, d_vuv, n_utts,
                      d_kq, d_kcnt);
   ITTS_LAUNCH_CHECK();
@@ -1242,7 +1272,7 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
     ITTS_HIP_CHECK(hipEventRecord(ev_total, s));
   }
   PulseArgs a{d_f0, d_sp, d_ap, d_utts, d_gpoff, d_ptot, d_pidx, d_wrap, d_vuv, d_R, d_y, p,
-              ctx->tw_compact[p.logfft], d_dcr, d_kq, d_kgp};
+              ctx->tw_compact[p.logfft], d_dcr, d_kq, d_kgp, d_kcnt + 2 * n_utts};
   {
     const int nchunks = (max_yl + RCHUNK - 1) / RCHUNK;
     hipLaunchKernelGGL(syn_randn_kernel, dim3((nchunks + NT - 1) / NT, n_utts), dim3(NT), 0, s, d_utts, jt, d_R);
@@ -1274,6 +1304,7 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
     ITTS_LAUNCH_CHECK();
     if (ap_ready) ITTS_HIP_CHECK(hipStreamWaitEvent(s, ap_ready, 0));
     a.kgpoff = d_kgp + (n_utts + 1);
+    a.next = d_kcnt + 2 * n_utts + 1;
     hipLaunchKernelGGL(syn_pulse_wave_kernel<false>, dim3((unsigned)(SYN_WAVE_OCC * n_cu)), dim3(NT), lds_v, s, a);
     ITTS_LAUNCH_CHECK();
   } else {
