@@ -469,15 +469,29 @@ __global__ __launch_bounds__(NT) void syn_pulse_emit_kernel(const SynUtt* __rest
 }
 
 // flat pulse numbering over the batch: gpoff[u] = sum_{u'<u} P_u', gpoff[U] = total
-__global__ void syn_pulse_offsets_kernel(const double* __restrict__ ptot, int n_utts, int64_t* __restrict__ gpoff) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int64_t run = 0;
-    for (int u = 0; u < n_utts; ++u) {
-      gpoff[u] = run;
-      run += (int64_t)ptot[u];
+// exclusive sums of n values by ONE wave, 64 at a time (a lone thread walking 256 utterances took 45-70 us right in
+// front of the pulse kernels: a dependent load and store per utterance)
+template <class Load>
+__device__ __forceinline__ void wave_offsets(int n, Load load, int64_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  int64_t carry = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int u = base + lane;
+    const int64_t v = u < n ? load(u) : 0;
+    int64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int64_t o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
     }
-    gpoff[n_utts] = run;
+    if (u < n) out[u] = carry + inc - v;
+    carry += __shfl(inc, 63);
   }
+  if (lane == 0) out[n] = carry;
+}
+__global__ __launch_bounds__(64) void syn_pulse_offsets_kernel(const double* __restrict__ ptot, int n_utts,
+                                                               int64_t* __restrict__ gpoff) {
+  if (blockIdx.x == 0) wave_offsets(n_utts, [&](int u) { return (int64_t)ptot[u]; }, gpoff);
 }
 
 // ---- WORLD randn stream with jump-ahead ---------------------------------------------------------
@@ -559,16 +573,11 @@ __global__ __launch_bounds__(NT) void syn_pulse_split_kernel(const SynUtt* __res
 }
 
 // flat numbering of each kind over the batch: kgp[kind][u] = sum over u' < u, kgp[kind][n_utts] = total
-__global__ void syn_kind_offsets_kernel(const int* __restrict__ kcnt, int n_utts, int64_t* __restrict__ kgp) {
-  if (threadIdx.x < 2 && blockIdx.x == 0) {
-    const int kind = threadIdx.x;
-    int64_t run = 0;
-    for (int u = 0; u < n_utts; ++u) {
-      kgp[kind * (n_utts + 1) + u] = run;
-      run += kcnt[kind * n_utts + u];
-    }
-    kgp[kind * (n_utts + 1) + n_utts] = run;
-  }
+__global__ __launch_bounds__(128) void syn_kind_offsets_kernel(const int* __restrict__ kcnt, int n_utts,
+                                                               int64_t* __restrict__ kgp) {
+  const int kind = threadIdx.x >> 6;      // a wave per kind
+  if (blockIdx.x == 0 && kind < 2)
+    wave_offsets(n_utts, [&](int u) { return (int64_t)kcnt[kind * n_utts + u]; }, kgp + kind * (n_utts + 1));
 }
 
 // minimum phase spectrum of the log-amplitude lg[0..h] (in z.x of the first h+1 entries is NOT
@@ -1255,7 +1264,7 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   hipLaunchKernelGGL(syn_pulse_split_kernel, dim3(8, n_utts), dim3(NT), 0, s, d_utts, d_ptot, d_pidx, d_vuv, n_utts,
                      d_kq, d_kcnt);
   ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syn_kind_offsets_kernel, dim3(1), dim3(64), 0, s, d_kcnt, n_utts, d_kgp);
+  hipLaunchKernelGGL(syn_kind_offsets_kernel, dim3(1), dim3(128), 0, s, d_kcnt, n_utts, d_kgp);
   ITTS_LAUNCH_CHECK();
   const bool wave_kernels = fft_size == 2 * wf::WF_N;
   int64_t* h_totals[2] = {nullptr, nullptr};
