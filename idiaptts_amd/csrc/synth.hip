@@ -810,7 +810,8 @@ __global__ __launch_bounds__(NT, 5) void syn_pulse_kernel(PulseArgs a) {
 // lane in registers (bin lane + 64 q in register q; bin 512 is carried by every lane), the seven real
 // transforms are wf::rfft1024 / irfft1024 (wave_fft.h: register passes, the wave's own 8.5 KB of LDS
 // for the transposes, no workgroup barrier), the responses stay in registers up to the overlap-add.
-// Persistent: 8 waves per CU take the pulses in turn, so the host no longer needs the pulse count.
+// Persistent: 8 or 12 waves per CU take the pulses from a counter, a few neighbours at a time (SYN_WAVE_DEAL_*), so the
+// host no longer needs the pulse count.
 // Spectra and responses are those of syn_pulse_kernel bit for bit; the two wave-wide sums (DC of the
 // periodic response, mean of the noise) add up in another order.
 // wave-uniform values said so (the pulse's scalars then live in SGPRs instead of one VGPR each)
