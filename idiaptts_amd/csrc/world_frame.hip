@@ -270,8 +270,11 @@ __device__ __forceinline__ double ct_bcast0(double v) {
 // the bins per lane: with eight waves per CU (256 registers) 146 of them live in scratch; four waves per CU (one per
 // SIMD, 256 + 98 registers, no scratch) measured SLOWER (round 5: 3.48 against 3.05 ms for 64 utterances): the second
 // wave of a SIMD covers more than the scratch traffic costs.
+#ifndef CTW_DEAL
+#define CTW_DEAL 2      // frames a wave takes from the counter at a time (0: dealt by stride, as until late in round 5: 4.42 -> 4.00 ms at 16 kHz)
+#endif
 template <int R, int TH = CTW_THREADS>
-__global__ __launch_bounds__(TH) void cheaptrick_wave_kernel(FrameArgs a, int64_t t_total) {
+__global__ __launch_bounds__(TH) void cheaptrick_wave_kernel(FrameArgs a, int64_t t_total, int* __restrict__ next) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FFT = 128 * R, H = 64 * R, K = H + 1, NW = TH / 64, CTW_SCAN = ctw_scan<R>();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l0 = wf::lane_id();
@@ -280,7 +283,21 @@ __global__ __launch_bounds__(TH) void cheaptrick_wave_kernel(FrameArgs a, int64_
   char* rows = smem + wf::table_bytes<R>() + (size_t)wv * wf::lds_bytes<R>();
   wf::plan_init(P, a.g_tw_compact, rows, smem);
   double* S = reinterpret_cast<double*>(rows);       // the exchange rows as 1088 doubles of scratch
+#if CTW_DEAL
+  // frames from a counter, CTW_DEAL neighbours at a time (as the pulses of syn_pulse_wave_kernel)
+  int64_t g = 0, g_end = 0;
+  for (;; ++g) {
+    if (g >= g_end) {
+      int base = 0;
+      if (l0 == 0) base = atomicAdd(next, CTW_DEAL);
+      g = __builtin_amdgcn_readfirstlane(base);
+      if (g >= t_total) break;
+      g_end = min(g + (int64_t)CTW_DEAL, t_total);
+    }
+#else
+  (void)next;
   for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < t_total; g += (int64_t)gridDim.x * NW) {
+#endif
     // opaque per frame: what derives from the lane number, the sampling rate and q1 is a handful of
     // integer and fp64 operations -- hoisted out of the loop it is sixty registers held for the
     // whole kernel
@@ -684,7 +701,9 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
   for (int u = 0; u < n_utts; ++u) t_max = std::max<int64_t>(t_max, h_f_off[u + 1] - h_f_off[u]);
   int64_t* d_rpos = nullptr;   // [t_total] + r_off [U] + r_len [U]
   uint32_t* d_rn = nullptr;
-  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_rpos, (size_t)(t_total + 2 * n_utts) * sizeof(int64_t), s));
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_rpos, (size_t)(t_total + 2 * n_utts + 1) * sizeof(int64_t), s));
+  int* d_next = reinterpret_cast<int*>(d_rpos + t_total + 2 * n_utts);      // the wave kernel's frame counter
+  ITTS_HIP_CHECK(hipMemsetAsync(d_next, 0, sizeof(int64_t), s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_rn, (size_t)t_total * rn_pitch * sizeof(uint32_t), s));
   int64_t* d_roff = d_rpos + t_total;
   int64_t* d_rlen = d_roff + n_utts;
@@ -708,12 +727,12 @@ extern "C" int itts_cheaptrick_mcep(const double* d_x, const int64_t* h_x_off, c
       const size_t lds = wf::table_bytes<8>() + (size_t)NW * wf::lds_bytes<8>();
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel<8>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(cheaptrick_wave_kernel<8>, grid, dim3(CTW_THREADS), lds, s, a, t_total);
+      hipLaunchKernelGGL(cheaptrick_wave_kernel<8>, grid, dim3(CTW_THREADS), lds, s, a, t_total, d_next);
     } else {
       const size_t lds = wf::table_bytes<16>() + (size_t)NW * wf::lds_bytes<16>();
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)cheaptrick_wave_kernel<16, TH16>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((cheaptrick_wave_kernel<16, TH16>), grid, dim3(TH16), lds, s, a, t_total);
+      hipLaunchKernelGGL((cheaptrick_wave_kernel<16, TH16>), grid, dim3(TH16), lds, s, a, t_total, d_next);
     }
     ITTS_LAUNCH_CHECK();
     a.far_only = 1;     // frames with an F0 at or beyond fs / 2: a pass that reads the F0 values and normally finds none
