@@ -77,7 +77,7 @@ __device__ __forceinline__ double interp_coarse(const double* __restrict__ f0, i
 // K1: phase increments + V/UV per sample
 __global__ __launch_bounds__(NT) void syn_inc_kernel(const double* __restrict__ f0, const SynUtt* __restrict__ utts,
                                                      SynParams p, double* __restrict__ inc,
-                                                     uint8_t* __restrict__ vuv) {
+                                                     uint8_t* __restrict__ vuv, double* __restrict__ y) {
   const SynUtt u = utts[blockIdx.y];
   if ((int)blockIdx.x >= u.nblk) return;
   const double* f = f0 + u.f_off;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(NT) void syn_inc_kernel(const double* __restrict__ 
       if (v == 0.0) fi = kDefaultF0;
       inc[u.s_off + i] = 2.0 * kPi * fi / p.fs;
       vuv[u.s_off + i] = (uint8_t)(v != 0.0);
+      y[u.y_off + i] = 0.0;       // (the overlap-add's target: a fill of its own was 64 us in front of this kernel)
     }
   }
 }
@@ -489,9 +490,19 @@ __device__ __forceinline__ void wave_offsets(int n, Load load, int64_t* __restri
   }
   if (lane == 0) out[n] = carry;
 }
-__global__ __launch_bounds__(64) void syn_pulse_offsets_kernel(const double* __restrict__ ptot, int n_utts,
-                                                               int64_t* __restrict__ gpoff) {
-  if (blockIdx.x == 0) wave_offsets(n_utts, [&](int u) { return (int64_t)ptot[u]; }, gpoff);
+__device__ void syn_dcr_table(int fft, double* __restrict__ dcr);
+// one launch of two workgroups between the phase scan and the split of the pulses by kind: block 0 numbers the pulses over
+// the batch (its first wave) and clears the split's counts, block 1 tabulates the DC remover's window (three launches
+// before: 24 + 13 + 6 us on the way to the pulse kernels)
+__global__ __launch_bounds__(NT) void syn_pulse_offsets_kernel(const double* __restrict__ ptot, int n_utts,
+                                                               int64_t* __restrict__ gpoff, int* __restrict__ kcnt,
+                                                               int kcnt_ints, int fft, double* __restrict__ dcr) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) wave_offsets(n_utts, [&](int u) { return (int64_t)ptot[u]; }, gpoff);
+    for (int i = threadIdx.x; i < kcnt_ints; i += NT) kcnt[i] = 0;
+  } else if (blockIdx.x == 1) {
+    syn_dcr_table(fft, dcr);
+  }
 }
 
 // ---- WORLD randn stream with jump-ahead ---------------------------------------------------------
@@ -616,7 +627,7 @@ __device__ inline void min_phase(const double* lg, int fft_rt, int logfft, doubl
 // hann(i) = 0.5 - 0.5 cos(2 pi (i + 1) / (1 + fft)), i < fft / 2, and the normaliser (the doubled sum,
 // reduced in the order the pulse kernel used when every pulse recomputed it: same bits).  Three
 // fp64 cosines per bin and pulse less.
-__global__ __launch_bounds__(NT) void syn_dcr_table_kernel(int fft, double* __restrict__ dcr) {
+__device__ void syn_dcr_table(int fft, double* __restrict__ dcr) {
   __shared__ double red[16];
   const int h = fft / 2;
   double dsum = 0.0;
@@ -1226,10 +1237,9 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_y, y_total * 8, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), n_utts * sizeof(SynUtt), hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(itts_spin_sync(s));
-  ITTS_HIP_CHECK(hipMemsetAsync(d_y, 0, y_total * 8, s));
 
   const dim3 gblk(max_nblk, n_utts);
-  hipLaunchKernelGGL(syn_inc_kernel, gblk, dim3(NT), 0, s, d_f0, d_utts, p, d_wrap, d_vuv);
+  hipLaunchKernelGGL(syn_inc_kernel, gblk, dim3(NT), 0, s, d_f0, d_utts, p, d_wrap, d_vuv, d_y);
   ITTS_LAUNCH_CHECK();
   const bool seq_phase = getenv("ITTS_SYNTH_SEQ_PHASE") != nullptr;   // A/B switch for the tests
   if (seq_phase) {
@@ -1246,13 +1256,9 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
     hipLaunchKernelGGL(syn_phase_scan_kernel, dim3(n_utts), dim3(PST), 0, s, d_utts, d_wrap, d_pidx, d_ptot);
   }
   ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syn_pulse_offsets_kernel, dim3(1), dim3(64), 0, s, d_ptot, n_utts, d_gpoff);
-  ITTS_LAUNCH_CHECK();
   const int h = fft_size / 2;
   double* d_dcr = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_dcr, (size_t)(h + 1) * 8, s));
-  hipLaunchKernelGGL(syn_dcr_table_kernel, dim3(1), dim3(NT), 0, s, fft_size, d_dcr);
-  ITTS_LAUNCH_CHECK();
   // the pulses by kind (a pulse kernel per kind: the unvoiced ones without what only a periodic response needs)
   int *d_kq = nullptr, *d_kcnt = nullptr;
   int64_t* d_kgp = nullptr;
@@ -1261,7 +1267,9 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   const size_t kcnt_bytes = (((size_t)(2 * n_utts + 2) * 4 + 255) / 256) * 256;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kcnt, kcnt_bytes, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_kgp, (size_t)2 * (n_utts + 1) * 8, s));
-  ITTS_HIP_CHECK(hipMemsetAsync(d_kcnt, 0, kcnt_bytes, s));
+  hipLaunchKernelGGL(syn_pulse_offsets_kernel, dim3(2), dim3(NT), 0, s, d_ptot, n_utts, d_gpoff, d_kcnt,
+                     (int)(kcnt_bytes / 4), fft_size, d_dcr);
+  ITTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(syn_pulse_split_kernel, dim3(8, n_utts), dim3(NT), 0, s, d_utts, d_ptot, d_pidx, d_vuv, n_utts,
                      d_kq, d_kcnt);
   ITTS_LAUNCH_CHECK();
