@@ -622,10 +622,10 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_taps, taps.size() * 8, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_lpf, lpf.size() * 8, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_lpf_off, lpf_off.size() * 4, s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_taps, taps.data(), taps.size() * 8, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf, lpf.data(), lpf.size() * 8, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_lpf_off, lpf_off.data(), lpf_off.size() * 4, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(itts_spin_sync(s));  // host staging vectors die with this frame
+  // (through the page-locked staging ring: the host vectors may go at once, and nothing waits for the stream)
+  if (int rc = itts::staged_upload(d_taps, taps.data(), taps.size() * 8, s)) return rc;
+  if (int rc = itts::staged_upload(d_lpf, lpf.data(), lpf.size() * 8, s)) return rc;
+  if (int rc = itts::staged_upload(d_lpf_off, lpf_off.data(), lpf_off.size() * 4, s)) return rc;
 
   const int64_t budget = (int64_t)24 << 30;  // scratch bytes per sub-batch (one sub-batch for 256 utterances: the per-utterance kernels then fill all CUs)
   int u0 = 0;
@@ -669,8 +669,7 @@ extern "C" int itts_dio(const double* d_x, const int64_t* h_x_off, const int64_t
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_score, cand_n * 8, s));
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_tmp, tmp_n * 8, s));
     ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_cnt, cnt_n * 4, s));
-    ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), U * sizeof(DioUtt), hipMemcpyHostToDevice, s));
-    ITTS_HIP_CHECK(itts_spin_sync(s));
+    if (int rc = itts::staged_upload(d_utts, utts.data(), U * sizeof(DioUtt), s)) return rc;
 
     hipLaunchKernelGGL(dio_mean_kernel, dim3(U), dim3(NT), 0, s, d_x, d_utts, d_mean);
     ITTS_LAUNCH_CHECK();

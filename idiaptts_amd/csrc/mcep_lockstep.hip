@@ -15,6 +15,7 @@
 // kernel of their own (7.7 ms per analysis, 3.4 ms on wave_fft.h) until round 4 folded them away.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -1283,9 +1284,26 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
     else hipLaunchKernelGGL(mcls_solve_kernel, dim3((unsigned)nr), dim3(NT), lds_solve, s, a);
     ITTS_LAUNCH_CHECK();
     if (it >= miniter && it < maxiter) {
+      // the count comes back into a page-locked word the host spins on (a copy into pageable memory went through the
+      // runtime's staging buffer: 31-39 us from the end of the solve to the next launch, eight times a call)
       int remaining = 0;
-      ITTS_HIP_CHECK(hipMemcpyAsync(&remaining, n_active, 4, hipMemcpyDeviceToHost, s));
-      ITTS_HIP_CHECK(itts_spin_sync(s));
+      {
+        volatile int* w = reinterpret_cast<volatile int*>(pinned_slot(ctx));
+        constexpr int kPending = 0x7fffffff;
+        w[0] = kPending;
+        ITTS_HIP_CHECK(hipMemcpyAsync(const_cast<int*>(w), n_active, 4, hipMemcpyDeviceToHost, s));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; w[0] == kPending; ++spins) {
+          __builtin_ia32_pause();
+          if ((spins & 0xffff) == 0xffff &&
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.2) {
+            ITTS_HIP_CHECK(hipStreamSynchronize(s));
+            break;
+          }
+        }
+        ITTS_REQUIRE(w[0] != kPending, "the frame count did not come back");
+        remaining = w[0];
+      }
       if (remaining <= 0) break;
       if (remaining < nr) {          // shrink the work list to the frames that still iterate
         ITTS_HIP_CHECK(hipMemsetAsync(n_active + 1, 0, 4, s));

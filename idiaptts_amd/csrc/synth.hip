@@ -1235,8 +1235,7 @@ static int world_synthesize_impl(const double* d_f0, const double* d_sp, const d
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_ptot, n_utts * 8, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_gpoff, (n_utts + 1) * 8, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&d_y, y_total * 8, s));
-  ITTS_HIP_CHECK(hipMemcpyAsync(d_utts, utts.data(), n_utts * sizeof(SynUtt), hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(itts_spin_sync(s));
+  if (int rc = itts::staged_upload(d_utts, utts.data(), n_utts * sizeof(SynUtt), s)) return rc;
 
   const dim3 gblk(max_nblk, n_utts);
   hipLaunchKernelGGL(syn_inc_kernel, gblk, dim3(NT), 0, s, d_f0, d_utts, p, d_wrap, d_vuv, d_y);
