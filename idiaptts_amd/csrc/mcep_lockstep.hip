@@ -697,13 +697,27 @@ struct LsArgs {
   double* sprev;         // [T]
   int* done;             // [T]
   int* iters;            // [T]
-  int* n_active;         // [1]
+  int* n_active;         // [MCLS_COUNTERS x 32]: frames done, counted on MCLS_COUNTERS words a cache line apart (mcls_count_done)
   int iter;              // current Newton iteration (1-based)
   int64_t ldk;           // row pitch of xp / cbuf (K rounded up to even: 16-byte aligned rows)
   const int* rows;       // frames still iterating (NULL: all T)
   int64_t n_rows;
   const double* apow;    // [m + 1] (-alpha)^r: the right-hand side's constant part, tabulated once per call
 };
+
+// A frame that stops iterating is counted.  On ONE word the quarter of a million frames that converge in the loop's
+// third round queued up in the L2 (that round's solve: 2.83 ms where the rounds around it, with as many frames, take
+// 1.95); on 64 words a cache line apart, picked by the workgroup, they do not.  mcls_remaining_kernel sums them for the host.
+constexpr int MCLS_COUNTERS = 64;
+__device__ __forceinline__ void mcls_count_done(int* counters) {
+  atomicAdd(counters + 32 * (blockIdx.x & (MCLS_COUNTERS - 1)), 1);
+}
+__global__ __launch_bounds__(64) void mcls_remaining_kernel(const int* __restrict__ counters, int T, int* __restrict__ out) {
+  int v = counters[32 * threadIdx.x];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (threadIdx.x == 0) out[0] = T - v;
+}
 
 
 
@@ -873,7 +887,7 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
       if (tid == 0) {
         a.done[g] = 1;
         a.iters[g] = a.iter;
-        atomicSub(a.n_active, 1);
+        mcls_count_done(a.n_active);
       }
       return;
     }
@@ -920,7 +934,7 @@ __global__ __launch_bounds__(NT) void mcls_solve_kernel(LsArgs a) {
   if (tid == 0 && a.iter == a.itr2) {
     a.done[g] = 1;
     a.iters[g] = a.itr2;
-    atomicSub(a.n_active, 1);
+    mcls_count_done(a.n_active);
   }
 }
 
@@ -1033,7 +1047,7 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
       if (lane == 0) {
         a.done[g] = 1;
         a.iters[g] = a.iter;
-        atomicSub(a.n_active, 1);
+        mcls_count_done(a.n_active);
       }
       return;
     }
@@ -1064,7 +1078,7 @@ __global__ __launch_bounds__(256, 3) void mcls_solve_dpp_kernel(LsArgs a) {
   if (lane == 0 && a.iter == a.itr2) {
     a.done[g] = 1;
     a.iters[g] = a.itr2;
-    atomicSub(a.n_active, 1);
+    mcls_count_done(a.n_active);
   }
 }
 
@@ -1202,13 +1216,15 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&done, (size_t)T * 4, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&iters, (size_t)T * 4, s));
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&rows, (size_t)T * 4, s));
-  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&n_active, 8, s));   // [0] active frames, [1] list cursor
+  // [MCLS_COUNTERS x 32] frames done, then [0] frames still iterating (mcls_remaining_kernel), [1] list cursor
+  constexpr size_t kCountInts = (size_t)MCLS_COUNTERS * 32;
+  ITTS_HIP_CHECK(itts::scratch_malloc((void**)&n_active, (kCountInts + 2) * 4, s));
   double* apow = nullptr;
   ITTS_HIP_CHECK(itts::scratch_malloc((void**)&apow, (size_t)m1 * 8, s));
   hipLaunchKernelGGL(mcls_alpha_pow_kernel, dim3((m1 + 63) / 64), dim3(64), 0, s, alpha, m1, apow);
   ITTS_LAUNCH_CHECK();
-  const int tcount[2] = {(int)T, 0};
-  ITTS_HIP_CHECK(hipMemcpyAsync(n_active, tcount, 8, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(n_active, 0, (kCountInts + 2) * 4, s));
+  int* n_left = n_active + kCountInts;
   LsArgs a{};
   a.in = d_in; a.in_is_power = in_is_power; a.T = T; a.flng = flng; a.logflng = logflng; a.m = order;
   a.alpha = alpha; a.eps = eps; a.itr1 = miniter; a.itr2 = maxiter; a.dd = threshold; a.xp = xp;
@@ -1291,7 +1307,9 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
         volatile int* w = reinterpret_cast<volatile int*>(pinned_slot(ctx));
         constexpr int kPending = 0x7fffffff;
         w[0] = kPending;
-        ITTS_HIP_CHECK(hipMemcpyAsync(const_cast<int*>(w), n_active, 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(mcls_remaining_kernel, dim3(1), dim3(64), 0, s, n_active, (int)T, n_left);
+        ITTS_LAUNCH_CHECK();
+        ITTS_HIP_CHECK(hipMemcpyAsync(const_cast<int*>(w), n_left, 4, hipMemcpyDeviceToHost, s));
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; w[0] == kPending; ++spins) {
           __builtin_ia32_pause();
@@ -1306,9 +1324,9 @@ int mcep_lockstep(DeviceContext* ctx, const double* d_in, int in_is_power, int64
       }
       if (remaining <= 0) break;
       if (remaining < nr) {          // shrink the work list to the frames that still iterate
-        ITTS_HIP_CHECK(hipMemsetAsync(n_active + 1, 0, 4, s));
+        ITTS_HIP_CHECK(hipMemsetAsync(n_left + 1, 0, 4, s));
         hipLaunchKernelGGL(mcls_compact_kernel, dim3((unsigned)std::min<int64_t>((T + 255) / 256, 1024)),
-                           dim3(256), 0, s, done, T, rows, n_active + 1);
+                           dim3(256), 0, s, done, T, rows, n_left + 1);
         ITTS_LAUNCH_CHECK();
         a.rows = rows;
         a.n_rows = remaining;
