@@ -812,15 +812,15 @@ def resident_epoch_section(dev, n_utts=1024, batch_utts=32):
                                "valid_frames_per_s": n / dt}}
 
 
-def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
+def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16, with_bilstm=True):
     """One epoch of `AcousticModelTrainer.train` over `n_utts` synthetic LJSpeech-shaped utterances through
     the PUBLIC API (reference model_trainers/ModularTrainer.py:379-560, AcousticModelTrainer.py), files on
     disk in the legacy layout the reference's tests use (`<id>.questions` [T, 425] and `cmp_mcep60/<id>.cmp`
-    [T, 187] raw float32 + min-max / mean-covariance `.bin` files): (i) the module path --
-    PyTorchDatareadersDataset + DataLoader + collate + RNNDyn modules + NamedLoss + fused HIP Adam, every
-    utterance read and normalised again each epoch as the reference does; (ii) `hparams.resident_dataset`
-    -- readers run once, the normalised frames stay in HBM, flat feed-forward step.  Two epochs each; the
-    SECOND epoch's `handler.train` call is the one reported (wall clock, device synchronised)."""
+    [T, 187] raw float32 + min-max / mean-covariance `.bin` files): the module path --
+    PyTorchDatareadersDataset + loader + collate + RNNDyn modules + NamedLoss + fused HIP Adam -- with and
+    without the device batch cache, `hparams.resident_dataset` (flat feed-forward step), and the BiLSTM
+    model on the cached module path.  Three epochs each; the THIRD epoch's `handler.train` call is the one
+    reported (wall clock, device synchronised)."""
     import logging
     import shutil
     import tempfile
@@ -848,13 +848,24 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
         out["files_GB"] = float(lengths.sum()) * (425 + 187) * 4 / 1e9
         out["files_written_s"] = time.perf_counter() - t0
         logging.getLogger().setLevel(logging.WARNING)
-        # module path twice: hparams.dataset_num_workers_gpu = 4 as the reference's default (reader threads here:
-        # hparams.dataset_worker_kind; torch's forked workers took 6.5 s an epoch on this stack), and no workers
+        # Rows (all through AcousticModelTrainer.train, hparams.dataset_num_workers_gpu = 4 reader threads as the
+        # reference's default of four workers):
+        #   module_path               nothing opted into: the readers' rows stay in HBM after the first epoch
+        #                             (hparams.dataset_device_cache, default on) and later batches are gathered there
+        #   module_path_uncached      hparams.dataset_device_cache = False: every epoch reads, normalises, pads and
+        #                             uploads again, as the reference does (what `module_path` was before round 6)
+        #   resident_dataset          hparams.resident_dataset: FrameShards + the flat feed-forward step
+        #   module_path_cached_bilstm BASELINE config 3's model (3 x 512 BiLSTM, 64 utterances a batch) on the cached
+        #                             module path, beside the `bilstm` section's step on one fixed batch
         only = os.environ.get("ITTS_TRAINER_EPOCH_ONLY")          # (scripts/prof_trainer_epoch.py)
-        for key, resident, workers in (("module_path", False, 4), ("module_path_no_workers", False, 0),
-                                       ("resident_dataset", True, 4)):
+        rows = (("module_path", {}), ("module_path_uncached", {"cache": False}), ("resident_dataset", {"resident": True}),
+                ("module_path_cached_bilstm", {"model": "RNNDYN-3_BiLSTM_512-1_FC_187", "batch": 64}))
+        for key, opt in rows:
             if only and key != only:
                 continue
+            if key == "module_path_cached_bilstm" and not with_bilstm:
+                continue
+            workers = 4
             hp = AcousticModelTrainer.create_hparams()
             hp.num_questions = 425
             hp.voice = "full"
@@ -862,11 +873,11 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
             hp.frame_size_ms = 5
             hp.num_coded_sps = 60
             hp.seed = 1
-            hp.epochs = 2
+            hp.epochs = 3
             hp.use_gpu = True
             hp.dataset_num_workers_gpu = workers
-            hp.model_type = "RNNDYN-2_TANH_512-1_FC_187"
-            hp.batch_size_train = batch_utts
+            hp.model_type = opt.get("model", "RNNDYN-2_TANH_512-1_FC_187")
+            hp.batch_size_train = opt.get("batch", batch_utts)
             hp.batch_size_val = n_val
             hp.val_set_perc = n_val / float(n_utts + n_val)
             hp.test_set_perc = 0.0
@@ -877,7 +888,8 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
             hp.optimiser_args["lr"] = 0.001
             hp.model_name = "bench_model"
             hp.world_dir = wdir
-            hp.resident_dataset = resident
+            hp.resident_dataset = bool(opt.get("resident", False))
+            hp.dataset_device_cache = bool(opt.get("cache", True))
             trainer = AcousticModelTrainer(**AcousticModelTrainer.legacy_support_init(wdir, qdir, ids, 425, hp))
             trainer.init(hp)
             handler = trainer.model_handler
@@ -897,14 +909,20 @@ def trainer_epoch_section(dev, n_utts=1024, batch_utts=32, n_val=16):
             trainer.train(hp)
             total = time.perf_counter() - t0
             frames = int(sum(lengths[ids.index(i)] for i in trainer.id_list_train))
+            steps = -(-len(trainer.id_list_train) // hp.batch_size_train)
             out[key] = {"train_utterances": len(trainer.id_list_train), "train_frames": frames,
-                        "dataloader_workers": workers,
+                        "dataloader_workers": workers, "model": hp.model_type, "batch_utts": hp.batch_size_train,
                         "epoch_s": epochs[-1], "epoch_s_all": [round(e, 4) for e in epochs],
+                        "steps_per_epoch": steps, "ms_per_step": epochs[-1] * 1e3 / steps,
                         "valid_frames_per_s": frames / epochs[-1],
                         "train_call_s": total,
-                        "what": "second epoch's handler.train (the first holds warm-up{}); train_call_s is the whole "
-                                "trainer.train call: 2 epochs + 2 validation passes + final checkpoint".format(
-                                    " and the one-off staging of the shards to HBM" if resident else "")}
+                        "what": "third epoch's handler.train (the first holds warm-up{}); train_call_s is the whole "
+                                "trainer.train call: 3 epochs + 3 validation passes + final checkpoint".format(
+                                    " and the one-off staging of the shards to HBM" if hp.resident_dataset else
+                                    " and the one upload of every utterance's rows" if hp.dataset_device_cache else "")}
+            loader = getattr(handler, "dataloader_train", None)
+            if hasattr(loader, "stats"):
+                out[key]["device_cache"] = dict(loader.stats, cached_GB=loader.cached_bytes() / 1e9)
             del trainer, handler
     except Exception as e:      # a bench row must not take the headline line down with it
         out["error"] = "{}: {}".format(type(e).__name__, e)
@@ -1330,7 +1348,14 @@ def main():
         if world == 1 and args.world_utts > 0:
             extra.update(resident_epoch_section(dev))
             if args.trainer_utts > 0:
-                extra.update(trainer_epoch_section(dev, args.trainer_utts))
+                extra.update(trainer_epoch_section(dev, args.trainer_utts, with_bilstm=args.bilstm_utts > 0))
+                te = extra["trainer_epoch"]
+                if "module_path_cached_bilstm" in te and "bilstm" in extra:
+                    te["module_path_cached_bilstm"]["bilstm_section_ms_per_step"] = extra["bilstm"]["ms_per_step"]
+                    te["module_path_cached_bilstm"]["bilstm_section_valid_frames_per_s"] = \
+                        extra["bilstm"]["valid_frames_per_s"]
+                    te["module_path_cached_bilstm"]["rate_vs_bilstm_section"] = \
+                        te["module_path_cached_bilstm"]["valid_frames_per_s"] / extra["bilstm"]["valid_frames_per_s"]
                 if "resident_epoch" in extra and "error" not in extra["trainer_epoch"]:
                     extra["trainer_epoch"]["bare_flat_step_valid_frames_per_s"] = value
                     extra["trainer_epoch"]["resident_epoch_section_valid_frames_per_s"] = \

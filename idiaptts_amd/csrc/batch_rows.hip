@@ -1,0 +1,236 @@
+// Padded mini-batches <-> rows stored back to back, on the device.
+//
+// The reference builds every mini-batch on the host: ModularModelHandlerPyTorch.prepare_batch (:388-465)
+// pads the utterances of a batch with torch.nn.utils.rnn.pad_sequence, writes a float sequence mask
+// (sequence_mask :467-491) and the training loop copies the result to the GPU (:745-760).  Here the
+// normalised, length matched rows of the utterances stay in HBM between the epochs (data_preparation/
+// DeviceBatchCache.py) and a batch is one launch per stream:
+//
+//   itts_batch_pad_gather_f32   padded[b, t, :] = rows[starts[b] + t, :]  (t < lens[b]),  else the fill row / zeros
+//                               (+ the [B, T, 1] mask); also pad_packed_sequence for the frame-independent
+//                               layers, which run on the valid rows only (nn/functional.py ValidRows)
+//   itts_batch_pack_rows_f32    its adjoint: rows[starts[b] + t, :] = padded[b, t, :]
+//   itts_batch_pad_colsum_f32   the sum over the padding positions of a padded batch, per column (the gradient of
+//                               the fill row), in a fixed order: partial sums per slab of rows, then one pass over
+//                               the slabs
+//
+// HBM bound, one wave per row: a row is 425 or 187 floats (LJSpeech shape) whose pitch is not a multiple of
+// 16 bytes, so lanes move one dword each -- 256 contiguous bytes per wave instruction, the shape that the
+// guide's table of plain stores gives at 6.0-6.2 TB/s; rows of 16-byte multiples on both sides take float4.
+#include <algorithm>
+
+#include "common.h"
+
+namespace itts {
+
+static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// padded position r -> (b, t)
+__device__ __forceinline__ void split_row(int64_t r, int64_t t_max, int n_utts, int batch_first, int& b, int64_t& t) {
+  if (batch_first) {
+    b = (int)(r / t_max);
+    t = r - (int64_t)b * t_max;
+  } else {
+    t = r / n_utts;
+    b = (int)(r - t * n_utts);
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void batch_pad_gather_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                               int64_t n_src, const int64_t* __restrict__ starts,
+                                                               const int64_t* __restrict__ lens, int n_utts,
+                                                               int64_t t_max, int width, int batch_first,
+                                                               const float* __restrict__ fill, int64_t rep_pos,
+                                                               const float* __restrict__ rep_row,
+                                                               float* __restrict__ dst, int64_t ld_dst,
+                                                               float* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wn = (int64_t)gridDim.x * 4;
+  for (int64_t r = w0; r < n_rows; r += wn) {
+    int b;
+    int64_t t;
+    split_row(r, t_max, n_utts, batch_first, b, t);
+    const int64_t i = starts[b] + t;
+    const bool valid = t < lens[b] && i >= 0 && i < n_src;
+    const float* s = valid ? src + i * ld_src : (r == rep_pos ? rep_row : fill);
+    float* d = dst + r * ld_dst;
+    if (VEC) {
+      for (int c = lane; c < (width >> 2); c += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s) v = reinterpret_cast<const float4*>(s)[c];
+        reinterpret_cast<float4*>(d)[c] = v;
+      }
+    } else {
+      for (int c = lane; c < width; c += 64) d[c] = s ? s[c] : 0.f;
+    }
+    if (mask && lane == 0) mask[r] = valid ? 1.f : 0.f;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void batch_pack_rows_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                              const int64_t* __restrict__ starts,
+                                                              const int64_t* __restrict__ lens, int n_utts,
+                                                              int64_t t_max, int width, int batch_first,
+                                                              float* __restrict__ dst, int64_t ld_dst, int dst_width,
+                                                              int64_t rep_pos, int64_t rep_dst_row) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wn = (int64_t)gridDim.x * 4;
+  for (int64_t r = w0; r < n_rows; r += wn) {
+    int b;
+    int64_t t;
+    split_row(r, t_max, n_utts, batch_first, b, t);
+    if (t >= lens[b] && r != rep_pos) continue;
+    const float* s = src + r * ld_src;
+    float* d = dst + (t < lens[b] ? starts[b] + t : rep_dst_row) * ld_dst;
+    if (VEC) {
+      for (int c = lane; c < (dst_width >> 2); c += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < (width >> 2)) v = reinterpret_cast<const float4*>(s)[c];
+        reinterpret_cast<float4*>(d)[c] = v;
+      }
+    } else {
+      for (int c = lane; c < dst_width; c += 64) d[c] = c < width ? s[c] : 0.f;
+    }
+  }
+}
+
+constexpr int kColsumSlabs = 512;
+
+// stage 1: workgroup s sums the padding rows of its slab of consecutive rows, wave w taking rows w, w + 4, ...
+// of the slab and lane l the columns l, l + 64, ...; the four waves' sums meet in LDS in wave order
+__global__ __launch_bounds__(256) void batch_pad_colsum_partial_kernel(const float* __restrict__ x, int64_t ld,
+                                                                       const int64_t* __restrict__ lens, int n_utts,
+                                                                       int64_t t_max, int width, int batch_first,
+                                                                       int64_t rows_per_slab,
+                                                                       float* __restrict__ partial) {
+  extern __shared__ float sm[];      // [4][width]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab, r1 = std::min<int64_t>(r0 + rows_per_slab, n_rows);
+  for (int c0 = 0; c0 < width; c0 += 64 * 8) {      // eight columns per lane and sweep
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      int b;
+      int64_t t;
+      split_row(r, t_max, n_utts, batch_first, b, t);
+      if (t < lens[b]) continue;
+      const float* s = x + r * ld;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j * 64 + lane;
+        if (c < width) acc[j] += s[c];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j * 64 + lane;
+      if (c < width) sm[wave * width + c] = acc[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < width; c += 256)
+    partial[(int64_t)blockIdx.x * width + c] = ((sm[c] + sm[width + c]) + sm[2 * width + c]) + sm[3 * width + c];
+}
+
+// stage 2: out[c] = sum over the slabs in slab order
+__global__ __launch_bounds__(256) void batch_pad_colsum_final_kernel(const float* __restrict__ partial, int n_slabs,
+                                                                     int width, float* __restrict__ out,
+                                                                     int out_width) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= out_width) return;
+  if (c >= width) {
+    out[c] = 0.f;
+    return;
+  }
+  float acc = 0.f;
+  for (int s = 0; s < n_slabs; ++s) acc += partial[(int64_t)s * width + c];
+  out[c] = acc;
+}
+
+static unsigned row_grid(int64_t n_rows) { return (unsigned)std::min<int64_t>((n_rows + 3) / 4, 16384); }
+
+}  // namespace itts
+
+using namespace itts;
+
+extern "C" int itts_batch_pad_gather_f32(const float* d_src, int64_t ld_src, int64_t n_src, const int64_t* d_starts,
+                                         const int64_t* d_lens, int n_utts, int64_t t_max, int width, int batch_first,
+                                         const float* d_fill_row, int64_t rep_pos, const float* d_rep_row,
+                                         float* d_dst, int64_t ld_dst, float* d_mask, void* stream) {
+  ITTS_REQUIRE(n_utts >= 0 && t_max >= 0 && width >= 0 && n_src >= 0 && ld_src >= width && ld_dst >= width, "bad sizes");
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  if (n_rows == 0) return ITTS_OK;
+  ITTS_REQUIRE(d_starts && d_lens && d_dst && (d_src || n_src == 0), "null pointer");
+  ITTS_REQUIRE(rep_pos < n_rows && (rep_pos < 0 || d_rep_row), "bad representative position");
+  const bool vec = width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(d_src) && aligned16(d_dst) &&
+                   (!d_fill_row || aligned16(d_fill_row)) && (rep_pos < 0 || aligned16(d_rep_row));
+  if (vec)
+    hipLaunchKernelGGL(batch_pad_gather_kernel<true>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
+                       ld_src, n_src, d_starts, d_lens, n_utts, t_max, width, batch_first, d_fill_row, rep_pos, d_rep_row,
+                       d_dst, ld_dst, d_mask);
+  else
+    hipLaunchKernelGGL(batch_pad_gather_kernel<false>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
+                       ld_src, n_src, d_starts, d_lens, n_utts, t_max, width, batch_first, d_fill_row, rep_pos, d_rep_row,
+                       d_dst, ld_dst, d_mask);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, const int64_t* d_starts,
+                                        const int64_t* d_lens, int n_utts, int64_t t_max, int width, int batch_first,
+                                        float* d_dst, int64_t ld_dst, int dst_width, int64_t rep_pos,
+                                        int64_t rep_dst_row, void* stream) {
+  ITTS_REQUIRE(n_utts >= 0 && t_max >= 0 && width >= 0 && dst_width >= width && ld_src >= width && ld_dst >= dst_width,
+               "bad sizes");
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  if (n_rows == 0 || dst_width == 0) return ITTS_OK;
+  ITTS_REQUIRE(d_starts && d_lens && d_src && d_dst, "null pointer");
+  ITTS_REQUIRE(rep_pos < n_rows && (rep_pos < 0 || rep_dst_row >= 0), "bad representative position");
+  const bool vec = width % 4 == 0 && dst_width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(d_src) &&
+                   aligned16(d_dst);
+  if (vec)
+    hipLaunchKernelGGL(batch_pack_rows_kernel<true>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
+                       ld_src, d_starts, d_lens, n_utts, t_max, width, batch_first, d_dst, ld_dst, dst_width, rep_pos,
+                       rep_dst_row);
+  else
+    hipLaunchKernelGGL(batch_pack_rows_kernel<false>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
+                       ld_src, d_starts, d_lens, n_utts, t_max, width, batch_first, d_dst, ld_dst, dst_width, rep_pos,
+                       rep_dst_row);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int64_t itts_batch_pad_colsum_workspace_bytes(int width) {
+  return (int64_t)kColsumSlabs * std::max(width, 0) * (int64_t)sizeof(float);
+}
+
+extern "C" int itts_batch_pad_colsum_f32(const float* d_x, int64_t ld_x, const int64_t* d_lens, int n_utts,
+                                         int64_t t_max, int width, int batch_first, float* d_out, int out_width,
+                                         void* d_workspace, void* stream) {
+  ITTS_REQUIRE(n_utts >= 0 && t_max >= 0 && width >= 0 && ld_x >= width && out_width >= width, "bad sizes");
+  if (out_width == 0) return ITTS_OK;
+  ITTS_REQUIRE(d_out && d_workspace, "null pointer");
+  ITTS_REQUIRE(width <= 4096, "at most 4096 columns");      // 4 x width floats of LDS
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  if (n_rows == 0) {
+    ITTS_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(float) * out_width, as_stream(stream)));
+    return ITTS_OK;
+  }
+  ITTS_REQUIRE(d_x && d_lens, "null pointer");
+  const int64_t rows_per_slab = (n_rows + kColsumSlabs - 1) / kColsumSlabs;
+  const int n_slabs = (int)((n_rows + rows_per_slab - 1) / rows_per_slab);
+  float* partial = static_cast<float*>(d_workspace);
+  hipLaunchKernelGGL(batch_pad_colsum_partial_kernel, dim3(n_slabs), dim3(256), sizeof(float) * 4 * width,
+                     as_stream(stream), d_x, ld_x, d_lens, n_utts, t_max, width, batch_first, rows_per_slab, partial);
+  ITTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(batch_pad_colsum_final_kernel, dim3((out_width + 255) / 256), dim3(256), 0, as_stream(stream),
+                     partial, n_slabs, width, d_out, out_width);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}

@@ -1,8 +1,8 @@
 """torch.autograd glue for the HIP acoustic-model kernels (PyTorch-ROCm only provides autograd,
 device memory and streams; every forward / backward computation below is a C-ABI call)."""
-import ctypes
-
 import collections
+import ctypes
+import threading
 
 import torch
 
@@ -157,6 +157,147 @@ class PackedBatch(object):
 
     def _hptr(self):
         return ctypes.c_void_p(self.h_lengths.data_ptr())
+
+
+_padding_state = threading.local()
+
+
+class padding_rows_identical(object):
+    """Context in which the caller vouches that all padding positions of the padded batches it hands to the model
+    hold the same row (true of ModularModelHandlerPyTorch.prepare_batch: pad_sequence writes zeros): the
+    frame-independent layer groups then run on the valid rows plus one representative row (ValidRows) instead of
+    every position of the padded tensor.  Outside such a context they compute all positions, as the reference
+    does."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = getattr(_padding_state, "identical", False)
+        _padding_state.identical = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _padding_state.identical = self.prev
+
+
+def padding_is_identical():
+    return getattr(_padding_state, "identical", False)
+
+
+class ValidRows(object):
+    """Bookkeeping of a padded batch for layers that treat every frame on its own (the Linear groups of
+    rnn_dyn/FFWrapper.py): they run on the VALID rows of the batch, stored back to back in the batch's own order
+    (utterance b at rows starts[b] ..), plus ONE row for all the padding positions -- the reference computes every
+    padding position of [B, T, F] (a third of an LJSpeech batch of 32 utterances), and every one of them holds the
+    same row (pad_sequence / pad_packed_sequence write zeros, an embedding of a padded index the same vector), so
+    one representative gives their common value: `representative` is the flat position (in the batch's layout) of
+    the last frame of the shortest utterance.  Unlike PackedBatch nothing is sorted and nothing but the lengths is
+    uploaded: starts / lens are what the kernels of csrc/batch_rows.hip index with."""
+
+    _cache = collections.OrderedDict()
+    _cache_max = 16
+
+    @classmethod
+    def get(cls, lengths, padded_time, batch_first, device):
+        import numpy as np
+        lens = np.asarray(torch.as_tensor(lengths).cpu(), dtype=np.int64)
+        key = (lens.tobytes(), int(padded_time), bool(batch_first), str(device))
+        vr = cls._cache.get(key)
+        if vr is None:
+            vr = cls(lens, padded_time, batch_first, device)
+            cls._cache[key] = vr
+            while len(cls._cache) > cls._cache_max:
+                cls._cache.popitem(last=False)
+        else:
+            cls._cache.move_to_end(key)
+        return vr
+
+    def __init__(self, lengths, padded_time, batch_first, device):
+        import numpy as np
+        if lengths.ndim != 1 or len(lengths) == 0 or lengths.min() < 0:
+            raise ValueError("lengths must be a non-empty vector of non-negative values")
+        if lengths.max() > padded_time:
+            raise ValueError("a length exceeds the padded time extent")
+        self.B, self.T, self.batch_first = len(lengths), int(padded_time), bool(batch_first)
+        self.N = int(lengths.sum())
+        self.n_pad = self.B * self.T - self.N
+        table = np.empty((2, self.B), dtype=np.int64)
+        table[0, 0] = 0
+        np.cumsum(lengths[:-1], out=table[0, 1:])
+        table[1] = lengths
+        host = torch.from_numpy(table)
+        if torch.cuda.is_available():
+            host = host.pin_memory()
+        self.table = host.to(device, non_blocking=True)       # ONE upload: starts, lens
+        self.starts, self.lens = self.table[0], self.table[1]
+        b = int(np.argmin(lengths))
+        self.representative = (b * self.T + self.T - 1) if batch_first else ((self.T - 1) * self.B + b)
+
+    def pack(self, padded, pad_cols=True):
+        """[B, T, F] / [T, B, F] -> [N (+ 1 when the batch has padding), F rounded up to a multiple of 4]"""
+        return PackValidFunction.apply(padded, self, pad_cols)
+
+    def unpack(self, rows):
+        """[N (+ 1), D] -> [B, T, D] / [T, B, D]; the padding positions take the last row's value"""
+        return UnpackValidFunction.apply(rows, self)
+
+
+class PackValidFunction(torch.autograd.Function):
+    """Valid rows of a padded batch back to back, then (when the batch has padding) the representative padding
+    row.  Backward: valid positions take their row's gradient; the gradient of the extra row -- the SUM over all
+    padding positions of what the layers passed back -- lands on the representative position, the other padding
+    positions get zero: whatever produced the identical padding rows sees the same total."""
+
+    @staticmethod
+    def forward(ctx, padded, vr, pad_cols):
+        if not padded.is_contiguous():
+            padded = padded.contiguous()
+        F = padded.shape[2]
+        width = (F + 3) // 4 * 4 if pad_cols else F
+        out = torch.empty((vr.N + (1 if vr.n_pad else 0), width), dtype=torch.float32, device=padded.device)
+        ops.batch_pack_rows(padded, vr.starts, vr.lens, vr.batch_first, vr.N, out_width=width, out=out,
+                            rep_pos=vr.representative if vr.n_pad else -1, rep_dst_row=vr.N)
+        ctx.vr, ctx.F = vr, F
+        return out[:, :F]      # (a view: the row pitch stays a multiple of 16 bytes for the GEMMs' vector loads)
+
+    @staticmethod
+    def backward(ctx, grad):
+        vr, F = ctx.vr, ctx.F
+        g = grad if grad.stride(-1) == 1 else grad.contiguous()
+        dx, _ = ops.batch_pad_gather(g[:vr.N], vr.starts, vr.lens, vr.B, vr.T, vr.batch_first, width=F,
+                                     rep_pos=vr.representative if vr.n_pad else -1,
+                                     rep_row=g[vr.N] if vr.n_pad else None)
+        return dx, None, None
+
+
+class UnpackValidFunction(torch.autograd.Function):
+    """[N (+ 1), D] rows -> the padded batch, every padding position holding the extra row (zeros without one).
+    Backward: the rows of the valid positions, and for the extra row the column sums over the padding
+    positions (csrc/batch_rows.hip: fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, rows, vr):
+        if rows.stride(-1) != 1:
+            rows = rows.contiguous()
+        fill = rows[vr.N] if vr.n_pad else None
+        out, _ = ops.batch_pad_gather(rows[:vr.N], vr.starts, vr.lens, vr.B, vr.T, vr.batch_first, fill_row=fill)
+        ctx.vr = vr
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        vr = ctx.vr
+        if not grad.is_contiguous():
+            grad = grad.contiguous()
+        D = grad.shape[2]
+        # rows of 16-byte multiples for the GEMMs of the layers' backward (LinearActFunction.backward pads otherwise)
+        width = (D + 3) // 4 * 4
+        full = torch.empty((vr.N + (1 if vr.n_pad else 0), width), dtype=torch.float32, device=grad.device)
+        ops.batch_pack_rows(grad, vr.starts, vr.lens, vr.batch_first, vr.N, out_width=width, out=full)
+        if vr.n_pad:
+            ops.batch_pad_colsum(grad, vr.lens, vr.batch_first, out=full[vr.N])
+        return full[:, :D], None
 
 
 class RowsGatherFunction(torch.autograd.Function):

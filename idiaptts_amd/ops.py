@@ -222,6 +222,86 @@ def rows_gather(src, idx, width=None, fill_row=None, out=None, out_width=None):
     return out
 
 
+def _batch_rows_2d(t, name):
+    """[B, T, D] / [T, B, D] padded batch (contiguous positions) -> row pitch"""
+    if t.dim() != 3 or (t.shape[2] > 1 and t.stride(2) != 1):
+        raise ValueError("{} must be a 3-D padded batch with contiguous rows".format(name))
+    ld = max(t.stride(1), t.shape[2], 1)
+    if t.shape[0] > 1 and t.shape[1] > 0 and t.stride(0) != ld * t.shape[1]:
+        raise ValueError("{}: the positions of the padded batch must be evenly spaced".format(name))
+    return ld
+
+
+def batch_pad_gather(rows, starts, lens, n_utts, t_max, batch_first, fill_row=None, want_mask=False, width=None,
+                     rep_pos=-1, rep_row=None):
+    """The padded batch of utterances whose rows lie back to back in `rows` (float32 [R, >= width]; utterance b:
+    rows starts[b] .. starts[b] + lens[b] - 1; starts / lens int64 [n_utts] on the device): position (b, t) takes
+    row starts[b] + t for t < lens[b], else the fill row (zeros when None) -- the padding position with flat index
+    `rep_pos` takes `rep_row` instead.  Returns (padded [B, T, width] or
+    [T, B, width], mask [B, T, 1] / [T, B, 1] or None) -- prepare_batch's pad_sequence + sequence_mask
+    (ModularModelHandlerPyTorch.py:388-491) in one launch."""
+    L = _lib.load()
+    _need(rows, torch.float32, "rows")
+    assert rows.dim() == 2 and (rows.shape[1] <= 1 or rows.stride(1) == 1)
+    assert starts.dtype == torch.int64 and lens.dtype == torch.int64 and starts.is_cuda and lens.is_cuda
+    assert starts.numel() >= n_utts and lens.numel() >= n_utts and starts.is_contiguous() and lens.is_contiguous()
+    width = rows.shape[1] if width is None else int(width)
+    shape = (n_utts, int(t_max), width) if batch_first else (int(t_max), n_utts, width)
+    out = torch.empty(shape, dtype=torch.float32, device=rows.device)
+    mask = torch.empty(shape[:2] + (1,), dtype=torch.float32, device=rows.device) if want_mask else None
+    fill = fill_row.contiguous() if fill_row is not None else None
+    rep = rep_row.contiguous() if rep_row is not None and rep_pos >= 0 else None
+    ld_src = rows.stride(0) if rows.shape[0] > 1 else max(rows.shape[1], 1)
+    _lib.check(L.itts_batch_pad_gather_f32(_ptr(rows), ld_src, rows.shape[0], _ptr(starts), _ptr(lens), n_utts,
+                                           int(t_max), width, 1 if batch_first else 0,
+                                           _ptr(fill) if fill is not None else None,
+                                           int(rep_pos) if rep is not None else -1, _ptr(rep), _ptr(out), max(width, 1),
+                                           _ptr(mask) if mask is not None else None, _stream()),
+               "itts_batch_pad_gather_f32")
+    return out, mask
+
+
+def batch_pack_rows(padded, starts, lens, batch_first, n_rows, out_width=None, out=None, rep_pos=-1, rep_dst_row=-1):
+    """rows[starts[b] + t, :] = padded position (b, t) for t < lens[b] (the adjoint of batch_pad_gather); columns
+    width .. out_width - 1 of the written rows are zeroed.  `n_rows` rows are allocated (rows no valid position maps
+    to are left unwritten: the caller owns them).  rep_pos >= 0: that padding position is copied to row rep_dst_row."""
+    L = _lib.load()
+    _need(padded, torch.float32, "padded")
+    ld = _batch_rows_2d(padded, "padded")
+    n_utts, t_max = (padded.shape[0], padded.shape[1]) if batch_first else (padded.shape[1], padded.shape[0])
+    width = padded.shape[2]
+    out_width = width if out_width is None else int(out_width)
+    if out is None:
+        out = torch.empty((int(n_rows), out_width), dtype=torch.float32, device=padded.device)
+    assert out.dim() == 2 and out.shape[0] >= n_rows and out.shape[1] >= out_width and \
+        (out.shape[1] <= 1 or out.stride(1) == 1)
+    ld_dst = out.stride(0) if out.shape[0] > 1 else max(out.shape[1], 1)
+    _lib.check(L.itts_batch_pack_rows_f32(_ptr(padded), ld, _ptr(starts), _ptr(lens), n_utts, t_max, width,
+                                          1 if batch_first else 0, _ptr(out), ld_dst, out_width, int(rep_pos),
+                                          int(rep_dst_row), _stream()),
+               "itts_batch_pack_rows_f32")
+    return out
+
+
+def batch_pad_colsum(padded, lens, batch_first, out=None):
+    """Per column, the sum of a padded batch over its padding positions (t >= lens[b]), in a fixed order; into `out`
+    (contiguous, at least as wide: the further columns are zeroed) when given."""
+    L = _lib.load()
+    _need(padded, torch.float32, "padded")
+    ld = _batch_rows_2d(padded, "padded")
+    n_utts, t_max = (padded.shape[0], padded.shape[1]) if batch_first else (padded.shape[1], padded.shape[0])
+    width = padded.shape[2]
+    if out is None:
+        out = torch.empty(width, dtype=torch.float32, device=padded.device)
+    assert out.dim() == 1 and out.is_contiguous() and out.numel() >= width
+    ws = torch.empty(max(int(L.itts_batch_pad_colsum_workspace_bytes(width)), 4), dtype=torch.uint8,
+                     device=padded.device)
+    _lib.check(L.itts_batch_pad_colsum_f32(_ptr(padded), ld, _ptr(lens), n_utts, t_max, width,
+                                           1 if batch_first else 0, _ptr(out), out.numel(), _ptr(ws), _stream()),
+               "itts_batch_pad_colsum_f32")
+    return out
+
+
 def linear_bwd_input(dz, w, yprev=None, act_prev=ACT_NONE, out=None):
     L = _lib.load()
     _need(dz, torch.float32, "dz")

@@ -100,6 +100,11 @@ class ExtendedHParams(object):
             # not in the reference: keep the (normalised, length matched) training data resident in
             # HBM as packed frame shards instead of loading one file per item and step
             resident_dataset=False,
+            # not in the reference: the rows the data readers return for an utterance stay in HBM after their first
+            # use and every later mini-batch is gathered on the device (the same batches in the same order: data_
+            # preparation/DeviceBatchCache.py); `dataset_device_cache_bytes` bounds what is kept (None: 60 % of the
+            # memory free at the first upload), utterances beyond it are read again each time
+            dataset_device_cache=True, dataset_device_cache_bytes=None,
             # not in the reference: checkpoints are serialised by a background thread
             async_checkpoint=False,
             # data

@@ -1,0 +1,347 @@
+"""Mini-batches from rows that stay in HBM between the epochs.
+
+The reference's training loop (ModularModelHandlerPyTorch.process_dataloader :683-882) gets every mini-batch from a
+`DataLoader` whose workers, each epoch again, read the utterances' files, normalise them (NpzDataReader
+.preprocess_sample :347-371), match the streams' lengths (PyTorchDatareadersDataset :99-197) and pad the batch
+(prepare_batch :388-465); the padded batch then crosses PCIe.  On an MI355X that host loop is 13 x slower than the
+training step it feeds, and none of it changes from one epoch to the next: what `dataset[i]` returns depends on `i`
+only (datasets whose items draw random numbers never come here).  So the first time an utterance is asked for, its
+rows -- exactly what `dataset[i]` returned -- are uploaded once into a per-stream arena on the device (LJSpeech: 13 100
+utterances x 612 floats per frame = 41 GB of the 288), and from then on a mini-batch is
+
+    index draw (the same `DataLoader` over `range(len(dataset))` as ThreadedBatchLoader: same batches, same order,
+    same draws from the generator)  ->  one upload of the batch's (start, length) table  ->  one
+    `itts_batch_pad_gather_f32` launch per stream (padded batch + float sequence mask; csrc/batch_rows.hip)
+
+yielding what `prepare_batch` yields for those items -- same keys in the same order, same lengths, bit for bit the same
+padded tensors -- already on the device.  Utterances not cached yet (all of them in the first epoch; under data
+parallelism those of the other ranks' shards as the shuffling brings them round) are read by the reader threads,
+packed into page-locked memory and appended to the arena on the way; once `byte_budget` is spent, further utterances
+pass through a scratch region at the arena's end instead and are read again next time.  Streams the arena cannot hold
+(not [T, D] float32, `other_pad_dims`, non-constant padding up to `min_frames`) keep their host arrays and go through
+`prepare_batch` itself.
+"""
+import collections
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from idiaptts_amd.src.data_preparation.ThreadedBatchLoader import _Indices
+
+
+class DeviceRowArena(object):
+    """Rows [capacity, width] float32 of one stream on the device; rows below `used` are kept, the rows behind them
+    are scratch.  All copies and gathers are queued on torch's current stream, i.e. in program order."""
+
+    def __init__(self, width, device, capacity_rows):
+        self.width, self.device = int(width), device
+        self.rows = torch.empty((max(int(capacity_rows), 1), self.width), dtype=torch.float32, device=device)
+        self.used = 0
+
+    @property
+    def capacity(self):
+        return self.rows.shape[0]
+
+    def ensure(self, rows_needed):
+        if rows_needed <= self.capacity:
+            return
+        grown = torch.empty((max(int(rows_needed), self.capacity * 3 // 2), self.width), dtype=torch.float32,
+                            device=self.device)
+        grown[:self.used].copy_(self.rows[:self.used])
+        self.rows = grown
+
+    def write(self, start, staged, keep):
+        """rows [start, start + len(staged)) <- staged (page-locked host rows); keep: they stay (used advances)"""
+        n = staged.shape[0]
+        self.ensure(start + n)
+        if n:
+            self.rows[start:start + n].copy_(staged, non_blocking=True)
+        if keep:
+            assert start == self.used
+            self.used += n
+
+    def pad_gather(self, table, n_utts, t_max, batch_first, want_mask):
+        """table: int64 [2, n_utts] on the device (starts, lens)"""
+        from idiaptts_amd import ops
+        return ops.batch_pad_gather(self.rows, table[0], table[1], n_utts, t_max, batch_first,
+                                    want_mask=want_mask)
+
+    def bytes(self):
+        return self.rows.numel() * 4
+
+
+class CachedBatchLoader(object):
+    """Iterable over the mini-batches of `dataset` -- `prepare_batch(items, common_divisor, batch_first, shard)` for
+    the index draws of `DataLoader(range(len(dataset)), batch_size, shuffle, generator=generator)` -- with the
+    arena streams of every batch on `device`."""
+
+    def __init__(self, dataset, batch_size, shuffle, device, batch_first, common_divisor=1, shard=None,
+                 mask_keys=(), threads=0, generator=None, byte_budget=None, depth=None, arena_factory=DeviceRowArena,
+                 host_collate=None):
+        self.dataset, self.batch_size = dataset, batch_size
+        self.device, self.batch_first = device, bool(batch_first)
+        self.common_divisor, self.shard, self.mask_keys = int(common_divisor), shard, tuple(mask_keys)
+        self.threads = max(0, int(threads))
+        self.depth = int(depth) if depth else max(2, 2 * self.threads)
+        self.byte_budget = byte_budget              # None: decided at the first insertion (share of the free HBM)
+        self._arena_factory = arena_factory
+        self._host_collate = host_collate           # prepare_batch, for the streams an arena cannot hold
+        self._index_loader = DataLoader(_Indices(len(dataset)), batch_size=batch_size, shuffle=shuffle,
+                                        generator=generator, collate_fn=list, num_workers=0)
+        self._pool = None
+        n = len(dataset)
+        self._keys = None                           # key order of an item
+        self._kind = {}                             # key -> "ids" | "list" | "arena" | "host"
+        self._want_mask = {}
+        self._min_frames = {}
+        self._arenas = {}
+        self._start = {}                            # key -> int64 [n] first arena row of the utterance (-1: not cached)
+        self._len = {}
+        self._cached = np.zeros(n, dtype=bool)
+        self._host_values = [None] * n              # per utterance: {key: value} of the non-arena keys
+        self._bytes_kept = 0
+        self.stats = {"hits": 0, "misses": 0, "passed_through": 0}
+
+    def __len__(self):
+        return len(self._index_loader)
+
+    # ------------------------------------------------------------------------------------------ classification
+    def _classify(self, item):
+        keys = list(item.keys())
+        for key in keys:
+            if key == "_id_list":
+                self._kind[key] = "ids"
+                continue
+            try:
+                reader = self.dataset.get_datareader_by_output_name(key)
+            except KeyError:
+                self._kind[key] = "list"
+                continue
+            value = item[key]
+            arena_ok = (isinstance(value, np.ndarray) and value.ndim == 2 and value.dtype == np.float32
+                        and reader.other_pad_dims is None
+                        and (reader.min_frames is None or getattr(reader, "pad_mode", "constant") == "constant"))
+            self._kind[key] = "arena" if arena_ok else "host"
+            self._want_mask[key] = key in self.mask_keys or bool(reader.requires_seq_mask)
+            self._min_frames[key] = reader.min_frames
+            if arena_ok:
+                n = len(self.dataset)
+                self._start[key] = np.full(n, -1, dtype=np.int64)
+                self._len[key] = np.zeros(n, dtype=np.int64)
+        self._keys = keys           # (last: the reader threads take a set `_keys` to mean `_kind` is complete)
+
+    # ------------------------------------------------------------------------------------------ reader side
+    def _read(self, misses):
+        """(reader threads) the items of the utterances not cached yet, their arena streams packed back to back in
+        page-locked memory"""
+        items = [self.dataset[i][0] for i in misses]
+        if self._keys is None:
+            return items, None                      # first batch ever: classified by the consumer, packed there
+        return items, self._stage(items)
+
+    def _stage(self, items):
+        staged = {}
+        pin = torch.cuda.is_available() and torch.device(self.device).type == "cuda"
+        for key, kind in self._kind.items():
+            if kind != "arena":
+                continue
+            arrays = [it[key] for it in items]
+            for a in arrays:
+                if not (isinstance(a, np.ndarray) and a.ndim == 2 and a.dtype == np.float32):
+                    raise TypeError("stream {} changed its type between items: the device batch cache needs [T, D] "
+                                    "float32 arrays throughout (hparams.dataset_device_cache = False turns it off)"
+                                    .format(key))
+            rows = sum(a.shape[0] for a in arrays)
+            buf = torch.empty((rows, arrays[0].shape[1]), dtype=torch.float32, pin_memory=pin)
+            if rows:
+                np.concatenate(arrays, axis=0, out=buf.numpy())
+            staged[key] = buf
+        return staged
+
+    # ------------------------------------------------------------------------------------------ consumer side
+    def _budget(self):
+        if self.byte_budget is None:
+            if torch.device(self.device).type == "cuda":
+                free, _ = torch.cuda.mem_get_info(self.device)
+                self.byte_budget = int(0.6 * free)
+            else:
+                self.byte_budget = 1 << 62
+        return self.byte_budget
+
+    def _insert(self, misses, items, staged):
+        """arena rows for the freshly read utterances: kept while the budget lasts, scratch afterwards"""
+        if self._keys is None:
+            self._classify(items[0])
+        if staged is None:
+            staged = self._stage(items)
+        arena_keys = [k for k in self._keys if self._kind[k] == "arena"]
+        row_bytes = sum(4 * staged[k].shape[1] for k in arena_keys)
+        budget = self._budget()
+        keep = []
+        for i, it in zip(misses, items):
+            need = sum(4 * it[k].shape[0] * it[k].shape[1] for k in arena_keys)
+            ok = self._bytes_kept + need <= budget
+            keep.append(ok)
+            if ok:
+                self._bytes_kept += need
+        # kept utterances first (they extend the arena), passed-through ones into the scratch rows behind them
+        order = [j for j, k in enumerate(keep) if k] + [j for j, k in enumerate(keep) if not k]
+        scratch = {}
+        for key in arena_keys:
+            lens = np.array([items[j][key].shape[0] for j in range(len(items))], dtype=np.int64)
+            src_off = np.concatenate([[0], np.cumsum(lens)])
+            arena = self._arenas.get(key)
+            if arena is None:
+                # room for the whole id list at this batch's mean length (it grows by half when that was too few),
+                # never more rows than the budget pays for, plus one batch of scratch
+                batch_rows = int(lens.sum())
+                guess = min(int(max(1.0, float(lens.mean())) * len(self.dataset) * 1.1),
+                            budget // max(row_bytes, 1)) + batch_rows
+                arena = self._arenas[key] = self._arena_factory(staged[key].shape[1], self.device, guess)
+            n_keep = sum(keep)
+            if n_keep == len(items):
+                start = arena.used
+                arena.write(start, staged[key], keep=True)
+                starts = start + src_off[:-1]
+            else:
+                # regroup the staged rows: kept ones first
+                parts = [staged[key][src_off[j]:src_off[j + 1]] for j in order]
+                kept_rows = int(sum(lens[j] for j in order[:n_keep]))
+                start = arena.used
+                if kept_rows:
+                    arena.write(start, torch.cat(parts[:n_keep]) if n_keep > 1 else parts[0], keep=True)
+                rest = torch.cat(parts[n_keep:]) if len(parts) - n_keep > 1 else parts[n_keep]
+                arena.write(arena.used, rest, keep=False)
+                new_off = np.concatenate([[0], np.cumsum(lens[order])])[:-1]
+                starts = np.empty(len(items), dtype=np.int64)
+                starts[order] = start + new_off
+            for j, i in enumerate(misses):
+                if keep[j]:
+                    self._start[key][i] = starts[j]
+                    self._len[key][i] = lens[j]
+            scratch[key] = {misses[j]: (int(starts[j]), int(lens[j])) for j in range(len(items)) if not keep[j]}
+        for j, (i, it) in enumerate(zip(misses, items)):
+            values = {k: it[k] for k in self._keys if self._kind[k] != "arena"}
+            if keep[j]:
+                self._host_values[i] = values
+                self._cached[i] = True
+            else:
+                scratch.setdefault("_values", {})[i] = values
+        self.stats["passed_through"] += len(items) - sum(keep)
+        return scratch
+
+    def _assemble(self, indices, scratch):
+        """What prepare_batch returns for these utterances (ModularModelHandlerPyTorch.py:388-465)."""
+        data, lengths = {}, {}
+        B = len(indices)
+        idx = np.asarray(indices, dtype=np.int64)
+        passed_values = scratch.get("_values", {}) if scratch else {}
+        values_of = [self._host_values[i] if self._cached[i] else passed_values[i] for i in indices]
+        arena_keys = [k for k in self._keys if self._kind[k] == "arena"]
+        tables = None
+        if arena_keys:
+            host = torch.empty((len(arena_keys), 2, B), dtype=torch.int64,
+                               pin_memory=torch.cuda.is_available() and torch.device(self.device).type == "cuda")
+            tab = host.numpy()
+            for a, key in enumerate(arena_keys):
+                tab[a, 0] = self._start[key][idx]
+                tab[a, 1] = self._len[key][idx]
+                for b, i in enumerate(indices):
+                    if not self._cached[i]:
+                        tab[a, 0, b], tab[a, 1, b] = scratch[key][i]
+            tables = host.to(self.device, non_blocking=True)          # ONE upload per batch
+        host_keys = [k for k in self._keys if self._kind[k] == "host"]
+        host_part = None
+        if host_keys:
+            host_part = self._host_collate([({k: v[k] for k in host_keys}, self.dataset) for v in values_of],
+                                           common_divisor=1, batch_first=self.batch_first, mask_keys=self.mask_keys)
+        for key in self._keys:
+            kind = self._kind[key]
+            if kind in ("ids", "list"):
+                data[key] = [v[key] for v in values_of]
+            elif kind == "host":
+                lengths[key] = host_part[1][key]
+                if key + "_mask" in host_part[0]:
+                    data[key + "_mask"] = host_part[0][key + "_mask"]
+                    lengths[key + "_mask"] = host_part[1][key + "_mask"]
+                data[key] = host_part[0][key]
+            else:
+                a = arena_keys.index(key)
+                lens = torch.from_numpy(tab[a, 1].copy())
+                lengths[key] = lens
+                t_max = int(tab[a, 1].max()) if B else 0
+                if self._min_frames[key] is not None and t_max < self._min_frames[key]:
+                    t_max = int(self._min_frames[key])
+                padded, mask = self._arenas[key].pad_gather(tables[a], B, t_max, self.batch_first,
+                                                            self._want_mask[key])
+                if mask is not None:
+                    data[key + "_mask"] = mask
+                    lengths[key + "_mask"] = lens
+                data[key] = padded
+        return data, lengths
+
+    # ------------------------------------------------------------------------------------------ iteration
+    def _select(self, indices):
+        """prepare_batch's own selection: the remainder that `common_divisor` does not divide is dropped, a rank
+        keeps its samples of the global batch (:392-395)"""
+        assert len(indices) >= self.common_divisor
+        remainder = len(indices) % self.common_divisor
+        if remainder > 0:
+            indices = indices[:-remainder]
+        if self.shard is not None:
+            indices = indices[self.shard[0]::self.shard[1]]
+        return list(indices)
+
+    def __iter__(self):
+        if self.threads > 0 and self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix="itts_cache")
+        pending = collections.deque()
+
+        def finish(entry):
+            indices, misses, job = entry
+            scratch = None
+            if misses:
+                items, staged = job.result() if hasattr(job, "result") else job
+                scratch = self._insert(misses, items, staged)
+            self.stats["hits"] += len(indices) - len(misses)
+            self.stats["misses"] += len(misses)
+            return self._assemble(indices, scratch)
+
+        try:
+            for drawn in self._index_loader:       # (draws what a DataLoader draws, when a DataLoader draws it)
+                indices = self._select(drawn)
+                in_flight = set()
+                for e in pending:
+                    in_flight.update(e[1])
+                misses = [i for i in dict.fromkeys(indices) if not self._cached[i] and i not in in_flight]
+                # an utterance another batch in flight is already reading: wait for that batch instead of reading twice
+                if any(not self._cached[i] and i in in_flight for i in indices):
+                    while pending:
+                        yield finish(pending.popleft())
+                    misses = [i for i in dict.fromkeys(indices) if not self._cached[i]]
+                if not misses:
+                    job = None
+                elif self._pool is not None:
+                    job = self._pool.submit(self._read, misses)
+                else:
+                    job = self._read(misses)
+                pending.append((indices, misses, job))
+                # batches that need no reading are built when their turn comes: nothing to run ahead for
+                while pending and (len(pending) >= self.depth or pending[0][2] is None):
+                    yield finish(pending.popleft())
+            while pending:
+                yield finish(pending.popleft())
+        finally:
+            for e in pending:
+                if hasattr(e[2], "cancel"):
+                    e[2].cancel()
+
+    def cached_bytes(self):
+        return self._bytes_kept
+
+    def __del__(self):
+        pool, self._pool = self._pool, None
+        if pool is not None:
+            pool.shutdown(wait=False)

@@ -29,6 +29,7 @@ from torch.utils.data import DataLoader
 
 from idiaptts_amd import ops, parallel
 from idiaptts_amd.misc import logging_sinks
+from idiaptts_amd.nn.functional import padding_rows_identical
 from idiaptts_amd.src.neural_networks.pytorch import config_json
 
 
@@ -423,6 +424,8 @@ class ModularModelHandlerPyTorch(object):
         self.dataloader_train = None
         self.dataloader_val = None
         self._resident = None          # HBM-resident training state (set_dataset, resident_dataset)
+        self._cached_loaders = {}      # loaders that keep their utterances' rows in HBM (DeviceBatchCache)
+        self._stock_padding = False    # the loaders' batches come from prepare_batch: padding positions are zeros
         self._batch_guard = None       # deferred NaN guard of process_batch(blocking=False)
 
     @staticmethod
@@ -530,20 +533,37 @@ class ModularModelHandlerPyTorch(object):
 
     def set_dataset(self, hparams, dataset_train, dataset_val, collate_fn=None):
         if hparams.get_value("resident_dataset", False):
-            return self._set_resident_dataset(hparams, dataset_train, dataset_val)
+            return self._set_resident_dataset(hparams, dataset_train, dataset_val, collate_fn)
         self._resident = None
+        self._set_loaders(hparams, dataset_train, dataset_val, collate_fn)
+
+    def _set_loaders(self, hparams, dataset_train, dataset_val, collate_fn=None):
         num_workers = hparams.dataset_num_workers_gpu if hparams.use_gpu \
             else hparams.dataset_num_workers_cpu
+        # hparams.dataset_device_cache (default on, GPU only): what the readers return for an utterance stays in HBM
+        # after its first use and later batches are gathered there (data_preparation/DeviceBatchCache.py)
+        device_cache = bool(hparams.use_gpu and hparams.get_value("dataset_device_cache", True)
+                            and torch.cuda.is_available())
         common = dict(batch_first=hparams.batch_first, collate_fn=collate_fn,
                       common_divisor=hparams.num_gpus, num_workers=num_workers,
                       pin_memory=hparams.dataset_pin_memory,
-                      worker_kind=hparams.get_value("dataset_worker_kind", "thread"))
+                      worker_kind=hparams.get_value("dataset_worker_kind", "thread"),
+                      device_cache=device_cache,
+                      device_cache_bytes=hparams.get_value("dataset_device_cache_bytes", None))
         self.dataloader_train = self._get_dataloader(
             batch_size=hparams.batch_size_train, dataset=dataset_train,
             shuffle=hparams.shuffle_train_set, **common)
         self.dataloader_val = self._get_dataloader(
             batch_size=hparams.batch_size_val, dataset=dataset_val,
             shuffle=hparams.shuffle_val_set, **common)
+        # every padding position of a stock batch holds zeros (pad_sequence; a reader that pads up to `min_frames`
+        # in another mode is the exception): the frame-independent layers may then skip them (nn/functional.py)
+        stock = collate_fn is None or collate_fn is self.prepare_batch \
+            or getattr(collate_fn, "__func__", None) is ModularModelHandlerPyTorch.prepare_batch
+        self._stock_padding = bool(stock) and all(
+            r.min_frames is None or getattr(r, "pad_mode", "constant") == "constant"
+            for ds in (dataset_train, dataset_val) if ds is not None
+            for r in getattr(ds, "datareaders", ()))
 
     @staticmethod
     def _items_draw_random_numbers(dataset):
@@ -556,11 +576,22 @@ class ModularModelHandlerPyTorch(object):
 
     def _get_dataloader(self, batch_size, dataset, batch_first=True, collate_fn=None,
                         common_divisor=1, num_workers=1, pin_memory=True, shuffle=False,
-                        worker_kind="process"):
+                        worker_kind="process", device_cache=False, device_cache_bytes=None):
+        stock = collate_fn is None or collate_fn is self.prepare_batch
         collate_fn = self.prepare_batch if collate_fn is None else collate_fn
         rank, world = parallel.dp_rank_world()
         extra = {}
         generator = None
+        cacheable = device_cache and stock and dataset is not None and len(dataset) > 0 \
+            and hasattr(dataset, "get_datareader_by_output_name") and not self._items_draw_random_numbers(dataset)
+        if cacheable:
+            # the loader of an earlier set_dataset call over the same dataset keeps what it has uploaded
+            # (ModularTrainer.train / test call set_dataset every time)
+            key = (id(dataset), len(dataset), batch_size, bool(shuffle), bool(batch_first),
+                   max(common_divisor, world), rank, world, num_workers if worker_kind == "thread" else 0)
+            kept = self._cached_loaders.get(key)
+            if kept is not None and kept.dataset is dataset:
+                return kept
         if world > 1:
             # One process per GPU: every rank draws the same global batches and keeps its own
             # samples; common_divisor makes the split even.  "The same batches" must not depend on
@@ -571,6 +602,15 @@ class ModularModelHandlerPyTorch(object):
             seed = parallel.broadcast_int(int(torch.empty((), dtype=torch.int64).random_().item()),
                                           device=self._dist_device())
             generator = torch.Generator().manual_seed(seed)
+        if cacheable:
+            from idiaptts_amd.src.data_preparation.DeviceBatchCache import CachedBatchLoader
+            device = self._device() if self.model is not None else torch.device("cuda", torch.cuda.current_device())
+            loader = CachedBatchLoader(dataset, batch_size, shuffle, device, batch_first,
+                                       common_divisor=common_divisor, shard=extra.get("shard"),
+                                       threads=num_workers if worker_kind == "thread" else 0, generator=generator,
+                                       byte_budget=device_cache_bytes, host_collate=self.prepare_batch)
+            self._cached_loaders[key] = loader
+            return loader
         collate = partial(collate_fn, common_divisor=common_divisor, batch_first=batch_first, **extra)
         if num_workers > 0 and worker_kind == "thread" and not self._items_draw_random_numbers(dataset):
             # hparams.dataset_num_workers_*: readers in THREADS of this process (hparams.dataset_worker_kind =
@@ -599,20 +639,35 @@ class ModularModelHandlerPyTorch(object):
         def __getitem__(self, i):
             return i
 
-    def _set_resident_dataset(self, hparams, dataset_train, dataset_val):
+    def _set_resident_dataset(self, hparams, dataset_train, dataset_val, collate_fn=None):
         """hparams.resident_dataset: the data readers run ONCE per id, their normalised, length
         matched outputs are packed into FrameShards and uploaded; the
         loaders then only draw utterance indices -- same batch sizes, same shuffling and the same
         RNG consumption as the per-item loaders -- and every mini-batch is gathered on the device
-        as packed valid frames.  Feed-forward models only (frame-independent layers)."""
+        as packed valid frames for the flat feed-forward step (idiaptts_amd.native_ff).  That step
+        covers Linear groups without dropout, one input and one target stream, Adam, one unweighted
+        masked MSE; any other model, optimiser or loss trains on the module path with the device
+        batch cache instead (data_preparation/DeviceBatchCache.py), which holds the same rows."""
         from idiaptts_amd.native_ff import FlatFFModel
         from idiaptts_amd.src.data_preparation.FrameShard import FrameShard
-        flat = FlatFFModel.from_module(self.model, self._device())
-        if flat is None:
-            raise NotImplementedError("hparams.resident_dataset needs a feed-forward model "
-                                      "(Linear groups without dropout).")
         if not hparams.use_gpu:
             raise RuntimeError("hparams.resident_dataset needs hparams.use_gpu.")
+        flat = FlatFFModel.from_module(self.model, self._device())
+        reason = None
+        if flat is None:
+            reason = "the model is not a stack of Linear groups without dropout"
+        else:
+            try:
+                for ds in (dataset_train, dataset_val):
+                    if ds is not None:
+                        self._resident_target_name(ds, self.model.input_names[0])
+            except NotImplementedError as e:
+                reason = str(e)
+        if reason is not None:
+            self.logger.info("resident_dataset: {}; training on the module path with the device batch cache."
+                             .format(reason))
+            self._resident = None
+            return self._set_loaders(hparams, dataset_train, dataset_val, collate_fn)
         device = self._device()
         in_name = self.model.input_names[0]
         shards = {}
@@ -632,7 +687,35 @@ class ModularModelHandlerPyTorch(object):
                                          batch_size=hparams.batch_size_val,
                                          shuffle=hparams.shuffle_val_set, **common) \
             if "val" in shards else None
-        self._resident = {"flat": flat, "shards": shards, "synced": False}
+        self._resident = {"flat": flat, "shards": shards, "synced": False,
+                          "datasets": (dataset_train, dataset_val, collate_fn)}
+
+    def _resident_unsupported(self, hparams, training):
+        """Why the flat feed-forward step cannot run this configuration (None: it can)."""
+        if training and not isinstance(self.optimiser, HipAdam):
+            return "the flat step trains with Adam"
+        if hparams.grad_clip_norm_type is not None and \
+                float(hparams.grad_clip_norm_type) not in (2.0, float("inf")):
+            return "the flat step clips with norm type 2 or inf"
+        if hparams.replace_inf_grads_by_zero:
+            return "replace_inf_grads_by_zero is not part of the flat step"
+        loss = self.losses[0] if len(self.losses) == 1 else None
+        if loss is None or getattr(loss, "loss_weight", 1.0) != 1.0 or getattr(loss, "start_step", 0) > 0 \
+                or getattr(loss, "kind", 0) != 0 or getattr(loss, "reduction", "mean_per_frame") != "mean_per_frame":
+            return "the flat step trains one unweighted masked-MSE loss (mean_per_frame)"
+        return None
+
+    def _resident_fall_through(self, hparams, reason, dataloader):
+        """Leaves the flat step for the module path (the rows come from the device batch cache from then on); returns
+        the module path's loader that stands for `dataloader`."""
+        self.logger.info("resident_dataset: {}; continuing on the module path with the device batch cache."
+                         .format(reason))
+        was_train = dataloader is self.dataloader_train
+        self._resident_sync_to_module()
+        train, val, collate_fn = self._resident["datasets"]
+        self._resident = None
+        self._set_loaders(hparams, train, val, collate_fn)
+        return self.dataloader_train if was_train else self.dataloader_val
 
     @staticmethod
     def _resident_target_name(dataset, input_name):
@@ -690,16 +773,9 @@ class ModularModelHandlerPyTorch(object):
         (idiaptts_amd.native_ff): same losses, same Adam, same scheduler calls."""
         res = self._resident
         flat = res["flat"]
-        if not isinstance(self.optimiser, HipAdam) and training:
-            raise NotImplementedError("resident_dataset trains with Adam.")
-        clip_kind = None
+        clip_kind = None                    # (what the flat step cannot do never gets here: _resident_unsupported)
         if hparams.grad_clip_norm_type is not None:
-            clip_kind = {2.0: 2, float("inf"): 0}.get(float(hparams.grad_clip_norm_type))
-            if clip_kind is None:
-                raise NotImplementedError("resident_dataset clips with norm type 2 or inf.")
-        if hparams.replace_inf_grads_by_zero:
-            raise NotImplementedError("replace_inf_grads_by_zero is not available with "
-                                      "resident_dataset.")
+            clip_kind = {2.0: 2, float("inf"): 0}[float(hparams.grad_clip_norm_type)]
         if not res["synced"]:
             self._resident_sync_from_module()
         if training and self.ema is not None and res.get("ema_shadow") is None:
@@ -708,8 +784,6 @@ class ModularModelHandlerPyTorch(object):
             from idiaptts_amd.native_ff import FlatFFModel
             res["ema_shadow"].copy_(FlatFFModel.from_module(self.ema.model, self._device()).params)
             self.ema.fused = True
-        if len(self.losses) != 1 or getattr(self.losses[0], "loss_weight", 1.0) != 1.0:
-            raise NotImplementedError("resident_dataset trains one unweighted masked-MSE loss.")
         loss_name = self.losses[0].name
         rank, world = parallel.dp_rank_world()
         total = None
@@ -1021,9 +1095,12 @@ class ModularModelHandlerPyTorch(object):
         reproduces the single-GPU step on the whole batch."""
         if self._resident is not None and dataloader in (self.dataloader_train,
                                                             self.dataloader_val):
-            key = "train" if dataloader is self.dataloader_train else "val"
-            return self._process_resident(dataloader, self._resident["shards"][key], hparams,
-                                          total_epoch, total_steps, current_epoch, training)
+            reason = self._resident_unsupported(hparams, training)
+            if reason is None:
+                key = "train" if dataloader is self.dataloader_train else "val"
+                return self._process_resident(dataloader, self._resident["shards"][key], hparams,
+                                              total_epoch, total_steps, current_epoch, training)
+            dataloader = self._resident_fall_through(hparams, reason, dataloader)
         model = self.model
         if training:
             model.train()
@@ -1057,7 +1134,9 @@ class ModularModelHandlerPyTorch(object):
             max_lengths = {k: (lengths[k].max() if torch.is_tensor(lengths[k]) else max(lengths[k]))
                            for k in data_dict if k in lengths}
             with torch.enable_grad() if training else torch.no_grad():
-                model(data_dict, lengths, max_lengths)
+                with padding_rows_identical(self._stock_padding and dataloader in (self.dataloader_train,
+                                                                                   self.dataloader_val)):
+                    model(data_dict, lengths, max_lengths)
                 losses = {}
                 for loss_fn in self.losses:
                     for loss_name, l in loss_fn(data_dict, lengths, total_steps).items():

@@ -12,6 +12,7 @@ import copy
 import torch
 from torch import nn
 
+from idiaptts_amd.nn.functional import ValidRows, padding_is_identical
 from idiaptts_amd.nn.modules import GRU, LSTM, RNN, LinearAct
 
 
@@ -28,8 +29,13 @@ class FusedActivation(nn.Identity):
 
 
 class FFWrapper(nn.Module):
-    def __init__(self, in_dim, layer_config):
+    # a padded batch is computed on its valid rows when at least this share of its positions is padding (packing and
+    # unpacking are two more passes over the rows; an LJSpeech batch of 32 utterances is one third padding)
+    min_padding_share = 1.0 / 16
+
+    def __init__(self, in_dim, layer_config, batch_first=None):
         super().__init__()
+        self.batch_first = batch_first
         nonlin = layer_config.nonlin      # "ReLU" / "Tanh"; older config.json files hold "relu"
         if nonlin is not None:
             nonlin = {"relu": "ReLU", "tanh": "Tanh"}.get(nonlin.lower(), nonlin)
@@ -52,6 +58,20 @@ class FFWrapper(nn.Module):
         pass
 
     def forward(self, input_, **kwargs):
+        """reference FFWrapper.py:63-73: the Sequential on every position of the padded tensor.  Inside a
+        `padding_rows_identical()` context (the handler's training / validation loops over stock batches) the
+        layers see the valid rows and one representative padding row instead; the padding positions of the
+        output receive that row's result, which is what every one of them would have computed."""
+        lengths = kwargs.get("seq_lengths_input")
+        if (lengths is not None and self.batch_first is not None and padding_is_identical() and input_.dim() == 3
+                and input_.is_cuda and input_.dtype == torch.float32
+                and not (self.training and any(isinstance(m, nn.Dropout) for m in self.module))):
+            T = input_.shape[1 if self.batch_first else 0]
+            B = input_.shape[0 if self.batch_first else 1]
+            if torch.is_tensor(lengths) and lengths.numel() == B:
+                vr = ValidRows.get(lengths, T, self.batch_first, input_.device)
+                if vr.n_pad >= self.min_padding_share * B * T and vr.N > 0:
+                    return vr.unpack(self.module(vr.pack(input_))), kwargs
         return self.module(input_), kwargs
 
 
@@ -130,7 +150,7 @@ class RNNDyn(nn.ModuleList):
                 raise NotImplementedError("Conv / BatchNorm groups are outside the accelerated "
                                           "path (SURVEY.md section 2).")
             else:
-                layer = FFWrapper(in_dim, layer_config)
+                layer = FFWrapper(in_dim, layer_config, config.batch_first)
             in_dim = layer.out_dim
             self.append(layer)
             self.layer_groups.append(layer)

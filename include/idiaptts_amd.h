@@ -214,6 +214,32 @@ int itts_rows_gather_f32(const float* d_src, int64_t ld_src, int64_t n_src, cons
                          int width, const float* d_fill_row, float* d_dst, int64_t ld_dst, int dst_width,
                          void* stream);
 
+/* ---- mini-batches on the device (ModularModelHandlerPyTorch.prepare_batch :388-465, sequence_mask :467-491) ----
+ * The rows of the utterances of a batch lie back to back in d_src (utterance b: rows d_starts[b] .. d_starts[b] +
+ * d_lens[b] - 1, d_starts / d_lens on the device); the padded batch is [n_utts, t_max, width] (batch_first) or
+ * [t_max, n_utts, width] with row pitch ld_dst.  Position (b, t) receives row d_starts[b] + t for t < d_lens[b]
+ * (and a row inside [0, n_src)), else d_fill_row[:width] (zeros when NULL) -- pad_sequence of the cached rows, or
+ * pad_packed_sequence with the layers' value of a padding position as the fill row; the padding position with flat
+ * index rep_pos (in the batch's layout; -1: none) receives d_rep_row[:width] instead; d_mask (may be NULL) receives
+ * the float sequence mask, one value per position in the batch's layout. */
+int itts_batch_pad_gather_f32(const float* d_src, int64_t ld_src, int64_t n_src, const int64_t* d_starts,
+                              const int64_t* d_lens, int n_utts, int64_t t_max, int width, int batch_first,
+                              const float* d_fill_row, int64_t rep_pos, const float* d_rep_row, float* d_dst,
+                              int64_t ld_dst, float* d_mask, void* stream);
+/* The adjoint: d_dst[d_starts[b] + t, :width] = padded position (b, t) of d_src for t < d_lens[b]; columns width ..
+ * dst_width - 1 of the written rows are zeroed (16-byte row pitches for the GEMMs).  Padding positions are not read,
+ * except the one with flat index rep_pos (-1: none), which is written to row rep_dst_row. */
+int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, const int64_t* d_starts, const int64_t* d_lens,
+                             int n_utts, int64_t t_max, int width, int batch_first, float* d_dst, int64_t ld_dst,
+                             int dst_width, int64_t rep_pos, int64_t rep_dst_row, void* stream);
+/* d_out[c] = sum of d_x[(b, t), c] over the padding positions (t >= d_lens[b]) of a padded batch, summed in a fixed
+ * order (the gradient that reaches the fill row of itts_batch_pad_gather_f32); d_out[width .. out_width - 1] = 0.
+ * d_workspace: itts_batch_pad_colsum_workspace_bytes(width) bytes on the device. */
+int64_t itts_batch_pad_colsum_workspace_bytes(int width);
+int itts_batch_pad_colsum_f32(const float* d_x, int64_t ld_x, const int64_t* d_lens, int n_utts, int64_t t_max,
+                              int width, int batch_first, float* d_out, int out_width, void* d_workspace,
+                              void* stream);
+
 /* ---- acoustic model: dense layers (rnn_dyn/FFWrapper.py:63-73 -> torch.nn.Linear + act) --- */
 #define ITTS_ACT_NONE 0
 #define ITTS_ACT_TANH 1

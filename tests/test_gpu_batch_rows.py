@@ -1,0 +1,228 @@
+"""csrc/batch_rows.hip on the GPU: padded batches from rows kept in HBM (prepare_batch's pad_sequence + sequence_mask,
+ModularModelHandlerPyTorch.py:388-491), the frame-independent layers on valid rows (rnn_dyn/FFWrapper.py:63-73) and
+the handler's cached loader against torch's DataLoader over prepare_batch."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+from torch.nn.utils.rnn import pad_sequence
+from torch.utils.data import DataLoader
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(lens, dev):
+    lens = np.asarray(lens, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    return torch.from_numpy(np.stack([starts, lens])).to(dev)
+
+
+@pytest.mark.parametrize("width", [1, 5, 8, 187, 425, 428])
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_pad_gather_pack_and_colsum_against_torch(gpu, width, batch_first):
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(width)
+    lens = [7, 1, 19, 4, 19, 11]
+    T = 23                                      # (longer than the longest: min_frames)
+    seqs = [torch.randn(n, width, generator=g) for n in lens]
+    rows = torch.cat(seqs).to(gpu)
+    tab = _table(lens, gpu)
+    want = pad_sequence(seqs + [torch.zeros(T, width)], batch_first=batch_first)
+    want = want[:-1] if batch_first else want[:, :-1]
+    got, mask = ops.batch_pad_gather(rows, tab[0], tab[1], len(lens), T, batch_first, want_mask=True)
+    assert torch.equal(got.cpu(), want)
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as H
+    assert torch.equal(mask.cpu(), H.sequence_mask(torch.tensor(lens), T, batch_first=batch_first))
+    # a fill row for the padding positions and another one for the representative position
+    fill, rep = torch.randn(width, generator=g).to(gpu), torch.randn(width, generator=g).to(gpu)
+    rep_pos = (1 * T + T - 1) if batch_first else ((T - 1) * len(lens) + 1)
+    got2, _ = ops.batch_pad_gather(rows, tab[0], tab[1], len(lens), T, batch_first, fill_row=fill, rep_pos=rep_pos,
+                                   rep_row=rep)
+    m = mask.cpu().bool().expand_as(want)
+    want2 = torch.where(m, want, fill.cpu().expand_as(want)).reshape(-1, width).clone()
+    want2[rep_pos] = rep.cpu()
+    assert torch.equal(got2.cpu().reshape(-1, width), want2)
+    # the adjoint, with zeroed pad columns and the representative row behind the valid ones
+    wpad = (width + 3) // 4 * 4
+    out = torch.full((sum(lens) + 1, wpad), float("nan"), device=gpu)
+    ops.batch_pack_rows(got2, tab[0], tab[1], batch_first, sum(lens), out_width=wpad, out=out, rep_pos=rep_pos,
+                        rep_dst_row=sum(lens))
+    assert torch.equal(out[:-1, :width].cpu(), rows.cpu()) and torch.equal(out[-1, :width].cpu(), rep.cpu())
+    assert wpad == width or bool((out[:, width:] == 0).all())
+    # column sums over the padding positions: fixed order (two calls agree bit for bit), float64 value
+    s0 = ops.batch_pad_colsum(got2, tab[1], batch_first)
+    s1 = ops.batch_pad_colsum(got2, tab[1], batch_first)
+    assert torch.equal(s0, s1)
+    ref = (got2.cpu().double() * (~m).double()).reshape(-1, width).sum(0)
+    assert float((s0.cpu().double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _ff_model(dev, batch_first, dims=(13, 32, 32, 7), act="TANH"):
+    import types
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    torch.manual_seed(3)
+    hp = types.SimpleNamespace(model_type="RNNDYN-2_{}_{}-1_FC_{}".format(act, dims[1], dims[3]),
+                               batch_first=batch_first, dropout=0.0)
+    cfg = rnn_dyn.convert_legacy_to_config((dims[0],), hp)
+    return cfg.create_model().to(dev)
+
+
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_ff_groups_on_valid_rows_equal_the_padded_computation(gpu, batch_first):
+    """The same model, the same padded batch: inside `padding_rows_identical()` the Linear groups run on valid rows
+    + one representative padding row.  Outputs agree bit for bit at EVERY position (a row's dot products do not
+    depend on where the row sits), parameter gradients to summation order -- also with a loss that is not masked,
+    where the padding positions do contribute."""
+    from idiaptts_amd.nn.functional import padding_rows_identical
+    model = _ff_model(gpu, batch_first)
+    g = torch.Generator().manual_seed(9)
+    lens = torch.tensor([37, 5, 64, 22, 64, 3, 50, 41])
+    seqs = [torch.randn(int(n), 13, generator=g) for n in lens]
+    x = pad_sequence(seqs, batch_first=batch_first).to(gpu)
+    T = int(lens.max())
+    w = torch.randn(7, generator=g).to(gpu)
+
+    def run(packed, masked):
+        model.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        with padding_rows_identical(packed):
+            y, _ = model(xin, seq_lengths_input=lens, max_length_inputs=T)
+        from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch
+        m = ModularModelHandlerPyTorch.sequence_mask(lens, T, batch_first=batch_first).to(gpu)
+        loss = ((y * w) ** 2 * (m if masked else 1.0)).sum()
+        loss.backward()
+        return y.detach().clone(), [p.grad.clone() for p in model.parameters()], xin.grad.clone()
+
+    for masked in (True, False):
+        y0, g0, dx0 = run(False, masked)
+        y1, g1, dx1 = run(True, masked)
+        assert torch.equal(y0, y1)
+        for a, b in zip(g0, g1):
+            scale = float(a.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-5 * scale
+        # input gradient: valid positions agree; over the padding positions the totals agree
+        m3 = ModularMask(lens, T, batch_first).to(gpu)
+        scale = float(dx0.abs().max()) + 1e-30
+        assert float(((dx0 - dx1) * m3).abs().max()) <= 2e-5 * scale
+        tot0, tot1 = (dx0 * (1 - m3)).reshape(-1, 13).sum(0), (dx1 * (1 - m3)).reshape(-1, 13).sum(0)
+        assert float((tot0 - tot1).abs().max()) <= 1e-4 * (float(tot0.abs().max()) + 1e-30) + 1e-6
+
+
+def ModularMask(lens, T, batch_first):
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as H
+    return H.sequence_mask(lens, T, batch_first=batch_first)
+
+
+def test_ff_groups_fall_back_to_all_positions(gpu):
+    """no context, no lengths, little padding, dropout in training: the layers see the padded tensor"""
+    from idiaptts_amd.nn import functional as F
+    model = _ff_model(gpu, True)
+    lens = torch.tensor([30, 31, 32, 32])
+    x = torch.randn(4, 32, 13, device=gpu)
+    calls = []
+    orig = F.ValidRows.get.__func__
+
+    def spy(cls, *a, **kw):
+        vr = orig(cls, *a, **kw)
+        calls.append(vr)
+        return vr
+
+    F.ValidRows.get = classmethod(spy)
+    try:
+        model(x, seq_lengths_input=lens, max_length_inputs=32)
+        assert not calls                                           # no context
+        with F.padding_rows_identical():
+            model(x, seq_lengths_input=lens, max_length_inputs=32)
+            assert calls and calls[-1].n_pad == 3                  # asked, but 3 of 128 positions: not packed
+            y_few, _ = model(x, seq_lengths_input=lens, max_length_inputs=32)
+        y_all, _ = model(x, seq_lengths_input=lens, max_length_inputs=32)
+        assert torch.equal(y_few, y_all)
+    finally:
+        F.ValidRows.get = classmethod(orig)
+
+
+class _Reader(object):
+    min_frames = None
+    other_pad_dims = None
+    max_frames = None
+    pad_mode = "constant"
+
+    def __init__(self, name, mask):
+        self.name, self.output_names, self.requires_seq_mask = name, [name], mask
+
+
+class _Dicts(torch.utils.data.Dataset):
+    def __init__(self, n):
+        rng = np.random.default_rng(1)
+        self.datareaders = [_Reader("x", False), _Reader("y", True)]
+        self.reads = 0
+        self.items = [{"x": rng.standard_normal((3 + (5 * i) % 11, 425)).astype(np.float32),
+                       "_id_list": "id%d" % i,
+                       "y": rng.standard_normal((3 + (5 * i) % 11, 187)).astype(np.float32)} for i in range(n)]
+
+    def get_datareader_by_output_name(self, name):
+        for r in self.datareaders:
+            if r.name == name:
+                return r
+        raise KeyError(name)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        self.reads += 1
+        return self.items[i], self
+
+
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_handler_cached_loader_equals_dataloader_with_shuffling(gpu, batch_first):
+    """hparams.dataset_device_cache (default): from the second epoch on every batch is gathered in HBM -- the same
+    batches in the same order, bit for bit, as DataLoader(shuffle=True, collate_fn=prepare_batch) gives, already on
+    the device, and no item is read again (reference: ModularModelHandlerPyTorch.py:500-548, :683-760)."""
+    from idiaptts_amd.src.data_preparation.DeviceBatchCache import CachedBatchLoader
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as H
+    ds_ref, ds = _Dicts(41), _Dicts(41)
+    torch.manual_seed(77)
+    ref_loader = DataLoader(ds_ref, batch_size=8, shuffle=True, num_workers=0,
+                            collate_fn=partial(H.prepare_batch, batch_first=batch_first))
+    ref = [[b for b in ref_loader] for _ in range(3)]
+    handler = H()
+    torch.manual_seed(77)
+    loader = handler._get_dataloader(batch_size=8, dataset=ds, batch_first=batch_first, num_workers=3,
+                                     pin_memory=True, shuffle=True, worker_kind="thread", device_cache=True)
+    assert isinstance(loader, CachedBatchLoader)
+    got = [[b for b in loader] for _ in range(3)]
+    assert ds.reads == len(ds) and ds_ref.reads == 3 * len(ds)
+    for e_ref, e_got in zip(ref, got):
+        assert len(e_ref) == len(e_got) == 6
+        for (d0, l0), (d1, l1) in zip(e_ref, e_got):
+            assert list(d0) == list(d1) == ["x", "_id_list", "y_mask", "y"] and list(l0) == list(l1)
+            assert d0["_id_list"] == d1["_id_list"]
+            for k in ("x", "y", "y_mask"):
+                assert d1[k].is_cuda and torch.equal(d0[k], d1[k].cpu())
+            for k in l0:
+                assert torch.equal(l0[k], l1[k])
+    # the same loader again for the same dataset (ModularTrainer.train / test call set_dataset every time)
+    again = handler._get_dataloader(batch_size=8, dataset=ds, batch_first=batch_first, num_workers=3,
+                                    pin_memory=True, shuffle=True, worker_kind="thread", device_cache=True)
+    assert again is loader
+    assert loader.stats["misses"] == len(ds) and loader.stats["hits"] == 2 * len(ds)
+
+
+def test_cached_loader_over_budget_on_the_device(gpu):
+    from idiaptts_amd.src.data_preparation.DeviceBatchCache import CachedBatchLoader
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as H
+    ds_ref, ds = _Dicts(30), _Dicts(30)
+    torch.manual_seed(5)
+    ref = [[b for b in DataLoader(ds_ref, batch_size=7, shuffle=True, num_workers=0,
+                                  collate_fn=partial(H.prepare_batch, batch_first=True))] for _ in range(2)]
+    torch.manual_seed(5)
+    loader = CachedBatchLoader(ds, 7, True, gpu, True, threads=2, byte_budget=4 * 612 * 60,
+                               host_collate=H.prepare_batch)
+    got = [[b for b in loader] for _ in range(2)]
+    assert 0 < loader._cached.sum() < len(ds) and loader.stats["passed_through"] > 0
+    for e_ref, e_got in zip(ref, got):
+        for (d0, _), (d1, _) in zip(e_ref, e_got):
+            for k in ("x", "y", "y_mask"):
+                assert torch.equal(d0[k], d1[k].cpu())
