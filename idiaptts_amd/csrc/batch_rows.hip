@@ -25,14 +25,17 @@ namespace itts {
 
 static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// padded position r -> (b, t)
+// padded position r -> (b, t); the entry points keep n_utts * t_max below 2^31, so 32-bit division does
 __device__ __forceinline__ void split_row(int64_t r, int64_t t_max, int n_utts, int batch_first, int& b, int64_t& t) {
+  const uint32_t r32 = (uint32_t)r;
   if (batch_first) {
-    b = (int)(r / t_max);
-    t = r - (int64_t)b * t_max;
+    const uint32_t q = r32 / (uint32_t)t_max;
+    b = (int)q;
+    t = r32 - q * (uint32_t)t_max;
   } else {
-    t = r / n_utts;
-    b = (int)(r - t * n_utts);
+    const uint32_t q = r32 / (uint32_t)n_utts;
+    t = q;
+    b = (int)(r32 - q * (uint32_t)n_utts);
   }
 }
 
@@ -98,29 +101,34 @@ __global__ __launch_bounds__(256) void batch_pack_rows_kernel(const float* __res
   }
 }
 
-constexpr int kColsumSlabs = 512;
+constexpr int kColsumSlabRows = 64;      // rows per workgroup of stage 1: 16 per wave
 
-// stage 1: workgroup s sums the padding rows of its slab of consecutive rows, wave w taking rows w, w + 4, ...
-// of the slab and lane l the columns l, l + 64, ...; the four waves' sums meet in LDS in wave order
+// stage 1: workgroup s sums the padding rows among its 64 consecutive rows -- wave w owns rows 16 w .. 16 w + 15
+// of the slab, its first 16 lanes work out (one division each, side by side) which of them are padding, the wave
+// then walks the set bits in row order, lane l adding the columns l, l + 64, ...; the four waves' sums meet in LDS
+// in wave order.  A fixed order throughout: the same batch gives the same bits.
 __global__ __launch_bounds__(256) void batch_pad_colsum_partial_kernel(const float* __restrict__ x, int64_t ld,
                                                                        const int64_t* __restrict__ lens, int n_utts,
                                                                        int64_t t_max, int width, int batch_first,
-                                                                       int64_t rows_per_slab,
                                                                        float* __restrict__ partial) {
   extern __shared__ float sm[];      // [4][width]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n_rows = (int64_t)n_utts * t_max;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab, r1 = std::min<int64_t>(r0 + rows_per_slab, n_rows);
+  const int64_t r0 = (int64_t)blockIdx.x * kColsumSlabRows + wave * 16;
+  bool pad = false;
+  if (lane < 16 && r0 + lane < n_rows) {
+    int b;
+    int64_t t;
+    split_row(r0 + lane, t_max, n_utts, batch_first, b, t);
+    pad = t >= lens[b];
+  }
+  const unsigned long long pads = __ballot(pad);
   for (int c0 = 0; c0 < width; c0 += 64 * 8) {      // eight columns per lane and sweep
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int64_t r = r0 + wave; r < r1; r += 4) {
-      int b;
-      int64_t t;
-      split_row(r, t_max, n_utts, batch_first, b, t);
-      if (t < lens[b]) continue;
-      const float* s = x + r * ld;
+    for (unsigned long long m = pads; m; m &= m - 1) {
+      const float* s = x + (r0 + __builtin_ctzll(m)) * ld;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = c0 + j * 64 + lane;
@@ -138,19 +146,19 @@ __global__ __launch_bounds__(256) void batch_pad_colsum_partial_kernel(const flo
     partial[(int64_t)blockIdx.x * width + c] = ((sm[c] + sm[width + c]) + sm[2 * width + c]) + sm[3 * width + c];
 }
 
-// stage 2: out[c] = sum over the slabs in slab order
+// stage 2: one wave per column -- lane l adds the slabs l, l + 64, ... in that order, the 64 sums meet in the
+// fixed butterfly of wave_sum
 __global__ __launch_bounds__(256) void batch_pad_colsum_final_kernel(const float* __restrict__ partial, int n_slabs,
                                                                      int width, float* __restrict__ out,
                                                                      int out_width) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= out_width) return;
-  if (c >= width) {
-    out[c] = 0.f;
-    return;
-  }
   float acc = 0.f;
-  for (int s = 0; s < n_slabs; ++s) acc += partial[(int64_t)s * width + c];
-  out[c] = acc;
+  if (c < width)
+    for (int s = lane; s < n_slabs; s += 64) acc += partial[(int64_t)s * width + c];
+  acc = wave_sum(acc);
+  if (lane == 0) out[c] = acc;
 }
 
 static unsigned row_grid(int64_t n_rows) { return (unsigned)std::min<int64_t>((n_rows + 3) / 4, 16384); }
@@ -166,6 +174,7 @@ extern "C" int itts_batch_pad_gather_f32(const float* d_src, int64_t ld_src, int
   ITTS_REQUIRE(n_utts >= 0 && t_max >= 0 && width >= 0 && n_src >= 0 && ld_src >= width && ld_dst >= width, "bad sizes");
   const int64_t n_rows = (int64_t)n_utts * t_max;
   if (n_rows == 0) return ITTS_OK;
+  ITTS_REQUIRE(n_rows < ((int64_t)1 << 31), "more than 2^31 positions");
   ITTS_REQUIRE(d_starts && d_lens && d_dst && (d_src || n_src == 0), "null pointer");
   ITTS_REQUIRE(rep_pos < n_rows && (rep_pos < 0 || d_rep_row), "bad representative position");
   const bool vec = width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(d_src) && aligned16(d_dst) &&
@@ -190,6 +199,7 @@ extern "C" int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, cons
                "bad sizes");
   const int64_t n_rows = (int64_t)n_utts * t_max;
   if (n_rows == 0 || dst_width == 0) return ITTS_OK;
+  ITTS_REQUIRE(n_rows < ((int64_t)1 << 31), "more than 2^31 positions");
   ITTS_REQUIRE(d_starts && d_lens && d_src && d_dst, "null pointer");
   ITTS_REQUIRE(rep_pos < n_rows && (rep_pos < 0 || rep_dst_row >= 0), "bad representative position");
   const bool vec = width % 4 == 0 && dst_width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(d_src) &&
@@ -206,8 +216,9 @@ extern "C" int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, cons
   return ITTS_OK;
 }
 
-extern "C" int64_t itts_batch_pad_colsum_workspace_bytes(int width) {
-  return (int64_t)kColsumSlabs * std::max(width, 0) * (int64_t)sizeof(float);
+extern "C" int64_t itts_batch_pad_colsum_workspace_bytes(int64_t n_rows, int width) {
+  const int64_t n_slabs = (std::max<int64_t>(n_rows, 0) + kColsumSlabRows - 1) / kColsumSlabRows;
+  return std::max<int64_t>(n_slabs, 1) * std::max(width, 0) * (int64_t)sizeof(float);
 }
 
 extern "C" int itts_batch_pad_colsum_f32(const float* d_x, int64_t ld_x, const int64_t* d_lens, int n_utts,
@@ -223,13 +234,13 @@ extern "C" int itts_batch_pad_colsum_f32(const float* d_x, int64_t ld_x, const i
     return ITTS_OK;
   }
   ITTS_REQUIRE(d_x && d_lens, "null pointer");
-  const int64_t rows_per_slab = (n_rows + kColsumSlabs - 1) / kColsumSlabs;
-  const int n_slabs = (int)((n_rows + rows_per_slab - 1) / rows_per_slab);
+  ITTS_REQUIRE(n_rows < ((int64_t)1 << 31), "more than 2^31 positions");
+  const int n_slabs = (int)((n_rows + kColsumSlabRows - 1) / kColsumSlabRows);
   float* partial = static_cast<float*>(d_workspace);
   hipLaunchKernelGGL(batch_pad_colsum_partial_kernel, dim3(n_slabs), dim3(256), sizeof(float) * 4 * width,
-                     as_stream(stream), d_x, ld_x, d_lens, n_utts, t_max, width, batch_first, rows_per_slab, partial);
+                     as_stream(stream), d_x, ld_x, d_lens, n_utts, t_max, width, batch_first, partial);
   ITTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(batch_pad_colsum_final_kernel, dim3((out_width + 255) / 256), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(batch_pad_colsum_final_kernel, dim3((out_width + 3) / 4), dim3(256), 0, as_stream(stream),
                      partial, n_slabs, width, d_out, out_width);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;

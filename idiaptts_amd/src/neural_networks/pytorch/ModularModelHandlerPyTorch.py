@@ -1178,7 +1178,8 @@ class ModularModelHandlerPyTorch(object):
                     dataloader_length=len(dataloader), hparams=hparams, total_epoch=total_epoch)
                 self.run_scheduler(hparams=hparams, loss=scheduler_loss,
                                    current_iter=current_iter)
-            if batch_index % logging_batch_index == 0:
+            if batch_index % logging_batch_index == 0 and self.logger.isEnabledFor(logging.INFO):
+                # (the line reads the losses back: a host wait for the whole queue -- only when somebody listens)
                 self.logger.info("{} mini batch [{}/{}]\tLoss: {}{}".format(
                     "Train" if training else "Test", batch_index + 1, len(dataloader),
                     " ".join("{}: {:.3f}".format(k, float(l.detach())) for k, l in losses.items()),

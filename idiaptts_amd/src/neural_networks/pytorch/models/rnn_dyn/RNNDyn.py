@@ -57,21 +57,32 @@ class FFWrapper(nn.Module):
     def init_hidden(self, batch_size=1):
         pass
 
+    def valid_rows_for(self, input_, kwargs):
+        """The ValidRows bookkeeping when this group may run on the valid rows of `input_` (see forward), else None."""
+        lengths = kwargs.get("seq_lengths_input")
+        if (lengths is None or self.batch_first is None or not padding_is_identical() or input_.dim() != 3
+                or not input_.is_cuda or input_.dtype != torch.float32 or not self.runs_on_rows()):
+            return None
+        T = input_.shape[1 if self.batch_first else 0]
+        B = input_.shape[0 if self.batch_first else 1]
+        if not torch.is_tensor(lengths) or lengths.numel() != B:
+            return None
+        vr = ValidRows.get(lengths, T, self.batch_first, input_.device)
+        return vr if vr.n_pad >= self.min_padding_share * B * T and vr.N > 0 else None
+
+    def runs_on_rows(self):
+        """dropout draws per position: in training the padding positions would not stay identical"""
+        return not (self.training and any(isinstance(m, nn.Dropout) for m in self.module))
+
     def forward(self, input_, **kwargs):
         """reference FFWrapper.py:63-73: the Sequential on every position of the padded tensor.  Inside a
         `padding_rows_identical()` context (the handler's training / validation loops over stock batches) the
         layers see the valid rows and one representative padding row instead; the padding positions of the
-        output receive that row's result, which is what every one of them would have computed."""
-        lengths = kwargs.get("seq_lengths_input")
-        if (lengths is not None and self.batch_first is not None and padding_is_identical() and input_.dim() == 3
-                and input_.is_cuda and input_.dtype == torch.float32
-                and not (self.training and any(isinstance(m, nn.Dropout) for m in self.module))):
-            T = input_.shape[1 if self.batch_first else 0]
-            B = input_.shape[0 if self.batch_first else 1]
-            if torch.is_tensor(lengths) and lengths.numel() == B:
-                vr = ValidRows.get(lengths, T, self.batch_first, input_.device)
-                if vr.n_pad >= self.min_padding_share * B * T and vr.N > 0:
-                    return vr.unpack(self.module(vr.pack(input_))), kwargs
+        output receive that row's result, which is what every one of them would have computed.  (RNNDyn.forward
+        keeps consecutive Linear groups on the rows without going back to the padded tensor in between.)"""
+        vr = self.valid_rows_for(input_, kwargs)
+        if vr is not None:
+            return vr.unpack(self.module(vr.pack(input_))), kwargs
         return self.module(input_), kwargs
 
 
@@ -173,13 +184,26 @@ class RNNDyn(nn.ModuleList):
             for idx, emb in enumerate(self.emb_groups.values()):
                 embeddings[emb.name] = emb(emb_inputs[idx][:, :, 0].long())
         last_hidden = None
+        rows = None          # (ValidRows, [N (+ 1), F]) while a run of Linear groups works on the valid rows
         for group_idx, module in enumerate(self.layer_groups):
-            for emb in self.emb_groups.values():
-                if self._affects(emb, group_idx):
-                    input_ = torch.cat((input_, embeddings[emb.name]), dim=2)
+            affected = [emb for emb in self.emb_groups.values() if self._affects(emb, group_idx)]
+            if isinstance(module, FFWrapper) and not affected:
+                if rows is None:
+                    vr = module.valid_rows_for(input_, kwargs)
+                    if vr is not None:
+                        rows = (vr, vr.pack(input_))
+                if rows is not None and module.runs_on_rows():
+                    rows = (rows[0], module.module(rows[1]))
+                    continue
+            if rows is not None:
+                input_, rows = rows[0].unpack(rows[1]), None
+            for emb in affected:
+                input_ = torch.cat((input_, embeddings[emb.name]), dim=2)
             input_, kwargs = module(input_, **kwargs)
             # hidden states are not passed from one RNN group to the next (reference :118-121)
             last_hidden = kwargs.pop("hidden", last_hidden)
+        if rows is not None:
+            input_ = rows[0].unpack(rows[1])
         kwargs["hidden"] = last_hidden
         return input_, kwargs
 

@@ -234,8 +234,8 @@ int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, const int64_t* 
                              int dst_width, int64_t rep_pos, int64_t rep_dst_row, void* stream);
 /* d_out[c] = sum of d_x[(b, t), c] over the padding positions (t >= d_lens[b]) of a padded batch, summed in a fixed
  * order (the gradient that reaches the fill row of itts_batch_pad_gather_f32); d_out[width .. out_width - 1] = 0.
- * d_workspace: itts_batch_pad_colsum_workspace_bytes(width) bytes on the device. */
-int64_t itts_batch_pad_colsum_workspace_bytes(int width);
+ * d_workspace: itts_batch_pad_colsum_workspace_bytes(n_utts * t_max, width) bytes on the device. */
+int64_t itts_batch_pad_colsum_workspace_bytes(int64_t n_rows, int width);
 int itts_batch_pad_colsum_f32(const float* d_x, int64_t ld_x, const int64_t* d_lens, int n_utts, int64_t t_max,
                               int width, int batch_first, float* d_out, int out_width, void* d_workspace,
                               void* stream);
