@@ -527,6 +527,18 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
         # 40-50 us of host side -- allocations, sort, table, launch -- between its events, the device idle)
         ms_ml_q = over_ranks(hip_event_queued_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off), stream, 8, 5),
                              dist.ReduceOp.MAX)
+        # the lone call again with a prepared plan (ops.MlpgPlan: offsets checked and sorted once, table in page-locked
+        # memory, scratch kept): what a caller solving the streams of one batch pays from the second stream on
+        ml_plan = ops.MlpgPlan(ml_off)
+        ml_out = torch.empty((ml_frames, 62), dtype=torch.float64, device=dev)
+        ops.mlpg_generation(feat, var, 62, ml_off, out=ml_out, plan=ml_plan)
+        sync()
+        ms_ml_p = over_ranks(hip_event_median_ms(lambda: ops.mlpg_generation(feat, var, 62, ml_off, out=ml_out,
+                                                                             plan=ml_plan), stream, 7),
+                             dist.ReduceOp.MAX)
+        sync()
+        ml_plan.close()
+        del ml_out
         ml_frames *= n_ranks                      # same lengths on every rank
         gbs = ml_frames * 2000 / (ms_ml * 1e-3) / 1e9
         gbs_q = ml_frames * 2000 / (ms_ml_q * 1e-3) / 1e9
@@ -537,6 +549,8 @@ def world_section(dev, n_utts, fs, cpu_seconds=25.0, with_cpu=True, with_mlpg=Tr
                        "frames_per_s": ml_frames / (ms_ml * 1e-3),
                        "algorithmic_GBps": gbs,
                        "frac_of_hbm_peak": gbs / PEAK_HBM_GBS / n_ranks,
+                       "ms_planned": ms_ml_p,
+                       "frac_of_hbm_peak_planned": ml_frames * 2000 / (ms_ml_p * 1e-3) / 1e9 / PEAK_HBM_GBS / n_ranks,
                        "ms_queued": ms_ml_q,
                        "roofline": {"bound": "hbm", "kernel": "mlpg_ring_kernel (one launch)",
                                     "from": "8 calls queued back to back, HIP events around them on the launch stream, / 8 "
@@ -734,6 +748,79 @@ def duration_mlpg_section(dev, n_utts=256):
         "duration_model_ms": ms_dur, "utterances_per_s": n_utts / (ms * 1e-3),
         "phones_per_s": P / (ms_dur * 1e-3), "frames_per_s": ml_off[-1] / (ms * 1e-3),
         "timing": "median of 7 passes, HIP events on the launch stream"}}
+
+
+def api_single_call_section(dev, fs=16000, seconds=6.6, repeats=20, with_cpu=True):
+    """ONE utterance through the reference's one-utterance signatures, numpy in -> numpy out, host <-> device copies
+    and every host-side step included (median wall clock of `repeats` calls after two warm-up calls):
+      analysis   WorldFeatLabelGen.world_extract_features (:778-807) + AudioProcessing.extract_mcep (:142-153),
+                 what WorldFeatLabelGen.extract_features (:809-889, called once per file by gen_data :996) does
+      synthesis  WorldFeatLabelGen.world_features_to_raw (:909-945)
+      mlpg       MLPG().generation (misc/mlpg.py:94-127) of the 60 mcep trajectories (one stream, as the reference
+                 calls it per stream)
+    beside the same three steps of the C oracle on one core.  Every other WORLD figure of this file is a 64-512
+    utterance batch; this is what a caller who changes nothing pays per call."""
+    from idiaptts_amd import lib
+    from idiaptts_amd.misc.mlpg import MLPG
+    from idiaptts_amd.src.data_preparation.audio.AudioProcessing import AudioProcessing
+    from idiaptts_amd.src.data_preparation.world.WorldFeatLabelGen import WorldFeatLabelGen
+    from idiaptts_amd.synthetic_audio import make_audio
+    L = lib.load()
+    alpha = L.itts_mcep_alpha(fs)
+    raw = make_audio(fs, seconds, 31)
+    rng = np.random.default_rng(2)
+
+    def analysis():
+        amp_sp, lf0, vuv, bap = WorldFeatLabelGen.world_extract_features(raw, fs, 5)
+        return amp_sp, lf0, vuv, bap, AudioProcessing.extract_mcep(amp_sp, 60, alpha)
+
+    amp_sp, lf0, vuv, bap, mcep = analysis()
+    T = len(lf0)
+    feats = rng.standard_normal((T, 180))
+    cov = np.diag(rng.uniform(0.01, 1.0, 180))
+
+    def synthesis():
+        return WorldFeatLabelGen.world_features_to_raw(amp_sp, lf0.copy(), vuv.copy(), bap, fs)
+
+    mlpg = MLPG()
+
+    def smooth():
+        return mlpg.generation(feats, cov, 60)
+
+    def median_ms(fn):
+        for _ in range(2):
+            fn()
+        times = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times)) * 1e3, float(np.min(times)) * 1e3
+
+    out = {"fs": fs, "audio_seconds": seconds, "frames": int(T), "repeats": repeats,
+           "timing": "median (and minimum) wall clock of one call, numpy in -> numpy out"}
+    for key, fn in (("analysis", analysis), ("synthesis", synthesis), ("mlpg", smooth)):
+        med, best = median_ms(fn)
+        out[key] = {"ms": med, "ms_min": best}
+    out["analysis"]["rtf"] = out["analysis"]["ms"] * 1e-3 / seconds
+    out["synthesis"]["rtf"] = out["synthesis"]["ms"] * 1e-3 / seconds
+    if with_cpu:
+        from oracle import capi
+        n_fft = L.itts_cheaptrick_fft_size(fs, 71.0)
+        t0 = time.perf_counter()
+        f0c, spc, apc = capi.wav2world(raw, fs)
+        bapc = capi.code_aperiodicity(apc, fs)
+        mcc = capi.mcep(np.sqrt(spc), 59, alpha)
+        t1 = time.perf_counter()
+        pw = np.exp(capi.mgc2sp_logamp(mcc, alpha, n_fft).astype(np.float32)).astype(np.float64) ** 2
+        capi.synthesize(f0c, pw, capi.decode_aperiodicity(bapc, fs, n_fft), fs)
+        t2 = time.perf_counter()
+        capi.mlpg(feats, np.diag(cov).copy(), 60)
+        t3 = time.perf_counter()
+        out["cpu_oracle_one_core_ms"] = {"analysis": (t1 - t0) * 1e3, "synthesis": (t2 - t1) * 1e3,
+                                         "mlpg": (t3 - t2) * 1e3}
+    return {"api_single_call": out}
 
 
 def gen_data_section(n_utts=512, batch_utts=64):
@@ -1361,6 +1448,7 @@ def main():
                     extra["trainer_epoch"]["resident_epoch_section_valid_frames_per_s"] = \
                         extra["resident_epoch"]["valid_frames_per_s"]
             extra.update(duration_mlpg_section(dev))
+            extra.update(api_single_call_section(dev, with_cpu=want_cpu))
             extra.update(gen_data_section(min(512, max(8, 2 * args.world_utts)),
                                           min(64, max(4, args.world_utts // 4))))
         out = {

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -1800,20 +1801,66 @@ __global__ void mlpg_widen_kernel(const float* __restrict__ src, int64_t ld, int
 
 // d_feat32 != nullptr: the input rows are float32 (d_feat unused); d_scratch then holds a [Ttot, 3 dim] float64
 // array behind the usual scratch, for the batches that do not take the one-pass kernel
+// What a call works out from the offsets alone, kept by a caller that solves over the same utterances again (the
+// streams of one batch: mcep, lf0, bap; a trainer's fixed validation set): the checks, the longest length and -- for
+// the one-pass kernel -- the (start, end) table in launch order, in page-locked memory of its own.  40-50 us of
+// host time in front of a 230-us launch otherwise.
+struct MlpgPlan {
+  std::vector<int64_t> offsets;      // [n_utts + 1]
+  int n_utts = 0;
+  int64_t t_total = 0, t_max = 0;
+  int64_t* table = nullptr;          // hipHostMalloc: (start, end) pairs, longest utterance first
+};
+
+static void mlpg_sorted_table(const int64_t* h_offsets, int n_utts, int64_t t_max, int64_t* out) {
+  // utterances longest first, equal lengths in their own order: a counting sort over the lengths (a comparison sort
+  // of 4 096 utterances was 0.15 ms of host time in front of a 2.8-ms launch)
+  std::vector<int> order(n_utts);
+  if (t_max <= (int64_t)1 << 20) {
+    std::vector<int> start((size_t)t_max + 2, 0);
+    for (int u = 0; u < n_utts; ++u) ++start[(size_t)(t_max - (h_offsets[u + 1] - h_offsets[u])) + 1];
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    for (int u = 0; u < n_utts; ++u) order[start[(size_t)(t_max - (h_offsets[u + 1] - h_offsets[u]))]++] = u;
+  } else {
+    for (int u = 0; u < n_utts; ++u) order[u] = u;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
+    });
+  }
+  for (int y = 0; y < n_utts; ++y) {
+    out[2 * y] = h_offsets[order[y]];
+    out[2 * y + 1] = h_offsets[order[y] + 1];
+  }
+}
+
+static int mlpg_check_offsets(const int64_t* h_offsets, int n_utts, int64_t* t_max) {
+  const int64_t t_total = h_offsets[n_utts];
+  ITTS_REQUIRE(h_offsets[0] == 0 && t_total >= 0, "offsets must start at 0");
+  for (int u = 0; u < n_utts; ++u)
+    ITTS_REQUIRE(h_offsets[u + 1] >= h_offsets[u], "offsets must be non-decreasing");
+  ITTS_REQUIRE(n_utts <= t_total + 1, "more utterances than frames");
+  *t_max = 0;
+  for (int u = 0; u < n_utts; ++u) *t_max = std::max(*t_max, h_offsets[u + 1] - h_offsets[u]);
+  return ITTS_OK;
+}
+
 static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int64_t ld_feat, int col0, int dim,
                                 const double* d_var, const int64_t* h_offsets, int n_utts,
                                 double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
-                                void* stream) {
+                                void* stream, const MlpgPlan* plan = nullptr) {
   ITTS_REQUIRE(d_var && h_offsets && (n_utts == 0 || ((d_feat || d_feat32) && d_out && d_scratch)), "null pointer");
   ITTS_REQUIRE(dim > 0 && n_utts >= 0 && col0 >= 0 && ocol0 >= 0, "bad sizes");
   ITTS_REQUIRE(ld_feat >= col0 + 3 * (int64_t)dim && ld_out >= ocol0 + (int64_t)dim,
                "leading dimension too small");
   if (n_utts == 0) return ITTS_OK;
   const int64_t t_total = h_offsets[n_utts];
-  ITTS_REQUIRE(h_offsets[0] == 0 && t_total >= 0, "offsets must start at 0");
-  for (int u = 0; u < n_utts; ++u)
-    ITTS_REQUIRE(h_offsets[u + 1] >= h_offsets[u], "offsets must be non-decreasing");
-  ITTS_REQUIRE(n_utts <= t_total + 1, "more utterances than frames");
+  int64_t t_max = 0;
+  if (plan) {
+    t_max = plan->t_max;
+  } else {
+    const int rc = mlpg_check_offsets(h_offsets, n_utts, &t_max);
+    if (rc) return rc;
+  }
   if (t_total == 0) return ITTS_OK;
   hipStream_t s = as_stream(stream);
   itts::ScratchScope scratch_scope(s);
@@ -1821,8 +1868,6 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
   int64_t* d_off = reinterpret_cast<int64_t*>(scratch + 3 * t_total * (int64_t)dim);
   int* d_nconv = reinterpret_cast<int*>(d_off + (t_total + 2));
   MlpgArgs a{d_feat, ld_feat, col0, dim, d_var, d_off, d_out, ld_out, ocol0, scratch, t_total, d_nconv};
-  int64_t t_max = 0;
-  for (int u = 0; u < n_utts; ++u) t_max = std::max(t_max, h_offsets[u + 1] - h_offsets[u]);
   // reduce -> scan -> solve with 16-frame chunks, two chunks per workgroup, input rows staged through
   // LDS (uploads its own tables and computes the factor in its first launch); batches of short
   // utterances: the sequential sweeps are as fast
@@ -1831,8 +1876,11 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
   // so small batches stay with the form above, which also divides an utterance among workgroups: 16 utterances 132
   // against 225 us, 64: 174 / 201, 256: 372 / 307, 4 096: 4 520 / 3 608).  ITTS_MLPG_STREAM=1 / ITTS_MLPG_RING=1 force one.
   const int nblk = (dim + RING_LANES - 1) / RING_LANES;
-  const char* force_stream = getenv("ITTS_MLPG_STREAM");
-  const char* force_ring = getenv("ITTS_MLPG_RING");
+  // (the environment is read once per process: five getenv calls were 2-3 us of every call)
+  static const char* const force_stream = getenv("ITTS_MLPG_STREAM");
+  static const char* const force_ring = getenv("ITTS_MLPG_RING");
+  static const bool env_narrow = getenv("ITTS_MLPG_NARROW") != nullptr, env_wide = getenv("ITTS_MLPG_WIDE") != nullptr,
+                    env_no_nt = getenv("ITTS_MLPG_NO_NT") != nullptr;
   const bool ring = n_utts <= 65535 &&          // (an utterance per blockIdx.y)
                     (force_ring ? true : (force_stream ? false : (int64_t)n_utts * nblk >= MLPG_RING_FROM));
   if (d_feat32 && !(t_max >= MLPG_SEQ_BELOW && ring)) {
@@ -1859,48 +1907,32 @@ static int mlpg_generation_impl(const double* d_feat, const float* d_feat32, int
       ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)mlpg_ring_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
       if (dev < 64) attr_done.fetch_or(uint64_t(1) << dev);
     }
-    // utterances longest first, equal lengths in their own order: a counting sort over the lengths (a comparison sort
-    // of 4 096 utterances was 0.15 ms of host time in front of a 2.8-ms launch)
-    std::vector<int> order(n_utts);
-    if (t_max <= (int64_t)1 << 20) {
-      std::vector<int> start((size_t)t_max + 2, 0);
-      for (int u = 0; u < n_utts; ++u) ++start[(size_t)(t_max - (h_offsets[u + 1] - h_offsets[u])) + 1];
-      for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
-      for (int u = 0; u < n_utts; ++u) order[start[(size_t)(t_max - (h_offsets[u + 1] - h_offsets[u]))]++] = u;
-    } else {
-      for (int u = 0; u < n_utts; ++u) order[u] = u;
-      std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-        return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
-      });
-    }
-    std::vector<int64_t> host(2 * (size_t)n_utts);
-    for (int y = 0; y < n_utts; ++y) {
-      host[2 * y] = h_offsets[order[y]];
-      host[2 * y + 1] = h_offsets[order[y] + 1];
-    }
     itts::PinnedTable table;          // (nothing between here and the launch returns early: the slot goes back after it)
-    {
+    const int64_t* bounds = plan ? plan->table : nullptr;
+    if (!bounds) {
+      std::vector<int64_t> host(2 * (size_t)n_utts);
+      mlpg_sorted_table(h_offsets, n_utts, t_max, host.data());
       const int rc = itts::pinned_table_begin(host.data(), host.size() * sizeof(int64_t), &table);
       if (rc) return rc;
+      bounds = static_cast<const int64_t*>(table.p);
     }
     a.offsets = nullptr;          // (the kernel has its bounds in the table)
-    RingArgs g{a, static_cast<const int64_t*>(table.p), (int)t_max, d_feat32};
+    RingArgs g{a, bounds, (int)t_max, d_feat32};
     // two dimensions a lane in the helpers (half the memory instructions) where that is what the kernel waits for: float32
     // rows in batches of many rounds of workgroups -- 4 096 utterances 2.68 against 3.23 ms.  With float64 rows the
     // kernel moves 3.8 - 4.1 TB/s either way (3.62 / 3.61 ms), and at 256 utterances the exchange's extra arithmetic
     // costs 3 - 5 % (317 / 301 us; float32 231 / 223).  ITTS_MLPG_WIDE=1 / ITTS_MLPG_NARROW=1 force one (even dim only).
-    const bool wide = dim % 2 == 0 && !getenv("ITTS_MLPG_NARROW") &&
-                      (getenv("ITTS_MLPG_WIDE") || (d_feat32 && (int64_t)n_utts * nblk >= 1024));
+    const bool wide = dim % 2 == 0 && !env_narrow && (env_wide || (d_feat32 && (int64_t)n_utts * nblk >= 1024));
     const dim3 rgrid((unsigned)nblk, (unsigned)n_utts), rblock(RING_THREADS);
     // (float64 rows, y small enough to wait in the memory-side cache: input rows non-temporal -- see RING_LD)
-    const bool nt_in = !getenv("ITTS_MLPG_NO_NT") && (int64_t)t_total * dim * 8 <= (int64_t)192 << 20;
+    const bool nt_in = !env_no_nt && (int64_t)t_total * dim * 8 <= (int64_t)192 << 20;
     if (d_feat32 && wide) hipLaunchKernelGGL((mlpg_ring_kernel<float, true, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
     else if (d_feat32) hipLaunchKernelGGL((mlpg_ring_kernel<float, false, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
     else if (wide) hipLaunchKernelGGL((mlpg_ring_kernel<double, true, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
     else if (nt_in) hipLaunchKernelGGL((mlpg_ring_kernel<double, false, true>), rgrid, rblock, RING_LDS_BYTES, s, g);
     else hipLaunchKernelGGL((mlpg_ring_kernel<double, false, false>), rgrid, rblock, RING_LDS_BYTES, s, g);
     const hipError_t launched = hipGetLastError();
-    const int rc_table = itts::pinned_table_end(&table, s);
+    const int rc_table = plan && plan->table ? ITTS_OK : itts::pinned_table_end(&table, s);
     if (launched != hipSuccess) {
       itts::set_error(std::string("mlpg_ring_kernel: ") + hipGetErrorString(launched));
       return ITTS_E_HIP;
@@ -1938,4 +1970,44 @@ extern "C" int itts_mlpg_generation_f32(const float* d_feat, int64_t ld_feat, in
                                         void* stream) {
   ITTS_REQUIRE(n_utts == 0 || d_feat, "null pointer");
   return mlpg_generation_impl(nullptr, d_feat, ld_feat, col0, dim, d_var, h_offsets, n_utts, d_out, ld_out, ocol0, d_scratch, stream);
+}
+
+// ---- prepared plans (see MlpgPlan) ----------------------------------------------------------------------------------
+extern "C" int itts_mlpg_plan_create(const int64_t* h_offsets, int n_utts, void** plan_out) {
+  ITTS_REQUIRE(h_offsets && plan_out && n_utts >= 0, "bad arguments");
+  *plan_out = nullptr;
+  std::unique_ptr<MlpgPlan> p(new MlpgPlan);
+  p->n_utts = n_utts;
+  p->offsets.assign(h_offsets, h_offsets + n_utts + 1);
+  p->t_total = h_offsets[n_utts];
+  if (n_utts > 0) {
+    const int rc = mlpg_check_offsets(h_offsets, n_utts, &p->t_max);
+    if (rc) return rc;
+    ITTS_HIP_CHECK(hipHostMalloc((void**)&p->table, 2 * (size_t)n_utts * sizeof(int64_t), hipHostMallocDefault));
+    mlpg_sorted_table(h_offsets, n_utts, p->t_max, p->table);
+  }
+  *plan_out = p.release();
+  return ITTS_OK;
+}
+
+extern "C" void itts_mlpg_plan_destroy(void* plan) {
+  MlpgPlan* p = static_cast<MlpgPlan*>(plan);
+  if (!p) return;
+  if (p->table) (void)hipHostFree(p->table);
+  delete p;
+}
+
+extern "C" int64_t itts_mlpg_plan_frames(const void* plan) {
+  return plan ? static_cast<const MlpgPlan*>(plan)->t_total : -1;
+}
+
+extern "C" int itts_mlpg_generation_planned(const void* plan, const void* d_feat, int feat_is_f32, int64_t ld_feat,
+                                            int col0, int dim, const double* d_var, double* d_out, int64_t ld_out,
+                                            int ocol0, void* d_scratch, void* stream) {
+  const MlpgPlan* p = static_cast<const MlpgPlan*>(plan);
+  ITTS_REQUIRE(p && (p->n_utts == 0 || d_feat), "null pointer");
+  // (a launch reads the plan's table in place: the plan must outlive the work queued on `stream`)
+  return mlpg_generation_impl(feat_is_f32 ? nullptr : static_cast<const double*>(d_feat),
+                              feat_is_f32 ? static_cast<const float*>(d_feat) : nullptr, ld_feat, col0, dim, d_var,
+                              p->offsets.data(), p->n_utts, d_out, ld_out, ocol0, d_scratch, stream, p);
 }

@@ -50,11 +50,15 @@ class MLPG(object):
         total = sum(int(d) for _, _, d in streams)
         out = torch.empty((off[-1], total), dtype=torch.float64, device=dev)
         o0 = 0
+        plan = ops.MlpgPlan(off) if len(streams) > 1 else None      # the offsets' share of a call, once for all streams
         for col0, covariance, dim in streams:
             var = np.ascontiguousarray(np.diag(np.asarray(covariance))[:3 * dim], dtype=np.float64)
-            ops.mlpg_generation(feats, torch.from_numpy(var).to(dev), int(dim), off, col0=int(col0), out=out, ocol0=o0)
+            ops.mlpg_generation(feats, torch.from_numpy(var).to(dev), int(dim), off, col0=int(col0), out=out, ocol0=o0,
+                                plan=plan)
             o0 += int(dim)
-        res = out.cpu().numpy()
+        res = out.cpu().numpy()             # (synchronises: the plan's table is no longer read)
+        if plan is not None:
+            plan.close()
         result, o0 = [], 0
         for _, _, dim in streams:
             result.append([res[off[u]:off[u + 1], o0:o0 + dim] for u in range(len(lengths))])

@@ -40,16 +40,52 @@ def _rows(t, name):
 
 
 # ---------------------------------------------------------------------------------------- MLPG
-def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0):
+class MlpgPlan(object):
+    """What `mlpg_generation` works out from the offsets alone (checks, longest length, the one-pass kernel's table in
+    launch order), prepared once for callers that solve over the same utterances again -- the streams of a batch, a
+    fixed validation set: a planned call then does nothing on the host but launch (40-50 us of a 260-us lone call
+    otherwise).  The scratch buffer of the largest call so far is kept as well."""
+
+    def __init__(self, offsets):
+        L = _lib.load()
+        offs = _lib.offsets_array(offsets)
+        self.n_utts = len(offs) - 1
+        self.t_total = int(offs[self.n_utts]) if self.n_utts >= 0 else 0
+        handle = ctypes.c_void_p()
+        _lib.check(L.itts_mlpg_plan_create(offs, self.n_utts, ctypes.byref(handle)), "itts_mlpg_plan_create")
+        self._handle = handle
+        self._scratch = None
+
+    def scratch(self, nbytes, device):
+        if self._scratch is None or self._scratch.numel() < nbytes or self._scratch.device != device:
+            self._scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=device)
+        return self._scratch
+
+    def close(self):
+        handle, self._handle = self._handle, None
+        if handle is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()          # (launches read the plan's table in place)
+            _lib.load().itts_mlpg_plan_destroy(handle)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0, plan=None):
     """Batched MLPG (misc/mlpg.py:94-127). feat [Ttot, >=col0+3*dim] f64 -- or f32, the acoustic model's own output
     type: widened in the solve's loads, the result is that of the f64 rows --, variances [3*dim] f64,
-    offsets: python list of U+1 frame offsets. Returns out [Ttot, dim] f64 (or writes into out)."""
+    offsets: python list of U+1 frame offsets (ignored with `plan`, an MlpgPlan made from them). Returns out
+    [Ttot, dim] f64 (or writes into out)."""
     L = _lib.load()
     f32 = feat.dtype == torch.float32
     _need(feat, torch.float32 if f32 else torch.float64, "feat")
     _need(variances, torch.float64, "variances")
     ld = _rows(feat, "feat")
-    t_total = int(offsets[-1])
+    t_total = plan.t_total if plan is not None else int(offsets[-1])
     if feat.shape[0] != t_total:
         raise ValueError("offsets[-1] != number of rows")
     if out is None:
@@ -57,10 +93,18 @@ def mlpg_generation(feat, variances, dim, offsets, col0=0, out=None, ocol0=0):
     _need(out, torch.float64, "out")
     ldo = _rows(out, "out")
     nbytes = (L.itts_mlpg_scratch_bytes_f32 if f32 else L.itts_mlpg_scratch_bytes)(t_total, dim)
+    if not variances.is_contiguous():
+        variances = variances.contiguous()
+    if plan is not None:
+        scratch = plan.scratch(nbytes, feat.device)
+        _lib.check(L.itts_mlpg_generation_planned(plan._handle, _ptr(feat), 1 if f32 else 0, ld, col0, dim,
+                                                  _ptr(variances), _ptr(out), ldo, ocol0, _ptr(scratch), _stream()),
+                   "itts_mlpg_generation_planned")
+        return out
     scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=feat.device)
     offs = _lib.offsets_array(offsets)
     entry = L.itts_mlpg_generation_f32 if f32 else L.itts_mlpg_generation
-    _lib.check(entry(_ptr(feat), ld, col0, dim, _ptr(variances.contiguous()),
+    _lib.check(entry(_ptr(feat), ld, col0, dim, _ptr(variances),
                      offs, len(offsets) - 1, _ptr(out), ldo, ocol0,
                      _ptr(scratch), _stream()), "itts_mlpg_generation")
     return out
@@ -78,6 +122,15 @@ def lf0_vuv(f0, offsets, f0_silence_threshold=30.0, lf0_zero=0.0):
                               float(f0_silence_threshold), float(lf0_zero), _ptr(lf0), _ptr(vuv),
                               _stream()), "itts_lf0_vuv")
     return lf0, vuv
+
+
+def sqrt_inplace(x):
+    """x <- sqrt(x) for a contiguous float64 tensor (IEEE square roots: numpy's bits)."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    assert x.is_contiguous()
+    _lib.check(L.itts_sqrt_inplace_f64(_ptr(x), x.numel(), _stream()), "itts_sqrt_inplace_f64")
+    return x
 
 
 def interpolate_lin_f32(x, offsets):

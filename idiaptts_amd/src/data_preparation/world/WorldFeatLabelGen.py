@@ -259,12 +259,13 @@ class WorldFeatLabelGen(ReaderBase):
             f0_silence_threshold = WorldFeatLabelGen.f0_silence_threshold
         if lf0_zero is None:
             lf0_zero = WorldFeatLabelGen.lf0_zero
+        # one trip to the device: the square root (:795) and lf0 / V-UV (:798-802) are taken there, before the
+        # envelope and the contour come back (np.sqrt of 1 321 x 513 values was 0.5 of the call's 2.6 ms)
         res = _world.analyse_batch([np.asarray(raw, dtype=np.float64)], fs, hop_size_ms, n_fft,
                                    want_sp=True, want_bap=True,
-                                   f0_method=WorldFeatLabelGen.f0_estimator)[0]
-        amp_sp = np.sqrt(res["sp"])
-        lf0, vuv = _world.lf0_vuv_from_f0(res["f0"], f0_silence_threshold, lf0_zero)
-        return amp_sp, lf0, vuv, res["bap"]
+                                   f0_method=WorldFeatLabelGen.f0_estimator, amplitude=True,
+                                   lf0_params=(f0_silence_threshold, lf0_zero))[0]
+        return res["sp"], res["lf0"], res["vuv"], res["bap"]
 
     @staticmethod
     def extract_features_batch(raws, fs, preemphasis_applied=True, n_fft=None, hop_size_ms=5,

@@ -62,10 +62,12 @@ def estimate_f0(x, x_off, f_off, fs, hop_ms=5.0, f0_method="dio"):
 
 
 def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
-                  mcep_order=None, mcep_alpha=None, want_bap=True, device=None, f0_method="dio"):
+                  mcep_order=None, mcep_alpha=None, want_bap=True, device=None, f0_method="dio",
+                  amplitude=False, lf0_params=None):
     """raws: list of float64 waveforms (already pre-emphasised). Returns a list of dicts with
-    f0 [T] f64, and optionally sp [T,K] f64 (power), ap [T,K] f64, mcep [T,order+1] f32,
-    bap [T,nap] f32."""
+    f0 [T] f64, and optionally sp [T,K] f64 (power; with `amplitude` its square root, taken on the device),
+    ap [T,K] f64, mcep [T,order+1] f32, bap [T,nap] f32; with lf0_params = (f0_silence_threshold, lf0_zero)
+    also lf0 / vuv [T, 1] f32 (WorldFeatLabelGen.py:798-802) from the contour while it is still on the device."""
     dev = _device(device)
     L = _lib.load()
     n_fft = n_fft or L.itts_cheaptrick_fft_size(int(fs), 71.0)
@@ -86,11 +88,18 @@ def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
     if want_sp or mcep_order is not None:
         sp, mc, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, hop_ms, n_fft, want_sp=want_sp,
                                         order=mcep_order, alpha=mcep_alpha)
+    lf0 = vuv = None
+    if lf0_params is not None:
+        lf0, vuv = ops.lf0_vuv(f0, f_off, lf0_params[0], lf0_params[1])
+    if amplitude and sp is not None:
+        ops.sqrt_inplace(sp)
     if want_ap or want_bap:
         main.wait_stream(side)
         for t in (x, f0):
             t.record_stream(side)
     f0 = f0.cpu().numpy()
+    lf0 = lf0.cpu().numpy() if lf0 is not None else None
+    vuv = vuv.cpu().numpy() if vuv is not None else None
     sp = sp.cpu().numpy() if sp is not None else None
     mc = mc.cpu().numpy() if mc is not None else None
     ap = ap.cpu().numpy() if ap is not None else None
@@ -99,6 +108,8 @@ def analyse_batch(raws, fs, hop_ms=5.0, n_fft=None, want_sp=True, want_ap=False,
     for u in range(len(raws)):
         a, b = f_off[u], f_off[u + 1]
         out.append({"f0": f0[a:b],
+                    "lf0": lf0[a:b, None] if lf0 is not None else None,
+                    "vuv": vuv[a:b, None] if vuv is not None else None,
                     "sp": sp[a:b] if sp is not None else None,
                     "ap": ap[a:b] if ap is not None else None,
                     "mcep": mc[a:b] if mc is not None else None,

@@ -167,6 +167,19 @@ int itts_mlpg_generation_f32(const float* d_feat, int64_t ld_feat, int col0, int
                              double* d_out, int64_t ld_out, int ocol0, void* d_scratch,
                              void* stream);
 
+/* A prepared plan for solving over the SAME utterance layout repeatedly -- the streams of one batch
+ * (mlpg.py:94-127 is called once per stream: mcep, lf0, bap), a fixed validation set: the checks of the offsets,
+ * the longest length and the one-pass kernel's (start, end) table in launch order are worked out once and kept
+ * (the table in page-locked memory the launches read in place), so a planned call does nothing on the host but
+ * launch.  The plan must outlive the work queued with it; destroy it after synchronising. */
+int itts_mlpg_plan_create(const int64_t* h_offsets, int n_utts, void** plan_out);
+void itts_mlpg_plan_destroy(void* plan);
+int64_t itts_mlpg_plan_frames(const void* plan);
+/* itts_mlpg_generation / itts_mlpg_generation_f32 (feat_is_f32) over the plan's utterances; d_scratch as for those. */
+int itts_mlpg_generation_planned(const void* plan, const void* d_feat, int feat_is_f32, int64_t ld_feat, int col0,
+                                 int dim, const double* d_var, double* d_out, int64_t ld_out, int ocol0,
+                                 void* d_scratch, void* stream);
+
 /* ---- frame utilities (misc/utils.py:40-105) --------------------------------------------- */
 /* compute_deltas == np.gradient(x, axis=0) in float32 (utils.py:103-105): part of
  * itts_assemble_cmp_f32 below (static, delta, delta-delta columns of every stream in one pass). */
@@ -179,6 +192,11 @@ int itts_mlpg_generation_f32(const float* d_feat, int64_t ld_feat, int col0, int
 int itts_lf0_vuv(const double* d_f0, const int64_t* h_f_off, int n_utts,
                  double f0_silence_threshold, float lf0_zero, float* d_lf0, float* d_vuv,
                  void* stream);
+/* d_x[i] = sqrt(d_x[i]) (IEEE, round to nearest): the amplitude envelope of
+ * WorldFeatLabelGen.world_extract_features (world/WorldFeatLabelGen.py:795, np.sqrt(sp)) from CheapTrick's power
+ * envelope, before it leaves the device. */
+int itts_sqrt_inplace_f64(double* d_x, int64_t n, void* stream);
+
 /* interpolate_lin (misc/utils.py:40-86) on float32 contours stored back to back: frames <= 0 are
  * gaps; bit-exact including the reference's quirks (target reached one frame early; a gap whose
  * next voiced frame is the last frame is filled, with that frame, by the last voiced value).

@@ -157,3 +157,14 @@ def test_empty_batches_are_no_ops(gpu):
     assert out.shape == (0, 187)
     s, c = ops.feature_stats(torch.empty((0, 8), dtype=torch.float32, device=gpu), 0, 8, True)
     assert float(s.abs().sum()) == 0 and float(c.abs().sum()) == 0
+
+
+def test_device_square_root_is_numpys(gpu):
+    """ops.sqrt_inplace (WorldFeatLabelGen.py:795, amp_sp = np.sqrt(sp) taken before the envelope leaves the device):
+    IEEE square roots -- the same bits as numpy, over magnitudes from denormal to huge"""
+    from idiaptts_amd import ops
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(0, 1, 4097) * 10.0 ** rng.integers(-300, 300, 4097),
+                        [0.0, 5e-324, 2.2250738585072014e-308, 1.0, 2.0, 1e-16, np.inf]])
+    got = ops.sqrt_inplace(torch.from_numpy(x.copy()).to(gpu)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), np.sqrt(x).view(np.uint64))

@@ -174,3 +174,27 @@ def test_mlpg_wide_helpers(gpu, monkeypatch, dtype):
         wide = ops.mlpg_generation(f, v, dim, offsets.tolist(), col0=col0).cpu().numpy()
         monkeypatch.delenv("ITTS_MLPG_WIDE")
         assert np.array_equal(narrow, wide), (lengths, dim)
+
+
+def test_planned_calls_equal_plain_calls(gpu):
+    """ops.MlpgPlan (itts_mlpg_plan_create / itts_mlpg_generation_planned): the offsets' share of a call prepared
+    once -- the same trajectories bit for bit, for the one-pass kernel and the small-batch forms, float64 and float32
+    rows, several streams on one plan (misc/mlpg.py:94-127 is called once per stream)."""
+    from idiaptts_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for n_utts, dim in ((3, 5), (300, 62), (1, 1)):
+        lens = torch.randint(40, 400, (n_utts,), generator=g).tolist()
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        feat = torch.randn(off[-1], 3 * dim + 4, dtype=torch.float64, generator=g).to(gpu)
+        var = (torch.rand(3 * dim, dtype=torch.float64, generator=g) + 0.05).to(gpu)
+        plan = ops.MlpgPlan(off)
+        for rows in (feat, feat.float()):
+            for col0 in (0, 4):
+                want = ops.mlpg_generation(rows, var, dim, off, col0=col0)
+                got = ops.mlpg_generation(rows, var, dim, off, col0=col0, plan=plan)
+                assert torch.equal(want, got)
+        plan.close()
+    with pytest.raises(Exception):
+        ops.MlpgPlan([0, 5, 3])
