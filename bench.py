@@ -826,7 +826,7 @@ def api_single_call_section(dev, fs=16000, seconds=6.6, repeats=20, with_cpu=Tru
 def gen_data_section(n_utts=512, batch_utts=64):
     """The drop-in WorldFeatLabelGen.gen_data end to end: wav files ->
     per-stream .npz archives with deltas + normalisation statistics, file I/O, host <-> device copies and
-    all host work included (median of 3 passes over the same files).  The files live on /dev/shm where it
+    all host work included (median of 5 passes over the same files, all passes listed).  The files live on /dev/shm where it
     is writable (the boxes' local disks throttle write-back after a few hundred MB: the same run took 0.16 s
     on one box and 0.71 s on another), else in the default temporary directory; `dir` in the row says which."""
     import tempfile
@@ -846,7 +846,7 @@ def gen_data_section(n_utts=512, batch_utts=64):
         gen = WorldFeatLabelGen(out_dir, add_deltas=True, num_coded_sps=60, batch_utts=batch_utts)
         gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids[:batch_utts])
         times = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             gen.gen_data(wav_dir, out_dir, "ids.txt", id_list=ids)
             times.append(time.perf_counter() - t0)

@@ -31,6 +31,9 @@ from ..DataReaderConfig import DataReaderConfig
 from ..DataReaders import ReaderBase
 
 
+_devices_with_tables = set()      # devices on which a gen_data pass of this process has run its first batch
+
+
 def _dist_device():
     """Device the statistics all-reduce runs on: the current GPU under RCCL ('nccl'), host
     memory under gloo."""
@@ -452,6 +455,42 @@ class WorldFeatLabelGen(ReaderBase):
             else:
                 _save_to_npz(path, np.ascontiguousarray(cmp_u[:, c0:c0 + w]), ext)
 
+    def _batch_schedule(self, id_list):
+        """The id list cut into the batches the device analyses.  `batch_utts` is the size of a batch in the middle of
+        the list; ITTS_GEN_DATA_SCHEDULE="32,96,128" (lab) gives explicit sizes for the first batches, mirrored at the
+        end, with `batch_utts` in between."""
+        n = len(id_list)
+        sizes = []
+        lab = os.environ.get("ITTS_GEN_DATA_SCHEDULE")
+        if lab:
+            head = [int(v) for v in lab.split(",") if v.strip()]
+            tail = head[::-1]
+            left = n
+            front = []
+            for v in head:
+                if left - sum(tail) <= 0 or v >= left:
+                    break
+                front.append(v)
+                left -= v
+            back = []
+            for v in tail[::-1][:len(front)][::-1]:
+                if v < left:
+                    back.append(v)
+                    left -= v
+            while left > 0:
+                v = min(self.batch_utts, left)
+                front.append(v)
+                left -= v
+            sizes = front + back
+        else:
+            sizes = [min(self.batch_utts, n - b0) for b0 in range(0, n, self.batch_utts)]
+        out, b0 = [], 0
+        for v in sizes:
+            out.append(id_list[b0:b0 + v])
+            b0 += v
+        assert b0 == n
+        return out
+
     def _gen_data_pipeline(self, dir_in, dir_out, file_ext, id_list, label_dict):
         """The hot loop of gen_data (reference :996-1013, one utterance at a time on one core):
         reader threads decode and pre-emphasise the next batches, the device turns a batch of
@@ -462,7 +501,7 @@ class WorldFeatLabelGen(ReaderBase):
         import torch
         loaded = [k for k, load in zip(("sp", "lf0", "vuv", "bap"), self.load_flags) if load]
         cols = stats = None
-        batches = [id_list[b0:b0 + self.batch_utts] for b0 in range(0, len(id_list), self.batch_utts)]
+        batches = self._batch_schedule(id_list)
 
         n_io = max(2, min(16, (os.cpu_count() or 2) // 2))
 
@@ -485,7 +524,8 @@ class WorldFeatLabelGen(ReaderBase):
             streams = [(d, ext, cols[k]) for (load, d, ext, _), k
                        in zip(self._streams(), ("sp", "lf0", "vuv", "bap")) if load]
             merge = _write_archives_native(cmp_host, f_off, names, dir_out, streams,
-                                           self.add_deltas, n_io)
+                                           self.add_deltas, max(2, n_io // 2))
+            mark("written: " + names[0])
             for u, si in merge:      # archive with foreign keys: _save_to_npz keeps them
                 d, ext, (c0, w) = streams[si]
                 cmp_u = cmp_host[f_off[u]:f_off[u + 1]]
@@ -504,19 +544,32 @@ class WorldFeatLabelGen(ReaderBase):
         # between two analyses (round 4: copy + synchronize per batch, 2.3 ms of every 17).
         depth = 3
         copy_stream = torch.cuda.Stream()
-        with cf.ThreadPoolExecutor(depth) as readers, cf.ThreadPoolExecutor(2) as writers:
+        # writer jobs are chunks of at most `chunk` utterances, four at a time: a batch's archives leave in parallel
+        # pieces, and the last batch -- whose write nothing overlaps -- is not one 13-ms job behind two others
+        chunk = max(8, int(os.environ.get("ITTS_GEN_DATA_WRITE_CHUNK", "32")))
+        n_writers = max(1, int(os.environ.get("ITTS_GEN_DATA_WRITERS", "4")))
+        with cf.ThreadPoolExecutor(depth) as readers, cf.ThreadPoolExecutor(n_writers) as writers:
             pending_reads = [readers.submit(read, names) for names in batches[:depth]]
             writes = []
             trace = os.environ.get("ITTS_GEN_DATA_TRACE") == "1"
             import time as _time
+            t_pass = _time.perf_counter()
+            events = []
+
+            def mark(what, bi=-1):
+                if trace:
+                    events.append(((_time.perf_counter() - t_pass) * 1e3, what, bi))
             in_copy = None          # (names, host tensor, f_off, event) of the batch whose copy is in flight
 
             def hand_over(item):
                 names_, host_, f_off_, done_ = item
                 done_.synchronize()
+                mark("copy to host done: " + names_[0])
                 cmp_host = host_.numpy()
                 if dir_out is not None:
-                    writes.append(writers.submit(write, names_, cmp_host, f_off_, cols))
+                    for a in range(0, len(names_), chunk):
+                        writes.append(writers.submit(write, names_[a:a + chunk], cmp_host,
+                                                     f_off_[a:a + chunk + 1], cols))
                 if label_dict is not None:
                     for u, n in enumerate(names_):
                         cmp_u = cmp_host[f_off_[u]:f_off_[u + 1]]
@@ -533,7 +586,9 @@ class WorldFeatLabelGen(ReaderBase):
             analysis_streams = [torch.cuda.Stream() for _ in range(n_flight)]
 
             def analyse(bi):
+                mark("analysis thread starts", bi)
                 samples, x_off, fss, arrived = pending_reads[bi].result()
+                mark("read there", bi)
                 pending_reads[bi] = None
                 assert len(set(fss)) == 1, "All files of a batch need the same sampling rate."
                 fs = fss[0]
@@ -551,6 +606,7 @@ class WorldFeatLabelGen(ReaderBase):
                         mgc_gamma=AudioProcessing.mgc_gamma if self.sp_type == "mgc" else None,
                         f0_method=self.f0_estimator)
                     ready = st.record_event()
+                mark("analysis queued (host side done)", bi)
                 return cmp_dev, f_off, ready, fs
 
             with cf.ThreadPoolExecutor(n_flight) as analysers:
@@ -565,14 +621,18 @@ class WorldFeatLabelGen(ReaderBase):
                     t_a = _time.perf_counter()
                     if bi not in analyses:
                         start(bi)
-                    if bi == 0:
-                        # the first batch alone: it builds the device's tables (on its stream)
+                    if bi == 0 and torch.cuda.current_device() not in _devices_with_tables:
+                        # the first batch of the process alone: it builds the device's tables (on its stream); later
+                        # calls find them there and start two batches at once like every other pair (a lone first
+                        # batch was 15 of a 100-ms pass over 512 utterances)
                         analyses[0].result()
                         torch.cuda.synchronize()
+                        _devices_with_tables.add(torch.cuda.current_device())
                     for ahead in range(1, n_flight):
                         if bi + ahead < len(batches) and bi + ahead not in analyses:
                             start(bi + ahead)
                     cmp_dev, f_off, ready, fs = analyses.pop(bi).result()
+                    mark("main has the result", bi)
                     t_b = _time.perf_counter()
                     main = torch.cuda.current_stream()
                     main.wait_event(ready)
@@ -602,6 +662,9 @@ class WorldFeatLabelGen(ReaderBase):
             if trace:
                 print("gen_data: waited {:.1f} ms for the writers".format(
                     (_time.perf_counter() - t_a) * 1e3))
+                mark("pass over")
+                for t, what, bi in sorted(events):
+                    print("  {:8.1f} ms  {}{}".format(t, what, "" if bi < 0 else " [batch {}]".format(bi)))
         for (load, _, _, normaliser), key in zip(self._streams(), ("sp", "lf0", "vuv", "bap")):
             if load and key != "vuv" and stats is not None:
                 stats.store(key, normaliser)
