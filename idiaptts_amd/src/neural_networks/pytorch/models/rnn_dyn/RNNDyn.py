@@ -65,8 +65,8 @@ class FFWrapper(nn.Module):
             return None
         T = input_.shape[1 if self.batch_first else 0]
         B = input_.shape[0 if self.batch_first else 1]
-        if not torch.is_tensor(lengths) or lengths.numel() != B:
-            return None
+        if not torch.is_tensor(lengths) or lengths.numel() != B or int(lengths.max()) > T:
+            return None        # (lengths of another time extent: an input merged over time, NamedForwardWrapper "attention")
         vr = ValidRows.get(lengths, T, self.batch_first, input_.device)
         return vr if vr.n_pad >= self.min_padding_share * B * T and vr.N > 0 else None
 

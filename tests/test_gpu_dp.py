@@ -184,6 +184,33 @@ def test_bench_starts_its_own_ranks(gpu):
     assert out["world"]["n_gpus"] == 2 and out["bilstm"]["n_gpus"] == 2
 
 
+def test_bench_with_eight_ranks_on_one_device(gpu):
+    """The driver's `bench.py --gpus 8` protocol with all eight ranks on this one device (gloo collectives; never a
+    measurement): rendezvous on 127.0.0.1, per-rank seeds, barrier + max-over-ranks timing, one JSON line from rank
+    0, both forms of BASELINE config 3 (64 utterances per GPU, and 64 in all = 8 per GPU) and the exchange plan the
+    first real SCALE record is to be checked against (reference hook: ModularModelHandlerPyTorch.py:732-735,
+    :757-763)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu",
+                          "--steps", "2", "--warmup", "1", "--ramp-steps", "0", "--utts-per-gpu", "2",
+                          "--world-utts", "0", "--bilstm-utts", "8", "--trainer-utts", "0", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and "shared_gpu" in out and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["utts_per_gpu"] == 2
+    assert out["bilstm"]["n_gpus"] == 8 and out["bilstm"]["utterances_global"] == 64
+    assert out["bilstm_global_batch"]["utterances_global"] == 8 and out["bilstm_global_batch"]["n_gpus"] == 8
+    plan = out["exchange_plan"]
+    assert plan["n_gpus"] == 8 and plan["bilstm_bigru_step"]["bytes_per_rank_per_step"] > 60e6
+    assert 0 < plan["config_3_as_worded"]["predicted_speedup_at_8_gpus"]["64_utterances_in_all"] < 2.5
+    assert plan["config_3_as_worded"]["predicted_speedup_at_8_gpus"]["64_utterances_per_gpu"] > 6
+
+
 def _rccl_one_rank_worker(ret_path):
     """Child process: RCCL with ONE rank on cuda:0, every collective of the N > 1 path forced on."""
     import torch.distributed as dist

@@ -69,3 +69,45 @@ def test_sequence_mask_and_prepare_batch(golden_dir):
     assert data["acoustic_features_mask"].shape == (5, 2, 1)
     assert data["acoustic_features_mask"][:, 1, 0].tolist() == [1, 1, 0, 0, 0]
     assert (data["questions"][2:, 1] == 0).all()
+
+
+def test_named_forward_wrapper_input_merges_follow_the_reference():
+    """NamedForwardModule.merge / _broadcast_time_dim (models/NamedForwardModule.py:115-148): cat, add, mean, mul and
+    the attention-style product summed over time; an input without a time axis is repeated over time first."""
+    import torch
+    from functools import reduce
+    from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import NamedForwardWrapper
+
+    class Echo(torch.nn.Module):
+        def init_hidden(self, batch_size=1):
+            pass
+
+        def forward(self, x, **kwargs):
+            return x, kwargs
+
+    g = torch.Generator().manual_seed(0)
+    for batch_first in (False, True):
+        T, B, D = 7, 3, 4
+        shape = (B, T, D) if batch_first else (T, B, D)
+        a, b = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+        per_utt = torch.randn(B, D, generator=g)                      # no time axis: broadcast
+        tdim = 1 if batch_first else 0
+        rep = per_utt.unsqueeze(tdim).repeat((1, T, 1) if batch_first else (T, 1, 1))
+        want = {"cat": torch.cat([a, b, rep], dim=2),
+                "add": torch.sum(torch.stack([a, b, rep]), dim=0),
+                "mean": torch.mean(torch.stack([a, b, rep]), dim=0),
+                "mul": reduce(lambda x, y: x * y, [a, b, rep]),
+                "attention": reduce(lambda x, y: x * y, [a, b, rep]).sum(dim=tdim, keepdim=True)}
+        for merge_type, expected in want.items():
+            cfg = NamedForwardWrapper.Config(None, input_names=["a", "b", "s"], batch_first=batch_first,
+                                             input_merge_type=merge_type, output_names=["out"])
+            w = NamedForwardWrapper(cfg)
+            w.model = Echo()
+            data = {"a": a, "b": b, "s": per_utt}
+            lengths = {"a": torch.full((B,), T)}
+            w(data, lengths, {"a": T})
+            assert torch.equal(data["out"], expected), merge_type
+            assert torch.equal(lengths["out"], lengths["a"])
+    import pytest
+    with pytest.raises(NotImplementedError):
+        NamedForwardWrapper(NamedForwardWrapper.Config(None, ["a"], False, input_merge_type="list"))
