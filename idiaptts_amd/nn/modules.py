@@ -2,6 +2,7 @@
 reference's state dicts load unchanged (`module.0.weight`,
 `module.weight_ih_l0[_reverse]`, ...)."""
 import math
+import os
 
 import torch
 from torch import nn
@@ -22,13 +23,42 @@ class LinearAct(nn.Linear):
         return LinearActFunction.apply(input_, self.weight, self.bias, self.act)
 
 
-def _pad_hidden(w_ih, w_hh, biases, h0s, G, H):
+_cu_count = {}
+
+
+def _persistent_width(H, rows, ndir, device):
+    """512 when a layer of hidden size H < 512 is better run zero-padded to the width the persistent
+    recurrences (csrc/rnn_persist.h) are built for, else None.  Those keep a whole recurrence inside one launch
+    at ~4 us per time step where the per-step kernels other sizes take cost ~9 us, but they take 8 / ndir tiles of
+    16 rows per round and the padded products are larger; measured on 3 x Bi-LSTM / GRU training steps of 2-10 s
+    utterances (scripts/rnn_hidden_probe.py, profiles/r6_rnn_hidden_probe.txt): H 128 / 256 / 384 at 64
+    utterances (one round) -15 / -17 / -22 % of the step, H 256 at 128 / 256 utterances 0 / +10 %, H 384 -17 / -3 %.
+    ITTS_RNN_PAD_HIDDEN=0 / 1 forces it off / on; ITTS_RNN_PERSISTENT=0 (no persistent kernels) turns it off too."""
+    force = os.environ.get("ITTS_RNN_PAD_HIDDEN")
+    if not (128 <= H < 512) or force == "0" or os.environ.get("ITTS_RNN_PERSISTENT", "1")[:1] == "0":
+        return None
+    if force == "1":
+        return 512
+    if device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _cu_count:
+        _cu_count[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    if _cu_count[idx] != 256:
+        return None
+    rounds = -(-((rows + 15) // 16) // (8 // ndir))
+    allowed = 1 if H < 320 else (2 if H < 448 else 4)
+    return 512 if rounds <= allowed else None
+
+
+def _pad_hidden(w_ih, w_hh, biases, h0s, G, H, rows=0):
     """The recurrence kernels tile the hidden units in groups of 16.  Any other hidden size runs
-    zero-padded to the next multiple: a padded unit has zero weights and biases, so its gates sit
+    zero-padded to the next multiple -- or to 512 where that puts the layer on the persistent recurrences
+    (_persistent_width) --: a padded unit has zero weights and biases, so its gates sit
     at sigma(0) / tanh(0), its state stays exactly 0 and -- its W_hh columns being zero -- it never
     reaches a real unit.  Differentiable torch ops: autograd slices the gradients back.
     w_ih [ndir, G*H, F], w_hh [ndir, G*H, H], biases [ndir, G*H] each, h0s [ndir, H] or None."""
-    Hp = (H + 15) // 16 * 16
+    Hp = _persistent_width(H, rows, w_ih.shape[0], w_ih.device) or (H + 15) // 16 * 16
     if Hp == H:
         return w_ih, w_hh, biases, h0s, H
     ndir, _, F = w_ih.shape
@@ -115,7 +145,7 @@ class LSTM(nn.Module):
             H = self.hidden_size
             w_ih, w_hh, (b_ih, b_hh), (hl, cl), Hp = _pad_hidden(
                 self._stack("weight_ih", layer), self._stack("weight_hh", layer),
-                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl, cl], 4, H)
+                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl, cl], 4, H, rows=pb.B)
             x, hn, cn = LSTMLayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl, cl,
                                                 torch.is_grad_enabled())
             x = _unpad_rows(x, ndir, H, Hp)
@@ -176,7 +206,7 @@ class GRU(nn.Module):
             H = self.hidden_size
             w_ih, w_hh, (b_ih, b_hh), (hl,), Hp = _pad_hidden(
                 self._stack("weight_ih", layer), self._stack("weight_hh", layer),
-                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl], 3, H)
+                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl], 3, H, rows=pb.B)
             x, hn = GRULayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl,
                                            torch.is_grad_enabled())
             x = _unpad_rows(x, ndir, H, Hp)

@@ -1,0 +1,50 @@
+"""Training step of RNNDYN-3_Bi<cell>_<H>-1_FC_187 on the bench's 64-utterance batch for several hidden sizes
+(bench.bilstm_section's harness): what the sizes beside 512 cost, with and without ITTS_RNN_PAD_HIDDEN."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from idiaptts_amd.bench_support import make_ff_batch           # noqa: E402
+from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as Handler  # noqa: E402
+from idiaptts_amd.src.neural_networks.pytorch.loss.NamedLoss import NamedLoss    # noqa: E402
+from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn               # noqa: E402
+from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import NamedForwardWrapper  # noqa: E402
+
+dev = torch.device("cuda", 0)
+n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+x, y, lengths = make_ff_batch(n_utts, seed=7)
+offs = np.concatenate([[0], np.cumsum(lengths)])
+batch = [{"questions": x[offs[i]:offs[i + 1]], "acoustic_features": y[offs[i]:offs[i + 1]]} for i in range(n_utts)]
+data, lens = Handler.prepare_batch(batch, batch_first=False, mask_keys=("acoustic_features",))
+data = {k: v.to(dev) for k, v in data.items()}
+for cell in ("LSTM", "GRU"):
+    for H in (128, 256, 384, 512):
+        for pad in ("0", "1"):
+            if H == 512 and pad == "1":
+                continue
+            os.environ["ITTS_RNN_PAD_HIDDEN"] = pad
+            torch.manual_seed(0)
+            hp = types.SimpleNamespace(model_type="RNNDYN-3_Bi{}_{}-1_FC_187".format(cell, H), batch_first=False, dropout=0.0)
+            h = Handler()
+            h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((425,), hp), input_names=["questions"],
+                                                      batch_first=False, name="AM", output_names=["pred_acoustic_features"]))
+            h.set_optimiser("Adam", lr=1e-3)
+            h.set_losses([NamedLoss.Config(name="mse", type_="MSELoss", seq_mask="acoustic_features_mask",
+                                           input_names=["acoustic_features", "pred_acoustic_features"], batch_first=False)])
+            for s in range(2):
+                ld, _ = h.process_batch(dict(data), lens, s, training=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for s in range(4):
+                ld, _ = h.process_batch(dict(data), lens, s + 2, training=True, blocking=False)
+            e1.record()
+            e1.synchronize()
+            h.finish_batches()
+            print("Bi%s H %4d  pad_hidden %s  %8.2f ms/step  loss %.5f" % (cell, H, pad, e0.elapsed_time(e1) / 4,
+                                                                         float(ld["mse"])), flush=True)
+            del h
