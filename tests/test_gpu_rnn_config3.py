@@ -202,3 +202,34 @@ print("max difference %%.2e" %% d)
                          text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "gave up" in res.stderr
+
+
+@pytest.mark.parametrize("cell,H", [("LSTM", 256), ("GRU", 384), ("LSTM", 136)])
+def test_other_hidden_sizes_on_the_persistent_recurrences(gpu, cell, H, monkeypatch):
+    """Hidden sizes 128..511 (the reference's RNNWrapper takes any, rnn_dyn/RNNWrapper.py:45-54) run zero-padded to
+    the 512 units the persistent recurrences are built for when the batch fits their rounds (nn/modules.py,
+    _persistent_width): the same outputs, states and gradients as the per-step kernels at the layer's own width --
+    a padded unit never reaches a real one --, within the budget the persistent path has against the step kernels
+    at 512, and every gradient has the parameter's own shape."""
+    from idiaptts_amd import nn as inn
+    from idiaptts_amd.nn import modules
+    torch.manual_seed(11)
+    lens = torch.tensor([211, 190, 190, 150, 97, 96, 31, 30, 17, 16, 15, 5, 4, 3, 2, 2, 1, 1], dtype=torch.int64)
+    layer = getattr(inn, cell)(96, H, 2, bidirectional=True).to(gpu)
+    x = torch.randn(int(lens.max()), len(lens), 96, device=gpu, requires_grad=True)
+    w_out = torch.randn(int(lens.max()), len(lens), 2 * H, device=gpu) / 8
+    assert modules._persistent_width(H, len(lens), 2, gpu) == 512          # (256 CUs: the rule applies on this box)
+    assert modules._persistent_width(H, 4096, 2, gpu) is None              # too many rounds
+    assert modules._persistent_width(1024, 16, 2, gpu) is None and modules._persistent_width(512, 16, 2, gpu) is None
+    outs = []
+    for pad in ("0", "1"):
+        monkeypatch.setenv("ITTS_RNN_PAD_HIDDEN", pad)
+        o, st = layer(x, None, lens)
+        st = list(st) if isinstance(st, (tuple, list)) else [st]
+        grads = torch.autograd.grad((o * w_out).sum(), [x] + list(layer.parameters()))
+        for g, p in zip(grads[1:], layer.parameters()):
+            assert g.shape == p.shape
+        outs.append([o.detach()] + [q.detach() for q in st] + list(grads))
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
