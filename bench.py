@@ -1421,7 +1421,7 @@ def main():
         # HBM bytes per GEMM launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
         # see profiles/r4_gemm_traffic.json); not re-measured inside bench.py.
         traffic = None
-        for name in ("r5_gemm_traffic.json", "r4_gemm_traffic.json", "r3g_gemm_traffic.json"):
+        for name in ("r6_gemm_traffic.json", "r5_gemm_traffic.json", "r4_gemm_traffic.json", "r3g_gemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.isfile(tpath) and args.utts_per_gpu == 32:
                 with open(tpath) as f:
