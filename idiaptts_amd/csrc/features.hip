@@ -334,6 +334,25 @@ __global__ __launch_bounds__(256) void sqrt_inplace_kernel(double* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] = __dsqrt_rn(x[i]);
 }
 
+// sp = amp_sp^2 in place (WorldFeatLabelGen.py:925, `np.square(amp_sp, dtype=np.float64)` in front of the synthesis):
+// one IEEE product per value, numpy's bits; 0.3 ms of one host core per 6.6-s utterance otherwise
+__global__ __launch_bounds__(256) void square_inplace_kernel(double* __restrict__ x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const double v = x[i];
+    x[i] = __dmul_rn(v, v);
+  }
+}
+
+extern "C" int itts_square_inplace_f64(double* d_x, int64_t n, void* stream) {
+  ITTS_REQUIRE(n >= 0 && (n == 0 || d_x), "bad arguments");
+  if (n == 0) return ITTS_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(square_inplace_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_x, n);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
 extern "C" int itts_sqrt_inplace_f64(double* d_x, int64_t n, void* stream) {
   ITTS_REQUIRE(n >= 0 && (n == 0 || d_x), "bad arguments");
   if (n == 0) return ITTS_OK;

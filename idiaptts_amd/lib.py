@@ -72,6 +72,7 @@ _SIGNATURES = {
     "itts_mlpg_plan_frames": (c_int64, [_P]),
     "itts_mlpg_generation_planned": (c_int, [_P, _P, c_int, c_int64, c_int, c_int, _P, _P, c_int64, c_int, _P, _P]),
     "itts_sqrt_inplace_f64": (c_int, [_P, c_int64, _P]),
+    "itts_square_inplace_f64": (c_int, [_P, c_int64, _P]),
     "itts_batch_pad_gather_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int, c_int64, c_int, c_int, _P, c_int64, _P,
                                           _P, c_int64, _P, _P]),
     "itts_batch_pack_rows_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int64, c_int, c_int, _P, c_int64, c_int,

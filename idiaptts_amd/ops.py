@@ -133,6 +133,15 @@ def sqrt_inplace(x):
     return x
 
 
+def square_inplace(x):
+    """x <- x * x for a contiguous float64 tensor (one IEEE product per value: numpy's bits)."""
+    L = _lib.load()
+    _need(x, torch.float64, "x")
+    assert x.is_contiguous()
+    _lib.check(L.itts_square_inplace_f64(_ptr(x), x.numel(), _stream()), "itts_square_inplace_f64")
+    return x
+
+
 def interpolate_lin_f32(x, offsets):
     """interpolate_lin (misc/utils.py:40-86) on float32 contours stored back to back:
     (interpolated [Ttot], vuv [Ttot])."""

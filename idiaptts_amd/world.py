@@ -223,14 +223,23 @@ def synthesise_features(f0, f_off, fs, n_fft, mc=None, alpha=None, sp=None, bap=
 
 
 def synthesise_batch(f0s, sps, baps, fs, n_fft, hop_ms=5.0, preemphasis=0.0, device=None,
-                     out_dtype=np.float64):
-    """f0s: list of [T] f64; sps: list of [T,K] f64 POWER spectra; baps: list of [T,nap] f64 coded
+                     out_dtype=np.float64, sp_is_amplitude=False):
+    """f0s: list of [T] f64; sps: list of [T,K] f64 POWER spectra -- or, with `sp_is_amplitude`, amplitude spectra
+    of any float type, widened and squared on the device after the upload (np.square(amp_sp, dtype=float64) of
+    WorldFeatLabelGen.py:925: the same bits) --; baps: list of [T,nap] f64 coded
     aperiodicity. Returns list of waveforms (float32 samples; float64 container when
     out_dtype is float64, like scipy.signal.lfilter gives the reference)."""
     dev = _device(device)
     f_off = offsets([len(f) for f in f0s])
     f0 = torch.from_numpy(np.ascontiguousarray(np.concatenate(f0s), dtype=np.float64)).to(dev)
-    sp = torch.from_numpy(np.ascontiguousarray(np.concatenate(sps), dtype=np.float64)).to(dev)
+    if sp_is_amplitude:
+        host = sps[0] if len(sps) == 1 else np.concatenate(sps)
+        sp = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+        if sp.dtype != torch.float64:
+            sp = sp.double()
+        ops.square_inplace(sp)
+    else:
+        sp = torch.from_numpy(np.ascontiguousarray(np.concatenate(sps), dtype=np.float64)).to(dev)
     bap = torch.from_numpy(np.ascontiguousarray(np.concatenate(baps), dtype=np.float64)).to(dev)
     y, y_off = synthesise_features(f0, f_off, fs, n_fft, sp=sp, bap=bap, hop_ms=hop_ms, preemphasis=preemphasis,
                                    dtype=torch.float64 if out_dtype == np.float64 else torch.float32)

@@ -196,6 +196,9 @@ int itts_lf0_vuv(const double* d_f0, const int64_t* h_f_off, int n_utts,
  * WorldFeatLabelGen.world_extract_features (world/WorldFeatLabelGen.py:795, np.sqrt(sp)) from CheapTrick's power
  * envelope, before it leaves the device. */
 int itts_sqrt_inplace_f64(double* d_x, int64_t n, void* stream);
+/* d_x[i] = d_x[i] * d_x[i] (one IEEE product): the power envelope WORLD's synthesis takes from the amplitude envelope
+ * of WorldFeatLabelGen.world_features_to_raw (world/WorldFeatLabelGen.py:925, np.square), after the upload. */
+int itts_square_inplace_f64(double* d_x, int64_t n, void* stream);
 
 /* interpolate_lin (misc/utils.py:40-86) on float32 contours stored back to back: frames <= 0 are
  * gaps; bit-exact including the reference's quirks (target reached one frame early; a gap whose

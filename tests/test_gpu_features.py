@@ -168,3 +168,16 @@ def test_device_square_root_is_numpys(gpu):
                         [0.0, 5e-324, 2.2250738585072014e-308, 1.0, 2.0, 1e-16, np.inf]])
     got = ops.sqrt_inplace(torch.from_numpy(x.copy()).to(gpu)).cpu().numpy()
     assert np.array_equal(got.view(np.uint64), np.sqrt(x).view(np.uint64))
+
+
+def test_device_square_is_numpys(gpu):
+    """ops.square_inplace (WorldFeatLabelGen.py:925, np.square(amp_sp, dtype=float64) taken after the upload): the same
+    bits, also for a float32 envelope widened first"""
+    from idiaptts_amd import ops
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, 5000) * 10.0 ** rng.integers(-160, 150, 5000)
+    got = ops.square_inplace(torch.from_numpy(x.copy()).to(gpu)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), np.square(x).view(np.uint64))
+    x32 = rng.uniform(0, 3, 4096).astype(np.float32)
+    got = ops.square_inplace(torch.from_numpy(x32).to(gpu).double()).cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), np.square(x32, dtype=np.float64).view(np.uint64))
