@@ -103,8 +103,9 @@ class ExtendedHParams(object):
             # not in the reference: the rows the data readers return for an utterance stay in HBM after their first
             # use and every later mini-batch is gathered on the device (the same batches in the same order: data_
             # preparation/DeviceBatchCache.py); `dataset_device_cache_bytes` bounds what is kept (None: 60 % of the
-            # memory free at the first upload), utterances beyond it are read again each time
-            dataset_device_cache=True, dataset_device_cache_bytes=None,
+            # memory free at the first upload), `dataset_host_cache_bytes` what page-locked host memory holds beyond that
+            # (None: a quarter of the free host memory; these utterances cross PCIe per batch but are not read again)
+            dataset_device_cache=True, dataset_device_cache_bytes=None, dataset_host_cache_bytes=None,
             # not in the reference: checkpoints are serialised by a background thread
             async_checkpoint=False,
             # data

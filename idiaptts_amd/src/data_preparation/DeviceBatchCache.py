@@ -17,7 +17,9 @@ yielding what `prepare_batch` yields for those items -- same keys in the same or
 padded tensors -- already on the device.  Utterances not cached yet (all of them in the first epoch; under data
 parallelism those of the other ranks' shards as the shuffling brings them round) are read by the reader threads,
 packed into page-locked memory and appended to the arena on the way; once `byte_budget` is spent, further utterances
-pass through a scratch region at the arena's end instead and are read again next time.  Streams the arena cannot hold
+keep their rows in that page-locked memory (`host_byte_budget`: they cross PCIe again for every batch they are in --
+into scratch rows behind the kept ones -- but are not read, normalised and matched again), and beyond that they pass
+through the scratch rows and are read again next time.  Streams the arena cannot hold
 (not [T, D] float32, `other_pad_dims`, non-constant padding up to `min_frames`) keep their host arrays and go through
 `prepare_batch` itself.
 """
@@ -79,13 +81,14 @@ class CachedBatchLoader(object):
 
     def __init__(self, dataset, batch_size, shuffle, device, batch_first, common_divisor=1, shard=None,
                  mask_keys=(), threads=0, generator=None, byte_budget=None, depth=None, arena_factory=DeviceRowArena,
-                 host_collate=None):
+                 host_collate=None, host_byte_budget=None):
         self.dataset, self.batch_size = dataset, batch_size
         self.device, self.batch_first = device, bool(batch_first)
         self.common_divisor, self.shard, self.mask_keys = int(common_divisor), shard, tuple(mask_keys)
         self.threads = max(0, int(threads))
         self.depth = int(depth) if depth else max(2, 2 * self.threads)
         self.byte_budget = byte_budget              # None: decided at the first insertion (share of the free HBM)
+        self.host_byte_budget = host_byte_budget    # page-locked second tier; None: a quarter of the free host memory
         self._arena_factory = arena_factory
         self._host_collate = host_collate           # prepare_batch, for the streams an arena cannot hold
         self._index_loader = DataLoader(_Indices(len(dataset)), batch_size=batch_size, shuffle=shuffle,
@@ -99,10 +102,13 @@ class CachedBatchLoader(object):
         self._arenas = {}
         self._start = {}                            # key -> int64 [n] first arena row of the utterance (-1: not cached)
         self._len = {}
-        self._cached = np.zeros(n, dtype=bool)
+        self._cached = np.zeros(n, dtype=bool)      # read once, rows kept (on the device or in page-locked memory)
+        self._on_host = np.zeros(n, dtype=bool)     # .. in page-locked memory: `_host_rows[key][i]`
+        self._host_rows = {}
         self._host_values = [None] * n              # per utterance: {key: value} of the non-arena keys
         self._bytes_kept = 0
-        self.stats = {"hits": 0, "misses": 0, "passed_through": 0}
+        self._host_bytes_kept = 0
+        self.stats = {"hits": 0, "misses": 0, "passed_through": 0, "host_tier": 0}
 
     def __len__(self):
         return len(self._index_loader)
@@ -170,75 +176,111 @@ class CachedBatchLoader(object):
                 self.byte_budget = 1 << 62
         return self.byte_budget
 
+    def _host_budget(self):
+        if self.host_byte_budget is None:
+            try:
+                import psutil
+                self.host_byte_budget = int(0.25 * psutil.virtual_memory().available)
+            except Exception:
+                self.host_byte_budget = 0
+        return self.host_byte_budget
+
     def _insert(self, misses, items, staged):
-        """arena rows for the freshly read utterances: kept while the budget lasts, scratch afterwards"""
+        """The freshly read utterances: rows appended to the arenas while the device budget lasts, kept in their
+        page-locked staging memory while the host budget lasts, else handed back for one pass through the scratch rows.
+        Returns {utterance: ({key: page-locked rows}, {key: value})} of the ones to pass through."""
         if self._keys is None:
             self._classify(items[0])
         if staged is None:
             staged = self._stage(items)
         arena_keys = [k for k in self._keys if self._kind[k] == "arena"]
         row_bytes = sum(4 * staged[k].shape[1] for k in arena_keys)
-        budget = self._budget()
-        keep = []
-        for i, it in zip(misses, items):
+        budget, host_budget = self._budget(), None
+        tier = []                       # per miss: 1 device, 2 page-locked host, 0 pass through
+        for it in items:
             need = sum(4 * it[k].shape[0] * it[k].shape[1] for k in arena_keys)
-            ok = self._bytes_kept + need <= budget
-            keep.append(ok)
-            if ok:
+            if self._bytes_kept + need <= budget:
                 self._bytes_kept += need
-        # kept utterances first (they extend the arena), passed-through ones into the scratch rows behind them
-        order = [j for j, k in enumerate(keep) if k] + [j for j, k in enumerate(keep) if not k]
-        scratch = {}
+                tier.append(1)
+                continue
+            if host_budget is None:
+                host_budget = self._host_budget()
+            if self._host_bytes_kept + need <= host_budget:
+                self._host_bytes_kept += need
+                tier.append(2)
+            else:
+                tier.append(0)
+        passed = {}
         for key in arena_keys:
-            lens = np.array([items[j][key].shape[0] for j in range(len(items))], dtype=np.int64)
-            src_off = np.concatenate([[0], np.cumsum(lens)])
+            lens = [items[j][key].shape[0] for j in range(len(items))]
+            src_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
             arena = self._arenas.get(key)
             if arena is None:
                 # room for the whole id list at this batch's mean length (it grows by half when that was too few),
                 # never more rows than the budget pays for, plus one batch of scratch
-                batch_rows = int(lens.sum())
-                guess = min(int(max(1.0, float(lens.mean())) * len(self.dataset) * 1.1),
+                batch_rows = int(src_off[-1])
+                guess = min(int(max(1.0, batch_rows / float(len(items))) * len(self.dataset) * 1.1),
                             budget // max(row_bytes, 1)) + batch_rows
                 arena = self._arenas[key] = self._arena_factory(staged[key].shape[1], self.device, guess)
-            n_keep = sum(keep)
-            if n_keep == len(items):
-                start = arena.used
-                arena.write(start, staged[key], keep=True)
-                starts = start + src_off[:-1]
+                self._host_rows[key] = {}
+            if all(t == 1 for t in tier):
+                first = arena.used
+                arena.write(first, staged[key], keep=True)           # the whole batch in one copy
+                starts = first + src_off[:-1]
             else:
-                # regroup the staged rows: kept ones first
-                parts = [staged[key][src_off[j]:src_off[j + 1]] for j in order]
-                kept_rows = int(sum(lens[j] for j in order[:n_keep]))
-                start = arena.used
-                if kept_rows:
-                    arena.write(start, torch.cat(parts[:n_keep]) if n_keep > 1 else parts[0], keep=True)
-                rest = torch.cat(parts[n_keep:]) if len(parts) - n_keep > 1 else parts[n_keep]
-                arena.write(arena.used, rest, keep=False)
-                new_off = np.concatenate([[0], np.cumsum(lens[order])])[:-1]
-                starts = np.empty(len(items), dtype=np.int64)
-                starts[order] = start + new_off
+                starts = np.full(len(items), -1, dtype=np.int64)
+                for j, t in enumerate(tier):
+                    if t == 1:
+                        starts[j] = arena.used
+                        arena.write(arena.used, staged[key][src_off[j]:src_off[j + 1]], keep=True)
             for j, i in enumerate(misses):
-                if keep[j]:
+                rows = staged[key][src_off[j]:src_off[j + 1]]        # (a view: keeps the staging buffer alive)
+                if tier[j] == 1:
                     self._start[key][i] = starts[j]
                     self._len[key][i] = lens[j]
-            scratch[key] = {misses[j]: (int(starts[j]), int(lens[j])) for j in range(len(items)) if not keep[j]}
+                elif tier[j] == 2:
+                    self._host_rows[key][i] = rows
+                    self._len[key][i] = lens[j]
+                else:
+                    passed.setdefault(i, ({}, None))[0][key] = rows
         for j, (i, it) in enumerate(zip(misses, items)):
             values = {k: it[k] for k in self._keys if self._kind[k] != "arena"}
-            if keep[j]:
+            if tier[j]:
                 self._host_values[i] = values
                 self._cached[i] = True
+                self._on_host[i] = tier[j] == 2
             else:
-                scratch.setdefault("_values", {})[i] = values
-        self.stats["passed_through"] += len(items) - sum(keep)
-        return scratch
+                passed[i] = (passed.get(i, ({}, None))[0], values)
+        self.stats["passed_through"] += sum(1 for t in tier if t == 0)
+        return passed
 
-    def _assemble(self, indices, scratch):
+    def _to_scratch(self, indices, passed):
+        """Rows of this batch's utterances that are not in the arenas -- page-locked tier, passed through -- copied
+        behind the kept rows.  Returns {key: {utterance: (start, length)}}."""
+        out = {}
+        away = [i for i in dict.fromkeys(indices) if self._on_host[i] or not self._cached[i]]
+        if not away:
+            return out
+        self.stats["host_tier"] += sum(1 for i in away if self._on_host[i])
+        for key, arena in self._arenas.items():
+            rows_of = {i: (self._host_rows[key][i] if self._on_host[i] else passed[i][0][key]) for i in away}
+            arena.ensure(arena.used + sum(r.shape[0] for r in rows_of.values()))      # (once: growing drops scratch rows)
+            pos, placed = arena.used, {}
+            for i, rows in rows_of.items():
+                arena.write(pos, rows, keep=False)
+                placed[i] = (pos, rows.shape[0])
+                pos += rows.shape[0]
+            out[key] = placed
+        return out
+
+    def _assemble(self, indices, passed):
         """What prepare_batch returns for these utterances (ModularModelHandlerPyTorch.py:388-465)."""
         data, lengths = {}, {}
         B = len(indices)
         idx = np.asarray(indices, dtype=np.int64)
-        passed_values = scratch.get("_values", {}) if scratch else {}
-        values_of = [self._host_values[i] if self._cached[i] else passed_values[i] for i in indices]
+        passed = passed or {}
+        scratch = self._to_scratch(indices, passed)
+        values_of = [self._host_values[i] if self._cached[i] else passed[i][1] for i in indices]
         arena_keys = [k for k in self._keys if self._kind[k] == "arena"]
         tables = None
         if arena_keys:
@@ -248,9 +290,10 @@ class CachedBatchLoader(object):
             for a, key in enumerate(arena_keys):
                 tab[a, 0] = self._start[key][idx]
                 tab[a, 1] = self._len[key][idx]
-                for b, i in enumerate(indices):
-                    if not self._cached[i]:
-                        tab[a, 0, b], tab[a, 1, b] = scratch[key][i]
+                if key in scratch:
+                    for b, i in enumerate(indices):
+                        if i in scratch[key]:
+                            tab[a, 0, b], tab[a, 1, b] = scratch[key][i]
             tables = host.to(self.device, non_blocking=True)          # ONE upload per batch
         host_keys = [k for k in self._keys if self._kind[k] == "host"]
         host_part = None
@@ -301,13 +344,13 @@ class CachedBatchLoader(object):
 
         def finish(entry):
             indices, misses, job = entry
-            scratch = None
+            passed = None
             if misses:
                 items, staged = job.result() if hasattr(job, "result") else job
-                scratch = self._insert(misses, items, staged)
+                passed = self._insert(misses, items, staged)
             self.stats["hits"] += len(indices) - len(misses)
             self.stats["misses"] += len(misses)
-            return self._assemble(indices, scratch)
+            return self._assemble(indices, passed)
 
         try:
             for drawn in self._index_loader:       # (draws what a DataLoader draws, when a DataLoader draws it)
@@ -340,6 +383,9 @@ class CachedBatchLoader(object):
 
     def cached_bytes(self):
         return self._bytes_kept
+
+    def host_cached_bytes(self):
+        return self._host_bytes_kept
 
     def __del__(self):
         pool, self._pool = self._pool, None

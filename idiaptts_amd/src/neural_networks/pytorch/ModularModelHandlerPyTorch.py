@@ -549,7 +549,12 @@ class ModularModelHandlerPyTorch(object):
                       pin_memory=hparams.dataset_pin_memory,
                       worker_kind=hparams.get_value("dataset_worker_kind", "thread"),
                       device_cache=device_cache,
-                      device_cache_bytes=hparams.get_value("dataset_device_cache_bytes", None))
+                      device_cache_bytes=hparams.get_value("dataset_device_cache_bytes", None),
+                      host_cache_bytes=hparams.get_value("dataset_host_cache_bytes", None))
+        # loaders of datasets that are gone give their rows back
+        live = {id(ds) for ds in (dataset_train, dataset_val) if ds is not None}
+        for key in [k for k in self._cached_loaders if k[0] not in live]:
+            del self._cached_loaders[key]
         self.dataloader_train = self._get_dataloader(
             batch_size=hparams.batch_size_train, dataset=dataset_train,
             shuffle=hparams.shuffle_train_set, **common)
@@ -576,7 +581,7 @@ class ModularModelHandlerPyTorch(object):
 
     def _get_dataloader(self, batch_size, dataset, batch_first=True, collate_fn=None,
                         common_divisor=1, num_workers=1, pin_memory=True, shuffle=False,
-                        worker_kind="process", device_cache=False, device_cache_bytes=None):
+                        worker_kind="process", device_cache=False, device_cache_bytes=None, host_cache_bytes=None):
         stock = collate_fn is None or collate_fn is self.prepare_batch
         collate_fn = self.prepare_batch if collate_fn is None else collate_fn
         rank, world = parallel.dp_rank_world()
@@ -608,7 +613,8 @@ class ModularModelHandlerPyTorch(object):
             loader = CachedBatchLoader(dataset, batch_size, shuffle, device, batch_first,
                                        common_divisor=common_divisor, shard=extra.get("shard"),
                                        threads=num_workers if worker_kind == "thread" else 0, generator=generator,
-                                       byte_budget=device_cache_bytes, host_collate=self.prepare_batch)
+                                       byte_budget=device_cache_bytes, host_collate=self.prepare_batch,
+                                       host_byte_budget=host_cache_bytes)
             self._cached_loaders[key] = loader
             return loader
         collate = partial(collate_fn, common_divisor=common_divisor, batch_first=batch_first, **extra)

@@ -25,13 +25,16 @@ class HostArena(object):
         self.used = 0
         self.grown = 0
 
-    def write(self, start, staged, keep):
-        n = staged.shape[0]
-        if start + n > self.rows.shape[0]:
-            grown = torch.full((max(start + n, self.rows.shape[0] * 3 // 2), self.width), float("nan"))
-            grown[:self.used] = self.rows[:self.used]
+    def ensure(self, rows_needed):
+        if rows_needed > self.rows.shape[0]:
+            grown = torch.full((max(rows_needed, self.rows.shape[0] * 3 // 2), self.width), float("nan"))
+            grown[:self.used] = self.rows[:self.used]          # (like the device arena: scratch rows are NOT carried over)
             self.rows = grown
             self.grown += 1
+
+    def write(self, start, staged, keep):
+        n = staged.shape[0]
+        self.ensure(start + n)
         self.rows[start:start + n] = staged
         if keep:
             assert start == self.used
@@ -125,7 +128,7 @@ def test_cached_batches_equal_prepare_batch_over_epochs(batch_first, shuffle, th
     assert torch.equal(ref_next, got_next)              # the same draws from the global generator
     # every utterance was read once, not once per epoch
     assert [r.loads for r in readers2] == [l // 3 for l in loads_ref]
-    assert loader.stats == {"hits": 2 * len(ds), "misses": len(ds), "passed_through": 0}
+    assert loader.stats == {"hits": 2 * len(ds), "misses": len(ds), "passed_through": 0, "host_tier": 0}
     if shuffle:
         assert not all(torch.equal(a[0]["x"], b[0]["x"]) for a, b in zip(ref[0], ref[1]) if a[0]["x"].shape == b[0]["x"].shape)
 
@@ -148,14 +151,38 @@ def test_budget_passes_the_rest_through_scratch_rows():
     ds2, readers2 = _dataset()
     per_frame = 4 * (5 + 3)
     budget = per_frame * 40                                  # room for a handful of utterances
-    got, _, loader = _cached_epochs(ds2, 4, True, True, 3, seed=5, byte_budget=budget)
+    got, _, loader = _cached_epochs(ds2, 4, True, True, 3, seed=5, byte_budget=budget, host_byte_budget=0)
     _assert_same(ref, got)
     assert 0 < loader._cached.sum() < len(ds2)
     assert loader.cached_bytes() <= budget
-    assert loader.stats["passed_through"] > 0
+    assert loader.stats["passed_through"] > 0 and loader.stats["host_tier"] == 0
     assert readers2[0].loads > len(ds2)                      # the passed-through ones are read again
     # kept rows never moved: an arena never grows beyond what the budget pays for plus one batch of scratch
     assert all(a.used * a.width * 4 <= budget for a in loader._arenas.values())
+
+
+def test_page_locked_second_tier_between_device_and_files():
+    """device budget for a few utterances, host budget for some more, the rest passed through: every batch equal to
+    prepare_batch's; an utterance of the first two tiers is read once, only the last tier again"""
+    ds, _ = _dataset()
+    ref, _ = _reference_epochs(ds, 4, True, False, 3, seed=9)
+    ds2, readers2 = _dataset()
+    per_frame = 4 * (5 + 3)
+    got, _, loader = _cached_epochs(ds2, 4, True, False, 3, seed=9, byte_budget=per_frame * 30,
+                                    host_byte_budget=per_frame * 45, threads=2)
+    _assert_same(ref, got)
+    n_dev = int((loader._cached & ~loader._on_host).sum())
+    n_host = int(loader._on_host.sum())
+    assert n_dev > 0 and n_host > 0 and n_dev + n_host < len(ds2)
+    assert loader.host_cached_bytes() <= per_frame * 45 and loader.cached_bytes() <= per_frame * 30
+    assert loader.stats["host_tier"] >= 2 * n_host - 1           # used from page-locked memory in epochs 2 and 3
+    assert loader.stats["passed_through"] == 3 * (len(ds2) - n_dev - n_host)
+    # all of it in page-locked memory: nothing read twice
+    ds3, readers3 = _dataset()
+    got, _, loader = _cached_epochs(ds3, 4, True, False, 3, seed=9, byte_budget=0, host_byte_budget=1 << 40)
+    _assert_same(ref, got)
+    assert loader._on_host.all() and loader.stats["passed_through"] == 0
+    assert readers3[1].loads <= 2 * len(ds3)                 # (one load per utterance, plus get_length's first look)
 
 
 def test_data_parallel_shards_and_remainder():

@@ -210,18 +210,30 @@ def test_handler_cached_loader_equals_dataloader_with_shuffling(gpu, batch_first
     assert loader.stats["misses"] == len(ds) and loader.stats["hits"] == 2 * len(ds)
 
 
-def test_cached_loader_over_budget_on_the_device(gpu):
+@pytest.mark.parametrize("host_budget", [0, 4 * 612 * 70, None])
+def test_cached_loader_over_budget_on_the_device(gpu, host_budget):
+    """beyond `byte_budget` the rows stay in page-locked memory (host_byte_budget; None: a share of the free host memory)
+    and cross PCIe per batch, beyond that they pass through scratch rows and are read again: the batches stay
+    prepare_batch's bit for bit"""
     from idiaptts_amd.src.data_preparation.DeviceBatchCache import CachedBatchLoader
     from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as H
     ds_ref, ds = _Dicts(30), _Dicts(30)
     torch.manual_seed(5)
     ref = [[b for b in DataLoader(ds_ref, batch_size=7, shuffle=True, num_workers=0,
-                                  collate_fn=partial(H.prepare_batch, batch_first=True))] for _ in range(2)]
+                                  collate_fn=partial(H.prepare_batch, batch_first=True))] for _ in range(3)]
     torch.manual_seed(5)
     loader = CachedBatchLoader(ds, 7, True, gpu, True, threads=2, byte_budget=4 * 612 * 60,
-                               host_collate=H.prepare_batch)
-    got = [[b for b in loader] for _ in range(2)]
-    assert 0 < loader._cached.sum() < len(ds) and loader.stats["passed_through"] > 0
+                               host_collate=H.prepare_batch, host_byte_budget=host_budget)
+    got = [[b for b in loader] for _ in range(3)]
+    on_device = int((loader._cached & ~loader._on_host).sum())
+    assert 0 < on_device < len(ds)
+    if host_budget == 0:
+        assert loader.stats["passed_through"] > 0 and loader.stats["host_tier"] == 0 and ds.reads > len(ds)
+    elif host_budget is None:
+        assert loader.stats["passed_through"] == 0 and loader._on_host.sum() == len(ds) - on_device
+        assert ds.reads == len(ds) and loader.stats["host_tier"] > 0
+    else:
+        assert loader.stats["passed_through"] > 0 and loader.stats["host_tier"] > 0
     for e_ref, e_got in zip(ref, got):
         for (d0, _), (d1, _) in zip(e_ref, e_got):
             for k in ("x", "y", "y_mask"):
