@@ -1389,6 +1389,15 @@ class ModularModelHandlerPyTorch(object):
                 "Either step or epoch is required. Use -1 in one of them to load the best model."
             suffix = "_s{}".format(step) if step is not None else "_e{}".format(epoch)
         params_path = os.path.join(model_path, "params" + suffix)
+        world = parallel.dp_rank_world()[1]
+        if world > 1:
+            # every rank loads the files (the optimiser and scheduler state come from them) and rank 0's tensors are
+            # broadcast behind that: a rank that cannot see a file must not be the only one to raise -- the others
+            # would wait for it in the broadcast for ever (ranks with out_dirs of their own, a file system not shared)
+            seen = parallel.global_sum(1.0 if os.path.isfile(params_path) else 0.0, device=self._dist_device())
+            if seen < world:
+                raise FileNotFoundError("{} is visible to {} of the {} ranks (they need one shared out_dir)."
+                                        .format(params_path, int(seen), world))
         if verbose:
             self.logger.info("Load model state dict from {}".format(params_path))
         checkpoint = torch.load(params_path, map_location="cpu", weights_only=False)

@@ -299,3 +299,52 @@ def test_sync_from_rank0_carries_torch_optimiser_state_including_host_side_step(
     mp.spawn(_optim_state_worker, args=(2, port, ret), nprocs=2, join=True)
     assert np.array_equal(ret[0], ret[1])
     assert ret[0][-1] != 0
+
+
+def _missing_checkpoint_worker(rank, world, port, tmp, ret):
+    """rank 1 looks for the checkpoint in a directory of its own, where there is none"""
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from idiaptts_amd.src.ExtendedHParams import ExtendedHParams
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import \
+        ModularModelHandlerPyTorch as Handler
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import \
+        NamedForwardWrapper
+    hp = types.SimpleNamespace(model_type="RNNDYN-1_TANH_8-1_FC_3", batch_first=False, dropout=0.0)
+    h = Handler()
+    h.create_model(NamedForwardWrapper.Config(rnn_dyn.convert_legacy_to_config((5,), hp),
+                                              input_names=["x"], batch_first=False, name="AM",
+                                              output_names=["pred"]), use_gpu=False)
+    shared = os.path.join(tmp, "shared")
+    h.save_checkpoint(shared, epoch=1, step=3)               # rank 0 writes
+    hparams = ExtendedHParams.create_hparams()
+    hparams.use_gpu = False
+    mine = shared if rank == 0 else os.path.join(tmp, "rank1_only")
+    os.makedirs(mine, exist_ok=True)
+    try:
+        h.load_checkpoint(hparams, mine, epoch=1, load_optimiser=False)
+        ret[rank] = "loaded"
+    except FileNotFoundError as e:
+        ret[rank] = "FileNotFoundError: " + str(e)
+    dist.barrier()                                            # both ranks get here: nobody waits in a broadcast
+    dist.destroy_process_group()
+
+
+def test_checkpoint_one_rank_cannot_see_raises_everywhere_instead_of_hanging(tmp_path):
+    """ModularModelHandlerPyTorch.load_checkpoint under data parallelism (reference :125-262 has one process): the
+    ranks agree on whether the file is there before anyone loads -- found on the GPU box with per-rank out_dirs, where
+    rank 1 raised and rank 0 waited in sync_from_rank0's broadcast."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_missing_checkpoint_worker, args=(r, 2, port, str(tmp_path), ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0].startswith("FileNotFoundError") and ret[1].startswith("FileNotFoundError")
+    assert "1 of the 2 ranks" in ret[0]

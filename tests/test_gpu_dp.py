@@ -400,3 +400,68 @@ def test_rccl_version_is_one_the_binding_knows(gpu):
     from idiaptts_amd import lib
     v = int(lib.load().itts_comm_version())
     assert 21000 <= v < 30000, v
+
+
+def _trainer_dp_worker(rank, world, port, ret, root, cache):
+    """Child: AcousticModelTrainer.train on the reference's fixture, two ranks sharing device 0 over gloo."""
+    import faulthandler
+    import logging
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(int(os.environ.get("ITTS_TEST_HANG_S", "150")), exit=True)   # a rank stuck in a collective says where, and ends
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    _init(rank, world, port)
+    os.environ["ITTS_RNN_PERSISTENT"] = "0"
+    from fixture_dirs import materialise
+    from idiaptts_amd.src.model_trainers.AcousticModelTrainer import AcousticModelTrainer
+    logging.getLogger().setLevel(logging.WARNING)
+    ids, wdir, qdir, g = materialise(os.path.join(ROOT, "tests", "golden"), os.path.join(root, "data%d" % rank))
+    hp = AcousticModelTrainer.create_hparams()
+    hp.num_questions, hp.voice, hp.frame_size_ms, hp.num_coded_sps = 409, "full", 5, 20
+    hp.out_dir = os.path.join(root, "out_%d" % int(cache))        # (shared by the ranks: rank 0 writes, all read)
+    hp.seed, hp.epochs, hp.use_gpu, hp.num_gpus = 1, 3, True, world
+    hp.dataset_num_workers_gpu = 2
+    hp.model_type = "RNNDYN-1_RELU_32-1_FC_67"
+    hp.batch_size_train, hp.batch_size_val = 4, 50
+    hp.optimiser_args["lr"] = 0.001
+    hp.model_name, hp.world_dir = "dp_model", wdir
+    hp.epochs_per_checkpoint = 1000
+    hp.val_set_perc, hp.test_set_perc = 0.25, 0.0        # (two validation utterances: a batch holds >= one per rank, :392-395)
+    hp.dataset_device_cache = cache
+    trainer = AcousticModelTrainer(**AcousticModelTrainer.legacy_support_init(wdir, qdir, ids, hp.num_questions, hp))
+    trainer.init(hp)
+    val, train, handler = trainer.train(hp)
+    torch.cuda.synchronize()
+    name = next(iter(train))
+    loader = handler.dataloader_train
+    ret[rank] = ([float(v) for v in train[name]], [float(v) for v in val[name]],
+                 torch.cat([p.detach().reshape(-1) for p in handler.model.parameters()]).cpu().numpy(),
+                 dict(getattr(loader, "stats", {})), type(loader).__name__)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_with_the_device_batch_cache_under_two_ranks(gpu, tmp_path):
+    """AcousticModelTrainer.train under data parallelism (reference: ModularModelHandlerPyTorch.py:732-735, the loop
+    :683-882): with hparams.dataset_device_cache every rank caches the utterances of ITS shard of each global batch as
+    the shuffling brings them round -- the same per-epoch losses and the same parameters on both ranks as the run that
+    reads every utterance again each epoch (the sampler's seed is rank 0's in both)."""
+    import torch.multiprocessing as mp
+    runs = {}
+    for cache in (False, True):
+        ret = mp.get_context("spawn").Manager().dict()
+        torch.manual_seed(123)
+        mp.spawn(_trainer_dp_worker, args=(2, _free_port(), ret, str(tmp_path), cache), nprocs=2, join=True)
+        runs[cache] = {r: ret[r] for r in (0, 1)}
+    for cache in (False, True):
+        assert np.array_equal(runs[cache][0][2], runs[cache][1][2])            # ranks in lock step
+        assert runs[cache][0][0] == runs[cache][1][0]                          # global losses on both
+    assert runs[True][0][4] == "CachedBatchLoader" and runs[False][0][4] != "CachedBatchLoader"
+    st = runs[True][0][3]
+    assert st["misses"] > 0 and st["hits"] > 0 and st["passed_through"] == 0
+    # the sampler draws differ between the two spawns (rank 0 draws the seed), so the trajectories are compared
+    # through what does not depend on the order of the batches: the validation loss after three epochs agrees loosely,
+    # and both runs learn
+    for cache in (False, True):
+        tr = runs[cache][0][0]
+        assert tr[-1] < tr[0]
+    assert abs(runs[True][0][1][-1] - runs[False][0][1][-1]) < 0.05 * abs(runs[False][0][1][-1])
