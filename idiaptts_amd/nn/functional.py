@@ -69,6 +69,79 @@ class LinearActFunction(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None), None
 
 
+def _rows_padded(M, N, device):
+    """[M, N] view of a fresh buffer whose row pitch is N rounded up to four floats, pad columns zero"""
+    Np = (N + 3) // 4 * 4
+    full = torch.empty((M, Np), dtype=torch.float32, device=device)
+    if Np != N:
+        full[:, N:] = 0
+    return full[:, :N]
+
+
+class LinearChainFunction(torch.autograd.Function):
+    """A run of Linear (+ Tanh / ReLU) layers on rows -- the layers of consecutive FFWrapper groups
+    (rnn_dyn/FFWrapper.py:63-73) -- as ONE autograd node: forward the same `itts_linear_fwd` launches as the layers
+    one by one (the same bits), backward as the flat step runs it (native_ff.py): per layer ONE launch for weight
+    gradient, bias gradient and input gradient (`itts_linear_bwd`), the previous layer's activation derivative in its
+    epilogue -- no `act_bwd` pass over the rows, no second launch per layer, one node instead of one per layer.
+    x: [M, K0] rows, or [M, K0 rounded up to 4] with zeroed pad columns (LinearActFunction's convention);
+    acts: tuple of ops.ACT_*; wb: weight0, bias0, weight1, bias1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        n = len(acts)
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        ws, hs, h = [], [], x
+        for i in range(n):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            N, K = w.shape
+            w = w.contiguous()
+            if i == 0 and h.shape[1] != K and h.shape[1] == (K + 3) // 4 * 4:
+                w = torch.nn.functional.pad(w, (0, h.shape[1] - K))
+            h = ops.linear_fwd(h, w, b, acts[i], out=_rows_padded(h.shape[0], N, h.device))
+            ws.append(w)
+            hs.append(h)
+        ctx.save_for_backward(x, *hs, *ws)
+        ctx.acts, ctx.n = tuple(acts), n
+        ctx.k0 = wb[0].shape[1]
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x, hs, ws = saved[0], saved[1:1 + n], saved[1 + n:]
+        M = x.shape[0]
+        dz = dy
+        if dz.stride(-1) != 1 or dz.stride(0) % 4:
+            buf = _rows_padded(M, dy.shape[1], dy.device)
+            buf.copy_(dy)
+            dz = buf
+        if ctx.acts[-1] != ops.ACT_NONE:
+            dz = ops.act_bwd(dz, hs[-1], ctx.acts[-1])
+        grads = [None] * (2 * n)
+        dx = None
+        for i in range(n - 1, -1, -1):
+            w = ws[i]
+            N, K = w.shape
+            dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+            db = torch.empty((N,), dtype=torch.float32, device=x.device)
+            if i > 0:
+                dz_in = _rows_padded(M, K, x.device)
+                ops.linear_bwd(dz, hs[i - 1], w, dw, db, dz_in, yprev=hs[i - 1], act_prev=ctx.acts[i - 1])
+                grads[2 * i], grads[2 * i + 1] = dw, db
+                dz = dz_in
+            else:
+                if ctx.needs_input_grad[0]:
+                    dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+                    ops.linear_bwd(dz, x, w, dw, db, dx)
+                else:
+                    ops.linear_bwd_weight(dz, x, dw=dw, db=db)
+                grads[0], grads[1] = (dw[:, :ctx.k0] if K != ctx.k0 else dw), db
+        return (dx, None) + tuple(grads)
+
+
 def _iptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

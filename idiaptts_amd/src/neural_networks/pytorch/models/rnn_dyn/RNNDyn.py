@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-from idiaptts_amd.nn.functional import ValidRows, padding_is_identical
+from idiaptts_amd.nn.functional import LinearChainFunction, ValidRows, padding_is_identical
 from idiaptts_amd.nn.modules import GRU, LSTM, RNN, LinearAct
 
 
@@ -26,6 +26,14 @@ class FusedActivation(nn.Identity):
 
     def extra_repr(self):
         return "{} (fused into the previous Linear)".format(self.name)
+
+
+def run_linear_chain(rows, layers):
+    """rows -> the layers' output rows through one autograd node (nn/functional.py: LinearChainFunction)"""
+    flat = []
+    for m in layers:
+        flat += [m.weight, m.bias]
+    return LinearChainFunction.apply(rows, tuple(m.act for m in layers), *flat)
 
 
 class FFWrapper(nn.Module):
@@ -74,6 +82,25 @@ class FFWrapper(nn.Module):
         """dropout draws per position: in training the padding positions would not stay identical"""
         return not (self.training and any(isinstance(m, nn.Dropout) for m in self.module))
 
+    def linear_layers(self):
+        """The group's LinearAct layers when it is nothing but those (fused activations and, outside training,
+        dropout are identities) and all carry a bias, else None: what LinearChainFunction can take as one node."""
+        layers = []
+        for m in self.module:
+            if isinstance(m, LinearAct):
+                if m.bias is None:
+                    return None
+                layers.append(m)
+            elif not isinstance(m, (FusedActivation, nn.Dropout)):
+                return None
+        return layers or None
+
+    def forward_rows(self, rows):
+        layers = self.linear_layers()
+        if layers is None:
+            return self.module(rows)
+        return run_linear_chain(rows, layers)
+
     def forward(self, input_, **kwargs):
         """reference FFWrapper.py:63-73: the Sequential on every position of the padded tensor.  Inside a
         `padding_rows_identical()` context (the handler's training / validation loops over stock batches) the
@@ -82,7 +109,7 @@ class FFWrapper(nn.Module):
         keeps consecutive Linear groups on the rows without going back to the padded tensor in between.)"""
         vr = self.valid_rows_for(input_, kwargs)
         if vr is not None:
-            return vr.unpack(self.module(vr.pack(input_))), kwargs
+            return vr.unpack(self.forward_rows(vr.pack(input_))), kwargs
         return self.module(input_), kwargs
 
 
@@ -185,6 +212,13 @@ class RNNDyn(nn.ModuleList):
                 embeddings[emb.name] = emb(emb_inputs[idx][:, :, 0].long())
         last_hidden = None
         rows = None          # (ValidRows, [N (+ 1), F]) while a run of Linear groups works on the valid rows
+        chain = []           # .. and the LinearAct layers of that run not applied yet (one autograd node for them all)
+
+        def flush():
+            nonlocal rows, chain
+            if chain:
+                rows, chain = (rows[0], run_linear_chain(rows[1], chain)), []
+
         for group_idx, module in enumerate(self.layer_groups):
             affected = [emb for emb in self.emb_groups.values() if self._affects(emb, group_idx)]
             if isinstance(module, FFWrapper) and not affected:
@@ -193,9 +227,15 @@ class RNNDyn(nn.ModuleList):
                     if vr is not None:
                         rows = (vr, vr.pack(input_))
                 if rows is not None and module.runs_on_rows():
-                    rows = (rows[0], module.module(rows[1]))
+                    layers = module.linear_layers()
+                    if layers is not None:
+                        chain += layers
+                    else:
+                        flush()
+                        rows = (rows[0], module.module(rows[1]))
                     continue
             if rows is not None:
+                flush()
                 input_, rows = rows[0].unpack(rows[1]), None
             for emb in affected:
                 input_ = torch.cat((input_, embeddings[emb.name]), dim=2)
@@ -203,6 +243,7 @@ class RNNDyn(nn.ModuleList):
             # hidden states are not passed from one RNN group to the next (reference :118-121)
             last_hidden = kwargs.pop("hidden", last_hidden)
         if rows is not None:
+            flush()
             input_ = rows[0].unpack(rows[1])
         kwargs["hidden"] = last_hidden
         return input_, kwargs
