@@ -1,6 +1,7 @@
 """torch.autograd glue for the HIP acoustic-model kernels (PyTorch-ROCm only provides autograd,
 device memory and streams; every forward / backward computation below is a C-ABI call)."""
 import collections
+import os
 import ctypes
 import threading
 
@@ -523,11 +524,18 @@ class LSTMLayerFunction(torch.autograd.Function):
                 for d in range(ndir)], dim=0)
         if want_c0:
             dc0 = dc0_rows.sum(dim=1)
-        dw_ih, db = ops.linear_bwd_weight(dg, x2)                      # [ndir*4H, F], [ndir*4H]
+        # The launch right behind a recurrence runs 20-25 % slow (the chip comes back from light load: LABNOTES 12g):
+        # the two small products W_hh' take that place, the large ones follow (95.9 -> 95.6 ms per 3 x 512 BiLSTM
+        # step, two A/B pairs; ITTS_RNN_BWD_SMALL_FIRST=0 for the old order)
+        small_first = os.environ.get("ITTS_RNN_BWD_SMALL_FIRST", "1") != "0"
+        if not small_first:
+            dw_ih, db = ops.linear_bwd_weight(dg, x2)                      # [ndir*4H, F], [ndir*4H]
         dw_hh = torch.empty((ndir, G4, H), dtype=torch.float32, device=dev)
         for d in range(ndir):
             ops.linear_bwd_weight(dg[:, d * G4:(d + 1) * G4], hprev[:, d * H:(d + 1) * H],
                                   dw=dw_hh[d], want_bias=False)
+        if small_first:
+            dw_ih, db = ops.linear_bwd_weight(dg, x2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dg, w_ih_cat)
@@ -605,13 +613,17 @@ class GRULayerFunction(torch.autograd.Function):
             dh0 = dh0_rows.sum(dim=1) + torch.stack([ops.linear_bwd_input(
                 ops.rows_gather(dgh[:, d * G3:(d + 1) * G3], pb.first_rows(d)).sum(0, keepdim=True), w_hh[d])[0]
                 for d in range(ndir)], dim=0)
-        dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]
+        small_first = os.environ.get("ITTS_RNN_BWD_SMALL_FIRST", "1") != "0"     # (as in the LSTM's backward)
+        if not small_first:
+            dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)                  # [ndir*3H, F], [ndir*3H]
         dw_hh = torch.empty((ndir, G3, H), dtype=torch.float32, device=dev)
         db_hh = torch.empty((ndir, G3), dtype=torch.float32, device=dev)
         for d in range(ndir):
             _, db = ops.linear_bwd_weight(dgh[:, d * G3:(d + 1) * G3], hprev[:, d * H:(d + 1) * H],
                                           dw=dw_hh[d])
             db_hh[d] = db
+        if small_first:
+            dw_ih, db_ih = ops.linear_bwd_weight(dgi, x2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dgi, w_ih_cat)
