@@ -158,6 +158,14 @@ def load():
         raise IttsError(
             "HIP library {} is missing. Build it with `python -m idiaptts_amd.build` "
             "(there is no CPU fallback).".format(LIB_PATH))
+    # torch first: its wheel carries a HIP runtime of its own, and the process must end up with ONE -- loaded the other
+    # way round (this library pulling in /opt/rocm's copy before torch brings its own) the two runtimes do not know
+    # each other's devices and allocations: "no ROCm-capable device is detected" from the first call that allocates
+    # (seen with __graft_entry__.build() followed by smoke() in one process)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
