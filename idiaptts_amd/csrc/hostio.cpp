@@ -197,27 +197,35 @@ void append_member(std::vector<unsigned char>& z, std::vector<Member>& dir, cons
   const size_t pad = (64 - total % 64) % 64;
   dict.append(pad, ' ');
   dict.push_back('\n');
-  std::vector<unsigned char> body;
-  body.reserve(10 + dict.size() + (size_t)rows * cols * 4);
-  const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
-  body.insert(body.end(), magic, magic + 8);
-  put16(body, (uint32_t)dict.size());
-  body.insert(body.end(), dict.begin(), dict.end());
-  const size_t head = body.size();
-  body.resize(head + (size_t)rows * cols * 4);
-  for (int64_t r = 0; r < rows; ++r)
-    memcpy(body.data() + head + (size_t)r * cols * 4, src + r * ld, (size_t)cols * 4);
+  // The member is built where it stays: local header (CRC patched in at the end), npy header, then the rows straight
+  // from the strided matrix, each row's CRC taken right behind its copy while it is in the cache.  (Until round 6 the
+  // body was assembled in a buffer of its own -- value-initialised, filled, summed, copied into the archive: five passes
+  // over every float on the 16 cores a box grants, where the writers are what a gen_data pass ends on.)
+  const size_t body_size = 10 + dict.size() + (size_t)rows * cols * 4;
   Member m;
   m.name = key + ".npy";
-  m.crc = crc32_update(0, body.data(), body.size());
-  m.size = (uint32_t)body.size();
+  m.size = (uint32_t)body_size;
   m.offset = (uint32_t)z.size();
   put32(z, 0x04034b50u); put16(z, 20); put16(z, 0); put16(z, 0);
   put16(z, 0); put16(z, 0x21);                       // time 00:00:00, date 1980-01-01
-  put32(z, m.crc); put32(z, m.size); put32(z, m.size);
+  const size_t crc_at = z.size();
+  put32(z, 0); put32(z, m.size); put32(z, m.size);
   put16(z, (uint32_t)m.name.size()); put16(z, 0);
   z.insert(z.end(), m.name.begin(), m.name.end());
-  z.insert(z.end(), body.begin(), body.end());
+  const size_t body_at = z.size();
+  const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+  z.insert(z.end(), magic, magic + 8);
+  put16(z, (uint32_t)dict.size());
+  z.insert(z.end(), dict.begin(), dict.end());
+  uint32_t crc = crc32_update(0, z.data() + body_at, z.size() - body_at);
+  const size_t row_bytes = (size_t)cols * 4;
+  for (int64_t r = 0; r < rows; ++r) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(src + r * ld);
+    z.insert(z.end(), p, p + row_bytes);
+    crc = crc32_update(crc, z.data() + z.size() - row_bytes, row_bytes);
+  }
+  m.crc = crc;
+  for (int k = 0; k < 4; ++k) z[crc_at + k] = (unsigned char)((crc >> (8 * k)) & 0xFF);
   dir.push_back(m);
 }
 

@@ -79,6 +79,9 @@ def test_native_archives_read_back_like_np_savez(tmp_path):
             assert np.array_equal(got, cmp_host[f_off[u]:f_off[u + 1]])
             assert np.array_equal(got, ref.load(os.path.basename(n)))
             for d, ext, _ in streams:
+                import zipfile
+                with zipfile.ZipFile(os.path.join(out_dir, d, os.path.basename(n) + ".npz")) as zf:
+                    assert zf.testzip() is None              # every member's CRC-32 (taken row by row while writing)
                 a = np.load(os.path.join(out_dir, d, os.path.basename(n) + ".npz"))
                 b = np.load(os.path.join(ref_dir, d, os.path.basename(n) + ".npz"))
                 assert sorted(a.files) == sorted(b.files)
