@@ -76,3 +76,83 @@ def test_grouped_tile_order_random_shapes(gpu):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
     assert "cases 25" in res.stdout
+
+
+def test_valid_rows_and_cached_batches_random_shapes(gpu):
+    """Random batch shapes through the round-6 batch kernels (csrc/batch_rows.hip): Linear groups on valid rows against
+    the padded computation (outputs bit for bit, gradients to rounding), and the cached loader against prepare_batch --
+    batches of one, no padding at all, a single frame, widths that are and are not multiples of four."""
+    from functools import partial
+    from torch.nn.utils.rnn import pad_sequence
+    from torch.utils.data import DataLoader
+    import types
+    from idiaptts_amd.nn.functional import padding_rows_identical
+    from idiaptts_amd.src.data_preparation.DeviceBatchCache import CachedBatchLoader
+    from idiaptts_amd.src.neural_networks.pytorch.ModularModelHandlerPyTorch import ModularModelHandlerPyTorch as H
+    from idiaptts_amd.src.neural_networks.pytorch.models import rnn_dyn
+    rng = np.random.default_rng(2026)
+    for case in range(14):
+        B = int(rng.choice([1, 2, 3, 9, 33]))
+        t_hi = int(rng.choice([1, 2, 17, 130]))
+        lens = torch.from_numpy(rng.integers(1, t_hi + 1, size=B))
+        if case % 5 == 0:
+            lens[:] = int(lens.max())                               # no padding at all
+        batch_first = bool(case % 2)
+        d_in, d_h, d_out = int(rng.choice([3, 8, 13])), int(rng.choice([16, 20])), int(rng.choice([1, 4, 7]))
+        act = ["TANH", "RELU"][case % 2]
+        torch.manual_seed(case)
+        hp = types.SimpleNamespace(model_type="RNNDYN-2_{}_{}-1_FC_{}".format(act, d_h, d_out), batch_first=batch_first,
+                                   dropout=0.0)
+        model = rnn_dyn.convert_legacy_to_config((d_in,), hp).create_model().to(gpu)
+        model.layer_groups[0].min_padding_share = 0.0               # (pack whenever there is any padding)
+        model.layer_groups[1].min_padding_share = 0.0
+        g = torch.Generator().manual_seed(case)
+        seqs = [torch.randn(int(n), d_in, generator=g) for n in lens]
+        x = pad_sequence(seqs, batch_first=batch_first).to(gpu)
+        T = int(lens.max())
+        outs = []
+        for packed in (False, True):
+            model.zero_grad()
+            with padding_rows_identical(packed):
+                y, _ = model(x, seq_lengths_input=lens, max_length_inputs=T)
+            (y ** 2).sum().backward()
+            outs.append((y.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+        assert torch.equal(outs[0][0], outs[1][0]), case
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert float((a - b).abs().max()) <= 3e-5 * (float(a.abs().max()) + 1e-30), case
+
+        # the cached loader over the same utterances (two streams, one masked)
+        class R(object):
+            min_frames = other_pad_dims = max_frames = None
+            pad_mode = "constant"
+
+            def __init__(self, name, mask):
+                self.name, self.output_names, self.requires_seq_mask = name, [name], mask
+
+        class D(torch.utils.data.Dataset):
+            datareaders = [R("x", False), R("y", True)]
+
+            def get_datareader_by_output_name(self, name):
+                return next(r for r in self.datareaders if r.name == name)
+
+            def __len__(self):
+                return B
+
+            def __getitem__(self, i):
+                return {"x": seqs[i].numpy(), "_id_list": str(i), "y": seqs[i].numpy()[:, :1] * 2}, self
+
+        ds = D()
+        bs = int(rng.integers(1, B + 1))
+        torch.manual_seed(100 + case)
+        ref = [[b for b in DataLoader(ds, batch_size=bs, shuffle=True, num_workers=0,
+                                      collate_fn=partial(H.prepare_batch, batch_first=batch_first))] for _ in range(2)]
+        torch.manual_seed(100 + case)
+        loader = CachedBatchLoader(ds, bs, True, gpu, batch_first, threads=int(case % 3), host_collate=H.prepare_batch)
+        got = [[b for b in loader] for _ in range(2)]
+        for e0, e1 in zip(ref, got):
+            assert len(e0) == len(e1)
+            for (d0, l0), (d1, l1) in zip(e0, e1):
+                assert list(d0) == list(d1) and d0["_id_list"] == d1["_id_list"]
+                for k in ("x", "y", "y_mask"):
+                    assert torch.equal(d0[k], d1[k].cpu()), (case, k)
+                assert torch.equal(l0["x"], l1["x"])
