@@ -10,6 +10,8 @@
 //                               (+ the [B, T, 1] mask); also pad_packed_sequence for the frame-independent
 //                               layers, which run on the valid rows only (nn/functional.py ValidRows)
 //   itts_batch_pack_rows_f32    its adjoint: rows[starts[b] + t, :] = padded[b, t, :]
+//   itts_batch_concat_rows_f32  rows[dst_starts[b] + t, :] = arena[src_starts[b] + t, :]: a mini-batch's valid frames
+//                               back to back (FrameShard.gather, the flat feed-forward step's input)
 //   itts_batch_pad_colsum_f32   the sum over the padding positions of a padded batch, per column (the gradient of
 //                               the fill row), in a fixed order: partial sums per slab of rows, then one pass over
 //                               the slabs
@@ -97,6 +99,39 @@ __global__ __launch_bounds__(256) void batch_pack_rows_kernel(const float* __res
       }
     } else {
       for (int c = lane; c < dst_width; c += 64) d[c] = c < width ? s[c] : 0.f;
+    }
+  }
+}
+
+// dst[dst_starts[b] + t, :] = src[src_starts[b] + t, :] for t < lens[b]: the utterances of a mini-batch out of an
+// arena, back to back in batch order (FrameShard.gather: the packed valid frames the flat feed-forward step takes).
+// Walks the B x t_max grid of positions like the kernels above; positions beyond an utterance's length leave at once.
+template <bool VEC>
+__global__ __launch_bounds__(256) void batch_concat_rows_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                                int64_t n_src, const int64_t* __restrict__ src_starts,
+                                                                const int64_t* __restrict__ dst_starts,
+                                                                const int64_t* __restrict__ lens, int n_utts,
+                                                                int64_t t_max, int width, float* __restrict__ dst,
+                                                                int64_t ld_dst, int dst_width) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wn = (int64_t)gridDim.x * 4;
+  for (int64_t r = w0; r < n_rows; r += wn) {
+    int b;
+    int64_t t;
+    split_row(r, t_max, n_utts, 1, b, t);
+    if (t >= lens[b]) continue;
+    const int64_t i = src_starts[b] + t;
+    const float* s = (i >= 0 && i < n_src) ? src + i * ld_src : nullptr;
+    float* d = dst + (dst_starts[b] + t) * ld_dst;
+    if (VEC) {
+      for (int c = lane; c < (dst_width >> 2); c += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s && c < (width >> 2)) v = reinterpret_cast<const float4*>(s)[c];
+        reinterpret_cast<float4*>(d)[c] = v;
+      }
+    } else {
+      for (int c = lane; c < dst_width; c += 64) d[c] = (s && c < width) ? s[c] : 0.f;
     }
   }
 }
@@ -212,6 +247,27 @@ extern "C" int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, cons
     hipLaunchKernelGGL(batch_pack_rows_kernel<false>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
                        ld_src, d_starts, d_lens, n_utts, t_max, width, batch_first, d_dst, ld_dst, dst_width, rep_pos,
                        rep_dst_row);
+  ITTS_LAUNCH_CHECK();
+  return ITTS_OK;
+}
+
+extern "C" int itts_batch_concat_rows_f32(const float* d_src, int64_t ld_src, int64_t n_src, const int64_t* d_src_starts,
+                                          const int64_t* d_dst_starts, const int64_t* d_lens, int n_utts, int64_t t_max,
+                                          int width, float* d_dst, int64_t ld_dst, int dst_width, void* stream) {
+  ITTS_REQUIRE(n_utts >= 0 && t_max >= 0 && width >= 0 && dst_width >= width && n_src >= 0 && ld_src >= width &&
+                   ld_dst >= dst_width, "bad sizes");
+  const int64_t n_rows = (int64_t)n_utts * t_max;
+  if (n_rows == 0 || dst_width == 0) return ITTS_OK;
+  ITTS_REQUIRE(n_rows < ((int64_t)1 << 31), "more than 2^31 positions");
+  ITTS_REQUIRE(d_src_starts && d_dst_starts && d_lens && d_dst && (d_src || n_src == 0), "null pointer");
+  const bool vec = width % 4 == 0 && dst_width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(d_src) &&
+                   aligned16(d_dst);
+  if (vec)
+    hipLaunchKernelGGL(batch_concat_rows_kernel<true>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
+                       ld_src, n_src, d_src_starts, d_dst_starts, d_lens, n_utts, t_max, width, d_dst, ld_dst, dst_width);
+  else
+    hipLaunchKernelGGL(batch_concat_rows_kernel<false>, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), d_src,
+                       ld_src, n_src, d_src_starts, d_dst_starts, d_lens, n_utts, t_max, width, d_dst, ld_dst, dst_width);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }

@@ -77,6 +77,8 @@ _SIGNATURES = {
                                           _P, c_int64, _P, _P]),
     "itts_batch_pack_rows_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int64, c_int, c_int, _P, c_int64, c_int,
                                          c_int64, c_int64, _P]),
+    "itts_batch_concat_rows_f32": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, c_int,
+                                           _P]),
     "itts_batch_pad_colsum_workspace_bytes": (c_int64, [c_int64, c_int]),
     "itts_batch_pad_colsum_f32": (c_int, [_P, c_int64, _P, c_int, c_int64, c_int, c_int, _P, c_int, _P, _P]),
     "itts_linear_fwd_mse_workspace_bytes": (c_int64, [c_int64, c_int]),

@@ -347,6 +347,24 @@ def batch_pack_rows(padded, starts, lens, batch_first, n_rows, out_width=None, o
     return out
 
 
+def batch_concat_rows(rows, table, n_out, t_max, width=None, out_width=None):
+    """out[dst_starts[b] + t] = rows[src_starts[b] + t] for t < lens[b]; table: int64 [3, B] on the device (src starts,
+    dst starts, lens); n_out rows of out_width floats (columns beyond `width` zero).  FrameShard.gather's batches."""
+    L = _lib.load()
+    _need(rows, torch.float32, "rows")
+    assert rows.dim() == 2 and (rows.shape[1] <= 1 or rows.stride(1) == 1)
+    assert table.dtype == torch.int64 and table.is_cuda and table.dim() == 2 and table.shape[0] == 3 and \
+        table.is_contiguous()
+    width = rows.shape[1] if width is None else int(width)
+    out_width = width if out_width is None else int(out_width)
+    out = torch.empty((int(n_out), out_width), dtype=torch.float32, device=rows.device)
+    ld_src = rows.stride(0) if rows.shape[0] > 1 else max(rows.shape[1], 1)
+    _lib.check(L.itts_batch_concat_rows_f32(_ptr(rows), ld_src, rows.shape[0], _ptr(table[0]), _ptr(table[1]),
+                                            _ptr(table[2]), table.shape[1], int(t_max), width, _ptr(out),
+                                            max(out_width, 1), out_width, _stream()), "itts_batch_concat_rows_f32")
+    return out
+
+
 def batch_pad_colsum(padded, lens, batch_first, out=None):
     """Per column, the sum of a padded batch over its padding positions (t >= lens[b]), in a fixed order; into `out`
     (contiguous, at least as wide: the further columns are zeroed) when given."""

@@ -136,9 +136,24 @@ class FrameShard(object):
 
     def gather(self, utt_indices):
         """Packed valid frames of the given utterances: (x [M, in_pitch], y [M, out_dim] view of a
-        [M, out_pitch] buffer, lengths).  One index upload and two row gathers on the device."""
+        [M, out_pitch] buffer, lengths).  On the device: one upload of the batch's (start, start in the batch, length)
+        table and one `itts_batch_concat_rows_f32` launch per matrix (until round 6: a row index of M entries built
+        with numpy per step, uploaded, two index_select)."""
         utt_indices = np.asarray(utt_indices, dtype=np.int64)
         lens = self.offsets[utt_indices + 1] - self.offsets[utt_indices]
+        if torch.is_tensor(self.x) and self.x.is_cuda and len(utt_indices) > 0:
+            from idiaptts_amd import ops
+            table = torch.empty((3, len(utt_indices)), dtype=torch.int64, pin_memory=True)
+            tab = table.numpy()
+            tab[0] = self.offsets[utt_indices]
+            tab[1, 0] = 0
+            np.cumsum(lens[:-1], out=tab[1, 1:])
+            tab[2] = lens
+            dev_table = table.to(self.x.device, non_blocking=True)
+            m, t_max = int(lens.sum()), int(lens.max())
+            x = ops.batch_concat_rows(self.x, dev_table, m, t_max)
+            y = ops.batch_concat_rows(self.y, dev_table, m, t_max)
+            return x, y[:, :self.out_dim], lens
         starts = np.repeat(self.offsets[utt_indices] - np.concatenate([[0], np.cumsum(lens)[:-1]]),
                            lens)
         rows = starts + np.arange(int(lens.sum()), dtype=np.int64)

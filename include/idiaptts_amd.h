@@ -253,6 +253,13 @@ int itts_batch_pad_gather_f32(const float* d_src, int64_t ld_src, int64_t n_src,
 int itts_batch_pack_rows_f32(const float* d_src, int64_t ld_src, const int64_t* d_starts, const int64_t* d_lens,
                              int n_utts, int64_t t_max, int width, int batch_first, float* d_dst, int64_t ld_dst,
                              int dst_width, int64_t rep_pos, int64_t rep_dst_row, void* stream);
+/* d_dst[d_dst_starts[b] + t, :width] = d_src[d_src_starts[b] + t, :width] for t < d_lens[b] (t_max >= every length);
+ * columns width .. dst_width - 1 of the written rows are zeroed: the valid frames of a mini-batch's utterances out of
+ * an arena, back to back in batch order -- the packed batch of the flat feed-forward step
+ * (data_preparation/FrameShard.py: gather), one launch instead of a row index built on the host. */
+int itts_batch_concat_rows_f32(const float* d_src, int64_t ld_src, int64_t n_src, const int64_t* d_src_starts,
+                               const int64_t* d_dst_starts, const int64_t* d_lens, int n_utts, int64_t t_max, int width,
+                               float* d_dst, int64_t ld_dst, int dst_width, void* stream);
 /* d_out[c] = sum of d_x[(b, t), c] over the padding positions (t >= d_lens[b]) of a padded batch, summed in a fixed
  * order (the gradient that reaches the fill row of itts_batch_pad_gather_f32); d_out[width .. out_width - 1] = 0.
  * d_workspace: itts_batch_pad_colsum_workspace_bytes(n_utts * t_max, width) bytes on the device. */

@@ -238,3 +238,23 @@ def test_cached_loader_over_budget_on_the_device(gpu, host_budget):
         for (d0, _), (d1, _) in zip(e_ref, e_got):
             for k in ("x", "y", "y_mask"):
                 assert torch.equal(d0[k], d1[k].cpu())
+
+
+def test_frame_shard_gather_on_the_device_equals_the_host_gather(gpu):
+    """FrameShard.gather (the flat feed-forward step's batches, hparams.resident_dataset): itts_batch_concat_rows_f32
+    over a (start, start in the batch, length) table against the row index the host path builds -- also a batch of
+    one utterance and repeated utterances"""
+    from idiaptts_amd.src.data_preparation.FrameShard import FrameShard
+    rng = np.random.default_rng(12)
+    lens = rng.integers(1, 40, size=17)
+    xs = [rng.standard_normal((n, 425)).astype(np.float32) for n in lens]
+    ys = [rng.standard_normal((n, 187)).astype(np.float32) for n in lens]
+    host = FrameShard.from_arrays(xs, ys, ["u%d" % i for i in range(17)])
+    dev = host.to(gpu)
+    for idx in ([3], [16, 0, 5, 5, 9], list(range(17)), [2, 1]):
+        x0, y0, l0 = host.gather(idx)
+        x1, y1, l1 = dev.gather(idx)
+        assert np.array_equal(l0, l1)
+        assert x1.is_cuda and x1.shape == (int(l0.sum()), 428) and y1.shape == (int(l0.sum()), 187)
+        assert np.array_equal(x0, x1.cpu().numpy()) and np.array_equal(y0, y1.cpu().numpy())
+        assert y1.stride(0) == 188                      # (a view of the padded rows: 16-byte pitch for the fused loss)
