@@ -458,10 +458,8 @@ def test_trainer_with_the_device_batch_cache_under_two_ranks(gpu, tmp_path):
     assert runs[True][0][4] == "CachedBatchLoader" and runs[False][0][4] != "CachedBatchLoader"
     st = runs[True][0][3]
     assert st["misses"] > 0 and st["hits"] > 0 and st["passed_through"] == 0
-    # the sampler draws differ between the two spawns (rank 0 draws the seed), so the trajectories are compared
-    # through what does not depend on the order of the batches: the validation loss after three epochs agrees loosely,
-    # and both runs learn
-    for cache in (False, True):
-        tr = runs[cache][0][0]
-        assert tr[-1] < tr[0]
-    assert abs(runs[True][0][1][-1] - runs[False][0][1][-1]) < 0.05 * abs(runs[False][0][1][-1])
+    # rank 0 draws the sampler's seed from the generator the trainer has just seeded (hparams.seed): both runs walk the
+    # same batches in the same order, and the cached batches are prepare_batch's bit for bit -- so are the trajectories
+    assert runs[True][0][0] == runs[False][0][0] and runs[True][0][1] == runs[False][0][1]
+    assert float(np.abs(runs[True][0][2] - runs[False][0][2]).max()) <= 1e-7
+    assert runs[True][0][0][-1] < runs[True][0][0][0]
