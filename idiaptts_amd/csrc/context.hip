@@ -327,10 +327,12 @@ const JumpTable* get_jump_table(DeviceContext* ctx) {
   return d;
 }
 
-__global__ __launch_bounds__(256) void randn_u32_kernel(const int64_t* __restrict__ off,
-                                                        const int64_t* __restrict__ len,
-                                                        const JumpTable* __restrict__ jt,
-                                                        uint32_t* __restrict__ R) {
+// The plain form (every lane stores its own chunk, 256 bytes from its neighbour's): ITTS_RANDN_DIRECT=1, kept as the
+// other side of tests/test_gpu_world.py's bit-for-bit comparison.
+__global__ __launch_bounds__(256) void randn_u32_direct_kernel(const int64_t* __restrict__ off,
+                                                               const int64_t* __restrict__ len,
+                                                               const JumpTable* __restrict__ jt,
+                                                               uint32_t* __restrict__ R) {
   const int u = blockIdx.y;
   const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n0 = chunk * RNG_CHUNK;
@@ -352,6 +354,54 @@ __global__ __launch_bounds__(256) void randn_u32_kernel(const int64_t* __restric
   }
 }
 
+// One lane generates the RNG_CHUNK consecutive normals of its chunk, so a wave's stores would land 256 bytes
+// apart; the values go through a padded LDS tile (half a chunk at a time) and leave as 128-byte runs.
+__global__ __launch_bounds__(256) void randn_u32_kernel(const int64_t* __restrict__ off,
+                                                        const int64_t* __restrict__ len,
+                                                        const JumpTable* __restrict__ jt,
+                                                        uint32_t* __restrict__ R) {
+  constexpr int HALF = RNG_CHUNK / 2;
+  __shared__ uint32_t tile[4][64 * (HALF + 1)];
+  const int u = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t chunk0 = (int64_t)blockIdx.x * 256 + wv * 64;  // the wave's first chunk
+  const int64_t n = len[u];
+  if ((int64_t)blockIdx.x * 256 * RNG_CHUNK >= n) return;      // the whole block is past the end
+  const int64_t chunk = chunk0 + lane;
+  const bool live = chunk * RNG_CHUNK < n;
+  uint32_t x = 0, y = 0, z = 0, w = 0;
+  if (live) {
+    const uint4 st = rng_chunk_state(jt, chunk);
+    x = st.x; y = st.y; z = st.z; w = st.w;
+  }
+  uint32_t* t = tile[wv];
+  uint32_t* out = R + off[u] + chunk0 * RNG_CHUNK;
+  const int64_t rem = n - chunk0 * RNG_CHUNK;  // normals the wave owes (<= 0: none)
+  for (int h = 0; h < 2; ++h) {
+    if (live) {
+#pragma unroll 4
+      for (int i = 0; i < HALF; ++i) {
+        uint32_t tmp = 0;
+        for (int q = 0; q < 12; ++q) {
+          const uint32_t s = x ^ (x << 11);
+          x = y; y = z; z = w;
+          w = (w ^ (w >> 19)) ^ (s ^ (s >> 8));
+          tmp += w >> 4;
+        }
+        t[lane * (HALF + 1) + i] = tmp;
+      }
+    }
+    __syncthreads();
+    const int col = lane & (HALF - 1), sub = lane / HALF;
+    for (int r = 0; r < 64; r += 64 / HALF) {
+      const int row = r + sub;
+      const int64_t idx = (int64_t)row * RNG_CHUNK + h * HALF + col;
+      if (idx < rem) out[idx] = t[row * (HALF + 1) + col];
+    }
+    __syncthreads();
+  }
+}
+
 int launch_randn_u32(DeviceContext* ctx, const int64_t* d_off, const int64_t* d_len, int n_utts,
                      int64_t max_len, uint32_t* d_R, hipStream_t s) {
   const JumpTable* jt = get_jump_table(ctx);
@@ -359,8 +409,12 @@ int launch_randn_u32(DeviceContext* ctx, const int64_t* d_off, const int64_t* d_
   ITTS_REQUIRE(max_len < ((int64_t)RNG_CHUNK << RNG_NJUMP), "utterance too long for the RNG jump table");
   if (n_utts == 0 || max_len <= 0) return ITTS_OK;
   const int64_t chunks = (max_len + RNG_CHUNK - 1) / RNG_CHUNK;
-  hipLaunchKernelGGL(randn_u32_kernel, dim3((unsigned)((chunks + 255) / 256), n_utts), dim3(256), 0, s,
-                     d_off, d_len, jt, d_R);
+  const char* direct = std::getenv("ITTS_RANDN_DIRECT");
+  const dim3 grid((unsigned)((chunks + 255) / 256), n_utts);
+  if (direct && direct[0] == '1')
+    hipLaunchKernelGGL(randn_u32_direct_kernel, grid, dim3(256), 0, s, d_off, d_len, jt, d_R);
+  else
+    hipLaunchKernelGGL(randn_u32_kernel, grid, dim3(256), 0, s, d_off, d_len, jt, d_R);
   ITTS_LAUNCH_CHECK();
   return ITTS_OK;
 }

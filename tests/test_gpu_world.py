@@ -83,6 +83,33 @@ def test_cheaptrick_and_fused_mcep_match_oracle(gpu, utts, golden_dir):
     assert np.abs(mc[:n0].astype(np.float32) - cmp_[:, :20]).max() <= 4.8e-7
 
 
+def test_randn_stream_through_the_lds_tile_is_the_plain_kernels_stream(gpu, utts):
+    """csrc/context.hip, randn_u32_kernel: the lanes' chunks of normals leave through a transposing LDS tile
+    (128-byte runs) instead of 64 stores 256 bytes apart.  CheapTrick adds the stream * 1e-12 to every windowed
+    segment, five orders of magnitude above an ulp of the samples: one wrong, missing or shifted normal changes the
+    bits of the spectrum.  Ragged lengths put the end of the stream inside a chunk, a half chunk and a wave."""
+    from idiaptts_amd import ops
+    fs = utts[0][1]
+    def cut(u, n):
+        return (u[0][:n], fs, u[2][:int(1000.0 * n / fs / 5.0) + 1], None)
+    cases = [utts, [cut(u, len(u[0]) // 3) for u in utts[:2]], [cut(utts[0], 4000), cut(utts[1], 900)]]
+    old = os.environ.get("ITTS_RANDN_DIRECT")
+    try:
+        for case in cases:
+            x, f0, x_off, f_off = _batch(case, gpu)
+            res = {}
+            for mode in ("1", "0"):
+                os.environ["ITTS_RANDN_DIRECT"] = mode
+                sp, _ = ops.cheaptrick_mcep(x, x_off, f0, f_off, fs, order=19, alpha=0.58, mc_dtype=torch.float64)[:2]
+                res[mode] = sp.cpu().numpy()
+            assert np.array_equal(res["0"], res["1"])
+    finally:
+        if old is None:
+            os.environ.pop("ITTS_RANDN_DIRECT", None)
+        else:
+            os.environ["ITTS_RANDN_DIRECT"] = old
+
+
 @pytest.mark.parametrize("order", [19, 24, 59])
 def test_fused_newton_products_equal_the_two_launches_bit_for_bit(gpu, utts, order):
     """csrc/mcep_lockstep.hip, mcls_fused3_kernel (round 5): a Newton round's two
