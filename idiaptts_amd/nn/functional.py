@@ -11,6 +11,27 @@ from .. import lib as _lib
 from .. import ops
 
 
+# The gradient a scalar loss's backward starts from, as an object the loss functions can recognise: `loss.backward()`
+# makes a fresh tensor of ones per call, and a Function's backward cannot tell ones from any other factor without
+# reading the value back, so it multiplies its stored gradient by it -- a pass over [frames x features] for a factor
+# of 1.  The training loop starts backward from `unit_gradient(loss)` instead; autograd hands that very tensor to
+# the root's backward, which then skips the product (x * 1.0 is x).
+_unit_gradients = {}
+
+
+def unit_gradient(like):
+    key = (like.device, like.dtype)
+    unit = _unit_gradients.get(key)
+    if unit is None:
+        unit = _unit_gradients[key] = torch.ones((), dtype=like.dtype, device=like.device)
+    return unit
+
+
+def is_unit_gradient(grad):
+    unit = _unit_gradients.get((grad.device, grad.dtype))
+    return unit is not None and grad.dim() == 0 and grad.data_ptr() == unit.data_ptr()
+
+
 class LinearActFunction(torch.autograd.Function):
     """y = act(x W^T + b) on rows (any leading shape); rnn_dyn/FFWrapper.py:63-73.
     An input whose last extent is `in_features` rounded up to a multiple of four (and not `in_features` itself:
