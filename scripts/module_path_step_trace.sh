@@ -2,7 +2,7 @@
 # which launches a step is made of, in order, with full names.   gpurun -- 'bash scripts/module_path_step_trace.sh <tag>'
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/${1:-mp_trace}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export ITTS_TRAINER_EPOCH_ONLY=module_path
+export ITTS_TRAINER_EPOCH_ONLY=${ITTS_TRAINER_EPOCH_ONLY:-module_path}
 rm -rf /tmp/mpt && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/mpt -- python3 $R/scripts/run_trainer_epoch.py > $O/epoch.txt 2>&1
 python3 - <<'PY' > $O/step_timeline.txt
 import csv, glob
