@@ -81,7 +81,7 @@ def _shared_initial_state(h):
     """The recurrence kernels take ONE initial state per layer and direction, shared by all rows
     (what RNNWrapper.init_hidden passes: a [.., 1, H] vector expanded over the batch).  Anything
     else would silently be replaced by row 0's state, so it is refused."""
-    if h is None or h.shape[1] == 1 or h.stride(1) == 0:
+    if h is None or h.shape[1] == 1 or h.stride(1) == 0 or getattr(h, "_itts_rows_shared", False):
         return
     if not bool((h == h[:, :1]).all()):
         raise NotImplementedError("Per-sequence initial states are not implemented: all rows of "
@@ -136,16 +136,23 @@ class LSTM(nn.Module):
             _shared_initial_state(h0)
             _shared_initial_state(c0)
         hn_all, cn_all = [], []
+        H = self.hidden_size
+        # Every layer's operands are put together BEFORE the first recurrence is launched: the host waits for each
+        # recurrence's verdict (rnn_persist.h), and what it still has to queue after that wait -- the stacking of
+        # the two directions' weights, four small copies a layer -- stands between the recurrence and the next
+        # layer's product on an idle device (90 us a layer boundary in the step's timeline).
+        operands = []
         for layer in range(self.num_layers):
             hl = cl = None
             if h0 is not None:
                 # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0
                 hl = h0[layer * ndir:(layer + 1) * ndir, 0, :]
                 cl = c0[layer * ndir:(layer + 1) * ndir, 0, :]
-            H = self.hidden_size
-            w_ih, w_hh, (b_ih, b_hh), (hl, cl), Hp = _pad_hidden(
+            operands.append(_pad_hidden(
                 self._stack("weight_ih", layer), self._stack("weight_hh", layer),
-                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl, cl], 4, H, rows=pb.B)
+                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl, cl], 4, H, rows=pb.B))
+        for layer in range(self.num_layers):
+            w_ih, w_hh, (b_ih, b_hh), (hl, cl), Hp = operands[layer]
             x, hn, cn = LSTMLayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl, cl,
                                                 torch.is_grad_enabled())
             x = _unpad_rows(x, ndir, H, Hp)
@@ -200,13 +207,16 @@ class GRU(nn.Module):
         x = pb.pack(input_, pad_cols=True)
         _shared_initial_state(hx)
         hn_all = []
+        H = self.hidden_size
+        operands = []            # (all layers' operands before the first recurrence: see LSTM.forward)
         for layer in range(self.num_layers):
             # all rows share the initial state (init_hidden expands [.., 1, H]); use row 0
             hl = hx[layer * ndir:(layer + 1) * ndir, 0, :] if hx is not None else None
-            H = self.hidden_size
-            w_ih, w_hh, (b_ih, b_hh), (hl,), Hp = _pad_hidden(
+            operands.append(_pad_hidden(
                 self._stack("weight_ih", layer), self._stack("weight_hh", layer),
-                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl], 3, H, rows=pb.B)
+                [self._stack("bias_ih", layer), self._stack("bias_hh", layer)], [hl], 3, H, rows=pb.B))
+        for layer in range(self.num_layers):
+            w_ih, w_hh, (b_ih, b_hh), (hl,), Hp = operands[layer]
             x, hn = GRULayerFunction.apply(x, pb, w_ih, w_hh, b_ih, b_hh, hl,
                                            torch.is_grad_enabled())
             x = _unpad_rows(x, ndir, H, Hp)

@@ -147,9 +147,17 @@ class RNNWrapper(nn.Module):
     def init_hidden(self, batch_size=1):
         size = list(self.h_0.size())
         size[1] = batch_size
+        # (copies of ONE state per layer and direction, and marked so: the recurrence kernels take a shared initial
+        # state only, and nn/modules.py would otherwise compare the rows on the device and wait for the answer --
+        # two host synchronisations at the start of every step)
         h_0 = self.h_0.expand(size).contiguous()
-        self.hidden = (h_0, self.c_0.expand(size).contiguous()) if isinstance(self.module, LSTM) \
-            else h_0
+        h_0._itts_rows_shared = True
+        if isinstance(self.module, LSTM):
+            c_0 = self.c_0.expand(size).contiguous()
+            c_0._itts_rows_shared = True
+            self.hidden = (h_0, c_0)
+        else:
+            self.hidden = h_0
 
     def forward(self, input_, seq_lengths_input, max_length_inputs, hidden=None, **kwargs):
         # the kernels take the padded tensor + lengths directly (no PackedSequence round trip)
