@@ -16,15 +16,17 @@ from idiaptts_amd.src.neural_networks.pytorch.models.NamedForwardWrapper import 
 
 dev = torch.device("cuda", 0)
 n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+sizes = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (128, 256, 384, 512)
+cells = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("LSTM", "GRU")
 x, y, lengths = make_ff_batch(n_utts, seed=7)
 offs = np.concatenate([[0], np.cumsum(lengths)])
 batch = [{"questions": x[offs[i]:offs[i + 1]], "acoustic_features": y[offs[i]:offs[i + 1]]} for i in range(n_utts)]
 data, lens = Handler.prepare_batch(batch, batch_first=False, mask_keys=("acoustic_features",))
 data = {k: v.to(dev) for k, v in data.items()}
-for cell in ("LSTM", "GRU"):
-    for H in (128, 256, 384, 512):
+for cell in cells:
+    for H in sizes:
         for pad in ("0", "1"):
-            if H == 512 and pad == "1":
+            if H >= 512 and pad == "1":
                 continue
             os.environ["ITTS_RNN_PAD_HIDDEN"] = pad
             torch.manual_seed(0)
